@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "mpc.pytorch_amd")
+for p in (PKG, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    import numpy as np
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture
+def load_golden():
+    return golden

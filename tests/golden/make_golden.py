@@ -1,0 +1,409 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the UNMODIFIED
+reference (locuslab/mpc.pytorch, mounted read-only at /root/reference).
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Every .npz holds the inputs AND the reference's outputs, so nothing at test
+time needs the reference.  Two flavours of every LQR-step output are stored:
+  *_batch : the reference called once with the whole batch (its batch-global
+            pnqp / line-search loops couple the problems);
+  *_pp    : the reference called once per problem (n_batch = 1) -- the
+            per-problem semantics the HIP kernels implement.
+"""
+import contextlib
+import importlib.util
+import io
+import os
+import re
+import sys
+import warnings
+
+import numpy as np
+import numpy.random as npr
+import torch
+
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/mpc"
+
+
+def load_reference():
+    spec = importlib.util.spec_from_file_location(
+        "mpc_ref", os.path.join(REF, "__init__.py"), submodule_search_locations=[REF])
+    pkg = importlib.util.module_from_spec(spec)
+    sys.modules["mpc_ref"] = pkg
+    spec.loader.exec_module(pkg)
+    import mpc_ref.mpc as ref_mpc          # noqa
+    import mpc_ref.lqr_step as ref_step    # noqa
+    import mpc_ref.pnqp as ref_pnqp        # noqa
+    import mpc_ref.util as ref_util        # noqa
+    return ref_mpc, ref_step, ref_pnqp, ref_util
+
+
+ref_mpc, ref_step, ref_pnqp, ref_util = load_reference()
+QuadCost, LinDx = ref_mpc.QuadCost, ref_mpc.LinDx
+
+
+def quiet(fn, *a, **k):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = fn(*a, **k)
+    return out, buf.getvalue()
+
+
+def npy(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    arrs = {k: v for k, v in arrs.items() if v is not None}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
+    sz = os.path.getsize(os.path.join(HERE, name + ".npz"))
+    print("wrote %-36s %8.1f KB" % (name + ".npz", sz / 1024))
+
+
+# --------------------------------------------------------------------------
+# synthetic problem recipe
+# --------------------------------------------------------------------------
+def make_problem(ns, nc, T, B, dtype, seed, with_f=True, u_scale=0.3):
+    g = torch.Generator().manual_seed(seed)
+    n = ns + nc
+    A = torch.randn(T, B, n, n, generator=g, dtype=torch.float64)
+    C = A.transpose(2, 3).matmul(A)
+    c = torch.randn(T, B, n, generator=g, dtype=torch.float64)
+    R = torch.eye(ns, dtype=torch.float64) + 0.2 * torch.randn(T - 1, B, ns, ns, generator=g, dtype=torch.float64) / ns ** 0.5
+    S = torch.randn(T - 1, B, ns, nc, generator=g, dtype=torch.float64) / ns ** 0.5
+    F = torch.cat((R, S), 3)
+    f = 0.1 * torch.randn(T - 1, B, ns, generator=g, dtype=torch.float64) if with_f else None
+    x_init = torch.randn(B, ns, generator=g, dtype=torch.float64)
+    u = u_scale * torch.randn(T, B, nc, generator=g, dtype=torch.float64)
+    cast = lambda t: None if t is None else t.to(dtype).contiguous()
+    return dict(C=cast(C), c=cast(c), F=cast(F), f=cast(f), x_init=cast(x_init), u=cast(u))
+
+
+def slice_b(t, b, dim):
+    if t is None or isinstance(t, float):
+        return t
+    return t.narrow(dim, b, 1).contiguous()
+
+
+def run_step(p, ns, nc, T, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None,
+             linesearch_decay=0.2, max_linesearch_iter=10):
+    """One reference LQRStep forward around the nominal (get_traj(u), u)."""
+    dx = LinDx(p["F"], p["f"])
+    cost = QuadCost(p["C"], p["c"])
+    x = ref_util.get_traj(T, p["u"], p["x_init"], dx)
+    fn = ref_step.LQRStep(
+        n_state=ns, n_ctrl=nc, T=T, u_lower=u_lower, u_upper=u_upper, u_zero_I=u_zero_I,
+        delta_u=delta_u, linesearch_decay=linesearch_decay, max_linesearch_iter=max_linesearch_iter,
+        true_cost=cost, true_dynamics=dx, delta_space=True, current_x=x, current_u=p["u"])
+    f = p["f"] if p["f"] is not None else torch.Tensor()
+    (new_x, new_u, nqp, costs, fdn, mean_alpha), _ = quiet(fn, p["x_init"], p["C"], p["c"], p["F"], f)
+    return dict(cur_x=x, new_x=new_x, new_u=new_u, n_qp=nqp, costs=costs, full_du_norm=fdn,
+                mean_alphas=mean_alpha.reshape(1))
+
+
+def step_case(name, ns, nc, T, B, dtype, seed, with_f=True, bounds=None, mask_seed=None,
+              delta_u=None, decay=0.2, max_ls=10, u_scale=0.3):
+    p = make_problem(ns, nc, T, B, dtype, seed, with_f, u_scale)
+    g = torch.Generator().manual_seed(seed + 1000)
+    u_lower = u_upper = None
+    if bounds == "tensor":
+        u_lower = -torch.rand(T, B, nc, generator=g, dtype=torch.float64).to(dtype)
+        u_upper = torch.rand(T, B, nc, generator=g, dtype=torch.float64).to(dtype)
+        # nominal controls must be feasible for the delta-space QP bounds to make sense
+        p["u"] = torch.max(torch.min(p["u"], u_upper), u_lower)
+    elif isinstance(bounds, float):
+        u_lower, u_upper = -bounds, bounds
+        p["u"] = p["u"].clamp(-bounds, bounds)
+    mask = None
+    if mask_seed is not None:
+        mask = torch.rand(T, B, nc, generator=torch.Generator().manual_seed(mask_seed)) < 0.35
+        p["u"] = p["u"] * (~mask).to(dtype)
+    kw = dict(u_lower=u_lower, u_upper=u_upper, u_zero_I=mask, delta_u=delta_u,
+              linesearch_decay=decay, max_linesearch_iter=max_ls)
+    out_b = run_step(p, ns, nc, T, **kw)
+    outs = []
+    for b in range(B):
+        pb = {k: slice_b(v, b, 0 if k == "x_init" else 1) for k, v in p.items()}
+        kwb = dict(kw)
+        kwb["u_lower"] = slice_b(u_lower, b, 1)
+        kwb["u_upper"] = slice_b(u_upper, b, 1)
+        kwb["u_zero_I"] = slice_b(mask, b, 1)
+        try:
+            outs.append(run_step(pb, ns, nc, T, **kwb))
+        except RuntimeError:
+            # torch>=2 rejects the reference's uint8 mask in util.bdiag when the masked
+            # assignment degenerates to a 1-element fill (nc=1, n_batch=1).  Run the problem
+            # twice side by side instead: two identical elements walk the batch-global loops
+            # exactly like one.
+            dup = lambda t, d: None if (t is None or isinstance(t, float)) else torch.cat((t, t), d)
+            pb2 = {k: dup(v, 0 if k == "x_init" else 1) for k, v in pb.items()}
+            kw2 = dict(kwb)
+            for k in ("u_lower", "u_upper", "u_zero_I"):
+                kw2[k] = dup(kwb[k], 1)
+            o2 = run_step(pb2, ns, nc, T, **kw2)
+            outs.append({k: (v if k in ("n_qp", "mean_alphas") else v.narrow(0 if v.dim() == 1 else 1, 0, 1))
+                         for k, v in o2.items()})
+    cat = lambda key, dim: torch.cat([o[key] for o in outs], dim)
+    # For f32 cases also store the reference run in DOUBLE precision on the same (f32-valued)
+    # inputs, per problem: the "reference truth" the stated fp32 tolerance is measured against.
+    ref64 = {}
+    if dtype == torch.float32:
+        outs64 = []
+        to64 = lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t
+        for b in range(B):
+            pb = {k: to64(slice_b(v, b, 0 if k == "x_init" else 1)) for k, v in p.items()}
+            kwb = dict(kw)
+            kwb["u_lower"] = to64(slice_b(u_lower, b, 1))
+            kwb["u_upper"] = to64(slice_b(u_upper, b, 1))
+            kwb["u_zero_I"] = slice_b(mask, b, 1)
+            outs64.append(run_step(pb, ns, nc, T, **kwb))
+        c64 = lambda key, dim: npy(torch.cat([o[key] for o in outs64], dim))
+        ref64 = dict(new_x_ref64=c64("new_x", 1), new_u_ref64=c64("new_u", 1), costs_ref64=c64("costs", 0),
+                     full_du_norm_ref64=c64("full_du_norm", 0))
+    meta = np.array([ns, nc, T, B, -1 if delta_u is None else 1, max_ls], dtype=np.int64)
+    save(name,
+         meta=meta, decay=np.array([decay]), delta_u=np.array([np.nan if delta_u is None else delta_u]),
+         C=npy(p["C"]), c=npy(p["c"]), F=npy(p["F"]), f=npy(p["f"]), x_init=npy(p["x_init"]),
+         cur_u=npy(p["u"]), cur_x=npy(out_b["cur_x"]),
+         u_lower=(np.array([u_lower]) if isinstance(u_lower, float) else npy(u_lower)),
+         u_upper=(np.array([u_upper]) if isinstance(u_upper, float) else npy(u_upper)),
+         u_zero_I=None if mask is None else npy(mask).astype(np.uint8),
+         new_x_batch=npy(out_b["new_x"]), new_u_batch=npy(out_b["new_u"]), costs_batch=npy(out_b["costs"]),
+         full_du_norm_batch=npy(out_b["full_du_norm"]), mean_alphas_batch=npy(out_b["mean_alphas"]),
+         n_qp_batch=npy(out_b["n_qp"]),
+         new_x_pp=npy(cat("new_x", 1)), new_u_pp=npy(cat("new_u", 1)), costs_pp=npy(cat("costs", 0)),
+         full_du_norm_pp=npy(cat("full_du_norm", 0)), alphas_pp=npy(cat("mean_alphas", 0)),
+         n_qp_pp=npy(cat("n_qp", 0)), **ref64)
+
+
+# --------------------------------------------------------------------------
+# full MPC.forward solves (reference tests + the notebook known-answer table)
+# --------------------------------------------------------------------------
+def parse_table(text):
+    rows = []
+    for line in text.splitlines():
+        m = re.match(r"\|\s*(\d+)\s*\|\s*([^|]+)\|\s*([^|]+)\|\s*([^|]+)\|\s*([^|]+)\|", line)
+        if m:
+            num = lambda s_: float(re.search(r"[-+0-9.eE]+", s_.replace("tensor", "")).group(0))
+            rows.append([num(m.group(i)) for i in range(1, 6)])
+    init = re.search(r"Initial mean\(cost\): ([0-9.eE+-]+)", text)
+    return np.array(rows), np.array([float(init.group(1))] if init else [])
+
+
+def mpc_case(name, ns, nc, T, C, c, F, f, x_init, u_lower, u_upper, **kw):
+    ctrl = ref_mpc.MPC(ns, nc, T, u_lower=u_lower, u_upper=u_upper, verbose=1, **kw)
+    (x, u, costs), txt = quiet(ctrl, x_init, QuadCost(C, c), LinDx(F, f))
+    table, init = parse_table(txt)
+    kwn = {("kw_" + k): np.array([v if v is not None else np.nan], dtype=np.float64) for k, v in kw.items()
+           if isinstance(v, (int, float, bool)) or v is None}
+    save(name, meta=np.array([ns, nc, T, C.shape[1]]), C=npy(C), c=npy(c), F=npy(F), f=npy(f), x_init=npy(x_init),
+         u_lower=None if u_lower is None else (np.array([u_lower]) if isinstance(u_lower, float) else npy(u_lower)),
+         u_upper=None if u_upper is None else (np.array([u_upper]) if isinstance(u_upper, float) else npy(u_upper)),
+         x=npy(x), u=npy(u), costs=npy(costs), table=table, init_cost=init, **kwn)
+
+
+def gen_mpc_cases():
+    # (1) notebook known answer: examples/Time Varying Linear-Quadratic Control.ipynb cell 1
+    torch.manual_seed(0)
+    B, ns, nc, T = 2, 3, 4, 5
+    n = ns + nc
+    C = torch.randn(T * B, n, n)
+    C = torch.bmm(C, C.transpose(1, 2)).view(T, B, n, n)
+    c = torch.randn(T, B, n)
+    R = (torch.eye(ns) + 0.2 * torch.randn(ns, ns)).repeat(T, B, 1, 1)
+    S = torch.randn(T, B, ns, nc)
+    F = torch.cat((R, S), dim=3)
+    x_init = torch.randn(B, ns)
+    u_lower = -torch.rand(T, B, nc)
+    u_upper = torch.rand(T, B, nc)
+    mpc_case("mpc_notebook_tvlq", ns, nc, T, C, c, F, None, x_init, u_lower, u_upper,
+             lqr_iter=20, backprop=False, exit_unconverged=False)
+
+    # (2,3) tests/test_mpc.py:91-149 test_lqr_linear_unbounded (inputs :92-111)
+    def npr_problem(seed, B, ns, nc, T, S_scale=1.0):
+        npr.seed(seed)
+        n = ns + nc
+        C = npr.randn(T, B, n, n)
+        C = np.matmul(C.transpose(0, 1, 3, 2), C)
+        c = npr.randn(T, B, n)
+        R = np.tile(np.eye(ns) + 0.2 * np.random.randn(ns, ns), (T, B, 1, 1))
+        S = S_scale * np.tile(np.random.randn(ns, nc), (T, B, 1, 1))
+        F = np.concatenate((R, S), axis=3)
+        f = np.tile(npr.randn(ns), (T, B, 1))
+        x_init = npr.randn(B, ns)
+        return [torch.tensor(a).double() for a in (C, c, F, f, x_init)]
+
+    C, c, F, f, x_init = npr_problem(1, 2, 3, 4, 5)
+    big = 1e4 * torch.ones(5, 2, 4).double()
+    mpc_case("mpc_linear_unbounded_big_bounds", 3, 4, 5, C, c, F, f, x_init, -big, big,
+             lqr_iter=10, backprop=False, exit_unconverged=True)
+    mpc_case("mpc_linear_unbounded_none", 3, 4, 5, C, c, F, f, x_init, None, None,
+             lqr_iter=10, backprop=False, exit_unconverged=False)
+
+    # (4) tests/test_mpc.py:152-194 test_lqr_linear_bounded
+    C, c, F, f, x_init = npr_problem(1, 2, 3, 4, 5)
+    u_lower = torch.tensor(-npr.random((5, 2, 4))).double()
+    u_upper = torch.tensor(npr.random((5, 2, 4))).double()
+    mpc_case("mpc_linear_bounded", 3, 4, 5, C, c, F, f, x_init, u_lower, u_upper,
+             lqr_iter=20, backprop=False, exit_unconverged=False)
+
+    # (5) tests/test_mpc.py:197-240 test_lqr_linear_bounded_delta
+    C, c, F, f, x_init = npr_problem(1, 2, 3, 4, 5, S_scale=0.01)
+    u_lower = torch.tensor(-npr.random((5, 2, 4))).double()
+    u_upper = torch.tensor(npr.random((5, 2, 4))).double()
+    mpc_case("mpc_linear_bounded_delta", 3, 4, 5, C, c, F, f, x_init, u_lower, u_upper,
+             lqr_iter=1, delta_u=0.1, backprop=False, exit_unconverged=False)
+
+    # (6) tests/test_mpc.py:243-299 test_lqr_cuda_singleton (nc = 1 scalar branches), on CPU
+    C, c, F, f, x_init = npr_problem(1, 5, 3, 1, 5)
+    big = 1e4 * torch.ones(5, 5, 1).double()
+    mpc_case("mpc_singleton_big_bounds", 3, 1, 5, C, c, F, f, x_init, -big, big,
+             lqr_iter=10, backprop=False, exit_unconverged=False)
+    mpc_case("mpc_singleton_none", 3, 1, 5, C, c, F, f, x_init, None, None,
+             lqr_iter=10, backprop=False, exit_unconverged=False)
+
+
+# --------------------------------------------------------------------------
+# KKT backward (LQRStepFn.backward) goldens
+# --------------------------------------------------------------------------
+def grad_case(name, ns, nc, T, B, dtype, seed, beta, with_f=True, lqr_iter=30, scale=1.0):
+    """Solve to the fixed point with the reference, then push random (dl_dx, dl_du) through
+    LQRStepFn.backward.  Stores the fixed point and all five gradients."""
+    p = make_problem(ns, nc, T, B, dtype, seed, with_f)
+    C = (scale * p["C"]).requires_grad_(True)
+    c = (scale * p["c"]).requires_grad_(True)
+    F = p["F"].clone().requires_grad_(True)
+    f = p["f"].clone().requires_grad_(True) if with_f else None
+    x_init = p["x_init"].clone().requires_grad_(True)
+    bounds = dict(u_lower=None, u_upper=None) if beta is None else dict(u_lower=-beta, u_upper=beta)
+    ctrl = ref_mpc.MPC(ns, nc, T, lqr_iter=lqr_iter, verbose=-1, exit_unconverged=False,
+                       detach_unconverged=False, eps=1e-9 if dtype == torch.float64 else 1e-4,
+                       **bounds)
+    (x, u, costs), _ = quiet(ctrl, x_init, QuadCost(C, c), LinDx(F, f))
+    g = torch.Generator().manual_seed(seed + 77)
+    gx = torch.randn(x.shape, generator=g, dtype=torch.float64).to(dtype)
+    gu = torch.randn(u.shape, generator=g, dtype=torch.float64).to(dtype)
+    loss = (x * gx).sum() + (u * gu).sum()
+    ins = [x_init, C, c, F] + ([f] if with_f else [])
+    grads = torch.autograd.grad(loss, ins)
+    save(name, meta=np.array([ns, nc, T, B]), beta=np.array([np.nan if beta is None else beta]),
+         C=npy(C), c=npy(c), F=npy(F), f=npy(f), x_init=npy(x_init),
+         x=npy(x), u=npy(u), dl_dx=npy(gx), dl_du=npy(gu),
+         dx_init=npy(grads[0]), dC=npy(grads[1]), dc=npy(grads[2]), dF=npy(grads[3]),
+         df=npy(grads[4]) if with_f else None)
+
+
+def jacobian_case(name, beta):
+    """tests/test_mpc.py:303-395 / :398-500 inputs; full du/d{C,c,F,f,x_init} Jacobians through
+    the reference's autograd (the numdifftools oracle is not installed here)."""
+    npr.seed(0)
+    torch.manual_seed(0)
+    B, ns, nc, T = 1, 2, 2, 3
+    n = ns + nc
+    C = 10. * npr.randn(T, B, n, n)
+    C = np.matmul(C.transpose(0, 1, 3, 2), C)
+    c = 10. * npr.randn(T, B, n)
+    x_init = npr.randn(B, ns)
+    F = npr.randn(T - 1, B, ns, n)
+    f = npr.randn(T - 1, B, ns)
+    tens = [torch.tensor(a).double().requires_grad_(True) for a in (C, c, x_init, F, f)]
+    _C, _c, _x, _F, _f = tens
+    lo = -beta * torch.ones(T, B, nc).double()
+    hi = beta * torch.ones(T, B, nc).double()
+    ctrl = ref_mpc.MPC(ns, nc, T, lo, hi, None, lqr_iter=20, verbose=-1, exit_unconverged=False)
+    (x, u, _), _ = quiet(ctrl, _x, QuadCost(_C, _c), LinDx(_F, _f))
+    uf = u.view(-1)
+    J = {k: [] for k in ("dC", "dc", "dx_init", "dF", "df")}
+    for i in range(len(uf)):
+        gs = torch.autograd.grad(uf[i], tens, retain_graph=True)
+        for k, gi in zip(("dC", "dc", "dx_init", "dF", "df"), gs):
+            J[k].append(gi.reshape(-1))
+    save(name, meta=np.array([ns, nc, T, B]), beta=np.array([beta]), C=C, c=c, x_init=x_init, F=F, f=f,
+         x=npy(x), u=npy(u), **{"J_" + k: torch.stack(v).numpy() for k, v in J.items()})
+
+
+# --------------------------------------------------------------------------
+# pnqp, get_traj / get_cost
+# --------------------------------------------------------------------------
+def pnqp_case(name, B, n, dtype, seed, warm):
+    npr.seed(seed)
+    H = npr.randn(B, n, n)
+    H = np.matmul(H.transpose(0, 2, 1), H)
+    q = npr.randn(B, n)
+    lower = -npr.random((B, n))
+    upper = npr.random((B, n))
+    x0 = 0.5 * npr.randn(B, n) if warm else None
+    tt = lambda a: None if a is None else torch.tensor(a).to(dtype)
+    H_, q_, lo_, hi_, x0_ = map(tt, (H, q, lower, upper, x0))
+    (xb, _, Ifb, itb), _ = quiet(ref_pnqp.pnqp, H_, q_, lo_, hi_, x_init=x0_)
+    xs, Ifs, its = [], [], []
+    for b in range(B):
+        (x1, _, If1, it1), _ = quiet(ref_pnqp.pnqp, H_[b:b + 1], q_[b:b + 1], lo_[b:b + 1], hi_[b:b + 1],
+                                     x_init=None if x0_ is None else x0_[b:b + 1])
+        xs.append(x1); Ifs.append(If1); its.append(it1)
+    save(name, H=npy(H_), q=npy(q_), lower=npy(lo_), upper=npy(hi_), x0=npy(x0_),
+         x_batch=npy(xb), If_batch=npy(Ifb), iters_batch=np.array([itb]),
+         x_pp=npy(torch.cat(xs)), If_pp=npy(torch.cat(Ifs)), iters_pp=np.array(its))
+
+
+def traj_cost_case():
+    p = make_problem(4, 2, 7, 3, torch.float64, 5)
+    x = ref_util.get_traj(7, p["u"], p["x_init"], LinDx(p["F"], p["f"]))
+    cost = ref_util.get_cost(7, p["u"], QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"]), x_init=p["x_init"])
+    save("traj_cost", **{k: npy(v) for k, v in p.items()}, x=npy(x), cost=npy(cost))
+
+
+if __name__ == "__main__":
+    f64, f32 = torch.float64, torch.float32
+    only = set(sys.argv[1:])
+    if only and "step" not in only:
+        step_case = lambda *a, **k: None
+    if only and "mpc" not in only:
+        gen_mpc_cases = lambda: None
+    if only and "grad" not in only:
+        grad_case = jacobian_case = lambda *a, **k: None
+    if only and "misc" not in only:
+        pnqp_case = lambda *a, **k: None
+        traj_cost_case = lambda: None
+    # ---- single LQR steps -------------------------------------------------
+    step_case("step_cfg1_f64", 4, 2, 10, 8, f64, 11, bounds="tensor")
+    step_case("step_cfg1_f32", 4, 2, 10, 8, f32, 11, bounds="tensor")
+    step_case("step_unbounded_f64", 3, 4, 5, 2, f64, 12, bounds=None)
+    step_case("step_unbounded_nof_f64", 3, 4, 6, 3, f64, 13, with_f=False, bounds=None)
+    step_case("step_ns_unbounded_f32", 12, 4, 50, 4, f32, 14, bounds=None)
+    step_case("step_ns_bounded_f32", 12, 4, 50, 4, f32, 14, bounds=1.0)
+    step_case("step_ns_bounded_f64", 12, 4, 20, 3, f64, 15, bounds=1.0)
+    step_case("step_nc1_scalar_f64", 3, 1, 20, 4, f64, 16, bounds=2.0, decay=0.2, max_ls=5)
+    step_case("step_nc1_unbounded_f32", 5, 1, 25, 4, f32, 17, bounds=None, decay=0.5, max_ls=2)
+    step_case("step_nc1_bounded_f32", 5, 1, 25, 4, f32, 17, bounds=0.5, decay=0.5, max_ls=2, u_scale=1.0)
+    step_case("step_delta_f64", 3, 4, 5, 2, f64, 18, bounds="tensor", delta_u=0.1)
+    step_case("step_masked_f64", 3, 2, 6, 4, f64, 19, bounds=None, mask_seed=3)
+    step_case("step_masked_nc1_f64", 3, 1, 6, 6, f64, 20, bounds=None, mask_seed=4)
+    step_case("step_masked_nc4_f32", 12, 4, 12, 3, f32, 21, bounds=None, mask_seed=5)
+    step_case("step_cfg5_f32", 32, 8, 8, 2, f32, 22, bounds=None)
+    step_case("step_cfg5_bounded_f64", 32, 8, 6, 2, f64, 23, bounds=0.5)
+    step_case("step_linesearch_f64", 4, 2, 8, 6, f64, 24, bounds=0.3, u_scale=2.0, decay=0.5, max_ls=4)
+    # ---- full solves --------------------------------------------------------
+    gen_mpc_cases()
+    # ---- backward -------------------------------------------------------------
+    grad_case("grad_unconstrained_f64", 4, 2, 6, 4, f64, 31, None)
+    grad_case("grad_constrained_f64", 4, 2, 6, 4, f64, 31, 0.4)
+    grad_case("grad_constrained_nof_f64", 3, 2, 5, 3, f64, 32, 0.3, with_f=False)
+    grad_case("grad_nc1_constrained_f64", 3, 1, 6, 4, f64, 33, 0.3)
+    grad_case("grad_ns_constrained_f32", 12, 4, 10, 3, f32, 34, 0.5)
+    grad_case("grad_ns_unconstrained_f64", 12, 4, 10, 2, f64, 35, None)
+    jacobian_case("jac_unconstrained", 100.0)
+    jacobian_case("jac_constrained", 0.5)
+    # ---- pnqp / traj --------------------------------------------------------
+    pnqp_case("pnqp_n100_f64", 2, 100, f64, 1, warm=False)
+    pnqp_case("pnqp_n4_warm_f64", 16, 4, f64, 2, warm=True)
+    pnqp_case("pnqp_n4_cold_f32", 16, 4, f32, 3, warm=False)
+    pnqp_case("pnqp_n1_f64", 8, 1, f64, 4, warm=False)
+    pnqp_case("pnqp_n8_warm_f32", 8, 8, f32, 5, warm=True)
+    traj_cost_case()

@@ -1,0 +1,40 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import numpy as np
+
+
+def bounds_of(z):
+    """(u_lower, u_upper) of a golden fixture: None, python floats, or [T,B,nc] arrays."""
+    if "u_lower" not in z:
+        return None, None
+    lo, hi = z["u_lower"], z["u_upper"]
+    if lo.shape == (1,):
+        return float(lo[0]), float(hi[0])
+    return lo, hi
+
+
+def step_kwargs(z):
+    """Keyword arguments of oracle.lqr_oracle.lqr_step for a step_* fixture."""
+    lo, hi = bounds_of(z)
+    du = None if np.isnan(z["delta_u"][0]) else float(z["delta_u"][0])
+    return dict(x_init=z["x_init"], C=z["C"], c=z["c"], F=z["F"], f=z.get("f"), cur_x=z["cur_x"],
+                cur_u=z["cur_u"], u_lower=lo, u_upper=hi, u_zero_I=z.get("u_zero_I"), delta_u=du,
+                linesearch_decay=float(z["decay"][0]), max_linesearch_iter=int(z["meta"][5]))
+
+
+def close_with_ref_noise(actual, desired, ref_noise, rtol, atol):
+    """|actual - desired| <= atol + rtol*|desired| + 2*ref_noise, element-wise.
+
+    ref_noise is the reference's own fp32-vs-fp64 deviation on that element; it widens the
+    stated tolerance only where the reference cannot reproduce itself any better."""
+    err = np.abs(np.asarray(actual, np.float64) - np.asarray(desired, np.float64))
+    lim = atol + rtol * np.abs(desired) + 2.0 * ref_noise
+    bad = err > lim
+    assert not bad.any(), "max excess %.3e at %s (err %.3e, lim %.3e)" % (
+        (err - lim).max(), np.unravel_index((err - lim).argmax(), err.shape), err.max(), lim.max())
+
+
+def scrambled_du_norm(du):
+    """The reference's full_du_norm for n_batch > 1: (u-new_u).transpose(1,2).contiguous()
+    .view(n_batch,-1).norm(2,1) (mpc/lqr_step.py:243-245) -- a reshape that mixes problems."""
+    T, B, nc = du.shape
+    return np.sqrt((np.ascontiguousarray(du.transpose(0, 2, 1)).reshape(B, -1) ** 2).sum(1))
