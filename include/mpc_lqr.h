@@ -1,0 +1,156 @@
+/*
+ * mpc_lqr.h -- C ABI of libmpc_lqr_hip.so: the MI355X (gfx950) batched LQR step.
+ *
+ * This is the drop-in boundary for the ONE hot path of locuslab/mpc.pytorch:
+ * everything `LQRStep(...)(x_init, C, c, F, f)` does (mpc/lqr_step.py:22-409)
+ * plus the helpers its caller `MPC.forward` runs on the same tensors
+ * (mpc/util.py:102-153, mpc/pnqp.py:5-82).  Plain pointers and sizes only; no
+ * torch types.  Every entry point
+ *   - takes DEVICE pointers (hipMalloc'ed / torch ROCm storage),
+ *   - enqueues on the given hipStream_t (passed as void*) and returns at once,
+ *   - allocates nothing, never synchronises (hipGraph-capturable),
+ *   - returns 0 on success, a negative MPC_E_* code on a rejected argument.
+ *
+ * Layout (identical to the reference's tensors): time-major, row-major,
+ *   C [T,B,n,n]  c [T,B,n]  F [T-1,B,ns,n]  f [T-1,B,ns] (or NULL)
+ *   x [T,B,ns]   u [T,B,nc] x_init [B,ns]   K [T,B,nc,ns]  k [T,B,nc]
+ * with n = ns + nc.  C, c, F, f carry explicit element strides for the T and B
+ * axes so the `.expand()`ed (stride-0) views MPC.forward builds
+ * (mpc/mpc.py:207-221) are read in place; their inner block is contiguous.
+ * All other arrays are contiguous.
+ */
+#ifndef MPC_LQR_H
+#define MPC_LQR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_LQR_ABI_VERSION 1
+
+enum { MPC_F32 = 0, MPC_F64 = 1 };
+enum { MPC_BOUND_NONE = 0, MPC_BOUND_SCALAR = 1, MPC_BOUND_TENSOR = 2 };
+enum {
+    MPC_OK = 0,
+    MPC_E_DIMS = -1,       /* unsupported / inconsistent sizes            */
+    MPC_E_NULL = -2,       /* a required pointer is NULL                  */
+    MPC_E_DTYPE = -3,
+    MPC_E_LAUNCH = -4,     /* hipLaunch failed; see mpc_lqr_last_error()  */
+    MPC_E_ARG = -5
+};
+/* per-problem status word bits (status[B]) */
+enum { MPC_ST_PNQP_UNCONVERGED = 1, MPC_ST_NONFINITE = 2 };
+
+/* The problem data of one LQRStepFn.forward call: (x_init, C, c, F, f) plus the
+ * closure state `current_x/current_u` (mpc/lqr_step.py:22-38, 277). */
+typedef struct mpc_lqr_problem {
+    int32_t B, T, ns, nc;
+    int32_t dtype;                    /* MPC_F32 | MPC_F64 */
+    int32_t _pad;
+    const void *x_init;               /* [B,ns] */
+    const void *C; int64_t C_st, C_sb; /* element strides of the T and B axes */
+    const void *c; int64_t c_st, c_sb;
+    const void *F; int64_t F_st, F_sb; /* only t < T-1 is read (mpc/lqr_step.py:217) */
+    const void *f; int64_t f_st, f_sb; /* NULL <=> the reference's empty tensor (mpc/mpc.py:360) */
+    const void *cur_x;                /* [T,B,ns] nominal states   */
+    const void *cur_u;                /* [T,B,nc] nominal controls */
+} mpc_lqr_problem;
+
+/* The LQRStep(...) keyword arguments that reach the kernels
+ * (mpc/lqr_step.py:22-38; defaults as there). */
+typedef struct mpc_lqr_options {
+    int32_t bound_mode;               /* u_lower/u_upper: none | python float | [T,B,nc] tensor */
+    int32_t max_linesearch_iter;      /* default 10 */
+    double lo_s, hi_s;                /* MPC_BOUND_SCALAR */
+    const void *lo, *hi;              /* MPC_BOUND_TENSOR, [T,B,nc] contiguous */
+    const uint8_t *zero_mask;         /* u_zero_I [T,B,nc] (1 = control forced to 0) or NULL */
+    double delta_u;                   /* NaN = None */
+    double linesearch_decay;          /* default 0.2 */
+    int32_t pnqp_iter;                /* n_iter of the in-sweep pnqp, 20 (mpc/lqr_step.py:137) */
+    int32_t _pad;
+} mpc_lqr_options;
+
+/* Outputs of LQRStepFn.forward (mpc/lqr_step.py:308-309) and LqrForOut (:17-20).
+ * Any pointer except new_x/new_u may be NULL. */
+typedef struct mpc_lqr_outputs {
+    void *new_x;            /* [T,B,ns] */
+    void *new_u;            /* [T,B,nc] */
+    void *costs;            /* [B] cost of the returned trajectory            */
+    void *old_costs;        /* [B] cost of the nominal trajectory             */
+    void *full_du_norm;     /* [B] ||u - u'||_2 of the alpha = 1 pass         */
+    void *alpha_du_norm;    /* [B] ||u - u'||_2 of the returned pass          */
+    void *alphas;           /* [B] line-search step actually used             */
+    int32_t *qp_iters;      /* [B] sum_t (1 + pnqp iterations), 0 if unbounded */
+    int32_t *status;        /* [B] MPC_ST_* bits                              */
+    void *K;                /* [T,B,nc,ns] feedback gains, optional           */
+    void *k;                /* [T,B,nc]   feed-forward,   optional           */
+} mpc_lqr_outputs;
+
+/* ABI / build identification. */
+int mpc_lqr_abi_version(void);
+const char *mpc_lqr_build_info(void);
+const char *mpc_lqr_last_error(void);
+
+/* Bytes of device scratch mpc_lqr_step / mpc_lqr_rollout need when out->K/k are
+ * NULL (the generic path parks K,k there between sweep and rollout). */
+int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p);
+
+/* (1) One whole LQR step = LQRStepFn.forward, mpc/lqr_step.py:277-309:
+ *     delta-space linear term (:284-296) + Riccati sweep `lqr_backward`
+ *     (:52-160, incl. pnqp mpc/pnqp.py:5-82 and the masked solve :99-127)
+ *     + line-searched rollout `lqr_forward` (:164-261) for LinDx/QuadCost.
+ *     `impl`: 0 = auto, 1 = generic kernels, 2 = fused MFMA kernel (n <= 16, f32). */
+int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
+                 void *workspace, int64_t workspace_bytes, int impl, void *stream);
+
+/* (2) The sweep alone: c_back + lqr_backward (mpc/lqr_step.py:284-296, 52-160).
+ *     Writes out->K, out->k (required), out->old_costs, out->qp_iters, out->status. */
+int mpc_lqr_sweep(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
+                  void *stream);
+
+/* (3) The rollout alone: lqr_forward (mpc/lqr_step.py:164-261) given K,k in out->K/out->k.
+ *     `old_costs_in` may be NULL (then util.get_cost of the nominal is recomputed, :169). */
+int mpc_lqr_rollout(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
+                    const void *old_costs_in, void *stream);
+
+/* (4) The closed-form part of LQRStepFn.backward, mpc/lqr_step.py:346-404: given the
+ *     solution (x*,u*) and the KKT solve's (dx,du) [= mpc_lqr_step on (C,-r,F), :328-340],
+ *     emit dC [T,B,n,n], dc [T,B,n], dF [T-1,B,ns,n], df [T-1,B,ns] (NULL if f empty),
+ *     dx_init [B,ns].  r = [dl_dx; dl_du] is passed as its two halves. */
+int mpc_lqr_kkt_grads(const mpc_lqr_problem *p, /* C,c,F (+strides); cur_x/cur_u = x*,u* */
+                      const void *dx, const void *du, const void *dl_dx, const void *dl_du,
+                      void *dC, void *dc, void *dF, void *df, void *dx_init, void *stream);
+
+/* (4b) r -> -r packing and the active-bound mask of mpc/lqr_step.py:316-326:
+ *     negr [T,B,n] = -[dl_dx; dl_du];  mask [T,B,nc] = |u*-lo|<=1e-8 | |u*-hi|<=1e-8
+ *     (mask may be NULL when unbounded). */
+int mpc_lqr_kkt_prepare(int dtype, int B, int T, int ns, int nc,
+                        const void *dl_dx, const void *dl_du, const void *u_star,
+                        const mpc_lqr_options *o, void *negr, uint8_t *mask, void *stream);
+
+/* (5) Standalone batched pnqp, mpc/pnqp.py:5-82.  H [B,n,n], q/lo/hi/x0/x [B,n];
+ *     x0 NULL = cold start (:14-19).  If_out [B,n] uint8 (1 = free), iters [B],
+ *     Hfree [B,n,n] receives H_ (free-set Hessian + 1e-11 I, :44-48) or NULL. */
+int mpc_pnqp(int dtype, int B, int n, const void *H, const void *q, const void *lo, const void *hi,
+             const void *x0, int n_iter, void *x, uint8_t *If_out, int32_t *iters, int32_t *status,
+             void *Hfree, void *stream);
+
+/* (6) util.get_traj (LinDx) + util.get_cost (QuadCost), mpc/util.py:102-153.
+ *     u = p->cur_u; writes x [T,B,ns] (if non-NULL) and cost [B] (if non-NULL and p->C set). */
+int mpc_traj_cost(const mpc_lqr_problem *p, void *x, void *cost, void *stream);
+
+/* (7) Device-side pieces of the iLQR driver loop (mpc/mpc.py:271-285, 299):
+ *     per-problem best-iterate select without host round trips.
+ *     take[b] = first || cost[b] <= best_cost[b] + eps ; where taken copy x,u,cost,du-norm.
+ *     flags[0] |= any(take) ; flags[1] = float bits unused ; max_du[0] = max_b full_du_norm. */
+int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double best_cost_eps,
+                    const void *x, const void *u, const void *costs, const void *du_norm,
+                    void *best_x, void *best_u, void *best_costs, void *best_du_norm,
+                    int32_t *any_improved, void *max_du_norm, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_LQR_H */

@@ -1,0 +1,235 @@
+// capi.hip -- extern "C" entry points of libmpc_lqr_hip.so (declared in include/mpc_lqr.h).
+// Argument validation + dtype / kernel dispatch; no computation happens on the host.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "lqr_common.h"
+
+namespace mpclqr {
+static thread_local std::string g_last_error;
+void set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
+
+static int fail(int code, const char *msg)
+{
+    set_last_error(msg);
+    return code;
+}
+
+static int check_problem(const mpc_lqr_problem *p, bool need_cost, bool need_nominal)
+{
+    if (!p) return fail(MPC_E_NULL, "problem is NULL");
+    if (p->B < 0 || p->T < 1 || p->ns < 1 || p->nc < 1) return fail(MPC_E_DIMS, "need B>=0, T>=1, ns>=1, nc>=1");
+    if (p->nc > 64) return fail(MPC_E_DIMS, "n_ctrl > 64 is not supported");
+    if (p->dtype != MPC_F32 && p->dtype != MPC_F64) return fail(MPC_E_DTYPE, "dtype must be MPC_F32 or MPC_F64");
+    if (p->B == 0) return MPC_OK;
+    if (need_cost && (!p->C || !p->c)) return fail(MPC_E_NULL, "C / c is NULL");
+    if (p->T > 1 && !p->F) return fail(MPC_E_NULL, "F is NULL");
+    if (!p->x_init) return fail(MPC_E_NULL, "x_init is NULL");
+    if (need_nominal && (!p->cur_x || !p->cur_u)) return fail(MPC_E_NULL, "current_x / current_u is NULL");
+    return MPC_OK;
+}
+
+static int check_options(const mpc_lqr_problem *p, const mpc_lqr_options *o)
+{
+    if (!o) return MPC_OK;
+    if (o->bound_mode < MPC_BOUND_NONE || o->bound_mode > MPC_BOUND_TENSOR) return fail(MPC_E_ARG, "bad bound_mode");
+    if (o->bound_mode == MPC_BOUND_TENSOR && (!o->lo || !o->hi) && p->B > 0) return fail(MPC_E_NULL, "tensor bounds are NULL");
+    if (o->max_linesearch_iter < 1) return fail(MPC_E_ARG, "max_linesearch_iter must be > 0");  // mpc/mpc.py:148
+    // mpc/lqr_step.py:195: delta_u without bounds is unimplemented in the reference as well
+    if (o->delta_u == o->delta_u && o->delta_u >= 0 && o->bound_mode == MPC_BOUND_NONE)
+        return fail(MPC_E_ARG, "delta_u requires u_lower/u_upper (mpc/lqr_step.py:195)");
+    return MPC_OK;
+}
+
+template <typename real>
+static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
+                     void *workspace, int64_t workspace_bytes, int impl, int phase_mask,
+                     const void *old_costs_in, hipStream_t st)
+{
+    StepParams<real> sp = make_params<real>(p, o, out);
+    sp.old_costs_in = (const real *)old_costs_in;
+    if (phase_mask & 2) {
+        if (!sp.new_x || !sp.new_u) return fail(MPC_E_NULL, "new_x / new_u is NULL");
+    }
+    const int64_t needK = (int64_t)p->T * p->B * p->nc * p->ns * (int64_t)sizeof(real);
+    const int64_t needk = (int64_t)p->T * p->B * p->nc * (int64_t)sizeof(real);
+    bool fast = false;
+    if (phase_mask == 3 && impl != 1) {
+        if constexpr (sizeof(real) == 4) {
+            fast = mfma16_supported(sp);
+            if (impl == 2 && !fast) return fail(MPC_E_DIMS, "fused MFMA kernel needs fp32 and n_state+n_ctrl <= 16");
+            if (fast) return launch_step_mfma16(sp, st);
+        } else if (impl == 2) {
+            return fail(MPC_E_DTYPE, "fused MFMA kernel is fp32 only");
+        }
+    }
+    if (!sp.K || !sp.k) {
+        if (phase_mask != 3) return fail(MPC_E_NULL, "K / k is NULL");
+        if (!workspace || workspace_bytes < needK + needk)
+            return fail(MPC_E_ARG, "workspace too small (see mpc_lqr_workspace_bytes)");
+        sp.K = (real *)workspace;
+        sp.k = (real *)((char *)workspace + needK);
+    }
+    return launch_step_generic<real>(sp, phase_mask, st);
+}
+}  // namespace mpclqr
+
+using namespace mpclqr;
+
+extern "C" {
+
+int mpc_lqr_abi_version(void) { return MPC_LQR_ABI_VERSION; }
+
+const char *mpc_lqr_build_info(void)
+{
+    return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32>, "
+           "kkt_grads, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
+}
+
+const char *mpc_lqr_last_error(void) { return g_last_error.c_str(); }
+
+int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p)
+{
+    if (!p) return 0;
+    const int64_t e = p->dtype == MPC_F64 ? 8 : 4;
+    return ((int64_t)p->T * p->B * p->nc * p->ns + (int64_t)p->T * p->B * p->nc) * e + 256;
+}
+
+int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
+                 void *workspace, int64_t workspace_bytes, int impl, void *stream)
+{
+    int rc = check_problem(p, true, true);
+    if (rc) return rc;
+    if ((rc = check_options(p, o))) return rc;
+    if (!out) return fail(MPC_E_NULL, "outputs is NULL");
+    if (p->B == 0) return MPC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return p->dtype == MPC_F32 ? step_impl<float>(p, o, out, workspace, workspace_bytes, impl, 3, nullptr, st)
+                               : step_impl<double>(p, o, out, workspace, workspace_bytes, impl, 3, nullptr, st);
+}
+
+int mpc_lqr_sweep(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out, void *stream)
+{
+    int rc = check_problem(p, true, true);
+    if (rc) return rc;
+    if ((rc = check_options(p, o))) return rc;
+    if (!out) return fail(MPC_E_NULL, "outputs is NULL");
+    if (p->B == 0) return MPC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return p->dtype == MPC_F32 ? step_impl<float>(p, o, out, nullptr, 0, 1, 1, nullptr, st)
+                               : step_impl<double>(p, o, out, nullptr, 0, 1, 1, nullptr, st);
+}
+
+int mpc_lqr_rollout(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
+                    const void *old_costs_in, void *stream)
+{
+    int rc = check_problem(p, true, true);
+    if (rc) return rc;
+    if ((rc = check_options(p, o))) return rc;
+    if (!out) return fail(MPC_E_NULL, "outputs is NULL");
+    if (p->B == 0) return MPC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    return p->dtype == MPC_F32 ? step_impl<float>(p, o, out, nullptr, 0, 1, 2, old_costs_in, st)
+                               : step_impl<double>(p, o, out, nullptr, 0, 1, 2, old_costs_in, st);
+}
+
+int mpc_lqr_kkt_grads(const mpc_lqr_problem *p, const void *dx, const void *du, const void *dl_dx,
+                      const void *dl_du, void *dC, void *dc, void *dF, void *df, void *dx_init, void *stream)
+{
+    int rc = check_problem(p, true, true);
+    if (rc) return rc;
+    if (p->B == 0) return MPC_OK;
+    if (!dx || !du || !dl_dx || !dl_du || !dC || !dc || !dx_init) return fail(MPC_E_NULL, "kkt_grads: NULL argument");
+    if (p->T > 1 && !dF) return fail(MPC_E_NULL, "kkt_grads: dF is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (p->dtype == MPC_F32) {
+        StepParams<float> sp = make_params<float>(p, nullptr, nullptr);
+        return launch_kkt_grads<float>(sp, (const float *)dx, (const float *)du, (const float *)dl_dx,
+                                       (const float *)dl_du, (float *)dC, (float *)dc, (float *)dF, (float *)df,
+                                       (float *)dx_init, st);
+    }
+    StepParams<double> sp = make_params<double>(p, nullptr, nullptr);
+    return launch_kkt_grads<double>(sp, (const double *)dx, (const double *)du, (const double *)dl_dx,
+                                    (const double *)dl_du, (double *)dC, (double *)dc, (double *)dF, (double *)df,
+                                    (double *)dx_init, st);
+}
+
+int mpc_lqr_kkt_prepare(int dtype, int B, int T, int ns, int nc, const void *dl_dx, const void *dl_du,
+                        const void *u_star, const mpc_lqr_options *o, void *negr, uint8_t *mask, void *stream)
+{
+    if (dtype != MPC_F32 && dtype != MPC_F64) return fail(MPC_E_DTYPE, "bad dtype");
+    if (B < 0 || T < 1 || ns < 1 || nc < 1) return fail(MPC_E_DIMS, "bad dims");
+    if (B == 0) return MPC_OK;
+    if (!dl_dx || !dl_du || !negr) return fail(MPC_E_NULL, "kkt_prepare: NULL argument");
+    const int mode = o ? o->bound_mode : MPC_BOUND_NONE;
+    if (mask && (mode == MPC_BOUND_NONE || !u_star)) return fail(MPC_E_ARG, "kkt_prepare: mask needs bounds and u*");
+    if (mask && mode == MPC_BOUND_TENSOR && (!o->lo || !o->hi)) return fail(MPC_E_NULL, "tensor bounds are NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MPC_F32)
+        return launch_kkt_prepare<float>(B, T, ns, nc, (const float *)dl_dx, (const float *)dl_du,
+                                         (const float *)u_star, mode, o ? (float)o->lo_s : 0.f,
+                                         o ? (float)o->hi_s : 0.f, o ? (const float *)o->lo : nullptr,
+                                         o ? (const float *)o->hi : nullptr, (float *)negr, mask, st);
+    return launch_kkt_prepare<double>(B, T, ns, nc, (const double *)dl_dx, (const double *)dl_du,
+                                      (const double *)u_star, mode, o ? o->lo_s : 0., o ? o->hi_s : 0.,
+                                      o ? (const double *)o->lo : nullptr, o ? (const double *)o->hi : nullptr,
+                                      (double *)negr, mask, st);
+}
+
+int mpc_pnqp(int dtype, int B, int n, const void *H, const void *q, const void *lo, const void *hi,
+             const void *x0, int n_iter, void *x, uint8_t *If_out, int32_t *iters, int32_t *status,
+             void *Hfree, void *stream)
+{
+    if (dtype != MPC_F32 && dtype != MPC_F64) return fail(MPC_E_DTYPE, "bad dtype");
+    if (B < 0 || n < 1) return fail(MPC_E_DIMS, "bad dims");
+    if (B == 0) return MPC_OK;
+    if (!H || !q || !lo || !hi || !x) return fail(MPC_E_NULL, "pnqp: NULL argument");
+    if (n_iter < 1) n_iter = 20;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MPC_F32)
+        return launch_pnqp<float>(B, n, (const float *)H, (const float *)q, (const float *)lo, (const float *)hi,
+                                  (const float *)x0, n_iter, (float *)x, If_out, iters, status, (float *)Hfree, st);
+    return launch_pnqp<double>(B, n, (const double *)H, (const double *)q, (const double *)lo, (const double *)hi,
+                               (const double *)x0, n_iter, (double *)x, If_out, iters, status, (double *)Hfree, st);
+}
+
+int mpc_traj_cost(const mpc_lqr_problem *p, void *x, void *cost, void *stream)
+{
+    if (!p) return fail(MPC_E_NULL, "problem is NULL");
+    int rc = check_problem(p, cost != nullptr, false);
+    if (rc) return rc;
+    if (p->B == 0) return MPC_OK;
+    if (!p->cur_u) return fail(MPC_E_NULL, "traj_cost: u (cur_u) is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (p->dtype == MPC_F32) {
+        StepParams<float> sp = make_params<float>(p, nullptr, nullptr);
+        return launch_traj_cost<float>(sp, (float *)x, (float *)cost, st);
+    }
+    StepParams<double> sp = make_params<double>(p, nullptr, nullptr);
+    return launch_traj_cost<double>(sp, (double *)x, (double *)cost, st);
+}
+
+int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double best_cost_eps, const void *x,
+                    const void *u, const void *costs, const void *du_norm, void *best_x, void *best_u,
+                    void *best_costs, void *best_du_norm, int32_t *any_improved, void *max_du_norm, void *stream)
+{
+    if (dtype != MPC_F32 && dtype != MPC_F64) return fail(MPC_E_DTYPE, "bad dtype");
+    if (B < 0 || T < 1 || ns < 1 || nc < 1) return fail(MPC_E_DIMS, "bad dims");
+    if (B == 0) return MPC_OK;
+    if (!x || !u || !costs || !du_norm || !best_x || !best_u || !best_costs || !best_du_norm)
+        return fail(MPC_E_NULL, "select_best: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MPC_F32)
+        return launch_select_best<float>(B, T, ns, nc, first, (float)best_cost_eps, (const float *)x,
+                                         (const float *)u, (const float *)costs, (const float *)du_norm,
+                                         (float *)best_x, (float *)best_u, (float *)best_costs,
+                                         (float *)best_du_norm, any_improved, (float *)max_du_norm, st);
+    return launch_select_best<double>(B, T, ns, nc, first, best_cost_eps, (const double *)x, (const double *)u,
+                                      (const double *)costs, (const double *)du_norm, (double *)best_x,
+                                      (double *)best_u, (double *)best_costs, (double *)best_du_norm,
+                                      any_improved, (double *)max_du_norm, st);
+}
+
+}  // extern "C"

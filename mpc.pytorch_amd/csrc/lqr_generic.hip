@@ -1,0 +1,900 @@
+// lqr_generic.hip -- shape-generic gfx950 kernels for the batched LQR step.
+//
+// One 64-lane wavefront (= one workgroup) owns one problem instance for the
+// whole horizon: all per-timestep blocks (Q, V, F, the augmented solve matrix)
+// live in LDS, the time loop never leaves the kernel.  Any (n_state, n_ctrl)
+// that fits LDS, float or double.  The n <= 16 / fp32 headline shape has its
+// own register/MFMA kernel (lqr_mfma16.hip); this file is the path every other
+// shape takes and the one the fast kernel is cross-checked against.
+//
+// Replaces, per reference call site (paths relative to locuslab/mpc.pytorch):
+//   sweep_problem    mpc/lqr_step.py:284-296 (c_back) + :52-160 (lqr_backward)
+//   pnqp_core        mpc/pnqp.py:5-82
+//   rollout_problem  mpc/lqr_step.py:164-261 (lqr_forward), mpc/util.py:129-153
+//   kkt_grads_kernel mpc/lqr_step.py:346-404
+//   traj_cost_kernel mpc/util.py:102-153
+//   select_best_kernel mpc/mpc.py:271-285, 299
+#include "lqr_common.h"
+
+namespace mpclqr {
+
+namespace {
+
+constexpr int WAVE = 64;
+
+template <typename real> __device__ __forceinline__ real rabs(real x) { return x < 0 ? -x : x; }
+template <typename real> __device__ __forceinline__ real rsqrt_(real x);
+template <> __device__ __forceinline__ float rsqrt_<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double rsqrt_<double>(double x) { return sqrt(x); }
+
+// util.eclamp (mpc/util.py:56-70): strict compares, bound value written exactly.
+template <typename real> __device__ __forceinline__ real eclamp(real x, real lo, real hi)
+{
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
+}
+
+template <typename real>
+struct Smem {
+    real *Q, *F, *W, *V, *A, *Kt, *M;
+    real *q, *v, *tau, *dtau, *kt, *Lcol, *px, *pg, *pdx, *pmx, *lb, *ub, *xn, *xn2, *dxv, *red;
+    int *If;
+    __device__ void carve(char *base, int ns, int nc, int nt)
+    {
+        const int n = ns + nc;
+        real *p = reinterpret_cast<real *>(base);
+        Q = p; p += n * n;
+        F = p; p += ns * n;
+        W = p; p += n * ns;
+        V = p; p += ns * ns;
+        A = p; p += nc * (nc + 1 + ns);
+        Kt = p; p += nc * ns;
+        M = p; p += nc * (ns + 1);
+        q = p; p += n;
+        v = p; p += ns;
+        tau = p; p += n;
+        dtau = p; p += n;
+        kt = p; p += nc;
+        Lcol = p; p += nc;
+        px = p; p += nc;
+        pg = p; p += nc;
+        pdx = p; p += nc;
+        pmx = p; p += nc;
+        lb = p; p += nc;
+        ub = p; p += nc;
+        xn = p; p += ns;
+        xn2 = p; p += ns;
+        dxv = p; p += ns;
+        red = p; p += nt;
+        If = reinterpret_cast<int *>(p);
+    }
+};
+
+// Sum over the workgroup, identical bits in every thread (fixed order).
+template <typename real> __device__ real block_sum(real v, real *red)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    red[tid] = v;
+    __syncthreads();
+    real s = 0;
+    for (int i = 0; i < nt; ++i) s += red[i];
+    __syncthreads();
+    return s;
+}
+
+// In-place pivoted LU of the leading nr x nr block of the row-major LDS matrix
+// A (nr x ncols) and solve for the trailing ncols-nr right-hand sides; threads
+// own columns.  On return A[:, nr:] = A[:, :nr]^{-1} * RHS.  This is the
+// Tensor.lu()/lu_solve pair of mpc/pnqp.py:18-19,53-54 and mpc/lqr_step.py:125-127,148,
+// and stands in for the per-sample torch.pinverse of :88-94 (identical for the
+// nonsingular Quu all configurations produce).
+template <typename real> __device__ void lu_solve_aug(real *A, int nr, int ncols, real *Lcol)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int p = 0; p < nr; ++p) {
+        int r = p;
+        real best = rabs(A[p * ncols + p]);
+        for (int i = p + 1; i < nr; ++i) {
+            real a = rabs(A[i * ncols + p]);
+            if (a > best) { best = a; r = i; }
+        }
+        __syncthreads();
+        if (r != p)
+            for (int j = tid; j < ncols; j += nt) {
+                real tmp = A[p * ncols + j];
+                A[p * ncols + j] = A[r * ncols + j];
+                A[r * ncols + j] = tmp;
+            }
+        __syncthreads();
+        const real d = A[p * ncols + p];
+        for (int i = p + 1 + tid; i < nr; i += nt) Lcol[i] = A[i * ncols + p] / d;
+        __syncthreads();
+        for (int j = p + 1 + tid; j < ncols; j += nt) {
+            const real pj = A[p * ncols + j];
+            for (int i = p + 1; i < nr; ++i) A[i * ncols + j] -= Lcol[i] * pj;
+        }
+        __syncthreads();
+    }
+    for (int j = nr + tid; j < ncols; j += nt) {
+        for (int k = nr - 1; k >= 0; --k) {
+            real x = A[k * ncols + j];
+            for (int i = k + 1; i < nr; ++i) x -= A[k * ncols + i] * A[i * ncols + j];
+            A[k * ncols + j] = x / A[k * ncols + k];
+        }
+    }
+    __syncthreads();
+}
+
+// 0.5 x'Hx + q'x with H given as (pointer, leading dim); every thread computes it.
+template <typename real>
+__device__ real qp_obj(const real *H, int ld, const real *q, const real *x, int n)
+{
+    real quad = 0, lin = 0;
+    for (int i = 0; i < n; ++i) {
+        real r = 0;
+        for (int j = 0; j < n; ++j) r += H[i * ld + j] * x[j];
+        quad += x[i] * r;
+        lin += q[i] * x[i];
+    }
+    return (real)0.5 * quad + lin;
+}
+
+// Projected-Newton box QP for ONE problem (mpc/pnqp.py:5-82 with n_batch = 1):
+//   min 0.5 x'Hx + q'x  s.t. lb <= x <= ub.
+// H (n x n, leading dim ldH) and qv may live in LDS or global memory.  `rhs`
+// (n x nrhs, leading dim ldR, may be NULL) is an extra right-hand side carried
+// through every factorisation so that on exit A[:, n+1:] = H_free^{-1} rhs_free
+// -- the K = -Quu_free^{-1} Qux of mpc/lqr_step.py:142-148 comes out of the same
+// elimination that produced the final Newton step.  x must already hold the
+// clamped start.  Returns the iteration index the reference returns.
+template <typename real>
+__device__ int pnqp_core(const real *H, int ldH, const real *qv, const real *rhs, int ldR, int nrhs,
+                         int n, int n_iter, real *A, real *Lcol, real *x, real *g, real *dx, real *mx,
+                         const real *lb, const real *ub, int *If, bool *converged)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int ncols = n + 1 + nrhs;
+    const real GAMMA = (real)0.1;
+    int it_ret = n_iter - 1;
+    bool conv = false;
+    for (int it = 0; it < n_iter; ++it) {
+        // :29-33 gradient, clamped / free sets
+        for (int i = tid; i < n; i += nt) {
+            real r = 0;
+            for (int j = 0; j < n; ++j) r += H[i * ldH + j] * x[j];
+            r += qv[i];
+            g[i] = r;
+            const real xi = x[i];
+            const bool ic = ((xi == lb[i]) && (r > 0)) || ((xi == ub[i]) && (r < 0));
+            If[i] = ic ? 0 : 1;
+        }
+        __syncthreads();
+        // :44-48 H_ = H on the free block (+1e-11 I), g_ = g on the free set
+        for (int e = tid; e < n * ncols; e += nt) {
+            const int i = e / ncols, j = e - i * ncols;
+            const bool fi = If[i] != 0;
+            real val;
+            if (j < n) {
+                val = (fi && If[j] != 0) ? H[i * ldH + j] : (real)0;
+                if (i == j) val += (real)1e-11;
+            } else if (j == n) {
+                val = fi ? g[i] : (real)0;
+            } else {
+                val = fi ? rhs[i * ldR + (j - n - 1)] : (real)0;
+            }
+            A[e] = val;
+        }
+        __syncthreads();
+        lu_solve_aug(A, n, ncols, Lcol);            // :50-54
+        for (int i = tid; i < n; i += nt) dx[i] = -A[i * ncols + n];
+        __syncthreads();
+        real nrm2 = 0;
+        for (int i = 0; i < n; ++i) nrm2 += dx[i] * dx[i];
+        if (!(rsqrt_<real>(nrm2) >= (real)1e-4)) {  // :56-59
+            conv = true;
+            it_ret = it;
+            break;
+        }
+        // :61-76 Armijo backtracking (n_batch = 1 form of the batch-global loop)
+        real alpha = 1;
+        const real obj_x = qp_obj(H, ldH, qv, x, n);
+        for (int count = 0; count < 10; ++count) {
+            for (int i = tid; i < n; i += nt) mx[i] = eclamp<real>(x[i] + alpha * dx[i], lb[i], ub[i]);
+            __syncthreads();
+            const real obj_m = qp_obj(H, ldH, qv, mx, n);
+            real den = 0;
+            for (int i = 0; i < n; ++i) den += g[i] * (x[i] - mx[i]);
+            const real arm = (obj_x - obj_m) / den;
+            __syncthreads();
+            if (arm <= GAMMA) alpha *= (real)0.1; else break;
+        }
+        for (int i = tid; i < n; i += nt) x[i] = mx[i];   // :78
+        __syncthreads();
+    }
+    *converged = conv;
+    return it_ret;
+}
+
+// ---------------------------------------------------------------------------
+// Riccati sweep for one problem.
+// ---------------------------------------------------------------------------
+template <typename real>
+__device__ void sweep_problem(const StepParams<real> &p, int b, Smem<real> &s, real *Kdst, real *kdst,
+                              real &old_cost, int &qp_total, int &status)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T, B = p.B;
+    const int ncols = nc + 1 + ns;
+    real oc = 0;
+    bool warm = false;
+    qp_total = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+        const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+        const long tb = (long)t * B + b;
+        for (int e = tid; e < n * n; e += nt) s.Q[e] = Ct[e];
+        if (t < T - 1) {
+            const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
+            for (int e = tid; e < ns * n; e += nt) s.F[e] = Ft[e];
+        }
+        for (int i = tid; i < n; i += nt)
+            s.tau[i] = i < ns ? p.cur_x[tb * ns + i] : p.cur_u[tb * nc + (i - ns)];
+        __syncthreads();
+        // delta-space linear term c_back = C tau + c (mpc/lqr_step.py:289-295) and the
+        // nominal cost 0.5 tau'C tau + c'tau (util.get_cost, :169) off the same product.
+        for (int i = tid; i < n; i += nt) {
+            real r = 0;
+            for (int j = 0; j < n; ++j) r += s.Q[i * n + j] * s.tau[j];
+            const real ci = ct[i], ti = s.tau[i];
+            oc += (real)0.5 * ti * r + ci * ti;
+            s.q[i] = r + ci;
+        }
+        if (t < T - 1) {
+            // Q = C + F'VF, q = c_back + F'v  (:65-70; the f-term of :72-74 is dead: f_back=None)
+            for (int e = tid; e < n * ns; e += nt) {
+                const int i = e / ns, k = e - i * ns;
+                real r = 0;
+                for (int m = 0; m < ns; ++m) r += s.F[m * n + i] * s.V[m * ns + k];
+                s.W[e] = r;
+            }
+            __syncthreads();
+            for (int e = tid; e < n * n; e += nt) {
+                const int i = e / n, j = e - i * n;
+                real r = 0;
+                for (int k = 0; k < ns; ++k) r += s.W[i * ns + k] * s.F[k * n + j];
+                s.Q[e] += r;
+            }
+            for (int i = tid; i < n; i += nt) {
+                real r = 0;
+                for (int m = 0; m < ns; ++m) r += s.F[m * n + i] * s.v[m];
+                s.q[i] += r;
+            }
+        }
+        __syncthreads();
+
+        const real *Quu = s.Q + ns * n + ns;   // leading dim n
+        const real *Qux = s.Q + ns * n;        // leading dim n
+        const real *qu = s.q + ns;
+        if (p.bound_mode == MPC_BOUND_NONE) {
+            // :84-94 unconstrained, :99-127 masked (u_zero_I): [Quu_ | qu_ | Qux_] eliminated at once
+            const uint8_t *mk = p.zero_mask ? p.zero_mask + tb * nc : nullptr;
+            for (int e = tid; e < nc * ncols; e += nt) {
+                const int i = e / ncols, j = e - i * ncols;
+                const bool mi = mk && mk[i];
+                real val;
+                if (j < nc) {
+                    const bool mj = mk && mk[j];
+                    val = (!mi && !mj) ? Quu[i * n + j] : (real)0;
+                    if (mi && i == j) val += (real)1e-8;     // :116
+                } else if (j == nc) {
+                    val = mi ? (real)0 : qu[i];
+                } else {
+                    val = mi ? (real)0 : Qux[i * n + (j - nc - 1)];
+                }
+                s.A[e] = val;
+            }
+            __syncthreads();
+            lu_solve_aug(s.A, nc, ncols, s.Lcol);
+        } else {
+            // :128-148 box constraints in delta space
+            for (int i = tid; i < nc; i += nt) {
+                const real u = p.cur_u[tb * nc + i];
+                real l = (p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[tb * nc + i]) - u;
+                real h = (p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : p.hi[tb * nc + i]) - u;
+                if (p.has_delta) {                            // :132-134
+                    if (l < -p.delta_u) l = -p.delta_u;
+                    if (h > p.delta_u) h = p.delta_u;
+                }
+                s.lb[i] = l;
+                s.ub[i] = h;
+            }
+            if (!warm) {
+                // cold start x = -H^{-1} q (mpc/pnqp.py:14-19)
+                for (int e = tid; e < nc * (nc + 1); e += nt) {
+                    const int i = e / (nc + 1), j = e - i * (nc + 1);
+                    s.A[e] = j < nc ? Quu[i * n + j] : qu[i];
+                }
+                __syncthreads();
+                lu_solve_aug(s.A, nc, nc + 1, s.Lcol);
+                for (int i = tid; i < nc; i += nt) s.px[i] = -s.A[i * (nc + 1) + nc];
+            } else {
+                for (int i = tid; i < nc; i += nt) s.px[i] = s.kt[i];   // warm start = k_{t+1} (:137,141)
+            }
+            __syncthreads();
+            for (int i = tid; i < nc; i += nt) s.px[i] = eclamp<real>(s.px[i], s.lb[i], s.ub[i]);
+            __syncthreads();
+            bool conv = false;
+            const int it = pnqp_core<real>(Quu, n, qu, Qux, n, ns, nc, p.pnqp_iter, s.A, s.Lcol, s.px, s.pg,
+                                           s.pdx, s.pmx, s.lb, s.ub, s.If, &conv);
+            qp_total += 1 + it;                               // :140
+            if (!conv) status |= MPC_ST_PNQP_UNCONVERGED;
+            warm = true;
+        }
+        for (int e = tid; e < nc * ns; e += nt) {
+            const int i = e / ns, j = e - i * ns;
+            s.Kt[e] = -s.A[i * ncols + nc + 1 + j];
+        }
+        for (int i = tid; i < nc; i += nt)
+            s.kt[i] = (p.bound_mode == MPC_BOUND_NONE) ? -s.A[i * ncols + nc] : s.px[i];
+        __syncthreads();
+        {
+            real *Kg = Kdst + tb * nc * ns, *kg = kdst + tb * nc;
+            for (int e = tid; e < nc * ns; e += nt) Kg[e] = s.Kt[e];
+            for (int i = tid; i < nc; i += nt) kg[i] = s.kt[i];
+        }
+        // :155-158 V = Qxx + Qxu K + K'Qux + K'Quu K ; v likewise (unmasked Quu, qu)
+        for (int e = tid; e < nc * (ns + 1); e += nt) {
+            const int l = e / (ns + 1), j = e - l * (ns + 1);
+            real r = 0;
+            for (int l2 = 0; l2 < nc; ++l2)
+                r += Quu[l * n + l2] * (j < ns ? s.Kt[l2 * ns + j] : s.kt[l2]);
+            s.M[e] = r;
+        }
+        __syncthreads();
+        for (int e = tid; e < ns * ns; e += nt) {
+            const int i = e / ns, j = e - i * ns;
+            real t1 = 0, t2 = 0, t3 = 0;
+            for (int l = 0; l < nc; ++l) {
+                const real kli = s.Kt[l * ns + i];
+                t1 += s.Q[i * n + ns + l] * s.Kt[l * ns + j];
+                t2 += kli * Qux[l * n + j];
+                t3 += kli * s.M[l * (ns + 1) + j];
+            }
+            s.V[e] = s.Q[i * n + j] + t1 + t2 + t3;
+        }
+        for (int i = tid; i < ns; i += nt) {
+            real t1 = 0, t2 = 0, t3 = 0;
+            for (int l = 0; l < nc; ++l) {
+                const real kli = s.Kt[l * ns + i];
+                t1 += s.Q[i * n + ns + l] * s.kt[l];
+                t2 += kli * qu[l];
+                t3 += kli * s.M[l * (ns + 1) + ns];
+            }
+            s.v[i] = s.q[i] + t1 + t2 + t3;
+        }
+        __syncthreads();
+    }
+    old_cost = block_sum<real>(oc, s.red);
+}
+
+// Nominal cost only (util.get_cost with x given, mpc/util.py:129-153).
+template <typename real>
+__device__ real nominal_cost(const StepParams<real> &p, int b, Smem<real> &s)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T, B = p.B;
+    real oc = 0;
+    for (int t = 0; t < T; ++t) {
+        const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+        const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+        const long tb = (long)t * B + b;
+        for (int e = tid; e < n * n; e += nt) s.Q[e] = Ct[e];
+        for (int i = tid; i < n; i += nt)
+            s.tau[i] = i < ns ? p.cur_x[tb * ns + i] : p.cur_u[tb * nc + (i - ns)];
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) {
+            real r = 0;
+            for (int j = 0; j < n; ++j) r += s.Q[i * n + j] * s.tau[j];
+            oc += (real)0.5 * s.tau[i] * r + ct[i] * s.tau[i];
+        }
+        __syncthreads();
+    }
+    return block_sum<real>(oc, s.red);
+}
+
+// ---------------------------------------------------------------------------
+// Line-searched rollout for one problem (mpc/lqr_step.py:164-261, LinDx/QuadCost).
+// ---------------------------------------------------------------------------
+template <typename real>
+__device__ void rollout_problem(const StepParams<real> &p, int b, Smem<real> &s, const real *Ksrc,
+                                const real *ksrc, real old_cost, int &status)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T, B = p.B;
+    real alpha = 1, cost = 0, dun = 0, full = 0;
+    for (int pass = 0; pass < p.max_ls; ++pass) {
+        for (int i = tid; i < ns; i += nt) {
+            const real xi = p.x_init[(long)b * ns + i];
+            s.xn[i] = xi;
+            s.dxv[i] = 0;
+            p.new_x[(long)b * ns + i] = xi;
+        }
+        real ca = 0, da = 0;
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const long tb = (long)t * B + b;
+            const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+            const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+            const real *Kg = Ksrc + tb * nc * ns, *kg = ksrc + tb * nc;
+            for (int e = tid; e < n * n; e += nt) s.Q[e] = Ct[e];
+            if (t < T - 1) {
+                const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
+                for (int e = tid; e < ns * n; e += nt) s.F[e] = Ft[e];
+            }
+            for (int i = tid; i < nc; i += nt) {
+                real r = 0;
+                for (int j = 0; j < ns; ++j) r += Kg[i * ns + j] * s.dxv[j];
+                const real u = p.cur_u[tb * nc + i];
+                real un = r + u + alpha * kg[i];                       // :192
+                if (p.zero_mask && p.zero_mask[tb * nc + i]) un = 0;   // :197-198
+                if (p.bound_mode != MPC_BOUND_NONE) {                  // :200-213
+                    real l = p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[tb * nc + i];
+                    real h = p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : p.hi[tb * nc + i];
+                    if (p.has_delta) {
+                        const real l2 = u - p.delta_u, h2 = u + p.delta_u;
+                        l = (l2 < l) ? l : l2;
+                        h = (h2 > h) ? h : h2;
+                    }
+                    un = eclamp<real>(un, l, h);
+                }
+                s.tau[ns + i] = un;
+                p.new_u[tb * nc + i] = un;
+                const real d = u - un;
+                da += d * d;
+            }
+            for (int j = tid; j < ns; j += nt) s.tau[j] = s.xn[j];
+            __syncthreads();
+            for (int i = tid; i < n; i += nt) {                        // :230-232
+                real r = 0;
+                for (int j = 0; j < n; ++j) r += s.Q[i * n + j] * s.tau[j];
+                ca += (real)0.5 * s.tau[i] * r + ct[i] * s.tau[i];
+            }
+            if (t < T - 1) {                                           // :216-222
+                const real *ft = p.f ? p.f + (long)t * p.f_st + (long)b * p.f_sb : nullptr;
+                for (int i = tid; i < ns; i += nt) {
+                    real r = 0;
+                    for (int j = 0; j < n; ++j) r += s.F[i * n + j] * s.tau[j];
+                    if (ft) r += ft[i];
+                    s.xn2[i] = r;
+                }
+            }
+            __syncthreads();
+            if (t < T - 1) {
+                const long tb1 = (long)(t + 1) * B + b;
+                for (int i = tid; i < ns; i += nt) {
+                    const real r = s.xn2[i];
+                    s.xn[i] = r;
+                    s.dxv[i] = r - p.cur_x[tb1 * ns + i];
+                    p.new_x[tb1 * ns + i] = r;
+                }
+            }
+            __syncthreads();
+        }
+        cost = block_sum<real>(ca, s.red);
+        dun = rsqrt_<real>(block_sum<real>(da, s.red));
+        if (pass == 0) full = dun;                                     // :243-245
+        // :176-179, 247, 252: keep shrinking while this problem's cost got worse
+        if (cost > old_cost && pass + 1 < p.max_ls) alpha *= p.ls_decay; else break;
+    }
+    if (!(cost == cost) || rabs(cost) > (real)3e38) status |= MPC_ST_NONFINITE;
+    if (tid == 0) {
+        if (p.costs) p.costs[b] = cost;
+        if (p.old_costs) p.old_costs[b] = old_cost;
+        if (p.full_du_norm) p.full_du_norm[b] = full;
+        if (p.alpha_du_norm) p.alpha_du_norm[b] = dun;
+        if (p.alphas) p.alphas[b] = alpha;
+    }
+}
+
+// phase_mask: 1 = sweep, 2 = rollout, 3 = both (K,k round-trip through p.K/p.k, L2-resident)
+template <typename real>
+__global__ void __launch_bounds__(WAVE) lqr_step_generic_kernel(StepParams<real> p, int phase_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem<real> s;
+    s.carve(smem_raw, p.ns, p.nc, blockDim.x);
+    const int b = blockIdx.x;
+    if (b >= p.B) return;
+    int status = 0, qp_total = 0;
+    real old_cost = 0;
+    if (phase_mask & 1) {
+        sweep_problem<real>(p, b, s, p.K, p.k, old_cost, qp_total, status);
+        if (threadIdx.x == 0) {
+            if (p.qp_iters) p.qp_iters[b] = qp_total;
+            if (p.old_costs) p.old_costs[b] = old_cost;
+        }
+    } else if (p.old_costs_in) {
+        old_cost = p.old_costs_in[b];
+    } else {
+        old_cost = nominal_cost<real>(p, b, s);
+    }
+    if (phase_mask & 2) {
+        // K,k were written by this same wave: make them visible to its own loads.
+        __threadfence_block();
+        __syncthreads();
+        rollout_problem<real>(p, b, s, p.K, p.k, old_cost, status);
+    }
+    if (threadIdx.x == 0 && p.status) {
+        if (phase_mask & 1) p.status[b] = status; else p.status[b] |= status;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// standalone pnqp (mpc/pnqp.py:5-82), one workgroup per problem, H read from HBM/L2
+// ---------------------------------------------------------------------------
+template <typename real>
+__global__ void pnqp_kernel(int B, int n, const real *H, const real *q, const real *lo, const real *hi,
+                            const real *x0, int n_iter, real *x_out, uint8_t *If_out, int *iters,
+                            int *status, real *Hfree)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (b >= B) return;
+    real *A = reinterpret_cast<real *>(smem_raw);     // n x (n+1)
+    real *Lcol = A + (size_t)n * (n + 1);
+    real *x = Lcol + n, *g = x + n, *dx = g + n, *mx = dx + n, *lb = mx + n, *ub = lb + n;
+    int *If = reinterpret_cast<int *>(ub + n);
+    const real *Hb = H + (size_t)b * n * n, *qb = q + (size_t)b * n;
+    for (int i = tid; i < n; i += nt) { lb[i] = lo[(size_t)b * n + i]; ub[i] = hi[(size_t)b * n + i]; }
+    if (x0 == nullptr) {
+        for (int e = tid; e < n * (n + 1); e += nt) {
+            const int i = e / (n + 1), j = e - i * (n + 1);
+            A[e] = j < n ? Hb[i * n + j] : qb[i];
+        }
+        __syncthreads();
+        lu_solve_aug(A, n, n + 1, Lcol);
+        for (int i = tid; i < n; i += nt) x[i] = -A[i * (n + 1) + n];
+    } else {
+        for (int i = tid; i < n; i += nt) x[i] = x0[(size_t)b * n + i];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) x[i] = eclamp<real>(x[i], lb[i], ub[i]);
+    __syncthreads();
+    bool conv = false;
+    const int it = pnqp_core<real>(Hb, n, qb, nullptr, 0, 0, n, n_iter, A, Lcol, x, g, dx, mx, lb, ub, If, &conv);
+    for (int i = tid; i < n; i += nt) {
+        x_out[(size_t)b * n + i] = x[i];
+        if (If_out) If_out[(size_t)b * n + i] = (uint8_t)If[i];
+    }
+    if (Hfree)
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e - i * n;
+            real val = (If[i] && If[j]) ? Hb[e] : (real)0;
+            if (i == j) val += (real)1e-11;
+            Hfree[(size_t)b * n * n + e] = val;
+        }
+    if (tid == 0) {
+        if (iters) iters[b] = it;
+        if (status) status[b] = conv ? 0 : MPC_ST_PNQP_UNCONVERGED;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// util.get_traj + util.get_cost (mpc/util.py:102-153)
+// ---------------------------------------------------------------------------
+template <typename real>
+__global__ void __launch_bounds__(WAVE) traj_cost_kernel(StepParams<real> p, real *x, real *cost)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem<real> s;
+    s.carve(smem_raw, p.ns, p.nc, blockDim.x);
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T, B = p.B;
+    if (b >= B) return;
+    for (int i = tid; i < ns; i += nt) {
+        const real xi = p.x_init[(long)b * ns + i];
+        s.xn[i] = xi;
+        if (x) x[(long)b * ns + i] = xi;
+    }
+    real ca = 0;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const long tb = (long)t * B + b;
+        if (cost) {
+            const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+            for (int e = tid; e < n * n; e += nt) s.Q[e] = Ct[e];
+        }
+        if (t < T - 1) {
+            const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
+            for (int e = tid; e < ns * n; e += nt) s.F[e] = Ft[e];
+        }
+        for (int i = tid; i < n; i += nt) s.tau[i] = i < ns ? s.xn[i] : p.cur_u[tb * nc + (i - ns)];
+        __syncthreads();
+        if (cost) {
+            const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+            for (int i = tid; i < n; i += nt) {
+                real r = 0;
+                for (int j = 0; j < n; ++j) r += s.Q[i * n + j] * s.tau[j];
+                ca += (real)0.5 * s.tau[i] * r + ct[i] * s.tau[i];
+            }
+        }
+        if (t < T - 1) {
+            const real *ft = p.f ? p.f + (long)t * p.f_st + (long)b * p.f_sb : nullptr;
+            for (int i = tid; i < ns; i += nt) {
+                real r = 0;
+                for (int j = 0; j < n; ++j) r += s.F[i * n + j] * s.tau[j];
+                if (ft) r += ft[i];
+                s.xn2[i] = r;
+            }
+        }
+        __syncthreads();
+        if (t < T - 1)
+            for (int i = tid; i < ns; i += nt) {
+                s.xn[i] = s.xn2[i];
+                if (x) x[((long)(t + 1) * B + b) * ns + i] = s.xn2[i];
+            }
+        __syncthreads();
+    }
+    if (cost) {
+        const real tot = block_sum<real>(ca, s.red);
+        if (tid == 0) cost[b] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// KKT backward, closed-form part (mpc/lqr_step.py:346-404)
+// ---------------------------------------------------------------------------
+template <typename real>
+__global__ void __launch_bounds__(WAVE)
+kkt_grads_kernel(StepParams<real> p, const real *dx, const real *du, const real *dl_dx, const real *dl_du,
+                 real *dC, real *dc, real *dF, real *df, real *dx_init)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem<real> s;
+    s.carve(smem_raw, p.ns, p.nc, blockDim.x);
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T, B = p.B;
+    if (b >= B) return;
+    // costates live in s.xn (lam), s.dxv (dlam); next values in s.xn2 / s.v
+    real *lam = s.xn, *dlam = s.dxv, *lam2 = s.xn2, *dlam2 = s.v;
+    bool have = false;
+    for (int t = T - 1; t >= 0; --t) {
+        const long tb = (long)t * B + b;
+        const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+        const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+        for (int e = tid; e < n * n; e += nt) s.Q[e] = Ct[e];
+        if (have) {
+            const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
+            for (int e = tid; e < ns * n; e += nt) s.F[e] = Ft[e];
+        }
+        for (int i = tid; i < n; i += nt) {
+            s.tau[i] = i < ns ? p.cur_x[tb * ns + i] : p.cur_u[tb * nc + (i - ns)];
+            s.dtau[i] = i < ns ? dx[tb * ns + i] : du[tb * nc + (i - ns)];
+        }
+        __syncthreads();
+        // :346-353  dC_t = -0.5 (dtau tau' + tau dtau'),  dc_t = -dtau
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e - i * n;
+            dC[tb * n * n + e] = (real)-0.5 * (s.dtau[i] * s.tau[j] + s.tau[i] * s.dtau[j]);
+        }
+        for (int i = tid; i < n; i += nt) dc[tb * n + i] = -s.dtau[i];
+        // :355-385 costate recursions (rows 0..ns-1 of C; F_x = first ns columns of F)
+        for (int i = tid; i < ns; i += nt) {
+            real r1 = 0, r2 = 0;
+            for (int j = 0; j < n; ++j) {
+                r1 += s.Q[i * n + j] * s.tau[j];
+                r2 += s.Q[i * n + j] * s.dtau[j];
+            }
+            r1 += ct[i];
+            r2 -= dl_dx[tb * ns + i];
+            if (have)
+                for (int m = 0; m < ns; ++m) {
+                    r1 += s.F[m * n + i] * lam[m];
+                    r2 += s.F[m * n + i] * dlam[m];
+                }
+            lam2[i] = r1;
+            dlam2[i] = r2;
+        }
+        // :387-400 dF_t = -(dlam_{t+1} tau_t' + lam_{t+1} dtau_t'),  df_t = -dlam_{t+1}
+        if (have) {
+            for (int e = tid; e < ns * n; e += nt) {
+                const int i = e / n, j = e - i * n;
+                dF[tb * ns * n + e] = -(dlam[i] * s.tau[j] + lam[i] * s.dtau[j]);
+            }
+            if (df)
+                for (int i = tid; i < ns; i += nt) df[tb * ns + i] = -dlam[i];
+        }
+        __syncthreads();
+        for (int i = tid; i < ns; i += nt) { lam[i] = lam2[i]; dlam[i] = dlam2[i]; }
+        __syncthreads();
+        have = true;
+    }
+    for (int i = tid; i < ns; i += nt) dx_init[(long)b * ns + i] = -dlam[i];   // :404
+}
+
+template <typename real>
+__global__ void kkt_prepare_kernel(long TB, int ns, int nc, const real *dl_dx, const real *dl_du,
+                                   const real *u_star, int bound_mode, real lo_s, real hi_s,
+                                   const real *lo, const real *hi, real *negr, uint8_t *mask)
+{
+    const int n = ns + nc;
+    const long total = TB * n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long tb = e / n;
+        const int i = (int)(e - tb * n);
+        if (i < ns) {
+            negr[e] = -dl_dx[tb * ns + i];                              // mpc/lqr_step.py:316-320, 339
+        } else {
+            const long ui = tb * nc + (i - ns);
+            negr[e] = -dl_du[ui];
+            if (mask) {                                                 // :322-326
+                const real l = bound_mode == MPC_BOUND_SCALAR ? lo_s : lo[ui];
+                const real h = bound_mode == MPC_BOUND_SCALAR ? hi_s : hi[ui];
+                const real u = u_star[ui];
+                mask[ui] = (rabs<real>(u - l) <= (real)1e-8 || rabs<real>(u - h) <= (real)1e-8) ? 1 : 0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// best-iterate select + convergence reductions (mpc/mpc.py:271-285, 299)
+// ---------------------------------------------------------------------------
+template <typename real> struct BitsOf;
+template <> struct BitsOf<float> { using type = unsigned int; };
+template <> struct BitsOf<double> { using type = unsigned long long; };
+
+template <typename real>
+__global__ void select_best_kernel(int B, int T, int ns, int nc, int first, real eps, const real *x,
+                                   const real *u, const real *costs, const real *du_norm, real *bx,
+                                   real *bu, real *bc, real *bd, int *any_improved, real *max_du)
+{
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (b >= B) return;
+    const real cnew = costs[b];
+    const bool take = first || (cnew <= bc[b] + eps);
+    if (take) {
+        for (int e = tid; e < T * ns; e += nt) {
+            const int t = e / ns, i = e - t * ns;
+            bx[((long)t * B + b) * ns + i] = x[((long)t * B + b) * ns + i];
+        }
+        for (int e = tid; e < T * nc; e += nt) {
+            const int t = e / nc, i = e - t * nc;
+            bu[((long)t * B + b) * nc + i] = u[((long)t * B + b) * nc + i];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (take) {
+            bc[b] = cnew;
+            bd[b] = du_norm[b];
+            if (!first && any_improved) atomicOr(any_improved, 1);
+        }
+        if (max_du) {
+            // non-negative floats order like their bit patterns; NaN sorts above everything
+            using bits = typename BitsOf<real>::type;
+            real d = du_norm[b];
+            if (d < 0) d = 0;
+            bits v;
+            __builtin_memcpy(&v, &d, sizeof(bits));
+            atomicMax(reinterpret_cast<bits *>(max_du), v);
+        }
+    }
+}
+
+inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error((std::string(what) + ": " + hipGetErrorString(e)).c_str());
+        return MPC_E_LAUNCH;
+    }
+    return MPC_OK;
+}
+
+}  // namespace
+
+size_t generic_lds_bytes(int ns, int nc, size_t elem)
+{
+    const size_t n = (size_t)ns + nc;
+    size_t cnt = n * n + ns * n + n * ns + (size_t)ns * ns + (size_t)nc * (nc + 1 + ns) + (size_t)nc * ns +
+                 (size_t)nc * (ns + 1) + n + ns + n + n + (size_t)nc * 8 + (size_t)ns * 3 + WAVE;
+    return cnt * elem + (size_t)nc * sizeof(int) + 16;
+}
+
+template <typename real> int launch_step_generic(const StepParams<real> &p, int phase_mask, hipStream_t st)
+{
+    const size_t lds = generic_lds_bytes(p.ns, p.nc, sizeof(real));
+    if (lds > 160 * 1024) { set_last_error("n_state/n_ctrl too large for the LDS-resident generic kernel"); return MPC_E_DIMS; }
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_step_generic_kernel<real>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(lqr_step_generic_kernel<real>, dim3(p.B), dim3(WAVE), lds, st, p, phase_mask);
+    return check_launch("lqr_step_generic_kernel");
+}
+
+template <typename real>
+int launch_pnqp(int B, int n, const real *H, const real *q, const real *lo, const real *hi, const real *x0,
+                int n_iter, real *x, uint8_t *If_out, int *iters, int *status, real *Hfree, hipStream_t st)
+{
+    const size_t lds = ((size_t)n * (n + 1) + 7 * (size_t)n) * sizeof(real) + (size_t)n * sizeof(int) + 16;
+    if (lds > 160 * 1024) { set_last_error("pnqp: n too large for LDS"); return MPC_E_DIMS; }
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pnqp_kernel<real>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int threads = n <= 32 ? 64 : (n <= 64 ? 128 : 256);
+    hipLaunchKernelGGL(pnqp_kernel<real>, dim3(B), dim3(threads), lds, st, B, n, H, q, lo, hi, x0, n_iter, x,
+                       If_out, iters, status, Hfree);
+    return check_launch("pnqp_kernel");
+}
+
+template <typename real> int launch_traj_cost(const StepParams<real> &p, real *x, real *cost, hipStream_t st)
+{
+    const size_t lds = generic_lds_bytes(p.ns, p.nc, sizeof(real));
+    if (lds > 160 * 1024) { set_last_error("traj_cost: dims too large"); return MPC_E_DIMS; }
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&traj_cost_kernel<real>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(traj_cost_kernel<real>, dim3(p.B), dim3(WAVE), lds, st, p, x, cost);
+    return check_launch("traj_cost_kernel");
+}
+
+template <typename real>
+int launch_kkt_grads(const StepParams<real> &p, const real *dx, const real *du, const real *dl_dx,
+                     const real *dl_du, real *dC, real *dc, real *dF, real *df, real *dx_init, hipStream_t st)
+{
+    const size_t lds = generic_lds_bytes(p.ns, p.nc, sizeof(real));
+    if (lds > 160 * 1024) { set_last_error("kkt_grads: dims too large"); return MPC_E_DIMS; }
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_grads_kernel<real>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kkt_grads_kernel<real>, dim3(p.B), dim3(WAVE), lds, st, p, dx, du, dl_dx, dl_du, dC, dc,
+                       dF, df, dx_init);
+    return check_launch("kkt_grads_kernel");
+}
+
+template <typename real>
+int launch_kkt_prepare(int B, int T, int ns, int nc, const real *dl_dx, const real *dl_du, const real *u_star,
+                       int bound_mode, real lo_s, real hi_s, const real *lo, const real *hi, real *negr,
+                       uint8_t *mask, hipStream_t st)
+{
+    const long TB = (long)T * B;
+    const long total = TB * (ns + nc);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kkt_prepare_kernel<real>, dim3(blocks), dim3(256), 0, st, TB, ns, nc, dl_dx, dl_du, u_star,
+                       bound_mode, lo_s, hi_s, lo, hi, negr, mask);
+    return check_launch("kkt_prepare_kernel");
+}
+
+template <typename real>
+int launch_select_best(int B, int T, int ns, int nc, int first, real eps, const real *x, const real *u,
+                       const real *costs, const real *du_norm, real *bx, real *bu, real *bc, real *bd,
+                       int *any_improved, real *max_du, hipStream_t st)
+{
+    if (any_improved) (void)hipMemsetAsync(any_improved, 0, sizeof(int), st);
+    if (max_du) (void)hipMemsetAsync(max_du, 0, sizeof(real), st);
+    hipLaunchKernelGGL(select_best_kernel<real>, dim3(B), dim3(WAVE), 0, st, B, T, ns, nc, first, eps, x, u, costs,
+                       du_norm, bx, bu, bc, bd, any_improved, max_du);
+    return check_launch("select_best_kernel");
+}
+
+#define INSTANTIATE(real)                                                                                     \
+    template int launch_step_generic<real>(const StepParams<real> &, int, hipStream_t);                        \
+    template int launch_pnqp<real>(int, int, const real *, const real *, const real *, const real *,          \
+                                   const real *, int, real *, uint8_t *, int *, int *, real *, hipStream_t);  \
+    template int launch_traj_cost<real>(const StepParams<real> &, real *, real *, hipStream_t);                \
+    template int launch_kkt_grads<real>(const StepParams<real> &, const real *, const real *, const real *,   \
+                                        const real *, real *, real *, real *, real *, real *, hipStream_t);   \
+    template int launch_kkt_prepare<real>(int, int, int, int, const real *, const real *, const real *, int,   \
+                                          real, real, const real *, const real *, real *, uint8_t *,          \
+                                          hipStream_t);                                                       \
+    template int launch_select_best<real>(int, int, int, int, int, real, const real *, const real *,          \
+                                          const real *, const real *, real *, real *, real *, real *, int *,  \
+                                          real *, hipStream_t);
+INSTANTIATE(float)
+INSTANTIATE(double)
+
+}  // namespace mpclqr

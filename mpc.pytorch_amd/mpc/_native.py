@@ -1,0 +1,417 @@
+"""ctypes binding of libmpc_lqr_hip.so (C ABI: include/mpc_lqr.h) + the tensor-level backend.
+
+torch is used here for device memory and the current HIP stream only; every
+computation on the LQR hot path happens inside the shared library's gfx950
+kernels.  There is NO CPU / eager fallback: if the library is missing or the
+tensors are not on a ROCm device the calls raise.
+"""
+import ctypes
+import math
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libmpc_lqr_hip.so"
+
+MPC_F32, MPC_F64 = 0, 1
+BOUND_NONE, BOUND_SCALAR, BOUND_TENSOR = 0, 1, 2
+ST_PNQP_UNCONVERGED, ST_NONFINITE = 1, 2
+IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA16 = 0, 1, 2
+
+_vp, _i32, _i64, _f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+
+
+class Problem(ctypes.Structure):
+    _fields_ = [("B", _i32), ("T", _i32), ("ns", _i32), ("nc", _i32), ("dtype", _i32), ("_pad", _i32),
+                ("x_init", _vp),
+                ("C", _vp), ("C_st", _i64), ("C_sb", _i64),
+                ("c", _vp), ("c_st", _i64), ("c_sb", _i64),
+                ("F", _vp), ("F_st", _i64), ("F_sb", _i64),
+                ("f", _vp), ("f_st", _i64), ("f_sb", _i64),
+                ("cur_x", _vp), ("cur_u", _vp)]
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("bound_mode", _i32), ("max_linesearch_iter", _i32), ("lo_s", _f64), ("hi_s", _f64),
+                ("lo", _vp), ("hi", _vp), ("zero_mask", _vp), ("delta_u", _f64),
+                ("linesearch_decay", _f64), ("pnqp_iter", _i32), ("_pad", _i32)]
+
+
+class Outputs(ctypes.Structure):
+    _fields_ = [("new_x", _vp), ("new_u", _vp), ("costs", _vp), ("old_costs", _vp), ("full_du_norm", _vp),
+                ("alpha_du_norm", _vp), ("alphas", _vp), ("qp_iters", _vp), ("status", _vp),
+                ("K", _vp), ("k", _vp)]
+
+
+EXPORTS = ("mpc_lqr_abi_version", "mpc_lqr_build_info", "mpc_lqr_last_error", "mpc_lqr_workspace_bytes",
+           "mpc_lqr_step", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_lqr_kkt_prepare",
+           "mpc_pnqp", "mpc_traj_cost", "mpc_select_best")
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.environ.get("MPC_LQR_HIP_LIB", os.path.join(_HERE, LIB_NAME))
+
+
+def load():
+    """dlopen the HIP library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise NativeLibraryMissing(
+            "%s not found at %s -- build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback." % (LIB_NAME, path))
+    L = ctypes.CDLL(path)
+    for name in EXPORTS:
+        getattr(L, name)   # AttributeError if the ABI is incomplete
+    L.mpc_lqr_build_info.restype = ctypes.c_char_p
+    L.mpc_lqr_last_error.restype = ctypes.c_char_p
+    L.mpc_lqr_workspace_bytes.restype = _i64
+    L.mpc_lqr_workspace_bytes.argtypes = [ctypes.POINTER(Problem)]
+    PP, OP, UP = ctypes.POINTER(Problem), ctypes.POINTER(Options), ctypes.POINTER(Outputs)
+    L.mpc_lqr_step.argtypes = [PP, OP, UP, _vp, _i64, ctypes.c_int, _vp]
+    L.mpc_lqr_sweep.argtypes = [PP, OP, UP, _vp]
+    L.mpc_lqr_rollout.argtypes = [PP, OP, UP, _vp, _vp]
+    L.mpc_lqr_kkt_grads.argtypes = [PP] + [_vp] * 10
+    L.mpc_lqr_kkt_prepare.argtypes = [ctypes.c_int] * 5 + [_vp, _vp, _vp, OP, _vp, _vp, _vp]
+    L.mpc_pnqp.argtypes = [ctypes.c_int] * 3 + [_vp] * 5 + [ctypes.c_int] + [_vp] * 6
+    L.mpc_traj_cost.argtypes = [PP, _vp, _vp, _vp]
+    L.mpc_select_best.argtypes = [ctypes.c_int] * 6 + [_f64] + [_vp] * 11
+    if L.mpc_lqr_abi_version() != 1:
+        raise RuntimeError("libmpc_lqr_hip ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, load().mpc_lqr_last_error().decode()))
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return MPC_F32
+    if t.dtype == torch.float64:
+        return MPC_F64
+    raise TypeError("the LQR kernels take float32 or float64 tensors, got %s" % t.dtype)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _require_device(*ts):
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "mpc (MI355X build): the LQR step runs only on ROCm device tensors; got a %s tensor. "
+                "There is no CPU fallback -- move the problem to the GPU." % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("all tensors of one LQR problem must live on the same device")
+    return dev
+
+
+def _block_strided(t, inner_dims):
+    """Return (tensor, stride_T, stride_B) with the trailing `inner_dims` dims densely packed.
+    Stride-0 (expanded) leading axes are kept as they are -- the kernels honour them."""
+    inner = t.shape[-inner_dims:]
+    want = []
+    acc = 1
+    for d in reversed(inner):
+        want.append(acc)
+        acc *= d
+    want = tuple(reversed(want))
+    ok = all(t.shape[-inner_dims + i] == 1 or t.stride()[-inner_dims + i] == want[i] for i in range(inner_dims))
+    if not ok:
+        t = t.contiguous()
+    return t, t.stride(0), t.stride(1)
+
+
+class StepOptions:
+    """The LQRStep keyword arguments that reach the kernels (mpc/lqr_step.py:22-38 of the reference)."""
+
+    def __init__(self, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None, linesearch_decay=0.2,
+                 max_linesearch_iter=10, pnqp_iter=20):
+        assert (u_lower is None) == (u_upper is None)
+        self.u_lower, self.u_upper, self.u_zero_I = u_lower, u_upper, u_zero_I
+        self.delta_u, self.linesearch_decay = delta_u, linesearch_decay
+        self.max_linesearch_iter, self.pnqp_iter = max_linesearch_iter, pnqp_iter
+
+    def to_struct(self, T, B, nc, like):
+        """-> (Options, keepalive list)"""
+        keep = []
+        o = Options()
+        o.max_linesearch_iter = int(self.max_linesearch_iter)
+        o.linesearch_decay = float(self.linesearch_decay)
+        o.delta_u = float("nan") if self.delta_u is None else float(self.delta_u)
+        o.pnqp_iter = int(self.pnqp_iter)
+        lo, hi = self.u_lower, self.u_upper
+        if lo is None:
+            o.bound_mode = BOUND_NONE
+        elif isinstance(lo, (float, int)) and isinstance(hi, (float, int)):
+            o.bound_mode, o.lo_s, o.hi_s = BOUND_SCALAR, float(lo), float(hi)
+        else:
+            def full(v):
+                if not torch.is_tensor(v):
+                    v = torch.full((1,), float(v))
+                v = v.detach().to(device=like.device, dtype=like.dtype)
+                return v.expand(T, B, nc).contiguous()
+            lo_t, hi_t = full(lo), full(hi)
+            keep += [lo_t, hi_t]
+            o.bound_mode, o.lo, o.hi = BOUND_TENSOR, lo_t.data_ptr(), hi_t.data_ptr()
+        if self.u_zero_I is not None:
+            m = self.u_zero_I.detach().to(device=like.device)
+            m = (m != 0).to(torch.uint8).expand(T, B, nc).contiguous()
+            keep.append(m)
+            o.zero_mask = m.data_ptr()
+        return o, keep
+
+
+class HipBackend:
+    """Tensor-level front of the C ABI.  All methods enqueue on torch's current stream."""
+
+    name = "hip-gfx950"
+
+    # -- helpers -------------------------------------------------------------------------------
+    @staticmethod
+    def _problem(x_init, C, c, F, f, cur_x, cur_u):
+        T, B, n = C.shape[0], C.shape[1], C.shape[2]
+        ns = x_init.shape[1]
+        nc = n - ns
+        keep = []
+        p = Problem()
+        p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, _dtype_code(C)
+        xi = x_init.detach().contiguous(); keep.append(xi); p.x_init = xi.data_ptr()
+        Cc, p.C_st, p.C_sb = _block_strided(C.detach(), 2); keep.append(Cc); p.C = Cc.data_ptr()
+        cc, p.c_st, p.c_sb = _block_strided(c.detach(), 1); keep.append(cc); p.c = cc.data_ptr()
+        if T > 1:
+            Fc, p.F_st, p.F_sb = _block_strided(F.detach(), 2); keep.append(Fc); p.F = Fc.data_ptr()
+        if f is not None and f.numel() > 0:
+            fc, p.f_st, p.f_sb = _block_strided(f.detach(), 1); keep.append(fc); p.f = fc.data_ptr()
+        if cur_x is not None:
+            cx = cur_x.detach().contiguous(); keep.append(cx); p.cur_x = cx.data_ptr()
+        if cur_u is not None:
+            cu = cur_u.detach().contiguous(); keep.append(cu); p.cur_u = cu.data_ptr()
+        return p, keep
+
+    @staticmethod
+    def _check_same(C, *others):
+        for t in others:
+            if t is not None and t.numel() > 0 and (t.dtype != C.dtype or t.device != C.device):
+                raise TypeError("all tensors of one LQR problem must share dtype and device")
+
+    # -- (1) LQRStepFn.forward ------------------------------------------------------------------
+    def lqr_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, want_gains=False, impl=IMPL_AUTO,
+                 rollout_problem=None):
+        """c_back + Riccati sweep + line-searched rollout.  Returns a dict of device tensors.
+
+        rollout_problem: optional (C, c, F, f) the rollout/true cost should use when they differ
+        from the sweep's (mpc/lqr_step.py:218-232 reads true_dynamics / true_cost)."""
+        dev = _require_device(x_init, C, c, F, cur_x, cur_u)
+        self._check_same(C, x_init, c, F, f, cur_x, cur_u)
+        L = load()
+        T, B, n = C.shape[0], C.shape[1], C.shape[2]
+        ns = x_init.shape[1]
+        nc = n - ns
+        p, keep = self._problem(x_init, C, c, F, f, cur_x, cur_u)
+        o, keep_o = opts.to_struct(T, B, nc, C)
+        kw = dict(device=dev, dtype=C.dtype)
+        res = dict(new_x=torch.empty(T, B, ns, **kw), new_u=torch.empty(T, B, nc, **kw),
+                   costs=torch.empty(B, **kw), old_costs=torch.empty(B, **kw),
+                   full_du_norm=torch.empty(B, **kw), alpha_du_norm=torch.empty(B, **kw),
+                   alphas=torch.empty(B, **kw),
+                   qp_iters=torch.zeros(B, device=dev, dtype=torch.int32),
+                   status=torch.zeros(B, device=dev, dtype=torch.int32))
+        out = Outputs()
+        for k in ("new_x", "new_u", "costs", "old_costs", "full_du_norm", "alpha_du_norm", "alphas",
+                  "qp_iters", "status"):
+            setattr(out, k, res[k].data_ptr())
+        split = rollout_problem is not None
+        ws = None
+        if want_gains or split:
+            res["K"] = torch.empty(T, B, nc, ns, **kw)
+            res["k"] = torch.empty(T, B, nc, **kw)
+            out.K, out.k = res["K"].data_ptr(), res["k"].data_ptr()
+        st = _stream(dev)
+        if split:
+            _check(L.mpc_lqr_sweep(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), st), "mpc_lqr_sweep")
+            rC, rc_, rF, rf = rollout_problem
+            p2, keep2 = self._problem(x_init, rC, rc_, rF, rf, cur_x, cur_u)
+            _check(L.mpc_lqr_rollout(ctypes.byref(p2), ctypes.byref(o), ctypes.byref(out), None, st),
+                   "mpc_lqr_rollout")
+            keep += keep2
+        else:
+            nbytes = 0
+            if not want_gains:
+                nbytes = int(L.mpc_lqr_workspace_bytes(ctypes.byref(p)))
+                ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            _check(L.mpc_lqr_step(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), _ptr(ws), nbytes,
+                                  int(impl), st), "mpc_lqr_step")
+        res["_keep"] = (keep, keep_o, ws)
+        return res
+
+    def lqr_sweep(self, x_init, C, c, F, cur_x, cur_u, opts):
+        """c_back + lqr_backward only -> dict(K, k, old_costs, qp_iters, status)."""
+        dev = _require_device(x_init, C, c, F, cur_x, cur_u)
+        self._check_same(C, x_init, c, F, cur_x, cur_u)
+        L = load()
+        T, B, n = C.shape[0], C.shape[1], C.shape[2]
+        ns = x_init.shape[1]
+        nc = n - ns
+        p, keep = self._problem(x_init, C, c, F, None, cur_x, cur_u)
+        o, keep_o = opts.to_struct(T, B, nc, C)
+        kw = dict(device=dev, dtype=C.dtype)
+        res = dict(K=torch.empty(T, B, nc, ns, **kw), k=torch.empty(T, B, nc, **kw),
+                   old_costs=torch.empty(B, **kw), qp_iters=torch.zeros(B, device=dev, dtype=torch.int32),
+                   status=torch.zeros(B, device=dev, dtype=torch.int32))
+        out = Outputs()
+        for k in res:
+            setattr(out, k, res[k].data_ptr())
+        _check(L.mpc_lqr_sweep(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), _stream(dev)), "mpc_lqr_sweep")
+        res["_keep"] = (keep, keep_o)
+        return res
+
+    # -- (4) LQRStepFn.backward -----------------------------------------------------------------
+    def kkt_backward(self, C, c, F, f, x_star, u_star, dl_dx, dl_du, opts, impl=IMPL_AUTO):
+        """dx_init, dC, dc, dF, df of mpc/lqr_step.py:312-407 (reference), all on device."""
+        dev = _require_device(C, c, F, x_star, u_star, dl_dx, dl_du)
+        L = load()
+        T, B, n = C.shape[0], C.shape[1], C.shape[2]
+        ns = x_star.shape[2]
+        nc = n - ns
+        kw = dict(device=dev, dtype=C.dtype)
+        code = _dtype_code(C)
+        st = _stream(dev)
+        dl_dx = dl_dx.detach().to(**kw).contiguous()
+        dl_du = dl_du.detach().to(**kw).contiguous()
+        x_star = x_star.detach().contiguous()
+        u_star = u_star.detach().contiguous()
+        o, keep_o = opts.to_struct(T, B, nc, C)
+        negr = torch.empty(T, B, n, **kw)
+        mask = None
+        if o.bound_mode != BOUND_NONE:
+            mask = torch.empty(T, B, nc, device=dev, dtype=torch.uint8)
+        _check(L.mpc_lqr_kkt_prepare(code, B, T, ns, nc, dl_dx.data_ptr(), dl_du.data_ptr(), u_star.data_ptr(),
+                                     ctypes.byref(o), negr.data_ptr(), _ptr(mask), st), "mpc_lqr_kkt_prepare")
+        # nested solve of :328-340: one LQR step on (C, -r, F, f=None) from the zero nominal with
+        # the active controls pinned; defaults linesearch_decay=0.2, max_linesearch_iter=10.
+        zx = torch.zeros(T, B, ns, **kw)
+        zu = torch.zeros(T, B, nc, **kw)
+        z0 = torch.zeros(B, ns, **kw)
+        inner = StepOptions(u_zero_I=mask)
+        sol = self.lqr_step(z0, C, negr, F, None, zx, zu, inner, impl=impl)
+        p, keep = self._problem(z0, C, c, F, f, x_star, u_star)
+        has_f = f is not None and f.numel() > 0
+        dC = torch.empty(T, B, n, n, **kw)
+        dc = torch.empty(T, B, n, **kw)
+        dF = torch.zeros(F.shape, **kw)
+        df = torch.empty(T - 1, B, ns, **kw) if has_f else None
+        dx_init = torch.empty(B, ns, **kw)
+        _check(L.mpc_lqr_kkt_grads(ctypes.byref(p), sol["new_x"].data_ptr(), sol["new_u"].data_ptr(),
+                                   dl_dx.data_ptr(), dl_du.data_ptr(), dC.data_ptr(), dc.data_ptr(),
+                                   dF.data_ptr(), _ptr(df), dx_init.data_ptr(), st), "mpc_lqr_kkt_grads")
+        return dict(dx_init=dx_init, dC=dC, dc=dc, dF=dF, df=df, dx=sol["new_x"], du=sol["new_u"],
+                    _keep=(keep, keep_o, negr, mask, sol))
+
+    # -- (5) pnqp -------------------------------------------------------------------------------
+    def pnqp(self, H, q, lower, upper, x_init=None, n_iter=20, want_Hfree=True):
+        dev = _require_device(H, q)
+        L = load()
+        B, n = H.shape[0], H.shape[1]
+        kw = dict(device=dev, dtype=H.dtype)
+        H = H.detach().contiguous(); q = q.detach().contiguous()
+
+        def full(v):
+            if not torch.is_tensor(v):
+                v = torch.full((1,), float(v))
+            return v.detach().to(**kw).expand(B, n).contiguous()
+        lo, hi = full(lower), full(upper)
+        x0 = None if x_init is None else x_init.detach().to(**kw).contiguous()
+        x = torch.empty(B, n, **kw)
+        If = torch.empty(B, n, device=dev, dtype=torch.uint8)
+        iters = torch.empty(B, device=dev, dtype=torch.int32)
+        status = torch.empty(B, device=dev, dtype=torch.int32)
+        Hfree = torch.empty(B, n, n, **kw) if want_Hfree else None
+        _check(L.mpc_pnqp(_dtype_code(H), B, n, H.data_ptr(), q.data_ptr(), lo.data_ptr(), hi.data_ptr(),
+                          _ptr(x0), int(n_iter), x.data_ptr(), If.data_ptr(), iters.data_ptr(),
+                          status.data_ptr(), _ptr(Hfree), _stream(dev)), "mpc_pnqp")
+        return dict(x=x, If=If, iters=iters, status=status, Hfree=Hfree)
+
+    # -- (6) get_traj / get_cost ----------------------------------------------------------------
+    def traj_cost(self, x_init, u, F, f, C=None, c=None, want_x=True):
+        dev = _require_device(x_init, u, F)
+        L = load()
+        T, B, nc = u.shape
+        ns = x_init.shape[1]
+        kw = dict(device=dev, dtype=u.dtype)
+        want_cost = C is not None
+        if want_cost:
+            p, keep = self._problem(x_init, C, c, F, f, None, u)
+        else:
+            p = Problem()
+            p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, _dtype_code(u)
+            keep = []
+            xi = x_init.detach().contiguous(); keep.append(xi); p.x_init = xi.data_ptr()
+            if T > 1:
+                Fc, p.F_st, p.F_sb = _block_strided(F.detach(), 2); keep.append(Fc); p.F = Fc.data_ptr()
+            if f is not None and f.numel() > 0:
+                fc, p.f_st, p.f_sb = _block_strided(f.detach(), 1); keep.append(fc); p.f = fc.data_ptr()
+            cu = u.detach().contiguous(); keep.append(cu); p.cur_u = cu.data_ptr()
+        x = torch.empty(T, B, ns, **kw) if want_x else None
+        cost = torch.empty(B, **kw) if want_cost else None
+        _check(L.mpc_traj_cost(ctypes.byref(p), _ptr(x), _ptr(cost), _stream(dev)), "mpc_traj_cost")
+        return x, cost
+
+    # -- (7) driver reductions ------------------------------------------------------------------
+    def select_best(self, first, eps, x, u, costs, du_norm, best):
+        """In-place update of best = dict(x,u,costs,full_du_norm); returns the 2-word device flag
+        buffers (any_improved int32[1], max_du real[1]) without synchronising."""
+        dev = _require_device(x, u, costs, du_norm)
+        L = load()
+        T, B, ns = x.shape
+        nc = u.shape[2]
+        any_improved = torch.empty(1, device=dev, dtype=torch.int32)
+        max_du = torch.empty(1, device=dev, dtype=x.dtype)
+        _check(L.mpc_select_best(_dtype_code(x), B, T, ns, nc, int(bool(first)), float(eps),
+                                 x.data_ptr(), u.data_ptr(), costs.data_ptr(), du_norm.data_ptr(),
+                                 best["x"].data_ptr(), best["u"].data_ptr(), best["costs"].data_ptr(),
+                                 best["full_du_norm"].data_ptr(), any_improved.data_ptr(), max_du.data_ptr(),
+                                 _stream(dev)), "mpc_select_best")
+        return any_improved, max_du
+
+
+_backend = None
+
+
+def backend():
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def set_backend_for_testing(obj):
+    """TEST HOOK ONLY.  tests/ use this to drive the host-side logic (MPC.forward, the autograd
+    wiring) on a CPU-only box with an oracle-backed stand-in.  The shipped package never calls it
+    and has no CPU implementation of its own."""
+    global _backend
+    prev = _backend
+    _backend = obj
+    return prev

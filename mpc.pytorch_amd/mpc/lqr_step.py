@@ -1,0 +1,184 @@
+"""`LQRStep(...)` -- one box-constrained LQR solve in delta space, as an autograd.Function.
+
+Host-side mirror of the reference's mpc/lqr_step.py:22-409 (same factory signature, same return
+tuples, same gradient convention).  What differs is where the work happens:
+
+  forward   c_back + Riccati sweep + pnqp + line-searched rollout  -> ONE kernel launch
+            (mpc_lqr_step; reference: ~4,000 ATen ops and several host syncs)
+  backward  KKT system = one more LQR step on (C, -r, F) + a costate / outer-product kernel
+            (mpc_lqr_kkt_prepare, mpc_lqr_step, mpc_lqr_kkt_grads)
+
+Module-valued `true_dynamics` / `true_cost` (iLQR on a simulator) keep the sweep on the kernel and
+run the rollout as a per-timestep loop of device ops, because the user's module has to be called.
+"""
+from collections import namedtuple
+
+import torch
+from torch.autograd import Function
+
+from . import _native
+from ._native import StepOptions
+
+LqrBackOut = namedtuple("lqrBackOut", "n_total_qp_iter")
+LqrForOut = namedtuple("lqrForOut", "objs full_du_norm alpha_du_norm mean_alphas costs")
+
+
+def _is_empty(f):
+    return f is None or f.numel() == 0
+
+
+def _same_storage(a, b):
+    if a is None or b is None:
+        return a is None and (b is None or b.numel() == 0)
+    return a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
+
+
+def _bound_at(v, t):
+    return v if isinstance(v, (float, int)) else v[t]
+
+
+def _module_rollout(n_state, n_ctrl, T, x_init, K, k, cur_x, cur_u, old_cost, true_cost, true_dynamics,
+                    opts):
+    """Rollout + per-problem line search when the dynamics or the cost is an nn.Module
+    (reference mpc/lqr_step.py:164-261).  Device ops only; the per-element step size is a [B,1]
+    column instead of the reference's B x B diag matrix (:192)."""
+    from . import mpc as _mpc
+    B = x_init.shape[0]
+    alpha = torch.ones(B, 1, dtype=x_init.dtype, device=x_init.device)
+    lin = isinstance(true_dynamics, _mpc.LinDx)
+    quad = isinstance(true_cost, _mpc.QuadCost)
+    full_du_norm = None
+    new_x = new_u = cost = None
+    with torch.no_grad():
+        for it in range(opts.max_linesearch_iter):
+            xs, us, objs = [x_init], [], []
+            dx = torch.zeros_like(x_init)
+            for t in range(T):
+                ut = cur_u[t]
+                nu = torch.einsum("bij,bj->bi", K[t], dx) + ut + alpha * k[t]
+                if opts.u_zero_I is not None:
+                    nu = nu.masked_fill(opts.u_zero_I[t].bool(), 0.0)
+                if opts.u_lower is not None:
+                    lo, hi = _bound_at(opts.u_lower, t), _bound_at(opts.u_upper, t)
+                    if opts.delta_u is not None:
+                        lo = torch.maximum(ut - opts.delta_u, torch.as_tensor(lo, dtype=ut.dtype, device=ut.device))
+                        hi = torch.minimum(ut + opts.delta_u, torch.as_tensor(hi, dtype=ut.dtype, device=ut.device))
+                    nu = torch.min(torch.max(nu, torch.as_tensor(lo, dtype=nu.dtype, device=nu.device)),
+                                   torch.as_tensor(hi, dtype=nu.dtype, device=nu.device))
+                us.append(nu)
+                tau = torch.cat((xs[t], nu), 1)
+                if t < T - 1:
+                    if lin:
+                        nx = torch.einsum("bij,bj->bi", true_dynamics.F[t].detach(), tau)
+                        if not _is_empty(true_dynamics.f):
+                            nx = nx + true_dynamics.f[t].detach()
+                    else:
+                        nx = true_dynamics(xs[t], nu).detach()
+                    xs.append(nx)
+                    dx = nx - cur_x[t + 1]
+                if quad:
+                    Ct, ct = true_cost.C[t].detach(), true_cost.c[t].detach()
+                    objs.append(0.5 * torch.einsum("bi,bij,bj->b", tau, Ct, tau) + (tau * ct).sum(1))
+                else:
+                    objs.append(true_cost(tau).detach())
+            new_x, new_u = torch.stack(xs), torch.stack(us)
+            cost = torch.stack(objs).sum(0)
+            du_norm = (cur_u - new_u).pow(2).sum((0, 2)).sqrt()
+            if full_du_norm is None:
+                full_du_norm = du_norm
+            worse = cost > old_cost
+            last = it + 1 >= opts.max_linesearch_iter
+            if last or not bool(worse.any()):
+                break
+            alpha = torch.where(worse.unsqueeze(1), alpha * opts.linesearch_decay, alpha)
+    return new_x, new_u, cost, full_du_norm, du_norm, alpha.squeeze(1)
+
+
+def LQRStep(n_state,
+            n_ctrl,
+            T,
+            u_lower=None,
+            u_upper=None,
+            u_zero_I=None,
+            delta_u=None,
+            linesearch_decay=0.2,
+            max_linesearch_iter=10,
+            true_cost=None,
+            true_dynamics=None,
+            delta_space=True,
+            current_x=None,
+            current_u=None,
+            verbose=0,
+            back_eps=1e-3,
+            no_op_forward=False):
+    """A single step of the box-constrained iLQR solver.
+
+    Required: n_state, n_ctrl, T.  The returned callable takes (x_init [B,ns], C [T,B,n,n],
+    c [T,B,n], F [T-1,B,ns,n], f [T-1,B,ns] or an EMPTY tensor) and returns
+    (new_x, new_u, n_total_qp_iter, costs, full_du_norm, mean_alphas), or (current_x, current_u)
+    when `no_op_forward` (used to attach the backward to an already-converged trajectory).
+
+    u_lower / u_upper: python floats or [T, n_batch, n_ctrl] tensors.
+    """
+    opts = StepOptions(u_lower=u_lower, u_upper=u_upper, u_zero_I=u_zero_I, delta_u=delta_u,
+                       linesearch_decay=linesearch_decay, max_linesearch_iter=max_linesearch_iter)
+
+    def solve(x_init, C, c, F, f):
+        from . import mpc as _mpc
+        be = _native.backend()
+        f_in = None if _is_empty(f) else f
+        lin = true_dynamics is None or isinstance(true_dynamics, _mpc.LinDx)
+        quad = true_cost is None or isinstance(true_cost, _mpc.QuadCost)
+        # Currently unimplemented in the reference as well (mpc/lqr_step.py:195):
+        assert not ((delta_u is not None) and (u_lower is None))
+        if lin and quad:
+            rp = None
+            tC, tc = (C, c) if true_cost is None else (true_cost.C, true_cost.c)
+            tF, tf = (F, f_in) if true_dynamics is None else (true_dynamics.F, true_dynamics.f)
+            if not (_same_storage(tC, C) and _same_storage(tc, c) and _same_storage(tF, F)
+                    and _same_storage(tf, f_in)):
+                rp = (tC, tc, tF, tf)     # true cost / dynamics differ from the quadratic model
+            r = be.lqr_step(x_init, C, c, F, f_in, current_x, current_u, opts, rollout_problem=rp)
+            return r["new_x"], r["new_u"], r["qp_iters"], r["costs"], r["full_du_norm"], r["alphas"]
+        sw = be.lqr_sweep(x_init.detach(), C, c, F, current_x.detach(), current_u.detach(), opts)
+        from . import util as _util
+        old_cost = _util.get_cost(T, current_u.detach(), true_cost, true_dynamics, x=current_x.detach())
+        nx, nu, cost, fdn, _, alphas = _module_rollout(
+            n_state, n_ctrl, T, x_init.detach(), sw["K"], sw["k"], current_x.detach(), current_u.detach(),
+            old_cost, true_cost, true_dynamics, opts)
+        return nx, nu, sw["qp_iters"], cost, fdn, alphas
+
+    class LQRStepFn(Function):
+        @staticmethod
+        def forward(ctx, x_init, C, c, F, f=None):
+            if f is None:
+                f = torch.empty(0)
+            if no_op_forward:
+                ctx.save_for_backward(x_init, C, c, F, f, current_x, current_u)
+                ctx.current_x, ctx.current_u = current_x, current_u
+                return current_x, current_u
+            if not delta_space:
+                assert False      # unimplemented upstream too (mpc/lqr_step.py:297-298)
+            assert current_x is not None
+            assert current_u is not None
+            ctx.current_x, ctx.current_u = current_x, current_u
+            new_x, new_u, qp_iters, costs, full_du_norm, alphas = solve(x_init, C, c, F, f)
+            ctx.save_for_backward(x_init, C, c, F, f, new_x, new_u)
+            # the reference hands back a CPU float tensor here (mpc/lqr_step.py:308)
+            n_qp = float(qp_iters.max().item()) if u_lower is not None else 0.0
+            return new_x, new_u, torch.Tensor([n_qp]), costs, full_du_norm, alphas.mean()
+
+        @staticmethod
+        def backward(ctx, dl_dx, dl_du, *unused):
+            x_init, C, c, F, f, new_x, new_u = ctx.saved_tensors
+            if dl_dx is None:
+                dl_dx = torch.zeros_like(new_x)
+            if dl_du is None:
+                dl_du = torch.zeros_like(new_u)
+            g = _native.backend().kkt_backward(
+                C, c, F, None if _is_empty(f) else f, new_x, new_u, dl_dx, dl_du,
+                StepOptions(u_lower=u_lower, u_upper=u_upper))
+            df = g["df"] if g["df"] is not None else torch.Tensor()
+            return g["dx_init"], g["dC"], g["dc"], g["dF"], df
+
+    return LQRStepFn.apply

@@ -1,0 +1,302 @@
+"""`MPC` -- the differentiable box-constrained iLQR driver, MI355X build.
+
+API mirror of the reference's mpc/mpc.py (`MPC`, `QuadCost`, `LinDx`, `GradMethods`): same
+constructor keywords, same `(x, u, costs)` return, same convergence / best-iterate rules
+(mpc/mpc.py:245-337).  The per-iteration work is the `mpc_lqr_step` kernel; the bookkeeping the
+reference does with a Python loop over the batch (best-iterate copy, `max(full_du_norm)`,
+mpc/mpc.py:279-285, 299) is the `mpc_select_best` kernel, so one iLQR iteration costs two launches
+and ONE small device->host read.
+"""
+from collections import namedtuple
+from enum import Enum
+
+import torch
+from torch.nn import Module
+
+from . import _native, util
+from ._native import StepOptions
+from .lqr_step import LQRStep
+
+QuadCost = namedtuple("QuadCost", "C c")
+LinDx = namedtuple("LinDx", "F f")
+QuadCost.__new__.__defaults__ = (None,) * len(QuadCost._fields)
+LinDx.__new__.__defaults__ = (None,) * len(LinDx._fields)
+
+
+class GradMethods(Enum):
+    AUTO_DIFF = 1
+    FINITE_DIFF = 2
+    ANALYTIC = 3
+    ANALYTIC_CHECK = 4
+
+
+class UnconvergedError(AssertionError):
+    """Raised where the reference does a bare `assert False` (mpc/mpc.py:321-324): some problem did
+    not reach a fixed point and exit_unconverged=True."""
+
+
+class MPC(Module):
+    """A differentiable box-constrained iLQR solver.
+
+        min_{tau={x,u}} sum_t 0.5 tau_t^T C_t tau_t + c_t^T tau_t
+                        s.t. x_{t+1} = f(x_t, u_t),  x_0 = x_init,  u_lower <= u <= u_upper
+
+    Constructor arguments are those of the reference (mpc/mpc.py:123-144): n_state, n_ctrl, T,
+    u_lower/u_upper (floats or [T,B,n_ctrl]), u_zero_I, u_init, lqr_iter, grad_method, delta_u,
+    verbose, eps, back_eps, n_batch, linesearch_decay, max_linesearch_iter, exit_unconverged,
+    detach_unconverged, backprop, slew_rate_penalty, prev_ctrl, not_improved_lim, best_cost_eps.
+    """
+
+    def __init__(self, n_state, n_ctrl, T, u_lower=None, u_upper=None, u_zero_I=None, u_init=None,
+                 lqr_iter=10, grad_method=GradMethods.ANALYTIC, delta_u=None, verbose=0, eps=1e-7,
+                 back_eps=1e-7, n_batch=None, linesearch_decay=0.2, max_linesearch_iter=10,
+                 exit_unconverged=True, detach_unconverged=True, backprop=True, slew_rate_penalty=None,
+                 prev_ctrl=None, not_improved_lim=5, best_cost_eps=1e-4):
+        super().__init__()
+        assert (u_lower is None) == (u_upper is None)
+        assert max_linesearch_iter > 0
+        self.n_state, self.n_ctrl, self.T = n_state, n_ctrl, T
+        self.u_lower = u_lower if isinstance(u_lower, float) else util.detach_maybe(u_lower)
+        self.u_upper = u_upper if isinstance(u_upper, float) else util.detach_maybe(u_upper)
+        self.u_zero_I = util.detach_maybe(u_zero_I)
+        self.u_init = util.detach_maybe(u_init)
+        self.lqr_iter = lqr_iter
+        self.grad_method = grad_method
+        self.delta_u = delta_u
+        self.verbose = verbose
+        self.eps = eps
+        self.back_eps = back_eps
+        self.n_batch = n_batch
+        self.linesearch_decay = linesearch_decay
+        self.max_linesearch_iter = max_linesearch_iter
+        self.exit_unconverged = exit_unconverged
+        self.detach_unconverged = detach_unconverged
+        self.backprop = backprop
+        self.not_improved_lim = not_improved_lim
+        self.best_cost_eps = best_cost_eps
+        self.slew_rate_penalty = slew_rate_penalty
+        self.prev_ctrl = prev_ctrl
+
+    # ------------------------------------------------------------------------------------------
+    def _expand_cost(self, cost, n_batch):
+        """[n,n] / [T,n,n] costs are broadcast to [T,B,n,n] as stride-0 views (never copied: the
+        kernels read them through their strides, so a shared cost matrix stays L2-resident)."""
+        C, c = cost
+        n = self.n_state + self.n_ctrl
+        if C.ndimension() == 2:
+            C = C.unsqueeze(0).unsqueeze(0).expand(self.T, n_batch, n, n)
+        elif C.ndimension() == 3:
+            C = C.unsqueeze(1).expand(self.T, n_batch, n, n)
+        if c.ndimension() == 1:
+            c = c.unsqueeze(0).unsqueeze(0).expand(self.T, n_batch, n)
+        elif c.ndimension() == 2:
+            c = c.unsqueeze(1).expand(self.T, n_batch, n)
+        if C.ndimension() != 4 or c.ndimension() != 3:
+            raise ValueError("MPC Error: Unexpected QuadCost shape.")
+        return QuadCost(C, c)
+
+    def forward(self, x_init, cost, dx):
+        assert isinstance(cost, (QuadCost, Module)) or callable(cost)
+        assert isinstance(dx, (LinDx, Module)) or callable(dx)
+        if self.n_batch is not None:
+            n_batch = self.n_batch
+        elif isinstance(cost, QuadCost) and cost.C.ndimension() == 4:
+            n_batch = cost.C.size(1)
+        else:
+            raise ValueError("MPC Error: Could not infer batch size, pass in as n_batch")
+        if isinstance(cost, QuadCost):
+            cost = self._expand_cost(cost, n_batch)
+        assert x_init.ndimension() == 2 and x_init.size(0) == n_batch
+
+        T, ns, nc = self.T, self.n_state, self.n_ctrl
+        if self.u_init is None:
+            u = torch.zeros(T, n_batch, nc, dtype=x_init.dtype, device=x_init.device)
+        else:
+            u = self.u_init
+            if u.ndimension() == 2:
+                u = u.unsqueeze(1).expand(T, n_batch, -1).clone()
+            u = u.to(dtype=x_init.dtype, device=x_init.device)
+
+        if self.verbose > 0:
+            print("Initial mean(cost): {:.4e}".format(
+                util.get_cost(T, u, cost, dx, x_init=x_init).mean().item()))
+
+        fast = (isinstance(cost, QuadCost) and isinstance(dx, LinDx) and self.slew_rate_penalty is None)
+        best = None
+        n_not_improved = 0
+        be = _native.backend()
+        for i in range(self.lqr_iter):
+            u = util.detach_maybe(u)
+            x = util.get_traj(T, u, x_init=x_init, dynamics=dx)
+            if isinstance(dx, LinDx):
+                F, f = dx.F, dx.f
+            else:
+                F, f = self.linearize_dynamics(x, util.detach_maybe(u), dx, diff=False)
+            if isinstance(cost, QuadCost):
+                C, c = cost.C, cost.c
+            else:
+                C, c, _ = self.approximate_cost(x, util.detach_maybe(u), cost, diff=False)
+
+            if fast:
+                # inner iterations are never differentiated (the reference detaches them too):
+                # call the kernel directly, no autograd node, no host-side tuple unpacking.
+                r = be.lqr_step(util.detach_maybe(x_init), C, c, F, f, x, u, self._step_options())
+                x, u, costs, full_du_norm = r["new_x"], r["new_u"], r["costs"], r["full_du_norm"]
+                qp_iters, alphas = r["qp_iters"], r["alphas"]
+            else:
+                with torch.no_grad():
+                    x, u, n_qp, costs, full_du_norm, mean_alphas = self.solve_lqr_subproblem(
+                        x_init, C, c, F, f, cost, dx, x, u)
+                qp_iters, alphas = None, None
+            n_not_improved += 1
+            assert x.ndimension() == 3 and u.ndimension() == 3
+
+            # best-iterate tracking, mpc/mpc.py:271-285 -- on the device
+            first = best is None
+            if first:
+                best = dict(x=torch.empty_like(x), u=torch.empty_like(u), costs=torch.empty_like(costs),
+                            full_du_norm=torch.empty_like(full_du_norm))
+            any_improved, max_du = be.select_best(first, self.best_cost_eps, x.contiguous(), u.contiguous(),
+                                                  costs, full_du_norm, best)
+            flags = torch.stack((any_improved[0].to(max_du.dtype), max_du[0])).tolist()   # the one sync
+            if flags[0] != 0:
+                n_not_improved = 0
+            max_du_norm = flags[1]
+
+            if self.verbose > 0:
+                if qp_iters is not None:
+                    n_qp = float(qp_iters.max().item())
+                    mean_alphas = alphas.mean()
+                util.table_log("lqr", (
+                    ("iter", i),
+                    ("mean(cost)", best["costs"].mean().item(), "{:.4e}"),
+                    ("||full_du||_max", max_du_norm, "{:.2e}"),
+                    ("mean(alphas)", float(mean_alphas), "{:.2e}"),
+                    ("total_qp_iters", n_qp),
+                ))
+            if max_du_norm < self.eps or n_not_improved > self.not_improved_lim:
+                break
+
+        x, u = best["x"], best["u"]
+        full_du_norm = best["full_du_norm"]
+        if isinstance(dx, LinDx):
+            F, f = dx.F, dx.f
+        else:
+            F, f = self.linearize_dynamics(x, u, dx, diff=True)
+        if isinstance(cost, QuadCost):
+            C, c = cost.C, cost.c
+        else:
+            C, c, _ = self.approximate_cost(x, u, cost, diff=True)
+
+        # attach the KKT backward at the best iterate (no compute), mpc/mpc.py:318-319
+        x, u = self.solve_lqr_subproblem(x_init, C, c, F, f, cost, dx, x, u, no_op_forward=True)
+
+        if self.detach_unconverged:
+            worst = float(full_du_norm.max().item())
+            if worst > self.eps:
+                if self.exit_unconverged:
+                    raise UnconvergedError(
+                        "MPC: max ||du|| = %.3e > eps = %.1e after %d LQR iterations "
+                        "(exit_unconverged=True)" % (worst, self.eps, self.lqr_iter))
+                if self.verbose >= 0:
+                    print("LQR Warning: All examples did not converge to a fixed point.")
+                    print("Detaching and *not* backpropping through the bad examples.")
+                keep = (full_du_norm < self.eps).to(x.dtype).view(1, -1, 1)
+                x = x * keep + x.detach() * (1. - keep)
+                u = u * keep + u.detach() * (1. - keep)
+        return (x, u, best["costs"])
+
+    # ------------------------------------------------------------------------------------------
+    def _step_options(self):
+        return StepOptions(u_lower=self.u_lower, u_upper=self.u_upper, u_zero_I=self.u_zero_I,
+                           delta_u=self.delta_u, linesearch_decay=self.linesearch_decay,
+                           max_linesearch_iter=self.max_linesearch_iter)
+
+    def solve_lqr_subproblem(self, x_init, C, c, F, f, cost, dynamics, x, u, no_op_forward=False):
+        """Build the LQRStep for the current nominal (x,u) and apply it (mpc/mpc.py:339-361)."""
+        if self.slew_rate_penalty is not None and not isinstance(cost, Module):
+            raise NotImplementedError(
+                "slew_rate_penalty is outside this build's hot-path scope (SURVEY.md section 8f-4)")
+        step = LQRStep(
+            n_state=self.n_state, n_ctrl=self.n_ctrl, T=self.T,
+            u_lower=self.u_lower, u_upper=self.u_upper, u_zero_I=self.u_zero_I,
+            true_cost=cost, true_dynamics=dynamics, delta_u=self.delta_u,
+            linesearch_decay=self.linesearch_decay, max_linesearch_iter=self.max_linesearch_iter,
+            delta_space=True, current_x=x, current_u=u, back_eps=self.back_eps,
+            no_op_forward=no_op_forward)
+        empty = torch.empty(0, dtype=x_init.dtype, device=x_init.device)
+        return step(x_init, C, c, F, f if f is not None else empty)
+
+    # ------------------------------------------------------------------------------------------
+    def approximate_cost(self, x, u, Cf, diff=True):
+        """Second-order expansion of a module cost along (x,u) via autograd (mpc/mpc.py:447-487)."""
+        with torch.enable_grad():
+            tau = torch.cat((x, u), dim=2).detach().requires_grad_(True)
+            costs, hessians, grads = [], [], []
+            for t in range(self.T):
+                tau_t = tau[t]
+                cost = Cf(tau_t)
+                grad = torch.autograd.grad(cost.sum(), tau_t, create_graph=True, retain_graph=True)[0]
+                rows = [torch.autograd.grad(grad[:, j].sum(), tau_t, retain_graph=True)[0]
+                        for j in range(tau.shape[2])]
+                hessian = torch.stack(rows, dim=-1)
+                costs.append(cost)
+                grads.append(grad - util.bmv(hessian, tau_t))
+                hessians.append(hessian)
+            costs, grads, hessians = torch.stack(costs), torch.stack(grads), torch.stack(hessians)
+            if not diff:
+                return hessians.detach(), grads.detach(), costs.detach()
+            return hessians, grads, costs
+
+    def linearize_dynamics(self, x, u, dynamics, diff):
+        """F_t = [df/dx | df/du], f_t = f(x_t,u_t) - F_t [x_t;u_t] along the trajectory
+        (mpc/mpc.py:490-601).  ANALYTIC uses the module's grad_input over all (T-1)*B points at
+        once; AUTO_DIFF batches the reference's (T-1)*n_state backward passes into n_state."""
+        T, ns, nc = self.T, self.n_state, self.n_ctrl
+        B = x.shape[1]
+        if self.grad_method == GradMethods.ANALYTIC:
+            # fresh leaves, as the reference (mpc/mpc.py:495-497): with diff=True the graph reaches the
+            # dynamics' parameters (through new_x, R, S), not the trajectory itself.
+            _x = x[:-1].reshape(-1, ns).detach().requires_grad_(True)
+            _u = u[:-1].reshape(-1, nc).detach().requires_grad_(True)
+            new_x = dynamics(_x, _u)
+            if not diff:
+                new_x, _x, _u = new_x.detach(), _x.detach(), _u.detach()
+            R, S = dynamics.grad_input(_x, _u)
+            f = (new_x - util.bmv(R, _x) - util.bmv(S, _u)).view(T - 1, B, ns)
+            F = torch.cat((R.reshape(T - 1, B, ns, ns), S.reshape(T - 1, B, ns, nc)), 3)
+            return F, f
+        if self.grad_method == GradMethods.AUTO_DIFF:
+            with torch.enable_grad():
+                xt = x[:-1].reshape(-1, ns).detach().requires_grad_(True)
+                ut = u[:-1].reshape(-1, nc).detach().requires_grad_(True)
+                new_x = dynamics(xt, ut)
+                Rs, Ss = [], []
+                for j in range(ns):      # n_state backward passes over ALL (T-1)*B points at once
+                    Rj, Sj = torch.autograd.grad(new_x[:, j].sum(), [xt, ut], retain_graph=True,
+                                                 create_graph=diff)
+                    Rs.append(Rj)
+                    Ss.append(Sj)
+                R, S = torch.stack(Rs, 1), torch.stack(Ss, 1)
+                if not diff:
+                    new_x, xt, ut, R, S = (z.detach() for z in (new_x, xt, ut, R, S))
+                f = (new_x - util.bmv(R, xt) - util.bmv(S, ut)).view(T - 1, B, ns)
+                F = torch.cat((R, S), 2).view(T - 1, B, ns, ns + nc)
+            return F, f
+        if self.grad_method == GradMethods.FINITE_DIFF:
+            eps = 1e-4
+            xt = x[:-1].reshape(-1, ns).detach()
+            ut = u[:-1].reshape(-1, nc).detach()
+            with torch.no_grad():
+                new_x = dynamics(xt, ut)
+                cols = []
+                for j in range(ns + nc):
+                    e = torch.zeros(ns + nc, dtype=xt.dtype, device=xt.device)
+                    e[j] = eps
+                    hi = dynamics(xt + e[:ns], ut + e[ns:])
+                    lo = dynamics(xt - e[:ns], ut - e[ns:])
+                    cols.append((hi - lo) / (2. * eps))
+                Fm = torch.stack(cols, 2)
+                f = (new_x - util.bmv(Fm, torch.cat((xt, ut), 1))).view(T - 1, B, ns)
+            return Fm.view(T - 1, B, ns, ns + nc), f
+        assert False

@@ -1,0 +1,88 @@
+"""TEST-ONLY stand-in for mpc._native.HipBackend, backed by the CPU oracle.
+
+Lets the CPU-only suite exercise the HOST logic of the product package (MPC.forward's iteration /
+best-iterate / convergence rules, the autograd wiring of LQRStep, argument expansion) without a
+GPU.  Installed with mpc._native.set_backend_for_testing(); the product never imports this file
+and has no CPU path of its own.  Per-problem semantics (lockstep=False) like the HIP kernels.
+"""
+import numpy as np
+import torch
+
+from oracle import lqr_oracle as O
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def _bound(v):
+    if v is None or isinstance(v, float):
+        return v
+    if isinstance(v, int):
+        return float(v)
+    return _np(v)
+
+
+class OracleBackend:
+    name = "cpu-oracle (tests only)"
+
+    def __init__(self, lockstep=False):
+        self.lockstep = lockstep
+        self.calls = []
+
+    def _t(self, a, like):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dtype=like.dtype)
+
+    def lqr_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, want_gains=False, impl=0, rollout_problem=None):
+        assert rollout_problem is None, "oracle backend: split true-cost rollout not modelled"
+        self.calls.append("lqr_step")
+        T = C.shape[0]
+        Fn = _np(F) if T > 1 else np.zeros((0, C.shape[1], x_init.shape[1], C.shape[2]), _np(C).dtype)
+        o = O.lqr_step(_np(x_init), _np(C), _np(c), Fn, _np(f), _np(cur_x), _np(cur_u),
+                       _bound(opts.u_lower), _bound(opts.u_upper), _np(opts.u_zero_I), opts.delta_u,
+                       opts.linesearch_decay, opts.max_linesearch_iter, lockstep=self.lockstep,
+                       return_gains=True)
+        B = C.shape[1]
+        res = {k: self._t(o[k], C) for k in ("new_x", "new_u", "costs", "old_costs", "full_du_norm",
+                                             "alpha_du_norm", "alphas", "K", "k")}
+        res["qp_iters"] = torch.full((B,), int(o["n_qp_iter"]), dtype=torch.int32)
+        res["status"] = torch.zeros(B, dtype=torch.int32)
+        return res
+
+    def lqr_sweep(self, x_init, C, c, F, cur_x, cur_u, opts):
+        self.calls.append("lqr_sweep")
+        r = self.lqr_step(x_init, C, c, F, None, cur_x, cur_u, opts, want_gains=True)
+        return {k: r[k] for k in ("K", "k", "old_costs", "qp_iters", "status")}
+
+    def kkt_backward(self, C, c, F, f, x_star, u_star, dl_dx, dl_du, opts, impl=0):
+        self.calls.append("kkt_backward")
+        o = O.kkt_backward(_np(C), _np(c), _np(F), _np(f), _np(x_star), _np(u_star),
+                           _np(dl_dx.to(C.dtype)), _np(dl_du.to(C.dtype)),
+                           _bound(opts.u_lower), _bound(opts.u_upper), lockstep=self.lockstep)
+        return {k: (None if o[k] is None else self._t(o[k], C)) for k in ("dx_init", "dC", "dc", "dF", "df", "dx", "du")}
+
+    def pnqp(self, H, q, lower, upper, x_init=None, n_iter=20, want_Hfree=True):
+        self.calls.append("pnqp")
+        o = O.pnqp(_np(H), _np(q), _bound(lower), _bound(upper), _np(x_init), n_iter=n_iter, lockstep=self.lockstep)
+        Hn = _np(H)
+        If = o["If"].astype(bool)
+        Hfree = np.where(If[:, :, None] & If[:, None, :], Hn, 0.0) + 1e-11 * np.eye(Hn.shape[1])
+        return dict(x=self._t(o["x"], H), If=torch.from_numpy(o["If"]), iters=torch.from_numpy(o["iters"]),
+                    status=torch.from_numpy((1 - o["converged"]).astype(np.int32)), Hfree=self._t(Hfree, H))
+
+    def traj_cost(self, x_init, u, F, f, C=None, c=None, want_x=True):
+        self.calls.append("traj_cost")
+        T, B, nc = u.shape
+        Fn = _np(F) if T > 1 else np.zeros((0, B, x_init.shape[1], x_init.shape[1] + nc), _np(u).dtype)
+        x, cost = O.traj_cost(_np(x_init), _np(u), Fn, _np(f), _np(C), _np(c))
+        return (self._t(x, u) if want_x else None), (None if cost is None else self._t(cost, u))
+
+    def select_best(self, first, eps, x, u, costs, du_norm, best):
+        self.calls.append("select_best")
+        take = torch.ones_like(costs, dtype=torch.bool) if first else costs <= best["costs"] + eps
+        best["x"][:, take] = x[:, take]
+        best["u"][:, take] = u[:, take]
+        best["costs"][take] = costs[take]
+        best["full_du_norm"][take] = du_norm[take]
+        any_improved = torch.tensor([int((not first) and bool(take.any()))], dtype=torch.int32)
+        return any_improved, du_norm.max().reshape(1)

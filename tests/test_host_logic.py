@@ -1,0 +1,273 @@
+"""CPU-only tests: the C ABI loads and exports what include/mpc_lqr.h declares, the product refuses
+CPU tensors (no fallback), and the HOST logic of the package (MPC.forward's iteration rules, the
+autograd wiring, argument handling) reproduces the reference's results when the kernels are
+replaced by the oracle (tests/oracle_backend.py -- a test hook, not a product path)."""
+import contextlib
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+from mpc import _native, mpc, util
+from mpc.lqr_step import LQRStep
+from mpc.mpc import GradMethods, LinDx, QuadCost
+from oracle_backend import OracleBackend
+
+
+@pytest.fixture
+def oracle_backend():
+    be = OracleBackend()
+    prev = _native.set_backend_for_testing(be)
+    yield be
+    _native.set_backend_for_testing(prev)
+
+
+def tt(z, k):
+    return torch.from_numpy(z[k]) if k in z else None
+
+
+# ---------------------------------------------------------------------------------------------
+# the boundary
+# ---------------------------------------------------------------------------------------------
+def test_library_loads_and_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mpc_lqr.h")).read()
+    declared = set(re.findall(r"\b(mpc_[a-z_]+)\s*\(", header))
+    assert {"mpc_lqr_step", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_pnqp",
+            "mpc_traj_cost", "mpc_select_best"} <= declared
+    L = _native.load()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert set(_native.EXPORTS) == declared
+    assert L.mpc_lqr_abi_version() == 1
+    assert b"gfx950" in L.mpc_lqr_build_info()
+
+
+def test_struct_layout_matches_header():
+    # sizeof checks guard the ctypes mirror against drift from include/mpc_lqr.h
+    assert ctypes.sizeof(_native.Problem) == 6 * 4 + 8 + 4 * (8 + 16) + 16
+    assert ctypes.sizeof(_native.Options) == 8 + 16 + 24 + 16 + 8
+    assert ctypes.sizeof(_native.Outputs) == 11 * 8
+
+
+def test_argument_validation_without_gpu():
+    L = _native.load()
+    p = _native.Problem()
+    p.B, p.T, p.ns, p.nc, p.dtype = 4, 0, 3, 1, 0
+    o, out = _native.Options(), _native.Outputs()
+    o.max_linesearch_iter, o.delta_u = 10, float('nan')
+    rc = L.mpc_lqr_step(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), None, 0, 0, None)
+    assert rc == -1 and b"T>=1" in L.mpc_lqr_last_error()
+    p.T, p.dtype = 5, 7
+    assert L.mpc_lqr_step(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), None, 0, 0, None) == -3
+    p.dtype = 0
+    assert L.mpc_lqr_step(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), None, 0, 0, None) == -2   # NULL C
+    p.B = 0      # empty batch is a no-op, not an error
+    assert L.mpc_lqr_step(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), None, 0, 0, None) == 0
+    assert L.mpc_pnqp(0, 0, 4, None, None, None, None, None, 20, None, None, None, None, None, None) == 0
+    assert L.mpc_pnqp(3, 1, 4, None, None, None, None, None, 20, None, None, None, None, None, None) == -3
+
+
+def test_product_refuses_cpu_tensors():
+    """No CPU / eager fallback: the shipped backend raises on host tensors."""
+    be = _native.HipBackend()
+    z = golden("step_unbounded_f64")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        be.lqr_step(tt(z, "x_init"), tt(z, "C"), tt(z, "c"), tt(z, "F"), tt(z, "f"), tt(z, "cur_x"),
+                    tt(z, "cur_u"), _native.StepOptions())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mpc.MPC(3, 4, 5)(tt(z, "x_init"), QuadCost(tt(z, "C"), tt(z, "c")), LinDx(tt(z, "F"), tt(z, "f")))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setenv("MPC_LQR_HIP_LIB", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_native, "_lib", None)
+    with pytest.raises(_native.NativeLibraryMissing, match="no CPU fallback"):
+        _native.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mpc.pytorch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in src.replace("oracle-backed", "").replace("an oracle", "") or fn == "_native.py", fn
+    src = open(os.path.join(pkg, "mpc", "_native.py")).read()
+    assert "import oracle" not in src and "from oracle" not in src and "lqr_oracle" not in src
+
+
+# ---------------------------------------------------------------------------------------------
+# MPC.forward host logic against the reference's own solves (kernels replaced by the oracle)
+# ---------------------------------------------------------------------------------------------
+MPC_CASES = ["mpc_notebook_tvlq", "mpc_linear_unbounded_big_bounds", "mpc_linear_unbounded_none",
+             "mpc_linear_bounded", "mpc_linear_bounded_delta", "mpc_singleton_big_bounds", "mpc_singleton_none"]
+
+
+def run_mpc_golden(z, verbose=-1, device=None):
+    ns, nc, T, B = (int(v) for v in z["meta"])
+    kw = {k[3:]: z[k][0] for k in z if k.startswith("kw_")}
+    kw2 = dict(lqr_iter=int(kw["lqr_iter"]), exit_unconverged=bool(kw["exit_unconverged"]))
+    if "delta_u" in kw:
+        kw2["delta_u"] = float(kw["delta_u"])
+    mv = (lambda t: t if t is None or device is None else t.to(device))
+    ctrl = mpc.MPC(ns, nc, T, u_lower=mv(tt(z, "u_lower")), u_upper=mv(tt(z, "u_upper")), verbose=verbose,
+                   backprop=False, **kw2)
+    return ctrl(mv(tt(z, "x_init")), QuadCost(mv(tt(z, "C")), mv(tt(z, "c"))), LinDx(mv(tt(z, "F")), mv(tt(z, "f"))))
+
+
+@pytest.mark.parametrize("name", MPC_CASES)
+def test_mpc_forward_matches_reference_solves(name, oracle_backend):
+    """tests/test_mpc.py:91-299 inputs + the notebook problem: same (x, u, costs) as the reference."""
+    z = golden(name)
+    x, u, costs = run_mpc_golden(z)
+    tol = 1e-6 if z["C"].dtype == np.float64 else 2e-4
+    np.testing.assert_allclose(x.detach().numpy(), z["x"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(u.detach().numpy(), z["u"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(costs.numpy(), z["costs"], rtol=1e-6)
+    if "delta_u" in name:
+        assert float(u.abs().max()) <= 0.1 + 1e-12          # tests/test_mpc.py:239-240
+    assert "select_best" in oracle_backend.calls
+
+
+def test_known_answer_table(oracle_backend):
+    """examples/Time Varying Linear-Quadratic Control.ipynb cell 1: the printed iteration table."""
+    z = golden("mpc_notebook_tvlq")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        run_mpc_golden(z, verbose=1)
+    txt = buf.getvalue()
+    assert "Initial mean(cost): 3.9041e+01" in txt
+    rows = [[c.strip() for c in line.strip("| \n").split("|")] for line in txt.splitlines()
+            if re.match(r"\|\s*\d+\s*\|", line)]
+    published = ["6.6806e+00", "6.4417e+00", "4.5778e+00", "4.4537e+00", "4.4527e+00"]   # notebook output
+    assert [r[1] for r in rows[:5]] == published
+    assert [r[3] for r in rows[:5]] == ["1.00e+00", "6.00e-01", "1.00e+00", "1.00e+00", "1.00e+00"]
+    # and the table the reference printed in this container agrees on the same columns
+    assert np.allclose([float(r[1]) for r in rows[:6]], z["table"][:6, 1], rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["jac_unconstrained", "jac_constrained"])
+def test_autograd_jacobians_match_reference(name, oracle_backend):
+    """tests/test_mpc.py:303-500: du/d{C,c,x_init,F,f} through MPC.forward + LQRStepFn.backward."""
+    z = golden(name)
+    ns, nc, T, B = (int(v) for v in z["meta"])
+    beta = float(z["beta"][0])
+    tens = [torch.from_numpy(z[k]).requires_grad_(True) for k in ("C", "c", "x_init", "F", "f")]
+    C, c, x0, F, f = tens
+    lo, hi = -beta * torch.ones(T, B, nc).double(), beta * torch.ones(T, B, nc).double()
+    x, u, _ = mpc.MPC(ns, nc, T, lo, hi, None, lqr_iter=20, verbose=-1, exit_unconverged=False)(
+        x0, QuadCost(C, c), LinDx(F, f))
+    np.testing.assert_allclose(u.detach().numpy(), z["u"], atol=1e-8)
+    uf = u.reshape(-1)
+    for i in range(len(uf)):
+        gs = torch.autograd.grad(uf[i], tens, retain_graph=True)
+        for k, g in zip(("dC", "dc", "dx_init", "dF", "df"), gs):
+            np.testing.assert_allclose(g.reshape(-1).numpy(), z["J_" + k][i], atol=1e-8)
+    assert "kkt_backward" in oracle_backend.calls
+
+
+def test_lqrstep_contract(oracle_backend):
+    """Return tuple / no-op mode / empty-f convention of LQRStep (mpc/lqr_step.py:277-309, 397-402)."""
+    z = golden("step_unbounded_nof_f64")
+    ns, nc, T, B = (int(v) for v in z["meta"][:4])
+    x0, C, c, F = (tt(z, k) for k in ("x_init", "C", "c", "F"))
+    cur_x, cur_u = tt(z, "cur_x"), tt(z, "cur_u")
+    step = LQRStep(ns, nc, T, true_cost=QuadCost(C, c), true_dynamics=LinDx(F, None), current_x=cur_x,
+                   current_u=cur_u)
+    out = step(x0, C, c, F, torch.Tensor())
+    assert len(out) == 6
+    new_x, new_u, n_qp, costs, fdn, mean_alpha = out
+    np.testing.assert_allclose(new_u.numpy(), z["new_u_pp"], atol=1e-9)
+    assert n_qp.device.type == "cpu" and n_qp.shape == (1,) and mean_alpha.ndim == 0
+    # no-op forward returns the nominal and wires the backward
+    Cg = C.clone().requires_grad_(True)
+    noop = LQRStep(ns, nc, T, true_cost=QuadCost(Cg, c), true_dynamics=LinDx(F, None), current_x=new_x,
+                   current_u=new_u, no_op_forward=True)
+    x2, u2 = noop(x0, Cg, c, F, torch.Tensor())
+    assert torch.equal(x2, new_x) and torch.equal(u2, new_u) and u2.requires_grad
+    (gC,) = torch.autograd.grad(u2.sum(), [Cg])
+    assert gC.shape == C.shape and torch.isfinite(gC).all()
+    with pytest.raises(AssertionError):
+        LQRStep(ns, nc, T, delta_space=False, current_x=cur_x, current_u=cur_u)(x0, C, c, F, torch.Tensor())
+    with pytest.raises(AssertionError):   # delta_u without bounds: unimplemented upstream too (:195)
+        LQRStep(ns, nc, T, delta_u=0.1, current_x=cur_x, current_u=cur_u)(x0, C, c, F, torch.Tensor())
+
+
+def test_driver_argument_handling(oracle_backend):
+    z = golden("step_cfg1_f64")
+    ns, nc, T, B = (int(v) for v in z["meta"][:4])
+    x0, C, c, F, f = (tt(z, k) for k in ("x_init", "C", "c", "F", "f"))
+    # time/batch-invariant cost given as [n,n] / [n]: expanded views, not copies (mpc/mpc.py:207-221)
+    C2, c2 = C[0, 0].contiguous(), c[0, 0].contiguous()
+    ctrl = mpc.MPC(ns, nc, T, lqr_iter=3, n_batch=B, exit_unconverged=False, verbose=-1)
+    x, u, costs = ctrl(x0, QuadCost(C2, c2), LinDx(F, f))
+    Cx = C2.expand(T, B, ns + nc, ns + nc).contiguous()
+    cx = c2.expand(T, B, ns + nc).contiguous()
+    x3, u3, _ = mpc.MPC(ns, nc, T, lqr_iter=3, exit_unconverged=False, verbose=-1)(x0, QuadCost(Cx, cx), LinDx(F, f))
+    np.testing.assert_allclose(u.detach().numpy(), u3.detach().numpy(), atol=1e-12)
+    with pytest.raises(ValueError, match="batch size"):
+        mpc.MPC(ns, nc, T)(x0, QuadCost(C2, c2), LinDx(F, f))
+    with pytest.raises(AssertionError):
+        mpc.MPC(ns, nc, T, u_lower=-1.0)
+    with pytest.raises(AssertionError):
+        mpc.MPC(ns, nc, T, max_linesearch_iter=0)
+    # exit_unconverged=True (the default) -> the reference's `assert False`, here a named AssertionError
+    with pytest.raises(mpc.UnconvergedError):
+        mpc.MPC(ns, nc, T, u_lower=tt(z, "u_lower"), u_upper=tt(z, "u_upper"), lqr_iter=1, verbose=-1)(
+            x0, QuadCost(C, c), LinDx(F, f))
+    # warm start through u_init [T, nc]
+    u0 = torch.zeros(T, nc, dtype=x0.dtype)
+    mpc.MPC(ns, nc, T, u_init=u0, lqr_iter=2, exit_unconverged=False, verbose=-1)(x0, QuadCost(C, c), LinDx(F, f))
+
+
+def test_util_mirror(oracle_backend):
+    z = golden("traj_cost")
+    T, B, nc = z["u"].shape
+    dx = LinDx(tt(z, "F"), tt(z, "f"))
+    x = util.get_traj(T, tt(z, "u"), tt(z, "x_init"), dx)
+    np.testing.assert_allclose(x.numpy(), z["x"], atol=1e-12)
+    cost = util.get_cost(T, tt(z, "u"), QuadCost(tt(z, "C"), tt(z, "c")), dx, x_init=tt(z, "x_init"))
+    np.testing.assert_allclose(cost.numpy(), z["cost"], rtol=1e-12)
+    cost2 = util.get_cost(T, tt(z, "u"), QuadCost(tt(z, "C"), tt(z, "c")), x=x)
+    np.testing.assert_allclose(cost2.numpy(), z["cost"], rtol=1e-12)
+    a, b = torch.randn(3, 4, 5), torch.randn(3, 5)
+    assert torch.allclose(util.bmv(a, b), a.bmm(b.unsqueeze(2)).squeeze(2))
+    assert torch.allclose(util.bger(b, b), b.unsqueeze(2) * b.unsqueeze(1))
+    v = torch.tensor([[-2.0, 0.5, 3.0]])
+    assert util.eclamp(v, -1.0, 1.0).tolist() == [[-1.0, 0.5, 1.0]] and v.tolist() == [[-1.0, 0.5, 1.0]]
+
+
+def test_pnqp_mirror(oracle_backend, capsys):
+    from mpc import pnqp as pnqp_mod
+    z = golden("pnqp_n4_warm_f64")
+    x, fac, If, n_it = pnqp_mod.pnqp(tt(z, "H"), tt(z, "q"), tt(z, "lower"), tt(z, "upper"), x_init=tt(z, "x0"))
+    np.testing.assert_allclose(x.numpy(), z["x_pp"], atol=1e-10)
+    assert isinstance(fac, tuple) and len(fac) == 2 and n_it == int(z["iters_pp"].max())
+    assert np.array_equal(If.numpy(), z["If_pp"])
+
+
+def test_module_dynamics_rollout_equals_lindx(oracle_backend):
+    """Affine dynamics given as an nn.Module take the host-driven rollout; results must equal the
+    LinDx kernel path (the reference's own cross-check, tests/test_mpc.py:503-558)."""
+    z = golden("mpc_linear_bounded")
+    ns, nc, T, B = (int(v) for v in z["meta"])
+    x0, C, c, F, f = (tt(z, k) for k in ("x_init", "C", "c", "F", "f"))
+
+    class Affine(torch.nn.Module):
+        def forward(self, x, u):
+            return x @ F[0, 0, :, :ns].t() + u @ F[0, 0, :, ns:].t() + f[0, 0]
+
+        def grad_input(self, x, u):
+            n = x.shape[0]
+            return F[0, 0, :, :ns].expand(n, ns, ns), F[0, 0, :, ns:].expand(n, ns, nc)
+
+    for gm in (GradMethods.ANALYTIC, GradMethods.AUTO_DIFF, GradMethods.FINITE_DIFF):
+        x, u, _ = mpc.MPC(ns, nc, T, u_lower=tt(z, "u_lower"), u_upper=tt(z, "u_upper"), lqr_iter=20,
+                          grad_method=gm, exit_unconverged=False, verbose=-1, backprop=False)(
+            x0, QuadCost(C, c), Affine())
+        np.testing.assert_allclose(u.detach().numpy(), z["u"], atol=2e-6)
