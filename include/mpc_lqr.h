@@ -105,6 +105,9 @@ int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p);
 int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
                  void *workspace, int64_t workspace_bytes, int impl, void *stream);
 
+/* Does kernel `impl` (1 generic, 2 fused MFMA) accept this problem/options pair?  1 yes, 0 no. */
+int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, int impl);
+
 /* (2) The sweep alone: c_back + lqr_backward (mpc/lqr_step.py:284-296, 52-160).
  *     Writes out->K, out->k (required), out->old_costs, out->qp_iters, out->status. */
 int mpc_lqr_sweep(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,

@@ -110,6 +110,20 @@ int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_l
                                : step_impl<double>(p, o, out, workspace, workspace_bytes, impl, 3, nullptr, st);
 }
 
+int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, int impl)
+{
+    if (!p || check_problem(p, false, false) != MPC_OK || check_options(p, o) != MPC_OK) return 0;
+    if (impl == 1) return generic_lds_bytes(p->ns, p->nc, p->dtype == MPC_F64 ? 8 : 4) <= 160 * 1024;
+    if (impl == 2) {
+        if (p->dtype != MPC_F32) return 0;
+        mpc_lqr_outputs out;
+        memset(&out, 0, sizeof(out));
+        StepParams<float> sp = make_params<float>(p, o, &out);
+        return mfma16_supported(sp) ? 1 : 0;
+    }
+    return 0;
+}
+
 int mpc_lqr_sweep(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out, void *stream)
 {
     int rc = check_problem(p, true, true);

@@ -45,7 +45,7 @@ class Outputs(ctypes.Structure):
 
 
 EXPORTS = ("mpc_lqr_abi_version", "mpc_lqr_build_info", "mpc_lqr_last_error", "mpc_lqr_workspace_bytes",
-           "mpc_lqr_step", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_lqr_kkt_prepare",
+           "mpc_lqr_step", "mpc_lqr_impl_supported", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_lqr_kkt_prepare",
            "mpc_pnqp", "mpc_traj_cost", "mpc_select_best")
 
 _lib = None
@@ -78,6 +78,7 @@ def load():
     L.mpc_lqr_workspace_bytes.argtypes = [ctypes.POINTER(Problem)]
     PP, OP, UP = ctypes.POINTER(Problem), ctypes.POINTER(Options), ctypes.POINTER(Outputs)
     L.mpc_lqr_step.argtypes = [PP, OP, UP, _vp, _i64, ctypes.c_int, _vp]
+    L.mpc_lqr_impl_supported.argtypes = [PP, OP, ctypes.c_int]
     L.mpc_lqr_sweep.argtypes = [PP, OP, UP, _vp]
     L.mpc_lqr_rollout.argtypes = [PP, OP, UP, _vp, _vp]
     L.mpc_lqr_kkt_grads.argtypes = [PP] + [_vp] * 10
@@ -217,6 +218,12 @@ class HipBackend:
             if t is not None and t.numel() > 0 and (t.dtype != C.dtype or t.device != C.device):
                 raise TypeError("all tensors of one LQR problem must share dtype and device")
 
+    def impl_supported(self, ns, nc, dtype, impl, opts=None):
+        p = Problem()
+        p.B, p.T, p.ns, p.nc = 1, 2, ns, nc
+        p.dtype = MPC_F32 if dtype == torch.float32 else MPC_F64
+        return bool(load().mpc_lqr_impl_supported(ctypes.byref(p), None, int(impl)))
+
     # -- (1) LQRStepFn.forward ------------------------------------------------------------------
     def lqr_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, want_gains=False, impl=IMPL_AUTO,
                  rollout_problem=None):
@@ -266,6 +273,43 @@ class HipBackend:
                                   int(impl), st), "mpc_lqr_step")
         res["_keep"] = (keep, keep_o, ws)
         return res
+
+    def plan_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, impl=IMPL_AUTO):
+        """Pre-bind one LQR step: argument structs and output buffers are built once, `plan()` is
+        then a single C call (no allocation, hipGraph-capturable).  Outputs are overwritten by
+        every call -- clone what must survive."""
+        dev = _require_device(x_init, C, c, F, cur_x, cur_u)
+        self._check_same(C, x_init, c, F, f, cur_x, cur_u)
+        L = load()
+        T, B, n = C.shape[0], C.shape[1], C.shape[2]
+        ns = x_init.shape[1]
+        nc = n - ns
+        p, keep = self._problem(x_init, C, c, F, f, cur_x, cur_u)
+        o, keep_o = opts.to_struct(T, B, nc, C)
+        kw = dict(device=dev, dtype=C.dtype)
+        res = dict(new_x=torch.empty(T, B, ns, **kw), new_u=torch.empty(T, B, nc, **kw),
+                   costs=torch.empty(B, **kw), old_costs=torch.empty(B, **kw),
+                   full_du_norm=torch.empty(B, **kw), alpha_du_norm=torch.empty(B, **kw),
+                   alphas=torch.empty(B, **kw),
+                   qp_iters=torch.zeros(B, device=dev, dtype=torch.int32),
+                   status=torch.zeros(B, device=dev, dtype=torch.int32))
+        out = Outputs()
+        for k in res:
+            setattr(out, k, res[k].data_ptr())
+        nbytes = int(L.mpc_lqr_workspace_bytes(ctypes.byref(p)))
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        pp, op, up, wp = ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), ws.data_ptr()
+        fn = L.mpc_lqr_step
+        impl = int(impl)
+
+        def run():
+            rc = fn(pp, op, up, wp, nbytes, impl, torch.cuda.current_stream(dev).cuda_stream)
+            if rc != 0:
+                _check(rc, "mpc_lqr_step")
+            return res
+        run.outputs = res
+        run._keep = (p, o, out, keep, keep_o, ws)
+        return run
 
     def lqr_sweep(self, x_init, C, c, F, cur_x, cur_u, opts):
         """c_back + lqr_backward only -> dict(K, k, old_costs, qp_iters, status)."""

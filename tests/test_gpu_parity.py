@@ -1,0 +1,320 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+  (a) the CPU oracle on the same inputs (per-problem semantics, tight tolerance),
+  (b) the committed outputs of the unmodified reference (tests/golden/),
+  (c) size-independent properties at BASELINE.json's full sizes.
+
+Tolerances.  float64: 1e-9.  float32: rtol 1e-3 / atol 1e-4 on x, u, costs, measured
+against the reference's float64 run of the same inputs and against its float32 run widened by the
+reference's own fp32-vs-fp64 deviation (pnqp stops at |dx| < 1e-4, so the reference cannot
+reproduce itself better than that in fp32).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden
+from helpers import bounds_of, close_with_ref_noise, step_kwargs
+
+pytestmark = pytest.mark.gpu
+
+STEP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "step_*.npz")))
+GRAD_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "grad_*.npz")))
+PNQP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "pnqp_*.npz")))
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def be():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from mpc import _native
+    b = _native.HipBackend()
+    _native.load()            # fail loudly if the extension is missing
+    return b
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def opts_of(z):
+    from mpc._native import StepOptions
+    lo, hi = bounds_of(z)
+    lo = dev(lo) if isinstance(lo, np.ndarray) else lo
+    hi = dev(hi) if isinstance(hi, np.ndarray) else hi
+    du = None if np.isnan(z["delta_u"][0]) else float(z["delta_u"][0])
+    return StepOptions(u_lower=lo, u_upper=hi, u_zero_I=dev(z.get("u_zero_I")), delta_u=du,
+                       linesearch_decay=float(z["decay"][0]), max_linesearch_iter=int(z["meta"][5]))
+
+
+def hip_step(be, z, impl=1, **kw):
+    r = be.lqr_step(dev(z["x_init"]), dev(z["C"]), dev(z["c"]), dev(z["F"]), dev(z.get("f")), dev(z["cur_x"]),
+                    dev(z["cur_u"]), opts_of(z), impl=impl, **kw)
+    torch.cuda.synchronize()
+    return {k: host(v) for k, v in r.items() if torch.is_tensor(v)}
+
+
+def impls_for(z):
+    ns, nc = int(z["meta"][0]), int(z["meta"][1])
+    from mpc import _native
+    out = [1]
+    if _native.backend().impl_supported(ns, nc, torch.from_numpy(z["C"][:0]).dtype, _native.IMPL_MFMA16):
+        out.append(_native.IMPL_MFMA16)
+    return out
+
+
+def check_step(r, o, z):
+    """r = HIP result, o = oracle per-problem result on the same inputs, z = golden fixture."""
+    f64 = z["C"].dtype == np.float64
+    if f64:
+        t = dict(rtol=1e-9, atol=1e-9)
+        for k in ("new_x", "new_u", "costs", "old_costs", "full_du_norm", "alphas"):
+            np.testing.assert_allclose(r[k], o[k], err_msg=k, **t)
+        np.testing.assert_allclose(r["new_x"], z["new_x_pp"], **t)
+        np.testing.assert_allclose(r["new_u"], z["new_u_pp"], **t)
+        np.testing.assert_allclose(r["costs"], z["costs_pp"], **t)
+        # and the reference's whole-batch call, to the stated tolerance
+        np.testing.assert_allclose(r["new_u"], z["new_u_batch"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(r["new_x"], z["new_x_batch"], rtol=1e-3, atol=1e-4)
+    else:
+        np.testing.assert_allclose(r["new_x"], z["new_x_ref64"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(r["new_u"], z["new_u_ref64"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(r["costs"], z["costs_ref64"], rtol=1e-4)
+        np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+        nx = np.abs(z["new_x_pp"] - z["new_x_ref64"])
+        nu = np.abs(z["new_u_pp"] - z["new_u_ref64"])
+        for mode in ("pp", "batch"):
+            close_with_ref_noise(r["new_x"], z["new_x_" + mode], nx, 1e-3, 1e-4)
+            close_with_ref_noise(r["new_u"], z["new_u_" + mode], nu, 1e-3, 1e-4)
+        np.testing.assert_allclose(r["full_du_norm"], z["full_du_norm_ref64"], rtol=2e-3, atol=2e-4)
+    assert (r["status"] & 2 == 0).all()
+
+
+@pytest.mark.parametrize("name", STEP_CASES)
+def test_lqr_step_parity(be, name):
+    """mpc_lqr_step == LQRStepFn.forward (mpc/lqr_step.py:277-309) on every fixture, every kernel."""
+    from oracle import lqr_oracle as O
+    z = golden(name)
+    o = O.lqr_step(lockstep=False, **step_kwargs(z))
+    for impl in impls_for(z):
+        r = hip_step(be, z, impl=impl)
+        check_step(r, o, z)
+    if z["C"].dtype == np.float64 and "u_lower" in z:
+        assert int(r["qp_iters"].max()) == int(z["n_qp_pp"].max())
+
+
+@pytest.mark.parametrize("name", ["step_cfg1_f64", "step_masked_f64", "step_ns_bounded_f32", "step_nc1_scalar_f64"])
+def test_split_sweep_and_rollout_entry_points(be, name):
+    """mpc_lqr_sweep (K, k) and mpc_lqr_rollout separately == the fused step, and K,k == oracle."""
+    from oracle import lqr_oracle as O
+    z = golden(name)
+    o = O.lqr_step(lockstep=False, return_gains=True, **step_kwargs(z))
+    sw = be.lqr_sweep(dev(z["x_init"]), dev(z["C"]), dev(z["c"]), dev(z["F"]), dev(z["cur_x"]), dev(z["cur_u"]), opts_of(z))
+    tol = 1e-9 if z["C"].dtype == np.float64 else 2e-3
+    np.testing.assert_allclose(host(sw["K"]), o["K"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(host(sw["k"]), o["k"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(host(sw["old_costs"]), o["old_costs"], rtol=1e-5)
+    # rollout with a *different* true cost than the quadratic model (true_cost != C path)
+    C2 = dev(z["C"]) * 1.0
+    r = be.lqr_step(dev(z["x_init"]), dev(z["C"]), dev(z["c"]), dev(z["F"]), dev(z.get("f")), dev(z["cur_x"]),
+                    dev(z["cur_u"]), opts_of(z), rollout_problem=(C2, dev(z["c"]), dev(z["F"]), dev(z.get("f"))))
+    np.testing.assert_allclose(host(r["new_u"]), o["new_u"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(host(r["costs"]), o["costs"], rtol=1e-4)
+
+
+def test_strided_expanded_inputs(be):
+    """MPC.forward hands over `.expand`ed (stride-0) C, c (mpc/mpc.py:207-221): read in place."""
+    from oracle import lqr_oracle as O
+    z = golden("step_cfg1_f64")
+    ns, nc, T, B = (int(v) for v in z["meta"][:4])
+    C0, c0 = z["C"][0, 0], z["c"][0, 0]
+    F0 = z["F"][:, 0]
+    Ce = dev(C0).expand(T, B, ns + nc, ns + nc)
+    ce = dev(c0).expand(T, B, ns + nc)
+    Fe = dev(F0).unsqueeze(1).expand(T - 1, B, ns, ns + nc)
+    assert Ce.stride(0) == 0 and Ce.stride(1) == 0 and Fe.stride(1) == 0
+    r = be.lqr_step(dev(z["x_init"]), Ce, ce, Fe, dev(z["f"]), dev(z["cur_x"]), dev(z["cur_u"]), opts_of(z), impl=1)
+    kw = step_kwargs(z)
+    kw.update(C=np.broadcast_to(C0, z["C"].shape), c=np.broadcast_to(c0, z["c"].shape),
+              F=np.broadcast_to(F0[:, None], z["F"].shape))
+    o = O.lqr_step(lockstep=False, **kw)
+    np.testing.assert_allclose(host(r["new_u"]), o["new_u"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(host(r["new_x"]), o["new_x"], rtol=1e-9, atol=1e-9)
+    # F carrying T entries (tests/test_mpc.py builds it with np.tile(T,...)): only t < T-1 is read
+    F_T = torch.cat((dev(z["F"]), torch.full((1, B, ns, ns + nc), float("nan"), device=DEV, dtype=torch.float64)))
+    r2 = be.lqr_step(dev(z["x_init"]), dev(z["C"]), dev(z["c"]), F_T, dev(z["f"]), dev(z["cur_x"]), dev(z["cur_u"]),
+                     opts_of(z), impl=1)
+    o2 = O.lqr_step(lockstep=False, **step_kwargs(z))
+    np.testing.assert_allclose(host(r2["new_u"]), o2["new_u"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_kkt_backward_parity(be, name):
+    """mpc_lqr_kkt_prepare + mpc_lqr_step + mpc_lqr_kkt_grads == LQRStepFn.backward (:312-407)."""
+    from mpc._native import StepOptions
+    z = golden(name)
+    beta = float(z["beta"][0])
+    lo, hi = (None, None) if np.isnan(beta) else (-beta, beta)
+    g = be.kkt_backward(dev(z["C"]), dev(z["c"]), dev(z["F"]), dev(z.get("f")), dev(z["x"]), dev(z["u"]),
+                        dev(z["dl_dx"]), dev(z["dl_du"]), StepOptions(u_lower=lo, u_upper=hi), impl=1)
+    f64 = z["C"].dtype == np.float64
+    for k in ("dx_init", "dC", "dc", "dF", "df"):
+        if k not in z:
+            assert g[k] is None
+            continue
+        scale = max(1.0, np.abs(z[k]).max())
+        np.testing.assert_allclose(host(g[k]) / scale, z[k] / scale, rtol=0, atol=1e-10 if f64 else 5e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["jac_unconstrained", "jac_constrained"])
+def test_autograd_jacobians_on_gpu(be, name):
+    """tests/test_mpc.py:303-500 end to end on the device: MPC.forward + autograd."""
+    from mpc import mpc
+    from mpc.mpc import LinDx, QuadCost
+    z = golden(name)
+    ns, nc, T, B = (int(v) for v in z["meta"])
+    beta = float(z["beta"][0])
+    tens = [dev(z[k]).requires_grad_(True) for k in ("C", "c", "x_init", "F", "f")]
+    C, c, x0, F, f = tens
+    lo = -beta * torch.ones(T, B, nc, dtype=torch.float64, device=DEV)
+    x, u, _ = mpc.MPC(ns, nc, T, lo, -lo, None, lqr_iter=20, verbose=-1, exit_unconverged=False)(
+        x0, QuadCost(C, c), LinDx(F, f))
+    np.testing.assert_allclose(host(u), z["u"], atol=1e-8)
+    uf = u.reshape(-1)
+    for i in range(len(uf)):
+        gs = torch.autograd.grad(uf[i], tens, retain_graph=True)
+        for k, g in zip(("dC", "dc", "dx_init", "dF", "df"), gs):
+            np.testing.assert_allclose(host(g).reshape(-1), z["J_" + k][i], atol=1e-8, err_msg=k)
+
+
+@pytest.mark.parametrize("name", PNQP_CASES)
+def test_pnqp_parity(be, name):
+    """mpc_pnqp == mpc/pnqp.py:5-82 per problem (incl. tests/test_mpc.py:65-88's n = 100 case)."""
+    z = golden(name)
+    r = be.pnqp(dev(z["H"]), dev(z["q"]), dev(z["lower"]), dev(z["upper"]), x_init=dev(z.get("x0")))
+    f64 = z["H"].dtype == np.float64
+    np.testing.assert_allclose(host(r["x"]), z["x_pp"], rtol=0, atol=1e-9 if f64 else 1e-5)
+    np.testing.assert_allclose(host(r["x"]), z["x_batch"], rtol=1e-3, atol=1e-4)
+    assert np.array_equal(host(r["If"]), z["If_pp"].astype(np.uint8))
+    if f64:
+        assert host(r["iters"]).tolist() == z["iters_pp"].tolist()
+    assert (host(r["status"]) == 0).all()
+    x = host(r["x"])
+    assert (x >= z["lower"]).all() and (x <= z["upper"]).all()
+    # public wrapper keeps the reference's return convention
+    from mpc import pnqp as pnqp_mod
+    xw, fac, If, n_it = pnqp_mod.pnqp(dev(z["H"]), dev(z["q"]), dev(z["lower"]), dev(z["upper"]), x_init=dev(z.get("x0")))
+    assert torch.equal(xw, r["x"]) and (isinstance(fac, tuple) if z["H"].shape[1] > 1 else torch.is_tensor(fac))
+
+
+def test_traj_cost_parity(be):
+    z = golden("traj_cost")
+    x, cost = be.traj_cost(dev(z["x_init"]), dev(z["u"]), dev(z["F"]), dev(z["f"]), dev(z["C"]), dev(z["c"]))
+    np.testing.assert_allclose(host(x), z["x"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(host(cost), z["cost"], rtol=1e-12)
+
+
+def test_select_best_kernel(be):
+    g = torch.Generator().manual_seed(0)
+    T, B, ns, nc = 5, 37, 3, 2
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64).to(DEV)
+    best = dict(x=mk(T, B, ns), u=mk(T, B, nc), costs=mk(B), full_du_norm=mk(B).abs())
+    ref = {k: v.clone() for k, v in best.items()}
+    x, u, costs, du = mk(T, B, ns), mk(T, B, nc), mk(B), mk(B).abs()
+    any_imp, max_du = be.select_best(False, 1e-4, x, u, costs, du, best)
+    take = costs <= ref["costs"] + 1e-4
+    assert 0 < int(take.sum()) < B
+    assert torch.equal(best["x"], torch.where(take.view(1, B, 1), x, ref["x"]))
+    assert torch.equal(best["u"], torch.where(take.view(1, B, 1), u, ref["u"]))
+    assert torch.equal(best["costs"], torch.where(take, costs, ref["costs"]))
+    assert int(any_imp.item()) == 1 and float(max_du.item()) == float(du.max().item())
+    any_imp, _ = be.select_best(True, 1e-4, x, u, costs + 100, du, best)
+    assert torch.equal(best["x"], x) and int(any_imp.item()) == 0
+
+
+MPC_CASES = ["mpc_notebook_tvlq", "mpc_linear_unbounded_big_bounds", "mpc_linear_unbounded_none",
+             "mpc_linear_bounded", "mpc_linear_bounded_delta", "mpc_singleton_big_bounds", "mpc_singleton_none"]
+
+
+@pytest.mark.parametrize("name", MPC_CASES)
+def test_mpc_forward_on_gpu(be, name):
+    """Full mpc.MPC solves on the device == the reference's solves (tests/test_mpc.py:91-299)."""
+    from test_host_logic import run_mpc_golden
+    z = golden(name)
+    x, u, costs = run_mpc_golden(z, device=DEV)
+    assert x.is_cuda
+    tol = 1e-6 if z["C"].dtype == np.float64 else 2e-4
+    np.testing.assert_allclose(host(x), z["x"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(host(u), z["u"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(host(costs), z["costs"], rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size checks at BASELINE.json's north-star configuration (ns=12, nc=4, T=50, B=4096, fp32)
+# ------------------------------------------------------------------------------------------------
+def _ns_problem(B, bounded, seed=0):
+    import bench
+    return bench.make_problem(12, 4, 50, B, torch.float32, DEV, seed=seed, u_scale=0.3 if bounded else 0.0,
+                              clamp=1.0 if bounded else None)
+
+
+@pytest.mark.parametrize("bounded", [False, True])
+def test_north_star_full_size_vs_oracle(be, bounded):
+    """B = 4096 at the headline shape: every problem against the oracle (it finishes in seconds)."""
+    from mpc._native import StepOptions
+    from oracle import lqr_oracle as O
+    p = _ns_problem(4096, bounded)
+    opts = StepOptions(u_lower=-1.0, u_upper=1.0) if bounded else StepOptions()
+    h = {k: host(v) for k, v in p.items()}
+    o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"],
+                   -1.0 if bounded else None, 1.0 if bounded else None, lockstep=False,
+                   nthreads=O.max_threads())
+    o64 = O.lqr_step(*(h[k].astype(np.float64) for k in ("x_init", "C", "c", "F", "f", "cur_x", "cur_u")),
+                     -1.0 if bounded else None, 1.0 if bounded else None, lockstep=False,
+                     nthreads=O.max_threads())
+    from mpc import _native
+    for impl in (1, 2):
+        if not be.impl_supported(12, 4, torch.float32, impl):
+            continue
+        r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts, impl=impl)
+        torch.cuda.synchronize()
+        for k in ("new_x", "new_u"):
+            np.testing.assert_allclose(host(r[k]), o64[k], rtol=1e-3, atol=1e-4, err_msg="impl %d %s" % (impl, k))
+            close_with_ref_noise(host(r[k]), o[k], np.abs(o[k] - o64[k]), 1e-3, 1e-4)
+        np.testing.assert_allclose(host(r["costs"]), o64["costs"], rtol=1e-4)
+        assert int(host(r["status"]).max()) == 0
+
+
+def test_north_star_properties(be):
+    """Size-independent properties at B = 4096:
+       (1) an unconstrained LQR step from ANY nominal lands on the optimum, so a second step from
+           there is a fixed point (||du|| ~ 0, same cost) -- idempotence;
+       (2) the optimum does not depend on the nominal it was reached from;
+       (3) costs never exceed the nominal's when the line search accepted (alpha > 0);
+       (4) bounded: controls inside the box, and the free-set gradient condition via a 2nd step."""
+    from mpc._native import StepOptions
+    p = _ns_problem(4096, False, seed=3)
+    r1 = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions())
+    r2 = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], r1["new_x"], r1["new_u"], StepOptions())
+    scale = r1["new_u"].abs().max().item()
+    assert (r2["full_du_norm"] / scale).max().item() < 5e-3
+    assert torch.allclose(r2["costs"], r1["costs"], rtol=2e-4)
+    assert (r1["costs"] <= r1["old_costs"] * (1 + 1e-5) + 1e-3).all()
+    q = _ns_problem(4096, True, seed=3)       # same problem data, a different (nonzero) nominal
+    r3 = be.lqr_step(q["x_init"], q["C"], q["c"], q["F"], q["f"], q["cur_x"], q["cur_u"], StepOptions())
+    assert torch.allclose(q["C"], p["C"]) and not torch.allclose(q["cur_u"], p["cur_u"])
+    assert (r3["new_u"] - r1["new_u"]).abs().max().item() < 2e-3 * max(1.0, scale)
+    ob = StepOptions(u_lower=-1.0, u_upper=1.0)
+    r4 = be.lqr_step(q["x_init"], q["C"], q["c"], q["F"], q["f"], q["cur_x"], q["cur_u"], ob)
+    assert r4["new_u"].min().item() >= -1.0 and r4["new_u"].max().item() <= 1.0
+    ok = r4["alphas"] > 0
+    assert (r4["costs"][ok] <= r4["old_costs"][ok] * (1 + 1e-5) + 1e-3).all()
+    assert int(r4["status"].max().item()) & 2 == 0
