@@ -55,22 +55,22 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
     }
     const int64_t needK = (int64_t)p->T * p->B * p->nc * p->ns * (int64_t)sizeof(real);
     const int64_t needk = (int64_t)p->T * p->B * p->nc * (int64_t)sizeof(real);
-    bool fast = false;
-    if (phase_mask == 3 && impl != 1) {
-        if constexpr (sizeof(real) == 4) {
-            fast = mfma16_supported(sp);
-            if (impl == 2 && !fast) return fail(MPC_E_DIMS, "fused MFMA kernel needs fp32 and n_state+n_ctrl <= 16");
-            if (fast) return launch_step_mfma16(sp, st);
-        } else if (impl == 2) {
-            return fail(MPC_E_DTYPE, "fused MFMA kernel is fp32 only");
-        }
-    }
     if (!sp.K || !sp.k) {
         if (phase_mask != 3) return fail(MPC_E_NULL, "K / k is NULL");
         if (!workspace || workspace_bytes < needK + needk)
             return fail(MPC_E_ARG, "workspace too small (see mpc_lqr_workspace_bytes)");
         sp.K = (real *)workspace;
         sp.k = (real *)((char *)workspace + needK);
+    }
+    if (phase_mask == 3 && impl != 1) {
+        if constexpr (sizeof(real) == 4) {
+            const bool fast = mfma16_supported(sp);
+            if (impl == 2 && !fast)
+                return fail(MPC_E_DIMS, "fused MFMA kernel needs fp32, n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16");
+            if (fast) return launch_step_mfma16(sp, st);
+        } else if (impl == 2) {
+            return fail(MPC_E_DTYPE, "fused MFMA kernel is fp32 only");
+        }
     }
     return launch_step_generic<real>(sp, phase_mask, st);
 }

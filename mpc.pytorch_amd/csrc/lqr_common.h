@@ -9,61 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/mpc_lqr.h"
+#include "lqr_params.h"
 
 namespace mpclqr {
-
-template <typename real>
-struct StepParams {
-    int B, T, ns, nc;
-    const real *x_init, *C, *c, *F, *f, *cur_x, *cur_u;
-    long C_st, C_sb, c_st, c_sb, F_st, F_sb, f_st, f_sb;
-    int bound_mode;
-    real lo_s, hi_s;
-    const real *lo, *hi;
-    const uint8_t *zero_mask;
-    int has_delta;
-    real delta_u;
-    real ls_decay;
-    int max_ls;
-    int pnqp_iter;
-    // outputs
-    real *new_x, *new_u, *costs, *old_costs, *full_du_norm, *alpha_du_norm, *alphas;
-    int *qp_iters, *status;
-    real *K, *k;                 // [T,B,nc,ns], [T,B,nc]
-    const real *old_costs_in;    // rollout-only entry point
-};
-
-template <typename real>
-inline StepParams<real> make_params(const mpc_lqr_problem *p, const mpc_lqr_options *o,
-                                    const mpc_lqr_outputs *out)
-{
-    StepParams<real> s;
-    s.B = p->B; s.T = p->T; s.ns = p->ns; s.nc = p->nc;
-    s.x_init = (const real *)p->x_init;
-    s.C = (const real *)p->C; s.C_st = p->C_st; s.C_sb = p->C_sb;
-    s.c = (const real *)p->c; s.c_st = p->c_st; s.c_sb = p->c_sb;
-    s.F = (const real *)p->F; s.F_st = p->F_st; s.F_sb = p->F_sb;
-    s.f = (const real *)p->f; s.f_st = p->f_st; s.f_sb = p->f_sb;
-    s.cur_x = (const real *)p->cur_x; s.cur_u = (const real *)p->cur_u;
-    s.bound_mode = o ? o->bound_mode : 0;
-    s.lo_s = o ? (real)o->lo_s : (real)0; s.hi_s = o ? (real)o->hi_s : (real)0;
-    s.lo = o ? (const real *)o->lo : nullptr; s.hi = o ? (const real *)o->hi : nullptr;
-    s.zero_mask = o ? o->zero_mask : nullptr;
-    s.has_delta = (o && o->delta_u == o->delta_u && o->delta_u >= 0) ? 1 : 0;
-    s.delta_u = s.has_delta ? (real)o->delta_u : (real)0;
-    s.ls_decay = o ? (real)o->linesearch_decay : (real)0.2;
-    s.max_ls = o ? o->max_linesearch_iter : 10;
-    s.pnqp_iter = (o && o->pnqp_iter > 0) ? o->pnqp_iter : 20;
-    s.new_x = out ? (real *)out->new_x : nullptr; s.new_u = out ? (real *)out->new_u : nullptr;
-    s.costs = out ? (real *)out->costs : nullptr; s.old_costs = out ? (real *)out->old_costs : nullptr;
-    s.full_du_norm = out ? (real *)out->full_du_norm : nullptr;
-    s.alpha_du_norm = out ? (real *)out->alpha_du_norm : nullptr;
-    s.alphas = out ? (real *)out->alphas : nullptr;
-    s.qp_iters = out ? out->qp_iters : nullptr; s.status = out ? out->status : nullptr;
-    s.K = out ? (real *)out->K : nullptr; s.k = out ? (real *)out->k : nullptr;
-    s.old_costs_in = nullptr;
-    return s;
-}
 
 void set_last_error(const char *msg);
 

@@ -1,6 +1,76 @@
-// placeholder until the fused kernel lands
+// lqr_mfma16.hip -- gfx950 binding of the fused MFMA LQR step (lqr_mfma16_body.h).
+//
+// One 64-lane wavefront per problem, one workgroup per wavefront, no LDS: at the headline
+// shape (n_state=12, n_ctrl=4, T=50, B=4096) that is 4096 wavefronts = 16 per CU = 4 per
+// SIMD, all resident at once (__launch_bounds__(64, 4) keeps the kernel at <= 128 VGPRs).
+// Every per-timestep block is streamed from HBM exactly once per pass with loads issued two
+// timesteps ahead of their use; the matrix work runs on v_mfma_f32_16x16x4_f32.
+#include <string>
 #include "lqr_common.h"
+
+#define MPC_DEV __device__ __forceinline__
+
 namespace mpclqr {
-bool mfma16_supported(const StepParams<float> &) { return false; }
-int launch_step_mfma16(const StepParams<float> &, hipStream_t) { set_last_error("mfma16 kernel not built"); return MPC_E_DIMS; }
+namespace wv {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+MPC_DEV int lane() { return (int)threadIdx.x; }
+MPC_DEV int problem() { return (int)blockIdx.x; }
+MPC_DEV f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+MPC_DEV float readlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+MPC_DEV int readlane_i(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+MPC_DEV float shfl_xor(float x, int m) { return __shfl_xor(x, m, 64); }
+MPC_DEV float rcp(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.f), r, r);     // one Newton step: <= 1 ulp
 }
+MPC_DEV bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+MPC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+MPC_DEV unsigned long long ballot(bool c) { return __ballot(c); }
+MPC_DEV int ctz64(unsigned long long m) { return __builtin_ctzll(m); }
+MPC_DEV void fence_own_stores()
+{
+    // same-CU visibility of this wave's own global stores to its later loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+}  // namespace wv
+}  // namespace mpclqr
+
+#include "lqr_mfma16_body.h"
+
+namespace mpclqr {
+namespace {
+
+template <bool FULL>
+__global__ void __launch_bounds__(64, 4) lqr_step_mfma16_kernel(StepParams<float> p)
+{
+    mfma16::step_problem<FULL>(p);
+}
+
+}  // namespace
+
+bool mfma16_supported(const StepParams<float> &p)
+{
+    return p.ns >= 1 && p.ns <= 12 && p.nc >= 1 && p.nc <= 4 && p.max_ls >= 1 && p.max_ls <= 16 && p.T >= 1;
+}
+
+int launch_step_mfma16(const StepParams<float> &p, hipStream_t st)
+{
+    if (!mfma16_supported(p)) { set_last_error("mfma16: needs n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16"); return MPC_E_DIMS; }
+    if (!p.K || !p.k) { set_last_error("mfma16: K / k scratch missing"); return MPC_E_NULL; }
+    if (!p.new_x || !p.new_u) { set_last_error("mfma16: new_x / new_u is NULL"); return MPC_E_NULL; }
+    if (p.ns == 12 && p.nc == 4)
+        hipLaunchKernelGGL(lqr_step_mfma16_kernel<true>, dim3(p.B), dim3(64), 0, st, p);
+    else
+        hipLaunchKernelGGL(lqr_step_mfma16_kernel<false>, dim3(p.B), dim3(64), 0, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error((std::string("lqr_step_mfma16_kernel: ") + hipGetErrorString(e)).c_str());
+        return MPC_E_LAUNCH;
+    }
+    return MPC_OK;
+}
+
+}  // namespace mpclqr

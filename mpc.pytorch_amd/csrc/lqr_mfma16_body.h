@@ -1,0 +1,672 @@
+// lqr_mfma16_body.h -- the fused LQR step for n_state <= 12, n_ctrl <= 4, fp32:
+// one 64-lane wavefront owns one problem for the whole horizon, every matrix
+// product of the step is a v_mfma_f32_16x16x4_f32 (exact fp32), and NO data ever
+// moves between lanes except a handful of readlanes of the 4x4 control block.
+//
+// This file is written against a tiny "wave" interface (namespace wv: lane(),
+// mfma(), readlane(), ...).  lqr_mfma16.hip binds it to the gfx950 builtins;
+// tests/emu/emu_mfma16.cpp binds it to a host-side 64-fiber lockstep emulator so
+// the very same source is parity-tested on a CPU-only box.
+//
+// What it replaces in locuslab/mpc.pytorch (one launch instead of ~4,000 ATen ops):
+//   sweep_step     mpc/lqr_step.py:284-296 (c_back) + :52-160 (lqr_backward)
+//   pnqp4          mpc/pnqp.py:5-82 (the in-sweep n_ctrl-dimensional box QP)
+//   rollout_pass   mpc/lqr_step.py:164-261 (lqr_forward), mpc/util.py:129-153
+//
+// ---------------------------------------------------------------------------
+// Layout.  MFMA 16x16x4 f32: lane l = 16 g + j holds  A[i=j][k=g],  B[k=g][j],
+// and D[4g+r][j] in accumulator register r.  The 16 variables of tau = [x;u] are
+// given "slots" rho = 0..15 so that u_a sits at rho = 4a (register 0 of lane
+// group a) and x_m at rho = 4 (m/3) + 1 + m%3 (registers 1..3):
+//
+//   * a symmetric matrix held in D layout IS its own A operand (block kb = register
+//     kb, contraction slot (g,kb) <-> rho = 4g+kb), so  Y = V F  and  Q = C + F'Y
+//     chain through registers with no shuffles; F is loaded once as lane (g,j) ->
+//     F[x-slot(g,kb)][var j] and serves as B of the first and A of the second product.
+//   * the four u-rows of Q land in register 0 spread over the four lane groups,
+//     which is exactly the B operand of K = -Quu^-1 [Qux|qu] and the A operand of
+//     Qxu K; K and M = Qux + Quu K come out of their MFMAs in that same layout.
+//   * column j = 0 carries the linear terms: Q'[:,0] = q, K'[:,0] = k, M'[:,0] =
+//     qu + Quu k, V'[:,0] = v.  (Q[u0][u0], the one entry that loses its place,
+//     is rebuilt from 3 FMAs + 4 readlanes.)
+//   * the rollout propagates SIXTEEN line-search candidates at once: column j of
+//     the B operand is the state of the trial with alpha = decay^j, so the whole
+//     line search of mpc/lqr_step.py:176-252 is one pass over C, F (a second pass
+//     re-runs the accepted column only when alpha = 1 was rejected).
+//
+// C is read as the symmetric matrix the reference documents it to be
+// (mpc/mpc.py:61-68; its own delta-space gradient C tau + c, :294, is only a
+// gradient for symmetric C).
+// ---------------------------------------------------------------------------
+#pragma once
+#include <math.h>
+#include "lqr_params.h"
+
+namespace mpclqr {
+namespace mfma16 {
+
+typedef StepParams<float> P;
+using wv::f32x4;
+
+struct Lane {
+    int g, j;
+    bool j0, jq;          // j == 0 (vector column), (j & 3) == 0 (u column)
+    int ja;               // j >> 2
+    int col;              // tau index of column slot j (0 if padding)
+    bool colv;
+    int row[4];           // tau-or-x index of row slot 4g+r: r = 0 -> control g, r >= 1 -> state 3g+r-1
+    bool rowv[4];
+    int offC[4];          // row[r]-as-tau-index * n + col     (C in D layout; rows 1..3 double as F rows)
+    int offT[4];          // col * n + row[r]-as-tau-index      (F as the rollout's A operand)
+    bool vC[4], vT[4];
+};
+
+MPC_DEV void lane_init(Lane &L, int lane, int ns, int nc)
+{
+    const int n = ns + nc;
+    L.g = lane >> 4;
+    L.j = lane & 15;
+    L.j0 = L.j == 0;
+    L.jq = (L.j & 3) == 0;
+    L.ja = L.j >> 2;
+    int coltau;
+    if (L.jq) { L.colv = L.ja < nc; coltau = ns + L.ja; }
+    else { const int x = 3 * L.ja + (L.j & 3) - 1; L.colv = x < ns; coltau = x; }
+    if (!L.colv) coltau = 0;
+    L.col = coltau;
+    for (int r = 0; r < 4; ++r) {
+        int tau;
+        if (r == 0) { L.rowv[0] = L.g < nc; L.row[0] = L.g; tau = ns + L.g; }
+        else { const int x = 3 * L.g + r - 1; L.rowv[r] = x < ns; L.row[r] = x; tau = x; }
+        if (!L.rowv[r]) { L.row[r] = 0; tau = 0; }
+        L.vC[r] = L.rowv[r] && L.colv;
+        L.offC[r] = L.vC[r] ? tau * n + coltau : 0;
+        // rollout: output row = state x(j) (x columns only), contraction slot = (g, r)
+        L.vT[r] = L.rowv[r] && L.colv && !L.jq;
+        L.offT[r] = L.vT[r] ? coltau * n + tau : 0;
+    }
+}
+
+MPC_DEV float sel(bool c, float a, float b) { return c ? a : b; }
+
+// ---------------------------------------------------------------------------
+// 4x4 symmetric factorisation  S = L D L'  on wave-uniform values (every lane
+// computes the same numbers).  Non-free rows/columns are replaced by identity.
+// Stands in for Tensor.lu()/lu_solve (mpc/pnqp.py:53-54, mpc/lqr_step.py:125-127,148)
+// and for the per-sample pinverse of mpc/lqr_step.py:88-94 (identical for SPD Quu).
+// ---------------------------------------------------------------------------
+struct Sym4 { float s00, s01, s02, s03, s11, s12, s13, s22, s23, s33; };
+struct Ldl4 { float l10, l20, l30, l21, l31, l32, i0, i1, i2, i3; };
+
+MPC_DEV void ldl4(Ldl4 &f, const Sym4 &s, const bool fr[4], float reg)
+{
+    const float a00 = fr[0] ? s.s00 + reg : 1.f;
+    const float a10 = (fr[0] && fr[1]) ? s.s01 : 0.f;
+    const float a20 = (fr[0] && fr[2]) ? s.s02 : 0.f;
+    const float a30 = (fr[0] && fr[3]) ? s.s03 : 0.f;
+    const float a11 = fr[1] ? s.s11 + reg : 1.f;
+    const float a21 = (fr[1] && fr[2]) ? s.s12 : 0.f;
+    const float a31 = (fr[1] && fr[3]) ? s.s13 : 0.f;
+    const float a22 = fr[2] ? s.s22 + reg : 1.f;
+    const float a32 = (fr[2] && fr[3]) ? s.s23 : 0.f;
+    const float a33 = fr[3] ? s.s33 + reg : 1.f;
+    f.i0 = wv::rcp(a00);
+    f.l10 = a10 * f.i0; f.l20 = a20 * f.i0; f.l30 = a30 * f.i0;
+    const float d1 = fmaf(-f.l10, a10, a11);
+    f.i1 = wv::rcp(d1);
+    const float t21 = fmaf(-f.l20, a10, a21);
+    const float t31 = fmaf(-f.l30, a10, a31);
+    f.l21 = t21 * f.i1; f.l31 = t31 * f.i1;
+    const float d2 = fmaf(-f.l21, t21, fmaf(-f.l20, a20, a22));
+    f.i2 = wv::rcp(d2);
+    const float t32 = fmaf(-f.l31, t21, fmaf(-f.l30, a20, a32));
+    f.l32 = t32 * f.i2;
+    const float d3 = fmaf(-f.l32, t32, fmaf(-f.l31, t31, fmaf(-f.l30, a30, a33)));
+    f.i3 = wv::rcp(d3);
+}
+
+MPC_DEV void ldl4_solve(const Ldl4 &f, float r0, float r1, float r2, float r3, float y[4])
+{
+    const float z0 = r0;
+    const float z1 = fmaf(-f.l10, z0, r1);
+    const float z2 = fmaf(-f.l21, z1, fmaf(-f.l20, z0, r2));
+    const float z3 = fmaf(-f.l32, z2, fmaf(-f.l31, z1, fmaf(-f.l30, z0, r3)));
+    const float w0 = z0 * f.i0, w1 = z1 * f.i1, w2 = z2 * f.i2, w3 = z3 * f.i3;
+    y[3] = w3;
+    y[2] = fmaf(-f.l32, y[3], w2);
+    y[1] = fmaf(-f.l31, y[3], fmaf(-f.l21, y[2], w1));
+    y[0] = fmaf(-f.l30, y[3], fmaf(-f.l20, y[2], fmaf(-f.l10, y[1], w0)));
+}
+
+MPC_DEV void sym4_mv(const Sym4 &s, const float x[4], float y[4])
+{
+    y[0] = fmaf(s.s03, x[3], fmaf(s.s02, x[2], fmaf(s.s01, x[1], s.s00 * x[0])));
+    y[1] = fmaf(s.s13, x[3], fmaf(s.s12, x[2], fmaf(s.s11, x[1], s.s01 * x[0])));
+    y[2] = fmaf(s.s23, x[3], fmaf(s.s22, x[2], fmaf(s.s12, x[1], s.s02 * x[0])));
+    y[3] = fmaf(s.s33, x[3], fmaf(s.s23, x[2], fmaf(s.s13, x[1], s.s03 * x[0])));
+}
+
+MPC_DEV float eclampf(float x, float lo, float hi)
+{
+    // util.eclamp (mpc/util.py:56-70): strict compares, the bound value is written exactly
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
+}
+
+MPC_DEV float qp_obj4(const Sym4 &s, const float q[4], const float x[4])
+{
+    float hx[4];
+    sym4_mv(s, x, hx);
+    const float quad = fmaf(x[3], hx[3], fmaf(x[2], hx[2], fmaf(x[1], hx[1], x[0] * hx[0])));
+    const float lin = fmaf(q[3], x[3], fmaf(q[2], x[2], fmaf(q[1], x[1], q[0] * x[0])));
+    return fmaf(0.5f, quad, lin);
+}
+
+// Projected-Newton box QP in n_ctrl <= 4 unknowns on wave-uniform values
+// (mpc/pnqp.py:5-82 with n_batch = 1).  x holds the clamped start on entry and the
+// solution on exit; fr/f are the free set and factorisation the reference returns
+// (those of the iteration that detected convergence, or of the last one).
+MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const float ub[4],
+                         const bool valid[4], int n_iter, float x[4], bool fr[4], Ldl4 &f, bool &converged)
+{
+    int it_ret = n_iter - 1;
+    converged = false;
+    for (int it = 0; it < n_iter; ++it) {
+        float g[4];
+        sym4_mv(s, x, g);                                           // :29
+        float gm[4];
+        for (int a = 0; a < 4; ++a) {
+            g[a] += q[a];
+            const bool ic = ((x[a] == lb[a]) && (g[a] > 0.f)) || ((x[a] == ub[a]) && (g[a] < 0.f));   // :32
+            fr[a] = valid[a] && !ic;
+            gm[a] = fr[a] ? g[a] : 0.f;
+        }
+        ldl4(f, s, fr, 1e-11f);                                      // :44-48
+        float dx[4];
+        ldl4_solve(f, gm[0], gm[1], gm[2], gm[3], dx);               // :50-54
+        float nrm2 = 0.f;
+        for (int a = 0; a < 4; ++a) {
+            dx[a] = fr[a] ? -dx[a] : 0.f;
+            nrm2 = fmaf(dx[a], dx[a], nrm2);
+        }
+        if (wv::uniform(!(sqrtf(nrm2) >= 1e-4f))) {                 // :56-59
+            converged = true;
+            it_ret = it;
+            break;
+        }
+        // :61-76 Armijo backtracking
+        float alpha = 1.f;
+        const float obj_x = qp_obj4(s, q, x);
+        float mx[4];
+        for (int count = 0; count < 10; ++count) {
+            for (int a = 0; a < 4; ++a) mx[a] = eclampf(fmaf(alpha, dx[a], x[a]), lb[a], ub[a]);
+            const float obj_m = qp_obj4(s, q, mx);
+            float den = 0.f;
+            for (int a = 0; a < 4; ++a) den = fmaf(g[a], x[a] - mx[a], den);
+            const float arm = (obj_x - obj_m) / den;
+            if (wv::uniform(arm <= 0.1f)) alpha *= 0.1f; else break;
+        }
+        for (int a = 0; a < 4; ++a) x[a] = mx[a];                    // :78
+    }
+    return it_ret;
+}
+
+// ---------------------------------------------------------------------------
+// Sweep
+// ---------------------------------------------------------------------------
+struct SwStage {
+    float C[4];       // C_t in D layout (register r = row slot 4g+r)
+    float F[3];       // F_t rows x-slot(g,kb), kb = 1..3, at column var(j)
+    float crow[4];    // c_t in row layout (wave-group uniform)
+    float trow[4];    // nominal tau_t in row layout: [u_g, x_3g, x_3g+1, x_3g+2]
+    float lo, hi;     // control bounds of u_g (tensor or scalar mode)
+    int zm;           // u_zero_I of u_g
+};
+
+template <bool FULL>
+MPC_DEV void sw_load(SwStage &s, const P &p, const Lane &L, int b, int t)
+{
+    const long tb = (long)t * p.B + b;
+    const float *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+    const float *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v = Ct[L.offC[r]];
+        s.C[r] = FULL ? v : sel(L.vC[r], v, 0.f);
+        const float w = ct[r == 0 ? p.ns + L.row[0] : L.row[r]];
+        s.crow[r] = FULL ? w : sel(L.rowv[r], w, 0.f);
+    }
+    if (t < p.T - 1) {
+        const float *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
+#pragma unroll
+        for (int kb = 1; kb < 4; ++kb) {
+            const float v = Ft[L.offC[kb]];
+            s.F[kb - 1] = FULL ? v : sel(L.vC[kb], v, 0.f);
+        }
+    } else {
+        s.F[0] = s.F[1] = s.F[2] = 0.f;
+    }
+    {
+        const float v = p.cur_u[tb * p.nc + L.row[0]];
+        s.trow[0] = FULL ? v : sel(L.rowv[0], v, 0.f);
+    }
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        const float v = p.cur_x[tb * p.ns + L.row[r]];
+        s.trow[r] = FULL ? v : sel(L.rowv[r], v, 0.f);
+    }
+    s.lo = s.hi = 0.f;
+    if (p.bound_mode == MPC_BOUND_TENSOR) {
+        s.lo = p.lo[tb * p.nc + L.row[0]];
+        s.hi = p.hi[tb * p.nc + L.row[0]];
+    } else if (p.bound_mode == MPC_BOUND_SCALAR) {
+        s.lo = p.lo_s;
+        s.hi = p.hi_s;
+    }
+    s.zm = 0;
+    if (p.zero_mask) s.zm = L.rowv[0] ? (int)p.zero_mask[tb * p.nc + L.row[0]] : 0;
+}
+
+struct SwState {
+    f32x4 Vp;          // V' in D layout: rows/cols = x slots, column 0 = v, u slots = finite junk
+    float oc;          // nominal-cost partial (lanes j == 0)
+    float kprev[4];    // warm start of the next pnqp = k_{t+1}   (mpc/lqr_step.py:137,141)
+    int warm;
+    int qp_total;
+    int status;
+};
+
+template <bool FULL>
+MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st, int b, int t)
+{
+    const bool last = (t == p.T - 1);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // c_back - c = C tau  (mpc/lqr_step.py:289-295): contraction over all 16 slots, column 0 only
+    f32x4 CB = zero4;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) CB = wv::mfma(s.C[kb], sel(L.j0, s.trow[kb], 0.f), CB);
+
+    // Y = V_{t+1} F_t   (:65-70), x slots only (kb = 1..3)
+    f32x4 Y = zero4;
+    f32x4 Q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Q[r] = sel(L.j0, s.crow[r], s.C[r]);
+    float q00p = 0.f;
+    if (!last) {
+#pragma unroll
+        for (int kb = 1; kb < 4; ++kb) Y = wv::mfma(st.Vp[kb], s.F[kb - 1], Y);
+        // Q = C + F'Y ; column 0: F'v  (Y's column 0 is swapped for v = V'[:,0])
+        q00p = fmaf(s.F[2], Y[3], fmaf(s.F[1], Y[2], s.F[0] * Y[1]));
+#pragma unroll
+        for (int kb = 1; kb < 4; ++kb) Q = wv::mfma(s.F[kb - 1], sel(L.j0, st.Vp[kb], Y[kb]), Q);
+    }
+    // nominal cost 0.5 tau'C tau + c'tau (util.get_cost, mpc/lqr_step.py:169) off the same product
+    {
+        float ocl = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ocl = fmaf(s.trow[r], fmaf(0.5f, CB[r], s.crow[r]), ocl);
+        st.oc += sel(L.j0, ocl, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Q[r] += CB[r];          // CB is exactly 0 outside column 0
+
+    // ---- the 4x4 control block, wave-uniform -------------------------------------------------
+    const float U = Q[0];        // lane (g,j): Q[u_g][var j]; lane (g,0): qu[g]
+    Sym4 S;
+    S.s01 = wv::readlane(U, 4);  S.s02 = wv::readlane(U, 8);  S.s03 = wv::readlane(U, 12);
+    S.s11 = wv::readlane(U, 20); S.s12 = wv::readlane(U, 24); S.s13 = wv::readlane(U, 28);
+    S.s22 = wv::readlane(U, 40); S.s23 = wv::readlane(U, 44);
+    S.s33 = wv::readlane(U, 60);
+    S.s00 = wv::readlane(s.C[0], 0);
+    if (!last)
+        S.s00 += (wv::readlane(q00p, 0) + wv::readlane(q00p, 16)) + (wv::readlane(q00p, 32) + wv::readlane(q00p, 48));
+    float qu[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) qu[a] = wv::readlane(U, 16 * a);
+
+    bool valid[4], fr[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) valid[a] = a < p.nc;
+    Ldl4 f;
+    float kq[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool bounded = p.bound_mode != MPC_BOUND_NONE;
+    if (!bounded) {
+        // :84-94 unconstrained / :99-127 masked (u_zero_I): masked rows and columns drop out
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            fr[a] = valid[a];
+            if (p.zero_mask) fr[a] = fr[a] && (wv::readlane_i(s.zm, 16 * a) == 0);
+        }
+        ldl4(f, S, fr, 0.f);
+    } else {
+        // :128-141 box constraints in delta space
+        float lb[4], ub[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float u = wv::readlane(s.trow[0], 16 * a);
+            float l = wv::readlane(s.lo, 16 * a) - u;
+            float h = wv::readlane(s.hi, 16 * a) - u;
+            if (p.has_delta) {                                      // :132-134
+                if (l < -p.delta_u) l = -p.delta_u;
+                if (h > p.delta_u) h = p.delta_u;
+            }
+            lb[a] = valid[a] ? l : 0.f;
+            ub[a] = valid[a] ? h : 0.f;
+        }
+        if (!st.warm) {
+            // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
+            ldl4(f, S, valid, 0.f);
+            float y[4];
+            ldl4_solve(f, valid[0] ? qu[0] : 0.f, valid[1] ? qu[1] : 0.f, valid[2] ? qu[2] : 0.f,
+                       valid[3] ? qu[3] : 0.f, y);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) kq[a] = valid[a] ? -y[a] : 0.f;
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) kq[a] = st.kprev[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) kq[a] = eclampf(kq[a], lb[a], ub[a]);
+        bool conv = false;
+        const int it = pnqp4(S, qu, lb, ub, valid, p.pnqp_iter, kq, fr, f, conv);
+        st.qp_total += 1 + it;                                      // :140
+        if (!conv) st.status |= MPC_ST_PNQP_UNCONVERGED;
+        st.warm = 1;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) st.kprev[a] = kq[a];
+    }
+
+    // A operand of K' = -H_free^-1 [Qux | qu]: lane (i = 4a, g) holds -inv[a][g]
+    float Ainv;
+    {
+        float y[4];
+        ldl4_solve(f, L.g == 0 ? 1.f : 0.f, L.g == 1 ? 1.f : 0.f, L.g == 2 ? 1.f : 0.f, L.g == 3 ? 1.f : 0.f, y);
+        float val = L.ja == 0 ? y[0] : (L.ja == 1 ? y[1] : (L.ja == 2 ? y[2] : y[3]));
+        const bool fa = L.ja == 0 ? fr[0] : (L.ja == 1 ? fr[1] : (L.ja == 2 ? fr[2] : fr[3]));
+        const bool fg = L.g == 0 ? fr[0] : (L.g == 1 ? fr[1] : (L.g == 2 ? fr[2] : fr[3]));
+        Ainv = (L.jq && fa && fg) ? -val : 0.f;
+    }
+    f32x4 Kacc = wv::mfma(Ainv, U, zero4);
+    float Kp = Kacc[0];           // lane (g,j): K[g][var j]; lane (g,0): k[g]
+    if (bounded) {
+        const float kg = L.g == 0 ? kq[0] : (L.g == 1 ? kq[1] : (L.g == 2 ? kq[2] : kq[3]));
+        Kp = sel(L.j0, kg, Kp);   // k is the QP solution itself (:136-141)
+    }
+    // A operand Quu (unmasked, :155-158): lane (i = 4a, g) holds Quu[a][g] = U at the same lane,
+    // except column 0 where U carries qu: there Quu[0][g] is needed.
+    float Aquu;
+    {
+        const float s0g = L.g == 0 ? S.s00 : (L.g == 1 ? S.s01 : (L.g == 2 ? S.s02 : S.s03));
+        Aquu = L.jq ? sel(L.j0, s0g, U) : 0.f;
+    }
+    f32x4 Min = zero4;
+    Min[0] = U;
+    const f32x4 Macc = wv::mfma(Aquu, Kp, Min);
+    const float Mp = Macc[0];     // lane (g,j): (Qux + Quu K)[g][var j]; lane (g,0): qu + Quu k
+
+    // :155-158  V = Qxx + Qxu K + K'(Qux + Quu K),  v = qx + Qxu k + K'(qu + Quu k)
+    f32x4 Vn = wv::mfma(U, Kp, Q);
+    Vn = wv::mfma(Kp, Mp, Vn);
+    st.Vp = Vn;
+
+    // gains out: K [T,B,nc,ns], k [T,B,nc]
+    {
+        const long tb = (long)t * p.B + b;
+        if (L.rowv[0]) {
+            if (L.j0) p.k[tb * p.nc + L.g] = Kp;
+            else if (!L.jq && L.colv) p.K[(tb * p.nc + L.g) * p.ns + L.col] = Kp;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Rollout
+// ---------------------------------------------------------------------------
+struct RoStage {
+    float C[4];       // C_t, D layout (A operand of C tau')
+    float FA[4];      // F_t as A operand: lane (i = x slot, g), block kb -> F[x(i)][var(4g+kb)]
+    float KA[3];      // K_t as A operand: lane (i = 4a, g), block kb -> K[a][x-slot(g,kb)]
+    float crow[4];
+    float xbar[3];    // nominal x_t, row layout
+    float frow[3];    // f_t, row layout
+    float ubar, kk;   // nominal u_g, feed-forward k_g
+    float lo, hi;
+    int zm;
+};
+
+template <bool FULL>
+MPC_DEV void ro_load(RoStage &s, const P &p, const Lane &L, int b, int t)
+{
+    const long tb = (long)t * p.B + b;
+    const float *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+    const float *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v = Ct[L.offC[r]];
+        s.C[r] = FULL ? v : sel(L.vC[r], v, 0.f);
+        const float w = ct[r == 0 ? p.ns + L.row[0] : L.row[r]];
+        s.crow[r] = FULL ? w : sel(L.rowv[r], w, 0.f);
+    }
+    if (t < p.T - 1) {
+        const float *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const float v = Ft[L.offT[kb]];
+            s.FA[kb] = sel(L.vT[kb], v, 0.f);
+        }
+        if (p.f) {
+            const float *ft = p.f + (long)t * p.f_st + (long)b * p.f_sb;
+#pragma unroll
+            for (int kb = 1; kb < 4; ++kb) {
+                const float v = ft[L.row[kb]];
+                s.frow[kb - 1] = FULL ? v : sel(L.rowv[kb], v, 0.f);
+            }
+        } else {
+            s.frow[0] = s.frow[1] = s.frow[2] = 0.f;
+        }
+    } else {
+        s.FA[0] = s.FA[1] = s.FA[2] = s.FA[3] = 0.f;
+        s.frow[0] = s.frow[1] = s.frow[2] = 0.f;
+    }
+    {
+        const bool ka = L.jq && (L.ja < p.nc);
+        const float *Kt = p.K + (tb * p.nc + (ka ? L.ja : 0)) * p.ns;
+#pragma unroll
+        for (int kb = 1; kb < 4; ++kb) {
+            const float v = Kt[L.row[kb]];
+            s.KA[kb - 1] = sel(ka && L.rowv[kb], v, 0.f);
+        }
+    }
+#pragma unroll
+    for (int kb = 1; kb < 4; ++kb) {
+        const float v = p.cur_x[tb * p.ns + L.row[kb]];
+        s.xbar[kb - 1] = FULL ? v : sel(L.rowv[kb], v, 0.f);
+    }
+    {
+        const float v = p.cur_u[tb * p.nc + L.row[0]];
+        s.ubar = FULL ? v : sel(L.rowv[0], v, 0.f);
+        const float w = p.k[tb * p.nc + L.row[0]];
+        s.kk = FULL ? w : sel(L.rowv[0], w, 0.f);
+    }
+    s.lo = s.hi = 0.f;
+    if (p.bound_mode == MPC_BOUND_TENSOR) {
+        s.lo = p.lo[tb * p.nc + L.row[0]];
+        s.hi = p.hi[tb * p.nc + L.row[0]];
+    } else if (p.bound_mode == MPC_BOUND_SCALAR) {
+        s.lo = p.lo_s;
+        s.hi = p.hi_s;
+    }
+    s.zm = 0;
+    if (p.zero_mask) s.zm = L.rowv[0] ? (int)p.zero_mask[tb * p.nc + L.row[0]] : 0;
+}
+
+struct RoState {
+    float xrow[3];    // x'_t of trial j (column j), row layout
+    float cost;       // partial of this lane group
+    float du2;
+    float alpha;      // step of trial j
+};
+
+template <bool FULL>
+MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &st, int b, int t, int jsel)
+{
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bool last = (t == p.T - 1);
+    // new_u = K dx + u + alpha k   (mpc/lqr_step.py:192)
+    f32x4 Uacc = zero4;
+#pragma unroll
+    for (int kb = 1; kb < 4; ++kb) Uacc = wv::mfma(s.KA[kb - 1], st.xrow[kb - 1] - s.xbar[kb - 1], Uacc);
+    // x_{t+1} = F [x;u] + f  (:216-222): the x part does not wait for u
+    f32x4 Xacc = zero4;
+    Xacc[1] = s.frow[0]; Xacc[2] = s.frow[1]; Xacc[3] = s.frow[2];
+    if (!last) {
+#pragma unroll
+        for (int kb = 1; kb < 4; ++kb) Xacc = wv::mfma(s.FA[kb], st.xrow[kb - 1], Xacc);
+    }
+    float un = Uacc[0] + s.ubar + st.alpha * s.kk;
+    if (p.zero_mask && s.zm) un = 0.f;                               // :197-198
+    if (p.bound_mode != MPC_BOUND_NONE) {                            // :200-213
+        float l = s.lo, h = s.hi;
+        if (p.has_delta) {
+            const float l2 = s.ubar - p.delta_u, h2 = s.ubar + p.delta_u;
+            l = (l2 < l) ? l : l2;
+            h = (h2 > h) ? h : h2;
+        }
+        un = eclampf(un, l, h);
+    }
+    if (!FULL) un = sel(L.rowv[0], un, 0.f);
+    if (!last) Xacc = wv::mfma(s.FA[0], un, Xacc);
+    // obj_t = 0.5 tau'C tau + c'tau   (:230-232)
+    f32x4 Cacc = wv::mfma(s.C[0], un, zero4);
+#pragma unroll
+    for (int kb = 1; kb < 4; ++kb) Cacc = wv::mfma(s.C[kb], st.xrow[kb - 1], Cacc);
+    float ca = un * fmaf(0.5f, Cacc[0], s.crow[0]);
+#pragma unroll
+    for (int kb = 1; kb < 4; ++kb) ca = fmaf(st.xrow[kb - 1], fmaf(0.5f, Cacc[kb], s.crow[kb]), ca);
+    st.cost += ca;
+    const float d = s.ubar - un;
+    st.du2 = fmaf(d, d, st.du2);
+    if (L.j == jsel) {
+        const long tb = (long)t * p.B + b;
+        if (L.rowv[0]) p.new_u[tb * p.nc + L.row[0]] = un;
+#pragma unroll
+        for (int kb = 1; kb < 4; ++kb)
+            if (L.rowv[kb]) p.new_x[tb * p.ns + L.row[kb]] = st.xrow[kb - 1];
+    }
+    if (!last) {
+        st.xrow[0] = Xacc[1]; st.xrow[1] = Xacc[2]; st.xrow[2] = Xacc[3];
+    }
+}
+
+// One pass over the horizon with all 16 line-search trials in flight; trial `jsel` is stored.
+template <bool FULL>
+MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, int jsel, float &cost_j, float &du2_j)
+{
+    RoState st;
+#pragma unroll
+    for (int kb = 1; kb < 4; ++kb) st.xrow[kb - 1] = L.rowv[kb] ? p.x_init[(long)b * p.ns + L.row[kb]] : 0.f;
+    st.cost = 0.f;
+    st.du2 = 0.f;
+    {
+        // alpha_j = decay^min(j, max_ls-1)    (:247)
+        float a = 1.f;
+        const int e = L.j < p.max_ls - 1 ? L.j : p.max_ls - 1;
+        for (int i = 0; i < e; ++i) a *= p.ls_decay;
+        st.alpha = a;
+    }
+    const int T = p.T;
+    RoStage s0, s1, s2;
+    ro_load<FULL>(s0, p, L, b, 0);
+    ro_load<FULL>(s1, p, L, b, T > 1 ? 1 : 0);
+    int t = 0;
+    while (true) {
+        ro_load<FULL>(s2, p, L, b, t + 2 < T ? t + 2 : T - 1);
+        rollout_step<FULL>(p, L, s0, st, b, t, jsel);
+        if (++t >= T) break;
+        ro_load<FULL>(s0, p, L, b, t + 2 < T ? t + 2 : T - 1);
+        rollout_step<FULL>(p, L, s1, st, b, t, jsel);
+        if (++t >= T) break;
+        ro_load<FULL>(s1, p, L, b, t + 2 < T ? t + 2 : T - 1);
+        rollout_step<FULL>(p, L, s2, st, b, t, jsel);
+        if (++t >= T) break;
+    }
+    // sum the four lane groups: every lane of column j ends with the trial's totals
+    float c = st.cost, d = st.du2;
+    c += wv::shfl_xor(c, 16); d += wv::shfl_xor(d, 16);
+    c += wv::shfl_xor(c, 32); d += wv::shfl_xor(d, 32);
+    cost_j = c;
+    du2_j = d;
+}
+
+template <bool FULL>
+MPC_DEV void step_problem(const P &p)
+{
+    const int lane = wv::lane();
+    const int b = wv::problem();
+    if (b >= p.B) return;
+    Lane L;
+    lane_init(L, lane, p.ns, p.nc);
+    const int T = p.T;
+
+    // ---- Riccati sweep, t = T-1 .. 0, loads two steps ahead ----------------------------------
+    SwState ss;
+    ss.Vp = f32x4{0.f, 0.f, 0.f, 0.f};
+    ss.oc = 0.f;
+    ss.warm = 0;
+    ss.qp_total = 0;
+    ss.status = 0;
+    ss.kprev[0] = ss.kprev[1] = ss.kprev[2] = ss.kprev[3] = 0.f;
+    {
+        SwStage s0, s1, s2;
+        sw_load<FULL>(s0, p, L, b, T - 1);
+        sw_load<FULL>(s1, p, L, b, T > 1 ? T - 2 : 0);
+        int t = T - 1;
+        while (true) {
+            sw_load<FULL>(s2, p, L, b, t - 2 >= 0 ? t - 2 : 0);
+            sweep_step<FULL>(p, L, s0, ss, b, t);
+            if (--t < 0) break;
+            sw_load<FULL>(s0, p, L, b, t - 2 >= 0 ? t - 2 : 0);
+            sweep_step<FULL>(p, L, s1, ss, b, t);
+            if (--t < 0) break;
+            sw_load<FULL>(s1, p, L, b, t - 2 >= 0 ? t - 2 : 0);
+            sweep_step<FULL>(p, L, s2, ss, b, t);
+            if (--t < 0) break;
+        }
+    }
+    const float old_cost = (wv::readlane(ss.oc, 0) + wv::readlane(ss.oc, 16)) +
+                           (wv::readlane(ss.oc, 32) + wv::readlane(ss.oc, 48));
+
+    // K, k were written by this wave and are re-read by other lanes of it: drain the stores.
+    wv::fence_own_stores();
+
+    // ---- line-searched rollout (mpc/lqr_step.py:164-261) ---------------------------------------
+    float cost_j, du2_j;
+    rollout_pass<FULL>(p, L, b, 0, cost_j, du2_j);
+    const float full2 = wv::readlane(du2_j, 0);                      // :243-245 (alpha = 1 trial)
+    // first trial whose cost did not get worse, else the last one (:176-179, 247, 252)
+    const unsigned long long okm = wv::ballot(!(cost_j > old_cost) && L.g == 0 && L.j < p.max_ls);
+    int jstar = p.max_ls - 1;
+    if (okm) jstar = wv::ctz64(okm);
+    jstar = wv::uniform(jstar);
+    if (jstar != 0) rollout_pass<FULL>(p, L, b, jstar, cost_j, du2_j);
+    const float cost = wv::readlane(cost_j, jstar);
+    const float dun2 = wv::readlane(du2_j, jstar);
+    float alpha = 1.f;
+    for (int i = 0; i < jstar; ++i) alpha *= p.ls_decay;
+    int status = ss.status;
+    if (!(cost == cost) || fabsf(cost) > 3e38f) status |= MPC_ST_NONFINITE;
+    if (lane == 0) {
+        if (p.costs) p.costs[b] = cost;
+        if (p.old_costs) p.old_costs[b] = old_cost;
+        if (p.full_du_norm) p.full_du_norm[b] = sqrtf(full2);
+        if (p.alpha_du_norm) p.alpha_du_norm[b] = sqrtf(dun2);
+        if (p.alphas) p.alphas[b] = alpha;
+        if (p.qp_iters) p.qp_iters[b] = ss.qp_total;
+        if (p.status) p.status[b] = status;
+    }
+}
+
+}  // namespace mfma16
+}  // namespace mpclqr

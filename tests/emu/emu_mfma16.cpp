@@ -1,0 +1,163 @@
+// emu_mfma16.cpp -- TEST INFRASTRUCTURE: host-side lockstep emulation of one gfx950 wavefront,
+// used to run the product kernel source mpc.pytorch_amd/csrc/lqr_mfma16_body.h on a CPU-only box.
+//
+// The kernel body is written per lane against the `wv::` interface.  Here every lane is a
+// ucontext fiber; a cross-lane intrinsic (mfma, readlane, shfl, ballot) deposits its operands
+// in a double-buffered exchange area and yields, the scheduler runs all 64 lanes up to the
+// same intrinsic, and on resumption each lane computes its result exactly as the hardware
+// defines it (v_mfma_f32_16x16x4_f32: lane 16k+i holds A[i][k], lane 16k+j holds B[k][j],
+// lane 16g+j register r holds D[4g+r][j]; fp32 fma chain over k = 0..3).
+//
+// Built by tests/test_emu_mfma16.py with the host clang++ of the ROCm toolchain (or g++).
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#define MPC_EMULATE 1
+#define MPC_DEV static inline
+
+namespace emu {
+enum { NL = 64, STACK = 256 * 1024 };
+struct Wave {
+    ucontext_t main_ctx, ctx[NL];
+    char *stack[NL];
+    bool done[NL];
+    int cur;
+    int problem;
+    // exchange area, two generations
+    float fa[2][NL], fb[2][NL];
+    int ia[2][NL];
+    unsigned seq[NL];
+};
+static Wave W;
+static void (*g_body)(void);
+
+static void yield_lane() { swapcontext(&W.ctx[W.cur], &W.main_ctx); }
+static void trampoline()
+{
+    g_body();
+    W.done[W.cur] = true;
+    swapcontext(&W.ctx[W.cur], &W.main_ctx);
+}
+static void run_wave(int problem, void (*body)(void))
+{
+    g_body = body;
+    W.problem = problem;
+    for (int l = 0; l < NL; ++l) {
+        if (!W.stack[l]) W.stack[l] = (char *)malloc(STACK);
+        getcontext(&W.ctx[l]);
+        W.ctx[l].uc_stack.ss_sp = W.stack[l];
+        W.ctx[l].uc_stack.ss_size = STACK;
+        W.ctx[l].uc_link = &W.main_ctx;
+        makecontext(&W.ctx[l], trampoline, 0);
+        W.done[l] = false;
+        W.seq[l] = 0;
+    }
+    for (;;) {
+        int ndone = 0;
+        for (int l = 0; l < NL; ++l) {
+            if (W.done[l]) { ++ndone; continue; }
+            W.cur = l;
+            swapcontext(&W.main_ctx, &W.ctx[l]);
+        }
+        if (ndone == NL) break;
+    }
+}
+}  // namespace emu
+
+namespace mpclqr {
+namespace wv {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+static inline int lane() { return emu::W.cur; }
+static inline int problem() { return emu::W.problem; }
+static inline f32x4 mfma(float a, float b, f32x4 c)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = a;
+    w.fb[gen][l] = b;
+    emu::yield_lane();
+    const int g = l >> 4, j = l & 15;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(w.fa[gen][16 * k + i], w.fb[gen][16 * k + j], acc);
+        d[r] = acc;
+    }
+    return d;
+}
+static inline float readlane(float x, int src)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = x;
+    emu::yield_lane();
+    return w.fa[gen][src];
+}
+static inline int readlane_i(int x, int src)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.ia[gen][l] = x;
+    emu::yield_lane();
+    return w.ia[gen][src];
+}
+static inline float shfl_xor(float x, int m)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = x;
+    emu::yield_lane();
+    return w.fa[gen][l ^ m];
+}
+static inline unsigned long long ballot(bool c)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.ia[gen][l] = c ? 1 : 0;
+    emu::yield_lane();
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; ++i) if (w.ia[gen][i]) m |= 1ull << i;
+    return m;
+}
+static inline float rcp(float x) { return 1.0f / x; }
+static inline bool uniform(bool c)
+{
+    // must be wave-uniform: check it
+    const int v = readlane_i((int)c, 0);
+    if (v != (int)c) { fprintf(stderr, "emu: non-uniform branch condition in lane %d\n", emu::W.cur); abort(); }
+    return c;
+}
+static inline int uniform(int v)
+{
+    const int v0 = readlane_i(v, 0);
+    if (v0 != v) { fprintf(stderr, "emu: non-uniform value in lane %d\n", emu::W.cur); abort(); }
+    return v;
+}
+static inline int ctz64(unsigned long long m) { return __builtin_ctzll(m); }
+static inline void fence_own_stores() {}
+}  // namespace wv
+}  // namespace mpclqr
+
+#include "../../mpc.pytorch_amd/csrc/lqr_mfma16_body.h"
+
+static const mpclqr::StepParams<float> *g_p;
+static void body_full() { mpclqr::mfma16::step_problem<true>(*g_p); }
+static void body_gen() { mpclqr::mfma16::step_problem<false>(*g_p); }
+
+extern "C" int emu_lqr_step_mfma16(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
+                                   int force_general)
+{
+    if (p->dtype != MPC_F32) return MPC_E_DTYPE;
+    mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, out);
+    if (!(sp.ns >= 1 && sp.ns <= 12 && sp.nc >= 1 && sp.nc <= 4 && sp.max_ls >= 1 && sp.max_ls <= 16)) return MPC_E_DIMS;
+    if (!sp.K || !sp.k || !sp.new_x || !sp.new_u) return MPC_E_NULL;
+    g_p = &sp;
+    const bool full = sp.ns == 12 && sp.nc == 4 && !force_general;
+    for (int b = 0; b < sp.B; ++b) emu::run_wave(b, full ? body_full : body_gen);
+    return 0;
+}

@@ -1,0 +1,100 @@
+"""TEST INFRASTRUCTURE: run the fused MFMA kernel SOURCE (mpc.pytorch_amd/csrc/lqr_mfma16_body.h)
+on the CPU through the 64-fiber wavefront emulator in tests/emu/emu_mfma16.cpp.
+
+This is how the kernel's lane/register layout algebra is parity-tested on a box without a GPU;
+on the GPU box the same source runs on the real v_mfma_f32_16x16x4_f32 (tests/test_gpu_parity.py).
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+from mpc import _native as N
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_EMU = os.path.join(_HERE, "emu")
+_LIB = None
+
+
+def build():
+    so = os.path.join(_EMU, "libemu_mfma16.so")
+    src = os.path.join(_EMU, "emu_mfma16.cpp")
+    body = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc", "lqr_mfma16_body.h")
+    params = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc", "lqr_params.h")
+    deps = [src, body, params]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        cxx = "/opt/rocm/lib/llvm/bin/clang++"
+        if not os.path.exists(cxx):
+            cxx = shutil.which("clang++")
+        assert cxx, "the emulator needs clang++ (ext_vector_type)"
+        subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.emu_lqr_step_mfma16.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options),
+                                             ctypes.POINTER(N.Outputs), ctypes.c_int]
+    return _LIB
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p).value
+
+
+def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None,
+             linesearch_decay=0.2, max_linesearch_iter=10, pnqp_iter=20, force_general=False):
+    """Same signature as oracle.lqr_oracle.lqr_step; float32 only.  Returns the kernel's outputs."""
+    f32 = np.float32
+    C = np.ascontiguousarray(C, f32); c = np.ascontiguousarray(c, f32)
+    x_init = np.ascontiguousarray(x_init, f32)
+    T, B, n, _ = C.shape
+    ns = x_init.shape[1]
+    nc = n - ns
+    F = np.ascontiguousarray(F, f32) if T > 1 else np.zeros((0, B, ns, n), f32)
+    f = None if (f is None or np.asarray(f).size == 0) else np.ascontiguousarray(f, f32)
+    cur_x = np.ascontiguousarray(cur_x, f32); cur_u = np.ascontiguousarray(cur_u, f32)
+    p = N.Problem()
+    p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, N.MPC_F32
+    p.x_init = _ptr(x_init)
+    p.C, p.C_st, p.C_sb = _ptr(C), B * n * n, n * n
+    p.c, p.c_st, p.c_sb = _ptr(c), B * n, n
+    if T > 1:
+        p.F, p.F_st, p.F_sb = _ptr(F), B * ns * n, ns * n
+    if f is not None:
+        p.f, p.f_st, p.f_sb = _ptr(f), B * ns, ns
+    p.cur_x, p.cur_u = _ptr(cur_x), _ptr(cur_u)
+    o = N.Options()
+    o.max_linesearch_iter = int(max_linesearch_iter)
+    o.linesearch_decay = float(linesearch_decay)
+    o.delta_u = float("nan") if delta_u is None else float(delta_u)
+    o.pnqp_iter = int(pnqp_iter)
+    keep = []
+    if u_lower is None:
+        o.bound_mode = N.BOUND_NONE
+    elif isinstance(u_lower, float) and isinstance(u_upper, float):
+        o.bound_mode, o.lo_s, o.hi_s = N.BOUND_SCALAR, u_lower, u_upper
+    else:
+        lo = np.ascontiguousarray(np.broadcast_to(np.asarray(u_lower, f32), (T, B, nc)))
+        hi = np.ascontiguousarray(np.broadcast_to(np.asarray(u_upper, f32), (T, B, nc)))
+        keep += [lo, hi]
+        o.bound_mode, o.lo, o.hi = N.BOUND_TENSOR, _ptr(lo), _ptr(hi)
+    if u_zero_I is not None:
+        zm = np.ascontiguousarray((np.asarray(u_zero_I) != 0).astype(np.uint8))
+        keep.append(zm)
+        o.zero_mask = _ptr(zm)
+    res = dict(new_x=np.full((T, B, ns), np.nan, f32), new_u=np.full((T, B, nc), np.nan, f32),
+               costs=np.empty(B, f32), old_costs=np.empty(B, f32), full_du_norm=np.empty(B, f32),
+               alpha_du_norm=np.empty(B, f32), alphas=np.empty(B, f32),
+               qp_iters=np.zeros(B, np.int32), status=np.zeros(B, np.int32),
+               K=np.full((T, B, nc, ns), np.nan, f32), k=np.full((T, B, nc), np.nan, f32))
+    out = N.Outputs()
+    for key, arr in res.items():
+        setattr(out, key, _ptr(arr))
+    rc = lib().emu_lqr_step_mfma16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), int(force_general))
+    assert rc == 0, rc
+    return res

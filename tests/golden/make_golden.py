@@ -107,9 +107,18 @@ def run_step(p, ns, nc, T, u_lower=None, u_upper=None, u_zero_I=None, delta_u=No
                 mean_alphas=mean_alpha.reshape(1))
 
 
+ONLY = None      # set from --only name1,name2: regenerate just those fixtures
+
+
 def step_case(name, ns, nc, T, B, dtype, seed, with_f=True, bounds=None, mask_seed=None,
-              delta_u=None, decay=0.2, max_ls=10, u_scale=0.3):
+              delta_u=None, decay=0.2, max_ls=10, u_scale=0.3, indef=0.0):
+    if ONLY is not None and name not in ONLY:
+        return
     p = make_problem(ns, nc, T, B, dtype, seed, with_f, u_scale)
+    if indef:
+        # a NON-convex stage cost in the states: the Newton step is no longer a descent step for
+        # every problem, so the line search of mpc/lqr_step.py:176-252 really backtracks
+        p["C"][:, :, :ns, :ns] -= indef * torch.eye(ns, dtype=p["C"].dtype)
     g = torch.Generator().manual_seed(seed + 1000)
     u_lower = u_upper = None
     if bounds == "tensor":
@@ -361,7 +370,11 @@ def traj_cost_case():
 
 if __name__ == "__main__":
     f64, f32 = torch.float64, torch.float32
-    only = set(sys.argv[1:])
+    only = set(a for a in sys.argv[1:] if not a.startswith("--only="))
+    for a in sys.argv[1:]:
+        if a.startswith("--only="):
+            ONLY = set(a[len("--only="):].split(","))
+            only = {"step"}
     if only and "step" not in only:
         step_case = lambda *a, **k: None
     if only and "mpc" not in only:
@@ -389,6 +402,10 @@ if __name__ == "__main__":
     step_case("step_cfg5_f32", 32, 8, 8, 2, f32, 22, bounds=None)
     step_case("step_cfg5_bounded_f64", 32, 8, 6, 2, f64, 23, bounds=0.5)
     step_case("step_linesearch_f64", 4, 2, 8, 6, f64, 24, bounds=0.3, u_scale=2.0, decay=0.5, max_ls=4)
+    step_case("step_backtrack_a_f64", 4, 2, 8, 6, f64, 45, bounds=0.3, u_scale=2.0, decay=0.5, max_ls=4, indef=6.0)
+    step_case("step_backtrack_b_f64", 4, 2, 8, 6, f64, 40, bounds=0.3, u_scale=2.0, decay=0.5, max_ls=4, indef=6.0)
+    if ONLY is not None:
+        sys.exit(0)
     # ---- full solves --------------------------------------------------------
     gen_mpc_cases()
     # ---- backward -------------------------------------------------------------

@@ -1,0 +1,109 @@
+"""CPU parity tests of the fused MFMA kernel SOURCE (csrc/lqr_mfma16_body.h) run through the
+wavefront emulator (tests/emu/): the lane/register layout algebra, the in-register pnqp and the
+16-trial line search are checked against the oracle and the reference's golden outputs without a
+GPU.  The same source on the real matrix cores is covered by tests/test_gpu_parity.py (-m gpu).
+
+Tolerance: fp32 kernel vs the float64 oracle / reference on identical inputs: rtol 1e-3, atol 1e-4
+on trajectories, 1e-4 relative on costs, step sizes exact.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden
+from helpers import step_kwargs
+
+STEP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "step_*.npz")))
+STEP_CASES = [c for c in STEP_CASES if "cfg5" not in c]      # n = 40 is the generic kernel's
+
+
+def _f64(kw):
+    return {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == "f" else v)
+            for k, v in kw.items()}
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import emu_backend
+    emu_backend.lib()
+    return emu_backend
+
+
+@pytest.mark.parametrize("name", STEP_CASES)
+def test_emulated_kernel_matches_oracle_and_reference(emu, name):
+    from oracle import lqr_oracle as O
+    z = golden(name)
+    kw = step_kwargs(z)
+    o = O.lqr_step(lockstep=False, return_gains=True, **_f64(kw))
+    r = emu.lqr_step(**kw)
+    assert (r["status"] & 2 == 0).all()
+    np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["k"], o["k"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["costs"], o["costs"], rtol=1e-4)
+    np.testing.assert_allclose(r["old_costs"], o["old_costs"], rtol=1e-4)
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+    np.testing.assert_allclose(r["full_du_norm"], o["full_du_norm"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(r["alpha_du_norm"], o["alpha_du_norm"], rtol=2e-3, atol=2e-4)
+    # the unmodified reference's own outputs (per-problem calls), committed under tests/golden/
+    sfx = "_pp" if z["C"].dtype == np.float64 else "_ref64"
+    np.testing.assert_allclose(r["new_x"], z["new_x" + sfx], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["new_u"], z["new_u" + sfx], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["costs"], z["costs" + sfx], rtol=1e-4)
+    if "u_lower" in z:
+        assert abs(int(r["qp_iters"].max()) - int(o["n_qp_iter"])) <= 2     # trip counts are not a parity quantity
+
+
+@pytest.mark.parametrize("name", ["step_backtrack_a_f64", "step_backtrack_b_f64"])
+def test_line_search_trials_pick_the_reference_step(emu, name):
+    """All 16 trials are rolled out at once; the accepted one must be the first alpha = decay^j whose
+    cost did not get worse, else the last trial -- on the two fixtures with a non-convex stage cost,
+    where the reference really backtracks (a: accepts 0.5; b: never improves, returns decay^3)."""
+    z = golden(name)
+    kw = step_kwargs(z)
+    assert (z["alphas_pp"] < 1).any() and (z["alphas_pp"] == 1).any()
+    r = emu.lqr_step(**kw)
+    np.testing.assert_allclose(r["alphas"], z["alphas_pp"], rtol=1e-6)
+    np.testing.assert_allclose(r["new_u"], z["new_u_pp"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["new_x"], z["new_x_pp"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["costs"], z["costs_pp"], rtol=1e-4)
+    np.testing.assert_allclose(r["full_du_norm"], z["full_du_norm_pp"], rtol=2e-3, atol=2e-4)
+    assert (r["alpha_du_norm"] <= r["full_du_norm"] * (1 + 1e-6)).all()
+
+
+def test_padded_and_full_code_paths_agree(emu):
+    """n_state = 12, n_ctrl = 4 has a mask-free instantiation; it must equal the padded one bit for bit."""
+    z = golden("step_ns_bounded_f32")
+    kw = step_kwargs(z)
+    a = emu.lqr_step(**kw)
+    b = emu.lqr_step(force_general=True, **kw)
+    for k in ("new_x", "new_u", "costs", "K", "k", "alphas"):
+        np.testing.assert_array_equal(a[k], b[k])
+
+
+@pytest.mark.parametrize("ns,nc,T", [(1, 1, 1), (2, 1, 2), (7, 3, 9), (12, 1, 5), (11, 4, 6)])
+def test_odd_shapes_against_oracle(emu, ns, nc, T):
+    """Ragged sizes (T = 1, single state, partly filled slots), scalar bounds, with f."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(100 * ns + 10 * nc + T)
+    B, n = 3, ns + nc
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A) + 0.1 * np.eye(n)
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((max(T - 1, 0), B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((max(T - 1, 0), B, ns, nc)) / np.sqrt(ns)), 3)
+    f = 0.1 * rng.standard_normal((max(T - 1, 0), B, ns))
+    x_init = rng.standard_normal((B, ns))
+    cur_u = np.clip(0.3 * rng.standard_normal((T, B, nc)), -0.5, 0.5)
+    cur_x, _ = O.traj_cost(x_init, cur_u, F, f)
+    kw = dict(x_init=x_init, C=C, c=c, F=F, f=f, cur_x=cur_x, cur_u=cur_u, u_lower=-0.5, u_upper=0.5)
+    o = O.lqr_step(lockstep=False, return_gains=True, **kw)
+    r = emu.lqr_step(**kw)
+    np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["costs"], o["costs"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+    assert float(np.abs(r["new_u"]).max()) <= 0.5
