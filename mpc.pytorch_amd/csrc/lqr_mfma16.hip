@@ -43,10 +43,22 @@ MPC_DEV void fence_own_stores()
 namespace mpclqr {
 namespace {
 
-template <bool FULL>
+// MODE: 0 unconstrained, 1 unconstrained + u_zero_I, 2 box-constrained (pnqp in the sweep)
+template <bool FULL, int MODE>
 __global__ void __launch_bounds__(64, 4) lqr_step_mfma16_kernel(StepParams<float> p)
 {
-    mfma16::step_problem<FULL>(p);
+    mfma16::step_problem<FULL, MODE>(p);
+}
+
+template <bool FULL>
+void launch_mode(const StepParams<float> &p, hipStream_t st)
+{
+    if (p.bound_mode != MPC_BOUND_NONE)
+        hipLaunchKernelGGL((lqr_step_mfma16_kernel<FULL, 2>), dim3(p.B), dim3(64), 0, st, p);
+    else if (p.zero_mask)
+        hipLaunchKernelGGL((lqr_step_mfma16_kernel<FULL, 1>), dim3(p.B), dim3(64), 0, st, p);
+    else
+        hipLaunchKernelGGL((lqr_step_mfma16_kernel<FULL, 0>), dim3(p.B), dim3(64), 0, st, p);
 }
 
 }  // namespace
@@ -62,9 +74,9 @@ int launch_step_mfma16(const StepParams<float> &p, hipStream_t st)
     if (!p.K || !p.k) { set_last_error("mfma16: K / k scratch missing"); return MPC_E_NULL; }
     if (!p.new_x || !p.new_u) { set_last_error("mfma16: new_x / new_u is NULL"); return MPC_E_NULL; }
     if (p.ns == 12 && p.nc == 4)
-        hipLaunchKernelGGL(lqr_step_mfma16_kernel<true>, dim3(p.B), dim3(64), 0, st, p);
+        launch_mode<true>(p, st);
     else
-        hipLaunchKernelGGL(lqr_step_mfma16_kernel<false>, dim3(p.B), dim3(64), 0, st, p);
+        launch_mode<false>(p, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_last_error((std::string("lqr_step_mfma16_kernel: ") + hipGetErrorString(e)).c_str());

@@ -98,8 +98,11 @@ MPC_DEV float sel(bool c, float a, float b) { return c ? a : b; }
 struct Sym4 { float s00, s01, s02, s03, s11, s12, s13, s22, s23, s33; };
 struct Ldl4 { float l10, l20, l30, l21, l31, l32, i0, i1, i2, i3; };
 
-MPC_DEV void ldl4(Ldl4 &f, const Sym4 &s, const bool fr[4], float reg)
+template <bool MASKED>
+MPC_DEV void ldl4(Ldl4 &f, const Sym4 &s, const bool fr_[4], float reg)
 {
+    bool fr[4];
+    for (int a = 0; a < 4; ++a) fr[a] = MASKED ? fr_[a] : true;
     const float a00 = fr[0] ? s.s00 + reg : 1.f;
     const float a10 = (fr[0] && fr[1]) ? s.s01 : 0.f;
     const float a20 = (fr[0] && fr[2]) ? s.s02 : 0.f;
@@ -182,7 +185,7 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
             fr[a] = valid[a] && !ic;
             gm[a] = fr[a] ? g[a] : 0.f;
         }
-        ldl4(f, s, fr, 1e-11f);                                      // :44-48
+        ldl4<true>(f, s, fr, 1e-11f);                                // :44-48
         float dx[4];
         ldl4_solve(f, gm[0], gm[1], gm[2], gm[3], dx);               // :50-54
         float nrm2 = 0.f;
@@ -224,7 +227,8 @@ struct SwStage {
     int zm;           // u_zero_I of u_g
 };
 
-template <bool FULL>
+// MODE: 0 = unconstrained, 1 = unconstrained with u_zero_I (the KKT backward's solve), 2 = box bounds
+template <bool FULL, int MODE>
 MPC_DEV void sw_load(SwStage &s, const P &p, const Lane &L, int b, int t)
 {
     const long tb = (long)t * p.B + b;
@@ -257,15 +261,17 @@ MPC_DEV void sw_load(SwStage &s, const P &p, const Lane &L, int b, int t)
         s.trow[r] = FULL ? v : sel(L.rowv[r], v, 0.f);
     }
     s.lo = s.hi = 0.f;
-    if (p.bound_mode == MPC_BOUND_TENSOR) {
-        s.lo = p.lo[tb * p.nc + L.row[0]];
-        s.hi = p.hi[tb * p.nc + L.row[0]];
-    } else if (p.bound_mode == MPC_BOUND_SCALAR) {
-        s.lo = p.lo_s;
-        s.hi = p.hi_s;
-    }
     s.zm = 0;
-    if (p.zero_mask) s.zm = L.rowv[0] ? (int)p.zero_mask[tb * p.nc + L.row[0]] : 0;
+    if (MODE == 2) {
+        if (p.bound_mode == MPC_BOUND_TENSOR) {
+            s.lo = p.lo[tb * p.nc + L.row[0]];
+            s.hi = p.hi[tb * p.nc + L.row[0]];
+        } else {
+            s.lo = p.lo_s;
+            s.hi = p.hi_s;
+        }
+    }
+    if (MODE == 1) s.zm = L.rowv[0] ? (int)p.zero_mask[tb * p.nc + L.row[0]] : 0;
 }
 
 struct SwState {
@@ -277,7 +283,7 @@ struct SwState {
     int status;
 };
 
-template <bool FULL>
+template <bool FULL, int MODE>
 MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st, int b, int t)
 {
     const bool last = (t == p.T - 1);
@@ -331,15 +337,15 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     for (int a = 0; a < 4; ++a) valid[a] = a < p.nc;
     Ldl4 f;
     float kq[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool bounded = p.bound_mode != MPC_BOUND_NONE;
+    const bool bounded = MODE == 2;
     if (!bounded) {
         // :84-94 unconstrained / :99-127 masked (u_zero_I): masked rows and columns drop out
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             fr[a] = valid[a];
-            if (p.zero_mask) fr[a] = fr[a] && (wv::readlane_i(s.zm, 16 * a) == 0);
+            if (MODE == 1) fr[a] = fr[a] && (wv::readlane_i(s.zm, 16 * a) == 0);
         }
-        ldl4(f, S, fr, 0.f);
+        ldl4<(!FULL || MODE == 1)>(f, S, fr, 0.f);
     } else {
         // :128-141 box constraints in delta space
         float lb[4], ub[4];
@@ -357,7 +363,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         }
         if (!st.warm) {
             // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
-            ldl4(f, S, valid, 0.f);
+            ldl4<!FULL>(f, S, valid, 0.f);
             float y[4];
             ldl4_solve(f, valid[0] ? qu[0] : 0.f, valid[1] ? qu[1] : 0.f, valid[2] ? qu[2] : 0.f,
                        valid[3] ? qu[3] : 0.f, y);
@@ -384,9 +390,13 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         float y[4];
         ldl4_solve(f, L.g == 0 ? 1.f : 0.f, L.g == 1 ? 1.f : 0.f, L.g == 2 ? 1.f : 0.f, L.g == 3 ? 1.f : 0.f, y);
         float val = L.ja == 0 ? y[0] : (L.ja == 1 ? y[1] : (L.ja == 2 ? y[2] : y[3]));
-        const bool fa = L.ja == 0 ? fr[0] : (L.ja == 1 ? fr[1] : (L.ja == 2 ? fr[2] : fr[3]));
-        const bool fg = L.g == 0 ? fr[0] : (L.g == 1 ? fr[1] : (L.g == 2 ? fr[2] : fr[3]));
-        Ainv = (L.jq && fa && fg) ? -val : 0.f;
+        bool ok = L.jq;
+        if (!FULL || MODE != 0) {
+            const bool fa = L.ja == 0 ? fr[0] : (L.ja == 1 ? fr[1] : (L.ja == 2 ? fr[2] : fr[3]));
+            const bool fg = L.g == 0 ? fr[0] : (L.g == 1 ? fr[1] : (L.g == 2 ? fr[2] : fr[3]));
+            ok = ok && fa && fg;
+        }
+        Ainv = ok ? -val : 0.f;
     }
     f32x4 Kacc = wv::mfma(Ainv, U, zero4);
     float Kp = Kacc[0];           // lane (g,j): K[g][var j]; lane (g,0): k[g]
@@ -436,7 +446,7 @@ struct RoStage {
     int zm;
 };
 
-template <bool FULL>
+template <bool FULL, int MODE>
 MPC_DEV void ro_load(RoStage &s, const P &p, const Lane &L, int b, int t)
 {
     const long tb = (long)t * p.B + b;
@@ -491,15 +501,17 @@ MPC_DEV void ro_load(RoStage &s, const P &p, const Lane &L, int b, int t)
         s.kk = FULL ? w : sel(L.rowv[0], w, 0.f);
     }
     s.lo = s.hi = 0.f;
-    if (p.bound_mode == MPC_BOUND_TENSOR) {
-        s.lo = p.lo[tb * p.nc + L.row[0]];
-        s.hi = p.hi[tb * p.nc + L.row[0]];
-    } else if (p.bound_mode == MPC_BOUND_SCALAR) {
-        s.lo = p.lo_s;
-        s.hi = p.hi_s;
-    }
     s.zm = 0;
-    if (p.zero_mask) s.zm = L.rowv[0] ? (int)p.zero_mask[tb * p.nc + L.row[0]] : 0;
+    if (MODE == 2) {
+        if (p.bound_mode == MPC_BOUND_TENSOR) {
+            s.lo = p.lo[tb * p.nc + L.row[0]];
+            s.hi = p.hi[tb * p.nc + L.row[0]];
+        } else {
+            s.lo = p.lo_s;
+            s.hi = p.hi_s;
+        }
+    }
+    if (MODE != 0 && p.zero_mask) s.zm = L.rowv[0] ? (int)p.zero_mask[tb * p.nc + L.row[0]] : 0;
 }
 
 struct RoState {
@@ -509,7 +521,7 @@ struct RoState {
     float alpha;      // step of trial j
 };
 
-template <bool FULL>
+template <bool FULL, int MODE>
 MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &st, int b, int t, int jsel)
 {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -526,8 +538,8 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
         for (int kb = 1; kb < 4; ++kb) Xacc = wv::mfma(s.FA[kb], st.xrow[kb - 1], Xacc);
     }
     float un = Uacc[0] + s.ubar + st.alpha * s.kk;
-    if (p.zero_mask && s.zm) un = 0.f;                               // :197-198
-    if (p.bound_mode != MPC_BOUND_NONE) {                            // :200-213
+    if (MODE != 0 && s.zm) un = 0.f;                                 // :197-198
+    if (MODE == 2) {                                                 // :200-213
         float l = s.lo, h = s.hi;
         if (p.has_delta) {
             const float l2 = s.ubar - p.delta_u, h2 = s.ubar + p.delta_u;
@@ -561,7 +573,7 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
 }
 
 // One pass over the horizon with all 16 line-search trials in flight; trial `jsel` is stored.
-template <bool FULL>
+template <bool FULL, int MODE>
 MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, int jsel, float &cost_j, float &du2_j)
 {
     RoState st;
@@ -578,18 +590,18 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, int jsel, float &cos
     }
     const int T = p.T;
     RoStage s0, s1, s2;
-    ro_load<FULL>(s0, p, L, b, 0);
-    ro_load<FULL>(s1, p, L, b, T > 1 ? 1 : 0);
+    ro_load<FULL, MODE>(s0, p, L, b, 0);
+    ro_load<FULL, MODE>(s1, p, L, b, T > 1 ? 1 : 0);
     int t = 0;
     while (true) {
-        ro_load<FULL>(s2, p, L, b, t + 2 < T ? t + 2 : T - 1);
-        rollout_step<FULL>(p, L, s0, st, b, t, jsel);
+        ro_load<FULL, MODE>(s2, p, L, b, t + 2 < T ? t + 2 : T - 1);
+        rollout_step<FULL, MODE>(p, L, s0, st, b, t, jsel);
         if (++t >= T) break;
-        ro_load<FULL>(s0, p, L, b, t + 2 < T ? t + 2 : T - 1);
-        rollout_step<FULL>(p, L, s1, st, b, t, jsel);
+        ro_load<FULL, MODE>(s0, p, L, b, t + 2 < T ? t + 2 : T - 1);
+        rollout_step<FULL, MODE>(p, L, s1, st, b, t, jsel);
         if (++t >= T) break;
-        ro_load<FULL>(s1, p, L, b, t + 2 < T ? t + 2 : T - 1);
-        rollout_step<FULL>(p, L, s2, st, b, t, jsel);
+        ro_load<FULL, MODE>(s1, p, L, b, t + 2 < T ? t + 2 : T - 1);
+        rollout_step<FULL, MODE>(p, L, s2, st, b, t, jsel);
         if (++t >= T) break;
     }
     // sum the four lane groups: every lane of column j ends with the trial's totals
@@ -600,7 +612,7 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, int jsel, float &cos
     du2_j = d;
 }
 
-template <bool FULL>
+template <bool FULL, int MODE>
 MPC_DEV void step_problem(const P &p)
 {
     const int lane = wv::lane();
@@ -620,18 +632,18 @@ MPC_DEV void step_problem(const P &p)
     ss.kprev[0] = ss.kprev[1] = ss.kprev[2] = ss.kprev[3] = 0.f;
     {
         SwStage s0, s1, s2;
-        sw_load<FULL>(s0, p, L, b, T - 1);
-        sw_load<FULL>(s1, p, L, b, T > 1 ? T - 2 : 0);
+        sw_load<FULL, MODE>(s0, p, L, b, T - 1);
+        sw_load<FULL, MODE>(s1, p, L, b, T > 1 ? T - 2 : 0);
         int t = T - 1;
         while (true) {
-            sw_load<FULL>(s2, p, L, b, t - 2 >= 0 ? t - 2 : 0);
-            sweep_step<FULL>(p, L, s0, ss, b, t);
+            sw_load<FULL, MODE>(s2, p, L, b, t - 2 >= 0 ? t - 2 : 0);
+            sweep_step<FULL, MODE>(p, L, s0, ss, b, t);
             if (--t < 0) break;
-            sw_load<FULL>(s0, p, L, b, t - 2 >= 0 ? t - 2 : 0);
-            sweep_step<FULL>(p, L, s1, ss, b, t);
+            sw_load<FULL, MODE>(s0, p, L, b, t - 2 >= 0 ? t - 2 : 0);
+            sweep_step<FULL, MODE>(p, L, s1, ss, b, t);
             if (--t < 0) break;
-            sw_load<FULL>(s1, p, L, b, t - 2 >= 0 ? t - 2 : 0);
-            sweep_step<FULL>(p, L, s2, ss, b, t);
+            sw_load<FULL, MODE>(s1, p, L, b, t - 2 >= 0 ? t - 2 : 0);
+            sweep_step<FULL, MODE>(p, L, s2, ss, b, t);
             if (--t < 0) break;
         }
     }
@@ -643,14 +655,14 @@ MPC_DEV void step_problem(const P &p)
 
     // ---- line-searched rollout (mpc/lqr_step.py:164-261) ---------------------------------------
     float cost_j, du2_j;
-    rollout_pass<FULL>(p, L, b, 0, cost_j, du2_j);
+    rollout_pass<FULL, MODE>(p, L, b, 0, cost_j, du2_j);
     const float full2 = wv::readlane(du2_j, 0);                      // :243-245 (alpha = 1 trial)
     // first trial whose cost did not get worse, else the last one (:176-179, 247, 252)
     const unsigned long long okm = wv::ballot(!(cost_j > old_cost) && L.g == 0 && L.j < p.max_ls);
     int jstar = p.max_ls - 1;
     if (okm) jstar = wv::ctz64(okm);
     jstar = wv::uniform(jstar);
-    if (jstar != 0) rollout_pass<FULL>(p, L, b, jstar, cost_j, du2_j);
+    if (jstar != 0) rollout_pass<FULL, MODE>(p, L, b, jstar, cost_j, du2_j);
     const float cost = wv::readlane(cost_j, jstar);
     const float dun2 = wv::readlane(du2_j, jstar);
     float alpha = 1.f;

@@ -146,8 +146,13 @@ static inline void fence_own_stores() {}
 #include "../../mpc.pytorch_amd/csrc/lqr_mfma16_body.h"
 
 static const mpclqr::StepParams<float> *g_p;
-static void body_full() { mpclqr::mfma16::step_problem<true>(*g_p); }
-static void body_gen() { mpclqr::mfma16::step_problem<false>(*g_p); }
+template <bool FULL> static void body()
+{
+    const mpclqr::StepParams<float> &p = *g_p;
+    if (p.bound_mode != MPC_BOUND_NONE) mpclqr::mfma16::step_problem<FULL, 2>(p);
+    else if (p.zero_mask) mpclqr::mfma16::step_problem<FULL, 1>(p);
+    else mpclqr::mfma16::step_problem<FULL, 0>(p);
+}
 
 extern "C" int emu_lqr_step_mfma16(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
                                    int force_general)
@@ -158,6 +163,6 @@ extern "C" int emu_lqr_step_mfma16(const mpc_lqr_problem *p, const mpc_lqr_optio
     if (!sp.K || !sp.k || !sp.new_x || !sp.new_u) return MPC_E_NULL;
     g_p = &sp;
     const bool full = sp.ns == 12 && sp.nc == 4 && !force_general;
-    for (int b = 0; b < sp.B; ++b) emu::run_wave(b, full ? body_full : body_gen);
+    for (int b = 0; b < sp.B; ++b) emu::run_wave(b, full ? body<true> : body<false>);
     return 0;
 }
