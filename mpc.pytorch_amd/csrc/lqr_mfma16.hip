@@ -28,6 +28,29 @@ MPC_DEV bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 
 MPC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 MPC_DEV unsigned long long ballot(bool c) { return __ballot(c); }
 MPC_DEV int ctz64(unsigned long long m) { return __builtin_ctzll(m); }
+// ---- HBM -> LDS staging --------------------------------------------------------------------
+// One ring of NSTAGE stage buffers per wavefront (= per workgroup).
+#define MPC_LDS_BYTES (4 * 2208)
+__shared__ __attribute__((aligned(16))) char g_stage[MPC_LDS_BYTES];
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+// 16 (4) bytes per lane from the lane's own global address to LDS[off + 16 (4) * lane]
+MPC_DEV void dma16(const void *g, unsigned off)
+{
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage + off), 16, 0, 0);
+}
+MPC_DEV void dma4(const void *g, unsigned off)
+{
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage + off), 4, 0, 0);
+}
+MPC_DEV float lds_f32(unsigned off) { return *(const float *)(g_stage + off); }
+// Wait until at most N of this wave's vector-memory operations are outstanding.  hipcc does not
+// order LDS reads behind an LDS-DMA by itself; this is the ordering point (and a compiler barrier).
+template <int N> MPC_DEV void dma_wait()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 MPC_DEV void fence_own_stores()
 {
     // same-CU visibility of this wave's own global stores to its later loads

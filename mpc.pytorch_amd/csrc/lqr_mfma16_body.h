@@ -34,6 +34,14 @@
 //     line search of mpc/lqr_step.py:176-252 is one pass over C, F (a second pass
 //     re-runs the accepted column only when alpha = 1 was rejected).
 //
+// Staging.  Every per-timestep block (C_t 1 KiB, F_t 768 B, and one 416 B record of
+// the small vectors c, x, u, f, k, bounds, K) is DMA'd HBM -> LDS with
+// global_load_lds (16 B per lane, no VGPRs held while in flight) into a 4-slot ring
+// per wavefront, three timesteps ahead of its use; the step then picks its MFMA
+// operands out of LDS in whatever lane order the layout above wants.  The waits are
+// counted s_waitcnt vmcnt(N) on the number of NEWER DMA instructions (loads return in
+// order; stores in flight only make the wait more conservative).
+//
 // C is read as the symmetric matrix the reference documents it to be
 // (mpc/mpc.py:61-68; its own delta-space gradient C tau + c, :294, is only a
 // gradient for symmetric C).
@@ -59,6 +67,23 @@ struct Lane {
     int offC[4];          // row[r]-as-tau-index * n + col     (C in D layout; rows 1..3 double as F rows)
     int offT[4];          // col * n + row[r]-as-tau-index      (F as the rollout's A operand)
     bool vC[4], vT[4];
+    // byte offsets into an LDS stage
+    int aC[4];            // 4 * offC[r]                     (+LDS_C: C[r]; +LDS_F: F rows, r >= 1)
+    int aT[4];            // 4 * tau index of row slot r     (+V_c: c; +V_tau: nominal tau; +V_f: f, r >= 1)
+    int aFT[4];           // 4 * offT[r]                     (+LDS_F)
+    int aK[4];            // 4 * (ja * ns + row[r]), r >= 1  (+V_K)
+    int aG;               // 4 * g                           (+V_k, V_lo, V_hi)
+    bool vK[4];
+};
+
+// LDS stage layout (bytes).  The record of small vectors is laid out so that in the n_state = 12,
+// n_ctrl = 4 case every piece starts on a 16-byte granule (one DMA lane each).
+enum {
+    LDS_C = 0, LDS_F = 1024, LDS_V = 1792,
+    V_c = 0, V_tau = 64, V_f = 128, V_k = 176, V_lo = 192, V_hi = 208, V_K = 224,
+    STAGE_BYTES = 2208, NSTAGE = 4,
+    DMA_PER_STAGE_FULL = 3,     // C, F, record
+    DMA_PER_STAGE_MIN = 5       // padded shapes: at least C, F, c, x, u (one instruction each)
 };
 
 MPC_DEV void lane_init(Lane &L, int lane, int ns, int nc)
@@ -84,7 +109,103 @@ MPC_DEV void lane_init(Lane &L, int lane, int ns, int nc)
         // rollout: output row = state x(j) (x columns only), contraction slot = (g, r)
         L.vT[r] = L.rowv[r] && L.colv && !L.jq;
         L.offT[r] = L.vT[r] ? coltau * n + tau : 0;
+        L.aC[r] = 4 * L.offC[r];
+        L.aT[r] = 4 * tau;
+        L.aFT[r] = 4 * L.offT[r];
+        L.vK[r] = r > 0 && L.jq && L.ja < nc && L.rowv[r];
+        L.aK[r] = L.vK[r] ? 4 * (L.ja * ns + L.row[r]) : 0;
     }
+    L.aG = L.rowv[0] ? 4 * L.g : 0;
+}
+
+// ---------------------------------------------------------------------------
+// HBM -> LDS staging
+// ---------------------------------------------------------------------------
+// Source of the small-vector record for this lane (n_state = 12, n_ctrl = 4: lane = 16-byte granule).
+struct VecDma {
+    const char *ptr0;     // address for t = 0
+    long step;            // bytes per timestep
+    bool active;
+};
+
+template <int MODE, bool ROLL>
+MPC_DEV void vecdma_init(VecDma &v, const P &p, int lane, int b)
+{
+    // granules: 0-3 c | 4-6 x | 7 u | 8-10 f | 11 k | 12 lo | 13 hi | 14-25 K
+    v.active = false;
+    v.ptr0 = (const char *)p.c;
+    v.step = 0;
+    const long B = p.B;
+    if (lane < 4) {
+        v.active = true; v.ptr0 = (const char *)(p.c + (long)b * p.c_sb + 4 * lane); v.step = 4 * p.c_st;
+    } else if (lane < 7) {
+        v.active = true; v.ptr0 = (const char *)(p.cur_x + (long)b * 12 + 4 * (lane - 4)); v.step = 4 * B * 12;
+    } else if (lane == 7) {
+        v.active = true; v.ptr0 = (const char *)(p.cur_u + (long)b * 4); v.step = 4 * B * 4;
+    } else if (lane < 11) {
+        if (ROLL && p.f) { v.active = true; v.ptr0 = (const char *)(p.f + (long)b * p.f_sb + 4 * (lane - 8)); v.step = 4 * p.f_st; }
+    } else if (lane == 11) {
+        if (ROLL) { v.active = true; v.ptr0 = (const char *)(p.k + (long)b * 4); v.step = 4 * B * 4; }
+    } else if (lane < 14) {
+        if (MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR) {
+            v.active = true;
+            v.ptr0 = (const char *)((lane == 12 ? p.lo : p.hi) + (long)b * 4);
+            v.step = 4 * B * 4;
+        }
+    } else if (lane < 26) {
+        if (ROLL) { v.active = true; v.ptr0 = (const char *)(p.K + (long)b * 48 + 4 * (lane - 14)); v.step = 4 * B * 48; }
+    }
+}
+
+// Issue the DMA of timestep t into ring slot `slot`.  Exactly DMA_PER_STAGE_FULL instructions when
+// FULL, at least DMA_PER_STAGE_MIN otherwise (the counted waits rely on it).
+template <bool FULL, int MODE, bool ROLL>
+MPC_DEV void stage_issue(const P &p, const VecDma &vd, int lane, int b, int t, int slot)
+{
+    const unsigned base = (unsigned)slot * STAGE_BYTES;
+    const int n = p.ns + p.nc;
+    const float *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+    // F has T-1 entries; the last timestep re-reads a valid block nobody looks at
+    const float *Ft = Ct;
+    if (p.T > 1) Ft = p.F + (long)(t < p.T - 1 ? t : p.T - 2) * p.F_st + (long)b * p.F_sb;
+    if (FULL) {
+        wv::dma16(Ct + 4 * lane, base + LDS_C);
+        if (lane < 48) wv::dma16(Ft + 4 * lane, base + LDS_F);
+        if (vd.active) wv::dma16(vd.ptr0 + (long)t * vd.step, base + LDS_V);
+    } else {
+        const long tb = (long)t * p.B + b;
+        const int n2 = n * n, nf = p.T > 1 ? p.ns * n : 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i * 64 < n2) { const int e = lane + 64 * i; if (e < n2) wv::dma4(Ct + e, base + LDS_C + 256 * i); }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i * 64 < nf) { const int e = lane + 64 * i; if (e < nf) wv::dma4(Ft + e, base + LDS_F + 256 * i); }
+        if (lane < n) wv::dma4(p.c + (long)t * p.c_st + (long)b * p.c_sb + lane, base + LDS_V + V_c);
+        if (lane < p.ns) wv::dma4(p.cur_x + tb * p.ns + lane, base + LDS_V + V_tau);
+        if (lane < p.nc) wv::dma4(p.cur_u + tb * p.nc + lane, base + LDS_V + V_tau + 4 * p.ns);
+        if (MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR) {
+            if (lane < p.nc) wv::dma4(p.lo + tb * p.nc + lane, base + LDS_V + V_lo);
+            if (lane < p.nc) wv::dma4(p.hi + tb * p.nc + lane, base + LDS_V + V_hi);
+        }
+        if (ROLL) {
+            if (p.f && p.T > 1 && lane < p.ns)
+                wv::dma4(p.f + (long)(t < p.T - 1 ? t : p.T - 2) * p.f_st + (long)b * p.f_sb + lane, base + LDS_V + V_f);
+            if (lane < p.nc) wv::dma4(p.k + tb * p.nc + lane, base + LDS_V + V_k);
+            if (lane < p.nc * p.ns) wv::dma4(p.K + tb * p.nc * p.ns + lane, base + LDS_V + V_K);
+        }
+    }
+}
+
+template <bool FULL, int NEWER_STAGES>
+MPC_DEV void stage_wait()
+{
+    wv::dma_wait<NEWER_STAGES * (FULL ? (int)DMA_PER_STAGE_FULL : (int)DMA_PER_STAGE_MIN)>();
+}
+
+MPC_DEV int zm_load(const P &p, const Lane &L, int b, int t)
+{
+    return L.rowv[0] ? (int)p.zero_mask[((long)t * p.B + b) * p.nc + L.row[0]] : 0;
 }
 
 MPC_DEV float sel(bool c, float a, float b) { return c ? a : b; }
@@ -229,49 +350,38 @@ struct SwStage {
 
 // MODE: 0 = unconstrained, 1 = unconstrained with u_zero_I (the KKT backward's solve), 2 = box bounds
 template <bool FULL, int MODE>
-MPC_DEV void sw_load(SwStage &s, const P &p, const Lane &L, int b, int t)
+MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, int zm)
 {
-    const long tb = (long)t * p.B + b;
-    const float *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
-    const float *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+    const unsigned base = (unsigned)slot * STAGE_BYTES;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float v = Ct[L.offC[r]];
+        const float v = wv::lds_f32(base + LDS_C + L.aC[r]);
         s.C[r] = FULL ? v : sel(L.vC[r], v, 0.f);
-        const float w = ct[r == 0 ? p.ns + L.row[0] : L.row[r]];
+        const float w = wv::lds_f32(base + LDS_V + V_c + L.aT[r]);
         s.crow[r] = FULL ? w : sel(L.rowv[r], w, 0.f);
+        const float u = wv::lds_f32(base + LDS_V + V_tau + L.aT[r]);
+        s.trow[r] = FULL ? u : sel(L.rowv[r], u, 0.f);
     }
     if (t < p.T - 1) {
-        const float *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
 #pragma unroll
         for (int kb = 1; kb < 4; ++kb) {
-            const float v = Ft[L.offC[kb]];
+            const float v = wv::lds_f32(base + LDS_F + L.aC[kb]);
             s.F[kb - 1] = FULL ? v : sel(L.vC[kb], v, 0.f);
         }
     } else {
         s.F[0] = s.F[1] = s.F[2] = 0.f;
     }
-    {
-        const float v = p.cur_u[tb * p.nc + L.row[0]];
-        s.trow[0] = FULL ? v : sel(L.rowv[0], v, 0.f);
-    }
-#pragma unroll
-    for (int r = 1; r < 4; ++r) {
-        const float v = p.cur_x[tb * p.ns + L.row[r]];
-        s.trow[r] = FULL ? v : sel(L.rowv[r], v, 0.f);
-    }
     s.lo = s.hi = 0.f;
-    s.zm = 0;
     if (MODE == 2) {
         if (p.bound_mode == MPC_BOUND_TENSOR) {
-            s.lo = p.lo[tb * p.nc + L.row[0]];
-            s.hi = p.hi[tb * p.nc + L.row[0]];
+            s.lo = wv::lds_f32(base + LDS_V + V_lo + L.aG);
+            s.hi = wv::lds_f32(base + LDS_V + V_hi + L.aG);
         } else {
             s.lo = p.lo_s;
             s.hi = p.hi_s;
         }
     }
-    if (MODE == 1) s.zm = L.rowv[0] ? (int)p.zero_mask[tb * p.nc + L.row[0]] : 0;
+    s.zm = MODE == 1 ? zm : 0;
 }
 
 struct SwState {
@@ -447,30 +557,23 @@ struct RoStage {
 };
 
 template <bool FULL, int MODE>
-MPC_DEV void ro_load(RoStage &s, const P &p, const Lane &L, int b, int t)
+MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, int zm)
 {
-    const long tb = (long)t * p.B + b;
-    const float *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
-    const float *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+    const unsigned base = (unsigned)slot * STAGE_BYTES;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float v = Ct[L.offC[r]];
+        const float v = wv::lds_f32(base + LDS_C + L.aC[r]);
         s.C[r] = FULL ? v : sel(L.vC[r], v, 0.f);
-        const float w = ct[r == 0 ? p.ns + L.row[0] : L.row[r]];
+        const float w = wv::lds_f32(base + LDS_V + V_c + L.aT[r]);
         s.crow[r] = FULL ? w : sel(L.rowv[r], w, 0.f);
     }
     if (t < p.T - 1) {
-        const float *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const float v = Ft[L.offT[kb]];
-            s.FA[kb] = sel(L.vT[kb], v, 0.f);
-        }
+        for (int kb = 0; kb < 4; ++kb) s.FA[kb] = sel(L.vT[kb], wv::lds_f32(base + LDS_F + L.aFT[kb]), 0.f);
         if (p.f) {
-            const float *ft = p.f + (long)t * p.f_st + (long)b * p.f_sb;
 #pragma unroll
             for (int kb = 1; kb < 4; ++kb) {
-                const float v = ft[L.row[kb]];
+                const float v = wv::lds_f32(base + LDS_V + V_f + L.aT[kb]);
                 s.frow[kb - 1] = FULL ? v : sel(L.rowv[kb], v, 0.f);
             }
         } else {
@@ -480,38 +583,29 @@ MPC_DEV void ro_load(RoStage &s, const P &p, const Lane &L, int b, int t)
         s.FA[0] = s.FA[1] = s.FA[2] = s.FA[3] = 0.f;
         s.frow[0] = s.frow[1] = s.frow[2] = 0.f;
     }
-    {
-        const bool ka = L.jq && (L.ja < p.nc);
-        const float *Kt = p.K + (tb * p.nc + (ka ? L.ja : 0)) * p.ns;
-#pragma unroll
-        for (int kb = 1; kb < 4; ++kb) {
-            const float v = Kt[L.row[kb]];
-            s.KA[kb - 1] = sel(ka && L.rowv[kb], v, 0.f);
-        }
-    }
 #pragma unroll
     for (int kb = 1; kb < 4; ++kb) {
-        const float v = p.cur_x[tb * p.ns + L.row[kb]];
+        s.KA[kb - 1] = sel(L.vK[kb], wv::lds_f32(base + LDS_V + V_K + L.aK[kb]), 0.f);
+        const float v = wv::lds_f32(base + LDS_V + V_tau + L.aT[kb]);
         s.xbar[kb - 1] = FULL ? v : sel(L.rowv[kb], v, 0.f);
     }
     {
-        const float v = p.cur_u[tb * p.nc + L.row[0]];
+        const float v = wv::lds_f32(base + LDS_V + V_tau + L.aT[0]);
         s.ubar = FULL ? v : sel(L.rowv[0], v, 0.f);
-        const float w = p.k[tb * p.nc + L.row[0]];
+        const float w = wv::lds_f32(base + LDS_V + V_k + L.aG);
         s.kk = FULL ? w : sel(L.rowv[0], w, 0.f);
     }
     s.lo = s.hi = 0.f;
-    s.zm = 0;
     if (MODE == 2) {
         if (p.bound_mode == MPC_BOUND_TENSOR) {
-            s.lo = p.lo[tb * p.nc + L.row[0]];
-            s.hi = p.hi[tb * p.nc + L.row[0]];
+            s.lo = wv::lds_f32(base + LDS_V + V_lo + L.aG);
+            s.hi = wv::lds_f32(base + LDS_V + V_hi + L.aG);
         } else {
             s.lo = p.lo_s;
             s.hi = p.hi_s;
         }
     }
-    if (MODE != 0 && p.zero_mask) s.zm = L.rowv[0] ? (int)p.zero_mask[tb * p.nc + L.row[0]] : 0;
+    s.zm = zm;
 }
 
 struct RoState {
@@ -589,21 +683,34 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, int jsel, float &cos
         st.alpha = a;
     }
     const int T = p.T;
-    RoStage s0, s1, s2;
-    ro_load<FULL, MODE>(s0, p, L, b, 0);
-    ro_load<FULL, MODE>(s1, p, L, b, T > 1 ? 1 : 0);
-    int t = 0;
-    while (true) {
-        ro_load<FULL, MODE>(s2, p, L, b, t + 2 < T ? t + 2 : T - 1);
-        rollout_step<FULL, MODE>(p, L, s0, st, b, t, jsel);
-        if (++t >= T) break;
-        ro_load<FULL, MODE>(s0, p, L, b, t + 2 < T ? t + 2 : T - 1);
-        rollout_step<FULL, MODE>(p, L, s1, st, b, t, jsel);
-        if (++t >= T) break;
-        ro_load<FULL, MODE>(s1, p, L, b, t + 2 < T ? t + 2 : T - 1);
-        rollout_step<FULL, MODE>(p, L, s2, st, b, t, jsel);
-        if (++t >= T) break;
+    const int lane = wv::lane();
+    const bool use_zm = MODE != 0 && p.zero_mask != nullptr;
+    VecDma vd;
+    vecdma_init<MODE, true>(vd, p, lane, b);
+    // ring prologue: timesteps 0, 1, 2 in flight (indices past the horizon re-read the last step)
+    int zq[NSTAGE] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ti = i < T ? i : T - 1;
+        stage_issue<FULL, MODE, true>(p, vd, lane, b, ti, i);
+        if (use_zm) zq[i] = zm_load(p, L, b, ti);
     }
+    for (int t0 = 0; t0 < T; t0 += NSTAGE) {
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int t = t0 + i;
+            if (t < T) {
+                stage_wait<FULL, 2>();                       // slots of t+1, t+2 may still be in flight
+                RoStage s;
+                ro_read<FULL, MODE>(s, p, L, t, i, zq[i]);
+                const int tn = t + 3 < T ? t + 3 : T - 1;
+                stage_issue<FULL, MODE, true>(p, vd, lane, b, tn, (i + 3) % NSTAGE);
+                if (use_zm) zq[(i + 3) % NSTAGE] = zm_load(p, L, b, tn);
+                rollout_step<FULL, MODE>(p, L, s, st, b, t, jsel);
+            }
+        }
+    }
+    stage_wait<FULL, 0>();
     // sum the four lane groups: every lane of column j ends with the trial's totals
     float c = st.cost, d = st.du2;
     c += wv::shfl_xor(c, 16); d += wv::shfl_xor(d, 16);
@@ -631,21 +738,31 @@ MPC_DEV void step_problem(const P &p)
     ss.status = 0;
     ss.kprev[0] = ss.kprev[1] = ss.kprev[2] = ss.kprev[3] = 0.f;
     {
-        SwStage s0, s1, s2;
-        sw_load<FULL, MODE>(s0, p, L, b, T - 1);
-        sw_load<FULL, MODE>(s1, p, L, b, T > 1 ? T - 2 : 0);
-        int t = T - 1;
-        while (true) {
-            sw_load<FULL, MODE>(s2, p, L, b, t - 2 >= 0 ? t - 2 : 0);
-            sweep_step<FULL, MODE>(p, L, s0, ss, b, t);
-            if (--t < 0) break;
-            sw_load<FULL, MODE>(s0, p, L, b, t - 2 >= 0 ? t - 2 : 0);
-            sweep_step<FULL, MODE>(p, L, s1, ss, b, t);
-            if (--t < 0) break;
-            sw_load<FULL, MODE>(s1, p, L, b, t - 2 >= 0 ? t - 2 : 0);
-            sweep_step<FULL, MODE>(p, L, s2, ss, b, t);
-            if (--t < 0) break;
+        VecDma vd;
+        vecdma_init<MODE, false>(vd, p, lane, b);
+        int zq[NSTAGE] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int ti = T - 1 - i >= 0 ? T - 1 - i : 0;
+            stage_issue<FULL, MODE, false>(p, vd, lane, b, ti, i);
+            if (MODE == 1) zq[i] = zm_load(p, L, b, ti);
         }
+        for (int k0 = 0; k0 < T; k0 += NSTAGE) {
+#pragma unroll
+            for (int i = 0; i < NSTAGE; ++i) {
+                const int t = T - 1 - (k0 + i);
+                if (t >= 0) {
+                    stage_wait<FULL, 2>();
+                    SwStage s;
+                    sw_read<FULL, MODE>(s, p, L, t, i, zq[i]);
+                    const int tn = t - 3 >= 0 ? t - 3 : 0;
+                    stage_issue<FULL, MODE, false>(p, vd, lane, b, tn, (i + 3) % NSTAGE);
+                    if (MODE == 1) zq[(i + 3) % NSTAGE] = zm_load(p, L, b, tn);
+                    sweep_step<FULL, MODE>(p, L, s, ss, b, t);
+                }
+            }
+        }
+        stage_wait<FULL, 0>();
     }
     const float old_cost = (wv::readlane(ss.oc, 0) + wv::readlane(ss.oc, 16)) +
                            (wv::readlane(ss.oc, 32) + wv::readlane(ss.oc, 48));

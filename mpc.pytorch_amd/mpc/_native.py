@@ -220,9 +220,13 @@ class HipBackend:
 
     def impl_supported(self, ns, nc, dtype, impl, opts=None):
         p = Problem()
-        p.B, p.T, p.ns, p.nc = 1, 2, ns, nc
+        p.B, p.T, p.ns, p.nc = 1, 1, ns, nc
         p.dtype = MPC_F32 if dtype == torch.float32 else MPC_F64
-        return bool(load().mpc_lqr_impl_supported(ctypes.byref(p), None, int(impl)))
+        p.x_init = 16        # the query only looks at sizes and dtype; pointers are never dereferenced
+        o = None
+        if opts is not None:
+            o, _keep = opts.to_struct(1, 1, nc, torch.empty(0, dtype=dtype))
+        return bool(load().mpc_lqr_impl_supported(ctypes.byref(p), None if o is None else ctypes.byref(o), int(impl)))
 
     # -- (1) LQRStepFn.forward ------------------------------------------------------------------
     def lqr_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, want_gains=False, impl=IMPL_AUTO,

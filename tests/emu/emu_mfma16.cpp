@@ -31,9 +31,29 @@ struct Wave {
     float fa[2][NL], fb[2][NL];
     int ia[2][NL];
     unsigned seq[NL];
+    // LDS of the (single-wave) workgroup + the in-order queue of LDS-DMA instructions in flight
+    unsigned char lds[4 * 2208];
+    struct Dma { unsigned char data[NL][16]; bool act[NL]; unsigned off; int size; };
+    Dma q[64];
+    int qn;
+    int region_start;     // queue entries from here on belong to the current lockstep region
 };
 static Wave W;
 static void (*g_body)(void);
+// 0: DMA data lands at issue (earliest legal time); 1: it lands only when a counted wait forces it
+// (latest legal time).  A correct kernel gives identical results in both.
+static int g_dma_late = 0;
+static void dma_land(int keep)
+{
+    while (W.qn > keep) {
+        Wave::Dma &d = W.q[0];
+        for (int l = 0; l < NL; ++l)
+            if (d.act[l]) memcpy(W.lds + d.off + (unsigned)l * d.size, d.data[l], d.size);
+        memmove(&W.q[0], &W.q[1], sizeof(Wave::Dma) * (W.qn - 1));
+        --W.qn;
+        if (W.region_start > 0) --W.region_start;
+    }
+}
 
 static void yield_lane() { swapcontext(&W.ctx[W.cur], &W.main_ctx); }
 static void trampoline()
@@ -56,6 +76,9 @@ static void run_wave(int problem, void (*body)(void))
         W.done[l] = false;
         W.seq[l] = 0;
     }
+    W.qn = 0;
+    W.region_start = 0;
+    memset(W.lds, 0xff, sizeof(W.lds));     // NaN pattern: reading a slot before its DMA landed shows
     for (;;) {
         int ndone = 0;
         for (int l = 0; l < NL; ++l) {
@@ -64,6 +87,9 @@ static void run_wave(int problem, void (*body)(void))
             swapcontext(&W.main_ctx, &W.ctx[l]);
         }
         if (ndone == NL) break;
+        // every lane is now parked at the same lockstep point: the region's DMA instructions are complete
+        if (!g_dma_late) dma_land(0);
+        W.region_start = W.qn;
     }
 }
 }  // namespace emu
@@ -139,6 +165,40 @@ static inline int uniform(int v)
     return v;
 }
 static inline int ctz64(unsigned long long m) { return __builtin_ctzll(m); }
+// ---- LDS-DMA.  Between two lockstep points every lane runs the same instruction sequence (lanes
+// that branch around an instruction are inactive for it), and each DMA instruction of such a region
+// has its own LDS destination, so (offset, size) identifies the instruction a lane is taking part in.
+static inline void dma_n(const void *g, unsigned off, int size)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur;
+    emu::Wave::Dma *d = nullptr;
+    for (int i = w.region_start; i < w.qn; ++i)
+        if (w.q[i].off == off && w.q[i].size == size && !w.q[i].act[l]) { d = &w.q[i]; break; }
+    if (!d) {
+        if (w.qn >= 64) { fprintf(stderr, "emu: DMA queue overflow\n"); abort(); }
+        d = &w.q[w.qn++];
+        memset(d->act, 0, sizeof(d->act));
+        d->off = off;
+        d->size = size;
+    }
+    d->act[l] = true;
+    memcpy(d->data[l], g, size);
+}
+static inline void dma16(const void *g, unsigned off) { dma_n(g, off, 16); }
+static inline void dma4(const void *g, unsigned off) { dma_n(g, off, 4); }
+template <int N> static inline void dma_wait()
+{
+    // lockstep point: every lane has issued its part of the preceding DMA instructions
+    (void)readlane_i(0, 0);
+    if (emu::W.cur == 0) emu::dma_land(emu::g_dma_late ? N : 0);
+}
+static inline float lds_f32(unsigned off)
+{
+    float v;
+    memcpy(&v, emu::W.lds + off, 4);
+    return v;
+}
 static inline void fence_own_stores() {}
 }  // namespace wv
 }  // namespace mpclqr
@@ -153,6 +213,8 @@ template <bool FULL> static void body()
     else if (p.zero_mask) mpclqr::mfma16::step_problem<FULL, 1>(p);
     else mpclqr::mfma16::step_problem<FULL, 0>(p);
 }
+
+extern "C" void emu_set_dma_late(int late) { emu::g_dma_late = late; }
 
 extern "C" int emu_lqr_step_mfma16(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
                                    int force_general)

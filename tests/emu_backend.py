@@ -47,7 +47,7 @@ def _ptr(a):
 
 
 def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None,
-             linesearch_decay=0.2, max_linesearch_iter=10, pnqp_iter=20, force_general=False):
+             linesearch_decay=0.2, max_linesearch_iter=10, pnqp_iter=20, force_general=False, dma_late=False):
     """Same signature as oracle.lqr_oracle.lqr_step; float32 only.  Returns the kernel's outputs."""
     f32 = np.float32
     C = np.ascontiguousarray(C, f32); c = np.ascontiguousarray(c, f32)
@@ -95,6 +95,7 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
     out = N.Outputs()
     for key, arr in res.items():
         setattr(out, key, _ptr(arr))
+    lib().emu_set_dma_late(int(bool(dma_late)))
     rc = lib().emu_lqr_step_mfma16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), int(force_general))
     assert rc == 0, rc
     return res

