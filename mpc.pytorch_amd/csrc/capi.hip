@@ -55,22 +55,30 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
     }
     const int64_t needK = (int64_t)p->T * p->B * p->nc * p->ns * (int64_t)sizeof(real);
     const int64_t needk = (int64_t)p->T * p->B * p->nc * (int64_t)sizeof(real);
+    if (phase_mask == 3 && impl != 1) {
+        if constexpr (sizeof(real) == 4) {
+            const bool fast = mfma16_supported(sp);
+            if (impl == 2 && !fast)
+                return fail(MPC_E_DIMS, "fused MFMA kernel needs fp32, n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16");
+            if (fast) {
+                // the kernel parks its gains [T,B,4,16] in the workspace; out->K / out->k are optional
+                const int64_t need = (int64_t)p->T * p->B * 64 * (int64_t)sizeof(float);
+                if (!workspace || workspace_bytes < need)
+                    return fail(MPC_E_ARG, "workspace too small (see mpc_lqr_workspace_bytes)");
+                if ((sp.K == nullptr) != (sp.k == nullptr)) return fail(MPC_E_NULL, "pass both K and k, or neither");
+                sp.Kk = (float *)workspace;
+                return launch_step_mfma16(sp, st);
+            }
+        } else if (impl == 2) {
+            return fail(MPC_E_DTYPE, "fused MFMA kernel is fp32 only");
+        }
+    }
     if (!sp.K || !sp.k) {
         if (phase_mask != 3) return fail(MPC_E_NULL, "K / k is NULL");
         if (!workspace || workspace_bytes < needK + needk)
             return fail(MPC_E_ARG, "workspace too small (see mpc_lqr_workspace_bytes)");
         sp.K = (real *)workspace;
         sp.k = (real *)((char *)workspace + needK);
-    }
-    if (phase_mask == 3 && impl != 1) {
-        if constexpr (sizeof(real) == 4) {
-            const bool fast = mfma16_supported(sp);
-            if (impl == 2 && !fast)
-                return fail(MPC_E_DIMS, "fused MFMA kernel needs fp32, n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16");
-            if (fast) return launch_step_mfma16(sp, st);
-        } else if (impl == 2) {
-            return fail(MPC_E_DTYPE, "fused MFMA kernel is fp32 only");
-        }
     }
     return launch_step_generic<real>(sp, phase_mask, st);
 }
@@ -94,7 +102,9 @@ int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p)
 {
     if (!p) return 0;
     const int64_t e = p->dtype == MPC_F64 ? 8 : 4;
-    return ((int64_t)p->T * p->B * p->nc * p->ns + (int64_t)p->T * p->B * p->nc) * e + 256;
+    const int64_t generic = ((int64_t)p->T * p->B * p->nc * p->ns + (int64_t)p->T * p->B * p->nc) * e;
+    const int64_t fused = (int64_t)p->T * p->B * 64 * 4;      // gain record of the fused MFMA kernel
+    return (generic > fused ? generic : fused) + 256;
 }
 
 int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,

@@ -30,7 +30,7 @@ MPC_DEV unsigned long long ballot(bool c) { return __ballot(c); }
 MPC_DEV int ctz64(unsigned long long m) { return __builtin_ctzll(m); }
 // ---- HBM -> LDS staging --------------------------------------------------------------------
 // One ring of NSTAGE stage buffers per wavefront (= per workgroup).
-#define MPC_LDS_BYTES (4 * 2208)
+#define MPC_LDS_BYTES (4 * 2288 + 64)
 __shared__ __attribute__((aligned(16))) char g_stage[MPC_LDS_BYTES];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -44,6 +44,12 @@ MPC_DEV void dma4(const void *g, unsigned off)
     __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage + off), 4, 0, 0);
 }
 MPC_DEV float lds_f32(unsigned off) { return *(const float *)(g_stage + off); }
+MPC_DEV f32x4 lds_f32x4(unsigned off) { return *(const f32x4 *)(g_stage + off); }
+MPC_DEV void lds_store_f32(unsigned off, float v) { *(float *)(g_stage + off) = v; }
+MPC_DEV void lds_store_f32x4(unsigned off, f32x4 v) { *(f32x4 *)(g_stage + off) = v; }
+// LDS traffic between lanes of ONE wave: DS instructions execute in program order, so a compiler
+// barrier is all the ordering there is to ask for.
+MPC_DEV void lds_sync() { asm volatile("" ::: "memory"); }
 // Wait until at most N of this wave's vector-memory operations are outstanding.  hipcc does not
 // order LDS reads behind an LDS-DMA by itself; this is the ordering point (and a compiler barrier).
 template <int N> MPC_DEV void dma_wait()
@@ -94,7 +100,8 @@ bool mfma16_supported(const StepParams<float> &p)
 int launch_step_mfma16(const StepParams<float> &p, hipStream_t st)
 {
     if (!mfma16_supported(p)) { set_last_error("mfma16: needs n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16"); return MPC_E_DIMS; }
-    if (!p.K || !p.k) { set_last_error("mfma16: K / k scratch missing"); return MPC_E_NULL; }
+    if (!p.Kk) { set_last_error("mfma16: gain workspace missing"); return MPC_E_NULL; }
+    static_assert(MPC_LDS_BYTES == mfma16::LDS_TOTAL, "LDS layout out of sync");
     if (!p.new_x || !p.new_u) { set_last_error("mfma16: new_x / new_u is NULL"); return MPC_E_NULL; }
     if (p.ns == 12 && p.nc == 4)
         launch_mode<true>(p, st);

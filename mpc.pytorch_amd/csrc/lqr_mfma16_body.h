@@ -4,14 +4,14 @@
 // moves between lanes except a handful of readlanes of the 4x4 control block.
 //
 // This file is written against a tiny "wave" interface (namespace wv: lane(),
-// mfma(), readlane(), ...).  lqr_mfma16.hip binds it to the gfx950 builtins;
-// tests/emu/emu_mfma16.cpp binds it to a host-side 64-fiber lockstep emulator so
-// the very same source is parity-tested on a CPU-only box.
+// mfma(), readlane(), dma16(), lds_f32(), ...).  lqr_mfma16.hip binds it to the
+// gfx950 builtins; tests/emu/emu_mfma16.cpp binds it to a host-side 64-fiber
+// lockstep emulator so the very same source is parity-tested on a CPU-only box.
 //
 // What it replaces in locuslab/mpc.pytorch (one launch instead of ~4,000 ATen ops):
-//   sweep_step     mpc/lqr_step.py:284-296 (c_back) + :52-160 (lqr_backward)
-//   pnqp4          mpc/pnqp.py:5-82 (the in-sweep n_ctrl-dimensional box QP)
-//   rollout_pass   mpc/lqr_step.py:164-261 (lqr_forward), mpc/util.py:129-153
+//   sweep_step      mpc/lqr_step.py:284-296 (c_back) + :52-160 (lqr_backward)
+//   pnqp4           mpc/pnqp.py:5-82 (the in-sweep n_ctrl-dimensional box QP)
+//   rollout_*       mpc/lqr_step.py:164-261 (lqr_forward), mpc/util.py:129-153
 //
 // ---------------------------------------------------------------------------
 // Layout.  MFMA 16x16x4 f32: lane l = 16 g + j holds  A[i=j][k=g],  B[k=g][j],
@@ -29,18 +29,22 @@
 //   * column j = 0 carries the linear terms: Q'[:,0] = q, K'[:,0] = k, M'[:,0] =
 //     qu + Quu k, V'[:,0] = v.  (Q[u0][u0], the one entry that loses its place,
 //     is rebuilt from 3 FMAs + 4 readlanes.)
-//   * the rollout propagates SIXTEEN line-search candidates at once: column j of
-//     the B operand is the state of the trial with alpha = decay^j, so the whole
-//     line search of mpc/lqr_step.py:176-252 is one pass over C, F (a second pass
-//     re-runs the accepted column only when alpha = 1 was rejected).
+//   * the rollout keeps its state as column 0 of the B operand, [u;x] in slot order,
+//     so u' = K dx and x+ = F [x';u'] are MFMAs whose output is already the next
+//     step's operand.  When the full step (alpha = 1) is rejected, ONE more pass
+//     propagates all the remaining line-search candidates at once -- column j is the
+//     trial with alpha = decay^j (mpc/lqr_step.py:176-252) -- and a last pass stores
+//     the accepted one.
 //
-// Staging.  Every per-timestep block (C_t 1 KiB, F_t 768 B, and one 416 B record of
-// the small vectors c, x, u, f, k, bounds, K) is DMA'd HBM -> LDS with
+// Staging.  Every per-timestep block (C_t 1 KiB, F_t 768 B, and one ~0.5 KiB record
+// of the small vectors c, x, u, f, bounds and the gains) is DMA'd HBM -> LDS with
 // global_load_lds (16 B per lane, no VGPRs held while in flight) into a 4-slot ring
 // per wavefront, three timesteps ahead of its use; the step then picks its MFMA
-// operands out of LDS in whatever lane order the layout above wants.  The waits are
-// counted s_waitcnt vmcnt(N) on the number of NEWER DMA instructions (loads return in
-// order; stores in flight only make the wait more conservative).
+// operands out of LDS in whatever lane order the layout above wants (a per-lane
+// address picks "vector entry in column 0, matrix entry elsewhere", or a word of
+// zeros, so no select instructions are spent on it).  The waits are counted
+// s_waitcnt vmcnt(N) on the number of NEWER DMA instructions (loads return in order;
+// stores in flight only make the wait more conservative).
 //
 // C is read as the symmetric matrix the reference documents it to be
 // (mpc/mpc.py:61-68; its own delta-space gradient C tau + c, :294, is only a
@@ -56,39 +60,43 @@ namespace mfma16 {
 typedef StepParams<float> P;
 using wv::f32x4;
 
-struct Lane {
-    int g, j;
-    bool j0, jq;          // j == 0 (vector column), (j & 3) == 0 (u column)
-    int ja;               // j >> 2
-    int col;              // tau index of column slot j (0 if padding)
-    bool colv;
-    int row[4];           // tau-or-x index of row slot 4g+r: r = 0 -> control g, r >= 1 -> state 3g+r-1
-    bool rowv[4];
-    int offC[4];          // row[r]-as-tau-index * n + col     (C in D layout; rows 1..3 double as F rows)
-    int offT[4];          // col * n + row[r]-as-tau-index      (F as the rollout's A operand)
-    bool vC[4], vT[4];
-    // byte offsets into an LDS stage
-    int aC[4];            // 4 * offC[r]                     (+LDS_C: C[r]; +LDS_F: F rows, r >= 1)
-    int aT[4];            // 4 * tau index of row slot r     (+V_c: c; +V_tau: nominal tau; +V_f: f, r >= 1)
-    int aFT[4];           // 4 * offT[r]                     (+LDS_F)
-    int aK[4];            // 4 * (ja * ns + row[r]), r >= 1  (+V_K)
-    int aG;               // 4 * g                           (+V_k, V_lo, V_hi)
-    bool vK[4];
-};
-
-// LDS stage layout (bytes).  The record of small vectors is laid out so that in the n_state = 12,
-// n_ctrl = 4 case every piece starts on a 16-byte granule (one DMA lane each).
+// LDS layout (bytes): a ring of NSTAGE stages + 64 B of scratch.  The record of small vectors is
+// laid out so that in the n_state = 12, n_ctrl = 4 case every piece starts on a 16-byte granule
+// (one DMA lane each).
 enum {
     LDS_C = 0, LDS_F = 1024, LDS_V = 1792,
-    V_c = 0, V_tau = 64, V_f = 128, V_k = 176, V_lo = 192, V_hi = 208, V_K = 224,
-    STAGE_BYTES = 2208, NSTAGE = 4,
+    V_c = 0, V_tau = 64, V_f = 128, V_lo = 192, V_hi = 208, V_K = 224, V_zero = 480,
+    STAGE_BYTES = 2288, NSTAGE = 4,
+    LDS_SCRATCH = NSTAGE * STAGE_BYTES, LDS_TOTAL = LDS_SCRATCH + 64,
     DMA_PER_STAGE_FULL = 3,     // C, F, record
     DMA_PER_STAGE_MIN = 5       // padded shapes: at least C, F, c, x, u (one instruction each)
+};
+
+struct Lane {
+    int lane, g, j, ja;
+    bool j0, jq;          // j == 0 (vector column), (j & 3) == 0 (u column)
+    int col;              // tau index of column slot j (0 if padding)
+    bool colv;
+    int row[4];           // control index g (r = 0) / state index 3g+r-1 (r >= 1) of row slot 4g+r
+    bool rowv[4];
+    bool vC[4], vT[4], vK;
+    // byte offsets into an LDS stage
+    int aC[4];            // LDS_C + C[rowtau r][col]                    (rows 1..3 double as F rows: +LDS_F-LDS_C)
+    int aT[4];            // 4 * tau index of row slot r                  (+LDS_V+V_c: c; +V_tau: tau; +V_f: f)
+    int aQi[4];           // column 0: c[row r];   elsewhere: C[row r][col]
+    int aTb[4];           // column 0: tau[row r]; elsewhere: a word of zeros
+    int aFT[4];           // LDS_F + F[x(col)][rowtau r]                  (F as the rollout's A operand)
+    int aKA;              // u columns: the 16 B  Kk[ja][4g .. 4g+3];  elsewhere: zeros
+    int aKk;              // Kk[g][0] = k_g
+    int aG;               // 4 * g  (+LDS_V+V_lo / V_hi)
+    float eg[4];          // one-hot of g
+    float nea[4];         // -1 at (u column, ja == a), else 0
 };
 
 MPC_DEV void lane_init(Lane &L, int lane, int ns, int nc)
 {
     const int n = ns + nc;
+    L.lane = lane;
     L.g = lane >> 4;
     L.j = lane & 15;
     L.j0 = L.j == 0;
@@ -99,116 +107,34 @@ MPC_DEV void lane_init(Lane &L, int lane, int ns, int nc)
     else { const int x = 3 * L.ja + (L.j & 3) - 1; L.colv = x < ns; coltau = x; }
     if (!L.colv) coltau = 0;
     L.col = coltau;
+#pragma unroll
     for (int r = 0; r < 4; ++r) {
         int tau;
         if (r == 0) { L.rowv[0] = L.g < nc; L.row[0] = L.g; tau = ns + L.g; }
         else { const int x = 3 * L.g + r - 1; L.rowv[r] = x < ns; L.row[r] = x; tau = x; }
         if (!L.rowv[r]) { L.row[r] = 0; tau = 0; }
         L.vC[r] = L.rowv[r] && L.colv;
-        L.offC[r] = L.vC[r] ? tau * n + coltau : 0;
+        L.aC[r] = LDS_C + (L.vC[r] ? 4 * (tau * n + coltau) : 0);
+        L.aT[r] = 4 * tau;
+        L.aQi[r] = L.j0 ? LDS_V + V_c + L.aT[r] : L.aC[r];
+        L.aTb[r] = L.j0 ? LDS_V + V_tau + L.aT[r] : LDS_V + V_zero;
         // rollout: output row = state x(j) (x columns only), contraction slot = (g, r)
         L.vT[r] = L.rowv[r] && L.colv && !L.jq;
-        L.offT[r] = L.vT[r] ? coltau * n + tau : 0;
-        L.aC[r] = 4 * L.offC[r];
-        L.aT[r] = 4 * tau;
-        L.aFT[r] = 4 * L.offT[r];
-        L.vK[r] = r > 0 && L.jq && L.ja < nc && L.rowv[r];
-        L.aK[r] = L.vK[r] ? 4 * (L.ja * ns + L.row[r]) : 0;
+        L.aFT[r] = LDS_F + (L.vT[r] ? 4 * (coltau * n + tau) : 0);
+        L.eg[r] = L.g == r ? 1.f : 0.f;
+        L.nea[r] = (L.jq && L.ja == r) ? -1.f : 0.f;
     }
+    L.vK = L.jq && L.ja < nc;
+    L.aKA = L.vK ? LDS_V + V_K + 4 * (16 * L.ja + 4 * L.g) : LDS_V + V_zero;
+    L.aKk = LDS_V + V_K + 4 * 16 * L.g;
     L.aG = L.rowv[0] ? 4 * L.g : 0;
 }
 
-// ---------------------------------------------------------------------------
-// HBM -> LDS staging
-// ---------------------------------------------------------------------------
-// Source of the small-vector record for this lane (n_state = 12, n_ctrl = 4: lane = 16-byte granule).
-struct VecDma {
-    const char *ptr0;     // address for t = 0
-    long step;            // bytes per timestep
-    bool active;
-};
-
-template <int MODE, bool ROLL>
-MPC_DEV void vecdma_init(VecDma &v, const P &p, int lane, int b)
-{
-    // granules: 0-3 c | 4-6 x | 7 u | 8-10 f | 11 k | 12 lo | 13 hi | 14-25 K
-    v.active = false;
-    v.ptr0 = (const char *)p.c;
-    v.step = 0;
-    const long B = p.B;
-    if (lane < 4) {
-        v.active = true; v.ptr0 = (const char *)(p.c + (long)b * p.c_sb + 4 * lane); v.step = 4 * p.c_st;
-    } else if (lane < 7) {
-        v.active = true; v.ptr0 = (const char *)(p.cur_x + (long)b * 12 + 4 * (lane - 4)); v.step = 4 * B * 12;
-    } else if (lane == 7) {
-        v.active = true; v.ptr0 = (const char *)(p.cur_u + (long)b * 4); v.step = 4 * B * 4;
-    } else if (lane < 11) {
-        if (ROLL && p.f) { v.active = true; v.ptr0 = (const char *)(p.f + (long)b * p.f_sb + 4 * (lane - 8)); v.step = 4 * p.f_st; }
-    } else if (lane == 11) {
-        if (ROLL) { v.active = true; v.ptr0 = (const char *)(p.k + (long)b * 4); v.step = 4 * B * 4; }
-    } else if (lane < 14) {
-        if (MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR) {
-            v.active = true;
-            v.ptr0 = (const char *)((lane == 12 ? p.lo : p.hi) + (long)b * 4);
-            v.step = 4 * B * 4;
-        }
-    } else if (lane < 26) {
-        if (ROLL) { v.active = true; v.ptr0 = (const char *)(p.K + (long)b * 48 + 4 * (lane - 14)); v.step = 4 * B * 48; }
-    }
-}
-
-// Issue the DMA of timestep t into ring slot `slot`.  Exactly DMA_PER_STAGE_FULL instructions when
-// FULL, at least DMA_PER_STAGE_MIN otherwise (the counted waits rely on it).
-template <bool FULL, int MODE, bool ROLL>
-MPC_DEV void stage_issue(const P &p, const VecDma &vd, int lane, int b, int t, int slot)
-{
-    const unsigned base = (unsigned)slot * STAGE_BYTES;
-    const int n = p.ns + p.nc;
-    const float *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
-    // F has T-1 entries; the last timestep re-reads a valid block nobody looks at
-    const float *Ft = Ct;
-    if (p.T > 1) Ft = p.F + (long)(t < p.T - 1 ? t : p.T - 2) * p.F_st + (long)b * p.F_sb;
-    if (FULL) {
-        wv::dma16(Ct + 4 * lane, base + LDS_C);
-        if (lane < 48) wv::dma16(Ft + 4 * lane, base + LDS_F);
-        if (vd.active) wv::dma16(vd.ptr0 + (long)t * vd.step, base + LDS_V);
-    } else {
-        const long tb = (long)t * p.B + b;
-        const int n2 = n * n, nf = p.T > 1 ? p.ns * n : 1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i * 64 < n2) { const int e = lane + 64 * i; if (e < n2) wv::dma4(Ct + e, base + LDS_C + 256 * i); }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (i * 64 < nf) { const int e = lane + 64 * i; if (e < nf) wv::dma4(Ft + e, base + LDS_F + 256 * i); }
-        if (lane < n) wv::dma4(p.c + (long)t * p.c_st + (long)b * p.c_sb + lane, base + LDS_V + V_c);
-        if (lane < p.ns) wv::dma4(p.cur_x + tb * p.ns + lane, base + LDS_V + V_tau);
-        if (lane < p.nc) wv::dma4(p.cur_u + tb * p.nc + lane, base + LDS_V + V_tau + 4 * p.ns);
-        if (MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR) {
-            if (lane < p.nc) wv::dma4(p.lo + tb * p.nc + lane, base + LDS_V + V_lo);
-            if (lane < p.nc) wv::dma4(p.hi + tb * p.nc + lane, base + LDS_V + V_hi);
-        }
-        if (ROLL) {
-            if (p.f && p.T > 1 && lane < p.ns)
-                wv::dma4(p.f + (long)(t < p.T - 1 ? t : p.T - 2) * p.f_st + (long)b * p.f_sb + lane, base + LDS_V + V_f);
-            if (lane < p.nc) wv::dma4(p.k + tb * p.nc + lane, base + LDS_V + V_k);
-            if (lane < p.nc * p.ns) wv::dma4(p.K + tb * p.nc * p.ns + lane, base + LDS_V + V_K);
-        }
-    }
-}
-
-template <bool FULL, int NEWER_STAGES>
-MPC_DEV void stage_wait()
-{
-    wv::dma_wait<NEWER_STAGES * (FULL ? (int)DMA_PER_STAGE_FULL : (int)DMA_PER_STAGE_MIN)>();
-}
-
-MPC_DEV int zm_load(const P &p, const Lane &L, int b, int t)
-{
-    return L.rowv[0] ? (int)p.zero_mask[((long)t * p.B + b) * p.nc + L.row[0]] : 0;
-}
-
 MPC_DEV float sel(bool c, float a, float b) { return c ? a : b; }
+MPC_DEV float dot4(const float a[4], float b0, float b1, float b2, float b3)
+{
+    return fmaf(a[3], b3, fmaf(a[2], b2, fmaf(a[1], b1, a[0] * b0)));
+}
 
 // ---------------------------------------------------------------------------
 // 4x4 symmetric factorisation  S = L D L'  on wave-uniform values (every lane
@@ -223,6 +149,7 @@ template <bool MASKED>
 MPC_DEV void ldl4(Ldl4 &f, const Sym4 &s, const bool fr_[4], float reg)
 {
     bool fr[4];
+#pragma unroll
     for (int a = 0; a < 4; ++a) fr[a] = MASKED ? fr_[a] : true;
     const float a00 = fr[0] ? s.s00 + reg : 1.f;
     const float a10 = (fr[0] && fr[1]) ? s.s01 : 0.f;
@@ -292,7 +219,7 @@ MPC_DEV float qp_obj4(const Sym4 &s, const float q[4], const float x[4])
 // solution on exit; fr/f are the free set and factorisation the reference returns
 // (those of the iteration that detected convergence, or of the last one).
 MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const float ub[4],
-                         const bool valid[4], int n_iter, float x[4], bool fr[4], Ldl4 &f, bool &converged)
+                  const bool valid[4], int n_iter, float x[4], bool fr[4], Ldl4 &f, bool &converged)
 {
     int it_ret = n_iter - 1;
     converged = false;
@@ -300,6 +227,7 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
         float g[4];
         sym4_mv(s, x, g);                                           // :29
         float gm[4];
+#pragma unroll
         for (int a = 0; a < 4; ++a) {
             g[a] += q[a];
             const bool ic = ((x[a] == lb[a]) && (g[a] > 0.f)) || ((x[a] == ub[a]) && (g[a] < 0.f));   // :32
@@ -310,6 +238,7 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
         float dx[4];
         ldl4_solve(f, gm[0], gm[1], gm[2], gm[3], dx);               // :50-54
         float nrm2 = 0.f;
+#pragma unroll
         for (int a = 0; a < 4; ++a) {
             dx[a] = fr[a] ? -dx[a] : 0.f;
             nrm2 = fmaf(dx[a], dx[a], nrm2);
@@ -324,16 +253,120 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
         const float obj_x = qp_obj4(s, q, x);
         float mx[4];
         for (int count = 0; count < 10; ++count) {
+#pragma unroll
             for (int a = 0; a < 4; ++a) mx[a] = eclampf(fmaf(alpha, dx[a], x[a]), lb[a], ub[a]);
             const float obj_m = qp_obj4(s, q, mx);
             float den = 0.f;
+#pragma unroll
             for (int a = 0; a < 4; ++a) den = fmaf(g[a], x[a] - mx[a], den);
             const float arm = (obj_x - obj_m) / den;
             if (wv::uniform(arm <= 0.1f)) alpha *= 0.1f; else break;
         }
+#pragma unroll
         for (int a = 0; a < 4; ++a) x[a] = mx[a];                    // :78
     }
     return it_ret;
+}
+
+// ---------------------------------------------------------------------------
+// HBM -> LDS staging
+// ---------------------------------------------------------------------------
+// Source of the small-vector record for this lane (n_state = 12, n_ctrl = 4: lane = 16-byte granule):
+//   granules 0-3 c | 4-6 x | 7 u | 8-10 f | 12 lo | 13 hi | 14-29 Kk (gains of the sweep)
+struct VecDma {
+    const char *ptr;      // address for the next timestep to be issued
+    long step;            // bytes per timestep (negative in the sweep)
+    bool active;
+    bool is_f;            // f has T-1 entries: the last record re-reads f[T-2] (never used)
+};
+
+template <int MODE, bool ROLL>
+MPC_DEV void vecdma_init(VecDma &v, const P &p, int lane, int b, int t0)
+{
+    v.active = false;
+    v.is_f = false;
+    const char *q = (const char *)p.c;
+    long st = 0;
+    const long B = p.B;
+    if (lane < 4) {
+        v.active = true; q = (const char *)(p.c + (long)b * p.c_sb + 4 * lane); st = 4 * p.c_st;
+    } else if (lane < 7) {
+        v.active = true; q = (const char *)(p.cur_x + (long)b * 12 + 4 * (lane - 4)); st = 4 * B * 12;
+    } else if (lane == 7) {
+        v.active = true; q = (const char *)(p.cur_u + (long)b * 4); st = 4 * B * 4;
+    } else if (lane < 11) {
+        if (ROLL && p.f && p.T > 1) {
+            v.active = true; v.is_f = true;
+            q = (const char *)(p.f + (long)b * p.f_sb + 4 * (lane - 8)); st = 4 * p.f_st;
+        }
+    } else if (lane == 11) {
+    } else if (lane < 14) {
+        if (MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR) {
+            v.active = true; q = (const char *)((lane == 12 ? p.lo : p.hi) + (long)b * 4); st = 4 * B * 4;
+        }
+    } else if (lane < 30) {
+        if (ROLL) { v.active = true; q = (const char *)(p.Kk + (long)b * 64 + 4 * (lane - 14)); st = 4 * B * 64; }
+    }
+    v.ptr = q + (long)t0 * st;
+    v.step = ROLL ? st : -st;
+}
+
+// Issue the DMA of timestep t into ring slot `slot` and advance the record pointer (`advance` is
+// false for the re-issues past the end of the horizon, which only keep the DMA count constant).
+// Exactly DMA_PER_STAGE_FULL instructions when FULL, at least DMA_PER_STAGE_MIN otherwise.
+template <bool FULL, int MODE, bool ROLL>
+MPC_DEV void stage_issue(const P &p, VecDma &vd, int lane, int b, int t, int slot, bool advance)
+{
+    const unsigned base = (unsigned)slot * STAGE_BYTES;
+    const int n = p.ns + p.nc;
+    const float *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+    // F has T-1 entries; the last timestep re-reads a valid block nobody looks at
+    const float *Ft = Ct;
+    const int tf = t < p.T - 1 ? t : p.T - 2;
+    if (p.T > 1) Ft = p.F + (long)tf * p.F_st + (long)b * p.F_sb;
+    if (FULL) {
+        const unsigned lo16 = 16u * (unsigned)lane;
+        wv::dma16((const char *)Ct + lo16, base + LDS_C);
+        if (lane < 48) wv::dma16((const char *)Ft + lo16, base + LDS_F);
+        if (vd.active) {
+            const char *src = vd.ptr;
+            if (ROLL && vd.is_f && t >= p.T - 1) src -= vd.step;
+            wv::dma16(src, base + LDS_V);
+        }
+        if (advance) vd.ptr += vd.step;
+    } else {
+        const long tb = (long)t * p.B + b;
+        const int n2 = n * n, nf = p.T > 1 ? p.ns * n : 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i * 64 < n2) { const int e = lane + 64 * i; if (e < n2) wv::dma4(Ct + e, base + LDS_C + 256 * i); }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i * 64 < nf) { const int e = lane + 64 * i; if (e < nf) wv::dma4(Ft + e, base + LDS_F + 256 * i); }
+        if (lane < n) wv::dma4(p.c + (long)t * p.c_st + (long)b * p.c_sb + lane, base + LDS_V + V_c);
+        if (lane < p.ns) wv::dma4(p.cur_x + tb * p.ns + lane, base + LDS_V + V_tau);
+        if (lane < p.nc) wv::dma4(p.cur_u + tb * p.nc + lane, base + LDS_V + V_tau + 4 * p.ns);
+        if (MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR) {
+            if (lane < p.nc) wv::dma4(p.lo + tb * p.nc + lane, base + LDS_V + V_lo);
+            if (lane < p.nc) wv::dma4(p.hi + tb * p.nc + lane, base + LDS_V + V_hi);
+        }
+        if (ROLL) {
+            if (p.f && p.T > 1 && lane < p.ns)
+                wv::dma4(p.f + (long)tf * p.f_st + (long)b * p.f_sb + lane, base + LDS_V + V_f);
+            wv::dma4(p.Kk + tb * 64 + lane, base + LDS_V + V_K);
+        }
+    }
+}
+
+template <bool FULL, int NEWER_STAGES>
+MPC_DEV void stage_wait()
+{
+    wv::dma_wait<NEWER_STAGES * (FULL ? (int)DMA_PER_STAGE_FULL : (int)DMA_PER_STAGE_MIN)>();
+}
+
+MPC_DEV int zm_load(const P &p, const Lane &L, int b, int t)
+{
+    return L.rowv[0] ? (int)p.zero_mask[((long)t * p.B + b) * p.nc + L.row[0]] : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -341,9 +374,9 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
 // ---------------------------------------------------------------------------
 struct SwStage {
     float C[4];       // C_t in D layout (register r = row slot 4g+r)
+    float Qi[4];      // the same with column 0 replaced by c_t (row layout): accumulator init of Q'
+    float Tb[4];      // nominal tau_t in row layout in column 0, zeros elsewhere (B operand of C tau)
     float F[3];       // F_t rows x-slot(g,kb), kb = 1..3, at column var(j)
-    float crow[4];    // c_t in row layout (wave-group uniform)
-    float trow[4];    // nominal tau_t in row layout: [u_g, x_3g, x_3g+1, x_3g+2]
     float lo, hi;     // control bounds of u_g (tensor or scalar mode)
     int zm;           // u_zero_I of u_g
 };
@@ -355,17 +388,17 @@ MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, int
     const unsigned base = (unsigned)slot * STAGE_BYTES;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float v = wv::lds_f32(base + LDS_C + L.aC[r]);
+        const float v = wv::lds_f32(base + L.aC[r]);
         s.C[r] = FULL ? v : sel(L.vC[r], v, 0.f);
-        const float w = wv::lds_f32(base + LDS_V + V_c + L.aT[r]);
-        s.crow[r] = FULL ? w : sel(L.rowv[r], w, 0.f);
-        const float u = wv::lds_f32(base + LDS_V + V_tau + L.aT[r]);
-        s.trow[r] = FULL ? u : sel(L.rowv[r], u, 0.f);
+        const float w = wv::lds_f32(base + L.aQi[r]);
+        s.Qi[r] = FULL ? w : sel(L.j0 ? L.rowv[r] : L.vC[r], w, 0.f);
+        const float u = wv::lds_f32(base + L.aTb[r]);
+        s.Tb[r] = FULL ? u : sel(L.rowv[r], u, 0.f);
     }
     if (t < p.T - 1) {
 #pragma unroll
         for (int kb = 1; kb < 4; ++kb) {
-            const float v = wv::lds_f32(base + LDS_F + L.aC[kb]);
+            const float v = wv::lds_f32(base + (LDS_F - LDS_C) + L.aC[kb]);
             s.F[kb - 1] = FULL ? v : sel(L.vC[kb], v, 0.f);
         }
     } else {
@@ -402,13 +435,11 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     // c_back - c = C tau  (mpc/lqr_step.py:289-295): contraction over all 16 slots, column 0 only
     f32x4 CB = zero4;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) CB = wv::mfma(s.C[kb], sel(L.j0, s.trow[kb], 0.f), CB);
+    for (int kb = 0; kb < 4; ++kb) CB = wv::mfma(s.C[kb], s.Tb[kb], CB);
 
     // Y = V_{t+1} F_t   (:65-70), x slots only (kb = 1..3)
     f32x4 Y = zero4;
-    f32x4 Q;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Q[r] = sel(L.j0, s.crow[r], s.C[r]);
+    f32x4 Q = {s.Qi[0], s.Qi[1], s.Qi[2], s.Qi[3]};
     float q00p = 0.f;
     if (!last) {
 #pragma unroll
@@ -418,12 +449,13 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #pragma unroll
         for (int kb = 1; kb < 4; ++kb) Q = wv::mfma(s.F[kb - 1], sel(L.j0, st.Vp[kb], Y[kb]), Q);
     }
-    // nominal cost 0.5 tau'C tau + c'tau (util.get_cost, mpc/lqr_step.py:169) off the same product
+    // nominal cost 0.5 tau'C tau + c'tau (util.get_cost, mpc/lqr_step.py:169) off the same product:
+    // Tb is tau in column 0 and zero elsewhere, Qi is c there
     {
-        float ocl = 0.f;
+        float ocl = st.oc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ocl = fmaf(s.trow[r], fmaf(0.5f, CB[r], s.crow[r]), ocl);
-        st.oc += sel(L.j0, ocl, 0.f);
+        for (int r = 0; r < 4; ++r) ocl = fmaf(s.Tb[r], fmaf(0.5f, CB[r], s.Qi[r]), ocl);
+        st.oc = ocl;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) Q[r] += CB[r];          // CB is exactly 0 outside column 0
@@ -438,17 +470,13 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     S.s00 = wv::readlane(s.C[0], 0);
     if (!last)
         S.s00 += (wv::readlane(q00p, 0) + wv::readlane(q00p, 16)) + (wv::readlane(q00p, 32) + wv::readlane(q00p, 48));
-    float qu[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) qu[a] = wv::readlane(U, 16 * a);
 
     bool valid[4], fr[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) valid[a] = a < p.nc;
     Ldl4 f;
     float kq[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool bounded = MODE == 2;
-    if (!bounded) {
+    if (MODE != 2) {
         // :84-94 unconstrained / :99-127 masked (u_zero_I): masked rows and columns drop out
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -458,10 +486,11 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         ldl4<(!FULL || MODE == 1)>(f, S, fr, 0.f);
     } else {
         // :128-141 box constraints in delta space
-        float lb[4], ub[4];
+        float qu[4], lb[4], ub[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const float u = wv::readlane(s.trow[0], 16 * a);
+            qu[a] = wv::readlane(U, 16 * a);
+            const float u = wv::readlane(s.Tb[0], 16 * a);
             float l = wv::readlane(s.lo, 16 * a) - u;
             float h = wv::readlane(s.hi, 16 * a) - u;
             if (p.has_delta) {                                      // :132-134
@@ -498,45 +527,50 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     float Ainv;
     {
         float y[4];
-        ldl4_solve(f, L.g == 0 ? 1.f : 0.f, L.g == 1 ? 1.f : 0.f, L.g == 2 ? 1.f : 0.f, L.g == 3 ? 1.f : 0.f, y);
-        float val = L.ja == 0 ? y[0] : (L.ja == 1 ? y[1] : (L.ja == 2 ? y[2] : y[3]));
-        bool ok = L.jq;
+        ldl4_solve(f, L.eg[0], L.eg[1], L.eg[2], L.eg[3], y);
         if (!FULL || MODE != 0) {
-            const bool fa = L.ja == 0 ? fr[0] : (L.ja == 1 ? fr[1] : (L.ja == 2 ? fr[2] : fr[3]));
-            const bool fg = L.g == 0 ? fr[0] : (L.g == 1 ? fr[1] : (L.g == 2 ? fr[2] : fr[3]));
-            ok = ok && fa && fg;
+            // rows / columns outside the free set are exactly zero (the factor holds identity there)
+            const float fg = dot4(L.eg, fr[0] ? 1.f : 0.f, fr[1] ? 1.f : 0.f, fr[2] ? 1.f : 0.f, fr[3] ? 1.f : 0.f);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) y[a] = fr[a] ? y[a] * fg : 0.f;
         }
-        Ainv = ok ? -val : 0.f;
+        Ainv = dot4(L.nea, y[0], y[1], y[2], y[3]);
     }
-    f32x4 Kacc = wv::mfma(Ainv, U, zero4);
+    const f32x4 Kacc = wv::mfma(Ainv, U, zero4);
     float Kp = Kacc[0];           // lane (g,j): K[g][var j]; lane (g,0): k[g]
-    if (bounded) {
-        const float kg = L.g == 0 ? kq[0] : (L.g == 1 ? kq[1] : (L.g == 2 ? kq[2] : kq[3]));
-        Kp = sel(L.j0, kg, Kp);   // k is the QP solution itself (:136-141)
+    f32x4 Vn;
+    if (MODE == 0) {
+        // K = -Quu^-1 Qux makes Qux + Quu K vanish: V = Qxx + Qxu K, v = qx + Qxu k   (:155-158)
+        Vn = wv::mfma(U, Kp, Q);
+    } else {
+        if (MODE == 2) {
+            const float kg = dot4(L.eg, kq[0], kq[1], kq[2], kq[3]);
+            Kp = sel(L.j0, kg, Kp);   // k is the QP solution itself (:136-141)
+        }
+        // A operand Quu (unmasked, :155-158): lane (i = 4a, g) holds Quu[a][g] = U at the same lane,
+        // except column 0 where U carries qu: there Quu[0][g] is needed.
+        const float s0g = dot4(L.eg, S.s00, S.s01, S.s02, S.s03);
+        const float Aquu = L.jq ? sel(L.j0, s0g, U) : 0.f;
+        f32x4 Min = zero4;
+        Min[0] = U;
+        const f32x4 Macc = wv::mfma(Aquu, Kp, Min);
+        const float Mp = Macc[0];     // lane (g,j): (Qux + Quu K)[g][var j]; lane (g,0): qu + Quu k
+        // :155-158  V = Qxx + Qxu K + K'(Qux + Quu K),  v = qx + Qxu k + K'(qu + Quu k)
+        Vn = wv::mfma(U, Kp, Q);
+        Vn = wv::mfma(Kp, Mp, Vn);
     }
-    // A operand Quu (unmasked, :155-158): lane (i = 4a, g) holds Quu[a][g] = U at the same lane,
-    // except column 0 where U carries qu: there Quu[0][g] is needed.
-    float Aquu;
-    {
-        const float s0g = L.g == 0 ? S.s00 : (L.g == 1 ? S.s01 : (L.g == 2 ? S.s02 : S.s03));
-        Aquu = L.jq ? sel(L.j0, s0g, U) : 0.f;
-    }
-    f32x4 Min = zero4;
-    Min[0] = U;
-    const f32x4 Macc = wv::mfma(Aquu, Kp, Min);
-    const float Mp = Macc[0];     // lane (g,j): (Qux + Quu K)[g][var j]; lane (g,0): qu + Quu k
-
-    // :155-158  V = Qxx + Qxu K + K'(Qux + Quu K),  v = qx + Qxu k + K'(qu + Quu k)
-    f32x4 Vn = wv::mfma(U, Kp, Q);
-    Vn = wv::mfma(Kp, Mp, Vn);
     st.Vp = Vn;
 
-    // gains out: K [T,B,nc,ns], k [T,B,nc]
+    // gains: the wave's own record Kk[t][b][16 g + j] (read back by the rollout), and, when the caller
+    // asked for them, K [T,B,nc,ns] / k [T,B,nc] in the reference's layout
     {
         const long tb = (long)t * p.B + b;
-        if (L.rowv[0]) {
-            if (L.j0) p.k[tb * p.nc + L.g] = Kp;
-            else if (!L.jq && L.colv) p.K[(tb * p.nc + L.g) * p.ns + L.col] = Kp;
+        p.Kk[tb * 64 + L.lane] = Kp;
+        if (p.K != nullptr) {
+            if (L.rowv[0]) {
+                if (L.j0) p.k[tb * p.nc + L.g] = Kp;
+                else if (!L.jq && L.colv) p.K[(tb * p.nc + L.g) * p.ns + L.col] = Kp;
+            }
         }
     }
 }
@@ -545,7 +579,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 // Rollout
 // ---------------------------------------------------------------------------
 struct RoStage {
-    float C[4];       // C_t, D layout (A operand of C tau')
+    float C[4];       // C_t, D layout
     float FA[4];      // F_t as A operand: lane (i = x slot, g), block kb -> F[x(i)][var(4g+kb)]
     float KA[3];      // K_t as A operand: lane (i = 4a, g), block kb -> K[a][x-slot(g,kb)]
     float crow[4];
@@ -562,14 +596,17 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, int
     const unsigned base = (unsigned)slot * STAGE_BYTES;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float v = wv::lds_f32(base + LDS_C + L.aC[r]);
+        const float v = wv::lds_f32(base + L.aC[r]);
         s.C[r] = FULL ? v : sel(L.vC[r], v, 0.f);
         const float w = wv::lds_f32(base + LDS_V + V_c + L.aT[r]);
         s.crow[r] = FULL ? w : sel(L.rowv[r], w, 0.f);
     }
     if (t < p.T - 1) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) s.FA[kb] = sel(L.vT[kb], wv::lds_f32(base + LDS_F + L.aFT[kb]), 0.f);
+        for (int kb = 0; kb < 4; ++kb) {
+            const float v = wv::lds_f32(base + L.aFT[kb]);
+            s.FA[kb] = FULL ? v : sel(L.vT[kb], v, 0.f);      // u columns feed output rows nobody reads
+        }
         if (p.f) {
 #pragma unroll
             for (int kb = 1; kb < 4; ++kb) {
@@ -583,16 +620,21 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, int
         s.FA[0] = s.FA[1] = s.FA[2] = s.FA[3] = 0.f;
         s.frow[0] = s.frow[1] = s.frow[2] = 0.f;
     }
+    {
+        const f32x4 kv = wv::lds_f32x4(base + L.aKA);
+        s.KA[0] = FULL ? kv[1] : sel(L.rowv[1], kv[1], 0.f);
+        s.KA[1] = FULL ? kv[2] : sel(L.rowv[2], kv[2], 0.f);
+        s.KA[2] = FULL ? kv[3] : sel(L.rowv[3], kv[3], 0.f);
+    }
 #pragma unroll
     for (int kb = 1; kb < 4; ++kb) {
-        s.KA[kb - 1] = sel(L.vK[kb], wv::lds_f32(base + LDS_V + V_K + L.aK[kb]), 0.f);
         const float v = wv::lds_f32(base + LDS_V + V_tau + L.aT[kb]);
         s.xbar[kb - 1] = FULL ? v : sel(L.rowv[kb], v, 0.f);
     }
     {
         const float v = wv::lds_f32(base + LDS_V + V_tau + L.aT[0]);
         s.ubar = FULL ? v : sel(L.rowv[0], v, 0.f);
-        const float w = wv::lds_f32(base + LDS_V + V_k + L.aG);
+        const float w = wv::lds_f32(base + L.aKk);
         s.kk = FULL ? w : sel(L.rowv[0], w, 0.f);
     }
     s.lo = s.hi = 0.f;
@@ -610,13 +652,16 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, int
 
 struct RoState {
     float xrow[3];    // x'_t of trial j (column j), row layout
-    float cost;       // partial of this lane group
+    float cost;       // partial of this lane (group)
     float du2;
     float alpha;      // step of trial j
 };
 
-template <bool FULL, int MODE>
-MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &st, int b, int t, int jsel)
+// MULTI = false: one trial (every column carries it; column 0 is the one read), stage cost on the
+//                vector ALU;
+// MULTI = true : sixteen trials, alpha_j = decay^j in column j, stage cost = one more 16x16x16 product.
+template <bool FULL, int MODE, bool MULTI>
+MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &st, int b, int t)
 {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const bool last = (t == p.T - 1);
@@ -631,7 +676,7 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
 #pragma unroll
         for (int kb = 1; kb < 4; ++kb) Xacc = wv::mfma(s.FA[kb], st.xrow[kb - 1], Xacc);
     }
-    float un = Uacc[0] + s.ubar + st.alpha * s.kk;
+    float un = Uacc[0] + fmaf(st.alpha, s.kk, s.ubar);
     if (MODE != 0 && s.zm) un = 0.f;                                 // :197-198
     if (MODE == 2) {                                                 // :200-213
         float l = s.lo, h = s.hi;
@@ -645,37 +690,52 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
     if (!FULL) un = sel(L.rowv[0], un, 0.f);
     if (!last) Xacc = wv::mfma(s.FA[0], un, Xacc);
     // obj_t = 0.5 tau'C tau + c'tau   (:230-232)
-    f32x4 Cacc = wv::mfma(s.C[0], un, zero4);
+    if (MULTI) {
+        f32x4 Cacc = wv::mfma(s.C[0], un, zero4);
 #pragma unroll
-    for (int kb = 1; kb < 4; ++kb) Cacc = wv::mfma(s.C[kb], st.xrow[kb - 1], Cacc);
-    float ca = un * fmaf(0.5f, Cacc[0], s.crow[0]);
+        for (int kb = 1; kb < 4; ++kb) Cacc = wv::mfma(s.C[kb], st.xrow[kb - 1], Cacc);
+        float ca = un * fmaf(0.5f, Cacc[0], s.crow[0]);
 #pragma unroll
-    for (int kb = 1; kb < 4; ++kb) ca = fmaf(st.xrow[kb - 1], fmaf(0.5f, Cacc[kb], s.crow[kb]), ca);
-    st.cost += ca;
+        for (int kb = 1; kb < 4; ++kb) ca = fmaf(st.xrow[kb - 1], fmaf(0.5f, Cacc[kb], s.crow[kb]), ca);
+        st.cost += ca;
+    } else {
+        // tau' sits in row layout; hand it to every lane through 64 bytes of LDS: lane (g,j) needs
+        // tau'[4g+r] (its four C rows -- it has those) and tau'[slot j] (its C column)
+        if (L.j0) wv::lds_store_f32x4(LDS_SCRATCH + 16u * (unsigned)L.g, f32x4{un, st.xrow[0], st.xrow[1], st.xrow[2]});
+        wv::lds_sync();
+        const float tc = wv::lds_f32(LDS_SCRATCH + 4u * (unsigned)L.j);
+        wv::lds_sync();
+        const float sq = fmaf(s.C[3], st.xrow[2], fmaf(s.C[2], st.xrow[1], fmaf(s.C[1], st.xrow[0], s.C[0] * un)));
+        const float lin = fmaf(s.crow[3], st.xrow[2], fmaf(s.crow[2], st.xrow[1], fmaf(s.crow[1], st.xrow[0], s.crow[0] * un)));
+        st.cost = fmaf(0.5f * tc, sq, st.cost) + sel(L.j0, lin, 0.f);
+        const long tb = (long)t * p.B + b;
+        if (L.j0) {
+            if (L.rowv[0]) p.new_u[tb * p.nc + L.row[0]] = un;
+#pragma unroll
+            for (int kb = 1; kb < 4; ++kb)
+                if (L.rowv[kb]) p.new_x[tb * p.ns + L.row[kb]] = st.xrow[kb - 1];
+        }
+    }
     const float d = s.ubar - un;
     st.du2 = fmaf(d, d, st.du2);
-    if (L.j == jsel) {
-        const long tb = (long)t * p.B + b;
-        if (L.rowv[0]) p.new_u[tb * p.nc + L.row[0]] = un;
-#pragma unroll
-        for (int kb = 1; kb < 4; ++kb)
-            if (L.rowv[kb]) p.new_x[tb * p.ns + L.row[kb]] = st.xrow[kb - 1];
-    }
     if (!last) {
         st.xrow[0] = Xacc[1]; st.xrow[1] = Xacc[2]; st.xrow[2] = Xacc[3];
     }
 }
 
-// One pass over the horizon with all 16 line-search trials in flight; trial `jsel` is stored.
-template <bool FULL, int MODE>
-MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, int jsel, float &cost_j, float &du2_j)
+// One pass over the horizon.  MULTI: trial j uses alpha = decay^min(j, max_ls-1), nothing is stored.
+// Single: every column uses `alpha` and the trajectory is stored.  cost_j / du2_j: totals of trial j
+// (single: the same number in every lane).
+template <bool FULL, int MODE, bool MULTI>
+MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, float alpha, float &cost_j, float &du2_j)
 {
     RoState st;
 #pragma unroll
     for (int kb = 1; kb < 4; ++kb) st.xrow[kb - 1] = L.rowv[kb] ? p.x_init[(long)b * p.ns + L.row[kb]] : 0.f;
     st.cost = 0.f;
     st.du2 = 0.f;
-    {
+    st.alpha = alpha;
+    if (MULTI) {
         // alpha_j = decay^min(j, max_ls-1)    (:247)
         float a = 1.f;
         const int e = L.j < p.max_ls - 1 ? L.j : p.max_ls - 1;
@@ -683,16 +743,16 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, int jsel, float &cos
         st.alpha = a;
     }
     const int T = p.T;
-    const int lane = wv::lane();
+    const int lane = L.lane;
     const bool use_zm = MODE != 0 && p.zero_mask != nullptr;
     VecDma vd;
-    vecdma_init<MODE, true>(vd, p, lane, b);
+    vecdma_init<MODE, true>(vd, p, lane, b, 0);
     // ring prologue: timesteps 0, 1, 2 in flight (indices past the horizon re-read the last step)
     int zq[NSTAGE] = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int ti = i < T ? i : T - 1;
-        stage_issue<FULL, MODE, true>(p, vd, lane, b, ti, i);
+        stage_issue<FULL, MODE, true>(p, vd, lane, b, ti, i, i + 1 < T);
         if (use_zm) zq[i] = zm_load(p, L, b, ti);
     }
     for (int t0 = 0; t0 < T; t0 += NSTAGE) {
@@ -704,17 +764,20 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, int jsel, float &cos
                 RoStage s;
                 ro_read<FULL, MODE>(s, p, L, t, i, zq[i]);
                 const int tn = t + 3 < T ? t + 3 : T - 1;
-                stage_issue<FULL, MODE, true>(p, vd, lane, b, tn, (i + 3) % NSTAGE);
+                stage_issue<FULL, MODE, true>(p, vd, lane, b, tn, (i + 3) % NSTAGE, t + 4 < T);
                 if (use_zm) zq[(i + 3) % NSTAGE] = zm_load(p, L, b, tn);
-                rollout_step<FULL, MODE>(p, L, s, st, b, t, jsel);
+                rollout_step<FULL, MODE, MULTI>(p, L, s, st, b, t);
             }
         }
     }
     stage_wait<FULL, 0>();
-    // sum the four lane groups: every lane of column j ends with the trial's totals
+    // sum the four lane groups (and, single trial, the 16 column partials of the quadratic form)
     float c = st.cost, d = st.du2;
     c += wv::shfl_xor(c, 16); d += wv::shfl_xor(d, 16);
     c += wv::shfl_xor(c, 32); d += wv::shfl_xor(d, 32);
+    if (!MULTI) {
+        c += wv::shfl_xor(c, 1); c += wv::shfl_xor(c, 2); c += wv::shfl_xor(c, 4); c += wv::shfl_xor(c, 8);
+    }
     cost_j = c;
     du2_j = d;
 }
@@ -728,8 +791,11 @@ MPC_DEV void step_problem(const P &p)
     Lane L;
     lane_init(L, lane, p.ns, p.nc);
     const int T = p.T;
+    // the words of zeros of every ring slot, once
+    if (lane < 4 * NSTAGE) wv::lds_store_f32((unsigned)(lane >> 2) * STAGE_BYTES + LDS_V + V_zero + 4u * (unsigned)(lane & 3), 0.f);
+    wv::lds_sync();
 
-    // ---- Riccati sweep, t = T-1 .. 0, loads two steps ahead ----------------------------------
+    // ---- Riccati sweep, t = T-1 .. 0 ------------------------------------------------------------
     SwState ss;
     ss.Vp = f32x4{0.f, 0.f, 0.f, 0.f};
     ss.oc = 0.f;
@@ -739,12 +805,12 @@ MPC_DEV void step_problem(const P &p)
     ss.kprev[0] = ss.kprev[1] = ss.kprev[2] = ss.kprev[3] = 0.f;
     {
         VecDma vd;
-        vecdma_init<MODE, false>(vd, p, lane, b);
+        vecdma_init<MODE, false>(vd, p, lane, b, T - 1);
         int zq[NSTAGE] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int ti = T - 1 - i >= 0 ? T - 1 - i : 0;
-            stage_issue<FULL, MODE, false>(p, vd, lane, b, ti, i);
+            stage_issue<FULL, MODE, false>(p, vd, lane, b, ti, i, T - 2 - i >= 0);
             if (MODE == 1) zq[i] = zm_load(p, L, b, ti);
         }
         for (int k0 = 0; k0 < T; k0 += NSTAGE) {
@@ -756,7 +822,7 @@ MPC_DEV void step_problem(const P &p)
                     SwStage s;
                     sw_read<FULL, MODE>(s, p, L, t, i, zq[i]);
                     const int tn = t - 3 >= 0 ? t - 3 : 0;
-                    stage_issue<FULL, MODE, false>(p, vd, lane, b, tn, (i + 3) % NSTAGE);
+                    stage_issue<FULL, MODE, false>(p, vd, lane, b, tn, (i + 3) % NSTAGE, t - 4 >= 0);
                     if (MODE == 1) zq[(i + 3) % NSTAGE] = zm_load(p, L, b, tn);
                     sweep_step<FULL, MODE>(p, L, s, ss, b, t);
                 }
@@ -767,23 +833,29 @@ MPC_DEV void step_problem(const P &p)
     const float old_cost = (wv::readlane(ss.oc, 0) + wv::readlane(ss.oc, 16)) +
                            (wv::readlane(ss.oc, 32) + wv::readlane(ss.oc, 48));
 
-    // K, k were written by this wave and are re-read by other lanes of it: drain the stores.
+    // the gains were written by this wave and are re-read through the DMA: drain the stores
     wv::fence_own_stores();
 
     // ---- line-searched rollout (mpc/lqr_step.py:164-261) ---------------------------------------
     float cost_j, du2_j;
-    rollout_pass<FULL, MODE>(p, L, b, 0, cost_j, du2_j);
-    const float full2 = wv::readlane(du2_j, 0);                      // :243-245 (alpha = 1 trial)
-    // first trial whose cost did not get worse, else the last one (:176-179, 247, 252)
-    const unsigned long long okm = wv::ballot(!(cost_j > old_cost) && L.g == 0 && L.j < p.max_ls);
-    int jstar = p.max_ls - 1;
-    if (okm) jstar = wv::ctz64(okm);
-    jstar = wv::uniform(jstar);
-    if (jstar != 0) rollout_pass<FULL, MODE>(p, L, b, jstar, cost_j, du2_j);
-    const float cost = wv::readlane(cost_j, jstar);
-    const float dun2 = wv::readlane(du2_j, jstar);
+    rollout_pass<FULL, MODE, false>(p, L, b, 1.f, cost_j, du2_j);
+    float cost = wv::readlane(cost_j, 0);
+    float dun2 = wv::readlane(du2_j, 0);
+    const float full2 = dun2;                                        // :243-245 (alpha = 1 trial)
     float alpha = 1.f;
-    for (int i = 0; i < jstar; ++i) alpha *= p.ls_decay;
+    if (wv::uniform(cost > old_cost) && p.max_ls > 1) {
+        // the full step made it worse: run every remaining trial at once and take the first whose
+        // cost did not get worse, else the last one (:176-179, 247, 252)
+        rollout_pass<FULL, MODE, true>(p, L, b, 1.f, cost_j, du2_j);
+        const unsigned long long okm = wv::ballot(!(cost_j > old_cost) && L.g == 0 && L.j >= 1 && L.j < p.max_ls);
+        int jstar = p.max_ls - 1;
+        if (okm) jstar = wv::ctz64(okm);
+        jstar = wv::uniform(jstar);
+        for (int i = 0; i < jstar; ++i) alpha *= p.ls_decay;
+        rollout_pass<FULL, MODE, false>(p, L, b, alpha, cost_j, du2_j);
+        cost = wv::readlane(cost_j, 0);
+        dun2 = wv::readlane(du2_j, 0);
+    }
     int status = ss.status;
     if (!(cost == cost) || fabsf(cost) > 3e38f) status |= MPC_ST_NONFINITE;
     if (lane == 0) {

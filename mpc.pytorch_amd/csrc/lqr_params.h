@@ -24,6 +24,7 @@ struct StepParams {
     real *new_x, *new_u, *costs, *old_costs, *full_du_norm, *alpha_du_norm, *alphas;
     int *qp_iters, *status;
     real *K, *k;                 // [T,B,nc,ns], [T,B,nc]
+    real *Kk;                    // fused MFMA kernel: its own gain record [T,B,4,16] (workspace)
     const real *old_costs_in;    // rollout-only entry point
 };
 
@@ -55,6 +56,7 @@ inline StepParams<real> make_params(const mpc_lqr_problem *p, const mpc_lqr_opti
     s.alphas = out ? (real *)out->alphas : nullptr;
     s.qp_iters = out ? out->qp_iters : nullptr; s.status = out ? out->status : nullptr;
     s.K = out ? (real *)out->K : nullptr; s.k = out ? (real *)out->k : nullptr;
+    s.Kk = nullptr;
     s.old_costs_in = nullptr;
     return s;
 }

@@ -269,10 +269,9 @@ class HipBackend:
                    "mpc_lqr_rollout")
             keep += keep2
         else:
-            nbytes = 0
-            if not want_gains:
-                nbytes = int(L.mpc_lqr_workspace_bytes(ctypes.byref(p)))
-                ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            # scratch for the gains (the fused MFMA kernel always parks its own record there)
+            nbytes = int(L.mpc_lqr_workspace_bytes(ctypes.byref(p)))
+            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
             _check(L.mpc_lqr_step(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), _ptr(ws), nbytes,
                                   int(impl), st), "mpc_lqr_step")
         res["_keep"] = (keep, keep_o, ws)

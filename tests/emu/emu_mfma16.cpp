@@ -32,7 +32,7 @@ struct Wave {
     int ia[2][NL];
     unsigned seq[NL];
     // LDS of the (single-wave) workgroup + the in-order queue of LDS-DMA instructions in flight
-    unsigned char lds[4 * 2208];
+    unsigned char lds[4 * 2288 + 64];
     struct Dma { unsigned char data[NL][16]; bool act[NL]; unsigned off; int size; };
     Dma q[64];
     int qn;
@@ -199,6 +199,22 @@ static inline float lds_f32(unsigned off)
     memcpy(&v, emu::W.lds + off, 4);
     return v;
 }
+static inline f32x4 lds_f32x4(unsigned off)
+{
+    if (off & 15) { fprintf(stderr, "emu: misaligned ds_read_b128\n"); abort(); }
+    f32x4 v;
+    memcpy(&v, emu::W.lds + off, 16);
+    return v;
+}
+static inline void lds_store_f32(unsigned off, float v) { memcpy(emu::W.lds + off, &v, 4); }
+static inline void lds_store_f32x4(unsigned off, f32x4 v)
+{
+    if (off & 15) { fprintf(stderr, "emu: misaligned ds_write_b128\n"); abort(); }
+    memcpy(emu::W.lds + off, &v, 16);
+}
+// the hardware executes a wave's DS instructions in order; the lane-serial emulator needs every
+// lane to have passed the preceding stores/loads before any lane goes on
+static inline void lds_sync() { (void)readlane_i(0, 0); }
 static inline void fence_own_stores() {}
 }  // namespace wv
 }  // namespace mpclqr
@@ -222,7 +238,13 @@ extern "C" int emu_lqr_step_mfma16(const mpc_lqr_problem *p, const mpc_lqr_optio
     if (p->dtype != MPC_F32) return MPC_E_DTYPE;
     mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, out);
     if (!(sp.ns >= 1 && sp.ns <= 12 && sp.nc >= 1 && sp.nc <= 4 && sp.max_ls >= 1 && sp.max_ls <= 16)) return MPC_E_DIMS;
-    if (!sp.K || !sp.k || !sp.new_x || !sp.new_u) return MPC_E_NULL;
+    if (!sp.new_x || !sp.new_u) return MPC_E_NULL;
+    static float *kk_buf = nullptr;
+    static size_t kk_cap = 0;
+    const size_t need = (size_t)sp.T * sp.B * 64;
+    if (need > kk_cap) { free(kk_buf); kk_buf = (float *)malloc(need * sizeof(float)); kk_cap = need; }
+    for (size_t i = 0; i < need; ++i) kk_buf[i] = NAN;
+    sp.Kk = kk_buf;
     g_p = &sp;
     const bool full = sp.ns == 12 && sp.nc == 4 && !force_general;
     for (int b = 0; b < sp.B; ++b) emu::run_wave(b, full ? body<true> : body<false>);
