@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bounded", action="store_true", help="box constraints +-1 (pnqp in the sweep)")
-    ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic, 2 fused MFMA")
+    ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic, 2 fused MFMA, 3 DPP 4-problems-per-wave")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -121,7 +121,7 @@ def main():
     p = make_problem(NS, NC, T_H, B, torch.float32, dev, seed=1000 + rank,
                      u_scale=0.3 if args.bounded else 0.0, clamp=1.0 if args.bounded else None)
     opts = StepOptions(u_lower=-1.0, u_upper=1.0) if args.bounded else StepOptions()
-    impl_used = args.impl if args.impl else (2 if be.impl_supported(NS, NC, torch.float32, 2) else 1)
+    impl_used = args.impl if args.impl else (3 if be.impl_supported(NS, NC, torch.float32, 3) else 1)
 
     # argument structs + output buffers bound once: a timed step is exactly one C-ABI call
     step = be.plan_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts, impl=args.impl)
@@ -181,7 +181,7 @@ def main():
                                    "batch=%d per GPU, %s, one LQRStepFn.forward per step"
                                    % (B, "box bounds +-1 (pnqp)" if args.bounded else "unbounded"),
                        "global_batch": world * B, "horizon": T_H, "parallelism": "batch-shard x%d" % world,
-                       "kernel": {1: "lqr_step_generic_kernel<float>", 2: "lqr_step_mfma16_kernel"}[impl_used],
+                       "kernel": {1: "lqr_step_generic_kernel<float>", 2: "lqr_step_mfma16_kernel", 3: "lqr_step_dpp16_kernel"}[impl_used],
                        "finite": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

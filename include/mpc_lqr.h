@@ -94,18 +94,22 @@ const char *mpc_lqr_build_info(void);
 const char *mpc_lqr_last_error(void);
 
 /* Bytes of device scratch mpc_lqr_step / mpc_lqr_rollout need when out->K/k are
- * NULL (the generic path parks K,k there between sweep and rollout). */
+ * NULL (the generic path parks K,k there between sweep and rollout; the fused kernels always
+ * park their gain record [T,B,64] there). */
 int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p);
 
 /* (1) One whole LQR step = LQRStepFn.forward, mpc/lqr_step.py:277-309:
  *     delta-space linear term (:284-296) + Riccati sweep `lqr_backward`
  *     (:52-160, incl. pnqp mpc/pnqp.py:5-82 and the masked solve :99-127)
  *     + line-searched rollout `lqr_forward` (:164-261) for LinDx/QuadCost.
- *     `impl`: 0 = auto, 1 = generic kernels, 2 = fused MFMA kernel (n <= 16, f32). */
+ *     `impl`: 0 = auto, 1 = generic kernels (any shape, f32/f64), 2 = fused MFMA kernel (f32,
+ *     n_state <= 12, n_ctrl <= 4), 3 = 4-problems-per-wave DPP kernel (f32, n_state = 12,
+ *     n_ctrl = 4, 16-byte aligned blocks).  Auto picks 3, else 2, else 1.  The fused kernels need
+ *     `workspace` (mpc_lqr_workspace_bytes, 16-byte aligned); out->K / out->k are optional there. */
 int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
                  void *workspace, int64_t workspace_bytes, int impl, void *stream);
 
-/* Does kernel `impl` (1 generic, 2 fused MFMA) accept this problem/options pair?  1 yes, 0 no. */
+/* Does kernel `impl` (1 generic, 2 fused MFMA, 3 DPP) accept this problem/options pair?  1 yes, 0 no. */
 int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, int impl);
 
 /* (2) The sweep alone: c_back + lqr_backward (mpc/lqr_step.py:284-296, 52-160).

@@ -57,20 +57,23 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
     const int64_t needk = (int64_t)p->T * p->B * p->nc * (int64_t)sizeof(real);
     if (phase_mask == 3 && impl != 1) {
         if constexpr (sizeof(real) == 4) {
-            const bool fast = mfma16_supported(sp);
-            if (impl == 2 && !fast)
+            // the fused kernels park their gains [T,B,64] in the workspace; out->K / out->k are optional
+            const int64_t need = (int64_t)p->T * p->B * 64 * (int64_t)sizeof(float);
+            const bool have_ws = workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0);
+            if ((sp.K == nullptr) != (sp.k == nullptr)) return fail(MPC_E_NULL, "pass both K and k, or neither");
+            sp.Kk = (float *)workspace;
+            const bool dpp = dpp16_supported(sp), mfma = mfma16_supported(sp);
+            if (impl == 3 && !dpp)
+                return fail(MPC_E_DIMS, "DPP kernel needs fp32, n_state = 12, n_ctrl = 4 and 16-byte aligned blocks");
+            if (impl == 2 && !mfma)
                 return fail(MPC_E_DIMS, "fused MFMA kernel needs fp32, n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16");
-            if (fast) {
-                // the kernel parks its gains [T,B,4,16] in the workspace; out->K / out->k are optional
-                const int64_t need = (int64_t)p->T * p->B * 64 * (int64_t)sizeof(float);
-                if (!workspace || workspace_bytes < need)
-                    return fail(MPC_E_ARG, "workspace too small (see mpc_lqr_workspace_bytes)");
-                if ((sp.K == nullptr) != (sp.k == nullptr)) return fail(MPC_E_NULL, "pass both K and k, or neither");
-                sp.Kk = (float *)workspace;
-                return launch_step_mfma16(sp, st);
-            }
-        } else if (impl == 2) {
-            return fail(MPC_E_DTYPE, "fused MFMA kernel is fp32 only");
+            if ((impl == 3 || impl == 2 || dpp || mfma) && !have_ws)
+                return fail(MPC_E_ARG, "workspace too small or not 16-byte aligned (see mpc_lqr_workspace_bytes)");
+            if (impl == 3 || (impl == 0 && dpp)) return launch_step_dpp16(sp, st);
+            if (impl == 2 || (impl == 0 && mfma)) return launch_step_mfma16(sp, st);
+            sp.Kk = nullptr;
+        } else if (impl == 2 || impl == 3) {
+            return fail(MPC_E_DTYPE, "the fused kernels are fp32 only");
         }
     }
     if (!sp.K || !sp.k) {
@@ -92,7 +95,7 @@ int mpc_lqr_abi_version(void) { return MPC_LQR_ABI_VERSION; }
 
 const char *mpc_lqr_build_info(void)
 {
-    return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32>, "
+    return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32>, lqr_step_dpp16<f32>, "
            "kkt_grads, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
 }
 
@@ -124,12 +127,14 @@ int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, i
 {
     if (!p || check_problem(p, false, false) != MPC_OK || check_options(p, o) != MPC_OK) return 0;
     if (impl == 1) return generic_lds_bytes(p->ns, p->nc, p->dtype == MPC_F64 ? 8 : 4) <= 160 * 1024;
-    if (impl == 2) {
+    if (impl == 2 || impl == 3) {
         if (p->dtype != MPC_F32) return 0;
         mpc_lqr_outputs out;
         memset(&out, 0, sizeof(out));
         StepParams<float> sp = make_params<float>(p, o, &out);
-        return mfma16_supported(sp) ? 1 : 0;
+        if (impl == 2) return mfma16_supported(sp) ? 1 : 0;
+        // sizes only: the alignment of the actual tensors is checked at launch
+        return (sp.ns == 12 && sp.nc == 4) ? 1 : 0;
     }
     return 0;
 }

@@ -35,6 +35,10 @@ template <typename real> int launch_select_best(int B, int T, int ns, int nc, in
                                                 real *bd, int *any_improved, real *max_du, hipStream_t st);
 size_t generic_lds_bytes(int ns, int nc, size_t elem);
 
+// 4-problems-per-wave DPP path for n_state = 12, n_ctrl = 4, f32 (lqr_dpp16.hip)
+bool dpp16_supported(const StepParams<float> &p);
+int launch_step_dpp16(const StepParams<float> &p, hipStream_t st);
+
 // fused MFMA path for n <= 16, f32 (lqr_mfma16.hip)
 bool mfma16_supported(const StepParams<float> &p);
 int launch_step_mfma16(const StepParams<float> &p, hipStream_t st);

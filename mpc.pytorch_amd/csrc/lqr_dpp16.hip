@@ -1,0 +1,234 @@
+// lqr_dpp16.hip -- gfx950 binding of the 4-problems-per-wave DPP LQR step (lqr_dpp16_body.h).
+//
+// One 64-lane wavefront (= one workgroup) owns FOUR problems, one per 16-lane DPP row.  The headline
+// shape (n_state=12, n_ctrl=4, T=50, B=4096) is 1024 wavefronts = one per SIMD, each with the whole
+// 512-entry VGPR file and 36 KiB of LDS (4 workgroups per CU).  Matrix products are blocks of
+// v_fmac_f32_dpp ... row_newbcast:N written as inline asm (hipcc does not fold a DPP mov into v_fmac);
+// each block opens with s_nop 1 because the assembler's hazard padding does not look inside asm
+// (VALU write of a VGPR -> DPP read of it needs 2 wait states).
+#include <string>
+#include "lqr_common.h"
+
+#define MPC_DEV __device__ __forceinline__
+#define DPPM " row_mask:0xf bank_mask:0xf\n"
+
+namespace mpclqr {
+namespace wv {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+MPC_DEV int lane() { return (int)threadIdx.x; }
+MPC_DEV int problem() { return (int)blockIdx.x; }
+MPC_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // 1 ulp
+MPC_DEV bool uniform(bool c) { return c; }
+MPC_DEV int uniform(int v) { return v; }
+MPC_DEV bool any(bool c) { return __ballot(c) != 0ull; }
+
+// ---- DPP row broadcasts ----------------------------------------------------------------------
+template <int N> MPC_DEV float bcast(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + N, 0xf, 0xf, true));
+}
+// acc += bcast_N(src) * mul
+template <int N> MPC_DEV void fmac_bcast(float &acc, float src, float mul)
+{
+    asm("s_nop 1\n"
+        "v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3" DPPM
+        : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
+}
+// acc[i] += bcast_M(src[i]) * mul, i = 0..11
+template <int M, int NS> MPC_DEV void fma_bcast_lane12(float (&a)[12], const float (&s)[NS], float mul)
+{
+    asm("s_nop 1\n"
+        "v_fmac_f32_dpp %0, %12, %24 row_newbcast:%25" DPPM
+        "v_fmac_f32_dpp %1, %13, %24 row_newbcast:%25" DPPM
+        "v_fmac_f32_dpp %2, %14, %24 row_newbcast:%25" DPPM
+        "v_fmac_f32_dpp %3, %15, %24 row_newbcast:%25" DPPM
+        "v_fmac_f32_dpp %4, %16, %24 row_newbcast:%25" DPPM
+        "v_fmac_f32_dpp %5, %17, %24 row_newbcast:%25" DPPM
+        "v_fmac_f32_dpp %6, %18, %24 row_newbcast:%25" DPPM
+        "v_fmac_f32_dpp %7, %19, %24 row_newbcast:%25" DPPM
+        "v_fmac_f32_dpp %8, %20, %24 row_newbcast:%25" DPPM
+        "v_fmac_f32_dpp %9, %21, %24 row_newbcast:%25" DPPM
+        "v_fmac_f32_dpp %10, %22, %24 row_newbcast:%25" DPPM
+        "v_fmac_f32_dpp %11, %23, %24 row_newbcast:%25" DPPM
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+          "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]),
+          "v"(s[9]), "v"(s[10]), "v"(s[11]), "v"(mul), "n"(M));
+}
+// acc[i] += bcast_i(src) * mul
+MPC_DEV void fma_bcast_each16(float (&a)[16], float src, float mul)
+{
+    asm("s_nop 1\n"
+        "v_fmac_f32_dpp %0, %16, %17 row_newbcast:0" DPPM
+        "v_fmac_f32_dpp %1, %16, %17 row_newbcast:1" DPPM
+        "v_fmac_f32_dpp %2, %16, %17 row_newbcast:2" DPPM
+        "v_fmac_f32_dpp %3, %16, %17 row_newbcast:3" DPPM
+        "v_fmac_f32_dpp %4, %16, %17 row_newbcast:4" DPPM
+        "v_fmac_f32_dpp %5, %16, %17 row_newbcast:5" DPPM
+        "v_fmac_f32_dpp %6, %16, %17 row_newbcast:6" DPPM
+        "v_fmac_f32_dpp %7, %16, %17 row_newbcast:7" DPPM
+        "v_fmac_f32_dpp %8, %16, %17 row_newbcast:8" DPPM
+        "v_fmac_f32_dpp %9, %16, %17 row_newbcast:9" DPPM
+        "v_fmac_f32_dpp %10, %16, %17 row_newbcast:10" DPPM
+        "v_fmac_f32_dpp %11, %16, %17 row_newbcast:11" DPPM
+        "v_fmac_f32_dpp %12, %16, %17 row_newbcast:12" DPPM
+        "v_fmac_f32_dpp %13, %16, %17 row_newbcast:13" DPPM
+        "v_fmac_f32_dpp %14, %16, %17 row_newbcast:14" DPPM
+        "v_fmac_f32_dpp %15, %16, %17 row_newbcast:15" DPPM
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+          "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+        : "v"(src), "v"(mul));
+}
+MPC_DEV void fma_bcast_each12(float (&a)[12], float src, float mul)
+{
+    asm("s_nop 1\n"
+        "v_fmac_f32_dpp %0, %12, %13 row_newbcast:0" DPPM
+        "v_fmac_f32_dpp %1, %12, %13 row_newbcast:1" DPPM
+        "v_fmac_f32_dpp %2, %12, %13 row_newbcast:2" DPPM
+        "v_fmac_f32_dpp %3, %12, %13 row_newbcast:3" DPPM
+        "v_fmac_f32_dpp %4, %12, %13 row_newbcast:4" DPPM
+        "v_fmac_f32_dpp %5, %12, %13 row_newbcast:5" DPPM
+        "v_fmac_f32_dpp %6, %12, %13 row_newbcast:6" DPPM
+        "v_fmac_f32_dpp %7, %12, %13 row_newbcast:7" DPPM
+        "v_fmac_f32_dpp %8, %12, %13 row_newbcast:8" DPPM
+        "v_fmac_f32_dpp %9, %12, %13 row_newbcast:9" DPPM
+        "v_fmac_f32_dpp %10, %12, %13 row_newbcast:10" DPPM
+        "v_fmac_f32_dpp %11, %12, %13 row_newbcast:11" DPPM
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+          "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11])
+        : "v"(src), "v"(mul));
+}
+// acc += sum_i bcast_i(src) * mul[i]   (two accumulation chains)
+MPC_DEV void dot_bcast16(float &acc, float src, const float (&m)[16])
+{
+    float t;
+    asm("s_nop 1\n"
+        "v_mul_f32_dpp %1, %2, %4 row_newbcast:1" DPPM
+        "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0" DPPM
+        "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3" DPPM
+        "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2" DPPM
+        "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5" DPPM
+        "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4" DPPM
+        "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7" DPPM
+        "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6" DPPM
+        "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9" DPPM
+        "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8" DPPM
+        "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11" DPPM
+        "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10" DPPM
+        "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13" DPPM
+        "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12" DPPM
+        "v_fmac_f32_dpp %1, %2, %18 row_newbcast:15" DPPM
+        "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14" DPPM
+        "v_add_f32 %0, %0, %1\n"
+        : "+v"(acc), "=&v"(t)
+        : "v"(src), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]),
+          "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]));
+}
+MPC_DEV void dot_bcast12(float &acc, float src, const float (&m)[12])
+{
+    float t;
+    asm("s_nop 1\n"
+        "v_mul_f32_dpp %1, %2, %4 row_newbcast:1" DPPM
+        "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0" DPPM
+        "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3" DPPM
+        "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2" DPPM
+        "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5" DPPM
+        "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4" DPPM
+        "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7" DPPM
+        "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6" DPPM
+        "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9" DPPM
+        "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8" DPPM
+        "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11" DPPM
+        "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10" DPPM
+        "v_add_f32 %0, %0, %1\n"
+        : "+v"(acc), "=&v"(t)
+        : "v"(src), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]),
+          "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]));
+}
+// sum over the 16 lanes of the row, result in every lane (compiler-visible DPP: hazards handled)
+MPC_DEV float row_sum(float x)
+{
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true));   // row_mirror
+    return x;
+}
+
+// ---- HBM -> LDS staging --------------------------------------------------------------------
+#define MPC_DPP16_LDS (4 * 9216)
+__shared__ __attribute__((aligned(16))) char g_stage16[MPC_DPP16_LDS];
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+MPC_DEV void dma16(const void *g, unsigned off)
+{
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, 0);
+}
+MPC_DEV void dma16_if(bool active, const void *g, unsigned off)
+{
+    if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, 0);
+}
+MPC_DEV float lds_f32(unsigned off) { return *(const float *)(g_stage16 + off); }
+MPC_DEV f32x4 lds_f32x4(unsigned off) { return *(const f32x4 *)(g_stage16 + off); }
+MPC_DEV void store_f32x4(float *g, f32x4 v) { *(f32x4 *)g = v; }
+template <int N> MPC_DEV void dma_wait()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+MPC_DEV void fence_own_stores()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+}  // namespace wv
+}  // namespace mpclqr
+
+#include "lqr_dpp16_body.h"
+
+namespace mpclqr {
+namespace {
+
+// MODE: 0 unconstrained, 1 unconstrained + u_zero_I, 2 box-constrained (pnqp in the sweep)
+template <int MODE>
+__global__ void __launch_bounds__(64, 1) lqr_step_dpp16_kernel(StepParams<float> p)
+{
+    dpp16::step_wave<MODE>(p);
+}
+
+}  // namespace
+
+bool dpp16_supported(const StepParams<float> &p)
+{
+    // 16-byte DMA granules: every block the kernel streams must start on a 16-byte boundary
+    auto al = [](const void *q, long st, long sb) { return ((uintptr_t)q % 16 == 0) && (st % 4 == 0) && (sb % 4 == 0); };
+    if (!(p.ns == 12 && p.nc == 4 && p.T >= 1 && p.max_ls >= 1)) return false;
+    if (!al(p.C, p.C_st, p.C_sb) || !al(p.c, p.c_st, p.c_sb)) return false;
+    if (p.T > 1 && !al(p.F, p.F_st, p.F_sb)) return false;
+    if (p.f && !al(p.f, p.f_st, p.f_sb)) return false;
+    if (!al(p.cur_x, 0, 0) || !al(p.cur_u, 0, 0)) return false;
+    if (p.bound_mode == MPC_BOUND_TENSOR && (!al(p.lo, 0, 0) || !al(p.hi, 0, 0))) return false;
+    if (p.zero_mask && (uintptr_t)p.zero_mask % 4 != 0) return false;
+    return true;
+}
+
+int launch_step_dpp16(const StepParams<float> &p, hipStream_t st)
+{
+    if (!dpp16_supported(p)) { set_last_error("dpp16: needs n_state = 12, n_ctrl = 4, fp32, 16-byte aligned blocks"); return MPC_E_DIMS; }
+    if (!p.Kk || (uintptr_t)p.Kk % 16 != 0) { set_last_error("dpp16: gain workspace missing or misaligned"); return MPC_E_NULL; }
+    if (!p.new_x || !p.new_u) { set_last_error("dpp16: new_x / new_u is NULL"); return MPC_E_NULL; }
+    static_assert(MPC_DPP16_LDS == dpp16::LDS_TOTAL, "LDS layout out of sync");
+    const dim3 grid((p.B + 3) / 4), block(64);
+    if (p.bound_mode != MPC_BOUND_NONE) hipLaunchKernelGGL((lqr_step_dpp16_kernel<2>), grid, block, 0, st, p);
+    else if (p.zero_mask) hipLaunchKernelGGL((lqr_step_dpp16_kernel<1>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((lqr_step_dpp16_kernel<0>), grid, block, 0, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error((std::string("lqr_step_dpp16_kernel: ") + hipGetErrorString(e)).c_str());
+        return MPC_E_LAUNCH;
+    }
+    return MPC_OK;
+}
+
+}  // namespace mpclqr

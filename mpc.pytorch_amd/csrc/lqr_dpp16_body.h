@@ -1,0 +1,588 @@
+// lqr_dpp16_body.h -- the fused LQR step at the headline shape (n_state = 12, n_ctrl = 4, fp32):
+// FOUR problems per 64-lane wavefront, one problem per 16-lane DPP row, lane j of a row owning
+// variable j of tau = [x_0..x_11, u_0..u_3].  All algebra runs on the vector ALU as
+// v_fmac_f32 with a DPP row_newbcast operand (one lane of the row broadcast to the other 15 inside
+// the FMA itself), so the 4x4 control-block factorisation, the box QP and every matrix-vector
+// product are shared by four problems per instruction and nothing is computed 64 times over.
+//
+// Why not the matrix cores here: on gfx950 v_mfma_f32_16x16x4_f32 and the f32 VALU never co-execute
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r01_prof2_mfma16_v2.json) and one wave per problem
+// spends most of its issue slots on wave-uniform 4x4 work; see lqr_mfma16_body.h (kept as
+// impl 2, all shapes <= 12/4) and DESIGN.md for the measured comparison.
+//
+// Written against the `wv::` wave interface like lqr_mfma16_body.h: lqr_dpp16.hip binds it to gfx950
+// (inline-asm blocks of v_fmac_f32_dpp, global_load_lds DMA), tests/emu/ to the host emulator.
+//
+// What it replaces in locuslab/mpc.pytorch:
+//   sweep_step      mpc/lqr_step.py:284-296 (c_back) + :52-160 (lqr_backward)
+//   pnqp4           mpc/pnqp.py:5-82 (shared with lqr_mfma16_body.h)
+//   rollout_step    mpc/lqr_step.py:164-261 (lqr_forward), mpc/util.py:129-153
+//
+// Register layout of one row (lane j = variable j):
+//   Vc[i]  = V[i][j]      column j of the value Hessian (j < 12)       vv = v[j]
+//   Cc[i]  = C[j][i]      (C symmetric, mpc/mpc.py:61-68: row j is read as column j)
+//   Fc[m]  = F[m][j]      column j of the dynamics
+//   Y[i]   = (V F)[i][j]  = sum_m bcast_m(Vc[i]) * Fc[m]
+//   Q[i]   = (C + F'VF)[i][j] = Cc[i] + sum_m bcast_i(Fc[m]) * Y[m];   q = q[j]
+//   K[a]   = K[a][j]  (j < 12),  lane 12 carries k = K[.][12]
+// Staging: per wave a 4-slot LDS ring, 9 KiB per slot (4 x {C 1 KiB, F 768 B, small-vector record
+// 256 B, gain record 256 B}), filled by global_load_lds three timesteps ahead; counted vmcnt waits.
+#pragma once
+#include <math.h>
+#include "lqr_params.h"
+#include "lqr_small_math.h"
+
+namespace mpclqr {
+namespace dpp16 {
+
+typedef StepParams<float> P;
+using wv::f32x4;
+using mfma16::Sym4;
+using mfma16::Ldl4;
+using mfma16::ldl4;
+using mfma16::ldl4_solve;
+using mfma16::eclampf;
+using mfma16::sel;
+
+enum {
+    SC = 0, SF = 4096, SR = 7168, SG = 8192, STAGE_BYTES = 9216, NSTAGE = 4,
+    R_c = 0, R_tau = 64, R_f = 128, R_lo = 192, R_hi = 208,
+    LDS_TOTAL = NSTAGE * STAGE_BYTES,
+    DMA_SWEEP = 8,      // 4 C + 3 F + 1 record
+    DMA_ROLL = 9        // + 1 gain record
+};
+
+struct Lane {
+    int lane, p, j;       // problem slot in the wave, variable
+    int pb;               // problem index (clamped to B-1)
+    bool live;            // pb is a real problem of this wave
+    bool isu;             // j >= 12
+    int a;                // control index of this lane (j - 12), 0 for state lanes
+    // LDS byte offsets inside a stage
+    int aCrow;            // SC + p*1024 + 64 j                 (row j of C: 4 x b128)
+    int aFcol;            // SF + p*768 + 4 j                   (+64 m: F[m][j])
+    int aFrow;            // SF + p*768 + 64 min(j, 11)         (row j of F: 4 x b128, state lanes)
+    int aRec;             // SR + p*256 + 4 j                   (+R_c: c_j, +R_tau: tau_j)
+    int aRecA;            // SR + p*256 + 4 a                   (+R_lo / R_hi)
+    int aRecF;            // SR + p*256 + R_f + 4 min(j, 11)
+    int aKrow;            // SG + p*256 + 4 a                   (+16 jj: K[a][jj]; +192: k_a)
+};
+
+MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
+{
+    L.lane = lane;
+    L.p = lane >> 4;
+    L.j = lane & 15;
+    const int pb = 4 * wave + L.p;
+    L.live = pb < B;
+    L.pb = L.live ? pb : B - 1;
+    L.isu = L.j >= 12;
+    L.a = L.isu ? L.j - 12 : 0;
+    const int jx = L.j < 12 ? L.j : 11;
+    L.aCrow = SC + L.p * 1024 + 64 * L.j;
+    L.aFcol = SF + L.p * 768 + 4 * L.j;
+    L.aFrow = SF + L.p * 768 + 64 * jx;
+    L.aRec = SR + L.p * 256 + 4 * L.j;
+    L.aRecA = SR + L.p * 256 + 4 * L.a;
+    L.aRecF = SR + L.p * 256 + R_f + 4 * jx;
+    L.aKrow = SG + L.p * 256 + 4 * L.a;
+}
+
+// ---------------------------------------------------------------------------
+// HBM -> LDS staging: lane l of DMA instruction k moves 16 B.
+//   C  : instruction k = problem slot k, granule l            (4 instructions)
+//   F  : granule G = 64 k + l of the 4 x 48 granules           (3 instructions)
+//   rec: problem slot l>>4, granule l&15: 0-3 c | 4-6 x | 7 u | 8-10 f | 12 lo | 13 hi
+//   gains (rollout): problem slot l>>4, granule l&15 of the wave's own record Kk[t][b][16][4]
+// ---------------------------------------------------------------------------
+struct Dma {
+    const char *c_ptr[4];     // wave-uniform per problem slot
+    const char *f_ptr[3];     // per lane
+    const char *r_ptr;        // per lane
+    const char *g_ptr;        // per lane
+    long c_step, f_step, r_step, g_step;
+    bool r_active, r_is_f;
+};
+
+template <int MODE>
+MPC_DEV void dma_init(Dma &d, const P &p, const Lane &L, int wave)
+{
+    const long B = p.B;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int pbk = 4 * wave + k < p.B ? 4 * wave + k : p.B - 1;
+        d.c_ptr[k] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * L.lane;
+    }
+    d.c_step = 4 * p.C_st;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int G = 64 * k + L.lane;
+        const int slot = G / 48, gi = G - 48 * slot;
+        const int pbk = 4 * wave + slot < p.B ? 4 * wave + slot : p.B - 1;
+        d.f_ptr[k] = p.T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) + 16 * gi : (const char *)p.C;
+    }
+    d.f_step = 4 * p.F_st;
+    {
+        const int gi = L.lane & 15;
+        const long pb = L.pb;
+        d.r_active = false;
+        d.r_is_f = false;
+        const char *q = (const char *)p.c;
+        long st = 0;
+        if (gi < 4) { d.r_active = true; q = (const char *)(p.c + pb * p.c_sb + 4 * gi); st = 4 * p.c_st; }
+        else if (gi < 7) { d.r_active = true; q = (const char *)(p.cur_x + pb * 12 + 4 * (gi - 4)); st = 4 * B * 12; }
+        else if (gi == 7) { d.r_active = true; q = (const char *)(p.cur_u + pb * 4); st = 4 * B * 4; }
+        else if (gi < 11) {
+            if (p.f && p.T > 1) { d.r_active = true; d.r_is_f = true; q = (const char *)(p.f + pb * p.f_sb + 4 * (gi - 8)); st = 4 * p.f_st; }
+        } else if (gi == 12 || gi == 13) {
+            if (MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR) {
+                d.r_active = true; q = (const char *)((gi == 12 ? p.lo : p.hi) + pb * 4); st = 4 * B * 4;
+            }
+        }
+        d.r_ptr = q;
+        d.r_step = st;
+        d.g_ptr = (const char *)(p.Kk + pb * 64 + 4 * gi);
+        d.g_step = 4 * B * 64;
+    }
+}
+
+// DMA of timestep t into ring slot `slot`: exactly DMA_SWEEP (DMA_ROLL) instructions.
+template <bool ROLL>
+MPC_DEV void stage_issue(const P &p, const Dma &d, int t, int slot)
+{
+    const unsigned base = (unsigned)slot * STAGE_BYTES;
+    const long tl = t;
+    const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);     // F / f have T-1 entries
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wv::dma16(d.c_ptr[k] + tl * d.c_step, base + SC + 1024 * k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wv::dma16(d.f_ptr[k] + (p.T > 1 ? tf * d.f_step : 0), base + SF + 1024 * k);
+    // the record instruction is issued by every wave even if only some lanes take part
+    {
+        const char *src = d.r_ptr + (d.r_is_f ? tf : tl) * d.r_step;
+        wv::dma16_if(d.r_active, src, base + SR);
+    }
+    if (ROLL) wv::dma16(d.g_ptr + tl * d.g_step, base + SG);
+}
+
+MPC_DEV unsigned zm_load(const P &p, const Lane &L, int t)
+{
+    // u_zero_I [T,B,4] bytes: the four flags of this row's problem as one dword
+    return *(const unsigned *)(p.zero_mask + ((long)t * p.B + L.pb) * 4);
+}
+
+// ---------------------------------------------------------------------------
+// Sweep
+// ---------------------------------------------------------------------------
+struct SwStage {
+    float Cc[16];
+    float Fc[12];
+    float cj, tb;
+    float lo[4], hi[4];     // bounds of the row's four controls (row-uniform)
+    unsigned zm;
+};
+
+template <int MODE>
+MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, unsigned zm)
+{
+    const unsigned base = (unsigned)slot * STAGE_BYTES;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = wv::lds_f32x4(base + L.aCrow + 16 * q);
+        s.Cc[4 * q] = v[0]; s.Cc[4 * q + 1] = v[1]; s.Cc[4 * q + 2] = v[2]; s.Cc[4 * q + 3] = v[3];
+    }
+    if (t < p.T - 1) {
+#pragma unroll
+        for (int m = 0; m < 12; ++m) s.Fc[m] = wv::lds_f32(base + L.aFcol + 64 * m);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 12; ++m) s.Fc[m] = 0.f;
+    }
+    s.cj = wv::lds_f32(base + L.aRec + R_c);
+    s.tb = wv::lds_f32(base + L.aRec + R_tau);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { s.lo[a] = 0.f; s.hi[a] = 0.f; }
+    if (MODE == 2) {
+        if (p.bound_mode == MPC_BOUND_TENSOR) {
+            const f32x4 l = wv::lds_f32x4(base + SR + L.p * 256 + R_lo);
+            const f32x4 h = wv::lds_f32x4(base + SR + L.p * 256 + R_hi);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { s.lo[a] = l[a]; s.hi[a] = h[a]; }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { s.lo[a] = p.lo_s; s.hi[a] = p.hi_s; }
+        }
+    }
+    s.zm = MODE == 1 ? zm : 0u;
+}
+
+struct SwState {
+    float Vc[12];
+    float vv;
+    float oc;          // nominal-cost partial of this lane
+    float kprev[4];
+    int warm;
+    int qp_total;
+    int status;
+};
+
+template <int MODE>
+MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st, int t)
+{
+    const bool last = (t == p.T - 1);
+    // c_back = C tau + c (mpc/lqr_step.py:289-295) and the nominal stage cost (util.get_cost, :169)
+    float cb = s.cj;
+    wv::dot_bcast16(cb, s.tb, s.Cc);
+    st.oc = fmaf(s.tb, 0.5f * (cb + s.cj), st.oc);
+
+    float Q[16];
+    float q = cb;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Q[i] = s.Cc[i];
+    if (!last) {
+        // Y = V F, Q = C + F'Y, q = c_back + F'v   (:65-70)
+        float Y[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Y[i] = 0.f;
+        wv::fma_bcast_lane12<0>(Y, st.Vc, s.Fc[0]);   wv::fma_bcast_lane12<1>(Y, st.Vc, s.Fc[1]);
+        wv::fma_bcast_lane12<2>(Y, st.Vc, s.Fc[2]);   wv::fma_bcast_lane12<3>(Y, st.Vc, s.Fc[3]);
+        wv::fma_bcast_lane12<4>(Y, st.Vc, s.Fc[4]);   wv::fma_bcast_lane12<5>(Y, st.Vc, s.Fc[5]);
+        wv::fma_bcast_lane12<6>(Y, st.Vc, s.Fc[6]);   wv::fma_bcast_lane12<7>(Y, st.Vc, s.Fc[7]);
+        wv::fma_bcast_lane12<8>(Y, st.Vc, s.Fc[8]);   wv::fma_bcast_lane12<9>(Y, st.Vc, s.Fc[9]);
+        wv::fma_bcast_lane12<10>(Y, st.Vc, s.Fc[10]); wv::fma_bcast_lane12<11>(Y, st.Vc, s.Fc[11]);
+#pragma unroll
+        for (int m = 0; m < 12; ++m) wv::fma_bcast_each16(Q, s.Fc[m], Y[m]);
+        wv::dot_bcast12(q, st.vv, s.Fc);
+    }
+
+    // ---- the 4x4 control block: row-uniform copies out of lanes 12..15 --------------------------
+    Sym4 S;
+    S.s00 = wv::bcast<12>(Q[12]); S.s01 = wv::bcast<13>(Q[12]); S.s02 = wv::bcast<14>(Q[12]); S.s03 = wv::bcast<15>(Q[12]);
+    S.s11 = wv::bcast<13>(Q[13]); S.s12 = wv::bcast<14>(Q[13]); S.s13 = wv::bcast<15>(Q[13]);
+    S.s22 = wv::bcast<14>(Q[14]); S.s23 = wv::bcast<15>(Q[14]);
+    S.s33 = wv::bcast<15>(Q[15]);
+    float qu[4];
+    qu[0] = wv::bcast<12>(q); qu[1] = wv::bcast<13>(q); qu[2] = wv::bcast<14>(q); qu[3] = wv::bcast<15>(q);
+
+    bool fr[4] = {true, true, true, true};
+    const bool valid[4] = {true, true, true, true};
+    Ldl4 f;
+    float kq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0) {
+        ldl4<false>(f, S, fr, 0.f);                                   // :84-94
+    } else if (MODE == 1) {
+        // :99-127 u_zero_I: masked rows and columns drop out
+#pragma unroll
+        for (int a = 0; a < 4; ++a) fr[a] = ((s.zm >> (8 * a)) & 0xffu) == 0u;
+        ldl4<true>(f, S, fr, 0.f);
+    } else {
+        // :128-141 box constraints in delta space
+        float lb[4], ub[4], ubar[4];
+        ubar[0] = wv::bcast<12>(s.tb); ubar[1] = wv::bcast<13>(s.tb); ubar[2] = wv::bcast<14>(s.tb); ubar[3] = wv::bcast<15>(s.tb);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float l = s.lo[a] - ubar[a], h = s.hi[a] - ubar[a];
+            if (p.has_delta) {                                      // :132-134
+                if (l < -p.delta_u) l = -p.delta_u;
+                if (h > p.delta_u) h = p.delta_u;
+            }
+            lb[a] = l;
+            ub[a] = h;
+        }
+        if (!st.warm) {
+            // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
+            ldl4<false>(f, S, valid, 0.f);
+            float y[4];
+            ldl4_solve(f, qu[0], qu[1], qu[2], qu[3], y);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) kq[a] = -y[a];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) kq[a] = st.kprev[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) kq[a] = eclampf(kq[a], lb[a], ub[a]);
+        bool conv = false;
+        const int it = mfma16::pnqp4<false>(S, qu, lb, ub, valid, p.pnqp_iter, kq, fr, f, conv);
+        st.qp_total += 1 + it;                                      // :140
+        if (!conv) st.status |= MPC_ST_PNQP_UNCONVERGED;
+        st.warm = 1;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) st.kprev[a] = kq[a];
+    }
+
+    // K[:, j] = -H_free^-1 Qux[:, j]; lane 12 solves for k = -H_free^-1 qu instead
+    const bool j12 = L.j == 12;
+    float rhs[4], K[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) rhs[a] = sel(j12, qu[a], Q[12 + a]);
+    {
+        float y[4];
+        if (MODE == 0) {
+            ldl4_solve(f, rhs[0], rhs[1], rhs[2], rhs[3], y);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) K[a] = -y[a];
+        } else {
+            ldl4_solve(f, fr[0] ? rhs[0] : 0.f, fr[1] ? rhs[1] : 0.f, fr[2] ? rhs[2] : 0.f, fr[3] ? rhs[3] : 0.f, y);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) K[a] = fr[a] ? -y[a] : 0.f;
+            if (MODE == 2) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) K[a] = sel(j12, kq[a], K[a]);     // k is the QP solution (:136-141)
+            }
+        }
+    }
+
+    // V = Qxx + Qxu K + K'(Qux + Quu K),  v = qx + Qxu k + K'(qu + Quu k)    (:155-158)
+    float Vn[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Vn[i] = Q[i];
+    wv::fma_bcast_lane12<12>(Vn, Q, K[0]);      // += Q[i][12+a] K[a][j]
+    wv::fma_bcast_lane12<13>(Vn, Q, K[1]);
+    wv::fma_bcast_lane12<14>(Vn, Q, K[2]);
+    wv::fma_bcast_lane12<15>(Vn, Q, K[3]);
+    float vn = q;
+    wv::fmac_bcast<12>(vn, K[0], Q[12]); wv::fmac_bcast<12>(vn, K[1], Q[13]);
+    wv::fmac_bcast<12>(vn, K[2], Q[14]); wv::fmac_bcast<12>(vn, K[3], Q[15]);
+    if (MODE != 0) {
+        // with a full free set Qux + Quu K vanishes; with masked / clamped controls it does not
+        float M[4];
+        M[0] = fmaf(S.s03, K[3], fmaf(S.s02, K[2], fmaf(S.s01, K[1], fmaf(S.s00, K[0], rhs[0]))));
+        M[1] = fmaf(S.s13, K[3], fmaf(S.s12, K[2], fmaf(S.s11, K[1], fmaf(S.s01, K[0], rhs[1]))));
+        M[2] = fmaf(S.s23, K[3], fmaf(S.s22, K[2], fmaf(S.s12, K[1], fmaf(S.s02, K[0], rhs[2]))));
+        M[3] = fmaf(S.s33, K[3], fmaf(S.s23, K[2], fmaf(S.s13, K[1], fmaf(S.s03, K[0], rhs[3]))));
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            wv::fma_bcast_each12(Vn, K[a], M[a]);          // += K[a][i] M[a][j]
+            wv::fmac_bcast<12>(vn, M[a], K[a]);            // += K[a][j] m[a]
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) st.Vc[i] = Vn[i];
+    st.vv = vn;
+
+    // gains: the wave's own record Kk[t][b][j][4]; and K [T,B,4,12] / k [T,B,4] when asked for
+    if (L.live) {
+        const long tb = (long)t * p.B + L.pb;
+        wv::store_f32x4(p.Kk + tb * 64 + 4 * L.j, f32x4{K[0], K[1], K[2], K[3]});
+        if (p.K != nullptr) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (L.j < 12) p.K[(tb * 4 + a) * 12 + L.j] = K[a];
+                else if (j12) p.k[tb * 4 + a] = K[a];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Rollout
+// ---------------------------------------------------------------------------
+struct RoStage {
+    float Cr[16];     // row j of C
+    float Fr[16];     // row j of F (state lanes)
+    float Kr[12];     // row a of K (control lanes)
+    float cj, tb, fj, kk, lo, hi;
+    bool zm;
+};
+
+template <int MODE>
+MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, unsigned zm)
+{
+    const unsigned base = (unsigned)slot * STAGE_BYTES;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = wv::lds_f32x4(base + L.aCrow + 16 * q);
+        s.Cr[4 * q] = v[0]; s.Cr[4 * q + 1] = v[1]; s.Cr[4 * q + 2] = v[2]; s.Cr[4 * q + 3] = v[3];
+    }
+    if (t < p.T - 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = wv::lds_f32x4(base + L.aFrow + 16 * q);
+            s.Fr[4 * q] = v[0]; s.Fr[4 * q + 1] = v[1]; s.Fr[4 * q + 2] = v[2]; s.Fr[4 * q + 3] = v[3];
+        }
+        s.fj = p.f ? wv::lds_f32(base + L.aRecF) : 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s.Fr[i] = 0.f;
+        s.fj = 0.f;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 12; ++jj) s.Kr[jj] = wv::lds_f32(base + L.aKrow + 16 * jj);
+    s.kk = wv::lds_f32(base + L.aKrow + 192);
+    s.cj = wv::lds_f32(base + L.aRec + R_c);
+    s.tb = wv::lds_f32(base + L.aRec + R_tau);
+    s.lo = s.hi = 0.f;
+    if (MODE == 2) {
+        if (p.bound_mode == MPC_BOUND_TENSOR) {
+            s.lo = wv::lds_f32(base + L.aRecA + R_lo);
+            s.hi = wv::lds_f32(base + L.aRecA + R_hi);
+        } else {
+            s.lo = p.lo_s;
+            s.hi = p.hi_s;
+        }
+    }
+    s.zm = ((zm >> (8 * L.a)) & 0xffu) != 0u;
+}
+
+struct RoState {
+    float xs;         // x'_t[j] (state lanes)
+    float cost, du2;  // per-lane partials
+    float alpha;      // line-search step of this row's problem
+};
+
+template <int MODE>
+MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &st, int t)
+{
+    const bool last = (t == p.T - 1);
+    // new_u = K dx + u + alpha k   (mpc/lqr_step.py:192); control lanes hold row a of K
+    const float dx = L.isu ? 0.f : st.xs - s.tb;
+    float un = fmaf(st.alpha, s.kk, s.tb);
+    wv::dot_bcast12(un, dx, s.Kr);
+    if (MODE != 0 && s.zm) un = 0.f;                                 // :197-198
+    if (MODE == 2) {                                                 // :200-213
+        float l = s.lo, h = s.hi;
+        if (p.has_delta) {
+            const float l2 = s.tb - p.delta_u, h2 = s.tb + p.delta_u;
+            l = (l2 < l) ? l : l2;
+            h = (h2 > h) ? h : h2;
+        }
+        un = eclampf(un, l, h);
+    }
+    const float tp = L.isu ? un : st.xs;                             // tau'_t[j]
+    // obj_t = 0.5 tau'C tau + c'tau   (:230-232)
+    float sq = 0.f;
+    wv::dot_bcast16(sq, tp, s.Cr);
+    st.cost = fmaf(tp, fmaf(0.5f, sq, s.cj), st.cost);
+    if (L.isu) {
+        const float d = s.tb - un;
+        st.du2 = fmaf(d, d, st.du2);
+    }
+    if (L.live) {
+        const long tb = (long)t * p.B + L.pb;
+        if (L.isu) p.new_u[tb * 4 + L.a] = tp;
+        else p.new_x[tb * 12 + L.j] = tp;
+    }
+    // x_{t+1} = F [x;u] + f  (:216-222)
+    if (!last) {
+        float xn = s.fj;
+        wv::dot_bcast16(xn, tp, s.Fr);
+        st.xs = xn;
+    }
+}
+
+template <int MODE>
+MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st)
+{
+    const int T = p.T;
+    st.xs = L.isu ? 0.f : p.x_init[(long)L.pb * 12 + L.j];
+    st.cost = 0.f;
+    st.du2 = 0.f;
+    const bool use_zm = MODE != 0 && p.zero_mask != nullptr;
+    unsigned zq[NSTAGE] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ti = i < T ? i : T - 1;
+        stage_issue<true>(p, d, ti, i);
+        if (use_zm) zq[i] = zm_load(p, L, ti);
+    }
+    for (int t0 = 0; t0 < T; t0 += NSTAGE) {
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int t = t0 + i;
+            if (t < T) {
+                wv::dma_wait<2 * DMA_ROLL>();
+                RoStage s;
+                ro_read<MODE>(s, p, L, t, i, zq[i]);
+                const int tn = t + 3 < T ? t + 3 : T - 1;
+                stage_issue<true>(p, d, tn, (i + 3) % NSTAGE);
+                if (use_zm) zq[(i + 3) % NSTAGE] = zm_load(p, L, tn);
+                rollout_step<MODE>(p, L, s, st, t);
+            }
+        }
+    }
+    wv::dma_wait<0>();
+    st.cost = wv::row_sum(st.cost);
+    st.du2 = wv::row_sum(st.du2);
+}
+
+template <int MODE>
+MPC_DEV void step_wave(const P &p)
+{
+    const int lane = wv::lane();
+    const int wave = wv::problem();          // one workgroup = one wave = four problems
+    if (4 * wave >= p.B) return;
+    Lane L;
+    lane_init(L, lane, wave, p.B);
+    const int T = p.T;
+    Dma d;
+    dma_init<MODE>(d, p, L, wave);
+
+    // ---- Riccati sweep, t = T-1 .. 0 ------------------------------------------------------------
+    SwState ss;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) ss.Vc[i] = 0.f;
+    ss.vv = 0.f;
+    ss.oc = 0.f;
+    ss.warm = 0;
+    ss.qp_total = 0;
+    ss.status = 0;
+    ss.kprev[0] = ss.kprev[1] = ss.kprev[2] = ss.kprev[3] = 0.f;
+    {
+        unsigned zq[NSTAGE] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int ti = T - 1 - i >= 0 ? T - 1 - i : 0;
+            stage_issue<false>(p, d, ti, i);
+            if (MODE == 1) zq[i] = zm_load(p, L, ti);
+        }
+        for (int k0 = 0; k0 < T; k0 += NSTAGE) {
+#pragma unroll
+            for (int i = 0; i < NSTAGE; ++i) {
+                const int t = T - 1 - (k0 + i);
+                if (t >= 0) {
+                    wv::dma_wait<2 * DMA_SWEEP>();
+                    SwStage s;
+                    sw_read<MODE>(s, p, L, t, i, zq[i]);
+                    const int tn = t - 3 >= 0 ? t - 3 : 0;
+                    stage_issue<false>(p, d, tn, (i + 3) % NSTAGE);
+                    if (MODE == 1) zq[(i + 3) % NSTAGE] = zm_load(p, L, tn);
+                    sweep_step<MODE>(p, L, s, ss, t);
+                }
+            }
+        }
+        wv::dma_wait<0>();
+    }
+    const float old_cost = wv::row_sum(ss.oc);
+
+    // the gains were written by this wave and are re-read through the DMA: drain the stores
+    wv::fence_own_stores();
+
+    // ---- line-searched rollout (mpc/lqr_step.py:164-261): every row backtracks on its own ------
+    RoState rs;
+    rs.alpha = 1.f;
+    float full2 = 0.f;
+    for (int pass = 0; pass < p.max_ls; ++pass) {
+        rollout_pass<MODE>(p, L, d, rs);
+        if (pass == 0) full2 = rs.du2;                               // :243-245
+        // :176-179, 247, 252: shrink while this problem's cost got worse
+        const bool worse = rs.cost > old_cost && pass + 1 < p.max_ls;
+        if (worse) rs.alpha *= p.ls_decay;
+        if (!wv::any(worse)) break;
+    }
+    int status = ss.status;
+    if (!(rs.cost == rs.cost) || fabsf(rs.cost) > 3e38f) status |= MPC_ST_NONFINITE;
+    if (L.live && L.j == 0) {
+        const int b = L.pb;
+        if (p.costs) p.costs[b] = rs.cost;
+        if (p.old_costs) p.old_costs[b] = old_cost;
+        if (p.full_du_norm) p.full_du_norm[b] = sqrtf(full2);
+        if (p.alpha_du_norm) p.alpha_du_norm[b] = sqrtf(rs.du2);
+        if (p.alphas) p.alphas[b] = rs.alpha;
+        if (p.qp_iters) p.qp_iters[b] = ss.qp_total;
+        if (p.status) p.status[b] = status;
+    }
+}
+
+}  // namespace dpp16
+}  // namespace mpclqr

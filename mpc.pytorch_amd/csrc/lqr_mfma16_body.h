@@ -53,6 +53,7 @@
 #pragma once
 #include <math.h>
 #include "lqr_params.h"
+#include "lqr_small_math.h"
 
 namespace mpclqr {
 namespace mfma16 {
@@ -128,144 +129,6 @@ MPC_DEV void lane_init(Lane &L, int lane, int ns, int nc)
     L.aKA = L.vK ? LDS_V + V_K + 4 * (16 * L.ja + 4 * L.g) : LDS_V + V_zero;
     L.aKk = LDS_V + V_K + 4 * 16 * L.g;
     L.aG = L.rowv[0] ? 4 * L.g : 0;
-}
-
-MPC_DEV float sel(bool c, float a, float b) { return c ? a : b; }
-MPC_DEV float dot4(const float a[4], float b0, float b1, float b2, float b3)
-{
-    return fmaf(a[3], b3, fmaf(a[2], b2, fmaf(a[1], b1, a[0] * b0)));
-}
-
-// ---------------------------------------------------------------------------
-// 4x4 symmetric factorisation  S = L D L'  on wave-uniform values (every lane
-// computes the same numbers).  Non-free rows/columns are replaced by identity.
-// Stands in for Tensor.lu()/lu_solve (mpc/pnqp.py:53-54, mpc/lqr_step.py:125-127,148)
-// and for the per-sample pinverse of mpc/lqr_step.py:88-94 (identical for SPD Quu).
-// ---------------------------------------------------------------------------
-struct Sym4 { float s00, s01, s02, s03, s11, s12, s13, s22, s23, s33; };
-struct Ldl4 { float l10, l20, l30, l21, l31, l32, i0, i1, i2, i3; };
-
-template <bool MASKED>
-MPC_DEV void ldl4(Ldl4 &f, const Sym4 &s, const bool fr_[4], float reg)
-{
-    bool fr[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) fr[a] = MASKED ? fr_[a] : true;
-    const float a00 = fr[0] ? s.s00 + reg : 1.f;
-    const float a10 = (fr[0] && fr[1]) ? s.s01 : 0.f;
-    const float a20 = (fr[0] && fr[2]) ? s.s02 : 0.f;
-    const float a30 = (fr[0] && fr[3]) ? s.s03 : 0.f;
-    const float a11 = fr[1] ? s.s11 + reg : 1.f;
-    const float a21 = (fr[1] && fr[2]) ? s.s12 : 0.f;
-    const float a31 = (fr[1] && fr[3]) ? s.s13 : 0.f;
-    const float a22 = fr[2] ? s.s22 + reg : 1.f;
-    const float a32 = (fr[2] && fr[3]) ? s.s23 : 0.f;
-    const float a33 = fr[3] ? s.s33 + reg : 1.f;
-    f.i0 = wv::rcp(a00);
-    f.l10 = a10 * f.i0; f.l20 = a20 * f.i0; f.l30 = a30 * f.i0;
-    const float d1 = fmaf(-f.l10, a10, a11);
-    f.i1 = wv::rcp(d1);
-    const float t21 = fmaf(-f.l20, a10, a21);
-    const float t31 = fmaf(-f.l30, a10, a31);
-    f.l21 = t21 * f.i1; f.l31 = t31 * f.i1;
-    const float d2 = fmaf(-f.l21, t21, fmaf(-f.l20, a20, a22));
-    f.i2 = wv::rcp(d2);
-    const float t32 = fmaf(-f.l31, t21, fmaf(-f.l30, a20, a32));
-    f.l32 = t32 * f.i2;
-    const float d3 = fmaf(-f.l32, t32, fmaf(-f.l31, t31, fmaf(-f.l30, a30, a33)));
-    f.i3 = wv::rcp(d3);
-}
-
-MPC_DEV void ldl4_solve(const Ldl4 &f, float r0, float r1, float r2, float r3, float y[4])
-{
-    const float z0 = r0;
-    const float z1 = fmaf(-f.l10, z0, r1);
-    const float z2 = fmaf(-f.l21, z1, fmaf(-f.l20, z0, r2));
-    const float z3 = fmaf(-f.l32, z2, fmaf(-f.l31, z1, fmaf(-f.l30, z0, r3)));
-    const float w0 = z0 * f.i0, w1 = z1 * f.i1, w2 = z2 * f.i2, w3 = z3 * f.i3;
-    y[3] = w3;
-    y[2] = fmaf(-f.l32, y[3], w2);
-    y[1] = fmaf(-f.l31, y[3], fmaf(-f.l21, y[2], w1));
-    y[0] = fmaf(-f.l30, y[3], fmaf(-f.l20, y[2], fmaf(-f.l10, y[1], w0)));
-}
-
-MPC_DEV void sym4_mv(const Sym4 &s, const float x[4], float y[4])
-{
-    y[0] = fmaf(s.s03, x[3], fmaf(s.s02, x[2], fmaf(s.s01, x[1], s.s00 * x[0])));
-    y[1] = fmaf(s.s13, x[3], fmaf(s.s12, x[2], fmaf(s.s11, x[1], s.s01 * x[0])));
-    y[2] = fmaf(s.s23, x[3], fmaf(s.s22, x[2], fmaf(s.s12, x[1], s.s02 * x[0])));
-    y[3] = fmaf(s.s33, x[3], fmaf(s.s23, x[2], fmaf(s.s13, x[1], s.s03 * x[0])));
-}
-
-MPC_DEV float eclampf(float x, float lo, float hi)
-{
-    // util.eclamp (mpc/util.py:56-70): strict compares, the bound value is written exactly
-    if (x < lo) x = lo;
-    if (x > hi) x = hi;
-    return x;
-}
-
-MPC_DEV float qp_obj4(const Sym4 &s, const float q[4], const float x[4])
-{
-    float hx[4];
-    sym4_mv(s, x, hx);
-    const float quad = fmaf(x[3], hx[3], fmaf(x[2], hx[2], fmaf(x[1], hx[1], x[0] * hx[0])));
-    const float lin = fmaf(q[3], x[3], fmaf(q[2], x[2], fmaf(q[1], x[1], q[0] * x[0])));
-    return fmaf(0.5f, quad, lin);
-}
-
-// Projected-Newton box QP in n_ctrl <= 4 unknowns on wave-uniform values
-// (mpc/pnqp.py:5-82 with n_batch = 1).  x holds the clamped start on entry and the
-// solution on exit; fr/f are the free set and factorisation the reference returns
-// (those of the iteration that detected convergence, or of the last one).
-MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const float ub[4],
-                  const bool valid[4], int n_iter, float x[4], bool fr[4], Ldl4 &f, bool &converged)
-{
-    int it_ret = n_iter - 1;
-    converged = false;
-    for (int it = 0; it < n_iter; ++it) {
-        float g[4];
-        sym4_mv(s, x, g);                                           // :29
-        float gm[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            g[a] += q[a];
-            const bool ic = ((x[a] == lb[a]) && (g[a] > 0.f)) || ((x[a] == ub[a]) && (g[a] < 0.f));   // :32
-            fr[a] = valid[a] && !ic;
-            gm[a] = fr[a] ? g[a] : 0.f;
-        }
-        ldl4<true>(f, s, fr, 1e-11f);                                // :44-48
-        float dx[4];
-        ldl4_solve(f, gm[0], gm[1], gm[2], gm[3], dx);               // :50-54
-        float nrm2 = 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            dx[a] = fr[a] ? -dx[a] : 0.f;
-            nrm2 = fmaf(dx[a], dx[a], nrm2);
-        }
-        if (wv::uniform(!(sqrtf(nrm2) >= 1e-4f))) {                 // :56-59
-            converged = true;
-            it_ret = it;
-            break;
-        }
-        // :61-76 Armijo backtracking
-        float alpha = 1.f;
-        const float obj_x = qp_obj4(s, q, x);
-        float mx[4];
-        for (int count = 0; count < 10; ++count) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) mx[a] = eclampf(fmaf(alpha, dx[a], x[a]), lb[a], ub[a]);
-            const float obj_m = qp_obj4(s, q, mx);
-            float den = 0.f;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) den = fmaf(g[a], x[a] - mx[a], den);
-            const float arm = (obj_x - obj_m) / den;
-            if (wv::uniform(arm <= 0.1f)) alpha *= 0.1f; else break;
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) x[a] = mx[a];                    // :78
-    }
-    return it_ret;
 }
 
 // ---------------------------------------------------------------------------

@@ -29,10 +29,11 @@ struct Wave {
     int problem;
     // exchange area, two generations
     float fa[2][NL], fb[2][NL];
+    float fv[2][NL][16];
     int ia[2][NL];
     unsigned seq[NL];
     // LDS of the (single-wave) workgroup + the in-order queue of LDS-DMA instructions in flight
-    unsigned char lds[4 * 2288 + 64];
+    unsigned char lds[4 * 9216];            // the larger of the two kernels' rings
     struct Dma { unsigned char data[NL][16]; bool act[NL]; unsigned off; int size; };
     Dma q[64];
     int qn;
@@ -151,6 +152,81 @@ static inline unsigned long long ballot(bool c)
     return m;
 }
 static inline float rcp(float x) { return 1.0f / x; }
+// ---- DPP row_newbcast family (lqr_dpp16_body.h): lane N of the caller's 16-lane row -------------
+template <int N> static inline float bcast(float x)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = x;
+    emu::yield_lane();
+    return w.fa[gen][(l & ~15) + N];
+}
+template <int N> static inline void fmac_bcast(float &acc, float src, float mul) { acc = fmaf(bcast<N>(src), mul, acc); }
+template <int M, int NS> static inline void fma_bcast_lane12(float (&a)[12], const float (&s)[NS], float mul)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    for (int i = 0; i < 12; ++i) w.fv[gen][l][i] = s[i];
+    emu::yield_lane();
+    for (int i = 0; i < 12; ++i) a[i] = fmaf(w.fv[gen][(l & ~15) + M][i], mul, a[i]);
+}
+template <int NN> static inline void fma_bcast_each(float (&a)[NN], float src, float mul)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = src;
+    emu::yield_lane();
+    for (int i = 0; i < NN; ++i) a[i] = fmaf(w.fa[gen][(l & ~15) + i], mul, a[i]);
+}
+static inline void fma_bcast_each16(float (&a)[16], float src, float mul) { fma_bcast_each<16>(a, src, mul); }
+static inline void fma_bcast_each12(float (&a)[12], float src, float mul) { fma_bcast_each<12>(a, src, mul); }
+template <int NN> static inline void dot_bcast(float &acc, float src, const float (&m)[NN])
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = src;
+    emu::yield_lane();
+    // the kernel's two accumulation chains: even terms onto acc, odd terms onto a temporary
+    float t = w.fa[gen][(l & ~15) + 1] * m[1];
+    acc = fmaf(w.fa[gen][(l & ~15) + 0], m[0], acc);
+    for (int i = 2; i < NN; i += 2) {
+        t = fmaf(w.fa[gen][(l & ~15) + i + 1], m[i + 1], t);
+        acc = fmaf(w.fa[gen][(l & ~15) + i], m[i], acc);
+    }
+    acc += t;
+}
+static inline void dot_bcast16(float &acc, float src, const float (&m)[16]) { dot_bcast<16>(acc, src, m); }
+static inline void dot_bcast12(float &acc, float src, const float (&m)[12]) { dot_bcast<12>(acc, src, m); }
+static inline float row_sum(float x)
+{
+    emu::Wave &w = emu::W;
+    const int xors[4] = {1, 2, 0, 0};
+    (void)xors;
+    // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- as the hardware adds them
+    for (int step = 0; step < 4; ++step) {
+        const int l = w.cur, gen = w.seq[l]++ & 1;
+        w.fa[gen][l] = x;
+        emu::yield_lane();
+        const int r = l & ~15, j = l & 15;
+        int src;
+        if (step == 0) src = j ^ 1;
+        else if (step == 1) src = j ^ 2;
+        else if (step == 2) src = (j & 8) | (7 - (j & 7));
+        else src = 15 - j;
+        x += w.fa[gen][r + src];
+    }
+    return x;
+}
+static inline bool any(bool c)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.ia[gen][l] = c ? 1 : 0;
+    emu::yield_lane();
+    for (int i = 0; i < 64; ++i) if (w.ia[gen][i]) return true;
+    return false;
+}
+static inline void store_f32x4(float *g, f32x4 v) { memcpy(g, &v, 16); }
 static inline bool uniform(bool c)
 {
     // must be wave-uniform: check it
@@ -186,6 +262,7 @@ static inline void dma_n(const void *g, unsigned off, int size)
     memcpy(d->data[l], g, size);
 }
 static inline void dma16(const void *g, unsigned off) { dma_n(g, off, 16); }
+static inline void dma16_if(bool active, const void *g, unsigned off) { if (active) dma_n(g, off, 16); }
 static inline void dma4(const void *g, unsigned off) { dma_n(g, off, 4); }
 template <int N> static inline void dma_wait()
 {
@@ -220,6 +297,7 @@ static inline void fence_own_stores() {}
 }  // namespace mpclqr
 
 #include "../../mpc.pytorch_amd/csrc/lqr_mfma16_body.h"
+#include "../../mpc.pytorch_amd/csrc/lqr_dpp16_body.h"
 
 static const mpclqr::StepParams<float> *g_p;
 template <bool FULL> static void body()
@@ -248,5 +326,31 @@ extern "C" int emu_lqr_step_mfma16(const mpc_lqr_problem *p, const mpc_lqr_optio
     g_p = &sp;
     const bool full = sp.ns == 12 && sp.nc == 4 && !force_general;
     for (int b = 0; b < sp.B; ++b) emu::run_wave(b, full ? body<true> : body<false>);
+    return 0;
+}
+
+// ---- the 4-problems-per-wave DPP kernel (lqr_dpp16_body.h) -------------------------------------
+static void body_dpp16()
+{
+    const mpclqr::StepParams<float> &p = *g_p;
+    if (p.bound_mode != MPC_BOUND_NONE) mpclqr::dpp16::step_wave<2>(p);
+    else if (p.zero_mask) mpclqr::dpp16::step_wave<1>(p);
+    else mpclqr::dpp16::step_wave<0>(p);
+}
+
+extern "C" int emu_lqr_step_dpp16(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out)
+{
+    if (p->dtype != MPC_F32) return MPC_E_DTYPE;
+    mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, out);
+    if (!(sp.ns == 12 && sp.nc == 4 && sp.max_ls >= 1)) return MPC_E_DIMS;
+    if (!sp.new_x || !sp.new_u) return MPC_E_NULL;
+    static float *kk_buf = nullptr;
+    static size_t kk_cap = 0;
+    const size_t need = (size_t)sp.T * sp.B * 64 + 4;
+    if (need > kk_cap) { free(kk_buf); kk_buf = (float *)aligned_alloc(16, (need * sizeof(float) + 15) / 16 * 16); kk_cap = need; }
+    for (size_t i = 0; i < need; ++i) kk_buf[i] = NAN;
+    sp.Kk = kk_buf;
+    g_p = &sp;
+    for (int w = 0; 4 * w < sp.B; ++w) emu::run_wave(w, body_dpp16);
     return 0;
 }

@@ -21,9 +21,9 @@ _LIB = None
 def build():
     so = os.path.join(_EMU, "libemu_mfma16.so")
     src = os.path.join(_EMU, "emu_mfma16.cpp")
-    body = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc", "lqr_mfma16_body.h")
-    params = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc", "lqr_params.h")
-    deps = [src, body, params]
+    csrc = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, h) for h in ("lqr_mfma16_body.h", "lqr_dpp16_body.h", "lqr_small_math.h",
+                                                    "lqr_params.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         cxx = "/opt/rocm/lib/llvm/bin/clang++"
         if not os.path.exists(cxx):
@@ -39,6 +39,8 @@ def lib():
         _LIB = ctypes.CDLL(build())
         _LIB.emu_lqr_step_mfma16.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options),
                                              ctypes.POINTER(N.Outputs), ctypes.c_int]
+        _LIB.emu_lqr_step_dpp16.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options),
+                                            ctypes.POINTER(N.Outputs)]
     return _LIB
 
 
@@ -47,7 +49,8 @@ def _ptr(a):
 
 
 def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None,
-             linesearch_decay=0.2, max_linesearch_iter=10, pnqp_iter=20, force_general=False, dma_late=False):
+             linesearch_decay=0.2, max_linesearch_iter=10, pnqp_iter=20, force_general=False, dma_late=False,
+             kernel="mfma16"):
     """Same signature as oracle.lqr_oracle.lqr_step; float32 only.  Returns the kernel's outputs."""
     f32 = np.float32
     C = np.ascontiguousarray(C, f32); c = np.ascontiguousarray(c, f32)
@@ -96,6 +99,9 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
     for key, arr in res.items():
         setattr(out, key, _ptr(arr))
     lib().emu_set_dma_late(int(bool(dma_late)))
-    rc = lib().emu_lqr_step_mfma16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), int(force_general))
+    if kernel == "dpp16":
+        rc = lib().emu_lqr_step_dpp16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
+    else:
+        rc = lib().emu_lqr_step_mfma16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), int(force_general))
     assert rc == 0, rc
     return res

@@ -110,3 +110,79 @@ def test_odd_shapes_against_oracle(emu, ns, nc, T):
     np.testing.assert_allclose(r["costs"], o["costs"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
     assert float(np.abs(r["new_u"]).max()) <= 0.5
+
+
+# ---------------------------------------------------------------------------------------------
+# The 4-problems-per-wave DPP kernel (csrc/lqr_dpp16_body.h): n_state = 12, n_ctrl = 4 only
+# ---------------------------------------------------------------------------------------------
+DPP_CASES = [c for c in STEP_CASES if golden(c)["meta"][0] == 12 and golden(c)["meta"][1] == 4]
+
+
+@pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
+@pytest.mark.parametrize("name", DPP_CASES)
+def test_emulated_dpp16_matches_oracle_and_reference(emu, name, dma_late):
+    """Batches of 3 and 4 problems: the last wave of a batch that is not a multiple of 4 runs with
+    idle rows whose stores must stay masked."""
+    from oracle import lqr_oracle as O
+    z = golden(name)
+    kw = step_kwargs(z)
+    o = O.lqr_step(lockstep=False, return_gains=True, **_f64(kw))
+    r = emu.lqr_step(kernel="dpp16", dma_late=dma_late, **kw)
+    assert (r["status"] & 2 == 0).all()
+    # box-constrained float32: pnqp stops at |dx| < 1e-4 (mpc/pnqp.py:56), so two correct float32
+    # evaluations (and the reference's own float32 vs float64 runs) differ by a few 1e-4 in k
+    atol = 1e-3 if ("u_lower" in z and z["C"].dtype == np.float32) else 1e-4
+    for k in ("K", "k", "new_x", "new_u"):
+        np.testing.assert_allclose(r[k], o[k], rtol=1e-3, atol=atol, err_msg=k)
+    np.testing.assert_allclose(r["costs"], o["costs"], rtol=1e-4)
+    np.testing.assert_allclose(r["old_costs"], o["old_costs"], rtol=1e-4)
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+    np.testing.assert_allclose(r["full_du_norm"], o["full_du_norm"], rtol=2e-3, atol=2e-4)
+    sfx = "_pp" if z["C"].dtype == np.float64 else "_ref64"
+    np.testing.assert_allclose(r["new_x"], z["new_x" + sfx], rtol=1e-3, atol=atol)
+    np.testing.assert_allclose(r["new_u"], z["new_u" + sfx], rtol=1e-3, atol=atol)
+    np.testing.assert_allclose(r["costs"], z["costs" + sfx], rtol=1e-4)
+
+
+def _ns_problem(rng, T, B, indef=0.0, with_f=True):
+    ns, nc, n = 12, 4, 16
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A)
+    C[:, :, :ns, :ns] -= indef * np.eye(ns)
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((T - 1, B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((T - 1, B, ns, nc)) / np.sqrt(ns)), 3)
+    f = 0.1 * rng.standard_normal((T - 1, B, ns)) if with_f else None
+    x_init = rng.standard_normal((B, ns))
+    return dict(C=C, c=c, F=F, f=f, x_init=x_init)
+
+
+@pytest.mark.parametrize("case", ["tensor_bounds", "delta_u", "no_f", "backtrack", "T1", "B9"])
+def test_emulated_dpp16_options_against_oracle(emu, case):
+    """Tensor bounds, delta_u trust region, missing f, per-row backtracking (two rows of one wave stop
+    at different step sizes), T = 1, and a batch that leaves three rows of the last wave idle."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(5 if case == "backtrack" else sum(map(ord, case)))
+    T, B = (1 if case == "T1" else 7), (9 if case == "B9" else 5)
+    # backtrack: a non-convex state cost (as the step_backtrack_* fixtures) so the line search really shrinks
+    pr = _ns_problem(rng, T, B, indef=30.0 if case == "backtrack" else 0.0, with_f=case != "no_f")
+    cur_u = np.clip(0.5 * rng.standard_normal((T, B, 4)), -0.4, 0.4)
+    cur_x, _ = O.traj_cost(pr["x_init"], cur_u, pr["F"], pr["f"])
+    kw = dict(cur_x=cur_x, cur_u=cur_u, **pr)
+    if case == "tensor_bounds":
+        kw.update(u_lower=-0.4 - rng.random((T, B, 4)), u_upper=0.4 + rng.random((T, B, 4)))
+    elif case == "delta_u":
+        kw.update(u_lower=-0.4, u_upper=0.4, delta_u=0.1)
+    elif case == "backtrack":
+        kw.update(u_lower=-0.4, u_upper=0.4, linesearch_decay=0.5, max_linesearch_iter=4)
+    elif case != "no_f":
+        kw.update(u_lower=-0.4, u_upper=0.4)
+    o = O.lqr_step(lockstep=False, return_gains=True, **kw)
+    if case == "backtrack":
+        assert len(set(np.round(o["alphas"], 6))) > 1, "rows of one wave must stop at different alphas"
+    r = emu.lqr_step(kernel="dpp16", dma_late=True, **kw)
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+    np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=1e-4)

@@ -64,8 +64,9 @@ def impls_for(z):
     ns, nc = int(z["meta"][0]), int(z["meta"][1])
     from mpc import _native
     out = [1]
-    if _native.backend().impl_supported(ns, nc, torch.from_numpy(z["C"][:0]).dtype, _native.IMPL_MFMA16):
-        out.append(_native.IMPL_MFMA16)
+    for impl in (_native.IMPL_MFMA16, _native.IMPL_DPP16):
+        if _native.backend().impl_supported(ns, nc, torch.from_numpy(z["C"][:0]).dtype, impl):
+            out.append(impl)
     return out
 
 
@@ -281,7 +282,7 @@ def test_north_star_full_size_vs_oracle(be, bounded):
                      -1.0 if bounded else None, 1.0 if bounded else None, lockstep=False,
                      nthreads=O.max_threads())
     from mpc import _native
-    for impl in (1, 2):
+    for impl in (1, 2, 3):
         if not be.impl_supported(12, 4, torch.float32, impl):
             continue
         r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts, impl=impl)
