@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic, 2 fused MFMA, 3 DPP 4-problems-per-wave")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe-share", default="", help="diagnostic only: 'C' / 'F' / 'CF' = expand timestep 0 of C / F "
+                    "over the horizon (stride 0), which removes that array's HBM traffic without changing the arithmetic")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,6 +123,10 @@ def main():
     p = make_problem(NS, NC, T_H, B, torch.float32, dev, seed=1000 + rank,
                      u_scale=0.3 if args.bounded else 0.0, clamp=1.0 if args.bounded else None)
     opts = StepOptions(u_lower=-1.0, u_upper=1.0) if args.bounded else StepOptions()
+    if "C" in args.probe_share:
+        p["C"] = p["C"][:1].expand(T_H, -1, -1, -1)
+    if "F" in args.probe_share:
+        p["F"] = p["F"][:1].expand(T_H - 1, -1, -1, -1)
     impl_used = args.impl if args.impl else (3 if be.impl_supported(NS, NC, torch.float32, 3) else 1)
 
     # argument structs + output buffers bound once: a timed step is exactly one C-ABI call
