@@ -25,14 +25,8 @@
 //   Y[i]   = (V F)[i][j]  = sum_m bcast_m(Vc[i]) * Fc[m]
 //   Q[i]   = (C + F'VF)[i][j] = Cc[i] + sum_m bcast_i(Fc[m]) * Y[m];   q = q[j]
 //   K[a]   = K[a][j]  (j < 12),  lane 12 carries k = K[.][12]
-// Gains: the sweep parks K_t, k_t in the wave's own workspace record Kk[t][b] = {K [4][12], k [4]}
-// (208 B per problem-step) and the rollout DMAs it back -- the one piece of state that does not fit
-// on chip (4 x 50 x 208 B per wave; an in-register store was tried: it lands in AGPRs, which the
-// s_set_gpr_idx indexing cannot reach, and the copies cost more than the traffic).
-// Staging: per wave a 4-slot LDS ring (slot = t mod 4), 9 KiB per slot (4 x {C 1 KiB, F 768 B,
-// small-vector record 256 B, gain record 256 B}), filled by global_load_lds three timesteps ahead
-// with counted vmcnt waits; the ring is NOT refilled at the sweep -> rollout turn: timesteps 0..3
-// are still in it, only their gain records are fetched.
+// Staging: per wave a 4-slot LDS ring, 9 KiB per slot (4 x {C 1 KiB, F 768 B, small-vector record
+// 256 B, gain record 256 B}), filled by global_load_lds three timesteps ahead; counted vmcnt waits.
 #pragma once
 #include <math.h>
 #include "lqr_params.h"
@@ -53,8 +47,6 @@ using mfma16::sel;
 enum {
     SC = 0, SF = 4096, SR = 7168, SG = 8192, STAGE_BYTES = 9216, NSTAGE = 4,
     R_c = 0, R_tau = 64, R_f = 128, R_lo = 192, R_hi = 208,
-    G_k = 192,          // gain record: K [4][12] at 0, k [4] at 192
-    GAIN_FLOATS = 52,   // per problem-step in the workspace
     LDS_TOTAL = NSTAGE * STAGE_BYTES,
     DMA_SWEEP = 8,      // 4 C + 3 F + 1 record
     DMA_ROLL = 9        // + 1 gain record
@@ -73,7 +65,7 @@ struct Lane {
     int aRec;             // SR + p*256 + 4 j                   (+R_c: c_j, +R_tau: tau_j)
     int aRecA;            // SR + p*256 + 4 a                   (+R_lo / R_hi)
     int aRecF;            // SR + p*256 + R_f + 4 min(j, 11)
-    int aKrow;            // SG + p*256 + 48 a                  (row a of K: 3 x b128; + G_k - 44 a: k_a)
+    int aKrow;            // SG + p*256 + 4 a                   (+16 jj: K[a][jj]; +192: k_a)
 };
 
 MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
@@ -93,7 +85,7 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
     L.aRec = SR + L.p * 256 + 4 * L.j;
     L.aRecA = SR + L.p * 256 + 4 * L.a;
     L.aRecF = SR + L.p * 256 + R_f + 4 * jx;
-    L.aKrow = SG + L.p * 256 + 48 * L.a;
+    L.aKrow = SG + L.p * 256 + 4 * L.a;
 }
 
 // ---------------------------------------------------------------------------
@@ -101,14 +93,15 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
 //   C  : instruction k = problem slot k, granule l            (4 instructions)
 //   F  : granule G = 64 k + l of the 4 x 48 granules           (3 instructions)
 //   rec: problem slot l>>4, granule l&15: 0-3 c | 4-6 x | 7 u | 8-10 f | 12 lo | 13 hi
+//   gains (rollout): problem slot l>>4, granule l&15 of the wave's own record Kk[t][b][16][4]
 // ---------------------------------------------------------------------------
 struct Dma {
     const char *c_ptr[4];     // wave-uniform per problem slot
     const char *f_ptr[3];     // per lane
     const char *r_ptr;        // per lane
-    const char *g_ptr;        // per lane: granule l&15 (< 13) of the gain record of problem slot l>>4
+    const char *g_ptr;        // per lane
     long c_step, f_step, r_step, g_step;
-    bool r_active, r_is_f, g_active;
+    bool r_active, r_is_f;
 };
 
 template <int MODE>
@@ -148,42 +141,28 @@ MPC_DEV void dma_init(Dma &d, const P &p, const Lane &L, int wave)
         }
         d.r_ptr = q;
         d.r_step = st;
-        d.g_active = gi < 13;
-        d.g_ptr = (const char *)(p.Kk + pb * GAIN_FLOATS + 4 * (gi < 13 ? gi : 0));
-        d.g_step = 4 * B * GAIN_FLOATS;
+        d.g_ptr = (const char *)(p.Kk + pb * 64 + 4 * gi);
+        d.g_step = 4 * B * 64;
     }
 }
 
-// DMA of timestep t into ring slot t mod NSTAGE: exactly DMA_SWEEP instructions, DMA_ROLL with the gain
-// record.  `with_f`: the f granules take part (the rollout needs them; the sweep fetches them for the
-// timesteps it leaves in the ring for the rollout).
-MPC_DEV void gains_issue(const P &p, const Dma &d, int t)
-{
-    wv::dma16_if(d.g_active, d.g_ptr + (long)t * d.g_step, (unsigned)(t & (NSTAGE - 1)) * STAGE_BYTES + SG);
-}
-
+// DMA of timestep t into ring slot `slot`: exactly DMA_SWEEP (DMA_ROLL) instructions.
 template <bool ROLL>
-MPC_DEV void stage_issue(const P &p, const Dma &d, int t, bool with_f)
+MPC_DEV void stage_issue(const P &p, const Dma &d, int t, int slot)
 {
-    const unsigned base = (unsigned)(t & (NSTAGE - 1)) * STAGE_BYTES;
+    const unsigned base = (unsigned)slot * STAGE_BYTES;
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);     // F / f have T-1 entries
 #pragma unroll
     for (int k = 0; k < 4; ++k) wv::dma16(d.c_ptr[k] + tl * d.c_step, base + SC + 1024 * k);
 #pragma unroll
     for (int k = 0; k < 3; ++k) wv::dma16(d.f_ptr[k] + (p.T > 1 ? tf * d.f_step : 0), base + SF + 1024 * k);
-    const char *src = d.r_ptr + (d.r_is_f ? tf : tl) * d.r_step;
-    wv::dma16_if(d.r_active && (with_f || !d.r_is_f), src, base + SR);
-    if (ROLL) gains_issue(p, d, t);
-}
-
-// Counted wait for the stage of timestep t: `newer` = stages issued after it that may still be in flight.
-template <bool ROLL>
-MPC_DEV void stage_wait(int newer)
-{
-    if (newer >= 2) wv::dma_wait<2 * (ROLL ? (int)DMA_ROLL : (int)DMA_SWEEP)>();
-    else if (newer == 1) wv::dma_wait<(ROLL ? (int)DMA_ROLL : (int)DMA_SWEEP)>();
-    else wv::dma_wait<0>();
+    // the record instruction is issued by every wave even if only some lanes take part
+    {
+        const char *src = d.r_ptr + (d.r_is_f ? tf : tl) * d.r_step;
+        wv::dma16_if(d.r_active, src, base + SR);
+    }
+    if (ROLL) wv::dma16(d.g_ptr + tl * d.g_step, base + SG);
 }
 
 MPC_DEV unsigned zm_load(const P &p, const Lane &L, int t)
@@ -204,9 +183,9 @@ struct SwStage {
 };
 
 template <int MODE>
-MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, unsigned zm)
+MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, unsigned zm)
 {
-    const unsigned base = (unsigned)(t & (NSTAGE - 1)) * STAGE_BYTES;
+    const unsigned base = (unsigned)slot * STAGE_BYTES;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 v = wv::lds_f32x4(base + L.aCrow + 16 * q);
@@ -382,16 +361,10 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     for (int i = 0; i < 12; ++i) st.Vc[i] = Vn[i];
     st.vv = vn;
 
-    // gains: the wave's own record Kk[t][b] = {K [4][12], k [4]}; and K [T,B,4,12] / k [T,B,4] when asked for
+    // gains: the wave's own record Kk[t][b][j][4]; and K [T,B,4,12] / k [T,B,4] when asked for
     if (L.live) {
         const long tb = (long)t * p.B + L.pb;
-        float *rec = p.Kk + tb * GAIN_FLOATS;
-        if (L.j < 12) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) rec[12 * a + L.j] = K[a];
-        } else if (j12) {
-            wv::store_f32x4(rec + 48, f32x4{K[0], K[1], K[2], K[3]});
-        }
+        wv::store_f32x4(p.Kk + tb * 64 + 4 * L.j, f32x4{K[0], K[1], K[2], K[3]});
         if (p.K != nullptr) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -414,9 +387,9 @@ struct RoStage {
 };
 
 template <int MODE>
-MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, unsigned zm)
+MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, unsigned zm)
 {
-    const unsigned base = (unsigned)(t & (NSTAGE - 1)) * STAGE_BYTES;
+    const unsigned base = (unsigned)slot * STAGE_BYTES;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 v = wv::lds_f32x4(base + L.aCrow + 16 * q);
@@ -435,11 +408,8 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, unsigned zm)
         s.fj = 0.f;
     }
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const f32x4 v = wv::lds_f32x4(base + L.aKrow + 16 * q);
-        s.Kr[4 * q] = v[0]; s.Kr[4 * q + 1] = v[1]; s.Kr[4 * q + 2] = v[2]; s.Kr[4 * q + 3] = v[3];
-    }
-    s.kk = wv::lds_f32(base + L.aKrow + G_k - 44 * L.a);
+    for (int jj = 0; jj < 12; ++jj) s.Kr[jj] = wv::lds_f32(base + L.aKrow + 16 * jj);
+    s.kk = wv::lds_f32(base + L.aKrow + 192);
     s.cj = wv::lds_f32(base + L.aRec + R_c);
     s.tb = wv::lds_f32(base + L.aRec + R_tau);
     s.lo = s.hi = 0.f;
@@ -459,7 +429,6 @@ struct RoState {
     float xs;         // x'_t[j] (state lanes)
     float cost, du2;  // per-lane partials
     float alpha;      // line-search step of this row's problem
-    int present;      // timesteps 0 .. present-1 are already in the LDS ring when the pass starts
 };
 
 template <int MODE>
@@ -502,51 +471,39 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
     }
 }
 
-struct ZmRing { unsigned z0, z1, z2, z3; };
-MPC_DEV unsigned zm_get(const ZmRing &z, int t)
-{
-    const int s = t & 3;
-    return s == 0 ? z.z0 : (s == 1 ? z.z1 : (s == 2 ? z.z2 : z.z3));
-}
-MPC_DEV void zm_put(ZmRing &z, int t, unsigned v)
-{
-    const int s = t & 3;
-    if (s == 0) z.z0 = v; else if (s == 1) z.z1 = v; else if (s == 2) z.z2 = v; else z.z3 = v;
-}
-
 template <int MODE>
-MPC_DEV void sweep_all(const P &p, const Lane &L, const Dma &d, SwState &ss, ZmRing &zq)
-{
-    for (int t = p.T - 1; t >= 0; --t) {
-        stage_wait<false>(t < 2 ? t : 2);                // stages t-1, t-2 were issued after this one
-        SwStage s;
-        sw_read<MODE>(s, p, L, t, MODE == 1 ? zm_get(zq, t) : 0u);
-        if (t - 3 >= 0) {
-            // the timesteps the sweep leaves in the ring (0..3) are the rollout's first: fetch f for them
-            stage_issue<false>(p, d, t - 3, t - 3 < NSTAGE);
-            if (MODE != 0 && p.zero_mask) zm_put(zq, t - 3, zm_load(p, L, t - 3));
-        }
-        sweep_step<MODE>(p, L, s, ss, t);
-    }
-}
-
-// One rollout pass.  st.present: timesteps 0 .. present-1 are already in the ring, gain records included.
-template <int MODE>
-MPC_DEV void rollout_all(const P &p, const Lane &L, const Dma &d, RoState &st, ZmRing &zq)
+MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st)
 {
     const int T = p.T;
-    for (int t = 0; t < T; ++t) {
-        const int rest = T - 1 - t;
-        stage_wait<true>(rest < 2 ? rest : 2);           // stages t+1, t+2 may be in flight
-        RoStage s;
-        ro_read<MODE>(s, p, L, t, (MODE != 0 && p.zero_mask) ? zm_get(zq, t) : 0u);
-        // slot (t+3) mod 4 = slot of t-1, already consumed
-        if (t + 3 < T && t + 3 >= st.present) {
-            stage_issue<true>(p, d, t + 3, true);
-            if (MODE != 0 && p.zero_mask) zm_put(zq, t + 3, zm_load(p, L, t + 3));
-        }
-        rollout_step<MODE>(p, L, s, st, t);
+    st.xs = L.isu ? 0.f : p.x_init[(long)L.pb * 12 + L.j];
+    st.cost = 0.f;
+    st.du2 = 0.f;
+    const bool use_zm = MODE != 0 && p.zero_mask != nullptr;
+    unsigned zq[NSTAGE] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ti = i < T ? i : T - 1;
+        stage_issue<true>(p, d, ti, i);
+        if (use_zm) zq[i] = zm_load(p, L, ti);
     }
+    for (int t0 = 0; t0 < T; t0 += NSTAGE) {
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int t = t0 + i;
+            if (t < T) {
+                wv::dma_wait<2 * DMA_ROLL>();
+                RoStage s;
+                ro_read<MODE>(s, p, L, t, i, zq[i]);
+                const int tn = t + 3 < T ? t + 3 : T - 1;
+                stage_issue<true>(p, d, tn, (i + 3) % NSTAGE);
+                if (use_zm) zq[(i + 3) % NSTAGE] = zm_load(p, L, tn);
+                rollout_step<MODE>(p, L, s, st, t);
+            }
+        }
+    }
+    wv::dma_wait<0>();
+    st.cost = wv::row_sum(st.cost);
+    st.du2 = wv::row_sum(st.du2);
 }
 
 template <int MODE>
@@ -560,7 +517,6 @@ MPC_DEV void step_wave(const P &p)
     const int T = p.T;
     Dma d;
     dma_init<MODE>(d, p, L, wave);
-    ZmRing zq = {0u, 0u, 0u, 0u};
 
     // ---- Riccati sweep, t = T-1 .. 0 ------------------------------------------------------------
     SwState ss;
@@ -572,43 +528,42 @@ MPC_DEV void step_wave(const P &p)
     ss.qp_total = 0;
     ss.status = 0;
     ss.kprev[0] = ss.kprev[1] = ss.kprev[2] = ss.kprev[3] = 0.f;
-    for (int i = 0; i < 3; ++i) {
-        const int ti = T - 1 - i;
-        if (ti >= 0) {
-            stage_issue<false>(p, d, ti, ti < NSTAGE);
-            if (MODE != 0 && p.zero_mask) zm_put(zq, ti, zm_load(p, L, ti));
+    {
+        unsigned zq[NSTAGE] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int ti = T - 1 - i >= 0 ? T - 1 - i : 0;
+            stage_issue<false>(p, d, ti, i);
+            if (MODE == 1) zq[i] = zm_load(p, L, ti);
         }
+        for (int k0 = 0; k0 < T; k0 += NSTAGE) {
+#pragma unroll
+            for (int i = 0; i < NSTAGE; ++i) {
+                const int t = T - 1 - (k0 + i);
+                if (t >= 0) {
+                    wv::dma_wait<2 * DMA_SWEEP>();
+                    SwStage s;
+                    sw_read<MODE>(s, p, L, t, i, zq[i]);
+                    const int tn = t - 3 >= 0 ? t - 3 : 0;
+                    stage_issue<false>(p, d, tn, (i + 3) % NSTAGE);
+                    if (MODE == 1) zq[(i + 3) % NSTAGE] = zm_load(p, L, tn);
+                    sweep_step<MODE>(p, L, s, ss, t);
+                }
+            }
+        }
+        wv::dma_wait<0>();
     }
-    sweep_all<MODE>(p, L, d, ss, zq);
     const float old_cost = wv::row_sum(ss.oc);
+
     // the gains were written by this wave and are re-read through the DMA: drain the stores
     wv::fence_own_stores();
 
     // ---- line-searched rollout (mpc/lqr_step.py:164-261): every row backtracks on its own ------
     RoState rs;
     rs.alpha = 1.f;
-    rs.present = T < NSTAGE ? T : NSTAGE;     // timesteps 0 .. present-1 are in the ring after the sweep
     float full2 = 0.f;
     for (int pass = 0; pass < p.max_ls; ++pass) {
-        rs.xs = L.isu ? 0.f : p.x_init[(long)L.pb * 12 + L.j];
-        rs.cost = 0.f;
-        rs.du2 = 0.f;
-        if (pass == 0) {
-            // the ring still holds timesteps 0 .. present-1 from the sweep: only their gains are missing
-            for (int ti = 0; ti < rs.present; ++ti) gains_issue(p, d, ti);
-            wv::dma_wait<0>();
-        } else {
-            // a repeated pass starts from a ring that holds the END of the horizon: refill its head
-            for (int ti = 0; ti < 3 && ti < T; ++ti) {
-                stage_issue<true>(p, d, ti, true);
-                if (MODE != 0 && p.zero_mask) zm_put(zq, ti, zm_load(p, L, ti));
-            }
-            rs.present = T < 3 ? T : 3;
-        }
-        rollout_all<MODE>(p, L, d, rs, zq);
-        wv::dma_wait<0>();
-        rs.cost = wv::row_sum(rs.cost);
-        rs.du2 = wv::row_sum(rs.du2);
+        rollout_pass<MODE>(p, L, d, rs);
         if (pass == 0) full2 = rs.du2;                               // :243-245
         // :176-179, 247, 252: shrink while this problem's cost got worse
         const bool worse = rs.cost > old_cost && pass + 1 < p.max_ls;
