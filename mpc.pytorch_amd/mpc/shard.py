@@ -1,0 +1,74 @@
+"""Batch sharding of the LQR step over the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+Every tensor of the problem carries the batch as its 2nd axis (1st for x_init) and no arithmetic
+mixes problems, so rank r of R simply owns a contiguous block of problems: it solves its block with
+the local kernels (no data-path collective) and ONE all-gather reassembles the trajectories
+(new_x || new_u, plus the per-problem scalars).  Gradients (dC, dF, ...) stay sharded like their
+inputs.  The three batch-global loops of the reference (line search, pnqp, outer iLQR stop test --
+SURVEY.md section 8e) are per-problem in the kernels, so shards never need to agree on a trip count.
+"""
+import torch
+
+from . import _native
+
+
+def shard_bounds(n_batch, rank, world):
+    """[lo, hi) of the problems rank `rank` of `world` owns: blocks as even as possible, in order."""
+    base, extra = divmod(n_batch, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _cut(t, lo, hi, dim):
+    if t is None or not torch.is_tensor(t) or t.numel() == 0:
+        return t
+    return t.narrow(dim, lo, hi - lo)
+
+
+def shard_options(opts, lo, hi):
+    """The StepOptions of a block of problems: tensor bounds / masks are cut along the batch axis."""
+    return _native.StepOptions(u_lower=_cut(opts.u_lower, lo, hi, 1), u_upper=_cut(opts.u_upper, lo, hi, 1),
+                               u_zero_I=_cut(opts.u_zero_I, lo, hi, 1), delta_u=opts.delta_u,
+                               linesearch_decay=opts.linesearch_decay,
+                               max_linesearch_iter=opts.max_linesearch_iter, pnqp_iter=opts.pnqp_iter)
+
+
+def all_gather_batch(t, n_batch, dim, group=None):
+    """All-gather blocks of unequal size along `dim` (blocks are padded to the largest one on the wire)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = [b - a for a, b in (shard_bounds(n_batch, r, world) for r in range(world))]
+    m = max(sizes)
+    t = t.movedim(dim, 0).contiguous()
+    if t.shape[0] < m:
+        t = torch.cat((t, t.new_zeros((m - t.shape[0],) + tuple(t.shape[1:]))))
+    out = t.new_empty((world * m,) + tuple(t.shape[1:]))
+    dist.all_gather_into_tensor(out, t, group=group)
+    out = torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)])
+    return out.movedim(0, dim)
+
+
+def lqr_step_sharded(x_init, C, c, F, f, cur_x, cur_u, opts, group=None, gather=True, impl=_native.IMPL_AUTO):
+    """One LQR step on this rank's block of the batch; with `gather`, every rank returns the full
+    (new_x, new_u, costs, full_du_norm, alphas) after one all-gather of the trajectories.
+
+    All ranks pass the SAME full-batch tensors (or views of them); only the local block is read."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B = C.shape[1]
+    lo, hi = shard_bounds(B, rank, world)
+    r = _native.backend().lqr_step(_cut(x_init, lo, hi, 0), _cut(C, lo, hi, 1), _cut(c, lo, hi, 1),
+                                   _cut(F, lo, hi, 1), _cut(f, lo, hi, 1), _cut(cur_x, lo, hi, 1),
+                                   _cut(cur_u, lo, hi, 1), shard_options(opts, lo, hi), impl=impl)
+    if world == 1 or not gather:
+        return r
+    # ONE collective: trajectories and the per-problem scalars ride in the same buffer
+    T = C.shape[0]
+    tau = torch.cat((r["new_x"], r["new_u"]), 2)                                       # [T, b, n]
+    scal = torch.stack((r["costs"], r["full_du_norm"], r["alphas"]), 1).t().unsqueeze(2)  # [3, b, 1]
+    scal = scal.expand(3, hi - lo, tau.shape[2]).contiguous()
+    packed = all_gather_batch(torch.cat((tau, scal), 0), B, 1, group)                   # [T+3, B, n]
+    ns = r["new_x"].shape[2]
+    return dict(new_x=packed[:T, :, :ns], new_u=packed[:T, :, ns:], costs=packed[T, :, 0],
+                full_du_norm=packed[T + 1, :, 0], alphas=packed[T + 2, :, 0], local=r, block=(lo, hi))

@@ -1,0 +1,75 @@
+"""The N > 1 path on CPU: two processes over gloo, each solving its block of the batch (through the
+oracle-backed test backend -- there is no GPU here) and one all-gather reassembling the trajectories.
+On the GPU box bench.py runs the same code over RCCL with the HIP backend."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, B, out_dir):
+    for p in (os.path.join(ROOT, "mpc.pytorch_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from mpc import _native, shard
+    from mpc._native import StepOptions
+    from oracle_backend import OracleBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _native.set_backend_for_testing(OracleBackend())
+    g = torch.Generator().manual_seed(0)
+    T, ns, nc = 6, 4, 2
+    n = ns + nc
+    A = torch.randn(T, B, n, n, generator=g, dtype=torch.float64)
+    C = A.transpose(2, 3).matmul(A)
+    c = torch.randn(T, B, n, generator=g, dtype=torch.float64)
+    F = torch.cat((torch.eye(ns).double() + 0.1 * torch.randn(T - 1, B, ns, ns, generator=g, dtype=torch.float64),
+                   torch.randn(T - 1, B, ns, nc, generator=g, dtype=torch.float64)), 3)
+    f = 0.1 * torch.randn(T - 1, B, ns, generator=g, dtype=torch.float64)
+    x_init = torch.randn(B, ns, generator=g, dtype=torch.float64)
+    cur_u = torch.zeros(T, B, nc, dtype=torch.float64)
+    lo = -torch.rand(T, B, nc, generator=g, dtype=torch.float64)
+    hi = torch.rand(T, B, nc, generator=g, dtype=torch.float64)
+    from mpc import util
+    from mpc.mpc import LinDx
+    cur_x = util.get_traj(T, cur_u, x_init, LinDx(F, f))
+    opts = StepOptions(u_lower=lo, u_upper=hi)
+    r = shard.lqr_step_sharded(x_init, C, c, F, f, cur_x, cur_u, opts)
+    ref = _native.backend().lqr_step(x_init, C, c, F, f, cur_x, cur_u, opts)      # the whole batch, locally
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), block=np.array(r["block"]),
+             **{k: r[k].numpy() for k in ("new_x", "new_u", "costs", "full_du_norm", "alphas")},
+             **{"ref_" + k: ref[k].numpy() for k in ("new_x", "new_u", "costs", "full_du_norm", "alphas")})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [8, 5])
+def test_two_ranks_shard_the_batch_and_gather_once(tmp_path, B):
+    """B = 5 leaves the ranks with blocks of 3 and 2 problems: the gather pads on the wire only."""
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + B
+    mp.spawn(_worker, args=(world, port, B, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    blocks = [tuple(g["block"]) for g in got]
+    assert blocks[0][0] == 0 and blocks[0][1] == blocks[1][0] and blocks[1][1] == B
+    for g in got:
+        for k in ("new_x", "new_u", "costs", "full_du_norm", "alphas"):
+            np.testing.assert_allclose(g[k], g["ref_" + k], rtol=1e-12, atol=1e-12, err_msg=k)
+
+
+def test_shard_bounds_cover_the_batch():
+    sys.path.insert(0, os.path.join(ROOT, "mpc.pytorch_amd"))
+    from mpc import shard
+    for B in (1, 7, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            cuts = [shard.shard_bounds(B, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == B
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
