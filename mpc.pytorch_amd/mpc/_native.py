@@ -277,10 +277,12 @@ class HipBackend:
         res["_keep"] = (keep, keep_o, ws)
         return res
 
-    def plan_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, impl=IMPL_AUTO):
+    def plan_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, impl=IMPL_AUTO, out_x=None, out_u=None,
+                  workspace=None):
         """Pre-bind one LQR step: argument structs and output buffers are built once, `plan()` is
         then a single C call (no allocation, hipGraph-capturable).  Outputs are overwritten by
-        every call -- clone what must survive."""
+        every call -- clone what must survive.  out_x / out_u: write the new trajectory into these
+        (contiguous) tensors, e.g. the nominal buffers of the NEXT iteration's plan."""
         dev = _require_device(x_init, C, c, F, cur_x, cur_u)
         self._check_same(C, x_init, c, F, f, cur_x, cur_u)
         L = load()
@@ -290,17 +292,20 @@ class HipBackend:
         p, keep = self._problem(x_init, C, c, F, f, cur_x, cur_u)
         o, keep_o = opts.to_struct(T, B, nc, C)
         kw = dict(device=dev, dtype=C.dtype)
-        res = dict(new_x=torch.empty(T, B, ns, **kw), new_u=torch.empty(T, B, nc, **kw),
+        res = dict(new_x=torch.empty(T, B, ns, **kw) if out_x is None else out_x,
+                   new_u=torch.empty(T, B, nc, **kw) if out_u is None else out_u,
                    costs=torch.empty(B, **kw), old_costs=torch.empty(B, **kw),
                    full_du_norm=torch.empty(B, **kw), alpha_du_norm=torch.empty(B, **kw),
                    alphas=torch.empty(B, **kw),
                    qp_iters=torch.zeros(B, device=dev, dtype=torch.int32),
                    status=torch.zeros(B, device=dev, dtype=torch.int32))
+        assert res["new_x"].is_contiguous() and res["new_u"].is_contiguous()
         out = Outputs()
         for k in res:
             setattr(out, k, res[k].data_ptr())
         nbytes = int(L.mpc_lqr_workspace_bytes(ctypes.byref(p)))
-        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8) if workspace is None else workspace
+        assert ws.numel() >= nbytes
         pp, op, up, wp = ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), ws.data_ptr()
         fn = L.mpc_lqr_step
         impl = int(impl)

@@ -125,9 +125,14 @@ class MPC(Module):
         best = None
         n_not_improved = 0
         be = _native.backend()
+        plans = None
         for i in range(self.lqr_iter):
             u = util.detach_maybe(u)
-            x = util.get_traj(T, u, x_init=x_init, dynamics=dx)
+            if fast and plans is not None:
+                # LinDx: the states of the last rollout ARE get_traj(u) (mpc/mpc.py:251 recomputes them)
+                pass
+            else:
+                x = util.get_traj(T, u, x_init=x_init, dynamics=dx)
             if isinstance(dx, LinDx):
                 F, f = dx.F, dx.f
             else:
@@ -138,9 +143,18 @@ class MPC(Module):
                 C, c, _ = self.approximate_cost(x, util.detach_maybe(u), cost, diff=False)
 
             if fast:
-                # inner iterations are never differentiated (the reference detaches them too):
-                # call the kernel directly, no autograd node, no host-side tuple unpacking.
-                r = be.lqr_step(util.detach_maybe(x_init), C, c, F, f, x, u, self._step_options())
+                # inner iterations are never differentiated (the reference detaches them too): two
+                # pre-bound plans ping-pong the nominal between two buffers, so an iteration is one
+                # C call (no allocation, no autograd node, no host-side unpacking)
+                if plans is None:
+                    xa, ua = x.detach().contiguous(), u.detach().contiguous()
+                    xb, ub = torch.empty_like(xa), torch.empty_like(ua)
+                    xi, opts = util.detach_maybe(x_init), self._step_options()
+                    pa = be.plan_step(xi, C, c, F, f, xa, ua, opts, out_x=xb, out_u=ub)
+                    pb = be.plan_step(xi, C, c, F, f, xb, ub, opts, out_x=xa, out_u=ua,
+                                      workspace=pa._keep[-1] if hasattr(pa, "_keep") else None)
+                    plans = (pa, pb)
+                r = plans[i % 2]()
                 x, u, costs, full_du_norm = r["new_x"], r["new_u"], r["costs"], r["full_du_norm"]
                 qp_iters, alphas = r["qp_iters"], r["alphas"]
             else:

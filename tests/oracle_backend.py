@@ -49,6 +49,15 @@ class OracleBackend:
         res["status"] = torch.zeros(B, dtype=torch.int32)
         return res
 
+    def plan_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, impl=0, out_x=None, out_u=None, workspace=None):
+        def run():
+            r = self.lqr_step(x_init, C, c, F, f, cur_x, cur_u, opts)
+            if out_x is not None:
+                out_x.copy_(r["new_x"]); out_u.copy_(r["new_u"])
+                r["new_x"], r["new_u"] = out_x, out_u
+            return r
+        return run
+
     def lqr_sweep(self, x_init, C, c, F, cur_x, cur_u, opts):
         self.calls.append("lqr_sweep")
         r = self.lqr_step(x_init, C, c, F, None, cur_x, cur_u, opts, want_gains=True)
