@@ -203,7 +203,7 @@ bool dpp16_supported(const StepParams<float> &p)
 {
     // 16-byte DMA granules: every block the kernel streams must start on a 16-byte boundary
     auto al = [](const void *q, long st, long sb) { return ((uintptr_t)q % 16 == 0) && (st % 4 == 0) && (sb % 4 == 0); };
-    if (!(p.ns == 12 && p.nc == 4 && p.T >= 1 && p.max_ls >= 1)) return false;
+    if (!(p.ns == 12 && p.nc == 4 && p.T >= 1 && p.max_ls >= 1 && p.max_ls <= 16)) return false;
     if (!al(p.C, p.C_st, p.C_sb) || !al(p.c, p.c_st, p.c_sb)) return false;
     if (p.T > 1 && !al(p.F, p.F_st, p.F_sb)) return false;
     if (p.f && !al(p.f, p.f_st, p.f_sb)) return false;

@@ -431,16 +431,16 @@ struct RoState {
     float alpha;      // line-search step of this row's problem
 };
 
+// new_u = K dx + u + alpha k (mpc/lqr_step.py:192), zero mask (:197-198), box / delta_u clamp (:200-213);
+// control lanes hold row a of K
 template <int MODE>
-MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &st, int t)
+MPC_DEV float control_law(const P &p, const Lane &L, const RoStage &s, float xs, float alpha)
 {
-    const bool last = (t == p.T - 1);
-    // new_u = K dx + u + alpha k   (mpc/lqr_step.py:192); control lanes hold row a of K
-    const float dx = L.isu ? 0.f : st.xs - s.tb;
-    float un = fmaf(st.alpha, s.kk, s.tb);
+    const float dx = L.isu ? 0.f : xs - s.tb;
+    float un = fmaf(alpha, s.kk, s.tb);
     wv::dot_bcast12(un, dx, s.Kr);
-    if (MODE != 0 && s.zm) un = 0.f;                                 // :197-198
-    if (MODE == 2) {                                                 // :200-213
+    if (MODE != 0 && s.zm) un = 0.f;
+    if (MODE == 2) {
         float l = s.lo, h = s.hi;
         if (p.has_delta) {
             const float l2 = s.tb - p.delta_u, h2 = s.tb + p.delta_u;
@@ -449,6 +449,14 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
         }
         un = eclampf(un, l, h);
     }
+    return un;
+}
+
+template <int MODE>
+MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &st, int t)
+{
+    const bool last = (t == p.T - 1);
+    const float un = control_law<MODE>(p, L, s, st.xs, st.alpha);
     const float tp = L.isu ? un : st.xs;                             // tau'_t[j]
     // obj_t = 0.5 tau'C tau + c'tau   (:230-232)
     float sq = 0.f;
@@ -471,13 +479,50 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
     }
 }
 
+// The line-search trials alpha = decay^k, k = 1 .. nt, rolled out side by side off ONE pass over
+// C, F, K (the data is read from LDS once per timestep, every trial has its own state register):
+// only the costs come out; the accepted trial is replayed by a storing pass.
+enum { MAX_TRIALS = 15 };
+struct Trials {
+    float xs[MAX_TRIALS], cost[MAX_TRIALS], alpha[MAX_TRIALS];
+};
+
 template <int MODE>
-MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st)
+MPC_DEV void trials_step(const P &p, const Lane &L, const RoStage &s, Trials &tr, int nt, int t)
+{
+    const bool last = (t == p.T - 1);
+#pragma unroll
+    for (int k = 0; k < MAX_TRIALS; ++k) {
+        if (k < nt) {
+            const float un = control_law<MODE>(p, L, s, tr.xs[k], tr.alpha[k]);
+            const float tp = L.isu ? un : tr.xs[k];
+            float sq = 0.f;
+            wv::dot_bcast16(sq, tp, s.Cr);
+            tr.cost[k] = fmaf(tp, fmaf(0.5f, sq, s.cj), tr.cost[k]);
+            if (!last) {
+                float xn = s.fj;
+                wv::dot_bcast16(xn, tp, s.Fr);
+                tr.xs[k] = xn;
+            }
+        }
+    }
+}
+
+// One pass over the horizon.  tr == nullptr: the single trial of `st` (trajectory stored);
+// otherwise the nt trials of *tr (costs only).
+template <int MODE, bool MULTI>
+MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st, Trials &tr, int nt)
 {
     const int T = p.T;
-    st.xs = L.isu ? 0.f : p.x_init[(long)L.pb * 12 + L.j];
-    st.cost = 0.f;
-    st.du2 = 0.f;
+    const float x0 = L.isu ? 0.f : p.x_init[(long)L.pb * 12 + L.j];
+    if (MULTI) {
+#pragma unroll
+        for (int k = 0; k < MAX_TRIALS; ++k) { tr.xs[k] = x0; tr.cost[k] = 0.f; }
+    } else {
+        st.xs = x0;
+        st.cost = 0.f;
+        st.du2 = 0.f;
+    }
     const bool use_zm = MODE != 0 && p.zero_mask != nullptr;
     unsigned zq[NSTAGE] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -497,13 +542,20 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st)
                 const int tn = t + 3 < T ? t + 3 : T - 1;
                 stage_issue<true>(p, d, tn, (i + 3) % NSTAGE);
                 if (use_zm) zq[(i + 3) % NSTAGE] = zm_load(p, L, tn);
-                rollout_step<MODE>(p, L, s, st, t);
+                if (MULTI) trials_step<MODE>(p, L, s, tr, nt, t);
+                else rollout_step<MODE>(p, L, s, st, t);
             }
         }
     }
     wv::dma_wait<0>();
-    st.cost = wv::row_sum(st.cost);
-    st.du2 = wv::row_sum(st.du2);
+    if (MULTI) {
+#pragma unroll
+        for (int k = 0; k < MAX_TRIALS; ++k)
+            if (k < nt) tr.cost[k] = wv::row_sum(tr.cost[k]);
+    } else {
+        st.cost = wv::row_sum(st.cost);
+        st.du2 = wv::row_sum(st.du2);
+    }
 }
 
 template <int MODE>
@@ -560,15 +612,33 @@ MPC_DEV void step_wave(const P &p)
 
     // ---- line-searched rollout (mpc/lqr_step.py:164-261): every row backtracks on its own ------
     RoState rs;
+    Trials tr;
     rs.alpha = 1.f;
-    float full2 = 0.f;
-    for (int pass = 0; pass < p.max_ls; ++pass) {
-        rollout_pass<MODE>(p, L, d, rs);
-        if (pass == 0) full2 = rs.du2;                               // :243-245
-        // :176-179, 247, 252: shrink while this problem's cost got worse
-        const bool worse = rs.cost > old_cost && pass + 1 < p.max_ls;
-        if (worse) rs.alpha *= p.ls_decay;
-        if (!wv::any(worse)) break;
+    rollout_pass<MODE, false>(p, L, d, rs, tr, 0);
+    const float full2 = rs.du2;                                      // :243-245 (the alpha = 1 trial)
+    // :176-179, 247, 252: the step shrinks while the cost got worse; the first trial that did not get
+    // worse is taken, else the last one
+    const bool worse = rs.cost > old_cost && p.max_ls > 1;
+    if (wv::any(worse)) {
+        const int nt = p.max_ls - 1;
+        float a = 1.f;
+#pragma unroll
+        for (int k = 0; k < MAX_TRIALS; ++k) { a *= p.ls_decay; tr.alpha[k] = a; }
+        rollout_pass<MODE, true>(p, L, d, rs, tr, nt);
+        if (worse) {
+            float acc = tr.alpha[0];
+            bool found = false;
+#pragma unroll
+            for (int k = 0; k < MAX_TRIALS; ++k) {
+                if (k < nt && !found) {
+                    acc = tr.alpha[k];
+                    if (!(tr.cost[k] > old_cost)) found = true;
+                }
+            }
+            rs.alpha = acc;
+        }
+        // replay: rows that keep alpha = 1 reproduce what they already stored
+        rollout_pass<MODE, false>(p, L, d, rs, tr, 0);
     }
     int status = ss.status;
     if (!(rs.cost == rs.cost) || fabsf(rs.cost) > 3e38f) status |= MPC_ST_NONFINITE;

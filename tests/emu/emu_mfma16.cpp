@@ -342,7 +342,7 @@ extern "C" int emu_lqr_step_dpp16(const mpc_lqr_problem *p, const mpc_lqr_option
 {
     if (p->dtype != MPC_F32) return MPC_E_DTYPE;
     mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, out);
-    if (!(sp.ns == 12 && sp.nc == 4 && sp.max_ls >= 1)) return MPC_E_DIMS;
+    if (!(sp.ns == 12 && sp.nc == 4 && sp.max_ls >= 1 && sp.max_ls <= 16)) return MPC_E_DIMS;
     if (!sp.new_x || !sp.new_u) return MPC_E_NULL;
     static float *kk_buf = nullptr;
     static size_t kk_cap = 0;
