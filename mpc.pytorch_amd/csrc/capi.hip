@@ -175,6 +175,11 @@ int mpc_lqr_kkt_grads(const mpc_lqr_problem *p, const void *dx, const void *du, 
     hipStream_t st = (hipStream_t)stream;
     if (p->dtype == MPC_F32) {
         StepParams<float> sp = make_params<float>(p, nullptr, nullptr);
+        // headline shape: the 4-problems-per-wave DPP kernel (lqr_dpp16_body.h: kkt_wave)
+        if (kkt_dpp16_supported(sp, (const float *)dx, (const float *)du, (const float *)dl_dx, (const float *)dC,
+                                (const float *)dF))
+            return launch_kkt_dpp16(sp, (const float *)dx, (const float *)du, (const float *)dl_dx, (float *)dC,
+                                    (float *)dc, (float *)dF, (float *)df, (float *)dx_init, st);
         return launch_kkt_grads<float>(sp, (const float *)dx, (const float *)du, (const float *)dl_dx,
                                        (const float *)dl_du, (float *)dC, (float *)dc, (float *)dF, (float *)df,
                                        (float *)dx_init, st);

@@ -38,6 +38,10 @@ size_t generic_lds_bytes(int ns, int nc, size_t elem);
 // 4-problems-per-wave DPP path for n_state = 12, n_ctrl = 4, f32 (lqr_dpp16.hip)
 bool dpp16_supported(const StepParams<float> &p);
 int launch_step_dpp16(const StepParams<float> &p, hipStream_t st);
+bool kkt_dpp16_supported(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx,
+                         const float *dC, const float *dF);
+int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,
+                     float *dc, float *dF, float *df, float *dx_init, hipStream_t st);
 
 // fused MFMA path for n <= 16, f32 (lqr_mfma16.hip)
 bool mfma16_supported(const StepParams<float> &p);

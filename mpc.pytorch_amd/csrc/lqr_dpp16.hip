@@ -79,6 +79,30 @@ MPC_DEV void fma_bcast_each16(float (&a)[16], float src, float mul)
           "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
         : "v"(src), "v"(mul));
 }
+// a[i] = bcast_i(src) * mul
+MPC_DEV void mul_bcast_each16(float (&a)[16], float src, float mul)
+{
+    asm("s_nop 1\n"
+        "v_mul_f32_dpp %0, %16, %17 row_newbcast:0" DPPM
+        "v_mul_f32_dpp %1, %16, %17 row_newbcast:1" DPPM
+        "v_mul_f32_dpp %2, %16, %17 row_newbcast:2" DPPM
+        "v_mul_f32_dpp %3, %16, %17 row_newbcast:3" DPPM
+        "v_mul_f32_dpp %4, %16, %17 row_newbcast:4" DPPM
+        "v_mul_f32_dpp %5, %16, %17 row_newbcast:5" DPPM
+        "v_mul_f32_dpp %6, %16, %17 row_newbcast:6" DPPM
+        "v_mul_f32_dpp %7, %16, %17 row_newbcast:7" DPPM
+        "v_mul_f32_dpp %8, %16, %17 row_newbcast:8" DPPM
+        "v_mul_f32_dpp %9, %16, %17 row_newbcast:9" DPPM
+        "v_mul_f32_dpp %10, %16, %17 row_newbcast:10" DPPM
+        "v_mul_f32_dpp %11, %16, %17 row_newbcast:11" DPPM
+        "v_mul_f32_dpp %12, %16, %17 row_newbcast:12" DPPM
+        "v_mul_f32_dpp %13, %16, %17 row_newbcast:13" DPPM
+        "v_mul_f32_dpp %14, %16, %17 row_newbcast:14" DPPM
+        "v_mul_f32_dpp %15, %16, %17 row_newbcast:15" DPPM
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
+          "=&v"(a[8]), "=&v"(a[9]), "=&v"(a[10]), "=&v"(a[11]), "=&v"(a[12]), "=&v"(a[13]), "=&v"(a[14]), "=&v"(a[15])
+        : "v"(src), "v"(mul));
+}
 MPC_DEV void fma_bcast_each12(float (&a)[12], float src, float mul)
 {
     asm("s_nop 1\n"
@@ -197,7 +221,40 @@ __global__ void __launch_bounds__(64, 1) lqr_step_dpp16_kernel(StepParams<float>
     dpp16::step_wave<MODE>(p);
 }
 
+__global__ void __launch_bounds__(64, 1) lqr_kkt_dpp16_kernel(StepParams<float> p, dpp16::KktArgs k)
+{
+    dpp16::kkt_wave(p, k);
+}
+
 }  // namespace
+
+bool kkt_dpp16_supported(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx,
+                         const float *dC, const float *dF)
+{
+    auto al = [](const void *q, long st, long sb) { return ((uintptr_t)q % 16 == 0) && (st % 4 == 0) && (sb % 4 == 0); };
+    if (!(p.ns == 12 && p.nc == 4 && p.T >= 1)) return false;
+    if (!al(p.C, p.C_st, p.C_sb) || !al(p.c, p.c_st, p.c_sb)) return false;
+    if (p.T > 1 && !al(p.F, p.F_st, p.F_sb)) return false;
+    return al(p.cur_x, 0, 0) && al(p.cur_u, 0, 0) && al(dx, 0, 0) && al(du, 0, 0) && al(dl_dx, 0, 0) && al(dC, 0, 0) &&
+           (p.T == 1 || al(dF, 0, 0));
+}
+
+int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,
+                     float *dc, float *dF, float *df, float *dx_init, hipStream_t st)
+{
+    dpp16::KktArgs k;
+    k.dx = dx; k.du = du; k.dl_dx = dl_dx; k.dC = dC; k.dc = dc; k.dF = dF; k.df = df; k.dx_init = dx_init;
+    hipLaunchKernelGGL(lqr_kkt_dpp16_kernel, dim3((p.B + 3) / 4), dim3(64), 0, st, p, k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error((std::string("lqr_kkt_dpp16_kernel: ") + hipGetErrorString(e)).c_str());
+        return MPC_E_LAUNCH;
+    }
+    return MPC_OK;
+}
+
+namespace {
+}
 
 bool dpp16_supported(const StepParams<float> &p)
 {

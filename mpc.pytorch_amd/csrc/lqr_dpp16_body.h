@@ -618,27 +618,33 @@ MPC_DEV void step_wave(const P &p)
     const float full2 = rs.du2;                                      // :243-245 (the alpha = 1 trial)
     // :176-179, 247, 252: the step shrinks while the cost got worse; the first trial that did not get
     // worse is taken, else the last one
-    const bool worse = rs.cost > old_cost && p.max_ls > 1;
-    if (wv::any(worse)) {
-        const int nt = p.max_ls - 1;
-        float a = 1.f;
+    // Backtracking is usually one step deep (box-constrained problems) or runs to the end (a nominal
+    // that is already optimal): try alpha = decay on its own first, then ALL remaining trials at once.
+    const bool worse0 = rs.cost > old_cost && p.max_ls > 1;
+    if (wv::any(worse0)) {
+        if (worse0) rs.alpha = p.ls_decay;
+        rollout_pass<MODE, false>(p, L, d, rs, tr, 0);          // rows that keep alpha = 1 reproduce their result
+        const bool worse1 = worse0 && rs.cost > old_cost && p.max_ls > 2;
+        if (wv::any(worse1)) {
+            const int nt = p.max_ls - 2;                          // trials alpha = decay^2 .. decay^(max_ls-1)
+            float a = p.ls_decay;
 #pragma unroll
-        for (int k = 0; k < MAX_TRIALS; ++k) { a *= p.ls_decay; tr.alpha[k] = a; }
-        rollout_pass<MODE, true>(p, L, d, rs, tr, nt);
-        if (worse) {
-            float acc = tr.alpha[0];
-            bool found = false;
+            for (int k = 0; k < MAX_TRIALS; ++k) { a *= p.ls_decay; tr.alpha[k] = a; }
+            rollout_pass<MODE, true>(p, L, d, rs, tr, nt);
+            if (worse1) {
+                float acc = tr.alpha[0];
+                bool found = false;
 #pragma unroll
-            for (int k = 0; k < MAX_TRIALS; ++k) {
-                if (k < nt && !found) {
-                    acc = tr.alpha[k];
-                    if (!(tr.cost[k] > old_cost)) found = true;
+                for (int k = 0; k < MAX_TRIALS; ++k) {
+                    if (k < nt && !found) {
+                        acc = tr.alpha[k];
+                        if (!(tr.cost[k] > old_cost)) found = true;
+                    }
                 }
+                rs.alpha = acc;
             }
-            rs.alpha = acc;
+            rollout_pass<MODE, false>(p, L, d, rs, tr, 0);      // replay the accepted trials
         }
-        // replay: rows that keep alpha = 1 reproduce what they already stored
-        rollout_pass<MODE, false>(p, L, d, rs, tr, 0);
     }
     int status = ss.status;
     if (!(rs.cost == rs.cost) || fabsf(rs.cost) > 3e38f) status |= MPC_ST_NONFINITE;
@@ -652,6 +658,163 @@ MPC_DEV void step_wave(const P &p)
         if (p.qp_iters) p.qp_iters[b] = ss.qp_total;
         if (p.status) p.status[b] = status;
     }
+}
+
+
+// ---------------------------------------------------------------------------
+// KKT backward, closed-form part (mpc/lqr_step.py:346-404) in the same 4-problems-per-wave layout:
+// given the solution tau* = (x*, u*) and the KKT solve's dtau = (dx, du) [= the LQR step on (C, -r, F)
+// with the active controls pinned, :328-340], one backward pass over t emits
+//   dC_t = -0.5 (dtau tau' + tau dtau'),  dc_t = -dtau                                 (:346-353)
+//   lambda_t  = Cxx x + Cxu u + c_x + F_x' lambda_{t+1}                               (:355-369)
+//   dlambda_t = Cxx dx + Cxu du - r_x + F_x' dlambda_{t+1}                            (:371-385)
+//   dF_t = -(dlambda_{t+1} tau' + lambda_{t+1} dtau'),  df_t = -dlambda_{t+1}          (:387-400)
+//   dx_init = -dlambda_0                                                               (:404)
+// Lane j computes ROW j of dC (symmetric) and, j < 12, row j of dF: 64 contiguous bytes per lane.
+// HBM-bound: 3,952 B per problem-step in and out (C, F read once; dC, dF written once).
+// ---------------------------------------------------------------------------
+struct KktArgs {
+    const float *dx, *du, *dl_dx;
+    float *dC, *dc, *dF, *df, *dx_init;
+};
+
+enum { K_c = 0, K_tau = 64, K_dtau = 128, K_rx = 192, KKT_STAGE = 8192, DMA_KKT = 8 };
+
+struct KktDma {
+    const char *c_ptr[4];
+    const char *f_ptr[3];
+    const char *r_ptr;
+    long c_step, f_step, r_step;
+    bool r_active;
+};
+
+MPC_DEV void kkt_dma_init(KktDma &d, const P &p, const KktArgs &k, const Lane &L, int wave)
+{
+    const long B = p.B;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int pbk = 4 * wave + q < p.B ? 4 * wave + q : p.B - 1;
+        d.c_ptr[q] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * L.lane;
+    }
+    d.c_step = 4 * p.C_st;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int G = 64 * q + L.lane;
+        const int slot = G / 48, gi = G - 48 * slot;
+        const int pbk = 4 * wave + slot < p.B ? 4 * wave + slot : p.B - 1;
+        d.f_ptr[q] = p.T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) + 16 * gi : (const char *)p.C;
+    }
+    d.f_step = 4 * p.F_st;
+    // record granules: 0-3 c | 4-6 x* | 7 u* | 8-10 dx | 11 du | 12-14 dl_dx
+    const int gi = L.lane & 15;
+    const long pb = L.pb;
+    d.r_active = gi < 15;
+    const char *q = (const char *)p.c;
+    long st = 0;
+    if (gi < 4) { q = (const char *)(p.c + pb * p.c_sb + 4 * gi); st = 4 * p.c_st; }
+    else if (gi < 7) { q = (const char *)(p.cur_x + pb * 12 + 4 * (gi - 4)); st = 4 * B * 12; }
+    else if (gi == 7) { q = (const char *)(p.cur_u + pb * 4); st = 4 * B * 4; }
+    else if (gi < 11) { q = (const char *)(k.dx + pb * 12 + 4 * (gi - 8)); st = 4 * B * 12; }
+    else if (gi == 11) { q = (const char *)(k.du + pb * 4); st = 4 * B * 4; }
+    else if (gi < 15) { q = (const char *)(k.dl_dx + pb * 12 + 4 * (gi - 12)); st = 4 * B * 12; }
+    d.r_ptr = q;
+    d.r_step = st;
+}
+
+MPC_DEV void kkt_stage_issue(const P &p, const KktDma &d, int t, int slot)
+{
+    const unsigned base = (unsigned)slot * KKT_STAGE;
+    const long tl = t;
+    const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wv::dma16(d.c_ptr[q] + tl * d.c_step, base + SC + 1024 * q);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) wv::dma16(d.f_ptr[q] + (p.T > 1 ? tf * d.f_step : 0), base + SF + 1024 * q);
+    wv::dma16_if(d.r_active, d.r_ptr + tl * d.r_step, base + SR);
+}
+
+MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
+{
+    const int lane = wv::lane();
+    const int wave = wv::problem();
+    if (4 * wave >= p.B) return;
+    Lane L;
+    lane_init(L, lane, wave, p.B);
+    const int T = p.T;
+    KktDma d;
+    kkt_dma_init(d, p, k, L, wave);
+    float lam = 0.f, dlam = 0.f;          // lambda_{t+1}[j], dlambda_{t+1}[j]  (state lanes)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) kkt_stage_issue(p, d, T - 1 - i >= 0 ? T - 1 - i : 0, i);
+    for (int k0 = 0; k0 < T; k0 += NSTAGE) {
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int t = T - 1 - (k0 + i);
+            if (t >= 0) {
+                wv::dma_wait<2 * DMA_KKT>();
+                const unsigned base = (unsigned)i * KKT_STAGE;
+                float Cr[16], Fc[12];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = wv::lds_f32x4(base + L.aCrow + 16 * q);
+                    Cr[4 * q] = v[0]; Cr[4 * q + 1] = v[1]; Cr[4 * q + 2] = v[2]; Cr[4 * q + 3] = v[3];
+                }
+                const bool have = t < T - 1;
+                if (have) {
+#pragma unroll
+                    for (int m = 0; m < 12; ++m) Fc[m] = wv::lds_f32(base + L.aFcol + 64 * m);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 12; ++m) Fc[m] = 0.f;
+                }
+                const float cj = wv::lds_f32(base + L.aRec + K_c);
+                const float tj = wv::lds_f32(base + L.aRec + K_tau);
+                const float dj = wv::lds_f32(base + L.aRec + K_dtau);
+                const float rj = wv::lds_f32(base + SR + L.p * 256 + K_rx + 4 * (L.j < 12 ? L.j : 11));
+                kkt_stage_issue(p, d, t - 3 >= 0 ? t - 3 : 0, (i + 3) % NSTAGE);
+
+                const long tb = (long)t * p.B + L.pb;
+                // dF_t, df_t from the costates of t+1
+                if (have) {
+                    float row[16];
+                    wv::mul_bcast_each16(row, tj, -dlam);
+                    wv::fma_bcast_each16(row, dj, -lam);
+                    if (L.live && L.j < 12) {
+                        float *dst = k.dF + (tb * 12 + L.j) * 16;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            wv::store_f32x4(dst + 4 * q, f32x4{row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]});
+                        if (k.df) k.df[tb * 12 + L.j] = -dlam;
+                    }
+                }
+                // dC_t (row j), dc_t
+                {
+                    float row[16];
+                    wv::mul_bcast_each16(row, tj, -0.5f * dj);
+                    wv::fma_bcast_each16(row, dj, -0.5f * tj);
+                    if (L.live) {
+                        float *dst = k.dC + (tb * 16 + (L.j < 12 ? L.j : 12 + L.a)) * 16;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            wv::store_f32x4(dst + 4 * q, f32x4{row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]});
+                        k.dc[tb * 16 + L.j] = -dj;
+                    }
+                }
+                // costate recursions (rows 0..11 of C; F_x = first 12 columns of F)
+                float ln = cj, dn = L.j < 12 ? -rj : 0.f;
+                wv::dot_bcast16(ln, tj, Cr);
+                wv::dot_bcast16(dn, dj, Cr);
+                if (have) {
+                    wv::dot_bcast12(ln, lam, Fc);
+                    wv::dot_bcast12(dn, dlam, Fc);
+                }
+                lam = ln;
+                dlam = dn;
+            }
+        }
+    }
+    wv::dma_wait<0>();
+    if (L.live && L.j < 12) k.dx_init[(long)L.pb * 12 + L.j] = -dlam;
 }
 
 }  // namespace dpp16

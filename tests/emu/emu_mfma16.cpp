@@ -179,6 +179,15 @@ template <int NN> static inline void fma_bcast_each(float (&a)[NN], float src, f
     for (int i = 0; i < NN; ++i) a[i] = fmaf(w.fa[gen][(l & ~15) + i], mul, a[i]);
 }
 static inline void fma_bcast_each16(float (&a)[16], float src, float mul) { fma_bcast_each<16>(a, src, mul); }
+static inline void mul_bcast_each16(float (&a)[16], float src, float mul)
+{
+    for (int i = 0; i < 16; ++i) a[i] = -0.f;
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = src;
+    emu::yield_lane();
+    for (int i = 0; i < 16; ++i) a[i] = w.fa[gen][(l & ~15) + i] * mul;
+}
 static inline void fma_bcast_each12(float (&a)[12], float src, float mul) { fma_bcast_each<12>(a, src, mul); }
 template <int NN> static inline void dot_bcast(float &acc, float src, const float (&m)[NN])
 {
@@ -352,5 +361,21 @@ extern "C" int emu_lqr_step_dpp16(const mpc_lqr_problem *p, const mpc_lqr_option
     sp.Kk = kk_buf;
     g_p = &sp;
     for (int w = 0; 4 * w < sp.B; ++w) emu::run_wave(w, body_dpp16);
+    return 0;
+}
+
+static const mpclqr::dpp16::KktArgs *g_k;
+static void body_kkt16() { mpclqr::dpp16::kkt_wave(*g_p, *g_k); }
+
+extern "C" int emu_kkt_dpp16(const mpc_lqr_problem *p, const float *dx, const float *du, const float *dl_dx,
+                             float *dC, float *dc, float *dF, float *df, float *dx_init)
+{
+    mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, nullptr, nullptr);
+    if (!(sp.ns == 12 && sp.nc == 4)) return MPC_E_DIMS;
+    mpclqr::dpp16::KktArgs k;
+    k.dx = dx; k.du = du; k.dl_dx = dl_dx; k.dC = dC; k.dc = dc; k.dF = dF; k.df = df; k.dx_init = dx_init;
+    g_p = &sp;
+    g_k = &k;
+    for (int w = 0; 4 * w < sp.B; ++w) emu::run_wave(w, body_kkt16);
     return 0;
 }

@@ -105,3 +105,34 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
         rc = lib().emu_lqr_step_mfma16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), int(force_general))
     assert rc == 0, rc
     return res
+
+
+def kkt_grads(C, c, F, f, x_star, u_star, dx, du, dl_dx, dma_late=False):
+    """The closed-form part of LQRStepFn.backward (mpc/lqr_step.py:346-404) through the emulated
+    4-problems-per-wave kernel; n_state = 12, n_ctrl = 4, float32."""
+    f32 = np.float32
+    cast = lambda a: np.ascontiguousarray(a, f32)
+    C, c, F, x_star, u_star, dx, du, dl_dx = map(cast, (C, c, F, x_star, u_star, dx, du, dl_dx))
+    T, B, n, _ = C.shape
+    ns, nc = 12, 4
+    p = N.Problem()
+    p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, N.MPC_F32
+    x0 = np.zeros((B, ns), f32)
+    p.x_init = _ptr(x0)
+    p.C, p.C_st, p.C_sb = _ptr(C), B * n * n, n * n
+    p.c, p.c_st, p.c_sb = _ptr(c), B * n, n
+    if T > 1:
+        p.F, p.F_st, p.F_sb = _ptr(F), B * ns * n, ns * n
+    p.cur_x, p.cur_u = _ptr(x_star), _ptr(u_star)
+    has_f = f is not None and np.asarray(f).size > 0
+    out = dict(dC=np.full((T, B, n, n), np.nan, f32), dc=np.full((T, B, n), np.nan, f32),
+               dF=np.zeros((max(T - 1, 0), B, ns, n), f32), df=np.full((max(T - 1, 0), B, ns), np.nan, f32) if has_f else None,
+               dx_init=np.full((B, ns), np.nan, f32))
+    L = lib()
+    L.emu_set_dma_late(int(bool(dma_late)))
+    vp = ctypes.c_void_p
+    L.emu_kkt_dpp16.argtypes = [ctypes.POINTER(N.Problem)] + [vp] * 8
+    rc = L.emu_kkt_dpp16(ctypes.byref(p), _ptr(dx), _ptr(du), _ptr(dl_dx), _ptr(out["dC"]), _ptr(out["dc"]),
+                         _ptr(out["dF"]), _ptr(out["df"]), _ptr(out["dx_init"]))
+    assert rc == 0, rc
+    return out

@@ -186,3 +186,24 @@ def test_emulated_dpp16_options_against_oracle(emu, case):
     np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4, atol=1e-4)
     np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
+@pytest.mark.parametrize("bounded,with_f,B", [(False, True, 5), (True, True, 4), (True, False, 3)])
+def test_emulated_kkt_dpp16_matches_oracle(emu, bounded, with_f, B, dma_late):
+    """kkt_wave (dC, dc, dF, df, dx_init from tau*, dtau, dl_dx) against LQRStepFn.backward of the oracle,
+    fed with the oracle's own KKT solve (dx, du)."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(7 + B)
+    T = 6
+    pr = _ns_problem(rng, T, B, with_f=with_f)
+    cur_u = np.clip(0.5 * rng.standard_normal((T, B, 4)), -0.4, 0.4)
+    cur_x, _ = O.traj_cost(pr["x_init"], cur_u, pr["F"], pr["f"])
+    lo, hi = (-0.4, 0.4) if bounded else (None, None)
+    sol = O.lqr_step(lockstep=False, cur_x=cur_x, cur_u=cur_u, u_lower=lo, u_upper=hi, **pr)
+    dl_dx, dl_du = rng.standard_normal((T, B, 12)), rng.standard_normal((T, B, 4))
+    o = O.kkt_backward(pr["C"], pr["c"], pr["F"], pr["f"], sol["new_x"], sol["new_u"], dl_dx, dl_du, lo, hi)
+    r = emu.kkt_grads(pr["C"], pr["c"], pr["F"], pr["f"], sol["new_x"], sol["new_u"], o["dx"], o["du"], dl_dx,
+                      dma_late=dma_late)
+    for k in ("dC", "dc", "dF", "dx_init") + (("df",) if with_f else ()):
+        np.testing.assert_allclose(r[k], o[k], rtol=1e-4, atol=1e-4 * max(1.0, np.abs(o[k]).max()), err_msg=k)
