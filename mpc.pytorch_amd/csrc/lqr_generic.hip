@@ -21,6 +21,11 @@ namespace mpclqr {
 namespace {
 
 constexpr int WAVE = 64;
+constexpr int MAX_THREADS = 256;      // one to four wavefronts per problem, by problem size
+
+// Workgroup size for one problem: a single wavefront up to n = 24, four beyond (config 5: n = 40 keeps
+// 1600-entry blocks in LDS -- 25 entries per lane with one wave).
+inline int threads_for(int ns, int nc) { return (ns + nc) > 24 ? MAX_THREADS : WAVE; }
 
 template <typename real> __device__ __forceinline__ real rabs(real x) { return x < 0 ? -x : x; }
 template <typename real> __device__ __forceinline__ real rsqrt_(real x);
@@ -499,7 +504,7 @@ __device__ void rollout_problem(const StepParams<real> &p, int b, Smem<real> &s,
 
 // phase_mask: 1 = sweep, 2 = rollout, 3 = both (K,k round-trip through p.K/p.k, L2-resident)
 template <typename real>
-__global__ void __launch_bounds__(WAVE) lqr_step_generic_kernel(StepParams<real> p, int phase_mask)
+__global__ void __launch_bounds__(MAX_THREADS) lqr_step_generic_kernel(StepParams<real> p, int phase_mask)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem<real> s;
@@ -584,7 +589,7 @@ __global__ void pnqp_kernel(int B, int n, const real *H, const real *q, const re
 // util.get_traj + util.get_cost (mpc/util.py:102-153)
 // ---------------------------------------------------------------------------
 template <typename real>
-__global__ void __launch_bounds__(WAVE) traj_cost_kernel(StepParams<real> p, real *x, real *cost)
+__global__ void __launch_bounds__(MAX_THREADS) traj_cost_kernel(StepParams<real> p, real *x, real *cost)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem<real> s;
@@ -646,7 +651,7 @@ __global__ void __launch_bounds__(WAVE) traj_cost_kernel(StepParams<real> p, rea
 // KKT backward, closed-form part (mpc/lqr_step.py:346-404)
 // ---------------------------------------------------------------------------
 template <typename real>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(MAX_THREADS)
 kkt_grads_kernel(StepParams<real> p, const real *dx, const real *du, const real *dl_dx, const real *dl_du,
                  real *dC, real *dc, real *dF, real *df, real *dx_init)
 {
@@ -799,7 +804,7 @@ size_t generic_lds_bytes(int ns, int nc, size_t elem)
 {
     const size_t n = (size_t)ns + nc;
     size_t cnt = n * n + ns * n + n * ns + (size_t)ns * ns + (size_t)nc * (nc + 1 + ns) + (size_t)nc * ns +
-                 (size_t)nc * (ns + 1) + n + ns + n + n + (size_t)nc * 8 + (size_t)ns * 3 + WAVE;
+                 (size_t)nc * (ns + 1) + n + ns + n + n + (size_t)nc * 8 + (size_t)ns * 3 + MAX_THREADS;
     return cnt * elem + (size_t)nc * sizeof(int) + 16;
 }
 
@@ -810,7 +815,7 @@ template <typename real> int launch_step_generic(const StepParams<real> &p, int 
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_step_generic_kernel<real>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(lqr_step_generic_kernel<real>, dim3(p.B), dim3(WAVE), lds, st, p, phase_mask);
+    hipLaunchKernelGGL(lqr_step_generic_kernel<real>, dim3(p.B), dim3(threads_for(p.ns, p.nc)), lds, st, p, phase_mask);
     return check_launch("lqr_step_generic_kernel");
 }
 
@@ -836,7 +841,7 @@ template <typename real> int launch_traj_cost(const StepParams<real> &p, real *x
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&traj_cost_kernel<real>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(traj_cost_kernel<real>, dim3(p.B), dim3(WAVE), lds, st, p, x, cost);
+    hipLaunchKernelGGL(traj_cost_kernel<real>, dim3(p.B), dim3(threads_for(p.ns, p.nc)), lds, st, p, x, cost);
     return check_launch("traj_cost_kernel");
 }
 
@@ -849,7 +854,7 @@ int launch_kkt_grads(const StepParams<real> &p, const real *dx, const real *du, 
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_grads_kernel<real>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kkt_grads_kernel<real>, dim3(p.B), dim3(WAVE), lds, st, p, dx, du, dl_dx, dl_du, dC, dc,
+    hipLaunchKernelGGL(kkt_grads_kernel<real>, dim3(p.B), dim3(threads_for(p.ns, p.nc)), lds, st, p, dx, du, dl_dx, dl_du, dC, dc,
                        dF, df, dx_init);
     return check_launch("kkt_grads_kernel");
 }

@@ -20,18 +20,23 @@ def timed(fn, n=10, warm=2):
     ts = sorted(a.elapsed_time(b) for a, b in ev)
     return ts[len(ts) // 2]
 
-be = _native.HipBackend()
-out = {}
-for bounded in (False, True):
-    p = bench.make_problem(12, 4, 50, 4096, torch.float32, "cuda:0", seed=5, u_scale=0.3 if bounded else 0.0,
-                           clamp=1.0 if bounded else None)
-    opts = StepOptions(u_lower=-1.0, u_upper=1.0) if bounded else StepOptions()
-    r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts)
-    gx, gu = torch.randn_like(r["new_x"]), torch.randn_like(r["new_u"])
-    key = "bounded" if bounded else "unbounded"
-    out["kkt_backward_ms_" + key] = timed(lambda: be.kkt_backward(p["C"], p["c"], p["F"], p["f"], r["new_x"], r["new_u"], gx, gu, opts))
-    out["lqr_step_ms_" + key] = timed(lambda: be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts))
-    ctrl = mpc.MPC(12, 4, 50, u_lower=-1.0 if bounded else None, u_upper=1.0 if bounded else None, lqr_iter=5,
-                   verbose=-1, exit_unconverged=False, detach_unconverged=False)
-    out["mpc_forward_5iter_ms_" + key] = timed(lambda: ctrl(p["x_init"], QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"])), n=5, warm=1)
-print(json.dumps(out, indent=1))
+def main():
+    be = _native.HipBackend()
+    out = {}
+    for bounded in (False, True):
+        p = bench.make_problem(12, 4, 50, 4096, torch.float32, "cuda:0", seed=5, u_scale=0.3 if bounded else 0.0,
+                               clamp=1.0 if bounded else None)
+        opts = StepOptions(u_lower=-1.0, u_upper=1.0) if bounded else StepOptions()
+        r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts)
+        gx, gu = torch.randn_like(r["new_x"]), torch.randn_like(r["new_u"])
+        key = "bounded" if bounded else "unbounded"
+        out["kkt_backward_ms_" + key] = timed(lambda: be.kkt_backward(p["C"], p["c"], p["F"], p["f"], r["new_x"], r["new_u"], gx, gu, opts))
+        out["lqr_step_ms_" + key] = timed(lambda: be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts))
+        ctrl = mpc.MPC(12, 4, 50, u_lower=-1.0 if bounded else None, u_upper=1.0 if bounded else None, lqr_iter=5,
+                       verbose=-1, exit_unconverged=False, detach_unconverged=False)
+        out["mpc_forward_5iter_ms_" + key] = timed(lambda: ctrl(p["x_init"], QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"])), n=5, warm=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
