@@ -81,10 +81,10 @@ def cpu_baseline(sample_B, bounded, seed=123):
         O.lqr_step(*args, lockstep=False, nthreads=threads)
         reps += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or reps >= 50:
+        if dt > 10.0 or reps >= 2000:
             break
     return dict(value=sample_B * T_H * reps / dt, unit="problem-steps/s", cores=threads, kind="port",
-                sample="%d problems x T=%d, %d reps in %.1f s, oracle/lqr_oracle.c per-problem mode, OpenMP"
+                sample="%d problems x T=%d, %d repetitions in %.1f s, oracle/lqr_oracle.c (C restatement of the reference, per-problem mode), OpenMP over the host cores"
                        % (sample_B, T_H, reps, dt))
 
 

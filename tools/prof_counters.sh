@@ -13,3 +13,5 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE -d $O/pmc3 -o pmc3 -- $B --steps 5 --
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $O/pmc4 -o pmc4 -- $B --steps 5 --warmup 1 > $O/pmc4.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_LEVEL_WAVES SQ_INST_LEVEL_VMEM -d $O/pmc5 -o pmc5 -- $B --steps 5 --warmup 1 > $O/pmc5.log 2>&1
 echo done
+# keep only the summary (the sqlite outputs are tens of MB; gpurun merges at most 64 MiB back)
+python tools/prof_summary.py $O $O/summary.json > /dev/null && find $O -name "*.db" -delete
