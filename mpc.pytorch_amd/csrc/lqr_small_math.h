@@ -92,6 +92,11 @@ MPC_DEV float qp_obj4(const Sym4 &s, const float q[4], const float x[4])
     const float lin = fmaf(q[3], x[3], fmaf(q[2], x[2], fmaf(q[1], x[1], q[0] * x[0])));
     return fmaf(0.5f, quad, lin);
 }
+// the same objective when g = Hx + q is already at hand:  0.5 x'Hx + q'x = 0.5 x'(g + q)
+MPC_DEV float qp_obj4_from_grad(const float g[4], const float q[4], const float x[4])
+{
+    return 0.5f * fmaf(x[3], g[3] + q[3], fmaf(x[2], g[2] + q[2], fmaf(x[1], g[1] + q[1], x[0] * (g[0] + q[0]))));
+}
 
 // Projected-Newton box QP in n_ctrl <= 4 unknowns on wave-uniform values
 // (mpc/pnqp.py:5-82 with n_batch = 1).  x holds the clamped start on entry and the
@@ -125,7 +130,7 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
             dx[a] = fr[a] ? -dx[a] : 0.f;
             nrm2 = fmaf(dx[a], dx[a], nrm2);
         }
-        const bool small = !(sqrtf(nrm2) >= 1e-4f);
+        const bool small = !(nrm2 >= 1e-8f);                        // |dx| < 1e-4
         if (UNIFORM ? wv::uniform(small) : small) {                 // :56-59
             converged = true;
             it_ret = it;
@@ -133,7 +138,7 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
         }
         // :61-76 Armijo backtracking
         float alpha = 1.f;
-        const float obj_x = qp_obj4(s, q, x);
+        const float obj_x = qp_obj4_from_grad(g, q, x);
         float mx[4];
         for (int count = 0; count < 10; ++count) {
 #pragma unroll
@@ -142,7 +147,7 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
             float den = 0.f;
 #pragma unroll
             for (int a = 0; a < 4; ++a) den = fmaf(g[a], x[a] - mx[a], den);
-            const float arm = (obj_x - obj_m) / den;
+            const float arm = (obj_x - obj_m) * wv::rcp(den);
             const bool shrink = arm <= 0.1f;
             if (UNIFORM ? wv::uniform(shrink) : shrink) alpha *= 0.1f; else break;
         }
