@@ -217,6 +217,40 @@ def mpc_case(name, ns, nc, T, C, c, F, f, x_init, u_lower, u_upper, **kw):
          x=npy(x), u=npy(u), costs=npy(costs), table=table, init_cost=init, **kwn)
 
 
+def env_case(name, kind, T, B, lqr_iter, seed):
+    """BASELINE.json configs 2 / 3: iLQR on the reference's own simulator dynamics (AUTO_DIFF
+    linearisation, module rollout in the line search), double precision, a few problems."""
+    import importlib
+    sys.modules.setdefault("mpc", sys.modules["mpc_ref"])        # env_dx does `from mpc import util`
+    sys.modules.setdefault("mpc.util", ref_util)
+    mod = importlib.import_module("mpc_ref.env_dx." + kind)
+    dx = getattr(mod, "PendulumDx" if kind == "pendulum" else "CartpoleDx")()
+    dx.params = dx.params.double()
+    ns, nc = dx.n_state, dx.n_ctrl
+    g = torch.Generator().manual_seed(seed)
+    if kind == "pendulum":
+        th = (torch.rand(B, generator=g, dtype=torch.float64) - 0.5) * np.pi
+        thd = (torch.rand(B, generator=g, dtype=torch.float64) - 0.5) * 2.0
+        x_init = torch.stack((torch.cos(th), torch.sin(th), thd), 1)
+    else:
+        th = (torch.rand(B, generator=g, dtype=torch.float64) - 0.5) * 0.6
+        z = 0.2 * torch.randn(B, 3, generator=g, dtype=torch.float64)
+        x_init = torch.stack((z[:, 0], z[:, 1], torch.cos(th), torch.sin(th), z[:, 2]), 1)
+    q, p_ = dx.get_true_obj()
+    q, p_ = q.double(), p_.double()
+    Q = torch.diag(q).unsqueeze(0).unsqueeze(0).repeat(T, B, 1, 1)
+    pp = p_.unsqueeze(0).repeat(T, B, 1)
+    ctrl = ref_mpc.MPC(ns, nc, T, u_lower=dx.lower, u_upper=dx.upper, lqr_iter=lqr_iter, verbose=-1,
+                       exit_unconverged=False, detach_unconverged=False, linesearch_decay=dx.linesearch_decay,
+                       max_linesearch_iter=dx.max_linesearch_iter, grad_method=ref_mpc.GradMethods.AUTO_DIFF,
+                       eps=dx.mpc_eps)
+    (x, u, costs), _ = quiet(ctrl, x_init, QuadCost(Q, pp), dx)
+    save(name, meta=np.array([ns, nc, T, B, lqr_iter]), x_init=npy(x_init), Q=npy(Q), p=npy(pp),
+         lower=np.array([dx.lower]), upper=np.array([dx.upper]), decay=np.array([dx.linesearch_decay]),
+         max_ls=np.array([dx.max_linesearch_iter]), eps=np.array([dx.mpc_eps]),
+         x=npy(x), u=npy(u), costs=npy(costs))
+
+
 def gen_mpc_cases():
     # (1) notebook known answer: examples/Time Varying Linear-Quadratic Control.ipynb cell 1
     torch.manual_seed(0)
@@ -407,6 +441,11 @@ if __name__ == "__main__":
     if ONLY is not None:
         sys.exit(0)
     # ---- full solves --------------------------------------------------------
+    if not only or "env" in only:
+        env_case("ilqr_pendulum_f64", "pendulum", 20, 4, 8, 51)
+        env_case("ilqr_cartpole_f64", "cartpole", 25, 4, 8, 52)
+    if only == {"env"}:
+        sys.exit(0)
     gen_mpc_cases()
     # ---- backward -------------------------------------------------------------
     grad_case("grad_unconstrained_f64", 4, 2, 6, 4, f64, 31, None)

@@ -258,6 +258,19 @@ def test_mpc_forward_on_gpu(be, name):
     np.testing.assert_allclose(host(costs), z["costs"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("kind", ["pendulum", "cartpole"])
+def test_ilqr_on_simulator_dynamics_on_gpu(be, kind):
+    """BASELINE.json configs 2 / 3 (small batch, float64): iLQR on Pendulum / Cartpole dynamics on the
+    device == the reference's solves with its own env_dx modules."""
+    from test_host_logic import run_ilqr_golden
+    z = golden("ilqr_%s_f64" % kind)
+    x, u, costs = run_ilqr_golden(z, kind, device=DEV)
+    assert x.is_cuda
+    np.testing.assert_allclose(host(costs), z["costs"], rtol=1e-5)
+    np.testing.assert_allclose(host(x), z["x"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(u), z["u"], rtol=1e-4, atol=1e-4)
+
+
 # ------------------------------------------------------------------------------------------------
 # full-size checks at BASELINE.json's north-star configuration (ns=12, nc=4, T=50, B=4096, fp32)
 # ------------------------------------------------------------------------------------------------

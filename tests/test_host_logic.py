@@ -120,6 +120,32 @@ def run_mpc_golden(z, verbose=-1, device=None):
     return ctrl(mv(tt(z, "x_init")), QuadCost(mv(tt(z, "C")), mv(tt(z, "c"))), LinDx(mv(tt(z, "F")), mv(tt(z, "f"))))
 
 
+def run_ilqr_golden(z, kind, device=None):
+    """BASELINE.json configs 2 / 3 at small batch: iLQR on simulator dynamics (tests/envs.py),
+    AUTO_DIFF linearisation, module rollout in the line search."""
+    import envs
+    ns, nc, T, B, lqr_iter = (int(v) for v in z["meta"])
+    dx = (envs.PendulumSim if kind == "pendulum" else envs.CartpoleSim)()
+    mv = (lambda t: t if device is None else t.to(device))
+    ctrl = mpc.MPC(ns, nc, T, u_lower=float(z["lower"][0]), u_upper=float(z["upper"][0]), lqr_iter=lqr_iter,
+                   verbose=-1, exit_unconverged=False, detach_unconverged=False,
+                   linesearch_decay=float(z["decay"][0]), max_linesearch_iter=int(z["max_ls"][0]),
+                   grad_method=mpc.GradMethods.AUTO_DIFF, eps=float(z["eps"][0]))
+    return ctrl(mv(tt(z, "x_init")), QuadCost(mv(tt(z, "Q")), mv(tt(z, "p"))), dx)
+
+
+@pytest.mark.parametrize("kind", ["pendulum", "cartpole"])
+def test_ilqr_on_simulator_dynamics_matches_reference(kind, oracle_backend):
+    """The reference's own PendulumDx / CartpoleDx solves (mpc/env_dx/*.py, 8 iLQR iterations, B = 4,
+    float64): same trajectories and costs from this package's driver + fresh dynamics modules."""
+    z = golden("ilqr_%s_f64" % kind)
+    x, u, costs = run_ilqr_golden(z, kind)
+    np.testing.assert_allclose(costs.detach().numpy(), z["costs"], rtol=1e-5)
+    np.testing.assert_allclose(x.detach().numpy(), z["x"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(u.detach().numpy(), z["u"], rtol=1e-4, atol=1e-4)
+    assert "lqr_sweep" in oracle_backend.calls          # module dynamics: sweep on the kernel, rollout on the host
+
+
 @pytest.mark.parametrize("name", MPC_CASES)
 def test_mpc_forward_matches_reference_solves(name, oracle_backend):
     """tests/test_mpc.py:91-299 inputs + the notebook problem: same (x, u, costs) as the reference."""
