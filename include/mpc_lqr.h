@@ -41,7 +41,12 @@ enum {
     MPC_E_ARG = -5
 };
 /* per-problem status word bits (status[B]) */
-enum { MPC_ST_PNQP_UNCONVERGED = 1, MPC_ST_NONFINITE = 2 };
+enum {
+    MPC_ST_PNQP_UNCONVERGED = 1,   /* "pnqp warning: Did not converge" (mpc/pnqp.py:81) at some timestep   */
+    MPC_ST_NONFINITE = 2,          /* the returned cost is NaN / inf                                        */
+    MPC_ST_NOMINAL_OFF_DYNAMICS = 4 /* informational (DPP kernel): current_x is not the rollout of current_u,
+                                      the trajectory cost was evaluated from a second pass over C            */
+};
 
 /* The problem data of one LQRStepFn.forward call: (x_init, C, c, F, f) plus the
  * closure state `current_x/current_u` (mpc/lqr_step.py:22-38, 277). */

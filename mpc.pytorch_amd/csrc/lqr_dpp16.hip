@@ -179,6 +179,23 @@ MPC_DEV float row_sum(float x)
     return x;
 }
 
+MPC_DEV double dpp_f64(double x, int) { return x; }
+template <int CTRL> MPC_DEV double mov_dpp_f64(double x)
+{
+    const unsigned long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+MPC_DEV double row_sum_f64(double x)
+{
+    x += mov_dpp_f64<0xB1>(x);
+    x += mov_dpp_f64<0x4E>(x);
+    x += mov_dpp_f64<0x141>(x);
+    x += mov_dpp_f64<0x140>(x);
+    return x;
+}
+
 // ---- HBM -> LDS staging --------------------------------------------------------------------
 #define MPC_DPP16_LDS (4 * 9216)
 __shared__ __attribute__((aligned(16))) char g_stage16[MPC_DPP16_LDS];

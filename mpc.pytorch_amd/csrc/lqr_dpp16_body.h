@@ -27,6 +27,17 @@
 //   K[a]   = K[a][j]  (j < 12),  lane 12 carries k = K[.][12]
 // Staging: per wave a 4-slot LDS ring, 9 KiB per slot (4 x {C 1 KiB, F 768 B, small-vector record
 // 256 B, gain record 256 B}), filled by global_load_lds three timesteps ahead; counted vmcnt waits.
+//
+// One read of C.  The rollout does NOT stream C again to price its trajectory: for a rollout that obeys
+// the dynamics (it does by construction) around a nominal that obeys them too, the exact identity
+//     J(tau') = J(nominal) + w_0 + sum_t [ e_t'(m_t + M_t dx_t) + 0.5 e_t' Quu_t e_t ],
+//     e_t = du_t - K_t dx_t - k_t,  m = qu + Quu k,  M = Qux + Quu K,  w_0 = sum_t (0.5 k'Quu k + qu'k)
+// (telescoping Q_t(dx,du) - V_t(dx) over the sweep's own value function) needs only what the sweep
+// already holds: Quu_t rides in the spare 48 bytes of the gain record, (m, M) in a second record when
+// constraints make them non-zero.  Whether the nominal obeys the dynamics is CHECKED in the rollout
+// (|F tau + f - x_next| <= 1e-5 (1 + |x|), one more 16-term product per step); if any problem of the
+// wave fails it, the wave prices its rollout the reference's way, 0.5 tau'C tau + c'tau, from a second
+// stream of C (mpc/lqr_step.py:230-232).  Either way `costs` is the reference's quantity.
 #pragma once
 #include <math.h>
 #include "lqr_params.h"
@@ -48,9 +59,11 @@ enum {
     SC = 0, SF = 4096, SR = 7168, SG = 8192, STAGE_BYTES = 9216, NSTAGE = 4,
     R_c = 0, R_tau = 64, R_f = 128, R_lo = 192, R_hi = 208,
     LDS_TOTAL = NSTAGE * STAGE_BYTES,
-    DMA_SWEEP = 8,      // 4 C + 3 F + 1 record
-    DMA_ROLL = 9        // + 1 gain record
+    DMA_SWEEP = 8       // 4 C + 3 F + 1 record
 };
+// DMA instructions of one rollout stage: F, record, gains (+ C when priced directly, + (m, M) otherwise
+// when constraints are present)
+template <int MODE, bool DIRECT> struct RollDma { enum { N = 3 + 1 + 1 + (DIRECT ? 4 : (MODE != 0 ? 1 : 0)) }; };
 
 struct Lane {
     int lane, p, j;       // problem slot in the wave, variable
@@ -66,6 +79,8 @@ struct Lane {
     int aRecA;            // SR + p*256 + 4 a                   (+R_lo / R_hi)
     int aRecF;            // SR + p*256 + R_f + 4 min(j, 11)
     int aKrow;            // SG + p*256 + 4 a                   (+16 jj: K[a][jj]; +192: k_a)
+    int aS[4];            // SG + p*256 + 208 + 4 tri(a, b)     (Quu[a][b] of the packed upper triangle)
+    int aMrow;            // SC + p*256 + 4 a                   (second record, overlays the unused C slot)
 };
 
 MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
@@ -86,6 +101,13 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
     L.aRecA = SR + L.p * 256 + 4 * L.a;
     L.aRecF = SR + L.p * 256 + R_f + 4 * jx;
     L.aKrow = SG + L.p * 256 + 4 * L.a;
+    L.aMrow = SC + L.p * 256 + 4 * L.a;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int lo = L.a < b ? L.a : b, hi = L.a < b ? b : L.a;
+        const int tri = (lo == 0 ? 0 : (lo == 1 ? 4 : (lo == 2 ? 7 : 9))) + (hi - lo);
+        L.aS[b] = SG + L.p * 256 + 208 + 4 * tri;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -100,6 +122,7 @@ struct Dma {
     const char *f_ptr[3];     // per lane
     const char *r_ptr;        // per lane
     const char *g_ptr;        // per lane
+    const char *g2_ptr;       // per lane: the (m, M) record
     long c_step, f_step, r_step, g_step;
     bool r_active, r_is_f;
 };
@@ -142,19 +165,22 @@ MPC_DEV void dma_init(Dma &d, const P &p, const Lane &L, int wave)
         d.r_ptr = q;
         d.r_step = st;
         d.g_ptr = (const char *)(p.Kk + pb * 64 + 4 * gi);
+        d.g2_ptr = (const char *)(p.Kk + (long)p.T * B * 64 + pb * 64 + 4 * gi);
         d.g_step = 4 * B * 64;
     }
 }
 
-// DMA of timestep t into ring slot `slot`: exactly DMA_SWEEP (DMA_ROLL) instructions.
-template <bool ROLL>
+// DMA of timestep t into ring slot `slot`: exactly DMA_SWEEP / RollDma<MODE, DIRECT>::N instructions.
+template <int MODE, bool ROLL, bool DIRECT>
 MPC_DEV void stage_issue(const P &p, const Dma &d, int t, int slot)
 {
     const unsigned base = (unsigned)slot * STAGE_BYTES;
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);     // F / f have T-1 entries
+    if (!ROLL || DIRECT) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) wv::dma16(d.c_ptr[k] + tl * d.c_step, base + SC + 1024 * k);
+        for (int k = 0; k < 4; ++k) wv::dma16(d.c_ptr[k] + tl * d.c_step, base + SC + 1024 * k);
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) wv::dma16(d.f_ptr[k] + (p.T > 1 ? tf * d.f_step : 0), base + SF + 1024 * k);
     // the record instruction is issued by every wave even if only some lanes take part
@@ -162,7 +188,10 @@ MPC_DEV void stage_issue(const P &p, const Dma &d, int t, int slot)
         const char *src = d.r_ptr + (d.r_is_f ? tf : tl) * d.r_step;
         wv::dma16_if(d.r_active, src, base + SR);
     }
-    if (ROLL) wv::dma16(d.g_ptr + tl * d.g_step, base + SG);
+    if (ROLL) {
+        wv::dma16(d.g_ptr + tl * d.g_step, base + SG);
+        if (!DIRECT && MODE != 0) wv::dma16(d.g2_ptr + tl * d.g_step, base + SC);
+    }
 }
 
 MPC_DEV unsigned zm_load(const P &p, const Lane &L, int t)
@@ -219,7 +248,10 @@ MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, uns
 struct SwState {
     float Vc[12];
     float vv;
-    float oc;          // nominal-cost partial of this lane
+    // Kept in double: the rollout is priced as J_nominal + w_0 + (small terms), and J_nominal + w_0 is
+    // the difference of two sums that can each be 1e3 times the result.
+    double oc;         // nominal-cost partial of this lane
+    double w0;         // sum_t (0.5 k'Quu k + qu'k): the sweep's predicted cost change (row-uniform)
     float kprev[4];
     int warm;
     int qp_total;
@@ -233,7 +265,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     // c_back = C tau + c (mpc/lqr_step.py:289-295) and the nominal stage cost (util.get_cost, :169)
     float cb = s.cj;
     wv::dot_bcast16(cb, s.tb, s.Cc);
-    st.oc = fmaf(s.tb, 0.5f * (cb + s.cj), st.oc);
+    st.oc += (double)(s.tb * (0.5f * (cb + s.cj)));
 
     float Q[16];
     float q = cb;
@@ -344,9 +376,9 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     float vn = q;
     wv::fmac_bcast<12>(vn, K[0], Q[12]); wv::fmac_bcast<12>(vn, K[1], Q[13]);
     wv::fmac_bcast<12>(vn, K[2], Q[14]); wv::fmac_bcast<12>(vn, K[3], Q[15]);
+    float M[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE != 0) {
         // with a full free set Qux + Quu K vanishes; with masked / clamped controls it does not
-        float M[4];
         M[0] = fmaf(S.s03, K[3], fmaf(S.s02, K[2], fmaf(S.s01, K[1], fmaf(S.s00, K[0], rhs[0]))));
         M[1] = fmaf(S.s13, K[3], fmaf(S.s12, K[2], fmaf(S.s11, K[1], fmaf(S.s01, K[0], rhs[1]))));
         M[2] = fmaf(S.s23, K[3], fmaf(S.s22, K[2], fmaf(S.s12, K[1], fmaf(S.s02, K[0], rhs[2]))));
@@ -360,11 +392,30 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #pragma unroll
     for (int i = 0; i < 12; ++i) st.Vc[i] = Vn[i];
     st.vv = vn;
+    // the constant of the value function: w_t = w_{t+1} + 0.5 k'Quu k + qu'k  (k lives in lane 12)
+    {
+        const float k0 = wv::bcast<12>(K[0]), k1 = wv::bcast<12>(K[1]), k2 = wv::bcast<12>(K[2]), k3 = wv::bcast<12>(K[3]);
+        const float kk[4] = {k0, k1, k2, k3};
+        float sk[4];
+        mfma16::sym4_mv(S, kk, sk);
+        float w = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) w = fmaf(kk[a], fmaf(0.5f, sk[a], qu[a]), w);
+        st.w0 += (double)w;
+    }
 
-    // gains: the wave's own record Kk[t][b][j][4]; and K [T,B,4,12] / k [T,B,4] when asked for
+    // gains: the wave's own record Kk[t][b][j][4] = K[.][j] (j < 12), k (j = 12), Quu packed (j = 13..15);
+    // a second record (m, M) in the same layout when constraints are present;
+    // and K [T,B,4,12] / k [T,B,4] in the reference's layout when asked for
     if (L.live) {
         const long tb = (long)t * p.B + L.pb;
-        wv::store_f32x4(p.Kk + tb * 64 + 4 * L.j, f32x4{K[0], K[1], K[2], K[3]});
+        f32x4 rec = {K[0], K[1], K[2], K[3]};
+        if (L.j == 13) rec = f32x4{S.s00, S.s01, S.s02, S.s03};
+        if (L.j == 14) rec = f32x4{S.s11, S.s12, S.s13, S.s22};
+        if (L.j == 15) rec = f32x4{S.s23, S.s33, 0.f, 0.f};
+        wv::store_f32x4(p.Kk + tb * 64 + 4 * L.j, rec);
+        if (MODE != 0 && L.j <= 12)
+            wv::store_f32x4(p.Kk + ((long)p.T * p.B + tb) * 64 + 4 * L.j, f32x4{M[0], M[1], M[2], M[3]});
         if (p.K != nullptr) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -379,21 +430,36 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 // Rollout
 // ---------------------------------------------------------------------------
 struct RoStage {
-    float Cr[16];     // row j of C
+    float Cr[16];     // row j of C                         (direct pricing only)
     float Fr[16];     // row j of F (state lanes)
     float Kr[12];     // row a of K (control lanes)
-    float cj, tb, fj, kk, lo, hi;
+    float Mr[12];     // row a of M = Qux + Quu K           (identity pricing, constrained modes)
+    float Sr[4];      // row a of Quu                       (identity pricing)
+    float cj, tb, fj, kk, mk, lo, hi;
     bool zm;
 };
 
-template <int MODE>
+template <int MODE, bool DIRECT>
 MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, unsigned zm)
 {
     const unsigned base = (unsigned)slot * STAGE_BYTES;
+    s.cj = 0.f;
+    s.mk = 0.f;
+    if (DIRECT) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 v = wv::lds_f32x4(base + L.aCrow + 16 * q);
-        s.Cr[4 * q] = v[0]; s.Cr[4 * q + 1] = v[1]; s.Cr[4 * q + 2] = v[2]; s.Cr[4 * q + 3] = v[3];
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = wv::lds_f32x4(base + L.aCrow + 16 * q);
+            s.Cr[4 * q] = v[0]; s.Cr[4 * q + 1] = v[1]; s.Cr[4 * q + 2] = v[2]; s.Cr[4 * q + 3] = v[3];
+        }
+        s.cj = wv::lds_f32(base + L.aRec + R_c);
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s.Sr[b] = wv::lds_f32(base + L.aS[b]);
+        if (MODE != 0) {
+#pragma unroll
+            for (int jj = 0; jj < 12; ++jj) s.Mr[jj] = wv::lds_f32(base + L.aMrow + 16 * jj);
+            s.mk = wv::lds_f32(base + L.aMrow + 192);
+        }
     }
     if (t < p.T - 1) {
 #pragma unroll
@@ -410,7 +476,6 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
 #pragma unroll
     for (int jj = 0; jj < 12; ++jj) s.Kr[jj] = wv::lds_f32(base + L.aKrow + 16 * jj);
     s.kk = wv::lds_f32(base + L.aKrow + 192);
-    s.cj = wv::lds_f32(base + L.aRec + R_c);
     s.tb = wv::lds_f32(base + L.aRec + R_tau);
     s.lo = s.hi = 0.f;
     if (MODE == 2) {
@@ -427,18 +492,21 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
 
 struct RoState {
     float xs;         // x'_t[j] (state lanes)
-    float cost, du2;  // per-lane partials
+    float cost, du2;  // per-lane partials (identity pricing: of J - J_nominal - w_0)
     float alpha;      // line-search step of this row's problem
+    float pred;       // F tau + f of the nominal at t-1: what the nominal x_t must equal
+    float viol;       // > 0 once the nominal broke the dynamics somewhere
 };
 
 // new_u = K dx + u + alpha k (mpc/lqr_step.py:192), zero mask (:197-198), box / delta_u clamp (:200-213);
-// control lanes hold row a of K
+// control lanes hold row a of K.  `e` = du - K dx - k, the distance from the sweep's policy.
 template <int MODE>
-MPC_DEV float control_law(const P &p, const Lane &L, const RoStage &s, float xs, float alpha)
+MPC_DEV float control_law(const P &p, const Lane &L, const RoStage &s, float xs, float alpha, float &e, float &dx)
 {
-    const float dx = L.isu ? 0.f : xs - s.tb;
+    dx = L.isu ? 0.f : xs - s.tb;
     float un = fmaf(alpha, s.kk, s.tb);
     wv::dot_bcast12(un, dx, s.Kr);
+    const float pre = un;
     if (MODE != 0 && s.zm) un = 0.f;
     if (MODE == 2) {
         float l = s.lo, h = s.hi;
@@ -449,19 +517,39 @@ MPC_DEV float control_law(const P &p, const Lane &L, const RoStage &s, float xs,
         }
         un = eclampf(un, l, h);
     }
+    e = L.isu ? (un - pre) + (alpha - 1.f) * s.kk : 0.f;
     return un;
 }
 
-template <int MODE>
+// The stage's contribution to the trajectory cost.  DIRECT: 0.5 tau'C tau + c'tau (mpc/lqr_step.py:230-232).
+// Otherwise e'(m + M dx) + 0.5 e'Quu e (see the header): control lanes only.
+template <int MODE, bool DIRECT>
+MPC_DEV float stage_price(const Lane &L, const RoStage &s, float tp, float e, float dx)
+{
+    if (DIRECT) {
+        float sq = 0.f;
+        wv::dot_bcast16(sq, tp, s.Cr);
+        return tp * fmaf(0.5f, sq, s.cj);
+    }
+    float se = 0.f;
+    wv::fmac_bcast<12>(se, e, s.Sr[0]); wv::fmac_bcast<13>(se, e, s.Sr[1]);
+    wv::fmac_bcast<14>(se, e, s.Sr[2]); wv::fmac_bcast<15>(se, e, s.Sr[3]);
+    float lin = 0.5f * se;
+    if (MODE != 0) {
+        lin += s.mk;
+        wv::dot_bcast12(lin, dx, s.Mr);
+    }
+    return L.isu ? e * lin : 0.f;
+}
+
+template <int MODE, bool DIRECT>
 MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &st, int t)
 {
     const bool last = (t == p.T - 1);
-    const float un = control_law<MODE>(p, L, s, st.xs, st.alpha);
+    float e, dx;
+    const float un = control_law<MODE>(p, L, s, st.xs, st.alpha, e, dx);
     const float tp = L.isu ? un : st.xs;                             // tau'_t[j]
-    // obj_t = 0.5 tau'C tau + c'tau   (:230-232)
-    float sq = 0.f;
-    wv::dot_bcast16(sq, tp, s.Cr);
-    st.cost = fmaf(tp, fmaf(0.5f, sq, s.cj), st.cost);
+    st.cost += stage_price<MODE, DIRECT>(L, s, tp, e, dx);
     if (L.isu) {
         const float d = s.tb - un;
         st.du2 = fmaf(d, d, st.du2);
@@ -471,6 +559,19 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
         if (L.isu) p.new_u[tb * 4 + L.a] = tp;
         else p.new_x[tb * 12 + L.j] = tp;
     }
+    if (!DIRECT) {
+        // does the nominal obey x_t = F tau_{t-1} + f_{t-1}?  (the identity above assumes it)
+        if (t > 0 && !L.isu) {
+            const float r = fabsf(st.pred - s.tb) - 1e-5f * (1.f + fabsf(s.tb));
+            st.viol = r > st.viol ? r : st.viol;
+            if (!(r == r)) st.viol = 1.f;
+        }
+        if (!last) {
+            float pn = s.fj;
+            wv::dot_bcast16(pn, s.tb, s.Fr);
+            st.pred = pn;
+        }
+    }
     // x_{t+1} = F [x;u] + f  (:216-222)
     if (!last) {
         float xn = s.fj;
@@ -479,26 +580,25 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
     }
 }
 
-// The line-search trials alpha = decay^k, k = 1 .. nt, rolled out side by side off ONE pass over
-// C, F, K (the data is read from LDS once per timestep, every trial has its own state register):
-// only the costs come out; the accepted trial is replayed by a storing pass.
+// The line-search trials alpha = decay^k rolled out side by side off ONE pass over the data (read from LDS
+// once per timestep, every trial has its own state register): only the costs come out; the accepted
+// trial is replayed by a storing pass.
 enum { MAX_TRIALS = 15 };
 struct Trials {
     float xs[MAX_TRIALS], cost[MAX_TRIALS], alpha[MAX_TRIALS];
 };
 
-template <int MODE>
+template <int MODE, bool DIRECT>
 MPC_DEV void trials_step(const P &p, const Lane &L, const RoStage &s, Trials &tr, int nt, int t)
 {
     const bool last = (t == p.T - 1);
 #pragma unroll
     for (int k = 0; k < MAX_TRIALS; ++k) {
         if (k < nt) {
-            const float un = control_law<MODE>(p, L, s, tr.xs[k], tr.alpha[k]);
+            float e, dx;
+            const float un = control_law<MODE>(p, L, s, tr.xs[k], tr.alpha[k], e, dx);
             const float tp = L.isu ? un : tr.xs[k];
-            float sq = 0.f;
-            wv::dot_bcast16(sq, tp, s.Cr);
-            tr.cost[k] = fmaf(tp, fmaf(0.5f, sq, s.cj), tr.cost[k]);
+            tr.cost[k] += stage_price<MODE, DIRECT>(L, s, tp, e, dx);
             if (!last) {
                 float xn = s.fj;
                 wv::dot_bcast16(xn, tp, s.Fr);
@@ -508,10 +608,11 @@ MPC_DEV void trials_step(const P &p, const Lane &L, const RoStage &s, Trials &tr
     }
 }
 
-// One pass over the horizon.  tr == nullptr: the single trial of `st` (trajectory stored);
-// otherwise the nt trials of *tr (costs only).
-template <int MODE, bool MULTI>
-MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st, Trials &tr, int nt)
+// One pass over the horizon.  MULTI: the nt trials of tr (costs only); otherwise the single trial of st
+// (trajectory stored).  Costs come back as full trajectory costs (base = J_nominal + w_0 when priced by
+// the identity, 0 when priced directly).
+template <int MODE, bool MULTI, bool DIRECT>
+MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st, Trials &tr, int nt, float base)
 {
     const int T = p.T;
     const float x0 = L.isu ? 0.f : p.x_init[(long)L.pb * 12 + L.j];
@@ -522,13 +623,14 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st, 
         st.xs = x0;
         st.cost = 0.f;
         st.du2 = 0.f;
+        st.pred = 0.f;
     }
     const bool use_zm = MODE != 0 && p.zero_mask != nullptr;
     unsigned zq[NSTAGE] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int ti = i < T ? i : T - 1;
-        stage_issue<true>(p, d, ti, i);
+        stage_issue<MODE, true, DIRECT>(p, d, ti, i);
         if (use_zm) zq[i] = zm_load(p, L, ti);
     }
     for (int t0 = 0; t0 < T; t0 += NSTAGE) {
@@ -536,14 +638,14 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st, 
         for (int i = 0; i < NSTAGE; ++i) {
             const int t = t0 + i;
             if (t < T) {
-                wv::dma_wait<2 * DMA_ROLL>();
+                wv::dma_wait<2 * RollDma<MODE, DIRECT>::N>();
                 RoStage s;
-                ro_read<MODE>(s, p, L, t, i, zq[i]);
+                ro_read<MODE, DIRECT>(s, p, L, t, i, zq[i]);
                 const int tn = t + 3 < T ? t + 3 : T - 1;
-                stage_issue<true>(p, d, tn, (i + 3) % NSTAGE);
+                stage_issue<MODE, true, DIRECT>(p, d, tn, (i + 3) % NSTAGE);
                 if (use_zm) zq[(i + 3) % NSTAGE] = zm_load(p, L, tn);
-                if (MULTI) trials_step<MODE>(p, L, s, tr, nt, t);
-                else rollout_step<MODE>(p, L, s, st, t);
+                if (MULTI) trials_step<MODE, DIRECT>(p, L, s, tr, nt, t);
+                else rollout_step<MODE, DIRECT>(p, L, s, st, t);
             }
         }
     }
@@ -551,10 +653,50 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st, 
     if (MULTI) {
 #pragma unroll
         for (int k = 0; k < MAX_TRIALS; ++k)
-            if (k < nt) tr.cost[k] = wv::row_sum(tr.cost[k]);
+            if (k < nt) tr.cost[k] = base + wv::row_sum(tr.cost[k]);
     } else {
-        st.cost = wv::row_sum(st.cost);
+        st.cost = base + wv::row_sum(st.cost);
         st.du2 = wv::row_sum(st.du2);
+    }
+}
+
+// The line search of mpc/lqr_step.py:164-261, every row (problem) on its own.
+template <int MODE, bool DIRECT>
+MPC_DEV void line_search(const P &p, const Lane &L, const Dma &d, RoState &rs, float old_cost, float base, float &full2)
+{
+    Trials tr;
+    rs.alpha = 1.f;
+    rollout_pass<MODE, false, DIRECT>(p, L, d, rs, tr, 0, base);
+    full2 = rs.du2;                                                  // :243-245 (the alpha = 1 trial)
+    // :176-179, 247, 252: the step shrinks while the cost got worse; the first trial that did not get
+    // worse is taken, else the last one.  Backtracking is usually one step deep (box-constrained
+    // problems) or runs to the end (a nominal that is already optimal): try alpha = decay on its own
+    // first, then ALL remaining trials at once.
+    const bool worse0 = rs.cost > old_cost && p.max_ls > 1;
+    if (wv::any(worse0)) {
+        if (worse0) rs.alpha = p.ls_decay;
+        rollout_pass<MODE, false, DIRECT>(p, L, d, rs, tr, 0, base);    // rows that keep alpha = 1 reproduce their result
+        const bool worse1 = worse0 && rs.cost > old_cost && p.max_ls > 2;
+        if (wv::any(worse1)) {
+            const int nt = p.max_ls - 2;                          // trials alpha = decay^2 .. decay^(max_ls-1)
+            float a = p.ls_decay;
+#pragma unroll
+            for (int k = 0; k < MAX_TRIALS; ++k) { a *= p.ls_decay; tr.alpha[k] = a; }
+            rollout_pass<MODE, true, DIRECT>(p, L, d, rs, tr, nt, base);
+            if (worse1) {
+                float acc = tr.alpha[0];
+                bool found = false;
+#pragma unroll
+                for (int k = 0; k < MAX_TRIALS; ++k) {
+                    if (k < nt && !found) {
+                        acc = tr.alpha[k];
+                        if (!(tr.cost[k] > old_cost)) found = true;
+                    }
+                }
+                rs.alpha = acc;
+            }
+            rollout_pass<MODE, false, DIRECT>(p, L, d, rs, tr, 0, base);  // replay the accepted trials
+        }
     }
 }
 
@@ -575,7 +717,8 @@ MPC_DEV void step_wave(const P &p)
 #pragma unroll
     for (int i = 0; i < 12; ++i) ss.Vc[i] = 0.f;
     ss.vv = 0.f;
-    ss.oc = 0.f;
+    ss.oc = 0.0;
+    ss.w0 = 0.0;
     ss.warm = 0;
     ss.qp_total = 0;
     ss.status = 0;
@@ -585,7 +728,7 @@ MPC_DEV void step_wave(const P &p)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int ti = T - 1 - i >= 0 ? T - 1 - i : 0;
-            stage_issue<false>(p, d, ti, i);
+            stage_issue<MODE, false, false>(p, d, ti, i);
             if (MODE == 1) zq[i] = zm_load(p, L, ti);
         }
         for (int k0 = 0; k0 < T; k0 += NSTAGE) {
@@ -597,7 +740,7 @@ MPC_DEV void step_wave(const P &p)
                     SwStage s;
                     sw_read<MODE>(s, p, L, t, i, zq[i]);
                     const int tn = t - 3 >= 0 ? t - 3 : 0;
-                    stage_issue<false>(p, d, tn, (i + 3) % NSTAGE);
+                    stage_issue<MODE, false, false>(p, d, tn, (i + 3) % NSTAGE);
                     if (MODE == 1) zq[(i + 3) % NSTAGE] = zm_load(p, L, tn);
                     sweep_step<MODE>(p, L, s, ss, t);
                 }
@@ -605,47 +748,22 @@ MPC_DEV void step_wave(const P &p)
         }
         wv::dma_wait<0>();
     }
-    const float old_cost = wv::row_sum(ss.oc);
+    const double old_cost_d = wv::row_sum_f64(ss.oc);
+    const float old_cost = (float)old_cost_d;
 
     // the gains were written by this wave and are re-read through the DMA: drain the stores
     wv::fence_own_stores();
 
-    // ---- line-searched rollout (mpc/lqr_step.py:164-261): every row backtracks on its own ------
+    // ---- line-searched rollout (mpc/lqr_step.py:164-261) --------------------------------------
     RoState rs;
-    Trials tr;
-    rs.alpha = 1.f;
-    rollout_pass<MODE, false>(p, L, d, rs, tr, 0);
-    const float full2 = rs.du2;                                      // :243-245 (the alpha = 1 trial)
-    // :176-179, 247, 252: the step shrinks while the cost got worse; the first trial that did not get
-    // worse is taken, else the last one
-    // Backtracking is usually one step deep (box-constrained problems) or runs to the end (a nominal
-    // that is already optimal): try alpha = decay on its own first, then ALL remaining trials at once.
-    const bool worse0 = rs.cost > old_cost && p.max_ls > 1;
-    if (wv::any(worse0)) {
-        if (worse0) rs.alpha = p.ls_decay;
-        rollout_pass<MODE, false>(p, L, d, rs, tr, 0);          // rows that keep alpha = 1 reproduce their result
-        const bool worse1 = worse0 && rs.cost > old_cost && p.max_ls > 2;
-        if (wv::any(worse1)) {
-            const int nt = p.max_ls - 2;                          // trials alpha = decay^2 .. decay^(max_ls-1)
-            float a = p.ls_decay;
-#pragma unroll
-            for (int k = 0; k < MAX_TRIALS; ++k) { a *= p.ls_decay; tr.alpha[k] = a; }
-            rollout_pass<MODE, true>(p, L, d, rs, tr, nt);
-            if (worse1) {
-                float acc = tr.alpha[0];
-                bool found = false;
-#pragma unroll
-                for (int k = 0; k < MAX_TRIALS; ++k) {
-                    if (k < nt && !found) {
-                        acc = tr.alpha[k];
-                        if (!(tr.cost[k] > old_cost)) found = true;
-                    }
-                }
-                rs.alpha = acc;
-            }
-            rollout_pass<MODE, false>(p, L, d, rs, tr, 0);      // replay the accepted trials
-        }
-    }
+    rs.viol = 0.f;
+    float full2 = 0.f;
+    line_search<MODE, false>(p, L, d, rs, old_cost, (float)(old_cost_d + ss.w0), full2);
+    // a nominal that does not obey the dynamics voids the identity the pass was priced with: price the
+    // rollout the reference's way, from a second stream of C
+    const bool broken = wv::row_sum(rs.viol > 0.f ? 1.f : 0.f) > 0.f;
+    if (wv::any(broken)) line_search<MODE, true>(p, L, d, rs, old_cost, 0.f, full2);
+    if (broken) ss.status |= MPC_ST_NOMINAL_OFF_DYNAMICS;
     int status = ss.status;
     if (!(rs.cost == rs.cost) || fabsf(rs.cost) > 3e38f) status |= MPC_ST_NONFINITE;
     if (L.live && L.j == 0) {

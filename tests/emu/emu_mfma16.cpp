@@ -30,6 +30,7 @@ struct Wave {
     // exchange area, two generations
     float fa[2][NL], fb[2][NL];
     float fv[2][NL][16];
+    double fd[2][NL];
     int ia[2][NL];
     unsigned seq[NL];
     // LDS of the (single-wave) workgroup + the in-order queue of LDS-DMA instructions in flight
@@ -226,6 +227,19 @@ static inline float row_sum(float x)
     }
     return x;
 }
+static inline double row_sum_f64(double x)
+{
+    emu::Wave &w = emu::W;
+    for (int step = 0; step < 4; ++step) {
+        const int l = w.cur, gen = w.seq[l]++ & 1;
+        w.fd[gen][l] = x;
+        emu::yield_lane();
+        const int r = l & ~15, j = l & 15;
+        const int src = step == 0 ? (j ^ 1) : step == 1 ? (j ^ 2) : step == 2 ? ((j & 8) | (7 - (j & 7))) : 15 - j;
+        x += w.fd[gen][r + src];
+    }
+    return x;
+}
 static inline bool any(bool c)
 {
     emu::Wave &w = emu::W;
@@ -355,7 +369,7 @@ extern "C" int emu_lqr_step_dpp16(const mpc_lqr_problem *p, const mpc_lqr_option
     if (!sp.new_x || !sp.new_u) return MPC_E_NULL;
     static float *kk_buf = nullptr;
     static size_t kk_cap = 0;
-    const size_t need = (size_t)sp.T * sp.B * 64 + 4;
+    const size_t need = (size_t)sp.T * sp.B * 128 + 4;
     if (need > kk_cap) { free(kk_buf); kk_buf = (float *)aligned_alloc(16, (need * sizeof(float) + 15) / 16 * 16); kk_cap = need; }
     for (size_t i = 0; i < need; ++i) kk_buf[i] = NAN;
     sp.Kk = kk_buf;

@@ -133,6 +133,7 @@ def test_emulated_dpp16_matches_oracle_and_reference(emu, name, dma_late):
     o = O.lqr_step(lockstep=False, return_gains=True, **_f64(kw))
     r = emu.lqr_step(kernel="dpp16", dma_late=dma_late, **kw)
     assert (r["status"] & 2 == 0).all()
+    assert (r["status"] & 4 == 0).all()      # nominal = rollout of its controls: priced without re-reading C
     # box-constrained float32: pnqp stops at |dx| < 1e-4 (mpc/pnqp.py:56), so two correct float32
     # evaluations (and the reference's own float32 vs float64 runs) differ by a few 1e-4 in k
     atol = 1e-3 if ("u_lower" in z and z["C"].dtype == np.float32) else 1e-4
@@ -185,6 +186,7 @@ def test_emulated_dpp16_options_against_oracle(emu, case):
     if case == "backtrack":
         assert len(set(np.round(o["alphas"], 6))) > 1, "rows of one wave must stop at different alphas"
     r = emu.lqr_step(kernel="dpp16", dma_late=True, **kw)
+    assert (r["status"] & 4 == 0).all()
     np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
     np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=2e-4)
@@ -211,3 +213,28 @@ def test_emulated_kkt_dpp16_matches_oracle(emu, bounded, with_f, B, dma_late):
                       dma_late=dma_late)
     for k in ("dC", "dc", "dF", "dx_init") + (("df",) if with_f else ()):
         np.testing.assert_allclose(r[k], o[k], rtol=1e-4, atol=1e-4 * max(1.0, np.abs(o[k]).max()), err_msg=k)
+
+
+@pytest.mark.parametrize("bounded", [False, True])
+def test_emulated_dpp16_nominal_off_the_dynamics(emu, bounded):
+    """current_x that is NOT the rollout of current_u (LQRStep allows it): the cost identity the
+    rollout is normally priced with does not hold, the kernel must notice (status bit 4) and price the
+    trajectory from C like the reference.  Problems 0-2 are off, problem 3 (same wave) and 4 are on."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(11)
+    T, B = 7, 5
+    pr = _ns_problem(rng, T, B)
+    cur_u = np.clip(0.5 * rng.standard_normal((T, B, 4)), -0.4, 0.4)
+    cur_x, _ = O.traj_cost(pr["x_init"], cur_u, pr["F"], pr["f"])
+    cur_x[2:, :3] += 0.05 * rng.standard_normal((T - 2, 3, 12))
+    kw = dict(cur_x=cur_x, cur_u=cur_u, **pr)
+    if bounded:
+        kw.update(u_lower=-0.4, u_upper=0.4)
+    o = O.lqr_step(lockstep=False, **kw)
+    r = emu.lqr_step(kernel="dpp16", dma_late=True, **kw)
+    assert ((r["status"] & 4) != 0).tolist() == [True, True, True, False, False]
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+    np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(r["old_costs"], o["old_costs"], rtol=1e-4)
