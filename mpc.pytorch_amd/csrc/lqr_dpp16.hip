@@ -148,6 +148,19 @@ MPC_DEV void dot_bcast16(float &acc, float src, const float (&m)[16])
         : "v"(src), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]),
           "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]));
 }
+// acc += sum_b bcast_{12+b}(src) * m[b]   (the four control lanes)
+MPC_DEV void dot_bcast_u4(float &acc, float src, const float (&m)[4])
+{
+    float t;
+    asm("s_nop 1\n"
+        "v_mul_f32_dpp %1, %2, %4 row_newbcast:13" DPPM
+        "v_fmac_f32_dpp %0, %2, %3 row_newbcast:12" DPPM
+        "v_fmac_f32_dpp %1, %2, %6 row_newbcast:15" DPPM
+        "v_fmac_f32_dpp %0, %2, %5 row_newbcast:14" DPPM
+        "v_add_f32 %0, %0, %1\n"
+        : "+v"(acc), "=&v"(t)
+        : "v"(src), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]));
+}
 MPC_DEV void dot_bcast12(float &acc, float src, const float (&m)[12])
 {
     float t;

@@ -392,15 +392,16 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #pragma unroll
     for (int i = 0; i < 12; ++i) st.Vc[i] = Vn[i];
     st.vv = vn;
-    // the constant of the value function: w_t = w_{t+1} + 0.5 k'Quu k + qu'k  (k lives in lane 12)
+    // the constant of the value function: w_t = w_{t+1} + 0.5 k'Quu k + qu'k = w_{t+1} + 0.5 k'(m + qu),
+    // m = qu + Quu k (lane 12 of M; zero without constraints)
     {
-        const float k0 = wv::bcast<12>(K[0]), k1 = wv::bcast<12>(K[1]), k2 = wv::bcast<12>(K[2]), k3 = wv::bcast<12>(K[3]);
-        const float kk[4] = {k0, k1, k2, k3};
-        float sk[4];
-        mfma16::sym4_mv(S, kk, sk);
         float w = 0.f;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) w = fmaf(kk[a], fmaf(0.5f, sk[a], qu[a]), w);
+        for (int a = 0; a < 4; ++a) {
+            const float ka = wv::bcast<12>(K[a]);
+            const float ma = MODE != 0 ? wv::bcast<12>(M[a]) : 0.f;
+            w = fmaf(ka, 0.5f * (ma + qu[a]), w);
+        }
         st.w0 += (double)w;
     }
 
@@ -532,8 +533,7 @@ MPC_DEV float stage_price(const Lane &L, const RoStage &s, float tp, float e, fl
         return tp * fmaf(0.5f, sq, s.cj);
     }
     float se = 0.f;
-    wv::fmac_bcast<12>(se, e, s.Sr[0]); wv::fmac_bcast<13>(se, e, s.Sr[1]);
-    wv::fmac_bcast<14>(se, e, s.Sr[2]); wv::fmac_bcast<15>(se, e, s.Sr[3]);
+    wv::dot_bcast_u4(se, e, s.Sr);                 // sum_b bcast_{12+b}(e) Sr[b]
     float lin = 0.5f * se;
     if (MODE != 0) {
         lin += s.mk;
@@ -661,23 +661,27 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st, 
 }
 
 // The line search of mpc/lqr_step.py:164-261, every row (problem) on its own.
+// :176-179, 247, 252: the step shrinks while the cost got worse; the first trial that did not get worse is
+// taken, else the last one.  Backtracking is usually one step deep (box-constrained problems) or runs to
+// the end (a nominal that is already optimal): alpha = 1, then alpha = decay on its own, then ALL
+// remaining trials in one pass and a replay of the accepted ones.
 template <int MODE, bool DIRECT>
 MPC_DEV void line_search(const P &p, const Lane &L, const Dma &d, RoState &rs, float old_cost, float base, float &full2)
 {
     Trials tr;
     rs.alpha = 1.f;
-    rollout_pass<MODE, false, DIRECT>(p, L, d, rs, tr, 0, base);
-    full2 = rs.du2;                                                  // :243-245 (the alpha = 1 trial)
-    // :176-179, 247, 252: the step shrinks while the cost got worse; the first trial that did not get
-    // worse is taken, else the last one.  Backtracking is usually one step deep (box-constrained
-    // problems) or runs to the end (a nominal that is already optimal): try alpha = decay on its own
-    // first, then ALL remaining trials at once.
-    const bool worse0 = rs.cost > old_cost && p.max_ls > 1;
-    if (wv::any(worse0)) {
-        if (worse0) rs.alpha = p.ls_decay;
-        rollout_pass<MODE, false, DIRECT>(p, L, d, rs, tr, 0, base);    // rows that keep alpha = 1 reproduce their result
-        const bool worse1 = worse0 && rs.cost > old_cost && p.max_ls > 2;
-        if (wv::any(worse1)) {
+    bool worse0 = false;
+#pragma unroll 1
+    for (int phase = 0; phase < 3; ++phase) {
+        rollout_pass<MODE, false, DIRECT>(p, L, d, rs, tr, 0, base);   // rows whose alpha did not change reproduce their result
+        if (phase == 0) {
+            full2 = rs.du2;                                          // :243-245 (the alpha = 1 trial)
+            worse0 = rs.cost > old_cost && p.max_ls > 1;
+            if (!wv::any(worse0)) break;
+            if (worse0) rs.alpha = p.ls_decay;
+        } else if (phase == 1) {
+            const bool worse1 = worse0 && rs.cost > old_cost && p.max_ls > 2;
+            if (!wv::any(worse1)) break;
             const int nt = p.max_ls - 2;                          // trials alpha = decay^2 .. decay^(max_ls-1)
             float a = p.ls_decay;
 #pragma unroll
@@ -695,7 +699,6 @@ MPC_DEV void line_search(const P &p, const Lane &L, const Dma &d, RoState &rs, f
                 }
                 rs.alpha = acc;
             }
-            rollout_pass<MODE, false, DIRECT>(p, L, d, rs, tr, 0, base);  // replay the accepted trials
         }
     }
 }

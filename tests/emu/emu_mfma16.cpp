@@ -206,6 +206,19 @@ template <int NN> static inline void dot_bcast(float &acc, float src, const floa
     acc += t;
 }
 static inline void dot_bcast16(float &acc, float src, const float (&m)[16]) { dot_bcast<16>(acc, src, m); }
+static inline void dot_bcast_u4(float &acc, float src, const float (&m)[4])
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = src;
+    emu::yield_lane();
+    const int r = l & ~15;
+    float t = w.fa[gen][r + 13] * m[1];
+    acc = fmaf(w.fa[gen][r + 12], m[0], acc);
+    t = fmaf(w.fa[gen][r + 15], m[3], t);
+    acc = fmaf(w.fa[gen][r + 14], m[2], acc);
+    acc += t;
+}
 static inline void dot_bcast12(float &acc, float src, const float (&m)[12]) { dot_bcast<12>(acc, src, m); }
 static inline float row_sum(float x)
 {
