@@ -55,6 +55,76 @@ template <int M, int NS> MPC_DEV void fma_bcast_lane12(float (&a)[12], const flo
         : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]),
           "v"(s[9]), "v"(s[10]), "v"(s[11]), "v"(mul), "n"(M));
 }
+// two of the above in one block: a[i] += bcast_M(s[i]) * mul0 + bcast_{M+1}(s[i]) * mul1
+template <int M, int NS> MPC_DEV void fma_bcast_lane12x2(float (&a)[12], const float (&s)[NS], float mul0, float mul1)
+{
+    asm("s_nop 1\n"
+        "v_fmac_f32_dpp %0, %12, %24 row_newbcast:%26" DPPM
+        "v_fmac_f32_dpp %1, %13, %24 row_newbcast:%26" DPPM
+        "v_fmac_f32_dpp %2, %14, %24 row_newbcast:%26" DPPM
+        "v_fmac_f32_dpp %3, %15, %24 row_newbcast:%26" DPPM
+        "v_fmac_f32_dpp %4, %16, %24 row_newbcast:%26" DPPM
+        "v_fmac_f32_dpp %5, %17, %24 row_newbcast:%26" DPPM
+        "v_fmac_f32_dpp %6, %18, %24 row_newbcast:%26" DPPM
+        "v_fmac_f32_dpp %7, %19, %24 row_newbcast:%26" DPPM
+        "v_fmac_f32_dpp %8, %20, %24 row_newbcast:%26" DPPM
+        "v_fmac_f32_dpp %9, %21, %24 row_newbcast:%26" DPPM
+        "v_fmac_f32_dpp %10, %22, %24 row_newbcast:%26" DPPM
+        "v_fmac_f32_dpp %11, %23, %24 row_newbcast:%26" DPPM
+        "v_fmac_f32_dpp %0, %12, %25 row_newbcast:%27" DPPM
+        "v_fmac_f32_dpp %1, %13, %25 row_newbcast:%27" DPPM
+        "v_fmac_f32_dpp %2, %14, %25 row_newbcast:%27" DPPM
+        "v_fmac_f32_dpp %3, %15, %25 row_newbcast:%27" DPPM
+        "v_fmac_f32_dpp %4, %16, %25 row_newbcast:%27" DPPM
+        "v_fmac_f32_dpp %5, %17, %25 row_newbcast:%27" DPPM
+        "v_fmac_f32_dpp %6, %18, %25 row_newbcast:%27" DPPM
+        "v_fmac_f32_dpp %7, %19, %25 row_newbcast:%27" DPPM
+        "v_fmac_f32_dpp %8, %20, %25 row_newbcast:%27" DPPM
+        "v_fmac_f32_dpp %9, %21, %25 row_newbcast:%27" DPPM
+        "v_fmac_f32_dpp %10, %22, %25 row_newbcast:%27" DPPM
+        "v_fmac_f32_dpp %11, %23, %25 row_newbcast:%27" DPPM
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]), "v"(s[11]), "v"(mul0), "v"(mul1), "n"(M), "n"(M + 1));
+}
+// a[i] += bcast_i(src0) * mul0 + bcast_i(src1) * mul1
+MPC_DEV void fma_bcast_each16x2(float (&a)[16], float src0, float mul0, float src1, float mul1)
+{
+    asm("s_nop 1\n"
+        "v_fmac_f32_dpp %0, %16, %17 row_newbcast:0" DPPM
+        "v_fmac_f32_dpp %1, %16, %17 row_newbcast:1" DPPM
+        "v_fmac_f32_dpp %2, %16, %17 row_newbcast:2" DPPM
+        "v_fmac_f32_dpp %3, %16, %17 row_newbcast:3" DPPM
+        "v_fmac_f32_dpp %4, %16, %17 row_newbcast:4" DPPM
+        "v_fmac_f32_dpp %5, %16, %17 row_newbcast:5" DPPM
+        "v_fmac_f32_dpp %6, %16, %17 row_newbcast:6" DPPM
+        "v_fmac_f32_dpp %7, %16, %17 row_newbcast:7" DPPM
+        "v_fmac_f32_dpp %8, %16, %17 row_newbcast:8" DPPM
+        "v_fmac_f32_dpp %9, %16, %17 row_newbcast:9" DPPM
+        "v_fmac_f32_dpp %10, %16, %17 row_newbcast:10" DPPM
+        "v_fmac_f32_dpp %11, %16, %17 row_newbcast:11" DPPM
+        "v_fmac_f32_dpp %12, %16, %17 row_newbcast:12" DPPM
+        "v_fmac_f32_dpp %13, %16, %17 row_newbcast:13" DPPM
+        "v_fmac_f32_dpp %14, %16, %17 row_newbcast:14" DPPM
+        "v_fmac_f32_dpp %15, %16, %17 row_newbcast:15" DPPM
+        "v_fmac_f32_dpp %0, %18, %19 row_newbcast:0" DPPM
+        "v_fmac_f32_dpp %1, %18, %19 row_newbcast:1" DPPM
+        "v_fmac_f32_dpp %2, %18, %19 row_newbcast:2" DPPM
+        "v_fmac_f32_dpp %3, %18, %19 row_newbcast:3" DPPM
+        "v_fmac_f32_dpp %4, %18, %19 row_newbcast:4" DPPM
+        "v_fmac_f32_dpp %5, %18, %19 row_newbcast:5" DPPM
+        "v_fmac_f32_dpp %6, %18, %19 row_newbcast:6" DPPM
+        "v_fmac_f32_dpp %7, %18, %19 row_newbcast:7" DPPM
+        "v_fmac_f32_dpp %8, %18, %19 row_newbcast:8" DPPM
+        "v_fmac_f32_dpp %9, %18, %19 row_newbcast:9" DPPM
+        "v_fmac_f32_dpp %10, %18, %19 row_newbcast:10" DPPM
+        "v_fmac_f32_dpp %11, %18, %19 row_newbcast:11" DPPM
+        "v_fmac_f32_dpp %12, %18, %19 row_newbcast:12" DPPM
+        "v_fmac_f32_dpp %13, %18, %19 row_newbcast:13" DPPM
+        "v_fmac_f32_dpp %14, %18, %19 row_newbcast:14" DPPM
+        "v_fmac_f32_dpp %15, %18, %19 row_newbcast:15" DPPM
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+        : "v"(src0), "v"(mul0), "v"(src1), "v"(mul1));
+}
 // acc[i] += bcast_i(src) * mul
 MPC_DEV void fma_bcast_each16(float (&a)[16], float src, float mul)
 {

@@ -124,7 +124,7 @@ struct Dma {
     const char *g_ptr;        // per lane
     const char *g2_ptr;       // per lane: the (m, M) record
     long c_step, f_step, r_step, g_step;
-    bool r_active, r_is_f;
+    bool r_active, r_is_f, r_is_c;
 };
 
 template <int MODE>
@@ -152,6 +152,7 @@ MPC_DEV void dma_init(Dma &d, const P &p, const Lane &L, int wave)
         d.r_is_f = false;
         const char *q = (const char *)p.c;
         long st = 0;
+        d.r_is_c = gi < 4;
         if (gi < 4) { d.r_active = true; q = (const char *)(p.c + pb * p.c_sb + 4 * gi); st = 4 * p.c_st; }
         else if (gi < 7) { d.r_active = true; q = (const char *)(p.cur_x + pb * 12 + 4 * (gi - 4)); st = 4 * B * 12; }
         else if (gi == 7) { d.r_active = true; q = (const char *)(p.cur_u + pb * 4); st = 4 * B * 4; }
@@ -186,7 +187,8 @@ MPC_DEV void stage_issue(const P &p, const Dma &d, int t, int slot)
     // the record instruction is issued by every wave even if only some lanes take part
     {
         const char *src = d.r_ptr + (d.r_is_f ? tf : tl) * d.r_step;
-        wv::dma16_if(d.r_active, src, base + SR);
+        // the identity-priced rollout never looks at c; the sweep never looks at f
+        wv::dma16_if(d.r_active && !(ROLL && !DIRECT && d.r_is_c) && !(!ROLL && d.r_is_f), src, base + SR);
     }
     if (ROLL) {
         wv::dma16(d.g_ptr + tl * d.g_step, base + SG);
@@ -276,14 +278,11 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         float Y[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) Y[i] = 0.f;
-        wv::fma_bcast_lane12<0>(Y, st.Vc, s.Fc[0]);   wv::fma_bcast_lane12<1>(Y, st.Vc, s.Fc[1]);
-        wv::fma_bcast_lane12<2>(Y, st.Vc, s.Fc[2]);   wv::fma_bcast_lane12<3>(Y, st.Vc, s.Fc[3]);
-        wv::fma_bcast_lane12<4>(Y, st.Vc, s.Fc[4]);   wv::fma_bcast_lane12<5>(Y, st.Vc, s.Fc[5]);
-        wv::fma_bcast_lane12<6>(Y, st.Vc, s.Fc[6]);   wv::fma_bcast_lane12<7>(Y, st.Vc, s.Fc[7]);
-        wv::fma_bcast_lane12<8>(Y, st.Vc, s.Fc[8]);   wv::fma_bcast_lane12<9>(Y, st.Vc, s.Fc[9]);
-        wv::fma_bcast_lane12<10>(Y, st.Vc, s.Fc[10]); wv::fma_bcast_lane12<11>(Y, st.Vc, s.Fc[11]);
+        wv::fma_bcast_lane12x2<0>(Y, st.Vc, s.Fc[0], s.Fc[1]);   wv::fma_bcast_lane12x2<2>(Y, st.Vc, s.Fc[2], s.Fc[3]);
+        wv::fma_bcast_lane12x2<4>(Y, st.Vc, s.Fc[4], s.Fc[5]);   wv::fma_bcast_lane12x2<6>(Y, st.Vc, s.Fc[6], s.Fc[7]);
+        wv::fma_bcast_lane12x2<8>(Y, st.Vc, s.Fc[8], s.Fc[9]);   wv::fma_bcast_lane12x2<10>(Y, st.Vc, s.Fc[10], s.Fc[11]);
 #pragma unroll
-        for (int m = 0; m < 12; ++m) wv::fma_bcast_each16(Q, s.Fc[m], Y[m]);
+        for (int m = 0; m < 12; m += 2) wv::fma_bcast_each16x2(Q, s.Fc[m], Y[m], s.Fc[m + 1], Y[m + 1]);
         wv::dot_bcast12(q, st.vv, s.Fc);
     }
 
@@ -369,10 +368,8 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     float Vn[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Vn[i] = Q[i];
-    wv::fma_bcast_lane12<12>(Vn, Q, K[0]);      // += Q[i][12+a] K[a][j]
-    wv::fma_bcast_lane12<13>(Vn, Q, K[1]);
-    wv::fma_bcast_lane12<14>(Vn, Q, K[2]);
-    wv::fma_bcast_lane12<15>(Vn, Q, K[3]);
+    wv::fma_bcast_lane12x2<12>(Vn, Q, K[0], K[1]);      // += Q[i][12+a] K[a][j]
+    wv::fma_bcast_lane12x2<14>(Vn, Q, K[2], K[3]);
     float vn = q;
     wv::fmac_bcast<12>(vn, K[0], Q[12]); wv::fmac_bcast<12>(vn, K[1], Q[13]);
     wv::fmac_bcast<12>(vn, K[2], Q[14]); wv::fmac_bcast<12>(vn, K[3], Q[15]);

@@ -35,7 +35,7 @@ struct Wave {
     unsigned seq[NL];
     // LDS of the (single-wave) workgroup + the in-order queue of LDS-DMA instructions in flight
     unsigned char lds[4 * 9216];            // the larger of the two kernels' rings
-    struct Dma { unsigned char data[NL][16]; bool act[NL]; unsigned off; int size; };
+    struct Dma { unsigned char data[NL][16]; bool act[NL]; unsigned char seen[NL]; unsigned off; int size; };
     Dma q[64];
     int qn;
     int region_start;     // queue entries from here on belong to the current lockstep region
@@ -180,6 +180,16 @@ template <int NN> static inline void fma_bcast_each(float (&a)[NN], float src, f
     for (int i = 0; i < NN; ++i) a[i] = fmaf(w.fa[gen][(l & ~15) + i], mul, a[i]);
 }
 static inline void fma_bcast_each16(float (&a)[16], float src, float mul) { fma_bcast_each<16>(a, src, mul); }
+static inline void fma_bcast_each16x2(float (&a)[16], float s0, float m0, float s1, float m1)
+{
+    fma_bcast_each<16>(a, s0, m0);
+    fma_bcast_each<16>(a, s1, m1);
+}
+template <int M, int NS> static inline void fma_bcast_lane12x2(float (&a)[12], const float (&s)[NS], float m0, float m1)
+{
+    fma_bcast_lane12<M, NS>(a, s, m0);
+    fma_bcast_lane12<M + 1, NS>(a, s, m1);
+}
 static inline void mul_bcast_each16(float (&a)[16], float src, float mul)
 {
     for (int i = 0; i < 16; ++i) a[i] = -0.f;
@@ -280,25 +290,29 @@ static inline int ctz64(unsigned long long m) { return __builtin_ctzll(m); }
 // ---- LDS-DMA.  Between two lockstep points every lane runs the same instruction sequence (lanes
 // that branch around an instruction are inactive for it), and each DMA instruction of such a region
 // has its own LDS destination, so (offset, size) identifies the instruction a lane is taking part in.
-static inline void dma_n(const void *g, unsigned off, int size)
+static inline void dma_n(const void *g, unsigned off, int size, bool active = true)
 {
     emu::Wave &w = emu::W;
     const int l = w.cur;
     emu::Wave::Dma *d = nullptr;
     for (int i = w.region_start; i < w.qn; ++i)
-        if (w.q[i].off == off && w.q[i].size == size && !w.q[i].act[l]) { d = &w.q[i]; break; }
+        if (w.q[i].off == off && w.q[i].size == size && w.q[i].seen[l] == 0) { d = &w.q[i]; break; }
     if (!d) {
         if (w.qn >= 64) { fprintf(stderr, "emu: DMA queue overflow\n"); abort(); }
         d = &w.q[w.qn++];
         memset(d->act, 0, sizeof(d->act));
+        memset(d->seen, 0, sizeof(d->seen));
         d->off = off;
         d->size = size;
     }
+    d->seen[l] = 1;
+    // an exec-masked lane still passes the instruction: it takes its place in program order
+    if (!active) return;
     d->act[l] = true;
     memcpy(d->data[l], g, size);
 }
 static inline void dma16(const void *g, unsigned off) { dma_n(g, off, 16); }
-static inline void dma16_if(bool active, const void *g, unsigned off) { if (active) dma_n(g, off, 16); }
+static inline void dma16_if(bool active, const void *g, unsigned off) { dma_n(g, off, 16, active); }
 static inline void dma4(const void *g, unsigned off) { dma_n(g, off, 4); }
 template <int N> static inline void dma_wait()
 {
