@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPC_LQR_ABI_VERSION 1
+#define MPC_LQR_ABI_VERSION 2
 
 enum { MPC_F32 = 0, MPC_F64 = 1 };
 enum { MPC_BOUND_NONE = 0, MPC_BOUND_SCALAR = 1, MPC_BOUND_TENSOR = 2 };
@@ -47,6 +47,23 @@ enum {
     MPC_ST_NOMINAL_OFF_DYNAMICS = 4 /* informational (DPP kernel): current_x is not the rollout of current_u,
                                       the trajectory cost was evaluated from a second pass over C            */
 };
+
+/* The simulator dynamics the reference ships (mpc/env_dx/pendulum.py:18-84, cartpole.py:28-96),
+ * usable as the `true_dynamics` of a step (mpc/lqr_step.py:223-225) and linearised in closed form
+ * (replaces the (T-1)*n_state autograd passes of mpc/mpc.py:514-549).  n_ctrl = 1. */
+enum {
+    MPC_ENV_NONE = 0,
+    MPC_ENV_PENDULUM = 1,        /* PendulumDx(simple=True):  params (g, m, l),       n_state 3 */
+    MPC_ENV_PENDULUM_FULL = 2,   /* PendulumDx(simple=False): params (g, m, l, d, b), n_state 3 */
+    MPC_ENV_CARTPOLE = 3         /* CartpoleDx: params (gravity, masscart, masspole, length), n_state 5 */
+};
+typedef struct mpc_env_dynamics {
+    int32_t kind;                 /* MPC_ENV_* */
+    int32_t _pad;
+    const void *params;           /* DEVICE pointer, dtype of the problem, 3 / 5 / 4 values */
+    double dt;                    /* 0.05 in both modules */
+    double u_max;                 /* max_torque (2.0) / force_mag (100.0): the module clamps u to +-u_max */
+} mpc_env_dynamics;
 
 /* The problem data of one LQRStepFn.forward call: (x_init, C, c, F, f) plus the
  * closure state `current_x/current_u` (mpc/lqr_step.py:22-38, 277). */
@@ -75,6 +92,8 @@ typedef struct mpc_lqr_options {
     double linesearch_decay;          /* default 0.2 */
     int32_t pnqp_iter;                /* n_iter of the in-sweep pnqp, 20 (mpc/lqr_step.py:137) */
     int32_t _pad;
+    const mpc_env_dynamics *true_dynamics; /* NULL = LinDx(F,f) (mpc/lqr_step.py:216-222); else the rollout
+                                              calls the simulator (:223-225) -- generic kernels only */
 } mpc_lqr_options;
 
 /* Outputs of LQRStepFn.forward (mpc/lqr_step.py:308-309) and LqrForOut (:17-20).
@@ -152,6 +171,17 @@ int mpc_pnqp(int dtype, int B, int n, const void *H, const void *q, const void *
 /* (6) util.get_traj (LinDx) + util.get_cost (QuadCost), mpc/util.py:102-153.
  *     u = p->cur_u; writes x [T,B,ns] (if non-NULL) and cost [B] (if non-NULL and p->C set). */
 int mpc_traj_cost(const mpc_lqr_problem *p, void *x, void *cost, void *stream);
+
+/* (6b) util.get_traj with a shipped simulator as dynamics (mpc/util.py:107-113) + util.get_cost;
+ *     p->F/f are ignored (may be NULL), p->C/c optional as in (6). */
+int mpc_env_traj_cost(const mpc_lqr_problem *p, const mpc_env_dynamics *env, void *x, void *cost,
+                      void *stream);
+
+/* (6c) MPC.linearize_dynamics for a shipped simulator (mpc/mpc.py:490-549):
+ *     over N = (T-1)*B points (x [N,ns], u [N,1]):  F [N,ns,ns+1] = d env / d [x;u] (exact),
+ *     f [N,ns] = env(x,u) - F [x;u].  One thread per point. */
+int mpc_env_linearize(const mpc_env_dynamics *env, int dtype, int64_t N, const void *x, const void *u,
+                      void *F, void *f, void *stream);
 
 /* (7) Device-side pieces of the iLQR driver loop (mpc/mpc.py:271-285, 299):
  *     per-problem best-iterate select without host round trips.

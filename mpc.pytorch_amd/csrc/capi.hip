@@ -31,6 +31,15 @@ static int check_problem(const mpc_lqr_problem *p, bool need_cost, bool need_nom
     return MPC_OK;
 }
 
+static int check_env(const mpc_env_dynamics *e, int ns, int nc)
+{
+    if (e->kind < MPC_ENV_PENDULUM || e->kind > MPC_ENV_CARTPOLE) return fail(MPC_E_ARG, "unknown simulator kind");
+    if (!e->params) return fail(MPC_E_NULL, "simulator params is NULL");
+    if (nc != 1 || ns != env_ns(e->kind)) return fail(MPC_E_DIMS, "n_state / n_ctrl do not match the simulator");
+    if (!(e->dt > 0) || !(e->u_max >= 0)) return fail(MPC_E_ARG, "simulator dt / u_max");
+    return MPC_OK;
+}
+
 static int check_options(const mpc_lqr_problem *p, const mpc_lqr_options *o)
 {
     if (!o) return MPC_OK;
@@ -40,6 +49,10 @@ static int check_options(const mpc_lqr_problem *p, const mpc_lqr_options *o)
     // mpc/lqr_step.py:195: delta_u without bounds is unimplemented in the reference as well
     if (o->delta_u == o->delta_u && o->delta_u >= 0 && o->bound_mode == MPC_BOUND_NONE)
         return fail(MPC_E_ARG, "delta_u requires u_lower/u_upper (mpc/lqr_step.py:195)");
+    if (o->true_dynamics) {
+        int rc = check_env(o->true_dynamics, p->ns, p->nc);
+        if (rc) return rc;
+    }
     return MPC_OK;
 }
 
@@ -55,7 +68,9 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
     }
     const int64_t needK = (int64_t)p->T * p->B * p->nc * p->ns * (int64_t)sizeof(real);
     const int64_t needk = (int64_t)p->T * p->B * p->nc * (int64_t)sizeof(real);
-    if (phase_mask == 3 && impl != 1) {
+    if (sp.env.kind && (impl == 2 || impl == 3))
+        return fail(MPC_E_ARG, "a simulator as true_dynamics runs on the generic kernels only");
+    if (phase_mask == 3 && impl != 1 && !sp.env.kind) {
         if constexpr (sizeof(real) == 4) {
             // the fused kernels park their gains [T,B,64] in the workspace; out->K / out->k are optional
             const int64_t need = (int64_t)p->T * p->B * 128 * (int64_t)sizeof(float);   // gain record + (m, M) record
@@ -188,6 +203,49 @@ int mpc_lqr_kkt_grads(const mpc_lqr_problem *p, const void *dx, const void *du, 
     return launch_kkt_grads<double>(sp, (const double *)dx, (const double *)du, (const double *)dl_dx,
                                     (const double *)dl_du, (double *)dC, (double *)dc, (double *)dF, (double *)df,
                                     (double *)dx_init, st);
+}
+
+int mpc_env_traj_cost(const mpc_lqr_problem *p, const mpc_env_dynamics *env, void *x, void *cost, void *stream)
+{
+    if (!p || !env) return fail(MPC_E_NULL, "problem / simulator is NULL");
+    if (p->B < 0 || p->T < 1) return fail(MPC_E_DIMS, "need B>=0, T>=1");
+    if (p->dtype != MPC_F32 && p->dtype != MPC_F64) return fail(MPC_E_DTYPE, "dtype must be MPC_F32 or MPC_F64");
+    int rc = check_env(env, p->ns, p->nc);
+    if (rc) return rc;
+    if (p->B == 0) return MPC_OK;
+    if (!p->x_init || !p->cur_u) return fail(MPC_E_NULL, "x_init / u is NULL");
+    if (cost && (!p->C || !p->c)) return fail(MPC_E_NULL, "cost requested but C / c is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (p->dtype == MPC_F32) {
+        StepParams<float> sp = make_params<float>(p, nullptr, nullptr);
+        set_env(sp.env, env);
+        return launch_traj_cost<float>(sp, (float *)x, (float *)cost, st);
+    }
+    StepParams<double> sp = make_params<double>(p, nullptr, nullptr);
+    set_env(sp.env, env);
+    return launch_traj_cost<double>(sp, (double *)x, (double *)cost, st);
+}
+
+int mpc_env_linearize(const mpc_env_dynamics *env, int dtype, int64_t N, const void *x, const void *u, void *F,
+                      void *f, void *stream)
+{
+    if (!env) return fail(MPC_E_NULL, "simulator is NULL");
+    if (dtype != MPC_F32 && dtype != MPC_F64) return fail(MPC_E_DTYPE, "bad dtype");
+    if (env->kind < MPC_ENV_PENDULUM || env->kind > MPC_ENV_CARTPOLE) return fail(MPC_E_ARG, "unknown simulator kind");
+    int rc = check_env(env, env_ns(env->kind), 1);
+    if (rc) return rc;
+    if (N < 0) return fail(MPC_E_DIMS, "N < 0");
+    if (N == 0) return MPC_OK;
+    if (!x || !u || !F || !f) return fail(MPC_E_NULL, "env_linearize: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MPC_F32) {
+        EnvDesc<float> e;
+        set_env(e, env);
+        return launch_env_linearize<float>(e, (long)N, (const float *)x, (const float *)u, (float *)F, (float *)f, st);
+    }
+    EnvDesc<double> e;
+    set_env(e, env);
+    return launch_env_linearize<double>(e, (long)N, (const double *)x, (const double *)u, (double *)F, (double *)f, st);
 }
 
 int mpc_lqr_kkt_prepare(int dtype, int B, int T, int ns, int nc, const void *dl_dx, const void *dl_du,

@@ -1,0 +1,114 @@
+// env_dynamics.h -- the simulator dynamics the reference ships (mpc/env_dx/pendulum.py:49-84,
+// mpc/env_dx/cartpole.py:63-96) as device functions: one transition and its exact Jacobian.
+//
+// The reference linearises these modules with (T-1)*n_state autograd passes per iLQR iteration
+// (mpc/mpc.py:514-549) and calls them once per timestep per line-search pass from Python
+// (mpc/lqr_step.py:223-225).  Here the transition is evaluated inside the rollout kernel and the
+// Jacobian in closed form by one thread per trajectory point.
+#pragma once
+#include <math.h>
+#include "../../include/mpc_lqr.h"
+
+namespace mpclqr {
+
+#ifdef __HIPCC__
+#define MPC_HD __host__ __device__ __forceinline__
+#else
+#define MPC_HD inline
+#endif
+
+template <typename real> struct EnvDesc {
+    int kind;            // MPC_ENV_*
+    const real *params;  // device pointer: pendulum (g,m,l[,d,b]), cartpole (g,mcart,mpole,l)
+    real dt, u_max;
+};
+
+MPC_HD int env_ns(int kind) { return kind == MPC_ENV_CARTPOLE ? 5 : 3; }
+MPC_HD int env_np(int kind) { return kind == MPC_ENV_PENDULUM ? 3 : (kind == MPC_ENV_PENDULUM_FULL ? 5 : 4); }
+
+// One transition x+ = env(x,u).  If J != nullptr also d x+ / d [x;u], row-major [ns][ns+1].
+// The control passes through clamp(u, -u_max, u_max) (pendulum.py:66, cartpole.py:73); its
+// derivative is 1 on the closed interval, as torch.clamp's.
+template <typename real>
+MPC_HD void env_step(const EnvDesc<real> &e, const real *x, real u, real *out, real *J)
+{
+    const real dt = e.dt;
+    const real uc = u < -e.u_max ? -e.u_max : (u > e.u_max ? e.u_max : u);
+    const real du = (u >= -e.u_max && u <= e.u_max) ? (real)1 : (real)0;
+    if (e.kind == MPC_ENV_CARTPOLE) {
+        const real g = e.params[0], mc = e.params[1], mp = e.params[2], l = e.params[3];
+        const real mt = mp + mc, pml = mp * l;
+        const real px = x[0], v = x[1], c = x[2], s = x[3], w = x[4];
+        const real th = atan2(s, c);
+        const real ci = (uc + pml * w * w * s) / mt;
+        const real D = l * ((real)(4.0 / 3.0) - mp * c * c / mt);
+        const real N = g * s - c * ci;
+        const real ta = N / D;
+        const real xa = ci - pml * ta * c / mt;
+        const real th2 = th + dt * w;
+        const real c2 = cos(th2), s2 = sin(th2);
+        out[0] = px + dt * v;
+        out[1] = v + dt * xa;
+        out[2] = c2;
+        out[3] = s2;
+        out[4] = w + dt * ta;
+        if (J) {
+            const real r2 = c * c + s * s;
+            const real th_c = -s / r2, th_s = c / r2;
+            // columns: 0 x, 1 v, 2 c, 3 s, 4 w, 5 u
+            const real ci_s = pml * w * w / mt, ci_w = 2 * pml * w * s / mt, ci_u = du / mt;
+            const real D_c = -2 * l * mp * c / mt;
+            const real ta_c = (-ci - ta * D_c) / D;
+            const real ta_s = (g - c * ci_s) / D;
+            const real ta_w = (-c * ci_w) / D;
+            const real ta_u = (-c * ci_u) / D;
+            const real k = pml / mt;
+            const real xa_c = -k * (ta_c * c + ta);
+            const real xa_s = ci_s - k * ta_s * c;
+            const real xa_w = ci_w - k * ta_w * c;
+            const real xa_u = ci_u - k * ta_u * c;
+            for (int i = 0; i < 30; ++i) J[i] = 0;
+            J[0 * 6 + 0] = 1; J[0 * 6 + 1] = dt;
+            J[1 * 6 + 1] = 1; J[1 * 6 + 2] = dt * xa_c; J[1 * 6 + 3] = dt * xa_s;
+            J[1 * 6 + 4] = dt * xa_w; J[1 * 6 + 5] = dt * xa_u;
+            J[2 * 6 + 2] = -s2 * th_c; J[2 * 6 + 3] = -s2 * th_s; J[2 * 6 + 4] = -s2 * dt;
+            J[3 * 6 + 2] = c2 * th_c;  J[3 * 6 + 3] = c2 * th_s;  J[3 * 6 + 4] = c2 * dt;
+            J[4 * 6 + 2] = dt * ta_c; J[4 * 6 + 3] = dt * ta_s; J[4 * 6 + 4] = 1 + dt * ta_w;
+            J[4 * 6 + 5] = dt * ta_u;
+        }
+        return;
+    }
+    // pendulum: state (cos th, sin th, dth)
+    const real g = e.params[0], m = e.params[1], l = e.params[2];
+    const real c = x[0], s = x[1], w = x[2];
+    const real th = atan2(s, c);
+    const real kg = (real)1.5 * g / l, ku = (real)3 / (m * l * l);
+    real acc, acc_th = 0;     // acc_th: derivative of the acceleration through th (full model)
+    if (e.kind == MPC_ENV_PENDULUM) {
+        acc = kg * s + ku * uc;                                   // pendulum.py:70-71 (raw sin_th)
+    } else {
+        const real d = e.params[3], b = e.params[4];
+        acc = kg * sin(th + b) + ku * uc - d * th;                // pendulum.py:73-75
+        acc_th = kg * cos(th + b) - d;
+    }
+    const real w2 = w + dt * acc;
+    const real th2 = th + dt * w2;
+    const real c2 = cos(th2), s2 = sin(th2);
+    out[0] = c2;
+    out[1] = s2;
+    out[2] = w2;
+    if (J) {
+        const real r2 = c * c + s * s;
+        const real th_c = -s / r2, th_s = c / r2;
+        real w_c, w_s;
+        if (e.kind == MPC_ENV_PENDULUM) { w_c = 0; w_s = dt * kg; }
+        else { w_c = dt * acc_th * th_c; w_s = dt * acc_th * th_s; }
+        const real w_u = dt * ku * du;
+        const real t_c = th_c + dt * w_c, t_s = th_s + dt * w_s, t_w = dt, t_u = dt * w_u;
+        J[0] = -s2 * t_c; J[1] = -s2 * t_s; J[2] = -s2 * t_w; J[3] = -s2 * t_u;
+        J[4] = c2 * t_c;  J[5] = c2 * t_s;  J[6] = c2 * t_w;  J[7] = c2 * t_u;
+        J[8] = w_c;       J[9] = w_s;       J[10] = 1;        J[11] = w_u;
+    }
+}
+
+}  // namespace mpclqr

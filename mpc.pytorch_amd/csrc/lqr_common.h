@@ -33,6 +33,8 @@ template <typename real> int launch_select_best(int B, int T, int ns, int nc, in
                                                 const real *x, const real *u, const real *costs,
                                                 const real *du_norm, real *bx, real *bu, real *bc,
                                                 real *bd, int *any_improved, real *max_du, hipStream_t st);
+template <typename real> int launch_env_linearize(const EnvDesc<real> &env, long N, const real *x, const real *u,
+                                                  real *F, real *f, hipStream_t st);
 size_t generic_lds_bytes(int ns, int nc, size_t elem);
 
 // 4-problems-per-wave DPP path for n_state = 12, n_ctrl = 4, f32 (lqr_dpp16.hip)

@@ -433,7 +433,7 @@ __device__ void rollout_problem(const StepParams<real> &p, int b, Smem<real> &s,
             const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
             const real *Kg = Ksrc + tb * nc * ns, *kg = ksrc + tb * nc;
             for (int e = tid; e < n * n; e += nt) s.Q[e] = Ct[e];
-            if (t < T - 1) {
+            if (t < T - 1 && !p.env.kind) {
                 const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
                 for (int e = tid; e < ns * n; e += nt) s.F[e] = Ft[e];
             }
@@ -465,7 +465,9 @@ __device__ void rollout_problem(const StepParams<real> &p, int b, Smem<real> &s,
                 for (int j = 0; j < n; ++j) r += s.Q[i * n + j] * s.tau[j];
                 ca += (real)0.5 * s.tau[i] * r + ct[i] * s.tau[i];
             }
-            if (t < T - 1) {                                           // :216-222
+            if (t < T - 1 && p.env.kind) {                             // :223-225, a shipped simulator
+                if (tid == 0) env_step<real>(p.env, s.tau, s.tau[ns], s.xn2, nullptr);
+            } else if (t < T - 1) {                                    // :216-222
                 const real *ft = p.f ? p.f + (long)t * p.f_st + (long)b * p.f_sb : nullptr;
                 for (int i = tid; i < ns; i += nt) {
                     real r = 0;
@@ -610,7 +612,7 @@ __global__ void __launch_bounds__(MAX_THREADS) traj_cost_kernel(StepParams<real>
             const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
             for (int e = tid; e < n * n; e += nt) s.Q[e] = Ct[e];
         }
-        if (t < T - 1) {
+        if (t < T - 1 && !p.env.kind) {
             const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
             for (int e = tid; e < ns * n; e += nt) s.F[e] = Ft[e];
         }
@@ -624,7 +626,9 @@ __global__ void __launch_bounds__(MAX_THREADS) traj_cost_kernel(StepParams<real>
                 ca += (real)0.5 * s.tau[i] * r + ct[i] * s.tau[i];
             }
         }
-        if (t < T - 1) {
+        if (t < T - 1 && p.env.kind) {                                 // mpc/util.py:112-113
+            if (tid == 0) env_step<real>(p.env, s.tau, s.tau[ns], s.xn2, nullptr);
+        } else if (t < T - 1) {
             const real *ft = p.f ? p.f + (long)t * p.f_st + (long)b * p.f_sb : nullptr;
             for (int i = tid; i < ns; i += nt) {
                 real r = 0;
@@ -886,6 +890,39 @@ int launch_select_best(int B, int T, int ns, int nc, int first, real eps, const 
     return check_launch("select_best_kernel");
 }
 
+// ---------------------------------------------------------------------------
+// MPC.linearize_dynamics for a shipped simulator (mpc/mpc.py:490-549): one thread per
+// trajectory point, closed-form Jacobian, f = env(x,u) - F [x;u].
+// ---------------------------------------------------------------------------
+template <typename real>
+__global__ void env_linearize_kernel(EnvDesc<real> env, long N, const real *x, const real *u, real *F, real *f)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int ns = env_ns(env.kind), n = ns + 1;
+    real xi[5], out[5], J[30];
+    for (int j = 0; j < ns; ++j) xi[j] = x[i * ns + j];
+    const real ui = u[i];
+    env_step<real>(env, xi, ui, out, J);
+    for (int r = 0; r < ns; ++r) {
+        real acc = out[r];
+        for (int j = 0; j < ns; ++j) acc -= J[r * n + j] * xi[j];
+        acc -= J[r * n + ns] * ui;
+        f[i * ns + r] = acc;
+        for (int j = 0; j < n; ++j) F[(i * ns + r) * n + j] = J[r * n + j];
+    }
+}
+
+template <typename real>
+int launch_env_linearize(const EnvDesc<real> &env, long N, const real *x, const real *u, real *F, real *f,
+                         hipStream_t st)
+{
+    if (N <= 0) return MPC_OK;
+    hipLaunchKernelGGL(env_linearize_kernel<real>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, env, N, x,
+                       u, F, f);
+    return check_launch("env_linearize_kernel");
+}
+
 #define INSTANTIATE(real)                                                                                     \
     template int launch_step_generic<real>(const StepParams<real> &, int, hipStream_t);                        \
     template int launch_pnqp<real>(int, int, const real *, const real *, const real *, const real *,          \
@@ -896,6 +933,8 @@ int launch_select_best(int B, int T, int ns, int nc, int first, real eps, const 
     template int launch_kkt_prepare<real>(int, int, int, int, const real *, const real *, const real *, int,   \
                                           real, real, const real *, const real *, real *, uint8_t *,          \
                                           hipStream_t);                                                       \
+    template int launch_env_linearize<real>(const EnvDesc<real> &, long, const real *, const real *, real *,   \
+                                            real *, hipStream_t);                                             \
     template int launch_select_best<real>(int, int, int, int, int, real, const real *, const real *,          \
                                           const real *, const real *, real *, real *, real *, real *, int *,  \
                                           real *, hipStream_t);

@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 #include "../../include/mpc_lqr.h"
+#include "env_dynamics.h"
 
 namespace mpclqr {
 
@@ -26,7 +27,14 @@ struct StepParams {
     real *K, *k;                 // [T,B,nc,ns], [T,B,nc]
     real *Kk;                    // fused MFMA kernel: its own gain record [T,B,4,16] (workspace)
     const real *old_costs_in;    // rollout-only entry point
+    EnvDesc<real> env;           // true_dynamics of the rollout (kind 0 = the linear model)
 };
+
+template <typename real>
+inline void set_env(EnvDesc<real> &e, const mpc_env_dynamics *d)
+{
+    e.kind = d->kind; e.params = (const real *)d->params; e.dt = (real)d->dt; e.u_max = (real)d->u_max;
+}
 
 template <typename real>
 inline StepParams<real> make_params(const mpc_lqr_problem *p, const mpc_lqr_options *o,
@@ -58,6 +66,8 @@ inline StepParams<real> make_params(const mpc_lqr_problem *p, const mpc_lqr_opti
     s.K = out ? (real *)out->K : nullptr; s.k = out ? (real *)out->k : nullptr;
     s.Kk = nullptr;
     s.old_costs_in = nullptr;
+    s.env.kind = MPC_ENV_NONE; s.env.params = nullptr; s.env.dt = 0; s.env.u_max = 0;
+    if (o && o->true_dynamics) set_env(s.env, o->true_dynamics);
     return s;
 }
 

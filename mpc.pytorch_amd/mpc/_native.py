@@ -32,10 +32,34 @@ class Problem(ctypes.Structure):
                 ("cur_x", _vp), ("cur_u", _vp)]
 
 
+class EnvDynamics(ctypes.Structure):
+    _fields_ = [("kind", _i32), ("_pad", _i32), ("params", _vp), ("dt", _f64), ("u_max", _f64)]
+
+
 class Options(ctypes.Structure):
     _fields_ = [("bound_mode", _i32), ("max_linesearch_iter", _i32), ("lo_s", _f64), ("hi_s", _f64),
                 ("lo", _vp), ("hi", _vp), ("zero_mask", _vp), ("delta_u", _f64),
-                ("linesearch_decay", _f64), ("pnqp_iter", _i32), ("_pad", _i32)]
+                ("linesearch_decay", _f64), ("pnqp_iter", _i32), ("_pad", _i32),
+                ("true_dynamics", ctypes.POINTER(EnvDynamics))]
+
+
+ENV_PENDULUM, ENV_PENDULUM_FULL, ENV_CARTPOLE = 1, 2, 3
+
+
+class EnvSpec:
+    """What a shipped simulator module hands to the kernels: kind (ENV_*), its parameter tensor,
+    the integration step and the control clamp (mpc/env_dx/pendulum.py:23-37, cartpole.py:36-49)."""
+
+    def __init__(self, kind, params, dt, u_max):
+        self.kind, self.params, self.dt, self.u_max = int(kind), params, float(dt), float(u_max)
+        self.n_state = 5 if self.kind == ENV_CARTPOLE else 3
+        self.n_ctrl = 1
+
+    def to_struct(self, like):
+        prm = self.params.detach().to(device=like.device, dtype=like.dtype).contiguous()
+        e = EnvDynamics()
+        e.kind, e.params, e.dt, e.u_max = self.kind, prm.data_ptr(), self.dt, self.u_max
+        return e, prm
 
 
 class Outputs(ctypes.Structure):
@@ -46,7 +70,7 @@ class Outputs(ctypes.Structure):
 
 EXPORTS = ("mpc_lqr_abi_version", "mpc_lqr_build_info", "mpc_lqr_last_error", "mpc_lqr_workspace_bytes",
            "mpc_lqr_step", "mpc_lqr_impl_supported", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_lqr_kkt_prepare",
-           "mpc_pnqp", "mpc_traj_cost", "mpc_select_best")
+           "mpc_pnqp", "mpc_traj_cost", "mpc_env_traj_cost", "mpc_env_linearize", "mpc_select_best")
 
 _lib = None
 
@@ -85,8 +109,10 @@ def load():
     L.mpc_lqr_kkt_prepare.argtypes = [ctypes.c_int] * 5 + [_vp, _vp, _vp, OP, _vp, _vp, _vp]
     L.mpc_pnqp.argtypes = [ctypes.c_int] * 3 + [_vp] * 5 + [ctypes.c_int] + [_vp] * 6
     L.mpc_traj_cost.argtypes = [PP, _vp, _vp, _vp]
+    L.mpc_env_traj_cost.argtypes = [PP, ctypes.POINTER(EnvDynamics), _vp, _vp, _vp]
+    L.mpc_env_linearize.argtypes = [ctypes.POINTER(EnvDynamics), ctypes.c_int, _i64, _vp, _vp, _vp, _vp, _vp]
     L.mpc_select_best.argtypes = [ctypes.c_int] * 6 + [_f64] + [_vp] * 11
-    if L.mpc_lqr_abi_version() != 1:
+    if L.mpc_lqr_abi_version() != 2:
         raise RuntimeError("libmpc_lqr_hip ABI version mismatch")
     _lib = L
     return L
@@ -149,9 +175,10 @@ class StepOptions:
     """The LQRStep keyword arguments that reach the kernels (mpc/lqr_step.py:22-38 of the reference)."""
 
     def __init__(self, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None, linesearch_decay=0.2,
-                 max_linesearch_iter=10, pnqp_iter=20):
+                 max_linesearch_iter=10, pnqp_iter=20, true_dynamics=None):
         assert (u_lower is None) == (u_upper is None)
         self.u_lower, self.u_upper, self.u_zero_I = u_lower, u_upper, u_zero_I
+        self.true_dynamics = true_dynamics      # EnvSpec: the rollout calls the simulator, not F,f
         self.delta_u, self.linesearch_decay = delta_u, linesearch_decay
         self.max_linesearch_iter, self.pnqp_iter = max_linesearch_iter, pnqp_iter
 
@@ -182,6 +209,10 @@ class StepOptions:
             m = (m != 0).to(torch.uint8).expand(T, B, nc).contiguous()
             keep.append(m)
             o.zero_mask = m.data_ptr()
+        if self.true_dynamics is not None:
+            e, prm = self.true_dynamics.to_struct(like)
+            keep += [e, prm]
+            o.true_dynamics = ctypes.pointer(e)
         return o, keep
 
 
@@ -430,6 +461,43 @@ class HipBackend:
         cost = torch.empty(B, **kw) if want_cost else None
         _check(L.mpc_traj_cost(ctypes.byref(p), _ptr(x), _ptr(cost), _stream(dev)), "mpc_traj_cost")
         return x, cost
+
+    def env_traj_cost(self, x_init, u, env, C=None, c=None, want_x=True):
+        """util.get_traj through a shipped simulator (+ util.get_cost for a QuadCost)."""
+        dev = _require_device(x_init, u)
+        L = load()
+        T, B, nc = u.shape
+        ns = x_init.shape[1]
+        kw = dict(device=dev, dtype=u.dtype)
+        p = Problem()
+        p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, _dtype_code(u)
+        xi = x_init.detach().contiguous(); p.x_init = xi.data_ptr()
+        cu = u.detach().contiguous(); p.cur_u = cu.data_ptr()
+        keep = [xi, cu]
+        if C is not None:
+            Cc, p.C_st, p.C_sb = _block_strided(C.detach(), 2); keep.append(Cc); p.C = Cc.data_ptr()
+            cc, p.c_st, p.c_sb = _block_strided(c.detach(), 1); keep.append(cc); p.c = cc.data_ptr()
+        e, prm = env.to_struct(u)
+        x = torch.empty(T, B, ns, **kw) if want_x else None
+        cost = torch.empty(B, **kw) if C is not None else None
+        _check(L.mpc_env_traj_cost(ctypes.byref(p), ctypes.byref(e), _ptr(x), _ptr(cost), _stream(dev)),
+               "mpc_env_traj_cost")
+        return x, cost
+
+    def env_linearize(self, env, x, u, out_F=None, out_f=None):
+        """x [N,ns], u [N,1] -> F [N,ns,ns+1], f [N,ns] (closed-form Jacobian of the simulator)."""
+        dev = _require_device(x, u)
+        L = load()
+        N, ns = x.shape
+        kw = dict(device=dev, dtype=x.dtype)
+        x = x.detach().contiguous(); u = u.detach().contiguous()
+        F = torch.empty(N, ns, ns + 1, **kw) if out_F is None else out_F
+        f = torch.empty(N, ns, **kw) if out_f is None else out_f
+        assert F.is_contiguous() and f.is_contiguous() and F.numel() == N * ns * (ns + 1) and f.numel() == N * ns
+        e, prm = env.to_struct(x)
+        _check(L.mpc_env_linearize(ctypes.byref(e), _dtype_code(x), N, x.data_ptr(), u.data_ptr(),
+                                   F.data_ptr(), f.data_ptr(), _stream(dev)), "mpc_env_linearize")
+        return F, f
 
     # -- (7) driver reductions ------------------------------------------------------------------
     def select_best(self, first, eps, x, u, costs, du_norm, best):

@@ -131,14 +131,20 @@ def LQRStep(n_state,
         quad = true_cost is None or isinstance(true_cost, _mpc.QuadCost)
         # Currently unimplemented in the reference as well (mpc/lqr_step.py:195):
         assert not ((delta_u is not None) and (u_lower is None))
-        if lin and quad:
+        sim = hasattr(true_dynamics, "native_env")
+        if (lin or sim) and quad:
             rp = None
             tC, tc = (C, c) if true_cost is None else (true_cost.C, true_cost.c)
-            tF, tf = (F, f_in) if true_dynamics is None else (true_dynamics.F, true_dynamics.f)
+            tF, tf = (F, f_in) if (sim or true_dynamics is None) else (true_dynamics.F, true_dynamics.f)
             if not (_same_storage(tC, C) and _same_storage(tc, c) and _same_storage(tF, F)
                     and _same_storage(tf, f_in)):
                 rp = (tC, tc, tF, tf)     # true cost / dynamics differ from the quadratic model
-            r = be.lqr_step(x_init, C, c, F, f_in, current_x, current_u, opts, rollout_problem=rp)
+            o = opts
+            if sim:                        # a shipped simulator rolls out inside the kernel (:223-225)
+                o = StepOptions(u_lower=u_lower, u_upper=u_upper, u_zero_I=u_zero_I, delta_u=delta_u,
+                                linesearch_decay=linesearch_decay, max_linesearch_iter=max_linesearch_iter,
+                                true_dynamics=true_dynamics.native_env())
+            r = be.lqr_step(x_init, C, c, F, f_in, current_x, current_u, o, rollout_problem=rp)
             return r["new_x"], r["new_u"], r["qp_iters"], r["costs"], r["full_du_norm"], r["alphas"]
         sw = be.lqr_sweep(x_init.detach(), C, c, F, current_x.detach(), current_u.detach(), opts)
         from . import util as _util

@@ -122,18 +122,47 @@ class MPC(Module):
                 util.get_cost(T, u, cost, dx, x_init=x_init).mean().item()))
 
         fast = (isinstance(cost, QuadCost) and isinstance(dx, LinDx) and self.slew_rate_penalty is None)
+        # a shipped simulator (mpc.env_dx): closed-form linearisation kernel + the simulator inside the
+        # rollout kernel; FINITE_DIFF keeps the reference's central differences
+        sim = None
+        if (isinstance(cost, QuadCost) and hasattr(dx, "native_env") and self.slew_rate_penalty is None
+                and self.grad_method in (GradMethods.ANALYTIC, GradMethods.AUTO_DIFF) and T > 1):
+            sim = dx.native_env()
         best = None
         n_not_improved = 0
         be = _native.backend()
         plans = None
         for i in range(self.lqr_iter):
             u = util.detach_maybe(u)
-            if fast and plans is not None:
+            if sim is not None:
+                if plans is None:
+                    xi = util.detach_maybe(x_init)
+                    ua = u.detach().contiguous()
+                    xa, _ = be.env_traj_cost(xi, ua, sim)             # util.get_traj, mpc/mpc.py:251
+                    xb, ub = torch.empty_like(xa), torch.empty_like(ua)
+                    Fl = torch.empty(T - 1, n_batch, ns, ns + nc, dtype=xa.dtype, device=xa.device)
+                    fl = torch.empty(T - 1, n_batch, ns, dtype=xa.dtype, device=xa.device)
+                    opts = self._step_options()
+                    opts.true_dynamics = sim
+                    pa = be.plan_step(xi, cost.C, cost.c, Fl, fl, xa, ua, opts, out_x=xb, out_u=ub)
+                    pb = be.plan_step(xi, cost.C, cost.c, Fl, fl, xb, ub, opts, out_x=xa, out_u=ua,
+                                      workspace=pa._keep[-1] if hasattr(pa, "_keep") else None)
+                    plans = (pa, pb)
+                    noms = ((xa, ua), (xb, ub))
+                xn, un = noms[i % 2]
+                # the nominal of this iteration is the last rollout through the simulator itself
+                be.env_linearize(sim, xn[:-1].reshape(-1, ns), un[:-1].reshape(-1, nc), out_F=Fl, out_f=fl)
+                r = plans[i % 2]()
+                x, u, costs, full_du_norm = r["new_x"], r["new_u"], r["costs"], r["full_du_norm"]
+                qp_iters, alphas = r["qp_iters"], r["alphas"]
+            elif fast and plans is not None:
                 # LinDx: the states of the last rollout ARE get_traj(u) (mpc/mpc.py:251 recomputes them)
                 pass
             else:
                 x = util.get_traj(T, u, x_init=x_init, dynamics=dx)
-            if isinstance(dx, LinDx):
+            if sim is not None:
+                pass
+            elif isinstance(dx, LinDx):
                 F, f = dx.F, dx.f
             else:
                 F, f = self.linearize_dynamics(x, util.detach_maybe(u), dx, diff=False)
@@ -142,7 +171,9 @@ class MPC(Module):
             else:
                 C, c, _ = self.approximate_cost(x, util.detach_maybe(u), cost, diff=False)
 
-            if fast:
+            if sim is not None:
+                pass
+            elif fast:
                 # inner iterations are never differentiated (the reference detaches them too): two
                 # pre-bound plans ping-pong the nominal between two buffers, so an iteration is one
                 # C call (no allocation, no autograd node, no host-side unpacking)

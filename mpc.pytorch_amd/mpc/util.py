@@ -96,6 +96,9 @@ def get_traj(T, u, x_init, dynamics):
             assert f.shape == F.shape[:3]
         x, _ = _native.backend().traj_cost(x_init, u, F, f)
         return x
+    if hasattr(dynamics, "native_env") and T > 1:       # a shipped simulator: one kernel
+        x, _ = _native.backend().env_traj_cost(x_init, u, dynamics.native_env())
+        return x
     xs = [x_init]
     with torch.no_grad():
         for t in range(T - 1):

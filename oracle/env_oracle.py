@@ -1,0 +1,138 @@
+"""TEST INFRASTRUCTURE (not product): numpy restatement of the simulator dynamics the reference
+ships and of the rollout that calls them.
+
+  pendulum_step   mpc/env_dx/pendulum.py:49-84   (simple and 5-parameter variants)
+  cartpole_step   mpc/env_dx/cartpole.py:63-96
+  linearize       mpc/mpc.py:490-549: F = d step / d [x;u], f = step(x,u) - F [x;u].  The
+                  Jacobian is taken by Richardson-extrapolated central differences in float64 (error ~1e-12), on
+                  purpose NOT by the closed form the kernels use, so the two are independent.
+  rollout         mpc/lqr_step.py:164-261 with a module as true_dynamics (:223-225) and a QuadCost
+                  as true cost (:230-232), one problem at a time (= the reference with n_batch 1).
+
+Parity status: pinned -- tests/test_oracle_golden.py checks all three against outputs of the
+reference's own modules (tests/golden/env_*.npz).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline may import this file."""
+import numpy as np
+
+PENDULUM, PENDULUM_FULL, CARTPOLE = 1, 2, 3
+DT = 0.05
+
+
+def u_max_of(kind):
+    return 100.0 if kind == CARTPOLE else 2.0
+
+
+def pendulum_step(x, u, params, simple=True, dt=DT, max_torque=2.0):
+    """x [N,3] = (cos th, sin th, dth), u [N,1]."""
+    x = np.asarray(x, dtype=np.float64)
+    tq = np.clip(np.asarray(u, dtype=np.float64)[:, 0], -max_torque, max_torque)      # :66
+    c, s, w = x[:, 0], x[:, 1], x[:, 2]
+    th = np.arctan2(s, c)                                                             # :68
+    if simple:
+        g, m, l = params[:3]
+        w2 = w + dt * (-3. * g / (2. * l) * (-s) + 3. * tq / (m * l ** 2))            # :70-71
+    else:
+        g, m, l, d, b = params
+        w2 = w + dt * (-3. * g / (2. * l) * (-np.sin(th + b)) + 3. * tq / (m * l ** 2) - d * th)   # :73-75
+    th2 = th + w2 * dt                                                                # :76
+    return np.stack((np.cos(th2), np.sin(th2), w2), 1)                                # :77
+
+
+def cartpole_step(st, u, params, dt=DT, force_mag=100.0):
+    """st [N,5] = (x, dx, cos th, sin th, dth), u [N,1]."""
+    st = np.asarray(st, dtype=np.float64)
+    g, mc, mp, l = params
+    mt, pml = mp + mc, mp * l                                                         # :70-71
+    f = np.clip(np.asarray(u, dtype=np.float64)[:, 0], -force_mag, force_mag)         # :73
+    x, v, c, s, w = (st[:, i] for i in range(5))
+    th = np.arctan2(s, c)                                                             # :76
+    cart_in = (f + pml * w ** 2 * s) / mt                                             # :78
+    th_acc = (g * s - c * cart_in) / (l * (4. / 3. - mp * c ** 2 / mt))               # :79-81
+    xacc = cart_in - pml * th_acc * c / mt                                            # :82
+    th2 = th + dt * w                                                                 # :86
+    return np.stack((x + dt * v, v + dt * xacc, np.cos(th2), np.sin(th2), w + dt * th_acc), 1)   # :84-91
+
+
+def step(kind, x, u, params, clamp=True):
+    lim = u_max_of(kind) if clamp else np.inf
+    if kind == CARTPOLE:
+        return cartpole_step(x, u, params, force_mag=lim)
+    return pendulum_step(x, u, params, simple=(kind == PENDULUM), max_torque=lim)
+
+
+def linearize(kind, x, u, params, h=2e-4):
+    """x [N,ns], u [N,1] -> F [N,ns,ns+1], f [N,ns]."""
+    x = np.asarray(x, dtype=np.float64)
+    u = np.asarray(u, dtype=np.float64)
+    N, ns = x.shape
+    tau = np.concatenate((x, u), 1)
+    F = np.empty((N, ns, ns + 1))
+
+    # The control enters through clamp(u, -u_max, u_max) only; differences are taken of the smooth
+    # part at the clamped control and the clamp's own derivative is applied in closed form with
+    # autograd's convention (1 on the CLOSED interval) -- a finite difference would return 1/2 on
+    # a control sitting exactly at its bound, which is where bounded solves put it.
+    lim = u_max_of(kind)
+    tau_c = np.concatenate((x, np.clip(u, -lim, lim)), 1)
+
+    def central(j, hh):
+        e = np.zeros(ns + 1)
+        e[j] = hh
+        hi = step(kind, (tau_c + e)[:, :ns], (tau_c + e)[:, ns:], params, clamp=False)
+        lo = step(kind, (tau_c - e)[:, :ns], (tau_c - e)[:, ns:], params, clamp=False)
+        return (hi - lo) / (2 * hh)
+    for j in range(ns + 1):
+        F[:, :, j] = (4.0 * central(j, h / 2) - central(j, h)) / 3.0     # Richardson: O(h^4)
+    F[:, :, ns] *= ((u[:, 0] >= -lim) & (u[:, 0] <= lim))[:, None]
+    f = step(kind, x, u, params) - np.einsum("nij,nj->ni", F, tau)
+    return F, f
+
+
+def traj(kind, x_init, u, params):
+    """util.get_traj through the simulator (mpc/util.py:107-113)."""
+    T = u.shape[0]
+    xs = [np.asarray(x_init, dtype=np.float64)]
+    for t in range(T - 1):
+        xs.append(step(kind, xs[t], u[t], params))
+    return np.stack(xs)
+
+
+def quad_cost(C, c, x, u):
+    tau = np.concatenate((x, u), 2)
+    return (0.5 * np.einsum("tbi,tbij,tbj->b", tau, C, tau) + np.einsum("tbi,tbi->b", c, tau))
+
+
+def rollout(kind, params, x_init, C, c, K, k, cur_x, cur_u, lower, upper, decay, max_ls):
+    """lqr_forward (mpc/lqr_step.py:164-261), per problem.  Returns new_x, new_u, costs,
+    full_du_norm, alphas."""
+    T, B, nc = cur_u.shape
+    ns = x_init.shape[1]
+    old = quad_cost(C, c, cur_x, cur_u)                                               # :169
+    new_x = np.empty((T, B, ns)); new_u = np.empty((T, B, nc))
+    costs = np.empty(B); full = np.empty(B); alphas = np.empty(B)
+    for b in range(B):
+        alpha = 1.0
+        for it in range(max_ls):
+            xs = [x_init[b:b + 1]]
+            us = []
+            dx = np.zeros((1, ns))
+            for t in range(T):
+                nu = K[t, b:b + 1] @ dx[0] + cur_u[t, b:b + 1] + alpha * k[t, b:b + 1]    # :192
+                if lower is not None:
+                    nu = np.clip(nu, lower, upper)                                        # :200-213
+                us.append(nu)
+                if t < T - 1:
+                    nx = step(kind, xs[t], nu, params)                                    # :223-225
+                    xs.append(nx)
+                    dx = nx - cur_x[t + 1, b:b + 1]                                       # :227
+            X, U = np.stack(xs), np.stack(us)
+            cost = quad_cost(C[:, b:b + 1], c[:, b:b + 1], X, U)[0]                       # :230-232
+            dun = np.sqrt(((cur_u[:, b:b + 1] - U) ** 2).sum())
+            if it == 0:
+                full[b] = dun                                                             # :243-245
+            if cost > old[b] and it + 1 < max_ls:                                         # :176-179, 247
+                alpha *= decay
+            else:
+                break
+        new_x[:, b], new_u[:, b], costs[b], alphas[b] = X[:, 0], U[:, 0], cost, alpha
+    return new_x, new_u, costs, full, alphas

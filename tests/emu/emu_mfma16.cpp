@@ -420,3 +420,35 @@ extern "C" int emu_kkt_dpp16(const mpc_lqr_problem *p, const float *dx, const fl
     for (int w = 0; 4 * w < sp.B; ++w) emu::run_wave(w, body_kkt16);
     return 0;
 }
+
+// ---- env_dynamics.h on the host: the same source the linearisation / rollout kernels compile ----
+template <typename real>
+static void env_linearize_host(int kind, const real *params, double dt, double umax, long N, const real *x,
+                               const real *u, real *nxt, real *F, real *f)
+{
+    mpclqr::EnvDesc<real> e;
+    e.kind = kind; e.params = params; e.dt = (real)dt; e.u_max = (real)umax;
+    const int ns = mpclqr::env_ns(kind), n = ns + 1;
+    for (long i = 0; i < N; ++i) {
+        real out[5], J[30];
+        mpclqr::env_step<real>(e, x + i * ns, u[i], out, J);
+        for (int r = 0; r < ns; ++r) {
+            real acc = out[r];
+            for (int j = 0; j < ns; ++j) acc -= J[r * n + j] * x[i * ns + j];
+            acc -= J[r * n + ns] * u[i];
+            f[i * ns + r] = acc;
+            nxt[i * ns + r] = out[r];
+            for (int j = 0; j < n; ++j) F[(i * ns + r) * n + j] = J[r * n + j];
+        }
+    }
+}
+extern "C" void emu_env_linearize_f64(int kind, const double *params, double dt, double umax, long N, const double *x,
+                                      const double *u, double *nxt, double *F, double *f)
+{
+    env_linearize_host<double>(kind, params, dt, umax, N, x, u, nxt, F, f);
+}
+extern "C" void emu_env_linearize_f32(int kind, const float *params, double dt, double umax, long N, const float *x,
+                                      const float *u, float *nxt, float *F, float *f)
+{
+    env_linearize_host<float>(kind, params, dt, umax, N, x, u, nxt, F, f);
+}

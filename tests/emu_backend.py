@@ -23,7 +23,7 @@ def build():
     src = os.path.join(_EMU, "emu_mfma16.cpp")
     csrc = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc")
     deps = [src] + [os.path.join(csrc, h) for h in ("lqr_mfma16_body.h", "lqr_dpp16_body.h", "lqr_small_math.h",
-                                                    "lqr_params.h")]
+                                                    "lqr_params.h", "env_dynamics.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         cxx = "/opt/rocm/lib/llvm/bin/clang++"
         if not os.path.exists(cxx):
@@ -136,3 +136,17 @@ def kkt_grads(C, c, F, f, x_star, u_star, dx, du, dl_dx, dma_late=False):
                          _ptr(out["dF"]), _ptr(out["df"]), _ptr(out["dx_init"]))
     assert rc == 0, rc
     return out
+
+
+def env_linearize(kind, params, dt, u_max, x, u, dtype=np.float64):
+    """mpc.pytorch_amd/csrc/env_dynamics.h compiled for the host: next state, F, f at N points."""
+    sfx = "f64" if dtype == np.float64 else "f32"
+    x = np.ascontiguousarray(x, dtype); u = np.ascontiguousarray(u, dtype).reshape(-1)
+    params = np.ascontiguousarray(params, dtype)
+    Np, ns = x.shape
+    nxt = np.empty((Np, ns), dtype); F = np.empty((Np, ns, ns + 1), dtype); f = np.empty((Np, ns), dtype)
+    fn = getattr(lib(), "emu_env_linearize_" + sfx)
+    fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_long] + [ctypes.c_void_p] * 5
+    fn.restype = None
+    fn(int(kind), _ptr(params), float(dt), float(u_max), Np, _ptr(x), _ptr(u), _ptr(nxt), _ptr(F), _ptr(f))
+    return nxt, F, f

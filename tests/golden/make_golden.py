@@ -251,6 +251,62 @@ def env_case(name, kind, T, B, lqr_iter, seed):
          x=npy(x), u=npy(u), costs=npy(costs))
 
 
+def _ref_env(kind, simple=True, params=None):
+    import importlib
+    sys.modules.setdefault("mpc", sys.modules["mpc_ref"])
+    sys.modules.setdefault("mpc.util", ref_util)
+    if kind == "pendulum":
+        dx = importlib.import_module("mpc_ref.env_dx.pendulum").PendulumDx(params=params, simple=simple)
+    else:
+        dx = importlib.import_module("mpc_ref.env_dx.cartpole").CartpoleDx(params=params)
+    dx.params = dx.params.double()
+    return dx
+
+
+def env_lin_case(name, kind, T, B, seed, simple=True, params=None):
+    """The reference's own simulator modules at random points: next state, and F, f of
+    MPC.linearize_dynamics (GradMethods.AUTO_DIFF, mpc/mpc.py:514-549).  Controls reach past the
+    modules' clamp on purpose.  Also ONE reference LQRStep with the module as true_dynamics."""
+    dx = _ref_env(kind, simple, None if params is None else torch.tensor(params))
+    ns, nc = dx.n_state, dx.n_ctrl
+    g = torch.Generator().manual_seed(seed)
+    f64 = torch.float64
+    umax = dx.upper
+    u = (torch.rand(T, B, nc, generator=g, dtype=f64) - 0.5) * 2.6 * umax
+    th = (torch.rand(B, generator=g, dtype=f64) - 0.5) * 2 * np.pi
+    if kind == "pendulum":
+        x_init = torch.stack((torch.cos(th), torch.sin(th), torch.randn(B, generator=g, dtype=f64)), 1)
+    else:
+        z = torch.randn(B, 3, generator=g, dtype=f64)
+        x_init = torch.stack((z[:, 0], z[:, 1], torch.cos(th), torch.sin(th), z[:, 2]), 1)
+        u = u * 0.05
+    x = ref_util.get_traj(T, u, x_init, dx)
+    # off-manifold states as well (cos/sin not normalised): scale a few
+    x = x * (1.0 + 0.1 * torch.randn(T, B, 1, generator=g, dtype=f64))
+    ctrl = ref_mpc.MPC(ns, nc, T, u_lower=dx.lower, u_upper=dx.upper, lqr_iter=1, verbose=-1,
+                       grad_method=ref_mpc.GradMethods.AUTO_DIFF)
+    F, f = ctrl.linearize_dynamics(x, u, dx, diff=False)
+    nxt = dx(x[:-1].reshape(-1, ns), u[:-1].reshape(-1, nc)).view(T - 1, B, ns)
+    # one LQR step around a proper nominal, true_dynamics = the module
+    u0 = 0.3 * (torch.rand(T, B, nc, generator=g, dtype=f64) - 0.5) * umax * (0.05 if kind == "cartpole" else 1.0)
+    x0 = ref_util.get_traj(T, u0, x_init, dx)
+    F0, f0 = ctrl.linearize_dynamics(x0, u0, dx, diff=False)
+    q, p_ = dx.get_true_obj()
+    Q = torch.diag(q.double()).unsqueeze(0).unsqueeze(0).repeat(T, B, 1, 1)
+    pp = p_.double().unsqueeze(0).repeat(T, B, 1)
+    fn = ref_step.LQRStep(n_state=ns, n_ctrl=nc, T=T, u_lower=dx.lower, u_upper=dx.upper,
+                          linesearch_decay=dx.linesearch_decay, max_linesearch_iter=dx.max_linesearch_iter,
+                          true_cost=QuadCost(Q, pp), true_dynamics=dx, delta_space=True, current_x=x0,
+                          current_u=u0)
+    (new_x, new_u, nqp, costs, fdn, mean_alpha), _ = quiet(fn, x_init, Q, pp, F0, f0)
+    save(name, meta=np.array([ns, nc, T, B]), params=npy(dx.params), simple=np.array([int(simple)]),
+         x=npy(x), u=npy(u), next=npy(nxt), F=npy(F), f=npy(f), x_init=npy(x_init),
+         lower=np.array([dx.lower]), upper=np.array([dx.upper]), decay=np.array([dx.linesearch_decay]),
+         max_ls=np.array([dx.max_linesearch_iter]), Q=npy(Q), p=npy(pp),
+         step_cur_x=npy(x0), step_cur_u=npy(u0), step_F=npy(F0), step_f=npy(f0), step_new_x=npy(new_x),
+         step_new_u=npy(new_u), step_costs=npy(costs), step_full_du_norm=npy(fdn))
+
+
 def gen_mpc_cases():
     # (1) notebook known answer: examples/Time Varying Linear-Quadratic Control.ipynb cell 1
     torch.manual_seed(0)
@@ -444,6 +500,10 @@ if __name__ == "__main__":
     if not only or "env" in only:
         env_case("ilqr_pendulum_f64", "pendulum", 20, 4, 8, 51)
         env_case("ilqr_cartpole_f64", "cartpole", 25, 4, 8, 52)
+        env_lin_case("env_pendulum_f64", "pendulum", 12, 6, 61)
+        env_lin_case("env_pendulum_full_f64", "pendulum", 12, 6, 62, simple=False,
+                     params=(9.0, 1.2, 0.8, 0.3, 0.2))
+        env_lin_case("env_cartpole_f64", "cartpole", 12, 6, 63)
     if only == {"env"}:
         sys.exit(0)
     gen_mpc_cases()

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from oracle import lqr_oracle as O
+from oracle import env_oracle as E
 
 
 def _np(t):
@@ -43,6 +44,17 @@ class OracleBackend:
                        opts.linesearch_decay, opts.max_linesearch_iter, lockstep=self.lockstep,
                        return_gains=True)
         B = C.shape[1]
+        env = getattr(opts, "true_dynamics", None)
+        if env is not None:      # the simulator is the true dynamics of the rollout (mpc/lqr_step.py:223-225)
+            assert opts.u_zero_I is None and opts.delta_u is None
+            lo, hi = _bound(opts.u_lower), _bound(opts.u_upper)
+            assert lo is None or isinstance(lo, float)
+            nx, nu, cs, fdn, al = E.rollout(env.kind, _np(env.params).astype(np.float64), _np(x_init).astype(np.float64),
+                                            _np(C).astype(np.float64), _np(c).astype(np.float64), o["K"].astype(np.float64),
+                                            o["k"].astype(np.float64), _np(cur_x).astype(np.float64),
+                                            _np(cur_u).astype(np.float64), lo, hi, opts.linesearch_decay,
+                                            opts.max_linesearch_iter)
+            o.update(new_x=nx, new_u=nu, costs=cs, full_du_norm=fdn, alpha_du_norm=fdn, alphas=al)
         res = {k: self._t(o[k], C) for k in ("new_x", "new_u", "costs", "old_costs", "full_du_norm",
                                              "alpha_du_norm", "alphas", "K", "k")}
         res["qp_iters"] = torch.full((B,), int(o["n_qp_iter"]), dtype=torch.int32)
@@ -85,6 +97,23 @@ class OracleBackend:
         Fn = _np(F) if T > 1 else np.zeros((0, B, x_init.shape[1], x_init.shape[1] + nc), _np(u).dtype)
         x, cost = O.traj_cost(_np(x_init), _np(u), Fn, _np(f), _np(C), _np(c))
         return (self._t(x, u) if want_x else None), (None if cost is None else self._t(cost, u))
+
+    def env_traj_cost(self, x_init, u, env, C=None, c=None, want_x=True):
+        self.calls.append("env_traj_cost")
+        x = E.traj(env.kind, _np(x_init).astype(np.float64), _np(u).astype(np.float64), _np(env.params).astype(np.float64))
+        cost = None
+        if C is not None:
+            cost = self._t(E.quad_cost(_np(C).astype(np.float64), _np(c).astype(np.float64), x, _np(u).astype(np.float64)), u)
+        return (self._t(x, u) if want_x else None), cost
+
+    def env_linearize(self, env, x, u, out_F=None, out_f=None):
+        self.calls.append("env_linearize")
+        F, f = E.linearize(env.kind, _np(x), _np(u), _np(env.params).astype(np.float64))
+        F, f = self._t(F, x), self._t(f, x)
+        if out_F is not None:
+            out_F.copy_(F.view_as(out_F)); out_f.copy_(f.view_as(out_f))
+            return out_F, out_f
+        return F, f
 
     def select_best(self, first, eps, x, u, costs, du_norm, best):
         self.calls.append("select_best")

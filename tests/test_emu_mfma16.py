@@ -238,3 +238,29 @@ def test_emulated_dpp16_nominal_off_the_dynamics(emu, bounded):
     np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4, atol=1e-4)
     np.testing.assert_allclose(r["old_costs"], o["old_costs"], rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# env_dynamics.h (the simulator transition + closed-form Jacobian the kernels compile), on the host
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kind", [("env_pendulum_f64", 1), ("env_pendulum_full_f64", 2), ("env_cartpole_f64", 3)])
+def test_env_dynamics_header_matches_reference_modules(name, kind):
+    """transition == the reference module's forward; closed-form Jacobian == the reference's
+    autograd linearisation (mpc/mpc.py:514-549) to rounding, in float64 and float32."""
+    from oracle import env_oracle as E
+    import emu_backend as EB
+    z = golden(name)
+    ns, nc, T, B = (int(v) for v in z["meta"])
+    prm, umax = z["params"], E.u_max_of(kind)
+    x, u = z["x"][:-1].reshape(-1, ns), z["u"][:-1].reshape(-1, nc)
+    xr = E.traj(kind, z["x"][0], z["u"], prm)[:-1].reshape(-1, ns)     # where the reference linearises
+    for dtype, tol in ((np.float64, 1e-12), (np.float32, 5e-6)):
+        nxt, _, _ = EB.env_linearize(kind, prm, 0.05, umax, x, u, dtype)
+        np.testing.assert_allclose(nxt, z["next"].reshape(-1, ns), rtol=tol, atol=tol)
+        _, F, f = EB.env_linearize(kind, prm, 0.05, umax, xr, u, dtype)
+        np.testing.assert_allclose(F, z["F"].reshape(F.shape), rtol=tol, atol=tol)
+        np.testing.assert_allclose(f, z["f"].reshape(f.shape), rtol=tol, atol=tol * 5)
+    # on the bound the clamp still passes the derivative (torch.clamp convention)
+    _, F_on, _ = EB.env_linearize(1, [10., 1., 1.], 0.05, 2.0, [[0.3, 0.9, 0.1]], [[2.0]])
+    _, F_in, _ = EB.env_linearize(1, [10., 1., 1.], 0.05, 2.0, [[0.3, 0.9, 0.1]], [[1.0]])
+    assert F_on[0, 2, 3] == F_in[0, 2, 3] != 0

@@ -271,6 +271,94 @@ def test_ilqr_on_simulator_dynamics_on_gpu(be, kind):
     np.testing.assert_allclose(host(u), z["u"], rtol=1e-4, atol=1e-4)
 
 
+ENV_CASES = [("env_pendulum_f64", 1), ("env_pendulum_full_f64", 2), ("env_cartpole_f64", 3)]
+
+
+def _env_spec(z, kind, dtype):
+    from mpc._native import EnvSpec
+    return EnvSpec(kind, torch.from_numpy(z["params"]).to(dtype), 0.05, 100.0 if kind == 3 else 2.0)
+
+
+@pytest.mark.parametrize("name,kind", ENV_CASES)
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_env_kernels_match_reference_modules(be, name, kind, dtype):
+    """mpc_env_linearize == the reference's autograd linearisation of its own PendulumDx / CartpoleDx
+    (mpc/mpc.py:514-549); mpc_env_traj_cost == util.get_traj through the module (mpc/util.py:107-113);
+    mpc_lqr_step with the simulator as true_dynamics == LQRStep(true_dynamics=module)."""
+    from oracle import env_oracle as E
+    from mpc._native import StepOptions
+    z = golden(name)
+    ns, nc, T, B = (int(v) for v in z["meta"])
+    env = _env_spec(z, kind, dtype)
+    f64 = dtype == torch.float64
+    tol = 1e-11 if f64 else 5e-6
+    d = lambda a: dev(a).to(dtype)
+    xr, _ = be.env_traj_cost(d(z["x"][0]), d(z["u"]), env)
+    torch.cuda.synchronize()
+    ref_traj = E.traj(kind, z["x"][0], z["u"], z["params"])
+    np.testing.assert_allclose(host(xr), ref_traj, rtol=tol * 20, atol=tol * 20)
+    F, f = be.env_linearize(env, d(ref_traj[:-1].reshape(-1, ns)), d(z["u"][:-1].reshape(-1, nc)))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(host(F), z["F"].reshape(F.shape), rtol=tol, atol=tol)
+    np.testing.assert_allclose(host(f), z["f"].reshape(f.shape), rtol=tol * 5, atol=tol * 5)
+    opts = StepOptions(u_lower=float(z["lower"][0]), u_upper=float(z["upper"][0]), linesearch_decay=float(z["decay"][0]),
+                       max_linesearch_iter=int(z["max_ls"][0]), true_dynamics=env)
+    r = be.lqr_step(d(z["x_init"]), d(z["Q"]), d(z["p"]), d(z["step_F"]), d(z["step_f"]), d(z["step_cur_x"]),
+                    d(z["step_cur_u"]), opts)
+    torch.cuda.synchronize()
+    st = dict(rtol=1e-9, atol=1e-9) if f64 else dict(rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(host(r["new_x"]), z["step_new_x"], **st)
+    np.testing.assert_allclose(host(r["new_u"]), z["step_new_u"], **st)
+    np.testing.assert_allclose(host(r["costs"]), z["step_costs"], rtol=1e-9 if f64 else 1e-3)
+    with pytest.raises(RuntimeError, match="generic kernels only"):
+        be.lqr_step(d(z["x_init"]), d(z["Q"]), d(z["p"]), d(z["step_F"]), d(z["step_f"]), d(z["step_cur_x"]),
+                    d(z["step_cur_u"]), opts, impl=2)
+
+
+@pytest.mark.parametrize("kind", ["pendulum", "cartpole"])
+def test_ilqr_on_shipped_simulators_on_gpu(be, kind):
+    """mpc.env_dx modules: linearisation kernel + simulator inside the rollout kernel, whole solve in
+    float64 == the reference's solve; and, at B = 512 in float32, == the host-driven module path."""
+    from test_host_logic import run_ilqr_golden
+    from mpc import mpc
+    from mpc.mpc import QuadCost
+    from mpc.env_dx import cartpole, pendulum
+    import envs
+    z = golden("ilqr_%s_f64" % kind)
+    x, u, costs = run_ilqr_golden(z, kind, device=DEV, shipped=True)
+    np.testing.assert_allclose(host(costs), z["costs"], rtol=1e-5)
+    np.testing.assert_allclose(host(x), z["x"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(u), z["u"], rtol=1e-4, atol=1e-4)
+    # larger batch, float32: kernel path vs the module path of the same package
+    B, T = 512, int(z["meta"][2])
+    g = torch.Generator().manual_seed(7)
+    if kind == "pendulum":
+        dx, plain = pendulum.PendulumDx(), envs.PendulumSim()
+        th = (torch.rand(B, generator=g) - 0.5) * np.pi
+        x0 = torch.stack((th.cos(), th.sin(), (torch.rand(B, generator=g) - 0.5) * 2), 1)
+    else:
+        dx, plain = cartpole.CartpoleDx(), envs.CartpoleSim()
+        th = (torch.rand(B, generator=g) - 0.5) * 0.6
+        zz = 0.2 * torch.randn(B, 3, generator=g)
+        x0 = torch.stack((zz[:, 0], zz[:, 1], th.cos(), th.sin(), zz[:, 2]), 1)
+    q, p = dx.get_true_obj()
+    Q = torch.diag(q).repeat(T, B, 1, 1).to(DEV)
+    pp = p.repeat(T, B, 1).to(DEV)
+    outs = []
+    for mod in (dx, plain):
+        ctrl = mpc.MPC(dx.n_state, 1, T, u_lower=dx.lower, u_upper=dx.upper, lqr_iter=3, verbose=-1,
+                       exit_unconverged=False, detach_unconverged=False, linesearch_decay=dx.linesearch_decay,
+                       max_linesearch_iter=dx.max_linesearch_iter, grad_method=mpc.GradMethods.AUTO_DIFF,
+                       eps=dx.mpc_eps, backprop=False)
+        outs.append(ctrl(x0.to(DEV), QuadCost(Q, pp), mod))
+    (xa, ua, ca), (xb, ub, cb) = outs
+    # float32 iLQR amplifies rounding differently on the two paths: compare costs tightly, paths loosely
+    bad = ((ca - cb).abs() > 1e-3 * (1 + cb.abs())).float().mean().item()
+    assert bad < 0.02, bad
+    assert torch.isfinite(xa).all() and torch.isfinite(ua).all()
+    assert float((ua.abs() <= dx.upper + 1e-6).float().mean()) == 1.0
+
+
 # ------------------------------------------------------------------------------------------------
 # full-size checks at BASELINE.json's north-star configuration (ns=12, nc=4, T=50, B=4096, fp32)
 # ------------------------------------------------------------------------------------------------

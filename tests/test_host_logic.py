@@ -43,14 +43,15 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert set(_native.EXPORTS) == declared
-    assert L.mpc_lqr_abi_version() == 1
+    assert L.mpc_lqr_abi_version() == 2
     assert b"gfx950" in L.mpc_lqr_build_info()
 
 
 def test_struct_layout_matches_header():
     # sizeof checks guard the ctypes mirror against drift from include/mpc_lqr.h
     assert ctypes.sizeof(_native.Problem) == 6 * 4 + 8 + 4 * (8 + 16) + 16
-    assert ctypes.sizeof(_native.Options) == 8 + 16 + 24 + 16 + 8
+    assert ctypes.sizeof(_native.Options) == 8 + 16 + 24 + 16 + 8 + 8
+    assert ctypes.sizeof(_native.EnvDynamics) == 8 + 8 + 16
     assert ctypes.sizeof(_native.Outputs) == 11 * 8
 
 
@@ -120,12 +121,18 @@ def run_mpc_golden(z, verbose=-1, device=None):
     return ctrl(mv(tt(z, "x_init")), QuadCost(mv(tt(z, "C")), mv(tt(z, "c"))), LinDx(mv(tt(z, "F")), mv(tt(z, "f"))))
 
 
-def run_ilqr_golden(z, kind, device=None):
-    """BASELINE.json configs 2 / 3 at small batch: iLQR on simulator dynamics (tests/envs.py),
-    AUTO_DIFF linearisation, module rollout in the line search."""
+def run_ilqr_golden(z, kind, device=None, shipped=False):
+    """BASELINE.json configs 2 / 3 at small batch: iLQR on simulator dynamics, AUTO_DIFF.
+    shipped=False: plain torch modules (tests/envs.py) -> autograd linearisation + host-driven module
+    rollout; shipped=True: mpc.env_dx modules -> linearisation kernel + simulator inside the rollout."""
     import envs
     ns, nc, T, B, lqr_iter = (int(v) for v in z["meta"])
-    dx = (envs.PendulumSim if kind == "pendulum" else envs.CartpoleSim)()
+    if shipped:
+        from mpc.env_dx import cartpole, pendulum
+        dx = pendulum.PendulumDx() if kind == "pendulum" else cartpole.CartpoleDx()
+        dx.params = dx.params.double()
+    else:
+        dx = (envs.PendulumSim if kind == "pendulum" else envs.CartpoleSim)()
     mv = (lambda t: t if device is None else t.to(device))
     ctrl = mpc.MPC(ns, nc, T, u_lower=float(z["lower"][0]), u_upper=float(z["upper"][0]), lqr_iter=lqr_iter,
                    verbose=-1, exit_unconverged=False, detach_unconverged=False,
@@ -144,6 +151,69 @@ def test_ilqr_on_simulator_dynamics_matches_reference(kind, oracle_backend):
     np.testing.assert_allclose(x.detach().numpy(), z["x"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(u.detach().numpy(), z["u"], rtol=1e-4, atol=1e-4)
     assert "lqr_sweep" in oracle_backend.calls          # module dynamics: sweep on the kernel, rollout on the host
+
+
+@pytest.mark.parametrize("kind", ["pendulum", "cartpole"])
+def test_ilqr_on_shipped_simulators_takes_the_kernel_path(kind, oracle_backend):
+    """mpc.env_dx.PendulumDx / CartpoleDx: the driver linearises them with the closed-form kernel
+    and rolls them out inside the step kernel (here: their oracle stand-ins) -- same solves."""
+    z = golden("ilqr_%s_f64" % kind)
+    x, u, costs = run_ilqr_golden(z, kind, shipped=True)
+    np.testing.assert_allclose(costs.detach().numpy(), z["costs"], rtol=1e-5)
+    np.testing.assert_allclose(x.detach().numpy(), z["x"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(u.detach().numpy(), z["u"], rtol=1e-4, atol=1e-4)
+    assert "env_linearize" in oracle_backend.calls and "lqr_sweep" not in oracle_backend.calls
+
+
+def test_shipped_simulator_modules_mirror_the_reference():
+    """forward of mpc.env_dx modules == the reference modules' outputs (tests/golden/env_*.npz);
+    attributes the examples read are there."""
+    from mpc.env_dx import cartpole, pendulum
+    for name, dx in (("env_pendulum_f64", pendulum.PendulumDx()),
+                     ("env_pendulum_full_f64", pendulum.PendulumDx(params=torch.tensor([9.0, 1.2, 0.8, 0.3, 0.2]), simple=False)),
+                     ("env_cartpole_f64", cartpole.CartpoleDx())):
+        z = golden(name)
+        ns, nc, T, B = (int(v) for v in z["meta"])
+        dx.params = torch.from_numpy(z["params"])
+        nxt = dx(torch.from_numpy(z["x"][:-1]).reshape(-1, ns), torch.from_numpy(z["u"][:-1]).reshape(-1, nc))
+        np.testing.assert_allclose(nxt.numpy(), z["next"].reshape(-1, ns), rtol=1e-12, atol=1e-12)
+        assert dx(torch.from_numpy(z["x"][0, 0]), torch.from_numpy(z["u"][0, 0])).shape == (ns,)
+        q, p = dx.get_true_obj()
+        assert q.shape == (ns + nc,) and p.shape == (ns + nc,)
+        for attr in ("lower", "upper", "mpc_eps", "linesearch_decay", "max_linesearch_iter", "goal_state",
+                     "goal_weights", "ctrl_penalty", "dt", "n_state", "n_ctrl"):
+            assert hasattr(dx, attr)
+        assert dx.lower == float(z["lower"][0]) and dx.linesearch_decay == float(z["decay"][0])
+
+
+def test_dynamics_modules():
+    """mpc.dynamics: NNDynamics.grad_input == autograd Jacobian (reference tests/test_dynamics.py:25-56),
+    AffineDynamics, CtrlPassthroughDynamics."""
+    from mpc.dynamics import AffineDynamics, CtrlPassthroughDynamics, NNDynamics
+    torch.manual_seed(0)
+    for act in ("relu", "sigmoid"):
+        for passthrough in (True, False):
+            net = NNDynamics(4, 2, hidden_sizes=[16, 8], activation=act, passthrough=passthrough).double()
+            x = torch.randn(5, 4, dtype=torch.float64, requires_grad=True)
+            u = torch.randn(5, 2, dtype=torch.float64, requires_grad=True)
+            y = net(x, u)
+            R, S = net.grad_input(x, u)
+            for j in range(4):
+                gx, gu = torch.autograd.grad(y[:, j].sum(), [x, u], retain_graph=True)
+                np.testing.assert_allclose(R[:, j].detach().numpy(), gx.numpy(), atol=1e-12)
+                np.testing.assert_allclose(S[:, j].detach().numpy(), gu.numpy(), atol=1e-12)
+            assert net(x[0], u[0]).shape == (4,)
+    A, Bm, cc = torch.randn(3, 3), torch.randn(3, 2), torch.randn(3)
+    aff = AffineDynamics(A, Bm, cc)
+    x, u = torch.randn(6, 3), torch.randn(6, 2)
+    np.testing.assert_allclose(aff(x, u).numpy(), (x @ A.t() + u @ Bm.t() + cc).numpy(), rtol=1e-6)
+    R, S = aff.grad_input(x, u)
+    assert R.shape == (6, 3, 3) and S.shape == (6, 3, 2)
+    pas = CtrlPassthroughDynamics(aff)
+    tx = torch.cat((torch.randn(6, 2), x), 1)
+    out = pas(tx, u)
+    np.testing.assert_allclose(out[:, :2].numpy(), u.numpy())
+    np.testing.assert_allclose(out[:, 2:].numpy(), aff(x, u).numpy())
 
 
 @pytest.mark.parametrize("name", MPC_CASES)

@@ -156,3 +156,51 @@ def test_oracle_edge_cases():
     u_star = -np.linalg.solve(C[0, 0, ns:, ns:], C[0, 0, ns:, :ns] @ x0[0] + c[0, 0, ns:])
     np.testing.assert_allclose(o["new_u"][0, 0], u_star, rtol=1e-10)
     np.testing.assert_allclose(o["new_x"][0], x0)
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle/env_oracle.py: the shipped simulators, pinned on the reference's own modules
+# ---------------------------------------------------------------------------------------------
+ENV_CASES = [("env_pendulum_f64", 1), ("env_pendulum_full_f64", 2), ("env_cartpole_f64", 3)]
+
+
+@pytest.mark.parametrize("name,kind", ENV_CASES)
+def test_env_oracle_matches_reference_modules(name, kind):
+    """step == PendulumDx / CartpoleDx.forward; linearize == MPC.linearize_dynamics(AUTO_DIFF), which
+    re-rolls the trajectory from x[0] (mpc/mpc.py:524-527, 592-593); rollout == LQRStep with the module
+    as true_dynamics (mpc/lqr_step.py:223-225)."""
+    from oracle import env_oracle as E
+    z = golden(name)
+    ns, nc, T, B = (int(v) for v in z["meta"])
+    prm = z["params"]
+    x, u = z["x"][:-1].reshape(-1, ns), z["u"][:-1].reshape(-1, nc)
+    np.testing.assert_allclose(E.step(kind, x, u, prm), z["next"].reshape(-1, ns), rtol=1e-13, atol=1e-13)
+    xr = E.traj(kind, z["x"][0], z["u"], prm)
+    F, f = E.linearize(kind, xr[:-1].reshape(-1, ns), u, prm)
+    np.testing.assert_allclose(F, z["F"].reshape(F.shape), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(f, z["f"].reshape(f.shape), rtol=1e-9, atol=1e-9)
+    # controls past the module's clamp are in the pendulum fixtures: their column of F is exactly zero
+    sat = np.abs(u[:, 0]) > E.u_max_of(kind)
+    assert (kind == 3 or sat.any()) and np.all(F[sat][:, :, ns] == 0)
+    # one LQR step: sweep (C oracle) + rollout through the simulator
+    o = O.lqr_step(z["x_init"], z["Q"], z["p"], z["step_F"], z["step_f"], z["step_cur_x"], z["step_cur_u"],
+                   float(z["lower"][0]), float(z["upper"][0]), linesearch_decay=float(z["decay"][0]),
+                   max_linesearch_iter=int(z["max_ls"][0]), return_gains=True)
+    nx, nu, costs, full, alphas = E.rollout(kind, prm, z["x_init"], z["Q"], z["p"], o["K"], o["k"], z["step_cur_x"],
+                                            z["step_cur_u"], float(z["lower"][0]), float(z["upper"][0]),
+                                            float(z["decay"][0]), int(z["max_ls"][0]))
+    np.testing.assert_allclose(nx, z["step_new_x"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nu, z["step_new_u"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(costs, z["step_costs"], rtol=1e-9)
+
+
+def test_env_oracle_clamp_derivative_on_the_bound():
+    """torch.clamp passes the gradient on the CLOSED interval; a control sitting exactly on its bound
+    (where a bounded solve puts it) keeps its full derivative."""
+    from oracle import env_oracle as E
+    x = np.array([[0.3, 0.9, 0.1]])
+    F_in, _ = E.linearize(1, x, np.array([[1.0]]), np.array([10., 1., 1.]))
+    F_on, _ = E.linearize(1, x, np.array([[2.0]]), np.array([10., 1., 1.]))
+    F_out, _ = E.linearize(1, x, np.array([[2.0 + 1e-9]]), np.array([10., 1., 1.]))
+    np.testing.assert_allclose(F_on[0, 2, 3], F_in[0, 2, 3], rtol=1e-9)
+    assert np.all(F_out[0, :, 3] == 0)
