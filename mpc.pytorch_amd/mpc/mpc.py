@@ -30,6 +30,22 @@ class GradMethods(Enum):
     ANALYTIC_CHECK = 4
 
 
+class SlewRateCost(Module):
+    """A module cost plus the slew-rate quadratic on the augmented variable (u_prev, x, u)
+    (reference mpc/mpc.py:36-56)."""
+
+    def __init__(self, cost, slew_C, n_state, n_ctrl):
+        super().__init__()
+        self.cost, self.slew_C = cost, slew_C
+        self.n_state, self.n_ctrl = n_state, n_ctrl
+
+    def forward(self, tau):
+        return self.cost(tau[:, self.n_ctrl:]) + 0.5 * util.bquad(tau, self.slew_C[0])   # time-invariant
+
+    def grad_input(self, x, u):
+        raise NotImplementedError("Implement grad_input")
+
+
 class UnconvergedError(AssertionError):
     """Raised where the reference does a bare `assert False` (mpc/mpc.py:321-324): some problem did
     not reach a fixed point and exit_unconverged=True."""
@@ -260,8 +276,7 @@ class MPC(Module):
     def solve_lqr_subproblem(self, x_init, C, c, F, f, cost, dynamics, x, u, no_op_forward=False):
         """Build the LQRStep for the current nominal (x,u) and apply it (mpc/mpc.py:339-361)."""
         if self.slew_rate_penalty is not None and not isinstance(cost, Module):
-            raise NotImplementedError(
-                "slew_rate_penalty is outside this build's hot-path scope (SURVEY.md section 8f-4)")
+            return self._solve_slew_subproblem(x_init, C, c, F, f, cost, dynamics, x, u, no_op_forward)
         step = LQRStep(
             n_state=self.n_state, n_ctrl=self.n_ctrl, T=self.T,
             u_lower=self.u_lower, u_upper=self.u_upper, u_zero_I=self.u_zero_I,
@@ -271,6 +286,48 @@ class MPC(Module):
             no_op_forward=no_op_forward)
         empty = torch.empty(0, dtype=x_init.dtype, device=x_init.device)
         return step(x_init, C, c, F, f if f is not None else empty)
+
+    def _solve_slew_subproblem(self, x_init, C, c, F, f, cost, dynamics, x, u, no_op_forward):
+        """slew_rate_penalty: the same LQR step on the state augmented with the previous control,
+        z_t = (u_{t-1}, x_t), with 0.5*gamma*|u_t - u_{t-1}|^2 added to the stage cost
+        (reference mpc/mpc.py:362-445).  Pure re-packing around the kernel; autograd reaches C, c, F, f
+        through the padding ops."""
+        from .dynamics import CtrlPassthroughDynamics
+        T, ns, nc = self.T, self.n_state, self.n_ctrl
+        B = C.size(1)
+        n, na = ns + nc, ns + 2 * nc
+        kw = dict(dtype=C.dtype, device=C.device)
+        gI = self.slew_rate_penalty * torch.eye(nc, **kw)
+        slew_C = torch.zeros(T, B, na, na, **kw)
+        slew_C[:, :, :nc, :nc] = gI
+        slew_C[:, :, -nc:, :nc] = -gI
+        slew_C[:, :, :nc, -nc:] = -gI
+        slew_C[:, :, -nc:, -nc:] = gI
+        aC = slew_C + torch.nn.functional.pad(C, (nc, 0, nc, 0))
+        ac = torch.cat((torch.zeros(T, B, nc, **kw), c), 2)
+        carry = torch.cat((torch.zeros(nc, n, **kw), torch.eye(nc, **kw)), 1)       # u_t -> next state's u_{t-1}
+        aF = torch.cat((carry.expand(T - 1, B, nc, na),
+                        torch.cat((torch.zeros(T - 1, B, ns, nc, **kw), F), 3)), 2)
+        af = None if f is None or f.numel() == 0 else torch.cat((torch.zeros(T - 1, B, nc, **kw), f), 2)
+        if self.prev_ctrl is not None:
+            prev_u = self.prev_ctrl.detach().to(**kw)
+            while prev_u.ndimension() < 3:
+                prev_u = prev_u.unsqueeze(0)
+        else:
+            prev_u = torch.zeros(1, B, nc, **kw)
+        prev_u = prev_u.expand(1, B, nc)
+        ax = torch.cat((torch.cat((prev_u, util.detach_maybe(u)[:-1])), x), 2)
+        ax_init = torch.cat((prev_u[0], x_init), 1)
+        a_dyn = None if isinstance(dynamics, LinDx) else CtrlPassthroughDynamics(dynamics)
+        a_cost = QuadCost(aC, ac) if isinstance(cost, QuadCost) else SlewRateCost(cost, slew_C, ns, nc)
+        step = LQRStep(
+            n_state=n, n_ctrl=nc, T=T, u_lower=self.u_lower, u_upper=self.u_upper, u_zero_I=self.u_zero_I,
+            true_cost=a_cost, true_dynamics=a_dyn, delta_u=self.delta_u,
+            linesearch_decay=self.linesearch_decay, max_linesearch_iter=self.max_linesearch_iter,
+            delta_space=True, current_x=ax, current_u=u, back_eps=self.back_eps, no_op_forward=no_op_forward)
+        empty = torch.empty(0, **kw)
+        out = step(ax_init, aC, ac, aF, af if af is not None else empty)
+        return (out[0][:, :, nc:],) + tuple(out[1:])
 
     # ------------------------------------------------------------------------------------------
     def approximate_cost(self, x, u, Cf, diff=True):

@@ -307,6 +307,37 @@ def env_lin_case(name, kind, T, B, seed, simple=True, params=None):
          step_new_u=npy(new_u), step_costs=npy(costs), step_full_du_norm=npy(fdn))
 
 
+def slew_case(name, seed, ns=2, nc=2, T=4, B=2, gamma=1.0, prev=False):
+    """tests/test_mpc.py:652-744 (test_lqr_backward_cost_nn_dynamics_module_constrained_slew): MPC with
+    slew_rate_penalty on an NNDynamics module, box constraints, ANALYTIC linearisation; the solve and
+    the gradients of a fixed linear functional of (x,u) w.r.t. C, c, x_init and the first bias."""
+    from mpc_ref.dynamics import NNDynamics
+    npr.seed(seed)
+    torch.manual_seed(seed)
+    n = ns + nc
+    C = 10. * npr.randn(T, B, n, n)
+    C = np.matmul(C.transpose(0, 1, 3, 2), C)
+    c = 10. * npr.randn(T, B, n)
+    x_init = npr.randn(B, ns)
+    lo, hi = -np.ones((T, B, nc)), np.ones((T, B, nc))
+    dyn = NNDynamics(ns, nc, [10, 10], activation='sigmoid').double()
+    prev_ctrl = torch.tensor(0.3 * npr.randn(B, nc)) if prev else None
+    wx, wu = npr.randn(T, B, ns), npr.randn(T, B, nc)
+    tC, tc, tx0 = (torch.tensor(a, requires_grad=True) for a in (C, c, x_init))
+    ctrl = ref_mpc.MPC(ns, nc, T, torch.tensor(lo), torch.tensor(hi), None, lqr_iter=40, verbose=-1,
+                       max_linesearch_iter=1, grad_method=ref_mpc.GradMethods.ANALYTIC,
+                       slew_rate_penalty=gamma, prev_ctrl=prev_ctrl, exit_unconverged=False)
+    (x, u, costs), _ = quiet(ctrl, tx0, QuadCost(tC, tc), dyn)
+    loss = (x * torch.tensor(wx)).sum() + (u * torch.tensor(wu)).sum()
+    gC, gc, gx0, gb0 = torch.autograd.grad(loss, [tC, tc, tx0, dyn.fcs[0].bias])
+    arrs = {}
+    for i, fc in enumerate(dyn.fcs):
+        arrs["W%d" % i], arrs["b%d" % i] = npy(fc.weight), npy(fc.bias)
+    save(name, meta=np.array([ns, nc, T, B]), gamma=np.array([gamma]), C=C, c=c, x_init=x_init, lo=lo, hi=hi,
+         prev_ctrl=npy(prev_ctrl), wx=wx, wu=wu, x=npy(x), u=npy(u), costs=npy(costs), gC=npy(gC), gc=npy(gc),
+         gx0=npy(gx0), gb0=npy(gb0), **arrs)
+
+
 def gen_mpc_cases():
     # (1) notebook known answer: examples/Time Varying Linear-Quadratic Control.ipynb cell 1
     torch.manual_seed(0)
@@ -500,6 +531,8 @@ if __name__ == "__main__":
     if not only or "env" in only:
         env_case("ilqr_pendulum_f64", "pendulum", 20, 4, 8, 51)
         env_case("ilqr_cartpole_f64", "cartpole", 25, 4, 8, 52)
+        slew_case("mpc_slew_nn_f64", 0)
+        slew_case("mpc_slew_nn_prev_f64", 3, T=5, B=3, gamma=0.5, prev=True)
         env_lin_case("env_pendulum_f64", "pendulum", 12, 6, 61)
         env_lin_case("env_pendulum_full_f64", "pendulum", 12, 6, 62, simple=False,
                      params=(9.0, 1.2, 0.8, 0.3, 0.2))

@@ -271,6 +271,21 @@ def test_ilqr_on_simulator_dynamics_on_gpu(be, kind):
     np.testing.assert_allclose(host(u), z["u"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["mpc_slew_nn_f64", "mpc_slew_nn_prev_f64"])
+def test_slew_rate_penalty_on_gpu(be, name):
+    """slew_rate_penalty on the device == the reference's solve and gradients (float64; tolerance = the
+    pnqp stopping rule, the reference couples the problems of a batch through it)."""
+    from test_host_logic import run_slew_golden
+    z = golden(name)
+    x, u, costs, gC, gc, gx0, gb0 = run_slew_golden(z, device=DEV)
+    assert u.is_cuda
+    np.testing.assert_allclose(host(u), z["u"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(host(x), z["x"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(host(costs), z["costs"], rtol=2e-4)
+    for g, k in ((gC, "gC"), (gc, "gc"), (gx0, "gx0"), (gb0, "gb0")):
+        np.testing.assert_allclose(host(g), z[k], rtol=2e-3, atol=2e-4 * (1 + np.abs(z[k]).max()))
+
+
 ENV_CASES = [("env_pendulum_f64", 1), ("env_pendulum_full_f64", 2), ("env_cartpole_f64", 3)]
 
 

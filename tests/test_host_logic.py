@@ -216,6 +216,50 @@ def test_dynamics_modules():
     np.testing.assert_allclose(out[:, 2:].numpy(), aff(x, u).numpy())
 
 
+def run_slew_golden(z, device=None):
+    from mpc.dynamics import NNDynamics
+    ns, nc, T, B = (int(v) for v in z["meta"])
+    mv = (lambda t: t if device is None else t.to(device))
+    dyn = NNDynamics(ns, nc, [10, 10], activation="sigmoid").double()
+    with torch.no_grad():
+        for i, fc in enumerate(dyn.fcs):
+            fc.weight.copy_(torch.from_numpy(z["W%d" % i]))
+            fc.bias.copy_(torch.from_numpy(z["b%d" % i]))
+    if device is not None:
+        dyn = dyn.to(device)
+        dyn._wire()
+    C, c, x0 = (mv(tt(z, k)).requires_grad_(True) for k in ("C", "c", "x_init"))
+    prev = mv(tt(z, "prev_ctrl")) if "prev_ctrl" in z else None
+    ctrl = mpc.MPC(ns, nc, T, mv(tt(z, "lo")), mv(tt(z, "hi")), None, lqr_iter=40, verbose=-1,
+                   max_linesearch_iter=1, grad_method=GradMethods.ANALYTIC,
+                   slew_rate_penalty=float(z["gamma"][0]), prev_ctrl=prev, exit_unconverged=False)
+    x, u, costs = ctrl(x0, QuadCost(C, c), dyn)
+    loss = (x * mv(tt(z, "wx"))).sum() + (u * mv(tt(z, "wu"))).sum()
+    gC, gc, gx0, gb0 = torch.autograd.grad(loss, [C, c, x0, dyn.fcs[0].bias])
+    return x, u, costs, gC, gc, gx0, gb0
+
+
+@pytest.mark.parametrize("name", ["mpc_slew_nn_f64", "mpc_slew_nn_prev_f64"])
+@pytest.mark.parametrize("lockstep", [True, False])
+def test_slew_rate_penalty_matches_reference(name, lockstep):
+    """slew_rate_penalty (+ prev_ctrl) on an NNDynamics module with box constraints -- the setting of the
+    reference's tests/test_mpc.py:652-744: same solve, same gradients w.r.t. C, c, x_init and a weight
+    of the dynamics network.  lockstep: the oracle replays the reference's batch-global pnqp loop ->
+    agreement to rounding; per-problem (what the kernels do): within the pnqp stopping tolerance."""
+    prev = _native.set_backend_for_testing(OracleBackend(lockstep=lockstep))
+    try:
+        z = golden(name)
+        x, u, costs, gC, gc, gx0, gb0 = run_slew_golden(z)
+    finally:
+        _native.set_backend_for_testing(prev)
+    tol = 1e-9 if lockstep else 2e-4
+    np.testing.assert_allclose(u.detach().numpy(), z["u"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(x.detach().numpy(), z["x"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(costs.detach().numpy(), z["costs"], rtol=max(tol, 1e-6))
+    for g, k in ((gC, "gC"), (gc, "gc"), (gx0, "gx0"), (gb0, "gb0")):
+        np.testing.assert_allclose(g.numpy(), z[k], rtol=max(tol, 1e-7) * 10, atol=max(tol, 1e-9) * (1 + np.abs(z[k]).max()))
+
+
 @pytest.mark.parametrize("name", MPC_CASES)
 def test_mpc_forward_matches_reference_solves(name, oracle_backend):
     """tests/test_mpc.py:91-299 inputs + the notebook problem: same (x, u, costs) as the reference."""
