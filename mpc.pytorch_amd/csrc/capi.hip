@@ -70,6 +70,15 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
     const int64_t needk = (int64_t)p->T * p->B * p->nc * (int64_t)sizeof(real);
     if (sp.env.kind && (impl == 2 || impl == 3))
         return fail(MPC_E_ARG, "a simulator as true_dynamics runs on the generic kernels only");
+    if (impl == 4 && (phase_mask != 3 || !tiny_supported(p->ns, p->nc)))
+        return fail(MPC_E_DIMS, "lane-per-problem kernel needs n_ctrl = 1, n_state <= 6");
+    if (phase_mask == 3 && (impl == 4 || (impl == 0 && tiny_supported(p->ns, p->nc)))) {
+        // one lane per problem; gains parked in the workspace as [T][ns+1][B]
+        if (!workspace || workspace_bytes < needK + needk)
+            return fail(MPC_E_ARG, "workspace too small (see mpc_lqr_workspace_bytes)");
+        sp.Kk = (real *)workspace;
+        return launch_step_tiny<real>(sp, st);
+    }
     if (phase_mask == 3 && impl != 1 && !sp.env.kind) {
         if constexpr (sizeof(real) == 4) {
             // the fused kernels park their gains [T,B,64] in the workspace; out->K / out->k are optional
@@ -111,7 +120,7 @@ int mpc_lqr_abi_version(void) { return MPC_LQR_ABI_VERSION; }
 const char *mpc_lqr_build_info(void)
 {
     return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32>, lqr_step_dpp16<f32>, "
-           "kkt_grads, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
+           "lqr_step_tiny<f32,f64>, env_linearize, kkt_grads, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
 }
 
 const char *mpc_lqr_last_error(void) { return g_last_error.c_str(); }
@@ -142,6 +151,7 @@ int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, i
 {
     if (!p || check_problem(p, false, false) != MPC_OK || check_options(p, o) != MPC_OK) return 0;
     if (impl == 1) return generic_lds_bytes(p->ns, p->nc, p->dtype == MPC_F64 ? 8 : 4) <= 160 * 1024;
+    if (impl == 4) return tiny_supported(p->ns, p->nc) ? 1 : 0;
     if (impl == 2 || impl == 3) {
         if (p->dtype != MPC_F32) return 0;
         mpc_lqr_outputs out;

@@ -45,6 +45,10 @@ bool kkt_dpp16_supported(const StepParams<float> &p, const float *dx, const floa
 int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,
                      float *dc, float *dF, float *df, float *dx_init, hipStream_t st);
 
+// one lane per problem, n_ctrl = 1, n_state <= 6, f32 / f64 (lqr_tiny.hip)
+bool tiny_supported(int ns, int nc);
+template <typename real> int launch_step_tiny(const StepParams<real> &p, hipStream_t st);
+
 // fused MFMA path for n <= 16, f32 (lqr_mfma16.hip)
 bool mfma16_supported(const StepParams<float> &p);
 int launch_step_mfma16(const StepParams<float> &p, hipStream_t st);

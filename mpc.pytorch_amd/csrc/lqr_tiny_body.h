@@ -1,0 +1,238 @@
+// lqr_tiny_body.h -- one LQR step for problems with ONE control and a handful of states
+// (the reference's pendulum / cart-pole iLQR, BASELINE configs 2 and 3), ONE LANE PER PROBLEM.
+//
+// At n = n_state + 1 <= 7 a problem's whole Riccati recursion fits in one lane's registers
+// (Q 7x7, V 6x6, F 6x7): no LDS, no barriers, no cross-lane traffic, 64 problems per wavefront.
+// The generic kernel spends a wavefront (and ~10 barriers per timestep) on each of these.
+// Same semantics as lqr_generic.hip, specialised to n_ctrl = 1:
+//   sweep    mpc/lqr_step.py:52-160 (the nc == 1 branches :86-87, :121-123, :144-146)
+//   pnqp     mpc/pnqp.py:5-82 with n = 1 (:15-16, :50-51)
+//   rollout  mpc/lqr_step.py:164-261, true dynamics = F,f (:216-222) or a shipped simulator (:223-225)
+// Plain C++ (no HIP builtins): tests/emu/ compiles this header for the host and checks it against the
+// reference's golden outputs on a CPU-only box.
+#pragma once
+#include <math.h>
+#include "lqr_params.h"
+
+namespace mpclqr {
+namespace tiny {
+
+template <typename real> MPC_HD real clampr(real x, real lo, real hi)
+{
+    if (x < lo) x = lo;      // util.eclamp (mpc/util.py:56-70): strict compares, bound written exactly
+    if (x > hi) x = hi;
+    return x;
+}
+template <typename real> MPC_HD real absr(real x) { return x < 0 ? -x : x; }
+
+// pnqp for n = 1 (mpc/pnqp.py:5-82).  Returns the iteration index the reference returns; x in/out,
+// Hfree = the (regularised) free-set Hessian the returned x belongs to, is_free its free flag.
+template <typename real>
+MPC_HD int pnqp1(real H, real q, real lb, real ub, real &x, real &Hfree, bool &is_free, int n_iter, bool &conv)
+{
+    const real GAMMA = (real)0.1;
+    x = clampr<real>(x, lb, ub);                                   // :23
+    conv = false;
+    int ret = n_iter - 1;
+    Hfree = H + (real)1e-11;
+    is_free = true;
+    for (int it = 0; it < n_iter; ++it) {
+        const real g = H * x + q;                                  // :29
+        const bool ic = (x == lb && g > 0) || (x == ub && g < 0);  // :32
+        is_free = !ic;
+        Hfree = (is_free ? H : (real)0) + (real)1e-11;             // :44-48
+        const real dx = -((is_free ? g : (real)0) / Hfree);        // :50-51
+        if (!(absr<real>(dx) >= (real)1e-4)) { conv = true; ret = it; break; }   // :56-59
+        real alpha = 1, arm = GAMMA, xn = x;
+        int count = 0;
+        const real ox = (real)0.5 * H * x * x + q * x;
+        while (arm <= GAMMA && count < 10) {                       // :64-76
+            xn = clampr<real>(x + alpha * dx, lb, ub);
+            const real on = (real)0.5 * H * xn * xn + q * xn;
+            arm = (ox - on) / (g * (x - xn));
+            if (arm <= GAMMA) alpha *= (real)0.1;
+            ++count;
+        }
+        x = xn;                                                    // :78
+    }
+    return ret;
+}
+
+// One problem.  Kw: gain scratch laid out [T][NS+1][B] (k in row NS) so neighbouring lanes touch
+// neighbouring words.
+template <typename real, int NS>
+MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw)
+{
+    constexpr int N = NS + 1;
+    const int T = p.T, B = p.B;
+    real V[NS][NS], v[NS];
+    real old_cost = 0;
+    int status = 0, qp_total = 0;
+    bool warm = false;
+    real kprev = 0;
+
+    // ------------------------------------------------------------------ sweep
+    for (int t = T - 1; t >= 0; --t) {
+        const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+        const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+        const long tb = (long)t * B + b;
+        real Q[N][N], q[N], tau[N];
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) Q[i][j] = Ct[i * N + j];
+        for (int i = 0; i < NS; ++i) tau[i] = p.cur_x[tb * NS + i];
+        tau[NS] = p.cur_u[tb];
+        for (int i = 0; i < N; ++i) {                  // c_back = C tau + c (:289-295) and the nominal cost (:169)
+            real r = 0;
+            for (int j = 0; j < N; ++j) r += Q[i][j] * tau[j];
+            const real ci = ct[i];
+            old_cost += (real)0.5 * tau[i] * r + ci * tau[i];
+            q[i] = r + ci;
+        }
+        if (t < T - 1) {                               // Q = C + F'VF, q = c_back + F'v (:65-70)
+            const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
+            real F[NS][N];
+            for (int m = 0; m < NS; ++m)
+                for (int j = 0; j < N; ++j) F[m][j] = Ft[m * N + j];
+            for (int j = 0; j < N; ++j) {
+                real Y[NS];                            // column j of V F
+                for (int m = 0; m < NS; ++m) {
+                    real r = 0;
+                    for (int l = 0; l < NS; ++l) r += V[m][l] * F[l][j];
+                    Y[m] = r;
+                }
+                for (int i = 0; i < N; ++i) {
+                    real r = 0;
+                    for (int m = 0; m < NS; ++m) r += F[m][i] * Y[m];
+                    Q[i][j] += r;
+                }
+            }
+            for (int i = 0; i < N; ++i) {
+                real r = 0;
+                for (int m = 0; m < NS; ++m) r += F[m][i] * v[m];
+                q[i] += r;
+            }
+        }
+        const real Quu = Q[NS][NS], qu = q[NS];
+        real K[NS], k;
+        if (p.bound_mode == MPC_BOUND_NONE) {
+            const bool masked = p.zero_mask && p.zero_mask[tb];
+            if (masked) {                              // :99-127 with the control pinned: K = 0, k = 0
+                for (int j = 0; j < NS; ++j) K[j] = 0;
+                k = 0;
+            } else {                                   // :86-87
+                const real inv = (real)1 / Quu;
+                for (int j = 0; j < NS; ++j) K[j] = -(inv * Q[NS][j]);
+                k = -(inv * qu);
+            }
+        } else {                                       // :128-148
+            const real u = tau[NS];
+            real lb = (p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[tb]) - u;
+            real ub = (p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : p.hi[tb]) - u;
+            if (p.has_delta) {                         // :132-134
+                if (lb < -p.delta_u) lb = -p.delta_u;
+                if (ub > p.delta_u) ub = p.delta_u;
+            }
+            real x = warm ? kprev : -(qu / Quu);       // warm start = k_{t+1} (:137,141) / cold start pnqp.py:15-16
+            real Hf;
+            bool is_free, conv;
+            const int it = pnqp1<real>(Quu, qu, lb, ub, x, Hf, is_free, p.pnqp_iter, conv);
+            qp_total += 1 + it;                        // :140
+            if (!conv) status |= MPC_ST_PNQP_UNCONVERGED;
+            warm = true;
+            k = x;
+            for (int j = 0; j < NS; ++j) K[j] = is_free ? -(Q[NS][j] / Hf) : (real)0;   // :142-146
+        }
+        kprev = k;
+        for (int j = 0; j < NS; ++j) Kw[((long)t * N + j) * B + b] = K[j];
+        Kw[((long)t * N + NS) * B + b] = k;
+        if (p.K) for (int j = 0; j < NS; ++j) p.K[tb * NS + j] = K[j];
+        if (p.k) p.k[tb] = k;
+        // :155-158 V = Qxx + Qxu K + K'Qux + K'Quu K, v likewise (unmasked Quu, qu)
+        real M[NS];
+        for (int j = 0; j < NS; ++j) M[j] = Q[NS][j] + Quu * K[j];
+        const real mk = qu + Quu * k;
+        for (int i = 0; i < NS; ++i) {
+            for (int j = 0; j < NS; ++j) V[i][j] = Q[i][j] + Q[i][NS] * K[j] + K[i] * M[j];
+            v[i] = q[i] + Q[i][NS] * k + K[i] * mk;
+        }
+    }
+
+    // ------------------------------------------------------------------ rollout + line search
+    real alpha = 1, cost = 0, dun = 0, full = 0;
+    for (int pass = 0; pass < p.max_ls; ++pass) {
+        real x[NS], dx[NS];
+        for (int i = 0; i < NS; ++i) {
+            x[i] = p.x_init[(long)b * NS + i];
+            dx[i] = 0;
+            p.new_x[(long)b * NS + i] = x[i];
+        }
+        real ca = 0, da = 0;
+        for (int t = 0; t < T; ++t) {
+            const long tb = (long)t * B + b;
+            const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+            const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+            real r = 0;
+            for (int j = 0; j < NS; ++j) r += Kw[((long)t * N + j) * B + b] * dx[j];
+            const real u = p.cur_u[tb];
+            real un = r + u + alpha * Kw[((long)t * N + NS) * B + b];          // :192
+            if (p.zero_mask && p.zero_mask[tb]) un = 0;                         // :197-198
+            if (p.bound_mode != MPC_BOUND_NONE) {                               // :200-213
+                real l = p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[tb];
+                real h = p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : p.hi[tb];
+                if (p.has_delta) {
+                    const real l2 = u - p.delta_u, h2 = u + p.delta_u;
+                    l = (l2 < l) ? l : l2;
+                    h = (h2 > h) ? h : h2;
+                }
+                un = clampr<real>(un, l, h);
+            }
+            p.new_u[tb] = un;
+            da += (u - un) * (u - un);
+            real tau[N];
+            for (int j = 0; j < NS; ++j) tau[j] = x[j];
+            tau[NS] = un;
+            for (int i = 0; i < N; ++i) {                                       // :230-232
+                real s = 0;
+                for (int j = 0; j < N; ++j) s += Ct[i * N + j] * tau[j];
+                ca += (real)0.5 * tau[i] * s + ct[i] * tau[i];
+            }
+            if (t < T - 1) {
+                real xn[NS];
+                if (p.env.kind) {                                               // :223-225
+                    env_step<real>(p.env, x, un, xn, nullptr);
+                } else {                                                        // :216-222
+                    const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
+                    const real *ft = p.f ? p.f + (long)t * p.f_st + (long)b * p.f_sb : nullptr;
+                    for (int i = 0; i < NS; ++i) {
+                        real s = 0;
+                        for (int j = 0; j < N; ++j) s += Ft[i * N + j] * tau[j];
+                        xn[i] = ft ? s + ft[i] : s;
+                    }
+                }
+                const long tb1 = (long)(t + 1) * B + b;
+                for (int i = 0; i < NS; ++i) {
+                    x[i] = xn[i];
+                    dx[i] = xn[i] - p.cur_x[tb1 * NS + i];
+                    p.new_x[tb1 * NS + i] = xn[i];
+                }
+            }
+        }
+        cost = ca;
+        dun = sqrt(da);
+        if (pass == 0) full = dun;                                              // :243-245
+        if (cost > old_cost && pass + 1 < p.max_ls) alpha *= p.ls_decay; else break;   // :176-179, 247
+    }
+    if (!(cost == cost) || absr<real>(cost) > (real)3e38) status |= MPC_ST_NONFINITE;
+    if (p.costs) p.costs[b] = cost;
+    if (p.old_costs) p.old_costs[b] = old_cost;
+    if (p.full_du_norm) p.full_du_norm[b] = full;
+    if (p.alpha_du_norm) p.alpha_du_norm[b] = dun;
+    if (p.alphas) p.alphas[b] = alpha;
+    if (p.qp_iters) p.qp_iters[b] = qp_total;
+    if (p.status) p.status[b] = status;
+}
+
+MPC_HD bool shape_supported(int ns, int nc) { return nc == 1 && ns >= 1 && ns <= 6; }
+
+}  // namespace tiny
+}  // namespace mpclqr

@@ -452,3 +452,31 @@ extern "C" void emu_env_linearize_f32(int kind, const float *params, double dt, 
 {
     env_linearize_host<float>(kind, params, dt, umax, N, x, u, nxt, F, f);
 }
+
+// ---- lqr_tiny_body.h on the host: no cross-lane traffic, so a plain loop over the problems -------
+#include "../../mpc.pytorch_amd/csrc/lqr_tiny_body.h"
+template <typename real> static int tiny_host(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out)
+{
+    mpclqr::StepParams<real> sp = mpclqr::make_params<real>(p, o, out);
+    if (!mpclqr::tiny::shape_supported(sp.ns, sp.nc)) return MPC_E_DIMS;
+    if (!sp.new_x || !sp.new_u) return MPC_E_NULL;
+    const size_t need = (size_t)sp.T * sp.B * (sp.ns + 1);
+    real *kw = (real *)malloc(need * sizeof(real));
+    for (size_t i = 0; i < need; ++i) kw[i] = (real)NAN;
+    for (int b = 0; b < sp.B; ++b) {
+        switch (sp.ns) {
+        case 1: mpclqr::tiny::lqr_step_problem<real, 1>(sp, b, kw); break;
+        case 2: mpclqr::tiny::lqr_step_problem<real, 2>(sp, b, kw); break;
+        case 3: mpclqr::tiny::lqr_step_problem<real, 3>(sp, b, kw); break;
+        case 4: mpclqr::tiny::lqr_step_problem<real, 4>(sp, b, kw); break;
+        case 5: mpclqr::tiny::lqr_step_problem<real, 5>(sp, b, kw); break;
+        case 6: mpclqr::tiny::lqr_step_problem<real, 6>(sp, b, kw); break;
+        }
+    }
+    free(kw);
+    return 0;
+}
+extern "C" int emu_lqr_step_tiny(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out)
+{
+    return p->dtype == MPC_F32 ? tiny_host<float>(p, o, out) : tiny_host<double>(p, o, out);
+}

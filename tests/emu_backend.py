@@ -23,7 +23,7 @@ def build():
     src = os.path.join(_EMU, "emu_mfma16.cpp")
     csrc = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc")
     deps = [src] + [os.path.join(csrc, h) for h in ("lqr_mfma16_body.h", "lqr_dpp16_body.h", "lqr_small_math.h",
-                                                    "lqr_params.h", "env_dynamics.h")]
+                                                    "lqr_params.h", "env_dynamics.h", "lqr_tiny_body.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         cxx = "/opt/rocm/lib/llvm/bin/clang++"
         if not os.path.exists(cxx):
@@ -50,9 +50,12 @@ def _ptr(a):
 
 def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None,
              linesearch_decay=0.2, max_linesearch_iter=10, pnqp_iter=20, force_general=False, dma_late=False,
-             kernel="mfma16"):
-    """Same signature as oracle.lqr_oracle.lqr_step; float32 only.  Returns the kernel's outputs."""
-    f32 = np.float32
+             kernel="mfma16", dtype=np.float32, env=None):
+    """Same signature as oracle.lqr_oracle.lqr_step.  Returns the kernel's outputs.  The fused
+    kernels are float32; kernel="tiny" (lane-per-problem body, n_ctrl = 1) also runs in float64 and
+    takes env = (kind, params, dt, u_max): a shipped simulator as the rollout's true dynamics."""
+    f32 = np.dtype(dtype).type
+    assert f32 == np.float32 or kernel == "tiny"
     C = np.ascontiguousarray(C, f32); c = np.ascontiguousarray(c, f32)
     x_init = np.ascontiguousarray(x_init, f32)
     T, B, n, _ = C.shape
@@ -62,7 +65,7 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
     f = None if (f is None or np.asarray(f).size == 0) else np.ascontiguousarray(f, f32)
     cur_x = np.ascontiguousarray(cur_x, f32); cur_u = np.ascontiguousarray(cur_u, f32)
     p = N.Problem()
-    p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, N.MPC_F32
+    p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, (N.MPC_F32 if f32 == np.float32 else N.MPC_F64)
     p.x_init = _ptr(x_init)
     p.C, p.C_st, p.C_sb = _ptr(C), B * n * n, n * n
     p.c, p.c_st, p.c_sb = _ptr(c), B * n, n
@@ -99,7 +102,18 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
     for key, arr in res.items():
         setattr(out, key, _ptr(arr))
     lib().emu_set_dma_late(int(bool(dma_late)))
-    if kernel == "dpp16":
+    if env is not None:
+        e = N.EnvDynamics()
+        prm = np.ascontiguousarray(env[1], f32)
+        keep.append(prm)
+        e.kind, e.params, e.dt, e.u_max = int(env[0]), _ptr(prm), float(env[2]), float(env[3])
+        keep.append(e)
+        o.true_dynamics = ctypes.pointer(e)
+    if kernel == "tiny":
+        fn = lib().emu_lqr_step_tiny
+        fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs)]
+        rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
+    elif kernel == "dpp16":
         rc = lib().emu_lqr_step_dpp16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
     else:
         rc = lib().emu_lqr_step_mfma16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), int(force_general))

@@ -264,3 +264,87 @@ def test_env_dynamics_header_matches_reference_modules(name, kind):
     _, F_on, _ = EB.env_linearize(1, [10., 1., 1.], 0.05, 2.0, [[0.3, 0.9, 0.1]], [[2.0]])
     _, F_in, _ = EB.env_linearize(1, [10., 1., 1.], 0.05, 2.0, [[0.3, 0.9, 0.1]], [[1.0]])
     assert F_on[0, 2, 3] == F_in[0, 2, 3] != 0
+
+
+# ---------------------------------------------------------------------------------------------
+# The lane-per-problem body (csrc/lqr_tiny_body.h): n_ctrl = 1, n_state <= 6, float32 / float64
+# ---------------------------------------------------------------------------------------------
+NC1_CASES = [c for c in sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "step_*.npz")))
+             if golden(c)["meta"][1] == 1 and golden(c)["meta"][0] <= 6]
+
+
+@pytest.mark.parametrize("name", NC1_CASES)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tiny_body_matches_oracle_and_reference(emu, name, dtype):
+    """One-control fixtures (scalar pnqp, masked, unbounded): the lane-per-problem body against the
+    oracle (float64: to rounding, same QP iteration counts) and the reference's per-problem outputs."""
+    from oracle import lqr_oracle as O
+    z = golden(name)
+    kw = {k: (v.astype(dtype) if isinstance(v, np.ndarray) and v.dtype.kind == "f" else v) for k, v in step_kwargs(z).items()}
+    o = O.lqr_step(lockstep=False, return_gains=True, **kw)
+    r = emu.lqr_step(kernel="tiny", dtype=dtype, **kw)
+    tol = dict(rtol=1e-11, atol=1e-12) if dtype == np.float64 else dict(rtol=1e-3, atol=1e-4)
+    for key in ("new_x", "new_u", "costs", "old_costs", "full_du_norm", "alpha_du_norm"):
+        np.testing.assert_allclose(r[key], o[key], err_msg=key, **tol)
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+    np.testing.assert_allclose(r["K"], o["K"], **tol)
+    np.testing.assert_allclose(r["k"], o["k"], **tol)
+    if dtype == np.float64:
+        assert int(r["qp_iters"].max()) <= o["n_qp_iter"] and (kw["u_lower"] is None) == (r["qp_iters"].max() == 0)
+        if z["C"].dtype == np.float64:
+            np.testing.assert_allclose(r["new_x"], z["new_x_pp"], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(r["new_u"], z["new_u_pp"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("ns", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("case", ["scalar_bounds", "tensor_bounds", "delta_u", "no_f", "backtrack", "masked", "T1"])
+def test_tiny_body_options_against_oracle(emu, ns, case):
+    from oracle import lqr_oracle as O
+    for attempt in range(40):
+        if _tiny_option_case(emu, O, ns, case, 1000 * ns + len(case) + 7919 * attempt):
+            return
+    assert False, "no seed made the line search backtrack"
+
+
+def _tiny_option_case(emu, O, ns, case, seed):
+    rng = np.random.default_rng(seed)
+    T, B, n = (1 if case == "T1" else 7), 5, ns + 1
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A) + 0.1 * np.eye(n)
+    if case == "backtrack":
+        C[:, :, :ns, :ns] -= 4.0 * np.eye(ns)
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((max(T - 1, 0), B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((max(T - 1, 0), B, ns, 1)) / np.sqrt(ns)), 3)
+    f = None if case == "no_f" else 0.1 * rng.standard_normal((max(T - 1, 0), B, ns))
+    x_init = rng.standard_normal((B, ns))
+    cur_u = np.clip(0.3 * rng.standard_normal((T, B, 1)), -0.4, 0.4)
+    cur_x, _ = O.traj_cost(x_init, cur_u, F, f)
+    kw = dict(x_init=x_init, C=C, c=c, F=F, f=f, cur_x=cur_x, cur_u=cur_u, linesearch_decay=0.5, max_linesearch_iter=4)
+    if case == "tensor_bounds":
+        kw.update(u_lower=-0.5 - rng.random((T, B, 1)), u_upper=0.5 + rng.random((T, B, 1)))
+    elif case == "delta_u":
+        kw.update(u_lower=-0.5, u_upper=0.5, delta_u=0.05)
+    elif case == "masked":
+        kw.update(u_zero_I=rng.random((T, B, 1)) < 0.4)
+    elif case != "no_f":
+        kw.update(u_lower=-0.5, u_upper=0.5)
+    o = O.lqr_step(lockstep=False, **kw)
+    r = emu.lqr_step(kernel="tiny", dtype=np.float64, **kw)
+    for key in ("new_x", "new_u", "costs", "old_costs", "full_du_norm", "alpha_du_norm", "alphas"):
+        np.testing.assert_allclose(r[key], o[key], rtol=1e-10, atol=1e-11, err_msg=key)
+    return case != "backtrack" or bool((o["alphas"] < 1).any())
+
+
+@pytest.mark.parametrize("name,kind", [("env_pendulum_f64", 1), ("env_pendulum_full_f64", 2), ("env_cartpole_f64", 3)])
+def test_tiny_body_rolls_out_through_the_simulator(emu, name, kind):
+    """LQRStep(true_dynamics=PendulumDx / CartpoleDx) of the reference (mpc/lqr_step.py:223-225) ==
+    the lane-per-problem body with the simulator inside its rollout."""
+    z = golden(name)
+    r = emu.lqr_step(z["x_init"], z["Q"], z["p"], z["step_F"], z["step_f"], z["step_cur_x"], z["step_cur_u"],
+                     float(z["lower"][0]), float(z["upper"][0]), linesearch_decay=float(z["decay"][0]),
+                     max_linesearch_iter=int(z["max_ls"][0]), kernel="tiny", dtype=np.float64,
+                     env=(kind, z["params"], 0.05, 100.0 if kind == 3 else 2.0))
+    np.testing.assert_allclose(r["new_x"], z["step_new_x"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(r["new_u"], z["step_new_u"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(r["costs"], z["step_costs"], rtol=1e-9)

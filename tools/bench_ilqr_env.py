@@ -39,7 +39,10 @@ def problem(kind, B, T):
 def run(kind, B, T, iters, reps):
     dx, plain, x0, Q, pp = problem(kind, B, T)
     out = {"config": kind, "B": B, "T": T, "lqr_iter": iters}
-    for label, mod, r in (("kernel_path", dx, reps), ("module_path", plain, max(1, reps // 5))):
+    legs = (("kernel_path", dx, reps), ("module_path", plain, max(1, reps // 5)))
+    if "--kernel-only" in sys.argv:
+        legs = legs[:1]
+    for label, mod, r in legs:
         ctrl = mpc.MPC(dx.n_state, 1, T, u_lower=dx.lower, u_upper=dx.upper, lqr_iter=iters, verbose=-1,
                        exit_unconverged=False, detach_unconverged=False, linesearch_decay=dx.linesearch_decay,
                        max_linesearch_iter=dx.max_linesearch_iter, grad_method=mpc.GradMethods.AUTO_DIFF,
@@ -53,7 +56,8 @@ def run(kind, B, T, iters, reps):
         ms = (time.perf_counter() - t0) / r * 1e3
         out[label] = {"ms_per_solve": round(ms, 3), "ms_per_ilqr_iteration": round(ms / iters, 4),
                       "problem_steps_per_s": round(B * T * iters / (ms * 1e-3)), "mean_cost": float(c.mean())}
-    out["speedup"] = round(out["module_path"]["ms_per_solve"] / out["kernel_path"]["ms_per_solve"], 1)
+    if "module_path" in out:
+        out["speedup"] = round(out["module_path"]["ms_per_solve"] / out["kernel_path"]["ms_per_solve"], 1)
     return out
 
 
