@@ -759,34 +759,45 @@ __global__ void select_best_kernel(int B, int T, int ns, int nc, int first, real
                                    const real *u, const real *costs, const real *du_norm, real *bx,
                                    real *bu, real *bc, real *bd, int *any_improved, real *max_du)
 {
-    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    if (b >= B) return;
-    const real cnew = costs[b];
-    const bool take = first || (cnew <= bc[b] + eps);
-    if (take) {
-        for (int e = tid; e < T * ns; e += nt) {
-            const int t = e / ns, i = e - t * ns;
-            bx[((long)t * B + b) * ns + i] = x[((long)t * B + b) * ns + i];
+    // one wavefront per block walks problems b = blockIdx.x, += gridDim.x; the two batch-wide
+    // reductions cost ONE atomic per block (4096 same-address atomics serialise for ~30 us)
+    const int tid = threadIdx.x, nt = blockDim.x;
+    real dmax = 0;
+    bool dnan = false, improved = false;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const real cnew = costs[b];
+        const bool take = first || (cnew <= bc[b] + eps);
+        if (take) {
+            for (int e = tid; e < T * ns; e += nt) {
+                const int t = e / ns, i = e - t * ns;
+                bx[((long)t * B + b) * ns + i] = x[((long)t * B + b) * ns + i];
+            }
+            for (int e = tid; e < T * nc; e += nt) {
+                const int t = e / nc, i = e - t * nc;
+                bu[((long)t * B + b) * nc + i] = u[((long)t * B + b) * nc + i];
+            }
         }
-        for (int e = tid; e < T * nc; e += nt) {
-            const int t = e / nc, i = e - t * nc;
-            bu[((long)t * B + b) * nc + i] = u[((long)t * B + b) * nc + i];
+        __syncthreads();          // every lane has read bc[b] before lane 0 overwrites it
+        if (tid == 0) {
+            const real d = du_norm[b];
+            if (take) {
+                bc[b] = cnew;
+                bd[b] = d;
+                improved = true;
+            }
+            if (d != d) dnan = true;
+            else if (d > dmax) dmax = d;
         }
     }
-    __syncthreads();
     if (tid == 0) {
-        if (take) {
-            bc[b] = cnew;
-            bd[b] = du_norm[b];
-            if (!first && any_improved) atomicOr(any_improved, 1);
-        }
+        if (improved && !first && any_improved) atomicOr(any_improved, 1);
         if (max_du) {
             // non-negative floats order like their bit patterns; NaN sorts above everything
             using bits = typename BitsOf<real>::type;
-            real d = du_norm[b];
-            if (d < 0) d = 0;
+            real d = dnan ? (real)NAN : dmax;
             bits v;
             __builtin_memcpy(&v, &d, sizeof(bits));
+            if (dnan) v = v & ~((bits)1 << (sizeof(bits) * 8 - 1));      // positive NaN pattern
             atomicMax(reinterpret_cast<bits *>(max_du), v);
         }
     }
@@ -885,7 +896,7 @@ int launch_select_best(int B, int T, int ns, int nc, int first, real eps, const 
 {
     if (any_improved) (void)hipMemsetAsync(any_improved, 0, sizeof(int), st);
     if (max_du) (void)hipMemsetAsync(max_du, 0, sizeof(real), st);
-    hipLaunchKernelGGL(select_best_kernel<real>, dim3(B), dim3(WAVE), 0, st, B, T, ns, nc, first, eps, x, u, costs,
+    hipLaunchKernelGGL(select_best_kernel<real>, dim3(B < 512 ? B : 512), dim3(WAVE), 0, st, B, T, ns, nc, first, eps, x, u, costs,
                        du_norm, bx, bu, bc, bd, any_improved, max_du);
     return check_launch("select_best_kernel");
 }

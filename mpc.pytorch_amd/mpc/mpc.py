@@ -30,6 +30,23 @@ class GradMethods(Enum):
     ANALYTIC_CHECK = 4
 
 
+def _any_requires_grad(obj):
+    """Does a QuadCost / LinDx / module carry a tensor that asks for a gradient?  Modules are searched
+    through parameters, buffers and plain tensor attributes (the shipped simulators keep `params` as
+    one), recursively over sub-modules."""
+    if isinstance(obj, (QuadCost, LinDx)):
+        return any(torch.is_tensor(t) and t.requires_grad for t in obj)
+    if isinstance(obj, Module):
+        for m in obj.modules():
+            for v in list(m.parameters(recurse=False)) + list(vars(m).values()):
+                if torch.is_tensor(v) and v.requires_grad:
+                    return True
+                if isinstance(v, (list, tuple)) and any(torch.is_tensor(t) and t.requires_grad for t in v):
+                    return True
+        return False
+    return False
+
+
 class SlewRateCost(Module):
     """A module cost plus the slew-rate quadratic on the augmented variable (u_prev, x, u)
     (reference mpc/mpc.py:36-56)."""
@@ -240,8 +257,17 @@ class MPC(Module):
 
         x, u = best["x"], best["u"]
         full_du_norm = best["full_du_norm"]
+        if not self._wants_graph(x_init, cost, dx):
+            # nothing upstream asks for a gradient: the differentiable re-linearisation and the no-op
+            # step of mpc/mpc.py:308-319 would only build a graph nobody can reach
+            self._check_converged(full_du_norm)
+            return (x, u, best["costs"])
         if isinstance(dx, LinDx):
             F, f = dx.F, dx.f
+        elif sim is not None and not _any_requires_grad(dx):
+            # the simulator's parameters are constants here: closed-form kernel instead of autograd
+            Fl, fl = be.env_linearize(sim, x[:-1].reshape(-1, ns), u[:-1].reshape(-1, nc))
+            F, f = Fl.view(T - 1, n_batch, ns, ns + nc), fl.view(T - 1, n_batch, ns)
         else:
             F, f = self.linearize_dynamics(x, u, dx, diff=True)
         if isinstance(cost, QuadCost):
@@ -252,20 +278,37 @@ class MPC(Module):
         # attach the KKT backward at the best iterate (no compute), mpc/mpc.py:318-319
         x, u = self.solve_lqr_subproblem(x_init, C, c, F, f, cost, dx, x, u, no_op_forward=True)
 
-        if self.detach_unconverged:
-            worst = float(full_du_norm.max().item())
-            if worst > self.eps:
-                if self.exit_unconverged:
-                    raise UnconvergedError(
-                        "MPC: max ||du|| = %.3e > eps = %.1e after %d LQR iterations "
-                        "(exit_unconverged=True)" % (worst, self.eps, self.lqr_iter))
-                if self.verbose >= 0:
-                    print("LQR Warning: All examples did not converge to a fixed point.")
-                    print("Detaching and *not* backpropping through the bad examples.")
-                keep = (full_du_norm < self.eps).to(x.dtype).view(1, -1, 1)
-                x = x * keep + x.detach() * (1. - keep)
-                u = u * keep + u.detach() * (1. - keep)
+        if self._check_converged(full_du_norm):
+            keep = (full_du_norm < self.eps).to(x.dtype).view(1, -1, 1)
+            x = x * keep + x.detach() * (1. - keep)
+            u = u * keep + u.detach() * (1. - keep)
         return (x, u, best["costs"])
+
+    def _check_converged(self, full_du_norm):
+        """mpc/mpc.py:321-334: raise / warn when some problem did not reach a fixed point.  Returns
+        True when the unconverged problems have to be detached."""
+        if not self.detach_unconverged:
+            return False
+        worst = float(full_du_norm.max().item())
+        if worst > self.eps:
+            if self.exit_unconverged:
+                raise UnconvergedError(
+                    "MPC: max ||du|| = %.3e > eps = %.1e after %d LQR iterations "
+                    "(exit_unconverged=True)" % (worst, self.eps, self.lqr_iter))
+            if self.verbose >= 0:
+                print("LQR Warning: All examples did not converge to a fixed point.")
+                print("Detaching and *not* backpropping through the bad examples.")
+            return True
+        return False
+
+    @staticmethod
+    def _wants_graph(x_init, cost, dx):
+        if not torch.is_grad_enabled():
+            return False
+        if x_init.requires_grad or _any_requires_grad(cost) or _any_requires_grad(dx):
+            return True
+        # a plain callable may close over anything: keep the reference's behaviour for those
+        return not all(isinstance(z, (QuadCost, LinDx, Module)) for z in (cost, dx))
 
     # ------------------------------------------------------------------------------------------
     def _step_options(self):
