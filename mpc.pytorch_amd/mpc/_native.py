@@ -500,15 +500,19 @@ class HipBackend:
         return F, f
 
     # -- (7) driver reductions ------------------------------------------------------------------
-    def select_best(self, first, eps, x, u, costs, du_norm, best):
+    def select_best(self, first, eps, x, u, costs, du_norm, best, flags=None):
         """In-place update of best = dict(x,u,costs,full_du_norm); returns the 2-word device flag
-        buffers (any_improved int32[1], max_du real[1]) without synchronising."""
+        buffers (any_improved int32[1], max_du real[1]) without synchronising.  flags: write into
+        these two pre-allocated buffers."""
         dev = _require_device(x, u, costs, du_norm)
         L = load()
         T, B, ns = x.shape
         nc = u.shape[2]
-        any_improved = torch.empty(1, device=dev, dtype=torch.int32)
-        max_du = torch.empty(1, device=dev, dtype=x.dtype)
+        if flags is None:
+            any_improved = torch.empty(1, device=dev, dtype=torch.int32)
+            max_du = torch.empty(1, device=dev, dtype=x.dtype)
+        else:
+            any_improved, max_du = flags
         _check(L.mpc_select_best(_dtype_code(x), B, T, ns, nc, int(bool(first)), float(eps),
                                  x.data_ptr(), u.data_ptr(), costs.data_ptr(), du_norm.data_ptr(),
                                  best["x"].data_ptr(), best["u"].data_ptr(), best["costs"].data_ptr(),

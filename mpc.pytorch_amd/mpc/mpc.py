@@ -47,6 +47,30 @@ def _any_requires_grad(obj):
     return False
 
 
+class _FlagReader:
+    """The two words the driver needs from the device per iteration (any problem improved, max ||du||),
+    copied into pinned host memory asynchronously; `wait()` blocks on an event, not on the stream."""
+
+    def __init__(self, device, dtype):
+        self.device_flags = (torch.zeros(1, dtype=torch.int32, device=device), torch.zeros(1, dtype=dtype, device=device))
+        self.cuda = device.type == "cuda"
+        if self.cuda:
+            self.host = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.zeros(1, dtype=dtype).pin_memory())
+            self.event = torch.cuda.Event()
+
+    def start(self):
+        if self.cuda:
+            self.host[0].copy_(self.device_flags[0], non_blocking=True)
+            self.host[1].copy_(self.device_flags[1], non_blocking=True)
+            self.event.record()
+
+    def wait(self):
+        if self.cuda:
+            self.event.synchronize()
+            return int(self.host[0][0]) != 0, float(self.host[1][0])
+        return int(self.device_flags[0][0]) != 0, float(self.device_flags[1][0])
+
+
 class SlewRateCost(Module):
     """A module cost plus the slew-rate quadratic on the augmented variable (u_prev, x, u)
     (reference mpc/mpc.py:36-56)."""
@@ -161,99 +185,11 @@ class MPC(Module):
         if (isinstance(cost, QuadCost) and hasattr(dx, "native_env") and self.slew_rate_penalty is None
                 and self.grad_method in (GradMethods.ANALYTIC, GradMethods.AUTO_DIFF) and T > 1):
             sim = dx.native_env()
-        best = None
-        n_not_improved = 0
         be = _native.backend()
-        plans = None
-        for i in range(self.lqr_iter):
-            u = util.detach_maybe(u)
-            if sim is not None:
-                if plans is None:
-                    xi = util.detach_maybe(x_init)
-                    ua = u.detach().contiguous()
-                    xa, _ = be.env_traj_cost(xi, ua, sim)             # util.get_traj, mpc/mpc.py:251
-                    xb, ub = torch.empty_like(xa), torch.empty_like(ua)
-                    Fl = torch.empty(T - 1, n_batch, ns, ns + nc, dtype=xa.dtype, device=xa.device)
-                    fl = torch.empty(T - 1, n_batch, ns, dtype=xa.dtype, device=xa.device)
-                    opts = self._step_options()
-                    opts.true_dynamics = sim
-                    pa = be.plan_step(xi, cost.C, cost.c, Fl, fl, xa, ua, opts, out_x=xb, out_u=ub)
-                    pb = be.plan_step(xi, cost.C, cost.c, Fl, fl, xb, ub, opts, out_x=xa, out_u=ua,
-                                      workspace=pa._keep[-1] if hasattr(pa, "_keep") else None)
-                    plans = (pa, pb)
-                    noms = ((xa, ua), (xb, ub))
-                xn, un = noms[i % 2]
-                # the nominal of this iteration is the last rollout through the simulator itself
-                be.env_linearize(sim, xn[:-1].reshape(-1, ns), un[:-1].reshape(-1, nc), out_F=Fl, out_f=fl)
-                r = plans[i % 2]()
-                x, u, costs, full_du_norm = r["new_x"], r["new_u"], r["costs"], r["full_du_norm"]
-                qp_iters, alphas = r["qp_iters"], r["alphas"]
-            elif fast and plans is not None:
-                # LinDx: the states of the last rollout ARE get_traj(u) (mpc/mpc.py:251 recomputes them)
-                pass
-            else:
-                x = util.get_traj(T, u, x_init=x_init, dynamics=dx)
-            if sim is not None:
-                pass
-            elif isinstance(dx, LinDx):
-                F, f = dx.F, dx.f
-            else:
-                F, f = self.linearize_dynamics(x, util.detach_maybe(u), dx, diff=False)
-            if isinstance(cost, QuadCost):
-                C, c = cost.C, cost.c
-            else:
-                C, c, _ = self.approximate_cost(x, util.detach_maybe(u), cost, diff=False)
-
-            if sim is not None:
-                pass
-            elif fast:
-                # inner iterations are never differentiated (the reference detaches them too): two
-                # pre-bound plans ping-pong the nominal between two buffers, so an iteration is one
-                # C call (no allocation, no autograd node, no host-side unpacking)
-                if plans is None:
-                    xa, ua = x.detach().contiguous(), u.detach().contiguous()
-                    xb, ub = torch.empty_like(xa), torch.empty_like(ua)
-                    xi, opts = util.detach_maybe(x_init), self._step_options()
-                    pa = be.plan_step(xi, C, c, F, f, xa, ua, opts, out_x=xb, out_u=ub)
-                    pb = be.plan_step(xi, C, c, F, f, xb, ub, opts, out_x=xa, out_u=ua,
-                                      workspace=pa._keep[-1] if hasattr(pa, "_keep") else None)
-                    plans = (pa, pb)
-                r = plans[i % 2]()
-                x, u, costs, full_du_norm = r["new_x"], r["new_u"], r["costs"], r["full_du_norm"]
-                qp_iters, alphas = r["qp_iters"], r["alphas"]
-            else:
-                with torch.no_grad():
-                    x, u, n_qp, costs, full_du_norm, mean_alphas = self.solve_lqr_subproblem(
-                        x_init, C, c, F, f, cost, dx, x, u)
-                qp_iters, alphas = None, None
-            n_not_improved += 1
-            assert x.ndimension() == 3 and u.ndimension() == 3
-
-            # best-iterate tracking, mpc/mpc.py:271-285 -- on the device
-            first = best is None
-            if first:
-                best = dict(x=torch.empty_like(x), u=torch.empty_like(u), costs=torch.empty_like(costs),
-                            full_du_norm=torch.empty_like(full_du_norm))
-            any_improved, max_du = be.select_best(first, self.best_cost_eps, x.contiguous(), u.contiguous(),
-                                                  costs, full_du_norm, best)
-            flags = torch.stack((any_improved[0].to(max_du.dtype), max_du[0])).tolist()   # the one sync
-            if flags[0] != 0:
-                n_not_improved = 0
-            max_du_norm = flags[1]
-
-            if self.verbose > 0:
-                if qp_iters is not None:
-                    n_qp = float(qp_iters.max().item())
-                    mean_alphas = alphas.mean()
-                util.table_log("lqr", (
-                    ("iter", i),
-                    ("mean(cost)", best["costs"].mean().item(), "{:.4e}"),
-                    ("||full_du||_max", max_du_norm, "{:.2e}"),
-                    ("mean(alphas)", float(mean_alphas), "{:.2e}"),
-                    ("total_qp_iters", n_qp),
-                ))
-            if max_du_norm < self.eps or n_not_improved > self.not_improved_lim:
-                break
+        if fast or sim is not None:
+            best = self._iterate_planned(be, x_init, u, cost, dx, sim, n_batch)
+        else:
+            best = self._iterate_general(be, x_init, u, cost, dx)
 
         x, u = best["x"], best["u"]
         full_du_norm = best["full_du_norm"]
@@ -283,6 +219,111 @@ class MPC(Module):
             x = x * keep + x.detach() * (1. - keep)
             u = u * keep + u.detach() * (1. - keep)
         return (x, u, best["costs"])
+
+    def _iterate_planned(self, be, x_init, u, cost, dx, sim, n_batch):
+        """The iLQR loop (mpc/mpc.py:245-306) when the whole iteration lives on the device: QuadCost with
+        LinDx or a shipped simulator.  Inner iterations are never differentiated (the reference detaches
+        them too).  Two pre-bound step plans ping-pong the nominal between two buffers, so an iteration is
+        one C call (plus the linearisation kernel for a simulator) -- no allocation, no autograd node.
+        The states of a rollout ARE get_traj of its controls (:251 recomputes them).
+        The convergence flags of iteration i are read back while iteration i+1 already runs: the next
+        step is launched speculatively and simply not used if the flags say stop."""
+        T, ns, nc = self.T, self.n_state, self.n_ctrl
+        xi = util.detach_maybe(x_init)
+        ua = util.detach_maybe(u).contiguous()
+        opts = self._step_options()
+        if sim is not None:
+            xa, _ = be.env_traj_cost(xi, ua, sim)                         # util.get_traj, :251
+            F = torch.empty(T - 1, n_batch, ns, ns + nc, dtype=xa.dtype, device=xa.device)
+            f = torch.empty(T - 1, n_batch, ns, dtype=xa.dtype, device=xa.device)
+            opts.true_dynamics = sim
+        else:
+            xa = util.get_traj(T, ua, x_init=xi, dynamics=dx).contiguous()
+            F, f = dx.F, dx.f
+        xb, ub = torch.empty_like(xa), torch.empty_like(ua)
+        pa = be.plan_step(xi, cost.C, cost.c, F, f, xa, ua, opts, out_x=xb, out_u=ub)
+        pb = be.plan_step(xi, cost.C, cost.c, F, f, xb, ub, opts, out_x=xa, out_u=ua,
+                          workspace=pa._keep[-1] if hasattr(pa, "_keep") else None)
+        plans, noms = (pa, pb), ((xa, ua), (xb, ub))
+
+        def launch(i):
+            if sim is not None:      # linearise around the nominal = the last rollout through the simulator
+                xn, un = noms[i % 2]
+                be.env_linearize(sim, xn[:-1].reshape(-1, ns), un[:-1].reshape(-1, nc), out_F=F, out_f=f)
+            return plans[i % 2]()
+
+        best = dict(x=torch.empty_like(xa), u=torch.empty_like(ua),
+                    costs=torch.empty(n_batch, dtype=xa.dtype, device=xa.device),
+                    full_du_norm=torch.empty(n_batch, dtype=xa.dtype, device=xa.device))
+        reader = _FlagReader(xa.device, xa.dtype)
+        n_not_improved, i = 0, 0
+        r = launch(0)
+        while True:
+            # best-iterate tracking, :271-285 -- on the device
+            be.select_best(i == 0, self.best_cost_eps, r["new_x"], r["new_u"], r["costs"], r["full_du_norm"],
+                           best, flags=reader.device_flags)
+            reader.start()
+            nxt = launch(i + 1) if i + 1 < self.lqr_iter else None        # overlaps the read-back
+            any_improved, max_du_norm = reader.wait()
+            n_not_improved += 1
+            if any_improved:
+                n_not_improved = 0
+            if self.verbose > 0:
+                util.table_log("lqr", (
+                    ("iter", i),
+                    ("mean(cost)", best["costs"].mean().item(), "{:.4e}"),
+                    ("||full_du||_max", max_du_norm, "{:.2e}"),
+                    ("mean(alphas)", float(r["alphas"].mean()), "{:.2e}"),
+                    ("total_qp_iters", float(r["qp_iters"].max().item())),
+                ))
+            if max_du_norm < self.eps or n_not_improved > self.not_improved_lim or nxt is None:
+                break
+            r, i = nxt, i + 1
+        return best
+
+    def _iterate_general(self, be, x_init, u, cost, dx):
+        """The same loop with module-valued cost / dynamics or a slew penalty: linearisation and cost
+        expansion through torch, the LQR step through `solve_lqr_subproblem`."""
+        T = self.T
+        best = None
+        n_not_improved = 0
+        for i in range(self.lqr_iter):
+            u = util.detach_maybe(u)
+            x = util.get_traj(T, u, x_init=x_init, dynamics=dx)
+            if isinstance(dx, LinDx):
+                F, f = dx.F, dx.f
+            else:
+                F, f = self.linearize_dynamics(x, util.detach_maybe(u), dx, diff=False)
+            if isinstance(cost, QuadCost):
+                C, c = cost.C, cost.c
+            else:
+                C, c, _ = self.approximate_cost(x, util.detach_maybe(u), cost, diff=False)
+            with torch.no_grad():
+                x, u, n_qp, costs, full_du_norm, mean_alphas = self.solve_lqr_subproblem(
+                    x_init, C, c, F, f, cost, dx, x, u)
+            n_not_improved += 1
+            assert x.ndimension() == 3 and u.ndimension() == 3
+            first = best is None
+            if first:
+                best = dict(x=torch.empty_like(x), u=torch.empty_like(u), costs=torch.empty_like(costs),
+                            full_du_norm=torch.empty_like(full_du_norm))
+            any_improved, max_du = be.select_best(first, self.best_cost_eps, x.contiguous(), u.contiguous(),
+                                                  costs, full_du_norm, best)
+            flags = torch.stack((any_improved[0].to(max_du.dtype), max_du[0])).tolist()   # the one sync
+            if flags[0] != 0:
+                n_not_improved = 0
+            max_du_norm = flags[1]
+            if self.verbose > 0:
+                util.table_log("lqr", (
+                    ("iter", i),
+                    ("mean(cost)", best["costs"].mean().item(), "{:.4e}"),
+                    ("||full_du||_max", max_du_norm, "{:.2e}"),
+                    ("mean(alphas)", float(mean_alphas), "{:.2e}"),
+                    ("total_qp_iters", n_qp),
+                ))
+            if max_du_norm < self.eps or n_not_improved > self.not_improved_lim:
+                break
+        return best
 
     def _check_converged(self, full_du_norm):
         """mpc/mpc.py:321-334: raise / warn when some problem did not reach a fixed point.  Returns

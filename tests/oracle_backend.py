@@ -115,7 +115,7 @@ class OracleBackend:
             return out_F, out_f
         return F, f
 
-    def select_best(self, first, eps, x, u, costs, du_norm, best):
+    def select_best(self, first, eps, x, u, costs, du_norm, best, flags=None):
         self.calls.append("select_best")
         take = torch.ones_like(costs, dtype=torch.bool) if first else costs <= best["costs"] + eps
         best["x"][:, take] = x[:, take]
@@ -123,4 +123,7 @@ class OracleBackend:
         best["costs"][take] = costs[take]
         best["full_du_norm"][take] = du_norm[take]
         any_improved = torch.tensor([int((not first) and bool(take.any()))], dtype=torch.int32)
+        if flags is not None:
+            flags[0].copy_(any_improved); flags[1].copy_(du_norm.max().reshape(1))
+            return flags
         return any_improved, du_norm.max().reshape(1)
