@@ -288,6 +288,32 @@ MPC_DEV void dma16(const void *g, unsigned off)
 {
     __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, 0);
 }
+#ifndef MPC_DPP16_C_AUX
+#define MPC_DPP16_C_AUX 2      /* nt: measured 129-132 -> 123-124 us */
+#endif
+// the stage cost matrices: read exactly once per launch
+MPC_DEV void dma16_c(const void *g, unsigned off)
+{
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, MPC_DPP16_C_AUX);
+}
+#ifndef MPC_DPP16_FR_AUX
+#define MPC_DPP16_FR_AUX 0
+#endif
+// F in the rollout.  Its second and last read -- yet nt here is 6 % SLOWER (measured): the first
+// part of the rollout finds the blocks the sweep touched last still in the Infinity Cache.
+MPC_DEV void dma16_last(const void *g, unsigned off)
+{
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, MPC_DPP16_FR_AUX);
+}
+// results nobody in this launch reads again
+MPC_DEV void store_out(float *g, float v)
+{
+#ifdef MPC_DPP16_OUT_CACHED
+    *g = v;
+#else
+    __builtin_nontemporal_store(v, g);
+#endif
+}
 MPC_DEV void dma16_if(bool active, const void *g, unsigned off)
 {
     if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, 0);

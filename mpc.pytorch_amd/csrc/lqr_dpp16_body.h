@@ -180,10 +180,13 @@ MPC_DEV void stage_issue(const P &p, const Dma &d, int t, int slot)
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);     // F / f have T-1 entries
     if (!ROLL || DIRECT) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wv::dma16(d.c_ptr[k] + tl * d.c_step, base + SC + 1024 * k);
+        for (int k = 0; k < 4; ++k) wv::dma16_c(d.c_ptr[k] + tl * d.c_step, base + SC + 1024 * k);
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) wv::dma16(d.f_ptr[k] + (p.T > 1 ? tf * d.f_step : 0), base + SF + 1024 * k);
+    for (int k = 0; k < 3; ++k) {
+        if (ROLL) wv::dma16_last(d.f_ptr[k] + (p.T > 1 ? tf * d.f_step : 0), base + SF + 1024 * k);
+        else wv::dma16(d.f_ptr[k] + (p.T > 1 ? tf * d.f_step : 0), base + SF + 1024 * k);
+    }
     // the record instruction is issued by every wave even if only some lanes take part
     {
         const char *src = d.r_ptr + (d.r_is_f ? tf : tl) * d.r_step;
@@ -553,8 +556,8 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
     }
     if (L.live) {
         const long tb = (long)t * p.B + L.pb;
-        if (L.isu) p.new_u[tb * 4 + L.a] = tp;
-        else p.new_x[tb * 12 + L.j] = tp;
+        if (L.isu) wv::store_out(p.new_u + tb * 4 + L.a, tp);
+        else wv::store_out(p.new_x + tb * 12 + L.j, tp);
     }
     if (!DIRECT) {
         // does the nominal obey x_t = F tau_{t-1} + f_{t-1}?  (the identity above assumes it)

@@ -312,6 +312,9 @@ static inline void dma_n(const void *g, unsigned off, int size, bool active = tr
     memcpy(d->data[l], g, size);
 }
 static inline void dma16(const void *g, unsigned off) { dma_n(g, off, 16); }
+static inline void dma16_c(const void *g, unsigned off) { dma_n(g, off, 16); }
+static inline void dma16_last(const void *g, unsigned off) { dma_n(g, off, 16); }
+static inline void store_out(float *g, float v) { *g = v; }
 static inline void dma16_if(bool active, const void *g, unsigned off) { dma_n(g, off, 16, active); }
 static inline void dma4(const void *g, unsigned off) { dma_n(g, off, 4); }
 template <int N> static inline void dma_wait()
