@@ -40,6 +40,34 @@ template <typename real> __device__ __forceinline__ real eclamp(real x, real lo,
     return x;
 }
 
+// ---------------------------------------------------------------------------
+// 16x16 output tiles on v_mfma_f32_16x16x4_f32 with both operands read from LDS (fp32, the
+// n > 24 path with four wavefronts per problem: config 5's three GEMM-shaped products).
+// a_at(i, k) / b_at(k, j) return the operand element or 0 outside the matrix.
+// ---------------------------------------------------------------------------
+typedef float mfma_acc_t __attribute__((ext_vector_type(4)));
+template <class LA, class LB>
+__device__ __forceinline__ mfma_acc_t tile_mma(int r0, int c0, int K, LA a_at, LB b_at, mfma_acc_t acc)
+{
+    const int l = threadIdx.x & 63, r = l & 15, q = l >> 4;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const float a = a_at(r0 + r, k0 + q);
+        const float b = b_at(k0 + q, c0 + r);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// lane (r, q) of the accumulator holds D[4q + v][r], v = 0..3
+template <class FN> __device__ __forceinline__ void tile_each(int r0, int c0, int rows, int cols, FN fn)
+{
+    const int l = threadIdx.x & 63, r = l & 15, q = l >> 4;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int i = r0 + 4 * q + v, j = c0 + r;
+        if (i < rows && j < cols) fn(i, j, v);
+    }
+}
+
 template <typename real>
 struct Smem {
     real *Q, *F, *W, *V, *A, *Kt, *M;
@@ -94,38 +122,50 @@ template <typename real> __device__ real block_sum(real v, real *red)
 // Tensor.lu()/lu_solve pair of mpc/pnqp.py:18-19,53-54 and mpc/lqr_step.py:125-127,148,
 // and stands in for the per-sample torch.pinverse of :88-94 (identical for the
 // nonsingular Quu all configurations produce).
+// One wavefront does the whole elimination (the matrix is nr x (nr + 1 + ns): a few dozen columns),
+// so the 4 * nr block-wide barriers of the obvious version become wave-local fences; the other
+// wavefronts of the block wait at the single barrier at the end.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <typename real> __device__ void lu_solve_aug(real *A, int nr, int ncols, real *Lcol)
 {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int p = 0; p < nr; ++p) {
-        int r = p;
-        real best = rabs(A[p * ncols + p]);
-        for (int i = p + 1; i < nr; ++i) {
-            real a = rabs(A[i * ncols + p]);
-            if (a > best) { best = a; r = i; }
-        }
-        __syncthreads();
-        if (r != p)
-            for (int j = tid; j < ncols; j += nt) {
-                real tmp = A[p * ncols + j];
-                A[p * ncols + j] = A[r * ncols + j];
-                A[r * ncols + j] = tmp;
+    const int tid = threadIdx.x;
+    if (tid < WAVE) {
+        const int nt = WAVE;
+        for (int p = 0; p < nr; ++p) {
+            int r = p;
+            real best = rabs(A[p * ncols + p]);
+            for (int i = p + 1; i < nr; ++i) {
+                real a = rabs(A[i * ncols + p]);
+                if (a > best) { best = a; r = i; }
             }
-        __syncthreads();
-        const real d = A[p * ncols + p];
-        for (int i = p + 1 + tid; i < nr; i += nt) Lcol[i] = A[i * ncols + p] / d;
-        __syncthreads();
-        for (int j = p + 1 + tid; j < ncols; j += nt) {
-            const real pj = A[p * ncols + j];
-            for (int i = p + 1; i < nr; ++i) A[i * ncols + j] -= Lcol[i] * pj;
+            wave_sync();
+            if (r != p)
+                for (int j = tid; j < ncols; j += nt) {
+                    real tmp = A[p * ncols + j];
+                    A[p * ncols + j] = A[r * ncols + j];
+                    A[r * ncols + j] = tmp;
+                }
+            wave_sync();
+            const real d = A[p * ncols + p];
+            for (int i = p + 1 + tid; i < nr; i += nt) Lcol[i] = A[i * ncols + p] / d;
+            wave_sync();
+            for (int j = p + 1 + tid; j < ncols; j += nt) {
+                const real pj = A[p * ncols + j];
+                for (int i = p + 1; i < nr; ++i) A[i * ncols + j] -= Lcol[i] * pj;
+            }
+            wave_sync();
         }
-        __syncthreads();
-    }
-    for (int j = nr + tid; j < ncols; j += nt) {
-        for (int k = nr - 1; k >= 0; --k) {
-            real x = A[k * ncols + j];
-            for (int i = k + 1; i < nr; ++i) x -= A[k * ncols + i] * A[i * ncols + j];
-            A[k * ncols + j] = x / A[k * ncols + k];
+        for (int j = nr + tid; j < ncols; j += nt) {
+            for (int k = nr - 1; k >= 0; --k) {
+                real x = A[k * ncols + j];
+                for (int i = k + 1; i < nr; ++i) x -= A[k * ncols + i] * A[i * ncols + j];
+                A[k * ncols + j] = x / A[k * ncols + k];
+            }
         }
     }
     __syncthreads();
@@ -257,18 +297,45 @@ __device__ void sweep_problem(const StepParams<real> &p, int b, Smem<real> &s, r
         }
         if (t < T - 1) {
             // Q = C + F'VF, q = c_back + F'v  (:65-70; the f-term of :72-74 is dead: f_back=None)
-            for (int e = tid; e < n * ns; e += nt) {
-                const int i = e / ns, k = e - i * ns;
-                real r = 0;
-                for (int m = 0; m < ns; ++m) r += s.F[m * n + i] * s.V[m * ns + k];
-                s.W[e] = r;
-            }
-            __syncthreads();
-            for (int e = tid; e < n * n; e += nt) {
-                const int i = e / n, j = e - i * n;
-                real r = 0;
-                for (int k = 0; k < ns; ++k) r += s.W[i * ns + k] * s.F[k * n + j];
-                s.Q[e] += r;
+            bool on_mfma = false;
+            if constexpr (sizeof(real) == 4) on_mfma = nt > WAVE;
+            if (on_mfma) {
+                if constexpr (sizeof(real) == 4) {
+                    const int wv_id = tid >> 6, nwv = nt >> 6;
+                    const int ti_n = (n + 15) / 16, tk_n = (ns + 15) / 16;
+                    for (int tile = wv_id; tile < ti_n * tk_n; tile += nwv) {       // W = F'V
+                        const int r0 = 16 * (tile / tk_n), c0 = 16 * (tile % tk_n);
+                        mfma_acc_t acc = {0.f, 0.f, 0.f, 0.f};
+                        acc = tile_mma(r0, c0, ns,
+                                       [&](int i, int m) { return (i < n && m < ns) ? s.F[m * n + i] : 0.f; },
+                                       [&](int m, int k) { return (m < ns && k < ns) ? s.V[m * ns + k] : 0.f; }, acc);
+                        tile_each(r0, c0, n, ns, [&](int i, int k, int v) { s.W[i * ns + k] = acc[v]; });
+                    }
+                    __syncthreads();
+                    for (int tile = wv_id; tile < ti_n * ti_n; tile += nwv) {       // Q += W F
+                        const int r0 = 16 * (tile / ti_n), c0 = 16 * (tile % ti_n);
+                        mfma_acc_t acc = {0.f, 0.f, 0.f, 0.f};
+                        tile_each(r0, c0, n, n, [&](int i, int j, int v) { acc[v] = s.Q[i * n + j]; });
+                        acc = tile_mma(r0, c0, ns,
+                                       [&](int i, int k) { return (i < n && k < ns) ? s.W[i * ns + k] : 0.f; },
+                                       [&](int k, int j) { return (k < ns && j < n) ? s.F[k * n + j] : 0.f; }, acc);
+                        tile_each(r0, c0, n, n, [&](int i, int j, int v) { s.Q[i * n + j] = acc[v]; });
+                    }
+                }
+            } else {
+                for (int e = tid; e < n * ns; e += nt) {
+                    const int i = e / ns, k = e - i * ns;
+                    real r = 0;
+                    for (int m = 0; m < ns; ++m) r += s.F[m * n + i] * s.V[m * ns + k];
+                    s.W[e] = r;
+                }
+                __syncthreads();
+                for (int e = tid; e < n * n; e += nt) {
+                    const int i = e / n, j = e - i * n;
+                    real r = 0;
+                    for (int k = 0; k < ns; ++k) r += s.W[i * ns + k] * s.F[k * n + j];
+                    s.Q[e] += r;
+                }
             }
             for (int i = tid; i < n; i += nt) {
                 real r = 0;
@@ -357,16 +424,39 @@ __device__ void sweep_problem(const StepParams<real> &p, int b, Smem<real> &s, r
             s.M[e] = r;
         }
         __syncthreads();
-        for (int e = tid; e < ns * ns; e += nt) {
-            const int i = e / ns, j = e - i * ns;
-            real t1 = 0, t2 = 0, t3 = 0;
-            for (int l = 0; l < nc; ++l) {
-                const real kli = s.Kt[l * ns + i];
-                t1 += s.Q[i * n + ns + l] * s.Kt[l * ns + j];
-                t2 += kli * Qux[l * n + j];
-                t3 += kli * s.M[l * (ns + 1) + j];
+        bool v_on_mfma = false;
+        if constexpr (sizeof(real) == 4) v_on_mfma = nt > WAVE;
+        if (v_on_mfma) {
+            if constexpr (sizeof(real) == 4) {
+                // V = Qxx + Qxu K + K'(Qux + Quu K): two products with inner dimension n_ctrl
+                const int wv_id = tid >> 6, nwv = nt >> 6, tk_n = (ns + 15) / 16;
+                for (int tile = wv_id; tile < tk_n * tk_n; tile += nwv) {
+                    const int r0 = 16 * (tile / tk_n), c0 = 16 * (tile % tk_n);
+                    mfma_acc_t acc = {0.f, 0.f, 0.f, 0.f};
+                    tile_each(r0, c0, ns, ns, [&](int i, int j, int v) { acc[v] = s.Q[i * n + j]; });
+                    acc = tile_mma(r0, c0, nc,
+                                   [&](int i, int l) { return (i < ns && l < nc) ? s.Q[i * n + ns + l] : 0.f; },
+                                   [&](int l, int j) { return (l < nc && j < ns) ? s.Kt[l * ns + j] : 0.f; }, acc);
+                    acc = tile_mma(r0, c0, nc,
+                                   [&](int i, int l) { return (i < ns && l < nc) ? s.Kt[l * ns + i] : 0.f; },
+                                   [&](int l, int j) {
+                                       return (l < nc && j < ns) ? Qux[l * n + j] + s.M[l * (ns + 1) + j] : 0.f;
+                                   }, acc);
+                    tile_each(r0, c0, ns, ns, [&](int i, int j, int v) { s.V[i * ns + j] = acc[v]; });
+                }
             }
-            s.V[e] = s.Q[i * n + j] + t1 + t2 + t3;
+        } else {
+            for (int e = tid; e < ns * ns; e += nt) {
+                const int i = e / ns, j = e - i * ns;
+                real t1 = 0, t2 = 0, t3 = 0;
+                for (int l = 0; l < nc; ++l) {
+                    const real kli = s.Kt[l * ns + i];
+                    t1 += s.Q[i * n + ns + l] * s.Kt[l * ns + j];
+                    t2 += kli * Qux[l * n + j];
+                    t3 += kli * s.M[l * (ns + 1) + j];
+                }
+                s.V[e] = s.Q[i * n + j] + t1 + t2 + t3;
+            }
         }
         for (int i = tid; i < ns; i += nt) {
             real t1 = 0, t2 = 0, t3 = 0;
@@ -506,7 +596,7 @@ __device__ void rollout_problem(const StepParams<real> &p, int b, Smem<real> &s,
 
 // phase_mask: 1 = sweep, 2 = rollout, 3 = both (K,k round-trip through p.K/p.k, L2-resident)
 template <typename real>
-__global__ void __launch_bounds__(MAX_THREADS) lqr_step_generic_kernel(StepParams<real> p, int phase_mask)
+__global__ void __launch_bounds__(MAX_THREADS, (sizeof(real) == 4 ? 6 : 2)) lqr_step_generic_kernel(StepParams<real> p, int phase_mask)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem<real> s;

@@ -112,6 +112,41 @@ def test_lqr_step_parity(be, name):
         assert int(r["qp_iters"].max()) == int(z["n_qp_pp"].max())
 
 
+@pytest.mark.parametrize("ns,nc,T", [(32, 8, 12), (20, 5, 6), (30, 3, 5), (17, 9, 7), (45, 10, 4), (24, 1, 5)])
+@pytest.mark.parametrize("bounded", [False, True])
+def test_generic_kernel_large_shapes_on_mfma(be, ns, nc, T, bounded):
+    """n > 24 in float32: the generic kernel runs its three GEMM-shaped products (F'V, (F'V)F, the value
+    update) as 16x16 MFMA tiles over LDS operands, any size (ragged tiles are zero-padded).  Against the
+    oracle in float64 on the same inputs, and against the same kernel in float64 (scalar path)."""
+    from oracle import lqr_oracle as O
+    from mpc._native import StepOptions
+    rng = np.random.default_rng(100 * ns + nc)
+    B, n = 5, ns + nc
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A) + 0.1 * np.eye(n)
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((T - 1, B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((T - 1, B, ns, nc)) / np.sqrt(ns)), 3)
+    f = 0.1 * rng.standard_normal((T - 1, B, ns))
+    x_init = rng.standard_normal((B, ns))
+    cur_u = np.clip(0.3 * rng.standard_normal((T, B, nc)), -0.5, 0.5)
+    cur_x, _ = O.traj_cost(x_init, cur_u, F, f)
+    lo, hi = (-0.5, 0.5) if bounded else (None, None)
+    o = O.lqr_step(x_init, C, c, F, f, cur_x, cur_u, lo, hi, lockstep=False, return_gains=True)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        d = lambda a: dev(a).to(dt)
+        r = be.lqr_step(d(x_init), d(C), d(c), d(F), d(f), d(cur_x), d(cur_u), StepOptions(u_lower=lo, u_upper=hi),
+                        want_gains=True, impl=1)
+        torch.cuda.synchronize()
+        res[dt] = {k: host(v) for k, v in r.items() if torch.is_tensor(v)}
+    for k in ("new_x", "new_u", "K", "k"):
+        np.testing.assert_allclose(res[torch.float64][k], o[k], rtol=1e-8, atol=1e-8, err_msg=k)
+        np.testing.assert_allclose(res[torch.float32][k], o[k], rtol=2e-3, atol=5e-4, err_msg=k)
+    np.testing.assert_allclose(res[torch.float32]["costs"], o["costs"], rtol=2e-4)
+    np.testing.assert_allclose(res[torch.float32]["alphas"], o["alphas"], rtol=1e-6)
+
+
 @pytest.mark.parametrize("name", ["step_cfg1_f64", "step_masked_f64", "step_ns_bounded_f32", "step_nc1_scalar_f64"])
 def test_split_sweep_and_rollout_entry_points(be, name):
     """mpc_lqr_sweep (K, k) and mpc_lqr_rollout separately == the fused step, and K,k == oracle."""

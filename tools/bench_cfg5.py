@@ -16,6 +16,12 @@ gx, gu = torch.randn_like(r["new_x"]), torch.randn_like(r["new_u"])
 out = {"B": B,
        "lqr_step_ms": timed(lambda: be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts), n=5, warm=1),
        "kkt_backward_ms": timed(lambda: be.kkt_backward(p["C"], p["c"], p["F"], p["f"], r["new_x"], r["new_u"], gx, gu, opts), n=5, warm=1)}
+out["sweep_only_ms"] = timed(lambda: be.lqr_sweep(p["x_init"], p["C"], p["c"], p["F"], p["cur_x"], p["cur_u"], opts), n=5, warm=1)
+out["sweep_plus_rollout_split_ms"] = timed(lambda: be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts,
+                                                               rollout_problem=(p["C"], p["c"], p["F"], p["f"])), n=5, warm=1)
+bo = StepOptions(u_lower=-1.0, u_upper=1.0)
+out["lqr_step_bounded_ms"] = timed(lambda: be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], bo), n=5, warm=1)
+out["sweep_only_bounded_ms"] = timed(lambda: be.lqr_sweep(p["x_init"], p["C"], p["c"], p["F"], p["cur_x"], p["cur_u"], bo), n=5, warm=1)
 out["problem_steps_per_s"] = B * 64 / (out["lqr_step_ms"] * 1e-3)
 out["algorithmic_GBps"] = bench.algorithmic_bytes_per_problem(32, 8, 64) * B / (out["lqr_step_ms"] * 1e-3) / 1e9
 print(json.dumps(out))
