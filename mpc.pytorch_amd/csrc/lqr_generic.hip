@@ -241,7 +241,20 @@ __device__ int pnqp_core(const real *H, int ldH, const real *qv, const real *rhs
             it_ret = it;
             break;
         }
-        // :61-76 Armijo backtracking (n_batch = 1 form of the batch-global loop)
+        // :61-76 Armijo backtracking (n_batch = 1 form of the batch-global loop).  A Newton step that
+        // stays inside the box passes without evaluation: its Armijo ratio is exactly 1/2 for a quadratic
+        // (see lqr_small_math.h); evaluating it in float32 near convergence only measures rounding noise.
+        bool inside = true;
+        for (int i = 0; i < n; ++i) {
+            const real xn = x[i] + dx[i];
+            inside = inside & ((xn >= lb[i]) & (xn <= ub[i]));
+        }
+        if (inside) {
+            __syncthreads();
+            for (int i = tid; i < n; i += nt) x[i] += dx[i];
+            __syncthreads();
+            continue;
+        }
         real alpha = 1;
         const real obj_x = qp_obj(H, ldH, qv, x, n);
         for (int count = 0; count < 10; ++count) {

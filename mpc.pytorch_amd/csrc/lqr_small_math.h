@@ -30,15 +30,16 @@ MPC_DEV void ldl4(Ldl4 &f, const Sym4 &s, const bool fr_[4], float reg)
     bool fr[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) fr[a] = MASKED ? fr_[a] : true;
+    // (bitwise & on purpose: && makes the compiler branch on the exec mask for every pair)
     const float a00 = fr[0] ? s.s00 + reg : 1.f;
-    const float a10 = (fr[0] && fr[1]) ? s.s01 : 0.f;
-    const float a20 = (fr[0] && fr[2]) ? s.s02 : 0.f;
-    const float a30 = (fr[0] && fr[3]) ? s.s03 : 0.f;
+    const float a10 = (fr[0] & fr[1]) ? s.s01 : 0.f;
+    const float a20 = (fr[0] & fr[2]) ? s.s02 : 0.f;
+    const float a30 = (fr[0] & fr[3]) ? s.s03 : 0.f;
     const float a11 = fr[1] ? s.s11 + reg : 1.f;
-    const float a21 = (fr[1] && fr[2]) ? s.s12 : 0.f;
-    const float a31 = (fr[1] && fr[3]) ? s.s13 : 0.f;
+    const float a21 = (fr[1] & fr[2]) ? s.s12 : 0.f;
+    const float a31 = (fr[1] & fr[3]) ? s.s13 : 0.f;
     const float a22 = fr[2] ? s.s22 + reg : 1.f;
-    const float a32 = (fr[2] && fr[3]) ? s.s23 : 0.f;
+    const float a32 = (fr[2] & fr[3]) ? s.s23 : 0.f;
     const float a33 = fr[3] ? s.s33 + reg : 1.f;
     f.i0 = wv::rcp(a00);
     f.l10 = a10 * f.i0; f.l20 = a20 * f.i0; f.l30 = a30 * f.i0;
@@ -117,8 +118,8 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             g[a] += q[a];
-            const bool ic = ((x[a] == lb[a]) && (g[a] > 0.f)) || ((x[a] == ub[a]) && (g[a] < 0.f));   // :32
-            fr[a] = valid[a] && !ic;
+            const bool ic = ((x[a] == lb[a]) & (g[a] > 0.f)) | ((x[a] == ub[a]) & (g[a] < 0.f));      // :32
+            fr[a] = valid[a] & !ic;
             gm[a] = fr[a] ? g[a] : 0.f;
         }
         ldl4<true>(f, s, fr, 1e-11f);                                // :44-48
@@ -136,10 +137,26 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
             it_ret = it;
             break;
         }
-        // :61-76 Armijo backtracking
+        // :61-76 Armijo backtracking.  If the whole Newton step stays inside the box the test needs no
+        // evaluation: for dx = -H_ff^{-1} g_f the ratio (f(x) - f(x+dx)) / (g'(x - (x+dx))) is exactly 1/2
+        // (any H_ff, f quadratic), so alpha = 1 passes the 0.1 threshold.  (In float32 the evaluated
+        // ratio is rounding noise once |dx| ~ 1e-4 and sends the reference's own float32 run into ten
+        // futile halvings; the float64 reference takes the step.)
+        float mx[4];
+        bool inside = true;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float xn = x[a] + dx[a];
+            mx[a] = xn;
+            inside = inside & (((xn >= lb[a]) & (xn <= ub[a])) | !valid[a]);
+        }
+        if (UNIFORM ? wv::uniform(inside) : inside) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) x[a] = mx[a];
+            continue;
+        }
         float alpha = 1.f;
         const float obj_x = qp_obj4_from_grad(g, q, x);
-        float mx[4];
         for (int count = 0; count < 10; ++count) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) mx[a] = eclampf(fmaf(alpha, dx[a], x[a]), lb[a], ub[a]);

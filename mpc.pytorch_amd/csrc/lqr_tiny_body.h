@@ -43,6 +43,10 @@ MPC_HD int pnqp1(real H, real q, real lb, real ub, real &x, real &Hfree, bool &i
         Hfree = (is_free ? H : (real)0) + (real)1e-11;             // :44-48
         const real dx = -((is_free ? g : (real)0) / Hfree);        // :50-51
         if (!(absr<real>(dx) >= (real)1e-4)) { conv = true; ret = it; break; }   // :56-59
+        if (x + dx >= lb && x + dx <= ub) {                        // Newton step inside the box: its Armijo
+            x = x + dx;                                            // ratio is exactly 1/2, no evaluation
+            continue;
+        }
         real alpha = 1, arm = GAMMA, xn = x;
         int count = 0;
         const real ox = (real)0.5 * H * x * x + q * x;
