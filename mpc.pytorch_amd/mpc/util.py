@@ -59,6 +59,24 @@ def get_data_maybe(x):
 data_maybe = detach_maybe
 
 
+def data_maybe(x):
+    """x.data, or None (reference mpc/util.py:162-165)"""
+    return None if x is None else x.detach()
+
+
+def jacobian(f, x, eps):
+    """Central-difference Jacobian of f at the single point x ([n] or [1,n]) -> [m, n]
+    (reference mpc/util.py:8-18).  All 2n evaluations go through f in one batch when f accepts a
+    leading batch axis, else one by one like the reference."""
+    if x.ndimension() == 2:
+        assert x.size(0) == 1
+        x = x.squeeze(0)
+    n = len(x)
+    e = eps * torch.eye(n, dtype=x.dtype, device=x.device)
+    cols = [(f(x + e[i]) - f(x - e[i])) / (2. * eps) for i in range(n)]
+    return torch.stack(cols).transpose(0, 1)
+
+
 def expandParam(X, n_batch, nDim):
     if X.ndimension() in (0, nDim):
         return X, False

@@ -455,9 +455,10 @@ def test_north_star_full_size_vs_oracle(be, bounded):
         np.testing.assert_allclose(host(r["costs"]), o64["costs"], rtol=5e-4 if bounded else 1e-4)   # bounded: pnqp stop noise
         st = host(r["status"])
         assert (st & 2 == 0).all()                      # nothing non-finite
-        # bit 0 = "pnqp warning: Did not converge" (mpc/pnqp.py:81) -- in float32 a QP sitting on the
-        # |dx| < 1e-4 threshold may use up its 20 iterations (0.25 % of the QPs = 12 % of the problems here, the same share in all three kernels and in the float32 oracle: tools/st_probe.py); the reference only prints a warning
-        assert (st & 1).mean() < 0.25, "impl %d: %.3f %% of the problems carry an unconverged QP" % (impl, 100 * (st & 1).mean())
+        # bit 0 = "pnqp warning: Did not converge" (mpc/pnqp.py:81).
+        # float32 pnqp: every QP reaches |dx| < 1e-4 within its 20 iterations (the float32 reference does not:
+        # its Armijo ratio is rounding noise near convergence -- see lqr_small_math.h)
+        assert (st & 1).mean() < 0.01, "impl %d: %.3f %% of the problems carry an unconverged QP" % (impl, 100 * (st & 1).mean())
 
 
 def test_north_star_properties(be):
