@@ -255,15 +255,21 @@ __device__ int pnqp_core(const real *H, int ldH, const real *qv, const real *rhs
             __syncthreads();
             continue;
         }
+        // otherwise evaluate it, as f(x) - f(m) = -g'd - d'Hd/2 with d = m - x (no cancellation of two
+        // large objective values)
         real alpha = 1;
-        const real obj_x = qp_obj(H, ldH, qv, x, n);
         for (int count = 0; count < 10; ++count) {
             for (int i = tid; i < n; i += nt) mx[i] = eclamp<real>(x[i] + alpha * dx[i], lb[i], ub[i]);
             __syncthreads();
-            const real obj_m = qp_obj(H, ldH, qv, mx, n);
-            real den = 0;
-            for (int i = 0; i < n; ++i) den += g[i] * (x[i] - mx[i]);
-            const real arm = (obj_x - obj_m) / den;
+            real den = 0, dhd = 0;
+            for (int i = 0; i < n; ++i) {
+                const real di = mx[i] - x[i];
+                real r = 0;
+                for (int j = 0; j < n; ++j) r += H[i * ldH + j] * (mx[j] - x[j]);
+                den -= g[i] * di;
+                dhd += di * r;
+            }
+            const real arm = (den - (real)0.5 * dhd) / den;
             __syncthreads();
             if (arm <= GAMMA) alpha *= (real)0.1; else break;
         }
@@ -754,6 +760,41 @@ __global__ void __launch_bounds__(MAX_THREADS) traj_cost_kernel(StepParams<real>
     }
 }
 
+// util.get_traj (LinDx) for n_state + n_ctrl <= 16: one problem per 16-lane group, lane i owns state i and
+// reads row i of F_t (a group reads one contiguous block per step), tau is exchanged by row shuffles, the
+// next step's row is in flight while this one is summed.  The generic kernel above spends a whole
+// wavefront and two barriers per step on the same 192 multiply-adds.
+template <typename real>
+__global__ void __launch_bounds__(256) traj_rows16_kernel(StepParams<real> p, real *x)
+{
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, i = threadIdx.x & 15;
+    const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T, B = p.B;
+    const int b = gid < B ? gid : B - 1;            // idle groups shadow the last problem (no divergent shuffles)
+    const bool own = gid < B && i < ns;
+    real xi = i < ns ? p.x_init[(long)b * ns + i] : (real)0;
+    if (own) x[(long)b * ns + i] = xi;
+    real row[16], nxt[16];
+    const int ir = i < ns ? i : 0;
+    auto load_row = [&](int t, real *dst) {
+        const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb + (long)ir * n;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dst[j] = j < n ? Ft[j] : (real)0;
+    };
+    if (T > 1) load_row(0, row);
+    for (int t = 0; t < T - 1; ++t) {
+        if (t + 1 < T - 1) load_row(t + 1, nxt);
+        const real ui = (i >= ns && i < n) ? p.cur_u[((long)t * B + b) * nc + (i - ns)] : (real)0;
+        const real tau = i < ns ? xi : ui;
+        real acc = (p.f && i < ns) ? p.f[(long)t * p.f_st + (long)b * p.f_sb + i] : (real)0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc += row[j] * __shfl(tau, j, 16);
+        xi = acc;
+        if (own) x[((long)(t + 1) * B + b) * ns + i] = xi;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) row[j] = nxt[j];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // KKT backward, closed-form part (mpc/lqr_step.py:346-404)
 // ---------------------------------------------------------------------------
@@ -857,51 +898,62 @@ template <typename real> struct BitsOf;
 template <> struct BitsOf<float> { using type = unsigned int; };
 template <> struct BitsOf<double> { using type = unsigned long long; };
 
+// Pass 1: copy the trajectories of the problems that improved.  One thread per float, flat over [T,B,d]
+// (fully coalesced); every thread derives its problem's `take` from costs and the OLD best costs, which
+// pass 2 (stream-ordered after this one) then overwrites.
 template <typename real>
-__global__ void select_best_kernel(int B, int T, int ns, int nc, int first, real eps, const real *x,
-                                   const real *u, const real *costs, const real *du_norm, real *bx,
-                                   real *bu, real *bc, real *bd, int *any_improved, real *max_du)
+__global__ void select_copy_kernel(long total, int B, int d, int first, real eps, const real *src, real *dst,
+                                   const real *costs, const real *bc)
 {
-    // one wavefront per block walks problems b = blockIdx.x, += gridDim.x; the two batch-wide
-    // reductions cost ONE atomic per block (4096 same-address atomics serialise for ~30 us)
-    const int tid = threadIdx.x, nt = blockDim.x;
-    real dmax = 0;
-    bool dnan = false, improved = false;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int b = (int)((e / d) % B);
+    if (first || costs[b] <= bc[b] + eps) dst[e] = src[e];
+}
+
+// Pass 2: best costs / du-norms and the two batch-wide reductions; one atomic per block.
+template <typename real>
+__global__ void select_update_kernel(int B, int first, real eps, const real *costs, const real *du_norm, real *bc,
+                                     real *bd, int *any_improved, real *max_du)
+{
+    __shared__ real s_max[4];
+    __shared__ int s_flag[4];
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    real d = 0;
+    int improved = 0, isnan_ = 0;
+    if (b < B) {
+        d = du_norm[b];
         const real cnew = costs[b];
-        const bool take = first || (cnew <= bc[b] + eps);
-        if (take) {
-            for (int e = tid; e < T * ns; e += nt) {
-                const int t = e / ns, i = e - t * ns;
-                bx[((long)t * B + b) * ns + i] = x[((long)t * B + b) * ns + i];
-            }
-            for (int e = tid; e < T * nc; e += nt) {
-                const int t = e / nc, i = e - t * nc;
-                bu[((long)t * B + b) * nc + i] = u[((long)t * B + b) * nc + i];
-            }
+        if (first || cnew <= bc[b] + eps) {
+            bc[b] = cnew;
+            bd[b] = d;
+            improved = 1;
         }
-        __syncthreads();          // every lane has read bc[b] before lane 0 overwrites it
-        if (tid == 0) {
-            const real d = du_norm[b];
-            if (take) {
-                bc[b] = cnew;
-                bd[b] = d;
-                improved = true;
-            }
-            if (d != d) dnan = true;
-            else if (d > dmax) dmax = d;
-        }
+        if (d != d) { isnan_ = 1; d = 0; }
+        if (d < 0) d = 0;
     }
-    if (tid == 0) {
-        if (improved && !first && any_improved) atomicOr(any_improved, 1);
+    // wave reduction, then across the (<= 4) waves of the block
+    for (int off = 32; off > 0; off >>= 1) {
+        const real o = __shfl_down(d, off);
+        d = o > d ? o : d;
+        improved |= __shfl_down(improved, off);
+        isnan_ |= __shfl_down(isnan_, off);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_max[w] = d; s_flag[w] = improved | (isnan_ << 1); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int fl = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { d = s_max[i] > d ? s_max[i] : d; fl |= s_flag[i]; }
+        if ((fl & 1) && !first && any_improved) atomicOr(any_improved, 1);
         if (max_du) {
             // non-negative floats order like their bit patterns; NaN sorts above everything
             using bits = typename BitsOf<real>::type;
-            real d = dnan ? (real)NAN : dmax;
-            bits v;
-            __builtin_memcpy(&v, &d, sizeof(bits));
-            if (dnan) v = v & ~((bits)1 << (sizeof(bits) * 8 - 1));      // positive NaN pattern
-            atomicMax(reinterpret_cast<bits *>(max_du), v);
+            real v = (fl & 2) ? (real)NAN : d;
+            bits u;
+            __builtin_memcpy(&u, &v, sizeof(bits));
+            if (fl & 2) u = u & ~((bits)1 << (sizeof(bits) * 8 - 1));
+            atomicMax(reinterpret_cast<bits *>(max_du), u);
         }
     }
 }
@@ -954,6 +1006,11 @@ int launch_pnqp(int B, int n, const real *H, const real *q, const real *lo, cons
 
 template <typename real> int launch_traj_cost(const StepParams<real> &p, real *x, real *cost, hipStream_t st)
 {
+    if (!cost && x && !p.env.kind && p.ns + p.nc <= 16) {
+        const long groups = p.B;
+        hipLaunchKernelGGL(traj_rows16_kernel<real>, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, st, p, x);
+        return check_launch("traj_rows16_kernel");
+    }
     const size_t lds = generic_lds_bytes(p.ns, p.nc, sizeof(real));
     if (lds > 160 * 1024) { set_last_error("traj_cost: dims too large"); return MPC_E_DIMS; }
     if (lds > 64 * 1024)
@@ -999,8 +1056,13 @@ int launch_select_best(int B, int T, int ns, int nc, int first, real eps, const 
 {
     if (any_improved) (void)hipMemsetAsync(any_improved, 0, sizeof(int), st);
     if (max_du) (void)hipMemsetAsync(max_du, 0, sizeof(real), st);
-    hipLaunchKernelGGL(select_best_kernel<real>, dim3(B < 512 ? B : 512), dim3(WAVE), 0, st, B, T, ns, nc, first, eps, x, u, costs,
-                       du_norm, bx, bu, bc, bd, any_improved, max_du);
+    const long tx = (long)T * B * ns, tu = (long)T * B * nc;
+    hipLaunchKernelGGL(select_copy_kernel<real>, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, st, tx, B, ns, first,
+                       eps, x, bx, costs, bc);
+    hipLaunchKernelGGL(select_copy_kernel<real>, dim3((unsigned)((tu + 255) / 256)), dim3(256), 0, st, tu, B, nc, first,
+                       eps, u, bu, costs, bc);
+    hipLaunchKernelGGL(select_update_kernel<real>, dim3((B + 255) / 256), dim3(256), 0, st, B, first, eps, costs, du_norm,
+                       bc, bd, any_improved, max_du);
     return check_launch("select_best_kernel");
 }
 

@@ -155,16 +155,24 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
             for (int a = 0; a < 4; ++a) x[a] = mx[a];
             continue;
         }
+        // Otherwise evaluate it -- as f(x) - f(m) = -g'd - d'Hd/2 with d = m - x, not as the difference of
+        // the two objective values (the same number without the cancellation that makes it noise in float32).
         float alpha = 1.f;
-        const float obj_x = qp_obj4_from_grad(g, q, x);
         for (int count = 0; count < 10; ++count) {
+            float d[4], hd[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) mx[a] = eclampf(fmaf(alpha, dx[a], x[a]), lb[a], ub[a]);
-            const float obj_m = qp_obj4(s, q, mx);
-            float den = 0.f;
+            for (int a = 0; a < 4; ++a) {
+                mx[a] = eclampf(fmaf(alpha, dx[a], x[a]), lb[a], ub[a]);
+                d[a] = mx[a] - x[a];
+            }
+            sym4_mv(s, d, hd);
+            float den = 0.f, dhd = 0.f;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) den = fmaf(g[a], x[a] - mx[a], den);
-            const float arm = (obj_x - obj_m) * wv::rcp(den);
+            for (int a = 0; a < 4; ++a) {
+                den = fmaf(-g[a], d[a], den);
+                dhd = fmaf(d[a], hd[a], dhd);
+            }
+            const float arm = fmaf(-0.5f, dhd, den) * wv::rcp(den);
             const bool shrink = arm <= 0.1f;
             if (UNIFORM ? wv::uniform(shrink) : shrink) alpha *= 0.1f; else break;
         }

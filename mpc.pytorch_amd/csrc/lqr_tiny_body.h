@@ -49,11 +49,10 @@ MPC_HD int pnqp1(real H, real q, real lb, real ub, real &x, real &Hfree, bool &i
         }
         real alpha = 1, arm = GAMMA, xn = x;
         int count = 0;
-        const real ox = (real)0.5 * H * x * x + q * x;
         while (arm <= GAMMA && count < 10) {                       // :64-76
             xn = clampr<real>(x + alpha * dx, lb, ub);
-            const real on = (real)0.5 * H * xn * xn + q * xn;
-            arm = (ox - on) / (g * (x - xn));
+            const real d = xn - x;                                 // f(x) - f(xn) = -g d - H d^2 / 2, without
+            arm = (-g * d - (real)0.5 * H * d * d) / (-g * d);     // subtracting two large objective values
             if (arm <= GAMMA) alpha *= (real)0.1;
             ++count;
         }
