@@ -73,6 +73,38 @@ def test_argument_validation_without_gpu():
     assert L.mpc_pnqp(3, 1, 4, None, None, None, None, None, 20, None, None, None, None, None, None) == -3
 
 
+def test_simulator_entry_points_validate_arguments_without_gpu():
+    L = _native.load()
+    e = _native.EnvDynamics()
+    e.kind, e.dt, e.u_max = 9, 0.05, 2.0
+    assert L.mpc_env_linearize(ctypes.byref(e), 0, 10, None, None, None, None, None) == -5      # unknown kind
+    e.kind = _native.ENV_PENDULUM
+    assert L.mpc_env_linearize(ctypes.byref(e), 0, 10, None, None, None, None, None) == -2      # params NULL
+    e.params = 16
+    assert L.mpc_env_linearize(ctypes.byref(e), 0, 0, None, None, None, None, None) == 0        # nothing to do
+    assert L.mpc_env_linearize(ctypes.byref(e), 0, 10, None, None, None, None, None) == -2      # x NULL
+    assert L.mpc_env_linearize(ctypes.byref(e), 5, 10, None, None, None, None, None) == -3      # dtype
+    assert L.mpc_env_linearize(None, 0, 10, None, None, None, None, None) == -2
+    p = _native.Problem()
+    p.B, p.T, p.ns, p.nc, p.dtype = 4, 5, 5, 1, 0          # cart-pole sized problem, pendulum descriptor
+    assert L.mpc_env_traj_cost(ctypes.byref(p), ctypes.byref(e), None, None, None) == -1
+    assert b"simulator" in L.mpc_lqr_last_error()
+    p.ns = 3
+    assert L.mpc_env_traj_cost(ctypes.byref(p), ctypes.byref(e), None, None, None) == -2        # x_init NULL
+    p.B = 0
+    assert L.mpc_env_traj_cost(ctypes.byref(p), ctypes.byref(e), None, None, None) == 0
+    # a simulator as true_dynamics: sizes are checked against the problem, fused kernels refuse it
+    o, out = _native.Options(), _native.Outputs()
+    o.max_linesearch_iter, o.delta_u = 10, float('nan')
+    o.true_dynamics = ctypes.pointer(e)
+    p.B, p.ns, p.nc, p.T = 2, 12, 4, 3
+    p.x_init = p.C = p.c = p.F = p.cur_x = p.cur_u = 16
+    assert L.mpc_lqr_step(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), None, 0, 0, None) == -1
+    assert L.mpc_lqr_impl_supported(ctypes.byref(p), None, 4) == 0 and L.mpc_lqr_impl_supported(ctypes.byref(p), None, 3) == 1
+    p.ns, p.nc = 3, 1
+    assert L.mpc_lqr_impl_supported(ctypes.byref(p), None, 4) == 1
+
+
 def test_product_refuses_cpu_tensors():
     """No CPU / eager fallback: the shipped backend raises on host tensors."""
     be = _native.HipBackend()
