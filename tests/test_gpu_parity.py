@@ -466,6 +466,46 @@ def test_north_star_full_size_vs_oracle(be, bounded):
         assert (st & 1).mean() < 0.01, "impl %d: %.3f %% of the problems carry an unconverged QP" % (impl, 100 * (st & 1).mean())
 
 
+@pytest.mark.parametrize("shape", ["headline", "tiny", "generic"])
+def test_step_and_select_are_graph_capturable(be, shape):
+    """The C ABI promises "allocates nothing, never synchronises": a pre-bound step + best-iterate select
+    captured into a HIP graph replays on fresh inputs with the results of the eager calls."""
+    import bench
+    ns, nc, T, B = {"headline": (12, 4, 20, 64), "tiny": (3, 1, 12, 128), "generic": (7, 3, 9, 16)}[shape]
+    from mpc._native import StepOptions
+    p = bench.make_problem(ns, nc, T, B, torch.float32, DEV, seed=3, u_scale=0.3, clamp=1.0)
+    opts = StepOptions(u_lower=-1.0, u_upper=1.0)
+    plan = be.plan_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts)
+    best = dict(x=torch.zeros(T, B, ns, device=DEV), u=torch.zeros(T, B, nc, device=DEV),
+                costs=torch.zeros(B, device=DEV), full_du_norm=torch.zeros(B, device=DEV))
+    flags = (torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, device=DEV))
+    plan()                                                    # warm up outside the capture
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            r = plan()
+            be.select_best(True, 1e-4, r["new_x"], r["new_u"], r["costs"], r["full_du_norm"], best, flags=flags)
+    torch.cuda.current_stream().wait_stream(side)
+    # new inputs, in place: the graph holds the pointers, not the values
+    p["x_init"].mul_(0.5).add_(0.1)
+    p["c"].mul_(-1.0)
+    from mpc import util
+    from mpc.mpc import LinDx
+    p["cur_x"].copy_(util.get_traj(T, p["cur_u"], p["x_init"], LinDx(p["F"], p["f"])))
+    graph.replay()
+    torch.cuda.synchronize()
+    got = {k: r[k].clone() for k in ("new_x", "new_u", "costs")}
+    got_best, got_max = best["u"].clone(), float(flags[1][0])
+    e = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts)
+    torch.cuda.synchronize()
+    for k in got:
+        assert torch.equal(got[k], e[k]), k
+    assert torch.equal(got_best, e["new_u"]) and got_max == float(e["full_du_norm"].max())
+
+
 def test_north_star_properties(be):
     """Size-independent properties at B = 4096:
        (1) an unconstrained LQR step from ANY nominal lands on the optimum, so a second step from
