@@ -1,136 +1,136 @@
-"""Learnable / affine dynamics modules with closed-form input Jacobians -- host-side mirror of the
-reference's mpc/dynamics.py (NNDynamics :15-130, CtrlPassthroughDynamics :133-158,
-AffineDynamics :161-202).  These are callers of the LQR step (their `forward` is the module rollout
-of mpc/lqr_step.py:223-225, their `grad_input` feeds GradMethods.ANALYTIC, mpc/mpc.py:495-512);
-they are plain torch modules and run wherever their tensors live."""
+"""Dynamics modules with closed-form input Jacobians: `AffineDynamics`, `NNDynamics`,
+`CtrlPassthroughDynamics` -- the host-side mirror of the reference's mpc/dynamics.py (same class
+names, constructor arguments and `forward` / `grad_input` contracts; :15-130, :133-158, :161-202).
+
+They sit on either side of the LQR step: `forward` is what a module rollout calls once per timestep
+(mpc/lqr_step.py:223-225), `grad_input` is what GradMethods.ANALYTIC linearises with
+(mpc/mpc.py:495-512).  Plain torch; they run wherever their tensors live.
+"""
 import torch
-import torch.nn.functional as nnF
 from torch import nn
 
-ACTS = {
+_ACTIVATIONS = {
     "sigmoid": torch.sigmoid,
-    "relu": nnF.relu,
-    "elu": nnF.elu,
+    "relu": torch.relu,
+    "elu": nn.functional.elu,
 }
+ACTS = _ACTIVATIONS      # the reference exports the table under this name
 
 
-def _identity(z):
-    return z
+def _batched(*tensors):
+    """Promote 1-D arguments to a batch of one; report whether the first one was 1-D."""
+    was_vector = tensors[0].dim() == 1
+    return was_vector, tuple(t.unsqueeze(0) if t.dim() == 1 else t for t in tensors)
+
+
+class AffineDynamics(nn.Module):
+    """x' = A x + B u + c with one (A, B, c) shared by the batch.  A [ns,ns], B [ns,nc], c [ns] or None."""
+
+    def __init__(self, A, B, c=None):
+        super().__init__()
+        assert A.dim() == 2
+        assert B.dim() == 2
+        assert c is None or c.dim() == 1
+        self.A, self.B, self.c = A, B, c
+
+    def forward(self, x, u):
+        was_vector, (x, u) = _batched(x, u)
+        nxt = nn.functional.linear(x, self.A) + nn.functional.linear(u, self.B)
+        if self.c is not None:
+            nxt = nxt + self.c
+        return nxt[0] if was_vector else nxt
+
+    def grad_input(self, x, u):
+        batch = x.shape[0]
+        return self.A.expand(batch, *self.A.shape).clone(), self.B.expand(batch, *self.B.shape).clone()
 
 
 class NNDynamics(nn.Module):
-    """MLP x_{t+1} = net([x;u]) (+ x if passthrough).  `grad_input` returns the Jacobians
-    R = d/dx, S = d/du at the points of the LAST forward call (it re-uses that call's hidden
-    activations, as the reference does) for 'relu' and 'sigmoid' activations."""
+    """A fully connected network [x;u] -> x' (plus x itself when `passthrough`).
+
+    `grad_input(x, u)` returns (d x'/dx, d x'/du) at the points of the most recent `forward` call: it
+    re-uses that call's hidden activations instead of re-evaluating the network (the reference does the
+    same), and knows the derivative of 'relu' and 'sigmoid' layers.
+    """
 
     def __init__(self, n_state, n_ctrl, hidden_sizes=[100], activation="sigmoid", passthrough=True):
         super().__init__()
-        assert activation in ACTS
-        self.passthrough = passthrough
-        self.activation = activation
-        widths = [n_state + n_ctrl] + list(hidden_sizes) + [n_state]
-        self.fcs = nn.ModuleList(nn.Linear(a, b) for a, b in zip(widths[:-1], widths[1:]))
+        assert activation in _ACTIVATIONS
+        self.activation, self.passthrough = activation, passthrough
+        sizes = (n_state + n_ctrl, *hidden_sizes, n_state)
+        self.fcs = nn.ModuleList([nn.Linear(fan_in, fan_out) for fan_in, fan_out in zip(sizes, sizes[1:])])
         self._wire()
 
     def _wire(self):
-        self.acts = [ACTS[self.activation]] * (len(self.fcs) - 1) + [_identity]
-        self.Ws = [fc.weight for fc in self.fcs]
+        """(Re)build the views the reference exposes: per-layer activations `acts`, weights `Ws`."""
+        hidden = len(self.fcs) - 1
+        self.acts = [_ACTIVATIONS[self.activation]] * hidden + [lambda z: z]
+        self.Ws = [layer.weight for layer in self.fcs]
         self.zs = []
 
+    # pickles carry only what cannot be rebuilt
     def __getstate__(self):
         return (self.fcs, self.activation, self.passthrough)
 
     def __setstate__(self, state):
         super().__init__()
-        if len(state) == 2:          # pickles written before `passthrough` existed
-            self.fcs, self.activation = state
-            self.passthrough = True
-        else:
-            self.fcs, self.activation, self.passthrough = state
+        self.fcs, self.activation = state[0], state[1]
+        self.passthrough = state[2] if len(state) > 2 else True      # older pickles had no flag
         self._wire()
 
     def forward(self, x, u):
-        single = x.dim() == 1
-        if single:
-            x = x.unsqueeze(0)
-        if u.dim() == 1:
-            u = u.unsqueeze(0)
-        z = torch.cat((x, u), 1)
-        hidden = []
-        for act, fc in zip(self.acts, self.fcs):
-            z = act(fc(z))
-            hidden.append(z)
-        self.zs = hidden[:-1]         # hidden activations only; the output layer is linear
-        if self.passthrough:
-            z = z + x
-        return z.squeeze(0) if single else z
+        was_vector, (x, u) = _batched(x, u)
+        z, kept = torch.cat((x, u), dim=1), []
+        for act, layer in zip(self.acts, self.fcs):
+            z = act(layer(z))
+            kept.append(z)
+        self.zs = kept[:-1]                       # the output layer is linear: nothing to remember
+        out = z + x if self.passthrough else z
+        return out[0] if was_vector else out
+
+    def _slope(self, z):
+        if self.activation == "relu":
+            return (z > 0).to(z.dtype)
+        if self.activation == "sigmoid":
+            return z * (1. - z)
+        assert False, "grad_input knows relu and sigmoid"
 
     def grad_input(self, x, u):
-        single = x.dim() == 1
-        n_batch, n_state = (1, x.shape[0]) if single else x.shape
-        diff = x.requires_grad or u.requires_grad or torch.is_grad_enabled()
-        Ws = self.Ws if diff else [W.detach() for W in self.Ws]
-        zs = self.zs if diff else [z.detach() for z in self.zs]
-        assert len(zs) == len(Ws) - 1
-        jac = Ws[-1].unsqueeze(0).expand(n_batch, -1, -1)
-        for W, z in zip(reversed(Ws[:-1]), reversed(zs)):
-            if self.activation == "relu":
-                slope = (z > 0).to(W.dtype)
-            elif self.activation == "sigmoid":
-                slope = z * (1. - z)
-            else:
-                assert False
-            jac = jac.bmm(slope.unsqueeze(2) * W.unsqueeze(0))
-        R, S = jac[:, :, :n_state], jac[:, :, n_state:]
+        was_vector = x.dim() == 1
+        n_state = x.shape[-1]
+        keep_graph = torch.is_grad_enabled()
+        weights = self.Ws if keep_graph else [W.detach() for W in self.Ws]
+        hidden = self.zs if keep_graph else [z.detach() for z in self.zs]
+        assert len(hidden) == len(weights) - 1
+        # forward accumulation from the input side: J <- diag(act'(z_l)) W_l J
+        jac = None
+        for W, z in zip(weights[:-1], hidden):
+            layer_jac = self._slope(z).unsqueeze(2) * W                     # [B, out, in]
+            jac = layer_jac if jac is None else layer_jac.bmm(jac)
+        last = weights[-1]
+        jac = last.expand(hidden[0].shape[0] if hidden else x.reshape(-1, n_state).shape[0], *last.shape) \
+            if jac is None else torch.matmul(last, jac)
+        R, S = jac[..., :n_state], jac[..., n_state:]
         if self.passthrough:
-            R = R + torch.eye(n_state, dtype=R.dtype, device=R.device).unsqueeze(0)
-        if single:
-            R, S = R.squeeze(0), S.squeeze(0)
+            R = R + torch.eye(n_state, dtype=R.dtype, device=R.device)
+        if was_vector:
+            R, S = R[0], S[0]
         return R, S
 
 
 class CtrlPassthroughDynamics(nn.Module):
-    """Augmented dynamics for slew-rate problems: state (u_prev, x) -> (u, dynamics(x, u))."""
+    """Dynamics of the slew-rate augmentation: the state is (previous control, x) and a step returns
+    (this control, dynamics(x, u))."""
 
     def __init__(self, dynamics):
         super().__init__()
         self.dynamics = dynamics
 
     def forward(self, tilde_x, u):
-        single = tilde_x.dim() == 1
-        if single:
-            tilde_x = tilde_x.unsqueeze(0)
-        if u.dim() == 1:
-            u = u.unsqueeze(0)
-        nxt = torch.cat((u, self.dynamics(tilde_x[:, u.shape[1]:], u)), dim=1)
-        return nxt.squeeze() if single else nxt
+        was_vector, (tilde_x, u) = _batched(tilde_x, u)
+        inner_next = self.dynamics(tilde_x[:, u.shape[1]:], u)
+        out = torch.cat((u, inner_next), dim=1)
+        return out.squeeze() if was_vector else out
 
     def grad_input(self, x, u):
         assert False, "Unimplemented"
-
-
-class AffineDynamics(nn.Module):
-    """x_{t+1} = A x + B u (+ c), one (A, B, c) for the whole batch."""
-
-    def __init__(self, A, B, c=None):
-        super().__init__()
-        assert A.dim() == 2
-        assert B.dim() == 2
-        if c is not None:
-            assert c.dim() == 1
-        self.A, self.B, self.c = A, B, c
-
-    def forward(self, x, u):
-        single = x.dim() == 1
-        if single:
-            x = x.unsqueeze(0)
-        if u.dim() == 1:
-            u = u.unsqueeze(0)
-        z = x.mm(self.A.t()) + u.mm(self.B.t())
-        if self.c is not None:
-            z = z + self.c
-        return z.squeeze(0) if single else z
-
-    def grad_input(self, x, u):
-        n_batch = x.shape[0]
-        return (self.A.unsqueeze(0).repeat(n_batch, 1, 1), self.B.unsqueeze(0).repeat(n_batch, 1, 1))
