@@ -6,17 +6,42 @@
 namespace mpclqr {
 namespace {
 
+// G aligned lanes of a wavefront share a problem: exchanges are row shuffles, the gains the group's first
+// lane wrote to the scratch become visible to the others through an agent-scope fence.
+struct GroupLanes {
+    int G_, g_, base_;
+    __device__ int G() const { return G_; }
+    __device__ int g() const { return g_; }
+    __device__ void gather(double mine, double *all) const
+    {
+        for (int i = 0; i < G_; ++i) all[i] = __shfl(mine, base_ + i);
+    }
+    __device__ void gains_visible() const
+    {
+        __threadfence();
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
 template <typename real, int NS>
-__global__ void __launch_bounds__(64) lqr_step_tiny_kernel(StepParams<real> p)
+__global__ void __launch_bounds__(64) lqr_step_tiny_kernel(StepParams<real> p, int G)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= p.B) return;
-    tiny::lqr_step_problem<real, NS>(p, b, p.Kk);
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    int b = gid / G;
+    const bool active = b < p.B;
+    if (!active) b = p.B - 1;                // whole idle groups shadow the last problem, storing nothing
+    GroupLanes L{G, gid % G, (int)(threadIdx.x & 63) & ~(G - 1)};
+    tiny::lqr_step_problem<real, NS>(p, b, p.Kk, L, active);
 }
+
+// lanes per problem: one per line-search trial of a round, a power of two <= 8
+inline int trial_lanes(int max_ls) { return max_ls <= 1 ? 1 : (max_ls == 2 ? 2 : (max_ls <= 4 ? 4 : 8)); }
 
 template <typename real, int NS> int launch_ns(const StepParams<real> &p, hipStream_t st)
 {
-    hipLaunchKernelGGL((lqr_step_tiny_kernel<real, NS>), dim3((p.B + 63) / 64), dim3(64), 0, st, p);
+    const int G = trial_lanes(p.max_ls);
+    const long lanes = (long)p.B * G;
+    hipLaunchKernelGGL((lqr_step_tiny_kernel<real, NS>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, p, G);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_last_error(hipGetErrorString(e));

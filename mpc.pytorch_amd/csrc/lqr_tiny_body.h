@@ -61,16 +61,30 @@ MPC_HD int pnqp1(real H, real q, real lb, real ub, real &x, real &Hfree, bool &i
     return ret;
 }
 
-// One problem.  Kw: gain scratch laid out [T][NS+1][B] (k in row NS) so neighbouring lanes touch
-// neighbouring words.
+// The group of lanes that shares one problem: lane g of G evaluates line-search trial g of a round.
+// On the host (tests/emu) a "group" is one lane, and the rounds below are the reference's sequential passes.
+struct OneLane {
+    MPC_HD int G() const { return 1; }
+    MPC_HD int g() const { return 0; }
+    MPC_HD void gather(double mine, double *all) const { all[0] = mine; }
+    MPC_HD void gains_visible() const {}
+};
+
+// Riccati sweep of one problem.  Kw: gain scratch laid out [T][NS+1][B] (k in row NS) so neighbouring lanes
+// touch neighbouring words.  Every lane of a group runs the sweep (same instructions, no extra time); only
+// `writer` stores.
 template <typename real, int NS>
-MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw)
+MPC_HD void sweep_problem(const StepParams<real> &p, int b, real *Kw, bool writer, double &old_cost, int &status,
+                          int &qp_total)
 {
     constexpr int N = NS + 1;
     const int T = p.T, B = p.B;
     real V[NS][NS], v[NS];
-    real old_cost = 0;
-    int status = 0, qp_total = 0;
+    // trajectory costs are summed in double: the line search compares two nearly equal sums once iLQR
+    // is close to its fixed point, and float32 rounding there costs whole extra rollout passes
+    old_cost = 0;
+    status = 0;
+    qp_total = 0;
     bool warm = false;
     real kprev = 0;
 
@@ -88,7 +102,7 @@ MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw)
             real r = 0;
             for (int j = 0; j < N; ++j) r += Q[i][j] * tau[j];
             const real ci = ct[i];
-            old_cost += (real)0.5 * tau[i] * r + ci * tau[i];
+            old_cost += (double)((real)0.5 * tau[i] * r + ci * tau[i]);
             q[i] = r + ci;
         }
         if (t < T - 1) {                               // Q = C + F'VF, q = c_back + F'v (:65-70)
@@ -146,10 +160,12 @@ MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw)
             for (int j = 0; j < NS; ++j) K[j] = is_free ? -(Q[NS][j] / Hf) : (real)0;   // :142-146
         }
         kprev = k;
-        for (int j = 0; j < NS; ++j) Kw[((long)t * N + j) * B + b] = K[j];
-        Kw[((long)t * N + NS) * B + b] = k;
-        if (p.K) for (int j = 0; j < NS; ++j) p.K[tb * NS + j] = K[j];
-        if (p.k) p.k[tb] = k;
+        if (writer) {
+            for (int j = 0; j < NS; ++j) Kw[((long)t * N + j) * B + b] = K[j];
+            Kw[((long)t * N + NS) * B + b] = k;
+            if (p.K) for (int j = 0; j < NS; ++j) p.K[tb * NS + j] = K[j];
+            if (p.k) p.k[tb] = k;
+        }
         // :155-158 V = Qxx + Qxu K + K'Qux + K'Quu K, v likewise (unmasked Quu, qu)
         real M[NS];
         for (int j = 0; j < NS; ++j) M[j] = Q[NS][j] + Quu * K[j];
@@ -160,77 +176,133 @@ MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw)
         }
     }
 
-    // ------------------------------------------------------------------ rollout + line search
-    real alpha = 1, cost = 0, dun = 0, full = 0;
-    for (int pass = 0; pass < p.max_ls; ++pass) {
-        real x[NS], dx[NS];
-        for (int i = 0; i < NS; ++i) {
-            x[i] = p.x_init[(long)b * NS + i];
-            dx[i] = 0;
-            p.new_x[(long)b * NS + i] = x[i];
-        }
-        real ca = 0, da = 0;
-        for (int t = 0; t < T; ++t) {
-            const long tb = (long)t * B + b;
-            const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
-            const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
-            real r = 0;
-            for (int j = 0; j < NS; ++j) r += Kw[((long)t * N + j) * B + b] * dx[j];
-            const real u = p.cur_u[tb];
-            real un = r + u + alpha * Kw[((long)t * N + NS) * B + b];          // :192
-            if (p.zero_mask && p.zero_mask[tb]) un = 0;                         // :197-198
-            if (p.bound_mode != MPC_BOUND_NONE) {                               // :200-213
-                real l = p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[tb];
-                real h = p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : p.hi[tb];
-                if (p.has_delta) {
-                    const real l2 = u - p.delta_u, h2 = u + p.delta_u;
-                    l = (l2 < l) ? l : l2;
-                    h = (h2 > h) ? h : h2;
-                }
-                un = clampr<real>(un, l, h);
-            }
-            p.new_u[tb] = un;
-            da += (u - un) * (u - un);
-            real tau[N];
-            for (int j = 0; j < NS; ++j) tau[j] = x[j];
-            tau[NS] = un;
-            for (int i = 0; i < N; ++i) {                                       // :230-232
-                real s = 0;
-                for (int j = 0; j < N; ++j) s += Ct[i * N + j] * tau[j];
-                ca += (real)0.5 * tau[i] * s + ct[i] * tau[i];
-            }
-            if (t < T - 1) {
-                real xn[NS];
-                if (p.env.kind) {                                               // :223-225
-                    env_step<real>(p.env, x, un, xn, nullptr);
-                } else {                                                        // :216-222
-                    const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
-                    const real *ft = p.f ? p.f + (long)t * p.f_st + (long)b * p.f_sb : nullptr;
-                    for (int i = 0; i < NS; ++i) {
-                        real s = 0;
-                        for (int j = 0; j < N; ++j) s += Ft[i * N + j] * tau[j];
-                        xn[i] = ft ? s + ft[i] : s;
-                    }
-                }
-                const long tb1 = (long)(t + 1) * B + b;
-                for (int i = 0; i < NS; ++i) {
-                    x[i] = xn[i];
-                    dx[i] = xn[i] - p.cur_x[tb1 * NS + i];
-                    p.new_x[tb1 * NS + i] = xn[i];
-                }
-            }
-        }
-        cost = ca;
-        dun = sqrt(da);
-        if (pass == 0) full = dun;                                              // :243-245
-        if (cost > old_cost && pass + 1 < p.max_ls) alpha *= p.ls_decay; else break;   // :176-179, 247
+}
+
+// One rollout with step size alpha (mpc/lqr_step.py:186-241): trajectory cost and ||u - u'||; the trajectory
+// itself is written only when `store`.
+template <typename real, int NS>
+MPC_HD void rollout_pass(const StepParams<real> &p, int b, const real *Kw, real alpha, bool store, double &cost,
+                         real &dun)
+{
+    constexpr int N = NS + 1;
+    const int T = p.T, B = p.B;
+    real x[NS], dx[NS];
+    for (int i = 0; i < NS; ++i) {
+        x[i] = p.x_init[(long)b * NS + i];
+        dx[i] = 0;
+        if (store) p.new_x[(long)b * NS + i] = x[i];
     }
-    if (!(cost == cost) || absr<real>(cost) > (real)3e38) status |= MPC_ST_NONFINITE;
-    if (p.costs) p.costs[b] = cost;
-    if (p.old_costs) p.old_costs[b] = old_cost;
+    real da = 0;
+    double ca = 0;
+    for (int t = 0; t < T; ++t) {
+        const long tb = (long)t * B + b;
+        const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+        const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+        real r = 0;
+        for (int j = 0; j < NS; ++j) r += Kw[((long)t * N + j) * B + b] * dx[j];
+        const real u = p.cur_u[tb];
+        real un = r + u + alpha * Kw[((long)t * N + NS) * B + b];          // :192
+        if (p.zero_mask && p.zero_mask[tb]) un = 0;                         // :197-198
+        if (p.bound_mode != MPC_BOUND_NONE) {                               // :200-213
+            real l = p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[tb];
+            real h = p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : p.hi[tb];
+            if (p.has_delta) {
+                const real l2 = u - p.delta_u, h2 = u + p.delta_u;
+                l = (l2 < l) ? l : l2;
+                h = (h2 > h) ? h : h2;
+            }
+            un = clampr<real>(un, l, h);
+        }
+        if (store) p.new_u[tb] = un;
+        da += (u - un) * (u - un);
+        real tau[N];
+        for (int j = 0; j < NS; ++j) tau[j] = x[j];
+        tau[NS] = un;
+        for (int i = 0; i < N; ++i) {                                       // :230-232
+            real s = 0;
+            for (int j = 0; j < N; ++j) s += Ct[i * N + j] * tau[j];
+            ca += (double)((real)0.5 * tau[i] * s + ct[i] * tau[i]);
+        }
+        if (t < T - 1) {
+            real xn[NS];
+            if (p.env.kind) {                                               // :223-225
+                env_step<real>(p.env, x, un, xn, nullptr);
+            } else {                                                        // :216-222
+                const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
+                const real *ft = p.f ? p.f + (long)t * p.f_st + (long)b * p.f_sb : nullptr;
+                for (int i = 0; i < NS; ++i) {
+                    real s = 0;
+                    for (int j = 0; j < N; ++j) s += Ft[i * N + j] * tau[j];
+                    xn[i] = ft ? s + ft[i] : s;
+                }
+            }
+            const long tb1 = (long)(t + 1) * B + b;
+            for (int i = 0; i < NS; ++i) {
+                x[i] = xn[i];
+                dx[i] = xn[i] - p.cur_x[tb1 * NS + i];
+                if (store) p.new_x[tb1 * NS + i] = xn[i];
+            }
+        }
+    }
+    cost = ca;
+    dun = sqrt(da);
+}
+
+// One problem on a group of lanes.  The reference's line search (:176-179, 247) tries alpha = decay^j for
+// j = 0, 1, ... and keeps the first trial whose cost is not worse than the nominal's, else the last one.  A
+// group evaluates G consecutive trials at once; trial 0 (alpha = 1, the usual winner) writes its trajectory
+// as it goes, any other winner is replayed once.  `active`: this lane belongs to a real problem (idle tail
+// lanes shadow the last one so that the group exchanges stay uniform).
+template <typename real, int NS, class Lanes>
+MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw, const Lanes &L, bool active = true)
+{
+    const int G = L.G(), g = L.g();
+    const bool writer = active && g == 0;
+    double old_cost;
+    int status, qp_total;
+    sweep_problem<real, NS>(p, b, Kw, writer, old_cost, status, qp_total);
+    L.gains_visible();
+
+    int win = -1;                       // index of the accepted trial
+    double cost0 = 0, win_cost = 0;     // cost of trial 0 / of the accepted trial
+    real full = 0, win_dun = 0, win_alpha = 1;
+    for (int base = 0; base < p.max_ls && win < 0; base += G) {
+        const int j = base + g;
+        real alpha = 1;
+        for (int i = 0; i < j; ++i) alpha *= p.ls_decay;          // the same products the sequential search forms
+        double cost = 0;
+        real dun = 0;
+        if (j < p.max_ls) rollout_pass<real, NS>(p, b, Kw, alpha, writer && j == 0, cost, dun);
+        double costs[8], duns[8];
+        L.gather(cost, costs);
+        L.gather((double)dun, duns);
+        const int n = p.max_ls - base < G ? p.max_ls - base : G;
+        if (base == 0) { full = (real)duns[0]; cost0 = costs[0]; }    // :243-245
+        int w = -1;
+        for (int i = 0; i < n && w < 0; ++i)
+            if (!(costs[i] > old_cost)) w = i;
+        if (w < 0 && base + G >= p.max_ls) w = n - 1;                // nothing helped: the last trial stands
+        if (w >= 0) {
+            win = base + w;
+            win_cost = costs[w];
+            win_dun = (real)duns[w];
+            win_alpha = 1;
+            for (int i = 0; i < win; ++i) win_alpha *= p.ls_decay;
+        }
+    }
+    if (win != 0) {                      // replay the accepted trial to write its trajectory
+        double c2;
+        real d2;
+        rollout_pass<real, NS>(p, b, Kw, win_alpha, writer, c2, d2);
+    }
+    (void)cost0;
+    if (!writer) return;
+    if (!(win_cost == win_cost) || absr<double>(win_cost) > 3e38) status |= MPC_ST_NONFINITE;
+    if (p.costs) p.costs[b] = (real)win_cost;
+    if (p.old_costs) p.old_costs[b] = (real)old_cost;
     if (p.full_du_norm) p.full_du_norm[b] = full;
-    if (p.alpha_du_norm) p.alpha_du_norm[b] = dun;
-    if (p.alphas) p.alphas[b] = alpha;
+    if (p.alpha_du_norm) p.alpha_du_norm[b] = win_dun;
+    if (p.alphas) p.alphas[b] = win_alpha;
     if (p.qp_iters) p.qp_iters[b] = qp_total;
     if (p.status) p.status[b] = status;
 }

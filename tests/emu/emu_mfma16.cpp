@@ -468,12 +468,12 @@ template <typename real> static int tiny_host(const mpc_lqr_problem *p, const mp
     for (size_t i = 0; i < need; ++i) kw[i] = (real)NAN;
     for (int b = 0; b < sp.B; ++b) {
         switch (sp.ns) {
-        case 1: mpclqr::tiny::lqr_step_problem<real, 1>(sp, b, kw); break;
-        case 2: mpclqr::tiny::lqr_step_problem<real, 2>(sp, b, kw); break;
-        case 3: mpclqr::tiny::lqr_step_problem<real, 3>(sp, b, kw); break;
-        case 4: mpclqr::tiny::lqr_step_problem<real, 4>(sp, b, kw); break;
-        case 5: mpclqr::tiny::lqr_step_problem<real, 5>(sp, b, kw); break;
-        case 6: mpclqr::tiny::lqr_step_problem<real, 6>(sp, b, kw); break;
+        case 1: mpclqr::tiny::lqr_step_problem<real, 1>(sp, b, kw, mpclqr::tiny::OneLane()); break;
+        case 2: mpclqr::tiny::lqr_step_problem<real, 2>(sp, b, kw, mpclqr::tiny::OneLane()); break;
+        case 3: mpclqr::tiny::lqr_step_problem<real, 3>(sp, b, kw, mpclqr::tiny::OneLane()); break;
+        case 4: mpclqr::tiny::lqr_step_problem<real, 4>(sp, b, kw, mpclqr::tiny::OneLane()); break;
+        case 5: mpclqr::tiny::lqr_step_problem<real, 5>(sp, b, kw, mpclqr::tiny::OneLane()); break;
+        case 6: mpclqr::tiny::lqr_step_problem<real, 6>(sp, b, kw, mpclqr::tiny::OneLane()); break;
         }
     }
     free(kw);

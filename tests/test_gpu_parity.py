@@ -147,6 +147,36 @@ def test_generic_kernel_large_shapes_on_mfma(be, ns, nc, T, bounded):
     np.testing.assert_allclose(res[torch.float32]["alphas"], o["alphas"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("ns", [1, 3, 5, 6])
+@pytest.mark.parametrize("max_ls", [1, 2, 3, 5, 10])
+def test_lane_per_problem_kernel_parallel_line_search(be, ns, max_ls):
+    """The one-control kernel evaluates up to 8 line-search trials of a problem on neighbouring lanes and
+    replays the accepted one: same step sizes, costs and trajectories as the oracle's sequential search
+    (float64, problems whose stage cost is non-convex so the search really backtracks; B not a multiple of
+    the lane group)."""
+    from oracle import lqr_oracle as O
+    from mpc._native import StepOptions, IMPL_TINY
+    rng = np.random.default_rng(17 * ns + max_ls)
+    T, B, n = 9, 37, ns + 1
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A) + 0.1 * np.eye(n)
+    C[:, :, :ns, :ns] -= 5.0 * np.eye(ns)
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.3 * rng.standard_normal((T - 1, B, ns, ns)), rng.standard_normal((T - 1, B, ns, 1))), 3)
+    f = 0.1 * rng.standard_normal((T - 1, B, ns))
+    x_init = rng.standard_normal((B, ns))
+    cur_u = np.clip(0.3 * rng.standard_normal((T, B, 1)), -0.4, 0.4)
+    cur_x, _ = O.traj_cost(x_init, cur_u, F, f)
+    o = O.lqr_step(x_init, C, c, F, f, cur_x, cur_u, -0.5, 0.5, linesearch_decay=0.5, max_linesearch_iter=max_ls, lockstep=False)
+    r = be.lqr_step(dev(x_init), dev(C), dev(c), dev(F), dev(f), dev(cur_x), dev(cur_u),
+                    StepOptions(u_lower=-0.5, u_upper=0.5, linesearch_decay=0.5, max_linesearch_iter=max_ls), impl=IMPL_TINY)
+    torch.cuda.synchronize()
+    for k in ("alphas", "costs", "old_costs", "full_du_norm", "alpha_du_norm", "new_x", "new_u"):
+        np.testing.assert_allclose(host(r[k]), o[k], rtol=1e-9, atol=1e-10, err_msg=k)
+    if max_ls > 2:
+        assert len(np.unique(o["alphas"])) >= 2          # different trials win across the batch
+
+
 @pytest.mark.parametrize("name", ["step_cfg1_f64", "step_masked_f64", "step_ns_bounded_f32", "step_nc1_scalar_f64"])
 def test_split_sweep_and_rollout_entry_points(be, name):
     """mpc_lqr_sweep (K, k) and mpc_lqr_rollout separately == the fused step, and K,k == oracle."""
