@@ -903,9 +903,13 @@ template <> struct BitsOf<double> { using type = unsigned long long; };
 // pass 2 (stream-ordered after this one) then overwrites.
 template <typename real>
 __global__ void select_copy_kernel(long total, int B, int d, int first, real eps, const real *src, real *dst,
-                                   const real *costs, const real *bc)
+                                   const real *costs, const real *bc, int *zero_flag, real *zero_max)
 {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e == 0) {                         // pass 2 accumulates into these with atomics (no memset launches)
+        if (zero_flag) *zero_flag = 0;
+        if (zero_max) *zero_max = 0;
+    }
     if (e >= total) return;
     const int b = (int)((e / d) % B);
     if (first || costs[b] <= bc[b] + eps) dst[e] = src[e];
@@ -1054,13 +1058,11 @@ int launch_select_best(int B, int T, int ns, int nc, int first, real eps, const 
                        const real *costs, const real *du_norm, real *bx, real *bu, real *bc, real *bd,
                        int *any_improved, real *max_du, hipStream_t st)
 {
-    if (any_improved) (void)hipMemsetAsync(any_improved, 0, sizeof(int), st);
-    if (max_du) (void)hipMemsetAsync(max_du, 0, sizeof(real), st);
     const long tx = (long)T * B * ns, tu = (long)T * B * nc;
     hipLaunchKernelGGL(select_copy_kernel<real>, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, st, tx, B, ns, first,
-                       eps, x, bx, costs, bc);
+                       eps, x, bx, costs, bc, any_improved, max_du);
     hipLaunchKernelGGL(select_copy_kernel<real>, dim3((unsigned)((tu + 255) / 256)), dim3(256), 0, st, tu, B, nc, first,
-                       eps, u, bu, costs, bc);
+                       eps, u, bu, costs, bc, (int *)nullptr, (real *)nullptr);
     hipLaunchKernelGGL(select_update_kernel<real>, dim3((B + 255) / 256), dim3(256), 0, st, B, first, eps, costs, du_norm,
                        bc, bd, any_improved, max_du);
     return check_launch("select_best_kernel");

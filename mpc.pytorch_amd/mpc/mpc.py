@@ -52,16 +52,18 @@ class _FlagReader:
     copied into pinned host memory asynchronously; `wait()` blocks on an event, not on the stream."""
 
     def __init__(self, device, dtype):
-        self.device_flags = (torch.zeros(1, dtype=torch.int32, device=device), torch.zeros(1, dtype=dtype, device=device))
+        # one 16-byte block: int32 flag at byte 0, the maximum (float32 / float64) at byte 8 -> one copy
+        self._dev = torch.zeros(16, dtype=torch.uint8, device=device)
+        self.device_flags = (self._dev[0:4].view(torch.int32), self._dev[8:8 + torch.empty(0, dtype=dtype).element_size()].view(dtype))
         self.cuda = device.type == "cuda"
         if self.cuda:
-            self.host = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.zeros(1, dtype=dtype).pin_memory())
+            self._host = torch.zeros(16, dtype=torch.uint8).pin_memory()
+            self.host = (self._host[0:4].view(torch.int32), self._host[8:8 + self.device_flags[1].element_size()].view(dtype))
             self.event = torch.cuda.Event()
 
     def start(self):
         if self.cuda:
-            self.host[0].copy_(self.device_flags[0], non_blocking=True)
-            self.host[1].copy_(self.device_flags[1], non_blocking=True)
+            self._host.copy_(self._dev, non_blocking=True)
             self.event.record()
 
     def wait(self):
