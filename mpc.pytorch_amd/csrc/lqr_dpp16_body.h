@@ -848,9 +848,9 @@ MPC_DEV void kkt_stage_issue(const P &p, const KktDma &d, int t, int slot)
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wv::dma16(d.c_ptr[q] + tl * d.c_step, base + SC + 1024 * q);
+    for (int q = 0; q < 4; ++q) wv::dma16_once(d.c_ptr[q] + tl * d.c_step, base + SC + 1024 * q);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) wv::dma16(d.f_ptr[q] + (p.T > 1 ? tf * d.f_step : 0), base + SF + 1024 * q);
+    for (int q = 0; q < 3; ++q) wv::dma16_once(d.f_ptr[q] + (p.T > 1 ? tf * d.f_step : 0), base + SF + 1024 * q);
     wv::dma16_if(d.r_active, d.r_ptr + tl * d.r_step, base + SR);
 }
 
@@ -904,7 +904,7 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
                         float *dst = k.dF + (tb * 12 + L.j) * 16;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            wv::store_f32x4(dst + 4 * q, f32x4{row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]});
+                            wv::store_f32x4_out(dst + 4 * q, f32x4{row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]});
                         if (k.df) k.df[tb * 12 + L.j] = -dlam;
                     }
                 }
@@ -917,7 +917,7 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
                         float *dst = k.dC + (tb * 16 + (L.j < 12 ? L.j : 12 + L.a)) * 16;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            wv::store_f32x4(dst + 4 * q, f32x4{row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]});
+                            wv::store_f32x4_out(dst + 4 * q, f32x4{row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]});
                         k.dc[tb * 16 + L.j] = -dj;
                     }
                 }

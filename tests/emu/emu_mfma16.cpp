@@ -273,6 +273,7 @@ static inline bool any(bool c)
     return false;
 }
 static inline void store_f32x4(float *g, f32x4 v) { memcpy(g, &v, 16); }
+static inline void store_f32x4_out(float *g, f32x4 v) { memcpy(g, &v, 16); }
 static inline bool uniform(bool c)
 {
     // must be wave-uniform: check it
@@ -313,6 +314,7 @@ static inline void dma_n(const void *g, unsigned off, int size, bool active = tr
 }
 static inline void dma16(const void *g, unsigned off) { dma_n(g, off, 16); }
 static inline void dma16_c(const void *g, unsigned off) { dma_n(g, off, 16); }
+static inline void dma16_once(const void *g, unsigned off) { dma_n(g, off, 16); }
 static inline void dma16_last(const void *g, unsigned off) { dma_n(g, off, 16); }
 static inline void store_out(float *g, float v) { *g = v; }
 static inline void dma16_if(bool active, const void *g, unsigned off) { dma_n(g, off, 16, active); }
