@@ -147,6 +147,42 @@ def test_generic_kernel_large_shapes_on_mfma(be, ns, nc, T, bounded):
     np.testing.assert_allclose(res[torch.float32]["alphas"], o["alphas"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("ns,nc,T,B", [(3, 2, 1, 1), (30, 4, 1, 2), (5, 1, 2, 1), (12, 4, 1, 5), (12, 4, 2, 1), (2, 1, 1, 3)])
+def test_degenerate_sizes_every_kernel(be, ns, nc, T, B):
+    """T = 1 (no dynamics at all), one problem, one timestep pair: every kernel that takes the shape, float64
+    where it can, against the oracle; and MPC.forward end to end."""
+    from oracle import lqr_oracle as O
+    from mpc import _native, mpc
+    from mpc._native import StepOptions
+    from mpc.mpc import LinDx, QuadCost
+    rng = np.random.default_rng(ns + 10 * T + 100 * B)
+    n = ns + nc
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A) + 0.1 * np.eye(n)
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((T - 1, B, ns, ns)), rng.standard_normal((T - 1, B, ns, nc))), 3)
+    f = 0.1 * rng.standard_normal((T - 1, B, ns))
+    x_init = rng.standard_normal((B, ns))
+    cur_u = np.clip(0.3 * rng.standard_normal((T, B, nc)), -0.5, 0.5)
+    cur_x, _ = O.traj_cost(x_init, cur_u, F, f)
+    o = O.lqr_step(x_init, C, c, F, f, cur_x, cur_u, -0.5, 0.5, lockstep=False)
+    for impl in (1, 2, 3, 4):
+        for dt in (torch.float64, torch.float32):
+            if not be.impl_supported(ns, nc, dt, impl):
+                continue
+            d = lambda a: dev(a).to(dt)
+            r = be.lqr_step(d(x_init), d(C), d(c), d(F) if T > 1 else torch.empty(0, B, ns, n, dtype=dt, device=DEV),
+                            d(f) if T > 1 else None, d(cur_x), d(cur_u), StepOptions(u_lower=-0.5, u_upper=0.5), impl=impl)
+            torch.cuda.synchronize()
+            tol = dict(rtol=1e-9, atol=1e-10) if dt == torch.float64 else dict(rtol=1e-3, atol=1e-4)
+            for k in ("new_x", "new_u", "costs", "alphas"):
+                np.testing.assert_allclose(host(r[k]), o[k], err_msg="impl %d %s %s" % (impl, dt, k), **tol)
+    if T > 1:
+        x, u, costs = mpc.MPC(ns, nc, T, u_lower=-0.5, u_upper=0.5, lqr_iter=15, verbose=-1, exit_unconverged=False)(
+            dev(x_init), QuadCost(dev(C), dev(c)), LinDx(dev(F), dev(f)))
+        assert torch.isfinite(x).all() and float(u.abs().max()) <= 0.5 + 1e-12 and x.shape == (T, B, ns)
+
+
 @pytest.mark.parametrize("ns", [1, 3, 5, 6])
 @pytest.mark.parametrize("max_ls", [1, 2, 3, 5, 10])
 def test_lane_per_problem_kernel_parallel_line_search(be, ns, max_ls):
