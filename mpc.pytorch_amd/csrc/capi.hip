@@ -107,6 +107,20 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
         sp.K = (real *)workspace;
         sp.k = (real *)((char *)workspace + needK);
     }
+    if constexpr (sizeof(real) == 4) {
+        // n_state = 32, n_ctrl = 8, unconstrained: register-resident MFMA sweep (lqr_mfma40_body.h), then the
+        // generic rollout on its gains
+        if (impl == 5 && !(phase_mask == 3 && mfma40_supported(sp)))
+            return fail(MPC_E_DIMS, "MFMA sweep needs fp32, n_state = 32, n_ctrl = 8, no constraints, 16-byte aligned blocks");
+        if (phase_mask == 3 && (impl == 5 || impl == 0) && mfma40_supported(sp)) {
+            int rc = launch_sweep_mfma40(sp, st);
+            if (rc) return rc;
+            sp.old_costs_in = sp.old_costs;
+            return launch_step_generic<real>(sp, 2, st);
+        }
+    } else if (impl == 5) {
+        return fail(MPC_E_DTYPE, "the MFMA sweep is fp32 only");
+    }
     return launch_step_generic<real>(sp, phase_mask, st);
 }
 }  // namespace mpclqr
@@ -120,7 +134,7 @@ int mpc_lqr_abi_version(void) { return MPC_LQR_ABI_VERSION; }
 const char *mpc_lqr_build_info(void)
 {
     return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32>, lqr_step_dpp16<f32>, "
-           "lqr_step_tiny<f32,f64>, env_linearize, kkt_grads, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
+           "lqr_step_tiny<f32,f64>, lqr_sweep_mfma40<f32>, env_linearize, kkt_grads, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
 }
 
 const char *mpc_lqr_last_error(void) { return g_last_error.c_str(); }
@@ -152,6 +166,13 @@ int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, i
     if (!p || check_problem(p, false, false) != MPC_OK || check_options(p, o) != MPC_OK) return 0;
     if (impl == 1) return generic_lds_bytes(p->ns, p->nc, p->dtype == MPC_F64 ? 8 : 4) <= 160 * 1024;
     if (impl == 4) return tiny_supported(p->ns, p->nc) ? 1 : 0;
+    if (impl == 5) {
+        if (p->dtype != MPC_F32) return 0;
+        mpc_lqr_outputs out;
+        memset(&out, 0, sizeof(out));
+        StepParams<float> sp = make_params<float>(p, o, &out);
+        return (sp.ns == 32 && sp.nc == 8 && sp.bound_mode == MPC_BOUND_NONE && !sp.zero_mask && !sp.env.kind) ? 1 : 0;
+    }
     if (impl == 2 || impl == 3) {
         if (p->dtype != MPC_F32) return 0;
         mpc_lqr_outputs out;

@@ -49,6 +49,10 @@ int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *d
 bool tiny_supported(int ns, int nc);
 template <typename real> int launch_step_tiny(const StepParams<real> &p, hipStream_t st);
 
+// register-resident MFMA sweep for n_state = 32, n_ctrl = 8, f32, unconstrained (lqr_mfma40.hip)
+bool mfma40_supported(const StepParams<float> &p);
+int launch_sweep_mfma40(const StepParams<float> &p, hipStream_t st);
+
 // fused MFMA path for n <= 16, f32 (lqr_mfma16.hip)
 bool mfma16_supported(const StepParams<float> &p);
 int launch_step_mfma16(const StepParams<float> &p, hipStream_t st);

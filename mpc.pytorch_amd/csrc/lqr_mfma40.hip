@@ -1,0 +1,82 @@
+// lqr_mfma40.hip -- gfx950 binding of the register-resident MFMA sweep for n_state = 32, n_ctrl = 8
+// (lqr_mfma40_body.h): one wavefront per problem and per workgroup, a 3-slot LDS-DMA ring (35 KiB),
+// 4 wavefronts per CU.
+#include <string>
+#include "lqr_common.h"
+
+#define MPC_DEV __device__ __forceinline__
+
+namespace mpclqr {
+namespace wv {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+MPC_DEV int lane() { return (int)threadIdx.x; }
+MPC_DEV int problem() { return (int)blockIdx.x; }
+MPC_DEV f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+MPC_DEV float readlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+MPC_DEV float shfl_xor(float x, int m) { return __shfl_xor(x, m, 64); }
+MPC_DEV float rcp(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.f), r, r);     // one Newton step: <= 1 ulp
+}
+#define MPC_MFMA40_LDS (3 * 11904 + 512)
+__shared__ __attribute__((aligned(16))) char g_stage40[MPC_MFMA40_LDS];
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+MPC_DEV void dma16(const void *g, unsigned off)
+{
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage40 + off), 16, 0, 0);
+}
+MPC_DEV void dma16_if(bool active, const void *g, unsigned off)
+{
+    if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage40 + off), 16, 0, 0);
+}
+MPC_DEV float lds_f32(unsigned off) { return *(const float *)(g_stage40 + off); }
+MPC_DEV f32x4 lds_f32x4(unsigned off) { return *(const f32x4 *)(g_stage40 + off); }
+MPC_DEV void lds_store_f32(unsigned off, float v) { *(float *)(g_stage40 + off) = v; }
+// DS instructions of one wave execute in program order: a compiler barrier is all there is to ask for
+MPC_DEV void lds_sync() { asm volatile("" ::: "memory"); }
+// hipcc does not order LDS reads behind an LDS-DMA by itself; this is the ordering point
+template <int N> MPC_DEV void dma_wait()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+}  // namespace wv
+}  // namespace mpclqr
+
+#include "lqr_mfma40_body.h"
+
+namespace mpclqr {
+namespace {
+
+__global__ void __launch_bounds__(64, 1) lqr_sweep_mfma40_kernel(StepParams<float> p)
+{
+    mfma40::sweep_wave(p, p.K, p.k);
+}
+
+}  // namespace
+
+bool mfma40_supported(const StepParams<float> &p)
+{
+    auto al = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+    return p.ns == 32 && p.nc == 8 && p.T >= 1 && p.bound_mode == MPC_BOUND_NONE && !p.zero_mask && !p.env.kind &&
+           al(p.C) && al(p.c) && (p.T == 1 || al(p.F)) && al(p.cur_x) && al(p.cur_u) && p.C_st % 4 == 0 && p.C_sb % 4 == 0 &&
+           p.c_st % 4 == 0 && p.c_sb % 4 == 0 && p.F_st % 4 == 0 && p.F_sb % 4 == 0;
+}
+
+int launch_sweep_mfma40(const StepParams<float> &p, hipStream_t st)
+{
+    static_assert(MPC_MFMA40_LDS == mfma40::LDS_TOTAL, "LDS layout out of sync");
+    if (!mfma40_supported(p)) { set_last_error("mfma40: needs fp32, n_state = 32, n_ctrl = 8, unconstrained, 16-byte aligned blocks"); return MPC_E_DIMS; }
+    if (!p.K || !p.k) { set_last_error("mfma40: K / k missing"); return MPC_E_NULL; }
+    hipLaunchKernelGGL(lqr_sweep_mfma40_kernel, dim3(p.B), dim3(64), 0, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error((std::string("lqr_sweep_mfma40_kernel: ") + hipGetErrorString(e)).c_str());
+        return MPC_E_LAUNCH;
+    }
+    return MPC_OK;
+}
+
+}  // namespace mpclqr

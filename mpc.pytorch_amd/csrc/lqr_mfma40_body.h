@@ -1,0 +1,374 @@
+// lqr_mfma40_body.h -- the Riccati sweep for n_state = 32, n_ctrl = 8 (BASELINE config 5), fp32,
+// unconstrained: ONE wavefront per problem, every matrix product on v_mfma_f32_16x16x4_f32 with all
+// operands in registers -- Y = V F, Q = C + F'Y and V = Qxx + Qxu K chain through the accumulators
+// without a single cross-lane move of matrix data.  (The generic kernel runs this shape at 4 % of the
+// HBM roofline: its time goes into serialised LDS phases, not arithmetic.)
+//
+// Written against the wave interface `wv::` (mfma / readlane / shfl_xor / LDS / LDS-DMA): lqr_mfma40.hip
+// binds it to gfx950, tests/emu/ to the host-side lockstep emulator.
+//
+// Reference: mpc/lqr_step.py:284-296 (delta-space linear term) + :52-160 (lqr_backward), unconstrained
+// branch :84-94.  K, k are written in the reference's layout; the rollout is a separate kernel.
+//
+// Layout.  tau = [x(32); u(8)] padded to 48 = 3 tiles of 16.  MFMA 16x16x4: lane l = 16 q + r holds
+// A[i=r][k=q], B[k=q][j=r] and D[4q+v][r] in accumulator register v.  A 48x48 matrix in "D layout" is
+// tiles T[I][J], register v of lane (q,r) = M[16I + 4q + v][16J + r].
+//   * contraction order is ours to choose: block kb = (I',v) stands for rows m = 16I' + 4q + v.  With it
+//     a D-layout tile IS a B operand (register v of tile (I',J)), a SYMMETRIC D-layout matrix is its own A
+//     operand (V[16Im+r][m] = V[m][16Im+r] = register v of tile (I',Im)), and F, loaded once per step as
+//     FB[(I',v)][J] = F[16I'+4q+v][16J+r], is the B operand of Y = V F and the A operand (F') of Q += F'Y.
+//   * the u-rows of Q (tile row 2, lanes q < 2) are at once the right-hand sides of K = -Quu^-1 Qux and the
+//     A operand (Qxu = Qux') of V = Qxx + Qxu K; K comes out of its solve in the B layout that product wants.
+//   * vectors live in "row layout" (lane r holds entry 16J + r, the same in all four lane groups) or in
+//     "column layout" (lane group q holds entries 16I + 4q + v); matrix-vector products are per-lane partial
+//     sums over the tile registers plus a 2-step (across q) or 4-step (across r) butterfly.
+//   * the 8x8 Quu is read out with 36 readlanes and factorised (LDL') on wave-uniform values.
+// C is read as the symmetric matrix the reference documents it to be (mpc/mpc.py:61-68).
+#pragma once
+#include <math.h>
+#include "lqr_params.h"
+
+namespace mpclqr {
+namespace mfma40 {
+
+using wv::f32x4;
+constexpr int NS = 32, NC = 8, N = 40;
+constexpr int NSTAGE = 3;
+constexpr unsigned OFF_C = 0, OFF_F = 6400, OFF_R = 11520, STAGE_BYTES = 11904;
+constexpr unsigned OFF_SCR = NSTAGE * STAGE_BYTES;          // 512 B: row -> column layout turns
+constexpr unsigned LDS_TOTAL = OFF_SCR + 512;
+constexpr int DMA_PER_STAGE = 13;                           // 7 (C) + 5 (F) + 1 (c | x | u)
+typedef StepParams<float> P;
+
+struct Lane {
+    int lane, r, q, b;
+};
+
+struct Stream {
+    const char *c_ptr, *f_ptr, *r_ptr;      // this lane's 16-byte column of each block, timestep 0
+    long c_step, f_step, r_step;            // bytes per timestep
+    bool r_active;
+};
+
+MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L)
+{
+    const long b = L.b;
+    d.c_ptr = (const char *)(p.C + b * p.C_sb) + 16 * L.lane;
+    d.c_step = p.C_st * 4;
+    // T = 1 has no dynamics (F may be NULL): its five DMA slots re-read C, so the wait counts stay the same
+    d.f_ptr = p.T > 1 ? (const char *)(p.F + b * p.F_sb) + 16 * L.lane : d.c_ptr;
+    d.f_step = p.T > 1 ? p.F_st * 4 : 0;
+    // record: lanes 0..9 -> c_t (160 B), 10..17 -> x_t (128 B), 18..19 -> u_t (32 B)
+    d.r_active = L.lane < 20;
+    if (L.lane < 10) {
+        d.r_ptr = (const char *)(p.c + b * p.c_sb) + 16 * L.lane;
+        d.r_step = p.c_st * 4;
+    } else if (L.lane < 18) {
+        d.r_ptr = (const char *)(p.cur_x + b * NS) + 16 * (L.lane - 10);
+        d.r_step = (long)p.B * NS * 4;
+    } else {
+        d.r_ptr = (const char *)(p.cur_u + b * NC) + 16 * ((L.lane < 20 ? L.lane : 18) - 18);
+        d.r_step = (long)p.B * NC * 4;
+    }
+}
+
+MPC_DEV void stage_issue(const P &p, const Stream &d, const Lane &L, int t, int slot)
+{
+    const unsigned base = (unsigned)slot * STAGE_BYTES;
+    const long tl = t;
+    const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wv::dma16(d.c_ptr + tl * d.c_step + 1024 * k, base + OFF_C + 1024 * k);
+    wv::dma16_if(L.lane < 16, d.c_ptr + tl * d.c_step + 6144, base + OFF_C + 6144);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) wv::dma16(d.f_ptr + (p.T > 1 ? tf * d.f_step : 0) + 1024 * k, base + OFF_F + 1024 * k);
+    wv::dma16_if(d.r_active, d.r_ptr + tl * d.r_step, base + OFF_R);
+}
+
+// butterfly sums: across the four lane groups (lanes differing in bits 4,5), across the 16 lanes of a group
+MPC_DEV float sum_q(float x)
+{
+    x += wv::shfl_xor(x, 16);
+    x += wv::shfl_xor(x, 32);
+    return x;
+}
+MPC_DEV float sum_r(float x)
+{
+    x += wv::shfl_xor(x, 1);
+    x += wv::shfl_xor(x, 2);
+    x += wv::shfl_xor(x, 4);
+    x += wv::shfl_xor(x, 8);
+    return x;
+}
+
+// LDL' of the wave-uniform SPD 8x8 matrix S (upper triangle S[a][b], a <= b): L unit lower, d = 1/D.
+struct Ldl8 {
+    float l[8][8];   // l[i][j], j < i
+    float inv[8];
+};
+MPC_DEV void ldl8(Ldl8 &f, const float S[8][8])
+{
+    float a[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) a[i][j] = S[j][i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float dj = a[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) dj = fmaf(-f.l[j][k], a[j][k], dj);      // a[j][k] holds L_jk * D_k
+        f.inv[j] = wv::rcp(dj);
+#pragma unroll
+        for (int i = j + 1; i < 8; ++i) {
+            float s = a[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s = fmaf(-f.l[i][k], a[j][k], s);
+            a[i][j] = s;                       // L_ij * D_j
+            f.l[i][j] = s * f.inv[j];
+        }
+    }
+}
+// y = S^-1 rhs
+MPC_DEV void ldl8_solve(const Ldl8 &f, const float rhs[8], float y[8])
+{
+    float z[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float s = rhs[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s = fmaf(-f.l[i][k], z[k], s);
+        z[i] = s;
+    }
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        float s = z[i] * f.inv[i];
+#pragma unroll
+        for (int k = i + 1; k < 8; ++k) s = fmaf(-f.l[k][i], y[k], s);
+        y[i] = s;
+    }
+}
+
+// The sweep of one problem: K [T,B,8,32] and k [T,B,8] in the reference layout, old_costs[b].
+MPC_DEV void sweep_wave(const P &p, float *Kout, float *kout)
+{
+    Lane L;
+    L.lane = wv::lane();
+    L.r = L.lane & 15;
+    L.q = L.lane >> 4;
+    L.b = wv::problem();
+    if (L.b >= p.B) return;
+    const int T = p.T;
+    Stream d;
+    stream_init(d, p, L);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 Vd[2][2];                    // V, D layout
+    float vcol[2][4];                  // v, column layout: vcol[I][v] = v[16I + 4q + v]
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+#pragma unroll
+        for (int J = 0; J < 2; ++J) Vd[I][J] = zero4;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) vcol[I][v] = 0.f;
+    }
+    double old_cost = 0.0;
+
+    stage_issue(p, d, L, T - 1, 0);
+    stage_issue(p, d, L, T - 2 >= 0 ? T - 2 : 0, 1);
+    int slot = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        // keep two timesteps in flight (re-loading step 0 at the tail keeps the wait count fixed)
+        stage_issue(p, d, L, t - 2 >= 0 ? t - 2 : 0, slot + 2 >= NSTAGE ? slot + 2 - NSTAGE : slot + 2);
+        wv::dma_wait<2 * DMA_PER_STAGE>();
+        const unsigned base = (unsigned)slot * STAGE_BYTES;
+        const long tb = (long)t * p.B + L.b;
+
+        // ---- C in D layout (all nine tiles), tau in both layouts, c in row layout
+        f32x4 Qd[3][3];
+#pragma unroll
+        for (int I = 0; I < 3; ++I)
+#pragma unroll
+            for (int J = 0; J < 3; ++J)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = 16 * I + 4 * L.q + v, col = 16 * J + L.r;
+                    const bool in = row < N && col < N;
+                    const float x = wv::lds_f32(base + OFF_C + 4u * (unsigned)((in ? row : 0) * N + (in ? col : 0)));
+                    Qd[I][J][v] = in ? x : 0.f;
+                }
+        float tcol[3][4], trow[3], crow[3];
+#pragma unroll
+        for (int I = 0; I < 3; ++I)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = 16 * I + 4 * L.q + v;
+                const float x = wv::lds_f32(base + OFF_R + 160 + 4u * (unsigned)(i < N ? i : 0));
+                tcol[I][v] = i < N ? x : 0.f;
+            }
+#pragma unroll
+        for (int J = 0; J < 3; ++J) {
+            const int j = 16 * J + L.r;
+            const float x = wv::lds_f32(base + OFF_R + 160 + 4u * (unsigned)(j < N ? j : 0));
+            const float c = wv::lds_f32(base + OFF_R + 4u * (unsigned)(j < N ? j : 0));
+            trow[J] = j < N ? x : 0.f;
+            crow[J] = j < N ? c : 0.f;
+        }
+        // c_back = C tau + c (mpc/lqr_step.py:289-295) in row layout, and the nominal cost (:169)
+        float qrow[3];
+#pragma unroll
+        for (int J = 0; J < 3; ++J) {
+            float s = 0.f;
+#pragma unroll
+            for (int I = 0; I < 3; ++I)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) s = fmaf(Qd[I][J][v], tcol[I][v], s);
+            const float ct = sum_q(s);                       // (C tau)[16J + r]
+            qrow[J] = ct + crow[J];
+        }
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int J = 0; J < 3; ++J) s = fmaf(trow[J], fmaf(0.5f, qrow[J] - crow[J], crow[J]), s);
+            old_cost += (double)sum_r(s);
+        }
+
+        if (t < T - 1) {
+            // ---- F as FB[(I',v)][J] = F[16I' + 4q + v][16J + r]
+            float FB[8][3];
+#pragma unroll
+            for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int J = 0; J < 3; ++J) {
+                        const int m = 16 * Ip + 4 * L.q + v, col = 16 * J + L.r;
+                        const bool in = col < N;
+                        const float x = wv::lds_f32(base + OFF_F + 4u * (unsigned)(m * N + (in ? col : 0)));
+                        FB[4 * Ip + v][J] = in ? x : 0.f;
+                    }
+            // ---- Y = V F   (A operand = V by symmetry: register v of tile (I', Im))
+            f32x4 Yd[2][3];
+#pragma unroll
+            for (int Im = 0; Im < 2; ++Im)
+#pragma unroll
+                for (int J = 0; J < 3; ++J) {
+                    f32x4 acc = zero4;
+#pragma unroll
+                    for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc = wv::mfma(Vd[Ip][Im][v], FB[4 * Ip + v][J], acc);
+                    Yd[Im][J] = acc;
+                }
+            // ---- Q = C + F'Y  (A operand = F' = FB, B operand = Y in D layout); tiles (0,2), (1,2) are
+            // not needed below (Qxu is used through Qux)
+#pragma unroll
+            for (int I = 0; I < 3; ++I)
+#pragma unroll
+                for (int J = 0; J < 3; ++J) {
+                    if (J == 2 && I < 2) continue;
+                    f32x4 acc = Qd[I][J];
+#pragma unroll
+                    for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc = wv::mfma(FB[4 * Ip + v][I], Yd[Ip][J][v], acc);
+                    Qd[I][J] = acc;
+                }
+            // ---- q = c_back + F'v
+#pragma unroll
+            for (int J = 0; J < 3; ++J) {
+                float s = 0.f;
+#pragma unroll
+                for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) s = fmaf(FB[4 * Ip + v][J], vcol[Ip][v], s);
+                qrow[J] += sum_q(s);
+            }
+        }
+
+        // ---- Quu (wave-uniform), qu; K = -Quu^-1 Qux, k = -Quu^-1 qu   (:84-94; LDL' for the pinverse)
+        float S[8][8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int c = a; c < 8; ++c) S[a][c] = wv::readlane(Qd[2][2][a & 3], 16 * (a >> 2) + c);
+        Ldl8 fac;
+        ldl8(fac, S);
+        float qu[8], kk[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) qu[a] = wv::readlane(qrow[2], a);
+        ldl8_solve(fac, qu, kk);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) kk[a] = -kk[a];
+        f32x4 Kd[2];                    // K, B layout of the value update: register v of lane (q,r) = K[4q+v][16J+r]
+#pragma unroll
+        for (int J = 0; J < 2; ++J) {
+            float own[4], oth[4], rhs[8], sol[8];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                own[v] = Qd[2][J][v];
+                oth[v] = wv::shfl_xor(own[v], 16);
+            }
+            const bool odd = (L.q & 1) != 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                rhs[v] = odd ? oth[v] : own[v];
+                rhs[4 + v] = odd ? own[v] : oth[v];
+            }
+            ldl8_solve(fac, rhs, sol);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Kd[J][v] = L.q < 2 ? -(odd ? sol[4 + v] : sol[v]) : 0.f;
+            if (L.q < 2) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Kout[(tb * NC + 4 * L.q + v) * NS + 16 * J + L.r] = Kd[J][v];
+            }
+        }
+        if (L.lane < 8) {
+            float kv = kk[0];
+#pragma unroll
+            for (int a = 1; a < 8; ++a) kv = L.lane == a ? kk[a] : kv;
+            kout[tb * NC + L.lane] = kv;
+        }
+
+        // ---- V = Qxx + Qxu K, v = qx + Qxu k   (:155-158 with K'(Qux + Quu K) = 0, K'(qu + Quu k) = 0)
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+                f32x4 acc = Qd[I][J];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc = wv::mfma(Qd[2][I][v], Kd[J][v], acc);
+                Vd[I][J] = acc;
+            }
+        float vrow[2];
+#pragma unroll
+        for (int J = 0; J < 2; ++J) {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float ka = L.q == 0 ? kk[v] : (L.q == 1 ? kk[4 + v] : 0.f);
+                s = fmaf(Qd[2][J][v], ka, s);
+            }
+            vrow[J] = qrow[J] + sum_q(s);
+        }
+        // row -> column layout through the scratch words
+        wv::lds_sync();
+        if (L.q == 0) {
+            wv::lds_store_f32(OFF_SCR + 4u * (unsigned)L.r, vrow[0]);
+            wv::lds_store_f32(OFF_SCR + 64 + 4u * (unsigned)L.r, vrow[1]);
+        }
+        wv::lds_sync();
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            const f32x4 w = wv::lds_f32x4(OFF_SCR + 64u * (unsigned)I + 16u * (unsigned)L.q);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) vcol[I][v] = w[v];
+        }
+        slot = slot + 1 >= NSTAGE ? 0 : slot + 1;
+    }
+    if (L.lane == 0 && p.old_costs) p.old_costs[L.b] = (float)old_cost;
+    if (L.lane == 0 && p.qp_iters) p.qp_iters[L.b] = 0;
+    if (L.lane == 0 && p.status) p.status[L.b] = 0;
+}
+
+}  // namespace mfma40
+}  // namespace mpclqr

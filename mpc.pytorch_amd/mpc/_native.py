@@ -17,7 +17,7 @@ LIB_NAME = "libmpc_lqr_hip.so"
 MPC_F32, MPC_F64 = 0, 1
 BOUND_NONE, BOUND_SCALAR, BOUND_TENSOR = 0, 1, 2
 ST_PNQP_UNCONVERGED, ST_NONFINITE, ST_NOMINAL_OFF_DYNAMICS = 1, 2, 4
-IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA16, IMPL_DPP16, IMPL_TINY = 0, 1, 2, 3, 4
+IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA16, IMPL_DPP16, IMPL_TINY, IMPL_MFMA40 = 0, 1, 2, 3, 4, 5
 
 _vp, _i32, _i64, _f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 

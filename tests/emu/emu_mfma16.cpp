@@ -353,6 +353,7 @@ static inline void fence_own_stores() {}
 
 #include "../../mpc.pytorch_amd/csrc/lqr_mfma16_body.h"
 #include "../../mpc.pytorch_amd/csrc/lqr_dpp16_body.h"
+#include "../../mpc.pytorch_amd/csrc/lqr_mfma40_body.h"
 
 static const mpclqr::StepParams<float> *g_p;
 template <bool FULL> static void body()
@@ -484,4 +485,17 @@ template <typename real> static int tiny_host(const mpc_lqr_problem *p, const mp
 extern "C" int emu_lqr_step_tiny(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out)
 {
     return p->dtype == MPC_F32 ? tiny_host<float>(p, o, out) : tiny_host<double>(p, o, out);
+}
+
+
+// ---- lqr_mfma40_body.h: the n_state = 32, n_ctrl = 8 sweep (one emulated wavefront per problem) ----
+static void body_mfma40() { mpclqr::mfma40::sweep_wave(*g_p, g_p->K, g_p->k); }
+extern "C" int emu_lqr_sweep_mfma40(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out)
+{
+    if (p->dtype != MPC_F32) return MPC_E_DTYPE;
+    mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, out);
+    if (!(sp.ns == 32 && sp.nc == 8) || !sp.K || !sp.k) return MPC_E_DIMS;
+    g_p = &sp;
+    for (int b = 0; b < sp.B; ++b) emu::run_wave(b, body_mfma40);
+    return 0;
 }

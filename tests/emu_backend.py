@@ -23,7 +23,7 @@ def build():
     src = os.path.join(_EMU, "emu_mfma16.cpp")
     csrc = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc")
     deps = [src] + [os.path.join(csrc, h) for h in ("lqr_mfma16_body.h", "lqr_dpp16_body.h", "lqr_small_math.h",
-                                                    "lqr_params.h", "env_dynamics.h", "lqr_tiny_body.h")]
+                                                    "lqr_params.h", "env_dynamics.h", "lqr_tiny_body.h", "lqr_mfma40_body.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         cxx = "/opt/rocm/lib/llvm/bin/clang++"
         if not os.path.exists(cxx):
@@ -109,7 +109,11 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
         e.kind, e.params, e.dt, e.u_max = int(env[0]), _ptr(prm), float(env[2]), float(env[3])
         keep.append(e)
         o.true_dynamics = ctypes.pointer(e)
-    if kernel == "tiny":
+    if kernel == "mfma40_sweep":
+        fn = lib().emu_lqr_sweep_mfma40
+        fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs)]
+        rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
+    elif kernel == "tiny":
         fn = lib().emu_lqr_step_tiny
         fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs)]
         rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))

@@ -348,3 +348,45 @@ def test_tiny_body_rolls_out_through_the_simulator(emu, name, kind):
     np.testing.assert_allclose(r["new_x"], z["step_new_x"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(r["new_u"], z["step_new_u"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(r["costs"], z["step_costs"], rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------
+# The register-resident MFMA sweep (csrc/lqr_mfma40_body.h): n_state = 32, n_ctrl = 8, unconstrained
+# ---------------------------------------------------------------------------------------------
+def _cfg5_problem(rng, T, B):
+    from oracle import lqr_oracle as O
+    ns, nc, n = 32, 8, 40
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A) + 0.1 * np.eye(n)
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((max(T - 1, 0), B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((max(T - 1, 0), B, ns, nc)) / np.sqrt(ns)), 3)
+    f = 0.1 * rng.standard_normal((max(T - 1, 0), B, ns))
+    x_init = rng.standard_normal((B, ns))
+    cur_u = 0.3 * rng.standard_normal((T, B, nc))
+    cur_x, _ = O.traj_cost(x_init, cur_u, F, f)
+    return dict(x_init=x_init, C=C, c=c, F=F, f=f, cur_x=cur_x, cur_u=cur_u)
+
+
+@pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
+@pytest.mark.parametrize("T,B", [(6, 2), (1, 1), (2, 3)])
+def test_emulated_mfma40_sweep_matches_oracle(emu, T, B, dma_late):
+    """Gains and nominal cost of the config-5 sweep: every product on (emulated) MFMA with operands chained
+    through the accumulators, against the oracle, under both LDS-DMA timing extremes."""
+    from oracle import lqr_oracle as O
+    kw = _cfg5_problem(np.random.default_rng(10 * T + B), T, B)
+    o = O.lqr_step(lockstep=False, return_gains=True, **kw)
+    r = emu.lqr_step(kernel="mfma40_sweep", dma_late=dma_late, **kw)
+    np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(r["k"], o["k"], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(r["old_costs"], o["old_costs"], rtol=1e-5)
+
+
+def test_emulated_mfma40_sweep_on_the_reference_fixture(emu):
+    z = golden("step_cfg5_f32")
+    from oracle import lqr_oracle as O
+    kw = step_kwargs(z)
+    o = O.lqr_step(lockstep=False, return_gains=True, **_f64(kw))
+    r = emu.lqr_step(kernel="mfma40_sweep", **{k: v for k, v in kw.items() if k in ("x_init", "C", "c", "F", "f", "cur_x", "cur_u")})
+    np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["k"], o["k"], rtol=1e-3, atol=1e-4)

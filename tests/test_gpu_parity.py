@@ -64,7 +64,7 @@ def impls_for(z):
     ns, nc = int(z["meta"][0]), int(z["meta"][1])
     from mpc import _native
     out = [1]
-    for impl in (_native.IMPL_MFMA16, _native.IMPL_DPP16, _native.IMPL_TINY):
+    for impl in (_native.IMPL_MFMA16, _native.IMPL_DPP16, _native.IMPL_TINY, _native.IMPL_MFMA40):
         if _native.backend().impl_supported(ns, nc, torch.from_numpy(z["C"][:0]).dtype, impl):
             out.append(impl)
     return out
@@ -211,6 +211,31 @@ def test_lane_per_problem_kernel_parallel_line_search(be, ns, max_ls):
         np.testing.assert_allclose(host(r[k]), o[k], rtol=1e-9, atol=1e-10, err_msg=k)
     if max_ls > 2:
         assert len(np.unique(o["alphas"])) >= 2          # different trials win across the batch
+
+
+@pytest.mark.parametrize("T,B", [(12, 7), (1, 2), (64, 3)])
+def test_config5_mfma_sweep(be, T, B):
+    """n_state = 32, n_ctrl = 8, unconstrained, float32: the register-resident MFMA sweep (+ generic rollout)
+    is what `impl = 0` picks; against the oracle in float64 and the generic kernel."""
+    from oracle import lqr_oracle as O
+    from mpc._native import StepOptions, IMPL_MFMA40
+    import bench
+    p = bench.make_problem(32, 8, T, B, torch.float32, DEV, seed=T + B)
+    h = {k: host(v).astype(np.float64) for k, v in p.items()}
+    o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], lockstep=False, return_gains=True)
+    args = (p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions())
+    r5 = be.lqr_step(*args, impl=IMPL_MFMA40, want_gains=True)
+    r0 = be.lqr_step(*args, impl=0)
+    r1 = be.lqr_step(*args, impl=1)
+    torch.cuda.synchronize()
+    for k in ("K", "k", "new_x", "new_u"):
+        np.testing.assert_allclose(host(r5[k]), o[k], rtol=2e-3, atol=5e-4, err_msg=k)
+    np.testing.assert_allclose(host(r5["costs"]), o["costs"], rtol=2e-4)
+    np.testing.assert_allclose(host(r5["old_costs"]), o["old_costs"], rtol=1e-5)
+    assert torch.equal(r0["new_u"], r5["new_u"])                     # auto = the MFMA sweep
+    np.testing.assert_allclose(host(r1["new_u"]), host(r5["new_u"]), rtol=2e-3, atol=5e-4)
+    with pytest.raises(RuntimeError, match="MFMA sweep needs"):
+        be.lqr_step(*args[:-1], StepOptions(u_lower=-1.0, u_upper=1.0), impl=IMPL_MFMA40)
 
 
 @pytest.mark.parametrize("name", ["step_cfg1_f64", "step_masked_f64", "step_ns_bounded_f32", "step_nc1_scalar_f64"])
