@@ -108,15 +108,11 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
         sp.k = (real *)((char *)workspace + needK);
     }
     if constexpr (sizeof(real) == 4) {
-        // n_state = 32, n_ctrl = 8, unconstrained: register-resident MFMA sweep (lqr_mfma40_body.h), then the
-        // generic rollout on its gains
+        // n_state = 32, n_ctrl = 8, unconstrained: register-resident MFMA sweep and rollout (lqr_mfma40_body.h)
         if (impl == 5 && !(phase_mask == 3 && mfma40_supported(sp)))
             return fail(MPC_E_DIMS, "MFMA sweep needs fp32, n_state = 32, n_ctrl = 8, no constraints, 16-byte aligned blocks");
         if (phase_mask == 3 && (impl == 5 || impl == 0) && mfma40_supported(sp)) {
-            int rc = launch_sweep_mfma40(sp, st);
-            if (rc) return rc;
-            sp.old_costs_in = sp.old_costs;
-            return launch_step_generic<real>(sp, 2, st);
+            return launch_step_mfma40(sp, st);
         }
     } else if (impl == 5) {
         return fail(MPC_E_DTYPE, "the MFMA sweep is fp32 only");

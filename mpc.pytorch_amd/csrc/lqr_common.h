@@ -52,6 +52,7 @@ template <typename real> int launch_step_tiny(const StepParams<real> &p, hipStre
 // register-resident MFMA sweep for n_state = 32, n_ctrl = 8, f32, unconstrained (lqr_mfma40.hip)
 bool mfma40_supported(const StepParams<float> &p);
 int launch_sweep_mfma40(const StepParams<float> &p, hipStream_t st);
+int launch_step_mfma40(const StepParams<float> &p, hipStream_t st);
 
 // fused MFMA path for n <= 16, f32 (lqr_mfma16.hip)
 bool mfma16_supported(const StepParams<float> &p);

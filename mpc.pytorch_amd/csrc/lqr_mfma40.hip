@@ -19,7 +19,7 @@ MPC_DEV float rcp(float x)
     float r = __builtin_amdgcn_rcpf(x);
     return fmaf(fmaf(-x, r, 1.f), r, r);     // one Newton step: <= 1 ulp
 }
-#define MPC_MFMA40_LDS (3 * 11904 + 512)
+#define MPC_MFMA40_LDS (3 * 13056 + 512)
 __shared__ __attribute__((aligned(16))) char g_stage40[MPC_MFMA40_LDS];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -34,6 +34,14 @@ MPC_DEV void dma16_if(bool active, const void *g, unsigned off)
 MPC_DEV float lds_f32(unsigned off) { return *(const float *)(g_stage40 + off); }
 MPC_DEV f32x4 lds_f32x4(unsigned off) { return *(const f32x4 *)(g_stage40 + off); }
 MPC_DEV void lds_store_f32(unsigned off, float v) { *(float *)(g_stage40 + off) = v; }
+MPC_DEV void store_f32x4(float *g, f32x4 v) { *(f32x4 *)g = v; }
+MPC_DEV void fence_own_stores()
+{
+    // same-CU visibility of this wave's own global stores (the gains) to its later LDS-DMA reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 // DS instructions of one wave execute in program order: a compiler barrier is all there is to ask for
 MPC_DEV void lds_sync() { asm volatile("" ::: "memory"); }
 // hipcc does not order LDS reads behind an LDS-DMA by itself; this is the ordering point
@@ -52,7 +60,12 @@ namespace {
 
 __global__ void __launch_bounds__(64, 1) lqr_sweep_mfma40_kernel(StepParams<float> p)
 {
-    mfma40::sweep_wave(p, p.K, p.k);
+    (void)mfma40::sweep_wave(p, p.K, p.k);
+}
+
+__global__ void __launch_bounds__(64, 1) lqr_step_mfma40_kernel(StepParams<float> p)
+{
+    mfma40::step_wave(p, p.K, p.k);
 }
 
 }  // namespace
@@ -60,9 +73,27 @@ __global__ void __launch_bounds__(64, 1) lqr_sweep_mfma40_kernel(StepParams<floa
 bool mfma40_supported(const StepParams<float> &p)
 {
     auto al = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
-    return p.ns == 32 && p.nc == 8 && p.T >= 1 && p.bound_mode == MPC_BOUND_NONE && !p.zero_mask && !p.env.kind &&
+    return p.ns == 32 && p.nc == 8 && p.T >= 1 && p.max_ls >= 1 && p.max_ls <= 16 && p.bound_mode == MPC_BOUND_NONE && !p.zero_mask && !p.env.kind &&
            al(p.C) && al(p.c) && (p.T == 1 || al(p.F)) && al(p.cur_x) && al(p.cur_u) && p.C_st % 4 == 0 && p.C_sb % 4 == 0 &&
-           p.c_st % 4 == 0 && p.c_sb % 4 == 0 && p.F_st % 4 == 0 && p.F_sb % 4 == 0;
+           p.c_st % 4 == 0 && p.c_sb % 4 == 0 && p.F_st % 4 == 0 && p.F_sb % 4 == 0 &&
+           (!p.f || (al(p.f) && p.f_st % 4 == 0 && p.f_sb % 4 == 0)) && al(p.x_init);
+}
+
+int launch_step_mfma40(const StepParams<float> &p, hipStream_t st)
+{
+    if (!mfma40_supported(p)) { set_last_error("mfma40: needs fp32, n_state = 32, n_ctrl = 8, unconstrained, 16-byte aligned blocks"); return MPC_E_DIMS; }
+    if (!p.K || !p.k || !p.new_x || !p.new_u) { set_last_error("mfma40: K / k / new_x / new_u missing"); return MPC_E_NULL; }
+    if (((uintptr_t)p.K & 15) || ((uintptr_t)p.k & 15) || ((uintptr_t)p.new_x & 15) || ((uintptr_t)p.new_u & 15)) {
+        set_last_error("mfma40: outputs must be 16-byte aligned");
+        return MPC_E_ARG;
+    }
+    hipLaunchKernelGGL(lqr_step_mfma40_kernel, dim3(p.B), dim3(64), 0, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error((std::string("lqr_step_mfma40_kernel: ") + hipGetErrorString(e)).c_str());
+        return MPC_E_LAUNCH;
+    }
+    return MPC_OK;
 }
 
 int launch_sweep_mfma40(const StepParams<float> &p, hipStream_t st)

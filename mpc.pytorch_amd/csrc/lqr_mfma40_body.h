@@ -35,9 +35,12 @@ using wv::f32x4;
 constexpr int NS = 32, NC = 8, N = 40;
 constexpr int NSTAGE = 3;
 constexpr unsigned OFF_C = 0, OFF_F = 6400, OFF_R = 11520, STAGE_BYTES = 11904;
-constexpr unsigned OFF_SCR = NSTAGE * STAGE_BYTES;          // 512 B: row -> column layout turns
-constexpr unsigned LDS_TOTAL = OFF_SCR + 512;
 constexpr int DMA_PER_STAGE = 13;                           // 7 (C) + 5 (F) + 1 (c | x | u)
+// rollout stage: C | F | K_t (1 KiB) | record (c, x_{t+1}, u_t, f_t, k_t)
+constexpr unsigned ROFF_K = 11520, ROFF_R = 12544, RSTAGE_BYTES = 13056;
+constexpr int RDMA_PER_STAGE = 14;                          // 7 (C) + 5 (F) + 1 (K) + 1 (record)
+constexpr unsigned OFF_SCR = NSTAGE * RSTAGE_BYTES;         // 512 B: row -> column layout turns
+constexpr unsigned LDS_TOTAL = OFF_SCR + 512;
 typedef StepParams<float> P;
 
 struct Lane {
@@ -150,14 +153,14 @@ MPC_DEV void ldl8_solve(const Ldl8 &f, const float rhs[8], float y[8])
 }
 
 // The sweep of one problem: K [T,B,8,32] and k [T,B,8] in the reference layout, old_costs[b].
-MPC_DEV void sweep_wave(const P &p, float *Kout, float *kout)
+MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
 {
     Lane L;
     L.lane = wv::lane();
     L.r = L.lane & 15;
     L.q = L.lane >> 4;
     L.b = wv::problem();
-    if (L.b >= p.B) return;
+    if (L.b >= p.B) return 0.0;
     const int T = p.T;
     Stream d;
     stream_init(d, p, L);
@@ -368,6 +371,251 @@ MPC_DEV void sweep_wave(const P &p, float *Kout, float *kout)
     if (L.lane == 0 && p.old_costs) p.old_costs[L.b] = (float)old_cost;
     if (L.lane == 0 && p.qp_iters) p.qp_iters[L.b] = 0;
     if (L.lane == 0 && p.status) p.status[L.b] = 0;
+    return old_cost;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rollout + line search (mpc/lqr_step.py:164-261, LinDx / QuadCost, no bounds).
+// The state is a 32 x 16 matrix in D layout: column r is the trajectory of the trial alpha = decay^r, so
+// ONE pass prices every candidate of the line search; u' = K dx, x+ = F tau' + f and C tau' are MFMAs whose
+// A operands come straight from LDS and whose outputs are the next operands (same block order trick as
+// the sweep: x block (I',v) <-> 16I'+4q+v, u block v <-> 32+4q+v).  Trial 0 (the usual winner) writes its
+// trajectory as it goes; any other winner is replayed once with its alpha in every column.
+// ---------------------------------------------------------------------------------------------
+struct RStream {
+    const char *c_ptr, *f_ptr, *k_ptr, *r_ptr;
+    long c_step, f_step, k_step, r_step;
+    bool r_active, r_is_f, r_is_x;
+};
+
+MPC_DEV void rstream_init(RStream &d, const P &p, const Lane &L, const float *Kin, const float *kin)
+{
+    const long b = L.b;
+    d.c_ptr = (const char *)(p.C + b * p.C_sb) + 16 * L.lane;
+    d.c_step = p.C_st * 4;
+    d.f_ptr = p.T > 1 ? (const char *)(p.F + b * p.F_sb) + 16 * L.lane : d.c_ptr;
+    d.f_step = p.T > 1 ? p.F_st * 4 : 0;
+    d.k_ptr = (const char *)(Kin + b * (NC * NS)) + 16 * L.lane;
+    d.k_step = (long)p.B * NC * NS * 4;
+    // record: lanes 0..9 c_t | 10..17 x_{t+1} | 18..19 u_t | 20..27 f_t | 28..29 k_t
+    d.r_active = L.lane < 30;
+    d.r_is_f = false;
+    d.r_is_x = false;
+    if (L.lane < 10) {
+        d.r_ptr = (const char *)(p.c + b * p.c_sb) + 16 * L.lane;
+        d.r_step = p.c_st * 4;
+    } else if (L.lane < 18) {
+        d.r_ptr = (const char *)(p.cur_x + b * NS) + 16 * (L.lane - 10);
+        d.r_step = (long)p.B * NS * 4;
+        d.r_is_x = true;
+    } else if (L.lane < 20) {
+        d.r_ptr = (const char *)(p.cur_u + b * NC) + 16 * (L.lane - 18);
+        d.r_step = (long)p.B * NC * 4;
+    } else if (L.lane < 28) {
+        d.r_is_f = true;
+        d.r_active = p.f != nullptr && p.T > 1;
+        d.r_ptr = p.f ? (const char *)(p.f + b * p.f_sb) + 16 * (L.lane - 20) : d.c_ptr;
+        d.r_step = p.f_st * 4;
+    } else {
+        d.r_ptr = (const char *)(kin + b * NC) + 16 * ((L.lane < 30 ? L.lane : 28) - 28);
+        d.r_step = (long)p.B * NC * 4;
+    }
+}
+
+MPC_DEV void rstage_issue(const P &p, const RStream &d, const Lane &L, int t, int slot)
+{
+    const unsigned base = (unsigned)slot * RSTAGE_BYTES;
+    const long tl = t;
+    const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);      // F, f have T-1 entries
+    const long tx = t + 1 < p.T ? t + 1 : t;                         // x_{t+1}
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wv::dma16(d.c_ptr + tl * d.c_step + 1024 * k, base + OFF_C + 1024 * k);
+    wv::dma16_if(L.lane < 16, d.c_ptr + tl * d.c_step + 6144, base + OFF_C + 6144);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) wv::dma16(d.f_ptr + tf * d.f_step + 1024 * k, base + OFF_F + 1024 * k);
+    wv::dma16(d.k_ptr + tl * d.k_step, base + ROFF_K);
+    wv::dma16_if(d.r_active, d.r_ptr + (d.r_is_f ? tf : (d.r_is_x ? tx : tl)) * d.r_step, base + ROFF_R);
+}
+
+// One pass over the horizon.  alpha: this lane's (= its column's) step size.  Returns the column's cost and
+// squared control change in every lane of the column.
+MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alpha, bool store, double &cost, float &du2)
+{
+    const int T = p.T;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 Xd[2], DXd[2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Xd[I][v] = p.x_init[(long)L.b * NS + 16 * I + 4 * L.q + v];
+        DXd[I] = zero4;
+        if (store && L.r == 0) wv::store_f32x4(p.new_x + (long)L.b * NS + 16 * I + 4 * L.q, Xd[I]);
+    }
+    double cacc = 0.0;
+    float dacc = 0.f;
+    wv::dma_wait<0>();          // nothing of the sweep / the previous pass may still land in the ring
+    rstage_issue(p, d, L, 0, 0);
+    rstage_issue(p, d, L, 1 < T ? 1 : T - 1, 1);
+    int slot = 0;
+    for (int t = 0; t < T; ++t) {
+        rstage_issue(p, d, L, t + 2 < T ? t + 2 : T - 1, slot + 2 >= NSTAGE ? slot + 2 - NSTAGE : slot + 2);
+        wv::dma_wait<2 * RDMA_PER_STAGE>();
+        const unsigned base = (unsigned)slot * RSTAGE_BYTES;
+        const long tb = (long)t * p.B + L.b;
+        const unsigned rec = base + ROFF_R;
+        // ---- u' = K dx + u + alpha k   (:192)
+        f32x4 Ud = zero4;
+#pragma unroll
+        for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float a = wv::lds_f32(base + ROFF_K + 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 16 * Ip + 4 * L.q + v));
+                Ud = wv::mfma(L.r < NC ? a : 0.f, DXd[Ip][v], Ud);
+            }
+        {
+            const unsigned qo = 16u * (unsigned)(L.q < 2 ? L.q : 0);
+            const f32x4 ub = wv::lds_f32x4(rec + 288 + qo), kb = wv::lds_f32x4(rec + 448 + qo);
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float un = L.q < 2 ? Ud[v] + ub[v] + alpha * kb[v] : 0.f;
+                const float dd = L.q < 2 ? ub[v] - un : 0.f;
+                Ud[v] = un;
+                s = fmaf(dd, dd, s);
+            }
+            dacc += s;
+            if (store && L.r == 0 && L.q < 2) wv::store_f32x4(p.new_u + tb * NC + 4 * L.q, Ud);
+        }
+        // ---- stage cost 0.5 tau'C tau + c'tau   (:230-232); C tau' on MFMA (C read through its symmetry)
+        {
+            float part = 0.f;
+#pragma unroll
+            for (int I = 0; I < 3; ++I) {
+                f32x4 G = zero4;
+                const int col = 16 * I + L.r;
+                const bool cin = col < N;
+#pragma unroll
+                for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float a = wv::lds_f32(base + OFF_C + 4u * (unsigned)((16 * Ip + 4 * L.q + v) * N + (cin ? col : 0)));
+                        G = wv::mfma(cin ? a : 0.f, Xd[Ip][v], G);
+                    }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const bool in = cin && L.q < 2;
+                    const float a = wv::lds_f32(base + OFF_C + 4u * (unsigned)((in ? 32 + 4 * L.q + v : 0) * N + (cin ? col : 0)));
+                    G = wv::mfma(in ? a : 0.f, Ud[v], G);
+                }
+                // rows 16I + 4q + v of (C tau') against the same entries of tau' and c
+                const bool rin = I < 2 || L.q < 2;
+                const f32x4 cv = wv::lds_f32x4(rec + 4u * (unsigned)(rin ? 16 * I + 4 * L.q : 0));
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float tv = I < 2 ? Xd[I][v] : Ud[v];
+                    part = fmaf(rin ? tv : 0.f, fmaf(0.5f, G[v], cv[v]), part);
+                }
+            }
+            cacc += (double)part;
+        }
+        // ---- x+ = F tau' + f   (:216-222)
+        if (t < T - 1) {
+            const long tb1 = (long)(t + 1) * p.B + L.b;
+#pragma unroll
+            for (int Im = 0; Im < 2; ++Im) {
+                f32x4 acc = zero4;
+                if (p.f) acc = wv::lds_f32x4(rec + 320 + 4u * (unsigned)(16 * Im + 4 * L.q));
+                const int row = 16 * Im + L.r;
+#pragma unroll
+                for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float a = wv::lds_f32(base + OFF_F + 4u * (unsigned)(row * N + 16 * Ip + 4 * L.q + v));
+                        acc = wv::mfma(a, Xd[Ip][v], acc);
+                    }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float a = wv::lds_f32(base + OFF_F + 4u * (unsigned)(row * N + (L.q < 2 ? 32 + 4 * L.q + v : 0)));
+                    acc = wv::mfma(L.q < 2 ? a : 0.f, Ud[v], acc);
+                }
+                if (store && L.r == 0) wv::store_f32x4(p.new_x + tb1 * NS + 16 * Im + 4 * L.q, acc);
+                DXd[Im] = acc;      // parked here until both tiles are done (the second product still reads Xd)
+            }
+#pragma unroll
+            for (int Im = 0; Im < 2; ++Im) {
+                const f32x4 xb = wv::lds_f32x4(rec + 160 + 4u * (unsigned)(16 * Im + 4 * L.q));
+                Xd[Im] = DXd[Im];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) DXd[Im][v] = Xd[Im][v] - xb[v];
+            }
+        }
+        slot = slot + 1 >= NSTAGE ? 0 : slot + 1;
+    }
+    // column totals: the four lane groups hold disjoint rows
+    double c2 = cacc;
+    {
+        const float hi = (float)c2, lo = (float)(c2 - (double)hi);
+        const double o1 = (double)wv::shfl_xor(hi, 16) + (double)wv::shfl_xor(lo, 16);
+        c2 += o1;
+        const float hi2 = (float)c2, lo2 = (float)(c2 - (double)hi2);
+        c2 += (double)wv::shfl_xor(hi2, 32) + (double)wv::shfl_xor(lo2, 32);
+    }
+    cost = c2;
+    du2 = sum_q(dacc);
+}
+
+MPC_DEV void rollout_wave(const P &p, const float *Kin, const float *kin, double old_cost)
+{
+    Lane L;
+    L.lane = wv::lane();
+    L.r = L.lane & 15;
+    L.q = L.lane >> 4;
+    L.b = wv::problem();
+    if (L.b >= p.B) return;
+    RStream d;
+    rstream_init(d, p, L, Kin, kin);
+    float alpha = 1.f;
+    for (int i = 0; i < L.r; ++i) alpha *= p.ls_decay;            // column r tries decay^r
+    double cost;
+    float du2;
+    rollout_pass(p, d, L, alpha, true, cost, du2);
+    // first trial that is not worse than the nominal, else the last one (:176-179, 247)
+    int win = p.max_ls - 1;
+    for (int j = p.max_ls - 1; j >= 0; --j) {
+        const float cj_hi = wv::readlane((float)cost, j);
+        const double cj = (double)cj_hi + (double)wv::readlane((float)(cost - (double)(float)cost), j);
+        if (!(cj > old_cost)) win = j;
+    }
+    const float full2 = wv::readlane(du2, 0);
+    float win_alpha = 1.f;
+    for (int i = 0; i < win; ++i) win_alpha *= p.ls_decay;
+    double win_cost;
+    float win_du2;
+    if (win != 0) {
+        rollout_pass(p, d, L, win_alpha, true, win_cost, win_du2);
+    } else {
+        win_cost = cost;
+        win_du2 = du2;
+    }
+    const float wc_hi = wv::readlane((float)win_cost, 0);
+    const double wc = (double)wc_hi + (double)wv::readlane((float)(win_cost - (double)(float)win_cost), 0);
+    const float wd = wv::readlane(win_du2, 0);
+    if (L.lane == 0) {
+        int status = 0;
+        if (!(wc == wc) || fabs(wc) > 3e38) status |= MPC_ST_NONFINITE;
+        if (p.costs) p.costs[L.b] = (float)wc;
+        if (p.full_du_norm) p.full_du_norm[L.b] = sqrtf(full2);
+        if (p.alpha_du_norm) p.alpha_du_norm[L.b] = sqrtf(wd);
+        if (p.alphas) p.alphas[L.b] = win_alpha;
+        if (p.status) p.status[L.b] |= status;
+    }
+}
+
+MPC_DEV void step_wave(const P &p, float *K, float *k)
+{
+    const double old_cost = sweep_wave(p, K, k);
+    wv::fence_own_stores();
+    rollout_wave(p, K, k, old_cost);
 }
 
 }  // namespace mfma40

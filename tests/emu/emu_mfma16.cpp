@@ -34,7 +34,7 @@ struct Wave {
     int ia[2][NL];
     unsigned seq[NL];
     // LDS of the (single-wave) workgroup + the in-order queue of LDS-DMA instructions in flight
-    unsigned char lds[4 * 9216];            // the larger of the two kernels' rings
+    unsigned char lds[3 * 13056 + 512];     // the largest of the kernels' rings
     struct Dma { unsigned char data[NL][16]; bool act[NL]; unsigned char seen[NL]; unsigned off; int size; };
     Dma q[64];
     int qn;
@@ -489,7 +489,13 @@ extern "C" int emu_lqr_step_tiny(const mpc_lqr_problem *p, const mpc_lqr_options
 
 
 // ---- lqr_mfma40_body.h: the n_state = 32, n_ctrl = 8 sweep (one emulated wavefront per problem) ----
-static void body_mfma40() { mpclqr::mfma40::sweep_wave(*g_p, g_p->K, g_p->k); }
+static int g_m40_full = 0;
+static void body_mfma40()
+{
+    if (g_m40_full) mpclqr::mfma40::step_wave(*g_p, g_p->K, g_p->k);
+    else (void)mpclqr::mfma40::sweep_wave(*g_p, g_p->K, g_p->k);
+}
+extern "C" void emu_mfma40_full(int full) { g_m40_full = full; }
 extern "C" int emu_lqr_sweep_mfma40(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out)
 {
     if (p->dtype != MPC_F32) return MPC_E_DTYPE;

@@ -109,7 +109,8 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
         e.kind, e.params, e.dt, e.u_max = int(env[0]), _ptr(prm), float(env[2]), float(env[3])
         keep.append(e)
         o.true_dynamics = ctypes.pointer(e)
-    if kernel == "mfma40_sweep":
+    if kernel in ("mfma40_sweep", "mfma40"):
+        lib().emu_mfma40_full(int(kernel == "mfma40"))
         fn = lib().emu_lqr_sweep_mfma40
         fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs)]
         rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))

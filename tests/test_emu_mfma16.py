@@ -390,3 +390,37 @@ def test_emulated_mfma40_sweep_on_the_reference_fixture(emu):
     r = emu.lqr_step(kernel="mfma40_sweep", **{k: v for k, v in kw.items() if k in ("x_init", "C", "c", "F", "f", "cur_x", "cur_u")})
     np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(r["k"], o["k"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
+@pytest.mark.parametrize("case", ["plain", "T1", "no_f", "backtrack", "backtrack_ls3"])
+def test_emulated_mfma40_full_step(emu, case, dma_late):
+    """Sweep + rollout of the config-5 kernel: the 16 columns of the rolled-out state are the line-search
+    trials (alpha = decay^r); a non-convex stage cost makes trials other than the first win, which are then
+    replayed.  Against the oracle."""
+    from oracle import lqr_oracle as O
+    T, B = (1, 2) if case == "T1" else (6, 3)
+    for attempt in range(30):
+        rng = np.random.default_rng(50 + len(case) + 1000 * attempt)
+        kw = _cfg5_problem(rng, T, B)
+        if case == "no_f":
+            kw["f"] = None
+            kw["cur_x"], _ = O.traj_cost(kw["x_init"], kw["cur_u"], kw["F"], None)
+        if case.startswith("backtrack"):
+            kw["C"][:, :, :32, :32] -= 45.0 * np.eye(32)
+        opt = dict(linesearch_decay=0.5, max_linesearch_iter=3 if case.endswith("ls3") else 10)
+        o = O.lqr_step(lockstep=False, **kw, **opt)
+        if not case.startswith("backtrack") or (o["alphas"] < 1).any():
+            break
+    else:
+        assert False, "no seed made the line search backtrack"
+    r = emu.lqr_step(kernel="mfma40", dma_late=dma_late, **kw, **opt)
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+    # the non-convex problems are ill-conditioned on purpose (gains of order 10^2): float32 keeps ~3 digits there
+    wide = 20.0 if case.startswith("backtrack") else 1.0
+    np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=2e-3 * wide, atol=2e-4 * wide * (1 + np.abs(o["new_x"]).max()))
+    np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=2e-3 * wide, atol=2e-4 * wide * (1 + np.abs(o["new_u"]).max()))
+    np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4 * wide, atol=1e-3)
+    np.testing.assert_allclose(r["old_costs"], o["old_costs"], rtol=1e-5)
+    np.testing.assert_allclose(r["full_du_norm"], o["full_du_norm"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["alpha_du_norm"], o["alpha_du_norm"], rtol=1e-3, atol=1e-4)

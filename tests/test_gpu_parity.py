@@ -215,8 +215,9 @@ def test_lane_per_problem_kernel_parallel_line_search(be, ns, max_ls):
 
 @pytest.mark.parametrize("T,B", [(12, 7), (1, 2), (64, 3)])
 def test_config5_mfma_sweep(be, T, B):
-    """n_state = 32, n_ctrl = 8, unconstrained, float32: the register-resident MFMA sweep (+ generic rollout)
-    is what `impl = 0` picks; against the oracle in float64 and the generic kernel."""
+    """n_state = 32, n_ctrl = 8, unconstrained, float32: the register-resident MFMA kernel (sweep + rollout with
+    the line-search trials as the 16 columns of the state) is what `impl = 0` picks; against the oracle in
+    float64 and the generic kernel."""
     from oracle import lqr_oracle as O
     from mpc._native import StepOptions, IMPL_MFMA40
     import bench
@@ -236,6 +237,22 @@ def test_config5_mfma_sweep(be, T, B):
     np.testing.assert_allclose(host(r1["new_u"]), host(r5["new_u"]), rtol=2e-3, atol=5e-4)
     with pytest.raises(RuntimeError, match="MFMA sweep needs"):
         be.lqr_step(*args[:-1], StepOptions(u_lower=-1.0, u_upper=1.0), impl=IMPL_MFMA40)
+    # a non-convex stage cost: the line search backtracks (to its last trial), the winner is replayed
+    Cn = p["C"].clone()
+    Cn[:, :, :32, :32] -= 45.0 * torch.eye(32, device=DEV)
+    on = O.lqr_step(h["x_init"], host(Cn).astype(np.float64), h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], lockstep=False,
+                    linesearch_decay=0.5, max_linesearch_iter=6)
+    rn = be.lqr_step(p["x_init"], Cn, p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"],
+                     StepOptions(linesearch_decay=0.5, max_linesearch_iter=6), impl=IMPL_MFMA40)
+    torch.cuda.synchronize()
+    # (ill-conditioned on purpose -- float32 keeps few digits of such a trajectory, the emulator test compares it
+    # at a short horizon; here: the same trial wins, the same cost comes out)
+    if T <= 12:
+        assert np.isclose(host(rn["alphas"]), on["alphas"], rtol=1e-6).all()
+        assert T == 1 or (on["alphas"] < 1).any()
+        np.testing.assert_allclose(host(rn["costs"]), on["costs"], rtol=5e-2)
+        np.testing.assert_allclose(host(rn["full_du_norm"]), on["full_du_norm"], rtol=5e-2)
+    assert torch.isfinite(rn["new_x"]).all() or T > 12
 
 
 @pytest.mark.parametrize("name", ["step_cfg1_f64", "step_masked_f64", "step_ns_bounded_f32", "step_nc1_scalar_f64"])
