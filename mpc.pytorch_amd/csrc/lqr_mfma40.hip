@@ -1,6 +1,6 @@
 // lqr_mfma40.hip -- gfx950 binding of the register-resident MFMA sweep for n_state = 32, n_ctrl = 8
-// (lqr_mfma40_body.h): one wavefront per problem and per workgroup, a 3-slot LDS-DMA ring (35 KiB),
-// 4 wavefronts per CU.
+// (lqr_mfma40_body.h): one wavefront per problem and per workgroup, a 2-slot LDS-DMA ring (26 KiB),
+// up to 6 wavefronts per CU.
 #include <string>
 #include "lqr_common.h"
 
@@ -19,7 +19,7 @@ MPC_DEV float rcp(float x)
     float r = __builtin_amdgcn_rcpf(x);
     return fmaf(fmaf(-x, r, 1.f), r, r);     // one Newton step: <= 1 ulp
 }
-#define MPC_MFMA40_LDS (3 * 13056 + 512)
+#define MPC_MFMA40_LDS (2 * 13056 + 512)
 __shared__ __attribute__((aligned(16))) char g_stage40[MPC_MFMA40_LDS];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;

@@ -33,7 +33,7 @@ namespace mfma40 {
 
 using wv::f32x4;
 constexpr int NS = 32, NC = 8, N = 40;
-constexpr int NSTAGE = 3;
+constexpr int NSTAGE = 2;      // slots of the LDS-DMA ring: one step in flight (27 KiB per wave -> 6 waves per CU)
 constexpr unsigned OFF_C = 0, OFF_F = 6400, OFF_R = 11520, STAGE_BYTES = 11904;
 constexpr int DMA_PER_STAGE = 13;                           // 7 (C) + 5 (F) + 1 (c | x | u)
 // rollout stage: C | F | K_t (1 KiB) | record (c, x_{t+1}, u_t, f_t, k_t)
@@ -177,12 +177,11 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
     double old_cost = 0.0;
 
     stage_issue(p, d, L, T - 1, 0);
-    stage_issue(p, d, L, T - 2 >= 0 ? T - 2 : 0, 1);
     int slot = 0;
     for (int t = T - 1; t >= 0; --t) {
-        // keep two timesteps in flight (re-loading step 0 at the tail keeps the wait count fixed)
-        stage_issue(p, d, L, t - 2 >= 0 ? t - 2 : 0, slot + 2 >= NSTAGE ? slot + 2 - NSTAGE : slot + 2);
-        wv::dma_wait<2 * DMA_PER_STAGE>();
+        // keep the next timestep in flight (re-loading step 0 at the tail keeps the wait count fixed)
+        stage_issue(p, d, L, t - 1 >= 0 ? t - 1 : 0, slot ^ 1);
+        wv::dma_wait<DMA_PER_STAGE>();
         const unsigned base = (unsigned)slot * STAGE_BYTES;
         const long tb = (long)t * p.B + L.b;
 
@@ -366,7 +365,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
 #pragma unroll
             for (int v = 0; v < 4; ++v) vcol[I][v] = w[v];
         }
-        slot = slot + 1 >= NSTAGE ? 0 : slot + 1;
+        slot ^= 1;
     }
     if (L.lane == 0 && p.old_costs) p.old_costs[L.b] = (float)old_cost;
     if (L.lane == 0 && p.qp_iters) p.qp_iters[L.b] = 0;
@@ -455,11 +454,10 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
     float dacc = 0.f;
     wv::dma_wait<0>();          // nothing of the sweep / the previous pass may still land in the ring
     rstage_issue(p, d, L, 0, 0);
-    rstage_issue(p, d, L, 1 < T ? 1 : T - 1, 1);
     int slot = 0;
     for (int t = 0; t < T; ++t) {
-        rstage_issue(p, d, L, t + 2 < T ? t + 2 : T - 1, slot + 2 >= NSTAGE ? slot + 2 - NSTAGE : slot + 2);
-        wv::dma_wait<2 * RDMA_PER_STAGE>();
+        rstage_issue(p, d, L, t + 1 < T ? t + 1 : T - 1, slot ^ 1);
+        wv::dma_wait<RDMA_PER_STAGE>();
         const unsigned base = (unsigned)slot * RSTAGE_BYTES;
         const long tb = (long)t * p.B + L.b;
         const unsigned rec = base + ROFF_R;
@@ -549,7 +547,7 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
                 for (int v = 0; v < 4; ++v) DXd[Im][v] = Xd[Im][v] - xb[v];
             }
         }
-        slot = slot + 1 >= NSTAGE ? 0 : slot + 1;
+        slot ^= 1;
     }
     // column totals: the four lane groups hold disjoint rows
     double c2 = cacc;
