@@ -1,0 +1,187 @@
+// kkt_wave.hip -- the closed-form part of LQRStepFn.backward (mpc/lqr_step.py:346-404) for fp32 problems
+// with n = n_state + n_ctrl <= 64, split where the arithmetic splits:
+//
+//   kkt_costate_kernel   the two costate recursions (:355-385), sequential in t: one wavefront per problem,
+//                        lane i owns state i; C and F are read column-wise ((C tau)[i] = sum_j C[j][i] tau[j]
+//                        by symmetry, (Fx' lam)[i] = sum_m F[m][i] lam[m]): conflict-free LDS reads of blocks
+//                        that arrive by LDS-DMA one step ahead; tau[j] / lam[m] reach the lanes as readlanes.
+//                        lam_{t+1}, dlam_{t+1} are parked in the first 2 n_state words of the dF_t block.
+//   kkt_outer_kernel     dC_t, dc_t, dF_t (:346-353, :387-400): independent over (t, b), one wavefront each,
+//                        16 bytes per lane, every output byte written exactly once and fully coalesced
+//                        (the block first picks its two costates out of its own dF_t block).
+//
+// The generic kernel (lqr_generic.hip) does the same with one workgroup per problem and LDS-staged blocks;
+// at n = 40 it spends 0.86 ms on what is 1.5 GB of compulsory traffic.
+#include <string>
+#include "lqr_common.h"
+
+namespace mpclqr {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float lane_bcast(float x, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// HBM -> LDS, 16 bytes per lane, `bytes` contiguous bytes (a multiple of 16) starting at g
+__device__ __forceinline__ void dma_block(const float *g, char *lds, int bytes, int lane)
+{
+    for (int off = 0; off < bytes; off += 1024)
+        if (off + 16 * lane < bytes)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)((const char *)g + off + 16 * lane),
+                                             (lds_void_t *)(lds + off), 16, 0, 0);
+}
+
+__global__ void __launch_bounds__(64) kkt_costate_kernel(StepParams<float> p, const float *dx, const float *du,
+                                                         const float *dl_dx, float *dF, float *df, float *dx_init)
+{
+    // two slots of [C_t | F_t]; the block of step t-1 streams in while step t is summed
+    extern __shared__ __attribute__((aligned(16))) char kkt_lds[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T, B = p.B;
+    const int cbytes = n * n * 4, fbytes = ns * n * 4, slot_bytes = cbytes + fbytes;
+    const bool st = lane < ns;
+    const int li = st ? lane : 0;
+    auto issue = [&](int t, int slot) {
+        char *base = kkt_lds + slot * slot_bytes;
+        dma_block(p.C + (long)t * p.C_st + (long)b * p.C_sb, base, cbytes, lane);
+        if (t < T - 1) dma_block(p.F + (long)t * p.F_st + (long)b * p.F_sb, base + cbytes, fbytes, lane);
+    };
+    auto vectors = [&](int t, float &tau, float &d, float &cc, float &gx) {
+        const long tb = (long)t * B + b;
+        tau = 0.f; d = 0.f;
+        if (lane < ns) { tau = p.cur_x[tb * ns + lane]; d = dx[tb * ns + lane]; }
+        else if (lane < n) { tau = p.cur_u[tb * nc + (lane - ns)]; d = du[tb * nc + (lane - ns)]; }
+        cc = st ? p.c[(long)t * p.c_st + (long)b * p.c_sb + lane] : 0.f;
+        gx = st ? dl_dx[tb * ns + lane] : 0.f;
+    };
+    float lam = 0.f, dlam = 0.f;
+    float tau, d, cc, gx;
+    issue(T - 1, 0);
+    vectors(T - 1, tau, d, cc, gx);
+    int slot = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        // everything in flight is the stage of step t (and parked stores): wait, then start step t-1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float tau_n = 0.f, d_n = 0.f, cc_n = 0.f, gx_n = 0.f;
+        if (t > 0) {
+            issue(t - 1, slot ^ 1);
+            vectors(t - 1, tau_n, d_n, cc_n, gx_n);
+        }
+        const long tb = (long)t * B + b;
+        const float *Cl = (const float *)(kkt_lds + slot * slot_bytes);
+        const float *Fl = (const float *)(kkt_lds + slot * slot_bytes + cbytes);
+        float r1 = cc, r2 = -gx;
+        // (C tau)[i], (C dtau)[i] for the state rows, through column i of the symmetric C
+        for (int j = 0; j < n; j += 4) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float cj = Cl[(j + v) * n + li];
+                r1 = fmaf(cj, lane_bcast(tau, j + v), r1);
+                r2 = fmaf(cj, lane_bcast(d, j + v), r2);
+            }
+        }
+        if (t < T - 1) {
+            for (int m = 0; m < ns; m += 4) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float fm = Fl[(m + v) * n + li];
+                    r1 = fmaf(fm, lane_bcast(lam, m + v), r1);
+                    r2 = fmaf(fm, lane_bcast(dlam, m + v), r2);
+                }
+            }
+            if (st) {
+                float *park = dF + tb * (long)(ns * n);
+                park[lane] = lam;
+                park[ns + lane] = dlam;
+                if (df) df[tb * ns + lane] = -dlam;                               // :397-400
+            }
+        }
+        lam = r1;
+        dlam = r2;
+        tau = tau_n; d = d_n; cc = cc_n; gx = gx_n;
+        slot ^= 1;
+    }
+    if (st) dx_init[(long)b * ns + lane] = -dlam;                                 // :404
+}
+
+__global__ void __launch_bounds__(64) kkt_outer_kernel(StepParams<float> p, const float *dx, const float *du, float *dC,
+                                                       float *dc, float *dF)
+{
+    __shared__ __attribute__((aligned(16))) float sv[4][64];       // tau, dtau, lam_{t+1}, dlam_{t+1}
+    const long tb = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T, B = p.B;
+    const int t = (int)(tb / B);
+    const bool have = t < T - 1;
+    float tau = 0.f, d = 0.f;
+    if (lane < ns) { tau = p.cur_x[tb * ns + lane]; d = dx[tb * ns + lane]; }
+    else if (lane < n) { tau = p.cur_u[tb * nc + (lane - ns)]; d = du[tb * nc + (lane - ns)]; }
+    sv[0][lane] = tau;
+    sv[1][lane] = d;
+    float *dFt = dF + tb * (long)(ns * n);
+    if (have && lane < ns) {
+        sv[2][lane] = dFt[lane];
+        sv[3][lane] = dFt[ns + lane];
+    }
+    __syncthreads();
+    if (lane < n) dc[tb * n + lane] = -d;                                         // :352-353
+    // dC_t = -0.5 (dtau tau' + tau dtau')   (:346-351), four consecutive columns per lane
+    float *dCt = dC + tb * (long)(n * n);
+    for (int e = 4 * lane; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        const float di = sv[1][i], ti = sv[0][i];
+        const f32x4 tj = *(const f32x4 *)&sv[0][j], dj = *(const f32x4 *)&sv[1][j];
+        f32x4 o;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o[v] = -0.5f * fmaf(di, tj[v], ti * dj[v]);
+        *(f32x4 *)(dCt + e) = o;
+    }
+    // dF_t = -(dlam_{t+1} tau' + lam_{t+1} dtau')   (:387-396)
+    if (have) {
+        for (int e = 4 * lane; e < ns * n; e += 256) {
+            const int i = e / n, j = e - i * n;
+            const float li = sv[2][i], dli = sv[3][i];
+            const f32x4 tj = *(const f32x4 *)&sv[0][j], dj = *(const f32x4 *)&sv[1][j];
+            f32x4 o;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) o[v] = -fmaf(dli, tj[v], li * dj[v]);
+            *(f32x4 *)(dFt + e) = o;
+        }
+    }
+}
+
+}  // namespace
+
+bool kkt_wave_supported(const StepParams<float> &p, const float *dC, const float *dF)
+{
+    const int n = p.ns + p.nc;
+    auto al = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+    return n <= 64 && n % 4 == 0 && p.ns % 4 == 0 && p.ns * n >= 2 * p.ns && p.B > 0 && al(p.C) && (p.T == 1 || al(p.F)) &&
+           p.C_st % 4 == 0 && p.C_sb % 4 == 0 && p.F_st % 4 == 0 && p.F_sb % 4 == 0 &&
+           ((uintptr_t)dC & 15) == 0 && (p.T == 1 || ((uintptr_t)dF & 15) == 0);
+}
+
+int launch_kkt_wave(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,
+                    float *dc, float *dF, float *df, float *dx_init, hipStream_t st)
+{
+    const int n = p.ns + p.nc;
+    const size_t lds = 2 * (size_t)(n * n + p.ns * n) * 4;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_costate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kkt_costate_kernel, dim3(p.B), dim3(64), lds, st, p, dx, du, dl_dx, dF, df, dx_init);
+    hipLaunchKernelGGL(kkt_outer_kernel, dim3((unsigned)((long)p.T * p.B)), dim3(64), 0, st, p, dx, du, dC, dc, dF);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error((std::string("kkt_wave kernels: ") + hipGetErrorString(e)).c_str());
+        return MPC_E_LAUNCH;
+    }
+    return MPC_OK;
+}
+
+}  // namespace mpclqr

@@ -49,6 +49,11 @@ int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *d
 bool tiny_supported(int ns, int nc);
 template <typename real> int launch_step_tiny(const StepParams<real> &p, hipStream_t st);
 
+// costate + outer-product kernels of the KKT backward for n <= 64, f32 (kkt_wave.hip)
+bool kkt_wave_supported(const StepParams<float> &p, const float *dC, const float *dF);
+int launch_kkt_wave(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,
+                    float *dc, float *dF, float *df, float *dx_init, hipStream_t st);
+
 // register-resident MFMA sweep for n_state = 32, n_ctrl = 8, f32, unconstrained (lqr_mfma40.hip)
 bool mfma40_supported(const StepParams<float> &p);
 int launch_sweep_mfma40(const StepParams<float> &p, hipStream_t st);

@@ -318,6 +318,37 @@ def test_kkt_backward_parity(be, name):
         np.testing.assert_allclose(host(g[k]) / scale, z[k] / scale, rtol=0, atol=1e-10 if f64 else 5e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("ns,nc,T,B", [(32, 8, 9, 5), (20, 4, 6, 3), (8, 4, 5, 2), (32, 8, 1, 2), (60, 4, 3, 2)])
+@pytest.mark.parametrize("with_f,bounded", [(True, False), (False, True)])
+def test_kkt_backward_wave_kernels(be, ns, nc, T, B, with_f, bounded):
+    """float32 shapes up to n = 64 (config 5 among them): the costate recursion per wavefront + the fully
+    parallel outer-product kernel, through the whole backward (prepare, nested solve, gradients), against the
+    oracle in float64."""
+    from oracle import lqr_oracle as O
+    from mpc._native import StepOptions
+    import bench
+    p = bench.make_problem(ns, nc, T, B, torch.float32, DEV, seed=ns + T, u_scale=0.3 if bounded else 0.0, clamp=0.5 if bounded else None)
+    f = p["f"] if with_f else None
+    opts = StepOptions(u_lower=-0.5, u_upper=0.5) if bounded else StepOptions()
+    if not with_f:
+        from mpc import util
+        from mpc.mpc import LinDx
+        p["cur_x"] = util.get_traj(T, p["cur_u"], p["x_init"], LinDx(p["F"], None))
+    r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], f, p["cur_x"], p["cur_u"], opts)
+    gx, gu = torch.randn_like(r["new_x"]), torch.randn_like(r["new_u"])
+    g = be.kkt_backward(p["C"], p["c"], p["F"], f, r["new_x"], r["new_u"], gx, gu, opts)
+    torch.cuda.synchronize()
+    h = lambda t: None if t is None else host(t).astype(np.float64)
+    o = O.kkt_backward(h(p["C"]), h(p["c"]), h(p["F"]), h(f), h(r["new_x"]), h(r["new_u"]), h(gx), h(gu),
+                       -0.5 if bounded else None, 0.5 if bounded else None, lockstep=False)
+    for k in ("dx_init", "dC", "dc", "dF", "df"):
+        if o[k] is None or o[k].size == 0:
+            assert g[k] is None or g[k].numel() == 0
+            continue
+        scale = max(1.0, np.abs(o[k]).max())
+        np.testing.assert_allclose(host(g[k]) / scale, o[k] / scale, rtol=0, atol=2e-4, err_msg=k)
+
+
 @pytest.mark.parametrize("name", ["jac_unconstrained", "jac_constrained"])
 def test_autograd_jacobians_on_gpu(be, name):
     """tests/test_mpc.py:303-500 end to end on the device: MPC.forward + autograd."""
