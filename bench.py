@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- LQR problem-steps/s of the MI355X LQR step at BASELINE.json's headline workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--bounded] [--impl {0,1,2}]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--bounded] [--impl {0,1,2,3}]
 
 Workload (configs[3] of BASELINE.json, the one `metric` is quoted on): synthetic random linear
 dynamics, n_state=12, n_ctrl=4, T=50, batch=4096 PER GPU, fp32, contiguous time-major tensors
