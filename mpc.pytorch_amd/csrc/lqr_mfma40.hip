@@ -14,6 +14,14 @@ MPC_DEV int problem() { return (int)blockIdx.x; }
 MPC_DEV f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 MPC_DEV float readlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 MPC_DEV float shfl_xor(float x, int m) { return __shfl_xor(x, m, 64); }
+// sum over the four 16-lane rows, result in every lane: two row swaps (gfx950 v_permlane{16,32}_swap), no LDS
+MPC_DEV float sum_rows(float x)
+{
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 MPC_DEV float rcp(float x)
 {
     float r = __builtin_amdgcn_rcpf(x);

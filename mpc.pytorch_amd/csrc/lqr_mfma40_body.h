@@ -89,12 +89,7 @@ MPC_DEV void stage_issue(const P &p, const Stream &d, const Lane &L, int t, int 
 }
 
 // butterfly sums: across the four lane groups (lanes differing in bits 4,5), across the 16 lanes of a group
-MPC_DEV float sum_q(float x)
-{
-    x += wv::shfl_xor(x, 16);
-    x += wv::shfl_xor(x, 32);
-    return x;
-}
+MPC_DEV float sum_q(float x) { return wv::sum_rows(x); }
 MPC_DEV float sum_r(float x)
 {
     x += wv::shfl_xor(x, 1);
@@ -193,8 +188,9 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
             for (int J = 0; J < 3; ++J)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
+                    // only tile row / column 2 has padding (rows, columns 40..47)
                     const int row = 16 * I + 4 * L.q + v, col = 16 * J + L.r;
-                    const bool in = row < N && col < N;
+                    const bool in = (I < 2 || L.q < 2) && (J < 2 || L.r < 8);
                     const float x = wv::lds_f32(base + OFF_C + 4u * (unsigned)((in ? row : 0) * N + (in ? col : 0)));
                     Qd[I][J][v] = in ? x : 0.f;
                 }
@@ -244,7 +240,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
 #pragma unroll
                     for (int J = 0; J < 3; ++J) {
                         const int m = 16 * Ip + 4 * L.q + v, col = 16 * J + L.r;
-                        const bool in = col < N;
+                        const bool in = J < 2 || L.r < 8;
                         const float x = wv::lds_f32(base + OFF_F + 4u * (unsigned)(m * N + (in ? col : 0)));
                         FB[4 * Ip + v][J] = in ? x : 0.f;
                     }

@@ -142,6 +142,12 @@ static inline float shfl_xor(float x, int m)
     emu::yield_lane();
     return w.fa[gen][l ^ m];
 }
+static inline float sum_rows(float x)
+{
+    x += shfl_xor(x, 32);
+    x += shfl_xor(x, 16);
+    return x;
+}
 static inline unsigned long long ballot(bool c)
 {
     emu::Wave &w = emu::W;
