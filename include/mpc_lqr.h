@@ -129,8 +129,8 @@ int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p);
  *     `impl`: 0 = auto, 1 = generic kernels (any shape, f32/f64), 2 = fused MFMA kernel (f32,
  *     n_state <= 12, n_ctrl <= 4), 3 = 4-problems-per-wave DPP kernel (f32, n_state = 12,
  *     n_ctrl = 4, 16-byte aligned blocks), 4 = one lane per problem (n_ctrl = 1, n_state <= 6, f32/f64;
- *     the only fast kernel that takes a simulator as true_dynamics), 5 = register-resident MFMA sweep (f32,
- *     n_state = 32, n_ctrl = 8, unconstrained) + generic rollout.  Auto picks 5, 4, 3, 2, else 1.  The fused kernels need
+ *     the only fast kernel that takes a simulator as true_dynamics), 5 = register-resident MFMA step (f32,
+ *     n_state = 32, n_ctrl = 8).  Auto picks 5, 4, 3, 2, else 1.  The fused kernels need
  *     `workspace` (mpc_lqr_workspace_bytes, 16-byte aligned); out->K / out->k are optional there. */
 int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
                  void *workspace, int64_t workspace_bytes, int impl, void *stream);

@@ -110,7 +110,7 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
     if constexpr (sizeof(real) == 4) {
         // n_state = 32, n_ctrl = 8, unconstrained: register-resident MFMA sweep and rollout (lqr_mfma40_body.h)
         if (impl == 5 && !(phase_mask == 3 && mfma40_supported(sp)))
-            return fail(MPC_E_DIMS, "MFMA sweep needs fp32, n_state = 32, n_ctrl = 8, no constraints, 16-byte aligned blocks");
+            return fail(MPC_E_DIMS, "MFMA kernel needs fp32, n_state = 32, n_ctrl = 8, 16-byte aligned blocks, no simulator");
         if (phase_mask == 3 && (impl == 5 || impl == 0) && mfma40_supported(sp)) {
             return launch_step_mfma40(sp, st);
         }
@@ -167,7 +167,7 @@ int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, i
         mpc_lqr_outputs out;
         memset(&out, 0, sizeof(out));
         StepParams<float> sp = make_params<float>(p, o, &out);
-        return (sp.ns == 32 && sp.nc == 8 && sp.bound_mode == MPC_BOUND_NONE && !sp.zero_mask && !sp.env.kind) ? 1 : 0;
+        return (sp.ns == 32 && sp.nc == 8 && !sp.env.kind) ? 1 : 0;
     }
     if (impl == 2 || impl == 3) {
         if (p->dtype != MPC_F32) return 0;

@@ -54,9 +54,8 @@ bool kkt_wave_supported(const StepParams<float> &p, const float *dC, const float
 int launch_kkt_wave(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,
                     float *dc, float *dF, float *df, float *dx_init, hipStream_t st);
 
-// register-resident MFMA sweep for n_state = 32, n_ctrl = 8, f32, unconstrained (lqr_mfma40.hip)
+// register-resident MFMA step for n_state = 32, n_ctrl = 8, f32 (lqr_mfma40.hip)
 bool mfma40_supported(const StepParams<float> &p);
-int launch_sweep_mfma40(const StepParams<float> &p, hipStream_t st);
 int launch_step_mfma40(const StepParams<float> &p, hipStream_t st);
 
 // fused MFMA path for n <= 16, f32 (lqr_mfma16.hip)

@@ -14,6 +14,7 @@ MPC_DEV int problem() { return (int)blockIdx.x; }
 MPC_DEV f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 MPC_DEV float readlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 MPC_DEV float shfl_xor(float x, int m) { return __shfl_xor(x, m, 64); }
+MPC_DEV bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 // sum over the four 16-lane rows, result in every lane: two row swaps (gfx950 v_permlane{16,32}_swap), no LDS
 MPC_DEV float sum_rows(float x)
 {
@@ -66,14 +67,10 @@ template <int N> MPC_DEV void dma_wait()
 namespace mpclqr {
 namespace {
 
-__global__ void __launch_bounds__(64, 1) lqr_sweep_mfma40_kernel(StepParams<float> p)
+// MODE: 0 unconstrained, 1 unconstrained + u_zero_I, 2 box-constrained (pnqp8 in the sweep)
+template <int MODE> __global__ void __launch_bounds__(64, 1) lqr_step_mfma40_kernel(StepParams<float> p)
 {
-    (void)mfma40::sweep_wave(p, p.K, p.k);
-}
-
-__global__ void __launch_bounds__(64, 1) lqr_step_mfma40_kernel(StepParams<float> p)
-{
-    mfma40::step_wave(p, p.K, p.k);
+    mfma40::step_wave<MODE>(p, p.K, p.k);
 }
 
 }  // namespace
@@ -81,7 +78,8 @@ __global__ void __launch_bounds__(64, 1) lqr_step_mfma40_kernel(StepParams<float
 bool mfma40_supported(const StepParams<float> &p)
 {
     auto al = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
-    return p.ns == 32 && p.nc == 8 && p.T >= 1 && p.max_ls >= 1 && p.max_ls <= 16 && p.bound_mode == MPC_BOUND_NONE && !p.zero_mask && !p.env.kind &&
+    return p.ns == 32 && p.nc == 8 && p.T >= 1 && p.max_ls >= 1 && p.max_ls <= 16 && !p.env.kind &&
+           !(p.bound_mode != MPC_BOUND_NONE && p.zero_mask) &&
            al(p.C) && al(p.c) && (p.T == 1 || al(p.F)) && al(p.cur_x) && al(p.cur_u) && p.C_st % 4 == 0 && p.C_sb % 4 == 0 &&
            p.c_st % 4 == 0 && p.c_sb % 4 == 0 && p.F_st % 4 == 0 && p.F_sb % 4 == 0 &&
            (!p.f || (al(p.f) && p.f_st % 4 == 0 && p.f_sb % 4 == 0)) && al(p.x_init);
@@ -89,30 +87,21 @@ bool mfma40_supported(const StepParams<float> &p)
 
 int launch_step_mfma40(const StepParams<float> &p, hipStream_t st)
 {
-    if (!mfma40_supported(p)) { set_last_error("mfma40: needs fp32, n_state = 32, n_ctrl = 8, unconstrained, 16-byte aligned blocks"); return MPC_E_DIMS; }
+    if (!mfma40_supported(p)) { set_last_error("mfma40: needs fp32, n_state = 32, n_ctrl = 8, 16-byte aligned blocks"); return MPC_E_DIMS; }
     if (!p.K || !p.k || !p.new_x || !p.new_u) { set_last_error("mfma40: K / k / new_x / new_u missing"); return MPC_E_NULL; }
     if (((uintptr_t)p.K & 15) || ((uintptr_t)p.k & 15) || ((uintptr_t)p.new_x & 15) || ((uintptr_t)p.new_u & 15)) {
         set_last_error("mfma40: outputs must be 16-byte aligned");
         return MPC_E_ARG;
     }
-    hipLaunchKernelGGL(lqr_step_mfma40_kernel, dim3(p.B), dim3(64), 0, st, p);
+    if (p.bound_mode != MPC_BOUND_NONE)
+        hipLaunchKernelGGL(lqr_step_mfma40_kernel<2>, dim3(p.B), dim3(64), 0, st, p);
+    else if (p.zero_mask)
+        hipLaunchKernelGGL(lqr_step_mfma40_kernel<1>, dim3(p.B), dim3(64), 0, st, p);
+    else
+        hipLaunchKernelGGL(lqr_step_mfma40_kernel<0>, dim3(p.B), dim3(64), 0, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_last_error((std::string("lqr_step_mfma40_kernel: ") + hipGetErrorString(e)).c_str());
-        return MPC_E_LAUNCH;
-    }
-    return MPC_OK;
-}
-
-int launch_sweep_mfma40(const StepParams<float> &p, hipStream_t st)
-{
-    static_assert(MPC_MFMA40_LDS == mfma40::LDS_TOTAL, "LDS layout out of sync");
-    if (!mfma40_supported(p)) { set_last_error("mfma40: needs fp32, n_state = 32, n_ctrl = 8, unconstrained, 16-byte aligned blocks"); return MPC_E_DIMS; }
-    if (!p.K || !p.k) { set_last_error("mfma40: K / k missing"); return MPC_E_NULL; }
-    hipLaunchKernelGGL(lqr_sweep_mfma40_kernel, dim3(p.B), dim3(64), 0, st, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        set_last_error((std::string("lqr_sweep_mfma40_kernel: ") + hipGetErrorString(e)).c_str());
         return MPC_E_LAUNCH;
     }
     return MPC_OK;

@@ -1,5 +1,5 @@
 // lqr_mfma40_body.h -- the Riccati sweep for n_state = 32, n_ctrl = 8 (BASELINE config 5), fp32,
-// unconstrained: ONE wavefront per problem, every matrix product on v_mfma_f32_16x16x4_f32 with all
+// (unconstrained, u_zero_I-masked or box-constrained): ONE wavefront per problem, every matrix product on v_mfma_f32_16x16x4_f32 with all
 // operands in registers -- Y = V F, Q = C + F'Y and V = Qxx + Qxu K chain through the accumulators
 // without a single cross-lane move of matrix data.  (The generic kernel runs this shape at 4 % of the
 // HBM roofline: its time goes into serialised LDS phases, not arithmetic.)
@@ -147,8 +147,93 @@ MPC_DEV void ldl8_solve(const Ldl8 &f, const float rhs[8], float y[8])
     }
 }
 
+// Same factorisation of the free block: rows / columns outside `fr` become identity (their right-hand
+// sides are zero, so the solve returns zero there) -- mpc/pnqp.py:44-48 (H_ + 1e-11 I on the free set) and
+// mpc/lqr_step.py:99-127 (u_zero_I).
+MPC_DEV void ldl8_masked(Ldl8 &f, const float S[8][8], const bool fr[8], float reg)
+{
+    float M[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = a; c < 8; ++c) M[a][c] = a == c ? (fr[a] ? S[a][a] + reg : 1.f) : ((fr[a] & fr[c]) ? S[a][c] : 0.f);
+    ldl8(f, M);
+}
+MPC_DEV float sym8_row(const float S[8][8], int a, const float x[8])
+{
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s = fmaf(a <= c ? S[a][c] : S[c][a], x[c], s);
+    return s;
+}
+MPC_DEV float clampf(float x, float lo, float hi)
+{
+    if (x < lo) x = lo;      // util.eclamp (mpc/util.py:56-70): strict compares, bound written exactly
+    if (x > hi) x = hi;
+    return x;
+}
+
+// Projected-Newton box QP in 8 unknowns on wave-uniform values (mpc/pnqp.py:5-82, n_batch = 1), the
+// 8-dimensional sibling of lqr_small_math.h's pnqp4 (same Armijo restatements, see there).
+MPC_DEV int pnqp8(const float S[8][8], const float q[8], const float lb[8], const float ub[8], int n_iter, float x[8],
+                  bool fr[8], Ldl8 &f, bool &converged)
+{
+    int it_ret = n_iter - 1;
+    converged = false;
+    for (int it = 0; it < n_iter; ++it) {
+        float g[8], gm[8], dx[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            g[a] = sym8_row(S, a, x) + q[a];                                                         // :29
+            const bool ic = ((x[a] == lb[a]) & (g[a] > 0.f)) | ((x[a] == ub[a]) & (g[a] < 0.f));      // :32
+            fr[a] = !ic;
+            gm[a] = fr[a] ? g[a] : 0.f;
+        }
+        ldl8_masked(f, S, fr, 1e-11f);                                                                // :44-48
+        ldl8_solve(f, gm, dx);                                                                        // :50-54
+        float nrm2 = 0.f;
+        bool inside = true;
+        float mx[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            dx[a] = fr[a] ? -dx[a] : 0.f;
+            nrm2 = fmaf(dx[a], dx[a], nrm2);
+            mx[a] = x[a] + dx[a];
+            inside = inside & ((mx[a] >= lb[a]) & (mx[a] <= ub[a]));
+        }
+        if (wv::uniform(!(nrm2 >= 1e-8f))) {                                                          // :56-59
+            converged = true;
+            it_ret = it;
+            break;
+        }
+        if (!wv::uniform(inside)) {                                                                   // :61-76
+            float alpha = 1.f;
+            for (int count = 0; count < 10; ++count) {
+                float d[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    mx[a] = clampf(fmaf(alpha, dx[a], x[a]), lb[a], ub[a]);
+                    d[a] = mx[a] - x[a];
+                }
+                float den = 0.f, dhd = 0.f;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    den = fmaf(-g[a], d[a], den);
+                    dhd = fmaf(d[a], sym8_row(S, a, d), dhd);
+                }
+                const float arm = fmaf(-0.5f, dhd, den) * wv::rcp(den);
+                if (wv::uniform(arm <= 0.1f)) alpha *= 0.1f; else break;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) x[a] = mx[a];                                                      // :78
+    }
+    return it_ret;
+}
+
 // The sweep of one problem: K [T,B,8,32] and k [T,B,8] in the reference layout, old_costs[b].
-MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
+// MODE 0: unconstrained; 1: u_zero_I mask; 2: box constraints (pnqp8 on wave-uniform values).
+template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
 {
     Lane L;
     L.lane = wv::lane();
@@ -170,6 +255,11 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
         for (int v = 0; v < 4; ++v) vcol[I][v] = 0.f;
     }
     double old_cost = 0.0;
+    int qp_total = 0, status = 0;
+    bool warm = false;
+    float kprev[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) kprev[a] = 0.f;
 
     stage_issue(p, d, L, T - 1, 0);
     int slot = 0;
@@ -290,14 +380,64 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
 #pragma unroll
             for (int c = a; c < 8; ++c) S[a][c] = wv::readlane(Qd[2][2][a & 3], 16 * (a >> 2) + c);
         Ldl8 fac;
-        ldl8(fac, S);
         float qu[8], kk[8];
+        bool fr[8];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) qu[a] = wv::readlane(qrow[2], a);
-        ldl8_solve(fac, qu, kk);
+        for (int a = 0; a < 8; ++a) {
+            qu[a] = wv::readlane(qrow[2], a);
+            fr[a] = true;
+        }
+        if (MODE == 0) {
+            ldl8(fac, S);
+            ldl8_solve(fac, qu, kk);
 #pragma unroll
-        for (int a = 0; a < 8; ++a) kk[a] = -kk[a];
+            for (int a = 0; a < 8; ++a) kk[a] = -kk[a];
+        } else if (MODE == 1) {                          // :99-127: pinned controls drop out of the solve
+            float rq[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                fr[a] = p.zero_mask[tb * NC + a] == 0;
+                rq[a] = fr[a] ? qu[a] : 0.f;
+            }
+            ldl8_masked(fac, S, fr, 0.f);
+            ldl8_solve(fac, rq, kk);
+#pragma unroll
+            for (int a = 0; a < 8; ++a) kk[a] = fr[a] ? -kk[a] : 0.f;
+        } else {                                         // :128-148: box QP, warm start k_{t+1}
+            float lb[8], ub[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const float ua = wv::lds_f32(base + OFF_R + 288 + 4u * (unsigned)a);
+                lb[a] = (p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[tb * NC + a]) - ua;
+                ub[a] = (p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : p.hi[tb * NC + a]) - ua;
+                if (p.has_delta) {                       // :132-134
+                    if (lb[a] < -p.delta_u) lb[a] = -p.delta_u;
+                    if (ub[a] > p.delta_u) ub[a] = p.delta_u;
+                }
+            }
+            if (!warm) {                                 // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
+                ldl8(fac, S);
+                ldl8_solve(fac, qu, kk);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) kk[a] = -kk[a];
+            } else {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) kk[a] = kprev[a];
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) kk[a] = clampf(kk[a], lb[a], ub[a]);                         // :23
+            bool conv;
+            const int it = pnqp8(S, qu, lb, ub, p.pnqp_iter, kk, fr, fac, conv);
+            qp_total += 1 + it;                          // :140
+            if (!conv) status |= MPC_ST_PNQP_UNCONVERGED;
+            warm = true;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) kprev[a] = kk[a];
+        }
         f32x4 Kd[2];                    // K, B layout of the value update: register v of lane (q,r) = K[4q+v][16J+r]
+        f32x4 Md[2];                    // M = Qux + Quu K in the same layout (constrained modes)
+        Md[0] = zero4;
+        Md[1] = zero4;
 #pragma unroll
         for (int J = 0; J < 2; ++J) {
             float own[4], oth[4], rhs[8], sol[8];
@@ -312,9 +452,31 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
                 rhs[v] = odd ? oth[v] : own[v];
                 rhs[4 + v] = odd ? own[v] : oth[v];
             }
+            float rhs_full[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) rhs_full[a] = rhs[a];
+            if (MODE != 0) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) rhs[a] = fr[a] ? rhs[a] : 0.f;                            // :142-143
+            }
             ldl8_solve(fac, rhs, sol);
+            if (MODE != 0) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) sol[a] = fr[a] ? sol[a] : 0.f;
+            }
 #pragma unroll
             for (int v = 0; v < 4; ++v) Kd[J][v] = L.q < 2 ? -(odd ? sol[4 + v] : sol[v]) : 0.f;
+            if (MODE != 0) {
+                // M = Qux + Quu K for this lane's column (rows 4q+v), the B operand of K'M below
+                float Kc[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) Kc[a] = -sol[a];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float m0 = sym8_row(S, v, Kc), m1 = sym8_row(S, 4 + v, Kc);
+                    Md[J][v] = L.q < 2 ? (odd ? rhs_full[4 + v] + m1 : rhs_full[v] + m0) : 0.f;
+                }
+            }
             if (L.q < 2) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) Kout[(tb * NC + 4 * L.q + v) * NS + 16 * J + L.r] = Kd[J][v];
@@ -335,8 +497,15 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
                 f32x4 acc = Qd[I][J];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) acc = wv::mfma(Qd[2][I][v], Kd[J][v], acc);
+                if (MODE != 0) {                         // + K'(Qux + Quu K): K' as A operand is K's own registers
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc = wv::mfma(Kd[I][v], Md[J][v], acc);
+                }
                 Vd[I][J] = acc;
             }
+        float mk[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) mk[a] = MODE != 0 ? qu[a] + sym8_row(S, a, kk) : 0.f;
         float vrow[2];
 #pragma unroll
         for (int J = 0; J < 2; ++J) {
@@ -345,6 +514,10 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
             for (int v = 0; v < 4; ++v) {
                 const float ka = L.q == 0 ? kk[v] : (L.q == 1 ? kk[4 + v] : 0.f);
                 s = fmaf(Qd[2][J][v], ka, s);
+                if (MODE != 0) {                         // + K'(qu + Quu k)
+                    const float ma = L.q == 0 ? mk[v] : (L.q == 1 ? mk[4 + v] : 0.f);
+                    s = fmaf(Kd[J][v], ma, s);
+                }
             }
             vrow[J] = qrow[J] + sum_q(s);
         }
@@ -364,8 +537,8 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
         slot ^= 1;
     }
     if (L.lane == 0 && p.old_costs) p.old_costs[L.b] = (float)old_cost;
-    if (L.lane == 0 && p.qp_iters) p.qp_iters[L.b] = 0;
-    if (L.lane == 0 && p.status) p.status[L.b] = 0;
+    if (L.lane == 0 && p.qp_iters) p.qp_iters[L.b] = qp_total;
+    if (L.lane == 0 && p.status) p.status[L.b] = status;
     return old_cost;
 }
 
@@ -434,6 +607,7 @@ MPC_DEV void rstage_issue(const P &p, const RStream &d, const Lane &L, int t, in
 
 // One pass over the horizon.  alpha: this lane's (= its column's) step size.  Returns the column's cost and
 // squared control change in every lane of the column.
+template <int MODE>
 MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alpha, bool store, double &cost, float &du2)
 {
     const int T = p.T;
@@ -472,7 +646,19 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
             float s = 0.f;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float un = L.q < 2 ? Ud[v] + ub[v] + alpha * kb[v] : 0.f;
+                float un = L.q < 2 ? Ud[v] + ub[v] + alpha * kb[v] : 0.f;
+                if (MODE == 1 && L.q < 2 && p.zero_mask[tb * NC + 4 * L.q + v]) un = 0.f;           // :197-198
+                if (MODE == 2 && L.q < 2) {                                                          // :200-213
+                    const long ui = tb * NC + 4 * L.q + v;
+                    float lo = p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[ui];
+                    float hi = p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : p.hi[ui];
+                    if (p.has_delta) {
+                        const float l2 = ub[v] - p.delta_u, h2 = ub[v] + p.delta_u;
+                        lo = (l2 < lo) ? lo : l2;
+                        hi = (h2 > hi) ? hi : h2;
+                    }
+                    un = clampf(un, lo, hi);
+                }
                 const float dd = L.q < 2 ? ub[v] - un : 0.f;
                 Ud[v] = un;
                 s = fmaf(dd, dd, s);
@@ -558,7 +744,7 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
     du2 = sum_q(dacc);
 }
 
-MPC_DEV void rollout_wave(const P &p, const float *Kin, const float *kin, double old_cost)
+template <int MODE> MPC_DEV void rollout_wave(const P &p, const float *Kin, const float *kin, double old_cost)
 {
     Lane L;
     L.lane = wv::lane();
@@ -572,7 +758,7 @@ MPC_DEV void rollout_wave(const P &p, const float *Kin, const float *kin, double
     for (int i = 0; i < L.r; ++i) alpha *= p.ls_decay;            // column r tries decay^r
     double cost;
     float du2;
-    rollout_pass(p, d, L, alpha, true, cost, du2);
+    rollout_pass<MODE>(p, d, L, alpha, true, cost, du2);
     // first trial that is not worse than the nominal, else the last one (:176-179, 247)
     int win = p.max_ls - 1;
     for (int j = p.max_ls - 1; j >= 0; --j) {
@@ -586,7 +772,7 @@ MPC_DEV void rollout_wave(const P &p, const float *Kin, const float *kin, double
     double win_cost;
     float win_du2;
     if (win != 0) {
-        rollout_pass(p, d, L, win_alpha, true, win_cost, win_du2);
+        rollout_pass<MODE>(p, d, L, win_alpha, true, win_cost, win_du2);
     } else {
         win_cost = cost;
         win_du2 = du2;
@@ -605,11 +791,11 @@ MPC_DEV void rollout_wave(const P &p, const float *Kin, const float *kin, double
     }
 }
 
-MPC_DEV void step_wave(const P &p, float *K, float *k)
+template <int MODE> MPC_DEV void step_wave(const P &p, float *K, float *k)
 {
-    const double old_cost = sweep_wave(p, K, k);
+    const double old_cost = sweep_wave<MODE>(p, K, k);
     wv::fence_own_stores();
-    rollout_wave(p, K, k, old_cost);
+    rollout_wave<MODE>(p, K, k, old_cost);
 }
 
 }  // namespace mfma40

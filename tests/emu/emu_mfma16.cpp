@@ -496,10 +496,16 @@ extern "C" int emu_lqr_step_tiny(const mpc_lqr_problem *p, const mpc_lqr_options
 
 // ---- lqr_mfma40_body.h: the n_state = 32, n_ctrl = 8 sweep (one emulated wavefront per problem) ----
 static int g_m40_full = 0;
+template <int MODE> static void body_mfma40_mode()
+{
+    if (g_m40_full) mpclqr::mfma40::step_wave<MODE>(*g_p, g_p->K, g_p->k);
+    else (void)mpclqr::mfma40::sweep_wave<MODE>(*g_p, g_p->K, g_p->k);
+}
 static void body_mfma40()
 {
-    if (g_m40_full) mpclqr::mfma40::step_wave(*g_p, g_p->K, g_p->k);
-    else (void)mpclqr::mfma40::sweep_wave(*g_p, g_p->K, g_p->k);
+    if (g_p->bound_mode != MPC_BOUND_NONE) body_mfma40_mode<2>();
+    else if (g_p->zero_mask) body_mfma40_mode<1>();
+    else body_mfma40_mode<0>();
 }
 extern "C" void emu_mfma40_full(int full) { g_m40_full = full; }
 extern "C" int emu_lqr_sweep_mfma40(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out)

@@ -424,3 +424,38 @@ def test_emulated_mfma40_full_step(emu, case, dma_late):
     np.testing.assert_allclose(r["old_costs"], o["old_costs"], rtol=1e-5)
     np.testing.assert_allclose(r["full_du_norm"], o["full_du_norm"], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(r["alpha_du_norm"], o["alpha_du_norm"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
+@pytest.mark.parametrize("case", ["bounded", "tensor_bounds", "delta_u", "masked"])
+def test_emulated_mfma40_constrained_modes(emu, case, dma_late):
+    """Box constraints (pnqp in 8 unknowns on wave-uniform values, K'M terms of the value update on MFMA,
+    clamped rollout) and the u_zero_I mask of the KKT backward's nested solve, against the oracle."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(7 + len(case))
+    T, B = 6, 3
+    kw = _cfg5_problem(rng, T, B)
+    kw["cur_u"] = np.clip(kw["cur_u"], -0.4, 0.4)
+    kw["cur_x"], _ = O.traj_cost(kw["x_init"], kw["cur_u"], kw["F"], kw["f"])
+    opt = dict(linesearch_decay=0.5, max_linesearch_iter=6)
+    if case == "tensor_bounds":
+        opt.update(u_lower=-0.5 - rng.random((T, B, 8)), u_upper=0.5 + rng.random((T, B, 8)))
+    elif case == "delta_u":
+        opt.update(u_lower=-0.5, u_upper=0.5, delta_u=0.1)
+    elif case == "masked":
+        opt.update(u_zero_I=rng.random((T, B, 8)) < 0.35)
+    else:
+        opt.update(u_lower=-0.5, u_upper=0.5)
+    o = O.lqr_step(lockstep=False, return_gains=True, **kw, **opt)
+    r = emu.lqr_step(kernel="mfma40", dma_late=dma_late, **kw, **opt)
+    wide = 1.0      # (a non-convex box QP has no unique answer to compare: the unconstrained backtrack case above
+    #                  covers the replay of the line search)
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+    np.testing.assert_allclose(r["K"], o["K"], rtol=2e-3 * wide, atol=2e-4 * wide * (1 + np.abs(o["K"]).max()))
+    np.testing.assert_allclose(r["k"], o["k"], rtol=2e-3 * wide, atol=2e-4 * wide)
+    np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=2e-3 * wide, atol=2e-4 * wide * (1 + np.abs(o["new_x"]).max()))
+    np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=2e-3 * wide, atol=2e-4 * wide)
+    np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4 * wide, atol=1e-3)
+    if case != "masked":
+        assert float(np.abs(r["new_u"]).max()) <= (1.5 if case == "tensor_bounds" else 0.5) + 1e-6
+        assert int(r["qp_iters"].max()) <= o["n_qp_iter"] + 2

@@ -235,8 +235,24 @@ def test_config5_mfma_sweep(be, T, B):
     np.testing.assert_allclose(host(r5["old_costs"]), o["old_costs"], rtol=1e-5)
     assert torch.equal(r0["new_u"], r5["new_u"])                     # auto = the MFMA sweep
     np.testing.assert_allclose(host(r1["new_u"]), host(r5["new_u"]), rtol=2e-3, atol=5e-4)
-    with pytest.raises(RuntimeError, match="MFMA sweep needs"):
-        be.lqr_step(*args[:-1], StepOptions(u_lower=-1.0, u_upper=1.0), impl=IMPL_MFMA40)
+    # box constraints and the mask of the backward's nested solve run on the same kernel
+    ub = float(np.abs(h["cur_u"]).max()) * 0.8 + 0.05
+    cu = p["cur_u"].clamp(-ub, ub)
+    from mpc import util
+    from mpc.mpc import LinDx
+    cx = util.get_traj(T, cu, p["x_init"], LinDx(p["F"], p["f"]))
+    ob = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], host(cx).astype(np.float64), host(cu).astype(np.float64),
+                    -ub, ub, lockstep=False)
+    rb = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], cx, cu, StepOptions(u_lower=-ub, u_upper=ub), impl=IMPL_MFMA40)
+    mask = torch.rand(T, B, 8, device=DEV) < 0.3
+    om = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], u_zero_I=host(mask), lockstep=False)
+    rm = be.lqr_step(*args[:-1], StepOptions(u_zero_I=mask), impl=IMPL_MFMA40)
+    torch.cuda.synchronize()
+    for r_, o_ in ((rb, ob), (rm, om)):
+        np.testing.assert_allclose(host(r_["new_u"]), o_["new_u"], rtol=2e-3, atol=5e-4)
+        np.testing.assert_allclose(host(r_["new_x"]), o_["new_x"], rtol=2e-3, atol=5e-4)
+        np.testing.assert_allclose(host(r_["costs"]), o_["costs"], rtol=2e-4)
+    assert float(rb["new_u"].abs().max()) <= ub + 1e-6 and int(rb["status"].max()) == 0
     # a non-convex stage cost: the line search backtracks (to its last trial), the winner is replayed
     Cn = p["C"].clone()
     Cn[:, :, :32, :32] -= 45.0 * torch.eye(32, device=DEV)
