@@ -564,6 +564,39 @@ def test_ilqr_on_shipped_simulators_on_gpu(be, kind):
     assert float((ua.abs() <= dx.upper + 1e-6).float().mean()) == 1.0
 
 
+def test_learning_simulator_parameters_through_the_kernel_path(be, capsys):
+    """d loss / d (pendulum parameters): the iterations run on the kernels (closed-form linearisation, simulator in
+    the rollout), the final differentiable linearisation through autograd -- same gradient as the host-driven
+    module path; `verbose=1` prints the reference's table."""
+    from mpc import mpc
+    from mpc.mpc import QuadCost
+    from mpc.env_dx import pendulum
+    import envs
+    B, T = 16, 12
+    g = torch.Generator().manual_seed(3)
+    th = (torch.rand(B, generator=g, dtype=torch.float64) - 0.5) * 2.0
+    x0 = torch.stack((th.cos(), th.sin(), torch.zeros(B, dtype=torch.float64)), 1).to(DEV)
+    grads = []
+    for shipped in (True, False):
+        prm = torch.tensor([10.0, 1.0, 1.0], dtype=torch.float64, device=DEV, requires_grad=True)
+        dx = pendulum.PendulumDx(params=prm)
+        if not shipped:                      # hide the device description: plain-module path
+            dx.__class__ = type("PlainPendulum", (pendulum.PendulumDx,), {"native_env": property(lambda self: (_ for _ in ()).throw(AttributeError()))})
+        q, p_ = dx.get_true_obj()
+        Q = torch.diag(q.double()).repeat(T, B, 1, 1).to(DEV)
+        pp = p_.double().repeat(T, B, 1).to(DEV)
+        ctrl = mpc.MPC(3, 1, T, u_lower=dx.lower, u_upper=dx.upper, lqr_iter=25, verbose=1 if shipped else -1,
+                       exit_unconverged=False, detach_unconverged=False, linesearch_decay=dx.linesearch_decay,
+                       max_linesearch_iter=dx.max_linesearch_iter, grad_method=mpc.GradMethods.AUTO_DIFF, eps=1e-7)
+        x, u, costs = ctrl(x0, QuadCost(Q, pp), dx)
+        loss = (u ** 2).sum() + x[:, :, 2].pow(2).sum()
+        loss.backward()
+        grads.append(prm.grad.clone())
+        assert torch.isfinite(prm.grad).all() and prm.grad.abs().max() > 0
+    assert "||full_du||_max" in capsys.readouterr().out
+    np.testing.assert_allclose(host(grads[0]), host(grads[1]), rtol=1e-4, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------
 # full-size checks at BASELINE.json's north-star configuration (ns=12, nc=4, T=50, B=4096, fp32)
 # ------------------------------------------------------------------------------------------------
