@@ -94,6 +94,51 @@ def _module_rollout(n_state, n_ctrl, T, x_init, K, k, cur_x, cur_u, old_cost, tr
     return new_x, new_u, cost, full_du_norm, du_norm, alpha.squeeze(1)
 
 
+class _StepConfig:
+    """What one LQRStep(...) call fixes for its autograd node (closure state of the reference's factory)."""
+    __slots__ = ("solve", "no_op_forward", "delta_space", "current_x", "current_u", "u_lower", "u_upper")
+
+
+class _LQRStepFn(Function):
+    """One autograd node type for every LQRStep.  (The reference defines a new Function class inside each
+    LQRStep(...) call, mpc/lqr_step.py:275; a class object is only ever freed by the cyclic garbage collector,
+    which keeps every solve's tensors alive until it happens to run.)"""
+
+    @staticmethod
+    def forward(ctx, cfg, x_init, C, c, F, f=None):
+        if f is None:
+            f = torch.empty(0)
+        # Only the bounds go on ctx.  (The reference also parks current_x / current_u there, :281, 300-301: in
+        # the no-op forward those ARE the outputs, and output -> grad_fn -> ctx -> output is a cycle the
+        # garbage collector cannot see -- every differentiated solve would pin its tensors forever.)
+        ctx.u_lower, ctx.u_upper = cfg.u_lower, cfg.u_upper
+        if cfg.no_op_forward:
+            ctx.save_for_backward(x_init, C, c, F, f, cfg.current_x, cfg.current_u)
+            return cfg.current_x, cfg.current_u
+        if not cfg.delta_space:
+            assert False      # unimplemented upstream too (mpc/lqr_step.py:297-298)
+        assert cfg.current_x is not None
+        assert cfg.current_u is not None
+        new_x, new_u, qp_iters, costs, full_du_norm, alphas = cfg.solve(x_init, C, c, F, f)
+        ctx.save_for_backward(x_init, C, c, F, f, new_x, new_u)
+        # the reference hands back a CPU float tensor here (mpc/lqr_step.py:308)
+        n_qp = float(qp_iters.max().item()) if cfg.u_lower is not None else 0.0
+        return new_x, new_u, torch.Tensor([n_qp]), costs, full_du_norm, alphas.mean()
+
+    @staticmethod
+    def backward(ctx, dl_dx, dl_du, *unused):
+        x_init, C, c, F, f, new_x, new_u = ctx.saved_tensors
+        if dl_dx is None:
+            dl_dx = torch.zeros_like(new_x)
+        if dl_du is None:
+            dl_du = torch.zeros_like(new_u)
+        g = _native.backend().kkt_backward(
+            C, c, F, None if _is_empty(f) else f, new_x, new_u, dl_dx, dl_du,
+            StepOptions(u_lower=ctx.u_lower, u_upper=ctx.u_upper))
+        df = g["df"] if g["df"] is not None else torch.Tensor()
+        return None, g["dx_init"], g["dC"], g["dc"], g["dF"], df
+
+
 def LQRStep(n_state,
             n_ctrl,
             T,
@@ -154,37 +199,11 @@ def LQRStep(n_state,
             old_cost, true_cost, true_dynamics, opts)
         return nx, nu, sw["qp_iters"], cost, fdn, alphas
 
-    class LQRStepFn(Function):
-        @staticmethod
-        def forward(ctx, x_init, C, c, F, f=None):
-            if f is None:
-                f = torch.empty(0)
-            if no_op_forward:
-                ctx.save_for_backward(x_init, C, c, F, f, current_x, current_u)
-                ctx.current_x, ctx.current_u = current_x, current_u
-                return current_x, current_u
-            if not delta_space:
-                assert False      # unimplemented upstream too (mpc/lqr_step.py:297-298)
-            assert current_x is not None
-            assert current_u is not None
-            ctx.current_x, ctx.current_u = current_x, current_u
-            new_x, new_u, qp_iters, costs, full_du_norm, alphas = solve(x_init, C, c, F, f)
-            ctx.save_for_backward(x_init, C, c, F, f, new_x, new_u)
-            # the reference hands back a CPU float tensor here (mpc/lqr_step.py:308)
-            n_qp = float(qp_iters.max().item()) if u_lower is not None else 0.0
-            return new_x, new_u, torch.Tensor([n_qp]), costs, full_du_norm, alphas.mean()
+    cfg = _StepConfig()
+    cfg.solve, cfg.no_op_forward, cfg.delta_space = solve, no_op_forward, delta_space
+    cfg.current_x, cfg.current_u = current_x, current_u
+    cfg.u_lower, cfg.u_upper = u_lower, u_upper
 
-        @staticmethod
-        def backward(ctx, dl_dx, dl_du, *unused):
-            x_init, C, c, F, f, new_x, new_u = ctx.saved_tensors
-            if dl_dx is None:
-                dl_dx = torch.zeros_like(new_x)
-            if dl_du is None:
-                dl_du = torch.zeros_like(new_u)
-            g = _native.backend().kkt_backward(
-                C, c, F, None if _is_empty(f) else f, new_x, new_u, dl_dx, dl_du,
-                StepOptions(u_lower=u_lower, u_upper=u_upper))
-            df = g["df"] if g["df"] is not None else torch.Tensor()
-            return g["dx_init"], g["dC"], g["dc"], g["dF"], df
-
-    return LQRStepFn.apply
+    def apply(x_init, C, c, F, f=None):
+        return _LQRStepFn.apply(cfg, x_init, C, c, F, f)
+    return apply

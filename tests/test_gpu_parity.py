@@ -564,6 +564,31 @@ def test_ilqr_on_shipped_simulators_on_gpu(be, kind):
     assert float((ua.abs() <= dx.upper + 1e-6).float().mean()) == 1.0
 
 
+def test_slew_rate_properties_on_gpu(be):
+    """reference tests/test_mpc.py:802-861 on the device (float64)."""
+    from test_host_logic import _slew_rate_properties
+    _slew_rate_properties(device=DEV)
+
+
+def test_no_device_memory_growth_over_repeated_solves(be):
+    """reference tests/test_mpc.py:864-... (test_memory) in spirit: forward + backward in a loop keeps the
+    allocator's footprint flat."""
+    from mpc import mpc
+    from mpc.mpc import LinDx, QuadCost
+    import bench
+    p = bench.make_problem(4, 2, 8, 16, torch.float64, DEV, seed=5)
+    ctrl = mpc.MPC(4, 2, 8, u_lower=-0.5, u_upper=0.5, lqr_iter=5, verbose=-1, exit_unconverged=False)
+    seen = []
+    for it in range(12):
+        C = p["C"].clone().requires_grad_(True)
+        x, u, _ = ctrl(p["x_init"], QuadCost(C, p["c"]), LinDx(p["F"], p["f"]))
+        (u.sum() + x.sum()).backward()
+        del x, u, C
+        torch.cuda.synchronize()
+        seen.append(torch.cuda.memory_allocated())
+    assert max(seen[4:]) <= min(seen[4:]) + 4096, seen
+
+
 def test_learning_simulator_parameters_through_the_kernel_path(be, capsys):
     """d loss / d (pendulum parameters): the iterations run on the kernels (closed-form linearisation, simulator in
     the rollout), the final differentiable linearisation through autograd -- same gradient as the host-driven

@@ -462,3 +462,59 @@ def test_numdiff_and_jacobian_helpers():
     want = A.clone(); want[:, 0] += -0.2; want[:, 1] += 0.3
     np.testing.assert_allclose(J.numpy(), want.numpy(), atol=1e-8)
     assert util.data_maybe(None) is None and not util.data_maybe(x).requires_grad
+
+
+def _slew_rate_properties(device=None):
+    """reference tests/test_mpc.py:802-861 (test_lqr_slew_rate), restated."""
+    from mpc.dynamics import AffineDynamics
+    mv = (lambda t: t if device is None else t.to(device))
+    n_batch, n_state, n_ctrl, T, alpha = 2, 3, 4, 5, 0.2
+    n_sc = n_state + n_ctrl
+    torch.manual_seed(1)
+    C = torch.randn(T, n_batch, n_sc, n_sc, dtype=torch.float64)
+    C = mv(C.transpose(2, 3).matmul(C))
+    c = mv(torch.randn(T, n_batch, n_sc, dtype=torch.float64))
+    x_init = mv(torch.randn(n_batch, n_state, dtype=torch.float64))
+    R = mv(torch.eye(n_state, dtype=torch.float64) + alpha * torch.randn(n_state, n_state, dtype=torch.float64))
+    S = mv(torch.randn(n_state, n_ctrl, dtype=torch.float64))
+    f = mv(torch.randn(n_state, dtype=torch.float64))
+    dynamics = AffineDynamics(R, S, f)
+
+    def solve(**kw):
+        return mpc.MPC(n_state, n_ctrl, T, u_lower=None, u_upper=None, u_init=None, lqr_iter=10, backprop=False,
+                       verbose=-1, exit_unconverged=False, eps=1e-4, **kw)(x_init, QuadCost(C, c), dynamics)
+    x, u, objs = solve()
+    x_e, u_e, _ = solve(slew_rate_penalty=1e-6)
+    np.testing.assert_allclose(x.detach().cpu().numpy(), x_e.detach().cpu().numpy(), atol=1e-3)
+    np.testing.assert_allclose(u.detach().cpu().numpy(), u_e.detach().cpu().numpy(), atol=1e-3)
+    x_s, u_s, objs_s = solve(slew_rate_penalty=1.)
+    assert bool((objs < objs_s).all())
+    assert torch.norm(u_s[:-1] - u_s[1:]).item() < torch.norm(u[:-1] - u[1:]).item()
+
+
+def test_slew_rate_properties(oracle_backend):
+    _slew_rate_properties()
+
+
+def test_gradient_through_affine_module_equals_lindx(oracle_backend):
+    """reference tests/test_mpc.py:503-558: du/dF is the same whether the dynamics come as LinDx(F) or as
+    an AffineDynamics module built on the same tensor (ANALYTIC linearisation)."""
+    from mpc.dynamics import AffineDynamics
+    npr = np.random.RandomState(0)
+    torch.manual_seed(0)
+    n_batch, n_state, n_ctrl, T = 1, 2, 2, 2
+    n_sc = n_state + n_ctrl
+    C = 10. * npr.randn(T, n_batch, n_sc, n_sc)
+    C = torch.tensor(np.matmul(C.transpose(0, 1, 3, 2), C), requires_grad=True)
+    c = torch.tensor(10. * npr.randn(T, n_batch, n_sc), requires_grad=True)
+    x_init = torch.tensor(npr.randn(n_batch, n_state), requires_grad=True)
+    beta = 2.0
+    lo, hi = -beta * torch.ones(T, n_batch, n_ctrl, dtype=torch.float64), beta * torch.ones(T, n_batch, n_ctrl, dtype=torch.float64)
+    F = torch.randn(1, 1, n_state, n_sc, dtype=torch.float64).repeat(T - 1, 1, 1, 1).requires_grad_(True)
+    jac = []
+    for dyn in (LinDx(F), AffineDynamics(F[0, 0, :, :n_state], F[0, 0, :, n_state:])):
+        x, u, _ = mpc.MPC(n_state, n_ctrl, T, lo, hi, None, lqr_iter=20, verbose=-1)(x_init, QuadCost(C, c), dyn)
+        flat = u.reshape(-1)
+        jac.append(torch.stack([torch.autograd.grad(flat[i], [F], retain_graph=True)[0].reshape(-1) for i in range(len(flat))]))
+    np.testing.assert_allclose(jac[0].numpy(), jac[1].numpy(), atol=1e-4)
+    assert jac[0].abs().max() > 0
