@@ -328,6 +328,7 @@ int mpc_traj_cost(const mpc_lqr_problem *p, void *x, void *cost, void *stream)
     hipStream_t st = (hipStream_t)stream;
     if (p->dtype == MPC_F32) {
         StepParams<float> sp = make_params<float>(p, nullptr, nullptr);
+        if (!cost && x && traj_wave_supported(sp)) return launch_traj_wave(sp, (float *)x, st);
         return launch_traj_cost<float>(sp, (float *)x, (float *)cost, st);
     }
     StepParams<double> sp = make_params<double>(p, nullptr, nullptr);

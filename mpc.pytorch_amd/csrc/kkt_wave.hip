@@ -156,7 +156,57 @@ __global__ void __launch_bounds__(64) kkt_outer_kernel(StepParams<float> p, cons
     }
 }
 
+// util.get_traj (LinDx, mpc/util.py:114-126) for 16 < n <= 64: one wavefront per problem, F_t by LDS-DMA one
+// step ahead, lane i sums row i with tau[j] as readlane scalars.
+__global__ void __launch_bounds__(64) traj_wave_kernel(StepParams<float> p, float *x)
+{
+    extern __shared__ __attribute__((aligned(16))) char traj_lds[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T, B = p.B;
+    const int fbytes = ns * n * 4;
+    const bool st = lane < ns;
+    float xi = st ? p.x_init[(long)b * ns + lane] : 0.f;
+    if (st) x[(long)b * ns + lane] = xi;
+    if (T > 1) dma_block(p.F + (long)b * p.F_sb, traj_lds, fbytes, lane);
+    int slot = 0;
+    for (int t = 0; t < T - 1; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 1 < T - 1) dma_block(p.F + (long)(t + 1) * p.F_st + (long)b * p.F_sb, traj_lds + (slot ^ 1) * fbytes, fbytes, lane);
+        const float ui = (lane >= ns && lane < n) ? p.cur_u[((long)t * B + b) * nc + (lane - ns)] : 0.f;
+        const float tau = st ? xi : ui;
+        float acc = (p.f && st) ? p.f[(long)t * p.f_st + (long)b * p.f_sb + lane] : 0.f;
+        const float *Fl = (const float *)(traj_lds + slot * fbytes) + (st ? lane : 0) * n;
+        for (int j = 0; j < n; j += 4) {
+            const f32x4 row = *(const f32x4 *)(Fl + j);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc = fmaf(row[v], lane_bcast(tau, j + v), acc);
+        }
+        xi = acc;
+        if (st) x[((long)(t + 1) * B + b) * ns + lane] = xi;
+        slot ^= 1;
+    }
+}
+
 }  // namespace
+
+bool traj_wave_supported(const StepParams<float> &p)
+{
+    const int n = p.ns + p.nc;
+    return n > 16 && n <= 64 && n % 4 == 0 && p.B > 0 && !p.env.kind &&
+           (p.T == 1 || (((uintptr_t)p.F & 15) == 0 && p.F_st % 4 == 0 && p.F_sb % 4 == 0));
+}
+
+int launch_traj_wave(const StepParams<float> &p, float *x, hipStream_t st)
+{
+    const int n = p.ns + p.nc;
+    hipLaunchKernelGGL(traj_wave_kernel, dim3(p.B), dim3(64), 2 * (size_t)p.ns * n * 4, st, p, x);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error((std::string("traj_wave_kernel: ") + hipGetErrorString(e)).c_str());
+        return MPC_E_LAUNCH;
+    }
+    return MPC_OK;
+}
 
 bool kkt_wave_supported(const StepParams<float> &p, const float *dC, const float *dF)
 {

@@ -49,6 +49,9 @@ int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *d
 bool tiny_supported(int ns, int nc);
 template <typename real> int launch_step_tiny(const StepParams<real> &p, hipStream_t st);
 
+// wave-per-problem trajectory kernel for 16 < n <= 64, f32 (kkt_wave.hip)
+bool traj_wave_supported(const StepParams<float> &p);
+int launch_traj_wave(const StepParams<float> &p, float *x, hipStream_t st);
 // costate + outer-product kernels of the KKT backward for n <= 64, f32 (kkt_wave.hip)
 bool kkt_wave_supported(const StepParams<float> &p, const float *dC, const float *dF);
 int launch_kkt_wave(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,

@@ -413,6 +413,24 @@ def test_traj_cost_parity(be):
     np.testing.assert_allclose(host(cost), z["cost"], rtol=1e-12)
 
 
+@pytest.mark.parametrize("ns,nc,T,B", [(32, 8, 9, 5), (20, 4, 2, 3), (60, 4, 6, 2), (12, 4, 7, 9), (5, 2, 1, 3), (24, 8, 1, 2)])
+@pytest.mark.parametrize("with_f", [True, False])
+def test_trajectory_kernels_float32(be, ns, nc, T, B, with_f):
+    """util.get_traj (LinDx) in float32: the 16-lanes-per-problem kernel (n <= 16) and the wavefront-per-problem
+    kernel (n <= 64), against the oracle."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(ns + T)
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((max(T - 1, 0), B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((max(T - 1, 0), B, ns, nc)) / np.sqrt(ns)), 3)
+    f = 0.1 * rng.standard_normal((max(T - 1, 0), B, ns)) if with_f else None
+    x0, u = rng.standard_normal((B, ns)), rng.standard_normal((T, B, nc))
+    xo, _ = O.traj_cost(x0, u, F, f)
+    d = lambda a: None if a is None else dev(a).float()
+    x, _ = be.traj_cost(d(x0), d(u), d(F) if T > 1 else torch.empty(0, B, ns, ns + nc, device=DEV), d(f))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(host(x), xo, rtol=2e-4, atol=2e-4)
+
+
 def test_select_best_kernel(be):
     g = torch.Generator().manual_seed(0)
     T, B, ns, nc = 5, 37, 3, 2
