@@ -59,7 +59,10 @@ enum {
 };
 typedef struct mpc_env_dynamics {
     int32_t kind;                 /* MPC_ENV_* */
-    int32_t _pad;
+    int32_t linearize;            /* 1: mpc_lqr_step takes the sweep's F_t from the simulator's Jacobian at the nominal
+                                     (current_x, current_u), computed in the kernel: MPC.linearize_dynamics
+                                     (mpc/mpc.py:490-549) fused into the step; p->F, p->f are ignored (may be NULL).
+                                     Lane-per-problem kernel only. */
     const void *params;           /* DEVICE pointer, dtype of the problem, 3 / 5 / 4 values */
     double dt;                    /* 0.05 in both modules */
     double u_max;                 /* max_torque (2.0) / force_mag (100.0): the module clamps u to +-u_max */

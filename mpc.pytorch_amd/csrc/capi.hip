@@ -17,7 +17,7 @@ static int fail(int code, const char *msg)
     return code;
 }
 
-static int check_problem(const mpc_lqr_problem *p, bool need_cost, bool need_nominal)
+static int check_problem(const mpc_lqr_problem *p, bool need_cost, bool need_nominal, bool need_F = true)
 {
     if (!p) return fail(MPC_E_NULL, "problem is NULL");
     if (p->B < 0 || p->T < 1 || p->ns < 1 || p->nc < 1) return fail(MPC_E_DIMS, "need B>=0, T>=1, ns>=1, nc>=1");
@@ -25,7 +25,7 @@ static int check_problem(const mpc_lqr_problem *p, bool need_cost, bool need_nom
     if (p->dtype != MPC_F32 && p->dtype != MPC_F64) return fail(MPC_E_DTYPE, "dtype must be MPC_F32 or MPC_F64");
     if (p->B == 0) return MPC_OK;
     if (need_cost && (!p->C || !p->c)) return fail(MPC_E_NULL, "C / c is NULL");
-    if (p->T > 1 && !p->F) return fail(MPC_E_NULL, "F is NULL");
+    if (need_F && p->T > 1 && !p->F) return fail(MPC_E_NULL, "F is NULL");
     if (!p->x_init) return fail(MPC_E_NULL, "x_init is NULL");
     if (need_nominal && (!p->cur_x || !p->cur_u)) return fail(MPC_E_NULL, "current_x / current_u is NULL");
     return MPC_OK;
@@ -68,6 +68,8 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
     }
     const int64_t needK = (int64_t)p->T * p->B * p->nc * p->ns * (int64_t)sizeof(real);
     const int64_t needk = (int64_t)p->T * p->B * p->nc * (int64_t)sizeof(real);
+    if (sp.env.kind && sp.env.linearize && !(phase_mask == 3 && tiny_supported(p->ns, p->nc) && (impl == 0 || impl == 4)))
+        return fail(MPC_E_ARG, "in-kernel linearisation needs the lane-per-problem kernel (n_ctrl = 1, n_state <= 6)");
     if (sp.env.kind && (impl == 2 || impl == 3))
         return fail(MPC_E_ARG, "a simulator as true_dynamics runs on the generic kernels only");
     if (impl == 4 && (phase_mask != 3 || !tiny_supported(p->ns, p->nc)))
@@ -147,7 +149,8 @@ int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p)
 int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
                  void *workspace, int64_t workspace_bytes, int impl, void *stream)
 {
-    int rc = check_problem(p, true, true);
+    const bool inline_lin = o && o->true_dynamics && o->true_dynamics->linearize;
+    int rc = check_problem(p, true, true, !inline_lin);
     if (rc) return rc;
     if ((rc = check_options(p, o))) return rc;
     if (!out) return fail(MPC_E_NULL, "outputs is NULL");

@@ -19,6 +19,7 @@ namespace mpclqr {
 
 template <typename real> struct EnvDesc {
     int kind;            // MPC_ENV_*
+    int linearize;       // sweep model = Jacobian of the simulator at the nominal, computed in the kernel
     const real *params;  // device pointer: pendulum (g,m,l[,d,b]), cartpole (g,mcart,mpole,l)
     real dt, u_max;
 };

@@ -33,7 +33,7 @@ struct StepParams {
 template <typename real>
 inline void set_env(EnvDesc<real> &e, const mpc_env_dynamics *d)
 {
-    e.kind = d->kind; e.params = (const real *)d->params; e.dt = (real)d->dt; e.u_max = (real)d->u_max;
+    e.kind = d->kind; e.linearize = d->linearize; e.params = (const real *)d->params; e.dt = (real)d->dt; e.u_max = (real)d->u_max;
 }
 
 template <typename real>
@@ -66,7 +66,7 @@ inline StepParams<real> make_params(const mpc_lqr_problem *p, const mpc_lqr_opti
     s.K = out ? (real *)out->K : nullptr; s.k = out ? (real *)out->k : nullptr;
     s.Kk = nullptr;
     s.old_costs_in = nullptr;
-    s.env.kind = MPC_ENV_NONE; s.env.params = nullptr; s.env.dt = 0; s.env.u_max = 0;
+    s.env.kind = MPC_ENV_NONE; s.env.linearize = 0; s.env.params = nullptr; s.env.dt = 0; s.env.u_max = 0;
     if (o && o->true_dynamics) set_env(s.env, o->true_dynamics);
     return s;
 }

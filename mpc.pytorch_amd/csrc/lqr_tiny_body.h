@@ -106,10 +106,17 @@ MPC_HD void sweep_problem(const StepParams<real> &p, int b, real *Kw, bool write
             q[i] = r + ci;
         }
         if (t < T - 1) {                               // Q = C + F'VF, q = c_back + F'v (:65-70)
-            const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
             real F[NS][N];
-            for (int m = 0; m < NS; ++m)
-                for (int j = 0; j < N; ++j) F[m][j] = Ft[m * N + j];
+            if (p.env.kind && p.env.linearize) {       // F_t = d simulator / d [x;u] at the nominal (mpc/mpc.py:490-549)
+                real nxt[NS > 5 ? NS : 5], J[NS * N > 30 ? NS * N : 30];   // (sized for either simulator)
+                env_step<real>(p.env, tau, tau[NS], nxt, J);
+                for (int m = 0; m < NS; ++m)
+                    for (int j = 0; j < N; ++j) F[m][j] = J[m * N + j];
+            } else {
+                const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb;
+                for (int m = 0; m < NS; ++m)
+                    for (int j = 0; j < N; ++j) F[m][j] = Ft[m * N + j];
+            }
             for (int j = 0; j < N; ++j) {
                 real Y[NS];                            // column j of V F
                 for (int m = 0; m < NS; ++m) {
@@ -224,7 +231,7 @@ MPC_HD void rollout_pass(const StepParams<real> &p, int b, const real *Kw, real 
             ca += (double)((real)0.5 * tau[i] * s + ct[i] * tau[i]);
         }
         if (t < T - 1) {
-            real xn[NS];
+            real xn[NS > 5 ? NS : 5];
             if (p.env.kind) {                                               // :223-225
                 env_step<real>(p.env, x, un, xn, nullptr);
             } else {                                                        // :216-222

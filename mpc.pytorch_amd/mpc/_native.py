@@ -33,7 +33,7 @@ class Problem(ctypes.Structure):
 
 
 class EnvDynamics(ctypes.Structure):
-    _fields_ = [("kind", _i32), ("_pad", _i32), ("params", _vp), ("dt", _f64), ("u_max", _f64)]
+    _fields_ = [("kind", _i32), ("linearize", _i32), ("params", _vp), ("dt", _f64), ("u_max", _f64)]
 
 
 class Options(ctypes.Structure):
@@ -50,8 +50,9 @@ class EnvSpec:
     """What a shipped simulator module hands to the kernels: kind (ENV_*), its parameter tensor,
     the integration step and the control clamp (mpc/env_dx/pendulum.py:23-37, cartpole.py:36-49)."""
 
-    def __init__(self, kind, params, dt, u_max):
+    def __init__(self, kind, params, dt, u_max, linearize=False):
         self.kind, self.params, self.dt, self.u_max = int(kind), params, float(dt), float(u_max)
+        self.linearize = bool(linearize)     # the step kernel linearises the simulator itself (F, f not passed)
         self.n_state = 5 if self.kind == ENV_CARTPOLE else 3
         self.n_ctrl = 1
 
@@ -59,6 +60,7 @@ class EnvSpec:
         prm = self.params.detach().to(device=like.device, dtype=like.dtype).contiguous()
         e = EnvDynamics()
         e.kind, e.params, e.dt, e.u_max = self.kind, prm.data_ptr(), self.dt, self.u_max
+        e.linearize = int(self.linearize)
         return e, prm
 
 
@@ -233,7 +235,7 @@ class HipBackend:
         xi = x_init.detach().contiguous(); keep.append(xi); p.x_init = xi.data_ptr()
         Cc, p.C_st, p.C_sb = _block_strided(C.detach(), 2); keep.append(Cc); p.C = Cc.data_ptr()
         cc, p.c_st, p.c_sb = _block_strided(c.detach(), 1); keep.append(cc); p.c = cc.data_ptr()
-        if T > 1:
+        if T > 1 and F is not None:
             Fc, p.F_st, p.F_sb = _block_strided(F.detach(), 2); keep.append(Fc); p.F = Fc.data_ptr()
         if f is not None and f.numel() > 0:
             fc, p.f_st, p.f_sb = _block_strided(f.detach(), 1); keep.append(fc); p.f = fc.data_ptr()

@@ -226,7 +226,7 @@ class MPC(Module):
         """The iLQR loop (mpc/mpc.py:245-306) when the whole iteration lives on the device: QuadCost with
         LinDx or a shipped simulator.  Inner iterations are never differentiated (the reference detaches
         them too).  Two pre-bound step plans ping-pong the nominal between two buffers, so an iteration is
-        one C call (plus the linearisation kernel for a simulator) -- no allocation, no autograd node.
+        one C call (a simulator is linearised inside that call) -- no allocation, no autograd node.
         The states of a rollout ARE get_traj of its controls (:251 recomputes them).
         The convergence flags of iteration i are read back while iteration i+1 already runs: the next
         step is launched speculatively and simply not used if the flags say stop."""
@@ -236,8 +236,9 @@ class MPC(Module):
         opts = self._step_options()
         if sim is not None:
             xa, _ = be.env_traj_cost(xi, ua, sim)                         # util.get_traj, :251
-            F = torch.empty(T - 1, n_batch, ns, ns + nc, dtype=xa.dtype, device=xa.device)
-            f = torch.empty(T - 1, n_batch, ns, dtype=xa.dtype, device=xa.device)
+            # linearize_dynamics (:490-549) happens inside the step kernel: no F, f round trip through memory
+            sim.linearize = True
+            F = f = None
             opts.true_dynamics = sim
         else:
             xa = util.get_traj(T, ua, x_init=xi, dynamics=dx).contiguous()
@@ -249,9 +250,6 @@ class MPC(Module):
         plans, noms = (pa, pb), ((xa, ua), (xb, ub))
 
         def launch(i):
-            if sim is not None:      # linearise around the nominal = the last rollout through the simulator
-                xn, un = noms[i % 2]
-                be.env_linearize(sim, xn[:-1].reshape(-1, ns), un[:-1].reshape(-1, nc), out_F=F, out_f=f)
             return plans[i % 2]()
 
         best = dict(x=torch.empty_like(xa), u=torch.empty_like(ua),

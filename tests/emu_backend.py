@@ -107,6 +107,7 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
         prm = np.ascontiguousarray(env[1], f32)
         keep.append(prm)
         e.kind, e.params, e.dt, e.u_max = int(env[0]), _ptr(prm), float(env[2]), float(env[3])
+        e.linearize = int(len(env) > 4 and bool(env[4]))
         keep.append(e)
         o.true_dynamics = ctypes.pointer(e)
     if kernel in ("mfma40_sweep", "mfma40"):

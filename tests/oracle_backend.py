@@ -38,6 +38,14 @@ class OracleBackend:
         assert rollout_problem is None, "oracle backend: split true-cost rollout not modelled"
         self.calls.append("lqr_step")
         T = C.shape[0]
+        env0 = getattr(opts, "true_dynamics", None)
+        if env0 is not None and getattr(env0, "linearize", False):      # the step linearises the simulator itself
+            self.calls.append("inline_linearize")
+            ns_, nc_ = x_init.shape[1], C.shape[2] - x_init.shape[1]
+            Fl, fl = E.linearize(env0.kind, _np(cur_x[:-1].reshape(-1, ns_)), _np(cur_u[:-1].reshape(-1, nc_)),
+                                 _np(env0.params).astype(np.float64))
+            F = self._t(Fl, C).view(T - 1, C.shape[1], ns_, ns_ + nc_)
+            f = self._t(fl, C).view(T - 1, C.shape[1], ns_)
         Fn = _np(F) if T > 1 else np.zeros((0, C.shape[1], x_init.shape[1], C.shape[2]), _np(C).dtype)
         o = O.lqr_step(_np(x_init), _np(C), _np(c), Fn, _np(f), _np(cur_x), _np(cur_u),
                        _bound(opts.u_lower), _bound(opts.u_upper), _np(opts.u_zero_I), opts.delta_u,

@@ -348,6 +348,14 @@ def test_tiny_body_rolls_out_through_the_simulator(emu, name, kind):
     np.testing.assert_allclose(r["new_x"], z["step_new_x"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(r["new_u"], z["step_new_u"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(r["costs"], z["step_costs"], rtol=1e-9)
+    # the same step with the linearisation done inside the kernel (F, f not even passed)
+    F0 = np.zeros_like(z["step_F"])
+    r2 = emu.lqr_step(z["x_init"], z["Q"], z["p"], F0, None, z["step_cur_x"], z["step_cur_u"],
+                      float(z["lower"][0]), float(z["upper"][0]), linesearch_decay=float(z["decay"][0]),
+                      max_linesearch_iter=int(z["max_ls"][0]), kernel="tiny", dtype=np.float64,
+                      env=(kind, z["params"], 0.05, 100.0 if kind == 3 else 2.0, True))
+    np.testing.assert_allclose(r2["new_x"], z["step_new_x"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(r2["new_u"], z["step_new_u"], rtol=1e-9, atol=1e-9)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -194,7 +194,7 @@ def test_ilqr_on_shipped_simulators_takes_the_kernel_path(kind, oracle_backend):
     np.testing.assert_allclose(costs.detach().numpy(), z["costs"], rtol=1e-5)
     np.testing.assert_allclose(x.detach().numpy(), z["x"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(u.detach().numpy(), z["u"], rtol=1e-4, atol=1e-4)
-    assert "env_linearize" in oracle_backend.calls and "lqr_sweep" not in oracle_backend.calls
+    assert "inline_linearize" in oracle_backend.calls and "lqr_sweep" not in oracle_backend.calls
 
 
 def test_shipped_simulator_modules_mirror_the_reference():
