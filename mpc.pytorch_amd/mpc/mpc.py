@@ -47,6 +47,9 @@ def _any_requires_grad(obj):
     return False
 
 
+_PINNED = {}
+
+
 class _FlagReader:
     """The two words the driver needs from the device per iteration (any problem improved, max ||du||),
     copied into pinned host memory asynchronously; `wait()` blocks on an event, not on the stream."""
@@ -57,7 +60,11 @@ class _FlagReader:
         self.device_flags = (self._dev[0:4].view(torch.int32), self._dev[8:8 + torch.empty(0, dtype=dtype).element_size()].view(dtype))
         self.cuda = device.type == "cuda"
         if self.cuda:
-            self._host = torch.zeros(16, dtype=torch.uint8).pin_memory()
+            # page-locking memory costs milliseconds: one block per device, kept for the life of the process
+            key = (device.type, device.index)
+            if key not in _PINNED:
+                _PINNED[key] = torch.zeros(16, dtype=torch.uint8).pin_memory()
+            self._host = _PINNED[key]
             self.host = (self._host[0:4].view(torch.int32), self._host[8:8 + self.device_flags[1].element_size()].view(dtype))
             self.event = torch.cuda.Event()
 
