@@ -17,13 +17,15 @@ from mpc._native import StepOptions
 from oracle import lqr_oracle as O
 be = _native.HipBackend()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+NS, NC, TT = (int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (12, 4, 50)
+IMPLS = [i for i in (1, 2, 3, 4, 5) if be.impl_supported(NS, NC, torch.float32, i)]
 bad = 0
 for case in ("unbounded", "bounded", "tensor_bounds", "delta_u", "tight"):
     for seed in range(4):
         u_scale, clamp = (0.0, None) if case == "unbounded" else (0.3, 1.0)
         if case == "tight":
             u_scale, clamp = 0.2, 0.3
-        p = bench.make_problem(12, 4, 50, B, torch.float32, "cuda:0", seed=100 + seed, u_scale=u_scale, clamp=clamp)
+        p = bench.make_problem(NS, NC, TT, B, torch.float32, "cuda:0", seed=100 + seed, u_scale=u_scale, clamp=clamp)
         h = {k: v.cpu().numpy().astype(np.float64) for k, v in p.items()}
         kw = {}
         if case == "bounded":
@@ -32,7 +34,7 @@ for case in ("unbounded", "bounded", "tensor_bounds", "delta_u", "tight"):
             kw = dict(u_lower=-0.3, u_upper=0.3)
         elif case == "tensor_bounds":
             g = torch.Generator().manual_seed(seed)
-            lo = (-1.0 - torch.rand(50, B, 4, generator=g)).cuda(); hi = (1.0 + torch.rand(50, B, 4, generator=g)).cuda()
+            lo = (-1.0 - torch.rand(TT, B, NC, generator=g)).cuda(); hi = (1.0 + torch.rand(TT, B, NC, generator=g)).cuda()
             kw = dict(u_lower=lo, u_upper=hi)
         elif case == "delta_u":
             kw = dict(u_lower=-1.0, u_upper=1.0, delta_u=0.25)
@@ -40,7 +42,7 @@ for case in ("unbounded", "bounded", "tensor_bounds", "delta_u", "tight"):
         o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], okw.get("u_lower"), okw.get("u_upper"),
                        delta_u=okw.get("delta_u"), lockstep=False, nthreads=O.max_threads(), return_gains=True)
         opat = (o["K"] == 0).all(axis=-1)
-        for impl in (1, 2, 3):
+        for impl in IMPLS:
             r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions(**kw), impl=impl,
                             want_gains=True)
             torch.cuda.synchronize()
