@@ -171,20 +171,6 @@ template <typename real> __device__ void lu_solve_aug(real *A, int nr, int ncols
     __syncthreads();
 }
 
-// 0.5 x'Hx + q'x with H given as (pointer, leading dim); every thread computes it.
-template <typename real>
-__device__ real qp_obj(const real *H, int ld, const real *q, const real *x, int n)
-{
-    real quad = 0, lin = 0;
-    for (int i = 0; i < n; ++i) {
-        real r = 0;
-        for (int j = 0; j < n; ++j) r += H[i * ld + j] * x[j];
-        quad += x[i] * r;
-        lin += q[i] * x[i];
-    }
-    return (real)0.5 * quad + lin;
-}
-
 // Projected-Newton box QP for ONE problem (mpc/pnqp.py:5-82 with n_batch = 1):
 //   min 0.5 x'Hx + q'x  s.t. lb <= x <= ub.
 // H (n x n, leading dim ldH) and qv may live in LDS or global memory.  `rhs`

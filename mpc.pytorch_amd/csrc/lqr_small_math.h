@@ -85,20 +85,6 @@ MPC_DEV float eclampf(float x, float lo, float hi)
     return x;
 }
 
-MPC_DEV float qp_obj4(const Sym4 &s, const float q[4], const float x[4])
-{
-    float hx[4];
-    sym4_mv(s, x, hx);
-    const float quad = fmaf(x[3], hx[3], fmaf(x[2], hx[2], fmaf(x[1], hx[1], x[0] * hx[0])));
-    const float lin = fmaf(q[3], x[3], fmaf(q[2], x[2], fmaf(q[1], x[1], q[0] * x[0])));
-    return fmaf(0.5f, quad, lin);
-}
-// the same objective when g = Hx + q is already at hand:  0.5 x'Hx + q'x = 0.5 x'(g + q)
-MPC_DEV float qp_obj4_from_grad(const float g[4], const float q[4], const float x[4])
-{
-    return 0.5f * fmaf(x[3], g[3] + q[3], fmaf(x[2], g[2] + q[2], fmaf(x[1], g[1] + q[1], x[0] * (g[0] + q[0]))));
-}
-
 // Projected-Newton box QP in n_ctrl <= 4 unknowns on wave-uniform values
 // (mpc/pnqp.py:5-82 with n_batch = 1).  x holds the clamped start on entry and the
 // solution on exit; fr/f are the free set and factorisation the reference returns
