@@ -141,6 +141,7 @@ class MPC(Module):
         self.not_improved_lim = not_improved_lim
         self.best_cost_eps = best_cost_eps
         self.slew_rate_penalty = slew_rate_penalty
+        self.flag_reducer = None     # set by mpc.shard for lock-step sharded solves
         self.prev_ctrl = prev_ctrl
 
     # ------------------------------------------------------------------------------------------
@@ -272,6 +273,8 @@ class MPC(Module):
             reader.start()
             nxt = launch(i + 1) if i + 1 < self.lqr_iter else None        # overlaps the read-back
             any_improved, max_du_norm = reader.wait()
+            if self.flag_reducer is not None:          # shards agree on the batch-wide stop test (mpc.shard)
+                any_improved, max_du_norm = self.flag_reducer(any_improved, max_du_norm)
             n_not_improved += 1
             if any_improved:
                 n_not_improved = 0
@@ -317,7 +320,9 @@ class MPC(Module):
             any_improved, max_du = be.select_best(first, self.best_cost_eps, x.contiguous(), u.contiguous(),
                                                   costs, full_du_norm, best)
             flags = torch.stack((any_improved[0].to(max_du.dtype), max_du[0])).tolist()   # the one sync
-            if flags[0] != 0:
+            if self.flag_reducer is not None:
+                flags = list(self.flag_reducer(flags[0] != 0, flags[1]))
+            if flags[0]:
                 n_not_improved = 0
             max_du_norm = flags[1]
             if self.verbose > 0:

@@ -4,8 +4,11 @@ Every tensor of the problem carries the batch as its 2nd axis (1st for x_init) a
 mixes problems, so rank r of R simply owns a contiguous block of problems: it solves its block with
 the local kernels (no data-path collective) and ONE all-gather reassembles the trajectories
 (new_x || new_u, plus the per-problem scalars).  Gradients (dC, dF, ...) stay sharded like their
-inputs.  The three batch-global loops of the reference (line search, pnqp, outer iLQR stop test --
-SURVEY.md section 8e) are per-problem in the kernels, so shards never need to agree on a trip count.
+inputs.  Two of the three batch-global loops of the reference (line search, pnqp -- SURVEY.md section 8e) are
+per-problem in the kernels, so shards never need to agree on their trip counts.  The third, the outer iLQR
+stop test (max_b full_du_norm < eps, "no problem improved" counter; mpc/mpc.py:271-306), is per shard by
+default; `mpc_forward_sharded(..., lockstep=True)` all-reduces its two words per iteration so that every
+shard performs exactly the iterations the reference would perform on the whole batch.
 """
 import torch
 
@@ -72,3 +75,55 @@ def lqr_step_sharded(x_init, C, c, F, f, cur_x, cur_u, opts, group=None, gather=
     ns = r["new_x"].shape[2]
     return dict(new_x=packed[:T, :, :ns], new_u=packed[:T, :, ns:], costs=packed[T, :, 0],
                 full_du_norm=packed[T + 1, :, 0], alphas=packed[T + 2, :, 0], local=r, block=(lo, hi))
+
+
+def lockstep_reducer(group=None):
+    """(any_improved, max_du) of this shard -> of the whole batch: one 2-word all-reduce (MAX) per iteration."""
+    import torch.distributed as dist
+
+    def reduce(any_improved, max_du):
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor([1.0 if any_improved else 0.0, float("inf") if max_du != max_du else max_du],
+                         dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return bool(t[0].item() > 0), float(t[1].item())
+    return reduce
+
+
+def mpc_forward_sharded(ctrl, x_init, cost, dx, group=None, lockstep=False, gather=True):
+    """`ctrl(x_init, cost, dx)` (an mpc.MPC) on this rank's block of the batch; with `gather`, every rank returns
+    the full (x, u, costs) after one all-gather.  All ranks pass the same full-batch QuadCost / LinDx (or a
+    dynamics module); tensor-valued bounds, u_init, u_zero_I of `ctrl` are cut along the batch axis.
+    The returned local block keeps its autograd graph (`local`), the gathered tensors are plain data."""
+    import copy
+    import torch.distributed as dist
+    from .mpc import QuadCost, LinDx
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B = x_init.shape[0]
+    lo, hi = shard_bounds(B, rank, world)
+    local = copy.copy(ctrl)
+    for name, dim in (("u_lower", 1), ("u_upper", 1), ("u_zero_I", 1), ("u_init", 1), ("prev_ctrl", 0)):
+        v = getattr(ctrl, name, None)
+        if torch.is_tensor(v) and v.dim() > dim and v.shape[dim] == B:
+            setattr(local, name, _cut(v, lo, hi, dim))
+    if ctrl.n_batch is not None:
+        local.n_batch = hi - lo
+    local.flag_reducer = lockstep_reducer(group) if (lockstep and world > 1) else None
+
+    def cut_field(t, inner):          # batch axis of a cost / dynamics tensor: the one before its `inner` trailing axes
+        if t is None or not torch.is_tensor(t) or t.dim() <= inner:
+            return t
+        return _cut(t, lo, hi, t.dim() - inner - 1) if t.shape[t.dim() - inner - 1] == B else t
+    if isinstance(cost, QuadCost):
+        cost = QuadCost(cut_field(cost.C, 2), cut_field(cost.c, 1))
+    if isinstance(dx, LinDx):
+        dx = LinDx(cut_field(dx.F, 2), cut_field(dx.f, 1))
+    x, u, costs = local(_cut(x_init, lo, hi, 0), cost, dx)
+    if world == 1 or not gather:
+        return x, u, costs
+    T = x.shape[0]
+    tau = torch.cat((x.detach(), u.detach()), 2)
+    packed = all_gather_batch(torch.cat((tau, costs.detach().view(1, -1, 1).expand(1, hi - lo, tau.shape[2])), 0), B, 1, group)
+    ns = x.shape[2]
+    return packed[:T, :, :ns], packed[:T, :, ns:], packed[T, :, 0]

@@ -73,3 +73,62 @@ def test_shard_bounds_cover_the_batch():
             assert cuts[0][0] == 0 and cuts[-1][1] == B
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+
+
+def _mpc_worker(rank, world, port, lockstep, out_dir):
+    for p in (os.path.join(ROOT, "mpc.pytorch_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from mpc import _native, mpc, shard
+    from mpc.mpc import LinDx, QuadCost
+    from oracle_backend import OracleBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _native.set_backend_for_testing(OracleBackend())
+    g = torch.Generator().manual_seed(1)
+    T, ns, nc, B = 5, 3, 2, 5
+    n = ns + nc
+    A = torch.randn(T, B, n, n, generator=g, dtype=torch.float64)
+    C = A.transpose(2, 3).matmul(A)
+    c = torch.randn(T, B, n, generator=g, dtype=torch.float64)
+    F = torch.cat((torch.eye(ns).double() + 0.1 * torch.randn(T - 1, B, ns, ns, generator=g, dtype=torch.float64),
+                   torch.randn(T - 1, B, ns, nc, generator=g, dtype=torch.float64)), 3)
+    x_init = torch.randn(B, ns, generator=g, dtype=torch.float64)
+    lo = -torch.rand(T, B, nc, generator=g, dtype=torch.float64)
+    hi = torch.rand(T, B, nc, generator=g, dtype=torch.float64)
+    iters = []
+
+    class Counting(OracleBackend):
+        def select_best(self, *a, **k):
+            iters.append(1)
+            return super().select_best(*a, **k)
+    _native.set_backend_for_testing(Counting())
+    ctrl = mpc.MPC(ns, nc, T, u_lower=lo, u_upper=hi, lqr_iter=30, verbose=-1, exit_unconverged=False, eps=1e-6)
+    x, u, costs = shard.mpc_forward_sharded(ctrl, x_init, QuadCost(C, c), LinDx(F), lockstep=lockstep)
+    n_shard = len(iters)
+    del iters[:]
+    xr, ur, cr = ctrl(x_init, QuadCost(C, c), LinDx(F))              # the whole batch on one rank
+    np.savez(os.path.join(out_dir, "mpc_rank%d.npz" % rank), x=x.numpy(), u=u.numpy(), costs=costs.numpy(),
+             xr=xr.detach().numpy(), ur=ur.detach().numpy(), cr=cr.detach().numpy(), n_shard=n_shard, n_full=len(iters))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lockstep", [False, True])
+def test_sharded_mpc_forward(tmp_path, lockstep):
+    """MPC.forward over two ranks (blocks of 3 and 2 problems): same trajectories as the whole batch on one
+    rank; in lock-step mode the shards also run exactly the iterations of the whole-batch solve (the
+    batch-wide stop test of mpc/mpc.py:299 is all-reduced), otherwise each shard stops on its own."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000) + int(lockstep)
+    mp.spawn(_mpc_worker, args=(world, port, lockstep, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(os.path.join(str(tmp_path), "mpc_rank%d.npz" % r)) for r in range(world)]
+    for g in got:
+        np.testing.assert_allclose(g["u"], g["ur"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(g["x"], g["xr"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(g["costs"], g["cr"], rtol=1e-6)
+    np.testing.assert_array_equal(got[0]["u"], got[1]["u"])            # every rank holds the gathered result
+    if lockstep:
+        assert int(got[0]["n_shard"]) == int(got[1]["n_shard"]) == int(got[0]["n_full"])
