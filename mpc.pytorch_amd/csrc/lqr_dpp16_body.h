@@ -208,6 +208,24 @@ MPC_DEV unsigned zm_load(const P &p, const Lane &L, int t)
 // ---------------------------------------------------------------------------
 // Sweep
 // ---------------------------------------------------------------------------
+// acc[4I .. 4I+3] (lane j) += a[lane 4I+v] * b[lane j]: rows 4I..4I+3 of the outer product a b'
+template <int I, int N>
+MPC_DEV void outer_rows(float (&acc)[N], float a, float b)
+{
+    f32x4 c = {acc[4 * I], acc[4 * I + 1], acc[4 * I + 2], acc[4 * I + 3]};
+    c = wv::mfma4<I>(a, b, c);
+    acc[4 * I] = c[0]; acc[4 * I + 1] = c[1]; acc[4 * I + 2] = c[2]; acc[4 * I + 3] = c[3];
+}
+// acc (12 or 16 rows, lane j = column j) += a b'
+template <int N>
+MPC_DEV void outer_acc(float (&acc)[N], float a, float b)
+{
+    outer_rows<0>(acc, a, b);
+    outer_rows<1>(acc, a, b);
+    outer_rows<2>(acc, a, b);
+    if (N == 16) outer_rows<(N == 16 ? 3 : 0)>(acc, a, b);
+}
+
 struct SwStage {
     float Cc[16];
     float Fc[12];
@@ -278,14 +296,15 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     for (int i = 0; i < 16; ++i) Q[i] = s.Cc[i];
     if (!last) {
         // Y = V F, Q = C + F'Y, q = c_back + F'v   (:65-70)
+        // as sums of outer products on the matrix core: Y = sum_m V[:,m] F[m,:]  (V symmetric: lane i holds
+        // V[m][i] = V[i][m] in Vc[m]),  Q += sum_m F[m,:]' Y[m,:]
         float Y[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) Y[i] = 0.f;
-        wv::fma_bcast_lane12x2<0>(Y, st.Vc, s.Fc[0], s.Fc[1]);   wv::fma_bcast_lane12x2<2>(Y, st.Vc, s.Fc[2], s.Fc[3]);
-        wv::fma_bcast_lane12x2<4>(Y, st.Vc, s.Fc[4], s.Fc[5]);   wv::fma_bcast_lane12x2<6>(Y, st.Vc, s.Fc[6], s.Fc[7]);
-        wv::fma_bcast_lane12x2<8>(Y, st.Vc, s.Fc[8], s.Fc[9]);   wv::fma_bcast_lane12x2<10>(Y, st.Vc, s.Fc[10], s.Fc[11]);
 #pragma unroll
-        for (int m = 0; m < 12; m += 2) wv::fma_bcast_each16x2(Q, s.Fc[m], Y[m], s.Fc[m + 1], Y[m + 1]);
+        for (int m = 0; m < 12; ++m) outer_acc(Y, st.Vc[m], s.Fc[m]);
+#pragma unroll
+        for (int m = 0; m < 12; ++m) outer_acc(Q, s.Fc[m], Y[m]);
         wv::dot_bcast12(q, st.vv, s.Fc);
     }
 
@@ -371,8 +390,8 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     float Vn[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Vn[i] = Q[i];
-    wv::fma_bcast_lane12x2<12>(Vn, Q, K[0], K[1]);      // += Q[i][12+a] K[a][j]
-    wv::fma_bcast_lane12x2<14>(Vn, Q, K[2], K[3]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) outer_acc(Vn, Q[12 + a], K[a]);      // += Qux[a][i] K[a][j]  (Qux = Qxu')
     float vn = q;
     wv::fmac_bcast<12>(vn, K[0], Q[12]); wv::fmac_bcast<12>(vn, K[1], Q[13]);
     wv::fmac_bcast<12>(vn, K[2], Q[14]); wv::fmac_bcast<12>(vn, K[3], Q[15]);
@@ -385,7 +404,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         M[3] = fmaf(S.s33, K[3], fmaf(S.s23, K[2], fmaf(S.s13, K[1], fmaf(S.s03, K[0], rhs[3]))));
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            wv::fma_bcast_each12(Vn, K[a], M[a]);          // += K[a][i] M[a][j]
+            outer_acc(Vn, K[a], M[a]);                     // += K[a][i] M[a][j]
             wv::fmac_bcast<12>(vn, M[a], K[a]);            // += K[a][j] m[a]
         }
     }

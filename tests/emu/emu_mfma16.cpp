@@ -159,6 +159,17 @@ static inline unsigned long long ballot(bool c)
     return m;
 }
 static inline float rcp(float x) { return 1.0f / x; }
+// v_mfma_f32_4x4x1_16b_f32 cbsz:2 abid:ABID (lqr_dpp16_body.h): rows 4*ABID..+3 of a per-row outer product
+template <int ABID> static inline f32x4 mfma4(float a, float b, f32x4 c)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = a;
+    emu::yield_lane();
+    f32x4 d;
+    for (int v = 0; v < 4; ++v) d[v] = fmaf(w.fa[gen][(l & ~15) + 4 * ABID + v], b, c[v]);
+    return d;
+}
 // ---- DPP row_newbcast family (lqr_dpp16_body.h): lane N of the caller's 16-lane row -------------
 template <int N> static inline float bcast(float x)
 {
