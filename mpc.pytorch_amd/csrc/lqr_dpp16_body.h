@@ -64,6 +64,18 @@ enum {
 // DMA instructions of one rollout stage: F, record, gains (+ C when priced directly, + (m, M) otherwise
 // when constraints are present)
 template <int MODE, bool DIRECT> struct RollDma { enum { N = 3 + 1 + 1 + (DIRECT ? 4 : (MODE != 0 ? 1 : 0)) }; };
+// The identity-priced rollout does not stage C: its stage is F | record | gains (| (m, M)) = 5 (6) KiB, packed
+// back to back so the same LDS holds 7 (6) stages instead of 4 and the DMA runs 6 (5) timesteps ahead -- a
+// rollout step is ~0.45 us, four-deep staging would leave the loads less than an HBM round trip under load.
+// Block offsets stay those of the sweep's stage (SF, SR, SG) relative to a base biased by -SF.
+template <int MODE, bool DIRECT> struct RollRing {
+    enum {
+        BYTES = DIRECT ? (int)STAGE_BYTES : (MODE != 0 ? 6144 : 5120),
+        SLOTS = DIRECT ? (int)NSTAGE : (int)LDS_TOTAL / (MODE != 0 ? 6144 : 5120),
+        BIAS = DIRECT ? 0 : (int)SF,
+        MREC = DIRECT ? (int)SC : (int)SG + 1024       // where the (m, M) record goes
+    };
+};
 
 struct Lane {
     int lane, p, j;       // problem slot in the wave, variable
@@ -80,7 +92,9 @@ struct Lane {
     int aRecF;            // SR + p*256 + R_f + 4 min(j, 11)
     int aKrow;            // SG + p*256 + 4 a                   (+16 jj: K[a][jj]; +192: k_a)
     int aS[4];            // SG + p*256 + 208 + 4 tri(a, b)     (Quu[a][b] of the packed upper triangle)
-    int aMrow;            // SC + p*256 + 4 a                   (second record, overlays the unused C slot)
+    float *out0;          // this lane's element of new_x / new_u at t = 0 ...
+    long ostep;           // ... and its stride per timestep
+    int aMrow;            // SC + p*256 + 4 a                   (second record, relative to RollRing::MREC - SC)
 };
 
 MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
@@ -175,7 +189,8 @@ MPC_DEV void dma_init(Dma &d, const P &p, const Lane &L, int wave)
 template <int MODE, bool ROLL, bool DIRECT>
 MPC_DEV void stage_issue(const P &p, const Dma &d, int t, int slot)
 {
-    const unsigned base = (unsigned)slot * STAGE_BYTES;
+    const unsigned base = ROLL ? (unsigned)(slot * (int)RollRing<MODE, DIRECT>::BYTES - (int)RollRing<MODE, DIRECT>::BIAS)
+                               : (unsigned)slot * STAGE_BYTES;
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);     // F / f have T-1 entries
     if (!ROLL || DIRECT) {
@@ -195,7 +210,7 @@ MPC_DEV void stage_issue(const P &p, const Dma &d, int t, int slot)
     }
     if (ROLL) {
         wv::dma16(d.g_ptr + tl * d.g_step, base + SG);
-        if (!DIRECT && MODE != 0) wv::dma16(d.g2_ptr + tl * d.g_step, base + SC);
+        if (!DIRECT && MODE != 0) wv::dma16(d.g2_ptr + tl * d.g_step, base + RollRing<MODE, DIRECT>::MREC);
     }
 }
 
@@ -243,13 +258,9 @@ MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, uns
         const f32x4 v = wv::lds_f32x4(base + L.aCrow + 16 * q);
         s.Cc[4 * q] = v[0]; s.Cc[4 * q + 1] = v[1]; s.Cc[4 * q + 2] = v[2]; s.Cc[4 * q + 3] = v[3];
     }
-    if (t < p.T - 1) {
+    // at t = T-1 the F slot holds a copy of F[T-2] (stage_issue clamps the index) and nothing looks at it
 #pragma unroll
-        for (int m = 0; m < 12; ++m) s.Fc[m] = wv::lds_f32(base + L.aFcol + 64 * m);
-    } else {
-#pragma unroll
-        for (int m = 0; m < 12; ++m) s.Fc[m] = 0.f;
-    }
+    for (int m = 0; m < 12; ++m) s.Fc[m] = wv::lds_f32(base + L.aFcol + 64 * m);
     s.cj = wv::lds_f32(base + L.aRec + R_c);
     s.tb = wv::lds_f32(base + L.aRec + R_tau);
 #pragma unroll
@@ -298,9 +309,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         // Y = V F, Q = C + F'Y, q = c_back + F'v   (:65-70)
         // as sums of outer products on the matrix core: Y = sum_m V[:,m] F[m,:]  (V symmetric: lane i holds
         // V[m][i] = V[i][m] in Vc[m]),  Q += sum_m F[m,:]' Y[m,:]
-        float Y[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) Y[i] = 0.f;
+        float Y[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // folds into the first products' srcC
 #pragma unroll
         for (int m = 0; m < 12; ++m) outer_acc(Y, st.Vc[m], s.Fc[m]);
 #pragma unroll
@@ -462,7 +471,8 @@ struct RoStage {
 template <int MODE, bool DIRECT>
 MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, unsigned zm)
 {
-    const unsigned base = (unsigned)slot * STAGE_BYTES;
+    const unsigned base = (unsigned)(slot * (int)RollRing<MODE, DIRECT>::BYTES - (int)RollRing<MODE, DIRECT>::BIAS);
+    const unsigned mrec = base + (RollRing<MODE, DIRECT>::MREC - SC);
     s.cj = 0.f;
     s.mk = 0.f;
     if (DIRECT) {
@@ -477,22 +487,17 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
         for (int b = 0; b < 4; ++b) s.Sr[b] = wv::lds_f32(base + L.aS[b]);
         if (MODE != 0) {
 #pragma unroll
-            for (int jj = 0; jj < 12; ++jj) s.Mr[jj] = wv::lds_f32(base + L.aMrow + 16 * jj);
-            s.mk = wv::lds_f32(base + L.aMrow + 192);
+            for (int jj = 0; jj < 12; ++jj) s.Mr[jj] = wv::lds_f32(mrec + L.aMrow + 16 * jj);
+            s.mk = wv::lds_f32(mrec + L.aMrow + 192);
         }
     }
-    if (t < p.T - 1) {
+    // (t = T-1: a copy of F[T-2], unused)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = wv::lds_f32x4(base + L.aFrow + 16 * q);
-            s.Fr[4 * q] = v[0]; s.Fr[4 * q + 1] = v[1]; s.Fr[4 * q + 2] = v[2]; s.Fr[4 * q + 3] = v[3];
-        }
-        s.fj = p.f ? wv::lds_f32(base + L.aRecF) : 0.f;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s.Fr[i] = 0.f;
-        s.fj = 0.f;
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = wv::lds_f32x4(base + L.aFrow + 16 * q);
+        s.Fr[4 * q] = v[0]; s.Fr[4 * q + 1] = v[1]; s.Fr[4 * q + 2] = v[2]; s.Fr[4 * q + 3] = v[3];
     }
+    s.fj = p.f ? wv::lds_f32(base + L.aRecF) : 0.f;
 #pragma unroll
     for (int jj = 0; jj < 12; ++jj) s.Kr[jj] = wv::lds_f32(base + L.aKrow + 16 * jj);
     s.kk = wv::lds_f32(base + L.aKrow + 192);
@@ -573,11 +578,7 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
         const float d = s.tb - un;
         st.du2 = fmaf(d, d, st.du2);
     }
-    if (L.live) {
-        const long tb = (long)t * p.B + L.pb;
-        if (L.isu) wv::store_out(p.new_u + tb * 4 + L.a, tp);
-        else wv::store_out(p.new_x + tb * 12 + L.j, tp);
-    }
+    if (L.live) wv::store_out(L.out0 + t * L.ostep, tp);        // new_u (control lanes) / new_x: one store
     if (!DIRECT) {
         // does the nominal obey x_t = F tau_{t-1} + f_{t-1}?  (the identity above assumes it)
         if (t > 0 && !L.isu) {
@@ -645,24 +646,28 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st, 
         st.pred = 0.f;
     }
     const bool use_zm = MODE != 0 && p.zero_mask != nullptr;
-    unsigned zq[NSTAGE] = {0u, 0u, 0u, 0u};
+    enum { NS = RollRing<MODE, DIRECT>::SLOTS, LA = NS - 1, ND = RollDma<MODE, DIRECT>::N };
+    static_assert((LA - 1) * ND + 2 * LA < 64, "vmcnt is 6 bits");
+    unsigned zq[NS];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NS; ++i) zq[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
         const int ti = i < T ? i : T - 1;
         stage_issue<MODE, true, DIRECT>(p, d, ti, i);
         if (use_zm) zq[i] = zm_load(p, L, ti);
     }
-    for (int t0 = 0; t0 < T; t0 += NSTAGE) {
+    for (int t0 = 0; t0 < T; t0 += NS) {
 #pragma unroll
-        for (int i = 0; i < NSTAGE; ++i) {
+        for (int i = 0; i < NS; ++i) {
             const int t = t0 + i;
             if (t < T) {
-                wv::dma_wait<2 * RollDma<MODE, DIRECT>::N>();
+                wv::dma_wait<(LA - 1) * ND>();
                 RoStage s;
                 ro_read<MODE, DIRECT>(s, p, L, t, i, zq[i]);
-                const int tn = t + 3 < T ? t + 3 : T - 1;
-                stage_issue<MODE, true, DIRECT>(p, d, tn, (i + 3) % NSTAGE);
-                if (use_zm) zq[(i + 3) % NSTAGE] = zm_load(p, L, tn);
+                const int tn = t + LA < T ? t + LA : T - 1;
+                stage_issue<MODE, true, DIRECT>(p, d, tn, (i + LA) % NS);
+                if (use_zm) zq[(i + LA) % NS] = zm_load(p, L, tn);
                 if (MULTI) trials_step<MODE, DIRECT>(p, L, s, tr, nt, t);
                 else rollout_step<MODE, DIRECT>(p, L, s, st, t);
             }
@@ -730,6 +735,8 @@ MPC_DEV void step_wave(const P &p)
     if (4 * wave >= p.B) return;
     Lane L;
     lane_init(L, lane, wave, p.B);
+    L.out0 = L.isu ? p.new_u + (long)L.pb * 4 + L.a : p.new_x + (long)L.pb * 12 + L.j;
+    L.ostep = L.isu ? (long)p.B * 4 : (long)p.B * 12;
     const int T = p.T;
     Dma d;
     dma_init<MODE>(d, p, L, wave);
