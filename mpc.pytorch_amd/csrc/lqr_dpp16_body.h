@@ -923,9 +923,9 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
                 const long tb = (long)t * p.B + L.pb;
                 // dF_t, df_t from the costates of t+1
                 if (have) {
-                    float row[16];
-                    wv::mul_bcast_each16(row, tj, -dlam);
-                    wv::fma_bcast_each16(row, dj, -lam);
+                    float row[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    outer_acc(row, tj, -dlam);            // row j of -(dlam tau' + lam dtau'): two outer products
+                    outer_acc(row, dj, -lam);
                     if (L.live && L.j < 12) {
                         float *dst = k.dF + (tb * 12 + L.j) * 16;
 #pragma unroll
@@ -936,9 +936,9 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
                 }
                 // dC_t (row j), dc_t
                 {
-                    float row[16];
-                    wv::mul_bcast_each16(row, tj, -0.5f * dj);
-                    wv::fma_bcast_each16(row, dj, -0.5f * tj);
+                    float row[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    outer_acc(row, tj, -0.5f * dj);
+                    outer_acc(row, dj, -0.5f * tj);
                     if (L.live) {
                         float *dst = k.dC + (tb * 16 + (L.j < 12 ? L.j : 12 + L.a)) * 16;
 #pragma unroll
