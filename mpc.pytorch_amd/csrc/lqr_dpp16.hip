@@ -347,6 +347,21 @@ MPC_DEV void dma16_if(bool active, const void *g, unsigned off)
 {
     if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, 0);
 }
+// The immediate offset of an LDS-DMA moves the LDS destination together with the global source
+// (tools/ubench/dma_offset_probe.hip).  With the source pointer biased by -IMM once, at set-up, every DMA of a
+// stage names the same LDS anchor `mid` and differs only in IMM: one M0 write per stage instead of one per
+// instruction.  `g` is the biased pointer (true source - IMM), -4096 <= IMM < 4096.
+enum { DMA_PLAIN = 0, DMA_C = 1, DMA_LAST = 2 };
+template <int IMM, int KIND = DMA_PLAIN> MPC_DEV void dma16_at(const void *g, unsigned mid)
+{
+    static_assert(IMM >= -4096 && IMM < 4096, "13-bit signed immediate");
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + mid), 16, IMM,
+                                     KIND == DMA_C ? MPC_DPP16_C_AUX : (KIND == DMA_LAST ? MPC_DPP16_FR_AUX : 0));
+}
+template <int IMM> MPC_DEV void dma16_at_if(bool active, const void *g, unsigned mid)
+{
+    if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + mid), 16, IMM, 0);
+}
 MPC_DEV float lds_f32(unsigned off) { return *(const float *)(g_stage16 + off); }
 MPC_DEV f32x4 lds_f32x4(unsigned off) { return *(const f32x4 *)(g_stage16 + off); }
 MPC_DEV void store_f32x4(float *g, f32x4 v) { *(f32x4 *)g = v; }

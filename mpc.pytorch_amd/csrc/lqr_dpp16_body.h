@@ -64,18 +64,27 @@ enum {
 // DMA instructions of one rollout stage: F, record, gains (+ C when priced directly, + (m, M) otherwise
 // when constraints are present)
 template <int MODE, bool DIRECT> struct RollDma { enum { N = 3 + 1 + 1 + (DIRECT ? 4 : (MODE != 0 ? 1 : 0)) }; };
-// The identity-priced rollout does not stage C: its stage is F | record | gains (| (m, M)) = 5 (6) KiB, packed
+// The identity-priced rollout does not stage C: its stage is [(m, M)] | gains | F | record = 5 (6) KiB, packed
 // back to back so the same LDS holds 7 (6) stages instead of 4 and the DMA runs 6 (5) timesteps ahead -- a
 // rollout step is ~0.45 us, four-deep staging would leave the loads less than an HBM round trip under load.
-// Block offsets stay those of the sweep's stage (SF, SR, SG) relative to a base biased by -SF.
+// Every stage is addressed from its F block (`mid`): the sweep's C sits at mid-4096, the record at mid+3072,
+// the packed rollout's gains at mid-1024 and (m, M) at mid-2048; a rollout that prices directly keeps the
+// sweep's 9 KiB layout with the gains behind the record.
 template <int MODE, bool DIRECT> struct RollRing {
     enum {
         BYTES = DIRECT ? (int)STAGE_BYTES : (MODE != 0 ? 6144 : 5120),
         SLOTS = DIRECT ? (int)NSTAGE : (int)LDS_TOTAL / (MODE != 0 ? 6144 : 5120),
-        BIAS = DIRECT ? 0 : (int)SF,
-        MREC = DIRECT ? (int)SC : (int)SG + 1024       // where the (m, M) record goes
+        FOFF = DIRECT ? (int)SF : (MODE != 0 ? 2048 : 1024),        // F block inside a slot
+        GADJ = DIRECT ? 0 : (int)SF - 1024 - (int)SG,                // gains / (m, M) relative to the lane offsets,
+        MADJ = DIRECT ? 0 : (int)SF - 2048 - (int)SC                 // which are written for the sweep's layout
     };
 };
+// anchor of ring slot `slot`, and the base the lane offsets (SC / SF / SR / SG relative) apply to
+template <int MODE, bool ROLL, bool DIRECT> MPC_DEV unsigned stage_mid(int slot)
+{
+    return ROLL ? (unsigned)(slot * (int)RollRing<MODE, DIRECT>::BYTES + (int)RollRing<MODE, DIRECT>::FOFF)
+                : (unsigned)(slot * (int)STAGE_BYTES + (int)SF);
+}
 
 struct Lane {
     int lane, p, j;       // problem slot in the wave, variable
@@ -94,7 +103,7 @@ struct Lane {
     int aS[4];            // SG + p*256 + 208 + 4 tri(a, b)     (Quu[a][b] of the packed upper triangle)
     float *out0;          // this lane's element of new_x / new_u at t = 0 ...
     long ostep;           // ... and its stride per timestep
-    int aMrow;            // SC + p*256 + 4 a                   (second record, relative to RollRing::MREC - SC)
+    int aMrow;            // SC + p*256 + 4 a                   (second record; + RollRing::MADJ)
 };
 
 MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
@@ -132,11 +141,12 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
 //   gains (rollout): problem slot l>>4, granule l&15 of the wave's own record Kk[t][b][16][4]
 // ---------------------------------------------------------------------------
 struct Dma {
-    const char *c_ptr[4];     // wave-uniform per problem slot
-    const char *f_ptr[3];     // per lane
-    const char *r_ptr;        // per lane
-    const char *g_ptr;        // per lane
-    const char *g2_ptr;       // per lane: the (m, M) record
+    // all biased by minus the immediate their instruction carries (see wv::dma16_at)
+    const char *c_ptr[4];     // wave-uniform per problem slot        imm 1024 k - 4096
+    const char *f_ptr[3];     // per lane                             imm 1024 k
+    const char *r_ptr;        // per lane                             imm 3072
+    const char *g_ptr;        // per lane                             imm -1024 (packed rollout)
+    const char *g2_ptr;       // per lane: the (m, M) record          imm -2048 (packed rollout)
     long c_step, f_step, r_step, g_step;
     bool r_active, r_is_f, r_is_c;
 };
@@ -148,7 +158,7 @@ MPC_DEV void dma_init(Dma &d, const P &p, const Lane &L, int wave)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int pbk = 4 * wave + k < p.B ? 4 * wave + k : p.B - 1;
-        d.c_ptr[k] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * L.lane;
+        d.c_ptr[k] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * L.lane - (1024 * k - 4096);
     }
     d.c_step = 4 * p.C_st;
 #pragma unroll
@@ -156,7 +166,7 @@ MPC_DEV void dma_init(Dma &d, const P &p, const Lane &L, int wave)
         const int G = 64 * k + L.lane;
         const int slot = G / 48, gi = G - 48 * slot;
         const int pbk = 4 * wave + slot < p.B ? 4 * wave + slot : p.B - 1;
-        d.f_ptr[k] = p.T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) + 16 * gi : (const char *)p.C;
+        d.f_ptr[k] = (p.T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) + 16 * gi : (const char *)p.C) - 1024 * k;
     }
     d.f_step = 4 * p.F_st;
     {
@@ -177,40 +187,48 @@ MPC_DEV void dma_init(Dma &d, const P &p, const Lane &L, int wave)
                 d.r_active = true; q = (const char *)((gi == 12 ? p.lo : p.hi) + pb * 4); st = 4 * B * 4;
             }
         }
-        d.r_ptr = q;
+        d.r_ptr = q - 3072;
         d.r_step = st;
-        d.g_ptr = (const char *)(p.Kk + pb * 64 + 4 * gi);
-        d.g2_ptr = (const char *)(p.Kk + (long)p.T * B * 64 + pb * 64 + 4 * gi);
+        d.g_ptr = (const char *)(p.Kk + pb * 64 + 4 * gi) + 1024;
+        d.g2_ptr = (const char *)(p.Kk + (long)p.T * B * 64 + pb * 64 + 4 * gi) + 2048;
         d.g_step = 4 * B * 64;
     }
 }
 
-// DMA of timestep t into ring slot `slot`: exactly DMA_SWEEP / RollDma<MODE, DIRECT>::N instructions.
+// DMA of timestep t into ring slot `slot`: exactly DMA_SWEEP / RollDma<MODE, DIRECT>::N instructions, all but the
+// directly-priced rollout's gains on one M0.
 template <int MODE, bool ROLL, bool DIRECT>
 MPC_DEV void stage_issue(const P &p, const Dma &d, int t, int slot)
 {
-    const unsigned base = ROLL ? (unsigned)(slot * (int)RollRing<MODE, DIRECT>::BYTES - (int)RollRing<MODE, DIRECT>::BIAS)
-                               : (unsigned)slot * STAGE_BYTES;
+    const unsigned mid = stage_mid<MODE, ROLL, DIRECT>(slot);
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);     // F / f have T-1 entries
     if (!ROLL || DIRECT) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wv::dma16_c(d.c_ptr[k] + tl * d.c_step, base + SC + 1024 * k);
+        const long o = tl * d.c_step;
+        wv::dma16_at<-4096, wv::DMA_C>(d.c_ptr[0] + o, mid);
+        wv::dma16_at<-3072, wv::DMA_C>(d.c_ptr[1] + o, mid);
+        wv::dma16_at<-2048, wv::DMA_C>(d.c_ptr[2] + o, mid);
+        wv::dma16_at<-1024, wv::DMA_C>(d.c_ptr[3] + o, mid);
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (ROLL) wv::dma16_last(d.f_ptr[k] + (p.T > 1 ? tf * d.f_step : 0), base + SF + 1024 * k);
-        else wv::dma16(d.f_ptr[k] + (p.T > 1 ? tf * d.f_step : 0), base + SF + 1024 * k);
+    {
+        const long o = p.T > 1 ? tf * d.f_step : 0;
+        wv::dma16_at<0, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[0] + o, mid);
+        wv::dma16_at<1024, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[1] + o, mid);
+        wv::dma16_at<2048, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[2] + o, mid);
     }
     // the record instruction is issued by every wave even if only some lanes take part
     {
         const char *src = d.r_ptr + (d.r_is_f ? tf : tl) * d.r_step;
         // the identity-priced rollout never looks at c; the sweep never looks at f
-        wv::dma16_if(d.r_active && !(ROLL && !DIRECT && d.r_is_c) && !(!ROLL && d.r_is_f), src, base + SR);
+        wv::dma16_at_if<3072>(d.r_active && !(ROLL && !DIRECT && d.r_is_c) && !(!ROLL && d.r_is_f), src, mid);
     }
     if (ROLL) {
-        wv::dma16(d.g_ptr + tl * d.g_step, base + SG);
-        if (!DIRECT && MODE != 0) wv::dma16(d.g2_ptr + tl * d.g_step, base + RollRing<MODE, DIRECT>::MREC);
+        if (DIRECT) {
+            wv::dma16_at<0>(d.g_ptr - 1024 + tl * d.g_step, mid + (SG - SF));
+        } else {
+            wv::dma16_at<-1024>(d.g_ptr + tl * d.g_step, mid);
+            if (MODE != 0) wv::dma16_at<-2048>(d.g2_ptr + tl * d.g_step, mid);
+        }
     }
 }
 
@@ -471,8 +489,9 @@ struct RoStage {
 template <int MODE, bool DIRECT>
 MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, unsigned zm)
 {
-    const unsigned base = (unsigned)(slot * (int)RollRing<MODE, DIRECT>::BYTES - (int)RollRing<MODE, DIRECT>::BIAS);
-    const unsigned mrec = base + (RollRing<MODE, DIRECT>::MREC - SC);
+    const unsigned base = stage_mid<MODE, true, DIRECT>(slot) - SF;       // the lane offsets are SF-relative + SF
+    const unsigned mrec = base + RollRing<MODE, DIRECT>::MADJ;
+    const unsigned gain = base + RollRing<MODE, DIRECT>::GADJ;
     s.cj = 0.f;
     s.mk = 0.f;
     if (DIRECT) {
@@ -484,7 +503,7 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
         s.cj = wv::lds_f32(base + L.aRec + R_c);
     } else {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) s.Sr[b] = wv::lds_f32(base + L.aS[b]);
+        for (int b = 0; b < 4; ++b) s.Sr[b] = wv::lds_f32(gain + L.aS[b]);
         if (MODE != 0) {
 #pragma unroll
             for (int jj = 0; jj < 12; ++jj) s.Mr[jj] = wv::lds_f32(mrec + L.aMrow + 16 * jj);
@@ -499,8 +518,8 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
     }
     s.fj = p.f ? wv::lds_f32(base + L.aRecF) : 0.f;
 #pragma unroll
-    for (int jj = 0; jj < 12; ++jj) s.Kr[jj] = wv::lds_f32(base + L.aKrow + 16 * jj);
-    s.kk = wv::lds_f32(base + L.aKrow + 192);
+    for (int jj = 0; jj < 12; ++jj) s.Kr[jj] = wv::lds_f32(gain + L.aKrow + 16 * jj);
+    s.kk = wv::lds_f32(gain + L.aKrow + 192);
     s.tb = wv::lds_f32(base + L.aRec + R_tau);
     s.lo = s.hi = 0.f;
     if (MODE == 2) {

@@ -330,6 +330,16 @@ static inline void dma_n(const void *g, unsigned off, int size, bool active = tr
     memcpy(d->data[l], g, size);
 }
 static inline void dma16(const void *g, unsigned off) { dma_n(g, off, 16); }
+// immediate offset: moves source and destination together (g is the pointer biased by -IMM)
+enum { DMA_PLAIN = 0, DMA_C = 1, DMA_LAST = 2 };
+template <int IMM, int KIND = DMA_PLAIN> static inline void dma16_at(const void *g, unsigned mid)
+{
+    dma_n((const char *)g + IMM, (unsigned)((int)mid + IMM), 16);
+}
+template <int IMM> static inline void dma16_at_if(bool active, const void *g, unsigned mid)
+{
+    dma_n((const char *)g + IMM, (unsigned)((int)mid + IMM), 16, active);
+}
 static inline void dma16_c(const void *g, unsigned off) { dma_n(g, off, 16); }
 static inline void dma16_once(const void *g, unsigned off) { dma_n(g, off, 16); }
 static inline void dma16_last(const void *g, unsigned off) { dma_n(g, off, 16); }
