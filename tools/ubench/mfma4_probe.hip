@@ -37,6 +37,8 @@ template <int KIND> __global__ void __launch_bounds__(64, 1) rate(float *out, lo
     float a[12], b[12];
     for (int i = 0; i < 12; ++i) { a[i] = threadIdx.x * 0.001f + i; b[i] = 1.f + 1e-3f * i; }
     f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    float x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+    int sc = 0;
     long long t0 = clock64();
     for (int r = 0; r < rep; ++r) {
 #pragma unroll
@@ -46,6 +48,24 @@ template <int KIND> __global__ void __launch_bounds__(64, 1) rate(float *out, lo
                 acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[1], 2, 1, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[2], 2, 2, 0);
                 acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[3], 2, 3, 0);
+            } else if (KIND == 2) {   // an independent v_fmac after every MFMA: does it fill the second pass?
+                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[0], 2, 0, 0);
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x0) : "v"(b[m]), "v"(b[0]));
+                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[1], 2, 1, 0);
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x1) : "v"(b[m]), "v"(b[1]));
+                acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[2], 2, 2, 0);
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x2) : "v"(b[m]), "v"(b[2]));
+                acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[3], 2, 3, 0);
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x3) : "v"(b[m]), "v"(b[3]));
+            } else if (KIND == 3) {   // a scalar instruction after every MFMA
+                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[0], 2, 0, 0);
+                asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc));
+                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[1], 2, 1, 0);
+                asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc));
+                acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[2], 2, 2, 0);
+                asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc));
+                acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[3], 2, 3, 0);
+                asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc));
             } else {               // one accumulator: the dependent chain
                 acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[0], 2, 0, 0);
                 acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[m], b[m], acc[0], 2, 1, 0);
@@ -55,7 +75,7 @@ template <int KIND> __global__ void __launch_bounds__(64, 1) rate(float *out, lo
         }
     }
     long long t1 = clock64();
-    float s = 0;
+    float s = x0 + x1 + x2 + x3 + sc;
     for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     out[blockIdx.x * 64 + threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
@@ -88,22 +108,26 @@ int main()
     hipLaunchKernelGGL(probe_fma, dim3(1), dim3(64), 0, 0, out);
     hipMemcpy(h.data(), out, 192 * 4, hipMemcpyDeviceToHost);
     printf("rounding: mfma %.10g  fmaf %.10g  mul-then-add %.10g\n", h[0], h[64], h[128]);
-    for (int grid : {256, 1024, 2048}) {
-        for (int kind = 0; kind < 2; ++kind) {
+    for (int grid : {1024}) {
+        for (int kind = 0; kind < 4; ++kind) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             const int rep = 2000;
-            if (kind == 0) hipLaunchKernelGGL(rate<0>, dim3(grid), dim3(64), 0, 0, out, cyc, rep);
-            else hipLaunchKernelGGL(rate<1>, dim3(grid), dim3(64), 0, 0, out, cyc, rep);
+            auto go = [&]() {
+                if (kind == 0) hipLaunchKernelGGL(rate<0>, dim3(grid), dim3(64), 0, 0, out, cyc, rep);
+                else if (kind == 1) hipLaunchKernelGGL(rate<1>, dim3(grid), dim3(64), 0, 0, out, cyc, rep);
+                else if (kind == 2) hipLaunchKernelGGL(rate<2>, dim3(grid), dim3(64), 0, 0, out, cyc, rep);
+                else hipLaunchKernelGGL(rate<3>, dim3(grid), dim3(64), 0, 0, out, cyc, rep);
+            };
+            go();
             hipEventRecord(e0);
-            if (kind == 0) hipLaunchKernelGGL(rate<0>, dim3(grid), dim3(64), 0, 0, out, cyc, rep);
-            else hipLaunchKernelGGL(rate<1>, dim3(grid), dim3(64), 0, 0, out, cyc, rep);
+            go();
             hipEventRecord(e1);
             hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, e0, e1);
             std::vector<long long> hc(grid);
             hipMemcpy(hc.data(), cyc, grid * 8, hipMemcpyDeviceToHost);
             double mean = 0; for (auto v : hc) mean += v; mean /= grid;
-            printf("v_mfma_f32_4x4x1 %s grid %4d: %6.2f clk/instr, %6.3f ns/instr\n", kind ? "one accumulator  " : "four accumulators", grid, mean / (48.0 * rep), ms * 1e6 / (48.0 * rep));
+            printf("v_mfma_f32_4x4x1 %s grid %4d: %6.2f clk/instr, %6.3f ns/instr\n", kind == 0 ? "four accumulators" : kind == 1 ? "one accumulator  " : kind == 2 ? "four acc + v_fmac each (per MFMA)" : "four acc + s_add each (per MFMA)", grid, mean / (48.0 * rep), ms * 1e6 / (48.0 * rep));
         }
     }
     return 0;
