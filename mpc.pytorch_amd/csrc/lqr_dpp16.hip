@@ -2,10 +2,11 @@
 //
 // One 64-lane wavefront (= one workgroup) owns FOUR problems, one per 16-lane DPP row.  The headline
 // shape (n_state=12, n_ctrl=4, T=50, B=4096) is 1024 wavefronts = one per SIMD, each with the whole
-// 512-entry VGPR file and 36 KiB of LDS (4 workgroups per CU).  Matrix products are blocks of
-// v_fmac_f32_dpp ... row_newbcast:N written as inline asm (hipcc does not fold a DPP mov into v_fmac);
-// each block opens with s_nop 1 because the assembler's hazard padding does not look inside asm
-// (VALU write of a VGPR -> DPP read of it needs 2 wait states).
+// 512-entry VGPR file and 36 KiB of LDS (4 workgroups per CU).  Matrix-matrix products are batched 4x4 outer
+// products on the matrix core (mfma4); matrix-vector products are blocks of v_fmac_f32_dpp ... row_newbcast:N
+// written as inline asm (hipcc does not fold a DPP mov into v_fmac); each block opens with s_nop 1 because the
+// assembler's hazard padding does not look inside asm (VALU write of a VGPR -> DPP read of it needs 2 wait
+// states).
 #include <string>
 #include "lqr_common.h"
 
@@ -45,164 +46,6 @@ template <int N> MPC_DEV void fmac_bcast(float &acc, float src, float mul)
     asm("s_nop 1\n"
         "v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3" DPPM
         : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
-}
-// acc[i] += bcast_M(src[i]) * mul, i = 0..11
-template <int M, int NS> MPC_DEV void fma_bcast_lane12(float (&a)[12], const float (&s)[NS], float mul)
-{
-    asm("s_nop 1\n"
-        "v_fmac_f32_dpp %0, %12, %24 row_newbcast:%25" DPPM
-        "v_fmac_f32_dpp %1, %13, %24 row_newbcast:%25" DPPM
-        "v_fmac_f32_dpp %2, %14, %24 row_newbcast:%25" DPPM
-        "v_fmac_f32_dpp %3, %15, %24 row_newbcast:%25" DPPM
-        "v_fmac_f32_dpp %4, %16, %24 row_newbcast:%25" DPPM
-        "v_fmac_f32_dpp %5, %17, %24 row_newbcast:%25" DPPM
-        "v_fmac_f32_dpp %6, %18, %24 row_newbcast:%25" DPPM
-        "v_fmac_f32_dpp %7, %19, %24 row_newbcast:%25" DPPM
-        "v_fmac_f32_dpp %8, %20, %24 row_newbcast:%25" DPPM
-        "v_fmac_f32_dpp %9, %21, %24 row_newbcast:%25" DPPM
-        "v_fmac_f32_dpp %10, %22, %24 row_newbcast:%25" DPPM
-        "v_fmac_f32_dpp %11, %23, %24 row_newbcast:%25" DPPM
-        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-          "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11])
-        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]),
-          "v"(s[9]), "v"(s[10]), "v"(s[11]), "v"(mul), "n"(M));
-}
-// two of the above in one block: a[i] += bcast_M(s[i]) * mul0 + bcast_{M+1}(s[i]) * mul1
-template <int M, int NS> MPC_DEV void fma_bcast_lane12x2(float (&a)[12], const float (&s)[NS], float mul0, float mul1)
-{
-    asm("s_nop 1\n"
-        "v_fmac_f32_dpp %0, %12, %24 row_newbcast:%26" DPPM
-        "v_fmac_f32_dpp %1, %13, %24 row_newbcast:%26" DPPM
-        "v_fmac_f32_dpp %2, %14, %24 row_newbcast:%26" DPPM
-        "v_fmac_f32_dpp %3, %15, %24 row_newbcast:%26" DPPM
-        "v_fmac_f32_dpp %4, %16, %24 row_newbcast:%26" DPPM
-        "v_fmac_f32_dpp %5, %17, %24 row_newbcast:%26" DPPM
-        "v_fmac_f32_dpp %6, %18, %24 row_newbcast:%26" DPPM
-        "v_fmac_f32_dpp %7, %19, %24 row_newbcast:%26" DPPM
-        "v_fmac_f32_dpp %8, %20, %24 row_newbcast:%26" DPPM
-        "v_fmac_f32_dpp %9, %21, %24 row_newbcast:%26" DPPM
-        "v_fmac_f32_dpp %10, %22, %24 row_newbcast:%26" DPPM
-        "v_fmac_f32_dpp %11, %23, %24 row_newbcast:%26" DPPM
-        "v_fmac_f32_dpp %0, %12, %25 row_newbcast:%27" DPPM
-        "v_fmac_f32_dpp %1, %13, %25 row_newbcast:%27" DPPM
-        "v_fmac_f32_dpp %2, %14, %25 row_newbcast:%27" DPPM
-        "v_fmac_f32_dpp %3, %15, %25 row_newbcast:%27" DPPM
-        "v_fmac_f32_dpp %4, %16, %25 row_newbcast:%27" DPPM
-        "v_fmac_f32_dpp %5, %17, %25 row_newbcast:%27" DPPM
-        "v_fmac_f32_dpp %6, %18, %25 row_newbcast:%27" DPPM
-        "v_fmac_f32_dpp %7, %19, %25 row_newbcast:%27" DPPM
-        "v_fmac_f32_dpp %8, %20, %25 row_newbcast:%27" DPPM
-        "v_fmac_f32_dpp %9, %21, %25 row_newbcast:%27" DPPM
-        "v_fmac_f32_dpp %10, %22, %25 row_newbcast:%27" DPPM
-        "v_fmac_f32_dpp %11, %23, %25 row_newbcast:%27" DPPM
-        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11])
-        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]), "v"(s[11]), "v"(mul0), "v"(mul1), "n"(M), "n"(M + 1));
-}
-// a[i] += bcast_i(src0) * mul0 + bcast_i(src1) * mul1
-MPC_DEV void fma_bcast_each16x2(float (&a)[16], float src0, float mul0, float src1, float mul1)
-{
-    asm("s_nop 1\n"
-        "v_fmac_f32_dpp %0, %16, %17 row_newbcast:0" DPPM
-        "v_fmac_f32_dpp %1, %16, %17 row_newbcast:1" DPPM
-        "v_fmac_f32_dpp %2, %16, %17 row_newbcast:2" DPPM
-        "v_fmac_f32_dpp %3, %16, %17 row_newbcast:3" DPPM
-        "v_fmac_f32_dpp %4, %16, %17 row_newbcast:4" DPPM
-        "v_fmac_f32_dpp %5, %16, %17 row_newbcast:5" DPPM
-        "v_fmac_f32_dpp %6, %16, %17 row_newbcast:6" DPPM
-        "v_fmac_f32_dpp %7, %16, %17 row_newbcast:7" DPPM
-        "v_fmac_f32_dpp %8, %16, %17 row_newbcast:8" DPPM
-        "v_fmac_f32_dpp %9, %16, %17 row_newbcast:9" DPPM
-        "v_fmac_f32_dpp %10, %16, %17 row_newbcast:10" DPPM
-        "v_fmac_f32_dpp %11, %16, %17 row_newbcast:11" DPPM
-        "v_fmac_f32_dpp %12, %16, %17 row_newbcast:12" DPPM
-        "v_fmac_f32_dpp %13, %16, %17 row_newbcast:13" DPPM
-        "v_fmac_f32_dpp %14, %16, %17 row_newbcast:14" DPPM
-        "v_fmac_f32_dpp %15, %16, %17 row_newbcast:15" DPPM
-        "v_fmac_f32_dpp %0, %18, %19 row_newbcast:0" DPPM
-        "v_fmac_f32_dpp %1, %18, %19 row_newbcast:1" DPPM
-        "v_fmac_f32_dpp %2, %18, %19 row_newbcast:2" DPPM
-        "v_fmac_f32_dpp %3, %18, %19 row_newbcast:3" DPPM
-        "v_fmac_f32_dpp %4, %18, %19 row_newbcast:4" DPPM
-        "v_fmac_f32_dpp %5, %18, %19 row_newbcast:5" DPPM
-        "v_fmac_f32_dpp %6, %18, %19 row_newbcast:6" DPPM
-        "v_fmac_f32_dpp %7, %18, %19 row_newbcast:7" DPPM
-        "v_fmac_f32_dpp %8, %18, %19 row_newbcast:8" DPPM
-        "v_fmac_f32_dpp %9, %18, %19 row_newbcast:9" DPPM
-        "v_fmac_f32_dpp %10, %18, %19 row_newbcast:10" DPPM
-        "v_fmac_f32_dpp %11, %18, %19 row_newbcast:11" DPPM
-        "v_fmac_f32_dpp %12, %18, %19 row_newbcast:12" DPPM
-        "v_fmac_f32_dpp %13, %18, %19 row_newbcast:13" DPPM
-        "v_fmac_f32_dpp %14, %18, %19 row_newbcast:14" DPPM
-        "v_fmac_f32_dpp %15, %18, %19 row_newbcast:15" DPPM
-        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
-        : "v"(src0), "v"(mul0), "v"(src1), "v"(mul1));
-}
-// acc[i] += bcast_i(src) * mul
-MPC_DEV void fma_bcast_each16(float (&a)[16], float src, float mul)
-{
-    asm("s_nop 1\n"
-        "v_fmac_f32_dpp %0, %16, %17 row_newbcast:0" DPPM
-        "v_fmac_f32_dpp %1, %16, %17 row_newbcast:1" DPPM
-        "v_fmac_f32_dpp %2, %16, %17 row_newbcast:2" DPPM
-        "v_fmac_f32_dpp %3, %16, %17 row_newbcast:3" DPPM
-        "v_fmac_f32_dpp %4, %16, %17 row_newbcast:4" DPPM
-        "v_fmac_f32_dpp %5, %16, %17 row_newbcast:5" DPPM
-        "v_fmac_f32_dpp %6, %16, %17 row_newbcast:6" DPPM
-        "v_fmac_f32_dpp %7, %16, %17 row_newbcast:7" DPPM
-        "v_fmac_f32_dpp %8, %16, %17 row_newbcast:8" DPPM
-        "v_fmac_f32_dpp %9, %16, %17 row_newbcast:9" DPPM
-        "v_fmac_f32_dpp %10, %16, %17 row_newbcast:10" DPPM
-        "v_fmac_f32_dpp %11, %16, %17 row_newbcast:11" DPPM
-        "v_fmac_f32_dpp %12, %16, %17 row_newbcast:12" DPPM
-        "v_fmac_f32_dpp %13, %16, %17 row_newbcast:13" DPPM
-        "v_fmac_f32_dpp %14, %16, %17 row_newbcast:14" DPPM
-        "v_fmac_f32_dpp %15, %16, %17 row_newbcast:15" DPPM
-        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-          "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
-        : "v"(src), "v"(mul));
-}
-// a[i] = bcast_i(src) * mul
-MPC_DEV void mul_bcast_each16(float (&a)[16], float src, float mul)
-{
-    asm("s_nop 1\n"
-        "v_mul_f32_dpp %0, %16, %17 row_newbcast:0" DPPM
-        "v_mul_f32_dpp %1, %16, %17 row_newbcast:1" DPPM
-        "v_mul_f32_dpp %2, %16, %17 row_newbcast:2" DPPM
-        "v_mul_f32_dpp %3, %16, %17 row_newbcast:3" DPPM
-        "v_mul_f32_dpp %4, %16, %17 row_newbcast:4" DPPM
-        "v_mul_f32_dpp %5, %16, %17 row_newbcast:5" DPPM
-        "v_mul_f32_dpp %6, %16, %17 row_newbcast:6" DPPM
-        "v_mul_f32_dpp %7, %16, %17 row_newbcast:7" DPPM
-        "v_mul_f32_dpp %8, %16, %17 row_newbcast:8" DPPM
-        "v_mul_f32_dpp %9, %16, %17 row_newbcast:9" DPPM
-        "v_mul_f32_dpp %10, %16, %17 row_newbcast:10" DPPM
-        "v_mul_f32_dpp %11, %16, %17 row_newbcast:11" DPPM
-        "v_mul_f32_dpp %12, %16, %17 row_newbcast:12" DPPM
-        "v_mul_f32_dpp %13, %16, %17 row_newbcast:13" DPPM
-        "v_mul_f32_dpp %14, %16, %17 row_newbcast:14" DPPM
-        "v_mul_f32_dpp %15, %16, %17 row_newbcast:15" DPPM
-        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
-          "=&v"(a[8]), "=&v"(a[9]), "=&v"(a[10]), "=&v"(a[11]), "=&v"(a[12]), "=&v"(a[13]), "=&v"(a[14]), "=&v"(a[15])
-        : "v"(src), "v"(mul));
-}
-MPC_DEV void fma_bcast_each12(float (&a)[12], float src, float mul)
-{
-    asm("s_nop 1\n"
-        "v_fmac_f32_dpp %0, %12, %13 row_newbcast:0" DPPM
-        "v_fmac_f32_dpp %1, %12, %13 row_newbcast:1" DPPM
-        "v_fmac_f32_dpp %2, %12, %13 row_newbcast:2" DPPM
-        "v_fmac_f32_dpp %3, %12, %13 row_newbcast:3" DPPM
-        "v_fmac_f32_dpp %4, %12, %13 row_newbcast:4" DPPM
-        "v_fmac_f32_dpp %5, %12, %13 row_newbcast:5" DPPM
-        "v_fmac_f32_dpp %6, %12, %13 row_newbcast:6" DPPM
-        "v_fmac_f32_dpp %7, %12, %13 row_newbcast:7" DPPM
-        "v_fmac_f32_dpp %8, %12, %13 row_newbcast:8" DPPM
-        "v_fmac_f32_dpp %9, %12, %13 row_newbcast:9" DPPM
-        "v_fmac_f32_dpp %10, %12, %13 row_newbcast:10" DPPM
-        "v_fmac_f32_dpp %11, %12, %13 row_newbcast:11" DPPM
-        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-          "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11])
-        : "v"(src), "v"(mul));
 }
 // acc += sum_i bcast_i(src) * mul[i]   (two accumulation chains)
 MPC_DEV void dot_bcast16(float &acc, float src, const float (&m)[16])
@@ -296,27 +139,15 @@ MPC_DEV double row_sum_f64(double x)
 __shared__ __attribute__((aligned(16))) char g_stage16[MPC_DPP16_LDS];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
-MPC_DEV void dma16(const void *g, unsigned off)
-{
-    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, 0);
-}
+// cache policy bits of the stage DMAs (see dma16_at).  C is read exactly once per launch: nt (measured
+// 129-132 -> 123-124 us).  F in the rollout is its second and last read -- yet nt there is 6 % SLOWER: the first
+// part of the rollout finds the blocks the sweep touched last still in the Infinity Cache.
 #ifndef MPC_DPP16_C_AUX
-#define MPC_DPP16_C_AUX 2      /* nt: measured 129-132 -> 123-124 us */
+#define MPC_DPP16_C_AUX 2
 #endif
-// the stage cost matrices: read exactly once per launch
-MPC_DEV void dma16_c(const void *g, unsigned off)
-{
-    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, MPC_DPP16_C_AUX);
-}
 #ifndef MPC_DPP16_FR_AUX
 #define MPC_DPP16_FR_AUX 0
 #endif
-// F in the rollout.  Its second and last read -- yet nt here is 6 % SLOWER (measured): the first
-// part of the rollout finds the blocks the sweep touched last still in the Infinity Cache.
-MPC_DEV void dma16_last(const void *g, unsigned off)
-{
-    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, MPC_DPP16_FR_AUX);
-}
 // results nobody in this launch reads again
 MPC_DEV void store_out(float *g, float v)
 {

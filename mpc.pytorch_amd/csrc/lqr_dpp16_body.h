@@ -1,17 +1,24 @@
 // lqr_dpp16_body.h -- the fused LQR step at the headline shape (n_state = 12, n_ctrl = 4, fp32):
 // FOUR problems per 64-lane wavefront, one problem per 16-lane DPP row, lane j of a row owning
-// variable j of tau = [x_0..x_11, u_0..u_3].  All algebra runs on the vector ALU as
-// v_fmac_f32 with a DPP row_newbcast operand (one lane of the row broadcast to the other 15 inside
-// the FMA itself), so the 4x4 control-block factorisation, the box QP and every matrix-vector
-// product are shared by four problems per instruction and nothing is computed 64 times over.
+// variable j of tau = [x_0..x_11, u_0..u_3], i.e. column j of every matrix.
 //
-// Why not the matrix cores here: on gfx950 v_mfma_f32_16x16x4_f32 and the f32 VALU never co-execute
-// (SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r01_prof2_mfma16_v2.json) and one wave per problem
-// spends most of its issue slots on wave-uniform 4x4 work; see lqr_mfma16_body.h (kept as
-// impl 2, all shapes <= 12/4) and DESIGN.md for the measured comparison.
+//   matrix x matrix   batched 4x4 outer products on the matrix core: v_mfma_f32_4x4x1_16b_f32 with cbsz:2 takes
+//                     the A vector of the four blocks of a row from lanes 4*abid..+3 of that row and leaves B in
+//                     its lane, which is rows 4*abid..+3 of an outer product with one column per lane -- exactly
+//                     this layout, so V F, C + F'(VF) and Qxx + Qxu K are sums of such products with no data
+//                     movement (wv::mfma4, outer_acc below); 256 FMAs per issue slot
+//   matrix x vector   v_fmac_f32 with a DPP row_newbcast operand (one lane of the row broadcast to the other 15
+//                     inside the FMA itself): c_back, F'v, the rollout's K dx and F tau
+//   4x4 control block LDL', the box QP and the K solve on row-uniform values, shared by four problems per
+//                     instruction; nothing is computed 64 times over
+//
+// With one wavefront per SIMD every instruction costs an issue slot of >= 4.6 clocks whatever its kind
+// (tools/ubench/valu_rate.hip): the kernel is bound by its instruction count, and the 4x4x1 form does the
+// 384 product FMAs of a timestep in 96 instructions.  lqr_mfma16_body.h (one wave per problem on the 16x16x4
+// MFMA, all shapes <= 12/4) is kept as impl 2; DESIGN.md has the measured comparison.
 //
 // Written against the `wv::` wave interface like lqr_mfma16_body.h: lqr_dpp16.hip binds it to gfx950
-// (inline-asm blocks of v_fmac_f32_dpp, global_load_lds DMA), tests/emu/ to the host emulator.
+// (MFMA builtins, inline-asm blocks of v_fmac_f32_dpp, global_load_lds DMA), tests/emu/ to the host emulator.
 //
 // What it replaces in locuslab/mpc.pytorch:
 //   sweep_step      mpc/lqr_step.py:284-296 (c_back) + :52-160 (lqr_backward)
@@ -22,11 +29,11 @@
 //   Vc[i]  = V[i][j]      column j of the value Hessian (j < 12)       vv = v[j]
 //   Cc[i]  = C[j][i]      (C symmetric, mpc/mpc.py:61-68: row j is read as column j)
 //   Fc[m]  = F[m][j]      column j of the dynamics
-//   Y[i]   = (V F)[i][j]  = sum_m bcast_m(Vc[i]) * Fc[m]
-//   Q[i]   = (C + F'VF)[i][j] = Cc[i] + sum_m bcast_i(Fc[m]) * Y[m];   q = q[j]
+//   Y[i]   = (V F)[i][j]  = sum_m V[i][m] F[m][j]:   outer_acc(Y, Vc[m], Fc[m])  (V symmetric: lane i holds V[m][i])
+//   Q[i]   = (C + F'VF)[i][j] = Cc[i] + sum_m F[m][i] Y[m][j]:   outer_acc(Q, Fc[m], Y[m]);   q = q[j]
 //   K[a]   = K[a][j]  (j < 12),  lane 12 carries k = K[.][12]
-// Staging: per wave a 4-slot LDS ring, 9 KiB per slot (4 x {C 1 KiB, F 768 B, small-vector record
-// 256 B, gain record 256 B}), filled by global_load_lds three timesteps ahead; counted vmcnt waits.
+// Staging: per wave an LDS ring filled by global_load_lds ahead of use with counted vmcnt waits: the sweep 4 slots
+// of 9 KiB (4 x {C 1 KiB, F 768 B, small-vector record 256 B}), the rollout 7 (6) packed slots, see RollRing.
 //
 // One read of C.  The rollout does NOT stream C again to price its trajectory: for a rollout that obeys
 // the dynamics (it does by construction) around a nominal that obeys them too, the exact identity

@@ -29,7 +29,6 @@ struct Wave {
     int problem;
     // exchange area, two generations
     float fa[2][NL], fb[2][NL];
-    float fv[2][NL][16];
     double fd[2][NL];
     int ia[2][NL];
     unsigned seq[NL];
@@ -180,43 +179,6 @@ template <int N> static inline float bcast(float x)
     return w.fa[gen][(l & ~15) + N];
 }
 template <int N> static inline void fmac_bcast(float &acc, float src, float mul) { acc = fmaf(bcast<N>(src), mul, acc); }
-template <int M, int NS> static inline void fma_bcast_lane12(float (&a)[12], const float (&s)[NS], float mul)
-{
-    emu::Wave &w = emu::W;
-    const int l = w.cur, gen = w.seq[l]++ & 1;
-    for (int i = 0; i < 12; ++i) w.fv[gen][l][i] = s[i];
-    emu::yield_lane();
-    for (int i = 0; i < 12; ++i) a[i] = fmaf(w.fv[gen][(l & ~15) + M][i], mul, a[i]);
-}
-template <int NN> static inline void fma_bcast_each(float (&a)[NN], float src, float mul)
-{
-    emu::Wave &w = emu::W;
-    const int l = w.cur, gen = w.seq[l]++ & 1;
-    w.fa[gen][l] = src;
-    emu::yield_lane();
-    for (int i = 0; i < NN; ++i) a[i] = fmaf(w.fa[gen][(l & ~15) + i], mul, a[i]);
-}
-static inline void fma_bcast_each16(float (&a)[16], float src, float mul) { fma_bcast_each<16>(a, src, mul); }
-static inline void fma_bcast_each16x2(float (&a)[16], float s0, float m0, float s1, float m1)
-{
-    fma_bcast_each<16>(a, s0, m0);
-    fma_bcast_each<16>(a, s1, m1);
-}
-template <int M, int NS> static inline void fma_bcast_lane12x2(float (&a)[12], const float (&s)[NS], float m0, float m1)
-{
-    fma_bcast_lane12<M, NS>(a, s, m0);
-    fma_bcast_lane12<M + 1, NS>(a, s, m1);
-}
-static inline void mul_bcast_each16(float (&a)[16], float src, float mul)
-{
-    for (int i = 0; i < 16; ++i) a[i] = -0.f;
-    emu::Wave &w = emu::W;
-    const int l = w.cur, gen = w.seq[l]++ & 1;
-    w.fa[gen][l] = src;
-    emu::yield_lane();
-    for (int i = 0; i < 16; ++i) a[i] = w.fa[gen][(l & ~15) + i] * mul;
-}
-static inline void fma_bcast_each12(float (&a)[12], float src, float mul) { fma_bcast_each<12>(a, src, mul); }
 template <int NN> static inline void dot_bcast(float &acc, float src, const float (&m)[NN])
 {
     emu::Wave &w = emu::W;
@@ -340,9 +302,7 @@ template <int IMM> static inline void dma16_at_if(bool active, const void *g, un
 {
     dma_n((const char *)g + IMM, (unsigned)((int)mid + IMM), 16, active);
 }
-static inline void dma16_c(const void *g, unsigned off) { dma_n(g, off, 16); }
 static inline void dma16_once(const void *g, unsigned off) { dma_n(g, off, 16); }
-static inline void dma16_last(const void *g, unsigned off) { dma_n(g, off, 16); }
 static inline void store_out(float *g, float v) { *g = v; }
 static inline void dma16_if(bool active, const void *g, unsigned off) { dma_n(g, off, 16, active); }
 static inline void dma4(const void *g, unsigned off) { dma_n(g, off, 4); }
