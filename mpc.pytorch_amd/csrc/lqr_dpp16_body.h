@@ -947,29 +947,28 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
                 kkt_stage_issue(p, d, t - 3 >= 0 ? t - 3 : 0, (i + 3) % NSTAGE);
 
                 const long tb = (long)t * p.B + L.pb;
-                // dF_t, df_t from the costates of t+1
+                // dF_t, df_t from the costates of t+1.  Lane j holds COLUMN j (regs = rows): every register is then one
+                // row segment of 16 consecutive floats per problem and goes out as a fully coalesced dword store.
                 if (have) {
-                    float row[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    outer_acc(row, tj, -dlam);            // row j of -(dlam tau' + lam dtau'): two outer products
-                    outer_acc(row, dj, -lam);
-                    if (L.live && L.j < 12) {
-                        float *dst = k.dF + (tb * 12 + L.j) * 16;
+                    float col[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    outer_acc(col, -dlam, tj);            // -(dlam tau' + lam dtau')[r][j]
+                    outer_acc(col, -lam, dj);
+                    if (L.live) {
+                        float *dst = k.dF + tb * 192 + L.j;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            wv::store_f32x4_out(dst + 4 * q, f32x4{row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]});
-                        if (k.df) k.df[tb * 12 + L.j] = -dlam;
+                        for (int r = 0; r < 12; ++r) wv::store_f32_out(dst + 16 * r, col[r]);
+                        if (k.df && L.j < 12) k.df[tb * 12 + L.j] = -dlam;
                     }
                 }
-                // dC_t (row j), dc_t
+                // dC_t, dc_t: -0.5 (dtau tau' + tau dtau') is symmetric, row j = column j
                 {
-                    float row[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    outer_acc(row, tj, -0.5f * dj);
-                    outer_acc(row, dj, -0.5f * tj);
+                    float col[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    outer_acc(col, tj, -0.5f * dj);
+                    outer_acc(col, dj, -0.5f * tj);
                     if (L.live) {
-                        float *dst = k.dC + (tb * 16 + (L.j < 12 ? L.j : 12 + L.a)) * 16;
+                        float *dst = k.dC + tb * 256 + L.j;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            wv::store_f32x4_out(dst + 4 * q, f32x4{row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]});
+                        for (int r = 0; r < 16; ++r) wv::store_f32_out(dst + 16 * r, col[r]);
                         k.dc[tb * 16 + L.j] = -dj;
                     }
                 }
