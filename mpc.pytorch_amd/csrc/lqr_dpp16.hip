@@ -188,6 +188,13 @@ template <int IMM> MPC_DEV void dma16_at_if(bool active, const void *g, unsigned
 {
     if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + mid), 16, IMM, 0);
 }
+// a dword at a wave-uniform address, through the scalar cache (s_load_dword: lgkmcnt, not vmcnt); the memory is
+// read-only for the lifetime of the launch
+MPC_DEV unsigned load_uniform_u32(const unsigned *g)
+{
+    typedef const __attribute__((address_space(4))) unsigned const_u32_t;
+    return *(const_u32_t *)(unsigned long)g;
+}
 MPC_DEV float lds_f32(unsigned off) { return *(const float *)(g_stage16 + off); }
 MPC_DEV f32x4 lds_f32x4(unsigned off) { return *(const f32x4 *)(g_stage16 + off); }
 MPC_DEV void store_f32x4(float *g, f32x4 v) { *(f32x4 *)g = v; }

@@ -312,6 +312,7 @@ template <int N> static inline void dma_wait()
     (void)readlane_i(0, 0);
     if (emu::W.cur == 0) emu::dma_land(emu::g_dma_late ? N : 0);
 }
+static inline unsigned load_uniform_u32(const unsigned *g) { return *g; }
 static inline float lds_f32(unsigned off)
 {
     float v;
