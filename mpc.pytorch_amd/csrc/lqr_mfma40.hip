@@ -28,6 +28,14 @@ MPC_DEV float rcp(float x)
     float r = __builtin_amdgcn_rcpf(x);
     return fmaf(fmaf(-x, r, 1.f), r, r);     // one Newton step: <= 1 ulp
 }
+// a dword at a wave-uniform address through the scalar cache (s_load_dword: lgkmcnt, not vmcnt); read-only data
+MPC_DEV unsigned load_uniform_u32(const unsigned *g)
+{
+    typedef const __attribute__((address_space(4))) unsigned const_u32_t;
+    return *(const_u32_t *)(unsigned long)g;
+}
+// an opaque register-to-register identity (see mfma40::pick)
+MPC_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
 #define MPC_MFMA40_LDS (2 * 13056 + 512)
 __shared__ __attribute__((aligned(16))) char g_stage40[MPC_MFMA40_LDS];
 typedef __attribute__((address_space(3))) void lds_void_t;

@@ -31,6 +31,28 @@
 namespace mpclqr {
 namespace mfma40 {
 
+// c ? a : b on two values that both sit in registers.  Written through wv::pin because hipcc otherwise folds a
+// select of two elements of a small local array into ONE dynamically indexed load, which puts the array in scratch
+// memory: a store, a load and an `s_waitcnt vmcnt(0)` that also drains the staging DMAs, twice per timestep.
+MPC_DEV float pick(bool c, float a, float b)
+{
+    wv::pin(a);
+    wv::pin(b);
+    return c ? a : b;
+}
+
+// One problem per wavefront: its mask bytes and bound rows sit at wave-uniform addresses and come through the
+// scalar path.  A vector load would share the vmcnt queue with the staging DMAs, which the compiler cannot count
+// across the loop: it drains the queue in front of every use.
+MPC_DEV float uniform_f32(const float *g)
+{
+    const unsigned u = wv::load_uniform_u32((const unsigned *)g);
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+
 using wv::f32x4;
 constexpr int NS = 32, NC = 8, N = 40;
 constexpr int NSTAGE = 2;      // slots of the LDS-DMA ring: one step in flight (27 KiB per wave -> 6 waves per CU)
@@ -42,6 +64,11 @@ constexpr int RDMA_PER_STAGE = 14;                          // 7 (C) + 5 (F) + 1
 constexpr unsigned OFF_SCR = NSTAGE * RSTAGE_BYTES;         // 512 B: row -> column layout turns
 constexpr unsigned LDS_TOTAL = OFF_SCR + 512;
 typedef StepParams<float> P;
+// the flags of controls 4w .. 4w+3 of u_zero_I [T,B,8] at (t, b) = tb
+MPC_DEV unsigned zero_mask_word(const P &p, long tb, int w)
+{
+    return wv::load_uniform_u32((const unsigned *)(p.zero_mask + tb * 8) + w);
+}
 
 struct Lane {
     int lane, r, q, b;
@@ -394,9 +421,10 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
             for (int a = 0; a < 8; ++a) kk[a] = -kk[a];
         } else if (MODE == 1) {                          // :99-127: pinned controls drop out of the solve
             float rq[8];
+            const unsigned zlo = zero_mask_word(p, tb, 0), zhi = zero_mask_word(p, tb, 1);
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
-                fr[a] = p.zero_mask[tb * NC + a] == 0;
+                fr[a] = (((a < 4 ? zlo : zhi) >> (8 * (a & 3))) & 0xffu) == 0u;
                 rq[a] = fr[a] ? qu[a] : 0.f;
             }
             ldl8_masked(fac, S, fr, 0.f);
@@ -408,8 +436,8 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
                 const float ua = wv::lds_f32(base + OFF_R + 288 + 4u * (unsigned)a);
-                lb[a] = (p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[tb * NC + a]) - ua;
-                ub[a] = (p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : p.hi[tb * NC + a]) - ua;
+                lb[a] = (p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : uniform_f32(p.lo + tb * NC + a)) - ua;
+                ub[a] = (p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : uniform_f32(p.hi + tb * NC + a)) - ua;
                 if (p.has_delta) {                       // :132-134
                     if (lb[a] < -p.delta_u) lb[a] = -p.delta_u;
                     if (ub[a] > p.delta_u) ub[a] = p.delta_u;
@@ -465,7 +493,7 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
                 for (int a = 0; a < 8; ++a) sol[a] = fr[a] ? sol[a] : 0.f;
             }
 #pragma unroll
-            for (int v = 0; v < 4; ++v) Kd[J][v] = L.q < 2 ? -(odd ? sol[4 + v] : sol[v]) : 0.f;
+            for (int v = 0; v < 4; ++v) Kd[J][v] = L.q < 2 ? -pick(odd, sol[4 + v], sol[v]) : 0.f;
             if (MODE != 0) {
                 // M = Qux + Quu K for this lane's column (rows 4q+v), the B operand of K'M below
                 float Kc[8];
@@ -474,7 +502,7 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const float m0 = sym8_row(S, v, Kc), m1 = sym8_row(S, 4 + v, Kc);
-                    Md[J][v] = L.q < 2 ? (odd ? rhs_full[4 + v] + m1 : rhs_full[v] + m0) : 0.f;
+                    Md[J][v] = L.q < 2 ? pick(odd, rhs_full[4 + v] + m1, rhs_full[v] + m0) : 0.f;
                 }
             }
             if (L.q < 2) {
@@ -485,7 +513,7 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
         if (L.lane < 8) {
             float kv = kk[0];
 #pragma unroll
-            for (int a = 1; a < 8; ++a) kv = L.lane == a ? kk[a] : kv;
+            for (int a = 1; a < 8; ++a) kv = pick(L.lane == a, kk[a], kv);
             kout[tb * NC + L.lane] = kv;
         }
 
@@ -512,10 +540,10 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
             float s = 0.f;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float ka = L.q == 0 ? kk[v] : (L.q == 1 ? kk[4 + v] : 0.f);
+                const float ka = pick(L.q == 0, kk[v], pick(L.q == 1, kk[4 + v], 0.f));
                 s = fmaf(Qd[2][J][v], ka, s);
                 if (MODE != 0) {                         // + K'(qu + Quu k)
-                    const float ma = L.q == 0 ? mk[v] : (L.q == 1 ? mk[4 + v] : 0.f);
+                    const float ma = pick(L.q == 0, mk[v], pick(L.q == 1, mk[4 + v], 0.f));
                     s = fmaf(Kd[J][v], ma, s);
                 }
             }
@@ -644,14 +672,21 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
             const unsigned qo = 16u * (unsigned)(L.q < 2 ? L.q : 0);
             const f32x4 ub = wv::lds_f32x4(rec + 288 + qo), kb = wv::lds_f32x4(rec + 448 + qo);
             float s = 0.f;
+            unsigned zw = 0u;                    // the zero flags of controls 4q .. 4q+3
+            if (MODE == 1) {
+                const unsigned zlo = zero_mask_word(p, tb, 0), zhi = zero_mask_word(p, tb, 1);
+                zw = L.q == 0 ? zlo : zhi;
+            }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 float un = L.q < 2 ? Ud[v] + ub[v] + alpha * kb[v] : 0.f;
-                if (MODE == 1 && L.q < 2 && p.zero_mask[tb * NC + 4 * L.q + v]) un = 0.f;           // :197-198
+                if (MODE == 1 && L.q < 2 && ((zw >> (8 * v)) & 0xffu) != 0u) un = 0.f;               // :197-198
                 if (MODE == 2 && L.q < 2) {                                                          // :200-213
-                    const long ui = tb * NC + 4 * L.q + v;
-                    float lo = p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[ui];
-                    float hi = p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : p.hi[ui];
+                    float lo = p.lo_s, hi = p.hi_s;
+                    if (p.bound_mode != MPC_BOUND_SCALAR) {
+                        lo = pick(L.q == 0, uniform_f32(p.lo + tb * NC + v), uniform_f32(p.lo + tb * NC + 4 + v));
+                        hi = pick(L.q == 0, uniform_f32(p.hi + tb * NC + v), uniform_f32(p.hi + tb * NC + 4 + v));
+                    }
                     if (p.has_delta) {
                         const float l2 = ub[v] - p.delta_u, h2 = ub[v] + p.delta_u;
                         lo = (l2 < lo) ? lo : l2;
