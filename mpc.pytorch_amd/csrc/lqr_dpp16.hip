@@ -35,6 +35,9 @@ template <int ABID> MPC_DEV f32x4 mfma4(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 2, ABID, 0);
 }
 
+// nothing is scheduled across this point
+MPC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 // ---- DPP row broadcasts ----------------------------------------------------------------------
 template <int N> MPC_DEV float bcast(float x)
 {

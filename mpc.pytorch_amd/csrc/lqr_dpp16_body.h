@@ -353,10 +353,12 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         // as sums of outer products on the matrix core: Y = sum_m V[:,m] F[m,:]  (V symmetric: lane i holds
         // V[m][i] = V[i][m] in Vc[m]),  Q += sum_m F[m,:]' Y[m,:]
         float Y[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // folds into the first products' srcC
+        wv::sched_fence();
 #pragma unroll
         for (int m = 0; m < 12; ++m) outer_acc(Y, st.Vc[m], s.Fc[m]);
 #pragma unroll
         for (int m = 0; m < 12; ++m) outer_acc(Q, s.Fc[m], Y[m]);
+        wv::sched_fence();          // keep the 84 MFMAs one block: every MFMA <-> VALU turn costs ~7 clocks
         wv::dot_bcast12(q, st.vv, s.Fc);
     }
 
@@ -442,11 +444,6 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     float Vn[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Vn[i] = Q[i];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) outer_acc(Vn, Q[12 + a], K[a]);      // += Qux[a][i] K[a][j]  (Qux = Qxu')
-    float vn = q;
-    wv::fmac_bcast<12>(vn, K[0], Q[12]); wv::fmac_bcast<12>(vn, K[1], Q[13]);
-    wv::fmac_bcast<12>(vn, K[2], Q[14]); wv::fmac_bcast<12>(vn, K[3], Q[15]);
     float M[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE != 0) {
         // with a full free set Qux + Quu K vanishes; with masked / clamped controls it does not
@@ -454,11 +451,21 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         M[1] = fmaf(S.s13, K[3], fmaf(S.s12, K[2], fmaf(S.s11, K[1], fmaf(S.s01, K[0], rhs[1]))));
         M[2] = fmaf(S.s23, K[3], fmaf(S.s22, K[2], fmaf(S.s12, K[1], fmaf(S.s02, K[0], rhs[2]))));
         M[3] = fmaf(S.s33, K[3], fmaf(S.s23, K[2], fmaf(S.s13, K[1], fmaf(S.s03, K[0], rhs[3]))));
+    }
+    wv::sched_fence();              // the matrix-core block of the value update, undivided
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            outer_acc(Vn, K[a], M[a]);                     // += K[a][i] M[a][j]
-            wv::fmac_bcast<12>(vn, M[a], K[a]);            // += K[a][j] m[a]
-        }
+    for (int a = 0; a < 4; ++a) outer_acc(Vn, Q[12 + a], K[a]);      // += Qux[a][i] K[a][j]  (Qux = Qxu')
+    if (MODE != 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) outer_acc(Vn, K[a], M[a]);       // += K[a][i] M[a][j]
+    }
+    wv::sched_fence();
+    float vn = q;
+    wv::fmac_bcast<12>(vn, K[0], Q[12]); wv::fmac_bcast<12>(vn, K[1], Q[13]);
+    wv::fmac_bcast<12>(vn, K[2], Q[14]); wv::fmac_bcast<12>(vn, K[3], Q[15]);
+    if (MODE != 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wv::fmac_bcast<12>(vn, M[a], K[a]);      // += K[a][j] m[a]
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) st.Vc[i] = Vn[i];
