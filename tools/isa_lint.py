@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Static checks on the gfx950 ISA of the fused kernels (no GPU needed):
+
+  python tools/isa_lint.py            # compiles csrc/*.hip to assembly under /tmp and reports, per kernel,
+                                      #   * scratch (private memory) instructions  -- a dynamically indexed local array
+                                      #   * `s_waitcnt vmcnt(0)` inside a loop of < 3000 lines -- a drain of the staging
+                                      #     DMAs every trip (the compiler puts one in front of any vector load whose
+                                      #     result crosses the loop: masks, bound rows)
+                                      #   * VGPR / AGPR / spill counts
+  python tools/isa_lint.py --loops lqr_dpp16 'Li0EEE'   # instruction mix of every loop of the kernels matching the regex
+
+Both findings cost config 5 10 % and the masked headline step 12 % before they were removed."""
+import collections, os, re, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "mpc.pytorch_amd", "csrc")
+FLAGS = {"lqr_dpp16": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+FAST = ["lqr_dpp16", "lqr_mfma40", "lqr_mfma16", "lqr_tiny", "kkt_wave"]
+
+
+def assembly(name, out="/tmp/isa_lint"):
+    os.makedirs(out, exist_ok=True)
+    s = os.path.join(out, name + ".s")
+    src = os.path.join(CSRC, name + ".hip")
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if not os.path.exists(s) or any(os.path.getmtime(d) > os.path.getmtime(s) for d in deps):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-w",
+                               "-S", "--cuda-device-only"] + FLAGS.get(name, []) + ["-o", s, src])
+    return open(s).read().split("\n")
+
+
+def structure(lines):
+    kernels = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    loops = []
+    for i, l in enumerate(lines):
+        m = re.search(r"\b(s_cbranch\w+|s_branch)\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(2) in labels and labels[m.group(2)] < i:
+            loops.append((labels[m.group(2)], i))
+    return kernels, loops
+
+
+def short(k):
+    return re.sub(r"^_ZN6mpclqr12_GLOBAL__N_1\d+", "", k)[:48]
+
+
+def klass(op):
+    for pre, c in (("v_mfma", "mfma"), ("v_fmac_f32_dpp", "fmac_dpp"), ("v_mov_b32_dpp", "mov_dpp"), ("v_accvgpr", "acc"),
+                   ("v_readlane", "lane"), ("v_writelane", "lane"), ("v_", "valu"), ("ds_", "lds"), ("s_nop", "s_nop"),
+                   ("s_waitcnt", "waitcnt"), ("global_load", "gload"), ("global_store", "gstore"), ("scratch_", "scratch"),
+                   ("s_", "salu")):
+        if op.startswith(pre):
+            return c
+    return "other"
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--loops":
+        lines = assembly(sys.argv[2])
+        kernels, loops = structure(lines)
+        pat = re.compile(sys.argv[3] if len(sys.argv) > 3 else ".")
+        for a, b in loops:
+            k = [n for s, n in kernels if s <= a][-1]
+            if not pat.search(k) or b - a < 100:
+                continue
+            c = collections.Counter(klass(t.split()[0]) for t in (l.strip() for l in lines[a:b + 1])
+                                    if t and t[0] not in ";." and not t.endswith(":"))
+            print("%-40s lines %6d-%6d  %5d instr  %s" % (short(k), a, b, sum(c.values()), dict(c)))
+        return 0
+    bad = 0
+    for name in FAST:
+        lines = assembly(name)
+        kernels, loops = structure(lines)
+        per = collections.defaultdict(lambda: [0, 0])
+        for i, l in enumerate(lines):
+            ks = [n for s, n in kernels if s <= i]
+            if not ks:
+                continue
+            if "scratch_" in l and not l.strip().startswith(";"):
+                per[ks[-1]][0] += 1
+            if "s_waitcnt vmcnt(0)" in l:
+                inner = sorted(b - a for a, b in loops if a <= i <= b)
+                if inner and inner[0] < 3000:
+                    per[ks[-1]][1] += 1
+        meta = dict(re.findall(r"\.name:\s+(\S+)[\s\S]*?\.vgpr_count:\s+(\d+)", "\n".join(lines)))
+        for _, k in kernels:
+            sc, dr = per[k]
+            print("%-12s %-50s vgpr %4s  scratch ops %3d  vmcnt(0) in loops %3d" % (name, short(k), meta.get(k, "?"), sc, dr))
+            if name in ("lqr_dpp16", "lqr_mfma40") and sc:
+                bad += 1
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
