@@ -34,6 +34,8 @@ MPC_DEV unsigned load_uniform_u32(const unsigned *g)
     typedef const __attribute__((address_space(4))) unsigned const_u32_t;
     return *(const_u32_t *)(unsigned long)g;
 }
+// nothing is scheduled across this point
+MPC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // an opaque register-to-register identity (see mfma40::pick)
 MPC_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
 #define MPC_MFMA40_LDS (2 * 13056 + 512)

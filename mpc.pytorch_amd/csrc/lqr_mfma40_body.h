@@ -362,6 +362,7 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
                         FB[4 * Ip + v][J] = in ? x : 0.f;
                     }
             // ---- Y = V F   (A operand = V by symmetry: register v of tile (I', Im))
+            wv::sched_fence();
             f32x4 Yd[2][3];
 #pragma unroll
             for (int Im = 0; Im < 2; ++Im)
@@ -388,6 +389,7 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
                         for (int v = 0; v < 4; ++v) acc = wv::mfma(FB[4 * Ip + v][I], Yd[Ip][J][v], acc);
                     Qd[I][J] = acc;
                 }
+            wv::sched_fence();
             // ---- q = c_back + F'v
 #pragma unroll
             for (int J = 0; J < 3; ++J) {
@@ -660,14 +662,21 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
         const long tb = (long)t * p.B + L.b;
         const unsigned rec = base + ROFF_R;
         // ---- u' = K dx + u + alpha k   (:192)
+        // (operands first, then the matrix-core block undivided: an MFMA <-> VALU turn costs ~15 clocks here,
+        // tools/ubench/mfma16_turn.hip)
         f32x4 Ud = zero4;
+        {
+            float a[8];
 #pragma unroll
-        for (int Ip = 0; Ip < 2; ++Ip)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float a = wv::lds_f32(base + ROFF_K + 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 16 * Ip + 4 * L.q + v));
-                Ud = wv::mfma(L.r < NC ? a : 0.f, DXd[Ip][v], Ud);
+            for (int k = 0; k < 8; ++k) {
+                const float x = wv::lds_f32(base + ROFF_K + 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 16 * (k >> 2) + 4 * L.q + (k & 3)));
+                a[k] = L.r < NC ? x : 0.f;
             }
+            wv::sched_fence();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) Ud = wv::mfma(a[k], DXd[k >> 2][k & 3], Ud);
+            wv::sched_fence();
+        }
         {
             const unsigned qo = 16u * (unsigned)(L.q < 2 ? L.q : 0);
             const f32x4 ub = wv::lds_f32x4(rec + 288 + qo), kb = wv::lds_f32x4(rec + 448 + qo);
@@ -709,18 +718,25 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
                 f32x4 G = zero4;
                 const int col = 16 * I + L.r;
                 const bool cin = col < N;
+                {
+                    float a[12];
 #pragma unroll
-                for (int Ip = 0; Ip < 2; ++Ip)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const float a = wv::lds_f32(base + OFF_C + 4u * (unsigned)((16 * Ip + 4 * L.q + v) * N + (cin ? col : 0)));
-                        G = wv::mfma(cin ? a : 0.f, Xd[Ip][v], G);
+                    for (int k = 0; k < 8; ++k) {
+                        const float x = wv::lds_f32(base + OFF_C + 4u * (unsigned)((16 * (k >> 2) + 4 * L.q + (k & 3)) * N + (cin ? col : 0)));
+                        a[k] = cin ? x : 0.f;
                     }
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const bool in = cin && L.q < 2;
-                    const float a = wv::lds_f32(base + OFF_C + 4u * (unsigned)((in ? 32 + 4 * L.q + v : 0) * N + (cin ? col : 0)));
-                    G = wv::mfma(in ? a : 0.f, Ud[v], G);
+                    for (int v = 0; v < 4; ++v) {
+                        const bool in = cin && L.q < 2;
+                        const float x = wv::lds_f32(base + OFF_C + 4u * (unsigned)((in ? 32 + 4 * L.q + v : 0) * N + (cin ? col : 0)));
+                        a[8 + v] = in ? x : 0.f;
+                    }
+                    wv::sched_fence();
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) G = wv::mfma(a[k], Xd[k >> 2][k & 3], G);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) G = wv::mfma(a[8 + v], Ud[v], G);
+                    wv::sched_fence();
                 }
                 // rows 16I + 4q + v of (C tau') against the same entries of tau' and c
                 const bool rin = I < 2 || L.q < 2;
@@ -741,17 +757,22 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
                 f32x4 acc = zero4;
                 if (p.f) acc = wv::lds_f32x4(rec + 320 + 4u * (unsigned)(16 * Im + 4 * L.q));
                 const int row = 16 * Im + L.r;
+                {
+                    float a[12];
 #pragma unroll
-                for (int Ip = 0; Ip < 2; ++Ip)
+                    for (int k = 0; k < 8; ++k)
+                        a[k] = wv::lds_f32(base + OFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const float a = wv::lds_f32(base + OFF_F + 4u * (unsigned)(row * N + 16 * Ip + 4 * L.q + v));
-                        acc = wv::mfma(a, Xd[Ip][v], acc);
+                        const float x = wv::lds_f32(base + OFF_F + 4u * (unsigned)(row * N + (L.q < 2 ? 32 + 4 * L.q + v : 0)));
+                        a[8 + v] = L.q < 2 ? x : 0.f;
                     }
+                    wv::sched_fence();
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float a = wv::lds_f32(base + OFF_F + 4u * (unsigned)(row * N + (L.q < 2 ? 32 + 4 * L.q + v : 0)));
-                    acc = wv::mfma(L.q < 2 ? a : 0.f, Ud[v], acc);
+                    for (int k = 0; k < 8; ++k) acc = wv::mfma(a[k], Xd[k >> 2][k & 3], acc);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc = wv::mfma(a[8 + v], Ud[v], acc);
+                    wv::sched_fence();
                 }
                 if (store && L.r == 0) wv::store_f32x4(p.new_x + tb1 * NS + 16 * Im + 4 * L.q, acc);
                 DXd[Im] = acc;      // parked here until both tiles are done (the second product still reads Xd)
