@@ -92,7 +92,10 @@ bool mfma40_supported(const StepParams<float> &p)
            !(p.bound_mode != MPC_BOUND_NONE && p.zero_mask) &&
            al(p.C) && al(p.c) && (p.T == 1 || al(p.F)) && al(p.cur_x) && al(p.cur_u) && p.C_st % 4 == 0 && p.C_sb % 4 == 0 &&
            p.c_st % 4 == 0 && p.c_sb % 4 == 0 && p.F_st % 4 == 0 && p.F_sb % 4 == 0 &&
-           (!p.f || (al(p.f) && p.f_st % 4 == 0 && p.f_sb % 4 == 0)) && al(p.x_init);
+           (!p.f || (al(p.f) && p.f_st % 4 == 0 && p.f_sb % 4 == 0)) && al(p.x_init) &&
+           // mask bytes and bound rows are read as dwords through the scalar path
+           (!p.zero_mask || ((uintptr_t)p.zero_mask & 3) == 0) &&
+           (p.bound_mode != MPC_BOUND_TENSOR || ((((uintptr_t)p.lo | (uintptr_t)p.hi) & 3) == 0));
 }
 
 int launch_step_mfma40(const StepParams<float> &p, hipStream_t st)
