@@ -374,6 +374,18 @@ class HipBackend:
         return res
 
     # -- (4) LQRStepFn.backward -----------------------------------------------------------------
+    def _zero_nominal(self, T, B, ns, nc, kw):
+        """The nested solve's nominal (x, u, x_init) = 0: read-only, so one copy per shape serves every backward
+        (three fill kernels less per call)."""
+        key = (T, B, ns, nc, kw["dtype"], str(kw["device"]))
+        cache = self.__dict__.setdefault("_zero_cache", {})
+        z = cache.get(key)
+        if z is None:
+            if len(cache) >= 8:
+                cache.clear()
+            z = cache[key] = (torch.zeros(T, B, ns, **kw), torch.zeros(T, B, nc, **kw), torch.zeros(B, ns, **kw))
+        return z
+
     def kkt_backward(self, C, c, F, f, x_star, u_star, dl_dx, dl_du, opts, impl=IMPL_AUTO):
         """dx_init, dC, dc, dF, df of mpc/lqr_step.py:312-407 (reference), all on device."""
         dev = _require_device(C, c, F, x_star, u_star, dl_dx, dl_du)
@@ -397,16 +409,14 @@ class HipBackend:
                                      ctypes.byref(o), negr.data_ptr(), _ptr(mask), st), "mpc_lqr_kkt_prepare")
         # nested solve of :328-340: one LQR step on (C, -r, F, f=None) from the zero nominal with
         # the active controls pinned; defaults linesearch_decay=0.2, max_linesearch_iter=10.
-        zx = torch.zeros(T, B, ns, **kw)
-        zu = torch.zeros(T, B, nc, **kw)
-        z0 = torch.zeros(B, ns, **kw)
+        zx, zu, z0 = self._zero_nominal(T, B, ns, nc, kw)
         inner = StepOptions(u_zero_I=mask)
         sol = self.lqr_step(z0, C, negr, F, None, zx, zu, inner, impl=impl)
         p, keep = self._problem(z0, C, c, F, f, x_star, u_star)
         has_f = f is not None and f.numel() > 0
         dC = torch.empty(T, B, n, n, **kw)
         dc = torch.empty(T, B, n, **kw)
-        dF = torch.zeros(F.shape, **kw)
+        dF = torch.empty(F.shape, **kw)          # every kernel writes all of it (t < T-1 is all there is)
         df = torch.empty(T - 1, B, ns, **kw) if has_f else None
         dx_init = torch.empty(B, ns, **kw)
         _check(L.mpc_lqr_kkt_grads(ctypes.byref(p), sol["new_x"].data_ptr(), sol["new_u"].data_ptr(),
