@@ -1,7 +1,7 @@
 # per-wave SQ counters of every lqr_step dispatch of tools/ls_probe.py (diagnostic)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/ls_pmc; rm -rf $O; mkdir -p $O
-rocprofv3 --pmc SQ_INSTS SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O -o p -- env MPC_LQR_HIP_LIB=${LIB:-} python tools/ls_probe.py > $O/log 2>&1
+timeout 150 rocprofv3 --pmc SQ_INSTS SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O -o p -- env MPC_LQR_HIP_LIB=${LIB:-} python tools/ls_probe.py > $O/log 2>&1
 python - "$O" <<'PY'
 import glob, sqlite3, sys, collections
 db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
