@@ -762,3 +762,39 @@ def test_north_star_properties(be):
     ok = r4["alphas"] > 0
     assert (r4["costs"][ok] <= r4["old_costs"][ok] * (1 + 1e-5) + 1e-3).all()
     assert int(r4["status"].max().item()) & 2 == 0
+
+
+def test_kkt_backward_is_repeatable(be):
+    """The backward re-uses one zero nominal per shape and leaves dF to the kernels (no zero fill): two calls on
+    the same inputs, with another shape in between, return bit-identical gradients and never touch the cache."""
+    from mpc._native import StepOptions
+    import bench
+    p = bench.make_problem(12, 4, 9, 37, torch.float32, DEV, seed=3, u_scale=0.3, clamp=0.5)
+    opts = StepOptions(u_lower=-0.5, u_upper=0.5)
+    r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts)
+    gx, gu = torch.randn_like(r["new_x"]), torch.randn_like(r["new_u"])
+    a = be.kkt_backward(p["C"], p["c"], p["F"], p["f"], r["new_x"], r["new_u"], gx, gu, opts)
+    q = bench.make_problem(5, 2, 4, 6, torch.float32, DEV, seed=4)
+    rq = be.lqr_step(q["x_init"], q["C"], q["c"], q["F"], q["f"], q["cur_x"], q["cur_u"], StepOptions())
+    be.kkt_backward(q["C"], q["c"], q["F"], q["f"], rq["new_x"], rq["new_u"], torch.randn_like(rq["new_x"]),
+                    torch.randn_like(rq["new_u"]), StepOptions())
+    b = be.kkt_backward(p["C"], p["c"], p["F"], p["f"], r["new_x"], r["new_u"], gx, gu, opts)
+    torch.cuda.synchronize()
+    for k in ("dx_init", "dC", "dc", "dF", "df"):
+        assert torch.equal(a[k], b[k]), k
+        assert bool(torch.isfinite(a[k]).all()), k
+    for z in be._zero_cache.values():
+        assert all(float(t.abs().max()) == 0.0 for t in z)
+
+
+def test_sharded_solve_on_one_rank_is_the_plain_solve(be):
+    """shard.mpc_forward_sharded without a process group (world size 1) is MPC.forward."""
+    from mpc import mpc, shard
+    from mpc.mpc import LinDx, QuadCost
+    import bench
+    p = bench.make_problem(12, 4, 8, 21, torch.float32, DEV, seed=9, u_scale=0.3, clamp=1.0)
+    ctrl = mpc.MPC(12, 4, 8, u_lower=-1.0, u_upper=1.0, lqr_iter=6, verbose=-1, exit_unconverged=False)
+    x0, u0, c0 = ctrl(p["x_init"], QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"]))
+    x1, u1, c1 = shard.mpc_forward_sharded(ctrl, p["x_init"], QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"]), lockstep=True)
+    torch.cuda.synchronize()
+    assert torch.equal(x0, x1) and torch.equal(u0, u1) and torch.equal(c0, c1)
