@@ -93,6 +93,17 @@ template <int MODE, bool ROLL, bool DIRECT> MPC_DEV unsigned stage_mid(int slot)
                 : (unsigned)(slot * (int)STAGE_BYTES + (int)SF);
 }
 
+// ---- LDS bank conflicts ----------------------------------------------------------------------------------
+// Row-major 64-byte rows read as one b128 per lane (lane j = row j) put eight lanes on the same four banks, and
+// the four problems' F blocks (768 B apart) alias bank for bank under column reads.  Both go away by permuting
+// 16-byte granules, which the DMA does for free:
+//   rows read by b128 (C always, F in the rollout): quarter q of row j is stored at quarter q ^ s(j), s(j) = (j>>1)&3
+//   F read by columns (sweep, KKT):                 odd problems store row m at row m ^ 1 (the other 16 banks)
+MPC_DEV int quarter_swizzle(int row) { return (row >> 1) & 3; }
+// source granule (of the 64 of a 16x16 block / the 48 of a 12x16 block) for LDS granule position g
+MPC_DEV int src_granule_rows(int g) { return (g & ~3) | ((g & 3) ^ quarter_swizzle(g >> 2)); }
+MPC_DEV int src_granule_cols(int g, int problem_slot) { return g ^ ((problem_slot & 1) << 2); }
+
 struct Lane {
     int lane, p, j;       // problem slot in the wave, variable
     int pb;               // problem index (clamped to B-1)
@@ -101,9 +112,11 @@ struct Lane {
     bool isu;             // j >= 12
     int a;                // control index of this lane (j - 12), 0 for state lanes
     // LDS byte offsets inside a stage
-    int aCrow;            // SC + p*1024 + 64 j                 (row j of C: 4 x b128)
-    int aFcol;            // SF + p*768 + 4 j                   (+64 m: F[m][j])
-    int aFrow;            // SF + p*768 + 64 min(j, 11)         (row j of F: 4 x b128, state lanes)
+    // C and F sit in LDS in granule-permuted order (see lds_swizzle below): a lane's 16-byte DMA destination is
+    // fixed, its source is free, so the permutation costs nothing and the reads below are bank-conflict free
+    int aCq[4];           // SC + p*1024 + 64 j + 16 (q ^ s(j))  quarter q of row j of C            (b128)
+    int aFe, aFo;         // SF + p*768 + 4 j (+-64 for odd p)   F[m][j] at aFe + 64 m (m even) / aFo + 64 m (m odd)
+    int aFq[4];           // SF + p*768 + 64 j' + 16 (q ^ s(j')) quarter q of row j' = min(j, 11) of F (b128, rollout)
     int aRec;             // SR + p*256 + 4 j                   (+R_c: c_j, +R_tau: tau_j)
     int aRecA;            // SR + p*256 + 4 a                   (+R_lo / R_hi)
     int aRecF;            // SR + p*256 + R_f + 4 min(j, 11)
@@ -126,9 +139,13 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
     L.isu = L.j >= 12;
     L.a = L.isu ? L.j - 12 : 0;
     const int jx = L.j < 12 ? L.j : 11;
-    L.aCrow = SC + L.p * 1024 + 64 * L.j;
-    L.aFcol = SF + L.p * 768 + 4 * L.j;
-    L.aFrow = SF + L.p * 768 + 64 * jx;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        L.aCq[q] = SC + L.p * 1024 + 64 * L.j + 16 * (q ^ quarter_swizzle(L.j));
+        L.aFq[q] = SF + L.p * 768 + 64 * jx + 16 * (q ^ quarter_swizzle(jx));
+    }
+    L.aFe = SF + L.p * 768 + 4 * L.j + ((L.p & 1) ? 64 : 0);
+    L.aFo = SF + L.p * 768 + 4 * L.j - ((L.p & 1) ? 64 : 0);
     L.aRec = SR + L.p * 256 + 4 * L.j;
     L.aRecA = SR + L.p * 256 + 4 * L.a;
     L.aRecF = SR + L.p * 256 + R_f + 4 * jx;
@@ -152,7 +169,8 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
 struct Dma {
     // all biased by minus the immediate their instruction carries (see wv::dma16_at)
     const char *c_ptr[4];     // wave-uniform per problem slot        imm 1024 k - 4096
-    const char *f_ptr[3];     // per lane                             imm 1024 k
+    const char *f_ptr[3];     // per lane (column-read order)         imm 1024 k
+    const char *f_ptr_r[3];   // per lane (row-read order, rollout)   imm 1024 k
     const char *r_ptr;        // per lane                             imm 3072
     const char *g_ptr;        // per lane                             imm -1024 (packed rollout)
     const char *g2_ptr;       // per lane: the (m, M) record          imm -2048 (packed rollout)
@@ -167,7 +185,7 @@ MPC_DEV void dma_init(Dma &d, const P &p, const Lane &L, int wave)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int pbk = 4 * wave + k < p.B ? 4 * wave + k : p.B - 1;
-        d.c_ptr[k] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * L.lane - (1024 * k - 4096);
+        d.c_ptr[k] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * src_granule_rows(L.lane) - (1024 * k - 4096);
     }
     d.c_step = 4 * p.C_st;
 #pragma unroll
@@ -175,7 +193,9 @@ MPC_DEV void dma_init(Dma &d, const P &p, const Lane &L, int wave)
         const int G = 64 * k + L.lane;
         const int slot = G / 48, gi = G - 48 * slot;
         const int pbk = 4 * wave + slot < p.B ? 4 * wave + slot : p.B - 1;
-        d.f_ptr[k] = (p.T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) + 16 * gi : (const char *)p.C) - 1024 * k;
+        const char *fb = p.T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) : (const char *)p.C;
+        d.f_ptr[k] = fb + (p.T > 1 ? 16 * src_granule_cols(gi, slot) : 0) - 1024 * k;
+        d.f_ptr_r[k] = fb + (p.T > 1 ? 16 * src_granule_rows(gi) : 0) - 1024 * k;
     }
     d.f_step = 4 * p.F_st;
     {
@@ -221,9 +241,9 @@ MPC_DEV void stage_issue(const P &p, const Dma &d, int t, int slot)
     }
     {
         const long o = p.T > 1 ? tf * d.f_step : 0;
-        wv::dma16_at<0, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[0] + o, mid);
-        wv::dma16_at<1024, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[1] + o, mid);
-        wv::dma16_at<2048, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[2] + o, mid);
+        wv::dma16_at<0, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>((ROLL ? d.f_ptr_r[0] : d.f_ptr[0]) + o, mid);
+        wv::dma16_at<1024, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>((ROLL ? d.f_ptr_r[1] : d.f_ptr[1]) + o, mid);
+        wv::dma16_at<2048, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>((ROLL ? d.f_ptr_r[2] : d.f_ptr[2]) + o, mid);
     }
     // the record instruction is issued by every wave even if only some lanes take part
     {
@@ -298,12 +318,12 @@ MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, uns
     const unsigned base = (unsigned)slot * STAGE_BYTES;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 v = wv::lds_f32x4(base + L.aCrow + 16 * q);
+        const f32x4 v = wv::lds_f32x4(base + L.aCq[q]);
         s.Cc[4 * q] = v[0]; s.Cc[4 * q + 1] = v[1]; s.Cc[4 * q + 2] = v[2]; s.Cc[4 * q + 3] = v[3];
     }
     // at t = T-1 the F slot holds a copy of F[T-2] (stage_issue clamps the index) and nothing looks at it
 #pragma unroll
-    for (int m = 0; m < 12; ++m) s.Fc[m] = wv::lds_f32(base + L.aFcol + 64 * m);
+    for (int m = 0; m < 12; ++m) s.Fc[m] = wv::lds_f32(base + ((m & 1) ? L.aFo : L.aFe) + 64 * m);
     s.cj = wv::lds_f32(base + L.aRec + R_c);
     s.tb = wv::lds_f32(base + L.aRec + R_tau);
 #pragma unroll
@@ -529,7 +549,7 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
     if (DIRECT) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 v = wv::lds_f32x4(base + L.aCrow + 16 * q);
+            const f32x4 v = wv::lds_f32x4(base + L.aCq[q]);
             s.Cr[4 * q] = v[0]; s.Cr[4 * q + 1] = v[1]; s.Cr[4 * q + 2] = v[2]; s.Cr[4 * q + 3] = v[3];
         }
         s.cj = wv::lds_f32(base + L.aRec + R_c);
@@ -545,7 +565,7 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
     // (t = T-1: a copy of F[T-2], unused)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 v = wv::lds_f32x4(base + L.aFrow + 16 * q);
+        const f32x4 v = wv::lds_f32x4(base + L.aFq[q]);
         s.Fr[4 * q] = v[0]; s.Fr[4 * q + 1] = v[1]; s.Fr[4 * q + 2] = v[2]; s.Fr[4 * q + 3] = v[3];
     }
     s.fj = p.f ? wv::lds_f32(base + L.aRecF) : 0.f;
@@ -896,7 +916,7 @@ MPC_DEV void kkt_dma_init(KktDma &d, const P &p, const KktArgs &k, const Lane &L
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int pbk = 4 * wave + q < p.B ? 4 * wave + q : p.B - 1;
-        d.c_ptr[q] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * L.lane;
+        d.c_ptr[q] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * src_granule_rows(L.lane);
     }
     d.c_step = 4 * p.C_st;
 #pragma unroll
@@ -904,7 +924,7 @@ MPC_DEV void kkt_dma_init(KktDma &d, const P &p, const KktArgs &k, const Lane &L
         const int G = 64 * q + L.lane;
         const int slot = G / 48, gi = G - 48 * slot;
         const int pbk = 4 * wave + slot < p.B ? 4 * wave + slot : p.B - 1;
-        d.f_ptr[q] = p.T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) + 16 * gi : (const char *)p.C;
+        d.f_ptr[q] = p.T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) + 16 * src_granule_cols(gi, slot) : (const char *)p.C;
     }
     d.f_step = 4 * p.F_st;
     // record granules: 0-3 c | 4-6 x* | 7 u* | 8-10 dx | 11 du | 12-14 dl_dx
@@ -958,13 +978,13 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
                 float Cr[16], Fc[12];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = wv::lds_f32x4(base + L.aCrow + 16 * q);
+                    const f32x4 v = wv::lds_f32x4(base + L.aCq[q]);
                     Cr[4 * q] = v[0]; Cr[4 * q + 1] = v[1]; Cr[4 * q + 2] = v[2]; Cr[4 * q + 3] = v[3];
                 }
                 const bool have = t < T - 1;
                 if (have) {
 #pragma unroll
-                    for (int m = 0; m < 12; ++m) Fc[m] = wv::lds_f32(base + L.aFcol + 64 * m);
+                    for (int m = 0; m < 12; ++m) Fc[m] = wv::lds_f32(base + ((m & 1) ? L.aFo : L.aFe) + 64 * m);
                 } else {
 #pragma unroll
                     for (int m = 0; m < 12; ++m) Fc[m] = 0.f;
