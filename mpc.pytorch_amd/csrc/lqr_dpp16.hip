@@ -19,6 +19,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 MPC_DEV int lane() { return (int)threadIdx.x; }
 MPC_DEV int problem() { return (int)blockIdx.x; }
 MPC_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // 1 ulp
+// an opaque register-to-register identity: keeps hipcc from folding a chain of selects back into scalar mask logic
+MPC_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
 MPC_DEV bool uniform(bool c) { return c; }
 MPC_DEV int uniform(int v) { return v; }
 MPC_DEV bool any(bool c) { return __ballot(c) != 0ull; }

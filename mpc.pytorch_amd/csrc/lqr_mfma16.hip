@@ -24,6 +24,8 @@ MPC_DEV float rcp(float x)
     float r = __builtin_amdgcn_rcpf(x);
     return fmaf(fmaf(-x, r, 1.f), r, r);     // one Newton step: <= 1 ulp
 }
+// an opaque register-to-register identity: keeps hipcc from folding a chain of selects back into scalar mask logic
+MPC_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
 MPC_DEV bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 MPC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 MPC_DEV unsigned long long ballot(bool c) { return __ballot(c); }

@@ -10,6 +10,13 @@ namespace mpclqr {
 namespace mfma16 {
 
 MPC_DEV float sel(bool c, float a, float b) { return c ? a : b; }
+// (c0 & c1) ? x : 0 as two dependent selects (see ldl4)
+MPC_DEV float sel2(bool c0, bool c1, float x)
+{
+    float t = c1 ? x : 0.f;
+    wv::pin(t);
+    return c0 ? t : 0.f;
+}
 MPC_DEV float dot4(const float a[4], float b0, float b1, float b2, float b3)
 {
     return fmaf(a[3], b3, fmaf(a[2], b2, fmaf(a[1], b1, a[0] * b0)));
@@ -30,16 +37,19 @@ MPC_DEV void ldl4(Ldl4 &f, const Sym4 &s, const bool fr_[4], float reg)
     bool fr[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) fr[a] = MASKED ? fr_[a] : true;
-    // (bitwise & on purpose: && makes the compiler branch on the exec mask for every pair)
+    // An entry survives if both its row and its column are free: two selects in a row, NOT one select on the AND of
+    // the two masks -- lane masks live in SGPRs, their AND is a scalar instruction, and a VALU -> SALU -> VALU
+    // dependency costs ~16 clocks more than VALU -> VALU (tools/ubench/valu_rate.hip: 8.7 against 4.7 clocks per
+    // instruction of such a chain).  wv::pin keeps the compiler from merging the selects again.
     const float a00 = fr[0] ? s.s00 + reg : 1.f;
-    const float a10 = (fr[0] & fr[1]) ? s.s01 : 0.f;
-    const float a20 = (fr[0] & fr[2]) ? s.s02 : 0.f;
-    const float a30 = (fr[0] & fr[3]) ? s.s03 : 0.f;
+    const float a10 = MASKED ? sel2(fr[0], fr[1], s.s01) : s.s01;
+    const float a20 = MASKED ? sel2(fr[0], fr[2], s.s02) : s.s02;
+    const float a30 = MASKED ? sel2(fr[0], fr[3], s.s03) : s.s03;
     const float a11 = fr[1] ? s.s11 + reg : 1.f;
-    const float a21 = (fr[1] & fr[2]) ? s.s12 : 0.f;
-    const float a31 = (fr[1] & fr[3]) ? s.s13 : 0.f;
+    const float a21 = MASKED ? sel2(fr[1], fr[2], s.s12) : s.s12;
+    const float a31 = MASKED ? sel2(fr[1], fr[3], s.s13) : s.s13;
     const float a22 = fr[2] ? s.s22 + reg : 1.f;
-    const float a32 = (fr[2] & fr[3]) ? s.s23 : 0.f;
+    const float a32 = MASKED ? sel2(fr[2], fr[3], s.s23) : s.s23;
     const float a33 = fr[3] ? s.s33 + reg : 1.f;
     f.i0 = wv::rcp(a00);
     f.l10 = a10 * f.i0; f.l20 = a20 * f.i0; f.l30 = a30 * f.i0;
@@ -93,19 +103,33 @@ MPC_DEV float eclampf(float x, float lo, float hi)
 // 16-lane row has its own problem and the loops simply diverge per row.
 template <bool UNIFORM = true>
 MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const float ub[4],
-                  const bool valid[4], int n_iter, float x[4], bool fr[4], Ldl4 &f, bool &converged)
+                  const bool valid[4], int n_iter, float x[4], bool fr_out[4], Ldl4 &f, bool &converged)
 {
     int it_ret = n_iter - 1;
-    converged = false;
+    // What leaves the loop is carried as numbers, not as booleans: per-row loops diverge, a boolean that lives
+    // across a divergent loop is a lane mask in SGPRs, and every trip then merges each of them with three scalar
+    // instructions -- dependent on the vector ALU's compares (see ldl4).  A VGPR merges by the exec mask for free.
+    float fr_f[4] = {0.f, 0.f, 0.f, 0.f};
+    float conv_f = 0.f;
     for (int it = 0; it < n_iter; ++it) {
+        bool fr[4];
         float g[4];
         sym4_mv(s, x, g);                                           // :29
         float gm[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             g[a] += q[a];
-            const bool ic = ((x[a] == lb[a]) & (g[a] > 0.f)) | ((x[a] == ub[a]) & (g[a] < 0.f));      // :32
-            fr[a] = valid[a] & !ic;
+            // :32  clamped = (x == lb & g > 0) | (x == ub & g < 0), decided on the vector ALU: the larger of
+            // "g if at the lower bound" and "-g if at the upper bound" is positive exactly then
+            float r_lo = (x[a] == lb[a]) ? g[a] : -1.f;
+            float r_hi = (x[a] == ub[a]) ? -g[a] : -1.f;
+            wv::pin(r_lo);
+            wv::pin(r_hi);
+            float r = fmaxf(r_lo, r_hi);
+            wv::pin(r);
+            fr[a] = valid[a] & !(r > 0.f);
+            fr_f[a] = fr[a] ? 1.f : 0.f;
+            wv::pin(fr_f[a]);
             gm[a] = fr[a] ? g[a] : 0.f;
         }
         ldl4<true>(f, s, fr, 1e-11f);                                // :44-48
@@ -119,7 +143,8 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
         }
         const bool small = !(nrm2 >= 1e-8f);                        // |dx| < 1e-4
         if (UNIFORM ? wv::uniform(small) : small) {                 // :56-59
-            converged = true;
+            conv_f = 1.f;
+            wv::pin(conv_f);
             it_ret = it;
             break;
         }
@@ -129,13 +154,19 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
         // ratio is rounding noise once |dx| ~ 1e-4 and sends the reference's own float32 run into ten
         // futile halvings; the float64 reference takes the step.)
         float mx[4];
-        bool inside = true;
+        float in_f = 1.f;                       // stays 1 while every coordinate is inside (selects, no mask logic)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const float xn = x[a] + dx[a];
             mx[a] = xn;
-            inside = inside & (((xn >= lb[a]) & (xn <= ub[a])) | !valid[a]);
+            if (valid[a]) {
+                in_f = (xn >= lb[a]) ? in_f : 0.f;
+                wv::pin(in_f);
+                in_f = (xn <= ub[a]) ? in_f : 0.f;
+                wv::pin(in_f);
+            }
         }
+        const bool inside = in_f > 0.f;
         if (UNIFORM ? wv::uniform(inside) : inside) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) x[a] = mx[a];
@@ -165,6 +196,9 @@ MPC_DEV int pnqp4(const Sym4 &s, const float q[4], const float lb[4], const floa
 #pragma unroll
         for (int a = 0; a < 4; ++a) x[a] = mx[a];                    // :78
     }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) fr_out[a] = fr_f[a] != 0.f;
+    converged = conv_f != 0.f;
     return it_ret;
 }
 

@@ -180,6 +180,25 @@ template <int KIND> __global__ void __launch_bounds__(64, 1) k(float *out, long 
                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11])
                 : "v"(s[0]), "v"(m));
 #undef X
+        } else if (KIND == 25) {
+            // the mask logic of the box QP: two compares into SGPR masks, a scalar AND, a select on the result
+            unsigned long long m0, m1, m2;
+#define X(i) "v_cmp_lt_f32_e64 %12, %15, %" #i "\nv_cmp_gt_f32_e64 %13, %16, %" #i "\ns_and_b64 %14, %12, %13\nv_cndmask_b32_e64 %" #i ", %15, %16, %14\n"
+            asm volatile(R12(X)
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]),
+                  "=&s"(m0), "=&s"(m1), "=&s"(m2)
+                : "v"(s[0]), "v"(m) : "scc");
+#undef X
+        } else if (KIND == 26) {
+            // the same decision without the scalar unit: compare, select 0/1, compare-and-select again
+            unsigned long long m0, m1;
+            float t;
+#define X(i) "v_cmp_lt_f32_e64 %12, %15, %" #i "\nv_cndmask_b32_e64 %14, %16, %15, %12\nv_cmp_gt_f32_e64 %13, %14, %" #i "\nv_cndmask_b32_e64 %" #i ", %15, %16, %13\n"
+            asm volatile(R12(X)
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]),
+                  "=&s"(m0), "=&s"(m1), "=&v"(t)
+                : "v"(s[0]), "v"(m));
+#undef X
         } else if (KIND == 8) {
             // plain fmac reading a different source each time through 2 DPP-free alternates: v_fma_f32 (VOP3)
 #define X(i) "v_fma_f32 %" #i ", %12, %13, %" #i "\n"
@@ -240,6 +259,8 @@ int main()
         run<22>("s_and_b64 / s_or_b64 dependent", grid, rep, out, cyc);
         run<23>("v_readlane / v_writelane dependent", grid, rep, out, cyc);
         run<24>("v_max_f32", grid, rep, out, cyc);
+        run<25>("cmp, cmp, s_and, cndmask (per instr, dependent)", grid, rep, out, cyc);
+        run<26>("cmp, cndmask, cmp, cndmask (per instr, dependent)", grid, rep, out, cyc);
         run<9>("v_fmac_f32, one accumulator (dependent)", grid, rep, out, cyc);
         run<10>("v_fmac_f32, two accumulators", grid, rep, out, cyc);
         run<11>("v_rcp_f32 dependent", grid, rep, out, cyc);
