@@ -183,7 +183,13 @@ MPC_DEV void ldl8_masked(Ldl8 &f, const float S[8][8], const bool fr[8], float r
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int c = a; c < 8; ++c) M[a][c] = a == c ? (fr[a] ? S[a][a] + reg : 1.f) : ((fr[a] & fr[c]) ? S[a][c] : 0.f);
+        for (int c = a; c < 8; ++c) {
+            // off the diagonal two dependent selects instead of one on the AND of the masks: the AND is a scalar
+            // instruction in the middle of a vector dependency chain (+16 clocks, see lqr_small_math.h)
+            float off = fr[c] ? S[a][c] : 0.f;
+            wv::pin(off);
+            M[a][c] = a == c ? (fr[a] ? S[a][a] + reg : 1.f) : (fr[a] ? off : 0.f);
+        }
     ldl8(f, M);
 }
 MPC_DEV float sym8_row(const float S[8][8], int a, const float x[8])
@@ -212,22 +218,32 @@ MPC_DEV int pnqp8(const float S[8][8], const float q[8], const float lb[8], cons
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             g[a] = sym8_row(S, a, x) + q[a];                                                         // :29
-            const bool ic = ((x[a] == lb[a]) & (g[a] > 0.f)) | ((x[a] == ub[a]) & (g[a] < 0.f));      // :32
-            fr[a] = !ic;
+            // :32 clamped = (x == lb & g > 0) | (x == ub & g < 0), on the vector ALU (as in pnqp4)
+            float r_lo = (x[a] == lb[a]) ? g[a] : -1.f;
+            float r_hi = (x[a] == ub[a]) ? -g[a] : -1.f;
+            wv::pin(r_lo);
+            wv::pin(r_hi);
+            float r = fmaxf(r_lo, r_hi);
+            wv::pin(r);
+            fr[a] = !(r > 0.f);
             gm[a] = fr[a] ? g[a] : 0.f;
         }
         ldl8_masked(f, S, fr, 1e-11f);                                                                // :44-48
         ldl8_solve(f, gm, dx);                                                                        // :50-54
         float nrm2 = 0.f;
-        bool inside = true;
+        float in_f = 1.f;
         float mx[8];
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             dx[a] = fr[a] ? -dx[a] : 0.f;
             nrm2 = fmaf(dx[a], dx[a], nrm2);
             mx[a] = x[a] + dx[a];
-            inside = inside & ((mx[a] >= lb[a]) & (mx[a] <= ub[a]));
+            in_f = (mx[a] >= lb[a]) ? in_f : 0.f;
+            wv::pin(in_f);
+            in_f = (mx[a] <= ub[a]) ? in_f : 0.f;
+            wv::pin(in_f);
         }
+        const bool inside = in_f > 0.f;
         if (wv::uniform(!(nrm2 >= 1e-8f))) {                                                          // :56-59
             converged = true;
             it_ret = it;
