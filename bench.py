@@ -106,7 +106,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # (MPC_BENCH_FORCE_DIST=1: take the process-group path at world size 1 too -- a single-GPU box can then
+    # exercise the RCCL initialisation and the collectives of the N > 1 run)
+    saved_stdout = None
+    if world > 1 or os.environ.get("MPC_BENCH_FORCE_DIST"):
+        # RCCL writes a version banner to file descriptor 1 when the communicator is created; stdout carries exactly
+        # one JSON line, so everything until then goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -204,7 +212,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(512, args.bounded)
-        print(json.dumps(out))
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
