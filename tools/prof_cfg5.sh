@@ -3,9 +3,9 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_cfg5
 mkdir -p $O
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python tools/bench_cfg5.py 1024 > $O/kt.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM -d $O/pmc1 -o pmc1 -- python tools/bench_cfg5.py 1024 > $O/pmc1.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_LEVEL_VMEM -d $O/pmc2 -o pmc2 -- python tools/bench_cfg5.py 1024 > $O/pmc2.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python tools/bench_cfg5.py 1024 > $O/kt.log 2>&1
+timeout 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM -d $O/pmc1 -o pmc1 -- python tools/bench_cfg5.py 1024 > $O/pmc1.log 2>&1
+timeout 150 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_LEVEL_VMEM -d $O/pmc2 -o pmc2 -- python tools/bench_cfg5.py 1024 > $O/pmc2.log 2>&1
 python - <<PY
 import glob, json, sqlite3
 O="$O"
