@@ -88,20 +88,43 @@ MPC_HD void sweep_problem(const StepParams<real> &p, int b, real *Kw, bool write
     bool warm = false;
     real kprev = 0;
 
-    // ------------------------------------------------------------------ sweep
-    for (int t = T - 1; t >= 0; --t) {
+    // One lane walks the horizon alone: nothing hides a load's latency but the lane's own arithmetic.  Up to
+    // n_state = 4 the stage of the next timestep (C, c, x, u: n^2 + 2n + 1 numbers) is fetched while this one is
+    // worked on; wider states would pay for the second copy with register spills.
+    constexpr bool PREFETCH = NS <= 4;
+    struct Stage { real C[N][N], c[N], tau[N]; };
+    auto fetch = [&](int t, Stage &g) {
         const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
         const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
         const long tb = (long)t * B + b;
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) g.C[i][j] = Ct[i * N + j];
+        for (int i = 0; i < N; ++i) g.c[i] = ct[i];
+        for (int i = 0; i < NS; ++i) g.tau[i] = p.cur_x[tb * NS + i];
+        g.tau[NS] = p.cur_u[tb];
+    };
+    Stage ahead;
+    if (PREFETCH) fetch(T - 1, ahead);
+
+    // ------------------------------------------------------------------ sweep
+    for (int t = T - 1; t >= 0; --t) {
+        const long tb = (long)t * B + b;
+        Stage held;
+        if (PREFETCH) {
+            held = ahead;
+            if (t > 0) fetch(t - 1, ahead);
+        } else {
+            fetch(t, ahead);
+        }
+        const Stage &now = PREFETCH ? held : ahead;
         real Q[N][N], q[N], tau[N];
         for (int i = 0; i < N; ++i)
-            for (int j = 0; j < N; ++j) Q[i][j] = Ct[i * N + j];
-        for (int i = 0; i < NS; ++i) tau[i] = p.cur_x[tb * NS + i];
-        tau[NS] = p.cur_u[tb];
+            for (int j = 0; j < N; ++j) Q[i][j] = now.C[i][j];
+        for (int i = 0; i < N; ++i) tau[i] = now.tau[i];
         for (int i = 0; i < N; ++i) {                  // c_back = C tau + c (:289-295) and the nominal cost (:169)
             real r = 0;
             for (int j = 0; j < N; ++j) r += Q[i][j] * tau[j];
-            const real ci = ct[i];
+            const real ci = now.c[i];
             old_cost += (double)((real)0.5 * tau[i] * r + ci * tau[i]);
             q[i] = r + ci;
         }
@@ -201,14 +224,41 @@ MPC_HD void rollout_pass(const StepParams<real> &p, int b, const real *Kw, real 
     }
     real da = 0;
     double ca = 0;
-    for (int t = 0; t < T; ++t) {
+    // (the same one-stage look-ahead as the sweep: gains, nominal control and next nominal state, C, c)
+    constexpr bool PREFETCH = NS <= 4;
+    struct Stage { real K[N], u, xn[NS], C[N][N], c[N]; };
+    auto fetch = [&](int t, Stage &g) {
         const long tb = (long)t * B + b;
         const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
         const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
+        for (int j = 0; j < N; ++j) g.K[j] = Kw[((long)t * N + j) * B + b];
+        g.u = p.cur_u[tb];
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) g.C[i][j] = Ct[i * N + j];
+        for (int i = 0; i < N; ++i) g.c[i] = ct[i];
+        if (t < T - 1) {
+            const long tb1 = (long)(t + 1) * B + b;
+            for (int i = 0; i < NS; ++i) g.xn[i] = p.cur_x[tb1 * NS + i];
+        } else {
+            for (int i = 0; i < NS; ++i) g.xn[i] = 0;
+        }
+    };
+    Stage ahead;
+    if (PREFETCH) fetch(0, ahead);
+    for (int t = 0; t < T; ++t) {
+        const long tb = (long)t * B + b;
+        Stage held;
+        if (PREFETCH) {
+            held = ahead;
+            if (t + 1 < T) fetch(t + 1, ahead);
+        } else {
+            fetch(t, ahead);
+        }
+        const Stage &now = PREFETCH ? held : ahead;
         real r = 0;
-        for (int j = 0; j < NS; ++j) r += Kw[((long)t * N + j) * B + b] * dx[j];
-        const real u = p.cur_u[tb];
-        real un = r + u + alpha * Kw[((long)t * N + NS) * B + b];          // :192
+        for (int j = 0; j < NS; ++j) r += now.K[j] * dx[j];
+        const real u = now.u;
+        real un = r + u + alpha * now.K[NS];                                // :192
         if (p.zero_mask && p.zero_mask[tb]) un = 0;                         // :197-198
         if (p.bound_mode != MPC_BOUND_NONE) {                               // :200-213
             real l = p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[tb];
@@ -227,8 +277,8 @@ MPC_HD void rollout_pass(const StepParams<real> &p, int b, const real *Kw, real 
         tau[NS] = un;
         for (int i = 0; i < N; ++i) {                                       // :230-232
             real s = 0;
-            for (int j = 0; j < N; ++j) s += Ct[i * N + j] * tau[j];
-            ca += (double)((real)0.5 * tau[i] * s + ct[i] * tau[i]);
+            for (int j = 0; j < N; ++j) s += now.C[i][j] * tau[j];
+            ca += (double)((real)0.5 * tau[i] * s + now.c[i] * tau[i]);
         }
         if (t < T - 1) {
             real xn[NS > 5 ? NS : 5];
@@ -246,7 +296,7 @@ MPC_HD void rollout_pass(const StepParams<real> &p, int b, const real *Kw, real 
             const long tb1 = (long)(t + 1) * B + b;
             for (int i = 0; i < NS; ++i) {
                 x[i] = xn[i];
-                dx[i] = xn[i] - p.cur_x[tb1 * NS + i];
+                dx[i] = xn[i] - now.xn[i];
                 if (store) p.new_x[tb1 * NS + i] = xn[i];
             }
         }
