@@ -92,8 +92,9 @@ def cpu_baseline(sample_B, bounded, seed=123):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=100,
+                    help="untimed launches first: the clocks and the Infinity Cache settle over the first ~100 (a step is 0.1 ms)")
     ap.add_argument("--bounded", action="store_true", help="box constraints +-1 (pnqp in the sweep)")
     ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic, 2 fused MFMA, 3 DPP 4-problems-per-wave")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
