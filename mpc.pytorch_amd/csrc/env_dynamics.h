@@ -27,6 +27,48 @@ template <typename real> struct EnvDesc {
 MPC_HD int env_ns(int kind) { return kind == MPC_ENV_CARTPOLE ? 5 : 3; }
 MPC_HD int env_np(int kind) { return kind == MPC_ENV_PENDULUM ? 3 : (kind == MPC_ENV_PENDULUM_FULL ? 5 : 4); }
 
+// sin / cos of an angle of a few radians.  float on the device: the hardware's v_sin_f32 / v_cos_f32 (two
+// instructions each against ~90 of the library routine with its argument reduction; absolute error < 1e-6, inside
+// the fp32 parity tolerance -- tests/test_gpu_parity.py pins F, f and the trajectories against the reference's
+// modules).  The simulator kernels are bound by one lane's instruction count, and the three libm calls of a
+// transition were a third of it.  double and the host build keep the library functions.
+MPC_HD float env_sin(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __sinf(x);
+#else
+    return sinf(x);
+#endif
+}
+MPC_HD float env_cos(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __cosf(x);
+#else
+    return cosf(x);
+#endif
+}
+MPC_HD double env_sin(double x) { return sin(x); }
+MPC_HD double env_cos(double x) { return cos(x); }
+
+// (cos, sin)(atan2(s, c) + delta) without forming the angle: (c, s) / |(c, s)| rotated by delta.  The reference takes
+// atan2 and then cos / sin of the sum (pendulum.py:68,76-77, cartpole.py:76,86-91); the rotation is the same
+// number in exact arithmetic and needs no atan2.
+template <typename real>
+MPC_HD void rotate_direction(real c, real s, real delta, real &c2, real &s2)
+{
+    const real r2 = c * c + s * s;
+    real cu = 1, su = 0;                              // atan2(0, 0) = 0
+    if (r2 > 0) {
+        const real rinv = (real)1 / sqrt(r2);
+        cu = c * rinv;
+        su = s * rinv;
+    }
+    const real cd = env_cos(delta), sd = env_sin(delta);
+    c2 = cu * cd - su * sd;
+    s2 = su * cd + cu * sd;
+}
+
 // One transition x+ = env(x,u).  If J != nullptr also d x+ / d [x;u], row-major [ns][ns+1].
 // The control passes through clamp(u, -u_max, u_max) (pendulum.py:66, cartpole.py:73); its
 // derivative is 1 on the closed interval, as torch.clamp's.
@@ -40,14 +82,13 @@ MPC_HD void env_step(const EnvDesc<real> &e, const real *x, real u, real *out, r
         const real g = e.params[0], mc = e.params[1], mp = e.params[2], l = e.params[3];
         const real mt = mp + mc, pml = mp * l;
         const real px = x[0], v = x[1], c = x[2], s = x[3], w = x[4];
-        const real th = atan2(s, c);
         const real ci = (uc + pml * w * w * s) / mt;
         const real D = l * ((real)(4.0 / 3.0) - mp * c * c / mt);
         const real N = g * s - c * ci;
         const real ta = N / D;
         const real xa = ci - pml * ta * c / mt;
-        const real th2 = th + dt * w;
-        const real c2 = cos(th2), s2 = sin(th2);
+        real c2, s2;                                  // th2 = th + dt * w
+        rotate_direction<real>(c, s, dt * w, c2, s2);
         out[0] = px + dt * v;
         out[1] = v + dt * xa;
         out[2] = c2;
@@ -82,19 +123,22 @@ MPC_HD void env_step(const EnvDesc<real> &e, const real *x, real u, real *out, r
     // pendulum: state (cos th, sin th, dth)
     const real g = e.params[0], m = e.params[1], l = e.params[2];
     const real c = x[0], s = x[1], w = x[2];
-    const real th = atan2(s, c);
     const real kg = (real)1.5 * g / l, ku = (real)3 / (m * l * l);
     real acc, acc_th = 0;     // acc_th: derivative of the acceleration through th (full model)
+    real c2, s2;
     if (e.kind == MPC_ENV_PENDULUM) {
         acc = kg * s + ku * uc;                                   // pendulum.py:70-71 (raw sin_th)
+        rotate_direction<real>(c, s, dt * (w + dt * acc), c2, s2);   // th2 = th + dt * w2
     } else {
+        const real th = atan2(s, c);                              // the full model needs the angle itself
         const real d = e.params[3], b = e.params[4];
-        acc = kg * sin(th + b) + ku * uc - d * th;                // pendulum.py:73-75
-        acc_th = kg * cos(th + b) - d;
+        acc = kg * env_sin(th + b) + ku * uc - d * th;            // pendulum.py:73-75
+        acc_th = kg * env_cos(th + b) - d;
+        const real th2 = th + dt * (w + dt * acc);
+        c2 = env_cos(th2);
+        s2 = env_sin(th2);
     }
     const real w2 = w + dt * acc;
-    const real th2 = th + dt * w2;
-    const real c2 = cos(th2), s2 = sin(th2);
     out[0] = c2;
     out[1] = s2;
     out[2] = w2;
