@@ -93,15 +93,23 @@ MPC_HD void sweep_problem(const StepParams<real> &p, int b, real *Kw, bool write
     // worked on; wider states would pay for the second copy with register spills.
     constexpr bool PREFETCH = NS <= 4;
     struct Stage { real C[N][N], c[N], tau[N]; };
-    auto fetch = [&](int t, Stage &g) {
-        const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
-        const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
-        const long tb = (long)t * B + b;
+    // The stages are visited in order, so every array is a per-lane pointer that steps back by one timestep per
+    // fetch: a vector register pair each, instead of a scalar base and stride per array -- the kernel's ~14 arrays
+    // do not fit the scalar registers, and their spills were a quarter of its instructions.
+    const real *Cp = p.C + (long)(T - 1) * p.C_st + (long)b * p.C_sb;
+    const real *cp = p.c + (long)(T - 1) * p.c_st + (long)b * p.c_sb;
+    const real *xp = p.cur_x + ((long)(T - 1) * B + b) * NS;
+    const real *up = p.cur_u + ((long)(T - 1) * B + b);
+    auto fetch = [&](int, Stage &g) {
         for (int i = 0; i < N; ++i)
-            for (int j = 0; j < N; ++j) g.C[i][j] = Ct[i * N + j];
-        for (int i = 0; i < N; ++i) g.c[i] = ct[i];
-        for (int i = 0; i < NS; ++i) g.tau[i] = p.cur_x[tb * NS + i];
-        g.tau[NS] = p.cur_u[tb];
+            for (int j = 0; j < N; ++j) g.C[i][j] = Cp[i * N + j];
+        for (int i = 0; i < N; ++i) g.c[i] = cp[i];
+        for (int i = 0; i < NS; ++i) g.tau[i] = xp[i];
+        g.tau[NS] = up[0];
+        Cp -= p.C_st;
+        cp -= p.c_st;
+        xp -= (long)B * NS;
+        up -= B;
     };
     Stage ahead;
     if (PREFETCH) fetch(T - 1, ahead);
@@ -227,21 +235,28 @@ MPC_HD void rollout_pass(const StepParams<real> &p, int b, const real *Kw, real 
     // (the same one-stage look-ahead as the sweep: gains, nominal control and next nominal state, C, c)
     constexpr bool PREFETCH = NS <= 4;
     struct Stage { real K[N], u, xn[NS], C[N][N], c[N]; };
+    // (per-lane pointers stepping forward one timestep per fetch, as in the sweep)
+    const real *Cp = p.C + (long)b * p.C_sb;
+    const real *cp = p.c + (long)b * p.c_sb;
+    const real *Kp = Kw + b;
+    const real *up = p.cur_u + b;
+    const real *xp = p.cur_x + ((long)B + b) * NS;         // the nominal state of t + 1
     auto fetch = [&](int t, Stage &g) {
-        const long tb = (long)t * B + b;
-        const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
-        const real *ct = p.c + (long)t * p.c_st + (long)b * p.c_sb;
-        for (int j = 0; j < N; ++j) g.K[j] = Kw[((long)t * N + j) * B + b];
-        g.u = p.cur_u[tb];
+        for (int j = 0; j < N; ++j) g.K[j] = Kp[(long)j * B];
+        g.u = up[0];
         for (int i = 0; i < N; ++i)
-            for (int j = 0; j < N; ++j) g.C[i][j] = Ct[i * N + j];
-        for (int i = 0; i < N; ++i) g.c[i] = ct[i];
+            for (int j = 0; j < N; ++j) g.C[i][j] = Cp[i * N + j];
+        for (int i = 0; i < N; ++i) g.c[i] = cp[i];
         if (t < T - 1) {
-            const long tb1 = (long)(t + 1) * B + b;
-            for (int i = 0; i < NS; ++i) g.xn[i] = p.cur_x[tb1 * NS + i];
+            for (int i = 0; i < NS; ++i) g.xn[i] = xp[i];
         } else {
             for (int i = 0; i < NS; ++i) g.xn[i] = 0;
         }
+        Cp += p.C_st;
+        cp += p.c_st;
+        Kp += (long)N * B;
+        up += B;
+        xp += (long)B * NS;
     };
     Stage ahead;
     if (PREFETCH) fetch(0, ahead);
