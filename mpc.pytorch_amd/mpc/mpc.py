@@ -240,7 +240,11 @@ class MPC(Module):
         step is launched speculatively and simply not used if the flags say stop."""
         T, ns, nc = self.T, self.n_state, self.n_ctrl
         xi = util.detach_maybe(x_init)
+        # the ping-pong plans WRITE into `ua`: it must be this solve's own buffer, never the caller's u_init
+        # (detach / to / contiguous all return the same storage for a contiguous tensor)
         ua = util.detach_maybe(u).contiguous()
+        if self.u_init is not None and ua.untyped_storage().data_ptr() == self.u_init.untyped_storage().data_ptr():
+            ua = ua.clone()
         opts = self._step_options()
         if sim is not None:
             xa, _ = be.env_traj_cost(xi, ua, sim)                         # util.get_traj, :251

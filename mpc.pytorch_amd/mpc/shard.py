@@ -33,7 +33,8 @@ def shard_options(opts, lo, hi):
     return _native.StepOptions(u_lower=_cut(opts.u_lower, lo, hi, 1), u_upper=_cut(opts.u_upper, lo, hi, 1),
                                u_zero_I=_cut(opts.u_zero_I, lo, hi, 1), delta_u=opts.delta_u,
                                linesearch_decay=opts.linesearch_decay,
-                               max_linesearch_iter=opts.max_linesearch_iter, pnqp_iter=opts.pnqp_iter)
+                               max_linesearch_iter=opts.max_linesearch_iter, pnqp_iter=opts.pnqp_iter,
+                               true_dynamics=opts.true_dynamics)     # a simulator EnvSpec has no batch axis
 
 
 def all_gather_batch(t, n_batch, dim, group=None):
@@ -97,7 +98,7 @@ def mpc_forward_sharded(ctrl, x_init, cost, dx, group=None, lockstep=False, gath
     The returned local block keeps its autograd graph (`local`), the gathered tensors are plain data."""
     import copy
     import torch.distributed as dist
-    from .mpc import QuadCost, LinDx
+    from .mpc import QuadCost, LinDx, UnconvergedError
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B = x_init.shape[0]
@@ -119,7 +120,23 @@ def mpc_forward_sharded(ctrl, x_init, cost, dx, group=None, lockstep=False, gath
         cost = QuadCost(cut_field(cost.C, 2), cut_field(cost.c, 1))
     if isinstance(dx, LinDx):
         dx = LinDx(cut_field(dx.F, 2), cut_field(dx.f, 1))
-    x, u, costs = local(_cut(x_init, lo, hi, 0), cost, dx)
+    # A shard that raises UnconvergedError (exit_unconverged=True, mpc/mpc.py:321-324) must not leave the other
+    # ranks blocked in the collective below: every rank learns whether ANY shard failed (one 1-word MAX
+    # all-reduce, only when a collective follows) and then all raise, or none does.
+    err = None
+    try:
+        x, u, costs = local(_cut(x_init, lo, hi, 0), cost, dx)
+    except UnconvergedError as e:
+        if world == 1 or not (gather or lockstep):
+            raise
+        err = e
+    if world > 1 and (gather or lockstep):
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        bad = torch.tensor([0.0 if err is None else 1.0], device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+        if float(bad.item()) > 0:
+            raise err if err is not None else UnconvergedError(
+                "MPC (sharded): another rank's block of problems did not converge (exit_unconverged=True)")
     if world == 1 or not gather:
         return x, u, costs
     T = x.shape[0]

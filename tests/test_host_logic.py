@@ -306,6 +306,24 @@ def test_mpc_forward_matches_reference_solves(name, oracle_backend):
     assert "select_best" in oracle_backend.calls
 
 
+def test_mpc_forward_never_writes_the_callers_u_init(oracle_backend):
+    """The reference never mutates `u_init` (mpc/mpc.py:230-243 only reads it).  The ping-pong step plans of
+    this package write their new controls into raw buffers: a 3-D, contiguous, right-dtype u_init must not
+    be one of them -- a warm start reused over repeated solves would otherwise change between calls."""
+    z = golden("mpc_linear_bounded")
+    ns, nc, T, B = (int(v) for v in z["meta"])
+    g = torch.Generator().manual_seed(5)
+    u_init = (0.1 * torch.randn(T, B, nc, generator=g)).to(tt(z, "C").dtype).contiguous()
+    keep = u_init.clone()
+    outs = []
+    for _ in range(2):
+        ctrl = mpc.MPC(ns, nc, T, u_lower=tt(z, "u_lower"), u_upper=tt(z, "u_upper"), u_init=u_init, lqr_iter=6,
+                       verbose=-1, backprop=False, exit_unconverged=False)
+        outs.append(ctrl(tt(z, "x_init"), QuadCost(tt(z, "C"), tt(z, "c")), LinDx(tt(z, "F"), tt(z, "f"))))
+        assert torch.equal(u_init, keep), "MPC.forward wrote into the caller's u_init"
+    assert torch.equal(outs[0][1], outs[1][1])          # same warm start -> same answer
+
+
 def test_known_answer_table(oracle_backend):
     """examples/Time Varying Linear-Quadratic Control.ipynb cell 1: the printed iteration table."""
     z = golden("mpc_notebook_tvlq")

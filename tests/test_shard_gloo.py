@@ -132,3 +132,50 @@ def test_sharded_mpc_forward(tmp_path, lockstep):
     np.testing.assert_array_equal(got[0]["u"], got[1]["u"])            # every rank holds the gathered result
     if lockstep:
         assert int(got[0]["n_shard"]) == int(got[1]["n_shard"]) == int(got[0]["n_full"])
+
+
+def _unconverged_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "mpc.pytorch_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from mpc import _native, mpc, shard
+    from mpc.mpc import LinDx, QuadCost
+    from oracle_backend import OracleBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _native.set_backend_for_testing(OracleBackend())
+    g = torch.Generator().manual_seed(2)
+    T, ns, nc, B = 5, 3, 2, 4
+    n = ns + nc
+    A = torch.randn(T, B, n, n, generator=g, dtype=torch.float64)
+    C = A.transpose(2, 3).matmul(A)
+    c = torch.randn(T, B, n, generator=g, dtype=torch.float64)
+    F = torch.cat((torch.eye(ns).double() + 0.1 * torch.randn(T - 1, B, ns, ns, generator=g, dtype=torch.float64),
+                   torch.randn(T - 1, B, ns, nc, generator=g, dtype=torch.float64)), 3)
+    x_init = torch.randn(B, ns, generator=g, dtype=torch.float64)
+    # rank 0's block (problems 0, 1) starts AT its optimum (x_init = 0, c = 0 -> u = 0): converged after one
+    # step; rank 1's block needs several iterations against its bounds and gets only one
+    c[:, :2] = 0
+    x_init[:2] = 0
+    ctrl = mpc.MPC(ns, nc, T, u_lower=-0.05, u_upper=0.05, lqr_iter=1, verbose=-1, exit_unconverged=True, eps=1e-9)
+    raised = 0
+    try:
+        shard.mpc_forward_sharded(ctrl, x_init, QuadCost(C, c), LinDx(F))
+    except mpc.UnconvergedError:
+        raised = 1
+    np.savez(os.path.join(out_dir, "unc_rank%d.npz" % rank), raised=raised)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_unconverged_error_is_raised_by_every_rank(tmp_path):
+    """exit_unconverged=True (mpc/mpc.py:321-324) with one shard converged and the other not: every rank raises
+    (the converged one is told through a 1-word all-reduce) instead of one raising and the other waiting forever
+    in the all-gather.  mp.spawn(join=True) would hang / time out on the old behaviour."""
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_unconverged_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [int(np.load(os.path.join(str(tmp_path), "unc_rank%d.npz" % r))["raised"]) for r in range(world)]
+    assert got == [1, 1]
