@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- LQR problem-steps/s of the MI355X LQR step at BASELINE.json's headline workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--bounded] [--impl {0,1,2,3}]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--bounded] [--impl {0..5}] [--no-extra]
 
 Workload (configs[3] of BASELINE.json, the one `metric` is quoted on): synthetic random linear
 dynamics, n_state=12, n_ctrl=4, T=50, batch=4096 PER GPU, fp32, contiguous time-major tensors
 (recipe: SURVEY.md section 8d).  A "step" is one LQRStepFn.forward on that batch -- delta-space
 linear term + Riccati sweep + line-searched rollout (mpc/lqr_step.py:277-309 of the reference) --
-with every input already resident in HBM.  N > 1: one process per GPU (torch.distributed/RCCL),
-each rank owns its own 4096 problems (weak scaling, no data-path collective); the trajectories are
-re-assembled with ONE all-gather at the end of the timed region (north_star: "all-gather only to
-reassemble trajectories").
+with every input already resident in HBM.
 
-Prints ONE JSON line on rank 0: the driver's contract fields + `roofline` (algorithmic bytes /
-mean kernel time from HIP events on the launch stream, vs the 8 TB/s HBM peak) + `cpu_baseline`
-(the C oracle on the host cores over a bounded sample of the same workload, rank 0, N=1 only).
+N > 1: one process per GPU over torch.distributed / RCCL.  Launched either by the driver
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK / WORLD_SIZE in the
+environment) or plainly as `python bench.py --gpus N`, in which case this script RE-EXECUTES ITSELF under
+torch.distributed.run with N ranks on 127.0.0.1 (and exits non-zero if the node has fewer than N GPUs --
+it never falls back to fewer ranks).  Each rank owns its own 4096 problems (weak scaling, no data-path
+collective); the trajectories are re-assembled with ONE all-gather at the end of the timed region
+(north_star: "all-gather only to reassemble trajectories").
+
+Prints ONE JSON line on rank 0: the driver's contract fields + `roofline` (algorithmic bytes / mean kernel
+time from HIP events on the launch stream, vs the 8 TB/s HBM peak) + `cpu_baseline` (the C oracle on the host
+cores over a bounded sample of the same workload, rank 0, N=1 only; `reference_probe` = the unmodified
+reference timed in the build container, another box, from profiles/ref_cpu_probe.json) + `extra` (N=1 only:
+the secondary rows of SURVEY.md 8(d), measured in this same run with the same event method -- box-constrained
+step, KKT backward with its own roofline, 5-iteration MPC.forward, config 5 at B=1024 / 8192 with both
+fractions, the 10-iteration iLQR solves of configs 2 / 3).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,27 +42,35 @@ sys.path.insert(0, ROOT)
 NS, NC, T_H, B_PER_GPU = 12, 4, 50, 4096
 EV_GROUP = 5
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TF = 157.3  # same guide: v_mfma_f32_16x16x4_f32, dense
+SETTLE_LAUNCHES = 100     # clocks and the Infinity Cache settle over the first ~100 launches (a step is 0.1 ms)
+KERNEL_NAMES = {1: "lqr_step_generic_kernel<float>", 2: "lqr_step_mfma16_kernel", 3: "lqr_step_dpp16_kernel",
+                4: "lqr_step_tiny_kernel", 5: "lqr_step_mfma40_kernel"}
 
 
-def make_problem(ns, nc, T, B, dtype, device, seed=0, u_scale=0.0, clamp=None, with_f=True):
+def make_problem(ns, nc, T, B, dtype, device, seed=0, u_scale=0.0, clamp=None, with_f=True, on_device=False):
     """SURVEY.md 8(d) recipe: C = A'A (PSD), c ~ N(0,1), F = [I + 0.2 N/sqrt(ns) | N/sqrt(ns)],
-    f = 0.1 N, x_init ~ N(0,1); nominal u = u_scale * N (clamped), nominal x = its rollout."""
+    f = 0.1 N, x_init ~ N(0,1); nominal u = u_scale * N (clamped), nominal x = its rollout.
+    on_device: draw the numbers with the device's generator (the big config-5 batches; not reproducible on
+    the host, so never used where the CPU oracle has to see the same problem)."""
     from mpc import util
     from mpc.mpc import LinDx
-    g = torch.Generator(device="cpu").manual_seed(seed)
+    gdev = device if on_device else "cpu"
+    g = torch.Generator(device=gdev).manual_seed(seed)
     n = ns + nc
+    kw = dict(generator=g, dtype=torch.float32, device=gdev)
     chunks = []
     for t0 in range(0, T, 10):      # generate in slabs: keeps host memory modest at B = 4096
-        A = torch.randn(min(10, T - t0), B, n, n, generator=g, dtype=torch.float32)
-        chunks.append(A.transpose(2, 3).matmul(A).to(dtype))
-    C = torch.cat(chunks).to(device)
-    c = torch.randn(T, B, n, generator=g, dtype=torch.float32).to(dtype).to(device)
-    R = torch.eye(ns) + 0.2 * torch.randn(T - 1, B, ns, ns, generator=g) / ns ** 0.5
-    S = torch.randn(T - 1, B, ns, nc, generator=g) / ns ** 0.5
+        A = torch.randn(min(10, T - t0), B, n, n, **kw)
+        chunks.append(A.transpose(2, 3).matmul(A).to(dtype).to(device))
+    C = torch.cat(chunks)
+    c = torch.randn(T, B, n, **kw).to(dtype).to(device)
+    R = torch.eye(ns, device=gdev) + 0.2 * torch.randn(T - 1, B, ns, ns, **kw) / ns ** 0.5
+    S = torch.randn(T - 1, B, ns, nc, **kw) / ns ** 0.5
     F = torch.cat((R, S), 3).to(dtype).to(device)
-    f = (0.1 * torch.randn(T - 1, B, ns, generator=g)).to(dtype).to(device) if with_f else None
-    x_init = torch.randn(B, ns, generator=g).to(dtype).to(device)
-    u = (u_scale * torch.randn(T, B, nc, generator=g)).to(dtype).to(device)
+    f = (0.1 * torch.randn(T - 1, B, ns, **kw)).to(dtype).to(device) if with_f else None
+    x_init = torch.randn(B, ns, **kw).to(dtype).to(device)
+    u = (u_scale * torch.randn(T, B, nc, **kw)).to(dtype).to(device)
     if clamp is not None:
         u = u.clamp(-clamp, clamp)
     cur_x = util.get_traj(T, u, x_init, LinDx(F, f))
@@ -63,6 +82,21 @@ def algorithmic_bytes_per_problem(ns, nc, T, elem=4, with_f=True):
     C, c, F, f, x_init, nominal (x,u) in, new (x,u) out, (cost, du-norm)."""
     n = ns + nc
     return elem * (T * n * n + T * n + (T - 1) * ns * n + ((T - 1) * ns if with_f else 0) + ns + T * n + T * n + 2)
+
+
+def kkt_algorithmic_bytes_per_problem(ns, nc, T, elem=4, with_f=True):
+    """SURVEY.md 8(d), KKT backward: C and dC, F and dF, c and dc, f and df, (x*, u*) and (dl_dx, dl_du), x_init
+    and dx_init -- every array read or written once (195,264 B at the headline shape)."""
+    n = ns + nc
+    return elem * (2 * T * n * n + 2 * (T - 1) * ns * n + 2 * T * n + (2 * (T - 1) * ns if with_f else 0) + 2 * T * n + 2 * ns)
+
+
+def algorithmic_flops_per_problem_step(ns, nc):
+    """2 x MACs of one unconstrained problem-step (17.3 kFLOP at 12/4, 256 kFLOP at 32/8)."""
+    n = ns + nc
+    mac = (ns * ns * n + n * n * ns + n * ns + nc ** 3 / 3.0 + nc * nc * (ns + 1) + 3 * ns * ns * nc + nc * nc * ns
+           + 3 * ns * nc + n * n + nc * ns + ns * n + n * n + 2 * n)
+    return 2.0 * mac
 
 
 def cpu_baseline(sample_B, bounded, seed=123):
@@ -84,9 +118,160 @@ def cpu_baseline(sample_B, bounded, seed=123):
         dt = time.perf_counter() - t0
         if dt > 10.0 or reps >= 2000:
             break
-    return dict(value=sample_B * T_H * reps / dt, unit="problem-steps/s", cores=threads, kind="port",
-                sample="%d problems x T=%d, %d repetitions in %.1f s, oracle/lqr_oracle.c (C restatement of the reference, per-problem mode), OpenMP over the host cores"
-                       % (sample_B, T_H, reps, dt))
+    out = dict(value=sample_B * T_H * reps / dt, unit="problem-steps/s", cores=threads, kind="port",
+               sample="%d problems x T=%d, %d repetitions in %.1f s, oracle/lqr_oracle.c (C restatement of the reference, per-problem mode), OpenMP over the host cores"
+                      % (sample_B, T_H, reps, dt))
+    probe = os.path.join(ROOT, "profiles", "ref_cpu_probe.json")
+    if os.path.exists(probe):
+        try:
+            # the UNMODIFIED reference (PyTorch CPU) timed by tools/ref_cpu_probe.py in the build container:
+            # another box, another core count -- reported beside the same-box port, never mixed with it
+            out["reference_probe"] = json.load(open(probe))
+        except Exception:
+            pass
+    return out
+
+
+def time_launches(fn, steps, warmup, barrier=None):
+    """W untimed launches, then exactly K launches bracketed by barrier + synchronize on both sides.
+    HIP events bracket consecutive runs of EV_GROUP launches on the stream the kernel runs on (torch's
+    current stream), back to back, so every launch of the timed region lies inside exactly one pair; an event
+    costs ~3 us of stream time, which neither `value` nor the per-launch figure should pay K times.
+    Returns (wall seconds of the K launches, mean ms per launch by the events, last result)."""
+    r = None
+    for _ in range(warmup):
+        r = fn()
+    group = max(1, min(EV_GROUP, steps))
+    n_ev = (steps + group - 1) // group
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    (barrier or torch.cuda.synchronize)()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i % group == 0:
+            ev[i // group][0].record()
+        r = fn()
+        if i % group == group - 1 or i == steps - 1:
+            ev[i // group][1].record()
+    return t0, ev, r
+
+
+def finish_timing(t0, ev, steps, barrier=None):
+    (barrier or torch.cuda.synchronize)()
+    elapsed = time.perf_counter() - t0
+    return elapsed, sum(a.elapsed_time(b) for a, b in ev) / steps
+
+
+def timed(fn, steps=20, warmup=5):
+    t0, ev, r = time_launches(fn, steps, warmup)
+    elapsed, kern_ms = finish_timing(t0, ev, steps)
+    return elapsed * 1e3 / steps, kern_ms, r
+
+
+def hbm_roofline(abytes, kern_ms, **more):
+    ach = abytes / (kern_ms * 1e-3) / 1e9
+    d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "algorithmic_bytes_per_launch": abytes, "kernel_ms": kern_ms}
+    d.update(more)
+    return d
+
+
+def extra_rows(be, dev, steps):
+    """SURVEY.md 8(d) secondary rows, same run, same event method.  Every row: what was launched, ms per launch
+    by HIP events (`ms`), wall ms per launch (`wall_ms`), and a roofline where the bytes are defined."""
+    from mpc import mpc
+    from mpc._native import StepOptions
+    from mpc.mpc import LinDx, QuadCost
+    rows = {}
+    k = max(10, min(steps, 50))
+
+    def step_row(p, opts, ns, nc, T, B, impl=0):
+        plan = be.plan_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts, impl=impl)
+        wall, ms, r = timed(plan, k, 10)
+        ok = bool(torch.isfinite(r["costs"]).all().item())
+        return dict(ms=ms, wall_ms=wall, problem_steps_per_s=B * T / (ms * 1e-3), finite=ok,
+                    roofline=hbm_roofline(algorithmic_bytes_per_problem(ns, nc, T) * B, ms)), r
+
+    def kkt_row(p, r, opts, ns, nc, T, B):
+        gx, gu = torch.randn_like(r["new_x"]), torch.randn_like(r["new_u"])
+        nx, nu = r["new_x"].clone(), r["new_u"].clone()
+        wall, ms, g = timed(lambda: be.kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, opts), k, 5)
+        return dict(ms=ms, wall_ms=wall, finite=bool(torch.isfinite(g["dC"]).all().item()),
+                    launches="mpc_lqr_kkt_prepare + mpc_lqr_step (nested solve) + mpc_lqr_kkt_grads",
+                    roofline=hbm_roofline(kkt_algorithmic_bytes_per_problem(ns, nc, T) * B, ms))
+
+    # ---- the headline shape: box-constrained step, KKT backward, 5-iteration MPC.forward ----------------
+    for bounded in (False, True):
+        key = "bounded" if bounded else "unbounded"
+        p = make_problem(NS, NC, T_H, B_PER_GPU, torch.float32, dev, seed=5, u_scale=0.3 if bounded else 0.0,
+                         clamp=1.0 if bounded else None)
+        opts = StepOptions(u_lower=-1.0, u_upper=1.0) if bounded else StepOptions()
+        row, r = step_row(p, opts, NS, NC, T_H, B_PER_GPU)
+        if bounded:
+            row["workload"] = "headline shape, box bounds +-1 (pnqp in the sweep), nominal u ~ 0.3 N clamped"
+            rows["lqr_step_bounded"] = row
+        rows["kkt_backward_" + key] = kkt_row(p, r, opts, NS, NC, T_H, B_PER_GPU)
+        ctrl = mpc.MPC(NS, NC, T_H, u_lower=-1.0 if bounded else None, u_upper=1.0 if bounded else None,
+                       lqr_iter=5, verbose=-1, exit_unconverged=False, detach_unconverged=False, backprop=False)
+        cost, dx = QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"])
+        wall, ms, _ = timed(lambda: ctrl(p["x_init"], cost, dx), 5, 2)
+        rows["mpc_forward_5iter_" + key] = dict(ms=ms, wall_ms=wall, lqr_iter=5,
+                                                note="whole MPC.forward: initial trajectory kernel + 5 x (step + select_best)")
+        del p, r, ctrl, cost, dx
+    # ---- config 5: n_state=32 n_ctrl=8 T=64, the MFMA tile path; B=1024 is one GPU's share of 8192 over 8 ------
+    for B5 in (1024, 8192):
+        p = make_problem(32, 8, 64, B5, torch.float32, dev, seed=9, on_device=True)
+        row, r = step_row(p, StepOptions(), 32, 8, 64, B5)
+        tf = algorithmic_flops_per_problem_step(32, 8) * B5 * 64 / (row["ms"] * 1e-3) / 1e12
+        row["mfma_fp32"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": tf / FP32_MFMA_PEAK_TF}
+        rows["cfg5_step_B%d" % B5] = row
+        if B5 == 1024:
+            rows["cfg5_kkt_backward_B1024"] = kkt_row(p, r, StepOptions(), 32, 8, 64, B5)
+            pb = dict(p)
+            rowb, _ = step_row(pb, StepOptions(u_lower=-1.0, u_upper=1.0), 32, 8, 64, B5)
+            rows["cfg5_step_bounded_B1024"] = rowb
+        del p, r
+    torch.cuda.empty_cache()
+    # ---- configs 2 / 3: the shipped simulators, whole 10-iteration iLQR solves (L2-resident: latency-bound) ----
+    from tools.bench_ilqr_env import problem as env_problem
+    for kind, B, T in (("pendulum", 1024, 20), ("cartpole", 4096, 25)):
+        dxm, _plain, x0, Q, pp = env_problem(kind, B, T)
+        ctrl = mpc.MPC(dxm.n_state, 1, T, u_lower=dxm.lower, u_upper=dxm.upper, lqr_iter=10, verbose=-1,
+                       exit_unconverged=False, detach_unconverged=False, linesearch_decay=dxm.linesearch_decay,
+                       max_linesearch_iter=dxm.max_linesearch_iter, grad_method=mpc.GradMethods.AUTO_DIFF,
+                       eps=1e-12, backprop=False, not_improved_lim=10 ** 6)
+        cost = QuadCost(Q, pp)
+        wall, ms, out = timed(lambda: ctrl(x0, cost, dxm), 5, 2)
+        rows["cfg%d_ilqr_%s_10iter" % (2 if kind == "pendulum" else 3, kind)] = dict(
+            ms=ms, wall_ms=wall, lqr_iter=10, B=B, T=T, ms_per_iteration=ms / 10,
+            problem_steps_per_s=B * T * 10 / (ms * 1e-3), mean_cost=float(out[2].mean()),
+            note="MPC.forward on mpc.env_dx.%s: the step kernel linearises the simulator and rolls it out itself"
+                 % ("PendulumDx" if kind == "pendulum" else "CartpoleDx"))
+    return rows
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this very script under torch.distributed.run.
+    Refuses (non-zero exit) when the node cannot give N GPUs -- never a silent fall-back to fewer ranks."""
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d visible on this node -- refusing to run fewer ranks\n"
+                         % (args.gpus, have))
+        sys.exit(3)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MPC_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -94,18 +279,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=100,
-                    help="untimed launches first: the clocks and the Infinity Cache settle over the first ~100 (a step is 0.1 ms)")
+                    help="untimed launches of the step immediately before the timed region")
     ap.add_argument("--bounded", action="store_true", help="box constraints +-1 (pnqp in the sweep)")
     ap.add_argument("--impl", type=int, default=0, help="0 auto, 1 generic, 2 fused MFMA, 3 DPP 4-problems-per-wave")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary rows (`extra`)")
     ap.add_argument("--probe-share", default="", help="diagnostic only: 'C' / 'F' / 'CF' = expand timestep 0 of C / F "
                     "over the horizon (stride 0), which removes that array's HBM traffic without changing the arithmetic")
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if not launched and args.gpus > 1:
+        respawn_under_torchrun(args)          # does not return
+    if launched and world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE) -- refusing\n" % (args.gpus, world))
+        sys.exit(3)
     dist = None
     # (MPC_BENCH_FORCE_DIST=1: take the process-group path at world size 1 too -- a single-GPU box can then
     # exercise the RCCL initialisation and the collectives of the N > 1 run)
@@ -118,10 +312,16 @@ def main():
         os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if torch.cuda.device_count() <= local:
+            sys.stderr.write("bench.py: rank %d has no GPU %d on this node\n" % (rank, local))
+            sys.exit(3)
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert args.gpus == world or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+        assert dist.get_world_size() == world
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -147,47 +347,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up launches (not warm-up steps of the contract, reported as `settle_launches`): the first launches of a
+    # fresh process run at boost clocks with a cold Infinity Cache and read 3 % fast or slow depending on the box;
+    # W = 5 of the driver's default call alone would time the transient
+    settle = max(0, SETTLE_LAUNCHES - args.warmup)
+    for _ in range(settle):
+        step()
     r = None
     for _ in range(args.warmup):
         r = step()
+    if r is None:
+        r = step.outputs
     gathered = None
     if dist is not None:
         tau = torch.cat((r["new_x"], r["new_u"]), 2)
         gathered = torch.empty((world,) + tuple(tau.shape), dtype=tau.dtype, device=dev)
         dist.all_gather_into_tensor(gathered, tau)
-    # HIP events bracket every launch on the stream the kernel runs on (torch's current stream)
-    # Event pairs bracket consecutive runs of EV_GROUP launches, back to back, so every launch of the timed
-    # region lies inside exactly one pair; an event costs ~3 us of stream time, which neither `value` nor the
-    # per-launch figure should pay K times.  kernel_ms = sum of the pairs / K (includes the ~1.5 us launch
-    # gaps inside a run: a slight over-estimate of the rocprofv3 kernel duration).
-    group = max(1, min(EV_GROUP, args.steps))
-    n_ev = (args.steps + group - 1) // group
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i % group == 0:
-            ev[i // group][0].record()
-        r = step()
-        if i % group == group - 1 or i == args.steps - 1:
-            ev[i // group][1].record()
+    t0, ev, r = time_launches(step, args.steps, 0, barrier)
     if dist is not None:
         tau = torch.cat((r["new_x"], r["new_u"]), 2)
         dist.all_gather_into_tensor(gathered, tau)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    elapsed, kern_ms = finish_timing(t0, ev, args.steps, barrier)
     if dist is not None:
         tt = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = tt.tolist()
 
     ok = bool(torch.isfinite(r["costs"]).all().item()) and int(r["status"].max().item()) & 2 == 0
+    if dist is not None:
+        okt = torch.tensor([1.0 if ok else 0.0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item() > 0)
+        # the gathered buffer holds every rank's trajectories: rank r's block must be what rank r computed
+        mine = gathered[rank]
+        ok = ok and bool(torch.equal(mine, torch.cat((r["new_x"], r["new_u"]), 2)))
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B * T_H / (elapsed / args.steps)
         abytes = algorithmic_bytes_per_problem(NS, NC, T_H) * B
-        achieved = abytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
@@ -205,12 +402,18 @@ def main():
                                    "batch=%d per GPU, %s, one LQRStepFn.forward per step"
                                    % (B, "box bounds +-1 (pnqp)" if args.bounded else "unbounded"),
                        "global_batch": world * B, "horizon": T_H, "parallelism": "batch-shard x%d" % world,
-                       "kernel": {1: "lqr_step_generic_kernel<float>", 2: "lqr_step_mfma16_kernel", 3: "lqr_step_dpp16_kernel"}[impl_used],
-                       "finite": ok},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": abytes, "kernel_ms": kern_ms},
+                       "kernel": KERNEL_NAMES.get(impl_used, "impl %d" % impl_used),
+                       "settle_launches": settle, "finite": ok,
+                       "launcher": ("torch.distributed.run (self-spawned by bench.py)" if os.environ.get("MPC_BENCH_SPAWNED")
+                                    else "torch.distributed.run") if launched else "single process",
+                       "collective": None if dist is None else "one all_gather_into_tensor of new_x||new_u (RCCL) inside the timed region"},
+            "roofline": hbm_roofline(abytes, kern_ms, traffic=traffic),
         }
+        if world == 1 and not args.no_extra:
+            try:
+                out["extra"] = extra_rows(be, dev, args.steps)
+            except Exception as e:      # the contract line must survive a failing secondary row
+                out["extra"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(512, args.bounded)
         if saved_stdout is not None:

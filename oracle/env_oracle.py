@@ -136,3 +136,42 @@ def rollout(kind, params, x_init, C, c, K, k, cur_x, cur_u, lower, upper, decay,
                 break
         new_x[:, b], new_u[:, b], costs[b], alphas[b] = X[:, 0], U[:, 0], cost, alpha
     return new_x, new_u, costs, full, alphas
+
+
+def rollout_batched(kind, params, x_init, C, c, K, k, cur_x, cur_u, lower, upper, decay, max_ls):
+    """`rollout` for large batches: the max_ls trials alpha = decay^i are each rolled out over the WHOLE batch
+    with numpy and every problem takes its first trial that did not get worse (else the last) -- the per-problem
+    loop of `rollout` in a different order, same results (checked against it in tests/test_oracle_golden.py).
+    Also returns the per-trial costs and the nominal cost so a test can recognise a line-search tie."""
+    T, B, nc = cur_u.shape
+    ns = x_init.shape[1]
+    old = quad_cost(C, c, cur_x, cur_u)
+    done = np.zeros(B, bool)
+    new_x = np.empty((T, B, ns)); new_u = np.empty((T, B, nc))
+    costs = np.empty(B); full = np.empty(B); alphas = np.empty(B)
+    trial_costs = np.full((max_ls, B), np.nan)
+    for it in range(max_ls):
+        alpha = decay ** it
+        xs = [np.asarray(x_init, dtype=np.float64)]
+        us = []
+        dx = np.zeros((B, ns))
+        for t in range(T):
+            nu = np.einsum("bij,bj->bi", K[t], dx) + cur_u[t] + alpha * k[t]
+            if lower is not None:
+                nu = np.clip(nu, lower, upper)
+            us.append(nu)
+            if t < T - 1:
+                nx = step(kind, xs[t], nu, params)
+                xs.append(nx)
+                dx = nx - cur_x[t + 1]
+        X, U = np.stack(xs), np.stack(us)
+        cost = quad_cost(C, c, X, U)
+        trial_costs[it] = cost
+        if it == 0:
+            full[:] = np.sqrt(((cur_u - U) ** 2).sum((0, 2)))
+        take = ~done & (~(cost > old) | (it + 1 >= max_ls))
+        new_x[:, take], new_u[:, take], costs[take], alphas[take] = X[:, take], U[:, take], cost[take], alpha
+        done |= take
+        if done.all():
+            break
+    return new_x, new_u, costs, full, alphas, trial_costs, old

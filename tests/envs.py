@@ -50,3 +50,26 @@ class CartpoleSim(nn.Module):
         w = torch.tensor([0.1, 0.1, 1.0, 1.0, 0.1], dtype=dtype)
         goal = torch.tensor([0.0, 0.0, 1.0, 0.0, 0.0], dtype=dtype)
         return torch.cat((w, torch.full((1,), 0.001, dtype=dtype))), torch.cat((-w.sqrt() * goal, torch.zeros(1, dtype=dtype)))
+
+
+class SmoothCost(nn.Module):
+    """A smooth, convex, NON-quadratic stage cost on tau = (x, u) [B, n] -> [B]:
+        0.5 sum_i w_i (tau_i - goal_i)^2 + beta sum_j log cosh((P tau)_j)
+    Hessian diag(w) + beta P' diag(sech^2(P tau)) P is positive definite and changes along the trajectory, so
+    MPC.approximate_cost (reference mpc/mpc.py:447-487) has something to expand at every iteration.  `goal`
+    and `P` are Parameters: the backward of a solve reaches them through the differentiable expansion."""
+
+    def __init__(self, n, m=3, beta=2.0, seed=0, dtype=torch.float64):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.w = (0.5 + torch.rand(n, generator=g, dtype=dtype))
+        self.goal = nn.Parameter(0.5 * torch.randn(n, generator=g, dtype=dtype))
+        self.P = nn.Parameter(torch.randn(m, n, generator=g, dtype=dtype) / n ** 0.5)
+        self.beta = beta
+
+    def forward(self, tau):
+        w = self.w.to(tau.device)
+        z = tau.matmul(self.P.t())
+        # log cosh z, written so that large |z| does not overflow
+        lc = z.abs() + torch.log1p(torch.exp(-2.0 * z.abs())) - 0.6931471805599453
+        return 0.5 * (w * (tau - self.goal) ** 2).sum(1) + self.beta * lc.sum(1)

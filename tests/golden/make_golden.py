@@ -338,6 +338,35 @@ def slew_case(name, seed, ns=2, nc=2, T=4, B=2, gamma=1.0, prev=False):
          gx0=npy(gx0), gb0=npy(gb0), **arrs)
 
 
+def module_cost_case(name, seed, ns=3, nc=2, T=5, B=3, bound=0.6, lqr_iter=25):
+    """A non-quadratic nn.Module cost through the reference's MPC.forward: every iteration expands it with
+    approximate_cost (mpc/mpc.py:447-487, called at :261), the line search prices trials with the module itself
+    (mpc/lqr_step.py:233-234) and the final differentiable expansion (:316) carries the gradient of a fixed linear
+    functional of (x, u) into the module's parameters.  LinDx dynamics, box constraints, float64."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    import envs
+    npr.seed(seed)
+    torch.manual_seed(seed)
+    n = ns + nc
+    R = np.tile(np.eye(ns) + 0.2 * npr.randn(ns, ns), (T - 1, B, 1, 1))
+    S = np.tile(npr.randn(ns, nc), (T - 1, B, 1, 1))
+    F = torch.tensor(np.concatenate((R, S), axis=3))
+    f = torch.tensor(0.1 * npr.randn(T - 1, B, ns))
+    x_init = torch.tensor(npr.randn(B, ns))
+    wx, wu = npr.randn(T, B, ns), npr.randn(T, B, nc)
+    cost = envs.SmoothCost(n, seed=seed)
+    ctrl = ref_mpc.MPC(ns, nc, T, u_lower=-bound, u_upper=bound, lqr_iter=lqr_iter, verbose=-1, n_batch=B,
+                       exit_unconverged=False, detach_unconverged=False, eps=1e-9)
+    (x, u, costs), _ = quiet(ctrl, x_init, cost, LinDx(F, f))
+    loss = (x * torch.tensor(wx)).sum() + (u * torch.tensor(wu)).sum()
+    g_goal, g_P = torch.autograd.grad(loss, [cost.goal, cost.P])
+    # one expansion on its own, at the solution: (C, c, stage costs) of approximate_cost
+    Cq, cq, sc = ctrl.approximate_cost(x.detach(), u.detach(), cost, diff=False)
+    save(name, meta=np.array([ns, nc, T, B]), seed=np.array([seed]), bound=np.array([bound]), lqr_iter=np.array([lqr_iter]),
+         F=npy(F), f=npy(f), x_init=npy(x_init), wx=wx, wu=wu, x=npy(x), u=npy(u), costs=npy(costs),
+         g_goal=npy(g_goal), g_P=npy(g_P), approx_C=npy(Cq), approx_c=npy(cq), approx_costs=npy(sc))
+
+
 def gen_mpc_cases():
     # (1) notebook known answer: examples/Time Varying Linear-Quadratic Control.ipynb cell 1
     torch.manual_seed(0)
@@ -533,6 +562,8 @@ if __name__ == "__main__":
         env_case("ilqr_cartpole_f64", "cartpole", 25, 4, 8, 52)
         slew_case("mpc_slew_nn_f64", 0)
         slew_case("mpc_slew_nn_prev_f64", 3, T=5, B=3, gamma=0.5, prev=True)
+        module_cost_case("mpc_module_cost_f64", 7)
+        module_cost_case("mpc_module_cost_wide_f64", 8, ns=4, nc=1, T=6, B=4, bound=5.0)
         env_lin_case("env_pendulum_f64", "pendulum", 12, 6, 61)
         env_lin_case("env_pendulum_full_f64", "pendulum", 12, 6, 62, simple=False,
                      params=(9.0, 1.2, 0.8, 0.3, 0.2))

@@ -649,52 +649,32 @@ def _ns_problem(B, bounded, seed=0):
                               clamp=1.0 if bounded else None)
 
 
-@pytest.mark.parametrize("bounded", [False, True])
-def test_north_star_full_size_vs_oracle(be, bounded):
-    """B = 4096 at the headline shape: every problem against the oracle (it finishes in seconds)."""
+def test_north_star_full_size_vs_oracle(be):
+    """B = 4096 at the headline shape, unconstrained: every problem, every kernel against the oracle (it finishes
+    in seconds).  The box-constrained headline step is held entry by entry, with tie problems classified, in
+    tests/test_gpu_fullsize.py::test_headline_bounded_every_problem_vs_oracle."""
     from mpc._native import StepOptions
     from oracle import lqr_oracle as O
-    p = _ns_problem(4096, bounded)
-    opts = StepOptions(u_lower=-1.0, u_upper=1.0) if bounded else StepOptions()
+    p = _ns_problem(4096, False)
+    opts = StepOptions()
     h = {k: host(v) for k, v in p.items()}
-    o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"],
-                   -1.0 if bounded else None, 1.0 if bounded else None, lockstep=False,
+    o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], None, None, lockstep=False,
                    nthreads=O.max_threads())
     o64 = O.lqr_step(*(h[k].astype(np.float64) for k in ("x_init", "C", "c", "F", "f", "cur_x", "cur_u")),
-                     -1.0 if bounded else None, 1.0 if bounded else None, lockstep=False,
-                     nthreads=O.max_threads())
-    from mpc import _native
+                     None, None, lockstep=False, nthreads=O.max_threads())
     for impl in (1, 2, 3):
         if not be.impl_supported(12, 4, torch.float32, impl):
             continue
         r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts, impl=impl)
         torch.cuda.synchronize()
         for k in ("new_x", "new_u"):
-            if not bounded:
-                np.testing.assert_allclose(host(r[k]), o64[k], rtol=1e-3, atol=1e-4, err_msg="impl %d %s" % (impl, k))
-            else:
-                # pnqp stops at |dx| < 1e-4 (mpc/pnqp.py:56), so in fp32 the reference's own float32 run
-                # misses the float64 one by up to ~2e-3 on ~0.02 % of the 3.3 M trajectory entries
-                # (measured with the oracle: 574 + 171 entries).  Same statement for the kernels:
-                # A line search whose trial cost ties with the nominal cost to float32 rounding can take the
-                # other branch (alpha = 1 vs decay): those problems (a handful of 4096) are compared on costs
-                # only; everywhere else the trajectories agree entry by entry.
-                for ref, ra in ((o64[k], o64["alphas"]), (o[k], o["alphas"])):
-                    same = np.isclose(host(r["alphas"]), ra, rtol=1e-5)
-                    assert same.mean() > 0.997, "impl %d: %d problems took another line-search step" % (impl, (~same).sum())
-                    err = np.abs(host(r[k]).astype(np.float64) - ref)[:, same]
-                    bad = err > 1e-4 + 1e-3 * np.abs(ref[:, same])
-                    assert bad.mean() < 1e-3, "impl %d %s: %d entries off" % (impl, k, bad.sum())
-                    assert err.max() < 1e-2, "impl %d %s: max err %.3e" % (impl, k, err.max())
-                continue
+            np.testing.assert_allclose(host(r[k]), o64[k], rtol=1e-3, atol=1e-4, err_msg="impl %d %s" % (impl, k))
             close_with_ref_noise(host(r[k]), o[k], np.abs(o[k] - o64[k]), 1e-3, 1e-4)
-        np.testing.assert_allclose(host(r["costs"]), o64["costs"], rtol=5e-4 if bounded else 1e-4)   # bounded: pnqp stop noise
+        np.testing.assert_allclose(host(r["costs"]), o64["costs"], rtol=1e-4)
+        np.testing.assert_allclose(host(r["alphas"]), o64["alphas"], rtol=1e-6)
+        np.testing.assert_allclose(host(r["full_du_norm"]), o64["full_du_norm"], rtol=1e-3, atol=1e-4)
         st = host(r["status"])
-        assert (st & 2 == 0).all()                      # nothing non-finite
-        # bit 0 = "pnqp warning: Did not converge" (mpc/pnqp.py:81).
-        # float32 pnqp: every QP reaches |dx| < 1e-4 within its 20 iterations (the float32 reference does not:
-        # its Armijo ratio is rounding noise near convergence -- see lqr_small_math.h)
-        assert (st & 1).mean() < 0.01, "impl %d: %.3f %% of the problems carry an unconverged QP" % (impl, 100 * (st & 1).mean())
+        assert (st == 0).all()                      # nothing non-finite, the nominal obeys the dynamics
 
 
 @pytest.mark.parametrize("shape", ["headline", "tiny", "generic"])

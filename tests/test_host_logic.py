@@ -271,6 +271,56 @@ def run_slew_golden(z, device=None):
     return x, u, costs, gC, gc, gx0, gb0
 
 
+MODULE_COST_CASES = ["mpc_module_cost_f64", "mpc_module_cost_wide_f64"]
+
+
+def run_module_cost_golden(z, device=None):
+    """MPC.forward with a non-quadratic nn.Module cost (tests/envs.py SmoothCost) on LinDx dynamics."""
+    import envs
+    ns, nc, T, B = (int(v) for v in z["meta"])
+    mv = (lambda t: t if device is None else t.to(device))
+    cost = envs.SmoothCost(ns + nc, seed=int(z["seed"][0]))
+    if device is not None:
+        cost = cost.to(device)
+    bound = float(z["bound"][0])
+    ctrl = mpc.MPC(ns, nc, T, u_lower=-bound, u_upper=bound, lqr_iter=int(z["lqr_iter"][0]), verbose=-1, n_batch=B,
+                   exit_unconverged=False, detach_unconverged=False, eps=1e-9)
+    x, u, costs = ctrl(mv(tt(z, "x_init")), cost, LinDx(mv(tt(z, "F")), mv(tt(z, "f"))))
+    loss = (x * mv(tt(z, "wx"))).sum() + (u * mv(tt(z, "wu"))).sum()
+    g_goal, g_P = torch.autograd.grad(loss, [cost.goal, cost.P])
+    Cq, cq, sc = ctrl.approximate_cost(mv(tt(z, "x")), mv(tt(z, "u")), cost, diff=False)
+    return x, u, costs, g_goal, g_P, Cq, cq, sc
+
+
+def check_module_cost(out, z, tol):
+    x, u, costs, g_goal, g_P, Cq, cq, sc = (t.detach().cpu().numpy() for t in out)
+    # the expansion itself (mpc/mpc.py:447-487) at the reference's solution: autograd of the same module
+    np.testing.assert_allclose(Cq, z["approx_C"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(cq, z["approx_c"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(sc, z["approx_costs"], rtol=1e-12)
+    np.testing.assert_allclose(u, z["u"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(x, z["x"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(costs, z["costs"], rtol=max(tol, 1e-7))
+    for g, k in ((g_goal, "g_goal"), (g_P, "g_P")):
+        np.testing.assert_allclose(g, z[k], rtol=10 * tol, atol=10 * tol * (1 + np.abs(z[k]).max()))
+
+
+@pytest.mark.parametrize("name", MODULE_COST_CASES)
+@pytest.mark.parametrize("lockstep", [True, False])
+def test_module_cost_matches_reference(name, lockstep):
+    """SURVEY.md 8(f-4), `approximate_cost`: the reference's MPC.forward on a non-quadratic module cost (goldens
+    made by tests/golden/make_golden.py module_cost_case) -- same expansion, same solve, same gradients into the
+    module's parameters.  lockstep = the reference's batch-global pnqp / line-search loops (agreement to
+    rounding); per problem = what the kernels do (within the pnqp stopping tolerance)."""
+    prev = _native.set_backend_for_testing(OracleBackend(lockstep=lockstep))
+    try:
+        z = golden(name)
+        out = run_module_cost_golden(z)
+    finally:
+        _native.set_backend_for_testing(prev)
+    check_module_cost(out, z, 1e-7 if lockstep else 2e-4)
+
+
 @pytest.mark.parametrize("name", ["mpc_slew_nn_f64", "mpc_slew_nn_prev_f64"])
 @pytest.mark.parametrize("lockstep", [True, False])
 def test_slew_rate_penalty_matches_reference(name, lockstep):

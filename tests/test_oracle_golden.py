@@ -192,6 +192,13 @@ def test_env_oracle_matches_reference_modules(name, kind):
     np.testing.assert_allclose(nx, z["step_new_x"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(nu, z["step_new_u"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(costs, z["step_costs"], rtol=1e-9)
+    # the batched form the full-batch GPU tests use: the same per-problem line search, trial by trial
+    bx, bu, bc, bfull, balpha, trials, old = E.rollout_batched(
+        kind, prm, z["x_init"], z["Q"], z["p"], o["K"], o["k"], z["step_cur_x"], z["step_cur_u"],
+        float(z["lower"][0]), float(z["upper"][0]), float(z["decay"][0]), int(z["max_ls"][0]))
+    for a, b in ((bx, nx), (bu, nu), (bc, costs), (bfull, full), (balpha, alphas)):
+        np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(old, E.quad_cost(z["Q"], z["p"], z["step_cur_x"], z["step_cur_u"]), rtol=1e-13)
 
 
 def test_env_oracle_clamp_derivative_on_the_bound():
