@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPC_LQR_ABI_VERSION 2
+#define MPC_LQR_ABI_VERSION 3
 
 enum { MPC_F32 = 0, MPC_F64 = 1 };
 enum { MPC_BOUND_NONE = 0, MPC_BOUND_SCALAR = 1, MPC_BOUND_TENSOR = 2 };
@@ -172,6 +172,13 @@ int mpc_lqr_kkt_prepare(int dtype, int B, int T, int ns, int nc,
 int mpc_pnqp(int dtype, int B, int n, const void *H, const void *q, const void *lo, const void *hi,
              const void *x0, int n_iter, void *x, uint8_t *If_out, int32_t *iters, int32_t *status,
              void *Hfree, void *stream);
+/* (5b) The same solve, also returning the factorisation the reference returns as `H_lu_` (mpc/pnqp.py:52, 59, 82):
+ *     LU [B,n,n] = packed pivoted LU of H_ from the last Newton system the solve factorised, pivots [B,n] int32,
+ *     1-based row interchanges -- the layout of torch.linalg.lu_factor / LAPACK getrf, usable with lu_solve.
+ *     Either may be NULL. */
+int mpc_pnqp_lu(int dtype, int B, int n, const void *H, const void *q, const void *lo, const void *hi,
+                const void *x0, int n_iter, void *x, uint8_t *If_out, int32_t *iters, int32_t *status,
+                void *Hfree, void *LU, int32_t *pivots, void *stream);
 
 /* (6) util.get_traj (LinDx) + util.get_cost (QuadCost), mpc/util.py:102-153.
  *     u = p->cur_u; writes x [T,B,ns] (if non-NULL) and cost [B] (if non-NULL and p->C set). */

@@ -304,9 +304,9 @@ int mpc_lqr_kkt_prepare(int dtype, int B, int T, int ns, int nc, const void *dl_
                                       (double *)negr, mask, st);
 }
 
-int mpc_pnqp(int dtype, int B, int n, const void *H, const void *q, const void *lo, const void *hi,
-             const void *x0, int n_iter, void *x, uint8_t *If_out, int32_t *iters, int32_t *status,
-             void *Hfree, void *stream)
+int mpc_pnqp_lu(int dtype, int B, int n, const void *H, const void *q, const void *lo, const void *hi,
+                const void *x0, int n_iter, void *x, uint8_t *If_out, int32_t *iters, int32_t *status,
+                void *Hfree, void *LU, int32_t *pivots, void *stream)
 {
     if (dtype != MPC_F32 && dtype != MPC_F64) return fail(MPC_E_DTYPE, "bad dtype");
     if (B < 0 || n < 1) return fail(MPC_E_DIMS, "bad dims");
@@ -316,9 +316,18 @@ int mpc_pnqp(int dtype, int B, int n, const void *H, const void *q, const void *
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MPC_F32)
         return launch_pnqp<float>(B, n, (const float *)H, (const float *)q, (const float *)lo, (const float *)hi,
-                                  (const float *)x0, n_iter, (float *)x, If_out, iters, status, (float *)Hfree, st);
+                                  (const float *)x0, n_iter, (float *)x, If_out, iters, status, (float *)Hfree,
+                                  (float *)LU, pivots, st);
     return launch_pnqp<double>(B, n, (const double *)H, (const double *)q, (const double *)lo, (const double *)hi,
-                               (const double *)x0, n_iter, (double *)x, If_out, iters, status, (double *)Hfree, st);
+                               (const double *)x0, n_iter, (double *)x, If_out, iters, status, (double *)Hfree,
+                               (double *)LU, pivots, st);
+}
+
+int mpc_pnqp(int dtype, int B, int n, const void *H, const void *q, const void *lo, const void *hi,
+             const void *x0, int n_iter, void *x, uint8_t *If_out, int32_t *iters, int32_t *status,
+             void *Hfree, void *stream)
+{
+    return mpc_pnqp_lu(dtype, B, n, H, q, lo, hi, x0, n_iter, x, If_out, iters, status, Hfree, nullptr, nullptr, stream);
 }
 
 int mpc_traj_cost(const mpc_lqr_problem *p, void *x, void *cost, void *stream)

@@ -20,7 +20,7 @@ template <typename real> int launch_step_generic(const StepParams<real> &p, int 
 template <typename real> int launch_pnqp(int B, int n, const real *H, const real *q, const real *lo,
                                          const real *hi, const real *x0, int n_iter, real *x,
                                          uint8_t *If_out, int *iters, int *status, real *Hfree,
-                                         hipStream_t st);
+                                         real *LU, int *pivots, hipStream_t st);
 template <typename real> int launch_traj_cost(const StepParams<real> &p, real *x, real *cost, hipStream_t st);
 template <typename real> int launch_kkt_grads(const StepParams<real> &p, const real *dx, const real *du,
                                               const real *dl_dx, const real *dl_du, real *dC, real *dc,

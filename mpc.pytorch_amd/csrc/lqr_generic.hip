@@ -131,7 +131,11 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <typename real> __device__ void lu_solve_aug(real *A, int nr, int ncols, real *Lcol)
+// KEEP_L: the multipliers are also stored below the diagonal and the row interchanges recorded (1-based, the
+// LAPACK / torch.linalg.lu_factor convention: row p was swapped with row piv[p]; the swap runs over the whole row,
+// so earlier multipliers move with it) -- A[:, :nr] is then the packed LU the reference hands back from pnqp
+// (mpc/pnqp.py:52, 59, 82).
+template <typename real, bool KEEP_L = false> __device__ void lu_solve_aug(real *A, int nr, int ncols, real *Lcol, int *piv = nullptr)
 {
     const int tid = threadIdx.x;
     if (tid < WAVE) {
@@ -152,7 +156,12 @@ template <typename real> __device__ void lu_solve_aug(real *A, int nr, int ncols
                 }
             wave_sync();
             const real d = A[p * ncols + p];
-            for (int i = p + 1 + tid; i < nr; i += nt) Lcol[i] = A[i * ncols + p] / d;
+            for (int i = p + 1 + tid; i < nr; i += nt) {
+                const real l = A[i * ncols + p] / d;
+                Lcol[i] = l;
+                if (KEEP_L) A[i * ncols + p] = l;
+            }
+            if (KEEP_L && piv && tid == 0) piv[p] = r + 1;
             wave_sync();
             for (int j = p + 1 + tid; j < ncols; j += nt) {
                 const real pj = A[p * ncols + j];
@@ -179,10 +188,10 @@ template <typename real> __device__ void lu_solve_aug(real *A, int nr, int ncols
 // -- the K = -Quu_free^{-1} Qux of mpc/lqr_step.py:142-148 comes out of the same
 // elimination that produced the final Newton step.  x must already hold the
 // clamped start.  Returns the iteration index the reference returns.
-template <typename real>
+template <typename real, bool KEEP_L = false>
 __device__ int pnqp_core(const real *H, int ldH, const real *qv, const real *rhs, int ldR, int nrhs,
                          int n, int n_iter, real *A, real *Lcol, real *x, real *g, real *dx, real *mx,
-                         const real *lb, const real *ub, int *If, bool *converged)
+                         const real *lb, const real *ub, int *If, bool *converged, int *piv = nullptr)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int ncols = n + 1 + nrhs;
@@ -217,7 +226,7 @@ __device__ int pnqp_core(const real *H, int ldH, const real *qv, const real *rhs
             A[e] = val;
         }
         __syncthreads();
-        lu_solve_aug(A, n, ncols, Lcol);            // :50-54
+        lu_solve_aug<real, KEEP_L>(A, n, ncols, Lcol, piv);            // :50-54
         for (int i = tid; i < n; i += nt) dx[i] = -A[i * ncols + n];
         __syncthreads();
         real nrm2 = 0;
@@ -638,7 +647,7 @@ __global__ void __launch_bounds__(MAX_THREADS, (sizeof(real) == 4 ? 6 : 2)) lqr_
 template <typename real>
 __global__ void pnqp_kernel(int B, int n, const real *H, const real *q, const real *lo, const real *hi,
                             const real *x0, int n_iter, real *x_out, uint8_t *If_out, int *iters,
-                            int *status, real *Hfree)
+                            int *status, real *Hfree, real *LU, int *pivots)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -647,6 +656,7 @@ __global__ void pnqp_kernel(int B, int n, const real *H, const real *q, const re
     real *Lcol = A + (size_t)n * (n + 1);
     real *x = Lcol + n, *g = x + n, *dx = g + n, *mx = dx + n, *lb = mx + n, *ub = lb + n;
     int *If = reinterpret_cast<int *>(ub + n);
+    int *piv = If + n;
     const real *Hb = H + (size_t)b * n * n, *qb = q + (size_t)b * n;
     for (int i = tid; i < n; i += nt) { lb[i] = lo[(size_t)b * n + i]; ub[i] = hi[(size_t)b * n + i]; }
     if (x0 == nullptr) {
@@ -664,11 +674,19 @@ __global__ void pnqp_kernel(int B, int n, const real *H, const real *q, const re
     for (int i = tid; i < n; i += nt) x[i] = eclamp<real>(x[i], lb[i], ub[i]);
     __syncthreads();
     bool conv = false;
-    const int it = pnqp_core<real>(Hb, n, qb, nullptr, 0, 0, n, n_iter, A, Lcol, x, g, dx, mx, lb, ub, If, &conv);
+    const int it = pnqp_core<real, true>(Hb, n, qb, nullptr, 0, 0, n, n_iter, A, Lcol, x, g, dx, mx, lb, ub, If, &conv, piv);
     for (int i = tid; i < n; i += nt) {
         x_out[(size_t)b * n + i] = x[i];
         if (If_out) If_out[(size_t)b * n + i] = (uint8_t)If[i];
+        if (pivots) pivots[(size_t)b * n + i] = piv[i];
     }
+    // the factorisation of the last Newton system, packed as torch.linalg.lu_factor packs it (what the reference
+    // returns as H_lu_, mpc/pnqp.py:52-59, 82): nobody has to factor H_ again
+    if (LU)
+        for (int e = tid; e < n * n; e += nt) {
+            const int i = e / n, j = e - i * n;
+            LU[(size_t)b * n * n + e] = A[i * (n + 1) + j];
+        }
     if (Hfree)
         for (int e = tid; e < n * n; e += nt) {
             const int i = e / n, j = e - i * n;
@@ -981,16 +999,17 @@ template <typename real> int launch_step_generic(const StepParams<real> &p, int 
 
 template <typename real>
 int launch_pnqp(int B, int n, const real *H, const real *q, const real *lo, const real *hi, const real *x0,
-                int n_iter, real *x, uint8_t *If_out, int *iters, int *status, real *Hfree, hipStream_t st)
+                int n_iter, real *x, uint8_t *If_out, int *iters, int *status, real *Hfree, real *LU, int *pivots,
+                hipStream_t st)
 {
-    const size_t lds = ((size_t)n * (n + 1) + 7 * (size_t)n) * sizeof(real) + (size_t)n * sizeof(int) + 16;
+    const size_t lds = ((size_t)n * (n + 1) + 7 * (size_t)n) * sizeof(real) + 2 * (size_t)n * sizeof(int) + 16;
     if (lds > 160 * 1024) { set_last_error("pnqp: n too large for LDS"); return MPC_E_DIMS; }
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pnqp_kernel<real>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int threads = n <= 32 ? 64 : (n <= 64 ? 128 : 256);
     hipLaunchKernelGGL(pnqp_kernel<real>, dim3(B), dim3(threads), lds, st, B, n, H, q, lo, hi, x0, n_iter, x,
-                       If_out, iters, status, Hfree);
+                       If_out, iters, status, Hfree, LU, pivots);
     return check_launch("pnqp_kernel");
 }
 
@@ -1090,7 +1109,8 @@ int launch_env_linearize(const EnvDesc<real> &env, long N, const real *x, const 
 #define INSTANTIATE(real)                                                                                     \
     template int launch_step_generic<real>(const StepParams<real> &, int, hipStream_t);                        \
     template int launch_pnqp<real>(int, int, const real *, const real *, const real *, const real *,          \
-                                   const real *, int, real *, uint8_t *, int *, int *, real *, hipStream_t);  \
+                                   const real *, int, real *, uint8_t *, int *, int *, real *, real *, int *, \
+                                   hipStream_t);                                                              \
     template int launch_traj_cost<real>(const StepParams<real> &, real *, real *, hipStream_t);                \
     template int launch_kkt_grads<real>(const StepParams<real> &, const real *, const real *, const real *,   \
                                         const real *, real *, real *, real *, real *, real *, hipStream_t);   \

@@ -19,6 +19,8 @@ BOUND_NONE, BOUND_SCALAR, BOUND_TENSOR = 0, 1, 2
 ST_PNQP_UNCONVERGED, ST_NONFINITE, ST_NOMINAL_OFF_DYNAMICS = 1, 2, 4
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA16, IMPL_DPP16, IMPL_TINY, IMPL_MFMA40 = 0, 1, 2, 3, 4, 5
 
+ABI_VERSION = 3      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
+
 _vp, _i32, _i64, _f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 
 
@@ -72,7 +74,7 @@ class Outputs(ctypes.Structure):
 
 EXPORTS = ("mpc_lqr_abi_version", "mpc_lqr_build_info", "mpc_lqr_last_error", "mpc_lqr_workspace_bytes",
            "mpc_lqr_step", "mpc_lqr_impl_supported", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_lqr_kkt_prepare",
-           "mpc_pnqp", "mpc_traj_cost", "mpc_env_traj_cost", "mpc_env_linearize", "mpc_select_best")
+           "mpc_pnqp", "mpc_pnqp_lu", "mpc_traj_cost", "mpc_env_traj_cost", "mpc_env_linearize", "mpc_select_best")
 
 _lib = None
 
@@ -110,11 +112,12 @@ def load():
     L.mpc_lqr_kkt_grads.argtypes = [PP] + [_vp] * 10
     L.mpc_lqr_kkt_prepare.argtypes = [ctypes.c_int] * 5 + [_vp, _vp, _vp, OP, _vp, _vp, _vp]
     L.mpc_pnqp.argtypes = [ctypes.c_int] * 3 + [_vp] * 5 + [ctypes.c_int] + [_vp] * 6
+    L.mpc_pnqp_lu.argtypes = [ctypes.c_int] * 3 + [_vp] * 5 + [ctypes.c_int] + [_vp] * 8
     L.mpc_traj_cost.argtypes = [PP, _vp, _vp, _vp]
     L.mpc_env_traj_cost.argtypes = [PP, ctypes.POINTER(EnvDynamics), _vp, _vp, _vp]
     L.mpc_env_linearize.argtypes = [ctypes.POINTER(EnvDynamics), ctypes.c_int, _i64, _vp, _vp, _vp, _vp, _vp]
     L.mpc_select_best.argtypes = [ctypes.c_int] * 6 + [_f64] + [_vp] * 11
-    if L.mpc_lqr_abi_version() != 2:
+    if L.mpc_lqr_abi_version() != ABI_VERSION:
         raise RuntimeError("libmpc_lqr_hip ABI version mismatch")
     _lib = L
     return L
@@ -426,7 +429,7 @@ class HipBackend:
                     _keep=(keep, keep_o, negr, mask, sol))
 
     # -- (5) pnqp -------------------------------------------------------------------------------
-    def pnqp(self, H, q, lower, upper, x_init=None, n_iter=20, want_Hfree=True):
+    def pnqp(self, H, q, lower, upper, x_init=None, n_iter=20, want_Hfree=True, want_lu=False):
         dev = _require_device(H, q)
         L = load()
         B, n = H.shape[0], H.shape[1]
@@ -444,10 +447,14 @@ class HipBackend:
         iters = torch.empty(B, device=dev, dtype=torch.int32)
         status = torch.empty(B, device=dev, dtype=torch.int32)
         Hfree = torch.empty(B, n, n, **kw) if want_Hfree else None
-        _check(L.mpc_pnqp(_dtype_code(H), B, n, H.data_ptr(), q.data_ptr(), lo.data_ptr(), hi.data_ptr(),
-                          _ptr(x0), int(n_iter), x.data_ptr(), If.data_ptr(), iters.data_ptr(),
-                          status.data_ptr(), _ptr(Hfree), _stream(dev)), "mpc_pnqp")
-        return dict(x=x, If=If, iters=iters, status=status, Hfree=Hfree)
+        # want_lu: the packed LU + 1-based pivots of the last Newton system (torch.linalg.lu_factor's layout) --
+        # the factor the kernel computed anyway, instead of a rocSOLVER call on Hfree afterwards
+        LU = torch.empty(B, n, n, **kw) if want_lu else None
+        piv = torch.empty(B, n, device=dev, dtype=torch.int32) if want_lu else None
+        _check(L.mpc_pnqp_lu(_dtype_code(H), B, n, H.data_ptr(), q.data_ptr(), lo.data_ptr(), hi.data_ptr(),
+                             _ptr(x0), int(n_iter), x.data_ptr(), If.data_ptr(), iters.data_ptr(),
+                             status.data_ptr(), _ptr(Hfree), _ptr(LU), _ptr(piv), _stream(dev)), "mpc_pnqp_lu")
+        return dict(x=x, If=If, iters=iters, status=status, Hfree=Hfree, LU=LU, pivots=piv)
 
     # -- (6) get_traj / get_cost ----------------------------------------------------------------
     def traj_cost(self, x_init, u, F, f, C=None, c=None, want_x=True):

@@ -94,6 +94,50 @@ def _module_rollout(n_state, n_ctrl, T, x_init, K, k, cur_x, cur_u, old_cost, tr
     return new_x, new_u, cost, full_du_norm, du_norm, alpha.squeeze(1)
 
 
+class _AsyncHostScalar(torch.Tensor):
+    """A 1-element CPU tensor whose value arrives by an asynchronous device->host copy; the first torch operation
+    that touches it (float(), .item(), printing, arithmetic, .numpy()) first waits for the stream the copy was
+    enqueued on.  What `LQRStep(...)` returns as `n_total_qp_iter`: the reference hands back a CPU float tensor
+    there (mpc/lqr_step.py:308) and pays a device synchronisation for it in every forward; here nothing waits
+    unless somebody looks."""
+
+    @staticmethod
+    def __new__(cls, host, waiter):
+        t = torch.Tensor._make_subclass(cls, host)
+        t._waiter = waiter
+        return t
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        for a in args:
+            w = getattr(a, "_waiter", None) if isinstance(a, cls) else None
+            if w is not None:
+                a._waiter = None
+                w()
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+
+_PINNED_RING = {}      # device index -> [pinned float32 tensor of _RING slots, next slot]
+_RING = 256
+
+
+def _host_scalar_async(dev_scalar):
+    """int32 / float device tensor [1] -> CPU float tensor [1], without synchronising (see _AsyncHostScalar).
+    The pinned landing slots are a ring per device: a value is valid until _RING later solves have been issued."""
+    if not dev_scalar.is_cuda:
+        return dev_scalar.to(torch.float32).reshape(1).cpu()
+    key = dev_scalar.device.index
+    ring = _PINNED_RING.get(key)
+    if ring is None:
+        ring = _PINNED_RING[key] = [torch.zeros(_RING, dtype=torch.float32).pin_memory(), 0]
+    slot = ring[0][ring[1]:ring[1] + 1]
+    ring[1] = (ring[1] + 1) % _RING
+    slot.copy_(dev_scalar.to(torch.float32).reshape(1), non_blocking=True)
+    stream = torch.cuda.current_stream(dev_scalar.device)
+    return _AsyncHostScalar(slot, stream.synchronize)
+
+
 class _StepConfig:
     """What one LQRStep(...) call fixes for its autograd node (closure state of the reference's factory)."""
     __slots__ = ("solve", "no_op_forward", "delta_space", "current_x", "current_u", "u_lower", "u_upper")
@@ -121,9 +165,14 @@ class _LQRStepFn(Function):
         assert cfg.current_u is not None
         new_x, new_u, qp_iters, costs, full_du_norm, alphas = cfg.solve(x_init, C, c, F, f)
         ctx.save_for_backward(x_init, C, c, F, f, new_x, new_u)
-        # the reference hands back a CPU float tensor here (mpc/lqr_step.py:308)
-        n_qp = float(qp_iters.max().item()) if cfg.u_lower is not None else 0.0
-        return new_x, new_u, torch.Tensor([n_qp]), costs, full_du_norm, alphas.mean()
+        # n_total_qp_iter stays on the device here; LQRStep's wrapper turns it into the CPU float tensor of the
+        # reference (mpc/lqr_step.py:308) by an asynchronous copy -- no host synchronisation in a forward.
+        # Value: max over the problems of sum_t (1 + that problem's pnqp iterations).  The reference's loops are
+        # batch-global, so it reports sum_t (1 + max over the batch) >= this; they agree for n_batch = 1.  Only the
+        # "total_qp_iters" log column and this third return value see it.
+        n_qp = qp_iters.max().reshape(1) if cfg.u_lower is not None else qp_iters[:1]     # unbounded: zeros, no kernel
+        ctx.mark_non_differentiable(n_qp)
+        return new_x, new_u, n_qp, costs, full_du_norm, alphas.mean()
 
     @staticmethod
     def backward(ctx, dl_dx, dl_du, *unused):
@@ -205,5 +254,9 @@ def LQRStep(n_state,
     cfg.u_lower, cfg.u_upper = u_lower, u_upper
 
     def apply(x_init, C, c, F, f=None):
-        return _LQRStepFn.apply(cfg, x_init, C, c, F, f)
+        out = _LQRStepFn.apply(cfg, x_init, C, c, F, f)
+        if no_op_forward:
+            return out
+        n_qp = _host_scalar_async(out[2]) if u_lower is not None else torch.zeros(1)
+        return out[:2] + (n_qp,) + out[3:]
     return apply

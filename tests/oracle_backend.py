@@ -90,14 +90,18 @@ class OracleBackend:
                            _bound(opts.u_lower), _bound(opts.u_upper), lockstep=self.lockstep)
         return {k: (None if o[k] is None else self._t(o[k], C)) for k in ("dx_init", "dC", "dc", "dF", "df", "dx", "du")}
 
-    def pnqp(self, H, q, lower, upper, x_init=None, n_iter=20, want_Hfree=True):
+    def pnqp(self, H, q, lower, upper, x_init=None, n_iter=20, want_Hfree=True, want_lu=False):
         self.calls.append("pnqp")
         o = O.pnqp(_np(H), _np(q), _bound(lower), _bound(upper), _np(x_init), n_iter=n_iter, lockstep=self.lockstep)
         Hn = _np(H)
         If = o["If"].astype(bool)
         Hfree = np.where(If[:, :, None] & If[:, None, :], Hn, 0.0) + 1e-11 * np.eye(Hn.shape[1])
+        LU = piv = None
+        if want_lu:      # the checker's own factorisation (LAPACK through torch on the CPU)
+            LU, piv = torch.linalg.lu_factor(self._t(Hfree, H))
         return dict(x=self._t(o["x"], H), If=torch.from_numpy(o["If"]), iters=torch.from_numpy(o["iters"]),
-                    status=torch.from_numpy((1 - o["converged"]).astype(np.int32)), Hfree=self._t(Hfree, H))
+                    status=torch.from_numpy((1 - o["converged"]).astype(np.int32)), Hfree=self._t(Hfree, H),
+                    LU=LU, pivots=piv)
 
     def traj_cost(self, x_init, u, F, f, C=None, c=None, want_x=True):
         self.calls.append("traj_cost")

@@ -404,6 +404,27 @@ def test_pnqp_parity(be, name):
     from mpc import pnqp as pnqp_mod
     xw, fac, If, n_it = pnqp_mod.pnqp(dev(z["H"]), dev(z["q"]), dev(z["lower"]), dev(z["upper"]), x_init=dev(z.get("x0")))
     assert torch.equal(xw, r["x"]) and (isinstance(fac, tuple) if z["H"].shape[1] > 1 else torch.is_tensor(fac))
+    n = z["H"].shape[1]
+    if n > 1:
+        # (LU, pivots) is the kernel's own factorisation of the last Newton system H_ (free block of H + 1e-11 I,
+        # mpc/pnqp.py:44-54), in torch.linalg.lu_factor's layout: it solves H_ like the reference's H_lu_ does,
+        # and it IS LAPACK's factorisation up to rounding (same partial pivoting)
+        LU, piv = fac
+        assert LU.shape == (z["H"].shape[0], n, n) and piv.dtype == torch.int32 and piv.shape == (z["H"].shape[0], n)
+        assert int(piv.min()) >= 1 and int(piv.max()) <= n
+        Ifb = host(r["If"]).astype(bool)
+        Hfree = np.where(Ifb[:, :, None] & Ifb[:, None, :], z["H"].astype(np.float64), 0.0) + 1e-11 * np.eye(n)
+        g = torch.Generator().manual_seed(n)
+        rhs = torch.randn(z["H"].shape[0], n, 3, generator=g, dtype=LU.dtype).to(DEV)
+        sol = torch.linalg.lu_solve(LU, piv, rhs)
+        res = np.einsum("bij,bjk->bik", Hfree, host(sol).astype(np.float64)) - host(rhs)
+        # clamped rows of H_ are 1e-11 * I: their solution components are ~1e11 * rhs -- compare on the free rows
+        free_rows = np.broadcast_to(Ifb[:, :, None], res.shape)
+        assert np.abs(res[free_rows]).max() < (1e-8 if f64 else 2e-3), np.abs(res[free_rows]).max()
+        LUt, pivt = torch.linalg.lu_factor(torch.from_numpy(Hfree).to(LU.dtype))
+        assert torch.equal(pivt, piv.cpu())
+        np.testing.assert_allclose(host(LU), LUt.numpy(), rtol=1e-9 if f64 else 1e-4, atol=1e-9 if f64 else 1e-4)
+    assert int(n_it) == int(host(r["iters"]).max())
 
 
 def test_traj_cost_parity(be):
@@ -715,6 +736,48 @@ def test_step_and_select_are_graph_capturable(be, shape):
     for k in got:
         assert torch.equal(got[k], e[k]), k
     assert torch.equal(got_best, e["new_u"]) and got_max == float(e["full_du_norm"].max())
+
+
+def test_lqrstep_forward_with_bounds_never_synchronises(be):
+    """a box-constrained `LQRStep(...)` forward (the autograd node, not just the C call) does
+    no device->host read -- it is captured into a HIP graph whole (any .item() / .tolist() inside would abort the
+    capture) and replays on new inputs with the eager results; `n_total_qp_iter` arrives as the reference's CPU
+    float tensor (mpc/lqr_step.py:308) through an asynchronous copy that waits only when somebody looks."""
+    import bench
+    from mpc import util
+    from mpc.lqr_step import LQRStep
+    from mpc.mpc import LinDx, QuadCost
+    ns, nc, T, B = 12, 4, 20, 64
+    p = bench.make_problem(ns, nc, T, B, torch.float32, DEV, seed=4, u_scale=0.3, clamp=1.0)
+
+    def run():
+        step = LQRStep(ns, nc, T, u_lower=-1.0, u_upper=1.0, true_cost=QuadCost(p["C"], p["c"]),
+                       true_dynamics=LinDx(p["F"], p["f"]), current_x=p["cur_x"], current_u=p["cur_u"])
+        return step(p["x_init"], p["C"], p["c"], p["F"], p["f"])
+    with torch.no_grad():
+        e = run()                                    # warm-up outside the capture (pinned ring, allocator)
+        torch.cuda.synchronize()
+        assert e[2].device.type == "cpu" and e[2].shape == (1,)
+        n_eager = float(e[2])
+        assert n_eager >= T                          # sum_t (1 + iterations) of the slowest problem
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                out = run()
+        torch.cuda.current_stream().wait_stream(side)
+        p["x_init"].mul_(0.7).add_(0.05)
+        p["c"].mul_(-1.0)
+        p["cur_x"].copy_(util.get_traj(T, p["cur_u"], p["x_init"], LinDx(p["F"], p["f"])))
+        graph.replay()
+        torch.cuda.synchronize()
+        got_u, got_c = out[1].clone(), out[3].clone()
+        n_graph = float(out[2])
+        e2 = run()
+        torch.cuda.synchronize()
+    assert torch.equal(got_u, e2[1]) and torch.equal(got_c, e2[3])
+    assert n_graph == float(e2[2])
 
 
 def test_north_star_properties(be):

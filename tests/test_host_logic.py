@@ -43,7 +43,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert set(_native.EXPORTS) == declared
-    assert L.mpc_lqr_abi_version() == 2
+    assert L.mpc_lqr_abi_version() == _native.ABI_VERSION == 3
     assert b"gfx950" in L.mpc_lqr_build_info()
 
 
@@ -489,6 +489,15 @@ def test_pnqp_mirror(oracle_backend, capsys):
     np.testing.assert_allclose(x.numpy(), z["x_pp"], atol=1e-10)
     assert isinstance(fac, tuple) and len(fac) == 2 and n_it == int(z["iters_pp"].max())
     assert np.array_equal(If.numpy(), z["If_pp"])
+    # the iteration count is read from the device only when it is looked at; it then behaves like the int it is
+    assert n_it + 1 == int(z["iters_pp"].max()) + 1 and "%d" % n_it == str(int(n_it)) == "{}".format(n_it)
+    assert len(range(n_it)) == int(n_it)
+    # (LU, pivots) solve H_ like the reference's H_lu_ does (mpc/pnqp.py:53-54)
+    rhs = torch.ones(fac[0].shape[0], fac[0].shape[1], 1, dtype=fac[0].dtype)
+    sol = torch.linalg.lu_solve(fac[0], fac[1], rhs)
+    Hn, Ifb = z["H"], z["If_pp"].astype(bool)
+    Hfree = np.where(Ifb[:, :, None] & Ifb[:, None, :], Hn, 0.0) + 1e-11 * np.eye(Hn.shape[1])
+    np.testing.assert_allclose(np.einsum("bij,bjk->bik", Hfree, sol.numpy()), rhs.numpy(), atol=1e-8)
 
 
 def test_module_dynamics_rollout_equals_lindx(oracle_backend):
