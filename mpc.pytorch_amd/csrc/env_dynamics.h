@@ -28,14 +28,19 @@ MPC_HD int env_ns(int kind) { return kind == MPC_ENV_CARTPOLE ? 5 : 3; }
 MPC_HD int env_np(int kind) { return kind == MPC_ENV_PENDULUM ? 3 : (kind == MPC_ENV_PENDULUM_FULL ? 5 : 4); }
 
 // sin / cos of an angle of a few radians.  float on the device: the hardware's v_sin_f32 / v_cos_f32 (two
-// instructions each against ~90 of the library routine with its argument reduction; absolute error < 1e-6, inside
+// instructions each against ~90 of the library routine with its argument reduction; absolute error < 2e-6, inside
 // the fp32 parity tolerance -- tests/test_gpu_parity.py pins F, f and the trajectories against the reference's
 // modules).  The simulator kernels are bound by one lane's instruction count, and the three libm calls of a
 // transition were a third of it.  double and the host build keep the library functions.
+// The fast path is taken for |x| <= 32 rad only: v_sin_f32 works on x / 2 pi, whose float rounding turns into an
+// angle error of |x| * 6e-8 (2e-6 at the threshold), and the instruction is defined for |x / 2 pi| <= 256 at all.  A
+// diverging line-search trial (angular velocity in the thousands) leaves that range; it takes the library routine,
+// so that every trial cost -- and with it the accepted step -- is the one torch.sin / torch.cos would give.
+#define MPC_ENV_FAST_TRIG_MAX 32.0f
 MPC_HD float env_sin(float x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __sinf(x);
+    return fabsf(x) <= MPC_ENV_FAST_TRIG_MAX ? __sinf(x) : sinf(x);
 #else
     return sinf(x);
 #endif
@@ -43,7 +48,7 @@ MPC_HD float env_sin(float x)
 MPC_HD float env_cos(float x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __cosf(x);
+    return fabsf(x) <= MPC_ENV_FAST_TRIG_MAX ? __cosf(x) : cosf(x);
 #else
     return cosf(x);
 #endif
