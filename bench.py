@@ -204,8 +204,12 @@ def extra_rows(be, dev, steps):
         key = "bounded" if bounded else "unbounded"
         p = make_problem(NS, NC, T_H, B_PER_GPU, torch.float32, dev, seed=5, u_scale=0.3 if bounded else 0.0,
                          clamp=1.0 if bounded else None)
-        opts = StepOptions(u_lower=-1.0, u_upper=1.0) if bounded else StepOptions()
+        opts = StepOptions(u_lower=-1.0, u_upper=1.0, nominal_on_dynamics=True) if bounded else StepOptions(nominal_on_dynamics=True)
         row, r = step_row(p, opts, NS, NC, T_H, B_PER_GPU)
+        if not bounded:
+            rowv, _ = step_row(p, StepOptions(), NS, NC, T_H, B_PER_GPU)
+            rowv["workload"] = "headline shape, unbounded, nominal NOT vouched for: the kernel verifies it at every timestep (bare LQRStep call)"
+            rows["lqr_step_unbounded_verified_nominal"] = rowv
         if bounded:
             row["workload"] = "headline shape, box bounds +-1 (pnqp in the sweep), nominal u ~ 0.3 N clamped"
             rows["lqr_step_bounded"] = row
@@ -285,6 +289,9 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary rows (`extra`)")
+    ap.add_argument("--verify-nominal", action="store_true",
+                    help="do not vouch for the nominal: the kernel verifies at every timestep that current_x is the rollout "
+                         "of current_u (what a bare LQRStep(...) call with an arbitrary nominal gets)")
     ap.add_argument("--probe-share", default="", help="diagnostic only: 'C' / 'F' / 'CF' = expand timestep 0 of C / F "
                     "over the horizon (stride 0), which removes that array's HBM traffic without changing the arithmetic")
     args = ap.parse_args()
@@ -332,7 +339,11 @@ def main():
     B = args.batch
     p = make_problem(NS, NC, T_H, B, torch.float32, dev, seed=1000 + rank,
                      u_scale=0.3 if args.bounded else 0.0, clamp=1.0 if args.bounded else None)
-    opts = StepOptions(u_lower=-1.0, u_upper=1.0) if args.bounded else StepOptions()
+    # the nominal IS util.get_traj of the nominal controls (make_problem), as MPC.forward hands it to every step
+    # (mpc/mpc.py:251): the step is told so (MPC_OPT_NOMINAL_ON_DYNAMICS), like mpc.MPC does; --verify-nominal times the
+    # general entry, which checks the premise at every timestep
+    vouch = not args.verify_nominal
+    opts = StepOptions(u_lower=-1.0, u_upper=1.0, nominal_on_dynamics=vouch) if args.bounded else StepOptions(nominal_on_dynamics=vouch)
     if "C" in args.probe_share:
         p["C"] = p["C"][:1].expand(T_H, -1, -1, -1)
     if "F" in args.probe_share:
@@ -403,6 +414,7 @@ def main():
                                    % (B, "box bounds +-1 (pnqp)" if args.bounded else "unbounded"),
                        "global_batch": world * B, "horizon": T_H, "parallelism": "batch-shard x%d" % world,
                        "kernel": KERNEL_NAMES.get(impl_used, "impl %d" % impl_used),
+                       "nominal": "util.get_traj of the nominal controls" + (", flagged on-dynamics as mpc.MPC flags it" if vouch else ", verified by the kernel at every timestep"),
                        "settle_launches": settle, "finite": ok,
                        "launcher": ("torch.distributed.run (self-spawned by bench.py)" if os.environ.get("MPC_BENCH_SPAWNED")
                                     else "torch.distributed.run") if launched else "single process",

@@ -83,6 +83,17 @@ typedef struct mpc_lqr_problem {
     const void *cur_u;                /* [T,B,nc] nominal controls */
 } mpc_lqr_problem;
 
+/* mpc_lqr_options.flags */
+enum {
+    MPC_OPT_NOMINAL_ON_DYNAMICS = 1  /* the caller GUARANTEES that cur_x is the rollout of cur_u through (F, f) from
+                                        x_init -- what MPC.forward hands to every step (it recomputes x with
+                                        util.get_traj, mpc/mpc.py:251) and what a previous step's (new_x, new_u) is.
+                                        The 4-problems-per-wave kernel prices its rollout by an identity of the sweep's
+                                        value function that holds exactly then; without the flag it verifies the premise
+                                        at every timestep (and prices from C itself where it fails, MPC_ST_NOMINAL_OFF_
+                                        DYNAMICS), with it the verification is skipped.  Other kernels ignore it. */
+};
+
 /* The LQRStep(...) keyword arguments that reach the kernels
  * (mpc/lqr_step.py:22-38; defaults as there). */
 typedef struct mpc_lqr_options {
@@ -94,7 +105,7 @@ typedef struct mpc_lqr_options {
     double delta_u;                   /* NaN = None */
     double linesearch_decay;          /* default 0.2 */
     int32_t pnqp_iter;                /* n_iter of the in-sweep pnqp, 20 (mpc/lqr_step.py:137) */
-    int32_t _pad;
+    int32_t flags;                    /* MPC_OPT_* bits (0 = none) */
     const mpc_env_dynamics *true_dynamics; /* NULL = LinDx(F,f) (mpc/lqr_step.py:216-222); else the rollout
                                               calls the simulator (:223-225) -- generic kernels only */
 } mpc_lqr_options;

@@ -18,6 +18,7 @@ namespace wv {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 MPC_DEV int lane() { return (int)threadIdx.x; }
 MPC_DEV int problem() { return (int)blockIdx.x; }
+MPC_DEV unsigned long long clock() { return (unsigned long long)clock64(); }
 MPC_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // 1 ulp
 // an opaque register-to-register identity: keeps hipcc from folding a chain of selects back into scalar mask logic
 MPC_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
@@ -206,7 +207,9 @@ MPC_DEV void store_f32x4(float *g, f32x4 v) { *(f32x4 *)g = v; }
 template <int N> MPC_DEV void dma_wait()
 {
     static_assert(N >= 0 && N < 64, "vmcnt is 6 bits on gfx9");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    // (the trailing comment marks the wait as written by hand: tools/isa_lint.py looks for the UNMARKED vmcnt(0) the
+    // compiler puts in front of a vector load it cannot count across a loop)
+    asm volatile("s_waitcnt vmcnt(%0) ; counted" ::"n"(N) : "memory");
 }
 MPC_DEV void fence_own_stores()
 {

@@ -50,8 +50,36 @@
 #include "lqr_params.h"
 #include "lqr_small_math.h"
 
+// statistics hooks of the host emulator build (tests/emu): no-ops in the kernel
+#ifndef MPC_STAT
+#define MPC_STAT(i)
+#endif
+
+// member functions: MPC_DEV is `static inline` in the host emulator build, which a member cannot be
+#ifndef MPC_DEVM
+#define MPC_DEVM MPC_DEV
+#endif
+
 namespace mpclqr {
 namespace dpp16 {
+
+// Diagnostic builds only (-DMPC_DPP16_PROF, tools/prof_phases.py): shader-clock totals of the phases of the two
+// loops, per wave, written where K would go.  Every probe drains the LDS / scalar queue (s_memtime), so the phases
+// are timed back to back, not overlapped -- an upper bound for each.
+#ifdef MPC_DPP16_PROF
+struct Prof { unsigned long long acc[16]; unsigned long long last; };
+#define PROF_DECL Prof prof_; for (int i_ = 0; i_ < 16; ++i_) prof_.acc[i_] = 0; prof_.last = wv::clock()
+#define PROF_ARG , Prof &prof_
+#define PROF_PASS , prof_
+#define PROF_MARK(slot) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = wv::clock(); prof_.acc[slot] += n_ - prof_.last; prof_.last = n_; } while (0)
+#define PROF_MARK_ALL(slot) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = wv::clock(); prof_.acc[slot] += n_ - prof_.last; prof_.last = n_; } while (0)
+#else
+#define PROF_DECL
+#define PROF_ARG
+#define PROF_PASS
+#define PROF_MARK(slot)
+#define PROF_MARK_ALL(slot)
+#endif
 
 typedef StepParams<float> P;
 using wv::f32x4;
@@ -61,6 +89,151 @@ using mfma16::ldl4;
 using mfma16::ldl4_solve;
 using mfma16::eclampf;
 using mfma16::sel;
+
+// ---------------------------------------------------------------------------
+// The same projected-Newton box QP for the kernel that keeps one problem per 16-lane ROW (lqr_dpp16_body.h):
+// four unknowns, every lane of a row computes its problem's (row-uniform) numbers, the four rows of a wave
+// differ.  Same iterates and the same answer as pnqp4 / mpc/pnqp.py:5-82; what differs is how the wave gets there:
+//   * ONE wave-uniform loop.  A row that has converged freezes its x; every later trip then recomputes that
+//     row's gradient, free set and factorisation from the same numbers, so what the last trip leaves behind is
+//     valid for all four rows -- no per-row exit, hence no exec-mask bookkeeping, no state carried in lane masks.
+//   * the confirming iteration costs a gradient, not a factorisation.  The reference stops in the iteration
+//     whose Newton step is shorter than 1e-4 (:56-59).  After a FULL Newton step (x + dx inside the box) the
+//     gradient vanishes on the free set, so if the free set of the new point is the one just factorised the next
+//     step is zero to rounding (~1e-7): that iteration is recognised from the free-set test alone and returns
+//     the factorisation it would have recomputed.
+//   * free-set flags are numbers (0 / 1) and the masked matrix is built by multiplication, not by selects on
+//     combined lane masks (see ldl4).
+// ---------------------------------------------------------------------------
+MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const float ub[4], int n_iter,
+                       float x[4], bool fr_out[4], Ldl4 &f, bool &converged)
+{
+    const float reg = 1e-11f;                                       // :47
+    const float dg[4] = {s.s00 + reg - 1.f, s.s11 + reg - 1.f, s.s22 + reg - 1.f, s.s33 + reg - 1.f};
+    float m[4] = {-1.f, -1.f, -1.f, -1.f};                          // free set of the last factorisation (none yet)
+    float done = 0.f, conv = 0.f, full = 0.f, it_ret = (float)(n_iter - 1);
+    // The gradient H x + q (:29) is carried along: every step d is followed by g += H d, and H d is also what the
+    // Armijo test of a projected step needs (:61-76) -- one product serves both.
+    float g[4];
+    mfma16::sym4_mv(s, x, g);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) g[a] += q[a];
+    MPC_STAT(4);
+    for (int it = 0; it < n_iter; ++it) {
+        if (done == 0.f) MPC_STAT(0);
+        MPC_STAT(5);
+        float mn[4], diff = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            // :32  clamped = (x == lb & g > 0) | (x == ub & g < 0)
+            const float r_lo = (x[a] == lb[a]) ? g[a] : -1.f;
+            const float r_hi = (x[a] == ub[a]) ? -g[a] : -1.f;
+            mn[a] = (fmaxf(r_lo, r_hi) > 0.f) ? 0.f : 1.f;
+            diff += fabsf(mn[a] - m[a]);
+        }
+        // the free set just factorised, reached by a full Newton step: the step from here is zero -- converged (:56-59)
+        const bool confirmed = (diff == 0.f) & (full != 0.f) & (done == 0.f);
+        it_ret = confirmed ? (float)it : it_ret;
+        conv = confirmed ? 1.f : conv;
+        done = confirmed ? 1.f : done;
+        if (!wv::any(done == 0.f)) break;
+        if (done == 0.f) MPC_STAT(1);
+        MPC_STAT(6);
+        // :44-54  H_ = H on the free block (+1e-11 I, identity elsewhere), dx = -H_^-1 g_
+        Ldl4 fn;
+        {
+            const float a10 = (mn[0] * mn[1]) * s.s01, a20 = (mn[0] * mn[2]) * s.s02, a30 = (mn[0] * mn[3]) * s.s03;
+            const float a21 = (mn[1] * mn[2]) * s.s12, a31 = (mn[1] * mn[3]) * s.s13, a32 = (mn[2] * mn[3]) * s.s23;
+            const float a00 = fmaf(mn[0], dg[0], 1.f), a11 = fmaf(mn[1], dg[1], 1.f);
+            const float a22 = fmaf(mn[2], dg[2], 1.f), a33 = fmaf(mn[3], dg[3], 1.f);
+            fn.i0 = wv::rcp(a00);
+            fn.l10 = a10 * fn.i0; fn.l20 = a20 * fn.i0; fn.l30 = a30 * fn.i0;
+            const float d1 = fmaf(-fn.l10, a10, a11);
+            fn.i1 = wv::rcp(d1);
+            const float t21 = fmaf(-fn.l20, a10, a21);
+            const float t31 = fmaf(-fn.l30, a10, a31);
+            fn.l21 = t21 * fn.i1; fn.l31 = t31 * fn.i1;
+            const float d2 = fmaf(-fn.l21, t21, fmaf(-fn.l20, a20, a22));
+            fn.i2 = wv::rcp(d2);
+            const float t32 = fmaf(-fn.l31, t21, fmaf(-fn.l30, a20, a32));
+            fn.l32 = t32 * fn.i2;
+            const float d3 = fmaf(-fn.l32, t32, fmaf(-fn.l31, t31, fmaf(-fn.l30, a30, a33)));
+            fn.i3 = wv::rcp(d3);
+        }
+        float y[4], dx[4];
+        ldl4_solve(fn, mn[0] * g[0], mn[1] * g[1], mn[2] * g[2], mn[3] * g[3], y);
+        float nrm2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            dx[a] = -(mn[a] * y[a]);
+            nrm2 = fmaf(dx[a], dx[a], nrm2);
+        }
+        // what this trip factorised is what the solve returns for every row (frozen rows recompute their own)
+        f = fn;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) m[a] = mn[a];
+        const bool small = !(nrm2 >= 1e-8f) & (done == 0.f);        // |dx| < 1e-4  (:56-59)
+        it_ret = small ? (float)it : it_ret;
+        conv = small ? 1.f : conv;
+        done = small ? 1.f : done;
+        // :61-78  the step: x + dx when that stays inside the box (its Armijo ratio is exactly 1/2, see pnqp4), else the
+        // projection of x + alpha dx with alpha = 1, 0.1, ... by the Armijo rule.  d = step taken (0 on a converged row).
+        const float live = 1.f - done;
+        float xc[4], d[4], hd[4], out = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float xn = x[a] + dx[a];
+            xc[a] = eclampf(xn, lb[a], ub[a]);
+            out += fabsf(xc[a] - xn);
+            d[a] = (xc[a] - x[a]) * live;
+        }
+        mfma16::sym4_mv(s, d, hd);
+        const bool inside = out == 0.f;
+        full = inside ? 1.f : 0.f;
+        const bool test = !inside & (done == 0.f);
+        if (wv::any(test)) {
+            if (test) MPC_STAT(2);
+            // f(x) - f(m) = -g'd - d'Hd/2 with d = m - x, against 0.1 g'(x - m)
+            float den = 0.f, dhd = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                den = fmaf(-g[a], d[a], den);
+                dhd = fmaf(d[a], hd[a], dhd);
+            }
+            const float arm = fmaf(-0.5f, dhd, den) * wv::rcp(den);
+            if (test & (arm <= 0.1f)) {
+                // (rare: one QP in a hundred) shorter steps, this row only
+                float alpha = 0.1f;
+                for (int count = 1; count < 10; ++count) {
+                    MPC_STAT(3);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        xc[a] = eclampf(fmaf(alpha, dx[a], x[a]), lb[a], ub[a]);
+                        d[a] = xc[a] - x[a];
+                    }
+                    mfma16::sym4_mv(s, d, hd);
+                    float den2 = 0.f, dhd2 = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        den2 = fmaf(-g[a], d[a], den2);
+                        dhd2 = fmaf(d[a], hd[a], dhd2);
+                    }
+                    const float arm2 = fmaf(-0.5f, dhd2, den2) * wv::rcp(den2);
+                    if (arm2 <= 0.1f) alpha *= 0.1f; else break;
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            x[a] = (done != 0.f) ? x[a] : xc[a];                    // :78 (a converged row keeps its x)
+            g[a] += hd[a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) fr_out[a] = m[a] != 0.f;
+    converged = conv != 0.f;
+    return (int)it_ret;
+}
 
 enum {
     SC = 0, SF = 4096, SR = 7168, SG = 8192, STAGE_BYTES = 9216, NSTAGE = 4,
@@ -121,7 +294,7 @@ struct Lane {
     int aRecA;            // SR + p*256 + 4 a                   (+R_lo / R_hi)
     int aRecF;            // SR + p*256 + R_f + 4 min(j, 11)
     int aKrow;            // SG + p*256 + 4 a                   (+16 jj: K[a][jj]; +192: k_a)
-    int aS[4];            // SG + p*256 + 208 + 4 tri(a, b)     (Quu[a][b] of the packed upper triangle)
+    int aS[4];            // SG + p*256 + 16 (12 + max(a,b)) + 4 min(a,b)   (Quu[a][b], see lane_init)
     float *out0;          // this lane's element of new_x / new_u at t = 0 ...
     long ostep;           // ... and its stride per timestep
     int aMrow;            // SC + p*256 + 4 a                   (second record; + RollRing::MADJ)
@@ -151,11 +324,13 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
     L.aRecF = SR + L.p * 256 + R_f + 4 * jx;
     L.aKrow = SG + L.p * 256 + 4 * L.a;
     L.aMrow = SC + L.p * 256 + 4 * L.a;
+    // Quu in the gain record: lanes 13..15 carry columns 1..3 of Quu as they stand in their Q registers
+    // (element r of lane 12 + c = Quu[r][c]); Quu[0][0], which only lane 12 (the k lane) holds, replaces the
+    // redundant Quu[2][1] in lane 13.  Quu[a][b] is read as (column max(a,b), row min(a,b)).
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int lo = L.a < b ? L.a : b, hi = L.a < b ? b : L.a;
-        const int tri = (lo == 0 ? 0 : (lo == 1 ? 4 : (lo == 2 ? 7 : 9))) + (hi - lo);
-        L.aS[b] = SG + L.p * 256 + 208 + 4 * tri;
+        L.aS[b] = SG + L.p * 256 + (hi == 0 ? 16 * 13 + 4 * 2 : 16 * (12 + hi) + 4 * lo);
     }
 }
 
@@ -165,101 +340,177 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
 //   F  : granule G = 64 k + l of the 4 x 48 granules           (3 instructions)
 //   rec: problem slot l>>4, granule l&15: 0-3 c | 4-6 x | 7 u | 8-10 f | 12 lo | 13 hi
 //   gains (rollout): problem slot l>>4, granule l&15 of the wave's own record Kk[t][b][16][4]
+// Every lane keeps RUNNING source pointers that step along the horizon (one 64-bit add per pointer and timestep;
+// t * stride + base per DMA cost three times that).  Every lane takes part in every instruction: a granule nobody
+// reads in this pass (c in the identity-priced rollout, f in the sweep, the unused ones) is aliased to a granule of
+// the nominal state -- the same cache lines its neighbours fetch, no extra HBM traffic, and no exec-mask
+// bookkeeping around the DMA.  Rows of a partial last wave repeat problem B-1 (loads and stores: the same values
+// to the same addresses).
 // ---------------------------------------------------------------------------
 struct Dma {
     // all biased by minus the immediate their instruction carries (see wv::dma16_at)
-    const char *c_ptr[4];     // wave-uniform per problem slot        imm 1024 k - 4096
-    const char *f_ptr[3];     // per lane (column-read order)         imm 1024 k
-    const char *f_ptr_r[3];   // per lane (row-read order, rollout)   imm 1024 k
+    const char *c_ptr[4];     // per lane                             imm 1024 k - 4096
+    const char *f_ptr[3];     // per lane (column-read order in the sweep, row-read order in the rollout)  imm 1024 k
     const char *r_ptr;        // per lane                             imm 3072
     const char *g_ptr;        // per lane                             imm -1024 (packed rollout)
     const char *g2_ptr;       // per lane: the (m, M) record          imm -2048 (packed rollout)
-    long c_step, f_step, r_step, g_step;
-    bool r_active, r_is_f, r_is_c;
+    long c_step, f_step, g_step;      // bytes per timestep (wave-uniform)
+    long r_step;                      // bytes per timestep of this lane's record source
+    long r_step_nof;                  // the same, but 0 on lanes that stream f (a move that leaves F / f in place)
 };
 
-template <int MODE>
-MPC_DEV void dma_init(Dma &d, const P &p, const Lane &L, int wave)
+// Position the pointers on the first stage of a pass: t = T-1 for the sweep, t = 0 for a rollout.
+// F / f have T-1 entries: stage t reads entry min(t, T-2) (stage T-1 never looks at its copy).
+template <int MODE, bool ROLL, bool DIRECT>
+MPC_DEV void dma_seek(Dma &d, const P &p, const Lane &L, int wave)
 {
     const long B = p.B;
+    const int T = p.T;
+    const long t0 = ROLL ? 0 : T - 1;
+    const long tf0 = (ROLL || T < 2) ? 0 : T - 2;
+    d.c_step = 4 * p.C_st;
+    d.f_step = T > 1 ? 4 * p.F_st : 0;
+    d.g_step = 4 * B * 64;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int pbk = 4 * wave + k < p.B ? 4 * wave + k : p.B - 1;
-        d.c_ptr[k] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * src_granule_rows(L.lane) - (1024 * k - 4096);
+        d.c_ptr[k] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * src_granule_rows(L.lane) - (1024 * k - 4096) + t0 * d.c_step;
     }
-    d.c_step = 4 * p.C_st;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int G = 64 * k + L.lane;
         const int slot = G / 48, gi = G - 48 * slot;
         const int pbk = 4 * wave + slot < p.B ? 4 * wave + slot : p.B - 1;
-        const char *fb = p.T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) : (const char *)p.C;
-        d.f_ptr[k] = fb + (p.T > 1 ? 16 * src_granule_cols(gi, slot) : 0) - 1024 * k;
-        d.f_ptr_r[k] = fb + (p.T > 1 ? 16 * src_granule_rows(gi) : 0) - 1024 * k;
+        const char *fb = T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) : (const char *)p.C;
+        const int perm = ROLL ? src_granule_rows(gi) : src_granule_cols(gi, slot);
+        d.f_ptr[k] = fb + (T > 1 ? 16 * perm : 0) - 1024 * k + tf0 * d.f_step;
     }
-    d.f_step = 4 * p.F_st;
     {
         const int gi = L.lane & 15;
         const long pb = L.pb;
-        d.r_active = false;
-        d.r_is_f = false;
-        const char *q = (const char *)p.c;
-        long st = 0;
-        d.r_is_c = gi < 4;
-        if (gi < 4) { d.r_active = true; q = (const char *)(p.c + pb * p.c_sb + 4 * gi); st = 4 * p.c_st; }
-        else if (gi < 7) { d.r_active = true; q = (const char *)(p.cur_x + pb * 12 + 4 * (gi - 4)); st = 4 * B * 12; }
-        else if (gi == 7) { d.r_active = true; q = (const char *)(p.cur_u + pb * 4); st = 4 * B * 4; }
-        else if (gi < 11) {
-            if (p.f && p.T > 1) { d.r_active = true; d.r_is_f = true; q = (const char *)(p.f + pb * p.f_sb + 4 * (gi - 8)); st = 4 * p.f_st; }
+        const bool want_c = !ROLL || DIRECT;            // the identity-priced rollout never looks at c
+        const bool want_f = ROLL && p.f && T > 1;       // the sweep never looks at f
+        const bool want_b = MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR;
+        const char *q = (const char *)(p.cur_x + pb * 12 + 4 * (gi % 3));       // the alias: a granule of the nominal state
+        long st = 4 * B * 12;
+        bool is_f = false;
+        if (gi < 4) {
+            if (want_c) { q = (const char *)(p.c + pb * p.c_sb + 4 * gi); st = 4 * p.c_st; }
+        } else if (gi < 7) {
+            q = (const char *)(p.cur_x + pb * 12 + 4 * (gi - 4));
+        } else if (gi == 7) {
+            q = (const char *)(p.cur_u + pb * 4); st = 4 * B * 4;
+        } else if (gi < 11) {
+            if (want_f) { q = (const char *)(p.f + pb * p.f_sb + 4 * (gi - 8)); st = 4 * p.f_st; is_f = true; }
         } else if (gi == 12 || gi == 13) {
-            if (MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR) {
-                d.r_active = true; q = (const char *)((gi == 12 ? p.lo : p.hi) + pb * 4); st = 4 * B * 4;
-            }
+            if (want_b) { q = (const char *)((gi == 12 ? p.lo : p.hi) + pb * 4); st = 4 * B * 4; }
         }
-        d.r_ptr = q - 3072;
+        d.r_ptr = q - 3072 + (is_f ? tf0 : t0) * st;
         d.r_step = st;
-        d.g_ptr = (const char *)(p.Kk + pb * 64 + 4 * gi) + 1024;
-        d.g2_ptr = (const char *)(p.Kk + (long)p.T * B * 64 + pb * 64 + 4 * gi) + 2048;
-        d.g_step = 4 * B * 64;
+        d.r_step_nof = is_f ? 0 : st;
+        d.g_ptr = (const char *)(p.Kk + pb * 64 + 4 * gi) + 1024 + t0 * d.g_step;
+        d.g2_ptr = (const char *)(p.Kk + (long)T * B * 64 + pb * 64 + 4 * gi) + 2048 + t0 * d.g_step;
     }
 }
 
-// DMA of timestep t into ring slot `slot`: exactly DMA_SWEEP / RollDma<MODE, DIRECT>::N instructions, all but the
-// directly-priced rollout's gains on one M0.
+// DMA of the stage the pointers stand on into the ring slot anchored at `mid`: exactly DMA_SWEEP /
+// RollDma<MODE, DIRECT>::N instructions, all but the directly-priced rollout's gains on one M0.
 template <int MODE, bool ROLL, bool DIRECT>
-MPC_DEV void stage_issue(const P &p, const Dma &d, int t, int slot)
+MPC_DEV void stage_issue(const Dma &d, unsigned mid)
 {
-    const unsigned mid = stage_mid<MODE, ROLL, DIRECT>(slot);
-    const long tl = t;
-    const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);     // F / f have T-1 entries
     if (!ROLL || DIRECT) {
-        const long o = tl * d.c_step;
-        wv::dma16_at<-4096, wv::DMA_C>(d.c_ptr[0] + o, mid);
-        wv::dma16_at<-3072, wv::DMA_C>(d.c_ptr[1] + o, mid);
-        wv::dma16_at<-2048, wv::DMA_C>(d.c_ptr[2] + o, mid);
-        wv::dma16_at<-1024, wv::DMA_C>(d.c_ptr[3] + o, mid);
+        wv::dma16_at<-4096, wv::DMA_C>(d.c_ptr[0], mid);
+        wv::dma16_at<-3072, wv::DMA_C>(d.c_ptr[1], mid);
+        wv::dma16_at<-2048, wv::DMA_C>(d.c_ptr[2], mid);
+        wv::dma16_at<-1024, wv::DMA_C>(d.c_ptr[3], mid);
     }
-    {
-        const long o = p.T > 1 ? tf * d.f_step : 0;
-        wv::dma16_at<0, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>((ROLL ? d.f_ptr_r[0] : d.f_ptr[0]) + o, mid);
-        wv::dma16_at<1024, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>((ROLL ? d.f_ptr_r[1] : d.f_ptr[1]) + o, mid);
-        wv::dma16_at<2048, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>((ROLL ? d.f_ptr_r[2] : d.f_ptr[2]) + o, mid);
-    }
-    // the record instruction is issued by every wave even if only some lanes take part
-    {
-        const char *src = d.r_ptr + (d.r_is_f ? tf : tl) * d.r_step;
-        // the identity-priced rollout never looks at c; the sweep never looks at f
-        wv::dma16_at_if<3072>(d.r_active && !(ROLL && !DIRECT && d.r_is_c) && !(!ROLL && d.r_is_f), src, mid);
-    }
+    wv::dma16_at<0, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[0], mid);
+    wv::dma16_at<1024, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[1], mid);
+    wv::dma16_at<2048, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[2], mid);
+    wv::dma16_at<3072>(d.r_ptr, mid);
     if (ROLL) {
         if (DIRECT) {
-            wv::dma16_at<0>(d.g_ptr - 1024 + tl * d.g_step, mid + (SG - SF));
+            wv::dma16_at<0>(d.g_ptr - 1024, mid + (SG - SF));
         } else {
-            wv::dma16_at<-1024>(d.g_ptr + tl * d.g_step, mid);
-            if (MODE != 0) wv::dma16_at<-2048>(d.g2_ptr + tl * d.g_step, mid);
+            wv::dma16_at<-1024>(d.g_ptr, mid);
+            if (MODE != 0) wv::dma16_at<-2048>(d.g2_ptr, mid);
         }
     }
 }
+
+// Step the pointers to the next stage of the pass (t-1 in the sweep, t+1 in a rollout).  move_f (wave-uniform):
+// the F / f index changes with it (it does not between stages T-1 and T-2).
+template <int MODE, bool ROLL, bool DIRECT>
+MPC_DEV void stage_move(Dma &d, bool move_f)
+{
+    const long fs = move_f ? d.f_step : 0;
+    const long rs = ROLL ? (move_f ? d.r_step : d.r_step_nof) : d.r_step;
+    if (!ROLL || DIRECT) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d.c_ptr[k] += ROLL ? d.c_step : -d.c_step;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.f_ptr[k] += ROLL ? fs : -fs;
+    d.r_ptr += ROLL ? rs : -rs;
+    if (ROLL) {
+        d.g_ptr += d.g_step;
+        if (MODE != 0 && !DIRECT) d.g2_ptr += d.g_step;
+    }
+}
+
+// counted wait in the tail of a pass: exactly `rem` (<= K) stages of ND instructions each are newer than the one needed
+template <int K, int ND> MPC_DEV void tail_wait(int rem)
+{
+    if (K == 0 || rem >= K) wv::dma_wait<K * ND>();
+    else tail_wait<(K > 0 ? K - 1 : 0), ND>(rem);
+}
+
+// The DMA of the stage LOOKAHEAD timesteps away, handed to the arithmetic of the current timestep in four parts of
+// two instructions each: issued in one burst of eight, the instructions queue up behind the CU's one texture-address
+// unit (shared by the four waves) and each stalls the wave ~27 clocks; spread between the blocks of arithmetic they
+// cost their issue slot.  `on` is wave-uniform (no stage left to fetch in the last timesteps of a pass).
+template <int MODE, bool ROLL, bool DIRECT> struct Feed {
+    Dma &d;
+    unsigned mid;
+    bool on;
+    bool move_f;
+    template <int K> MPC_DEVM void part()
+    {
+        if (!on) return;
+        enum { NC = (!ROLL || DIRECT) ? 4 : 0 };      // C instructions of a stage
+        if (ROLL && !DIRECT) {
+            // packed rollout stage: F0 F1 | F2 REC | G [G2] | moves
+            if (K == 0) {
+                wv::dma16_at<0, wv::DMA_LAST>(d.f_ptr[0], mid);
+                wv::dma16_at<1024, wv::DMA_LAST>(d.f_ptr[1], mid);
+            } else if (K == 1) {
+                wv::dma16_at<2048, wv::DMA_LAST>(d.f_ptr[2], mid);
+                wv::dma16_at<3072>(d.r_ptr, mid);
+            } else if (K == 2) {
+                wv::dma16_at<-1024>(d.g_ptr, mid);
+                if (MODE != 0) wv::dma16_at<-2048>(d.g2_ptr, mid);
+            } else {
+                stage_move<MODE, ROLL, DIRECT>(d, move_f);
+            }
+        } else {
+            if (K == 0) {
+                wv::dma16_at<-4096, wv::DMA_C>(d.c_ptr[0], mid);
+                wv::dma16_at<-3072, wv::DMA_C>(d.c_ptr[1], mid);
+            } else if (K == 1) {
+                wv::dma16_at<-2048, wv::DMA_C>(d.c_ptr[2], mid);
+                wv::dma16_at<-1024, wv::DMA_C>(d.c_ptr[3], mid);
+            } else if (K == 2) {
+                wv::dma16_at<0, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[0], mid);
+                wv::dma16_at<1024, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[1], mid);
+            } else {
+                wv::dma16_at<2048, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[2], mid);
+                wv::dma16_at<3072>(d.r_ptr, mid);
+                if (ROLL) wv::dma16_at<0>(d.g_ptr - 1024, mid + (SG - SF));
+                stage_move<MODE, ROLL, DIRECT>(d, move_f);
+            }
+        }
+    }
+};
 
 struct ZmRaw { unsigned m[4]; };        // the masks of the wave's four problems (uniform)
 MPC_DEV ZmRaw zm_fetch(const P &p, const Lane &L, int t)
@@ -353,12 +604,16 @@ struct SwState {
     int warm;
     int qp_total;
     int status;
+    float *rec;        // this lane's 16 bytes of the gain record of the current timestep (steps back by rec_step)
+    float *rec2;       // ... of the (m, M) record
+    long rec_step;
 };
 
 template <int MODE>
-MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st, int t)
+MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st, int t, Feed<MODE, false, false> &feed)
 {
     const bool last = (t == p.T - 1);
+    feed.template part<0>();
     // c_back = C tau + c (mpc/lqr_step.py:289-295) and the nominal stage cost (util.get_cost, :169)
     float cb = s.cj;
     wv::dot_bcast16(cb, s.tb, s.Cc);
@@ -376,10 +631,18 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         wv::sched_fence();
 #pragma unroll
         for (int m = 0; m < 12; ++m) outer_acc(Y, st.Vc[m], s.Fc[m]);
+        wv::sched_fence();
+        feed.template part<1>();
+        wv::sched_fence();
 #pragma unroll
         for (int m = 0; m < 12; ++m) outer_acc(Q, s.Fc[m], Y[m]);
-        wv::sched_fence();          // keep the 84 MFMAs one block: every MFMA <-> VALU turn costs ~7 clocks
+        wv::sched_fence();          // keep the MFMAs in blocks: every MFMA <-> VALU turn costs ~7 clocks
+        feed.template part<2>();
+        wv::sched_fence();
         wv::dot_bcast12(q, st.vv, s.Fc);
+    } else {
+        feed.template part<1>();
+        feed.template part<2>();
     }
 
     // ---- the 4x4 control block: row-uniform copies out of lanes 12..15 --------------------------
@@ -430,7 +693,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #pragma unroll
         for (int a = 0; a < 4; ++a) kq[a] = eclampf(kq[a], lb[a], ub[a]);
         bool conv = false;
-        const int it = mfma16::pnqp4<false>(S, qu, lb, ub, valid, p.pnqp_iter, kq, fr, f, conv);
+        const int it = pnqp4_rows(S, qu, lb, ub, p.pnqp_iter, kq, fr, f, conv);
         st.qp_total += 1 + it;                                      // :140
         if (!conv) st.status |= MPC_ST_PNQP_UNCONVERGED;
         st.warm = 1;
@@ -472,6 +735,8 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         M[2] = fmaf(S.s23, K[3], fmaf(S.s22, K[2], fmaf(S.s12, K[1], fmaf(S.s02, K[0], rhs[2]))));
         M[3] = fmaf(S.s33, K[3], fmaf(S.s23, K[2], fmaf(S.s13, K[1], fmaf(S.s03, K[0], rhs[3]))));
     }
+    wv::sched_fence();
+    feed.template part<3>();
     wv::sched_fence();              // the matrix-core block of the value update, undivided
 #pragma unroll
     for (int a = 0; a < 4; ++a) outer_acc(Vn, Q[12 + a], K[a]);      // += Qux[a][i] K[a][j]  (Qux = Qxu')
@@ -497,31 +762,36 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const float ka = wv::bcast<12>(K[a]);
-            const float ma = MODE != 0 ? wv::bcast<12>(M[a]) : 0.f;
-            w = fmaf(ka, 0.5f * (ma + qu[a]), w);
+            const float mq = MODE != 0 ? wv::bcast<12>(M[a]) + qu[a] : qu[a];
+            w = fmaf(ka, 0.5f * mq, w);
         }
         st.w0 += (double)w;
     }
 
-    // gains: the wave's own record Kk[t][b][j][4] = K[.][j] (j < 12), k (j = 12), Quu packed (j = 13..15);
-    // a second record (m, M) in the same layout when constraints are present;
-    // and K [T,B,4,12] / k [T,B,4] in the reference's layout when asked for
-    if (L.live) {
-        const long tb = (long)t * p.B + L.pb;
-        f32x4 rec = {K[0], K[1], K[2], K[3]};
-        if (L.j == 13) rec = f32x4{S.s00, S.s01, S.s02, S.s03};
-        if (L.j == 14) rec = f32x4{S.s11, S.s12, S.s13, S.s22};
-        if (L.j == 15) rec = f32x4{S.s23, S.s33, 0.f, 0.f};
-        wv::store_f32x4(p.Kk + tb * 64 + 4 * L.j, rec);
-        if (MODE != 0 && L.j <= 12)
-            wv::store_f32x4(p.Kk + ((long)p.T * p.B + tb) * 64 + 4 * L.j, f32x4{M[0], M[1], M[2], M[3]});
+    // gains: the wave's own record Kk[t][b][j][4] = K[.][j] (j < 12), k (j = 12), columns 1..3 of Quu (j = 13..15,
+    // Quu[0][0] in place of the redundant Quu[2][1], see lane_init); a second record (m, M) in the same layout when
+    // constraints are present; and K [T,B,4,12] / k [T,B,4] in the reference's layout when asked for.
+    // (Rows of a partial last wave repeat problem B-1: the same values to the same addresses.)
+    {
+        const bool quu = L.j >= 13;
+        f32x4 rec = {sel(quu, Q[12], K[0]), sel(quu, Q[13], K[1]), sel(quu, Q[14], K[2]), sel(quu, Q[15], K[3])};
+        rec[2] = sel(L.j == 13, S.s00, rec[2]);
+        wv::store_f32x4(st.rec, rec);
+        st.rec -= st.rec_step;
+        if (MODE != 0) {
+            wv::store_f32x4(st.rec2, f32x4{M[0], M[1], M[2], M[3]});       // lanes 13..15: never read
+            st.rec2 -= st.rec_step;
+        }
+#ifndef MPC_DPP16_PROF
         if (p.K != nullptr) {
+            const long tb = (long)t * p.B + L.pb;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 if (L.j < 12) p.K[(tb * 4 + a) * 12 + L.j] = K[a];
                 else if (j12) p.k[tb * 4 + a] = K[a];
             }
         }
+#endif
     }
 }
 
@@ -592,6 +862,7 @@ struct RoState {
     float alpha;      // line-search step of this row's problem
     float pred;       // F tau + f of the nominal at t-1: what the nominal x_t must equal
     float viol;       // > 0 once the nominal broke the dynamics somewhere
+    float *out;       // this lane's element of new_x / new_u at the current timestep
 };
 
 // new_u = K dx + u + alpha k (mpc/lqr_step.py:192), zero mask (:197-198), box / delta_u clamp (:200-213);
@@ -637,25 +908,31 @@ MPC_DEV float stage_price(const Lane &L, const RoStage &s, float tp, float e, fl
     return L.isu ? e * lin : 0.f;
 }
 
-template <int MODE, bool DIRECT>
-MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &st, int t)
+template <int MODE, bool DIRECT, bool CHECK>
+MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &st, int t, Feed<MODE, true, DIRECT> &feed)
 {
     const bool last = (t == p.T - 1);
+    feed.template part<0>();
     float e, dx;
     const float un = control_law<MODE>(p, L, s, st.xs, st.alpha, e, dx);
     const float tp = L.isu ? un : st.xs;                             // tau'_t[j]
+    feed.template part<1>();
     st.cost += stage_price<MODE, DIRECT>(L, s, tp, e, dx);
-    if (L.isu) {
-        const float d = s.tb - un;
-        st.du2 = fmaf(d, d, st.du2);
+    {
+        const float d = sel(L.isu, s.tb - un, 0.f);                  // (selects, not branches: lane-dependent
+        st.du2 = fmaf(d, d, st.du2);                                 //  branches cost exec-mask bookkeeping)
     }
-    if (L.live) wv::store_out(L.out0 + t * L.ostep, tp);        // new_u (control lanes) / new_x: one store
-    if (!DIRECT) {
-        // does the nominal obey x_t = F tau_{t-1} + f_{t-1}?  (the identity above assumes it)
-        if (t > 0 && !L.isu) {
-            const float r = fabsf(st.pred - s.tb) - 1e-5f * (1.f + fabsf(s.tb));
+    wv::store_out(st.out, tp);                                  // new_u (control lanes) / new_x: one store
+    st.out += L.ostep;
+    feed.template part<2>();
+    if (!DIRECT && CHECK) {
+        // does the nominal obey x_t = F tau_{t-1} + f_{t-1}?  (the identity above assumes it; CHECK is off when the
+        // caller vouches for it, MPC_OPT_NOMINAL_ON_DYNAMICS)
+        if (t > 0) {
+            float r = fabsf(st.pred - s.tb) - 1e-5f * (1.f + fabsf(s.tb));
+            r = (r == r) ? r : 1.f;
+            r = sel(L.isu, 0.f, r);
             st.viol = r > st.viol ? r : st.viol;
-            if (!(r == r)) st.viol = 1.f;
         }
         if (!last) {
             float pn = s.fj;
@@ -663,6 +940,7 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
             st.pred = pn;
         }
     }
+    feed.template part<3>();
     // x_{t+1} = F [x;u] + f  (:216-222)
     if (!last) {
         float xn = s.fj;
@@ -702,11 +980,14 @@ MPC_DEV void trials_step(const P &p, const Lane &L, const RoStage &s, Trials &tr
 // One pass over the horizon.  MULTI: the nt trials of tr (costs only); otherwise the single trial of st
 // (trajectory stored).  Costs come back as full trajectory costs (base = J_nominal + w_0 when priced by
 // the identity, 0 when priced directly).
-template <int MODE, bool MULTI, bool DIRECT>
-MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st, Trials &tr, int nt, float base)
+template <int MODE, bool MULTI, bool DIRECT, bool CHECK>
+MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, RoState &st, Trials &tr, int nt, float base PROF_ARG)
 {
     const int T = p.T;
-    const float x0 = L.isu ? 0.f : p.x_init[(long)L.pb * 12 + L.j];
+    float x0 = L.isu ? 0.f : p.x_init[(long)L.pb * 12 + L.j];
+    // have the load land HERE: a vector load still pending when the loop is entered makes the compiler drain the
+    // whole DMA queue (s_waitcnt vmcnt(0)) in front of its first use in every trip -- it cannot count across the loop
+    wv::pin(x0);
     if (MULTI) {
 #pragma unroll
         for (int k = 0; k < MAX_TRIALS; ++k) { tr.xs[k] = x0; tr.cost[k] = 0.f; }
@@ -715,6 +996,7 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st, 
         st.cost = 0.f;
         st.du2 = 0.f;
         st.pred = 0.f;
+        st.out = L.out0;
     }
     const bool use_zm = MODE != 0 && p.zero_mask != nullptr;
     enum { NS = RollRing<MODE, DIRECT>::SLOTS, LA = NS - 1, ND = RollDma<MODE, DIRECT>::N };
@@ -722,26 +1004,39 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st, 
     unsigned zq[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) zq[i] = 0u;
+    dma_seek<MODE, true, DIRECT>(d, p, L, wave);
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int ti = i < T ? i : T - 1;
-        stage_issue<MODE, true, DIRECT>(p, d, ti, i);
-        if (use_zm) zq[i] = zm_pick(L, zm_fetch(p, L, ti));
+        if (i < T) {
+            stage_issue<MODE, true, DIRECT>(d, stage_mid<MODE, true, DIRECT>(i));
+            stage_move<MODE, true, DIRECT>(d, i + 1 <= T - 2);
+            if (use_zm) zq[i] = zm_pick(L, zm_fetch(p, L, i));
+        }
     }
     for (int t0 = 0; t0 < T; t0 += NS) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const int t = t0 + i;
             if (t < T) {
-                wv::dma_wait<(LA - 1) * ND>();
+                // stages t+1 .. min(t + LA - 1, T - 1) are in flight behind the one needed now
+                PROF_MARK(7);
+                if (T - 1 - t >= LA - 1) wv::dma_wait<(LA - 1) * ND>();
+                else tail_wait<LA - 2, ND>(T - 1 - t);
+                PROF_MARK(4);
                 RoStage s;
                 ro_read<MODE, DIRECT>(s, p, L, t, i, zq[i]);
-                const int tn = t + LA < T ? t + LA : T - 1;
-                stage_issue<MODE, true, DIRECT>(p, d, tn, (i + LA) % NS);
+                PROF_MARK(5);
+                const int tn = t + LA;
                 ZmRaw zr = {{0u, 0u, 0u, 0u}};
-                if (use_zm) zr = zm_fetch(p, L, tn);
-                if (MULTI) trials_step<MODE, DIRECT>(p, L, s, tr, nt, t);
-                else rollout_step<MODE, DIRECT>(p, L, s, st, t);
+                if (use_zm && tn < T) zr = zm_fetch(p, L, tn);
+                Feed<MODE, true, DIRECT> feed = {d, stage_mid<MODE, true, DIRECT>((i + LA) % NS), tn < T, tn + 1 <= T - 2};
+                PROF_MARK(6);
+                if (MULTI) {
+                    feed.template part<0>(); feed.template part<1>(); feed.template part<2>(); feed.template part<3>();
+                    trials_step<MODE, DIRECT>(p, L, s, tr, nt, t);
+                } else {
+                    rollout_step<MODE, DIRECT, CHECK>(p, L, s, st, t, feed);
+                }
                 if (use_zm) zq[(i + LA) % NS] = zm_pick(L, zr);
             }
         }
@@ -762,15 +1057,15 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, const Dma &d, RoState &st, 
 // taken, else the last one.  Backtracking is usually one step deep (box-constrained problems) or runs to
 // the end (a nominal that is already optimal): alpha = 1, then alpha = decay on its own, then ALL
 // remaining trials in one pass and a replay of the accepted ones.
-template <int MODE, bool DIRECT>
-MPC_DEV void line_search(const P &p, const Lane &L, const Dma &d, RoState &rs, float old_cost, float base, float &full2)
+template <int MODE, bool DIRECT, bool CHECK>
+MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, RoState &rs, float old_cost, float base, float &full2 PROF_ARG)
 {
     Trials tr;
     rs.alpha = 1.f;
     bool worse0 = false;
 #pragma unroll 1
     for (int phase = 0; phase < 3; ++phase) {
-        rollout_pass<MODE, false, DIRECT>(p, L, d, rs, tr, 0, base);   // rows whose alpha did not change reproduce their result
+        rollout_pass<MODE, false, DIRECT, CHECK>(p, L, d, wave, rs, tr, 0, base PROF_PASS);   // rows whose alpha did not change reproduce their result
         if (phase == 0) {
             full2 = rs.du2;                                          // :243-245 (the alpha = 1 trial)
             worse0 = rs.cost > old_cost && p.max_ls > 1;
@@ -783,7 +1078,7 @@ MPC_DEV void line_search(const P &p, const Lane &L, const Dma &d, RoState &rs, f
             float a = p.ls_decay;
 #pragma unroll
             for (int k = 0; k < MAX_TRIALS; ++k) { a *= p.ls_decay; tr.alpha[k] = a; }
-            rollout_pass<MODE, true, DIRECT>(p, L, d, rs, tr, nt, base);
+            rollout_pass<MODE, true, DIRECT, CHECK>(p, L, d, wave, rs, tr, nt, base PROF_PASS);
             if (worse1) {
                 float acc = tr.alpha[0];
                 bool found = false;
@@ -804,6 +1099,8 @@ template <int MODE>
 MPC_DEV void step_wave(const P &p)
 {
     const int lane = wv::lane();
+    // (which problem group a workgroup -- hence an XCD: block b runs on XCD b % 8 -- takes makes no difference:
+    // four remappings measured within 0.5 %, profiles/r02_experiments.md)
     const int wave = wv::problem();          // one workgroup = one wave = four problems
     if (4 * wave >= p.B) return;
     Lane L;
@@ -812,7 +1109,7 @@ MPC_DEV void step_wave(const P &p)
     L.ostep = L.isu ? (long)p.B * 4 : (long)p.B * 12;
     const int T = p.T;
     Dma d;
-    dma_init<MODE>(d, p, L, wave);
+    PROF_DECL;
 
     // ---- Riccati sweep, t = T-1 .. 0 ------------------------------------------------------------
     SwState ss;
@@ -825,33 +1122,46 @@ MPC_DEV void step_wave(const P &p)
     ss.qp_total = 0;
     ss.status = 0;
     ss.kprev[0] = ss.kprev[1] = ss.kprev[2] = ss.kprev[3] = 0.f;
+    ss.rec_step = (long)p.B * 64;
+    ss.rec = p.Kk + ((long)(T - 1) * p.B + L.pb) * 64 + 4 * L.j;
+    ss.rec2 = ss.rec + (long)T * p.B * 64;
     {
         unsigned zq[NSTAGE] = {0u, 0u, 0u, 0u};
+        dma_seek<MODE, false, false>(d, p, L, wave);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int ti = T - 1 - i >= 0 ? T - 1 - i : 0;
-            stage_issue<MODE, false, false>(p, d, ti, i);
-            if (MODE == 1) zq[i] = zm_pick(L, zm_fetch(p, L, ti));
+            const int ti = T - 1 - i;
+            if (ti >= 0) {
+                stage_issue<MODE, false, false>(d, stage_mid<MODE, false, false>(i));
+                stage_move<MODE, false, false>(d, ti <= T - 2);           // on to stage ti - 1
+                if (MODE == 1) zq[i] = zm_pick(L, zm_fetch(p, L, ti));
+            }
         }
         for (int k0 = 0; k0 < T; k0 += NSTAGE) {
 #pragma unroll
             for (int i = 0; i < NSTAGE; ++i) {
                 const int t = T - 1 - (k0 + i);
                 if (t >= 0) {
-                    wv::dma_wait<2 * DMA_SWEEP>();
+                    // stages t-1 and t-2 (where they exist) are in flight behind the one needed now
+                    PROF_MARK(3);
+                    if (t >= 2) wv::dma_wait<2 * DMA_SWEEP>();
+                    else wv::dma_wait<0>();
+                    PROF_MARK(0);
                     SwStage s;
                     sw_read<MODE>(s, p, L, t, i, zq[i]);
-                    const int tn = t - 3 >= 0 ? t - 3 : 0;
-                    stage_issue<MODE, false, false>(p, d, tn, (i + 3) % NSTAGE);
+                    PROF_MARK(1);
                     ZmRaw zr = {{0u, 0u, 0u, 0u}};
-                    if (MODE == 1) zr = zm_fetch(p, L, tn);
-                    sweep_step<MODE>(p, L, s, ss, t);
+                    if (MODE == 1 && t >= 3) zr = zm_fetch(p, L, t - 3);
+                    Feed<MODE, false, false> feed = {d, stage_mid<MODE, false, false>((i + 3) % NSTAGE), t >= 3, true};
+                    PROF_MARK(2);
+                    sweep_step<MODE>(p, L, s, ss, t, feed);
                     if (MODE == 1) zq[(i + 3) % NSTAGE] = zm_pick(L, zr);
                 }
             }
         }
         wv::dma_wait<0>();
     }
+    PROF_MARK_ALL(8);           // slot 8: set-up + sweep tail; slots 0-3: wait / LDS reads / DMA issue / arithmetic of the sweep
     const double old_cost_d = wv::row_sum_f64(ss.oc);
     const float old_cost = (float)old_cost_d;
 
@@ -862,15 +1172,25 @@ MPC_DEV void step_wave(const P &p)
     RoState rs;
     rs.viol = 0.f;
     float full2 = 0.f;
-    line_search<MODE, false>(p, L, d, rs, old_cost, (float)(old_cost_d + ss.w0), full2);
-    // a nominal that does not obey the dynamics voids the identity the pass was priced with: price the
-    // rollout the reference's way, from a second stream of C
-    const bool broken = wv::row_sum(rs.viol > 0.f ? 1.f : 0.f) > 0.f;
-    if (wv::any(broken)) line_search<MODE, true>(p, L, d, rs, old_cost, 0.f, full2);
-    if (broken) ss.status |= MPC_ST_NOMINAL_OFF_DYNAMICS;
+    if (p.on_dynamics) {
+        // the caller vouches for the nominal (MPC_OPT_NOMINAL_ON_DYNAMICS): no verification in the loop
+        line_search<MODE, false, false>(p, L, d, wave, rs, old_cost, (float)(old_cost_d + ss.w0), full2 PROF_PASS);
+    } else {
+        line_search<MODE, false, true>(p, L, d, wave, rs, old_cost, (float)(old_cost_d + ss.w0), full2 PROF_PASS);
+        // a nominal that does not obey the dynamics voids the identity the pass was priced with: price the
+        // rollout the reference's way, from a second stream of C
+        const bool broken = wv::row_sum(rs.viol > 0.f ? 1.f : 0.f) > 0.f;
+        if (wv::any(broken)) line_search<MODE, true, false>(p, L, d, wave, rs, old_cost, 0.f, full2 PROF_PASS);
+        if (broken) ss.status |= MPC_ST_NOMINAL_OFF_DYNAMICS;
+    }
+#ifdef MPC_DPP16_PROF
+    PROF_MARK_ALL(9);           // slot 9: between the loops + rollout tail; slots 4-7: the same four phases of the rollout
+    if (p.K != nullptr && lane == 0)
+        for (int i_ = 0; i_ < 16; ++i_) p.K[(long)wave * 16 + i_] = (float)prof_.acc[i_];
+#endif
     int status = ss.status;
     if (!(rs.cost == rs.cost) || fabsf(rs.cost) > 3e38f) status |= MPC_ST_NONFINITE;
-    if (L.live && L.j == 0) {
+    if (L.j == 0) {
         const int b = L.pb;
         if (p.costs) p.costs[b] = rs.cost;
         if (p.old_costs) p.old_costs[b] = old_cost;

@@ -41,16 +41,16 @@ MPC_DEV void ldl4(Ldl4 &f, const Sym4 &s, const bool fr_[4], float reg)
     // the two masks -- lane masks live in SGPRs, their AND is a scalar instruction, and a VALU -> SALU -> VALU
     // dependency costs ~16 clocks more than VALU -> VALU (tools/ubench/valu_rate.hip: 8.7 against 4.7 clocks per
     // instruction of such a chain).  wv::pin keeps the compiler from merging the selects again.
-    const float a00 = fr[0] ? s.s00 + reg : 1.f;
+    const float a00 = fr[0] ? (reg != 0.f ? s.s00 + reg : s.s00) : 1.f;
     const float a10 = MASKED ? sel2(fr[0], fr[1], s.s01) : s.s01;
     const float a20 = MASKED ? sel2(fr[0], fr[2], s.s02) : s.s02;
     const float a30 = MASKED ? sel2(fr[0], fr[3], s.s03) : s.s03;
-    const float a11 = fr[1] ? s.s11 + reg : 1.f;
+    const float a11 = fr[1] ? (reg != 0.f ? s.s11 + reg : s.s11) : 1.f;
     const float a21 = MASKED ? sel2(fr[1], fr[2], s.s12) : s.s12;
     const float a31 = MASKED ? sel2(fr[1], fr[3], s.s13) : s.s13;
-    const float a22 = fr[2] ? s.s22 + reg : 1.f;
+    const float a22 = fr[2] ? (reg != 0.f ? s.s22 + reg : s.s22) : 1.f;
     const float a32 = MASKED ? sel2(fr[2], fr[3], s.s23) : s.s23;
-    const float a33 = fr[3] ? s.s33 + reg : 1.f;
+    const float a33 = fr[3] ? (reg != 0.f ? s.s33 + reg : s.s33) : 1.f;
     f.i0 = wv::rcp(a00);
     f.l10 = a10 * f.i0; f.l20 = a20 * f.i0; f.l30 = a30 * f.i0;
     const float d1 = fmaf(-f.l10, a10, a11);

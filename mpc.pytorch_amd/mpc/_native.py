@@ -41,11 +41,12 @@ class EnvDynamics(ctypes.Structure):
 class Options(ctypes.Structure):
     _fields_ = [("bound_mode", _i32), ("max_linesearch_iter", _i32), ("lo_s", _f64), ("hi_s", _f64),
                 ("lo", _vp), ("hi", _vp), ("zero_mask", _vp), ("delta_u", _f64),
-                ("linesearch_decay", _f64), ("pnqp_iter", _i32), ("_pad", _i32),
+                ("linesearch_decay", _f64), ("pnqp_iter", _i32), ("flags", _i32),
                 ("true_dynamics", ctypes.POINTER(EnvDynamics))]
 
 
 ENV_PENDULUM, ENV_PENDULUM_FULL, ENV_CARTPOLE = 1, 2, 3
+OPT_NOMINAL_ON_DYNAMICS = 1          # mpc_lqr_options.flags
 
 
 class EnvSpec:
@@ -180,8 +181,10 @@ class StepOptions:
     """The LQRStep keyword arguments that reach the kernels (mpc/lqr_step.py:22-38 of the reference)."""
 
     def __init__(self, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None, linesearch_decay=0.2,
-                 max_linesearch_iter=10, pnqp_iter=20, true_dynamics=None):
+                 max_linesearch_iter=10, pnqp_iter=20, true_dynamics=None, nominal_on_dynamics=False):
         assert (u_lower is None) == (u_upper is None)
+        # the caller guarantees cur_x = rollout of cur_u through (F, f): MPC.forward's nominal always is (mpc/mpc.py:251)
+        self.nominal_on_dynamics = bool(nominal_on_dynamics)
         self.u_lower, self.u_upper, self.u_zero_I = u_lower, u_upper, u_zero_I
         self.true_dynamics = true_dynamics      # EnvSpec: the rollout calls the simulator, not F,f
         self.delta_u, self.linesearch_decay = delta_u, linesearch_decay
@@ -195,6 +198,7 @@ class StepOptions:
         o.linesearch_decay = float(self.linesearch_decay)
         o.delta_u = float("nan") if self.delta_u is None else float(self.delta_u)
         o.pnqp_iter = int(self.pnqp_iter)
+        o.flags = OPT_NOMINAL_ON_DYNAMICS if self.nominal_on_dynamics else 0
         lo, hi = self.u_lower, self.u_upper
         if lo is None:
             o.bound_mode = BOUND_NONE

@@ -255,6 +255,8 @@ class MPC(Module):
         else:
             xa = util.get_traj(T, ua, x_init=xi, dynamics=dx).contiguous()
             F, f = dx.F, dx.f
+            # every nominal of this loop obeys (F, f) by construction: get_traj above, then each step's own rollout
+            opts.nominal_on_dynamics = True
         xb, ub = torch.empty_like(xa), torch.empty_like(ua)
         pa = be.plan_step(xi, cost.C, cost.c, F, f, xa, ua, opts, out_x=xb, out_u=ub)
         pb = be.plan_step(xi, cost.C, cost.c, F, f, xb, ub, opts, out_x=xa, out_u=ua,

@@ -34,7 +34,8 @@ def shard_options(opts, lo, hi):
                                u_zero_I=_cut(opts.u_zero_I, lo, hi, 1), delta_u=opts.delta_u,
                                linesearch_decay=opts.linesearch_decay,
                                max_linesearch_iter=opts.max_linesearch_iter, pnqp_iter=opts.pnqp_iter,
-                               true_dynamics=opts.true_dynamics)     # a simulator EnvSpec has no batch axis
+                               true_dynamics=opts.true_dynamics,     # a simulator EnvSpec has no batch axis
+                               nominal_on_dynamics=opts.nominal_on_dynamics)
 
 
 def all_gather_batch(t, n_batch, dim, group=None):

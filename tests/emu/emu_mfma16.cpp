@@ -18,6 +18,10 @@
 
 #define MPC_EMULATE 1
 #define MPC_DEV static inline
+#define MPC_DEVM inline
+// statistics of the row-wise pnqp (lane 0 of each 16-lane row counts): trips, factorisations, Armijo entries ...
+extern "C" { long emu_stats[16]; }
+#define MPC_STAT(i) do { if ((mpclqr::wv::lane() & 15) == 0) ++emu_stats[i]; } while (0)
 
 namespace emu {
 enum { NL = 64, STACK = 256 * 1024 };

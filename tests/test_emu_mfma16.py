@@ -187,6 +187,11 @@ def test_emulated_dpp16_options_against_oracle(emu, case):
         assert len(set(np.round(o["alphas"], 6))) > 1, "rows of one wave must stop at different alphas"
     r = emu.lqr_step(kernel="dpp16", dma_late=True, **kw)
     assert (r["status"] & 4 == 0).all()
+    # MPC_OPT_NOMINAL_ON_DYNAMICS: with the caller vouching for the nominal the in-loop verification is compiled out;
+    # the results are the same numbers
+    rv = emu.lqr_step(kernel="dpp16", dma_late=True, nominal_on_dynamics=True, **kw)
+    for k in ("new_x", "new_u", "costs", "alphas", "full_du_norm"):
+        np.testing.assert_array_equal(rv[k], r[k])
     np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
     np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=2e-4)

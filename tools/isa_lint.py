@@ -77,7 +77,7 @@ def main():
                 continue
             if "scratch_" in l and not l.strip().startswith(";"):
                 per[ks[-1]][0] += 1
-            if "s_waitcnt vmcnt(0)" in l:
+            if "s_waitcnt vmcnt(0)" in l and "; counted" not in l:      # hand-written tail waits carry the marker
                 inner = sorted(b - a for a, b in loops if a <= i <= b)
                 if inner and inner[0] < 3000:
                     per[ks[-1]][1] += 1
