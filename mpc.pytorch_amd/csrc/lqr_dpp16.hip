@@ -123,6 +123,167 @@ MPC_DEV float row_sum(float x)
     return x;
 }
 
+// Four row sums in one go: lane j of a row comes back with sum over the row's 16 lanes of p_a, a = j & 3.
+// Two exchanges inside the quads (each lane keeps the addend of "its" a and hands over the other), then the four quads
+// of the row are added with two rotations: 6 selects + 5 DPP adds (four separate row_sum calls: 16 DPP adds).
+MPC_DEV float quad_sums(float p0, float p1, float p2, float p3, int j)
+{
+    const bool o1 = (j & 1) != 0, o2 = (j & 2) != 0;
+    const float t0 = o1 ? p1 : p0, t1 = o1 ? p0 : p1, t2 = o1 ? p3 : p2, t3 = o1 ? p2 : p3;
+    const float r01 = t0 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t1), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    const float r23 = t2 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t3), 0xB1, 0xf, 0xf, true));
+    const float u0 = o2 ? r23 : r01, u1 = o2 ? r01 : r23;
+    float r = u0 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u1), 0x4E, 0xf, 0xf, true));            // quad_perm [2,3,0,1]
+    r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x124, 0xf, 0xf, true));                      // row_ror:4
+    r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x128, 0xf, 0xf, true));                      // row_ror:8
+    return r;
+}
+
+// ---- the gains of the whole horizon in the accumulation half of the register file (mode 0) ----------------------
+// a[4t .. 4t+3] = the four gain registers of timestep t.  The compiler never allocates AccVGPRs in this kernel (its
+// MFMAs accumulate in VGPRs, -amdgpu-mfma-vgpr-form, and it stays under 256 VGPRs -- tests/test_isa_lint.py checks
+// that nothing else touches a[...]); the clobber lists put the registers into the kernel's allocation.
+MPC_DEV void rg_put(int t, f32x4 v)
+{
+    switch (t) {
+        case 0: asm volatile("v_accvgpr_write_b32 a0, %0\n v_accvgpr_write_b32 a1, %1\n v_accvgpr_write_b32 a2, %2\n v_accvgpr_write_b32 a3, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a0", "a1", "a2", "a3"); break;
+        case 1: asm volatile("v_accvgpr_write_b32 a4, %0\n v_accvgpr_write_b32 a5, %1\n v_accvgpr_write_b32 a6, %2\n v_accvgpr_write_b32 a7, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a4", "a5", "a6", "a7"); break;
+        case 2: asm volatile("v_accvgpr_write_b32 a8, %0\n v_accvgpr_write_b32 a9, %1\n v_accvgpr_write_b32 a10, %2\n v_accvgpr_write_b32 a11, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a8", "a9", "a10", "a11"); break;
+        case 3: asm volatile("v_accvgpr_write_b32 a12, %0\n v_accvgpr_write_b32 a13, %1\n v_accvgpr_write_b32 a14, %2\n v_accvgpr_write_b32 a15, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a12", "a13", "a14", "a15"); break;
+        case 4: asm volatile("v_accvgpr_write_b32 a16, %0\n v_accvgpr_write_b32 a17, %1\n v_accvgpr_write_b32 a18, %2\n v_accvgpr_write_b32 a19, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a16", "a17", "a18", "a19"); break;
+        case 5: asm volatile("v_accvgpr_write_b32 a20, %0\n v_accvgpr_write_b32 a21, %1\n v_accvgpr_write_b32 a22, %2\n v_accvgpr_write_b32 a23, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a20", "a21", "a22", "a23"); break;
+        case 6: asm volatile("v_accvgpr_write_b32 a24, %0\n v_accvgpr_write_b32 a25, %1\n v_accvgpr_write_b32 a26, %2\n v_accvgpr_write_b32 a27, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a24", "a25", "a26", "a27"); break;
+        case 7: asm volatile("v_accvgpr_write_b32 a28, %0\n v_accvgpr_write_b32 a29, %1\n v_accvgpr_write_b32 a30, %2\n v_accvgpr_write_b32 a31, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a28", "a29", "a30", "a31"); break;
+        case 8: asm volatile("v_accvgpr_write_b32 a32, %0\n v_accvgpr_write_b32 a33, %1\n v_accvgpr_write_b32 a34, %2\n v_accvgpr_write_b32 a35, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a32", "a33", "a34", "a35"); break;
+        case 9: asm volatile("v_accvgpr_write_b32 a36, %0\n v_accvgpr_write_b32 a37, %1\n v_accvgpr_write_b32 a38, %2\n v_accvgpr_write_b32 a39, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a36", "a37", "a38", "a39"); break;
+        case 10: asm volatile("v_accvgpr_write_b32 a40, %0\n v_accvgpr_write_b32 a41, %1\n v_accvgpr_write_b32 a42, %2\n v_accvgpr_write_b32 a43, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a40", "a41", "a42", "a43"); break;
+        case 11: asm volatile("v_accvgpr_write_b32 a44, %0\n v_accvgpr_write_b32 a45, %1\n v_accvgpr_write_b32 a46, %2\n v_accvgpr_write_b32 a47, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a44", "a45", "a46", "a47"); break;
+        case 12: asm volatile("v_accvgpr_write_b32 a48, %0\n v_accvgpr_write_b32 a49, %1\n v_accvgpr_write_b32 a50, %2\n v_accvgpr_write_b32 a51, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a48", "a49", "a50", "a51"); break;
+        case 13: asm volatile("v_accvgpr_write_b32 a52, %0\n v_accvgpr_write_b32 a53, %1\n v_accvgpr_write_b32 a54, %2\n v_accvgpr_write_b32 a55, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a52", "a53", "a54", "a55"); break;
+        case 14: asm volatile("v_accvgpr_write_b32 a56, %0\n v_accvgpr_write_b32 a57, %1\n v_accvgpr_write_b32 a58, %2\n v_accvgpr_write_b32 a59, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a56", "a57", "a58", "a59"); break;
+        case 15: asm volatile("v_accvgpr_write_b32 a60, %0\n v_accvgpr_write_b32 a61, %1\n v_accvgpr_write_b32 a62, %2\n v_accvgpr_write_b32 a63, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a60", "a61", "a62", "a63"); break;
+        case 16: asm volatile("v_accvgpr_write_b32 a64, %0\n v_accvgpr_write_b32 a65, %1\n v_accvgpr_write_b32 a66, %2\n v_accvgpr_write_b32 a67, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a64", "a65", "a66", "a67"); break;
+        case 17: asm volatile("v_accvgpr_write_b32 a68, %0\n v_accvgpr_write_b32 a69, %1\n v_accvgpr_write_b32 a70, %2\n v_accvgpr_write_b32 a71, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a68", "a69", "a70", "a71"); break;
+        case 18: asm volatile("v_accvgpr_write_b32 a72, %0\n v_accvgpr_write_b32 a73, %1\n v_accvgpr_write_b32 a74, %2\n v_accvgpr_write_b32 a75, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a72", "a73", "a74", "a75"); break;
+        case 19: asm volatile("v_accvgpr_write_b32 a76, %0\n v_accvgpr_write_b32 a77, %1\n v_accvgpr_write_b32 a78, %2\n v_accvgpr_write_b32 a79, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a76", "a77", "a78", "a79"); break;
+        case 20: asm volatile("v_accvgpr_write_b32 a80, %0\n v_accvgpr_write_b32 a81, %1\n v_accvgpr_write_b32 a82, %2\n v_accvgpr_write_b32 a83, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a80", "a81", "a82", "a83"); break;
+        case 21: asm volatile("v_accvgpr_write_b32 a84, %0\n v_accvgpr_write_b32 a85, %1\n v_accvgpr_write_b32 a86, %2\n v_accvgpr_write_b32 a87, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a84", "a85", "a86", "a87"); break;
+        case 22: asm volatile("v_accvgpr_write_b32 a88, %0\n v_accvgpr_write_b32 a89, %1\n v_accvgpr_write_b32 a90, %2\n v_accvgpr_write_b32 a91, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a88", "a89", "a90", "a91"); break;
+        case 23: asm volatile("v_accvgpr_write_b32 a92, %0\n v_accvgpr_write_b32 a93, %1\n v_accvgpr_write_b32 a94, %2\n v_accvgpr_write_b32 a95, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a92", "a93", "a94", "a95"); break;
+        case 24: asm volatile("v_accvgpr_write_b32 a96, %0\n v_accvgpr_write_b32 a97, %1\n v_accvgpr_write_b32 a98, %2\n v_accvgpr_write_b32 a99, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a96", "a97", "a98", "a99"); break;
+        case 25: asm volatile("v_accvgpr_write_b32 a100, %0\n v_accvgpr_write_b32 a101, %1\n v_accvgpr_write_b32 a102, %2\n v_accvgpr_write_b32 a103, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a100", "a101", "a102", "a103"); break;
+        case 26: asm volatile("v_accvgpr_write_b32 a104, %0\n v_accvgpr_write_b32 a105, %1\n v_accvgpr_write_b32 a106, %2\n v_accvgpr_write_b32 a107, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a104", "a105", "a106", "a107"); break;
+        case 27: asm volatile("v_accvgpr_write_b32 a108, %0\n v_accvgpr_write_b32 a109, %1\n v_accvgpr_write_b32 a110, %2\n v_accvgpr_write_b32 a111, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a108", "a109", "a110", "a111"); break;
+        case 28: asm volatile("v_accvgpr_write_b32 a112, %0\n v_accvgpr_write_b32 a113, %1\n v_accvgpr_write_b32 a114, %2\n v_accvgpr_write_b32 a115, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a112", "a113", "a114", "a115"); break;
+        case 29: asm volatile("v_accvgpr_write_b32 a116, %0\n v_accvgpr_write_b32 a117, %1\n v_accvgpr_write_b32 a118, %2\n v_accvgpr_write_b32 a119, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a116", "a117", "a118", "a119"); break;
+        case 30: asm volatile("v_accvgpr_write_b32 a120, %0\n v_accvgpr_write_b32 a121, %1\n v_accvgpr_write_b32 a122, %2\n v_accvgpr_write_b32 a123, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a120", "a121", "a122", "a123"); break;
+        case 31: asm volatile("v_accvgpr_write_b32 a124, %0\n v_accvgpr_write_b32 a125, %1\n v_accvgpr_write_b32 a126, %2\n v_accvgpr_write_b32 a127, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a124", "a125", "a126", "a127"); break;
+        case 32: asm volatile("v_accvgpr_write_b32 a128, %0\n v_accvgpr_write_b32 a129, %1\n v_accvgpr_write_b32 a130, %2\n v_accvgpr_write_b32 a131, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a128", "a129", "a130", "a131"); break;
+        case 33: asm volatile("v_accvgpr_write_b32 a132, %0\n v_accvgpr_write_b32 a133, %1\n v_accvgpr_write_b32 a134, %2\n v_accvgpr_write_b32 a135, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a132", "a133", "a134", "a135"); break;
+        case 34: asm volatile("v_accvgpr_write_b32 a136, %0\n v_accvgpr_write_b32 a137, %1\n v_accvgpr_write_b32 a138, %2\n v_accvgpr_write_b32 a139, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a136", "a137", "a138", "a139"); break;
+        case 35: asm volatile("v_accvgpr_write_b32 a140, %0\n v_accvgpr_write_b32 a141, %1\n v_accvgpr_write_b32 a142, %2\n v_accvgpr_write_b32 a143, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a140", "a141", "a142", "a143"); break;
+        case 36: asm volatile("v_accvgpr_write_b32 a144, %0\n v_accvgpr_write_b32 a145, %1\n v_accvgpr_write_b32 a146, %2\n v_accvgpr_write_b32 a147, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a144", "a145", "a146", "a147"); break;
+        case 37: asm volatile("v_accvgpr_write_b32 a148, %0\n v_accvgpr_write_b32 a149, %1\n v_accvgpr_write_b32 a150, %2\n v_accvgpr_write_b32 a151, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a148", "a149", "a150", "a151"); break;
+        case 38: asm volatile("v_accvgpr_write_b32 a152, %0\n v_accvgpr_write_b32 a153, %1\n v_accvgpr_write_b32 a154, %2\n v_accvgpr_write_b32 a155, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a152", "a153", "a154", "a155"); break;
+        case 39: asm volatile("v_accvgpr_write_b32 a156, %0\n v_accvgpr_write_b32 a157, %1\n v_accvgpr_write_b32 a158, %2\n v_accvgpr_write_b32 a159, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a156", "a157", "a158", "a159"); break;
+        case 40: asm volatile("v_accvgpr_write_b32 a160, %0\n v_accvgpr_write_b32 a161, %1\n v_accvgpr_write_b32 a162, %2\n v_accvgpr_write_b32 a163, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a160", "a161", "a162", "a163"); break;
+        case 41: asm volatile("v_accvgpr_write_b32 a164, %0\n v_accvgpr_write_b32 a165, %1\n v_accvgpr_write_b32 a166, %2\n v_accvgpr_write_b32 a167, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a164", "a165", "a166", "a167"); break;
+        case 42: asm volatile("v_accvgpr_write_b32 a168, %0\n v_accvgpr_write_b32 a169, %1\n v_accvgpr_write_b32 a170, %2\n v_accvgpr_write_b32 a171, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a168", "a169", "a170", "a171"); break;
+        case 43: asm volatile("v_accvgpr_write_b32 a172, %0\n v_accvgpr_write_b32 a173, %1\n v_accvgpr_write_b32 a174, %2\n v_accvgpr_write_b32 a175, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a172", "a173", "a174", "a175"); break;
+        case 44: asm volatile("v_accvgpr_write_b32 a176, %0\n v_accvgpr_write_b32 a177, %1\n v_accvgpr_write_b32 a178, %2\n v_accvgpr_write_b32 a179, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a176", "a177", "a178", "a179"); break;
+        case 45: asm volatile("v_accvgpr_write_b32 a180, %0\n v_accvgpr_write_b32 a181, %1\n v_accvgpr_write_b32 a182, %2\n v_accvgpr_write_b32 a183, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a180", "a181", "a182", "a183"); break;
+        case 46: asm volatile("v_accvgpr_write_b32 a184, %0\n v_accvgpr_write_b32 a185, %1\n v_accvgpr_write_b32 a186, %2\n v_accvgpr_write_b32 a187, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a184", "a185", "a186", "a187"); break;
+        case 47: asm volatile("v_accvgpr_write_b32 a188, %0\n v_accvgpr_write_b32 a189, %1\n v_accvgpr_write_b32 a190, %2\n v_accvgpr_write_b32 a191, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a188", "a189", "a190", "a191"); break;
+        case 48: asm volatile("v_accvgpr_write_b32 a192, %0\n v_accvgpr_write_b32 a193, %1\n v_accvgpr_write_b32 a194, %2\n v_accvgpr_write_b32 a195, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a192", "a193", "a194", "a195"); break;
+        case 49: asm volatile("v_accvgpr_write_b32 a196, %0\n v_accvgpr_write_b32 a197, %1\n v_accvgpr_write_b32 a198, %2\n v_accvgpr_write_b32 a199, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a196", "a197", "a198", "a199"); break;
+        case 50: asm volatile("v_accvgpr_write_b32 a200, %0\n v_accvgpr_write_b32 a201, %1\n v_accvgpr_write_b32 a202, %2\n v_accvgpr_write_b32 a203, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a200", "a201", "a202", "a203"); break;
+        case 51: asm volatile("v_accvgpr_write_b32 a204, %0\n v_accvgpr_write_b32 a205, %1\n v_accvgpr_write_b32 a206, %2\n v_accvgpr_write_b32 a207, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a204", "a205", "a206", "a207"); break;
+        case 52: asm volatile("v_accvgpr_write_b32 a208, %0\n v_accvgpr_write_b32 a209, %1\n v_accvgpr_write_b32 a210, %2\n v_accvgpr_write_b32 a211, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a208", "a209", "a210", "a211"); break;
+        case 53: asm volatile("v_accvgpr_write_b32 a212, %0\n v_accvgpr_write_b32 a213, %1\n v_accvgpr_write_b32 a214, %2\n v_accvgpr_write_b32 a215, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a212", "a213", "a214", "a215"); break;
+        case 54: asm volatile("v_accvgpr_write_b32 a216, %0\n v_accvgpr_write_b32 a217, %1\n v_accvgpr_write_b32 a218, %2\n v_accvgpr_write_b32 a219, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a216", "a217", "a218", "a219"); break;
+        case 55: asm volatile("v_accvgpr_write_b32 a220, %0\n v_accvgpr_write_b32 a221, %1\n v_accvgpr_write_b32 a222, %2\n v_accvgpr_write_b32 a223, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a220", "a221", "a222", "a223"); break;
+        case 56: asm volatile("v_accvgpr_write_b32 a224, %0\n v_accvgpr_write_b32 a225, %1\n v_accvgpr_write_b32 a226, %2\n v_accvgpr_write_b32 a227, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a224", "a225", "a226", "a227"); break;
+        case 57: asm volatile("v_accvgpr_write_b32 a228, %0\n v_accvgpr_write_b32 a229, %1\n v_accvgpr_write_b32 a230, %2\n v_accvgpr_write_b32 a231, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a228", "a229", "a230", "a231"); break;
+        case 58: asm volatile("v_accvgpr_write_b32 a232, %0\n v_accvgpr_write_b32 a233, %1\n v_accvgpr_write_b32 a234, %2\n v_accvgpr_write_b32 a235, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a232", "a233", "a234", "a235"); break;
+        case 59: asm volatile("v_accvgpr_write_b32 a236, %0\n v_accvgpr_write_b32 a237, %1\n v_accvgpr_write_b32 a238, %2\n v_accvgpr_write_b32 a239, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a236", "a237", "a238", "a239"); break;
+        case 60: asm volatile("v_accvgpr_write_b32 a240, %0\n v_accvgpr_write_b32 a241, %1\n v_accvgpr_write_b32 a242, %2\n v_accvgpr_write_b32 a243, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a240", "a241", "a242", "a243"); break;
+        case 61: asm volatile("v_accvgpr_write_b32 a244, %0\n v_accvgpr_write_b32 a245, %1\n v_accvgpr_write_b32 a246, %2\n v_accvgpr_write_b32 a247, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a244", "a245", "a246", "a247"); break;
+        case 62: asm volatile("v_accvgpr_write_b32 a248, %0\n v_accvgpr_write_b32 a249, %1\n v_accvgpr_write_b32 a250, %2\n v_accvgpr_write_b32 a251, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a248", "a249", "a250", "a251"); break;
+        case 63: asm volatile("v_accvgpr_write_b32 a252, %0\n v_accvgpr_write_b32 a253, %1\n v_accvgpr_write_b32 a254, %2\n v_accvgpr_write_b32 a255, %3" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "a252", "a253", "a254", "a255"); break;
+    }
+}
+MPC_DEV f32x4 rg_get(int t)
+{
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+    switch (t) {
+        case 0: asm volatile("v_accvgpr_read_b32 %0, a0\n v_accvgpr_read_b32 %1, a1\n v_accvgpr_read_b32 %2, a2\n v_accvgpr_read_b32 %3, a3" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 1: asm volatile("v_accvgpr_read_b32 %0, a4\n v_accvgpr_read_b32 %1, a5\n v_accvgpr_read_b32 %2, a6\n v_accvgpr_read_b32 %3, a7" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 2: asm volatile("v_accvgpr_read_b32 %0, a8\n v_accvgpr_read_b32 %1, a9\n v_accvgpr_read_b32 %2, a10\n v_accvgpr_read_b32 %3, a11" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 3: asm volatile("v_accvgpr_read_b32 %0, a12\n v_accvgpr_read_b32 %1, a13\n v_accvgpr_read_b32 %2, a14\n v_accvgpr_read_b32 %3, a15" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 4: asm volatile("v_accvgpr_read_b32 %0, a16\n v_accvgpr_read_b32 %1, a17\n v_accvgpr_read_b32 %2, a18\n v_accvgpr_read_b32 %3, a19" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 5: asm volatile("v_accvgpr_read_b32 %0, a20\n v_accvgpr_read_b32 %1, a21\n v_accvgpr_read_b32 %2, a22\n v_accvgpr_read_b32 %3, a23" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 6: asm volatile("v_accvgpr_read_b32 %0, a24\n v_accvgpr_read_b32 %1, a25\n v_accvgpr_read_b32 %2, a26\n v_accvgpr_read_b32 %3, a27" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 7: asm volatile("v_accvgpr_read_b32 %0, a28\n v_accvgpr_read_b32 %1, a29\n v_accvgpr_read_b32 %2, a30\n v_accvgpr_read_b32 %3, a31" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 8: asm volatile("v_accvgpr_read_b32 %0, a32\n v_accvgpr_read_b32 %1, a33\n v_accvgpr_read_b32 %2, a34\n v_accvgpr_read_b32 %3, a35" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 9: asm volatile("v_accvgpr_read_b32 %0, a36\n v_accvgpr_read_b32 %1, a37\n v_accvgpr_read_b32 %2, a38\n v_accvgpr_read_b32 %3, a39" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 10: asm volatile("v_accvgpr_read_b32 %0, a40\n v_accvgpr_read_b32 %1, a41\n v_accvgpr_read_b32 %2, a42\n v_accvgpr_read_b32 %3, a43" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 11: asm volatile("v_accvgpr_read_b32 %0, a44\n v_accvgpr_read_b32 %1, a45\n v_accvgpr_read_b32 %2, a46\n v_accvgpr_read_b32 %3, a47" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 12: asm volatile("v_accvgpr_read_b32 %0, a48\n v_accvgpr_read_b32 %1, a49\n v_accvgpr_read_b32 %2, a50\n v_accvgpr_read_b32 %3, a51" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 13: asm volatile("v_accvgpr_read_b32 %0, a52\n v_accvgpr_read_b32 %1, a53\n v_accvgpr_read_b32 %2, a54\n v_accvgpr_read_b32 %3, a55" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 14: asm volatile("v_accvgpr_read_b32 %0, a56\n v_accvgpr_read_b32 %1, a57\n v_accvgpr_read_b32 %2, a58\n v_accvgpr_read_b32 %3, a59" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 15: asm volatile("v_accvgpr_read_b32 %0, a60\n v_accvgpr_read_b32 %1, a61\n v_accvgpr_read_b32 %2, a62\n v_accvgpr_read_b32 %3, a63" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 16: asm volatile("v_accvgpr_read_b32 %0, a64\n v_accvgpr_read_b32 %1, a65\n v_accvgpr_read_b32 %2, a66\n v_accvgpr_read_b32 %3, a67" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 17: asm volatile("v_accvgpr_read_b32 %0, a68\n v_accvgpr_read_b32 %1, a69\n v_accvgpr_read_b32 %2, a70\n v_accvgpr_read_b32 %3, a71" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 18: asm volatile("v_accvgpr_read_b32 %0, a72\n v_accvgpr_read_b32 %1, a73\n v_accvgpr_read_b32 %2, a74\n v_accvgpr_read_b32 %3, a75" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 19: asm volatile("v_accvgpr_read_b32 %0, a76\n v_accvgpr_read_b32 %1, a77\n v_accvgpr_read_b32 %2, a78\n v_accvgpr_read_b32 %3, a79" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 20: asm volatile("v_accvgpr_read_b32 %0, a80\n v_accvgpr_read_b32 %1, a81\n v_accvgpr_read_b32 %2, a82\n v_accvgpr_read_b32 %3, a83" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 21: asm volatile("v_accvgpr_read_b32 %0, a84\n v_accvgpr_read_b32 %1, a85\n v_accvgpr_read_b32 %2, a86\n v_accvgpr_read_b32 %3, a87" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 22: asm volatile("v_accvgpr_read_b32 %0, a88\n v_accvgpr_read_b32 %1, a89\n v_accvgpr_read_b32 %2, a90\n v_accvgpr_read_b32 %3, a91" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 23: asm volatile("v_accvgpr_read_b32 %0, a92\n v_accvgpr_read_b32 %1, a93\n v_accvgpr_read_b32 %2, a94\n v_accvgpr_read_b32 %3, a95" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 24: asm volatile("v_accvgpr_read_b32 %0, a96\n v_accvgpr_read_b32 %1, a97\n v_accvgpr_read_b32 %2, a98\n v_accvgpr_read_b32 %3, a99" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 25: asm volatile("v_accvgpr_read_b32 %0, a100\n v_accvgpr_read_b32 %1, a101\n v_accvgpr_read_b32 %2, a102\n v_accvgpr_read_b32 %3, a103" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 26: asm volatile("v_accvgpr_read_b32 %0, a104\n v_accvgpr_read_b32 %1, a105\n v_accvgpr_read_b32 %2, a106\n v_accvgpr_read_b32 %3, a107" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 27: asm volatile("v_accvgpr_read_b32 %0, a108\n v_accvgpr_read_b32 %1, a109\n v_accvgpr_read_b32 %2, a110\n v_accvgpr_read_b32 %3, a111" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 28: asm volatile("v_accvgpr_read_b32 %0, a112\n v_accvgpr_read_b32 %1, a113\n v_accvgpr_read_b32 %2, a114\n v_accvgpr_read_b32 %3, a115" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 29: asm volatile("v_accvgpr_read_b32 %0, a116\n v_accvgpr_read_b32 %1, a117\n v_accvgpr_read_b32 %2, a118\n v_accvgpr_read_b32 %3, a119" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 30: asm volatile("v_accvgpr_read_b32 %0, a120\n v_accvgpr_read_b32 %1, a121\n v_accvgpr_read_b32 %2, a122\n v_accvgpr_read_b32 %3, a123" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 31: asm volatile("v_accvgpr_read_b32 %0, a124\n v_accvgpr_read_b32 %1, a125\n v_accvgpr_read_b32 %2, a126\n v_accvgpr_read_b32 %3, a127" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 32: asm volatile("v_accvgpr_read_b32 %0, a128\n v_accvgpr_read_b32 %1, a129\n v_accvgpr_read_b32 %2, a130\n v_accvgpr_read_b32 %3, a131" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 33: asm volatile("v_accvgpr_read_b32 %0, a132\n v_accvgpr_read_b32 %1, a133\n v_accvgpr_read_b32 %2, a134\n v_accvgpr_read_b32 %3, a135" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 34: asm volatile("v_accvgpr_read_b32 %0, a136\n v_accvgpr_read_b32 %1, a137\n v_accvgpr_read_b32 %2, a138\n v_accvgpr_read_b32 %3, a139" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 35: asm volatile("v_accvgpr_read_b32 %0, a140\n v_accvgpr_read_b32 %1, a141\n v_accvgpr_read_b32 %2, a142\n v_accvgpr_read_b32 %3, a143" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 36: asm volatile("v_accvgpr_read_b32 %0, a144\n v_accvgpr_read_b32 %1, a145\n v_accvgpr_read_b32 %2, a146\n v_accvgpr_read_b32 %3, a147" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 37: asm volatile("v_accvgpr_read_b32 %0, a148\n v_accvgpr_read_b32 %1, a149\n v_accvgpr_read_b32 %2, a150\n v_accvgpr_read_b32 %3, a151" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 38: asm volatile("v_accvgpr_read_b32 %0, a152\n v_accvgpr_read_b32 %1, a153\n v_accvgpr_read_b32 %2, a154\n v_accvgpr_read_b32 %3, a155" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 39: asm volatile("v_accvgpr_read_b32 %0, a156\n v_accvgpr_read_b32 %1, a157\n v_accvgpr_read_b32 %2, a158\n v_accvgpr_read_b32 %3, a159" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 40: asm volatile("v_accvgpr_read_b32 %0, a160\n v_accvgpr_read_b32 %1, a161\n v_accvgpr_read_b32 %2, a162\n v_accvgpr_read_b32 %3, a163" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 41: asm volatile("v_accvgpr_read_b32 %0, a164\n v_accvgpr_read_b32 %1, a165\n v_accvgpr_read_b32 %2, a166\n v_accvgpr_read_b32 %3, a167" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 42: asm volatile("v_accvgpr_read_b32 %0, a168\n v_accvgpr_read_b32 %1, a169\n v_accvgpr_read_b32 %2, a170\n v_accvgpr_read_b32 %3, a171" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 43: asm volatile("v_accvgpr_read_b32 %0, a172\n v_accvgpr_read_b32 %1, a173\n v_accvgpr_read_b32 %2, a174\n v_accvgpr_read_b32 %3, a175" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 44: asm volatile("v_accvgpr_read_b32 %0, a176\n v_accvgpr_read_b32 %1, a177\n v_accvgpr_read_b32 %2, a178\n v_accvgpr_read_b32 %3, a179" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 45: asm volatile("v_accvgpr_read_b32 %0, a180\n v_accvgpr_read_b32 %1, a181\n v_accvgpr_read_b32 %2, a182\n v_accvgpr_read_b32 %3, a183" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 46: asm volatile("v_accvgpr_read_b32 %0, a184\n v_accvgpr_read_b32 %1, a185\n v_accvgpr_read_b32 %2, a186\n v_accvgpr_read_b32 %3, a187" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 47: asm volatile("v_accvgpr_read_b32 %0, a188\n v_accvgpr_read_b32 %1, a189\n v_accvgpr_read_b32 %2, a190\n v_accvgpr_read_b32 %3, a191" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 48: asm volatile("v_accvgpr_read_b32 %0, a192\n v_accvgpr_read_b32 %1, a193\n v_accvgpr_read_b32 %2, a194\n v_accvgpr_read_b32 %3, a195" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 49: asm volatile("v_accvgpr_read_b32 %0, a196\n v_accvgpr_read_b32 %1, a197\n v_accvgpr_read_b32 %2, a198\n v_accvgpr_read_b32 %3, a199" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 50: asm volatile("v_accvgpr_read_b32 %0, a200\n v_accvgpr_read_b32 %1, a201\n v_accvgpr_read_b32 %2, a202\n v_accvgpr_read_b32 %3, a203" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 51: asm volatile("v_accvgpr_read_b32 %0, a204\n v_accvgpr_read_b32 %1, a205\n v_accvgpr_read_b32 %2, a206\n v_accvgpr_read_b32 %3, a207" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 52: asm volatile("v_accvgpr_read_b32 %0, a208\n v_accvgpr_read_b32 %1, a209\n v_accvgpr_read_b32 %2, a210\n v_accvgpr_read_b32 %3, a211" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 53: asm volatile("v_accvgpr_read_b32 %0, a212\n v_accvgpr_read_b32 %1, a213\n v_accvgpr_read_b32 %2, a214\n v_accvgpr_read_b32 %3, a215" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 54: asm volatile("v_accvgpr_read_b32 %0, a216\n v_accvgpr_read_b32 %1, a217\n v_accvgpr_read_b32 %2, a218\n v_accvgpr_read_b32 %3, a219" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 55: asm volatile("v_accvgpr_read_b32 %0, a220\n v_accvgpr_read_b32 %1, a221\n v_accvgpr_read_b32 %2, a222\n v_accvgpr_read_b32 %3, a223" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 56: asm volatile("v_accvgpr_read_b32 %0, a224\n v_accvgpr_read_b32 %1, a225\n v_accvgpr_read_b32 %2, a226\n v_accvgpr_read_b32 %3, a227" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 57: asm volatile("v_accvgpr_read_b32 %0, a228\n v_accvgpr_read_b32 %1, a229\n v_accvgpr_read_b32 %2, a230\n v_accvgpr_read_b32 %3, a231" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 58: asm volatile("v_accvgpr_read_b32 %0, a232\n v_accvgpr_read_b32 %1, a233\n v_accvgpr_read_b32 %2, a234\n v_accvgpr_read_b32 %3, a235" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 59: asm volatile("v_accvgpr_read_b32 %0, a236\n v_accvgpr_read_b32 %1, a237\n v_accvgpr_read_b32 %2, a238\n v_accvgpr_read_b32 %3, a239" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 60: asm volatile("v_accvgpr_read_b32 %0, a240\n v_accvgpr_read_b32 %1, a241\n v_accvgpr_read_b32 %2, a242\n v_accvgpr_read_b32 %3, a243" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 61: asm volatile("v_accvgpr_read_b32 %0, a244\n v_accvgpr_read_b32 %1, a245\n v_accvgpr_read_b32 %2, a246\n v_accvgpr_read_b32 %3, a247" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 62: asm volatile("v_accvgpr_read_b32 %0, a248\n v_accvgpr_read_b32 %1, a249\n v_accvgpr_read_b32 %2, a250\n v_accvgpr_read_b32 %3, a251" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+        case 63: asm volatile("v_accvgpr_read_b32 %0, a252\n v_accvgpr_read_b32 %1, a253\n v_accvgpr_read_b32 %2, a254\n v_accvgpr_read_b32 %3, a255" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)); break;
+    }
+    return f32x4{r0, r1, r2, r3};
+}
+
 MPC_DEV double dpp_f64(double x, int) { return x; }
 template <int CTRL> MPC_DEV double mov_dpp_f64(double x)
 {
@@ -225,7 +386,8 @@ MPC_DEV void fence_own_stores()
 namespace mpclqr {
 namespace {
 
-// MODE: 0 unconstrained, 1 unconstrained + u_zero_I, 2 box-constrained (pnqp in the sweep)
+// MODE: 0 unconstrained with the gains in registers (T <= 64), 1 unconstrained + u_zero_I, 2 box-constrained (pnqp in the
+// sweep), 3 unconstrained with the gains through memory (any T)
 template <int MODE>
 __global__ void __launch_bounds__(64, 1) lqr_step_dpp16_kernel(StepParams<float> p)
 {
@@ -290,7 +452,8 @@ int launch_step_dpp16(const StepParams<float> &p, hipStream_t st)
     const dim3 grid((p.B + 3) / 4), block(64);
     if (p.bound_mode != MPC_BOUND_NONE) hipLaunchKernelGGL((lqr_step_dpp16_kernel<2>), grid, block, 0, st, p);
     else if (p.zero_mask) hipLaunchKernelGGL((lqr_step_dpp16_kernel<1>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((lqr_step_dpp16_kernel<0>), grid, block, 0, st, p);
+    else if (p.T <= dpp16::RG_STEPS) hipLaunchKernelGGL((lqr_step_dpp16_kernel<0>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((lqr_step_dpp16_kernel<3>), grid, block, 0, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_last_error((std::string("lqr_step_dpp16_kernel: ") + hipGetErrorString(e)).c_str());

@@ -83,6 +83,28 @@ struct Prof { unsigned long long acc[16]; unsigned long long last; };
 
 typedef StepParams<float> P;
 using wv::f32x4;
+
+// MODE of the step kernel:
+//   0  unconstrained, horizon T <= RG_STEPS: the gains of the whole horizon stay in the register file between the
+//      sweep and the rollouts (no record written, none read back: 512 of the 3,376 bytes a problem-step moves)
+//   1  unconstrained + u_zero_I          2  box-constrained (pnqp in the sweep)
+//   3  unconstrained, any T: gains through the record in memory like modes 1 and 2
+constexpr bool con(int MODE) { return MODE == 1 || MODE == 2; }       // constrained: (m, M) terms, masks, clamps
+constexpr bool rgm(int MODE) { return MODE < 1; }                     // register-resident gains
+
+// The gain record of timestep t as the sweep holds it: lane j < 12 K[0..3][j], lane 12 k[0..3], lanes 13..15 columns
+// 1..3 of Quu (Quu[0][0] in element 2 of lane 13).  Registers cannot be indexed by a runtime t, so put / get are
+// switches over t whose cases name their registers statically: a compare tree of ~12 scalar instructions around four
+// register moves (the array lives in the accumulation half of the 512-entry file).
+enum { RG_STEPS = 64 };
+// (the storage itself is the wave interface's: wv::rg_put / wv::rg_get name accumulation registers a[4t .. 4t+3] in
+// inline assembly on the GPU -- as compiler-visible values the 256 registers were copied around at every loop
+// boundary, 112 us against 99 -- and a plain per-lane array in the host emulator)
+template <bool ON> struct Gains {};
+MPC_DEV void gain_put(Gains<true> &, int t, f32x4 v) { wv::rg_put(t, v); }
+MPC_DEV f32x4 gain_get(const Gains<true> &, int t) { return wv::rg_get(t); }
+MPC_DEV void gain_put(Gains<false> &, int, f32x4) {}
+MPC_DEV f32x4 gain_get(const Gains<false> &, int) { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 using mfma16::Sym4;
 using mfma16::Ldl4;
 using mfma16::ldl4;
@@ -243,7 +265,7 @@ enum {
 };
 // DMA instructions of one rollout stage: F, record, gains (+ C when priced directly, + (m, M) otherwise
 // when constraints are present)
-template <int MODE, bool DIRECT> struct RollDma { enum { N = 3 + 1 + 1 + (DIRECT ? 4 : (MODE != 0 ? 1 : 0)) }; };
+template <int MODE, bool DIRECT> struct RollDma { enum { N = 3 + 1 + (rgm(MODE) ? 0 : 1) + (DIRECT ? 4 : (con(MODE) ? 1 : 0)) }; };
 // The identity-priced rollout does not stage C: its stage is [(m, M)] | gains | F | record = 5 (6) KiB, packed
 // back to back so the same LDS holds 7 (6) stages instead of 4 and the DMA runs 6 (5) timesteps ahead -- a
 // rollout step is ~0.45 us, four-deep staging would leave the loads less than an HBM round trip under load.
@@ -252,9 +274,10 @@ template <int MODE, bool DIRECT> struct RollDma { enum { N = 3 + 1 + 1 + (DIRECT
 // sweep's 9 KiB layout with the gains behind the record.
 template <int MODE, bool DIRECT> struct RollRing {
     enum {
-        BYTES = DIRECT ? (int)STAGE_BYTES : (MODE != 0 ? 6144 : 5120),
-        SLOTS = DIRECT ? (int)NSTAGE : (int)LDS_TOTAL / (MODE != 0 ? 6144 : 5120),
-        FOFF = DIRECT ? (int)SF : (MODE != 0 ? 2048 : 1024),        // F block inside a slot
+        // (register-resident gains: the stage is F | record = 4 KiB, nine stages in flight)
+        BYTES = DIRECT ? (int)STAGE_BYTES : (con(MODE) ? 6144 : (rgm(MODE) ? 4096 : 5120)),
+        SLOTS = DIRECT ? (int)NSTAGE : (int)LDS_TOTAL / (con(MODE) ? 6144 : (rgm(MODE) ? 4096 : 5120)),
+        FOFF = DIRECT ? (int)SF : (con(MODE) ? 2048 : (rgm(MODE) ? 0 : 1024)),        // F block inside a slot
         GADJ = DIRECT ? 0 : (int)SF - 1024 - (int)SG,                // gains / (m, M) relative to the lane offsets,
         MADJ = DIRECT ? 0 : (int)SF - 2048 - (int)SC                 // which are written for the sweep's layout
     };
@@ -428,12 +451,12 @@ MPC_DEV void stage_issue(const Dma &d, unsigned mid)
     wv::dma16_at<1024, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[1], mid);
     wv::dma16_at<2048, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[2], mid);
     wv::dma16_at<3072>(d.r_ptr, mid);
-    if (ROLL) {
+    if (ROLL && !rgm(MODE)) {
         if (DIRECT) {
             wv::dma16_at<0>(d.g_ptr - 1024, mid + (SG - SF));
         } else {
             wv::dma16_at<-1024>(d.g_ptr, mid);
-            if (MODE != 0) wv::dma16_at<-2048>(d.g2_ptr, mid);
+            if (con(MODE)) wv::dma16_at<-2048>(d.g2_ptr, mid);
         }
     }
 }
@@ -452,9 +475,9 @@ MPC_DEV void stage_move(Dma &d, bool move_f)
 #pragma unroll
     for (int k = 0; k < 3; ++k) d.f_ptr[k] += ROLL ? fs : -fs;
     d.r_ptr += ROLL ? rs : -rs;
-    if (ROLL) {
+    if (ROLL && !rgm(MODE)) {
         d.g_ptr += d.g_step;
-        if (MODE != 0 && !DIRECT) d.g2_ptr += d.g_step;
+        if (con(MODE) && !DIRECT) d.g2_ptr += d.g_step;
     }
 }
 
@@ -487,8 +510,8 @@ template <int MODE, bool ROLL, bool DIRECT> struct Feed {
                 wv::dma16_at<2048, wv::DMA_LAST>(d.f_ptr[2], mid);
                 wv::dma16_at<3072>(d.r_ptr, mid);
             } else if (K == 2) {
-                wv::dma16_at<-1024>(d.g_ptr, mid);
-                if (MODE != 0) wv::dma16_at<-2048>(d.g2_ptr, mid);
+                if (!rgm(MODE)) wv::dma16_at<-1024>(d.g_ptr, mid);
+                if (con(MODE)) wv::dma16_at<-2048>(d.g2_ptr, mid);
             } else {
                 stage_move<MODE, ROLL, DIRECT>(d, move_f);
             }
@@ -505,7 +528,7 @@ template <int MODE, bool ROLL, bool DIRECT> struct Feed {
             } else {
                 wv::dma16_at<2048, ROLL ? wv::DMA_LAST : wv::DMA_PLAIN>(d.f_ptr[2], mid);
                 wv::dma16_at<3072>(d.r_ptr, mid);
-                if (ROLL) wv::dma16_at<0>(d.g_ptr - 1024, mid + (SG - SF));
+                if (ROLL && !rgm(MODE)) wv::dma16_at<0>(d.g_ptr - 1024, mid + (SG - SF));
                 stage_move<MODE, ROLL, DIRECT>(d, move_f);
             }
         }
@@ -610,7 +633,7 @@ struct SwState {
 };
 
 template <int MODE>
-MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st, int t, Feed<MODE, false, false> &feed)
+MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st, int t, Feed<MODE, false, false> &feed, Gains<rgm(MODE)> &G)
 {
     const bool last = (t == p.T - 1);
     feed.template part<0>();
@@ -658,7 +681,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     const bool valid[4] = {true, true, true, true};
     Ldl4 f;
     float kq[4] = {0.f, 0.f, 0.f, 0.f};
-    if (MODE == 0) {
+    if (!con(MODE)) {
         ldl4<false>(f, S, fr, 0.f);                                   // :84-94
     } else if (MODE == 1) {
         // :99-127 u_zero_I: masked rows and columns drop out
@@ -708,7 +731,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     for (int a = 0; a < 4; ++a) rhs[a] = sel(j12, qu[a], Q[12 + a]);
     {
         float y[4];
-        if (MODE == 0) {
+        if (!con(MODE)) {
             ldl4_solve(f, rhs[0], rhs[1], rhs[2], rhs[3], y);
 #pragma unroll
             for (int a = 0; a < 4; ++a) K[a] = -y[a];
@@ -728,7 +751,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #pragma unroll
     for (int i = 0; i < 12; ++i) Vn[i] = Q[i];
     float M[4] = {0.f, 0.f, 0.f, 0.f};
-    if (MODE != 0) {
+    if (con(MODE)) {
         // with a full free set Qux + Quu K vanishes; with masked / clamped controls it does not
         M[0] = fmaf(S.s03, K[3], fmaf(S.s02, K[2], fmaf(S.s01, K[1], fmaf(S.s00, K[0], rhs[0]))));
         M[1] = fmaf(S.s13, K[3], fmaf(S.s12, K[2], fmaf(S.s11, K[1], fmaf(S.s01, K[0], rhs[1]))));
@@ -740,7 +763,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     wv::sched_fence();              // the matrix-core block of the value update, undivided
 #pragma unroll
     for (int a = 0; a < 4; ++a) outer_acc(Vn, Q[12 + a], K[a]);      // += Qux[a][i] K[a][j]  (Qux = Qxu')
-    if (MODE != 0) {
+    if (con(MODE)) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) outer_acc(Vn, K[a], M[a]);       // += K[a][i] M[a][j]
     }
@@ -748,7 +771,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     float vn = q;
     wv::fmac_bcast<12>(vn, K[0], Q[12]); wv::fmac_bcast<12>(vn, K[1], Q[13]);
     wv::fmac_bcast<12>(vn, K[2], Q[14]); wv::fmac_bcast<12>(vn, K[3], Q[15]);
-    if (MODE != 0) {
+    if (con(MODE)) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) wv::fmac_bcast<12>(vn, M[a], K[a]);      // += K[a][j] m[a]
     }
@@ -762,7 +785,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const float ka = wv::bcast<12>(K[a]);
-            const float mq = MODE != 0 ? wv::bcast<12>(M[a]) + qu[a] : qu[a];
+            const float mq = con(MODE) ? wv::bcast<12>(M[a]) + qu[a] : qu[a];
             w = fmaf(ka, 0.5f * mq, w);
         }
         st.w0 += (double)w;
@@ -776,9 +799,13 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         const bool quu = L.j >= 13;
         f32x4 rec = {sel(quu, Q[12], K[0]), sel(quu, Q[13], K[1]), sel(quu, Q[14], K[2]), sel(quu, Q[15], K[3])};
         rec[2] = sel(L.j == 13, S.s00, rec[2]);
-        wv::store_f32x4(st.rec, rec);
-        st.rec -= st.rec_step;
-        if (MODE != 0) {
+        if (rgm(MODE)) {
+            gain_put(G, t, rec);                         // stays in the register file until the rollouts
+        } else {
+            wv::store_f32x4(st.rec, rec);
+            st.rec -= st.rec_step;
+        }
+        if (con(MODE)) {
             wv::store_f32x4(st.rec2, f32x4{M[0], M[1], M[2], M[3]});       // lanes 13..15: never read
             st.rec2 -= st.rec_step;
         }
@@ -805,8 +832,28 @@ struct RoStage {
     float Mr[12];     // row a of M = Qux + Quu K           (identity pricing, constrained modes)
     float Sr[4];      // row a of Quu                       (identity pricing)
     float cj, tb, fj, kk, mk, lo, hi;
+    f32x4 rec;        // register-resident gains (mode 0): the record in the sweep's own layout, see Gains
     bool zm;
 };
+
+// Mode 0: k_a and row a of Quu for control lane 12 + a out of the column-layout record -- needed only where a
+// trial's step differs from the sweep's policy (alpha < 1), i.e. not in the first pass of a line search.
+MPC_DEV void rg_price_terms(RoStage &s, const Lane &L)
+{
+    const f32x4 r = s.rec;
+    const float k0 = wv::bcast<12>(r[0]), k1 = wv::bcast<12>(r[1]), k2 = wv::bcast<12>(r[2]), k3 = wv::bcast<12>(r[3]);
+    const int a = L.a;
+    s.kk = a == 0 ? k0 : (a == 1 ? k1 : (a == 2 ? k2 : k3));
+    // Quu[i][c] = element i of lane 12 + c (c = 1..3), Quu[0][0] = element 2 of lane 13 (lane_init)
+    const float q00 = wv::bcast<13>(r[2]);
+    const float q01 = wv::bcast<13>(r[0]), q11 = wv::bcast<13>(r[1]);
+    const float q02 = wv::bcast<14>(r[0]), q12 = wv::bcast<14>(r[1]), q22 = wv::bcast<14>(r[2]);
+    const float q03 = wv::bcast<15>(r[0]), q13 = wv::bcast<15>(r[1]), q23 = wv::bcast<15>(r[2]), q33 = wv::bcast<15>(r[3]);
+    s.Sr[0] = a == 0 ? q00 : (a == 1 ? q01 : (a == 2 ? q02 : q03));
+    s.Sr[1] = a == 0 ? q01 : (a == 1 ? q11 : (a == 2 ? q12 : q13));
+    s.Sr[2] = a == 0 ? q02 : (a == 1 ? q12 : (a == 2 ? q22 : q23));
+    s.Sr[3] = a == 0 ? q03 : (a == 1 ? q13 : (a == 2 ? q23 : q33));
+}
 
 template <int MODE, bool DIRECT>
 MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, unsigned zm)
@@ -825,8 +872,8 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
         s.cj = wv::lds_f32(base + L.aRec + R_c);
     } else {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) s.Sr[b] = wv::lds_f32(gain + L.aS[b]);
-        if (MODE != 0) {
+        for (int b = 0; b < 4; ++b) s.Sr[b] = rgm(MODE) ? 0.f : wv::lds_f32(gain + L.aS[b]);
+        if (con(MODE)) {
 #pragma unroll
             for (int jj = 0; jj < 12; ++jj) s.Mr[jj] = wv::lds_f32(mrec + L.aMrow + 16 * jj);
             s.mk = wv::lds_f32(mrec + L.aMrow + 192);
@@ -839,9 +886,13 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
         s.Fr[4 * q] = v[0]; s.Fr[4 * q + 1] = v[1]; s.Fr[4 * q + 2] = v[2]; s.Fr[4 * q + 3] = v[3];
     }
     s.fj = p.f ? wv::lds_f32(base + L.aRecF) : 0.f;
+    if (!rgm(MODE)) {
 #pragma unroll
-    for (int jj = 0; jj < 12; ++jj) s.Kr[jj] = wv::lds_f32(gain + L.aKrow + 16 * jj);
-    s.kk = wv::lds_f32(gain + L.aKrow + 192);
+        for (int jj = 0; jj < 12; ++jj) s.Kr[jj] = wv::lds_f32(gain + L.aKrow + 16 * jj);
+        s.kk = wv::lds_f32(gain + L.aKrow + 192);
+    } else {
+        s.kk = 0.f;
+    }
     s.tb = wv::lds_f32(base + L.aRec + R_tau);
     s.lo = s.hi = 0.f;
     if (MODE == 2) {
@@ -863,6 +914,7 @@ struct RoState {
     float pred;       // F tau + f of the nominal at t-1: what the nominal x_t must equal
     float viol;       // > 0 once the nominal broke the dynamics somewhere
     float *out;       // this lane's element of new_x / new_u at the current timestep
+    bool price_on;    // (wave-uniform) some row of this pass steps off the sweep's policy: the identity's terms are not all zero
 };
 
 // new_u = K dx + u + alpha k (mpc/lqr_step.py:192), zero mask (:197-198), box / delta_u clamp (:200-213);
@@ -871,10 +923,19 @@ template <int MODE>
 MPC_DEV float control_law(const P &p, const Lane &L, const RoStage &s, float xs, float alpha, float &e, float &dx)
 {
     dx = L.isu ? 0.f : xs - s.tb;
-    float un = fmaf(alpha, s.kk, s.tb);
-    wv::dot_bcast12(un, dx, s.Kr);
+    float un;
+    if (rgm(MODE)) {
+        // the record is in the sweep's layout (lane j: K[0..3][j], lane 12: k): K dx + alpha k is ONE reduction over the
+        // row per control, lane 12 contributing alpha k_a -- four sums that a two-level exchange lands in the lanes
+        // with (j & 3) == a, control lane 12 + a among them
+        const float mult = L.j == 12 ? alpha : dx;
+        un = s.tb + wv::quad_sums(s.rec[0] * mult, s.rec[1] * mult, s.rec[2] * mult, s.rec[3] * mult, L.j);
+    } else {
+        un = fmaf(alpha, s.kk, s.tb);
+        wv::dot_bcast12(un, dx, s.Kr);
+    }
     const float pre = un;
-    if (MODE != 0 && s.zm) un = 0.f;
+    if (con(MODE) && s.zm) un = 0.f;
     if (MODE == 2) {
         float l = s.lo, h = s.hi;
         if (p.has_delta) {
@@ -901,7 +962,7 @@ MPC_DEV float stage_price(const Lane &L, const RoStage &s, float tp, float e, fl
     float se = 0.f;
     wv::dot_bcast_u4(se, e, s.Sr);                 // sum_b bcast_{12+b}(e) Sr[b]
     float lin = 0.5f * se;
-    if (MODE != 0) {
+    if (con(MODE)) {
         lin += s.mk;
         wv::dot_bcast12(lin, dx, s.Mr);
     }
@@ -917,7 +978,8 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
     const float un = control_law<MODE>(p, L, s, st.xs, st.alpha, e, dx);
     const float tp = L.isu ? un : st.xs;                             // tau'_t[j]
     feed.template part<1>();
-    st.cost += stage_price<MODE, DIRECT>(L, s, tp, e, dx);
+    // (mode 0 on the sweep's own policy, alpha = 1 everywhere: e = 0, the identity's stage terms vanish)
+    if (DIRECT || !rgm(MODE) || st.price_on) st.cost += stage_price<MODE, DIRECT>(L, s, tp, e, dx);
     {
         const float d = sel(L.isu, s.tb - un, 0.f);                  // (selects, not branches: lane-dependent
         st.du2 = fmaf(d, d, st.du2);                                 //  branches cost exec-mask bookkeeping)
@@ -981,7 +1043,7 @@ MPC_DEV void trials_step(const P &p, const Lane &L, const RoStage &s, Trials &tr
 // (trajectory stored).  Costs come back as full trajectory costs (base = J_nominal + w_0 when priced by
 // the identity, 0 when priced directly).
 template <int MODE, bool MULTI, bool DIRECT, bool CHECK>
-MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, RoState &st, Trials &tr, int nt, float base PROF_ARG)
+MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gains<rgm(MODE)> &G, RoState &st, Trials &tr, int nt, float base PROF_ARG)
 {
     const int T = p.T;
     float x0 = L.isu ? 0.f : p.x_init[(long)L.pb * 12 + L.j];
@@ -998,7 +1060,8 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, RoState &
         st.pred = 0.f;
         st.out = L.out0;
     }
-    const bool use_zm = MODE != 0 && p.zero_mask != nullptr;
+    st.price_on = MULTI || wv::any(st.alpha != 1.f);
+    const bool use_zm = con(MODE) && p.zero_mask != nullptr;
     enum { NS = RollRing<MODE, DIRECT>::SLOTS, LA = NS - 1, ND = RollDma<MODE, DIRECT>::N };
     static_assert((LA - 1) * ND + 2 * LA < 64, "vmcnt is 6 bits");
     unsigned zq[NS];
@@ -1025,6 +1088,10 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, RoState &
                 PROF_MARK(4);
                 RoStage s;
                 ro_read<MODE, DIRECT>(s, p, L, t, i, zq[i]);
+                if (rgm(MODE)) {
+                    s.rec = gain_get(G, t);
+                    if (!DIRECT && st.price_on) rg_price_terms(s, L);
+                }
                 PROF_MARK(5);
                 const int tn = t + LA;
                 ZmRaw zr = {{0u, 0u, 0u, 0u}};
@@ -1058,14 +1125,14 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, RoState &
 // the end (a nominal that is already optimal): alpha = 1, then alpha = decay on its own, then ALL
 // remaining trials in one pass and a replay of the accepted ones.
 template <int MODE, bool DIRECT, bool CHECK>
-MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, RoState &rs, float old_cost, float base, float &full2 PROF_ARG)
+MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, const Gains<rgm(MODE)> &G, RoState &rs, float old_cost, float base, float &full2 PROF_ARG)
 {
     Trials tr;
     rs.alpha = 1.f;
     bool worse0 = false;
 #pragma unroll 1
     for (int phase = 0; phase < 3; ++phase) {
-        rollout_pass<MODE, false, DIRECT, CHECK>(p, L, d, wave, rs, tr, 0, base PROF_PASS);   // rows whose alpha did not change reproduce their result
+        rollout_pass<MODE, false, DIRECT, CHECK>(p, L, d, wave, G, rs, tr, 0, base PROF_PASS);   // rows whose alpha did not change reproduce their result
         if (phase == 0) {
             full2 = rs.du2;                                          // :243-245 (the alpha = 1 trial)
             worse0 = rs.cost > old_cost && p.max_ls > 1;
@@ -1078,7 +1145,7 @@ MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, RoState &r
             float a = p.ls_decay;
 #pragma unroll
             for (int k = 0; k < MAX_TRIALS; ++k) { a *= p.ls_decay; tr.alpha[k] = a; }
-            rollout_pass<MODE, true, DIRECT, CHECK>(p, L, d, wave, rs, tr, nt, base PROF_PASS);
+            rollout_pass<MODE, true, DIRECT, CHECK>(p, L, d, wave, G, rs, tr, nt, base PROF_PASS);
             if (worse1) {
                 float acc = tr.alpha[0];
                 bool found = false;
@@ -1109,6 +1176,7 @@ MPC_DEV void step_wave(const P &p)
     L.ostep = L.isu ? (long)p.B * 4 : (long)p.B * 12;
     const int T = p.T;
     Dma d;
+    Gains<rgm(MODE)> G;
     PROF_DECL;
 
     // ---- Riccati sweep, t = T-1 .. 0 ------------------------------------------------------------
@@ -1154,7 +1222,7 @@ MPC_DEV void step_wave(const P &p)
                     if (MODE == 1 && t >= 3) zr = zm_fetch(p, L, t - 3);
                     Feed<MODE, false, false> feed = {d, stage_mid<MODE, false, false>((i + 3) % NSTAGE), t >= 3, true};
                     PROF_MARK(2);
-                    sweep_step<MODE>(p, L, s, ss, t, feed);
+                    sweep_step<MODE>(p, L, s, ss, t, feed, G);
                     if (MODE == 1) zq[(i + 3) % NSTAGE] = zm_pick(L, zr);
                 }
             }
@@ -1174,13 +1242,13 @@ MPC_DEV void step_wave(const P &p)
     float full2 = 0.f;
     if (p.on_dynamics) {
         // the caller vouches for the nominal (MPC_OPT_NOMINAL_ON_DYNAMICS): no verification in the loop
-        line_search<MODE, false, false>(p, L, d, wave, rs, old_cost, (float)(old_cost_d + ss.w0), full2 PROF_PASS);
+        line_search<MODE, false, false>(p, L, d, wave, G, rs, old_cost, (float)(old_cost_d + ss.w0), full2 PROF_PASS);
     } else {
-        line_search<MODE, false, true>(p, L, d, wave, rs, old_cost, (float)(old_cost_d + ss.w0), full2 PROF_PASS);
+        line_search<MODE, false, true>(p, L, d, wave, G, rs, old_cost, (float)(old_cost_d + ss.w0), full2 PROF_PASS);
         // a nominal that does not obey the dynamics voids the identity the pass was priced with: price the
         // rollout the reference's way, from a second stream of C
         const bool broken = wv::row_sum(rs.viol > 0.f ? 1.f : 0.f) > 0.f;
-        if (wv::any(broken)) line_search<MODE, true, false>(p, L, d, wave, rs, old_cost, 0.f, full2 PROF_PASS);
+        if (wv::any(broken)) line_search<MODE, true, false>(p, L, d, wave, G, rs, old_cost, 0.f, full2 PROF_PASS);
         if (broken) ss.status |= MPC_ST_NOMINAL_OFF_DYNAMICS;
     }
 #ifdef MPC_DPP16_PROF

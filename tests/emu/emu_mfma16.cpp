@@ -33,6 +33,7 @@ struct Wave {
     int problem;
     // exchange area, two generations
     float fa[2][NL], fb[2][NL];
+    float fq[2][NL][4];
     double fd[2][NL];
     int ia[2][NL];
     unsigned seq[NL];
@@ -235,6 +236,31 @@ static inline float row_sum(float x)
     }
     return x;
 }
+// register-resident gains of lqr_dpp16.hip (accumulation registers a[4t..4t+3] there): one array per lane here
+static f32x4 g_rg[64][64];
+static inline void rg_put(int t, f32x4 v) { g_rg[emu::W.cur][t] = v; }
+static inline f32x4 rg_get(int t) { return g_rg[emu::W.cur][t]; }
+// wv::quad_sums of lqr_dpp16.hip: lane j of a row gets the row sum of p_(j & 3)
+static inline float quad_sums(float p0, float p1, float p2, float p3, int j)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    float *buf = &w.fq[gen][l][0];
+    buf[0] = p0; buf[1] = p1; buf[2] = p2; buf[3] = p3;
+    emu::yield_lane();
+    const int r = l & ~15, a = j & 3;
+    // the hardware's order of additions: pairs, quads, then the quads rotated in
+    float q[4];
+    for (int k = 0; k < 4; ++k) {
+        const int b = r + 4 * k;
+        const float lo = w.fq[gen][b + 0][a] + w.fq[gen][b + 1][a], hi = w.fq[gen][b + 2][a] + w.fq[gen][b + 3][a];
+        q[k] = lo + hi;
+    }
+    const int me = (l & 15) >> 2;
+    const float s1 = q[me] + q[(me + 1) & 3];
+    const float s2 = q[(me + 2) & 3] + q[(me + 3) & 3];
+    return s1 + s2;
+}
 static inline double row_sum_f64(double x)
 {
     emu::Wave &w = emu::W;
@@ -385,7 +411,8 @@ static void body_dpp16()
     const mpclqr::StepParams<float> &p = *g_p;
     if (p.bound_mode != MPC_BOUND_NONE) mpclqr::dpp16::step_wave<2>(p);
     else if (p.zero_mask) mpclqr::dpp16::step_wave<1>(p);
-    else mpclqr::dpp16::step_wave<0>(p);
+    else if (p.T <= mpclqr::dpp16::RG_STEPS) mpclqr::dpp16::step_wave<0>(p);
+    else mpclqr::dpp16::step_wave<3>(p);
 }
 
 extern "C" int emu_lqr_step_dpp16(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out)

@@ -38,10 +38,10 @@ def _findings(name):
 
 def test_dpp16_kernels_keep_their_arrays_in_registers_and_their_dma_queue_full():
     f = _findings("lqr_dpp16")
-    assert len(f) == 4
+    assert len(f) == 5                           # step kernel modes 0..3 + the KKT kernel
     for k, v in f.items():
         assert v["scratch"] == 0, k
-        if "Li0E" in k or "kkt" in k:            # headline kernel and its backward: no drain anywhere
+        if "Li0E" in k or "Li3E" in k or "kkt" in k:            # headline kernels and the backward: no drain anywhere
             assert v["drains"] == 0, (k, v)
 
 
@@ -50,3 +50,25 @@ def test_mfma40_kernels_keep_their_arrays_in_registers_and_their_dma_queue_full(
     assert len(f) == 3
     for k, v in f.items():
         assert v == {"scratch": 0, "drains": 0}, (k, v)
+
+
+def test_register_resident_gains_own_the_accumulation_registers():
+    """Mode 0 of the headline kernel parks the gains of the whole horizon in a[0..255] through inline assembly
+    (wv::rg_put / rg_get, lqr_dpp16.hip).  That is only sound while the compiler itself never allocates an AccVGPR in
+    that kernel: every a-register access must be one of the hand-written v_accvgpr_write / v_accvgpr_read, and no MFMA
+    may accumulate there."""
+    import re
+    import isa_lint
+    lines = isa_lint.assembly("lqr_dpp16")
+    kernels, _ = isa_lint.structure(lines)
+    start = [i for i, n in kernels if "kernelILi0E" in n][0]
+    end = min([i for i, n in kernels if i > start] + [len(lines)])
+    body = [l for l in lines[start:end] if not l.strip().startswith(";")]
+    acc = [l for l in body if re.search(r"\ba\[?\d", l)]
+    assert len(acc) > 512                                   # the switches are there
+    for l in acc:
+        op = l.split()[0]
+        assert op in ("v_accvgpr_write_b32", "v_accvgpr_read_b32"), l
+    for l in body:
+        if l.strip().startswith("v_mfma"):
+            assert not re.search(r"\ba\[", l), l
