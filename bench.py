@@ -40,10 +40,11 @@ sys.path.insert(0, os.path.join(ROOT, "mpc.pytorch_amd"))
 sys.path.insert(0, ROOT)
 
 NS, NC, T_H, B_PER_GPU = 12, 4, 50, 4096
-EV_GROUP = 5
+EV_GROUP = 20            # launches per HIP-event pair (an event pair opens a ~3-10 us gap in the stream)
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_MFMA_PEAK_TF = 157.3  # same guide: v_mfma_f32_16x16x4_f32, dense
-SETTLE_LAUNCHES = 100     # clocks and the Infinity Cache settle over the first ~100 launches (a step is 0.1 ms)
+SETTLE_LAUNCHES = 200     # the power controller settles over the first ~120 launches of a fresh process: ~17 at boost
+                          # clocks (87 us), a dip to 100 us, back to 87-88 us (profiles/r02_kt_durations.json)
 KERNEL_NAMES = {1: "lqr_step_generic_kernel<float>", 2: "lqr_step_mfma16_kernel", 3: "lqr_step_dpp16_kernel",
                 4: "lqr_step_tiny_kernel", 5: "lqr_step_mfma40_kernel"}
 
@@ -358,9 +359,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # set-up launches (not warm-up steps of the contract, reported as `settle_launches`): the first launches of a
-    # fresh process run at boost clocks with a cold Infinity Cache and read 3 % fast or slow depending on the box;
-    # W = 5 of the driver's default call alone would time the transient
+    # set-up launches (not warm-up steps of the contract, reported as `settle_launches`): a fresh process sees ~17
+    # launches at boost clocks, then the power controller's dip (+15 % per launch), then the sustained state from
+    # launch ~120 on; W = 5 of the driver's default call alone would time the transient
     settle = max(0, SETTLE_LAUNCHES - args.warmup)
     for _ in range(settle):
         step()
