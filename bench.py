@@ -225,12 +225,15 @@ def extra_rows(be, dev, steps):
     # ---- config 5: n_state=32 n_ctrl=8 T=64, the MFMA tile path; B=1024 is one GPU's share of 8192 over 8 ------
     for B5 in (1024, 8192):
         p = make_problem(32, 8, 64, B5, torch.float32, dev, seed=9, on_device=True)
-        row, r = step_row(p, StepOptions(), 32, 8, 64, B5)
+        row, r = step_row(p, StepOptions(nominal_on_dynamics=True), 32, 8, 64, B5)      # as mpc.MPC calls it
         tf = algorithmic_flops_per_problem_step(32, 8) * B5 * 64 / (row["ms"] * 1e-3) / 1e12
         row["mfma_fp32"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                             "frac": tf / FP32_MFMA_PEAK_TF}
         rows["cfg5_step_B%d" % B5] = row
         if B5 == 1024:
+            rowv, _ = step_row(p, StepOptions(), 32, 8, 64, B5)
+            rowv["workload"] = "config 5, nominal NOT vouched for: every line-search trial priced from C in the rollout (bare LQRStep call)"
+            rows["cfg5_step_B1024_verified_nominal"] = rowv
             rows["cfg5_kkt_backward_B1024"] = kkt_row(p, r, StepOptions(), 32, 8, 64, B5)
             pb = dict(p)
             rowb, _ = step_row(pb, StepOptions(u_lower=-1.0, u_upper=1.0), 32, 8, 64, B5)

@@ -57,7 +57,7 @@ MPC_DEV void lds_sync() { asm volatile("" ::: "memory"); }
 template <int N> MPC_DEV void dma_wait()
 {
     static_assert(N >= 0 && N < 64, "vmcnt is 6 bits on gfx9");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) ; counted" ::"n"(N) : "memory");
 }
 MPC_DEV void fence_own_stores()
 {

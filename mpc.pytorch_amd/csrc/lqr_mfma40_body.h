@@ -276,7 +276,7 @@ MPC_DEV int pnqp8(const float S[8][8], const float q[8], const float lb[8], cons
 
 // The sweep of one problem: K [T,B,8,32] and k [T,B,8] in the reference layout, old_costs[b].
 // MODE 0: unconstrained; 1: u_zero_I mask; 2: box constraints (pnqp8 on wave-uniform values).
-template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout)
+template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out = nullptr)
 {
     Lane L;
     L.lane = wv::lane();
@@ -298,6 +298,7 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
         for (int v = 0; v < 4; ++v) vcol[I][v] = 0.f;
     }
     double old_cost = 0.0;
+    double w0 = 0.0;                   // sum_t 0.5 qu'k: the value function's predicted change of the cost (unconstrained)
     int qp_total = 0, status = 0;
     bool warm = false;
     float kprev[8];
@@ -379,32 +380,33 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
                     }
             // ---- Y = V F   (A operand = V by symmetry: register v of tile (I', Im))
             wv::sched_fence();
+            // (three tiles at a time, their accumulation chains interleaved: an MFMA that waits for the previous one's
+            // accumulator issues every 40 clocks, an independent one every 32)
             f32x4 Yd[2][3];
 #pragma unroll
-            for (int Im = 0; Im < 2; ++Im)
+            for (int Im = 0; Im < 2; ++Im) {
 #pragma unroll
-                for (int J = 0; J < 3; ++J) {
-                    f32x4 acc = zero4;
+                for (int J = 0; J < 3; ++J) Yd[Im][J] = zero4;
 #pragma unroll
-                    for (int Ip = 0; Ip < 2; ++Ip)
+                for (int Ip = 0; Ip < 2; ++Ip)
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) acc = wv::mfma(Vd[Ip][Im][v], FB[4 * Ip + v][J], acc);
-                    Yd[Im][J] = acc;
-                }
+                    for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int J = 0; J < 3; ++J) Yd[Im][J] = wv::mfma(Vd[Ip][Im][v], FB[4 * Ip + v][J], Yd[Im][J]);
+            }
             // ---- Q = C + F'Y  (A operand = F' = FB, B operand = Y in D layout); tiles (0,2), (1,2) are
             // not needed below (Qxu is used through Qux)
 #pragma unroll
             for (int I = 0; I < 3; ++I)
 #pragma unroll
-                for (int J = 0; J < 3; ++J) {
-                    if (J == 2 && I < 2) continue;
-                    f32x4 acc = Qd[I][J];
+                for (int Ip = 0; Ip < 2; ++Ip)
 #pragma unroll
-                    for (int Ip = 0; Ip < 2; ++Ip)
+                    for (int v = 0; v < 4; ++v)
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) acc = wv::mfma(FB[4 * Ip + v][I], Yd[Ip][J][v], acc);
-                    Qd[I][J] = acc;
-                }
+                        for (int J = 0; J < 3; ++J) {
+                            if (J == 2 && I < 2) continue;
+                            Qd[I][J] = wv::mfma(FB[4 * Ip + v][I], Yd[Ip][J][v], Qd[I][J]);
+                        }
             wv::sched_fence();
             // ---- q = c_back + F'v
 #pragma unroll
@@ -435,8 +437,13 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
         if (MODE == 0) {
             ldl8(fac, S);
             ldl8_solve(fac, qu, kk);
+            float w = 0.f;
 #pragma unroll
-            for (int a = 0; a < 8; ++a) kk[a] = -kk[a];
+            for (int a = 0; a < 8; ++a) {
+                kk[a] = -kk[a];
+                w = fmaf(qu[a], kk[a], w);
+            }
+            w0 += 0.5 * (double)w;
         } else if (MODE == 1) {                          // :99-127: pinned controls drop out of the solve
             float rq[8];
             const unsigned zlo = zero_mask_word(p, tb, 0), zhi = zero_mask_word(p, tb, 1);
@@ -536,19 +543,25 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
         }
 
         // ---- V = Qxx + Qxu K, v = qx + Qxu k   (:155-158 with K'(Qux + Quu K) = 0, K'(qu + Quu k) = 0)
+        // (the four tiles' chains interleaved, see Y above)
 #pragma unroll
         for (int I = 0; I < 2; ++I)
 #pragma unroll
-            for (int J = 0; J < 2; ++J) {
-                f32x4 acc = Qd[I][J];
+            for (int J = 0; J < 2; ++J) Vd[I][J] = Qd[I][J];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) acc = wv::mfma(Qd[2][I][v], Kd[J][v], acc);
-                if (MODE != 0) {                         // + K'(Qux + Quu K): K' as A operand is K's own registers
+        for (int v = 0; v < 4; ++v)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) acc = wv::mfma(Kd[I][v], Md[J][v], acc);
-                }
-                Vd[I][J] = acc;
-            }
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J) Vd[I][J] = wv::mfma(Qd[2][I][v], Kd[J][v], Vd[I][J]);
+        if (MODE != 0) {                                 // + K'(Qux + Quu K): K' as A operand is K's own registers
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int I = 0; I < 2; ++I)
+#pragma unroll
+                    for (int J = 0; J < 2; ++J) Vd[I][J] = wv::mfma(Kd[I][v], Md[J][v], Vd[I][J]);
+        }
         float mk[8];
 #pragma unroll
         for (int a = 0; a < 8; ++a) mk[a] = MODE != 0 ? qu[a] + sym8_row(S, a, kk) : 0.f;
@@ -585,6 +598,7 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
     if (L.lane == 0 && p.old_costs) p.old_costs[L.b] = (float)old_cost;
     if (L.lane == 0 && p.qp_iters) p.qp_iters[L.b] = qp_total;
     if (L.lane == 0 && p.status) p.status[L.b] = status;
+    if (w0_out) *w0_out = w0;
     return old_cost;
 }
 
@@ -863,11 +877,191 @@ template <int MODE> MPC_DEV void rollout_wave(const P &p, const float *Kin, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Unconstrained step on a nominal that is KNOWN to obey the dynamics (MPC_OPT_NOMINAL_ON_DYNAMICS: what
+// MPC.forward hands to every step).  With linear dynamics and an exact quadratic model the cost along the search
+// direction is exactly J(alpha) = J(nominal) + (2 alpha - alpha^2) w0, w0 = sum_t 0.5 qu'k from the sweep -- the
+// same identity the 4-problems-per-wave kernel prices with (lqr_dpp16_body.h).  So the line search
+// (mpc/lqr_step.py:176-179, 247) is decided BEFORE the rollout, and the one pass that follows needs neither C
+// (6.4 of the 13 KB a rollout stage streams) nor the 36 MFMAs per step of C tau': stage = F | K_t | record,
+// four slots in the same LDS, the DMA three steps ahead.  Column r still rolls out alpha = decay^r (column 0 gives
+// full_du_norm, :243-245); the winner's column stores.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned LOFF_F = 0, LOFF_K = 5120, LOFF_R = 6144, LSTAGE_BYTES = 6656;
+constexpr int LSLOTS = 4, LDMA_PER_STAGE = 7;                  // 5 (F) + 1 (K) + 1 (record)
+static_assert(LSLOTS * LSTAGE_BYTES <= LDS_TOTAL, "lean rollout ring exceeds the wave's LDS");
+
+MPC_DEV void lstage_issue(const P &p, const RStream &d, const Lane &L, int t, int slot)
+{
+    const unsigned base = (unsigned)slot * LSTAGE_BYTES;
+    const long tl = t;
+    const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);      // F, f have T-1 entries
+    const long tx = t + 1 < p.T ? t + 1 : t;                         // x_{t+1}
+#pragma unroll
+    for (int k = 0; k < 5; ++k) wv::dma16(d.f_ptr + tf * d.f_step + 1024 * k, base + LOFF_F + 1024 * k);
+    wv::dma16(d.k_ptr + tl * d.k_step, base + LOFF_K);
+    // (lanes 0..9 would carry c_t, which this pass never looks at: they sit the instruction out)
+    wv::dma16_if(d.r_active && L.lane >= 10, d.r_ptr + (d.r_is_f ? tf : (d.r_is_x ? tx : tl)) * d.r_step, base + LOFF_R);
+}
+
+MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const float *kin, double old_cost, double w0)
+{
+    const int T = p.T;
+    RStream d;
+    rstream_init(d, p, L, Kin, kin);
+    float alpha = 1.f;
+    for (int i = 0; i < L.r; ++i) alpha *= p.ls_decay;            // column r tries decay^r
+    // first trial that is not worse than the nominal, else the last one (:176-179, 247)
+    int win = p.max_ls - 1;
+    {
+        float a = 1.f;
+        for (int j = 0; j < p.max_ls; ++j) {
+            const double cj = old_cost + (2.0 * (double)a - (double)a * (double)a) * w0;
+            if (!(cj > old_cost)) { win = j; break; }
+            a *= p.ls_decay;
+        }
+    }
+    float win_alpha = 1.f;
+    for (int i = 0; i < win; ++i) win_alpha *= p.ls_decay;
+    const bool store = L.r == win;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 Xd[2], DXd[2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Xd[I][v] = p.x_init[(long)L.b * NS + 16 * I + 4 * L.q + v];
+        DXd[I] = zero4;
+        if (store) wv::store_f32x4(p.new_x + (long)L.b * NS + 16 * I + 4 * L.q, Xd[I]);
+    }
+    float dacc = 0.f;
+    wv::dma_wait<0>();          // nothing of the sweep may still land in the ring
+#pragma unroll
+    for (int i = 0; i < LSLOTS - 1; ++i) lstage_issue(p, d, L, i < T ? i : T - 1, i);
+    for (int t = 0; t < T; ++t) {
+        // stages t+1, t+2 are in flight behind the one needed now (re-issuing the last stage at the tail keeps the count)
+        wv::dma_wait<(LSLOTS - 2) * LDMA_PER_STAGE>();
+        const unsigned base = (unsigned)(t % LSLOTS) * LSTAGE_BYTES;
+        const long tb = (long)t * p.B + L.b;
+        const unsigned rec = base + LOFF_R;
+        // ---- u' = K dx + u + alpha k   (:192)
+        f32x4 Ud = zero4;
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float x = wv::lds_f32(base + LOFF_K + 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 16 * (k >> 2) + 4 * L.q + (k & 3)));
+            a[k] = L.r < NC ? x : 0.f;
+        }
+        const unsigned qo = 16u * (unsigned)(L.q < 2 ? L.q : 0);
+        const f32x4 ub = wv::lds_f32x4(rec + 288 + qo), kb = wv::lds_f32x4(rec + 448 + qo);
+        {
+            const int tn = t + LSLOTS - 1;
+            lstage_issue(p, d, L, tn < T ? tn : T - 1, tn % LSLOTS);
+        }
+        wv::sched_fence();
+        {
+            // two half-length accumulation chains side by side (dependent MFMAs issue every 40 clocks, independent 32)
+            f32x4 U2 = zero4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                Ud = wv::mfma(a[k], DXd[0][k], Ud);
+                U2 = wv::mfma(a[4 + k], DXd[1][k], U2);
+            }
+            wv::sched_fence();
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Ud[v] += U2[v];
+        }
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float un = L.q < 2 ? Ud[v] + ub[v] + alpha * kb[v] : 0.f;
+                const float dd = L.q < 2 ? ub[v] - un : 0.f;
+                Ud[v] = un;
+                s = fmaf(dd, dd, s);
+            }
+            dacc += s;
+            if (store && L.q < 2) wv::store_f32x4(p.new_u + tb * NC + 4 * L.q, Ud);
+        }
+        // ---- x+ = F tau' + f   (:216-222)
+        if (t < T - 1) {
+            const long tb1 = (long)(t + 1) * p.B + L.b;
+            // both output tiles at once: operands of the two first, then their accumulation chains interleaved
+            f32x4 acc[2];
+            float fa[2][12];
+#pragma unroll
+            for (int Im = 0; Im < 2; ++Im) {
+                acc[Im] = zero4;
+                if (p.f) acc[Im] = wv::lds_f32x4(rec + 320 + 4u * (unsigned)(16 * Im + 4 * L.q));
+                const int row = 16 * Im + L.r;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    fa[Im][k] = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float x = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + (L.q < 2 ? 32 + 4 * L.q + v : 0)));
+                    fa[Im][8 + v] = L.q < 2 ? x : 0.f;
+                }
+            }
+            wv::sched_fence();
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][k], Xd[k >> 2][k & 3], acc[Im]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + v], Ud[v], acc[Im]);
+            wv::sched_fence();
+#pragma unroll
+            for (int Im = 0; Im < 2; ++Im) {
+                if (store) wv::store_f32x4(p.new_x + tb1 * NS + 16 * Im + 4 * L.q, acc[Im]);
+                DXd[Im] = acc[Im];
+            }
+#pragma unroll
+            for (int Im = 0; Im < 2; ++Im) {
+                const f32x4 xb = wv::lds_f32x4(rec + 160 + 4u * (unsigned)(16 * Im + 4 * L.q));
+                Xd[Im] = DXd[Im];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) DXd[Im][v] = Xd[Im][v] - xb[v];
+            }
+        }
+    }
+    wv::dma_wait<0>();
+    const float du2 = sum_q(dacc);
+    const float full2 = wv::readlane(du2, 0);
+    float wd = full2;
+    for (int j = 1; j < 16; ++j) {                   // (uniform loop; readlane wants a constant lane only in the kernel build)
+        const float dj = wv::readlane(du2, j);
+        if (j == win) wd = dj;
+    }
+    const double wc = old_cost + (2.0 * (double)win_alpha - (double)win_alpha * (double)win_alpha) * w0;
+    if (L.lane == 0) {
+        int status = 0;
+        if (!(wc == wc) || fabs(wc) > 3e38) status |= MPC_ST_NONFINITE;
+        if (p.costs) p.costs[L.b] = (float)wc;
+        if (p.full_du_norm) p.full_du_norm[L.b] = sqrtf(full2);
+        if (p.alpha_du_norm) p.alpha_du_norm[L.b] = sqrtf(wd);
+        if (p.alphas) p.alphas[L.b] = win_alpha;
+        if (p.status) p.status[L.b] |= status;
+    }
+}
+
 template <int MODE> MPC_DEV void step_wave(const P &p, float *K, float *k)
 {
-    const double old_cost = sweep_wave<MODE>(p, K, k);
+    double w0 = 0.0;
+    const double old_cost = sweep_wave<MODE>(p, K, k, &w0);
     wv::fence_own_stores();
-    rollout_wave<MODE>(p, K, k, old_cost);
+    if (MODE == 0 && p.on_dynamics) {
+        Lane L;
+        L.lane = wv::lane();
+        L.r = L.lane & 15;
+        L.q = L.lane >> 4;
+        L.b = wv::problem();
+        if (L.b >= p.B) return;
+        rollout_lean(p, L, K, k, old_cost, w0);
+    } else {
+        rollout_wave<MODE>(p, K, k, old_cost);
+    }
 }
 
 }  // namespace mfma40

@@ -417,7 +417,8 @@ class HipBackend:
         # nested solve of :328-340: one LQR step on (C, -r, F, f=None) from the zero nominal with
         # the active controls pinned; defaults linesearch_decay=0.2, max_linesearch_iter=10.
         zx, zu, z0 = self._zero_nominal(T, B, ns, nc, kw)
-        inner = StepOptions(u_zero_I=mask)
+        # (the zero nominal obeys x+ = F tau with f = None: the step may skip verifying it)
+        inner = StepOptions(u_zero_I=mask, nominal_on_dynamics=True)
         sol = self.lqr_step(z0, C, negr, F, None, zx, zu, inner, impl=impl)
         p, keep = self._problem(z0, C, c, F, f, x_star, u_star)
         has_f = f is not None and f.numel() > 0

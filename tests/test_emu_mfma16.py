@@ -406,13 +406,16 @@ def test_emulated_mfma40_sweep_on_the_reference_fixture(emu):
 
 
 @pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
-@pytest.mark.parametrize("case", ["plain", "T1", "no_f", "backtrack", "backtrack_ls3"])
-def test_emulated_mfma40_full_step(emu, case, dma_late):
+@pytest.mark.parametrize("vouch", [False, True], ids=["verified", "vouched"])
+@pytest.mark.parametrize("case", ["plain", "T1", "T2", "T5", "no_f", "backtrack", "backtrack_ls3"])
+def test_emulated_mfma40_full_step(emu, case, dma_late, vouch):
     """Sweep + rollout of the config-5 kernel: the 16 columns of the rolled-out state are the line-search
     trials (alpha = decay^r); a non-convex stage cost makes trials other than the first win, which are then
     replayed.  Against the oracle."""
     from oracle import lqr_oracle as O
-    T, B = (1, 2) if case == "T1" else (6, 3)
+    # vouch: MPC_OPT_NOMINAL_ON_DYNAMICS -- the unconstrained step decides its line search from the sweep's predicted
+    # cost change and rolls out once, without C (rollout_lean); same results as the pass that prices every trial
+    T, B = {"T1": (1, 2), "T2": (2, 2), "T5": (5, 2)}.get(case, (6, 3))
     for attempt in range(30):
         rng = np.random.default_rng(50 + len(case) + 1000 * attempt)
         kw = _cfg5_problem(rng, T, B)
@@ -427,7 +430,7 @@ def test_emulated_mfma40_full_step(emu, case, dma_late):
             break
     else:
         assert False, "no seed made the line search backtrack"
-    r = emu.lqr_step(kernel="mfma40", dma_late=dma_late, **kw, **opt)
+    r = emu.lqr_step(kernel="mfma40", dma_late=dma_late, nominal_on_dynamics=vouch, **kw, **opt)
     np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
     # the non-convex problems are ill-conditioned on purpose (gains of order 10^2): float32 keeps ~3 digits there
     wide = 20.0 if case.startswith("backtrack") else 1.0

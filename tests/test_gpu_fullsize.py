@@ -264,11 +264,13 @@ def test_simulator_step_full_batch_vs_oracle(be, kind, B, T, inline_linearize):
 # ------------------------------------------------------------------------------------------------
 # (d) config 5 with > 1 wave per SIMD and a partial last wave
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["unbounded", "bounded", "masked"])
+@pytest.mark.parametrize("mode", ["unbounded", "unbounded_vouched", "bounded", "masked"])
 def test_config5_full_waves_vs_oracle(be, mode):
     """ns=32 nc=8 T=64 (BASELINE configs[4]) at B = 1030 -- one wavefront per problem: 1030 waves > 1024 SIMDs,
     so some SIMDs hold two waves and the grid has a ragged tail -- on the register-resident MFMA kernel
-    (impl 5), against the float64 oracle: unconstrained, box-constrained (8-unknown pnqp), u_zero_I-masked."""
+    (impl 5), against the float64 oracle: unconstrained, box-constrained (8-unknown pnqp), u_zero_I-masked;
+    "vouched" = MPC_OPT_NOMINAL_ON_DYNAMICS, the unconstrained step's lean rollout (line search decided from the
+    sweep's predicted cost change, one pass without C)."""
     import bench
     from mpc import util
     from mpc._native import StepOptions, IMPL_MFMA40
@@ -277,6 +279,8 @@ def test_config5_full_waves_vs_oracle(be, mode):
     T, B = 64, full_batch(1030)
     p = bench.make_problem(32, 8, T, B, torch.float32, DEV, seed=21, u_scale=0.0 if mode != "bounded" else 0.3)
     kw, okw = {}, {}
+    if mode == "unbounded_vouched":
+        kw = dict(nominal_on_dynamics=True)
     if mode == "bounded":
         ub = 0.5
         p["cur_u"] = p["cur_u"].clamp(-ub, ub)

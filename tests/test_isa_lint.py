@@ -30,8 +30,7 @@ def _findings(name):
         if "scratch_" in l and not l.strip().startswith(";"):
             f["scratch"] += 1
         if "s_waitcnt vmcnt(0)" in l and "; counted" not in l:      # hand-written tail waits carry the marker
-            inner = sorted(b - a for a, b in loops if a <= i <= b)
-            if inner and inner[0] < 2000:        # a loop over timesteps, not the loop over line-search passes
+            if isa_lint.in_timestep_loop(lines, loops, i):
                 f["drains"] += 1
     return out
 

@@ -39,6 +39,23 @@ def structure(lines):
     return kernels, loops
 
 
+_DMA_LOOPS = {}
+
+
+def in_timestep_loop(lines, loops, i):
+    """Is line i inside a loop over timesteps?  = the smallest enclosing loop that stages data (has an LDS-DMA in its
+    body) and has no other staging loop nested inside it (the loop over line-search passes does)."""
+    key = id(lines)
+    if key not in _DMA_LOOPS:
+        _DMA_LOOPS[key] = [(a, b) for a, b in loops if any("_load_lds_" in x for x in lines[a:b])]
+    dma = _DMA_LOOPS[key]
+    around = sorted((b - a, a, b) for a, b in dma if a <= i <= b)
+    if not around:
+        return False
+    _, a, b = around[0]
+    return not any((c, d) != (a, b) and a <= c and d <= b and (d - c) < (b - a) - 50 for c, d in dma)
+
+
 def short(k):
     return re.sub(r"^_ZN6mpclqr12_GLOBAL__N_1\d+", "", k)[:48]
 
@@ -78,8 +95,7 @@ def main():
             if "scratch_" in l and not l.strip().startswith(";"):
                 per[ks[-1]][0] += 1
             if "s_waitcnt vmcnt(0)" in l and "; counted" not in l:      # hand-written tail waits carry the marker
-                inner = sorted(b - a for a, b in loops if a <= i <= b)
-                if inner and inner[0] < 3000:
+                if in_timestep_loop(lines, loops, i):
                     per[ks[-1]][1] += 1
         meta = dict(re.findall(r"\.name:\s+(\S+)[\s\S]*?\.vgpr_count:\s+(\d+)", "\n".join(lines)))
         for _, k in kernels:
