@@ -84,7 +84,7 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
     if (phase_mask == 3 && impl != 1 && !sp.env.kind) {
         if constexpr (sizeof(real) == 4) {
             // the fused kernels park their gains [T,B,64] in the workspace; out->K / out->k are optional
-            const int64_t need = (int64_t)p->T * p->B * 128 * (int64_t)sizeof(float);   // gain record + (m, M) record
+            const int64_t need = (int64_t)p->T * p->B * (128 + 16) * (int64_t)sizeof(float);   // gain record + (m, M) record + trial trajectory
             const bool have_ws = workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0);
             if ((sp.K == nullptr) != (sp.k == nullptr)) return fail(MPC_E_NULL, "pass both K and k, or neither");
             sp.Kk = (float *)workspace;
@@ -142,7 +142,8 @@ int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p)
     if (!p) return 0;
     const int64_t e = p->dtype == MPC_F64 ? 8 : 4;
     const int64_t generic = ((int64_t)p->T * p->B * p->nc * p->ns + (int64_t)p->T * p->B * p->nc) * e;
-    const int64_t fused = (int64_t)p->T * p->B * 128 * 4;     // gain records of the fused kernels
+    const int64_t fused = (int64_t)p->T * p->B * (128 + 16) * 4;     // gain records of the fused kernels + the second
+                                                                       // line-search trial's trajectory (box-constrained 12/4 kernel)
     return (generic > fused ? generic : fused) + 256;
 }
 

@@ -320,6 +320,8 @@ struct Lane {
     int aS[4];            // SG + p*256 + 16 (12 + max(a,b)) + 4 min(a,b)   (Quu[a][b], see lane_init)
     float *out0;          // this lane's element of new_x / new_u at t = 0 ...
     long ostep;           // ... and its stride per timestep
+    float *scr0;          // this lane's element of the second trial's trajectory [T,B,16] (workspace) at t = 0
+    long ostep1;          // = 16 B
     int aMrow;            // SC + p*256 + 4 a                   (second record; + RollRing::MADJ)
 };
 
@@ -915,6 +917,10 @@ struct RoState {
     float viol;       // > 0 once the nominal broke the dynamics somewhere
     float *out;       // this lane's element of new_x / new_u at the current timestep
     bool price_on;    // (wave-uniform) some row of this pass steps off the sweep's policy: the identity's terms are not all zero
+    // the pair pass of the box-constrained line search: a second trial (alpha = decay) rolled out beside the first, its
+    // trajectory parked in the workspace
+    float xs1, cost1, du21;
+    float *out1;
 };
 
 // new_u = K dx + u + alpha k (mpc/lqr_step.py:192), zero mask (:197-198), box / delta_u clamp (:200-213);
@@ -969,7 +975,7 @@ MPC_DEV float stage_price(const Lane &L, const RoStage &s, float tp, float e, fl
     return L.isu ? e * lin : 0.f;
 }
 
-template <int MODE, bool DIRECT, bool CHECK>
+template <int MODE, bool DIRECT, bool CHECK, bool PAIR = false>
 MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &st, int t, Feed<MODE, true, DIRECT> &feed)
 {
     const bool last = (t == p.T - 1);
@@ -1009,6 +1015,24 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
         wv::dot_bcast16(xn, tp, s.Fr);
         st.xs = xn;
     }
+    if (PAIR) {
+        // the second trial, alpha = decay, off the same stage registers
+        float e1, dx1;
+        const float un1 = control_law<MODE>(p, L, s, st.xs1, p.ls_decay, e1, dx1);
+        const float tp1 = L.isu ? un1 : st.xs1;
+        st.cost1 += stage_price<MODE, DIRECT>(L, s, tp1, e1, dx1);
+        {
+            const float d = sel(L.isu, s.tb - un1, 0.f);
+            st.du21 = fmaf(d, d, st.du21);
+        }
+        wv::store_out(st.out1, tp1);
+        st.out1 += L.ostep1;
+        if (!last) {
+            float xn = s.fj;
+            wv::dot_bcast16(xn, tp1, s.Fr);
+            st.xs1 = xn;
+        }
+    }
 }
 
 // The line-search trials alpha = decay^k rolled out side by side off ONE pass over the data (read from LDS
@@ -1042,7 +1066,7 @@ MPC_DEV void trials_step(const P &p, const Lane &L, const RoStage &s, Trials &tr
 // One pass over the horizon.  MULTI: the nt trials of tr (costs only); otherwise the single trial of st
 // (trajectory stored).  Costs come back as full trajectory costs (base = J_nominal + w_0 when priced by
 // the identity, 0 when priced directly).
-template <int MODE, bool MULTI, bool DIRECT, bool CHECK>
+template <int MODE, bool MULTI, bool DIRECT, bool CHECK, bool PAIR = false>
 MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gains<rgm(MODE)> &G, RoState &st, Trials &tr, int nt, float base PROF_ARG)
 {
     const int T = p.T;
@@ -1059,6 +1083,12 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gai
         st.du2 = 0.f;
         st.pred = 0.f;
         st.out = L.out0;
+        if (PAIR) {
+            st.xs1 = x0;
+            st.cost1 = 0.f;
+            st.du21 = 0.f;
+            st.out1 = L.scr0;
+        }
     }
     st.price_on = MULTI || wv::any(st.alpha != 1.f);
     const bool use_zm = con(MODE) && p.zero_mask != nullptr;
@@ -1102,7 +1132,7 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gai
                     feed.template part<0>(); feed.template part<1>(); feed.template part<2>(); feed.template part<3>();
                     trials_step<MODE, DIRECT>(p, L, s, tr, nt, t);
                 } else {
-                    rollout_step<MODE, DIRECT, CHECK>(p, L, s, st, t, feed);
+                    rollout_step<MODE, DIRECT, CHECK, PAIR>(p, L, s, st, t, feed);
                 }
                 if (use_zm) zq[(i + LA) % NS] = zm_pick(L, zr);
             }
@@ -1116,6 +1146,10 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gai
     } else {
         st.cost = base + wv::row_sum(st.cost);
         st.du2 = wv::row_sum(st.du2);
+        if (PAIR) {
+            st.cost1 = base + wv::row_sum(st.cost1);
+            st.du21 = wv::row_sum(st.du21);
+        }
     }
 }
 
@@ -1130,6 +1164,55 @@ MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, const Gain
     Trials tr;
     rs.alpha = 1.f;
     bool worse0 = false;
+    if (MODE == 2 && !DIRECT && p.max_ls >= 2) {
+        // Box constraints: one problem in six steps back to alpha = decay, i.e. every second wave -- and the slowest wave
+        // is the kernel's time.  The first pass therefore rolls out alpha = 1 AND alpha = decay side by side (one read of
+        // the stage, two states; the second trajectory goes to the workspace); a row that takes the second trial copies
+        // it over afterwards.  Only a row that rejects both (rare) sends the wave into the remaining trials + a replay.
+        rollout_pass<MODE, false, DIRECT, CHECK, true>(p, L, d, wave, G, rs, tr, 0, base PROF_PASS);
+        full2 = rs.du2;                                              // :243-245 (the alpha = 1 trial)
+        worse0 = rs.cost > old_cost;
+        if (!wv::any(worse0)) return;
+        const bool worse1 = worse0 && rs.cost1 > old_cost && p.max_ls > 2;
+        if (worse0) {
+            rs.alpha = p.ls_decay;
+            rs.cost = rs.cost1;
+            rs.du2 = rs.du21;
+        }
+        if (!wv::any(worse1)) {
+            // trajectory of the second trial -> new_x / new_u, rows that took it (the stores of this wave's own pass
+            // must have landed: they are read back through the vector path)
+            wv::fence_own_stores();
+            const float *src = L.scr0;
+            float *dst = L.out0;
+            for (int t = 0; t < p.T; ++t) {
+                const float v = *src;
+                if (worse0) wv::store_out(dst, v);
+                src += L.ostep1;
+                dst += L.ostep;
+            }
+            return;
+        }
+        const int nt = p.max_ls - 2;                                 // trials alpha = decay^2 .. decay^(max_ls-1)
+        float a = p.ls_decay;
+#pragma unroll
+        for (int k = 0; k < MAX_TRIALS; ++k) { a *= p.ls_decay; tr.alpha[k] = a; }
+        rollout_pass<MODE, true, DIRECT, CHECK>(p, L, d, wave, G, rs, tr, nt, base PROF_PASS);
+        if (worse1) {
+            float acc = tr.alpha[0];
+            bool found = false;
+#pragma unroll
+            for (int k = 0; k < MAX_TRIALS; ++k) {
+                if (k < nt && !found) {
+                    acc = tr.alpha[k];
+                    if (!(tr.cost[k] > old_cost)) found = true;
+                }
+            }
+            rs.alpha = acc;
+        }
+        rollout_pass<MODE, false, DIRECT, CHECK>(p, L, d, wave, G, rs, tr, 0, base PROF_PASS);       // replay: every row stores its accepted trial
+        return;
+    }
 #pragma unroll 1
     for (int phase = 0; phase < 3; ++phase) {
         rollout_pass<MODE, false, DIRECT, CHECK>(p, L, d, wave, G, rs, tr, 0, base PROF_PASS);   // rows whose alpha did not change reproduce their result
@@ -1174,6 +1257,8 @@ MPC_DEV void step_wave(const P &p)
     lane_init(L, lane, wave, p.B);
     L.out0 = L.isu ? p.new_u + (long)L.pb * 4 + L.a : p.new_x + (long)L.pb * 12 + L.j;
     L.ostep = L.isu ? (long)p.B * 4 : (long)p.B * 12;
+    L.scr0 = p.Kk + (long)p.T * p.B * 128 + (long)L.pb * 16 + L.j;      // behind the two records
+    L.ostep1 = (long)p.B * 16;
     const int T = p.T;
     Dma d;
     Gains<rgm(MODE)> G;

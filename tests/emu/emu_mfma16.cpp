@@ -423,7 +423,7 @@ extern "C" int emu_lqr_step_dpp16(const mpc_lqr_problem *p, const mpc_lqr_option
     if (!sp.new_x || !sp.new_u) return MPC_E_NULL;
     static float *kk_buf = nullptr;
     static size_t kk_cap = 0;
-    const size_t need = (size_t)sp.T * sp.B * 128 + 4;
+    const size_t need = (size_t)sp.T * sp.B * (128 + 16) + 4;     // two records + the second trial's trajectory
     if (need > kk_cap) { free(kk_buf); kk_buf = (float *)aligned_alloc(16, (need * sizeof(float) + 15) / 16 * 16); kk_cap = need; }
     for (size_t i = 0; i < need; ++i) kk_buf[i] = NAN;
     sp.Kk = kk_buf;
