@@ -139,6 +139,14 @@ MPC_DEV float quad_sums(float p0, float p1, float p2, float p3, int j)
     return r;
 }
 
+// Sum over the four quads of a row (lanes j, j+4, j+8, j+12 of the same row): two row rotations.
+MPC_DEV float ring_sum(float r)
+{
+    r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x124, 0xf, 0xf, true));                      // row_ror:4
+    r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x128, 0xf, 0xf, true));                      // row_ror:8
+    return r;
+}
+
 // ---- the gains of the whole horizon in the accumulation half of the register file (mode 0) ----------------------
 // a[4t .. 4t+3] = the four gain registers of timestep t.  The compiler never allocates AccVGPRs in this kernel (its
 // MFMAs accumulate in VGPRs, -amdgpu-mfma-vgpr-form, and it stays under 256 VGPRs -- tests/test_isa_lint.py checks

@@ -127,32 +127,41 @@ using mfma16::sel;
 //   * free-set flags are numbers (0 / 1) and the masked matrix is built by multiplication, not by selects on
 //     combined lane masks (see ldl4).
 // ---------------------------------------------------------------------------
-MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const float ub[4], int n_iter,
+MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const float ub[4], int n_iter, int j,
                        float x[4], bool fr_out[4], Ldl4 &f, bool &converged)
 {
+    // Everything that is one number per unknown (x, g, the bounds, the free-set flags, the step) lives as ONE register
+    // with unknown a in the lanes of quad a (lanes 4a..4a+3 of the row): a clamp, a compare, a gradient update is one
+    // instruction instead of four.  H x is four multiply-adds whose x operand is a DPP broadcast of lane 4b against
+    // column b of H (quad a holds H[a][b]); sums over the unknowns are two row rotations (wv::ring_sum).  Only the
+    // factorisation and its triangular solves stay row-uniform scalars, fed by broadcasts.
     const float reg = 1e-11f;                                       // :47
     const float dg[4] = {s.s00 + reg - 1.f, s.s11 + reg - 1.f, s.s22 + reg - 1.f, s.s33 + reg - 1.f};
-    float m[4] = {-1.f, -1.f, -1.f, -1.f};                          // free set of the last factorisation (none yet)
+    const bool q0 = j < 4, q1 = j < 8, q2 = j < 12;
+#define MPC_QV(v0, v1, v2, v3) (q0 ? (v0) : (q1 ? (v1) : (q2 ? (v2) : (v3))))
+    const float Hc[4] = {MPC_QV(s.s00, s.s01, s.s02, s.s03), MPC_QV(s.s01, s.s11, s.s12, s.s13),
+                         MPC_QV(s.s02, s.s12, s.s22, s.s23), MPC_QV(s.s03, s.s13, s.s23, s.s33)};
+    const float lbv = MPC_QV(lb[0], lb[1], lb[2], lb[3]), ubv = MPC_QV(ub[0], ub[1], ub[2], ub[3]);
+    float xv = MPC_QV(x[0], x[1], x[2], x[3]);
+    float mv = -1.f;                                                // free set of the last factorisation (none yet)
     float done = 0.f, conv = 0.f, full = 0.f, it_ret = (float)(n_iter - 1);
     // The gradient H x + q (:29) is carried along: every step d is followed by g += H d, and H d is also what the
     // Armijo test of a projected step needs (:61-76) -- one product serves both.
-    float g[4];
-    mfma16::sym4_mv(s, x, g);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) g[a] += q[a];
+    // (same order of additions as sym4_mv: the products are bit-identical to the row-uniform form)
+#define MPC_HV(out, v) do { out = wv::bcast<0>(v) * Hc[0]; wv::fmac_bcast<4>(out, v, Hc[1]); \
+                            wv::fmac_bcast<8>(out, v, Hc[2]); wv::fmac_bcast<12>(out, v, Hc[3]); } while (0)
+    float gv;
+    MPC_HV(gv, xv);
+    gv += MPC_QV(q[0], q[1], q[2], q[3]);
     MPC_STAT(4);
     for (int it = 0; it < n_iter; ++it) {
         if (done == 0.f) MPC_STAT(0);
         MPC_STAT(5);
-        float mn[4], diff = 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            // :32  clamped = (x == lb & g > 0) | (x == ub & g < 0)
-            const float r_lo = (x[a] == lb[a]) ? g[a] : -1.f;
-            const float r_hi = (x[a] == ub[a]) ? -g[a] : -1.f;
-            mn[a] = (fmaxf(r_lo, r_hi) > 0.f) ? 0.f : 1.f;
-            diff += fabsf(mn[a] - m[a]);
-        }
+        // :32  clamped = (x == lb & g > 0) | (x == ub & g < 0)
+        const float r_lo = (xv == lbv) ? gv : -1.f;
+        const float r_hi = (xv == ubv) ? -gv : -1.f;
+        const float mnv = (fmaxf(r_lo, r_hi) > 0.f) ? 0.f : 1.f;
+        const float diff = wv::ring_sum(fabsf(mnv - mv));
         // the free set just factorised, reached by a full Newton step: the step from here is zero -- converged (:56-59)
         const bool confirmed = (diff == 0.f) & (full != 0.f) & (done == 0.f);
         it_ret = confirmed ? (float)it : it_ret;
@@ -162,6 +171,7 @@ MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const
         if (done == 0.f) MPC_STAT(1);
         MPC_STAT(6);
         // :44-54  H_ = H on the free block (+1e-11 I, identity elsewhere), dx = -H_^-1 g_
+        const float mn[4] = {wv::bcast<0>(mnv), wv::bcast<4>(mnv), wv::bcast<8>(mnv), wv::bcast<12>(mnv)};
         Ldl4 fn;
         {
             const float a10 = (mn[0] * mn[1]) * s.s01, a20 = (mn[0] * mn[2]) * s.s02, a30 = (mn[0] * mn[3]) * s.s03;
@@ -182,18 +192,14 @@ MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const
             const float d3 = fmaf(-fn.l32, t32, fmaf(-fn.l31, t31, fmaf(-fn.l30, a30, a33)));
             fn.i3 = wv::rcp(d3);
         }
-        float y[4], dx[4];
-        ldl4_solve(fn, mn[0] * g[0], mn[1] * g[1], mn[2] * g[2], mn[3] * g[3], y);
-        float nrm2 = 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            dx[a] = -(mn[a] * y[a]);
-            nrm2 = fmaf(dx[a], dx[a], nrm2);
-        }
+        const float rv = mnv * gv;
+        float y[4];
+        ldl4_solve(fn, wv::bcast<0>(rv), wv::bcast<4>(rv), wv::bcast<8>(rv), wv::bcast<12>(rv), y);
+        const float dxv = -(mnv * MPC_QV(y[0], y[1], y[2], y[3]));
+        const float nrm2 = wv::ring_sum(dxv * dxv);
         // what this trip factorised is what the solve returns for every row (frozen rows recompute their own)
         f = fn;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) m[a] = mn[a];
+        mv = mnv;
         const bool small = !(nrm2 >= 1e-8f) & (done == 0.f);        // |dx| < 1e-4  (:56-59)
         it_ret = small ? (float)it : it_ret;
         conv = small ? 1.f : conv;
@@ -201,58 +207,41 @@ MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const
         // :61-78  the step: x + dx when that stays inside the box (its Armijo ratio is exactly 1/2, see pnqp4), else the
         // projection of x + alpha dx with alpha = 1, 0.1, ... by the Armijo rule.  d = step taken (0 on a converged row).
         const float live = 1.f - done;
-        float xc[4], d[4], hd[4], out = 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float xn = x[a] + dx[a];
-            xc[a] = eclampf(xn, lb[a], ub[a]);
-            out += fabsf(xc[a] - xn);
-            d[a] = (xc[a] - x[a]) * live;
-        }
-        mfma16::sym4_mv(s, d, hd);
+        const float xnv = xv + dxv;
+        float xcv = eclampf(xnv, lbv, ubv);
+        const float out = wv::ring_sum(fabsf(xcv - xnv));
+        float dv = (xcv - xv) * live, hdv;
+        MPC_HV(hdv, dv);
         const bool inside = out == 0.f;
         full = inside ? 1.f : 0.f;
         const bool test = !inside & (done == 0.f);
         if (wv::any(test)) {
             if (test) MPC_STAT(2);
             // f(x) - f(m) = -g'd - d'Hd/2 with d = m - x, against 0.1 g'(x - m)
-            float den = 0.f, dhd = 0.f;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                den = fmaf(-g[a], d[a], den);
-                dhd = fmaf(d[a], hd[a], dhd);
-            }
+            const float den = wv::ring_sum(-gv * dv), dhd = wv::ring_sum(dv * hdv);
             const float arm = fmaf(-0.5f, dhd, den) * wv::rcp(den);
             if (test & (arm <= 0.1f)) {
                 // (rare: one QP in a hundred) shorter steps, this row only
                 float alpha = 0.1f;
                 for (int count = 1; count < 10; ++count) {
                     MPC_STAT(3);
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        xc[a] = eclampf(fmaf(alpha, dx[a], x[a]), lb[a], ub[a]);
-                        d[a] = xc[a] - x[a];
-                    }
-                    mfma16::sym4_mv(s, d, hd);
-                    float den2 = 0.f, dhd2 = 0.f;
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        den2 = fmaf(-g[a], d[a], den2);
-                        dhd2 = fmaf(d[a], hd[a], dhd2);
-                    }
+                    xcv = eclampf(fmaf(alpha, dxv, xv), lbv, ubv);
+                    dv = xcv - xv;
+                    MPC_HV(hdv, dv);
+                    const float den2 = wv::ring_sum(-gv * dv), dhd2 = wv::ring_sum(dv * hdv);
                     const float arm2 = fmaf(-0.5f, dhd2, den2) * wv::rcp(den2);
                     if (arm2 <= 0.1f) alpha *= 0.1f; else break;
                 }
             }
         }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            x[a] = (done != 0.f) ? x[a] : xc[a];                    // :78 (a converged row keeps its x)
-            g[a] += hd[a];
-        }
+        xv = (done != 0.f) ? xv : xcv;                              // :78 (a converged row keeps its x)
+        gv += hdv;
     }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) fr_out[a] = m[a] != 0.f;
+#undef MPC_HV
+#undef MPC_QV
+    x[0] = wv::bcast<0>(xv); x[1] = wv::bcast<4>(xv); x[2] = wv::bcast<8>(xv); x[3] = wv::bcast<12>(xv);
+    fr_out[0] = wv::bcast<0>(mv) != 0.f; fr_out[1] = wv::bcast<4>(mv) != 0.f;
+    fr_out[2] = wv::bcast<8>(mv) != 0.f; fr_out[3] = wv::bcast<12>(mv) != 0.f;
     converged = conv != 0.f;
     return (int)it_ret;
 }
@@ -718,7 +707,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #pragma unroll
         for (int a = 0; a < 4; ++a) kq[a] = eclampf(kq[a], lb[a], ub[a]);
         bool conv = false;
-        const int it = pnqp4_rows(S, qu, lb, ub, p.pnqp_iter, kq, fr, f, conv);
+        const int it = pnqp4_rows(S, qu, lb, ub, p.pnqp_iter, L.j, kq, fr, f, conv);
         st.qp_total += 1 + it;                                      // :140
         if (!conv) st.status |= MPC_ST_PNQP_UNCONVERGED;
         st.warm = 1;

@@ -261,6 +261,19 @@ static inline float quad_sums(float p0, float p1, float p2, float p3, int j)
     const float s2 = q[(me + 2) & 3] + q[(me + 3) & 3];
     return s1 + s2;
 }
+// wv::ring_sum of lqr_dpp16.hip: x + row_ror:4, then + row_ror:8 (lane j receives lane j - n of its row)
+static inline float ring_sum(float x)
+{
+    emu::Wave &w = emu::W;
+    for (int n = 4; n <= 8; n += 4) {
+        const int l = w.cur, gen = w.seq[l]++ & 1;
+        w.fa[gen][l] = x;
+        emu::yield_lane();
+        const int r = l & ~15, j = l & 15;
+        x += w.fa[gen][r + ((j - n) & 15)];
+    }
+    return x;
+}
 static inline double row_sum_f64(double x)
 {
     emu::Wave &w = emu::W;
