@@ -8,14 +8,81 @@ ships and of the rollout that calls them.
                   purpose NOT by the closed form the kernels use, so the two are independent.
   rollout         mpc/lqr_step.py:164-261 with a module as true_dynamics (:223-225) and a QuadCost
                   as true cost (:230-232), one problem at a time (= the reference with n_batch 1).
+  mlp_step / mlp_jacobian   mpc/dynamics.py:57-80 (NNDynamics.forward) and :82-128 (grad_input): kind MLP, whose
+                  `params` is an `Mlp` (weights, biases, activation, passthrough) instead of a parameter vector.
 
 Parity status: pinned -- tests/test_oracle_golden.py checks all three against outputs of the
 reference's own modules (tests/golden/env_*.npz).  Only tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline may import this file."""
 import numpy as np
 
-PENDULUM, PENDULUM_FULL, CARTPOLE = 1, 2, 3
+PENDULUM, PENDULUM_FULL, CARTPOLE, MLP = 1, 2, 3, 4
 DT = 0.05
+
+
+class Mlp:
+    """The network of mpc/dynamics.py:15-36: Linear layers (weights [out, in], biases [out]), the same activation
+    after every layer but the last, `passthrough` adds the state to the output (:74-75)."""
+
+    def __init__(self, Ws, bs, activation="sigmoid", passthrough=True):
+        self.Ws = [np.asarray(W, dtype=np.float64) for W in Ws]
+        self.bs = [np.asarray(b, dtype=np.float64) for b in bs]
+        assert activation in ("sigmoid", "relu", "elu")
+        self.activation, self.passthrough = activation, bool(passthrough)
+
+    @classmethod
+    def from_npz(cls, z):
+        L = int(z["nn_meta"][0])
+        return cls([z["W%d" % i] for i in range(L)], [z["b%d" % i] for i in range(L)],
+                   ("sigmoid", "relu", "elu")[int(z["nn_meta"][1])], bool(z["nn_meta"][2]))
+
+
+def _act(z, kind):
+    if kind == "sigmoid":
+        return 1.0 / (1.0 + np.exp(-z))
+    if kind == "relu":
+        return np.maximum(z, 0.0)
+    return np.where(z > 0, z, np.expm1(np.minimum(z, 0.0)))                              # F.elu, alpha = 1
+
+
+def mlp_hidden(x, u, net):
+    """Activations of every hidden layer and the output, at points x [N,ns], u [N,nc] (mpc/dynamics.py:66-72)."""
+    z = np.concatenate((np.asarray(x, dtype=np.float64), np.asarray(u, dtype=np.float64)), 1)
+    zs = []
+    for i, (W, b) in enumerate(zip(net.Ws, net.bs)):
+        z = z @ W.T + b
+        if i + 1 < len(net.Ws):
+            z = _act(z, net.activation)
+            zs.append(z)
+    return zs, z
+
+
+def mlp_step(x, u, net):
+    _, out = mlp_hidden(x, u, net)
+    return out + np.asarray(x, dtype=np.float64) if net.passthrough else out              # :74-75
+
+
+def mlp_jacobian(x, u, net):
+    """d mlp_step / d [x;u] at every point, [N, ns, ns+nc] (grad_input, mpc/dynamics.py:82-128: the chain
+    W_L diag(act'(z_{L-1})) W_{L-1} ... with act' = z (1 - z) for the sigmoid and [z > 0] for relu; elu is not
+    implemented there (`assert False`), its slope here is 1 / z + 1 on the two branches)."""
+    zs, _ = mlp_hidden(x, u, net)
+    N, ns = np.asarray(x).shape
+    J = None
+    for W, z in zip(net.Ws[:-1], zs):
+        if net.activation == "sigmoid":
+            d = z * (1.0 - z)
+        elif net.activation == "relu":
+            d = (z > 0).astype(np.float64)
+        else:
+            d = np.where(z > 0, 1.0, z + 1.0)
+        G = d[:, :, None] * W[None]
+        J = G if J is None else np.einsum("nij,njk->nik", G, J)
+    last = net.Ws[-1]
+    J = np.broadcast_to(last, (N,) + last.shape).copy() if J is None else np.einsum("ij,njk->nik", last, J)
+    if net.passthrough:
+        J[:, :, :ns] += np.eye(ns)
+    return J
 
 
 def u_max_of(kind):
@@ -54,6 +121,8 @@ def cartpole_step(st, u, params, dt=DT, force_mag=100.0):
 
 
 def step(kind, x, u, params, clamp=True):
+    if kind == MLP:
+        return mlp_step(x, u, params)
     lim = u_max_of(kind) if clamp else np.inf
     if kind == CARTPOLE:
         return cartpole_step(x, u, params, force_mag=lim)
@@ -66,6 +135,9 @@ def linearize(kind, x, u, params, h=2e-4):
     u = np.asarray(u, dtype=np.float64)
     N, ns = x.shape
     tau = np.concatenate((x, u), 1)
+    if kind == MLP:                 # closed form, like the reference's own ANALYTIC path (mpc/mpc.py:495-512)
+        F = mlp_jacobian(x, u, params)
+        return F, mlp_step(x, u, params) - np.einsum("nij,nj->ni", F, tau)
     F = np.empty((N, ns, ns + 1))
 
     # The control enters through clamp(u, -u_max, u_max) only; differences are taken of the smooth

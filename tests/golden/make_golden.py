@@ -307,6 +307,56 @@ def env_lin_case(name, kind, T, B, seed, simple=True, params=None):
          step_new_u=npy(new_u), step_costs=npy(costs), step_full_du_norm=npy(fdn))
 
 
+def nn_case(name, seed, ns, nc, hidden, act, passthrough, T, B, bound, decay=0.2, max_ls=10, lqr_iter=6,
+            w_scale=1.0):
+    """mpc.dynamics.NNDynamics (mpc/dynamics.py:15-128) as the dynamics: the module at random points (forward and
+    grad_input), MPC.linearize_dynamics(ANALYTIC) along a nominal, ONE reference LQRStep with the module as
+    true_dynamics (mpc/lqr_step.py:223-225), and a whole MPC.forward solve."""
+    from mpc_ref.dynamics import NNDynamics
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed)
+    f64 = torch.float64
+    dyn = NNDynamics(ns, nc, list(hidden), activation=act, passthrough=passthrough).double()
+    with torch.no_grad():
+        for fc in dyn.fcs:
+            fc.weight.mul_(w_scale)
+    n = ns + nc
+    N = 24
+    px = torch.randn(N, ns, generator=g, dtype=f64)
+    pu = torch.randn(N, nc, generator=g, dtype=f64)
+    with torch.no_grad():
+        pnext = dyn(px, pu)
+        pR, pS = dyn.grad_input(px, pu)
+    x_init = torch.randn(B, ns, generator=g, dtype=f64)
+    u0 = 0.3 * torch.randn(T, B, nc, generator=g, dtype=f64)
+    A = torch.randn(T, B, n, n, generator=g, dtype=f64)
+    C = A.transpose(2, 3).matmul(A) + 0.1 * torch.eye(n, dtype=f64)
+    c = torch.randn(T, B, n, generator=g, dtype=f64)
+    with torch.no_grad():
+        x0 = ref_util.get_traj(T, u0, x_init, dyn)
+    lo, hi = (None, None) if bound is None else (-float(bound), float(bound))
+    ctrl = ref_mpc.MPC(ns, nc, T, u_lower=lo, u_upper=hi, lqr_iter=lqr_iter, verbose=-1,
+                       exit_unconverged=False, detach_unconverged=False, linesearch_decay=decay,
+                       max_linesearch_iter=max_ls, grad_method=ref_mpc.GradMethods.ANALYTIC, u_init=u0.clone())
+    F0, f0 = ctrl.linearize_dynamics(x0, u0, dyn, diff=False)
+    fn = ref_step.LQRStep(n_state=ns, n_ctrl=nc, T=T, u_lower=lo, u_upper=hi, linesearch_decay=decay,
+                          max_linesearch_iter=max_ls, true_cost=QuadCost(C, c), true_dynamics=dyn,
+                          delta_space=True, current_x=x0, current_u=u0)
+    with torch.no_grad():
+        (new_x, new_u, nqp, costs, fdn, mean_alpha), _ = quiet(fn, x_init, C, c, F0, f0)
+    (sx, su, scosts), _ = quiet(ctrl, x_init, QuadCost(C, c), dyn)
+    arrs = {}
+    for i, fc in enumerate(dyn.fcs):
+        arrs["W%d" % i], arrs["b%d" % i] = npy(fc.weight), npy(fc.bias)
+    save(name, meta=np.array([ns, nc, T, B, lqr_iter]),
+         nn_meta=np.array([len(dyn.fcs), ("sigmoid", "relu", "elu").index(act), int(passthrough)]),
+         bound=np.array([np.nan if bound is None else bound]), decay=np.array([decay]), max_ls=np.array([max_ls]),
+         px=npy(px), pu=npy(pu), pnext=npy(pnext), pR=npy(pR), pS=npy(pS),
+         x_init=npy(x_init), C=npy(C), c=npy(c), step_cur_x=npy(x0), step_cur_u=npy(u0), step_F=npy(F0),
+         step_f=npy(f0), step_new_x=npy(new_x), step_new_u=npy(new_u), step_costs=npy(costs),
+         step_full_du_norm=npy(fdn), solve_x=npy(sx), solve_u=npy(su), solve_costs=npy(scosts), **arrs)
+
+
 def slew_case(name, seed, ns=2, nc=2, T=4, B=2, gamma=1.0, prev=False):
     """tests/test_mpc.py:652-744 (test_lqr_backward_cost_nn_dynamics_module_constrained_slew): MPC with
     slew_rate_penalty on an NNDynamics module, box constraints, ANALYTIC linearisation; the solve and
@@ -534,6 +584,14 @@ if __name__ == "__main__":
     if only and "misc" not in only:
         pnqp_case = lambda *a, **k: None
         traj_cost_case = lambda: None
+    # ---- NNDynamics as the dynamics (`nn` alone regenerates just these) -----
+    if not only or "nn" in only:
+        nn_case("nn_sigmoid_f64", 71, 4, 2, [24], "sigmoid", True, 8, 5, 1.0)
+        nn_case("nn_relu2_f64", 72, 6, 3, [20, 12], "relu", True, 7, 4, None, w_scale=1.5)
+        nn_case("nn_headline_f64", 73, 12, 4, [100], "sigmoid", True, 10, 6, 0.5)
+        nn_case("nn_nopass_f64", 74, 3, 1, [16, 16, 8], "sigmoid", False, 6, 4, 0.8, decay=0.5, max_ls=4)
+    if only == {"nn"}:
+        sys.exit(0)
     # ---- single LQR steps -------------------------------------------------
     step_case("step_cfg1_f64", 4, 2, 10, 8, f64, 11, bounds="tensor")
     step_case("step_cfg1_f32", 4, 2, 10, 8, f32, 11, bounds="tensor")

@@ -201,6 +201,51 @@ def test_env_oracle_matches_reference_modules(name, kind):
     np.testing.assert_allclose(old, E.quad_cost(z["Q"], z["p"], z["step_cur_x"], z["step_cur_u"]), rtol=1e-13)
 
 
+NN_CASES = ["nn_sigmoid_f64", "nn_relu2_f64", "nn_headline_f64", "nn_nopass_f64"]
+
+
+@pytest.mark.parametrize("name", NN_CASES)
+def test_mlp_oracle_matches_reference_nndynamics(name):
+    """mlp_step == NNDynamics.forward, mlp_jacobian == NNDynamics.grad_input (mpc/dynamics.py:57-128), linearize ==
+    MPC.linearize_dynamics(ANALYTIC) (mpc/mpc.py:495-512), rollout == LQRStep with the module as true_dynamics."""
+    from oracle import env_oracle as E
+    z = golden(name)
+    ns, nc, T, B = (int(v) for v in z["meta"][:4])
+    net = E.Mlp.from_npz(z)
+    np.testing.assert_allclose(E.mlp_step(z["px"], z["pu"], net), z["pnext"], rtol=1e-12, atol=1e-12)
+    J = E.mlp_jacobian(z["px"], z["pu"], net)
+    np.testing.assert_allclose(J[:, :, :ns], z["pR"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(J[:, :, ns:], z["pS"], rtol=1e-12, atol=1e-12)
+    if net.activation == "sigmoid":            # smooth: the closed form is also the derivative of mlp_step
+        h = 1e-5
+        for j in range(ns + nc):
+            e = np.zeros(ns + nc)
+            e[j] = h
+            d = (E.mlp_step(z["px"] + e[:ns], z["pu"] + e[ns:], net) - E.mlp_step(z["px"] - e[:ns], z["pu"] - e[ns:], net)) / (2 * h)
+            np.testing.assert_allclose(J[:, :, j], d, rtol=1e-6, atol=1e-8)
+    xr = E.traj(E.MLP, z["x_init"], z["step_cur_u"], net)
+    np.testing.assert_allclose(xr, z["step_cur_x"], rtol=1e-12, atol=1e-12)
+    F, f = E.linearize(E.MLP, xr[:-1].reshape(-1, ns), z["step_cur_u"][:-1].reshape(-1, nc), net)
+    np.testing.assert_allclose(F, z["step_F"].reshape(F.shape), rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(f, z["step_f"].reshape(f.shape), rtol=1e-11, atol=1e-11)
+    bound = float(z["bound"][0])
+    lo, hi = (None, None) if np.isnan(bound) else (-bound, bound)
+    o = O.lqr_step(z["x_init"], z["C"], z["c"], z["step_F"], z["step_f"], z["step_cur_x"], z["step_cur_u"], lo, hi,
+                   linesearch_decay=float(z["decay"][0]), max_linesearch_iter=int(z["max_ls"][0]), return_gains=True)
+    nx, nu, costs, full, alphas = E.rollout(E.MLP, net, z["x_init"], z["C"], z["c"], o["K"], o["k"], z["step_cur_x"],
+                                            z["step_cur_u"], lo, hi, float(z["decay"][0]), int(z["max_ls"][0]))
+    np.testing.assert_allclose(nx, z["step_new_x"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(nu, z["step_new_u"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(costs, z["step_costs"], rtol=1e-8)
+    # (full_du_norm of a whole-batch reference call is not comparable: mpc/lqr_step.py:243-245 views the transposed
+    # [T, nc, B] difference as [B, T nc], which mixes the problems unless n_batch = 1)
+    bx, bu, bc, bfull, balpha, _, _ = E.rollout_batched(
+        E.MLP, net, z["x_init"], z["C"], z["c"], o["K"], o["k"], z["step_cur_x"], z["step_cur_u"], lo, hi,
+        float(z["decay"][0]), int(z["max_ls"][0]))
+    for a, b in ((bx, nx), (bu, nu), (bc, costs), (bfull, full), (balpha, alphas)):
+        np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-13)
+
+
 def test_env_oracle_clamp_derivative_on_the_bound():
     """torch.clamp passes the gradient on the CLOSED interval; a control sitting exactly on its bound
     (where a bounded solve puts it) keeps its full derivative."""
