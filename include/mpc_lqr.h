@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPC_LQR_ABI_VERSION 3
+#define MPC_LQR_ABI_VERSION 4
 
 enum { MPC_F32 = 0, MPC_F64 = 1 };
 enum { MPC_BOUND_NONE = 0, MPC_BOUND_SCALAR = 1, MPC_BOUND_TENSOR = 2 };
@@ -205,6 +205,38 @@ int mpc_env_traj_cost(const mpc_lqr_problem *p, const mpc_env_dynamics *env, voi
  *     f [N,ns] = env(x,u) - F [x;u].  One thread per point. */
 int mpc_env_linearize(const mpc_env_dynamics *env, int dtype, int64_t N, const void *x, const void *u,
                       void *F, void *f, void *stream);
+
+/* (6d) mpc.dynamics.NNDynamics (mpc/dynamics.py:15-128) as the dynamics: a fully connected network
+ *      [x;u] -> x' whose weights are shared by the whole batch, fp32.  W[l] / b[l] are nn.Linear's own tensors
+ *      (row-major [widths[l+1]][widths[l]], [widths[l+1]]), device pointers; the same activation follows every layer
+ *      but the last; `passthrough` adds x to the output (:74-75).  n_state <= 16. */
+enum { MPC_ACT_SIGMOID = 0, MPC_ACT_RELU = 1, MPC_ACT_ELU = 2 };
+#define MPC_MLP_MAX_LAYERS 4
+typedef struct mpc_mlp_dynamics {
+    int32_t n_layers;                         /* Linear layers (hidden + output), 1..MPC_MLP_MAX_LAYERS */
+    int32_t activation;                       /* MPC_ACT_* */
+    int32_t passthrough;
+    int32_t widths[MPC_MLP_MAX_LAYERS + 1];   /* widths[0] = n_state + n_ctrl, widths[n_layers] = n_state */
+    const void *W[MPC_MLP_MAX_LAYERS];
+    const void *b[MPC_MLP_MAX_LAYERS];
+} mpc_mlp_dynamics;
+
+/* device scratch (16-byte aligned) the two calls below need for the re-packed weights */
+int64_t mpc_mlp_workspace_bytes(const mpc_mlp_dynamics *net);
+
+/*      lqr_forward with the network as true_dynamics (mpc/lqr_step.py:164-261, the module branch :223-225) and a
+ *      QuadCost: gains K [T,B,nc,ns], k [T,B,nc] of a sweep (mpc_lqr_step's out->K/k), old_costs [B] = cost of the
+ *      nominal (its out->old_costs); fills out->new_x/new_u/costs/full_du_norm/alpha_du_norm/alphas.
+ *      K == NULL: util.get_traj (+ get_cost when p->C is given) of the controls p->cur_u through the network
+ *      (mpc/util.py:102-153): out->new_x, out->costs. */
+int mpc_mlp_rollout(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_mlp_dynamics *net, const void *K,
+                    const void *k, const void *old_costs, const mpc_lqr_outputs *out, void *workspace,
+                    int64_t workspace_bytes, void *stream);
+
+/*      MPC.linearize_dynamics(GradMethods.ANALYTIC) for the network (mpc/mpc.py:495-512, NNDynamics.grad_input
+ *      mpc/dynamics.py:82-128) at N points x [N,ns], u [N,nc]: F [N,ns,ns+nc], f [N,ns] = net(x,u) - F [x;u]. */
+int mpc_mlp_linearize(const mpc_mlp_dynamics *net, int n_state, int n_ctrl, int64_t N, const void *x, const void *u,
+                      void *F, void *f, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* (7) Device-side pieces of the iLQR driver loop (mpc/mpc.py:271-285, 299):
  *     per-problem best-iterate select without host round trips.

@@ -132,7 +132,7 @@ int mpc_lqr_abi_version(void) { return MPC_LQR_ABI_VERSION; }
 const char *mpc_lqr_build_info(void)
 {
     return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32>, lqr_step_dpp16<f32>, "
-           "lqr_step_tiny<f32,f64>, lqr_step_mfma40<f32>, env_linearize, kkt_grads, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
+           "lqr_step_tiny<f32,f64>, lqr_step_mfma40<f32>, nn_rollout<f32>, nn_linearize<f32>, env_linearize, kkt_grads, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
 }
 
 const char *mpc_lqr_last_error(void) { return g_last_error.c_str(); }
@@ -281,6 +281,53 @@ int mpc_env_linearize(const mpc_env_dynamics *env, int dtype, int64_t N, const v
     EnvDesc<double> e;
     set_env(e, env);
     return launch_env_linearize<double>(e, (long)N, (const double *)x, (const double *)u, (double *)F, (double *)f, st);
+}
+
+int64_t mpc_mlp_workspace_bytes(const mpc_mlp_dynamics *net)
+{
+    if (!net || net->n_layers < 1 || net->n_layers > MPC_MLP_MAX_LAYERS) return 0;
+    int64_t fl = 0;
+    for (int l = 0; l < net->n_layers; ++l) {
+        const int64_t in = (net->widths[l] + 15) & ~15, out = (net->widths[l + 1] + 15) & ~15;
+        fl += out * in + out;
+    }
+    return fl * 4 + 256;
+}
+
+int mpc_mlp_rollout(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_mlp_dynamics *net, const void *K,
+                    const void *k, const void *old_costs, const mpc_lqr_outputs *out, void *workspace,
+                    int64_t workspace_bytes, void *stream)
+{
+    if (!p || !out) return fail(MPC_E_NULL, "problem / outputs is NULL");
+    if (p->B < 0 || p->T < 1 || p->ns < 1 || p->nc < 1) return fail(MPC_E_DIMS, "need B>=0, T>=1, ns>=1, nc>=1");
+    if (p->dtype != MPC_F32) return fail(MPC_E_DTYPE, "the network kernels are fp32 only");
+    if (p->B == 0) return MPC_OK;
+    if (!p->x_init || !p->cur_u) return fail(MPC_E_NULL, "x_init / current_u is NULL");
+    if ((p->C == nullptr) != (p->c == nullptr)) return fail(MPC_E_NULL, "pass both C and c, or neither");
+    if (!out->new_x) return fail(MPC_E_NULL, "new_x is NULL");
+    if ((K == nullptr) != (k == nullptr)) return fail(MPC_E_NULL, "pass both K and k, or neither");
+    if (K) {
+        if (!p->cur_x || !p->C || !old_costs || !out->new_u)
+            return fail(MPC_E_NULL, "line search needs current_x, C, c, old_costs and new_u");
+        int rc = check_options(p, o);
+        if (rc) return rc;
+        if (o && o->true_dynamics) return fail(MPC_E_ARG, "mpc_mlp_rollout: options.true_dynamics must be NULL");
+    }
+    StepParams<float> sp = make_params<float>(p, K ? o : nullptr, out);
+    sp.K = (float *)K;
+    sp.k = (float *)k;
+    sp.old_costs_in = (const float *)old_costs;
+    return launch_nn_rollout(sp, net, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int mpc_mlp_linearize(const mpc_mlp_dynamics *net, int n_state, int n_ctrl, int64_t N, const void *x, const void *u,
+                      void *F, void *f, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (n_state < 1 || n_ctrl < 1 || N < 0) return fail(MPC_E_DIMS, "need n_state>=1, n_ctrl>=1, N>=0");
+    if (N == 0) return MPC_OK;
+    if (!x || !u || !F || !f) return fail(MPC_E_NULL, "mlp_linearize: NULL argument");
+    return launch_nn_linearize(net, (long)N, n_state, n_ctrl, (const float *)x, (const float *)u, (float *)F, (float *)f,
+                               workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int mpc_lqr_kkt_prepare(int dtype, int B, int T, int ns, int nc, const void *dl_dx, const void *dl_du,

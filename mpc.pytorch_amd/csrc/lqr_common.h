@@ -61,6 +61,11 @@ int launch_kkt_wave(const StepParams<float> &p, const float *dx, const float *du
 bool mfma40_supported(const StepParams<float> &p);
 int launch_step_mfma40(const StepParams<float> &p, hipStream_t st);
 
+// NNDynamics inside the kernels: rollout / line search and Jacobian on MFMA, 16 problems per wave (nn_dynamics.hip)
+int launch_nn_rollout(const StepParams<float> &p, const mpc_mlp_dynamics *net, void *workspace, int64_t bytes, hipStream_t st);
+int launch_nn_linearize(const mpc_mlp_dynamics *net, long N, int ns, int nc, const float *x, const float *u, float *F,
+                        float *f, void *workspace, int64_t bytes, hipStream_t st);
+
 // fused MFMA path for n <= 16, f32 (lqr_mfma16.hip)
 bool mfma16_supported(const StepParams<float> &p);
 int launch_step_mfma16(const StepParams<float> &p, hipStream_t st);

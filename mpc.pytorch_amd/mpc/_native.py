@@ -19,7 +19,7 @@ BOUND_NONE, BOUND_SCALAR, BOUND_TENSOR = 0, 1, 2
 ST_PNQP_UNCONVERGED, ST_NONFINITE, ST_NOMINAL_OFF_DYNAMICS = 1, 2, 4
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA16, IMPL_DPP16, IMPL_TINY, IMPL_MFMA40 = 0, 1, 2, 3, 4, 5
 
-ABI_VERSION = 3      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
+ABI_VERSION = 4      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
 
 _vp, _i32, _i64, _f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 
@@ -67,6 +67,51 @@ class EnvSpec:
         return e, prm
 
 
+MLP_MAX_LAYERS = 4
+ACT_CODES = {"sigmoid": 0, "relu": 1, "elu": 2}
+
+
+class MlpDynamics(ctypes.Structure):          # struct mpc_mlp_dynamics
+    _fields_ = [("n_layers", _i32), ("activation", _i32), ("passthrough", _i32),
+                ("widths", _i32 * (MLP_MAX_LAYERS + 1)), ("W", _vp * MLP_MAX_LAYERS), ("b", _vp * MLP_MAX_LAYERS)]
+
+
+class MlpSpec:
+    """What mpc.dynamics.NNDynamics hands to the kernels: its Linear layers' weights and biases (as they are NOW:
+    the struct is rebuilt for every call, a training loop changes them between calls), the activation and the
+    passthrough flag (mpc/dynamics.py:15-36)."""
+
+    def __init__(self, weights, biases, activation, passthrough):
+        self.weights, self.biases = list(weights), list(biases)
+        self.activation, self.passthrough = activation, bool(passthrough)
+        self.n_state = self.weights[-1].shape[0]
+        self.n_ctrl = self.weights[0].shape[1] - self.n_state
+
+    @staticmethod
+    def supported(weights, activation, like):
+        """fp32 on the device of `like`, at most four layers, n_state <= 16 (the kernels' limits)."""
+        return (like.is_cuda and like.dtype == torch.float32 and 1 <= len(weights) <= MLP_MAX_LAYERS
+                and activation in ACT_CODES and weights[-1].shape[0] <= 16
+                and all(W.shape[0] <= 4096 for W in weights)
+                and all(W.is_cuda and W.dtype == torch.float32 for W in weights))
+
+    def to_struct(self, like):
+        e = MlpDynamics()
+        keep = []
+        e.n_layers, e.activation, e.passthrough = len(self.weights), ACT_CODES[self.activation], int(self.passthrough)
+        e.widths[0] = self.weights[0].shape[1]
+        for l, (W, b) in enumerate(zip(self.weights, self.biases)):
+            W = W.detach().to(device=like.device, dtype=torch.float32).contiguous()
+            b = b.detach().to(device=like.device, dtype=torch.float32).contiguous()
+            keep += [W, b]
+            e.widths[l + 1] = W.shape[0]
+            e.W[l], e.b[l] = W.data_ptr(), b.data_ptr()
+        nbytes = int(load().mpc_mlp_workspace_bytes(ctypes.byref(e)))
+        ws = torch.empty(nbytes, device=like.device, dtype=torch.uint8)
+        keep.append(ws)
+        return e, ws, nbytes, keep
+
+
 class Outputs(ctypes.Structure):
     _fields_ = [("new_x", _vp), ("new_u", _vp), ("costs", _vp), ("old_costs", _vp), ("full_du_norm", _vp),
                 ("alpha_du_norm", _vp), ("alphas", _vp), ("qp_iters", _vp), ("status", _vp),
@@ -75,7 +120,8 @@ class Outputs(ctypes.Structure):
 
 EXPORTS = ("mpc_lqr_abi_version", "mpc_lqr_build_info", "mpc_lqr_last_error", "mpc_lqr_workspace_bytes",
            "mpc_lqr_step", "mpc_lqr_impl_supported", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_lqr_kkt_prepare",
-           "mpc_pnqp", "mpc_pnqp_lu", "mpc_traj_cost", "mpc_env_traj_cost", "mpc_env_linearize", "mpc_select_best")
+           "mpc_pnqp", "mpc_pnqp_lu", "mpc_traj_cost", "mpc_env_traj_cost", "mpc_env_linearize", "mpc_select_best",
+           "mpc_mlp_workspace_bytes", "mpc_mlp_rollout", "mpc_mlp_linearize")
 
 _lib = None
 
@@ -118,6 +164,11 @@ def load():
     L.mpc_env_traj_cost.argtypes = [PP, ctypes.POINTER(EnvDynamics), _vp, _vp, _vp]
     L.mpc_env_linearize.argtypes = [ctypes.POINTER(EnvDynamics), ctypes.c_int, _i64, _vp, _vp, _vp, _vp, _vp]
     L.mpc_select_best.argtypes = [ctypes.c_int] * 6 + [_f64] + [_vp] * 11
+    MP = ctypes.POINTER(MlpDynamics)
+    L.mpc_mlp_workspace_bytes.restype = _i64
+    L.mpc_mlp_workspace_bytes.argtypes = [MP]
+    L.mpc_mlp_rollout.argtypes = [PP, OP, MP, _vp, _vp, _vp, UP, _vp, _i64, _vp]
+    L.mpc_mlp_linearize.argtypes = [MP, ctypes.c_int, ctypes.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
     if L.mpc_lqr_abi_version() != ABI_VERSION:
         raise RuntimeError("libmpc_lqr_hip ABI version mismatch")
     _lib = L
@@ -521,6 +572,74 @@ class HipBackend:
         e, prm = env.to_struct(x)
         _check(L.mpc_env_linearize(ctypes.byref(e), _dtype_code(x), N, x.data_ptr(), u.data_ptr(),
                                    F.data_ptr(), f.data_ptr(), _stream(dev)), "mpc_env_linearize")
+        return F, f
+
+    # -- (6d) NNDynamics in the kernels --------------------------------------------------------
+    def mlp_rollout(self, x_init, C, c, K, k, cur_x, cur_u, old_costs, opts, net, out_x=None, out_u=None):
+        """lqr_forward with the network as true_dynamics (mpc/lqr_step.py:164-261): gains K, k and the nominal's
+        cost come from a sweep (`lqr_step(..., want_gains=True)`)."""
+        dev = _require_device(x_init, C, c, K, k, cur_x, cur_u, old_costs)
+        L = load()
+        T, B, nc = cur_u.shape
+        ns = x_init.shape[1]
+        p, keep = self._problem(x_init, C, c, None, None, cur_x, cur_u)
+        o, keep_o = opts.to_struct(T, B, nc, C)
+        e, ws, nbytes, keep_e = net.to_struct(C)
+        kw = dict(device=dev, dtype=C.dtype)
+        res = dict(new_x=torch.empty(T, B, ns, **kw) if out_x is None else out_x,
+                   new_u=torch.empty(T, B, nc, **kw) if out_u is None else out_u,
+                   costs=torch.empty(B, **kw), old_costs=torch.empty(B, **kw),
+                   full_du_norm=torch.empty(B, **kw), alpha_du_norm=torch.empty(B, **kw),
+                   alphas=torch.empty(B, **kw), status=torch.zeros(B, device=dev, dtype=torch.int32))
+        out = Outputs()
+        for name in res:
+            setattr(out, name, res[name].data_ptr())
+        Kc, kc, oc = K.detach().contiguous(), k.detach().contiguous(), old_costs.detach().contiguous()
+        _check(L.mpc_mlp_rollout(ctypes.byref(p), ctypes.byref(o), ctypes.byref(e), Kc.data_ptr(), kc.data_ptr(),
+                                 oc.data_ptr(), ctypes.byref(out), ws.data_ptr(), nbytes, _stream(dev)),
+               "mpc_mlp_rollout")
+        res["_keep"] = (keep, keep_o, keep_e, Kc, kc, oc)
+        return res
+
+    def mlp_traj_cost(self, x_init, u, net, C=None, c=None):
+        """util.get_traj through the network (+ util.get_cost for a QuadCost), mpc/util.py:102-153."""
+        dev = _require_device(x_init, u)
+        L = load()
+        T, B, nc = u.shape
+        ns = x_init.shape[1]
+        kw = dict(device=dev, dtype=u.dtype)
+        p = Problem()
+        p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, _dtype_code(u)
+        xi = x_init.detach().contiguous(); p.x_init = xi.data_ptr()
+        cu = u.detach().contiguous(); p.cur_u = cu.data_ptr()
+        keep = [xi, cu]
+        if C is not None:
+            Cc, p.C_st, p.C_sb = _block_strided(C.detach(), 2); keep.append(Cc); p.C = Cc.data_ptr()
+            cc, p.c_st, p.c_sb = _block_strided(c.detach(), 1); keep.append(cc); p.c = cc.data_ptr()
+        e, ws, nbytes, keep_e = net.to_struct(u)
+        x = torch.empty(T, B, ns, **kw)
+        cost = torch.empty(B, **kw) if C is not None else None
+        out = Outputs()
+        out.new_x, out.costs = x.data_ptr(), _ptr(cost)
+        _check(L.mpc_mlp_rollout(ctypes.byref(p), None, ctypes.byref(e), None, None, None, ctypes.byref(out),
+                                 ws.data_ptr(), nbytes, _stream(dev)), "mpc_mlp_rollout")
+        return x, cost
+
+    def mlp_linearize(self, net, x, u, out_F=None, out_f=None):
+        """x [N,ns], u [N,nc] -> F [N,ns,ns+nc], f [N,ns]: NNDynamics.grad_input + the affine term of
+        MPC.linearize_dynamics (mpc/dynamics.py:82-128, mpc/mpc.py:495-512), no [N, hidden, n] intermediates."""
+        dev = _require_device(x, u)
+        L = load()
+        N, ns = x.shape
+        nc = u.shape[1]
+        kw = dict(device=dev, dtype=x.dtype)
+        x = x.detach().contiguous(); u = u.detach().contiguous()
+        F = torch.empty(N, ns, ns + nc, **kw) if out_F is None else out_F
+        f = torch.empty(N, ns, **kw) if out_f is None else out_f
+        assert F.is_contiguous() and f.is_contiguous() and F.numel() == N * ns * (ns + nc) and f.numel() == N * ns
+        e, ws, nbytes, keep_e = net.to_struct(x)
+        _check(L.mpc_mlp_linearize(ctypes.byref(e), ns, nc, N, x.data_ptr(), u.data_ptr(), F.data_ptr(), f.data_ptr(),
+                                   ws.data_ptr(), nbytes, _stream(dev)), "mpc_mlp_linearize")
         return F, f
 
     # -- (7) driver reductions ------------------------------------------------------------------

@@ -1,0 +1,143 @@
+"""GPU parity (-m gpu) of the NNDynamics kernels (csrc/nn_dynamics.hip: the network's layers on MFMA, 16 problems per
+wavefront) against oracle/env_oracle.py, which is pinned on the reference's own NNDynamics (tests/golden/nn_*.npz,
+tests/test_oracle_golden.py): util.get_traj through the network, MPC.linearize_dynamics(ANALYTIC), the line-searched
+rollout of one LQR step -- on the fixtures themselves and at BASELINE-sized batches on random networks.
+
+Tolerance: float32 kernels against the float64 oracle, rtol 1e-3 / atol 1e-4 on x, u, 1e-3 on costs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from test_gpu_fullsize import host, strict_step_check
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NN_CASES = ["nn_sigmoid_f64", "nn_relu2_f64", "nn_headline_f64", "nn_nopass_f64"]
+
+
+@pytest.fixture(scope="module")
+def be():
+    from mpc import _native
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    _native.load()            # fail loudly if the extension is missing
+    return _native.HipBackend()
+
+
+def f32(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).float().to(DEV)
+
+
+def spec_of(net):
+    from mpc._native import MlpSpec
+    return MlpSpec([f32(W) for W in net.Ws], [f32(b) for b in net.bs], net.activation, net.passthrough)
+
+
+def random_net(ns, nc, hidden, act, passthrough, seed, scale=1.0):
+    from oracle import env_oracle as E
+    rng = np.random.RandomState(seed)
+    sizes = [ns + nc] + list(hidden) + [ns]
+    Ws = [scale * rng.uniform(-1, 1, (o, i)) / np.sqrt(i) for i, o in zip(sizes, sizes[1:])]
+    bs = [rng.uniform(-1, 1, o) / np.sqrt(i) for i, o in zip(sizes, sizes[1:])]
+    return E.Mlp(Ws, bs, act, passthrough)
+
+
+@pytest.mark.parametrize("name", NN_CASES)
+def test_network_kernels_on_the_reference_fixtures(be, name):
+    """The three kernels on the inputs of the fixtures the reference generated: forward / Jacobian at the random
+    points, the nominal trajectory, F and f along it, and the LQR step's line-searched rollout (gains from the float64
+    C oracle's sweep) against the REFERENCE's own outputs."""
+    from mpc._native import StepOptions
+    from oracle import env_oracle as E
+    from oracle import lqr_oracle as O
+    z = golden(name)
+    ns, nc, T, B = (int(v) for v in z["meta"][:4])
+    net = E.Mlp.from_npz(z)
+    sp = spec_of(net)
+    # points: one "trajectory" of length 2 per point gives the forward map; linearize gives the Jacobian
+    x1, _ = be.mlp_traj_cost(f32(z["px"]), f32(np.stack((z["pu"], z["pu"]))), sp)
+    np.testing.assert_allclose(host(x1)[1], z["pnext"], rtol=1e-4, atol=2e-5)
+    F, f = be.mlp_linearize(sp, f32(z["px"]), f32(z["pu"]))
+    np.testing.assert_allclose(host(F)[:, :, :ns], z["pR"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(host(F)[:, :, ns:], z["pS"], rtol=1e-4, atol=2e-5)
+    tau = np.concatenate((z["px"], z["pu"]), 1)
+    np.testing.assert_allclose(host(f), z["pnext"] - np.einsum("nij,nj->ni", np.concatenate((z["pR"], z["pS"]), 2), tau),
+                               rtol=1e-4, atol=5e-5)
+    # nominal trajectory and its linearisation
+    xs, _ = be.mlp_traj_cost(f32(z["x_init"]), f32(z["step_cur_u"]), sp)
+    np.testing.assert_allclose(host(xs), z["step_cur_x"], rtol=1e-4, atol=5e-5)
+    Fl, fl = be.mlp_linearize(sp, f32(z["step_cur_x"][:-1].reshape(-1, ns)), f32(z["step_cur_u"][:-1].reshape(-1, nc)))
+    np.testing.assert_allclose(host(Fl).reshape(z["step_F"].shape), z["step_F"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(host(fl).reshape(z["step_f"].shape), z["step_f"], rtol=1e-4, atol=5e-5)
+    # one LQR step: sweep = float64 oracle, rollout = the kernel
+    bound = float(z["bound"][0])
+    lo, hi = (None, None) if np.isnan(bound) else (-bound, bound)
+    decay, max_ls = float(z["decay"][0]), int(z["max_ls"][0])
+    o = O.lqr_step(z["x_init"], z["C"], z["c"], z["step_F"], z["step_f"], z["step_cur_x"], z["step_cur_u"], lo, hi,
+                   linesearch_decay=decay, max_linesearch_iter=max_ls, return_gains=True)
+    old = E.quad_cost(z["C"], z["c"], z["step_cur_x"], z["step_cur_u"])
+    r = be.mlp_rollout(f32(z["x_init"]), f32(z["C"]), f32(z["c"]), f32(o["K"]), f32(o["k"]), f32(z["step_cur_x"]),
+                       f32(z["step_cur_u"]), f32(old), StepOptions(u_lower=lo, u_upper=hi, linesearch_decay=decay,
+                                                                  max_linesearch_iter=max_ls), sp)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(host(r["new_u"]), z["step_new_u"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(host(r["new_x"]), z["step_new_x"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(host(r["costs"]), z["step_costs"], rtol=1e-3)
+    assert (host(r["status"]) == 0).all()
+    # trajectory cost through the network
+    _, c0 = be.mlp_traj_cost(f32(z["x_init"]), f32(z["step_cur_u"]), sp, C=f32(z["C"]), c=f32(z["c"]))
+    np.testing.assert_allclose(host(c0), old, rtol=1e-4)
+
+
+@pytest.mark.parametrize("ns,nc,hidden,act,passthrough,B,T,bound", [
+    (12, 4, [100], "sigmoid", True, 4096, 50, 0.5),          # the headline shape with the reference's default network
+    (12, 4, [100], "relu", True, 1000, 20, None),            # ragged last group (1000 = 62 * 16 + 8), unbounded
+    (5, 1, [64, 48], "sigmoid", True, 517, 25, 2.0),         # two hidden layers, one control
+    (16, 8, [256, 32, 20], "elu", False, 260, 12, 1.0),      # n = 24: two input tiles; three hidden layers; no passthrough
+    (3, 2, [], "sigmoid", True, 100, 6, None),               # a single Linear layer
+])
+def test_network_rollout_and_linearisation_at_full_batches(be, ns, nc, hidden, act, passthrough, B, T, bound):
+    """Random networks at BASELINE-sized batches, every problem: the nominal trajectory, F / f at all (T-1) B points and
+    the line-searched rollout of a step whose sweep the float64 C oracle did (line-search ties classified as in
+    tests/test_gpu_fullsize.py)."""
+    from mpc._native import StepOptions
+    from oracle import env_oracle as E
+    from oracle import lqr_oracle as O
+    net = random_net(ns, nc, hidden, act, passthrough, seed=ns * 100 + nc, scale=0.8)
+    sp = spec_of(net)
+    rng = np.random.RandomState(B)
+    n = ns + nc
+    x0 = rng.randn(B, ns)
+    u0 = 0.3 * rng.randn(T, B, nc)
+    if bound is not None:
+        u0 = np.clip(u0, -bound, bound)
+    A = rng.randn(T, B, n, n)
+    C = np.einsum("tbki,tbkj->tbij", A, A) + 0.1 * np.eye(n)
+    c = rng.randn(T, B, n)
+    xs = E.traj(E.MLP, x0, u0, net)
+    xk, ck = be.mlp_traj_cost(f32(x0), f32(u0), sp, C=f32(C), c=f32(c))
+    scale = 1.0 + np.abs(xs).max()
+    assert np.abs(host(xk) - xs).max() < 2e-4 * scale
+    old = E.quad_cost(C, c, xs, u0)
+    np.testing.assert_allclose(host(ck), old, rtol=1e-3)
+    Fl, fl = E.linearize(E.MLP, xs[:-1].reshape(-1, ns), u0[:-1].reshape(-1, nc), net)
+    Fk, fk = be.mlp_linearize(sp, f32(xs[:-1].reshape(-1, ns)), f32(u0[:-1].reshape(-1, nc)))
+    np.testing.assert_allclose(host(Fk), Fl, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(host(fk), fl, rtol=1e-3, atol=1e-4 * scale)
+    Fl, fl = Fl.reshape(T - 1, B, ns, n), fl.reshape(T - 1, B, ns)
+    lo, hi = (None, None) if bound is None else (-bound, bound)
+    decay, max_ls = 0.2, 6
+    o = O.lqr_step(x0, C, c, Fl, fl, xs, u0, lo, hi, linesearch_decay=decay, max_linesearch_iter=max_ls, lockstep=False,
+                   nthreads=O.max_threads(), return_gains=True)
+    nx, nu, costs, full, alphas, trials, old2 = E.rollout_batched(E.MLP, net, x0, C, c, o["K"], o["k"], xs, u0, lo, hi,
+                                                                   decay, max_ls)
+    o.update(new_x=nx, new_u=nu, costs=costs, alphas=alphas, old_costs=old2, full_du_norm=full)
+    r = be.mlp_rollout(f32(x0), f32(C), f32(c), f32(o["K"]), f32(o["k"]), f32(xs), f32(u0), f32(old2),
+                       StepOptions(u_lower=lo, u_upper=hi, linesearch_decay=decay, max_linesearch_iter=max_ls), sp)
+    torch.cuda.synchronize()
+    ties = strict_step_check("nn_%d_%d_%s_B%d" % (ns, nc, act, B), r, o, B, rtol=1e-3, atol=2e-4 * scale, cost_rtol=1e-3,
+                             have_gains=False)
+    same = ~ties
+    np.testing.assert_allclose(host(r["full_du_norm"])[same], full[same], rtol=2e-3, atol=2e-4)
+    if bound is not None:
+        assert (host(r["new_u"]) >= lo - 1e-6).all() and (host(r["new_u"]) <= hi + 1e-6).all()

@@ -43,7 +43,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert set(_native.EXPORTS) == declared
-    assert L.mpc_lqr_abi_version() == _native.ABI_VERSION == 3
+    assert L.mpc_lqr_abi_version() == _native.ABI_VERSION == 4
     assert b"gfx950" in L.mpc_lqr_build_info()
 
 
@@ -53,6 +53,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_native.Options) == 8 + 16 + 24 + 16 + 8 + 8
     assert ctypes.sizeof(_native.EnvDynamics) == 8 + 8 + 16
     assert ctypes.sizeof(_native.Outputs) == 11 * 8
+    assert ctypes.sizeof(_native.MlpDynamics) == 3 * 4 + 5 * 4 + 4 * 8 + 4 * 8
 
 
 def test_argument_validation_without_gpu():
