@@ -289,7 +289,7 @@ int64_t mpc_mlp_workspace_bytes(const mpc_mlp_dynamics *net)
     int64_t fl = 0;
     for (int l = 0; l < net->n_layers; ++l) {
         const int64_t in = (net->widths[l] + 15) & ~15, out = (net->widths[l + 1] + 15) & ~15;
-        fl += out * in + out;
+        fl += out * (in + 4) + out;          // rows padded by 16 bytes (LDS banks), see nn_dynamics.hip
     }
     return fl * 4 + 256;
 }

@@ -31,90 +31,130 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// The packed network: one block of floats, layer after layer, W_l as [wp[l+1]][wp[l] + 4] (rows padded by 16 bytes so
+// that the sixteen rows a 16-byte-per-lane read touches do not fall on the same LDS banks) followed by b_l [wp[l+1]].
+// The block is copied into LDS at kernel start when it fits (WL), else read from global memory through the caches.
 struct MlpDesc {
     int L, act, pass;            // Linear layers, MPC_ACT_*, passthrough
     int w[MPC_MLP_MAX_LAYERS + 1];   // widths: w[0] = n_state + n_ctrl, w[L] = n_state
     int wp[MPC_MLP_MAX_LAYERS + 1];  // rounded up to 16
-    const float *W[MPC_MLP_MAX_LAYERS];   // packed [wp[l+1]][wp[l]]
-    const float *b[MPC_MLP_MAX_LAYERS];   // packed [wp[l+1]]
+    int woff[MPC_MLP_MAX_LAYERS], boff[MPC_MLP_MAX_LAYERS];   // offsets (floats) into the packed block
+    int total;                   // floats in the packed block (a multiple of 4)
+    const float *packed;         // in the workspace
 };
 
 struct PackArgs {
-    int L;
-    int w[MPC_MLP_MAX_LAYERS + 1], wp[MPC_MLP_MAX_LAYERS + 1];
+    MlpDesc d;
     const float *W[MPC_MLP_MAX_LAYERS], *b[MPC_MLP_MAX_LAYERS];
-    float *Wp[MPC_MLP_MAX_LAYERS], *bp[MPC_MLP_MAX_LAYERS];
+    float *dst;
 };
 
 __global__ void mlp_pack_kernel(PackArgs a)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    for (int l = 0; l < a.L; ++l) {
-        const int in = a.w[l], out = a.w[l + 1], inp = a.wp[l], outp = a.wp[l + 1];
-        for (int e = tid; e < outp * inp; e += nt) {
-            const int o = e / inp, i = e - o * inp;
-            a.Wp[l][e] = (o < out && i < in) ? a.W[l][o * in + i] : 0.f;
+    for (int l = 0; l < a.d.L; ++l) {
+        const int in = a.d.w[l], out = a.d.w[l + 1], ldp = a.d.wp[l] + 4, outp = a.d.wp[l + 1];
+        for (int e = tid; e < outp * ldp; e += nt) {
+            const int o = e / ldp, i = e - o * ldp;
+            a.dst[a.d.woff[l] + e] = (o < out && i < in) ? a.W[l][o * in + i] : 0.f;
         }
-        for (int o = tid; o < outp; o += nt) a.bp[l][o] = o < out ? a.b[l][o] : 0.f;
+        for (int o = tid; o < outp; o += nt) a.dst[a.d.boff[l] + o] = o < out ? a.b[l][o] : 0.f;
     }
 }
 
-__device__ __forceinline__ float act_fn(float a, int kind)
+// wave-local ordering of LDS traffic: a wavefront's LDS instructions execute in order, only the compiler has to be
+// kept from moving them (the per-wave staging areas are never touched by another wave)
+__device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); }
+
+// the activation on one accumulator (one wave-uniform branch per tile, not per element)
+__device__ __forceinline__ f32x4 act_fn(f32x4 a, int kind)
 {
-    if (kind == MPC_ACT_SIGMOID) return 1.f / (1.f + expf(-a));
-    if (kind == MPC_ACT_RELU) return fmaxf(a, 0.f);
-    return a > 0.f ? a : expm1f(a);                                   // F.elu, alpha = 1
+    if (kind == MPC_ACT_SIGMOID) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a[v] = __frcp_rn(1.f + __expf(-a[v]));   // v_exp_f32 / v_rcp_f32: ~1e-7 relative
+    } else if (kind == MPC_ACT_RELU) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a[v] = fmaxf(a[v], 0.f);
+    } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a[v] = a[v] > 0.f ? a[v] : expm1f(a[v]);   // F.elu, alpha = 1
+    }
+    return a;
 }
 // derivative of the activation from its OUTPUT (mpc/dynamics.py:104-112)
-__device__ __forceinline__ float slope_fn(float z, int kind)
+__device__ __forceinline__ f32x4 slope_fn(f32x4 z, int kind)
 {
-    if (kind == MPC_ACT_SIGMOID) return z * (1.f - z);
-    if (kind == MPC_ACT_RELU) return z > 0.f ? 1.f : 0.f;
-    return z > 0.f ? 1.f : z + 1.f;
+    if (kind == MPC_ACT_SIGMOID) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) z[v] = z[v] * (1.f - z[v]);
+    } else if (kind == MPC_ACT_RELU) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) z[v] = z[v] > 0.f ? 1.f : 0.f;
+    } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) z[v] = z[v] > 0.f ? 1.f : z[v] + 1.f;
+    }
+    return z;
 }
 
 // All layers for the sixteen columns staged in tauS (row r = column's [x;u], zero padded to wp[0]).  Hidden
 // activations go to zbase: layer l at zbase + l * 16 * ZS when KEEP (the Jacobian needs them all), else ping-pong.
 // Returns the output layer's accumulator: features 4q..4q+3 of column r (n_state <= 16: one tile).
+// wts: the packed network (LDS or global).  The operand loads of the next K-step are issued before the current
+// one's MFMAs: with one wavefront per SIMD nothing else hides their latency.
 template <bool KEEP>
-__device__ f32x4 mlp_forward(const MlpDesc &m, const float *tauS, int TS, float *zbase, int ZS, int q, int r)
+__device__ __forceinline__ f32x4 mlp_forward(const MlpDesc &m, const float *wts, const float *tauS, int TS, float *zbase,
+                                             int ZS, int q, int r)
 {
     const float *in = tauS;
     int is = TS;
     f32x4 res = {0.f, 0.f, 0.f, 0.f};
     for (int l = 0; l < m.L; ++l) {
-        const int nin_t = m.wp[l] >> 4, nout_t = m.wp[l + 1] >> 4, ld = m.wp[l];
-        const float *W = m.W[l], *bias = m.b[l];
+        const int nin_t = m.wp[l] >> 4, nout_t = m.wp[l + 1] >> 4, ldp = m.wp[l] + 4;
+        const float *W = wts + m.woff[l], *bias = wts + m.boff[l];
         float *dst = zbase + (KEEP ? l : (l & 1)) * 16 * ZS;
         const bool last = l + 1 == m.L;
+        const float *irow = in + r * is + 4 * q;
         for (int to = 0; to < nout_t; ++to) {
             // four accumulation chains (one per K-block of a 16-byte load), joined at the end
             f32x4 a0 = *reinterpret_cast<const f32x4 *>(bias + 16 * to + 4 * q);
             f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
-            const float *wrow = W + (long)(16 * to + r) * ld + 4 * q;
-            const float *irow = in + r * is + 4 * q;
+            const float *wrow = W + (16 * to + r) * ldp + 4 * q;
+            f32x4 a = *reinterpret_cast<const f32x4 *>(wrow);
+            f32x4 b = *reinterpret_cast<const f32x4 *>(irow);
             for (int ti = 0; ti < nin_t; ++ti) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + 16 * ti);
-                const f32x4 b = *reinterpret_cast<const f32x4 *>(irow + 16 * ti);
+                const int nx = ti + 1 < nin_t ? ti + 1 : ti;
+                const f32x4 an = *reinterpret_cast<const f32x4 *>(wrow + 16 * nx);
+                const f32x4 bn = *reinterpret_cast<const f32x4 *>(irow + 16 * nx);
                 a0 = mfma(a[0], b[0], a0);
                 a1 = mfma(a[1], b[1], a1);
                 a2 = mfma(a[2], b[2], a2);
                 a3 = mfma(a[3], b[3], a3);
+                a = an;
+                b = bn;
             }
             f32x4 acc = (a0 + a1) + (a2 + a3);
             if (!last) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[v] = act_fn(acc[v], m.act);
-                *reinterpret_cast<f32x4 *>(dst + r * ZS + 16 * to + 4 * q) = acc;
+                *reinterpret_cast<f32x4 *>(dst + r * ZS + 16 * to + 4 * q) = act_fn(acc, m.act);
             } else if (to == 0) {
                 res = acc;
             }
         }
-        __syncthreads();
+        wave_sync();
         in = dst;
         is = ZS;
     }
     return res;
+}
+
+// the packed network into LDS (all waves of the workgroup), or a pointer to it in global memory
+template <bool WL> __device__ __forceinline__ const float *stage_weights(const MlpDesc &m, float *wl)
+{
+    if (!WL) return m.packed;
+    for (int e = threadIdx.x * 4; e < m.total; e += blockDim.x * 4)
+        *reinterpret_cast<f32x4 *>(wl + e) = *reinterpret_cast<const f32x4 *>(m.packed + e);
+    __syncthreads();
+    return wl;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -122,12 +162,17 @@ __device__ f32x4 mlp_forward(const MlpDesc &m, const float *tauS, int TS, float 
 // lane (q, r): problem r of the group, quarter q of every per-problem loop (controls i = q, q+4, ..; cost rows likewise);
 // the state x' is the output accumulator: features 4q..4q+3.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) nn_rollout_kernel(StepParams<float> p, MlpDesc m, int TS, int ZS)
+template <bool WL>
+__global__ void __launch_bounds__(256) nn_rollout_kernel(StepParams<float> p, MlpDesc m, int TS, int ZS, int wave_floats)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *tauS = lds, *dxS = tauS + 16 * TS, *zb = dxS + 16 * TS;
-    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
-    const int b_raw = blockIdx.x * 16 + r;
+    const float *wts = stage_weights<WL>(m, lds);
+    const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    float *tauS = lds + (WL ? m.total : 0) + wave * wave_floats, *dxS = tauS + 16 * TS, *zb = dxS + 16 * TS;
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const long group = (long)blockIdx.x * nwave + wave;
+    if (group * 16 >= p.B) return;
+    const long b_raw = group * 16 + r;
     const bool valid = b_raw < p.B;
     const long b = valid ? b_raw : p.B - 1;
     const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T;
@@ -138,7 +183,7 @@ __global__ void __launch_bounds__(64) nn_rollout_kernel(StepParams<float> p, Mlp
         tauS[i] = 0.f;
         dxS[i] = 0.f;
     }
-    __syncthreads();
+    wave_sync();
     float alpha = 1.f, cost = 0.f, dun = 0.f, full = 0.f;
     bool active = valid;
     const int max_ls = has_gain ? p.max_ls : 1;
@@ -161,7 +206,7 @@ __global__ void __launch_bounds__(64) nn_rollout_kernel(StepParams<float> p, Mlp
                     dxS[r * TS + f] = has_gain ? xr[v] - p.cur_x[tb * ns + f] : 0.f;      // :227
                 }
             }
-            __syncthreads();
+            wave_sync();
             for (int i = q; i < nc; i += 4) {
                 const float u = p.cur_u[tb * nc + i];
                 float un = u;
@@ -188,7 +233,7 @@ __global__ void __launch_bounds__(64) nn_rollout_kernel(StepParams<float> p, Mlp
                 const float d = u - un;
                 da = fmaf(d, d, da);
             }
-            __syncthreads();
+            wave_sync();
             if (has_cost) {                                                                 // :230-232
                 const float *Ct = p.C + (long)t * p.C_st + b * p.C_sb;
                 const float *ct = p.c + (long)t * p.c_st + b * p.c_sb;
@@ -199,7 +244,7 @@ __global__ void __launch_bounds__(64) nn_rollout_kernel(StepParams<float> p, Mlp
                 }
             }
             if (t < T - 1) {                                                                // :223-225
-                const f32x4 o = mlp_forward<false>(m, tauS, TS, zb, ZS, q, r);
+                const f32x4 o = mlp_forward<false>(m, wts, tauS, TS, zb, ZS, q, r);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int f = 4 * q + v;
@@ -207,7 +252,7 @@ __global__ void __launch_bounds__(64) nn_rollout_kernel(StepParams<float> p, Mlp
                     if (active && f < ns) p.new_x[((long)(t + 1) * B + b) * ns + f] = xr[v];
                 }
             } else {
-                __syncthreads();
+                wave_sync();
             }
         }
         ca += __shfl_xor(ca, 16);
@@ -240,14 +285,18 @@ __global__ void __launch_bounds__(64) nn_rollout_kernel(StepParams<float> p, Mlp
 // G_l = diag(s_l) W_l G_{l-1} is [width_l x n]: tile (to, tj) in accumulator layout is rows 16 to + 4q + v, column
 // 16 tj + r -- written to this lane's own LDS slot and read back by this lane as the B operand of layer l + 1.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) nn_linearize_kernel(MlpDesc m, long N, int ns, int nc, const float *x, const float *u,
-                                                          float *F, float *f, int TS, int ZS, int GT)
+template <bool WL>
+__global__ void __launch_bounds__(512) nn_linearize_kernel(MlpDesc m, long N, int ns, int nc, const float *x, const float *u,
+                                                           float *F, float *f, int TS, int ZS, int GT, int wave_floats)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *tauS = lds, *zb = tauS + 16 * TS;
-    f32x4 *G0 = reinterpret_cast<f32x4 *>(zb + (m.L > 1 ? m.L - 1 : 1) * 16 * ZS), *G1 = G0 + (long)GT * 64;
-    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
-    const long p0 = (long)blockIdx.x * 16;
+    const float *wts = stage_weights<WL>(m, lds);
+    const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    float *tauS = lds + (WL ? m.total : 0) + wave * wave_floats, *zb = tauS + 16 * TS;
+    f32x4 *G0 = reinterpret_cast<f32x4 *>(zb + (m.L > 1 ? m.L - 1 : 1) * 16 * ZS), *G1 = G0 + GT * 64;
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const long p0 = ((long)blockIdx.x * nwave + wave) * 16;
+    if (p0 >= N) return;
     const long pt = (p0 + r < N) ? p0 + r : N - 1;
     const int n = ns + nc, NTJ = m.wp[0] >> 4;
     for (int f0 = 4 * q; f0 < m.wp[0]; f0 += 16) {
@@ -257,8 +306,8 @@ __global__ void __launch_bounds__(64) nn_linearize_kernel(MlpDesc m, long N, int
             tauS[r * TS + fe] = fe < ns ? x[pt * ns + fe] : (fe < n ? u[pt * nc + (fe - ns)] : 0.f);
         }
     }
-    __syncthreads();
-    f32x4 out = mlp_forward<true>(m, tauS, TS, zb, ZS, q, r);
+    wave_sync();
+    f32x4 out = mlp_forward<true>(m, wts, tauS, TS, zb, ZS, q, r);
     if (m.pass) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) out[v] += (4 * q + v < ns) ? tauS[r * TS + 4 * q + v] : 0.f;
@@ -268,24 +317,22 @@ __global__ void __launch_bounds__(64) nn_linearize_kernel(MlpDesc m, long N, int
         if (p0 + pp >= N) break;
         f32x4 *Gprev = G0, *Gcur = G1;
         for (int l = 0; l < Lh; ++l) {
-            const int nout_t = m.wp[l + 1] >> 4, nin_t = m.wp[l] >> 4, ld = m.wp[l];
+            const int nout_t = m.wp[l + 1] >> 4, nin_t = m.wp[l] >> 4, ld = m.wp[l] + 4;
             const float *zrow = zb + l * 16 * ZS + pp * ZS;
-            const float *W = m.W[l];
+            const float *W = wts + m.woff[l];
             for (int to = 0; to < nout_t; ++to) {
-                f32x4 s = *reinterpret_cast<const f32x4 *>(zrow + 16 * to + 4 * q);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) s[v] = slope_fn(s[v], m.act);
+                const f32x4 s = slope_fn(*reinterpret_cast<const f32x4 *>(zrow + 16 * to + 4 * q), m.act);
                 for (int tj = 0; tj < NTJ; ++tj) {
                     f32x4 g;
                     if (l == 0) {
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) g[v] = s[v] * W[(long)(16 * to + 4 * q + v) * ld + 16 * tj + r];
+                        for (int v = 0; v < 4; ++v) g[v] = s[v] * W[(16 * to + 4 * q + v) * ld + 16 * tj + r];
                     } else {
                         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-                        const float *wrow = W + (long)(16 * to + r) * ld + 4 * q;
+                        const float *wrow = W + (16 * to + r) * ld + 4 * q;
                         for (int ti = 0; ti < nin_t; ++ti) {
                             const f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + 16 * ti);
-                            const f32x4 gp = Gprev[(long)(ti * NTJ + tj) * 64 + lane];
+                            const f32x4 gp = Gprev[(ti * NTJ + tj) * 64 + lane];
                             a0 = mfma(a[0], gp[0], a0);
                             a1 = mfma(a[1], gp[1], a1);
                             a2 = mfma(a[2], gp[2], a2);
@@ -293,7 +340,7 @@ __global__ void __launch_bounds__(64) nn_linearize_kernel(MlpDesc m, long N, int
                         }
                         g = ((a0 + a1) + (a2 + a3)) * s;
                     }
-                    Gcur[(long)(to * NTJ + tj) * 64 + lane] = g;
+                    Gcur[(to * NTJ + tj) * 64 + lane] = g;
                 }
             }
             f32x4 *sw = Gprev;
@@ -303,19 +350,19 @@ __global__ void __launch_bounds__(64) nn_linearize_kernel(MlpDesc m, long N, int
         // output layer: J = W_L G_{L-1}  (n_state <= 16: one row tile)
         float fs[4] = {0.f, 0.f, 0.f, 0.f};
         {
-            const int l = Lh, nin_t = m.wp[l] >> 4, ld = m.wp[l];
-            const float *W = m.W[l];
+            const int l = Lh, nin_t = m.wp[l] >> 4, ld = m.wp[l] + 4;
+            const float *W = wts + m.woff[l];
             for (int tj = 0; tj < NTJ; ++tj) {
                 f32x4 J;
                 if (Lh == 0) {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) J[v] = W[(long)(4 * q + v) * ld + 16 * tj + r];
+                    for (int v = 0; v < 4; ++v) J[v] = W[(4 * q + v) * ld + 16 * tj + r];
                 } else {
                     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-                    const float *wrow = W + (long)r * ld + 4 * q;
+                    const float *wrow = W + r * ld + 4 * q;
                     for (int ti = 0; ti < nin_t; ++ti) {
                         const f32x4 a = *reinterpret_cast<const f32x4 *>(wrow + 16 * ti);
-                        const f32x4 gp = Gprev[(long)(ti * NTJ + tj) * 64 + lane];
+                        const f32x4 gp = Gprev[(ti * NTJ + tj) * 64 + lane];
                         a0 = mfma(a[0], gp[0], a0);
                         a1 = mfma(a[1], gp[1], a1);
                         a2 = mfma(a[2], gp[2], a2);
@@ -351,6 +398,295 @@ __global__ void __launch_bounds__(64) nn_linearize_kernel(MlpDesc m, long N, int
     }
 }
 
+// ===============================================================================================================
+// The network the reference builds by default -- ONE hidden layer (mpc/dynamics.py:16: hidden_sizes=[100]) -- with
+// n_state + n_ctrl <= 16 and at most 16 HT hidden units: the whole network lives in registers.  A operands of both
+// layers, the biases and (for the Jacobian) W_1 in accumulator layout are loaded once per wavefront; the hidden
+// activations never leave the accumulators (tile `to` of layer 1's output IS K-step `to` of layer 2's B operand).
+// ===============================================================================================================
+template <int N> __device__ __forceinline__ float bcast(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + N, 0xf, 0xf, true));   // row_newbcast:N
+}
+
+template <int HT> struct NetRegs {
+    f32x4 w1[HT], b1[HT], w2[HT], b2;
+};
+
+template <int HT> __device__ __forceinline__ void load_net(NetRegs<HT> &R, const MlpDesc &m, int q, int r)
+{
+    const float *P = m.packed;
+    const int ld2 = m.wp[1] + 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int to = 0; to < HT; ++to) {
+        const bool in = 16 * to < m.wp[1];
+        R.w1[to] = in ? *reinterpret_cast<const f32x4 *>(P + m.woff[0] + (16 * to + r) * 20 + 4 * q) : zero;
+        R.b1[to] = in ? *reinterpret_cast<const f32x4 *>(P + m.boff[0] + 16 * to + 4 * q) : zero;
+        R.w2[to] = in ? *reinterpret_cast<const f32x4 *>(P + m.woff[1] + r * ld2 + 16 * to + 4 * q) : zero;
+    }
+    R.b2 = *reinterpret_cast<const f32x4 *>(P + m.boff[1] + 4 * q);
+}
+
+// pre[to] = W_1 tau + b_1 (accumulator layout: hidden units 16 to + 4q + v, column r)
+template <int HT> __device__ __forceinline__ void layer1(const NetRegs<HT> &R, f32x4 tq, f32x4 (&pre)[HT])
+{
+#pragma unroll
+    for (int to = 0; to < HT; ++to) pre[to] = R.b1[to];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int to = 0; to < HT; ++to) pre[to] = mfma(R.w1[to][v], tq[v], pre[to]);
+}
+// W_2 z (+ init), four accumulation chains
+template <int HT> __device__ __forceinline__ f32x4 layer2(const NetRegs<HT> &R, const f32x4 (&z)[HT], f32x4 init)
+{
+    f32x4 a0 = init, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+#pragma unroll
+    for (int to = 0; to < HT; ++to) {
+        a0 = mfma(R.w2[to][0], z[to][0], a0);
+        a1 = mfma(R.w2[to][1], z[to][1], a1);
+        a2 = mfma(R.w2[to][2], z[to][2], a2);
+        a3 = mfma(R.w2[to][3], z[to][3], a3);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+// sixteen floats of a row that need not be 16-byte aligned or 16 long (columns >= len come back as 0)
+__device__ __forceinline__ void load_row(const float *row, int len, bool vec, f32x4 (&o)[4])
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (vec) {
+            o[g] = 4 * g < len ? *reinterpret_cast<const f32x4 *>(row + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[g][e] = 4 * g + e < len ? row[4 * g + e] : 0.f;
+        }
+    }
+}
+
+// lqr_forward through the network, one wavefront per workgroup, sixteen problems per wavefront (see nn_rollout_kernel
+// for the roles of the lanes).  What one step needs from memory -- rows 4q..4q+3 of C_t, c_t, row q of K_t, k_t, the
+// nominal -- is requested one step ahead, before the network's MFMAs, and consumed after them.
+template <int HT>
+__global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p, MlpDesc m)
+{
+    __shared__ __attribute__((aligned(16))) float tauS[16 * 20], dxS[16 * 20];
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    const long b_raw = (long)blockIdx.x * 16 + r;
+    const bool valid = b_raw < p.B;
+    const long b = valid ? b_raw : p.B - 1;
+    const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T;
+    const long B = p.B;
+    const bool has_gain = p.K != nullptr, has_cost = p.C != nullptr;
+    const bool vecC = (n & 3) == 0 && (p.C_st & 3) == 0 && (p.C_sb & 3) == 0, vecK = (ns & 3) == 0;
+    const float old_cost = p.old_costs_in ? p.old_costs_in[b] : 0.f;
+    NetRegs<HT> R;
+    load_net<HT>(R, m, q, r);
+    for (int i = lane; i < 16 * 20; i += 64) {
+        tauS[i] = 0.f;
+        dxS[i] = 0.f;
+    }
+    wave_sync();
+    float alpha = 1.f, cost = 0.f, dun = 0.f, full = 0.f;
+    bool active = valid;
+    const int max_ls = has_gain ? p.max_ls : 1;
+    const bool own_u = q < nc;                  // this lane computes control i = q (n_ctrl <= 4)
+    for (int pass = 0; pass < max_ls; ++pass) {
+        f32x4 xr;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int f = 4 * q + v;
+            xr[v] = f < ns ? p.x_init[b * ns + f] : 0.f;
+            if (active && f < ns) p.new_x[b * ns + f] = xr[v];
+        }
+        // operands of step t, requested at step t - 1
+        f32x4 Cr[4][4], Kr[4], cq = {0.f, 0.f, 0.f, 0.f}, cx = cq;
+        float kq = 0.f, uq = 0.f;
+        auto request = [&](int t) {
+            const long tb = (long)t * B + b;
+            if (has_cost) {
+                const float *Ct = p.C + (long)t * p.C_st + b * p.C_sb, *ct = p.c + (long)t * p.c_st + b * p.c_sb;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int i = 4 * q + v < n ? 4 * q + v : 0;
+                    load_row(Ct + i * n, 4 * q + v < n ? n : 0, vecC, Cr[v]);
+                    cq[v] = 4 * q + v < n ? ct[i] : 0.f;
+                }
+            }
+            if (has_gain) {
+                load_row(p.K + (tb * nc + (own_u ? q : 0)) * ns, own_u ? ns : 0, vecK, Kr);
+                kq = own_u ? p.k[tb * nc + q] : 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cx[v] = 4 * q + v < ns ? p.cur_x[tb * ns + 4 * q + v] : 0.f;
+            }
+            uq = own_u ? p.cur_u[tb * nc + q] : 0.f;
+        };
+        request(0);
+        float ca = 0.f, da = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const long tb = (long)t * B + b;
+            // the state quad goes first: a quad that straddles n_state also covers control slots, written next
+            *reinterpret_cast<f32x4 *>(tauS + r * 20 + 4 * q) = xr;
+            *reinterpret_cast<f32x4 *>(dxS + r * 20 + 4 * q) = has_gain ? xr - cx : f32x4{0.f, 0.f, 0.f, 0.f};   // :227
+            wave_sync();
+            if (own_u) {
+                float un = uq;
+                if (has_gain) {
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 d = *reinterpret_cast<const f32x4 *>(dxS + r * 20 + 4 * g);
+                        s0 = fmaf(Kr[g][0], d[0], s0);
+                        s1 = fmaf(Kr[g][1], d[1], s1);
+                        s0 = fmaf(Kr[g][2], d[2], s0);
+                        s1 = fmaf(Kr[g][3], d[3], s1);
+                    }
+                    un = (s0 + s1) + uq + alpha * kq;                                       // :192
+                    if (p.zero_mask && p.zero_mask[tb * nc + q]) un = 0.f;                  // :197-198
+                    if (p.bound_mode != MPC_BOUND_NONE) {                                   // :200-213
+                        float lo = p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[tb * nc + q];
+                        float hi = p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : p.hi[tb * nc + q];
+                        if (p.has_delta) {
+                            const float l2 = uq - p.delta_u, h2 = uq + p.delta_u;
+                            lo = (l2 < lo) ? lo : l2;
+                            hi = (h2 > hi) ? hi : h2;
+                        }
+                        if (un < lo) un = lo;                                               // util.eclamp
+                        if (un > hi) un = hi;
+                    }
+                    if (active) p.new_u[tb * nc + q] = un;
+                }
+                tauS[r * 20 + ns + q] = un;
+                const float d = uq - un;
+                da = fmaf(d, d, da);
+            }
+            wave_sync();
+            const f32x4 tq = *reinterpret_cast<const f32x4 *>(tauS + r * 20 + 4 * q);
+            if (has_cost) {                                                                 // :230-232
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 tg = *reinterpret_cast<const f32x4 *>(tauS + r * 20 + 4 * g);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[v] = fmaf(Cr[v][g][e], tg[e], s[v]);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) ca = fmaf(tq[v], fmaf(0.5f, s[v], cq[v]), ca);
+            }
+            if (t + 1 < T) {
+                request(t + 1);
+                f32x4 z[HT];                                                                // :223-225
+                layer1<HT>(R, tq, z);
+#pragma unroll
+                for (int to = 0; to < HT; ++to) z[to] = act_fn(z[to], m.act);
+                const f32x4 o = layer2<HT>(R, z, R.b2);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int f = 4 * q + v;
+                    xr[v] = f < ns ? o[v] + (m.pass ? xr[v] : 0.f) : 0.f;                   // mpc/dynamics.py:74-75
+                    if (active && f < ns) p.new_x[((long)(t + 1) * B + b) * ns + f] = xr[v];
+                }
+            }
+            wave_sync();
+        }
+        ca += __shfl_xor(ca, 16);
+        ca += __shfl_xor(ca, 32);
+        da += __shfl_xor(da, 16);
+        da += __shfl_xor(da, 32);
+        const float dn = sqrtf(da);
+        if (pass == 0) full = dn;                                                           // :243-245
+        if (active) {
+            cost = ca;
+            dun = dn;
+            if (has_gain && ca > old_cost && pass + 1 < max_ls) alpha *= p.ls_decay; else active = false;   // :176-179, 247
+        }
+        if (!__any(active)) break;
+    }
+    if (q == 0 && valid) {
+        if (p.costs) p.costs[b] = cost;
+        if (p.old_costs) p.old_costs[b] = old_cost;
+        if (p.full_du_norm) p.full_du_norm[b] = full;
+        if (p.alpha_du_norm) p.alpha_du_norm[b] = dun;
+        if (p.alphas) p.alphas[b] = alpha;
+        if (p.status && (!(cost == cost) || fabsf(cost) > 3e38f)) p.status[b] |= MPC_ST_NONFINITE;
+    }
+}
+
+// F, f at sixteen points per wavefront, everything in registers.  Per point the chain W_2 diag(s) W_1 is 4 HT MFMAs whose
+// B operand is s (of THAT point: a DPP row broadcast of the lane that holds it) times W_1 in accumulator layout.
+// f = net - F tau needs no reduction either: net - F tau = W_2 (z - s .* (W_1 tau)) + b_2, one more pass of layer 2.
+template <int HT, int PP> struct JacPoints {
+    static __device__ __forceinline__ void run(const NetRegs<HT> &R, const f32x4 (&w1d)[HT], const f32x4 (&s)[HT], int pass,
+                                               long p0, long N, int ns, int n, int q, int r, float *F)
+    {
+        if (p0 + PP < N) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll
+            for (int to = 0; to < HT; ++to) {
+                a0 = mfma(R.w2[to][0], bcast<PP>(s[to][0]) * w1d[to][0], a0);
+                a1 = mfma(R.w2[to][1], bcast<PP>(s[to][1]) * w1d[to][1], a1);
+                a2 = mfma(R.w2[to][2], bcast<PP>(s[to][2]) * w1d[to][2], a2);
+                a3 = mfma(R.w2[to][3], bcast<PP>(s[to][3]) * w1d[to][3], a3);
+            }
+            const f32x4 J = (a0 + a1) + (a2 + a3);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = 4 * q + v;
+                if (i < ns && r < n) F[((p0 + PP) * ns + i) * n + r] = J[v] + ((pass && i == r) ? 1.f : 0.f);   // mpc/dynamics.py:118-125
+            }
+        }
+        JacPoints<HT, PP + 1>::run(R, w1d, s, pass, p0, N, ns, n, q, r, F);
+    }
+};
+template <int HT> struct JacPoints<HT, 16> {
+    static __device__ __forceinline__ void run(const NetRegs<HT> &, const f32x4 (&)[HT], const f32x4 (&)[HT], int, long, long, int, int,
+                                               int, int, float *) {}
+};
+
+template <int HT>
+__global__ void __launch_bounds__(64) nn_linearize_fast_kernel(MlpDesc m, long N, int ns, int nc, const float *x, const float *u,
+                                                               float *F, float *f)
+{
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    const long p0 = (long)blockIdx.x * 16;
+    const long pt = (p0 + r < N) ? p0 + r : N - 1;
+    const int n = ns + nc;
+    NetRegs<HT> R;
+    load_net<HT>(R, m, q, r);
+    f32x4 w1d[HT];                      // W_1 in accumulator layout: rows (hidden units) 16 to + 4q + v, column r
+#pragma unroll
+    for (int to = 0; to < HT; ++to)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            w1d[to][v] = 16 * to < m.wp[1] ? m.packed[m.woff[0] + (16 * to + 4 * q + v) * 20 + r] : 0.f;
+    f32x4 tq;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int fe = 4 * q + v;
+        tq[v] = fe < ns ? x[pt * ns + fe] : (fe < n ? u[pt * nc + (fe - ns)] : 0.f);
+    }
+    f32x4 z[HT], s[HT];
+    layer1<HT>(R, tq, z);
+#pragma unroll
+    for (int to = 0; to < HT; ++to) {
+        const f32x4 lin = z[to] - R.b1[to];                     // W_1 tau
+        z[to] = act_fn(z[to], m.act);
+        s[to] = slope_fn(z[to], m.act);
+        z[to] = z[to] - s[to] * lin;
+    }
+    const f32x4 fv = layer2<HT>(R, z, R.b2);                    // net(x, u) - F [x;u]  (the passthrough x cancels)
+    if (p0 + r < N) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (4 * q + v < ns) f[pt * ns + 4 * q + v] = fv[v];                              // mpc/mpc.py:508-509
+    }
+    JacPoints<HT, 0>::run(R, w1d, s, m.pass, p0, N, ns, n, q, r, F);
+}
+
 inline int check_launch(const char *what)
 {
     hipError_t e = hipGetLastError();
@@ -363,7 +699,7 @@ inline int check_launch(const char *what)
 
 int pad16(int v) { return (v + 15) & ~15; }
 
-// validates the network, lays the packed weights out in the workspace and launches the packing kernel
+// validates the network, lays the packed block out in the workspace and launches the packing kernel
 int mlp_prepare(const mpc_mlp_dynamics *net, int ns, int nc, void *workspace, int64_t bytes, MlpDesc &d, hipStream_t st)
 {
     if (!net) { set_last_error("network is NULL"); return MPC_E_NULL; }
@@ -371,27 +707,32 @@ int mlp_prepare(const mpc_mlp_dynamics *net, int ns, int nc, void *workspace, in
     if (net->activation < MPC_ACT_SIGMOID || net->activation > MPC_ACT_ELU) { set_last_error("network: unknown activation"); return MPC_E_ARG; }
     if (net->widths[0] != ns + nc || net->widths[net->n_layers] != ns) { set_last_error("network: widths[0] must be n_state + n_ctrl, widths[L] n_state"); return MPC_E_DIMS; }
     if (ns > 16) { set_last_error("network kernels: n_state <= 16"); return MPC_E_DIMS; }
+    for (int l = 0; l <= net->n_layers; ++l)
+        if (net->widths[l] < 1 || net->widths[l] > 4096) { set_last_error("network: layer width out of range"); return MPC_E_DIMS; }
     if (mpc_mlp_workspace_bytes(net) > bytes || !workspace || ((uintptr_t)workspace & 15)) {
         set_last_error("network: workspace too small or not 16-byte aligned (see mpc_mlp_workspace_bytes)");
         return MPC_E_ARG;
     }
     PackArgs a;
-    a.L = d.L = net->n_layers;
+    d.L = net->n_layers;
     d.act = net->activation;
     d.pass = net->passthrough ? 1 : 0;
-    float *w = (float *)workspace;
-    for (int l = 0; l <= net->n_layers; ++l) {
-        if (net->widths[l] < 1 || net->widths[l] > 4096) { set_last_error("network: layer width out of range"); return MPC_E_DIMS; }
-        a.w[l] = d.w[l] = net->widths[l];
-        a.wp[l] = d.wp[l] = pad16(net->widths[l]);
+    for (int l = 0; l <= d.L; ++l) {
+        d.w[l] = net->widths[l];
+        d.wp[l] = pad16(net->widths[l]);
     }
-    for (int l = 0; l < net->n_layers; ++l) {
+    int off = 0;
+    for (int l = 0; l < d.L; ++l) {
         if (!net->W[l] || !net->b[l]) { set_last_error("network: weight / bias pointer is NULL"); return MPC_E_NULL; }
         a.W[l] = (const float *)net->W[l];
         a.b[l] = (const float *)net->b[l];
-        a.Wp[l] = w; d.W[l] = w; w += (size_t)d.wp[l + 1] * d.wp[l];
-        a.bp[l] = w; d.b[l] = w; w += d.wp[l + 1];
+        d.woff[l] = off; off += d.wp[l + 1] * (d.wp[l] + 4);
+        d.boff[l] = off; off += d.wp[l + 1];
     }
+    d.total = off;
+    d.packed = (const float *)workspace;
+    a.d = d;
+    a.dst = (float *)workspace;
     hipLaunchKernelGGL(mlp_pack_kernel, dim3(64), dim3(256), 0, st, a);
     return check_launch("mlp_pack_kernel");
 }
@@ -403,6 +744,15 @@ int max_hidden_pad(const MlpDesc &d)
     return h;
 }
 
+// LDS budget of a workgroup: the packed network (when it is staged) + one staging area per wavefront
+constexpr size_t LDS_MAX = 160 * 1024, WEIGHTS_IN_LDS_MAX = 96 * 1024;
+
+template <typename K> void allow_lds(K kernel, size_t lds)
+{
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 }  // namespace
 
 int launch_nn_rollout(const StepParams<float> &p, const mpc_mlp_dynamics *net, void *workspace, int64_t bytes, hipStream_t st)
@@ -410,12 +760,34 @@ int launch_nn_rollout(const StepParams<float> &p, const mpc_mlp_dynamics *net, v
     MlpDesc d;
     int rc = mlp_prepare(net, p.ns, p.nc, workspace, bytes, d, st);
     if (rc) return rc;
+    if (d.L == 2 && d.wp[0] == 16 && d.wp[1] <= 128 && p.nc <= 4) {
+        // one hidden layer of <= 128 units, n <= 16: the register-resident kernel
+        const unsigned g = (unsigned)(((long)p.B + 15) / 16);
+        const int ht = d.wp[1] >> 4;
+        if (ht <= 2) hipLaunchKernelGGL(nn_rollout_fast_kernel<2>, dim3(g), dim3(64), 0, st, p, d);
+        else if (ht <= 4) hipLaunchKernelGGL(nn_rollout_fast_kernel<4>, dim3(g), dim3(64), 0, st, p, d);
+        else if (ht <= 7) hipLaunchKernelGGL(nn_rollout_fast_kernel<7>, dim3(g), dim3(64), 0, st, p, d);
+        else hipLaunchKernelGGL(nn_rollout_fast_kernel<8>, dim3(g), dim3(64), 0, st, p, d);
+        return check_launch("nn_rollout_fast_kernel");
+    }
     const int TS = d.wp[0] + 4, ZS = max_hidden_pad(d) + 4;
-    const size_t lds = ((size_t)2 * 16 * TS + (size_t)2 * 16 * ZS) * sizeof(float);
-    if (lds > 160 * 1024) { set_last_error("network: layers too wide for the LDS-resident kernel"); return MPC_E_DIMS; }
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nn_rollout_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(nn_rollout_kernel, dim3((unsigned)((p.B + 15) / 16)), dim3(64), lds, st, p, d, TS, ZS);
+    const int wave_floats = 2 * 16 * TS + 2 * 16 * ZS;
+    const size_t wbytes = (size_t)d.total * 4, per_wave = (size_t)wave_floats * 4;
+    const bool wl = wbytes <= WEIGHTS_IN_LDS_MAX && wbytes + per_wave <= LDS_MAX;
+    if (!wl && per_wave > LDS_MAX) { set_last_error("network: layers too wide for the LDS-resident kernel"); return MPC_E_DIMS; }
+    // sixteen problems per wavefront; few groups -> one wavefront per workgroup so that every CU gets one
+    const long groups = ((long)p.B + 15) / 16;
+    int nw = groups >= 2048 ? 4 : (groups >= 1024 ? 2 : 1);
+    while (nw > 1 && (wl ? wbytes : 0) + nw * per_wave > LDS_MAX) nw >>= 1;
+    const size_t lds = (wl ? wbytes : 0) + nw * per_wave;
+    const unsigned grid = (unsigned)((groups + nw - 1) / nw);
+    if (wl) {
+        allow_lds(&nn_rollout_kernel<true>, lds);
+        hipLaunchKernelGGL(nn_rollout_kernel<true>, dim3(grid), dim3(64 * nw), lds, st, p, d, TS, ZS, wave_floats);
+    } else {
+        allow_lds(&nn_rollout_kernel<false>, lds);
+        hipLaunchKernelGGL(nn_rollout_kernel<false>, dim3(grid), dim3(64 * nw), lds, st, p, d, TS, ZS, wave_floats);
+    }
     return check_launch("nn_rollout_kernel");
 }
 
@@ -425,14 +797,34 @@ int launch_nn_linearize(const mpc_mlp_dynamics *net, long N, int ns, int nc, con
     MlpDesc d;
     int rc = mlp_prepare(net, ns, nc, workspace, bytes, d, st);
     if (rc) return rc;
+    if (d.L == 2 && d.wp[0] == 16 && d.wp[1] <= 128) {
+        const unsigned g = (unsigned)((N + 15) / 16);
+        const int ht = d.wp[1] >> 4;
+        if (ht <= 2) hipLaunchKernelGGL(nn_linearize_fast_kernel<2>, dim3(g), dim3(64), 0, st, d, N, ns, nc, x, u, F, f);
+        else if (ht <= 4) hipLaunchKernelGGL(nn_linearize_fast_kernel<4>, dim3(g), dim3(64), 0, st, d, N, ns, nc, x, u, F, f);
+        else if (ht <= 7) hipLaunchKernelGGL(nn_linearize_fast_kernel<7>, dim3(g), dim3(64), 0, st, d, N, ns, nc, x, u, F, f);
+        else hipLaunchKernelGGL(nn_linearize_fast_kernel<8>, dim3(g), dim3(64), 0, st, d, N, ns, nc, x, u, F, f);
+        return check_launch("nn_linearize_fast_kernel");
+    }
     const int TS = d.wp[0] + 4, ZS = max_hidden_pad(d) + 4, NTJ = d.wp[0] >> 4;
     int GT = 1;
     for (int l = 1; l < d.L; ++l) GT = (d.wp[l] >> 4) * NTJ > GT ? (d.wp[l] >> 4) * NTJ : GT;
-    const size_t lds = ((size_t)16 * TS + (size_t)(d.L > 1 ? d.L - 1 : 1) * 16 * ZS) * sizeof(float) + (size_t)2 * GT * 64 * 16;
-    if (lds > 160 * 1024) { set_last_error("network: layers too wide for the LDS-resident kernel"); return MPC_E_DIMS; }
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&nn_linearize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(nn_linearize_kernel, dim3((unsigned)((N + 15) / 16)), dim3(64), lds, st, d, N, ns, nc, x, u, F, f, TS, ZS, GT);
+    const int wave_floats = 16 * TS + (d.L > 1 ? d.L - 1 : 1) * 16 * ZS + 2 * GT * 64 * 4;
+    const size_t wbytes = (size_t)d.total * 4, per_wave = (size_t)wave_floats * 4;
+    const bool wl = wbytes <= WEIGHTS_IN_LDS_MAX && wbytes + per_wave <= LDS_MAX;
+    if (!wl && per_wave > LDS_MAX) { set_last_error("network: layers too wide for the LDS-resident kernel"); return MPC_E_DIMS; }
+    const long groups = (N + 15) / 16;
+    int nw = groups >= 4096 ? 8 : (groups >= 2048 ? 4 : (groups >= 1024 ? 2 : 1));
+    while (nw > 1 && (wl ? wbytes : 0) + nw * per_wave > LDS_MAX) nw >>= 1;
+    const size_t lds = (wl ? wbytes : 0) + nw * per_wave;
+    const unsigned grid = (unsigned)((groups + nw - 1) / nw);
+    if (wl) {
+        allow_lds(&nn_linearize_kernel<true>, lds);
+        hipLaunchKernelGGL(nn_linearize_kernel<true>, dim3(grid), dim3(64 * nw), lds, st, d, N, ns, nc, x, u, F, f, TS, ZS, GT, wave_floats);
+    } else {
+        allow_lds(&nn_linearize_kernel<false>, lds);
+        hipLaunchKernelGGL(nn_linearize_kernel<false>, dim3(grid), dim3(64 * nw), lds, st, d, N, ns, nc, x, u, F, f, TS, ZS, GT, wave_floats);
+    }
     return check_launch("nn_linearize_kernel");
 }
 

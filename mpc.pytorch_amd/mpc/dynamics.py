@@ -88,6 +88,16 @@ class NNDynamics(nn.Module):
         out = z + x if self.passthrough else z
         return out[0] if was_vector else out
 
+    def native_net(self, like):
+        """The network as the kernels take it (csrc/nn_dynamics.hip: layers on MFMA, 16 problems per wavefront), or None
+        when this network / tensor is outside their limits (fp32 on the device, <= 4 layers, n_state <= 16) -- the
+        caller then calls the module timestep by timestep like the reference (mpc/lqr_step.py:223-225)."""
+        from ._native import MlpSpec
+        weights = [layer.weight for layer in self.fcs]
+        if not MlpSpec.supported(weights, self.activation, like):
+            return None
+        return MlpSpec(weights, [layer.bias for layer in self.fcs], self.activation, self.passthrough)
+
     def _slope(self, z):
         if self.activation == "relu":
             return (z > 0).to(z.dtype)

@@ -8,8 +8,9 @@ tuples, same gradient convention).  What differs is where the work happens:
   backward  KKT system = one more LQR step on (C, -r, F) + a costate / outer-product kernel
             (mpc_lqr_kkt_prepare, mpc_lqr_step, mpc_lqr_kkt_grads)
 
-Module-valued `true_dynamics` / `true_cost` (iLQR on a simulator) keep the sweep on the kernel and
-run the rollout as a per-timestep loop of device ops, because the user's module has to be called.
+Module-valued `true_dynamics` / `true_cost` keep the sweep on the kernel; the shipped simulators and
+`mpc.dynamics.NNDynamics` (fp32) also roll out inside kernels, any other module is called timestep by
+timestep in a loop of device ops.
 """
 from collections import namedtuple
 
@@ -240,8 +241,22 @@ def LQRStep(n_state,
                                 true_dynamics=true_dynamics.native_env())
             r = be.lqr_step(x_init, C, c, F, f_in, current_x, current_u, o, rollout_problem=rp)
             return r["new_x"], r["new_u"], r["qp_iters"], r["costs"], r["full_du_norm"], r["alphas"]
-        sw = be.lqr_sweep(x_init.detach(), C, c, F, current_x.detach(), current_u.detach(), opts)
         from . import util as _util
+        net = true_dynamics.native_net(C) if quad and hasattr(true_dynamics, "native_net") else None
+        if net is not None:
+            # NNDynamics (:223-225): the sweep on the fastest kernel for this shape (its own rollout through F, f is
+            # one pass whose result is discarded), then the line-searched rollout through the network in one kernel
+            sweep_opts = StepOptions(u_lower=u_lower, u_upper=u_upper, u_zero_I=u_zero_I, delta_u=delta_u,
+                                     linesearch_decay=linesearch_decay, max_linesearch_iter=1)
+            cx, cu = current_x.detach(), current_u.detach()
+            r = be.lqr_step(x_init.detach(), C.detach(), c.detach(), F.detach(), f_in, cx, cu, sweep_opts, want_gains=True)
+            tC, tc = (C, c) if true_cost is None else (true_cost.C, true_cost.c)
+            old_cost = r["old_costs"]
+            if not (_same_storage(tC, C) and _same_storage(tc, c)):
+                old_cost = _util.get_cost(T, cu, true_cost, true_dynamics, x=cx)
+            rr = be.mlp_rollout(x_init.detach(), tC.detach(), tc.detach(), r["K"], r["k"], cx, cu, old_cost, opts, net)
+            return rr["new_x"], rr["new_u"], r["qp_iters"], rr["costs"], rr["full_du_norm"], rr["alphas"]
+        sw = be.lqr_sweep(x_init.detach(), C, c, F, current_x.detach(), current_u.detach(), opts)
         old_cost = _util.get_cost(T, current_u.detach(), true_cost, true_dynamics, x=current_x.detach())
         nx, nu, cost, fdn, _, alphas = _module_rollout(
             n_state, n_ctrl, T, x_init.detach(), sw["K"], sw["k"], current_x.detach(), current_u.detach(),

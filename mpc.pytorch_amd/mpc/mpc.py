@@ -459,6 +459,12 @@ class MPC(Module):
         T, ns, nc = self.T, self.n_state, self.n_ctrl
         B = x.shape[1]
         if self.grad_method == GradMethods.ANALYTIC:
+            net = dynamics.native_net(x) if (not diff and hasattr(dynamics, "native_net") and T > 1) else None
+            if net is not None and net.activation != "elu":
+                # NNDynamics: forward, grad_input and the affine term in one kernel, no [N, hidden, n] intermediates
+                # (elu has no grad_input in the reference, mpc/dynamics.py:113-114: left to the module to refuse)
+                Fl, fl = _native.backend().mlp_linearize(net, x[:-1].reshape(-1, ns), u[:-1].reshape(-1, nc))
+                return Fl.view(T - 1, B, ns, ns + nc), fl.view(T - 1, B, ns)
             # fresh leaves, as the reference (mpc/mpc.py:495-497): with diff=True the graph reaches the
             # dynamics' parameters (through new_x, R, S), not the trajectory itself.
             _x = x[:-1].reshape(-1, ns).detach().requires_grad_(True)

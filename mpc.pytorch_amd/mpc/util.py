@@ -117,6 +117,10 @@ def get_traj(T, u, x_init, dynamics):
     if hasattr(dynamics, "native_env") and T > 1:       # a shipped simulator: one kernel
         x, _ = _native.backend().env_traj_cost(x_init, u, dynamics.native_env())
         return x
+    net = dynamics.native_net(x_init) if hasattr(dynamics, "native_net") and T > 1 else None
+    if net is not None:                                  # NNDynamics: the whole rollout in one kernel
+        x, _ = _native.backend().mlp_traj_cost(x_init, u.to(x_init.dtype), net)
+        return x
     xs = [x_init]
     with torch.no_grad():
         for t in range(T - 1):

@@ -141,3 +141,75 @@ def test_network_rollout_and_linearisation_at_full_batches(be, ns, nc, hidden, a
     np.testing.assert_allclose(host(r["full_du_norm"])[same], full[same], rtol=2e-3, atol=2e-4)
     if bound is not None:
         assert (host(r["new_u"]) >= lo - 1e-6).all() and (host(r["new_u"]) <= hi + 1e-6).all()
+
+
+def _mpc_solve(z, dyn, dev, lqr_iter=None):
+    from mpc import mpc
+    ns, nc, T, B, it = (int(v) for v in z["meta"])
+    bound = float(z["bound"][0])
+    lo, hi = (None, None) if np.isnan(bound) else (-bound, bound)
+    ctrl = mpc.MPC(ns, nc, T, u_lower=lo, u_upper=hi, lqr_iter=lqr_iter or it, verbose=-1, exit_unconverged=False,
+                   detach_unconverged=False, linesearch_decay=float(z["decay"][0]),
+                   max_linesearch_iter=int(z["max_ls"][0]), grad_method=mpc.GradMethods.ANALYTIC,
+                   u_init=f32(z["step_cur_u"]).to(dev))
+    return ctrl(f32(z["x_init"]).to(dev), mpc.QuadCost(f32(z["C"]).to(dev), f32(z["c"]).to(dev)), dyn)
+
+
+def _module_of(z, dev):
+    from mpc.dynamics import NNDynamics
+    from oracle import env_oracle as E
+    net = E.Mlp.from_npz(z)
+    ns, nc = (int(v) for v in z["meta"][:2])
+    hidden = [W.shape[0] for W in net.Ws[:-1]]
+    dyn = NNDynamics(ns, nc, hidden, activation=net.activation, passthrough=net.passthrough)
+    with torch.no_grad():
+        for fc, W, b in zip(dyn.fcs, net.Ws, net.bs):
+            fc.weight.copy_(torch.from_numpy(W).float())
+            fc.bias.copy_(torch.from_numpy(b).float())
+    return dyn.to(dev)
+
+
+@pytest.mark.parametrize("name", NN_CASES)
+def test_mpc_forward_with_nndynamics_matches_the_reference_solve(be, name, monkeypatch):
+    """mpc.MPC(...)(x_init, QuadCost, NNDynamics) on the device, float32 -- trajectory, linearisation and rollouts in the
+    kernels -- against the reference's own float64 solve of the same problem (fixture `solve_*`), and against this
+    package's host-driven path (the module called timestep by timestep), which must take the same iterations."""
+    from mpc import _native
+    z = golden(name)
+    dyn = _module_of(z, DEV)
+    calls = {"rollout": 0, "linearize": 0}
+    orig_r, orig_l = _native.HipBackend.mlp_rollout, _native.HipBackend.mlp_linearize
+
+    def count_r(self, *a, **k):
+        calls["rollout"] += 1
+        return orig_r(self, *a, **k)
+
+    def count_l(self, *a, **k):
+        calls["linearize"] += 1
+        return orig_l(self, *a, **k)
+    monkeypatch.setattr(_native.HipBackend, "mlp_rollout", count_r)
+    monkeypatch.setattr(_native.HipBackend, "mlp_linearize", count_l)
+    x, u, costs = _mpc_solve(z, dyn, DEV)
+    torch.cuda.synchronize()
+    assert calls["rollout"] >= 1 and calls["linearize"] >= 1          # the kernels ran, not the module loop
+    np.testing.assert_allclose(host(costs), z["solve_costs"], rtol=2e-3)
+    np.testing.assert_allclose(host(u), z["solve_u"], rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(host(x), z["solve_x"], rtol=5e-3, atol=5e-3)
+    # the host-driven path of this package on the same problem
+    monkeypatch.setattr(type(dyn), "native_net", lambda self, like: None)
+    x2, u2, costs2 = _mpc_solve(z, dyn, DEV)
+    np.testing.assert_allclose(host(costs), host(costs2), rtol=1e-3)
+    # (two float32 paths, six iLQR iterations apart: the same tolerance as against the float64 solve)
+    np.testing.assert_allclose(host(u), host(u2), rtol=5e-3, atol=5e-3)
+
+
+def test_lqrstep_gradients_flow_to_the_network_parameters(be):
+    """The differentiable path is unchanged by the kernels: with diff=True the linearisation goes through torch and a
+    loss on (x, u) reaches the network's weights (tests/test_mpc.py:652-744 checks the same for its slew variant)."""
+    z = golden("nn_sigmoid_f64")
+    dyn = _module_of(z, DEV)
+    x, u, costs = _mpc_solve(z, dyn, DEV, lqr_iter=8)
+    loss = x.pow(2).sum() + u.pow(2).sum()
+    g = torch.autograd.grad(loss, [dyn.fcs[0].weight, dyn.fcs[-1].bias], allow_unused=True)
+    assert all(t is not None and torch.isfinite(t).all() for t in g)
+    assert float(g[0].abs().max()) > 0
