@@ -255,6 +255,43 @@ def extra_rows(be, dev, steps):
             problem_steps_per_s=B * T * 10 / (ms * 1e-3), mean_cost=float(out[2].mean()),
             note="MPC.forward on mpc.env_dx.%s: the step kernel linearises the simulator and rolls it out itself"
                  % ("PendulumDx" if kind == "pendulum" else "CartpoleDx"))
+    # ---- NNDynamics (the reference's default network: one hidden layer of 100 sigmoid units) at the headline shape ----
+    from mpc.dynamics import NNDynamics
+    torch.manual_seed(0)
+    dyn = NNDynamics(NS, NC, [100], activation="sigmoid").to(dev)
+    net = dyn.native_net(torch.empty(1, device=dev))
+    p = make_problem(NS, NC, T_H, B_PER_GPU, torch.float32, dev, seed=5, u_scale=0.3, clamp=1.0)
+    xs, _ = be.mlp_traj_cost(p["x_init"], p["cur_u"], net)
+    X, U = xs[:-1].reshape(-1, NS), p["cur_u"][:-1].reshape(-1, NC)
+    wall, ms, _ = timed(lambda: be.mlp_traj_cost(p["x_init"], p["cur_u"], net), k, 5)
+    rows["nn_get_traj"] = dict(ms=ms, wall_ms=wall, problem_steps_per_s=B_PER_GPU * T_H / (ms * 1e-3),
+                               workload="util.get_traj through NNDynamics(12, 4, [100], sigmoid), B=%d T=%d: weight packing + "
+                                        "one kernel, the network's layers on fp32 MFMA, 16 problems per wavefront" % (B_PER_GPU, T_H))
+    wall, ms, (Fl, fl) = timed(lambda: be.mlp_linearize(net, X, U), k, 5)
+    flops = 2.0 * X.shape[0] * (16 * 112 * 16 + 2 * 112 * 16)             # per point: W2 (16x112) G (112x16) + two layer passes, padded tiles
+    rows["nn_linearize"] = dict(ms=ms, wall_ms=wall, points=int(X.shape[0]), finite=bool(torch.isfinite(Fl).all().item()),
+                                workload="MPC.linearize_dynamics(ANALYTIC) for that network at all (T-1) B points: F [N,12,16], f [N,12]",
+                                mfma_fp32={"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF,
+                                           "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF})
+    F, f = Fl.view(T_H - 1, B_PER_GPU, NS, NS + NC), fl.view(T_H - 1, B_PER_GPU, NS)
+    sw_opts = StepOptions(u_lower=-1.0, u_upper=1.0, max_linesearch_iter=1)
+    opts = StepOptions(u_lower=-1.0, u_upper=1.0)
+    sw = be.lqr_step(p["x_init"], p["C"], p["c"], F, f, xs, p["cur_u"], sw_opts, want_gains=True)
+    wall, ms, rr = timed(lambda: be.mlp_rollout(p["x_init"], p["C"], p["c"], sw["K"], sw["k"], xs, p["cur_u"], sw["old_costs"],
+                                                opts, net), k, 5)
+    rows["nn_rollout_linesearch"] = dict(ms=ms, wall_ms=wall, mean_alpha=float(rr["alphas"].mean()),
+                                         finite=bool(torch.isfinite(rr["costs"]).all().item()),
+                                         workload="lqr_forward with the network as true_dynamics (bounds +-1, up to 10 line-search "
+                                                  "passes per problem) after a sweep on the 12/4 kernel")
+    ctrl = mpc.MPC(NS, NC, T_H, u_lower=-1.0, u_upper=1.0, lqr_iter=5, verbose=-1, exit_unconverged=False,
+                   detach_unconverged=False, grad_method=mpc.GradMethods.ANALYTIC, backprop=False, u_init=p["cur_u"].clone())
+    cost = QuadCost(p["C"], p["c"])
+    with torch.no_grad():
+        wall, ms, _ = timed(lambda: ctrl(p["x_init"], cost, dyn), 3, 1)
+    rows["nn_mpc_forward_5iter"] = dict(ms=ms, wall_ms=wall, lqr_iter=5,
+                                        note="whole MPC.forward on the network: per iteration get_traj + linearisation + sweep + "
+                                             "line-searched rollout kernels; the module called timestep by timestep (this package's "
+                                             "fallback, the reference's only path) takes ~450 ms (tools/nn_bench.py)")
     return rows
 
 
