@@ -420,10 +420,14 @@ template <int HT> __device__ __forceinline__ void load_net(NetRegs<HT> &R, const
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int to = 0; to < HT; ++to) {
-        const bool in = 16 * to < m.wp[1];
-        R.w1[to] = in ? *reinterpret_cast<const f32x4 *>(P + m.woff[0] + (16 * to + r) * 20 + 4 * q) : zero;
-        R.b1[to] = in ? *reinterpret_cast<const f32x4 *>(P + m.boff[0] + 16 * to + 4 * q) : zero;
-        R.w2[to] = in ? *reinterpret_cast<const f32x4 *>(P + m.woff[1] + r * ld2 + 16 * to + 4 * q) : zero;
+        const bool in = 16 * to < m.wp[1];                      // (wave-uniform)
+        const int tc = in ? to : 0;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(P + m.woff[0] + (16 * tc + r) * 20 + 4 * q);
+        const f32x4 bb = *reinterpret_cast<const f32x4 *>(P + m.boff[0] + 16 * tc + 4 * q);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(P + m.woff[1] + r * ld2 + 16 * tc + 4 * q);
+        R.w1[to] = in ? a : zero;
+        R.b1[to] = in ? bb : zero;
+        R.w2[to] = in ? c : zero;
     }
     R.b2 = *reinterpret_cast<const f32x4 *>(P + m.boff[1] + 4 * q);
 }
@@ -452,24 +456,39 @@ template <int HT> __device__ __forceinline__ f32x4 layer2(const NetRegs<HT> &R, 
     return (a0 + a1) + (a2 + a3);
 }
 
-// sixteen floats of a row that need not be 16-byte aligned or 16 long (columns >= len come back as 0)
+// sixteen floats of a row that need not be 16-byte aligned or 16 long (columns >= len come back as 0).  Every load is
+// unconditional from a clamped address and masked afterwards: a load under a lane-dependent condition becomes a branch
+// around it, and the joins of those branches are where the compiler drains the whole load queue.
 __device__ __forceinline__ void load_row(const float *row, int len, bool vec, f32x4 (&o)[4])
 {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if (vec) {
-            o[g] = 4 * g < len ? *reinterpret_cast<const f32x4 *>(row + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool in = 4 * g < len;
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(row + (in ? 4 * g : 0));
+            o[g] = in ? t : f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[g][e] = 4 * g + e < len ? row[4 * g + e] : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const bool in = 4 * g + e < len;
+                const float t = row[in ? 4 * g + e : 0];
+                o[g][e] = in ? t : 0.f;
+            }
         }
     }
+}
+__device__ __forceinline__ float load_if(const float *p, long idx, bool in)
+{
+    const float t = p[in ? idx : 0];
+    return in ? t : 0.f;
 }
 
 // lqr_forward through the network, one wavefront per workgroup, sixteen problems per wavefront (see nn_rollout_kernel
 // for the roles of the lanes).  What one step needs from memory -- rows 4q..4q+3 of C_t, c_t, row q of K_t, k_t, the
 // nominal -- is requested one step ahead, before the network's MFMAs, and consumed after them.
-template <int HT>
+// GAIN: line search with feedback gains (else the controls are the nominal ones); COST: the quadratic cost is summed.
+// Rows are read 16 bytes at a time: n_state and n_state + n_ctrl multiples of 4 (else the general kernel runs).
+template <int HT, bool GAIN, bool COST>
 __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p, MlpDesc m)
 {
     __shared__ __attribute__((aligned(16))) float tauS[16 * 20], dxS[16 * 20];
@@ -479,8 +498,7 @@ __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p
     const long b = valid ? b_raw : p.B - 1;
     const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T;
     const long B = p.B;
-    const bool has_gain = p.K != nullptr, has_cost = p.C != nullptr;
-    const bool vecC = (n & 3) == 0 && (p.C_st & 3) == 0 && (p.C_sb & 3) == 0, vecK = (ns & 3) == 0;
+    constexpr bool has_gain = GAIN, has_cost = COST, vecC = true, vecK = true;
     const float old_cost = p.old_costs_in ? p.old_costs_in[b] : 0.f;
     NetRegs<HT> R;
     load_net<HT>(R, m, q, r);
@@ -498,52 +516,55 @@ __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int f = 4 * q + v;
-            xr[v] = f < ns ? p.x_init[b * ns + f] : 0.f;
+            xr[v] = load_if(p.x_init, b * ns + f, f < ns);
             if (active && f < ns) p.new_x[b * ns + f] = xr[v];
         }
-        // operands of step t, requested at step t - 1
-        f32x4 Cr[4][4], Kr[4], cq = {0.f, 0.f, 0.f, 0.f}, cx = cq;
-        float kq = 0.f, uq = 0.f;
-        auto request = [&](int t) {
+        // operands of step t, requested one step ahead, before the network's MFMAs of step t - 1.  (Two steps ahead
+        // with a second register set was no faster: at ~460 registers the loads serialise behind register reuse.)
+        struct Ops {
+            f32x4 Cr[4][4], Kr[4], cq, cx;
+            float kq, uq;
+        } opA;
+        auto request = [&](int t, Ops &o) {
             const long tb = (long)t * B + b;
             if (has_cost) {
                 const float *Ct = p.C + (long)t * p.C_st + b * p.C_sb, *ct = p.c + (long)t * p.c_st + b * p.c_sb;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int i = 4 * q + v < n ? 4 * q + v : 0;
-                    load_row(Ct + i * n, 4 * q + v < n ? n : 0, vecC, Cr[v]);
-                    cq[v] = 4 * q + v < n ? ct[i] : 0.f;
+                    load_row(Ct + i * n, 4 * q + v < n ? n : 0, vecC, o.Cr[v]);
+                    o.cq[v] = load_if(ct, i, 4 * q + v < n);
                 }
             }
             if (has_gain) {
-                load_row(p.K + (tb * nc + (own_u ? q : 0)) * ns, own_u ? ns : 0, vecK, Kr);
-                kq = own_u ? p.k[tb * nc + q] : 0.f;
+                load_row(p.K + (tb * nc + (own_u ? q : 0)) * ns, own_u ? ns : 0, vecK, o.Kr);
+                o.kq = load_if(p.k, tb * nc + q, own_u);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) cx[v] = 4 * q + v < ns ? p.cur_x[tb * ns + 4 * q + v] : 0.f;
+                for (int v = 0; v < 4; ++v) o.cx[v] = load_if(p.cur_x, tb * ns + 4 * q + v, 4 * q + v < ns);
             }
-            uq = own_u ? p.cur_u[tb * nc + q] : 0.f;
+            o.uq = load_if(p.cur_u, tb * nc + q, own_u);
         };
-        request(0);
         float ca = 0.f, da = 0.f;
-        for (int t = 0; t < T; ++t) {
+        auto step = [&](int t, Ops &o) {
             const long tb = (long)t * B + b;
             // the state quad goes first: a quad that straddles n_state also covers control slots, written next
             *reinterpret_cast<f32x4 *>(tauS + r * 20 + 4 * q) = xr;
-            *reinterpret_cast<f32x4 *>(dxS + r * 20 + 4 * q) = has_gain ? xr - cx : f32x4{0.f, 0.f, 0.f, 0.f};   // :227
+            *reinterpret_cast<f32x4 *>(dxS + r * 20 + 4 * q) = has_gain ? xr - o.cx : f32x4{0.f, 0.f, 0.f, 0.f};   // :227
             wave_sync();
             if (own_u) {
+                const float uq = o.uq;
                 float un = uq;
                 if (has_gain) {
                     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 d = *reinterpret_cast<const f32x4 *>(dxS + r * 20 + 4 * g);
-                        s0 = fmaf(Kr[g][0], d[0], s0);
-                        s1 = fmaf(Kr[g][1], d[1], s1);
-                        s0 = fmaf(Kr[g][2], d[2], s0);
-                        s1 = fmaf(Kr[g][3], d[3], s1);
+                        s0 = fmaf(o.Kr[g][0], d[0], s0);
+                        s1 = fmaf(o.Kr[g][1], d[1], s1);
+                        s0 = fmaf(o.Kr[g][2], d[2], s0);
+                        s1 = fmaf(o.Kr[g][3], d[3], s1);
                     }
-                    un = (s0 + s1) + uq + alpha * kq;                                       // :192
+                    un = (s0 + s1) + uq + alpha * o.kq;                                     // :192
                     if (p.zero_mask && p.zero_mask[tb * nc + q]) un = 0.f;                  // :197-198
                     if (p.bound_mode != MPC_BOUND_NONE) {                                   // :200-213
                         float lo = p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : p.lo[tb * nc + q];
@@ -572,27 +593,29 @@ __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p
 #pragma unroll
                     for (int v = 0; v < 4; ++v)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) s[v] = fmaf(Cr[v][g][e], tg[e], s[v]);
+                        for (int e = 0; e < 4; ++e) s[v] = fmaf(o.Cr[v][g][e], tg[e], s[v]);
                 }
 #pragma unroll
-                for (int v = 0; v < 4; ++v) ca = fmaf(tq[v], fmaf(0.5f, s[v], cq[v]), ca);
+                for (int v = 0; v < 4; ++v) ca = fmaf(tq[v], fmaf(0.5f, s[v], o.cq[v]), ca);
             }
+            if (t + 1 < T) request(t + 1, o);
             if (t + 1 < T) {
-                request(t + 1);
                 f32x4 z[HT];                                                                // :223-225
                 layer1<HT>(R, tq, z);
 #pragma unroll
                 for (int to = 0; to < HT; ++to) z[to] = act_fn(z[to], m.act);
-                const f32x4 o = layer2<HT>(R, z, R.b2);
+                const f32x4 out = layer2<HT>(R, z, R.b2);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int f = 4 * q + v;
-                    xr[v] = f < ns ? o[v] + (m.pass ? xr[v] : 0.f) : 0.f;                   // mpc/dynamics.py:74-75
+                    xr[v] = f < ns ? out[v] + (m.pass ? xr[v] : 0.f) : 0.f;                 // mpc/dynamics.py:74-75
                     if (active && f < ns) p.new_x[((long)(t + 1) * B + b) * ns + f] = xr[v];
                 }
             }
             wave_sync();
-        }
+        };
+        request(0, opA);
+        for (int t = 0; t < T; ++t) step(t, opA);
         ca += __shfl_xor(ca, 16);
         ca += __shfl_xor(ca, 32);
         da += __shfl_xor(da, 16);
@@ -662,12 +685,13 @@ __global__ void __launch_bounds__(64) nn_linearize_fast_kernel(MlpDesc m, long N
     for (int to = 0; to < HT; ++to)
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-            w1d[to][v] = 16 * to < m.wp[1] ? m.packed[m.woff[0] + (16 * to + 4 * q + v) * 20 + r] : 0.f;
+            w1d[to][v] = load_if(m.packed, m.woff[0] + (16 * to + 4 * q + v) * 20 + r, 16 * to < m.wp[1]);
     f32x4 tq;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int fe = 4 * q + v;
-        tq[v] = fe < ns ? x[pt * ns + fe] : (fe < n ? u[pt * nc + (fe - ns)] : 0.f);
+        const float tx = load_if(x, pt * ns + fe, fe < ns), tu = load_if(u, pt * nc + (fe - ns), fe >= ns && fe < n);
+        tq[v] = fe < ns ? tx : tu;
     }
     f32x4 z[HT], s[HT];
     layer1<HT>(R, tq, z);
@@ -760,14 +784,23 @@ int launch_nn_rollout(const StepParams<float> &p, const mpc_mlp_dynamics *net, v
     MlpDesc d;
     int rc = mlp_prepare(net, p.ns, p.nc, workspace, bytes, d, st);
     if (rc) return rc;
-    if (d.L == 2 && d.wp[0] == 16 && d.wp[1] <= 128 && p.nc <= 4) {
+    const bool rows16 = (p.ns & 3) == 0 && ((p.ns + p.nc) & 3) == 0 && (!p.C || ((p.C_st & 3) == 0 && (p.C_sb & 3) == 0));
+    if (d.L == 2 && d.wp[0] == 16 && d.wp[1] <= 128 && p.nc <= 4 && rows16) {
         // one hidden layer of <= 128 units, n <= 16: the register-resident kernel
         const unsigned g = (unsigned)(((long)p.B + 15) / 16);
         const int ht = d.wp[1] >> 4;
-        if (ht <= 2) hipLaunchKernelGGL(nn_rollout_fast_kernel<2>, dim3(g), dim3(64), 0, st, p, d);
-        else if (ht <= 4) hipLaunchKernelGGL(nn_rollout_fast_kernel<4>, dim3(g), dim3(64), 0, st, p, d);
-        else if (ht <= 7) hipLaunchKernelGGL(nn_rollout_fast_kernel<7>, dim3(g), dim3(64), 0, st, p, d);
-        else hipLaunchKernelGGL(nn_rollout_fast_kernel<8>, dim3(g), dim3(64), 0, st, p, d);
+        const int mode = p.K ? 2 : (p.C ? 1 : 0);
+#define MPC_NN_LAUNCH(HT_)                                                                                                  \
+        do {                                                                                                                 \
+            if (mode == 2) hipLaunchKernelGGL((nn_rollout_fast_kernel<HT_, true, true>), dim3(g), dim3(64), 0, st, p, d);      \
+            else if (mode == 1) hipLaunchKernelGGL((nn_rollout_fast_kernel<HT_, false, true>), dim3(g), dim3(64), 0, st, p, d); \
+            else hipLaunchKernelGGL((nn_rollout_fast_kernel<HT_, false, false>), dim3(g), dim3(64), 0, st, p, d);              \
+        } while (0)
+        if (ht <= 2) MPC_NN_LAUNCH(2);
+        else if (ht <= 4) MPC_NN_LAUNCH(4);
+        else if (ht <= 7) MPC_NN_LAUNCH(7);
+        else MPC_NN_LAUNCH(8);
+#undef MPC_NN_LAUNCH
         return check_launch("nn_rollout_fast_kernel");
     }
     const int TS = d.wp[0] + 4, ZS = max_hidden_pad(d) + 4;
