@@ -12,7 +12,9 @@ Module-valued `true_dynamics` / `true_cost` keep the sweep on the kernel; the sh
 `mpc.dynamics.NNDynamics` (fp32) also roll out inside kernels, any other module is called timestep by
 timestep in a loop of device ops.
 """
-from collections import namedtuple
+import os
+import weakref
+from collections import OrderedDict, namedtuple
 
 import torch
 from torch.autograd import Function
@@ -38,60 +40,151 @@ def _bound_at(v, t):
     return v if isinstance(v, (float, int)) else v[t]
 
 
+def _rollout_pass(T, x_init, K, k, cur_x, cur_u, alpha, true_cost, true_dynamics, opts):
+    """One pass of lqr_forward (mpc/lqr_step.py:181-241) with a module as dynamics and / or cost, every problem with its
+    own step size alpha [B,1]: device ops only, nothing read back.  Returns new_x, new_u, cost [B], ||u - u'|| [B]."""
+    from . import mpc as _mpc
+    lin = isinstance(true_dynamics, _mpc.LinDx)
+    quad = isinstance(true_cost, _mpc.QuadCost)
+    xs, us, objs = [x_init], [], []
+    dx = torch.zeros_like(x_init)
+    for t in range(T):
+        ut = cur_u[t]
+        nu = torch.einsum("bij,bj->bi", K[t], dx) + ut + alpha * k[t]
+        if opts.u_zero_I is not None:
+            nu = nu.masked_fill(opts.u_zero_I[t].bool(), 0.0)
+        if opts.u_lower is not None:
+            lo, hi = _bound_at(opts.u_lower, t), _bound_at(opts.u_upper, t)
+            if opts.delta_u is not None:          # (no host scalar becomes a device tensor here: that copy cannot be captured)
+                lo = torch.maximum(ut - opts.delta_u, lo.to(ut.dtype)) if torch.is_tensor(lo) else (ut - opts.delta_u).clamp(min=float(lo))
+                hi = torch.minimum(ut + opts.delta_u, hi.to(ut.dtype)) if torch.is_tensor(hi) else (ut + opts.delta_u).clamp(max=float(hi))
+            if torch.is_tensor(lo):
+                nu = torch.min(torch.max(nu, lo.to(nu.dtype)), hi.to(nu.dtype))
+            else:
+                nu = nu.clamp(float(lo), float(hi))
+        us.append(nu)
+        tau = torch.cat((xs[t], nu), 1)
+        if t < T - 1:
+            if lin:
+                nx = torch.einsum("bij,bj->bi", true_dynamics.F[t].detach(), tau)
+                if not _is_empty(true_dynamics.f):
+                    nx = nx + true_dynamics.f[t].detach()
+            else:
+                nx = true_dynamics(xs[t], nu).detach()
+            xs.append(nx)
+            dx = nx - cur_x[t + 1]
+        if quad:
+            Ct, ct = true_cost.C[t].detach(), true_cost.c[t].detach()
+            objs.append(0.5 * torch.einsum("bi,bij,bj->b", tau, Ct, tau) + (tau * ct).sum(1))
+        else:
+            objs.append(true_cost(tau).detach())
+    new_x, new_u = torch.stack(xs), torch.stack(us)
+    cost = torch.stack(objs).sum(0)
+    du_norm = (cur_u - new_u).pow(2).sum((0, 2)).sqrt()
+    return new_x, new_u, cost, du_norm
+
+
+class _GraphedPass:
+    """`_rollout_pass` for one (module, shapes, options) captured in a HIP graph: a pass is T x ~15 small launches, which
+    the host issues slower than the device runs them; replayed, the pass costs one launch.  The gains, the nominal and the
+    step sizes are copied into the graph's static buffers (they change every call); the cost's C, c, tensor bounds and the
+    module's parameters are captured by address -- the cache key holds those addresses, an optimiser updating weights in
+    place is seen.  Capturing runs the module three extra times (two warm-ups on a side stream + the capture itself)."""
+
+    def __init__(self, T, x_init, K, k, cur_x, cur_u, true_cost, true_dynamics, opts):
+        self.static = [t.clone() for t in (x_init, K, k, cur_x, cur_u)]
+        self.alpha = torch.ones(x_init.shape[0], 1, dtype=x_init.dtype, device=x_init.device)
+        run = lambda: _rollout_pass(T, *self.static, self.alpha, true_cost, true_dynamics, opts)
+        side = torch.cuda.Stream(device=x_init.device)
+        side.wait_stream(torch.cuda.current_stream(x_init.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                run()
+        torch.cuda.current_stream(x_init.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = run()
+
+    def __call__(self, x_init, K, k, cur_x, cur_u, alpha):
+        for dst, src in zip(self.static, (x_init, K, k, cur_x, cur_u)):
+            dst.copy_(src)
+        self.alpha.copy_(alpha)
+        self.graph.replay()
+        return self.out
+
+
+_PASS_GRAPHS = OrderedDict()       # key -> (_GraphedPass | None when capture failed, weak refs to the modules)
+_PASS_GRAPHS_MAX = 4
+
+
+def _addr(v):
+    return v.data_ptr() if torch.is_tensor(v) else v
+
+
+def _graphed_pass(T, x_init, K, k, cur_x, cur_u, true_cost, true_dynamics, opts):
+    """The cached graph for this rollout, or None.  OPT-IN: a replayed graph repeats the device work it recorded, so a
+    module whose behaviour depends on Python-side state (a flag, a counter, `train()` / `eval()`) would silently keep its
+    recorded behaviour.  A module declares itself safe with the attribute `hip_graph = True` (or MPC_ROLLOUT_GRAPH=1
+    turns it on for all; MPC_NO_ROLLOUT_GRAPH=1 off for all).  A module that cannot be captured -- anything that
+    synchronises, e.g. `.item()` -- is remembered and called eagerly."""
+    from . import mpc as _mpc
+    wanted = (os.environ.get("MPC_ROLLOUT_GRAPH") or getattr(true_dynamics, "hip_graph", False)
+              or getattr(true_cost, "hip_graph", False))
+    if (not wanted or not x_init.is_cuda or os.environ.get("MPC_NO_ROLLOUT_GRAPH")
+            or torch.cuda.is_current_stream_capturing()):
+        return None
+
+    def ident(obj):
+        if isinstance(obj, _mpc.QuadCost):
+            return ("quad", obj.C.data_ptr(), obj.c.data_ptr(), tuple(obj.C.stride()))
+        if isinstance(obj, _mpc.LinDx):
+            return ("lin", obj.F.data_ptr(), _addr(obj.f) if not _is_empty(obj.f) else 0)
+        return ("mod", id(obj))
+    key = (ident(true_cost), ident(true_dynamics), T, tuple(K.shape), x_init.dtype, x_init.device.index,
+           _addr(opts.u_lower), _addr(opts.u_upper), _addr(opts.u_zero_I), opts.delta_u)
+    refs = tuple(weakref.ref(o) for o in (true_cost, true_dynamics) if isinstance(o, torch.nn.Module))
+    hit = _PASS_GRAPHS.get(key)
+    if hit is not None and all(r() is o for r, o in zip(hit[1], (o for o in (true_cost, true_dynamics) if isinstance(o, torch.nn.Module)))):
+        _PASS_GRAPHS.move_to_end(key)
+        return hit[0]
+    try:
+        g = _GraphedPass(T, x_init, K, k, cur_x, cur_u, true_cost, true_dynamics, opts)
+    except Exception:                 # not capturable: remember, and run it eagerly from now on
+        g = None
+        torch.cuda.synchronize(x_init.device)
+    _PASS_GRAPHS[key] = (g, refs)
+    while len(_PASS_GRAPHS) > _PASS_GRAPHS_MAX:
+        _PASS_GRAPHS.popitem(last=False)
+    return g
+
+
 def _module_rollout(n_state, n_ctrl, T, x_init, K, k, cur_x, cur_u, old_cost, true_cost, true_dynamics,
                     opts):
     """Rollout + per-problem line search when the dynamics or the cost is an nn.Module
     (reference mpc/lqr_step.py:164-261).  Device ops only; the per-element step size is a [B,1]
-    column instead of the reference's B x B diag matrix (:192)."""
-    from . import mpc as _mpc
+    column instead of the reference's B x B diag matrix (:192).  For a module that opts in (`hip_graph = True`) a pass
+    is one replay of a HIP graph (`_GraphedPass`: a pass is launch-bound at small batches); the only read-back is the
+    line search's own "did any cost get worse" (:176-179)."""
     B = x_init.shape[0]
     alpha = torch.ones(B, 1, dtype=x_init.dtype, device=x_init.device)
-    lin = isinstance(true_dynamics, _mpc.LinDx)
-    quad = isinstance(true_cost, _mpc.QuadCost)
     full_du_norm = None
-    new_x = new_u = cost = None
     with torch.no_grad():
+        graphed = _graphed_pass(T, x_init, K, k, cur_x, cur_u, true_cost, true_dynamics, opts)
         for it in range(opts.max_linesearch_iter):
-            xs, us, objs = [x_init], [], []
-            dx = torch.zeros_like(x_init)
-            for t in range(T):
-                ut = cur_u[t]
-                nu = torch.einsum("bij,bj->bi", K[t], dx) + ut + alpha * k[t]
-                if opts.u_zero_I is not None:
-                    nu = nu.masked_fill(opts.u_zero_I[t].bool(), 0.0)
-                if opts.u_lower is not None:
-                    lo, hi = _bound_at(opts.u_lower, t), _bound_at(opts.u_upper, t)
-                    if opts.delta_u is not None:
-                        lo = torch.maximum(ut - opts.delta_u, torch.as_tensor(lo, dtype=ut.dtype, device=ut.device))
-                        hi = torch.minimum(ut + opts.delta_u, torch.as_tensor(hi, dtype=ut.dtype, device=ut.device))
-                    nu = torch.min(torch.max(nu, torch.as_tensor(lo, dtype=nu.dtype, device=nu.device)),
-                                   torch.as_tensor(hi, dtype=nu.dtype, device=nu.device))
-                us.append(nu)
-                tau = torch.cat((xs[t], nu), 1)
-                if t < T - 1:
-                    if lin:
-                        nx = torch.einsum("bij,bj->bi", true_dynamics.F[t].detach(), tau)
-                        if not _is_empty(true_dynamics.f):
-                            nx = nx + true_dynamics.f[t].detach()
-                    else:
-                        nx = true_dynamics(xs[t], nu).detach()
-                    xs.append(nx)
-                    dx = nx - cur_x[t + 1]
-                if quad:
-                    Ct, ct = true_cost.C[t].detach(), true_cost.c[t].detach()
-                    objs.append(0.5 * torch.einsum("bi,bij,bj->b", tau, Ct, tau) + (tau * ct).sum(1))
-                else:
-                    objs.append(true_cost(tau).detach())
-            new_x, new_u = torch.stack(xs), torch.stack(us)
-            cost = torch.stack(objs).sum(0)
-            du_norm = (cur_u - new_u).pow(2).sum((0, 2)).sqrt()
+            if graphed is not None:
+                new_x, new_u, cost, du_norm = graphed(x_init, K, k, cur_x, cur_u, alpha)
+            else:
+                new_x, new_u, cost, du_norm = _rollout_pass(T, x_init, K, k, cur_x, cur_u, alpha, true_cost,
+                                                            true_dynamics, opts)
             if full_du_norm is None:
-                full_du_norm = du_norm
+                full_du_norm = du_norm.clone()
             worse = cost > old_cost
             last = it + 1 >= opts.max_linesearch_iter
             if last or not bool(worse.any()):
                 break
             alpha = torch.where(worse.unsqueeze(1), alpha * opts.linesearch_decay, alpha)
+        if graphed is not None:       # the graph's output buffers are overwritten by the next replay
+            new_x, new_u, cost, du_norm = new_x.clone(), new_u.clone(), cost.clone(), du_norm.clone()
     return new_x, new_u, cost, full_du_norm, du_norm, alpha.squeeze(1)
 
 

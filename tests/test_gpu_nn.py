@@ -213,3 +213,54 @@ def test_lqrstep_gradients_flow_to_the_network_parameters(be):
     g = torch.autograd.grad(loss, [dyn.fcs[0].weight, dyn.fcs[-1].bias], allow_unused=True)
     assert all(t is not None and torch.isfinite(t).all() for t in g)
     assert float(g[0].abs().max()) > 0
+
+
+class _TanhDynamics(torch.nn.Module):
+    """A user module the kernels know nothing about: x' = x + 0.1 tanh(A x + B u)."""
+
+    def __init__(self, ns, nc, sync=False):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.A = torch.nn.Parameter(torch.randn(ns, ns, generator=g) / ns ** 0.5)
+        self.B = torch.nn.Parameter(torch.randn(ns, nc, generator=g) / ns ** 0.5)
+        self.sync = sync
+        self.calls = 0
+        self.hip_graph = True              # nothing in forward() depends on Python-side state: safe to replay
+
+    def forward(self, x, u):
+        self.calls += 1
+        if self.sync:
+            float(x.sum().item())          # a host read-back: cannot be captured in a graph
+        return x + 0.1 * torch.tanh(x @ self.A.t() + u @ self.B.t())
+
+
+@pytest.mark.parametrize("sync", [False, True])
+def test_module_rollout_replays_a_graph_and_matches_the_eager_pass(be, sync, monkeypatch):
+    """An arbitrary nn.Module as dynamics (mpc/lqr_step.py:223-225): the line-search passes of `_module_rollout` are
+    replays of one captured HIP graph (opt-in: the module sets `hip_graph = True`) and give what the eager loop of
+    device ops gives; a module that synchronises cannot be captured and silently keeps the eager loop."""
+    from mpc import lqr_step, mpc
+    ns, nc, T, B = 6, 2, 12, 64
+    dyn = _TanhDynamics(ns, nc, sync=sync).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    n = ns + nc
+    A = torch.randn(T, B, n, n, generator=g)
+    C = (A.transpose(2, 3) @ A + 0.1 * torch.eye(n)).to(DEV)
+    c = torch.randn(T, B, n, generator=g).to(DEV)
+    x0 = torch.randn(B, ns, generator=g).to(DEV)
+
+    def solve():
+        ctrl = mpc.MPC(ns, nc, T, u_lower=-1.0, u_upper=1.0, lqr_iter=4, verbose=-1, exit_unconverged=False,
+                       detach_unconverged=False, grad_method=mpc.GradMethods.AUTO_DIFF, backprop=False)
+        with torch.no_grad():
+            return ctrl(x0, mpc.QuadCost(C, c), dyn)
+    lqr_step._PASS_GRAPHS.clear()
+    x1, u1, c1 = solve()
+    entries = list(lqr_step._PASS_GRAPHS.values())
+    assert len(entries) >= 1
+    assert all((e[0] is None) == sync for e in entries)       # captured, or remembered as not capturable
+    monkeypatch.setenv("MPC_NO_ROLLOUT_GRAPH", "1")
+    x2, u2, c2 = solve()
+    np.testing.assert_allclose(host(c1), host(c2), rtol=1e-5)
+    np.testing.assert_allclose(host(u1), host(u2), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(x1), host(x2), rtol=1e-4, atol=1e-5)
