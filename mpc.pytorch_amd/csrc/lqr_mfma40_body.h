@@ -1051,6 +1051,10 @@ template <int MODE> MPC_DEV void step_wave(const P &p, float *K, float *k)
     double w0 = 0.0;
     const double old_cost = sweep_wave<MODE>(p, K, k, &w0);
     wv::fence_own_stores();
+#ifdef MPC_CFG5_SWEEP_ONLY
+    if (old_cost == 1.2345e300) return;    // (diagnostic build: the sweep alone; keeps old_cost / w0 alive)
+    if (old_cost != 1.2345e300) { if (wv::lane() == 0 && p.costs) p.costs[wv::problem()] = (float)(old_cost + w0); return; }
+#endif
     if (MODE == 0 && p.on_dynamics) {
         Lane L;
         L.lane = wv::lane();
