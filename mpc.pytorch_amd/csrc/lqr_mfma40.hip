@@ -23,6 +23,30 @@ MPC_DEV float sum_rows(float x)
     auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// rows 0 and 1 (lanes 0..15, 16..31) of x, each copied to all four rows: the same two row swaps
+MPC_DEV void rows01(float x, float &r0, float &r1)
+{
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);     // rows {0,1,0,1}
+    auto b = __builtin_amdgcn_permlane16_swap(a[0], a[0], false, false);
+    r0 = __uint_as_float(b[0]);
+    r1 = __uint_as_float(b[1]);
+}
+// DPP row broadcast: lane N of the caller's 16-lane row
+template <int N> MPC_DEV float bcast(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + N, 0xf, 0xf, true));
+}
+// acc += bcast_N(src) * mul (src written long before: no DPP read-after-write wait states needed)
+template <int N> MPC_DEV void fmac_bcast_settled(float &acc, float src, float mul)
+{
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
+}
+// the same right behind the instruction that wrote src
+template <int N> MPC_DEV void fmac_bcast(float &acc, float src, float mul)
+{
+    asm("s_nop 1\n"
+        "v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
+}
 MPC_DEV float rcp(float x)
 {
     float r = __builtin_amdgcn_rcpf(x);

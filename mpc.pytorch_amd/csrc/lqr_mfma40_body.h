@@ -22,11 +22,16 @@
 //   * vectors live in "row layout" (lane r holds entry 16J + r, the same in all four lane groups) or in
 //     "column layout" (lane group q holds entries 16I + 4q + v); matrix-vector products are per-lane partial
 //     sums over the tile registers plus a 2-step (across q) or 4-step (across r) butterfly.
-//   * the 8x8 Quu is read out with 36 readlanes and factorised (LDL') on wave-uniform values.
+//   * the 8x8 Quu is factorised (LDL') spread over lanes in the unconstrained sweep (Ldl8V), and read out with 36
+//     readlanes and factorised on wave-uniform values where masks / the box QP need it uniform.
 // C is read as the symmetric matrix the reference documents it to be (mpc/mpc.py:61-68).
 #pragma once
 #include <math.h>
 #include "lqr_params.h"
+
+#ifndef MPC_DEVM
+#define MPC_DEVM MPC_DEV
+#endif
 
 namespace mpclqr {
 namespace mfma40 {
@@ -172,6 +177,78 @@ MPC_DEV void ldl8_solve(const Ldl8 &f, const float rhs[8], float y[8])
         for (int k = i + 1; k < 8; ++k) s = fmaf(-f.l[k][i], y[k], s);
         y[i] = s;
     }
+}
+
+// ---- the same factorisation with the matrix spread over lanes (unconstrained sweep) ------------------------------
+// All four 16-lane rows hold the same data; inside a row lane a < 8 holds matrix row a.  col[c] = column c of the
+// symmetric matrix (lane a: A[a][c]).  Right-looking LDL': per pivot one reciprocal, one scaling and one
+// v_fmac_f32_dpp per remaining column (60 instructions against ~170 on wave-uniform values, and no readlanes to make
+// the 36 entries uniform first).  The triangular solves of per-lane right-hand sides read L[a][c] as a DPP broadcast
+// of lane a of nl[c] = -L[:, c] -- the same 64 multiply-adds as with scalar operands.
+struct Ldl8V {
+    float nl[8];     // lane a: -L[a][c]  (valid for a > c)
+    float inv[8];    // 1 / D_c in every lane
+};
+template <int C, int M> struct Ldl8VElim {
+    static MPC_DEVM void run(float (&col)[8], float nlc)
+    {
+        wv::fmac_bcast<M>(col[M], col[C], nlc);             // A[a][m] -= L[a][c] A[m][c]
+        Ldl8VElim<C, M + 1>::run(col, nlc);
+    }
+};
+template <int C> struct Ldl8VElim<C, 8> { static MPC_DEVM void run(float (&)[8], float) {} };
+template <int C> struct Ldl8VPivot {
+    static MPC_DEVM void run(Ldl8V &f, float (&col)[8])
+    {
+        f.inv[C] = wv::rcp(wv::bcast<C>(col[C]));
+        f.nl[C] = -(col[C] * f.inv[C]);
+        Ldl8VElim<C, C + 1>::run(col, f.nl[C]);
+        Ldl8VPivot<C + 1>::run(f, col);
+    }
+};
+template <> struct Ldl8VPivot<8> { static MPC_DEVM void run(Ldl8V &, float (&)[8]) {} };
+MPC_DEV void ldl8v(Ldl8V &f, float (&col)[8]) { Ldl8VPivot<0>::run(f, col); }
+
+// z_I -= sum_{k < I} L[I][k] z_k
+template <int I, int K> struct Ldl8VFwdRow {
+    static MPC_DEVM void run(const Ldl8V &f, float (&z)[8])
+    {
+        wv::fmac_bcast_settled<I>(z[I], f.nl[K], z[K]);
+        Ldl8VFwdRow<I, K + 1>::run(f, z);
+    }
+};
+template <int I> struct Ldl8VFwdRow<I, I> { static MPC_DEVM void run(const Ldl8V &, float (&)[8]) {} };
+template <int I> struct Ldl8VFwd {
+    static MPC_DEVM void run(const Ldl8V &f, float (&z)[8])
+    {
+        Ldl8VFwdRow<I, 0>::run(f, z);
+        Ldl8VFwd<I + 1>::run(f, z);
+    }
+};
+template <> struct Ldl8VFwd<8> { static MPC_DEVM void run(const Ldl8V &, float (&)[8]) {} };
+// y_I = z_I / D_I - sum_{k > I} L[k][I] y_k
+template <int I, int K> struct Ldl8VBwdRow {
+    static MPC_DEVM void run(const Ldl8V &f, float (&y)[8])
+    {
+        wv::fmac_bcast_settled<K>(y[I], f.nl[I], y[K]);
+        Ldl8VBwdRow<I, K + 1>::run(f, y);
+    }
+};
+template <int I> struct Ldl8VBwdRow<I, 8> { static MPC_DEVM void run(const Ldl8V &, float (&)[8]) {} };
+template <int I> struct Ldl8VBwd {
+    static MPC_DEVM void run(const Ldl8V &f, float (&y)[8])
+    {
+        y[I] *= f.inv[I];
+        Ldl8VBwdRow<I, I + 1>::run(f, y);
+        Ldl8VBwd<I - 1>::run(f, y);
+    }
+};
+template <> struct Ldl8VBwd<-1> { static MPC_DEVM void run(const Ldl8V &, float (&)[8]) {} };
+// y = S^-1 y, per lane
+MPC_DEV void ldl8v_solve(const Ldl8V &f, float (&y)[8])
+{
+    Ldl8VFwd<1>::run(f, y);
+    Ldl8VBwd<7>::run(f, y);
 }
 
 // Same factorisation of the free block: rows / columns outside `fr` become identity (their right-hand
@@ -420,13 +497,13 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
             }
         }
 
-        // ---- Quu (wave-uniform), qu; K = -Quu^-1 Qux, k = -Quu^-1 qu   (:84-94; LDL' for the pinverse)
+        // ---- Quu, qu; K = -Quu^-1 Qux, k = -Quu^-1 qu   (:84-94; LDL' for the pinverse)
+        // Constrained modes: Quu is read out with 36 readlanes and factorised on wave-uniform values (masks, the box QP).
+        // Unconstrained: Quu stays spread over lanes (Ldl8V): column c of it is register c & 3 of lane row c >> 2 of the
+        // accumulator tile, copied to all four lane rows with two row swaps per register.
         float S[8][8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int c = a; c < 8; ++c) S[a][c] = wv::readlane(Qd[2][2][a & 3], 16 * (a >> 2) + c);
         Ldl8 fac;
+        Ldl8V facv;
         float qu[8], kk[8];
         bool fr[8];
 #pragma unroll
@@ -435,15 +512,18 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
             fr[a] = true;
         }
         if (MODE == 0) {
-            ldl8(fac, S);
-            ldl8_solve(fac, qu, kk);
-            float w = 0.f;
+            float col[8];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                kk[a] = -kk[a];
-                w = fmaf(qu[a], kk[a], w);
-            }
-            w0 += 0.5 * (double)w;
+            for (int v = 0; v < 4; ++v) wv::rows01(Qd[2][2][v], col[v], col[4 + v]);
+            ldl8v(facv, col);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int c = a; c < 8; ++c) S[a][c] = wv::readlane(Qd[2][2][a & 3], 16 * (a >> 2) + c);
+        }
+        if (MODE == 0) {
+            // (k comes out of the first of the two K solves below: lane rows 2, 3 carry qu as their right-hand side)
         } else if (MODE == 1) {                          // :99-127: pinned controls drop out of the solve
             float rq[8];
             const unsigned zlo = zero_mask_word(p, tb, 0), zhi = zero_mask_word(p, tb, 1);
@@ -511,11 +591,23 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
             if (MODE != 0) {
 #pragma unroll
                 for (int a = 0; a < 8; ++a) rhs[a] = fr[a] ? rhs[a] : 0.f;                            // :142-143
-            }
-            ldl8_solve(fac, rhs, sol);
-            if (MODE != 0) {
+                ldl8_solve(fac, rhs, sol);
 #pragma unroll
                 for (int a = 0; a < 8; ++a) sol[a] = fr[a] ? sol[a] : 0.f;
+            } else {
+                // lane rows 2, 3 hold padding rows of Qux: in the first solve they take qu and return -k
+#pragma unroll
+                for (int a = 0; a < 8; ++a) sol[a] = (J == 0 && L.q >= 2) ? qu[a] : rhs[a];
+                ldl8v_solve(facv, sol);
+                if (J == 0) {
+                    float w = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) {
+                        kk[a] = -wv::readlane(sol[a], 32);
+                        w = fmaf(qu[a], kk[a], w);
+                    }
+                    w0 += 0.5 * (double)w;
+                }
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) Kd[J][v] = L.q < 2 ? -pick(odd, sol[4 + v], sol[v]) : 0.f;

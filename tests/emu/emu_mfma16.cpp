@@ -186,6 +186,17 @@ template <int N> static inline float bcast(float x)
     return w.fa[gen][(l & ~15) + N];
 }
 template <int N> static inline void fmac_bcast(float &acc, float src, float mul) { acc = fmaf(bcast<N>(src), mul, acc); }
+template <int N> static inline void fmac_bcast_settled(float &acc, float src, float mul) { acc = fmaf(bcast<N>(src), mul, acc); }
+// wv::rows01 of lqr_mfma40.hip: rows 0 and 1 of x copied to every 16-lane row
+static inline void rows01(float x, float &r0, float &r1)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = x;
+    emu::yield_lane();
+    r0 = w.fa[gen][l & 15];
+    r1 = w.fa[gen][16 + (l & 15)];
+}
 template <int NN> static inline void dot_bcast(float &acc, float src, const float (&m)[NN])
 {
     emu::Wave &w = emu::W;
