@@ -442,6 +442,19 @@ template <int HT> __device__ __forceinline__ void layer1(const NetRegs<HT> &R, f
 #pragma unroll
         for (int to = 0; to < HT; ++to) pre[to] = mfma(R.w1[to][v], tq[v], pre[to]);
 }
+// the same with layer 1's operands (A operand and bias of every tile) read from this lane's own LDS slots instead of
+// 8 HT registers: the line-search kernel needs those registers for a timestep's rows of C and K
+template <int HT> __device__ __forceinline__ void layer1_lds(const f32x4 *w1s, const f32x4 *b1s, f32x4 tq, f32x4 (&pre)[HT])
+{
+#pragma unroll
+    for (int to = 0; to < HT; ++to) {
+        const f32x4 w = w1s[64 * to];
+        f32x4 a = b1s[64 * to];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a = mfma(w[v], tq[v], a);
+        pre[to] = a;
+    }
+}
 // W_2 z (+ init), four accumulation chains
 template <int HT> __device__ __forceinline__ f32x4 layer2(const NetRegs<HT> &R, const f32x4 (&z)[HT], f32x4 init)
 {
@@ -492,6 +505,7 @@ template <int HT, bool GAIN, bool COST>
 __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p, MlpDesc m)
 {
     __shared__ __attribute__((aligned(16))) float tauS[16 * 20], dxS[16 * 20];
+    __shared__ f32x4 netS[GAIN && COST ? 2 * HT * 64 : 1];        // layer 1 of the line-search kernel: [w1 | b1][tile][lane]
     const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
     const long b_raw = (long)blockIdx.x * 16 + r;
     const bool valid = b_raw < p.B;
@@ -505,6 +519,16 @@ __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p
     for (int i = lane; i < 16 * 20; i += 64) {
         tauS[i] = 0.f;
         dxS[i] = 0.f;
+    }
+    if (GAIN && COST) {
+        // (this instantiation sits at the 512-register limit: layer 1's operands move to LDS, two 16-byte reads per tile and step)
+#pragma unroll
+        for (int to = 0; to < HT; ++to) {
+            netS[64 * to + lane] = R.w1[to];
+            netS[64 * (HT + to) + lane] = R.b1[to];
+            R.w1[to] = f32x4{0.f, 0.f, 0.f, 0.f};
+            R.b1[to] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     wave_sync();
     float alpha = 1.f, cost = 0.f, dun = 0.f, full = 0.f;
@@ -601,7 +625,7 @@ __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p
             if (t + 1 < T) request(t + 1, o);
             if (t + 1 < T) {
                 f32x4 z[HT];                                                                // :223-225
-                layer1<HT>(R, tq, z);
+                if (GAIN && COST) layer1_lds<HT>(netS + lane, netS + 64 * HT + lane, tq, z); else layer1<HT>(R, tq, z);
 #pragma unroll
                 for (int to = 0; to < HT; ++to) z[to] = act_fn(z[to], m.act);
                 const f32x4 out = layer2<HT>(R, z, R.b2);

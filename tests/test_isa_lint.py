@@ -71,3 +71,23 @@ def test_register_resident_gains_own_the_accumulation_registers():
     for l in body:
         if l.strip().startswith("v_mfma"):
             assert not re.search(r"\ba\[", l), l
+
+
+def test_network_kernels_stay_in_registers():
+    """csrc/nn_dynamics.hip: no scratch memory and no spilled vector registers in any instantiation; the register-resident
+    kernels hold the network (both layers' operands for up to 8 hidden tiles), the kernel with the line search and
+    the cost runs at the 512-register limit of one wave per SIMD -- a spill there would put the per-step operands in memory."""
+    import re
+    import isa_lint
+    lines = isa_lint.assembly("nn_dynamics")
+    text = "\n".join(lines)
+    kernels, _ = isa_lint.structure(lines)
+    names = [n for _, n in kernels]
+    assert sum("nn_rollout_fast_kernel" in n for n in names) == 12        # 4 widths x (trajectory, + cost, line search)
+    assert sum("nn_linearize_fast_kernel" in n for n in names) == 4
+    assert sum("nn_rollout_kernel" in n for n in names) == 2 and sum("nn_linearize_kernel" in n for n in names) == 2
+    assert not any("scratch_" in l and not l.strip().startswith(";") for l in lines)
+    spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]
+    assert len(spills) >= len(names) and all(v == 0 for v in spills)
+    # every layer product is on the matrix core
+    assert sum(l.strip().startswith("v_mfma_f32_16x16x4") for l in lines) > 500
