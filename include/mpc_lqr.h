@@ -216,6 +216,12 @@ typedef struct mpc_mlp_dynamics {
     int32_t n_layers;                         /* Linear layers (hidden + output), 1..MPC_MLP_MAX_LAYERS */
     int32_t activation;                       /* MPC_ACT_* */
     int32_t passthrough;
+    int32_t ctrl_carry;                       /* 0, or n_ctrl: mpc.dynamics.CtrlPassthroughDynamics around the network (the
+                                                 slew-rate augmentation, mpc/mpc.py:362-445, mpc/dynamics.py:131-150): the state
+                                                 is (previous control, x), a step returns (this control, net(x, u)).  The
+                                                 weights then describe the augmented map: zero columns for the previous control
+                                                 in W[0], zero rows for it in the last layer; the first ctrl_carry entries of the
+                                                 next state are the control itself and take no passthrough.  Rollout only. */
     int32_t widths[MPC_MLP_MAX_LAYERS + 1];   /* widths[0] = n_state + n_ctrl, widths[n_layers] = n_state */
     const void *W[MPC_MLP_MAX_LAYERS];
     const void *b[MPC_MLP_MAX_LAYERS];

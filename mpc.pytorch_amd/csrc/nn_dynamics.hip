@@ -36,6 +36,7 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __buil
 // The block is copied into LDS at kernel start when it fits (WL), else read from global memory through the caches.
 struct MlpDesc {
     int L, act, pass;            // Linear layers, MPC_ACT_*, passthrough
+    int carry;                   // mpc_mlp_dynamics.ctrl_carry
     int w[MPC_MLP_MAX_LAYERS + 1];   // widths: w[0] = n_state + n_ctrl, w[L] = n_state
     int wp[MPC_MLP_MAX_LAYERS + 1];  // rounded up to 16
     int woff[MPC_MLP_MAX_LAYERS], boff[MPC_MLP_MAX_LAYERS];   // offsets (floats) into the packed block
@@ -248,9 +249,12 @@ __global__ void __launch_bounds__(256) nn_rollout_kernel(StepParams<float> p, Ml
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int f = 4 * q + v;
-                    xr[v] = f < ns ? o[v] + (m.pass ? xr[v] : 0.f) : 0.f;                   // mpc/dynamics.py:74-75
+                    // mpc/dynamics.py:74-75; an augmented state's first entries are the control just applied (:139-147)
+                    const float skip = f < m.carry ? tauS[r * TS + ns + f] : (m.pass ? xr[v] : 0.f);
+                    xr[v] = f < ns ? o[v] + skip : 0.f;
                     if (active && f < ns) p.new_x[((long)(t + 1) * B + b) * ns + f] = xr[v];
                 }
+                wave_sync();
             } else {
                 wave_sync();
             }
@@ -632,7 +636,8 @@ __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int f = 4 * q + v;
-                    xr[v] = f < ns ? out[v] + (m.pass ? xr[v] : 0.f) : 0.f;                 // mpc/dynamics.py:74-75
+                    const float skip = f < m.carry ? tauS[r * 20 + ns + f] : (m.pass ? xr[v] : 0.f);   // mpc/dynamics.py:74-75, :139-147
+                    xr[v] = f < ns ? out[v] + skip : 0.f;
                     if (active && f < ns) p.new_x[((long)(t + 1) * B + b) * ns + f] = xr[v];
                 }
             }
@@ -765,6 +770,9 @@ int mlp_prepare(const mpc_mlp_dynamics *net, int ns, int nc, void *workspace, in
     d.L = net->n_layers;
     d.act = net->activation;
     d.pass = net->passthrough ? 1 : 0;
+    d.carry = net->ctrl_carry;
+    if (d.carry != 0 && d.carry != nc) { set_last_error("network: ctrl_carry must be 0 or n_ctrl"); return MPC_E_ARG; }
+    if (d.carry >= ns) { set_last_error("network: ctrl_carry needs n_state (augmented) > n_ctrl"); return MPC_E_DIMS; }
     for (int l = 0; l <= d.L; ++l) {
         d.w[l] = net->widths[l];
         d.wp[l] = pad16(net->widths[l]);
@@ -852,6 +860,7 @@ int launch_nn_linearize(const mpc_mlp_dynamics *net, long N, int ns, int nc, con
                         float *f, void *workspace, int64_t bytes, hipStream_t st)
 {
     MlpDesc d;
+    if (net && net->ctrl_carry) { set_last_error("mlp_linearize: ctrl_carry describes a rollout only (linearise the network itself)"); return MPC_E_ARG; }
     int rc = mlp_prepare(net, ns, nc, workspace, bytes, d, st);
     if (rc) return rc;
     if (d.L == 2 && d.wp[0] == 16 && d.wp[1] <= 128) {

@@ -72,7 +72,7 @@ ACT_CODES = {"sigmoid": 0, "relu": 1, "elu": 2}
 
 
 class MlpDynamics(ctypes.Structure):          # struct mpc_mlp_dynamics
-    _fields_ = [("n_layers", _i32), ("activation", _i32), ("passthrough", _i32),
+    _fields_ = [("n_layers", _i32), ("activation", _i32), ("passthrough", _i32), ("ctrl_carry", _i32),
                 ("widths", _i32 * (MLP_MAX_LAYERS + 1)), ("W", _vp * MLP_MAX_LAYERS), ("b", _vp * MLP_MAX_LAYERS)]
 
 
@@ -81,11 +81,27 @@ class MlpSpec:
     the struct is rebuilt for every call, a training loop changes them between calls), the activation and the
     passthrough flag (mpc/dynamics.py:15-36)."""
 
-    def __init__(self, weights, biases, activation, passthrough):
+    def __init__(self, weights, biases, activation, passthrough, ctrl_carry=0):
         self.weights, self.biases = list(weights), list(biases)
         self.activation, self.passthrough = activation, bool(passthrough)
+        self.ctrl_carry = int(ctrl_carry)      # CtrlPassthroughDynamics around the network (see `augmented`)
         self.n_state = self.weights[-1].shape[0]
         self.n_ctrl = self.weights[0].shape[1] - self.n_state
+
+    def augmented(self):
+        """The same network as the dynamics of the slew-rate augmentation (mpc/dynamics.py:131-150): state (previous
+        control, x), a step returns (this control, net(x, u)).  Zero columns for the previous control in the first layer,
+        zero rows for it in the last; the kernels write the control itself into those rows (`ctrl_carry`)."""
+        nc = self.n_ctrl
+        W, b = list(self.weights), list(self.biases)
+        W[0] = torch.cat((W[0].new_zeros(W[0].shape[0], nc), W[0]), 1) if len(W) > 1 else W[0]
+        if len(W) == 1:
+            W[0] = torch.cat((W[0].new_zeros(nc, W[0].shape[1] + nc),
+                              torch.cat((W[0].new_zeros(W[0].shape[0], nc), W[0]), 1)), 0)
+        else:
+            W[-1] = torch.cat((W[-1].new_zeros(nc, W[-1].shape[1]), W[-1]), 0)
+        b[-1] = torch.cat((b[-1].new_zeros(nc), b[-1]), 0)
+        return MlpSpec(W, b, self.activation, self.passthrough, ctrl_carry=nc)
 
     @staticmethod
     def supported(weights, activation, like):
@@ -99,6 +115,7 @@ class MlpSpec:
         e = MlpDynamics()
         keep = []
         e.n_layers, e.activation, e.passthrough = len(self.weights), ACT_CODES[self.activation], int(self.passthrough)
+        e.ctrl_carry = self.ctrl_carry
         e.widths[0] = self.weights[0].shape[1]
         for l, (W, b) in enumerate(zip(self.weights, self.biases)):
             W = W.detach().to(device=like.device, dtype=torch.float32).contiguous()

@@ -142,5 +142,13 @@ class CtrlPassthroughDynamics(nn.Module):
         out = torch.cat((u, inner_next), dim=1)
         return out.squeeze() if was_vector else out
 
+    def native_net(self, like):
+        """Around an NNDynamics the kernels can run (fp32, augmented n_state <= 16): the augmented network, else None."""
+        inner = getattr(self.dynamics, "native_net", None)
+        net = inner(like) if inner is not None and not isinstance(self.dynamics, CtrlPassthroughDynamics) else None
+        if net is None or net.n_state + net.n_ctrl > 16:
+            return None
+        return net.augmented()
+
     def grad_input(self, x, u):
         assert False, "Unimplemented"

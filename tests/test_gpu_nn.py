@@ -264,3 +264,63 @@ def test_module_rollout_replays_a_graph_and_matches_the_eager_pass(be, sync, mon
     np.testing.assert_allclose(host(c1), host(c2), rtol=1e-5)
     np.testing.assert_allclose(host(u1), host(u2), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(host(x1), host(x2), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["mpc_slew_nn_f64", "mpc_slew_nn_prev_f64"])
+def test_slew_rate_penalty_on_the_network_kernels(be, name, monkeypatch):
+    """slew_rate_penalty around NNDynamics (the reference's tests/test_mpc.py:652-744 setting) in float32: the augmented
+    dynamics CtrlPassthroughDynamics(NNDynamics) roll out inside the network kernel (`ctrl_carry`), and the solve agrees
+    with the reference's float64 fixture and with this package's host-driven float32 path."""
+    from mpc import _native, mpc
+    from mpc.dynamics import NNDynamics
+    z = golden(name)
+    ns, nc, T, B = (int(v) for v in z["meta"])
+    dyn = NNDynamics(ns, nc, [10, 10], activation="sigmoid")
+    with torch.no_grad():
+        for i, fc in enumerate(dyn.fcs):
+            fc.weight.copy_(torch.from_numpy(z["W%d" % i]).float())
+            fc.bias.copy_(torch.from_numpy(z["b%d" % i]).float())
+    dyn = dyn.to(DEV)
+    carried = []
+    orig = _native.HipBackend.mlp_rollout
+
+    def spy(self, *a, **k):
+        carried.append(a[9].ctrl_carry)
+        return orig(self, *a, **k)
+    monkeypatch.setattr(_native.HipBackend, "mlp_rollout", spy)
+
+    def solve():
+        prev = f32(z["prev_ctrl"]) if "prev_ctrl" in z else None
+        ctrl = mpc.MPC(ns, nc, T, f32(z["lo"]), f32(z["hi"]), None, lqr_iter=40, verbose=-1, max_linesearch_iter=1,
+                       grad_method=mpc.GradMethods.ANALYTIC, slew_rate_penalty=float(z["gamma"][0]), prev_ctrl=prev,
+                       exit_unconverged=False, backprop=False)
+        with torch.no_grad():
+            return ctrl(f32(z["x_init"]), mpc.QuadCost(f32(z["C"]), f32(z["c"])), dyn)
+    x, u, costs = solve()
+    torch.cuda.synchronize()
+    assert carried and all(c == nc for c in carried)          # the augmented network ran in the kernel
+    np.testing.assert_allclose(host(u), z["u"], rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(host(x), z["x"], rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(host(costs), z["costs"], rtol=2e-3)
+    monkeypatch.setattr(NNDynamics, "native_net", lambda self, like: None)
+    x2, u2, costs2 = solve()
+    np.testing.assert_allclose(host(u), host(u2), rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(host(costs), host(costs2), rtol=1e-3)
+
+
+@pytest.mark.parametrize("ns,nc,hidden", [(4, 4, [32]), (5, 2, [24]), (6, 2, [16, 16])])
+def test_ctrl_carry_rollout_matches_the_augmented_map(be, ns, nc, hidden):
+    """`MlpSpec.augmented()` (CtrlPassthroughDynamics around the network, mpc/dynamics.py:131-150) through both rollout
+    kernels -- (4, 4, [32]) takes the register-resident one -- against z' = (u, net(x, u)) stepped in numpy."""
+    from oracle import env_oracle as E
+    net = random_net(ns, nc, hidden, "sigmoid", True, seed=7)
+    aug = spec_of(net).augmented()
+    rng = np.random.RandomState(3)
+    T, B = 9, 37
+    z0 = rng.randn(B, nc + ns)
+    u = rng.randn(T, B, nc)
+    zs = [z0]
+    for t in range(T - 1):
+        zs.append(np.concatenate((u[t], E.mlp_step(zs[t][:, nc:], u[t], net)), 1))
+    zk, _ = be.mlp_traj_cost(f32(z0), f32(u), aug)
+    np.testing.assert_allclose(host(zk), np.stack(zs), rtol=1e-4, atol=1e-4)

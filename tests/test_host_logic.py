@@ -53,7 +53,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_native.Options) == 8 + 16 + 24 + 16 + 8 + 8
     assert ctypes.sizeof(_native.EnvDynamics) == 8 + 8 + 16
     assert ctypes.sizeof(_native.Outputs) == 11 * 8
-    assert ctypes.sizeof(_native.MlpDynamics) == 3 * 4 + 5 * 4 + 4 * 8 + 4 * 8
+    assert ctypes.sizeof(_native.MlpDynamics) == 4 * 4 + 5 * 4 + 4 + 4 * 8 + 4 * 8       # 9 ints + padding to 8
 
 
 def test_argument_validation_without_gpu():
