@@ -72,7 +72,7 @@ __device__ __forceinline__ f32x4 act_fn(f32x4 a, int kind)
 {
     if (kind == MPC_ACT_SIGMOID) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) a[v] = __frcp_rn(1.f + __expf(-a[v]));   // v_exp_f32 / v_rcp_f32: ~1e-7 relative
+        for (int v = 0; v < 4; ++v) a[v] = __builtin_amdgcn_rcpf(1.f + __expf(-a[v]));   // v_exp_f32 + v_rcp_f32 (1 ulp each), no division sequence
     } else if (kind == MPC_ACT_RELU) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) a[v] = fmaxf(a[v], 0.f);
@@ -505,7 +505,9 @@ __device__ __forceinline__ float load_if(const float *p, long idx, bool in)
 // nominal -- is requested one step ahead, before the network's MFMAs, and consumed after them.
 // GAIN: line search with feedback gains (else the controls are the nominal ones); COST: the quadratic cost is summed.
 // Rows are read 16 bytes at a time: n_state and n_state + n_ctrl multiples of 4 (else the general kernel runs).
-template <int HT, bool GAIN, bool COST>
+// ACT: the activation as a compile-time constant (the exp / reciprocal of 28 sigmoids per lane and step are the largest
+// block of vector work in the step; a runtime switch keeps all three variants and their branches inside the time loop)
+template <int HT, bool GAIN, bool COST, int ACT>
 __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p, MlpDesc m)
 {
     __shared__ __attribute__((aligned(16))) float tauS[16 * 20], dxS[16 * 20];
@@ -631,7 +633,7 @@ __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p
                 f32x4 z[HT];                                                                // :223-225
                 if (GAIN && COST) layer1_lds<HT>(netS + lane, netS + 64 * HT + lane, tq, z); else layer1<HT>(R, tq, z);
 #pragma unroll
-                for (int to = 0; to < HT; ++to) z[to] = act_fn(z[to], m.act);
+                for (int to = 0; to < HT; ++to) z[to] = act_fn(z[to], ACT);
                 const f32x4 out = layer2<HT>(R, z, R.b2);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -676,14 +678,23 @@ template <int HT, int PP> struct JacPoints {
                                                long p0, long N, int ns, int n, int q, int r, float *F)
     {
         if (p0 + PP < N) {
+            // all B operands of the point first, then the MFMAs as one block: an MFMA issued right behind the vector
+            // instruction that feeds it costs 56 clocks instead of 32 (tools/ubench/mfma16_turn.hip)
+            f32x4 g[HT];
+#pragma unroll
+            for (int to = 0; to < HT; ++to)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) g[to][v] = bcast<PP>(s[to][v]) * w1d[to][v];
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
 #pragma unroll
             for (int to = 0; to < HT; ++to) {
-                a0 = mfma(R.w2[to][0], bcast<PP>(s[to][0]) * w1d[to][0], a0);
-                a1 = mfma(R.w2[to][1], bcast<PP>(s[to][1]) * w1d[to][1], a1);
-                a2 = mfma(R.w2[to][2], bcast<PP>(s[to][2]) * w1d[to][2], a2);
-                a3 = mfma(R.w2[to][3], bcast<PP>(s[to][3]) * w1d[to][3], a3);
+                a0 = mfma(R.w2[to][0], g[to][0], a0);
+                a1 = mfma(R.w2[to][1], g[to][1], a1);
+                a2 = mfma(R.w2[to][2], g[to][2], a2);
+                a3 = mfma(R.w2[to][3], g[to][3], a3);
             }
+            __builtin_amdgcn_sched_barrier(0);
             const f32x4 J = (a0 + a1) + (a2 + a3);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -699,7 +710,7 @@ template <int HT> struct JacPoints<HT, 16> {
                                                int, int, float *) {}
 };
 
-template <int HT>
+template <int HT, int ACT>
 __global__ void __launch_bounds__(64) nn_linearize_fast_kernel(MlpDesc m, long N, int ns, int nc, const float *x, const float *u,
                                                                float *F, float *f)
 {
@@ -727,8 +738,8 @@ __global__ void __launch_bounds__(64) nn_linearize_fast_kernel(MlpDesc m, long N
 #pragma unroll
     for (int to = 0; to < HT; ++to) {
         const f32x4 lin = z[to] - R.b1[to];                     // W_1 tau
-        z[to] = act_fn(z[to], m.act);
-        s[to] = slope_fn(z[to], m.act);
+        z[to] = act_fn(z[to], ACT);
+        s[to] = slope_fn(z[to], ACT);
         z[to] = z[to] - s[to] * lin;
     }
     const f32x4 fv = layer2<HT>(R, z, R.b2);                    // net(x, u) - F [x;u]  (the passthrough x cancels)
@@ -822,16 +833,23 @@ int launch_nn_rollout(const StepParams<float> &p, const mpc_mlp_dynamics *net, v
         const unsigned g = (unsigned)(((long)p.B + 15) / 16);
         const int ht = d.wp[1] >> 4;
         const int mode = p.K ? 2 : (p.C ? 1 : 0);
-#define MPC_NN_LAUNCH(HT_)                                                                                                  \
-        do {                                                                                                                 \
-            if (mode == 2) hipLaunchKernelGGL((nn_rollout_fast_kernel<HT_, true, true>), dim3(g), dim3(64), 0, st, p, d);      \
-            else if (mode == 1) hipLaunchKernelGGL((nn_rollout_fast_kernel<HT_, false, true>), dim3(g), dim3(64), 0, st, p, d); \
-            else hipLaunchKernelGGL((nn_rollout_fast_kernel<HT_, false, false>), dim3(g), dim3(64), 0, st, p, d);              \
+#define MPC_NN_LAUNCH_A(HT_, ACT_)                                                                                                \
+        do {                                                                                                                       \
+            if (mode == 2) hipLaunchKernelGGL((nn_rollout_fast_kernel<HT_, true, true, ACT_>), dim3(g), dim3(64), 0, st, p, d);      \
+            else if (mode == 1) hipLaunchKernelGGL((nn_rollout_fast_kernel<HT_, false, true, ACT_>), dim3(g), dim3(64), 0, st, p, d); \
+            else hipLaunchKernelGGL((nn_rollout_fast_kernel<HT_, false, false, ACT_>), dim3(g), dim3(64), 0, st, p, d);              \
+        } while (0)
+#define MPC_NN_LAUNCH(HT_)                                                                  \
+        do {                                                                                 \
+            if (d.act == MPC_ACT_SIGMOID) MPC_NN_LAUNCH_A(HT_, MPC_ACT_SIGMOID);             \
+            else if (d.act == MPC_ACT_RELU) MPC_NN_LAUNCH_A(HT_, MPC_ACT_RELU);              \
+            else MPC_NN_LAUNCH_A(HT_, MPC_ACT_ELU);                                          \
         } while (0)
         if (ht <= 2) MPC_NN_LAUNCH(2);
         else if (ht <= 4) MPC_NN_LAUNCH(4);
         else if (ht <= 7) MPC_NN_LAUNCH(7);
         else MPC_NN_LAUNCH(8);
+#undef MPC_NN_LAUNCH_A
 #undef MPC_NN_LAUNCH
         return check_launch("nn_rollout_fast_kernel");
     }
@@ -866,10 +884,17 @@ int launch_nn_linearize(const mpc_mlp_dynamics *net, long N, int ns, int nc, con
     if (d.L == 2 && d.wp[0] == 16 && d.wp[1] <= 128) {
         const unsigned g = (unsigned)((N + 15) / 16);
         const int ht = d.wp[1] >> 4;
-        if (ht <= 2) hipLaunchKernelGGL(nn_linearize_fast_kernel<2>, dim3(g), dim3(64), 0, st, d, N, ns, nc, x, u, F, f);
-        else if (ht <= 4) hipLaunchKernelGGL(nn_linearize_fast_kernel<4>, dim3(g), dim3(64), 0, st, d, N, ns, nc, x, u, F, f);
-        else if (ht <= 7) hipLaunchKernelGGL(nn_linearize_fast_kernel<7>, dim3(g), dim3(64), 0, st, d, N, ns, nc, x, u, F, f);
-        else hipLaunchKernelGGL(nn_linearize_fast_kernel<8>, dim3(g), dim3(64), 0, st, d, N, ns, nc, x, u, F, f);
+#define MPC_NN_LIN(HT_)                                                                                                             \
+        do {                                                                                                                        \
+            if (d.act == MPC_ACT_SIGMOID) hipLaunchKernelGGL((nn_linearize_fast_kernel<HT_, MPC_ACT_SIGMOID>), dim3(g), dim3(64), 0, st, d, N, ns, nc, x, u, F, f); \
+            else if (d.act == MPC_ACT_RELU) hipLaunchKernelGGL((nn_linearize_fast_kernel<HT_, MPC_ACT_RELU>), dim3(g), dim3(64), 0, st, d, N, ns, nc, x, u, F, f);   \
+            else hipLaunchKernelGGL((nn_linearize_fast_kernel<HT_, MPC_ACT_ELU>), dim3(g), dim3(64), 0, st, d, N, ns, nc, x, u, F, f);                              \
+        } while (0)
+        if (ht <= 2) MPC_NN_LIN(2);
+        else if (ht <= 4) MPC_NN_LIN(4);
+        else if (ht <= 7) MPC_NN_LIN(7);
+        else MPC_NN_LIN(8);
+#undef MPC_NN_LIN
         return check_launch("nn_linearize_fast_kernel");
     }
     const int TS = d.wp[0] + 4, ZS = max_hidden_pad(d) + 4, NTJ = d.wp[0] >> 4;

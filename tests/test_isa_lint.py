@@ -83,8 +83,8 @@ def test_network_kernels_stay_in_registers():
     text = "\n".join(lines)
     kernels, _ = isa_lint.structure(lines)
     names = [n for _, n in kernels]
-    assert sum("nn_rollout_fast_kernel" in n for n in names) == 12        # 4 widths x (trajectory, + cost, line search)
-    assert sum("nn_linearize_fast_kernel" in n for n in names) == 4
+    assert sum("nn_rollout_fast_kernel" in n for n in names) == 36        # 4 widths x (trajectory, + cost, line search) x 3 activations
+    assert sum("nn_linearize_fast_kernel" in n for n in names) == 12
     assert sum("nn_rollout_kernel" in n for n in names) == 2 and sum("nn_linearize_kernel" in n for n in names) == 2
     assert not any("scratch_" in l and not l.strip().startswith(";") for l in lines)
     spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]
