@@ -210,7 +210,18 @@ def rollout(kind, params, x_init, C, c, K, k, cur_x, cur_u, lower, upper, decay,
     return new_x, new_u, costs, full, alphas
 
 
-def rollout_batched(kind, params, x_init, C, c, K, k, cur_x, cur_u, lower, upper, decay, max_ls):
+def _bounds_at(lower, upper, t, ut, delta_u):
+    """Bounds of timestep t (floats or [T,B,nc] arrays), intersected with u +- delta_u (mpc/lqr_step.py:200-211)."""
+    lo = lower[t] if isinstance(lower, np.ndarray) and lower.ndim == 3 else lower
+    hi = upper[t] if isinstance(upper, np.ndarray) and upper.ndim == 3 else upper
+    if delta_u is not None:
+        lo = np.maximum(lo, ut - delta_u)
+        hi = np.minimum(hi, ut + delta_u)
+    return lo, hi
+
+
+def rollout_batched(kind, params, x_init, C, c, K, k, cur_x, cur_u, lower, upper, decay, max_ls, delta_u=None,
+                    u_zero_I=None):
     """`rollout` for large batches: the max_ls trials alpha = decay^i are each rolled out over the WHOLE batch
     with numpy and every problem takes its first trial that did not get worse (else the last) -- the per-problem
     loop of `rollout` in a different order, same results (checked against it in tests/test_oracle_golden.py).
@@ -229,8 +240,11 @@ def rollout_batched(kind, params, x_init, C, c, K, k, cur_x, cur_u, lower, upper
         dx = np.zeros((B, ns))
         for t in range(T):
             nu = np.einsum("bij,bj->bi", K[t], dx) + cur_u[t] + alpha * k[t]
+            if u_zero_I is not None:
+                nu = np.where(u_zero_I[t], 0.0, nu)                                       # :197-198
             if lower is not None:
-                nu = np.clip(nu, lower, upper)
+                lo, hi = _bounds_at(lower, upper, t, cur_u[t], delta_u)
+                nu = np.minimum(np.maximum(nu, lo), hi)                                   # util.eclamp
             us.append(nu)
             if t < T - 1:
                 nx = step(kind, xs[t], nu, params)

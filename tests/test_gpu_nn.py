@@ -324,3 +324,50 @@ def test_ctrl_carry_rollout_matches_the_augmented_map(be, ns, nc, hidden):
         zs.append(np.concatenate((u[t], E.mlp_step(zs[t][:, nc:], u[t], net)), 1))
     zk, _ = be.mlp_traj_cost(f32(z0), f32(u), aug)
     np.testing.assert_allclose(host(zk), np.stack(zs), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("ns,nc,hidden", [(12, 4, [100]), (6, 3, [40, 24])])
+def test_network_rollout_with_tensor_bounds_delta_u_and_pinned_controls(be, ns, nc, hidden):
+    """The options of lqr_forward that bracket the control (mpc/lqr_step.py:197-213) through both rollout kernels:
+    per-(t, b, i) bounds, delta_u around the nominal, u_zero_I -- against oracle/env_oracle.rollout_batched."""
+    from mpc._native import StepOptions
+    from oracle import env_oracle as E
+    from oracle import lqr_oracle as O
+    net = random_net(ns, nc, hidden, "sigmoid", True, seed=11, scale=0.8)
+    sp = spec_of(net)
+    rng = np.random.RandomState(5)
+    T, B, n = 14, 203, ns + nc
+    x0 = rng.randn(B, ns)
+    lo = -0.3 - rng.rand(T, B, nc)
+    hi = 0.3 + rng.rand(T, B, nc)
+    u0 = np.clip(0.3 * rng.randn(T, B, nc), lo, hi)
+    A = rng.randn(T, B, n, n)
+    C = np.einsum("tbki,tbkj->tbij", A, A) + 0.1 * np.eye(n)
+    c = rng.randn(T, B, n)
+    xs = E.traj(E.MLP, x0, u0, net)
+    Fl, fl = E.linearize(E.MLP, xs[:-1].reshape(-1, ns), u0[:-1].reshape(-1, nc), net)
+    Fl, fl = Fl.reshape(T - 1, B, ns, n), fl.reshape(T - 1, B, ns)
+    for delta_u, masked in ((None, False), (0.25, False), (None, True)):
+        mask = (rng.rand(T, B, nc) < 0.2) if masked else None
+        kw = dict(u_lower=lo, u_upper=hi) if not masked else {}
+        okw = dict(kw)
+        if delta_u is not None:
+            okw["delta_u"] = delta_u
+        if masked:
+            okw["u_zero_I"] = mask
+        o = O.lqr_step(x0, C, c, Fl, fl, xs, u0, linesearch_decay=0.2, max_linesearch_iter=5, lockstep=False,
+                       nthreads=O.max_threads(), return_gains=True, **okw)
+        nx, nu, costs, full, alphas, trials, old = E.rollout_batched(
+            E.MLP, net, x0, C, c, o["K"], o["k"], xs, u0, None if masked else lo, None if masked else hi, 0.2, 5,
+            delta_u=delta_u, u_zero_I=mask)
+        o.update(new_x=nx, new_u=nu, costs=costs, alphas=alphas, old_costs=old, full_du_norm=full)
+        opts = StepOptions(u_lower=None if masked else f32(lo), u_upper=None if masked else f32(hi), delta_u=delta_u,
+                           u_zero_I=None if mask is None else torch.from_numpy(mask).to(DEV), linesearch_decay=0.2,
+                           max_linesearch_iter=5)
+        r = be.mlp_rollout(f32(x0), f32(C), f32(c), f32(o["K"]), f32(o["k"]), f32(xs), f32(u0), f32(old), opts, sp)
+        torch.cuda.synchronize()
+        scale = 1.0 + np.abs(xs).max()
+        strict_step_check("nn_opts_%d_%s_%s" % (ns, delta_u, masked), r, o, B, rtol=1e-3, atol=2e-4 * scale, cost_rtol=1e-3,
+                          have_gains=False)
+        if masked:
+            assert (host(r["new_u"])[mask] == 0).all()
