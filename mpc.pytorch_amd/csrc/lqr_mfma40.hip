@@ -47,6 +47,15 @@ template <int N> MPC_DEV void fmac_bcast(float &acc, float src, float mul)
     asm("s_nop 1\n"
         "v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
 }
+// sum over the 16 lanes of a row, in every lane of it
+MPC_DEV float row_sum(float x)
+{
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true));   // row_mirror
+    return x;
+}
 MPC_DEV float rcp(float x)
 {
     float r = __builtin_amdgcn_rcpf(x);

@@ -351,6 +351,94 @@ MPC_DEV int pnqp8(const float S[8][8], const float q[8], const float lb[8], cons
     return it_ret;
 }
 
+// ---- the same box QP with its vectors spread over lanes (lane a < 8 of every 16-lane row: entry a; lanes 8..15 hold
+// zeros and stay free, which makes them inert in every product and row sum).  col0[c]: column c of H (lane a: H[a][c]).
+// A trip is ~210 instructions against ~500 on wave-uniform values: the gradient and H d are 8 DPP multiply-adds each, the
+// tests / clamps / steps one instruction per vector, the factorisation is ldl8v; only the triangular solve keeps its 64
+// multiply-adds (every lane solves the same right-hand side, read as DPP broadcasts).
+// Same iterates as pnqp8 / mpc/pnqp.py:5-82 (n_batch = 1).  On return xv is the solution, mv the free set (1 / 0) and f
+// the factorisation of the iteration that recognised convergence (:56-59), as the reference returns them.
+template <int C> struct Pnqp8vMat {
+    static MPC_DEVM void run(const float (&col0)[8], float mnv, float dgv, int r, float (&colm)[8])
+    {
+        colm[C] = (mnv * wv::bcast<C>(mnv)) * col0[C];
+        colm[C] = r == C ? dgv : colm[C];
+        Pnqp8vMat<C + 1>::run(col0, mnv, dgv, r, colm);
+    }
+};
+template <> struct Pnqp8vMat<8> { static MPC_DEVM void run(const float (&)[8], float, float, int, float (&)[8]) {} };
+template <int C> struct Pnqp8vMv {          // acc += H v  (v spread over lanes)
+    static MPC_DEVM void run(const float (&col0)[8], float v, float &acc)
+    {
+        wv::fmac_bcast<C>(acc, v, col0[C]);
+        Pnqp8vMv<C + 1>::run(col0, v, acc);
+    }
+};
+template <> struct Pnqp8vMv<8> { static MPC_DEVM void run(const float (&)[8], float, float &) {} };
+template <int A> struct Pnqp8vSpread {      // y[a] = entry a of the row's vector v, in every lane
+    static MPC_DEVM void run(float v, float (&y)[8])
+    {
+        y[A] = wv::bcast<A>(v);
+        Pnqp8vSpread<A + 1>::run(v, y);
+    }
+};
+template <> struct Pnqp8vSpread<8> { static MPC_DEVM void run(float, float (&)[8]) {} };
+// lane a < 8 picks y[a] (y is the same in all lanes), lanes 8..15 get 0
+MPC_DEV float gather8(const float (&y)[8], int r)
+{
+    float v = 0.f;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) v = pick(r == a, y[a], v);
+    return v;
+}
+MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, float ubv, int n_iter, int r, float &xv,
+                   float &mv, Ldl8V &f, bool &converged)
+{
+    int it_ret = n_iter - 1;
+    converged = false;
+    const float dgm = diagv + 1e-11f - 1.f;                        // :47 (identity off the free set)
+    for (int it = 0; it < n_iter; ++it) {
+        float gv = qv;
+        Pnqp8vMv<0>::run(col0, xv, gv);                            // :29
+        // :32 clamped = (x == lb & g > 0) | (x == ub & g < 0)
+        const float r_lo = (xv == lbv) ? gv : -1.f;
+        const float r_hi = (xv == ubv) ? -gv : -1.f;
+        const float mnv = (fmaxf(r_lo, r_hi) > 0.f) ? 0.f : 1.f;
+        float colm[8];
+        Pnqp8vMat<0>::run(col0, mnv, fmaf(mnv, dgm, 1.f), r, colm);   // :44-48
+        Ldl8V fn;
+        ldl8v(fn, colm);
+        float y[8];
+        Pnqp8vSpread<0>::run(mnv * gv, y);
+        ldl8v_solve(fn, y);                                        // :50-54
+        const float dxv = -(mnv * gather8(y, r));
+        const float nrm2 = wv::row_sum(dxv * dxv);
+        float mxv = xv + dxv;
+        const float outv = wv::row_sum(((mxv < lbv) | (mxv > ubv)) ? 1.f : 0.f);
+        f = fn;
+        mv = mnv;
+        if (wv::uniform(!(nrm2 >= 1e-8f))) {                       // :56-59
+            converged = true;
+            it_ret = it;
+            break;
+        }
+        if (!wv::uniform(outv == 0.f)) {                           // :61-76
+            float alpha = 1.f;
+            for (int count = 0; count < 10; ++count) {
+                mxv = clampf(fmaf(alpha, dxv, xv), lbv, ubv);
+                const float dv = mxv - xv;
+                float hdv = 0.f;
+                Pnqp8vMv<0>::run(col0, dv, hdv);
+                const float den = wv::row_sum(-gv * dv), dhd = wv::row_sum(dv * hdv);
+                const float arm = fmaf(-0.5f, dhd, den) * wv::rcp(den);
+                if (wv::uniform(arm <= 0.1f)) alpha *= 0.1f; else break;
+            }
+        }
+        xv = mxv;                                                  // :78
+    }
+    return it_ret;
+}
+
 // The sweep of one problem: K [T,B,8,32] and k [T,B,8] in the reference layout, old_costs[b].
 // MODE 0: unconstrained; 1: u_zero_I mask; 2: box constraints (pnqp8 on wave-uniform values).
 template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out = nullptr)
@@ -378,9 +466,7 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
     double w0 = 0.0;                   // sum_t 0.5 qu'k: the value function's predicted change of the cost (unconstrained)
     int qp_total = 0, status = 0;
     bool warm = false;
-    float kprev[8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a) kprev[a] = 0.f;
+    float kprev_v = 0.f;               // box QP: the previous timestep's solution, spread over lanes (warm start)
 
     stage_issue(p, d, L, T - 1, 0);
     int slot = 0;
@@ -537,35 +623,56 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
 #pragma unroll
             for (int a = 0; a < 8; ++a) kk[a] = fr[a] ? -kk[a] : 0.f;
         } else {                                         // :128-148: box QP, warm start k_{t+1}
-            float lb[8], ub[8];
+            // the QP's data spread over lanes (pnqp8v): H's columns by two row swaps per accumulator register
+            float col0[8];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const float ua = wv::lds_f32(base + OFF_R + 288 + 4u * (unsigned)a);
-                lb[a] = (p.bound_mode == MPC_BOUND_SCALAR ? p.lo_s : uniform_f32(p.lo + tb * NC + a)) - ua;
-                ub[a] = (p.bound_mode == MPC_BOUND_SCALAR ? p.hi_s : uniform_f32(p.hi + tb * NC + a)) - ua;
-                if (p.has_delta) {                       // :132-134
-                    if (lb[a] < -p.delta_u) lb[a] = -p.delta_u;
-                    if (ub[a] > p.delta_u) ub[a] = p.delta_u;
+            for (int v = 0; v < 4; ++v) wv::rows01(Qd[2][2][v], col0[v], col0[4 + v]);
+            float diagv = 0.f;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) diagv = pick(L.r == a, col0[a], diagv);
+            const bool r8 = L.r < 8;
+            const float uav = wv::lds_f32(base + OFF_R + 288 + 4u * (unsigned)(r8 ? L.r : 0));
+            float lov = p.lo_s, hiv = p.hi_s;
+            if (p.bound_mode != MPC_BOUND_SCALAR) {
+                float lo8[8], hi8[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    lo8[a] = uniform_f32(p.lo + tb * NC + a);
+                    hi8[a] = uniform_f32(p.hi + tb * NC + a);
                 }
+                lov = gather8(lo8, L.r);
+                hiv = gather8(hi8, L.r);
             }
+            float lbv = r8 ? lov - uav : 0.f, ubv = r8 ? hiv - uav : 0.f;
+            if (p.has_delta) {                           // :132-134
+                lbv = r8 ? fmaxf(lbv, -p.delta_u) : 0.f;
+                ubv = r8 ? fminf(ubv, p.delta_u) : 0.f;
+            }
+            const float qv = r8 ? qrow[2] : 0.f;
+            float xv = kprev_v;
             if (!warm) {                                 // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
-                ldl8(fac, S);
-                ldl8_solve(fac, qu, kk);
+                float colc[8], y[8];
 #pragma unroll
-                for (int a = 0; a < 8; ++a) kk[a] = -kk[a];
-            } else {
-#pragma unroll
-                for (int a = 0; a < 8; ++a) kk[a] = kprev[a];
+                for (int a = 0; a < 8; ++a) colc[a] = col0[a];
+                Ldl8V f0;
+                ldl8v(f0, colc);
+                Pnqp8vSpread<0>::run(qv, y);
+                ldl8v_solve(f0, y);
+                xv = -gather8(y, L.r);
             }
-#pragma unroll
-            for (int a = 0; a < 8; ++a) kk[a] = clampf(kk[a], lb[a], ub[a]);                         // :23
+            xv = clampf(xv, lbv, ubv);                   // :23
             bool conv;
-            const int it = pnqp8(S, qu, lb, ub, p.pnqp_iter, kk, fr, fac, conv);
+            float mv = 1.f;
+            const int it = pnqp8v(col0, diagv, qv, lbv, ubv, p.pnqp_iter, L.r, xv, mv, facv, conv);
             qp_total += 1 + it;                          // :140
             if (!conv) status |= MPC_ST_PNQP_UNCONVERGED;
             warm = true;
+            kprev_v = xv;
 #pragma unroll
-            for (int a = 0; a < 8; ++a) kprev[a] = kk[a];
+            for (int a = 0; a < 8; ++a) {
+                kk[a] = wv::readlane(xv, a);
+                fr[a] = wv::readlane(mv, a) != 0.f;
+            }
         }
         f32x4 Kd[2];                    // K, B layout of the value update: register v of lane (q,r) = K[4q+v][16J+r]
         f32x4 Md[2];                    // M = Qux + Quu K in the same layout (constrained modes)
@@ -591,7 +698,13 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
             if (MODE != 0) {
 #pragma unroll
                 for (int a = 0; a < 8; ++a) rhs[a] = fr[a] ? rhs[a] : 0.f;                            // :142-143
-                ldl8_solve(fac, rhs, sol);
+                if (MODE == 2) {
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) sol[a] = rhs[a];
+                    ldl8v_solve(facv, sol);
+                } else {
+                    ldl8_solve(fac, rhs, sol);
+                }
 #pragma unroll
                 for (int a = 0; a < 8; ++a) sol[a] = fr[a] ? sol[a] : 0.f;
             } else {

@@ -9,3 +9,7 @@ for B in (1024, 8192):
     plan = be.plan_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions(nominal_on_dynamics=True))
     w, ms, r = bench.timed(plan, 40, 20)
     print("B", B, "ms", round(ms, 4))
+p = bench.make_problem(32, 8, 64, 1024, torch.float32, "cuda:0", seed=9, on_device=True)
+plan = be.plan_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions(u_lower=-1.0, u_upper=1.0))
+w, ms, r = bench.timed(plan, 40, 20)
+print("bounded B 1024 ms", round(ms, 4), "unconverged", int((r["status"] & 1).sum()))
