@@ -1035,6 +1035,10 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
     du2 = sum_q(dacc);
 }
 
+template <int MODE, bool REPLAY>
+MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const float *kin, double old_cost, double w0,
+                          float replay_alpha = 1.f);
+
 template <int MODE> MPC_DEV void rollout_wave(const P &p, const float *Kin, const float *kin, double old_cost)
 {
     Lane L;
@@ -1062,15 +1066,23 @@ template <int MODE> MPC_DEV void rollout_wave(const P &p, const float *Kin, cons
     for (int i = 0; i < win; ++i) win_alpha *= p.ls_decay;
     double win_cost;
     float win_du2;
-    if (win != 0) {
-        rollout_pass<MODE>(p, d, L, win_alpha, true, win_cost, win_du2);
-    } else {
-        win_cost = cost;
-        win_du2 = du2;
+    // the winner's cost and step length are those of its column in the pricing pass; a winner other than the first trial
+    // (which stored as it went) is rolled out once more for its trajectory alone: F, K and the record, no C, no pricing
+    win_cost = cost;
+    win_du2 = du2;
+    if (win != 0) rollout_lean<MODE, true>(p, L, Kin, kin, old_cost, 0.0, win_alpha);
+    float wc_hi = wv::readlane((float)win_cost, 0), wc_lo = wv::readlane((float)(win_cost - (double)(float)win_cost), 0);
+    float wd = wv::readlane(win_du2, 0);
+    for (int j = 1; j < 16; ++j) {                   // (uniform loop; readlane wants a constant lane only in the kernel build)
+        const float hj = wv::readlane((float)win_cost, j), lj = wv::readlane((float)(win_cost - (double)(float)win_cost), j);
+        const float dj = wv::readlane(win_du2, j);
+        if (j == win) {
+            wc_hi = hj;
+            wc_lo = lj;
+            wd = dj;
+        }
     }
-    const float wc_hi = wv::readlane((float)win_cost, 0);
-    const double wc = (double)wc_hi + (double)wv::readlane((float)(win_cost - (double)(float)win_cost), 0);
-    const float wd = wv::readlane(win_du2, 0);
+    const double wc = (double)wc_hi + (double)wc_lo;
     if (L.lane == 0) {
         int status = 0;
         if (!(wc == wc) || fabs(wc) > 3e38) status |= MPC_ST_NONFINITE;
@@ -1109,7 +1121,12 @@ MPC_DEV void lstage_issue(const P &p, const RStream &d, const Lane &L, int t, in
     wv::dma16_if(d.r_active && L.lane >= 10, d.r_ptr + (d.r_is_f ? tf : (d.r_is_x ? tx : tl)) * d.r_step, base + LOFF_R);
 }
 
-MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const float *kin, double old_cost, double w0)
+// REPLAY (any MODE): the line search has been decided by a pricing pass (rollout_wave) and its winner was not the
+// first trial: every column rolls the winner's step `replay_alpha` with the mode's mask / clamp, column 0 stores; nothing
+// is priced and no result scalars are written (the pricing pass has them).
+template <int MODE, bool REPLAY>
+MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const float *kin, double old_cost, double w0,
+                          float replay_alpha)
 {
     const int T = p.T;
     RStream d;
@@ -1118,7 +1135,7 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
     for (int i = 0; i < L.r; ++i) alpha *= p.ls_decay;            // column r tries decay^r
     // first trial that is not worse than the nominal, else the last one (:176-179, 247)
     int win = p.max_ls - 1;
-    {
+    if (!REPLAY) {
         float a = 1.f;
         for (int j = 0; j < p.max_ls; ++j) {
             const double cj = old_cost + (2.0 * (double)a - (double)a * (double)a) * w0;
@@ -1128,6 +1145,10 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
     }
     float win_alpha = 1.f;
     for (int i = 0; i < win; ++i) win_alpha *= p.ls_decay;
+    if (REPLAY) {
+        alpha = replay_alpha;
+        win = 0;
+    }
     const bool store = L.r == win;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 Xd[2], DXd[2];
@@ -1177,9 +1198,28 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
         }
         {
             float s = 0.f;
+            unsigned zw = 0u;                    // the zero flags of controls 4q .. 4q+3
+            if (MODE == 1) {
+                const unsigned zlo = zero_mask_word(p, tb, 0), zhi = zero_mask_word(p, tb, 1);
+                zw = L.q == 0 ? zlo : zhi;
+            }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float un = L.q < 2 ? Ud[v] + ub[v] + alpha * kb[v] : 0.f;
+                float un = L.q < 2 ? Ud[v] + ub[v] + alpha * kb[v] : 0.f;
+                if (MODE == 1 && L.q < 2 && ((zw >> (8 * v)) & 0xffu) != 0u) un = 0.f;               // :197-198
+                if (MODE == 2 && L.q < 2) {                                                          // :200-213
+                    float lo = p.lo_s, hi = p.hi_s;
+                    if (p.bound_mode != MPC_BOUND_SCALAR) {
+                        lo = pick(L.q == 0, uniform_f32(p.lo + tb * NC + v), uniform_f32(p.lo + tb * NC + 4 + v));
+                        hi = pick(L.q == 0, uniform_f32(p.hi + tb * NC + v), uniform_f32(p.hi + tb * NC + 4 + v));
+                    }
+                    if (p.has_delta) {
+                        const float l2 = ub[v] - p.delta_u, h2 = ub[v] + p.delta_u;
+                        lo = (l2 < lo) ? lo : l2;
+                        hi = (h2 > hi) ? hi : h2;
+                    }
+                    un = clampf(un, lo, hi);
+                }
                 const float dd = L.q < 2 ? ub[v] - un : 0.f;
                 Ud[v] = un;
                 s = fmaf(dd, dd, s);
@@ -1232,6 +1272,7 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
         }
     }
     wv::dma_wait<0>();
+    if (REPLAY) return;
     const float du2 = sum_q(dacc);
     const float full2 = wv::readlane(du2, 0);
     float wd = full2;
@@ -1267,7 +1308,7 @@ template <int MODE> MPC_DEV void step_wave(const P &p, float *K, float *k)
         L.q = L.lane >> 4;
         L.b = wv::problem();
         if (L.b >= p.B) return;
-        rollout_lean(p, L, K, k, old_cost, w0);
+        rollout_lean<0, false>(p, L, K, k, old_cost, w0);
     } else {
         rollout_wave<MODE>(p, K, k, old_cost);
     }
