@@ -56,6 +56,30 @@ MPC_HD float env_cos(float x)
 MPC_HD double env_sin(double x) { return sin(x); }
 MPC_HD double env_cos(double x) { return cos(x); }
 
+// 1 / x and 1 / sqrt(x).  float on the device: v_rcp_f32 / v_rsq_f32 and one Newton step (<= 1 ulp, 3 instructions); `a / b`
+// compiles to the IEEE sequence (v_div_scale x2, v_rcp, four FMAs, v_div_fmas, v_div_fixup: 10 instructions), of which
+// a cart-pole transition with its Jacobian had 15 -- on kernels bound by one lane's instruction count.
+MPC_HD float env_inv(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.f), r, r);
+#else
+    return 1.f / x;
+#endif
+}
+MPC_HD double env_inv(double x) { return 1.0 / x; }
+MPC_HD float env_rsqrt(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rsqf(x);
+    return r * fmaf(-0.5f * x * r, r, 1.5f);
+#else
+    return 1.f / sqrtf(x);
+#endif
+}
+MPC_HD double env_rsqrt(double x) { return 1.0 / sqrt(x); }
+
 // (cos, sin)(atan2(s, c) + delta) without forming the angle: (c, s) / |(c, s)| rotated by delta.  The reference takes
 // atan2 and then cos / sin of the sum (pendulum.py:68,76-77, cartpole.py:76,86-91); the rotation is the same
 // number in exact arithmetic and needs no atan2.
@@ -65,7 +89,7 @@ MPC_HD void rotate_direction(real c, real s, real delta, real &c2, real &s2)
     const real r2 = c * c + s * s;
     real cu = 1, su = 0;                              // atan2(0, 0) = 0
     if (r2 > 0) {
-        const real rinv = (real)1 / sqrt(r2);
+        const real rinv = env_rsqrt(r2);
         cu = c * rinv;
         su = s * rinv;
     }
@@ -85,13 +109,13 @@ MPC_HD void env_step(const EnvDesc<real> &e, const real *x, real u, real *out, r
     const real du = (u >= -e.u_max && u <= e.u_max) ? (real)1 : (real)0;
     if (e.kind == MPC_ENV_CARTPOLE) {
         const real g = e.params[0], mc = e.params[1], mp = e.params[2], l = e.params[3];
-        const real mt = mp + mc, pml = mp * l;
+        const real mt = mp + mc, pml = mp * l, imt = env_inv(mt);
         const real px = x[0], v = x[1], c = x[2], s = x[3], w = x[4];
-        const real ci = (uc + pml * w * w * s) / mt;
-        const real D = l * ((real)(4.0 / 3.0) - mp * c * c / mt);
+        const real ci = (uc + pml * w * w * s) * imt;
+        const real D = l * ((real)(4.0 / 3.0) - mp * c * c * imt), iD = env_inv(D);
         const real N = g * s - c * ci;
-        const real ta = N / D;
-        const real xa = ci - pml * ta * c / mt;
+        const real ta = N * iD;
+        const real xa = ci - pml * ta * c * imt;
         real c2, s2;                                  // th2 = th + dt * w
         rotate_direction<real>(c, s, dt * w, c2, s2);
         out[0] = px + dt * v;
@@ -100,16 +124,16 @@ MPC_HD void env_step(const EnvDesc<real> &e, const real *x, real u, real *out, r
         out[3] = s2;
         out[4] = w + dt * ta;
         if (J) {
-            const real r2 = c * c + s * s;
-            const real th_c = -s / r2, th_s = c / r2;
+            const real ir2 = env_inv(c * c + s * s);
+            const real th_c = -s * ir2, th_s = c * ir2;
             // columns: 0 x, 1 v, 2 c, 3 s, 4 w, 5 u
-            const real ci_s = pml * w * w / mt, ci_w = 2 * pml * w * s / mt, ci_u = du / mt;
-            const real D_c = -2 * l * mp * c / mt;
-            const real ta_c = (-ci - ta * D_c) / D;
-            const real ta_s = (g - c * ci_s) / D;
-            const real ta_w = (-c * ci_w) / D;
-            const real ta_u = (-c * ci_u) / D;
-            const real k = pml / mt;
+            const real ci_s = pml * w * w * imt, ci_w = 2 * pml * w * s * imt, ci_u = du * imt;
+            const real D_c = -2 * l * mp * c * imt;
+            const real ta_c = (-ci - ta * D_c) * iD;
+            const real ta_s = (g - c * ci_s) * iD;
+            const real ta_w = (-c * ci_w) * iD;
+            const real ta_u = (-c * ci_u) * iD;
+            const real k = pml * imt;
             const real xa_c = -k * (ta_c * c + ta);
             const real xa_s = ci_s - k * ta_s * c;
             const real xa_w = ci_w - k * ta_w * c;
@@ -128,7 +152,7 @@ MPC_HD void env_step(const EnvDesc<real> &e, const real *x, real u, real *out, r
     // pendulum: state (cos th, sin th, dth)
     const real g = e.params[0], m = e.params[1], l = e.params[2];
     const real c = x[0], s = x[1], w = x[2];
-    const real kg = (real)1.5 * g / l, ku = (real)3 / (m * l * l);
+    const real kg = (real)1.5 * g * env_inv(l), ku = (real)3 * env_inv(m * l * l);
     real acc, acc_th = 0;     // acc_th: derivative of the acceleration through th (full model)
     real c2, s2;
     if (e.kind == MPC_ENV_PENDULUM) {
@@ -148,8 +172,8 @@ MPC_HD void env_step(const EnvDesc<real> &e, const real *x, real u, real *out, r
     out[1] = s2;
     out[2] = w2;
     if (J) {
-        const real r2 = c * c + s * s;
-        const real th_c = -s / r2, th_s = c / r2;
+        const real ir2 = env_inv(c * c + s * s);
+        const real th_c = -s * ir2, th_s = c * ir2;
         real w_c, w_s;
         if (e.kind == MPC_ENV_PENDULUM) { w_c = 0; w_s = dt * kg; }
         else { w_c = dt * acc_th * th_c; w_s = dt * acc_th * th_s; }

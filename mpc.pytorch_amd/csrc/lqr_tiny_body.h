@@ -41,7 +41,7 @@ MPC_HD int pnqp1(real H, real q, real lb, real ub, real &x, real &Hfree, bool &i
         const bool ic = (x == lb && g > 0) || (x == ub && g < 0);  // :32
         is_free = !ic;
         Hfree = (is_free ? H : (real)0) + (real)1e-11;             // :44-48
-        const real dx = -((is_free ? g : (real)0) / Hfree);        // :50-51
+        const real dx = -((is_free ? g : (real)0) * env_inv(Hfree)); // :50-51 (reciprocal + Newton step, see env_inv)
         if (!(absr<real>(dx) >= (real)1e-4)) { conv = true; ret = it; break; }   // :56-59
         if (x + dx >= lb && x + dx <= ub) {                        // Newton step inside the box: its Armijo
             x = x + dx;                                            // ratio is exactly 1/2, no evaluation
@@ -52,7 +52,7 @@ MPC_HD int pnqp1(real H, real q, real lb, real ub, real &x, real &Hfree, bool &i
         while (arm <= GAMMA && count < 10) {                       // :64-76
             xn = clampr<real>(x + alpha * dx, lb, ub);
             const real d = xn - x;                                 // f(x) - f(xn) = -g d - H d^2 / 2, without
-            arm = (-g * d - (real)0.5 * H * d * d) / (-g * d);     // subtracting two large objective values
+            arm = (-g * d - (real)0.5 * H * d * d) * env_inv(-g * d);   // subtracting two large objective values
             if (arm <= GAMMA) alpha *= (real)0.1;
             ++count;
         }
@@ -175,7 +175,7 @@ MPC_HD void sweep_problem(const StepParams<real> &p, int b, real *Kw, bool write
                 for (int j = 0; j < NS; ++j) K[j] = 0;
                 k = 0;
             } else {                                   // :86-87
-                const real inv = (real)1 / Quu;
+                const real inv = env_inv(Quu);
                 for (int j = 0; j < NS; ++j) K[j] = -(inv * Q[NS][j]);
                 k = -(inv * qu);
             }
@@ -187,7 +187,7 @@ MPC_HD void sweep_problem(const StepParams<real> &p, int b, real *Kw, bool write
                 if (lb < -p.delta_u) lb = -p.delta_u;
                 if (ub > p.delta_u) ub = p.delta_u;
             }
-            real x = warm ? kprev : -(qu / Quu);       // warm start = k_{t+1} (:137,141) / cold start pnqp.py:15-16
+            real x = warm ? kprev : -(qu * env_inv(Quu)); // warm start = k_{t+1} (:137,141) / cold start pnqp.py:15-16
             real Hf;
             bool is_free, conv;
             const int it = pnqp1<real>(Quu, qu, lb, ub, x, Hf, is_free, p.pnqp_iter, conv);
@@ -195,7 +195,8 @@ MPC_HD void sweep_problem(const StepParams<real> &p, int b, real *Kw, bool write
             if (!conv) status |= MPC_ST_PNQP_UNCONVERGED;
             warm = true;
             k = x;
-            for (int j = 0; j < NS; ++j) K[j] = is_free ? -(Q[NS][j] / Hf) : (real)0;   // :142-146
+            const real iHf = env_inv(Hf);
+            for (int j = 0; j < NS; ++j) K[j] = is_free ? -(Q[NS][j] * iHf) : (real)0;   // :142-146
         }
         kprev = k;
         if (writer) {
