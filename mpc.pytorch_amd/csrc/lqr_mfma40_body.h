@@ -478,19 +478,20 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
         const long tb = (long)t * p.B + L.b;
 
         // ---- C in D layout (all nine tiles), tau in both layouts, c in row layout
+        // Tile (I, J), registers v = 0..3 of lane (q, r) = C[16I + 4q + v][16J + r] -- read through C's symmetry as
+        // C[16J + r][16I + 4q .. + 3]: four consecutive floats of one row, ONE 16-byte LDS read per tile instead of four
+        // 4-byte reads (rows are 160 B, so every such quadruple is 16-byte aligned)
         f32x4 Qd[3][3];
 #pragma unroll
         for (int I = 0; I < 3; ++I)
 #pragma unroll
-            for (int J = 0; J < 3; ++J)
+            for (int J = 0; J < 3; ++J) {
+                // only tile row / column 2 has padding (rows, columns 40..47)
+                const bool in = (I < 2 || L.q < 2) && (J < 2 || L.r < 8);
+                const f32x4 x = wv::lds_f32x4(base + OFF_C + 4u * (unsigned)(in ? (16 * J + L.r) * N + 16 * I + 4 * L.q : 0));
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    // only tile row / column 2 has padding (rows, columns 40..47)
-                    const int row = 16 * I + 4 * L.q + v, col = 16 * J + L.r;
-                    const bool in = (I < 2 || L.q < 2) && (J < 2 || L.r < 8);
-                    const float x = wv::lds_f32(base + OFF_C + 4u * (unsigned)((in ? row : 0) * N + (in ? col : 0)));
-                    Qd[I][J][v] = in ? x : 0.f;
-                }
+                for (int v = 0; v < 4; ++v) Qd[I][J][v] = in ? x[v] : 0.f;
+            }
         float tcol[3][4], trow[3], crow[3];
 #pragma unroll
         for (int I = 0; I < 3; ++I)
