@@ -91,7 +91,11 @@ enum {
                                         The 4-problems-per-wave kernel prices its rollout by an identity of the sweep's
                                         value function that holds exactly then; without the flag it verifies the premise
                                         at every timestep (and prices from C itself where it fails, MPC_ST_NOMINAL_OFF_
-                                        DYNAMICS), with it the verification is skipped.  Other kernels ignore it. */
+                                        DYNAMICS), with it the verification is skipped.  Other kernels ignore it. */,
+    MPC_OPT_SWEEP_ONLY = 2           /* mpc_lqr_step stops after the Riccati sweep (lqr_backward, mpc/lqr_step.py:52-160):
+                                        out->K / out->k (required), old_costs, qp_iters and status are written, the
+                                        trajectory outputs are not touched.  For callers that roll out themselves -- a
+                                        module as true_dynamics (:223-225) -- on the fast kernel of the shape. */
 };
 
 /* The LQRStep(...) keyword arguments that reach the kernels

@@ -63,11 +63,24 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
 {
     StepParams<real> sp = make_params<real>(p, o, out);
     sp.old_costs_in = (const real *)old_costs_in;
-    if (phase_mask & 2) {
+    if ((phase_mask & 2) && !sp.sweep_only) {
         if (!sp.new_x || !sp.new_u) return fail(MPC_E_NULL, "new_x / new_u is NULL");
     }
     const int64_t needK = (int64_t)p->T * p->B * p->nc * p->ns * (int64_t)sizeof(real);
     const int64_t needk = (int64_t)p->T * p->B * p->nc * (int64_t)sizeof(real);
+    if (sp.sweep_only) {
+        if (phase_mask != 3) return fail(MPC_E_ARG, "MPC_OPT_SWEEP_ONLY is an option of mpc_lqr_step");
+        if (!sp.K || !sp.k) return fail(MPC_E_NULL, "MPC_OPT_SWEEP_ONLY needs out->K and out->k");
+        if (sp.env.kind) return fail(MPC_E_ARG, "MPC_OPT_SWEEP_ONLY with a simulator as true_dynamics");
+        // the kernels that can stop after their sweep: the 12/4 and 32/8 fused ones; every other shape takes the generic sweep
+        bool fused = false;
+        if constexpr (sizeof(real) == 4) fused = (impl == 0 || impl == 3) ? dpp16_supported(sp) : false;
+        if constexpr (sizeof(real) == 4) fused = fused || ((impl == 0 || impl == 5) && mfma40_supported(sp));
+        if (!fused) {
+            if (impl != 0 && impl != 1) return fail(MPC_E_ARG, "MPC_OPT_SWEEP_ONLY: this kernel cannot stop after its sweep");
+            return launch_step_generic<real>(sp, 1, st);
+        }
+    }
     if (sp.env.kind && sp.env.linearize && !(phase_mask == 3 && tiny_supported(p->ns, p->nc) && (impl == 0 || impl == 4)))
         return fail(MPC_E_ARG, "in-kernel linearisation needs the lane-per-problem kernel (n_ctrl = 1, n_state <= 6)");
     if (sp.env.kind && (impl == 2 || impl == 3))

@@ -455,7 +455,7 @@ int launch_step_dpp16(const StepParams<float> &p, hipStream_t st)
 {
     if (!dpp16_supported(p)) { set_last_error("dpp16: needs n_state = 12, n_ctrl = 4, fp32, 16-byte aligned blocks"); return MPC_E_DIMS; }
     if (!p.Kk || (uintptr_t)p.Kk % 16 != 0) { set_last_error("dpp16: gain workspace missing or misaligned"); return MPC_E_NULL; }
-    if (!p.new_x || !p.new_u) { set_last_error("dpp16: new_x / new_u is NULL"); return MPC_E_NULL; }
+    if (!p.sweep_only && (!p.new_x || !p.new_u)) { set_last_error("dpp16: new_x / new_u is NULL"); return MPC_E_NULL; }
     static_assert(MPC_DPP16_LDS == dpp16::LDS_TOTAL, "LDS layout out of sync");
     const dim3 grid((p.B + 3) / 4), block(64);
     if (p.bound_mode != MPC_BOUND_NONE) hipLaunchKernelGGL((lqr_step_dpp16_kernel<2>), grid, block, 0, st, p);

@@ -1307,6 +1307,14 @@ MPC_DEV void step_wave(const P &p)
     const double old_cost_d = wv::row_sum_f64(ss.oc);
     const float old_cost = (float)old_cost_d;
 
+    if (p.sweep_only) {                  // MPC_OPT_SWEEP_ONLY: the caller rolls out itself (a module as true_dynamics)
+        if (L.j == 0) {
+            if (p.old_costs) p.old_costs[L.pb] = old_cost;
+            if (p.qp_iters) p.qp_iters[L.pb] = ss.qp_total;
+            if (p.status) p.status[L.pb] = ss.status;
+        }
+        return;
+    }
     // the gains were written by this wave and are re-read through the DMA: drain the stores
     wv::fence_own_stores();
 

@@ -134,7 +134,7 @@ bool mfma40_supported(const StepParams<float> &p)
 int launch_step_mfma40(const StepParams<float> &p, hipStream_t st)
 {
     if (!mfma40_supported(p)) { set_last_error("mfma40: needs fp32, n_state = 32, n_ctrl = 8, 16-byte aligned blocks"); return MPC_E_DIMS; }
-    if (!p.K || !p.k || !p.new_x || !p.new_u) { set_last_error("mfma40: K / k / new_x / new_u missing"); return MPC_E_NULL; }
+    if (!p.K || !p.k || (!p.sweep_only && (!p.new_x || !p.new_u))) { set_last_error("mfma40: K / k / new_x / new_u missing"); return MPC_E_NULL; }
     if (((uintptr_t)p.K & 15) || ((uintptr_t)p.k & 15) || ((uintptr_t)p.new_x & 15) || ((uintptr_t)p.new_u & 15)) {
         set_last_error("mfma40: outputs must be 16-byte aligned");
         return MPC_E_ARG;

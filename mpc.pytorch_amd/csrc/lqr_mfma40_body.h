@@ -1297,6 +1297,7 @@ template <int MODE> MPC_DEV void step_wave(const P &p, float *K, float *k)
 {
     double w0 = 0.0;
     const double old_cost = sweep_wave<MODE>(p, K, k, &w0);
+    if (p.sweep_only) return;           // MPC_OPT_SWEEP_ONLY (the sweep has written K, k, old_costs, qp_iters, status)
     wv::fence_own_stores();
 #ifdef MPC_CFG5_SWEEP_ONLY
     if (old_cost == 1.2345e300) return;    // (diagnostic build: the sweep alone; keeps old_cost / w0 alive)

@@ -22,6 +22,7 @@ struct StepParams {
     int max_ls;
     int pnqp_iter;
     int on_dynamics;             // MPC_OPT_NOMINAL_ON_DYNAMICS: the nominal is known to obey the dynamics
+    int sweep_only;              // MPC_OPT_SWEEP_ONLY: gains, nominal cost and QP counts, no rollout
     // outputs
     real *new_x, *new_u, *costs, *old_costs, *full_du_norm, *alpha_du_norm, *alphas;
     int *qp_iters, *status;
@@ -59,6 +60,7 @@ inline StepParams<real> make_params(const mpc_lqr_problem *p, const mpc_lqr_opti
     s.max_ls = o ? o->max_linesearch_iter : 10;
     s.pnqp_iter = (o && o->pnqp_iter > 0) ? o->pnqp_iter : 20;
     s.on_dynamics = (o && (o->flags & MPC_OPT_NOMINAL_ON_DYNAMICS)) ? 1 : 0;
+    s.sweep_only = (o && (o->flags & MPC_OPT_SWEEP_ONLY)) ? 1 : 0;
     s.new_x = out ? (real *)out->new_x : nullptr; s.new_u = out ? (real *)out->new_u : nullptr;
     s.costs = out ? (real *)out->costs : nullptr; s.old_costs = out ? (real *)out->old_costs : nullptr;
     s.full_du_norm = out ? (real *)out->full_du_norm : nullptr;

@@ -47,6 +47,7 @@ class Options(ctypes.Structure):
 
 ENV_PENDULUM, ENV_PENDULUM_FULL, ENV_CARTPOLE = 1, 2, 3
 OPT_NOMINAL_ON_DYNAMICS = 1          # mpc_lqr_options.flags
+OPT_SWEEP_ONLY = 2
 
 
 class EnvSpec:
@@ -249,10 +250,11 @@ class StepOptions:
     """The LQRStep keyword arguments that reach the kernels (mpc/lqr_step.py:22-38 of the reference)."""
 
     def __init__(self, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None, linesearch_decay=0.2,
-                 max_linesearch_iter=10, pnqp_iter=20, true_dynamics=None, nominal_on_dynamics=False):
+                 max_linesearch_iter=10, pnqp_iter=20, true_dynamics=None, nominal_on_dynamics=False, sweep_only=False):
         assert (u_lower is None) == (u_upper is None)
         # the caller guarantees cur_x = rollout of cur_u through (F, f): MPC.forward's nominal always is (mpc/mpc.py:251)
         self.nominal_on_dynamics = bool(nominal_on_dynamics)
+        self.sweep_only = bool(sweep_only)      # mpc_lqr_step stops after the Riccati sweep: K, k, old_costs, qp_iters only
         self.u_lower, self.u_upper, self.u_zero_I = u_lower, u_upper, u_zero_I
         self.true_dynamics = true_dynamics      # EnvSpec: the rollout calls the simulator, not F,f
         self.delta_u, self.linesearch_decay = delta_u, linesearch_decay
@@ -266,7 +268,7 @@ class StepOptions:
         o.linesearch_decay = float(self.linesearch_decay)
         o.delta_u = float("nan") if self.delta_u is None else float(self.delta_u)
         o.pnqp_iter = int(self.pnqp_iter)
-        o.flags = OPT_NOMINAL_ON_DYNAMICS if self.nominal_on_dynamics else 0
+        o.flags = (OPT_NOMINAL_ON_DYNAMICS if self.nominal_on_dynamics else 0) | (OPT_SWEEP_ONLY if self.sweep_only else 0)
         lo, hi = self.u_lower, self.u_upper
         if lo is None:
             o.bound_mode = BOUND_NONE
@@ -444,8 +446,14 @@ class HipBackend:
         out = Outputs()
         for k in res:
             setattr(out, k, res[k].data_ptr())
-        _check(L.mpc_lqr_sweep(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), _stream(dev)), "mpc_lqr_sweep")
-        res["_keep"] = (keep, keep_o)
+        # mpc_lqr_step with MPC_OPT_SWEEP_ONLY: the fused kernel of the shape stops after its sweep (the 12/4 kernel is
+        # ten times the generic sweep behind mpc_lqr_sweep); other shapes take the generic sweep through the same call
+        o.flags |= OPT_SWEEP_ONLY
+        nbytes = int(L.mpc_lqr_workspace_bytes(ctypes.byref(p)))
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        _check(L.mpc_lqr_step(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), _ptr(ws), nbytes, IMPL_AUTO, _stream(dev)),
+               "mpc_lqr_step (sweep only)")
+        res["_keep"] = (keep, keep_o, ws)
         return res
 
     # -- (4) LQRStepFn.backward -----------------------------------------------------------------

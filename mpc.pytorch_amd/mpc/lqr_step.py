@@ -337,12 +337,10 @@ def LQRStep(n_state,
         from . import util as _util
         net = true_dynamics.native_net(C) if quad and hasattr(true_dynamics, "native_net") else None
         if net is not None:
-            # NNDynamics (:223-225): the sweep on the fastest kernel for this shape (its own rollout through F, f is
-            # one pass whose result is discarded), then the line-searched rollout through the network in one kernel
-            sweep_opts = StepOptions(u_lower=u_lower, u_upper=u_upper, u_zero_I=u_zero_I, delta_u=delta_u,
-                                     linesearch_decay=linesearch_decay, max_linesearch_iter=1)
+            # NNDynamics (:223-225): the sweep on the fastest kernel for this shape (MPC_OPT_SWEEP_ONLY), then the
+            # line-searched rollout through the network in one kernel
             cx, cu = current_x.detach(), current_u.detach()
-            r = be.lqr_step(x_init.detach(), C.detach(), c.detach(), F.detach(), f_in, cx, cu, sweep_opts, want_gains=True)
+            r = be.lqr_sweep(x_init.detach(), C.detach(), c.detach(), F.detach(), cx, cu, opts)
             tC, tc = (C, c) if true_cost is None else (true_cost.C, true_cost.c)
             old_cost = r["old_costs"]
             if not (_same_storage(tC, C) and _same_storage(tc, c)):

@@ -841,3 +841,25 @@ def test_sharded_solve_on_one_rank_is_the_plain_solve(be):
     x1, u1, c1 = shard.mpc_forward_sharded(ctrl, p["x_init"], QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"]), lockstep=True)
     torch.cuda.synchronize()
     assert torch.equal(x0, x1) and torch.equal(u0, u1) and torch.equal(c0, c1)
+
+
+@pytest.mark.parametrize("ns,nc,T,B,bounded", [(12, 4, 20, 37, False), (12, 4, 20, 37, True), (32, 8, 9, 5, False),
+                                                (32, 8, 9, 5, True), (4, 2, 8, 11, True), (5, 1, 10, 70, True)])
+def test_sweep_only_returns_the_full_steps_gains(be, ns, nc, T, B, bounded):
+    """MPC_OPT_SWEEP_ONLY (what `lqr_sweep` asks for): the fused kernels stop after their sweep, other shapes take the
+    generic sweep; K, k, old_costs and qp_iters are those of the full step on the same inputs, bit for bit on the
+    kernels that did both."""
+    import bench
+    from mpc._native import StepOptions
+    p = bench.make_problem(ns, nc, T, B, torch.float32, DEV, seed=3, u_scale=0.3 if bounded else 0.0,
+                           clamp=1.0 if bounded else None)
+    kw = dict(u_lower=-1.0, u_upper=1.0) if bounded else {}
+    full = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions(**kw), want_gains=True)
+    sw = be.lqr_sweep(p["x_init"], p["C"], p["c"], p["F"], p["cur_x"], p["cur_u"], StepOptions(**kw))
+    torch.cuda.synchronize()
+    fused = (ns, nc) in ((12, 4), (32, 8))
+    tol = dict(rtol=0, atol=0) if fused else dict(rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(sw["K"]), host(full["K"]), **tol)
+    np.testing.assert_allclose(host(sw["k"]), host(full["k"]), **tol)
+    np.testing.assert_allclose(host(sw["old_costs"]), host(full["old_costs"]), rtol=1e-6 if fused else 1e-4)
+    assert (host(sw["qp_iters"]) == host(full["qp_iters"])).all() or not fused

@@ -74,6 +74,35 @@ def test_argument_validation_without_gpu():
     assert L.mpc_pnqp(3, 1, 4, None, None, None, None, None, 20, None, None, None, None, None, None) == -3
 
 
+def test_network_and_sweep_only_entry_points_validate_arguments_without_gpu():
+    """mpc_mlp_* (NNDynamics in the kernels) and MPC_OPT_SWEEP_ONLY reject bad arguments before any launch."""
+    L = _native.load()
+    net = _native.MlpDynamics()
+    assert L.mpc_mlp_workspace_bytes(ctypes.byref(net)) == 0                      # no layers
+    net.n_layers, net.activation, net.passthrough = 2, 0, 1
+    net.widths[0], net.widths[1], net.widths[2] = 16, 100, 12
+    assert L.mpc_mlp_workspace_bytes(ctypes.byref(net)) == 4 * (112 * 20 + 112 + 16 * 116 + 16) + 256
+    assert L.mpc_mlp_linearize(ctypes.byref(net), 12, 4, 0, None, None, None, None, None, 0, None) == 0    # N = 0
+    assert L.mpc_mlp_linearize(ctypes.byref(net), 12, 4, 8, None, None, None, None, None, 0, None) == -2   # x NULL
+    assert L.mpc_mlp_linearize(ctypes.byref(net), 12, 4, 8, 16, 16, 16, 16, None, 0, None) == -5           # no workspace
+    assert b"workspace" in L.mpc_lqr_last_error()
+    assert L.mpc_mlp_linearize(ctypes.byref(net), 11, 4, 8, 16, 16, 16, 16, 16, 1 << 20, None) == -1       # widths vs n_state
+    net.ctrl_carry = 4
+    assert L.mpc_mlp_linearize(ctypes.byref(net), 12, 4, 8, 16, 16, 16, 16, 16, 1 << 20, None) == -5       # rollout-only option
+    p = _native.Problem()
+    p.B, p.T, p.ns, p.nc, p.dtype = 4, 5, 12, 4, 1
+    out = _native.Outputs()
+    assert L.mpc_mlp_rollout(ctypes.byref(p), None, ctypes.byref(net), None, None, None, ctypes.byref(out), None, 0, None) == -3   # fp64
+    p.dtype = 0
+    assert L.mpc_mlp_rollout(ctypes.byref(p), None, ctypes.byref(net), None, None, None, ctypes.byref(out), None, 0, None) == -2   # x_init NULL
+    # MPC_OPT_SWEEP_ONLY needs somewhere to put the gains
+    p.x_init = p.C = p.c = p.F = p.cur_x = p.cur_u = 16
+    o = _native.Options()
+    o.max_linesearch_iter, o.delta_u, o.flags = 10, float('nan'), _native.OPT_SWEEP_ONLY
+    assert L.mpc_lqr_step(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), None, 0, 0, None) == -2
+    assert b"SWEEP_ONLY" in L.mpc_lqr_last_error()
+
+
 def test_simulator_entry_points_validate_arguments_without_gpu():
     L = _native.load()
     e = _native.EnvDynamics()
