@@ -56,6 +56,36 @@ def in_timestep_loop(lines, loops, i):
     return not any((c, d) != (a, b) and a <= c and d <= b and (d - c) < (b - a) - 50 for c, d in dma)
 
 
+def enclosing_loop_has_children(lines, i):
+    """LLVM annotates every block with its innermost loop ("in Loop: Header=BBx_y Depth=d") and every loop header with its
+    child loops.  True when line i sits in a loop that has child loops: a loop over line-search PASSES around the
+    timestep loops (a wait there is paid once per pass, not once per timestep)."""
+    hdr = None
+    for j in range(i, max(i - 400, 0), -1):
+        m = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=\d+", lines[j])
+        if m:
+            hdr = m.group(1)
+            break
+        m = re.match(r"^\.L(BB\d+_\d+):", lines[j])
+        if m and j + 1 < len(lines) and "Loop Header" in "".join(lines[j:j + 3]):
+            hdr = m.group(1)
+            break
+    if hdr is None:
+        return False
+    for j, l in enumerate(lines):
+        if l.startswith(".L" + hdr + ":"):
+            block = "".join(lines[j:j + 40])
+            head = block.split("\n")[0]
+            # the header's own comment lines follow its label until the first instruction
+            k = j + 1
+            while k < len(lines) and lines[k].lstrip().startswith(";"):
+                if "Child Loop" in lines[k]:
+                    return True
+                k += 1
+            return "Child Loop" in lines[j]
+    return False
+
+
 def short(k):
     return re.sub(r"^_ZN6mpclqr12_GLOBAL__N_1\d+", "", k)[:48]
 
