@@ -625,3 +625,31 @@ def test_gradient_through_affine_module_equals_lindx(oracle_backend):
         jac.append(torch.stack([torch.autograd.grad(flat[i], [F], retain_graph=True)[0].reshape(-1) for i in range(len(flat))]))
     np.testing.assert_allclose(jac[0].numpy(), jac[1].numpy(), atol=1e-4)
     assert jac[0].abs().max() > 0
+
+
+@pytest.mark.parametrize("hidden", [[], [7], [6, 5]])
+def test_augmented_network_is_the_ctrl_passthrough_map(hidden):
+    """MlpSpec.augmented() (what CtrlPassthroughDynamics.native_net hands to the kernels for the slew-rate augmentation,
+    mpc/dynamics.py:131-150): evaluating the augmented weights the way the kernels do -- layers, passthrough on the state
+    rows, the control written into the first `ctrl_carry` rows -- is CtrlPassthroughDynamics(NNDynamics).forward."""
+    from mpc._native import MlpSpec
+    from mpc.dynamics import CtrlPassthroughDynamics, NNDynamics
+    torch.manual_seed(4)
+    ns, nc, N = 3, 2, 9
+    for passthrough in (True, False):
+        net = NNDynamics(ns, nc, hidden, activation="sigmoid", passthrough=passthrough).double()
+        aug = MlpSpec([l.weight.detach() for l in net.fcs], [l.bias.detach() for l in net.fcs], "sigmoid", passthrough).augmented()
+        assert aug.ctrl_carry == nc and aug.n_state == ns + nc and aug.n_ctrl == nc
+        z, u = torch.randn(N, nc + ns, dtype=torch.float64), torch.randn(N, nc, dtype=torch.float64)
+        h = torch.cat((z, u), 1)
+        for i, (W, b) in enumerate(zip(aug.weights, aug.biases)):
+            h = h @ W.t() + b
+            if i + 1 < len(aug.weights):
+                h = torch.sigmoid(h)
+        out = h + (z if passthrough else 0.0)
+        out[:, :nc] = u                                   # ctrl_carry rows: the control itself, no passthrough
+        with torch.no_grad():
+            want = CtrlPassthroughDynamics(net)(z, u)
+        np.testing.assert_allclose(out.numpy(), want.numpy(), rtol=1e-12, atol=1e-12)
+    # on CPU tensors (or fp64) the modules keep the host-driven path
+    assert net.native_net(torch.zeros(1)) is None and CtrlPassthroughDynamics(net).native_net(torch.zeros(1)) is None
