@@ -2,6 +2,7 @@
 // Argument validation + dtype / kernel dispatch; no computation happens on the host.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -108,7 +109,14 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
                 return fail(MPC_E_DIMS, "fused MFMA kernel needs fp32, n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16");
             if ((impl == 3 || impl == 2 || dpp || mfma) && !have_ws)
                 return fail(MPC_E_ARG, "workspace too small or not 16-byte aligned (see mpc_lqr_workspace_bytes)");
-            if (impl == 3 || (impl == 0 && dpp)) return launch_step_dpp16(sp, st);
+            if (impl == 3 || (impl == 0 && dpp)) {
+                // ring depth (lqr_dpp16.hip): the unconstrained step always on the short ring; the constrained one there
+                // only when the batch has more waves (4 problems each) than the chip has SIMDs (256 CUs x 4)
+                const bool constrained = sp.bound_mode != MPC_BOUND_NONE || sp.zero_mask != nullptr;
+                const char *force = getenv("MPC_DPP16_RING");          // "2" / "4": A/B switch
+                const bool ring2 = force ? force[0] == '2' : (!constrained || (sp.B + 3) / 4 > 1024);
+                return ring2 ? launch_step_dpp16_ring2(sp, st) : launch_step_dpp16(sp, st);
+            }
             if (impl == 2 || (impl == 0 && mfma)) return launch_step_mfma16(sp, st);
             sp.Kk = nullptr;
         } else if (impl == 2 || impl == 3) {

@@ -40,6 +40,7 @@ size_t generic_lds_bytes(int ns, int nc, size_t elem);
 // 4-problems-per-wave DPP path for n_state = 12, n_ctrl = 4, f32 (lqr_dpp16.hip)
 bool dpp16_supported(const StepParams<float> &p);
 int launch_step_dpp16(const StepParams<float> &p, hipStream_t st);
+int launch_step_dpp16_ring2(const StepParams<float> &p, hipStream_t st);    // the same kernels on a 2-slot sweep ring (two waves per SIMD)
 bool kkt_dpp16_supported(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx,
                          const float *dC, const float *dF);
 int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,

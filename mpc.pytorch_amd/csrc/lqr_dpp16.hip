@@ -310,7 +310,10 @@ MPC_DEV double row_sum_f64(double x)
 }
 
 // ---- HBM -> LDS staging --------------------------------------------------------------------
-#define MPC_DPP16_LDS (4 * 9216)
+#ifndef MPC_DPP16_NSTAGE
+#define MPC_DPP16_NSTAGE 4
+#endif
+#define MPC_DPP16_LDS (MPC_DPP16_NSTAGE * 9216)
 __shared__ __attribute__((aligned(16))) char g_stage16[MPC_DPP16_LDS];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -402,13 +405,16 @@ __global__ void __launch_bounds__(64, 1) lqr_step_dpp16_kernel(StepParams<float>
     dpp16::step_wave<MODE>(p);
 }
 
+#if MPC_DPP16_NSTAGE == 4
 __global__ void __launch_bounds__(64, 1) lqr_kkt_dpp16_kernel(StepParams<float> p, dpp16::KktArgs k)
 {
     dpp16::kkt_wave(p, k);
 }
 
+#endif
 }  // namespace
 
+#if MPC_DPP16_NSTAGE == 4
 bool kkt_dpp16_supported(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx,
                          const float *dC, const float *dF)
 {
@@ -451,7 +457,21 @@ bool dpp16_supported(const StepParams<float> &p)
     return true;
 }
 
-int launch_step_dpp16(const StepParams<float> &p, hipStream_t st)
+#endif
+
+// This file is compiled twice (Makefile): with the 4-slot sweep ring (36 KiB of LDS per wave, four waves per CU) as
+// launch_step_dpp16, and with -DMPC_DPP16_NSTAGE=2 (18 KiB, eight waves per CU = two per SIMD) as launch_step_dpp16_ring2.
+// capi.hip picks: the memory-bound unconstrained step is faster on the short ring at every batch (fewer bytes in
+// flight per CU: 83.3 against 86.0 us at B = 4096, 65 against 74 at 1024); the instruction-bound constrained step wants the
+// deep ring while there is one wave per SIMD (B <= 4096: 184.8 against 191.0 us) and a second wave per SIMD beyond it
+// (B = 6144: 248 against 347 us; 8192: 304 against 371) -- profiles/r02_experiments.md 15.
+#if MPC_DPP16_NSTAGE == 4
+#define MPC_DPP16_LAUNCH launch_step_dpp16
+#else
+#define MPC_DPP16_LAUNCH launch_step_dpp16_ring2
+bool dpp16_supported(const StepParams<float> &p);
+#endif
+int MPC_DPP16_LAUNCH(const StepParams<float> &p, hipStream_t st)
 {
     if (!dpp16_supported(p)) { set_last_error("dpp16: needs n_state = 12, n_ctrl = 4, fp32, 16-byte aligned blocks"); return MPC_E_DIMS; }
     if (!p.Kk || (uintptr_t)p.Kk % 16 != 0) { set_last_error("dpp16: gain workspace missing or misaligned"); return MPC_E_NULL; }

@@ -60,6 +60,10 @@
 #define MPC_DEVM MPC_DEV
 #endif
 
+#ifndef MPC_DPP16_NSTAGE
+#define MPC_DPP16_NSTAGE 4
+#endif
+
 namespace mpclqr {
 namespace dpp16 {
 
@@ -247,7 +251,9 @@ MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const
 }
 
 enum {
-    SC = 0, SF = 4096, SR = 7168, SG = 8192, STAGE_BYTES = 9216, NSTAGE = 4,
+    // NSTAGE: slots of the sweep's staging ring (the DMA runs NSTAGE - 1 timesteps ahead).  4 in the product; the diagnostic
+    // build -DMPC_DPP16_NSTAGE=2 halves the wave's LDS so that a CU holds eight waves (two per SIMD) instead of four.
+    SC = 0, SF = 4096, SR = 7168, SG = 8192, STAGE_BYTES = 9216, NSTAGE = MPC_DPP16_NSTAGE, AHEAD = NSTAGE - 1,
     R_c = 0, R_tau = 64, R_f = 128, R_lo = 192, R_hi = 208,
     LDS_TOTAL = NSTAGE * STAGE_BYTES,
     DMA_SWEEP = 8       // 4 C + 3 F + 1 record
@@ -1103,7 +1109,7 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gai
                 // stages t+1 .. min(t + LA - 1, T - 1) are in flight behind the one needed now
                 PROF_MARK(7);
                 if (T - 1 - t >= LA - 1) wv::dma_wait<(LA - 1) * ND>();
-                else tail_wait<LA - 2, ND>(T - 1 - t);
+                else tail_wait<(LA >= 2 ? LA - 2 : 0), ND>(T - 1 - t);
                 PROF_MARK(4);
                 RoStage s;
                 ro_read<MODE, DIRECT>(s, p, L, t, i, zq[i]);
@@ -1268,10 +1274,10 @@ MPC_DEV void step_wave(const P &p)
     ss.rec = p.Kk + ((long)(T - 1) * p.B + L.pb) * 64 + 4 * L.j;
     ss.rec2 = ss.rec + (long)T * p.B * 64;
     {
-        unsigned zq[NSTAGE] = {0u, 0u, 0u, 0u};
+        unsigned zq[NSTAGE] = {};
         dma_seek<MODE, false, false>(d, p, L, wave);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < AHEAD; ++i) {
             const int ti = T - 1 - i;
             if (ti >= 0) {
                 stage_issue<MODE, false, false>(d, stage_mid<MODE, false, false>(i));
@@ -1286,18 +1292,18 @@ MPC_DEV void step_wave(const P &p)
                 if (t >= 0) {
                     // stages t-1 and t-2 (where they exist) are in flight behind the one needed now
                     PROF_MARK(3);
-                    if (t >= 2) wv::dma_wait<2 * DMA_SWEEP>();
+                    if (t >= AHEAD - 1) wv::dma_wait<(AHEAD - 1) * DMA_SWEEP>();
                     else wv::dma_wait<0>();
                     PROF_MARK(0);
                     SwStage s;
                     sw_read<MODE>(s, p, L, t, i, zq[i]);
                     PROF_MARK(1);
                     ZmRaw zr = {{0u, 0u, 0u, 0u}};
-                    if (MODE == 1 && t >= 3) zr = zm_fetch(p, L, t - 3);
-                    Feed<MODE, false, false> feed = {d, stage_mid<MODE, false, false>((i + 3) % NSTAGE), t >= 3, true};
+                    if (MODE == 1 && t >= AHEAD) zr = zm_fetch(p, L, t - AHEAD);
+                    Feed<MODE, false, false> feed = {d, stage_mid<MODE, false, false>((i + AHEAD) % NSTAGE), t >= AHEAD, true};
                     PROF_MARK(2);
                     sweep_step<MODE>(p, L, s, ss, t, feed, G);
-                    if (MODE == 1) zq[(i + 3) % NSTAGE] = zm_pick(L, zr);
+                    if (MODE == 1) zq[(i + AHEAD) % NSTAGE] = zm_pick(L, zr);
                 }
             }
         }
@@ -1370,7 +1376,7 @@ struct KktArgs {
     float *dC, *dc, *dF, *df, *dx_init;
 };
 
-enum { K_c = 0, K_tau = 64, K_dtau = 128, K_rx = 192, KKT_STAGE = 8192, DMA_KKT = 8 };
+enum { K_c = 0, K_tau = 64, K_dtau = 128, K_rx = 192, KKT_STAGE = 8192, DMA_KKT = 8, KKT_NSTAGE = 4 };
 
 struct KktDma {
     const char *c_ptr[4];
@@ -1438,9 +1444,9 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
     float lam = 0.f, dlam = 0.f;          // lambda_{t+1}[j], dlambda_{t+1}[j]  (state lanes)
 #pragma unroll
     for (int i = 0; i < 3; ++i) kkt_stage_issue(p, d, T - 1 - i >= 0 ? T - 1 - i : 0, i);
-    for (int k0 = 0; k0 < T; k0 += NSTAGE) {
+    for (int k0 = 0; k0 < T; k0 += KKT_NSTAGE) {
 #pragma unroll
-        for (int i = 0; i < NSTAGE; ++i) {
+        for (int i = 0; i < KKT_NSTAGE; ++i) {
             const int t = T - 1 - (k0 + i);
             if (t >= 0) {
                 wv::dma_wait<2 * DMA_KKT>();
@@ -1463,7 +1469,7 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
                 const float tj = wv::lds_f32(base + L.aRec + K_tau);
                 const float dj = wv::lds_f32(base + L.aRec + K_dtau);
                 const float rj = wv::lds_f32(base + SR + L.p * 256 + K_rx + 4 * (L.j < 12 ? L.j : 11));
-                kkt_stage_issue(p, d, t - 3 >= 0 ? t - 3 : 0, (i + 3) % NSTAGE);
+                kkt_stage_issue(p, d, t - 3 >= 0 ? t - 3 : 0, (i + 3) % KKT_NSTAGE);
 
                 const long tb = (long)t * p.B + L.pb;
                 // dF_t, df_t from the costates of t+1.  Lane j holds COLUMN j (regs = rows): every register is then one

@@ -18,8 +18,9 @@ _EMU = os.path.join(_HERE, "emu")
 _LIB = None
 
 
-def build():
-    so = os.path.join(_EMU, "libemu_mfma16.so")
+def build(ring2=False):
+    """ring2: the 12/4 kernel with its 2-slot sweep ring (-DMPC_DPP16_NSTAGE=2, the second compilation of lqr_dpp16.hip)."""
+    so = os.path.join(_EMU, "libemu_mfma16_ring2.so" if ring2 else "libemu_mfma16.so")
     src = os.path.join(_EMU, "emu_mfma16.cpp")
     csrc = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc")
     deps = [src] + [os.path.join(csrc, h) for h in ("lqr_mfma16_body.h", "lqr_dpp16_body.h", "lqr_small_math.h",
@@ -29,8 +30,20 @@ def build():
         if not os.path.exists(cxx):
             cxx = shutil.which("clang++")
         assert cxx, "the emulator needs clang++ (ext_vector_type)"
-        subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
+        subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+                              + (["-DMPC_DPP16_NSTAGE=2"] if ring2 else []) + ["-o", so, src])
     return so
+
+
+_LIB2 = None
+
+
+def lib_ring2():
+    global _LIB2
+    if _LIB2 is None:
+        _LIB2 = ctypes.CDLL(build(ring2=True))
+        _LIB2.emu_lqr_step_dpp16.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs)]
+    return _LIB2
 
 
 def lib():
@@ -103,6 +116,8 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
     for key, arr in res.items():
         setattr(out, key, _ptr(arr))
     lib().emu_set_dma_late(int(bool(dma_late)))
+    if kernel == "dpp16_ring2":
+        lib_ring2().emu_set_dma_late(int(bool(dma_late)))
     if env is not None:
         e = N.EnvDynamics()
         prm = np.ascontiguousarray(env[1], f32)
@@ -122,6 +137,8 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
         rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
     elif kernel == "dpp16":
         rc = lib().emu_lqr_step_dpp16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
+    elif kernel == "dpp16_ring2":
+        rc = lib_ring2().emu_lqr_step_dpp16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
     else:
         rc = lib().emu_lqr_step_mfma16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), int(force_general))
     assert rc == 0, rc

@@ -475,3 +475,55 @@ def test_emulated_mfma40_constrained_modes(emu, case, dma_late):
     if case != "masked":
         assert float(np.abs(r["new_u"]).max()) <= (1.5 if case == "tensor_bounds" else 0.5) + 1e-6
         assert int(r["qp_iters"].max()) <= o["n_qp_iter"] + 2
+
+
+# ---------------------------------------------------------------------------------------------
+# The same kernel on its 2-slot sweep ring (lqr_dpp16.hip is compiled twice; -DMPC_DPP16_NSTAGE=2 is what the
+# unconstrained step and large constrained batches run on): the staging look-ahead, its counted waits and the
+# smaller rollout rings are different code paths of the same source.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
+@pytest.mark.parametrize("name", DPP_CASES)
+def test_emulated_dpp16_short_ring_gives_the_deep_rings_numbers(emu, name, dma_late):
+    from oracle import lqr_oracle as O
+    z = golden(name)
+    kw = step_kwargs(z)
+    r4 = emu.lqr_step(kernel="dpp16", dma_late=dma_late, **kw)
+    r2 = emu.lqr_step(kernel="dpp16_ring2", dma_late=dma_late, **kw)
+    for k in ("K", "k", "new_x", "new_u", "costs", "old_costs", "alphas", "full_du_norm", "qp_iters", "status"):
+        np.testing.assert_array_equal(r2[k], r4[k], err_msg=k)      # the arithmetic is the same, only the staging differs
+
+
+@pytest.mark.parametrize("case", ["tensor_bounds", "delta_u", "no_f", "backtrack", "T1", "T2", "T3", "B9", "masked"])
+def test_emulated_dpp16_short_ring_options(emu, case):
+    """Short horizons around the ring depth (T = 1, 2, 3), every option, a ragged batch -- late DMA timing (data lands only
+    when a counted wait forces it): a wait that is too loose for the 1-stage look-ahead shows up as NaNs here."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(5 if case == "backtrack" else sum(map(ord, case)))
+    T = {"T1": 1, "T2": 2, "T3": 3}.get(case, 7)
+    B = 9 if case == "B9" else 5
+    pr = _ns_problem(rng, max(T, 2), B, indef=30.0 if case == "backtrack" else 0.0, with_f=case != "no_f")
+    if T == 1:
+        pr = {k: (v[:1] if k in ("C", "c") else (v[:0] if k in ("F", "f") and v is not None else v)) for k, v in pr.items()}
+    cur_u = np.clip(0.5 * rng.standard_normal((T, B, 4)), -0.4, 0.4)
+    cur_x, _ = O.traj_cost(pr["x_init"], cur_u, pr["F"], pr["f"])
+    kw = dict(cur_x=cur_x, cur_u=cur_u, **pr)
+    if case == "tensor_bounds":
+        kw.update(u_lower=-0.4 - rng.random((T, B, 4)), u_upper=0.4 + rng.random((T, B, 4)))
+    elif case == "delta_u":
+        kw.update(u_lower=-0.4, u_upper=0.4, delta_u=0.1)
+    elif case == "backtrack":
+        kw.update(u_lower=-0.4, u_upper=0.4, linesearch_decay=0.5, max_linesearch_iter=4)
+    elif case == "masked":
+        kw.update(u_zero_I=rng.random((T, B, 4)) < 0.3)
+    elif case != "no_f":
+        kw.update(u_lower=-0.4, u_upper=0.4)
+    o = O.lqr_step(lockstep=False, return_gains=True, **kw)
+    for vouch in (False, True):
+        r = emu.lqr_step(kernel="dpp16_ring2", dma_late=True, nominal_on_dynamics=vouch, **kw)
+        assert (r["status"] & 6 == 0).all()
+        np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+        np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4, atol=1e-4)
+        np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=1e-4)

@@ -319,3 +319,38 @@ def test_module_cost_on_gpu(be, name):
     out = run_module_cost_golden(z, device=DEV)
     assert DRY or out[1].is_cuda
     check_module_cost(out, z, 2e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# (e) the 12/4 kernel on both of its staging rings
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ring", ["2", "4"])
+@pytest.mark.parametrize("mode,B", [("unbounded", 4096), ("bounded", 4099), ("masked", 4099), ("bounded", 6144)])
+def test_headline_kernel_on_both_rings_vs_oracle(be, ring, mode, B, monkeypatch):
+    """lqr_dpp16.hip is compiled twice: a 4-slot sweep ring (four waves per CU) and a 2-slot one (eight); the library picks
+    by mode and batch (capi.hip).  Both are held to the float64 oracle here whatever it would pick (MPC_DPP16_RING
+    forces one): T = 50, every problem, ragged last wave; B = 6144 is where the constrained step changes rings."""
+    import bench
+    from mpc._native import StepOptions, IMPL_DPP16
+    from oracle import lqr_oracle as O
+    if DRY:
+        pytest.skip("ring selection is a property of the HIP library")
+    monkeypatch.setenv("MPC_DPP16_RING", ring)
+    T = 50
+    bounded = mode == "bounded"
+    p = bench.make_problem(12, 4, T, B, torch.float32, DEV, seed=2, u_scale=0.3 if bounded else 0.0, clamp=1.0 if bounded else None)
+    kw, okw = {}, {}
+    if bounded:
+        kw = okw = dict(u_lower=-1.0, u_upper=1.0)
+    elif mode == "masked":
+        g = torch.Generator().manual_seed(4)
+        mask = (torch.rand(T, B, 4, generator=g) < 0.3).to(DEV)
+        kw, okw = dict(u_zero_I=mask), dict(u_zero_I=host(mask))
+    h = {k: h64(v) for k, v in p.items()}
+    o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], lockstep=False,
+                   nthreads=O.max_threads(), return_gains=True, **okw)
+    for vouch in (False, True):
+        r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"],
+                        StepOptions(nominal_on_dynamics=vouch, **kw), impl=IMPL_DPP16, want_gains=True)
+        sync()
+        strict_step_check("ring%s_%s_B%d_%s" % (ring, mode, B, "vouched" if vouch else "verified"), r, o, B)
