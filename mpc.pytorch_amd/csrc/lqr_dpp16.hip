@@ -314,6 +314,13 @@ MPC_DEV double row_sum_f64(double x)
 #define MPC_DPP16_NSTAGE 4
 #endif
 #define MPC_DPP16_LDS (MPC_DPP16_NSTAGE * 9216)
+// the KKT kernel shares this file's staging array: it lives in the compilation whose array fits its ring
+#ifndef MPC_KKT16_NSTAGE
+#define MPC_KKT16_NSTAGE 4
+#endif
+#if !defined(MPC_DPP16_WITH_KKT) && !defined(MPC_DPP16_NO_KKT) && MPC_DPP16_NSTAGE == 4
+#define MPC_DPP16_WITH_KKT 1
+#endif
 __shared__ __attribute__((aligned(16))) char g_stage16[MPC_DPP16_LDS];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -405,7 +412,8 @@ __global__ void __launch_bounds__(64, 1) lqr_step_dpp16_kernel(StepParams<float>
     dpp16::step_wave<MODE>(p);
 }
 
-#if MPC_DPP16_NSTAGE == 4
+#ifdef MPC_DPP16_WITH_KKT
+static_assert(MPC_KKT16_NSTAGE * 8192 <= MPC_DPP16_LDS, "the KKT kernel's ring does not fit this compilation's staging array");
 __global__ void __launch_bounds__(64, 1) lqr_kkt_dpp16_kernel(StepParams<float> p, dpp16::KktArgs k)
 {
     dpp16::kkt_wave(p, k);
@@ -414,7 +422,7 @@ __global__ void __launch_bounds__(64, 1) lqr_kkt_dpp16_kernel(StepParams<float> 
 #endif
 }  // namespace
 
-#if MPC_DPP16_NSTAGE == 4
+#ifdef MPC_DPP16_WITH_KKT
 bool kkt_dpp16_supported(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx,
                          const float *dC, const float *dF)
 {
@@ -440,9 +448,9 @@ int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *d
     return MPC_OK;
 }
 
-namespace {
-}
+#endif
 
+#if MPC_DPP16_NSTAGE == 4
 bool dpp16_supported(const StepParams<float> &p)
 {
     // 16-byte DMA granules: every block the kernel streams must start on a 16-byte boundary

@@ -1376,7 +1376,11 @@ struct KktArgs {
     float *dC, *dc, *dF, *df, *dx_init;
 };
 
-enum { K_c = 0, K_tau = 64, K_dtau = 128, K_rx = 192, KKT_STAGE = 8192, DMA_KKT = 8, KKT_NSTAGE = 4 };
+#ifndef MPC_KKT16_NSTAGE
+#define MPC_KKT16_NSTAGE 4
+#endif
+enum { K_c = 0, K_tau = 64, K_dtau = 128, K_rx = 192, KKT_STAGE = 8192, DMA_KKT = 8, KKT_NSTAGE = MPC_KKT16_NSTAGE,
+       KKT_AHEAD = KKT_NSTAGE - 1 };
 
 struct KktDma {
     const char *c_ptr[4];
@@ -1443,13 +1447,13 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
     kkt_dma_init(d, p, k, L, wave);
     float lam = 0.f, dlam = 0.f;          // lambda_{t+1}[j], dlambda_{t+1}[j]  (state lanes)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) kkt_stage_issue(p, d, T - 1 - i >= 0 ? T - 1 - i : 0, i);
+    for (int i = 0; i < KKT_AHEAD; ++i) kkt_stage_issue(p, d, T - 1 - i >= 0 ? T - 1 - i : 0, i);
     for (int k0 = 0; k0 < T; k0 += KKT_NSTAGE) {
 #pragma unroll
         for (int i = 0; i < KKT_NSTAGE; ++i) {
             const int t = T - 1 - (k0 + i);
             if (t >= 0) {
-                wv::dma_wait<2 * DMA_KKT>();
+                wv::dma_wait<(KKT_AHEAD - 1) * DMA_KKT>();
                 const unsigned base = (unsigned)i * KKT_STAGE;
                 float Cr[16], Fc[12];
 #pragma unroll
@@ -1469,7 +1473,7 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
                 const float tj = wv::lds_f32(base + L.aRec + K_tau);
                 const float dj = wv::lds_f32(base + L.aRec + K_dtau);
                 const float rj = wv::lds_f32(base + SR + L.p * 256 + K_rx + 4 * (L.j < 12 ? L.j : 11));
-                kkt_stage_issue(p, d, t - 3 >= 0 ? t - 3 : 0, (i + 3) % KKT_NSTAGE);
+                kkt_stage_issue(p, d, t - KKT_AHEAD >= 0 ? t - KKT_AHEAD : 0, (i + KKT_AHEAD) % KKT_NSTAGE);
 
                 const long tb = (long)t * p.B + L.pb;
                 // dF_t, df_t from the costates of t+1.  Lane j holds COLUMN j (regs = rows): every register is then one

@@ -31,7 +31,7 @@ def build(ring2=False):
             cxx = shutil.which("clang++")
         assert cxx, "the emulator needs clang++ (ext_vector_type)"
         subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
-                              + (["-DMPC_DPP16_NSTAGE=2"] if ring2 else []) + ["-o", so, src])
+                              + (["-DMPC_DPP16_NSTAGE=2", "-DMPC_KKT16_NSTAGE=2"] if ring2 else []) + ["-o", so, src])
     return so
 
 
@@ -145,7 +145,7 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
     return res
 
 
-def kkt_grads(C, c, F, f, x_star, u_star, dx, du, dl_dx, dma_late=False):
+def kkt_grads(C, c, F, f, x_star, u_star, dx, du, dl_dx, dma_late=False, ring2=False):
     """The closed-form part of LQRStepFn.backward (mpc/lqr_step.py:346-404) through the emulated
     4-problems-per-wave kernel; n_state = 12, n_ctrl = 4, float32."""
     f32 = np.float32
@@ -166,7 +166,7 @@ def kkt_grads(C, c, F, f, x_star, u_star, dx, du, dl_dx, dma_late=False):
     out = dict(dC=np.full((T, B, n, n), np.nan, f32), dc=np.full((T, B, n), np.nan, f32),
                dF=np.zeros((max(T - 1, 0), B, ns, n), f32), df=np.full((max(T - 1, 0), B, ns), np.nan, f32) if has_f else None,
                dx_init=np.full((B, ns), np.nan, f32))
-    L = lib()
+    L = lib_ring2() if ring2 else lib()          # ring2: the 2-slot ring the library's KKT kernel is built with
     L.emu_set_dma_late(int(bool(dma_late)))
     vp = ctypes.c_void_p
     L.emu_kkt_dpp16.argtypes = [ctypes.POINTER(N.Problem)] + [vp] * 8

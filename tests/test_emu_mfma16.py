@@ -199,9 +199,10 @@ def test_emulated_dpp16_options_against_oracle(emu, case):
     np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("ring2", [False, True], ids=["ring4", "ring2"])
 @pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
 @pytest.mark.parametrize("bounded,with_f,B", [(False, True, 5), (True, True, 4), (True, False, 3)])
-def test_emulated_kkt_dpp16_matches_oracle(emu, bounded, with_f, B, dma_late):
+def test_emulated_kkt_dpp16_matches_oracle(emu, bounded, with_f, B, dma_late, ring2):
     """kkt_wave (dC, dc, dF, df, dx_init from tau*, dtau, dl_dx) against LQRStepFn.backward of the oracle,
     fed with the oracle's own KKT solve (dx, du)."""
     from oracle import lqr_oracle as O
@@ -215,7 +216,7 @@ def test_emulated_kkt_dpp16_matches_oracle(emu, bounded, with_f, B, dma_late):
     dl_dx, dl_du = rng.standard_normal((T, B, 12)), rng.standard_normal((T, B, 4))
     o = O.kkt_backward(pr["C"], pr["c"], pr["F"], pr["f"], sol["new_x"], sol["new_u"], dl_dx, dl_du, lo, hi)
     r = emu.kkt_grads(pr["C"], pr["c"], pr["F"], pr["f"], sol["new_x"], sol["new_u"], o["dx"], o["du"], dl_dx,
-                      dma_late=dma_late)
+                      dma_late=dma_late, ring2=ring2)       # (the library builds the kernel with the 2-slot ring)
     for k in ("dC", "dc", "dF", "dx_init") + (("df",) if with_f else ()):
         np.testing.assert_allclose(r[k], o[k], rtol=1e-4, atol=1e-4 * max(1.0, np.abs(o[k]).max()), err_msg=k)
 

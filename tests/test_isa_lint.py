@@ -31,14 +31,17 @@ def _findings(name):
             f["scratch"] += 1
         if "s_waitcnt vmcnt(0)" in l and "; counted" not in l:      # hand-written tail waits carry the marker
             # (a wait in a loop that has child loops is paid once per line-search pass, not per timestep)
-            if isa_lint.in_timestep_loop(lines, loops, i) and not (name == "lqr_dpp16" and isa_lint.enclosing_loop_has_children(lines, i)):
+            if isa_lint.in_timestep_loop(lines, loops, i) and not (name.startswith("lqr_dpp16") and isa_lint.enclosing_loop_has_children(lines, i)):
                 f["drains"] += 1
     return out
 
 
-def test_dpp16_kernels_keep_their_arrays_in_registers_and_their_dma_queue_full():
-    f = _findings("lqr_dpp16")
-    assert len(f) == 5                           # step kernel modes 0..3 + the KKT kernel
+@pytest.mark.parametrize("tu,kernels", [("lqr_dpp16", 4), ("lqr_dpp16_ring2", 5)])
+def test_dpp16_kernels_keep_their_arrays_in_registers_and_their_dma_queue_full(tu, kernels):
+    """Both compilations of lqr_dpp16.hip (csrc/Makefile): the 4-slot ring (step kernel modes 0..3) and the 2-slot one
+    (the same four + the KKT kernel)."""
+    f = _findings(tu)
+    assert len(f) == kernels
     for k, v in f.items():
         assert v["scratch"] == 0, k
         if "Li0E" in k or "Li3E" in k or "kkt" in k:            # headline kernels and the backward: no drain anywhere
@@ -52,14 +55,15 @@ def test_mfma40_kernels_keep_their_arrays_in_registers_and_their_dma_queue_full(
         assert v == {"scratch": 0, "drains": 0}, (k, v)
 
 
-def test_register_resident_gains_own_the_accumulation_registers():
+@pytest.mark.parametrize("tu", ["lqr_dpp16", "lqr_dpp16_ring2"])
+def test_register_resident_gains_own_the_accumulation_registers(tu):
     """Mode 0 of the headline kernel parks the gains of the whole horizon in a[0..255] through inline assembly
     (wv::rg_put / rg_get, lqr_dpp16.hip).  That is only sound while the compiler itself never allocates an AccVGPR in
     that kernel: every a-register access must be one of the hand-written v_accvgpr_write / v_accvgpr_read, and no MFMA
     may accumulate there."""
     import re
     import isa_lint
-    lines = isa_lint.assembly("lqr_dpp16")
+    lines = isa_lint.assembly(tu)          # (the unconstrained step runs on the 2-slot compilation)
     kernels, _ = isa_lint.structure(lines)
     start = [i for i, n in kernels if "kernelILi0E" in n][0]
     end = min([i for i, n in kernels if i > start] + [len(lines)])

@@ -13,14 +13,18 @@ Both findings cost config 5 10 % and the masked headline step 12 % before they w
 import collections, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mpc.pytorch_amd", "csrc")
-FLAGS = {"lqr_dpp16": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-FAST = ["lqr_dpp16", "lqr_mfma40", "lqr_mfma16", "lqr_tiny", "kkt_wave"]
+# the two compilations of lqr_dpp16.hip, as csrc/Makefile builds them
+FLAGS = {"lqr_dpp16": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DMPC_DPP16_NO_KKT"],
+         "lqr_dpp16_ring2": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DMPC_DPP16_NSTAGE=2", "-DMPC_DPP16_WITH_KKT", "-DMPC_KKT16_NSTAGE=2"]}
+SOURCES = {"lqr_dpp16_ring2": "lqr_dpp16"}
+FAST = ["lqr_dpp16", "lqr_dpp16_ring2", "lqr_mfma40", "lqr_mfma16", "lqr_tiny", "kkt_wave"]
 
 
 def assembly(name, out="/tmp/isa_lint"):
     os.makedirs(out, exist_ok=True)
-    s = os.path.join(out, name + ".s")
-    src = os.path.join(CSRC, name + ".hip")
+    import hashlib
+    s = os.path.join(out, name + "_" + hashlib.md5(" ".join(FLAGS.get(name, [])).encode()).hexdigest()[:8] + ".s")   # (flags are part of the cache key)
+    src = os.path.join(CSRC, SOURCES.get(name, name) + ".hip")
     deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if not os.path.exists(s) or any(os.path.getmtime(d) > os.path.getmtime(s) for d in deps):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-w",
