@@ -271,7 +271,11 @@ template <int MODE, bool DIRECT> struct RollRing {
     enum {
         // (register-resident gains: the stage is F | record = 4 KiB, nine stages in flight)
         BYTES = DIRECT ? (int)STAGE_BYTES : (con(MODE) ? 6144 : (rgm(MODE) ? 4096 : 5120)),
+#ifdef MPC_DPP16_RSLOTS
+        SLOTS = DIRECT ? (int)NSTAGE : (MPC_DPP16_RSLOTS),
+#else
         SLOTS = DIRECT ? (int)NSTAGE : (int)LDS_TOTAL / (con(MODE) ? 6144 : (rgm(MODE) ? 4096 : 5120)),
+#endif
         FOFF = DIRECT ? (int)SF : (con(MODE) ? 2048 : (rgm(MODE) ? 0 : 1024)),        // F block inside a slot
         GADJ = DIRECT ? 0 : (int)SF - 1024 - (int)SG,                // gains / (m, M) relative to the lane offsets,
         MADJ = DIRECT ? 0 : (int)SF - 2048 - (int)SC                 // which are written for the sweep's layout
