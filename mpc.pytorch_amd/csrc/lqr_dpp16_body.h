@@ -224,17 +224,25 @@ MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const
             // f(x) - f(m) = -g'd - d'Hd/2 with d = m - x, against 0.1 g'(x - m)
             const float den = wv::ring_sum(-gv * dv), dhd = wv::ring_sum(dv * hdv);
             const float arm = fmaf(-0.5f, dhd, den) * wv::rcp(den);
-            if (test & (arm <= 0.1f)) {
-                // (rare: one QP in a hundred) shorter steps, this row only
+            // (rare: one QP in a hundred) shorter steps.  Rows that do not need them ride along with their values
+            // untouched: the branch stays wave-uniform (no exec-mask bookkeeping around the DPP broadcasts inside)
+            bool go = test & (arm <= 0.1f);
+            if (wv::any(go)) {
                 float alpha = 0.1f;
                 for (int count = 1; count < 10; ++count) {
-                    MPC_STAT(3);
-                    xcv = eclampf(fmaf(alpha, dxv, xv), lbv, ubv);
-                    dv = xcv - xv;
-                    MPC_HV(hdv, dv);
-                    const float den2 = wv::ring_sum(-gv * dv), dhd2 = wv::ring_sum(dv * hdv);
+                    if (go) MPC_STAT(3);
+                    const float xt = eclampf(fmaf(alpha, dxv, xv), lbv, ubv);
+                    const float dt = xt - xv;
+                    float hdt;
+                    MPC_HV(hdt, dt);
+                    const float den2 = wv::ring_sum(-gv * dt), dhd2 = wv::ring_sum(dt * hdt);
                     const float arm2 = fmaf(-0.5f, dhd2, den2) * wv::rcp(den2);
-                    if (arm2 <= 0.1f) alpha *= 0.1f; else break;
+                    xcv = go ? xt : xcv;
+                    dv = go ? dt : dv;
+                    hdv = go ? hdt : hdv;
+                    go = go & (arm2 <= 0.1f);
+                    alpha = go ? alpha * 0.1f : alpha;
+                    if (!wv::any(go)) break;
                 }
             }
         }

@@ -528,3 +528,34 @@ def test_emulated_dpp16_short_ring_options(emu, case):
         np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=2e-4)
         np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4, atol=1e-4)
         np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("kernel", ["dpp16", "dpp16_ring2"])
+@pytest.mark.parametrize("T", [51, 57, 64, 65, 100])
+def test_emulated_dpp16_long_horizons(emu, kernel, T):
+    """Horizons past the headline's 50: T <= 64 keeps the gains in the register array of mode 0 (slots 50..63 are
+    touched by no other test), T > 64 runs mode 3 (the same kernel with the record through memory).  Both rings,
+    nominal verified and vouched for, unconstrained / box-constrained / masked, ragged batch.  (The emulator binds
+    rg_put / rg_get to a plain array: it checks the algorithm at these horizons; the hand-listed register cases are
+    checked on the GPU, tests/test_gpu_fullsize.py::test_headline_kernel_long_horizons_vs_oracle.)"""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(1000 + T)
+    B = 6
+    pr = _ns_problem(rng, T, B)
+    for mode in ("unbounded", "bounded", "masked"):
+        cur_u = np.clip(0.3 * rng.standard_normal((T, B, 4)), -1.0, 1.0) if mode == "bounded" else np.zeros((T, B, 4))
+        cur_x, _ = O.traj_cost(pr["x_init"], cur_u, pr["F"], pr["f"])
+        kw = dict(cur_x=cur_x, cur_u=cur_u, **pr)
+        if mode == "bounded":
+            kw.update(u_lower=-1.0, u_upper=1.0)
+        elif mode == "masked":
+            kw.update(u_zero_I=rng.random((T, B, 4)) < 0.3)
+        o = O.lqr_step(lockstep=False, return_gains=True, **kw)
+        for vouch in (False, True):
+            r = emu.lqr_step(kernel=kernel, dma_late=True, nominal_on_dynamics=vouch, **kw)
+            assert (r["status"] & 6 == 0).all()
+            np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+            np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=1e-3, atol=2e-4, err_msg=mode)
+            np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=2e-4, err_msg=mode)
+            np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4, atol=1e-4)
+            np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=2e-4)
