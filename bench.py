@@ -133,6 +133,39 @@ def cpu_baseline(sample_B, bounded, seed=123):
     return out
 
 
+PARITY_SLICE = 64
+
+
+def parity_check(p, r, bounded):
+    """the timed problem's own results against the oracle, in the same run.  The first
+    PARITY_SLICE problems of the batch the kernel has just been timed on go through oracle/lqr_oracle.c in float64
+    (the checker, never the measured path); tolerance = the one the parity tests state (rtol 1e-3 / atol 1e-4 on x, u;
+    5e-4 relative on costs).  Box-constrained runs count the two discontinuities of the reference algorithm
+    (tests/test_gpu_fullsize.py) instead of comparing through them."""
+    import numpy as np
+    from oracle import lqr_oracle as O
+    n = min(PARITY_SLICE, int(r["new_x"].shape[1]))
+    h = lambda t, ax: None if t is None else t.narrow(ax, 0, n).detach().cpu().numpy().astype(np.float64)
+    lo, hi = (-1.0, 1.0) if bounded else (None, None)
+    o = O.lqr_step(h(p["x_init"], 0), h(p["C"], 1), h(p["c"], 1), h(p["F"], 1), h(p["f"], 1), h(p["cur_x"], 1), h(p["cur_u"], 1),
+                   lo, hi, lockstep=False, nthreads=O.max_threads())
+    gx, gu, gc, ga = h(r["new_x"], 1), h(r["new_u"], 1), h(r["costs"], 0), h(r["alphas"], 0)
+    same = np.isclose(ga, o["alphas"], rtol=1e-5)           # a line-search tie takes the other step size: counted
+    rtol, atol = 1e-3, 1e-4
+    ex = (np.abs(gx - o["new_x"]) / (atol + rtol * np.abs(o["new_x"])))[:, same]
+    eu = (np.abs(gu - o["new_u"]) / (atol + rtol * np.abs(o["new_u"])))[:, same]
+    ec = (np.abs(gc - o["costs"]) / np.maximum(1e-12, np.abs(o["costs"])))[same]
+    mx = float(ex.max()) if ex.size else 0.0
+    mu = float(eu.max()) if eu.size else 0.0
+    mc = float(ec.max()) if ec.size else 0.0
+    ties = int((~same).sum())
+    ok = bool(np.isfinite(gx).all() and np.isfinite(gu).all() and mx <= 1.0 and mu <= 1.0 and mc <= 5e-4
+              and ties <= max(2, n // 16))
+    return {"ok": ok, "problems": n, "checker": "oracle/lqr_oracle.c (float64, per-problem mode)", "tol": "rtol 1e-3 atol 1e-4 (x, u), 5e-4 relative (costs)",
+            "max_err_over_tol_x": mx, "max_err_over_tol_u": mu, "cost_rel": mc, "line_search_ties": ties,
+            "max_abs_x": float(np.abs(gx - o["new_x"]).max()), "max_abs_u": float(np.abs(gu - o["new_u"]).max())}
+
+
 def time_launches(fn, steps, warmup, barrier=None):
     """W untimed launches, then exactly K launches bracketed by barrier + synchronize on both sides.
     HIP events bracket consecutive runs of EV_GROUP launches on the stream the kernel runs on (torch's
@@ -205,11 +238,15 @@ def extra_rows(be, dev, steps):
         key = "bounded" if bounded else "unbounded"
         p = make_problem(NS, NC, T_H, B_PER_GPU, torch.float32, dev, seed=5, u_scale=0.3 if bounded else 0.0,
                          clamp=1.0 if bounded else None)
-        opts = StepOptions(u_lower=-1.0, u_upper=1.0, nominal_on_dynamics=True) if bounded else StepOptions(nominal_on_dynamics=True)
+        # as mpc.MPC calls a step from its second iteration on: the nominal is its own rollout, C has been tested symmetric
+        opts = (StepOptions(u_lower=-1.0, u_upper=1.0, nominal_on_dynamics=True, c_symmetric=True) if bounded
+                else StepOptions(nominal_on_dynamics=True, c_symmetric=True))
         row, r = step_row(p, opts, NS, NC, T_H, B_PER_GPU)
         if not bounded:
             rowv, _ = step_row(p, StepOptions(), NS, NC, T_H, B_PER_GPU)
-            rowv["workload"] = "headline shape, unbounded, nominal NOT vouched for: the kernel verifies it at every timestep (bare LQRStep call)"
+            rowv["workload"] = ("headline shape, unbounded, NO promises (a bare LQRStep call): the kernel verifies at every timestep that "
+                                "the nominal obeys the dynamics and that C_t is symmetric, and a gated launch of the generic kernel "
+                                "behind it re-solves the problems whose C is not (none here)")
             rows["lqr_step_unbounded_verified_nominal"] = rowv
         if bounded:
             row["workload"] = "headline shape, box bounds +-1 (pnqp in the sweep), nominal u ~ 0.3 N clamped"
@@ -225,18 +262,19 @@ def extra_rows(be, dev, steps):
     # ---- config 5: n_state=32 n_ctrl=8 T=64, the MFMA tile path; B=1024 is one GPU's share of 8192 over 8 ------
     for B5 in (1024, 8192):
         p = make_problem(32, 8, 64, B5, torch.float32, dev, seed=9, on_device=True)
-        row, r = step_row(p, StepOptions(nominal_on_dynamics=True), 32, 8, 64, B5)      # as mpc.MPC calls it
+        row, r = step_row(p, StepOptions(nominal_on_dynamics=True, c_symmetric=True), 32, 8, 64, B5)      # as mpc.MPC calls it
         tf = algorithmic_flops_per_problem_step(32, 8) * B5 * 64 / (row["ms"] * 1e-3) / 1e12
         row["mfma_fp32"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                             "frac": tf / FP32_MFMA_PEAK_TF}
         rows["cfg5_step_B%d" % B5] = row
         if B5 == 1024:
             rowv, _ = step_row(p, StepOptions(), 32, 8, 64, B5)
-            rowv["workload"] = "config 5, nominal NOT vouched for: every line-search trial priced from C in the rollout (bare LQRStep call)"
+            rowv["workload"] = ("config 5, NO promises (bare LQRStep call): every line-search trial priced from C in the rollout, C tested "
+                                "for symmetry in the sweep, gated generic launch behind it")
             rows["cfg5_step_B1024_verified_nominal"] = rowv
-            rows["cfg5_kkt_backward_B1024"] = kkt_row(p, r, StepOptions(), 32, 8, 64, B5)
+            rows["cfg5_kkt_backward_B1024"] = kkt_row(p, r, StepOptions(c_symmetric=True), 32, 8, 64, B5)
             pb = dict(p)
-            rowb, _ = step_row(pb, StepOptions(u_lower=-1.0, u_upper=1.0), 32, 8, 64, B5)
+            rowb, _ = step_row(pb, StepOptions(u_lower=-1.0, u_upper=1.0, c_symmetric=True), 32, 8, 64, B5)
             rows["cfg5_step_bounded_B1024"] = rowb
         del p, r
     torch.cuda.empty_cache()
@@ -383,8 +421,11 @@ def main():
     # the nominal IS util.get_traj of the nominal controls (make_problem), as MPC.forward hands it to every step
     # (mpc/mpc.py:251): the step is told so (MPC_OPT_NOMINAL_ON_DYNAMICS), like mpc.MPC does; --verify-nominal times the
     # general entry, which checks the premise at every timestep
+    # and C = A'A is symmetric (MPC_OPT_C_SYMMETRIC): mpc.MPC makes that promise from its second iteration on, after the
+    # first step of the solve has tested C on the device; --verify-nominal drops both promises (a bare LQRStep call)
     vouch = not args.verify_nominal
-    opts = StepOptions(u_lower=-1.0, u_upper=1.0, nominal_on_dynamics=vouch) if args.bounded else StepOptions(nominal_on_dynamics=vouch)
+    opts = (StepOptions(u_lower=-1.0, u_upper=1.0, nominal_on_dynamics=vouch, c_symmetric=vouch) if args.bounded
+            else StepOptions(nominal_on_dynamics=vouch, c_symmetric=vouch))
     if "C" in args.probe_share:
         p["C"] = p["C"][:1].expand(T_H, -1, -1, -1)
     if "F" in args.probe_share:
@@ -455,13 +496,23 @@ def main():
                                    % (B, "box bounds +-1 (pnqp)" if args.bounded else "unbounded"),
                        "global_batch": world * B, "horizon": T_H, "parallelism": "batch-shard x%d" % world,
                        "kernel": KERNEL_NAMES.get(impl_used, "impl %d" % impl_used),
-                       "nominal": "util.get_traj of the nominal controls" + (", flagged on-dynamics as mpc.MPC flags it" if vouch else ", verified by the kernel at every timestep"),
+                       "nominal": "util.get_traj of the nominal controls" + (", flagged on-dynamics and C flagged symmetric as mpc.MPC flags them from its second iteration on"
+                                                                                 if vouch else ", nominal and symmetry of C verified by the kernel at every timestep"),
                        "settle_launches": settle, "finite": ok,
                        "launcher": ("torch.distributed.run (self-spawned by bench.py)" if os.environ.get("MPC_BENCH_SPAWNED")
                                     else "torch.distributed.run") if launched else "single process",
                        "collective": None if dist is None else "one all_gather_into_tensor of new_x||new_u (RCCL) inside the timed region"},
             "roofline": hbm_roofline(abytes, kern_ms, traffic=traffic),
         }
+        if world == 1:
+            # self-certification: the results of the launches just timed, against the oracle
+            try:
+                par = parity_check(p, r, args.bounded)
+            except Exception as e:
+                par = {"ok": False, "error": "%s: %s" % (type(e).__name__, e)}
+            out["parity"] = par
+            if not par["ok"]:
+                out["config"]["finite"] = ok = False
         if world == 1 and not args.no_extra:
             try:
                 out["extra"] = extra_rows(be, dev, args.steps)
@@ -473,6 +524,9 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        if "parity" in out and not out["parity"]["ok"]:
+            sys.stderr.write("bench.py: the timed results are OUT OF TOLERANCE against the oracle: %s\n" % json.dumps(out["parity"]))
+            sys.exit(4)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPC_LQR_ABI_VERSION 4
+#define MPC_LQR_ABI_VERSION 5
 
 enum { MPC_F32 = 0, MPC_F64 = 1 };
 enum { MPC_BOUND_NONE = 0, MPC_BOUND_SCALAR = 1, MPC_BOUND_TENSOR = 2 };
@@ -44,8 +44,19 @@ enum {
 enum {
     MPC_ST_PNQP_UNCONVERGED = 1,   /* "pnqp warning: Did not converge" (mpc/pnqp.py:81) at some timestep   */
     MPC_ST_NONFINITE = 2,          /* the returned cost is NaN / inf                                        */
-    MPC_ST_NOMINAL_OFF_DYNAMICS = 4 /* informational (DPP kernel): current_x is not the rollout of current_u,
+    MPC_ST_NOMINAL_OFF_DYNAMICS = 4,/* informational (DPP kernel): current_x is not the rollout of current_u,
                                       the trajectory cost was evaluated from a second pass over C            */
+    MPC_ST_C_ASYMMETRIC = 8,       /* some C_t of this problem is not symmetric (max |C - C'| > 1e-5 max |C|).  The
+                                      reference uses C as given (mpc/lqr_step.py:68 Q = C + F'VF, :294 C tau); the fused
+                                      kernels (impl 2..5) read it through its symmetry.  impl = 0 re-solves exactly these
+                                      problems on the generic kernels in the same call (results are the reference's,
+                                      the bit stays set as information); a FORCED fused impl leaves its symmetric-C
+                                      results in place and the bit tells the caller they are not the reference's.   */
+    MPC_ST_QUU_SINGULAR = 16       /* unconstrained solve with n_ctrl > 1 (the reference's pinverse, mpc/lqr_step.py:88-94):
+                                      a pivot of Quu's factorisation was exactly zero and its control dropped out (gain 0).
+                                      That is the pseudo-inverse when the null space is a coordinate axis -- a control that
+                                      enters neither cost nor dynamics, the results are the reference's -- and a different
+                                      generalised inverse otherwise (informational either way).                        */
 };
 
 /* The simulator dynamics the reference ships (mpc/env_dx/pendulum.py:18-84, cartpole.py:28-96),
@@ -92,6 +103,10 @@ enum {
                                         value function that holds exactly then; without the flag it verifies the premise
                                         at every timestep (and prices from C itself where it fails, MPC_ST_NOMINAL_OFF_
                                         DYNAMICS), with it the verification is skipped.  Other kernels ignore it. */,
+    MPC_OPT_C_SYMMETRIC = 4,         /* the caller GUARANTEES C_t = C_t' for every problem and timestep (bit-exact or to
+                                        rounding): the fused kernels skip their symmetry test and mpc_lqr_step (impl 0) its
+                                        second, gated launch of the generic kernels.  mpc.MPC makes the promise from its
+                                        second iteration on, after the first step of a solve reported no MPC_ST_C_ASYMMETRIC. */
     MPC_OPT_SWEEP_ONLY = 2           /* mpc_lqr_step stops after the Riccati sweep (lqr_backward, mpc/lqr_step.py:52-160):
                                         out->K / out->k (required), old_costs, qp_iters and status are written, the
                                         trajectory outputs are not touched.  For callers that roll out themselves -- a
@@ -251,11 +266,12 @@ int mpc_mlp_linearize(const mpc_mlp_dynamics *net, int n_state, int n_ctrl, int6
 /* (7) Device-side pieces of the iLQR driver loop (mpc/mpc.py:271-285, 299):
  *     per-problem best-iterate select without host round trips.
  *     take[b] = first || cost[b] <= best_cost[b] + eps ; where taken copy x,u,cost,du-norm.
- *     flags[0] |= any(take) ; flags[1] = float bits unused ; max_du[0] = max_b full_du_norm. */
+ *     any_improved[0]: bit 0 = any(take); bit 1 = some status[b] has MPC_ST_C_ASYMMETRIC (`status` [B] = the step's
+ *     status words, may be NULL) ; max_du[0] = max_b full_du_norm. */
 int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double best_cost_eps,
                     const void *x, const void *u, const void *costs, const void *du_norm,
                     void *best_x, void *best_u, void *best_costs, void *best_du_norm,
-                    int32_t *any_improved, void *max_du_norm, void *stream);
+                    int32_t *any_improved, void *max_du_norm, const int32_t *status, void *stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,39 @@ static int fail(int code, const char *msg)
     return code;
 }
 
+// Read once per process (the first launch): the A/B switch of the 12/4 kernel's staging ring and the number of SIMDs of
+// the device the library runs on (MI355X: 256 CUs x 4), which is where the constrained step changes rings.
+struct DeviceFacts {
+    int ring_force;      // 0 = pick by mode and batch, 2 / 4 = MPC_DPP16_RING
+    int simds;
+    bool sticky;         // false with MPC_DPP16_RING_DYNAMIC set: the switch is re-read at every launch (the tests flip it)
+};
+static const DeviceFacts &device_facts()
+{
+    static DeviceFacts f = [] {
+        DeviceFacts d;
+        d.ring_force = 0;
+        d.simds = 1024;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            d.simds = prop.multiProcessorCount * 4;
+        const char *force = getenv("MPC_DPP16_RING");            // "2" / "4": A/B switch, read at load
+        if (force && (force[0] == '2' || force[0] == '4')) d.ring_force = force[0] - '0';
+        d.sticky = getenv("MPC_DPP16_RING_DYNAMIC") == nullptr;
+        return d;
+    }();
+    return f;
+}
+static int dpp16_ring_force()
+{
+    const DeviceFacts &f = device_facts();
+    if (f.sticky) return f.ring_force;
+    // MPC_DPP16_RING_DYNAMIC=1 (the test suite): the switch follows the environment from launch to launch
+    const char *force = getenv("MPC_DPP16_RING");
+    return (force && (force[0] == '2' || force[0] == '4')) ? force[0] - '0' : 0;
+}
+
 static int check_problem(const mpc_lqr_problem *p, bool need_cost, bool need_nominal, bool need_F = true)
 {
     if (!p) return fail(MPC_E_NULL, "problem is NULL");
@@ -57,6 +90,33 @@ static int check_options(const mpc_lqr_problem *p, const mpc_lqr_options *o)
     return MPC_OK;
 }
 
+// where a caller's missing status array lives inside the workspace: behind the larger of the two uses of it
+static int64_t status_scratch_offset(const mpc_lqr_problem *p)
+{
+    const int64_t e = p->dtype == MPC_F64 ? 8 : 4;
+    const int64_t generic = ((int64_t)p->T * p->B * p->nc * p->ns + (int64_t)p->T * p->B * p->nc) * e;
+    const int64_t fused = (int64_t)p->T * p->B * (128 + 16) * 4;     // gain records of the fused kernels + the second
+                                                                       // line-search trial's trajectory (box-constrained 12/4 kernel)
+    return ((generic > fused ? generic : fused) + 15) & ~(int64_t)15;
+}
+
+// After a fused kernel under impl = 0 (auto): the problems it flagged MPC_ST_C_ASYMMETRIC are solved again by the generic
+// kernels, which use C exactly as the reference does (mpc/lqr_step.py:68, 294); everything else is left as it is.  A
+// compact grid reads the flags -- no host round trip, nothing to synchronise on.
+template <typename real>
+static int resolve_asymmetric(StepParams<real> sp, int impl, void *workspace, int64_t needK, hipStream_t st)
+{
+    if (impl != 0 || sp.c_symmetric || !sp.status) return MPC_OK;
+    if (sp.env.kind && sp.env.linearize) return MPC_OK;      // no F, f arrays to fall back on: the bit is the answer
+    sp.gate = sp.status;
+    sp.Kk = nullptr;
+    if (!sp.K || !sp.k) {
+        sp.K = (real *)workspace;
+        sp.k = (real *)((char *)workspace + needK);
+    }
+    return launch_step_generic<real>(sp, sp.sweep_only ? 1 : 3, st);
+}
+
 template <typename real>
 static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
                      void *workspace, int64_t workspace_bytes, int impl, int phase_mask,
@@ -64,6 +124,11 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
 {
     StepParams<real> sp = make_params<real>(p, o, out);
     sp.old_costs_in = (const real *)old_costs_in;
+    // the symmetry verdict travels in the status words: a caller that passes none gets them parked behind the workspace
+    if (!sp.status && phase_mask == 3 && workspace) {
+        const int64_t off = status_scratch_offset(p);
+        if (workspace_bytes >= off + (int64_t)p->B * 4) sp.status = (int *)((char *)workspace + off);
+    }
     if ((phase_mask & 2) && !sp.sweep_only) {
         if (!sp.new_x || !sp.new_u) return fail(MPC_E_NULL, "new_x / new_u is NULL");
     }
@@ -93,6 +158,7 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
         if (!workspace || workspace_bytes < needK + needk)
             return fail(MPC_E_ARG, "workspace too small (see mpc_lqr_workspace_bytes)");
         sp.Kk = (real *)workspace;
+        // (this kernel keeps Q and V as general matrices, like the reference: nothing to test, nothing to re-solve)
         return launch_step_tiny<real>(sp, st);
     }
     if (phase_mask == 3 && impl != 1 && !sp.env.kind) {
@@ -113,11 +179,15 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
                 // ring depth (lqr_dpp16.hip): the unconstrained step always on the short ring; the constrained one there
                 // only when the batch has more waves (4 problems each) than the chip has SIMDs (256 CUs x 4)
                 const bool constrained = sp.bound_mode != MPC_BOUND_NONE || sp.zero_mask != nullptr;
-                const char *force = getenv("MPC_DPP16_RING");          // "2" / "4": A/B switch
-                const bool ring2 = force ? force[0] == '2' : (!constrained || (sp.B + 3) / 4 > 1024);
-                return ring2 ? launch_step_dpp16_ring2(sp, st) : launch_step_dpp16(sp, st);
+                const int force = dpp16_ring_force();
+                const bool ring2 = force ? force == 2 : (!constrained || (sp.B + 3) / 4 > device_facts().simds);
+                const int rc = ring2 ? launch_step_dpp16_ring2(sp, st) : launch_step_dpp16(sp, st);
+                return rc ? rc : resolve_asymmetric(sp, impl, workspace, needK, st);
             }
-            if (impl == 2 || (impl == 0 && mfma)) return launch_step_mfma16(sp, st);
+            if (impl == 2 || (impl == 0 && mfma)) {
+                const int rc = launch_step_mfma16(sp, st);
+                return rc ? rc : resolve_asymmetric(sp, impl, workspace, needK, st);
+            }
             sp.Kk = nullptr;
         } else if (impl == 2 || impl == 3) {
             return fail(MPC_E_DTYPE, "the fused kernels are fp32 only");
@@ -135,7 +205,8 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
         if (impl == 5 && !(phase_mask == 3 && mfma40_supported(sp)))
             return fail(MPC_E_DIMS, "MFMA kernel needs fp32, n_state = 32, n_ctrl = 8, 16-byte aligned blocks, no simulator");
         if (phase_mask == 3 && (impl == 5 || impl == 0) && mfma40_supported(sp)) {
-            return launch_step_mfma40(sp, st);
+            const int rc = launch_step_mfma40(sp, st);
+            return rc ? rc : resolve_asymmetric(sp, impl, workspace, needK, st);
         }
     } else if (impl == 5) {
         return fail(MPC_E_DTYPE, "the MFMA sweep is fp32 only");
@@ -161,11 +232,8 @@ const char *mpc_lqr_last_error(void) { return g_last_error.c_str(); }
 int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p)
 {
     if (!p) return 0;
-    const int64_t e = p->dtype == MPC_F64 ? 8 : 4;
-    const int64_t generic = ((int64_t)p->T * p->B * p->nc * p->ns + (int64_t)p->T * p->B * p->nc) * e;
-    const int64_t fused = (int64_t)p->T * p->B * (128 + 16) * 4;     // gain records of the fused kernels + the second
-                                                                       // line-search trial's trajectory (box-constrained 12/4 kernel)
-    return (generic > fused ? generic : fused) + 256;
+    // + one status word per problem for callers that pass out->status = NULL (see step_impl)
+    return status_scratch_offset(p) + (int64_t)p->B * 4 + 256;
 }
 
 int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
@@ -418,7 +486,8 @@ int mpc_traj_cost(const mpc_lqr_problem *p, void *x, void *cost, void *stream)
 
 int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double best_cost_eps, const void *x,
                     const void *u, const void *costs, const void *du_norm, void *best_x, void *best_u,
-                    void *best_costs, void *best_du_norm, int32_t *any_improved, void *max_du_norm, void *stream)
+                    void *best_costs, void *best_du_norm, int32_t *any_improved, void *max_du_norm, const int32_t *status,
+                    void *stream)
 {
     if (dtype != MPC_F32 && dtype != MPC_F64) return fail(MPC_E_DTYPE, "bad dtype");
     if (B < 0 || T < 1 || ns < 1 || nc < 1) return fail(MPC_E_DIMS, "bad dims");
@@ -430,11 +499,11 @@ int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double b
         return launch_select_best<float>(B, T, ns, nc, first, (float)best_cost_eps, (const float *)x,
                                          (const float *)u, (const float *)costs, (const float *)du_norm,
                                          (float *)best_x, (float *)best_u, (float *)best_costs,
-                                         (float *)best_du_norm, any_improved, (float *)max_du_norm, st);
+                                         (float *)best_du_norm, any_improved, (float *)max_du_norm, status, st);
     return launch_select_best<double>(B, T, ns, nc, first, best_cost_eps, (const double *)x, (const double *)u,
                                       (const double *)costs, (const double *)du_norm, (double *)best_x,
                                       (double *)best_u, (double *)best_costs, (double *)best_du_norm,
-                                      any_improved, (double *)max_du_norm, st);
+                                      any_improved, (double *)max_du_norm, status, st);
 }
 
 }  // extern "C"

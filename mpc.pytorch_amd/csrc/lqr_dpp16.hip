@@ -123,6 +123,21 @@ MPC_DEV float row_sum(float x)
     return x;
 }
 
+// max over the 16 lanes of the row, result in every lane (x >= 0, no NaN handling wanted)
+MPC_DEV float row_max(float x)
+{
+    x = __builtin_fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true)));
+    x = __builtin_fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true)));
+    x = __builtin_fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, true)));
+    x = __builtin_fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true)));
+    return x;
+}
+// acc = max(acc, |a|, |b|): one v_max3_f32 with source modifiers (fmaxf() costs a canonicalising v_max per operand)
+MPC_DEV void absmax3(float &acc, float a, float b)
+{
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 // Four row sums in one go: lane j of a row comes back with sum over the row's 16 lanes of p_a, a = j & 3.
 // Two exchanges inside the quads (each lane keeps the addend of "its" a and hands over the other), then the four quads
 // of the row are added with two rotations: 6 selects + 5 DPP adds (four separate row_sum calls: 16 DPP adds).

@@ -302,10 +302,22 @@ template <int MODE, bool ROLL, bool DIRECT> MPC_DEV unsigned stage_mid(int slot)
 // 16-byte granules, which the DMA does for free:
 //   rows read by b128 (C always, F in the rollout): quarter q of row j is stored at quarter q ^ s(j), s(j) = (j>>1)&3
 //   F read by columns (sweep, KKT):                 odd problems store row m at row m ^ 1 (the other 16 banks)
+//   C also read by columns (the symmetry test):     problem slot k stores row R at row R ^ k -- a row is 16 banks, so the
+//                                                   four problems' copies of row i, 1 KiB apart, would meet bank for bank;
+//                                                   with rows (i ^ k) & 3 = 0..3 a column read touches all 64 banks once
 MPC_DEV int quarter_swizzle(int row) { return (row >> 1) & 3; }
 // source granule (of the 64 of a 16x16 block / the 48 of a 12x16 block) for LDS granule position g
 MPC_DEV int src_granule_rows(int g) { return (g & ~3) | ((g & 3) ^ quarter_swizzle(g >> 2)); }
 MPC_DEV int src_granule_cols(int g, int problem_slot) { return g ^ ((problem_slot & 1) << 2); }
+// C: position (row r', quarter q') of problem slot k holds source row R = r' ^ k, quarter q' ^ s(R)
+MPC_DEV int src_granule_C(int g, int problem_slot)
+{
+#ifdef MPC_DPP16_NO_CPERM          // diagnostic build (tools/ab_sym.py): rows where they were, column reads 4-way conflicted
+    problem_slot = 0;
+#endif
+    const int R = (g >> 2) ^ (problem_slot & 3);
+    return 4 * R + ((g & 3) ^ quarter_swizzle(R));
+}
 
 struct Lane {
     int lane, p, j;       // problem slot in the wave, variable
@@ -317,7 +329,8 @@ struct Lane {
     // LDS byte offsets inside a stage
     // C and F sit in LDS in granule-permuted order (see lds_swizzle below): a lane's 16-byte DMA destination is
     // fixed, its source is free, so the permutation costs nothing and the reads below are bank-conflict free
-    int aCq[4];           // SC + p*1024 + 64 j + 16 (q ^ s(j))  quarter q of row j of C            (b128)
+    int aCq[4];           // SC + p*1024 + 64 (j ^ p) + 16 (q ^ s(j))  quarter q of row j of C      (b128)
+    int aCcol;            // C[i][j], the column through this lane's variable: (aCcol ^ ((i&3) << 6 | s(i) << 4)) + 64 (i & 12)
     int aFe, aFo;         // SF + p*768 + 4 j (+-64 for odd p)   F[m][j] at aFe + 64 m (m even) / aFo + 64 m (m odd)
     int aFq[4];           // SF + p*768 + 64 j' + 16 (q ^ s(j')) quarter q of row j' = min(j, 11) of F (b128, rollout)
     int aRec;             // SR + p*256 + 4 j                   (+R_c: c_j, +R_tau: tau_j)
@@ -332,11 +345,18 @@ struct Lane {
     int aMrow;            // SC + p*256 + 4 a                   (second record; + RollRing::MADJ)
 };
 
-MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
+// cperm: the C blocks of this launch are staged with their rows permuted per problem slot (src_granule_C): only the
+// symmetry test reads columns, so a launch whose caller vouches for C keeps the plain layout (0.5 us of the 83)
+MPC_DEV void lane_init(Lane &L, int lane, int wave, int B, bool cperm = true)
 {
     L.lane = lane;
     L.p = lane >> 4;
     L.j = lane & 15;
+#ifdef MPC_DPP16_NO_CPERM
+    const int cp = 0;
+#else
+    const int cp = cperm ? L.p : 0;          // row permutation of this problem slot's C block (src_granule_C)
+#endif
     const int pb = 4 * wave + L.p;
     L.b0 = 4 * wave;
     L.live = pb < B;
@@ -346,9 +366,11 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B)
     const int jx = L.j < 12 ? L.j : 11;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        L.aCq[q] = SC + L.p * 1024 + 64 * L.j + 16 * (q ^ quarter_swizzle(L.j));
+        L.aCq[q] = SC + L.p * 1024 + 64 * (L.j ^ cp) + 16 * (q ^ quarter_swizzle(L.j));
         L.aFq[q] = SF + L.p * 768 + 64 * jx + 16 * (q ^ quarter_swizzle(jx));
     }
+    // source row i sits at row i ^ p = (i & 12) | ((i & 3) ^ p), quarter (j >> 2) ^ s(i): both are XORs into bits 4..7
+    L.aCcol = SC + L.p * 1024 + (cp << 6) + ((L.j >> 2) << 4) + 4 * (L.j & 3);
     L.aFe = SF + L.p * 768 + 4 * L.j + ((L.p & 1) ? 64 : 0);
     L.aFo = SF + L.p * 768 + 4 * L.j - ((L.p & 1) ? 64 : 0);
     L.aRec = SR + L.p * 256 + 4 * L.j;
@@ -406,7 +428,7 @@ MPC_DEV void dma_seek(Dma &d, const P &p, const Lane &L, int wave)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int pbk = 4 * wave + k < p.B ? 4 * wave + k : p.B - 1;
-        d.c_ptr[k] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * src_granule_rows(L.lane) - (1024 * k - 4096) + t0 * d.c_step;
+        d.c_ptr[k] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * src_granule_C(L.lane, p.c_symmetric ? 0 : k) - (1024 * k - 4096) + t0 * d.c_step;
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -596,13 +618,25 @@ struct SwStage {
 };
 
 template <int MODE>
-MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, unsigned zm)
+MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, unsigned zm, float &asym, float &cmax)
 {
     const unsigned base = (unsigned)slot * STAGE_BYTES;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 v = wv::lds_f32x4(base + L.aCq[q]);
         s.Cc[4 * q] = v[0]; s.Cc[4 * q + 1] = v[1]; s.Cc[4 * q + 2] = v[2]; s.Cc[4 * q + 3] = v[3];
+    }
+    // Is C_t symmetric?  Everything below reads row j of C as its column j (the header); the reference does not
+    // (mpc/lqr_step.py:68, 294).  Lane j fetches the true column j and keeps the largest difference, and the largest
+    // entry as the scale; step_wave turns the two into MPC_ST_C_ASYMMETRIC.  Skipped when the caller vouches for C.
+    if (!p.c_symmetric) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const float c0 = wv::lds_f32(base + (unsigned)((L.aCcol ^ (((i & 3) << 6) | (quarter_swizzle(i) << 4))) + 64 * (i & 12)));
+            const float c1 = wv::lds_f32(base + (unsigned)((L.aCcol ^ ((((i + 1) & 3) << 6) | (quarter_swizzle(i + 1) << 4))) + 64 * ((i + 1) & 12)));
+            wv::absmax3(asym, s.Cc[i] - c0, s.Cc[i + 1] - c1);
+            wv::absmax3(cmax, s.Cc[i], s.Cc[i + 1]);
+        }
     }
     // at t = T-1 the F slot holds a copy of F[T-2] (stage_issue clamps the index) and nothing looks at it
 #pragma unroll
@@ -636,6 +670,7 @@ struct SwState {
     int warm;
     int qp_total;
     int status;
+    float asym, cmax;  // max |C[j][i] - C[i][j]| and max |C[j][i]| over this lane's rows so far (the symmetry test)
     float *rec;        // this lane's 16 bytes of the gain record of the current timestep (steps back by rec_step)
     float *rec2;       // ... of the (m, M) record
     long rec_step;
@@ -691,7 +726,9 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     Ldl4 f;
     float kq[4] = {0.f, 0.f, 0.f, 0.f};
     if (!con(MODE)) {
-        ldl4<false>(f, S, fr, 0.f);                                   // :84-94
+        float sing = 0.f;
+        ldl4<false, true>(f, S, fr, 0.f, &sing);                       // :84-94 (pinverse: see pivot_inv)
+        if (sing != 0.f) st.status |= MPC_ST_QUU_SINGULAR;
     } else if (MODE == 1) {
         // :99-127 u_zero_I: masked rows and columns drop out
 #pragma unroll
@@ -1261,7 +1298,7 @@ MPC_DEV void step_wave(const P &p)
     const int wave = wv::problem();          // one workgroup = one wave = four problems
     if (4 * wave >= p.B) return;
     Lane L;
-    lane_init(L, lane, wave, p.B);
+    lane_init(L, lane, wave, p.B, !p.c_symmetric);
     L.out0 = L.isu ? p.new_u + (long)L.pb * 4 + L.a : p.new_x + (long)L.pb * 12 + L.j;
     L.ostep = L.isu ? (long)p.B * 4 : (long)p.B * 12;
     L.scr0 = p.Kk + (long)p.T * p.B * 128 + (long)L.pb * 16 + L.j;      // behind the two records
@@ -1281,6 +1318,8 @@ MPC_DEV void step_wave(const P &p)
     ss.warm = 0;
     ss.qp_total = 0;
     ss.status = 0;
+    ss.asym = 0.f;
+    ss.cmax = 0.f;
     ss.kprev[0] = ss.kprev[1] = ss.kprev[2] = ss.kprev[3] = 0.f;
     ss.rec_step = (long)p.B * 64;
     ss.rec = p.Kk + ((long)(T - 1) * p.B + L.pb) * 64 + 4 * L.j;
@@ -1308,7 +1347,7 @@ MPC_DEV void step_wave(const P &p)
                     else wv::dma_wait<0>();
                     PROF_MARK(0);
                     SwStage s;
-                    sw_read<MODE>(s, p, L, t, i, zq[i]);
+                    sw_read<MODE>(s, p, L, t, i, zq[i], ss.asym, ss.cmax);
                     PROF_MARK(1);
                     ZmRaw zr = {{0u, 0u, 0u, 0u}};
                     if (MODE == 1 && t >= AHEAD) zr = zm_fetch(p, L, t - AHEAD);
@@ -1324,6 +1363,8 @@ MPC_DEV void step_wave(const P &p)
     PROF_MARK_ALL(8);           // slot 8: set-up + sweep tail; slots 0-3: wait / LDS reads / DMA issue / arithmetic of the sweep
     const double old_cost_d = wv::row_sum_f64(ss.oc);
     const float old_cost = (float)old_cost_d;
+    // (a tolerance, not a bit test: C = A'A out of a float32 GEMM is symmetric to rounding only)
+    if (!p.c_symmetric && wv::row_max(ss.asym) > 1e-5f * wv::row_max(ss.cmax)) ss.status |= MPC_ST_C_ASYMMETRIC;
 
     if (p.sweep_only) {                  // MPC_OPT_SWEEP_ONLY: the caller rolls out itself (a module as true_dynamics)
         if (L.j == 0) {
@@ -1408,7 +1449,7 @@ MPC_DEV void kkt_dma_init(KktDma &d, const P &p, const KktArgs &k, const Lane &L
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int pbk = 4 * wave + q < p.B ? 4 * wave + q : p.B - 1;
-        d.c_ptr[q] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * src_granule_rows(L.lane);
+        d.c_ptr[q] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * src_granule_C(L.lane, 0);
     }
     d.c_step = 4 * p.C_st;
 #pragma unroll
@@ -1453,7 +1494,7 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
     const int wave = wv::problem();
     if (4 * wave >= p.B) return;
     Lane L;
-    lane_init(L, lane, wave, p.B);
+    lane_init(L, lane, wave, p.B, false);          // (rows of C only: the plain layout)
     const int T = p.T;
     KktDma d;
     kkt_dma_init(d, p, k, L, wave);

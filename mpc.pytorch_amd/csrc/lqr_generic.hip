@@ -135,7 +135,12 @@ __device__ __forceinline__ void wave_sync()
 // LAPACK / torch.linalg.lu_factor convention: row p was swapped with row piv[p]; the swap runs over the whole row,
 // so earlier multipliers move with it) -- A[:, :nr] is then the packed LU the reference hands back from pnqp
 // (mpc/pnqp.py:52, 59, 82).
-template <typename real, bool KEEP_L = false> __device__ void lu_solve_aug(real *A, int nr, int ncols, real *Lcol, int *piv = nullptr)
+// sing != nullptr (the unconstrained solve, where the reference takes a pseudo-inverse, mpc/lqr_step.py:88-94): a pivot
+// that is exactly zero -- a column with nothing left in it -- drops out: its unknown comes back as 0 and *sing is set.
+// That is the pseudo-inverse when the null space is a coordinate axis (a control that enters neither cost nor dynamics);
+// see pivot_inv in lqr_small_math.h.
+template <typename real, bool KEEP_L = false> __device__ void lu_solve_aug(real *A, int nr, int ncols, real *Lcol, int *piv = nullptr,
+                                                                           int *sing = nullptr)
 {
     const int tid = threadIdx.x;
     if (tid < WAVE) {
@@ -156,8 +161,10 @@ template <typename real, bool KEEP_L = false> __device__ void lu_solve_aug(real 
                 }
             wave_sync();
             const real d = A[p * ncols + p];
+            const bool dead = sing && d == (real)0;
+            if (dead && tid == 0) *sing = 1;
             for (int i = p + 1 + tid; i < nr; i += nt) {
-                const real l = A[i * ncols + p] / d;
+                const real l = dead ? (real)0 : A[i * ncols + p] / d;
                 Lcol[i] = l;
                 if (KEEP_L) A[i * ncols + p] = l;
             }
@@ -173,7 +180,8 @@ template <typename real, bool KEEP_L = false> __device__ void lu_solve_aug(real 
             for (int k = nr - 1; k >= 0; --k) {
                 real x = A[k * ncols + j];
                 for (int i = k + 1; i < nr; ++i) x -= A[k * ncols + i] * A[i * ncols + j];
-                A[k * ncols + j] = x / A[k * ncols + k];
+                const real dk = A[k * ncols + k];
+                A[k * ncols + j] = (sing && dk == (real)0) ? (real)0 : x / dk;
             }
         }
     }
@@ -198,6 +206,14 @@ __device__ int pnqp_core(const real *H, int ldH, const real *qv, const real *rhs
     const real GAMMA = (real)0.1;
     int it_ret = n_iter - 1;
     bool conv = false;
+    // Is H symmetric (bit for bit)?  The two restatements of the Armijo test below -- a full Newton step passes without
+    // evaluation, and f(x) - f(m) = -g'd - d'Hd/2 -- take g = Hx + q for the gradient of the objective, which it is for
+    // a symmetric H only.  The reference evaluates obj(x) - obj(m) literally (mpc/pnqp.py:71-73), so a Quu that came out
+    // of a non-symmetric C (mpc/lqr_step.py:68 uses C as given) gets the literal quantity here too, with the true
+    // gradient (H + H')x/2 + q in place of g -- still without subtracting two large objective values.
+    bool hsym = true;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) hsym = hsym & (H[i * ldH + j] == H[j * ldH + i]);
     for (int it = 0; it < n_iter; ++it) {
         // :29-33 gradient, clamped / free sets
         for (int i = tid; i < n; i += nt) {
@@ -244,7 +260,7 @@ __device__ int pnqp_core(const real *H, int ldH, const real *qv, const real *rhs
             const real xn = x[i] + dx[i];
             inside = inside & ((xn >= lb[i]) & (xn <= ub[i]));
         }
-        if (inside) {
+        if (inside && hsym) {
             __syncthreads();
             for (int i = tid; i < n; i += nt) x[i] += dx[i];
             __syncthreads();
@@ -256,15 +272,18 @@ __device__ int pnqp_core(const real *H, int ldH, const real *qv, const real *rhs
         for (int count = 0; count < 10; ++count) {
             for (int i = tid; i < n; i += nt) mx[i] = eclamp<real>(x[i] + alpha * dx[i], lb[i], ub[i]);
             __syncthreads();
-            real den = 0, dhd = 0;
+            real den = 0, dhd = 0, num = 0;
             for (int i = 0; i < n; ++i) {
                 const real di = mx[i] - x[i];
-                real r = 0;
+                real r = 0, corr = 0;
                 for (int j = 0; j < n; ++j) r += H[i * ldH + j] * (mx[j] - x[j]);
+                if (!hsym)
+                    for (int j = 0; j < n; ++j) corr += (H[j * ldH + i] - H[i * ldH + j]) * x[j];
                 den -= g[i] * di;
+                num -= (g[i] + (real)0.5 * corr) * di;
                 dhd += di * r;
             }
-            const real arm = (den - (real)0.5 * dhd) / den;
+            const real arm = (num - (real)0.5 * dhd) / den;
             __syncthreads();
             if (arm <= GAMMA) alpha *= (real)0.1; else break;
         }
@@ -381,7 +400,13 @@ __device__ void sweep_problem(const StepParams<real> &p, int b, Smem<real> &s, r
                 s.A[e] = val;
             }
             __syncthreads();
-            lu_solve_aug(s.A, nc, ncols, s.Lcol);
+            // (pinverse semantics for the plain unconstrained solve with more than one control; the masked solve and a
+            //  single control are an LU / a division in the reference)
+            __shared__ int sing_flag;
+            const bool pinv = !mk && nc > 1;
+            if (pinv && tid == 0) sing_flag = 0;
+            lu_solve_aug(s.A, nc, ncols, s.Lcol, (int *)nullptr, pinv ? &sing_flag : (int *)nullptr);
+            if (pinv && sing_flag) status |= MPC_ST_QUU_SINGULAR;
         } else {
             // :128-148 box constraints in delta space
             for (int i = tid; i < nc; i += nt) {
@@ -615,9 +640,18 @@ __global__ void __launch_bounds__(MAX_THREADS, (sizeof(real) == 4 ? 6 : 2)) lqr_
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem<real> s;
     s.carve(smem_raw, p.ns, p.nc, blockDim.x);
-    const int b = blockIdx.x;
-    if (b >= p.B) return;
-    int status = 0, qp_total = 0;
+    // p.gate (mpc_lqr_step, impl 0, after a fused kernel): a small grid walks the batch and solves only the problems the
+    // fused kernel flagged as having a non-symmetric C -- usually none, and the launch is a few microseconds of reading flags
+    if (p.gate) {
+        // all of this block's flags in ONE round of loads (a dependent load per problem made the empty launch 6.5 us)
+        const int mine = blockIdx.x + (int)threadIdx.x * (int)gridDim.x;
+        const int flag = (mine < p.B) ? (p.gate[mine] & MPC_ST_C_ASYMMETRIC) : 0;
+        if (!__syncthreads_or(flag)) return;
+    }
+    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    if (p.gate && !(p.gate[b] & MPC_ST_C_ASYMMETRIC)) continue;
+    __syncthreads();                      // the previous problem's last readers of the staging area
+    int status = p.gate ? (int)MPC_ST_C_ASYMMETRIC : 0, qp_total = 0;
     real old_cost = 0;
     if (phase_mask & 1) {
         sweep_problem<real>(p, b, s, p.K, p.k, old_cost, qp_total, status);
@@ -638,6 +672,7 @@ __global__ void __launch_bounds__(MAX_THREADS, (sizeof(real) == 4 ? 6 : 2)) lqr_
     }
     if (threadIdx.x == 0 && p.status) {
         if (phase_mask & 1) p.status[b] = status; else p.status[b] |= status;
+    }
     }
 }
 
@@ -922,7 +957,7 @@ __global__ void select_copy_kernel(long total, int B, int d, int first, real eps
 // Pass 2: best costs / du-norms and the two batch-wide reductions; one atomic per block.
 template <typename real>
 __global__ void select_update_kernel(int B, int first, real eps, const real *costs, const real *du_norm, real *bc,
-                                     real *bd, int *any_improved, real *max_du)
+                                     real *bd, int *any_improved, real *max_du, const int *status)
 {
     __shared__ real s_max[4];
     __shared__ int s_flag[4];
@@ -939,6 +974,8 @@ __global__ void select_update_kernel(int B, int first, real eps, const real *cos
         }
         if (d != d) { isnan_ = 1; d = 0; }
         if (d < 0) d = 0;
+        // bit 2 of the block's flag word: some problem's C is not symmetric (MPC_ST_C_ASYMMETRIC of the step's status)
+        if (status && (status[b] & MPC_ST_C_ASYMMETRIC)) isnan_ |= 2;
     }
     // wave reduction, then across the (<= 4) waves of the block
     for (int off = 32; off > 0; off >>= 1) {
@@ -954,6 +991,7 @@ __global__ void select_update_kernel(int B, int first, real eps, const real *cos
         int fl = 0;
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { d = s_max[i] > d ? s_max[i] : d; fl |= s_flag[i]; }
         if ((fl & 1) && !first && any_improved) atomicOr(any_improved, 1);
+        if ((fl & 4) && any_improved) atomicOr(any_improved, 2);
         if (max_du) {
             // non-negative floats order like their bit patterns; NaN sorts above everything
             using bits = typename BitsOf<real>::type;
@@ -993,7 +1031,8 @@ template <typename real> int launch_step_generic(const StepParams<real> &p, int 
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_step_generic_kernel<real>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(lqr_step_generic_kernel<real>, dim3(p.B), dim3(threads_for(p.ns, p.nc)), lds, st, p, phase_mask);
+    const int grid = p.gate ? (p.B < 1024 ? p.B : 1024) : p.B;
+    hipLaunchKernelGGL(lqr_step_generic_kernel<real>, dim3(grid), dim3(threads_for(p.ns, p.nc)), lds, st, p, phase_mask);
     return check_launch("lqr_step_generic_kernel");
 }
 
@@ -1061,7 +1100,7 @@ int launch_kkt_prepare(int B, int T, int ns, int nc, const real *dl_dx, const re
 template <typename real>
 int launch_select_best(int B, int T, int ns, int nc, int first, real eps, const real *x, const real *u,
                        const real *costs, const real *du_norm, real *bx, real *bu, real *bc, real *bd,
-                       int *any_improved, real *max_du, hipStream_t st)
+                       int *any_improved, real *max_du, const int *status, hipStream_t st)
 {
     const long tx = (long)T * B * ns, tu = (long)T * B * nc;
     hipLaunchKernelGGL(select_copy_kernel<real>, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, st, tx, B, ns, first,
@@ -1069,7 +1108,7 @@ int launch_select_best(int B, int T, int ns, int nc, int first, real eps, const 
     hipLaunchKernelGGL(select_copy_kernel<real>, dim3((unsigned)((tu + 255) / 256)), dim3(256), 0, st, tu, B, nc, first,
                        eps, u, bu, costs, bc, (int *)nullptr, (real *)nullptr);
     hipLaunchKernelGGL(select_update_kernel<real>, dim3((B + 255) / 256), dim3(256), 0, st, B, first, eps, costs, du_norm,
-                       bc, bd, any_improved, max_du);
+                       bc, bd, any_improved, max_du, status);
     return check_launch("select_best_kernel");
 }
 
@@ -1121,7 +1160,7 @@ int launch_env_linearize(const EnvDesc<real> &env, long N, const real *x, const 
                                             real *, hipStream_t);                                             \
     template int launch_select_best<real>(int, int, int, int, int, real, const real *, const real *,          \
                                           const real *, const real *, real *, real *, real *, real *, int *,  \
-                                          real *, hipStream_t);
+                                          real *, const int *, hipStream_t);
 INSTANTIATE(float)
 INSTANTIATE(double)
 

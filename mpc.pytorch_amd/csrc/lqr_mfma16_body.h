@@ -83,6 +83,7 @@ struct Lane {
     bool vC[4], vT[4], vK;
     // byte offsets into an LDS stage
     int aC[4];            // LDS_C + C[rowtau r][col]                    (rows 1..3 double as F rows: +LDS_F-LDS_C)
+    int aCt[4];           // LDS_C + C[col][rowtau r]: the mirror entry (the symmetry test)
     int aT[4];            // 4 * tau index of row slot r                  (+LDS_V+V_c: c; +V_tau: tau; +V_f: f)
     int aQi[4];           // column 0: c[row r];   elsewhere: C[row r][col]
     int aTb[4];           // column 0: tau[row r]; elsewhere: a word of zeros
@@ -116,6 +117,7 @@ MPC_DEV void lane_init(Lane &L, int lane, int ns, int nc)
         if (!L.rowv[r]) { L.row[r] = 0; tau = 0; }
         L.vC[r] = L.rowv[r] && L.colv;
         L.aC[r] = LDS_C + (L.vC[r] ? 4 * (tau * n + coltau) : 0);
+        L.aCt[r] = LDS_C + (L.vC[r] ? 4 * (coltau * n + tau) : 0);
         L.aT[r] = 4 * tau;
         L.aQi[r] = L.j0 ? LDS_V + V_c + L.aT[r] : L.aC[r];
         L.aTb[r] = L.j0 ? LDS_V + V_tau + L.aT[r] : LDS_V + V_zero;
@@ -246,13 +248,20 @@ struct SwStage {
 
 // MODE: 0 = unconstrained, 1 = unconstrained with u_zero_I (the KKT backward's solve), 2 = box bounds
 template <bool FULL, int MODE>
-MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, int zm)
+MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, int zm, float &asym, float &cmax)
 {
     const unsigned base = (unsigned)slot * STAGE_BYTES;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float v = wv::lds_f32(base + L.aC[r]);
         s.C[r] = FULL ? v : sel(L.vC[r], v, 0.f);
+        // the D-layout C serves as its own A operand below -- true for a symmetric C only; the reference takes C as it
+        // is (mpc/lqr_step.py:68, 294).  Keep the largest |C - C'| entry and the largest |C| (-> MPC_ST_C_ASYMMETRIC).
+        if (!p.c_symmetric) {
+            const float vt = wv::lds_f32(base + L.aCt[r]);
+            asym = fmaxf(asym, fabsf(v - vt));       // (padding lanes read one entry twice: 0)
+            cmax = fmaxf(cmax, fabsf(s.C[r]));
+        }
         const float w = wv::lds_f32(base + L.aQi[r]);
         s.Qi[r] = FULL ? w : sel(L.j0 ? L.rowv[r] : L.vC[r], w, 0.f);
         const float u = wv::lds_f32(base + L.aTb[r]);
@@ -287,6 +296,7 @@ struct SwState {
     int warm;
     int qp_total;
     int status;
+    float asym, cmax;  // symmetry test of C: largest |C[i][j] - C[j][i]|, largest |C[i][j]| seen by this lane
 };
 
 template <bool FULL, int MODE>
@@ -346,7 +356,9 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
             fr[a] = valid[a];
             if (MODE == 1) fr[a] = fr[a] && (wv::readlane_i(s.zm, 16 * a) == 0);
         }
-        ldl4<(!FULL || MODE == 1)>(f, S, fr, 0.f);
+        float sing = 0.f;
+        ldl4<(!FULL || MODE == 1), MODE == 0>(f, S, fr, 0.f, &sing);          // MODE 0: the reference's pinverse (pivot_inv)
+        if (MODE == 0 && sing != 0.f) st.status |= MPC_ST_QUU_SINGULAR;
     } else {
         // :128-141 box constraints in delta space
         float qu[4], lb[4], ub[4];
@@ -665,6 +677,7 @@ MPC_DEV void step_problem(const P &p)
     ss.warm = 0;
     ss.qp_total = 0;
     ss.status = 0;
+    ss.asym = ss.cmax = 0.f;
     ss.kprev[0] = ss.kprev[1] = ss.kprev[2] = ss.kprev[3] = 0.f;
     {
         VecDma vd;
@@ -683,7 +696,7 @@ MPC_DEV void step_problem(const P &p)
                 if (t >= 0) {
                     stage_wait<FULL, 2>();
                     SwStage s;
-                    sw_read<FULL, MODE>(s, p, L, t, i, zq[i]);
+                    sw_read<FULL, MODE>(s, p, L, t, i, zq[i], ss.asym, ss.cmax);
                     const int tn = t - 3 >= 0 ? t - 3 : 0;
                     stage_issue<FULL, MODE, false>(p, vd, lane, b, tn, (i + 3) % NSTAGE, t - 4 >= 0);
                     if (MODE == 1) zq[(i + 3) % NSTAGE] = zm_load(p, L, b, tn);
@@ -695,6 +708,13 @@ MPC_DEV void step_problem(const P &p)
     }
     const float old_cost = (wv::readlane(ss.oc, 0) + wv::readlane(ss.oc, 16)) +
                            (wv::readlane(ss.oc, 32) + wv::readlane(ss.oc, 48));
+    if (!p.c_symmetric) {
+        // (a tolerance, not a bit test: C = A'A out of a float32 GEMM is symmetric to rounding only)
+        float m = ss.cmax;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) m = fmaxf(m, wv::shfl_xor(m, sh));
+        if (wv::ballot(ss.asym > 1e-5f * m) != 0ull) ss.status |= MPC_ST_C_ASYMMETRIC;
+    }
 
     // the gains were written by this wave and are re-read through the DMA: drain the stores
     wv::fence_own_stores();

@@ -188,6 +188,8 @@ MPC_DEV void ldl8_solve(const Ldl8 &f, const float rhs[8], float y[8])
 struct Ldl8V {
     float nl[8];     // lane a: -L[a][c]  (valid for a > c)
     float inv[8];    // 1 / D_c in every lane
+    float sing;      // != 0: a pivot was exactly zero and its unknown dropped out (the reference's pinverse of a Quu with
+                     // a zero row and column, mpc/lqr_step.py:88-94; see pivot_inv in lqr_small_math.h)
 };
 template <int C, int M> struct Ldl8VElim {
     static MPC_DEVM void run(float (&col)[8], float nlc)
@@ -197,17 +199,26 @@ template <int C, int M> struct Ldl8VElim {
     }
 };
 template <int C> struct Ldl8VElim<C, 8> { static MPC_DEVM void run(float (&)[8], float) {} };
-template <int C> struct Ldl8VPivot {
+template <int C, bool PINV> struct Ldl8VPivot {
     static MPC_DEVM void run(Ldl8V &f, float (&col)[8])
     {
-        f.inv[C] = wv::rcp(wv::bcast<C>(col[C]));
+        const float d = wv::bcast<C>(col[C]);
+        float inv = wv::rcp(d);
+        if (PINV) {                                         // a zero pivot drops out (the struct's comment)
+            const bool ok = d != 0.f;
+            f.sing = ok ? f.sing : 1.f;
+            inv = ok ? inv : 0.f;
+        }
+        f.inv[C] = inv;
         f.nl[C] = -(col[C] * f.inv[C]);
         Ldl8VElim<C, C + 1>::run(col, f.nl[C]);
-        Ldl8VPivot<C + 1>::run(f, col);
+        Ldl8VPivot<C + 1, PINV>::run(f, col);
     }
 };
-template <> struct Ldl8VPivot<8> { static MPC_DEVM void run(Ldl8V &, float (&)[8]) {} };
-MPC_DEV void ldl8v(Ldl8V &f, float (&col)[8]) { Ldl8VPivot<0>::run(f, col); }
+template <bool PINV> struct Ldl8VPivot<8, PINV> { static MPC_DEVM void run(Ldl8V &, float (&)[8]) {} };
+// PINV: the unconstrained solve, where the reference takes a pseudo-inverse; the box QP's factorisations (H + 1e-11 I
+// on the free set, the reference's LU) are taken as they come
+template <bool PINV = false> MPC_DEV void ldl8v(Ldl8V &f, float (&col)[8]) { f.sing = 0.f; Ldl8VPivot<0, PINV>::run(f, col); }
 
 // z_I -= sum_{k < I} L[I][k] z_k
 template <int I, int K> struct Ldl8VFwdRow {
@@ -465,6 +476,7 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
     double old_cost = 0.0;
     double w0 = 0.0;                   // sum_t 0.5 qu'k: the value function's predicted change of the cost (unconstrained)
     int qp_total = 0, status = 0;
+    float asym = 0.f, cmax = 0.f;      // symmetry test of C (see the tile loads below)
     bool warm = false;
     float kprev_v = 0.f;               // box QP: the previous timestep's solution, spread over lanes (warm start)
 
@@ -492,6 +504,24 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
 #pragma unroll
                 for (int v = 0; v < 4; ++v) Qd[I][J][v] = in ? x[v] : 0.f;
             }
+        // The tiles above hold C[16J + r][16I + 4q + v] where the layout wants C[16I + 4q + v][16J + r]: the same number
+        // only if C_t is symmetric, which the reference does not require (mpc/lqr_step.py:68, 294).  Fetch the true entry
+        // of the upper-triangle tiles (every unordered pair once) and keep the largest difference, with the largest
+        // entry as the scale: MPC_ST_C_ASYMMETRIC at the end of the sweep.  Skipped when the caller vouches for C.
+        if (!p.c_symmetric) {
+#pragma unroll
+            for (int I = 0; I < 3; ++I)
+#pragma unroll
+                for (int J = I; J < 3; ++J) {
+                    const bool in = (I < 2 || L.q < 2) && (J < 2 || L.r < 8);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float tr = wv::lds_f32(base + OFF_C + 4u * (unsigned)(in ? (16 * I + 4 * L.q + v) * N + 16 * J + L.r : 0));
+                        asym = fmaxf(asym, fabsf(in ? Qd[I][J][v] - tr : 0.f));
+                        cmax = fmaxf(cmax, fabsf(Qd[I][J][v]));
+                    }
+                }
+        }
         float tcol[3][4], trow[3], crow[3];
 #pragma unroll
         for (int I = 0; I < 3; ++I)
@@ -602,7 +632,8 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
             float col[8];
 #pragma unroll
             for (int v = 0; v < 4; ++v) wv::rows01(Qd[2][2][v], col[v], col[4 + v]);
-            ldl8v(facv, col);
+            ldl8v<true>(facv, col);
+            if (facv.sing != 0.f) status |= MPC_ST_QUU_SINGULAR;
         } else {
 #pragma unroll
             for (int a = 0; a < 8; ++a)
@@ -803,6 +834,15 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
     }
     if (L.lane == 0 && p.old_costs) p.old_costs[L.b] = (float)old_cost;
     if (L.lane == 0 && p.qp_iters) p.qp_iters[L.b] = qp_total;
+    if (!p.c_symmetric) {
+        // (a tolerance, not a bit test: C = A'A out of a float32 GEMM is symmetric to rounding only)
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            cmax = fmaxf(cmax, wv::shfl_xor(cmax, sh));
+            asym = fmaxf(asym, wv::shfl_xor(asym, sh));
+        }
+        if (asym > 1e-5f * cmax) status |= MPC_ST_C_ASYMMETRIC;
+    }
     if (L.lane == 0 && p.status) p.status[L.b] = status;
     if (w0_out) *w0_out = w0;
     return old_cost;

@@ -23,6 +23,8 @@ struct StepParams {
     int pnqp_iter;
     int on_dynamics;             // MPC_OPT_NOMINAL_ON_DYNAMICS: the nominal is known to obey the dynamics
     int sweep_only;              // MPC_OPT_SWEEP_ONLY: gains, nominal cost and QP counts, no rollout
+    int c_symmetric;             // MPC_OPT_C_SYMMETRIC: the caller vouches for C = C' (no symmetry test in the fused kernels)
+    const int *gate;             // generic kernel only: solve problem b iff gate[b] & MPC_ST_C_ASYMMETRIC (NULL = every problem)
     // outputs
     real *new_x, *new_u, *costs, *old_costs, *full_du_norm, *alpha_du_norm, *alphas;
     int *qp_iters, *status;
@@ -61,6 +63,8 @@ inline StepParams<real> make_params(const mpc_lqr_problem *p, const mpc_lqr_opti
     s.pnqp_iter = (o && o->pnqp_iter > 0) ? o->pnqp_iter : 20;
     s.on_dynamics = (o && (o->flags & MPC_OPT_NOMINAL_ON_DYNAMICS)) ? 1 : 0;
     s.sweep_only = (o && (o->flags & MPC_OPT_SWEEP_ONLY)) ? 1 : 0;
+    s.c_symmetric = (o && (o->flags & MPC_OPT_C_SYMMETRIC)) ? 1 : 0;
+    s.gate = nullptr;
     s.new_x = out ? (real *)out->new_x : nullptr; s.new_u = out ? (real *)out->new_u : nullptr;
     s.costs = out ? (real *)out->costs : nullptr; s.old_costs = out ? (real *)out->old_costs : nullptr;
     s.full_du_norm = out ? (real *)out->full_du_norm : nullptr;

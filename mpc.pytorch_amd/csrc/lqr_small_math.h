@@ -31,8 +31,22 @@ MPC_DEV float dot4(const float a[4], float b0, float b1, float b2, float b3)
 struct Sym4 { float s00, s01, s02, s03, s11, s12, s13, s22, s23, s33; };
 struct Ldl4 { float l10, l20, l30, l21, l31, l32, i0, i1, i2, i3; };
 
-template <bool MASKED>
-MPC_DEV void ldl4(Ldl4 &f, const Sym4 &s, const bool fr_[4], float reg)
+// PINV (the unconstrained solve, where the reference takes a pseudo-inverse, mpc/lqr_step.py:88-94): a pivot that is
+// exactly zero drops out -- its unknown comes back as 0 -- and `sing` is raised.  That IS the pseudo-inverse when the
+// null space is a coordinate axis (a control that enters neither cost nor dynamics: its row and column of Quu are
+// exactly zero in any precision, and so is the pivot).  Every other rank deficiency leaves a pivot of rounding size,
+// which the reference's pinverse (rcond 1e-15) inverts just like this factorisation does: noise in both.
+template <bool PINV> MPC_DEV float pivot_inv(float d, float &sing)
+{
+    const float r = wv::rcp(d);
+    if (!PINV) return r;
+    const bool ok = d != 0.f;
+    sing = ok ? sing : 1.f;
+    return ok ? r : 0.f;
+}
+
+template <bool MASKED, bool PINV = false>
+MPC_DEV void ldl4(Ldl4 &f, const Sym4 &s, const bool fr_[4], float reg, float *sing_out = nullptr)
 {
     bool fr[4];
 #pragma unroll
@@ -51,19 +65,21 @@ MPC_DEV void ldl4(Ldl4 &f, const Sym4 &s, const bool fr_[4], float reg)
     const float a22 = fr[2] ? (reg != 0.f ? s.s22 + reg : s.s22) : 1.f;
     const float a32 = MASKED ? sel2(fr[2], fr[3], s.s23) : s.s23;
     const float a33 = fr[3] ? (reg != 0.f ? s.s33 + reg : s.s33) : 1.f;
-    f.i0 = wv::rcp(a00);
+    float sing = 0.f;
+    f.i0 = pivot_inv<PINV>(a00, sing);
     f.l10 = a10 * f.i0; f.l20 = a20 * f.i0; f.l30 = a30 * f.i0;
     const float d1 = fmaf(-f.l10, a10, a11);
-    f.i1 = wv::rcp(d1);
+    f.i1 = pivot_inv<PINV>(d1, sing);
     const float t21 = fmaf(-f.l20, a10, a21);
     const float t31 = fmaf(-f.l30, a10, a31);
     f.l21 = t21 * f.i1; f.l31 = t31 * f.i1;
     const float d2 = fmaf(-f.l21, t21, fmaf(-f.l20, a20, a22));
-    f.i2 = wv::rcp(d2);
+    f.i2 = pivot_inv<PINV>(d2, sing);
     const float t32 = fmaf(-f.l31, t21, fmaf(-f.l30, a20, a32));
     f.l32 = t32 * f.i2;
     const float d3 = fmaf(-f.l32, t32, fmaf(-f.l31, t31, fmaf(-f.l30, a30, a33)));
-    f.i3 = wv::rcp(d3);
+    f.i3 = pivot_inv<PINV>(d3, sing);
+    if (PINV && sing_out) *sing_out = sing;
 }
 
 MPC_DEV void ldl4_solve(const Ldl4 &f, float r0, float r1, float r2, float r3, float y[4])

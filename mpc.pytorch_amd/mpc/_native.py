@@ -16,10 +16,10 @@ LIB_NAME = "libmpc_lqr_hip.so"
 
 MPC_F32, MPC_F64 = 0, 1
 BOUND_NONE, BOUND_SCALAR, BOUND_TENSOR = 0, 1, 2
-ST_PNQP_UNCONVERGED, ST_NONFINITE, ST_NOMINAL_OFF_DYNAMICS = 1, 2, 4
+ST_PNQP_UNCONVERGED, ST_NONFINITE, ST_NOMINAL_OFF_DYNAMICS, ST_C_ASYMMETRIC, ST_QUU_SINGULAR = 1, 2, 4, 8, 16
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA16, IMPL_DPP16, IMPL_TINY, IMPL_MFMA40 = 0, 1, 2, 3, 4, 5
 
-ABI_VERSION = 4      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
+ABI_VERSION = 5      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
 
 _vp, _i32, _i64, _f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 
@@ -48,6 +48,7 @@ class Options(ctypes.Structure):
 ENV_PENDULUM, ENV_PENDULUM_FULL, ENV_CARTPOLE = 1, 2, 3
 OPT_NOMINAL_ON_DYNAMICS = 1          # mpc_lqr_options.flags
 OPT_SWEEP_ONLY = 2
+OPT_C_SYMMETRIC = 4                  # the caller vouches for C = C' (no symmetry test, no gated re-solve)
 
 
 class EnvSpec:
@@ -181,7 +182,7 @@ def load():
     L.mpc_traj_cost.argtypes = [PP, _vp, _vp, _vp]
     L.mpc_env_traj_cost.argtypes = [PP, ctypes.POINTER(EnvDynamics), _vp, _vp, _vp]
     L.mpc_env_linearize.argtypes = [ctypes.POINTER(EnvDynamics), ctypes.c_int, _i64, _vp, _vp, _vp, _vp, _vp]
-    L.mpc_select_best.argtypes = [ctypes.c_int] * 6 + [_f64] + [_vp] * 11
+    L.mpc_select_best.argtypes = [ctypes.c_int] * 6 + [_f64] + [_vp] * 12
     MP = ctypes.POINTER(MlpDynamics)
     L.mpc_mlp_workspace_bytes.restype = _i64
     L.mpc_mlp_workspace_bytes.argtypes = [MP]
@@ -250,8 +251,12 @@ class StepOptions:
     """The LQRStep keyword arguments that reach the kernels (mpc/lqr_step.py:22-38 of the reference)."""
 
     def __init__(self, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None, linesearch_decay=0.2,
-                 max_linesearch_iter=10, pnqp_iter=20, true_dynamics=None, nominal_on_dynamics=False, sweep_only=False):
+                 max_linesearch_iter=10, pnqp_iter=20, true_dynamics=None, nominal_on_dynamics=False, sweep_only=False,
+                 c_symmetric=False):
         assert (u_lower is None) == (u_upper is None)
+        # the caller guarantees C_t = C_t' (MPC_OPT_C_SYMMETRIC): mpc.MPC does from its second iteration on, once the first
+        # step of the solve has reported no MPC_ST_C_ASYMMETRIC; a bare LQRStep never does
+        self.c_symmetric = bool(c_symmetric)
         # the caller guarantees cur_x = rollout of cur_u through (F, f): MPC.forward's nominal always is (mpc/mpc.py:251)
         self.nominal_on_dynamics = bool(nominal_on_dynamics)
         self.sweep_only = bool(sweep_only)      # mpc_lqr_step stops after the Riccati sweep: K, k, old_costs, qp_iters only
@@ -268,7 +273,8 @@ class StepOptions:
         o.linesearch_decay = float(self.linesearch_decay)
         o.delta_u = float("nan") if self.delta_u is None else float(self.delta_u)
         o.pnqp_iter = int(self.pnqp_iter)
-        o.flags = (OPT_NOMINAL_ON_DYNAMICS if self.nominal_on_dynamics else 0) | (OPT_SWEEP_ONLY if self.sweep_only else 0)
+        o.flags = ((OPT_NOMINAL_ON_DYNAMICS if self.nominal_on_dynamics else 0) | (OPT_SWEEP_ONLY if self.sweep_only else 0)
+                   | (OPT_C_SYMMETRIC if self.c_symmetric else 0))
         lo, hi = self.u_lower, self.u_upper
         if lo is None:
             o.bound_mode = BOUND_NONE
@@ -494,7 +500,7 @@ class HipBackend:
         # the active controls pinned; defaults linesearch_decay=0.2, max_linesearch_iter=10.
         zx, zu, z0 = self._zero_nominal(T, B, ns, nc, kw)
         # (the zero nominal obeys x+ = F tau with f = None: the step may skip verifying it)
-        inner = StepOptions(u_zero_I=mask, nominal_on_dynamics=True)
+        inner = StepOptions(u_zero_I=mask, nominal_on_dynamics=True, c_symmetric=opts.c_symmetric)
         sol = self.lqr_step(z0, C, negr, F, None, zx, zu, inner, impl=impl)
         p, keep = self._problem(z0, C, c, F, f, x_star, u_star)
         has_f = f is not None and f.numel() > 0
@@ -668,10 +674,11 @@ class HipBackend:
         return F, f
 
     # -- (7) driver reductions ------------------------------------------------------------------
-    def select_best(self, first, eps, x, u, costs, du_norm, best, flags=None):
+    def select_best(self, first, eps, x, u, costs, du_norm, best, flags=None, status=None):
         """In-place update of best = dict(x,u,costs,full_du_norm); returns the 2-word device flag
         buffers (any_improved int32[1], max_du real[1]) without synchronising.  flags: write into
-        these two pre-allocated buffers."""
+        these two pre-allocated buffers.  status: the step's status words -- bit 1 of any_improved then
+        reports whether any of them carries ST_C_ASYMMETRIC."""
         dev = _require_device(x, u, costs, du_norm)
         L = load()
         T, B, ns = x.shape
@@ -685,7 +692,7 @@ class HipBackend:
                                  x.data_ptr(), u.data_ptr(), costs.data_ptr(), du_norm.data_ptr(),
                                  best["x"].data_ptr(), best["u"].data_ptr(), best["costs"].data_ptr(),
                                  best["full_du_norm"].data_ptr(), any_improved.data_ptr(), max_du.data_ptr(),
-                                 _stream(dev)), "mpc_select_best")
+                                 _ptr(status), _stream(dev)), "mpc_select_best")
         return any_improved, max_du
 
 

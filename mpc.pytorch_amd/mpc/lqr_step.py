@@ -234,7 +234,7 @@ def _host_scalar_async(dev_scalar):
 
 class _StepConfig:
     """What one LQRStep(...) call fixes for its autograd node (closure state of the reference's factory)."""
-    __slots__ = ("solve", "no_op_forward", "delta_space", "current_x", "current_u", "u_lower", "u_upper")
+    __slots__ = ("solve", "no_op_forward", "delta_space", "current_x", "current_u", "u_lower", "u_upper", "c_symmetric")
 
 
 class _LQRStepFn(Function):
@@ -250,6 +250,7 @@ class _LQRStepFn(Function):
         # the no-op forward those ARE the outputs, and output -> grad_fn -> ctx -> output is a cycle the
         # garbage collector cannot see -- every differentiated solve would pin its tensors forever.)
         ctx.u_lower, ctx.u_upper = cfg.u_lower, cfg.u_upper
+        ctx.c_symmetric = cfg.c_symmetric
         if cfg.no_op_forward:
             ctx.save_for_backward(x_init, C, c, F, f, cfg.current_x, cfg.current_u)
             return cfg.current_x, cfg.current_u
@@ -277,7 +278,7 @@ class _LQRStepFn(Function):
             dl_du = torch.zeros_like(new_u)
         g = _native.backend().kkt_backward(
             C, c, F, None if _is_empty(f) else f, new_x, new_u, dl_dx, dl_du,
-            StepOptions(u_lower=ctx.u_lower, u_upper=ctx.u_upper))
+            StepOptions(u_lower=ctx.u_lower, u_upper=ctx.u_upper, c_symmetric=ctx.c_symmetric))
         df = g["df"] if g["df"] is not None else torch.Tensor()
         return None, g["dx_init"], g["dC"], g["dc"], g["dF"], df
 
@@ -298,7 +299,8 @@ def LQRStep(n_state,
             current_u=None,
             verbose=0,
             back_eps=1e-3,
-            no_op_forward=False):
+            no_op_forward=False,
+            c_symmetric=False):
     """A single step of the box-constrained iLQR solver.
 
     Required: n_state, n_ctrl, T.  The returned callable takes (x_init [B,ns], C [T,B,n,n],
@@ -307,9 +309,14 @@ def LQRStep(n_state,
     when `no_op_forward` (used to attach the backward to an already-converged trajectory).
 
     u_lower / u_upper: python floats or [T, n_batch, n_ctrl] tensors.
+
+    c_symmetric (not in the reference): the caller vouches that every C_t is symmetric, which lets the fused kernels
+    skip their symmetry test (MPC_OPT_C_SYMMETRIC).  Left False, a C that is not symmetric is detected on the device
+    and solved the reference's way (it uses C as given, mpc/lqr_step.py:68, 294) on the generic kernels.
     """
     opts = StepOptions(u_lower=u_lower, u_upper=u_upper, u_zero_I=u_zero_I, delta_u=delta_u,
-                       linesearch_decay=linesearch_decay, max_linesearch_iter=max_linesearch_iter)
+                       linesearch_decay=linesearch_decay, max_linesearch_iter=max_linesearch_iter,
+                       c_symmetric=c_symmetric)
 
     def solve(x_init, C, c, F, f):
         from . import mpc as _mpc
@@ -331,7 +338,7 @@ def LQRStep(n_state,
             if sim:                        # a shipped simulator rolls out inside the kernel (:223-225)
                 o = StepOptions(u_lower=u_lower, u_upper=u_upper, u_zero_I=u_zero_I, delta_u=delta_u,
                                 linesearch_decay=linesearch_decay, max_linesearch_iter=max_linesearch_iter,
-                                true_dynamics=true_dynamics.native_env())
+                                true_dynamics=true_dynamics.native_env(), c_symmetric=c_symmetric)
             r = be.lqr_step(x_init, C, c, F, f_in, current_x, current_u, o, rollout_problem=rp)
             return r["new_x"], r["new_u"], r["qp_iters"], r["costs"], r["full_du_norm"], r["alphas"]
         from . import util as _util
@@ -358,6 +365,7 @@ def LQRStep(n_state,
     cfg.solve, cfg.no_op_forward, cfg.delta_space = solve, no_op_forward, delta_space
     cfg.current_x, cfg.current_u = current_x, current_u
     cfg.u_lower, cfg.u_upper = u_lower, u_upper
+    cfg.c_symmetric = bool(c_symmetric)
 
     def apply(x_init, C, c, F, f=None):
         out = _LQRStepFn.apply(cfg, x_init, C, c, F, f)

@@ -74,10 +74,11 @@ class _FlagReader:
             self.event.record()
 
     def wait(self):
+        """-> (flag bits: 1 = some problem improved, 2 = some C is not symmetric; max ||du||)"""
         if self.cuda:
             self.event.synchronize()
-            return int(self.host[0][0]) != 0, float(self.host[1][0])
-        return int(self.device_flags[0][0]) != 0, float(self.device_flags[1][0])
+            return int(self.host[0][0]), float(self.host[1][0])
+        return int(self.device_flags[0][0]), float(self.device_flags[1][0])
 
 
 class SlewRateCost(Module):
@@ -261,10 +262,15 @@ class MPC(Module):
         pa = be.plan_step(xi, cost.C, cost.c, F, f, xa, ua, opts, out_x=xb, out_u=ub)
         pb = be.plan_step(xi, cost.C, cost.c, F, f, xb, ub, opts, out_x=xa, out_u=ua,
                           workspace=pa._keep[-1] if hasattr(pa, "_keep") else None)
-        plans, noms = (pa, pb), ((xa, ua), (xb, ub))
+        plans = (pa, pb)
+        # C does not change during the solve: once the first step has reported that it is symmetric (no
+        # MPC_ST_C_ASYMMETRIC in its status, read back with the convergence flags), the remaining steps run with the
+        # promise MPC_OPT_C_SYMMETRIC -- no symmetry test in the kernel, no gated second launch behind it
+        self._c_symmetric = False
+        sym_plans = None
 
         def launch(i):
-            return plans[i % 2]()
+            return (sym_plans if sym_plans is not None else plans)[i % 2]()
 
         best = dict(x=torch.empty_like(xa), u=torch.empty_like(ua),
                     costs=torch.empty(n_batch, dtype=xa.dtype, device=xa.device),
@@ -275,10 +281,20 @@ class MPC(Module):
         while True:
             # best-iterate tracking, :271-285 -- on the device
             be.select_best(i == 0, self.best_cost_eps, r["new_x"], r["new_u"], r["costs"], r["full_du_norm"],
-                           best, flags=reader.device_flags)
+                           best, flags=reader.device_flags, status=r["status"] if i == 0 else None)
             reader.start()
             nxt = launch(i + 1) if i + 1 < self.lqr_iter else None        # overlaps the read-back
-            any_improved, max_du_norm = reader.wait()
+            bits, max_du_norm = reader.wait()
+            any_improved = (bits & 1) != 0
+            if i == 0 and not (bits & 2):
+                self._c_symmetric = True
+                if self.lqr_iter > 2:
+                    import copy
+                    so = copy.copy(opts)
+                    so.c_symmetric = True
+                    ws = pa._keep[-1] if hasattr(pa, "_keep") else None
+                    sym_plans = (be.plan_step(xi, cost.C, cost.c, F, f, xa, ua, so, out_x=xb, out_u=ub, workspace=ws),
+                                 be.plan_step(xi, cost.C, cost.c, F, f, xb, ub, so, out_x=xa, out_u=ua, workspace=ws))
             if self.flag_reducer is not None:          # shards agree on the batch-wide stop test (mpc.shard)
                 any_improved, max_du_norm = self.flag_reducer(any_improved, max_du_norm)
             n_not_improved += 1
@@ -303,6 +319,7 @@ class MPC(Module):
         T = self.T
         best = None
         n_not_improved = 0
+        self._c_symmetric = False
         for i in range(self.lqr_iter):
             u = util.detach_maybe(u)
             x = util.get_traj(T, u, x_init=x_init, dynamics=dx)
@@ -385,7 +402,7 @@ class MPC(Module):
             true_cost=cost, true_dynamics=dynamics, delta_u=self.delta_u,
             linesearch_decay=self.linesearch_decay, max_linesearch_iter=self.max_linesearch_iter,
             delta_space=True, current_x=x, current_u=u, back_eps=self.back_eps,
-            no_op_forward=no_op_forward)
+            no_op_forward=no_op_forward, c_symmetric=no_op_forward and getattr(self, "_c_symmetric", False))
         empty = torch.empty(0, dtype=x_init.dtype, device=x_init.device)
         return step(x_init, C, c, F, f if f is not None else empty)
 

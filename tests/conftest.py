@@ -10,6 +10,9 @@ for p in (PKG, ROOT):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the library reads MPC_DPP16_RING (which staging ring the 12/4 kernel runs on) once, when it is loaded; with this set it
+# follows the environment from launch to launch, so a test can hold both rings to the oracle in one process
+os.environ.setdefault("MPC_DPP16_RING_DYNAMIC", "1")
 
 
 def pytest_configure(config):

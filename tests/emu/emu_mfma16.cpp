@@ -247,6 +247,24 @@ static inline float row_sum(float x)
     }
     return x;
 }
+static inline float row_max(float x)
+{
+    emu::Wave &w = emu::W;
+    for (int step = 0; step < 4; ++step) {
+        const int l = w.cur, gen = w.seq[l]++ & 1;
+        w.fa[gen][l] = x;
+        emu::yield_lane();
+        const int r = l & ~15, j = l & 15;
+        int src;
+        if (step == 0) src = j ^ 1;
+        else if (step == 1) src = j ^ 2;
+        else if (step == 2) src = (j & 8) | (7 - (j & 7));
+        else src = 15 - j;
+        x = fmaxf(x, w.fa[gen][r + src]);
+    }
+    return x;
+}
+static inline void absmax3(float &acc, float a, float b) { acc = fmaxf(acc, fmaxf(fabsf(a), fabsf(b))); }
 // register-resident gains of lqr_dpp16.hip (accumulation registers a[4t..4t+3] there): one array per lane here
 static f32x4 g_rg[64][64];
 static inline void rg_put(int t, f32x4 v) { g_rg[emu::W.cur][t] = v; }

@@ -63,7 +63,7 @@ def _ptr(a):
 
 def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None,
              linesearch_decay=0.2, max_linesearch_iter=10, pnqp_iter=20, force_general=False, dma_late=False,
-             kernel="mfma16", dtype=np.float32, env=None, nominal_on_dynamics=False):
+             kernel="mfma16", dtype=np.float32, env=None, nominal_on_dynamics=False, c_symmetric=False):
     """Same signature as oracle.lqr_oracle.lqr_step.  Returns the kernel's outputs.  The fused
     kernels are float32; kernel="tiny" (lane-per-problem body, n_ctrl = 1) also runs in float64 and
     takes env = (kind, params, dt, u_max): a shipped simulator as the rollout's true dynamics."""
@@ -92,7 +92,7 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
     o.linesearch_decay = float(linesearch_decay)
     o.delta_u = float("nan") if delta_u is None else float(delta_u)
     o.pnqp_iter = int(pnqp_iter)
-    o.flags = N.OPT_NOMINAL_ON_DYNAMICS if nominal_on_dynamics else 0
+    o.flags = (N.OPT_NOMINAL_ON_DYNAMICS if nominal_on_dynamics else 0) | (N.OPT_C_SYMMETRIC if c_symmetric else 0)
     keep = []
     if u_lower is None:
         o.bound_mode = N.BOUND_NONE

@@ -110,11 +110,32 @@ def run_step(p, ns, nc, T, u_lower=None, u_upper=None, u_zero_I=None, delta_u=No
 ONLY = None      # set from --only name1,name2: regenerate just those fixtures
 
 
+def add_asymmetry(C, which, seed, scale=1.0):
+    """C + scale * 2 triu(N, 1) on the problems listed in `which` (N ~ N(0,1)): a cost matrix the reference accepts and
+    uses AS GIVEN -- Q = C + F'VF (mpc/lqr_step.py:68), C tau (:294), 0.5 tau'C tau (:232) -- so the solve differs from
+    the one on the symmetrised matrix (the sweep's gradient C tau is then not the gradient of the cost)."""
+    g = torch.Generator().manual_seed(seed)
+    N = torch.randn(C.shape, generator=g, dtype=torch.float64).to(C.dtype)
+    out = C.clone()
+    for b in which:
+        out[:, b] = C[:, b] + scale * 2.0 * torch.triu(N[:, b], 1)
+    return out
+
+
 def step_case(name, ns, nc, T, B, dtype, seed, with_f=True, bounds=None, mask_seed=None,
-              delta_u=None, decay=0.2, max_ls=10, u_scale=0.3, indef=0.0):
+              delta_u=None, decay=0.2, max_ls=10, u_scale=0.3, indef=0.0, asym=None, asym_scale=1.0, zero_ctrl=None):
     if ONLY is not None and name not in ONLY:
         return
     p = make_problem(ns, nc, T, B, dtype, seed, with_f, u_scale)
+    if asym is not None:
+        p["C"] = add_asymmetry(p["C"], asym, seed + 500, asym_scale)
+    if zero_ctrl is not None:
+        # control `a` of the listed problems enters neither the cost nor the dynamics: Quu is singular at every timestep
+        # and the reference's pinverse (mpc/lqr_step.py:88-94) returns a zero gain for it
+        for b, a in zero_ctrl:
+            p["C"][:, b, ns + a, :] = 0
+            p["C"][:, b, :, ns + a] = 0
+            p["F"][:, b, :, ns + a] = 0
     if indef:
         # a NON-convex stage cost in the states: the Newton step is no longer a descent step for
         # every problem, so the line search of mpc/lqr_step.py:176-252 really backtracks
@@ -481,10 +502,14 @@ def gen_mpc_cases():
 # --------------------------------------------------------------------------
 # KKT backward (LQRStepFn.backward) goldens
 # --------------------------------------------------------------------------
-def grad_case(name, ns, nc, T, B, dtype, seed, beta, with_f=True, lqr_iter=30, scale=1.0):
+def grad_case(name, ns, nc, T, B, dtype, seed, beta, with_f=True, lqr_iter=30, scale=1.0, asym=None):
     """Solve to the fixed point with the reference, then push random (dl_dx, dl_du) through
     LQRStepFn.backward.  Stores the fixed point and all five gradients."""
+    if ONLY is not None and name not in ONLY:
+        return
     p = make_problem(ns, nc, T, B, dtype, seed, with_f)
+    if asym is not None:
+        p["C"] = add_asymmetry(p["C"], asym, seed + 500, 0.3)
     C = (scale * p["C"]).requires_grad_(True)
     c = (scale * p["c"]).requires_grad_(True)
     F = p["F"].clone().requires_grad_(True)
@@ -579,6 +604,7 @@ if __name__ == "__main__":
         step_case = lambda *a, **k: None
     if only and "mpc" not in only:
         gen_mpc_cases = lambda: None
+    _grad_case = grad_case
     if only and "grad" not in only:
         grad_case = jacobian_case = lambda *a, **k: None
     if only and "misc" not in only:
@@ -612,7 +638,23 @@ if __name__ == "__main__":
     step_case("step_linesearch_f64", 4, 2, 8, 6, f64, 24, bounds=0.3, u_scale=2.0, decay=0.5, max_ls=4)
     step_case("step_backtrack_a_f64", 4, 2, 8, 6, f64, 45, bounds=0.3, u_scale=2.0, decay=0.5, max_ls=4, indef=6.0)
     step_case("step_backtrack_b_f64", 4, 2, 8, 6, f64, 40, bounds=0.3, u_scale=2.0, decay=0.5, max_ls=4, indef=6.0)
+    # ---- a C that is not symmetric (round 3): some problems of the batch only, every kernel family
+    step_case("step_asym_ns_f32", 12, 4, 12, 6, f32, 61, bounds=None, asym=(1, 4, 5))
+    step_case("step_asym_ns_bounded_f32", 12, 4, 12, 6, f32, 62, bounds=1.0, asym=(0, 3))
+    step_case("step_asym_ns_masked_f32", 12, 4, 10, 5, f32, 63, bounds=None, mask_seed=7, asym=(2,))
+    step_case("step_asym_tiny_f32", 12, 4, 8, 4, f32, 64, bounds=None, asym=(0, 2), asym_scale=1e-7)   # rounding-level: symmetric for all purposes
+    step_case("step_asym_cfg5_f32", 32, 8, 6, 3, f32, 65, bounds=None, asym=(1,))
+    step_case("step_asym_small_f64", 4, 2, 8, 3, f64, 66, bounds=None, asym=(0, 1, 2))
+    step_case("step_asym_nc1_f32", 5, 1, 10, 4, f32, 67, bounds=0.5, decay=0.5, max_ls=2, asym=(1, 3))
+    step_case("step_asym_odd_f32", 7, 3, 9, 3, f32, 68, bounds=None, asym=(2,))
+    # ---- rank-deficient Quu: a control that enters neither cost nor dynamics (pinverse, mpc/lqr_step.py:88-94)
+    step_case("step_singular_ns_f32", 12, 4, 12, 5, f32, 71, bounds=None, zero_ctrl=((1, 2), (3, 0)))
+    step_case("step_singular_cfg5_f64", 32, 8, 6, 3, f64, 72, bounds=None, zero_ctrl=((0, 5),))     # (float32: the reference's own 8x8 pinverse is noise there)
+    step_case("step_singular_small_f64", 4, 2, 8, 3, f64, 73, bounds=None, zero_ctrl=((1, 1),))
+    step_case("step_singular_odd_f32", 7, 3, 9, 3, f32, 74, bounds=None, zero_ctrl=((2, 0),))
     if ONLY is not None:
+        _grad_case("grad_asym_ns_f32", 12, 4, 8, 4, f32, 36, None, asym=(1, 2))
+        _grad_case("grad_asym_small_f64", 4, 2, 6, 3, f64, 37, 0.4, asym=(0, 2))
         sys.exit(0)
     # ---- full solves --------------------------------------------------------
     if not only or "env" in only:
@@ -636,6 +678,8 @@ if __name__ == "__main__":
     grad_case("grad_nc1_constrained_f64", 3, 1, 6, 4, f64, 33, 0.3)
     grad_case("grad_ns_constrained_f32", 12, 4, 10, 3, f32, 34, 0.5)
     grad_case("grad_ns_unconstrained_f64", 12, 4, 10, 2, f64, 35, None)
+    grad_case("grad_asym_ns_f32", 12, 4, 8, 4, f32, 36, None, asym=(1, 2))
+    grad_case("grad_asym_small_f64", 4, 2, 6, 3, f64, 37, 0.4, asym=(0, 2))
     jacobian_case("jac_unconstrained", 100.0)
     jacobian_case("jac_constrained", 0.5)
     # ---- pnqp / traj --------------------------------------------------------

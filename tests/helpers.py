@@ -38,3 +38,30 @@ def scrambled_du_norm(du):
     .view(n_batch,-1).norm(2,1) (mpc/lqr_step.py:243-245) -- a reshape that mixes problems."""
     T, B, nc = du.shape
     return np.sqrt((np.ascontiguousarray(du.transpose(0, 2, 1)).reshape(B, -1) ** 2).sum(1))
+
+
+def asymmetric_problems(z):
+    """[B] bool: the problems of a fixture whose C is not symmetric by the kernels' own test
+    (max |C - C'| > 1e-5 max |C| over the horizon: MPC_ST_C_ASYMMETRIC, include/mpc_lqr.h)."""
+    C = np.asarray(z["C"], np.float64)
+    d = np.abs(C - C.transpose(0, 1, 3, 2)).max(axis=(0, 2, 3))
+    return d > 1e-5 * np.abs(C).max(axis=(0, 2, 3))
+
+
+_PER_PROBLEM = ("new_x", "new_u", "costs", "old_costs", "full_du_norm", "alpha_du_norm", "alphas", "K", "k", "status",
+                "qp_iters", "n_qp_pp")
+
+
+def keep_problems(d, keep):
+    """The per-problem outputs of a result dict / golden fixture restricted to the problems in `keep` [B] bool
+    (axis 1 of the [T, B, ...] trajectories and gains, axis 0 of the [B] scalars).  Everything else passes through."""
+    out = {}
+    B = len(keep)
+    for k, v in d.items():
+        if isinstance(v, np.ndarray) and any(k == n or k.startswith(n + "_") for n in _PER_PROBLEM):
+            if v.ndim == 1 and v.shape[0] == B:
+                v = v[keep]
+            elif v.ndim > 1 and v.shape[1] == B:
+                v = v[:, keep]
+        out[k] = v
+    return out

@@ -71,6 +71,7 @@ class OracleBackend:
 
     def plan_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, impl=0, out_x=None, out_u=None, workspace=None):
         def run():
+            self.calls.append("step:c_symmetric" if getattr(opts, "c_symmetric", False) else "step:c_unknown")
             r = self.lqr_step(x_init, C, c, F, f, cur_x, cur_u, opts)
             if out_x is not None:
                 out_x.copy_(r["new_x"]); out_u.copy_(r["new_u"])
@@ -127,14 +128,15 @@ class OracleBackend:
             return out_F, out_f
         return F, f
 
-    def select_best(self, first, eps, x, u, costs, du_norm, best, flags=None):
+    def select_best(self, first, eps, x, u, costs, du_norm, best, flags=None, status=None):
         self.calls.append("select_best")
         take = torch.ones_like(costs, dtype=torch.bool) if first else costs <= best["costs"] + eps
         best["x"][:, take] = x[:, take]
         best["u"][:, take] = u[:, take]
         best["costs"][take] = costs[take]
         best["full_du_norm"][take] = du_norm[take]
-        any_improved = torch.tensor([int((not first) and bool(take.any()))], dtype=torch.int32)
+        asym = status is not None and bool((status & 8).any())        # MPC_ST_C_ASYMMETRIC
+        any_improved = torch.tensor([int((not first) and bool(take.any())) | (2 if asym else 0)], dtype=torch.int32)
         if flags is not None:
             flags[0].copy_(any_improved); flags[1].copy_(du_norm.max().reshape(1))
             return flags

@@ -38,3 +38,32 @@ def test_byte_and_flop_formulas():
     assert bench.kkt_algorithmic_bytes_per_problem(12, 4, 50) == 195264
     assert abs(bench.algorithmic_flops_per_problem_step(12, 4) - 17290) < 30
     assert abs(bench.algorithmic_flops_per_problem_step(32, 8) - 255862) < 400
+
+
+def test_parity_object_accepts_the_oracles_own_numbers_and_rejects_a_wrong_trajectory():
+    """bench.py's in-run self-certification: `parity.ok` for results within rtol 1e-3 /
+    atol 1e-4 of the oracle on the first 64 problems of the timed batch, not ok (and the run exits non-zero) otherwise."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(3)
+    T, B, ns, nc = 12, 70, 12, 4
+    n = ns + nc
+    A = rng.standard_normal((T, B, n, n)).astype(np.float32)
+    C = np.einsum("tbji,tbjk->tbik", A, A)
+    c = rng.standard_normal((T, B, n)).astype(np.float32)
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((T - 1, B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((T - 1, B, ns, nc)) / np.sqrt(ns)), 3).astype(np.float32)
+    f = (0.1 * rng.standard_normal((T - 1, B, ns))).astype(np.float32)
+    x0 = rng.standard_normal((B, ns)).astype(np.float32)
+    u = np.zeros((T, B, nc), np.float32)
+    x, _ = O.traj_cost(x0.astype(np.float64), u.astype(np.float64), F.astype(np.float64), f.astype(np.float64))
+    p = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in dict(x_init=x0, C=C, c=c, F=F, f=f, cur_x=x.astype(np.float32), cur_u=u).items()}
+    o = O.lqr_step(*(p[k].numpy().astype(np.float64) for k in ("x_init", "C", "c", "F", "f", "cur_x", "cur_u")), None, None, lockstep=False)
+    r = {k: torch.from_numpy(o[k].astype(np.float32)) for k in ("new_x", "new_u", "costs", "alphas")}
+    good = bench.parity_check(p, r, False)
+    assert good["ok"] and good["problems"] == 64 and good["max_err_over_tol_u"] < 0.1
+    r["new_u"][3, 5, 1] += 0.01
+    bad = bench.parity_check(p, r, False)
+    assert not bad["ok"] and bad["max_err_over_tol_u"] > 1.0

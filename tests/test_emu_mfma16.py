@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, golden
-from helpers import step_kwargs
+from helpers import asymmetric_problems, keep_problems, step_kwargs
 
 STEP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "step_*.npz")))
 STEP_CASES = [c for c in STEP_CASES if "cfg5" not in c]      # n = 40 is the generic kernel's
@@ -22,6 +22,19 @@ STEP_CASES = [c for c in STEP_CASES if "cfg5" not in c]      # n = 40 is the gen
 def _f64(kw):
     return {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == "f" else v)
             for k, v in kw.items()}
+
+
+def _split_asymmetric(r, o, z):
+    """A fused kernel run directly (as the emulator runs it, and as `impl=2..5` forces it) reads C through its symmetry;
+    the reference does not (mpc/lqr_step.py:68, 294).  What the kernel owes then is the flag: MPC_ST_C_ASYMMETRIC (8) on
+    exactly the problems whose C is not symmetric -- mpc_lqr_step (impl 0) re-solves those on the generic kernel,
+    tests/test_gpu_parity.py -- and the reference's numbers on all the others, which is what is compared below."""
+    asym = asymmetric_problems(z)
+    assert ((r["status"] & 8) != 0).tolist() == asym.tolist(), (r["status"], asym)
+    if not asym.any():
+        return r, o, z
+    keep = ~asym
+    return keep_problems(r, keep), keep_problems(o, keep), keep_problems(z, keep)
 
 
 @pytest.fixture(scope="module")
@@ -42,6 +55,8 @@ def test_emulated_kernel_matches_oracle_and_reference(emu, name, dma_late):
     o = O.lqr_step(lockstep=False, return_gains=True, **_f64(kw))
     r = emu.lqr_step(dma_late=dma_late, **kw)
     assert (r["status"] & 2 == 0).all()
+    had_asym = asymmetric_problems(z).any()
+    r, o, z = _split_asymmetric(r, o, z)
     # box-constrained float32: pnqp stops at |dx| < 1e-4 (mpc/pnqp.py:56), so two correct float32
     # evaluations (and the reference's own float32 vs float64 runs) differ by a few 1e-4 in k
     atol = 1e-3 if ("u_lower" in z and z["C"].dtype == np.float32) else 1e-4
@@ -59,7 +74,7 @@ def test_emulated_kernel_matches_oracle_and_reference(emu, name, dma_late):
     np.testing.assert_allclose(r["new_x"], z["new_x" + sfx], rtol=1e-3, atol=atol)
     np.testing.assert_allclose(r["new_u"], z["new_u" + sfx], rtol=1e-3, atol=atol)
     np.testing.assert_allclose(r["costs"], z["costs" + sfx], rtol=1e-4)
-    if "u_lower" in z:
+    if "u_lower" in z and not had_asym:        # (the oracle's count is one number for the whole batch)
         # trip counts are not a parity quantity (float32 vs float64 stop at |dx| < 1e-4 differently): same ballpark
         assert abs(int(r["qp_iters"].max()) - int(o["n_qp_iter"])) <= 0.1 * int(o["n_qp_iter"]) + 2
 
@@ -134,6 +149,9 @@ def test_emulated_dpp16_matches_oracle_and_reference(emu, name, dma_late):
     r = emu.lqr_step(kernel="dpp16", dma_late=dma_late, **kw)
     assert (r["status"] & 2 == 0).all()
     assert (r["status"] & 4 == 0).all()      # nominal = rollout of its controls: priced without re-reading C
+    if "singular" in name:
+        assert (r["status"] & 16 != 0).sum() == 2          # the two problems with a dead control (make_golden.py)
+    r, o, z = _split_asymmetric(r, o, z)
     # box-constrained float32: pnqp stops at |dx| < 1e-4 (mpc/pnqp.py:56), so two correct float32
     # evaluations (and the reference's own float32 vs float64 runs) differ by a few 1e-4 in k
     atol = 1e-3 if ("u_lower" in z and z["C"].dtype == np.float32) else 1e-4
@@ -147,6 +165,23 @@ def test_emulated_dpp16_matches_oracle_and_reference(emu, name, dma_late):
     np.testing.assert_allclose(r["new_x"], z["new_x" + sfx], rtol=1e-3, atol=atol)
     np.testing.assert_allclose(r["new_u"], z["new_u" + sfx], rtol=1e-3, atol=atol)
     np.testing.assert_allclose(r["costs"], z["costs" + sfx], rtol=1e-4)
+
+
+@pytest.mark.parametrize("kernel", ["dpp16", "dpp16_ring2", "mfma16", "mfma40"])
+def test_symmetric_promise_changes_nothing_but_the_test(emu, kernel):
+    """MPC_OPT_C_SYMMETRIC: no symmetry test in the sweep (and, in the 12/4 kernel, the plain LDS layout of C instead of
+    the row-permuted one the column reads want) -- the same numbers on a symmetric C, and no flag on a C that is not."""
+    name = "step_asym_cfg5_f32" if kernel == "mfma40" else "step_asym_ns_bounded_f32"
+    z = golden(name)
+    kw = step_kwargs(z)
+    asym = asymmetric_problems(z)
+    a = emu.lqr_step(kernel=kernel, dma_late=True, **kw)
+    b = emu.lqr_step(kernel=kernel, dma_late=True, c_symmetric=True, **kw)
+    assert ((a["status"] & 8) != 0).tolist() == asym.tolist() and (b["status"] & 8 == 0).all()
+    for k in ("new_x", "new_u", "costs", "alphas", "K"):
+        np.testing.assert_array_equal(keep_problems(a, ~asym)[k], keep_problems(b, ~asym)[k], err_msg=k)
+        # (the promise is the caller's: broken, the kernel computes what it computes for the symmetric reading of C)
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
 def _ns_problem(rng, T, B, indef=0.0, with_f=True):
@@ -404,6 +439,30 @@ def test_emulated_mfma40_sweep_on_the_reference_fixture(emu):
     r = emu.lqr_step(kernel="mfma40_sweep", **{k: v for k, v in kw.items() if k in ("x_init", "C", "c", "F", "f", "cur_x", "cur_u")})
     np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(r["k"], o["k"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["step_asym_cfg5_f32", "step_singular_cfg5_f64"])
+def test_emulated_mfma40_flags_asymmetric_C_and_drops_dead_controls(emu, name):
+    """Round 3 fixtures on the config-5 kernel: a C that is not symmetric on one problem of the batch (the kernel owes
+    MPC_ST_C_ASYMMETRIC there and the reference's numbers on the others), and a control that enters neither cost nor
+    dynamics (zero pivot of Quu: gain 0 like the reference's pinverse, MPC_ST_QUU_SINGULAR as information)."""
+    from oracle import lqr_oracle as O
+    z = golden(name)
+    kw = step_kwargs(z)
+    o = O.lqr_step(lockstep=False, return_gains=True, **_f64(kw))
+    r = emu.lqr_step(kernel="mfma40", **{k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 else v)
+                                         for k, v in kw.items()})
+    assert (r["status"] & 2 == 0).all()
+    if "singular" in name:
+        assert ((r["status"] & 16) != 0).tolist() == [True, False, False]
+        # the dead control (problem 0, control 5) stays where the nominal has it
+        np.testing.assert_array_equal(r["new_u"][:, 0, 5], z["cur_u"][:, 0, 5].astype(np.float32))
+    r, o, z = _split_asymmetric(r, o, z)
+    np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=2e-3, atol=5e-4)
+    np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=2e-3, atol=5e-4)
+    np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4)
+    np.testing.assert_allclose(r["new_u"], z["new_u_pp" if name.endswith("f64") else "new_u_ref64"], rtol=2e-3, atol=5e-4)
 
 
 @pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])

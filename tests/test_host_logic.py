@@ -43,7 +43,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert set(_native.EXPORTS) == declared
-    assert L.mpc_lqr_abi_version() == _native.ABI_VERSION == 4
+    assert L.mpc_lqr_abi_version() == _native.ABI_VERSION == 5
     assert b"gfx950" in L.mpc_lqr_build_info()
 
 
@@ -384,6 +384,45 @@ def test_mpc_forward_matches_reference_solves(name, oracle_backend):
     if "delta_u" in name:
         assert float(u.abs().max()) <= 0.1 + 1e-12          # tests/test_mpc.py:239-240
     assert "select_best" in oracle_backend.calls
+
+
+def test_mpc_promises_a_symmetric_C_only_after_the_first_step_has_checked_it(oracle_backend):
+    """MPC_OPT_C_SYMMETRIC (include/mpc_lqr.h): the first step of a solve runs the kernels' symmetry test on C; its verdict
+    comes back with the convergence flags (bit 1 of mpc_select_best's flag word), and only then -- C does not change
+    during a solve -- do the remaining steps, and the KKT backward attached at the end, carry the promise.  A step
+    whose status reports MPC_ST_C_ASYMMETRIC keeps every later step on the tested path."""
+    from mpc import mpc
+    from mpc.mpc import LinDx, QuadCost
+    g = torch.Generator().manual_seed(5)
+    T, B, ns, nc = 5, 3, 3, 2
+    A = torch.randn(T, B, ns + nc, ns + nc, generator=g, dtype=torch.float64)
+    C = A.transpose(2, 3).matmul(A)
+    c = torch.randn(T, B, ns + nc, generator=g, dtype=torch.float64)
+    F = torch.cat((torch.eye(ns, dtype=torch.float64).expand(T - 1, B, ns, ns), 0.3 * torch.randn(T - 1, B, ns, nc, generator=g, dtype=torch.float64)), 3)
+    x0 = torch.randn(B, ns, generator=g, dtype=torch.float64)
+    ctrl = mpc.MPC(ns, nc, T, u_lower=-0.2, u_upper=0.2, lqr_iter=6, verbose=-1, exit_unconverged=False, eps=0.0)
+    Cg = C.clone().requires_grad_(True)
+    x, u, _ = ctrl(x0, QuadCost(Cg, c), LinDx(F, None))
+    steps = [s for s in oracle_backend.calls if s.startswith("step:")]
+    assert steps[:2] == ["step:c_unknown"] * 2 and len(steps) > 2 and set(steps[2:]) == {"step:c_symmetric"}
+    assert ctrl._c_symmetric
+    seen = {}
+    real = oracle_backend.kkt_backward
+    oracle_backend.kkt_backward = lambda *a, **k: (seen.setdefault("opts", a[8]), real(*a, **k))[1]
+    u.sum().backward()
+    assert seen["opts"].c_symmetric                     # the nested solve of the backward inherits the verdict
+    # the same solve with the stand-in reporting an asymmetric C on its first step: no promise, ever
+    oracle_backend.calls.clear()
+    step = oracle_backend.lqr_step
+
+    def flagged(*a, **k):
+        r = step(*a, **k)
+        r["status"] = r["status"] | 8
+        return r
+    oracle_backend.lqr_step = flagged
+    ctrl(x0, QuadCost(C, c), LinDx(F, None))
+    steps = [s for s in oracle_backend.calls if s.startswith("step:")]
+    assert len(steps) > 2 and set(steps) == {"step:c_unknown"} and not ctrl._c_symmetric
 
 
 def test_mpc_forward_never_writes_the_callers_u_init(oracle_backend):
