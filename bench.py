@@ -212,7 +212,7 @@ def hbm_roofline(abytes, kern_ms, **more):
 def extra_rows(be, dev, steps):
     """SURVEY.md 8(d) secondary rows, same run, same event method.  Every row: what was launched, ms per launch
     by HIP events (`ms`), wall ms per launch (`wall_ms`), and a roofline where the bytes are defined."""
-    from mpc import mpc
+    from mpc import mpc, _native
     from mpc._native import StepOptions
     from mpc.mpc import LinDx, QuadCost
     rows = {}
@@ -229,8 +229,13 @@ def extra_rows(be, dev, steps):
         gx, gu = torch.randn_like(r["new_x"]), torch.randn_like(r["new_u"])
         nx, nu = r["new_x"].clone(), r["new_u"].clone()
         wall, ms, g = timed(lambda: be.kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, opts), k, 5)
+        import ctypes
+        pf, _keep = be._problem(p["x_init"], p["C"], p["c"], p["F"], p["f"], nx, nu)
+        of, _keep2 = opts.to_struct(T, B, nc, p["C"])
+        fused = bool(_native.load().mpc_lqr_kkt_fused_supported(ctypes.byref(pf), ctypes.byref(of)))
         return dict(ms=ms, wall_ms=wall, finite=bool(torch.isfinite(g["dC"]).all().item()),
-                    launches="mpc_lqr_kkt_prepare + mpc_lqr_step (nested solve) + mpc_lqr_kkt_grads",
+                    launches=("mpc_lqr_kkt_fused: ONE launch (sweep + lambda, then rollout + dlambda = V dx + v + all gradients)" if fused
+                              else "mpc_lqr_kkt_prepare + mpc_lqr_step (nested solve) + mpc_lqr_kkt_grads"),
                     roofline=hbm_roofline(kkt_algorithmic_bytes_per_problem(ns, nc, T) * B, ms))
 
     # ---- the headline shape: box-constrained step, KKT backward, 5-iteration MPC.forward ----------------

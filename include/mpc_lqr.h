@@ -196,6 +196,21 @@ int mpc_lqr_kkt_prepare(int dtype, int B, int T, int ns, int nc,
                         const void *dl_dx, const void *dl_du, const void *u_star,
                         const mpc_lqr_options *o, void *negr, uint8_t *mask, void *stream);
 
+/* (4c) ALL of LQRStepFn.backward (mpc/lqr_step.py:312-407) in ONE launch, where a kernel for it exists: fp32, n_state = 12,
+ *     n_ctrl = 4, T <= 64, 16-byte aligned blocks, and the caller's promise MPC_OPT_C_SYMMETRIC in o->flags (without it the
+ *     three calls above are the way: their step tests C and re-solves what is not symmetric).
+ *     p = (C, c, F, f) of the forward with cur_x / cur_u = the solution (x*, u*); p->f only decides whether df is written.
+ *     o = the forward's bounds: controls within 1e-8 of u_lower / u_upper are pinned in the KKT solve (:316-326); o may be
+ *     NULL (no bounds).  dl_dx [T,B,ns], dl_du [T,B,nc].  Outputs as (4); dx_out / du_out (the KKT solve's own dx, du) and
+ *     status [B] may be NULL.  workspace: mpc_lqr_kkt_fused_workspace_bytes(p), 16-byte aligned.
+ *     mpc_lqr_kkt_fused_supported: 1 if this (problem, options) pair has the kernel -- sizes, dtype and flags only; pointer
+ *     alignment is checked at launch (MPC_E_DIMS). */
+int mpc_lqr_kkt_fused_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o);
+int64_t mpc_lqr_kkt_fused_workspace_bytes(const mpc_lqr_problem *p);
+int mpc_lqr_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const void *dl_dx, const void *dl_du,
+                      void *dC, void *dc, void *dF, void *df, void *dx_init, void *dx_out, void *du_out, int32_t *status,
+                      void *workspace, int64_t workspace_bytes, void *stream);
+
 /* (5) Standalone batched pnqp, mpc/pnqp.py:5-82.  H [B,n,n], q/lo/hi/x0/x [B,n];
  *     x0 NULL = cold start (:14-19).  If_out [B,n] uint8 (1 = free), iters [B],
  *     Hfree [B,n,n] receives H_ (free-set Hessian + 1e-11 I, :44-48) or NULL. */

@@ -224,7 +224,7 @@ int mpc_lqr_abi_version(void) { return MPC_LQR_ABI_VERSION; }
 const char *mpc_lqr_build_info(void)
 {
     return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32>, lqr_step_dpp16<f32>, "
-           "lqr_step_tiny<f32,f64>, lqr_step_mfma40<f32>, nn_rollout<f32>, nn_linearize<f32>, env_linearize, kkt_grads, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
+           "lqr_step_tiny<f32,f64>, lqr_step_mfma40<f32>, nn_rollout<f32>, nn_linearize<f32>, env_linearize, kkt_grads, kkt_fused<f32>, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
 }
 
 const char *mpc_lqr_last_error(void) { return g_last_error.c_str(); }
@@ -327,6 +327,50 @@ int mpc_lqr_kkt_grads(const mpc_lqr_problem *p, const void *dx, const void *du, 
     return launch_kkt_grads<double>(sp, (const double *)dx, (const double *)du, (const double *)dl_dx,
                                     (const double *)dl_du, (double *)dC, (double *)dc, (double *)dF, (double *)df,
                                     (double *)dx_init, st);
+}
+
+int mpc_lqr_kkt_fused_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o)
+{
+    if (!p || check_problem(p, false, false) != MPC_OK || check_options(p, o) != MPC_OK) return 0;
+    if (p->dtype != MPC_F32 || p->ns != 12 || p->nc != 4 || p->T > 64) return 0;
+    if (!o || !(o->flags & MPC_OPT_C_SYMMETRIC)) return 0;
+    if (o->zero_mask || o->true_dynamics || (o->delta_u == o->delta_u && o->delta_u >= 0)) return 0;
+    return 1;
+}
+
+int64_t mpc_lqr_kkt_fused_workspace_bytes(const mpc_lqr_problem *p)
+{
+    return p ? kkt_fused_dpp16_workspace_bytes(p->T, p->B) : 0;
+}
+
+int mpc_lqr_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const void *dl_dx, const void *dl_du,
+                      void *dC, void *dc, void *dF, void *df, void *dx_init, void *dx_out, void *du_out, int32_t *status,
+                      void *workspace, int64_t workspace_bytes, void *stream)
+{
+    int rc = check_problem(p, true, true);
+    if (rc) return rc;
+    if ((rc = check_options(p, o))) return rc;
+    if (!mpc_lqr_kkt_fused_supported(p, o))
+        return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: needs fp32, n_state = 12, n_ctrl = 4, T <= 64 and MPC_OPT_C_SYMMETRIC "
+                                "(otherwise: mpc_lqr_kkt_prepare + mpc_lqr_step + mpc_lqr_kkt_grads)");
+    if (p->B == 0) return MPC_OK;
+    if (!dl_dx || !dl_du || !dC || !dc || !dx_init) return fail(MPC_E_NULL, "kkt_fused: NULL argument");
+    if (p->T > 1 && !dF) return fail(MPC_E_NULL, "kkt_fused: dF is NULL");
+    if ((df != nullptr) != (p->f != nullptr && p->T > 1)) return fail(MPC_E_NULL, "kkt_fused: df goes with f");
+    if ((dx_out == nullptr) != (du_out == nullptr)) return fail(MPC_E_NULL, "kkt_fused: pass both dx_out and du_out, or neither");
+    if (!workspace || workspace_bytes < kkt_fused_dpp16_workspace_bytes(p->T, p->B))
+        return fail(MPC_E_ARG, "workspace too small (see mpc_lqr_kkt_fused_workspace_bytes)");
+    mpc_lqr_outputs out;
+    memset(&out, 0, sizeof(out));
+    out.status = status;
+    StepParams<float> sp = make_params<float>(p, o, &out);
+    if (!kkt_fused_dpp16_supported(sp, (const float *)dl_dx, (const float *)dl_du, (const float *)dC, (const float *)dF,
+                                   (const float *)workspace))
+        return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: blocks must be 16-byte aligned");
+    // the nested solve is a plain LQRStep(...) in the reference (:328-338): linesearch_decay 0.2, max_linesearch_iter 10
+    return launch_kkt_fused_dpp16(sp, (const float *)dl_dx, (const float *)dl_du, (float *)dC, (float *)dc, (float *)dF,
+                                  (float *)df, (float *)dx_init, (float *)dx_out, (float *)du_out, (float *)workspace, 0.2f, 10,
+                                  (hipStream_t)stream);
 }
 
 int mpc_env_traj_cost(const mpc_lqr_problem *p, const mpc_env_dynamics *env, void *x, void *cost, void *stream)

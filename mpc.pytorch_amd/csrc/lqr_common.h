@@ -47,6 +47,14 @@ bool kkt_dpp16_supported(const StepParams<float> &p, const float *dx, const floa
 int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,
                      float *dc, float *dF, float *df, float *dx_init, hipStream_t st);
 
+// the whole KKT backward in one launch, n_state = 12, n_ctrl = 4, T <= 64, f32, symmetric C (lqr_dpp16.hip)
+bool kkt_fused_dpp16_supported(const StepParams<float> &p, const float *dl_dx, const float *dl_du, const float *dC,
+                               const float *dF, const float *ws);
+int64_t kkt_fused_dpp16_workspace_bytes(int T, int B);
+int launch_kkt_fused_dpp16(const StepParams<float> &p, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
+                           float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
+                           hipStream_t st);
+
 // one lane per problem, n_ctrl = 1, n_state <= 6, f32 / f64 (lqr_tiny.hip)
 bool tiny_supported(int ns, int nc);
 template <typename real> int launch_step_tiny(const StepParams<real> &p, hipStream_t st);

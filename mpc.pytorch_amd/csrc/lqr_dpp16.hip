@@ -369,6 +369,10 @@ MPC_DEV void dma16_once(const void *g, unsigned off)
     __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, MPC_KKT_LD_AUX);
 }
 MPC_DEV void store_f32_out(float *g, float v) { *g = v; }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+MPC_DEV void store_f32x2_out(float *g, float a, float b) { *(f32x2 *)g = f32x2{a, b}; }        // 8-byte aligned
+// the value of the neighbouring lane j ^ 1 (quad_perm [1,0,3,2])
+MPC_DEV float swap1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true)); }
 MPC_DEV void dma16_if(bool active, const void *g, unsigned off)
 {
     if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, 0);
@@ -427,6 +431,17 @@ __global__ void __launch_bounds__(64, 1) lqr_step_dpp16_kernel(StepParams<float>
     dpp16::step_wave<MODE>(p);
 }
 
+#if MPC_DPP16_NSTAGE == 4
+// the whole of LQRStepFn.backward in one launch (lqr_dpp16_body.h: kkt_fused_wave); MASKED = controls on a bound are pinned
+static_assert(dpp16::KF_P2_SLOTS * dpp16::KF_P2_STAGE <= MPC_DPP16_LDS, "the fused KKT kernel's second ring does not fit");
+template <bool MASKED>
+__global__ void __launch_bounds__(64, 1) lqr_kkt_fused_dpp16_kernel(StepParams<float> p, dpp16::KktFusedArgs k)
+{
+    dpp16::kkt_fused_wave<MASKED>(p, k);
+}
+
+#endif
+
 #ifdef MPC_DPP16_WITH_KKT
 static_assert(MPC_KKT16_NSTAGE * 8192 <= MPC_DPP16_LDS, "the KKT kernel's ring does not fit this compilation's staging array");
 __global__ void __launch_bounds__(64, 1) lqr_kkt_dpp16_kernel(StepParams<float> p, dpp16::KktArgs k)
@@ -458,6 +473,43 @@ int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *d
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_last_error((std::string("lqr_kkt_dpp16_kernel: ") + hipGetErrorString(e)).c_str());
+        return MPC_E_LAUNCH;
+    }
+    return MPC_OK;
+}
+
+#endif
+
+#if MPC_DPP16_NSTAGE == 4
+// (built in the compilation with the deep staging array: four sweep stages, six rollout stages, see kkt_fused_wave)
+bool kkt_fused_dpp16_supported(const StepParams<float> &p, const float *dl_dx, const float *dl_du, const float *dC,
+                               const float *dF, const float *ws)
+{
+    auto al = [](const void *q, long st, long sb) { return ((uintptr_t)q % 16 == 0) && (st % 4 == 0) && (sb % 4 == 0); };
+    if (!(p.ns == 12 && p.nc == 4 && p.T >= 1 && p.T <= dpp16::RG_STEPS)) return false;
+    if (!al(p.C, p.C_st, p.C_sb) || !al(p.c, p.c_st, p.c_sb)) return false;
+    if (p.T > 1 && !al(p.F, p.F_st, p.F_sb)) return false;
+    if (p.bound_mode == MPC_BOUND_TENSOR && (!al(p.lo, 0, 0) || !al(p.hi, 0, 0))) return false;
+    if (p.zero_mask || p.has_delta) return false;
+    return al(p.cur_x, 0, 0) && al(p.cur_u, 0, 0) && al(dl_dx, 0, 0) && al(dl_du, 0, 0) && al(dC, 0, 0) && al(ws, 0, 0) &&
+           (p.T == 1 || al(dF, 0, 0));
+}
+
+int64_t kkt_fused_dpp16_workspace_bytes(int T, int B) { return (int64_t)T * B * (dpp16::KF_VBLK + 24) * 4 + 64; }
+
+int launch_kkt_fused_dpp16(const StepParams<float> &p, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
+                           float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
+                           hipStream_t st)
+{
+    dpp16::KktFusedArgs k;
+    k.dl_dx = dl_dx; k.dl_du = dl_du; k.dC = dC; k.dc = dc; k.dF = dF; k.df = df; k.dx_init = dx_init;
+    k.dx_out = dx_out; k.du_out = du_out; k.vws = ws; k.decay = decay; k.max_ls = max_ls;
+    const dim3 grid((p.B + 3) / 4), block(64);
+    if (p.bound_mode != MPC_BOUND_NONE) hipLaunchKernelGGL((lqr_kkt_fused_dpp16_kernel<true>), grid, block, 0, st, p, k);
+    else hipLaunchKernelGGL((lqr_kkt_fused_dpp16_kernel<false>), grid, block, 0, st, p, k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error((std::string("lqr_kkt_fused_dpp16_kernel: ") + hipGetErrorString(e)).c_str());
         return MPC_E_LAUNCH;
     }
     return MPC_OK;

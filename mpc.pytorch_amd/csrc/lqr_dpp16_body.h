@@ -1571,5 +1571,454 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
     if (L.live && L.j < 12) k.dx_init[(long)L.pb * 12 + L.j] = -dlam;
 }
 
+
+// ---------------------------------------------------------------------------
+// The WHOLE KKT backward in one launch (round 3): LQRStepFn.backward, mpc/lqr_step.py:312-407.
+//
+// The reference (and the three-launch path: mpc_lqr_kkt_prepare, mpc_lqr_step, mpc_lqr_kkt_grads) solves the KKT
+// system as one more LQR step on (C, -r, F) from the zero nominal with the active controls pinned (:328-340) and then
+// walks the horizon backwards once more for the two costates (:355-385).  Streamed that way C and F are read three
+// times.  Two facts remove the third walk and the kernels in between:
+//   * lambda_t = C_x tau*_t + c_x + F_x' lambda_{t+1} (:355-369) involves nothing the nested solve produces: it rides
+//     along with the Riccati sweep, which has C_t and F_t staged anyway;
+//   * dlambda_t (:371-385) is the costate of the nested LQR problem along ITS OWN optimal trajectory, and for a
+//     trajectory that follows the sweep's policy the costate is the gradient of the cost-to-go:
+//         dlambda_t = V_t dx_t + v_t
+//     (substitute dlambda_{t+1} = V_{t+1} F dtau + v_{t+1} into the recursion: [C + F'V_{t+1}F]_x dtau + q_x, and with
+//     du = K dx + alpha k, Qux + Quu K = 0 on the free controls and K = 0 on the pinned ones that is
+//     V_t dx_t + v_t - (1 - alpha) Qxu k_t.  alpha < 1 -- a full step that does not decrease the nested cost, i.e. a C
+//     that is not positive semi-definite along the sweep -- therefore leaves dlambda_t = V_t dx_t + v_t + (1 - alpha) g_t
+//     with g_t = F_x' g_{t+1} - Qxu k_t, a third 12-vector recursion of the sweep that does not depend on alpha).
+// Pass 1 (t = T-1 .. 0): the sweep with c_back = -r (the nominal is zero), gains parked in the register file like mode
+//     0 of the step kernel, the pinned set taken straight from u* and the bounds (:316-326, no mask array), lambda_t
+//     and g_t beside it; V_t (packed upper triangle, 78 floats), v_t, lambda_t and g_t go to the workspace: 384 + 96 B
+//     per problem-step against the 1,792 B of reading C_t and F_t again.
+// Pass 2 (t = 0 .. T-1): the rollout dtau_t, dx_{t+1} = F dtau, dlambda_{t+1} = V_{t+1} dx_{t+1} + v_{t+1}, and with
+//     them every gradient of the timestep: dC_t, dc_t, dF_t, df_t (:346-353, 387-400) as coalesced row segments.
+// HBM traffic per problem-step: C, F, F again, the small vectors and 2 x 480 B of (V, v, lambda, g) in; dC, dF, dc, df
+// out -- 1.12 GB per launch at the headline shape against 1.30 GB in three launches, and no launch in between.
+// The line search of the nested step (:176-179, defaults decay 0.2, 10 trials) is decided from the sweep's predicted
+// change of the cost, (2 alpha - alpha^2) w0, like the lean rollout of the 32/8 kernel.
+// T <= RG_STEPS, symmetric C (the caller's promise MPC_OPT_C_SYMMETRIC: capi.hip takes the three-launch route
+// without it).
+// ---------------------------------------------------------------------------
+struct KktFusedArgs {
+    const float *dl_dx, *dl_du;     // [T,B,12], [T,B,4]
+    float *dC, *dc, *dF, *df, *dx_init;
+    float *dx_out, *du_out;         // the KKT solve's own (dx, du), optional
+    float *vws;                     // workspace: [T,B,96] packed V | v, then [T,B,24] lambda | g
+    float decay;                    // linesearch_decay of the nested step (0.2)
+    int max_ls;                     // its max_linesearch_iter (10)
+};
+// Rings: the fused kernel is built in the compilation with the deep staging array (36 KiB).  Pass 1 stages exactly like
+// the step kernel's sweep (four slots, the DMA three timesteps ahead, handed to the arithmetic in four parts); pass 2 has
+// six of its smaller stages in flight, reads a stage into registers one timestep BEFORE it is worked on and issues a
+// timestep's stores right behind that read: vector stores sit in the same vmcnt queue as the stage DMAs, a counted wait
+// can only count the loads (reads and writes complete out of order with respect to each other), so a wait pays for
+// every store still in flight -- behind the read they have a timestep of arithmetic to land in.
+enum { KF_VBLK = 96,
+       KF_P2_STAGE = 5632, KF_P2_SLOTS = LDS_TOTAL / KF_P2_STAGE >= 6 ? 6 : 3, KF_P2_AHEAD = KF_P2_SLOTS - 1, KF_P2_DMA = 6 };
+// row offset of row i in the packed upper triangle of a symmetric 12 x 12: entries (i, j >= i) at tri_off(i) + j - i
+MPC_DEV int tri_off(int i) { return 12 * i - (i * (i - 1)) / 2; }
+
+struct KfStage1 {            // pass 1: what a timestep reads out of its stage
+    float Cc[16], Fc[12];
+    float rj, tj, cx;
+    float lo[4], hi[4];
+};
+struct KfStage2 {            // pass 2
+    float Fr[16], Vn[12];
+    float tj, l1, g1, v1;
+};
+
+template <bool MASKED>
+MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
+{
+    const int lane = wv::lane();
+    const int wave = wv::problem();
+    if (4 * wave >= p.B) return;
+    Lane L;
+    lane_init(L, lane, wave, p.B, false);
+    const int T = p.T;
+    const long B = p.B;
+    const int gi = lane & 15;
+    const long pb = L.pb;
+    const bool xs_lane = L.j < 12;
+    const int jx = xs_lane ? L.j : 11;
+
+    // ---- pass 1: Riccati sweep of the nested problem + lambda + g ------------------------------------------------
+    // The step kernel's own sweep staging (Dma / stage_issue / Feed: running pointers, one M0 per stage, the DMA handed
+    // to the arithmetic in four parts, C with the read-once policy); only the record's sources differ:
+    // granules 0-2 dl_dx, 3 dl_du, 4-6 x*, 7 u*, 8-10 c_x, 12 lo, 13 hi (tensor bounds), the rest aliased to x*
+    Dma d;
+    {
+        const long t0 = T - 1, tf0 = T < 2 ? 0 : T - 2;
+        d.c_step = 4 * p.C_st;
+        d.f_step = T > 1 ? 4 * p.F_st : 0;
+        d.g_step = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pbk = 4 * wave + q < p.B ? 4 * wave + q : p.B - 1;
+            d.c_ptr[q] = (const char *)(p.C + (long)pbk * p.C_sb) + 16 * src_granule_C(lane, 0) - (1024 * q - 4096) + t0 * d.c_step;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int G = 64 * q + lane;
+            const int slot = G / 48, g2 = G - 48 * slot;
+            const int pbk = 4 * wave + slot < p.B ? 4 * wave + slot : p.B - 1;
+            const char *fb = T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) : (const char *)p.C;
+            d.f_ptr[q] = fb + (T > 1 ? 16 * src_granule_cols(g2, slot) : 0) - 1024 * q + tf0 * d.f_step;
+        }
+        const bool tb = MASKED && p.bound_mode == MPC_BOUND_TENSOR;
+        const char *q = (const char *)(p.cur_x + pb * 12 + 4 * (gi % 3));
+        long st = 4 * B * 12;
+        if (gi < 3) { q = (const char *)(k.dl_dx + pb * 12 + 4 * gi); }
+        else if (gi == 3) { q = (const char *)(k.dl_du + pb * 4); st = 4 * B * 4; }
+        else if (gi < 7) { q = (const char *)(p.cur_x + pb * 12 + 4 * (gi - 4)); }
+        else if (gi == 7) { q = (const char *)(p.cur_u + pb * 4); st = 4 * B * 4; }
+        else if (gi < 11) { q = (const char *)(p.c + pb * p.c_sb + 4 * (gi - 8)); st = 4 * p.c_st; }
+        else if (tb && gi == 12) { q = (const char *)(p.lo + pb * 4); st = 4 * B * 4; }
+        else if (tb && gi == 13) { q = (const char *)(p.hi + pb * 4); st = 4 * B * 4; }
+        d.r_ptr = q - 3072 + t0 * st;
+        d.r_step = st;
+        d.r_step_nof = st;
+        d.g_ptr = d.g2_ptr = d.r_ptr;
+    }
+
+    float Vc[12], vv = 0.f, lam = 0.f, gv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Vc[i] = 0.f;
+    double w0 = 0.0;
+    int status = 0;
+    Gains<true> G;
+    // this lane's element (., j) of the packed (V | v) block and of (lambda | g), at t = T-1, stepping back a timestep a trip
+    float *vp = k.vws + ((long)(T - 1) * B + pb) * KF_VBLK + L.j;
+    float *lp = k.vws + (long)T * B * KF_VBLK + ((long)(T - 1) * B + pb) * 24 + L.j;
+    const long vstep = B * KF_VBLK, lstep = B * 24;
+
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) {
+        const int ti = T - 1 - i;
+        if (ti >= 0) {
+            stage_issue<0, false, false>(d, stage_mid<0, false, false>(i));
+            stage_move<0, false, false>(d, ti <= T - 2);
+        }
+    }
+    for (int k0 = 0; k0 < T; k0 += NSTAGE) {
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int t = T - 1 - (k0 + i);
+            if (t >= 0) {
+                const bool last = t == T - 1;
+                if (t >= AHEAD - 1) wv::dma_wait<(AHEAD - 1) * DMA_SWEEP>();
+                else wv::dma_wait<0>();
+                KfStage1 s1;
+                {
+                    const unsigned base = (unsigned)i * STAGE_BYTES;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = wv::lds_f32x4(base + L.aCq[q]);
+                        s1.Cc[4 * q] = v[0]; s1.Cc[4 * q + 1] = v[1]; s1.Cc[4 * q + 2] = v[2]; s1.Cc[4 * q + 3] = v[3];
+                    }
+#pragma unroll
+                    for (int m = 0; m < 12; ++m) s1.Fc[m] = wv::lds_f32(base + ((m & 1) ? L.aFo : L.aFe) + 64 * m);
+                    s1.rj = wv::lds_f32(base + L.aRec);                                        // (dl_dx | dl_du)[j]
+                    s1.tj = wv::lds_f32(base + L.aRec + 64);                                   // tau*[j]
+                    s1.cx = wv::lds_f32(base + SR + L.p * 256 + 128 + 4 * jx);                 // c[j], j < 12
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { s1.lo[a] = 0.f; s1.hi[a] = 0.f; }
+                    if (MASKED) {
+                        if (p.bound_mode == MPC_BOUND_TENSOR) {
+                            const f32x4 l = wv::lds_f32x4(base + SR + L.p * 256 + R_lo);
+                            const f32x4 h = wv::lds_f32x4(base + SR + L.p * 256 + R_hi);
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) { s1.lo[a] = l[a]; s1.hi[a] = h[a]; }
+                        } else {
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) { s1.lo[a] = p.lo_s; s1.hi[a] = p.hi_s; }
+                        }
+                    }
+                }
+                Feed<0, false, false> feed = {d, stage_mid<0, false, false>((i + AHEAD) % NSTAGE), t >= AHEAD, true};
+                feed.template part<0>();
+
+                // lambda_t = C_x tau* + c_x + F_x' lambda_{t+1}   (:355-369; rows 0..11 of C, F_x = first 12 columns)
+                float ln = s1.cx;
+                wv::dot_bcast16(ln, s1.tj, s1.Cc);
+                if (!last) wv::dot_bcast12(ln, lam, s1.Fc);
+
+                // the nested problem's sweep step: c_back = C 0 - r = -r   (:328-340, :52-160)
+                float Q[16];
+                float q = -s1.rj;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Q[r] = s1.Cc[r];
+                if (!last) {
+                    float Y[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    wv::sched_fence();
+#pragma unroll
+                    for (int m = 0; m < 12; ++m) outer_acc(Y, Vc[m], s1.Fc[m]);
+                    wv::sched_fence();
+                    feed.template part<1>();
+                    wv::sched_fence();
+#pragma unroll
+                    for (int m = 0; m < 12; ++m) outer_acc(Q, s1.Fc[m], Y[m]);
+                    wv::sched_fence();
+                    feed.template part<2>();
+                    wv::sched_fence();
+                    wv::dot_bcast12(q, vv, s1.Fc);
+                } else {
+                    feed.template part<1>();
+                    feed.template part<2>();
+                }
+                Sym4 S;
+                S.s00 = wv::bcast<12>(Q[12]); S.s01 = wv::bcast<13>(Q[12]); S.s02 = wv::bcast<14>(Q[12]); S.s03 = wv::bcast<15>(Q[12]);
+                S.s11 = wv::bcast<13>(Q[13]); S.s12 = wv::bcast<14>(Q[13]); S.s13 = wv::bcast<15>(Q[13]);
+                S.s22 = wv::bcast<14>(Q[14]); S.s23 = wv::bcast<15>(Q[14]);
+                S.s33 = wv::bcast<15>(Q[15]);
+                float qu[4];
+                qu[0] = wv::bcast<12>(q); qu[1] = wv::bcast<13>(q); qu[2] = wv::bcast<14>(q); qu[3] = wv::bcast<15>(q);
+                bool fr[4] = {true, true, true, true};
+                Ldl4 f;
+                if (MASKED) {
+                    // :316-326 a control sitting on a bound (to 1e-8) is pinned in the nested solve
+                    const float us[4] = {wv::bcast<12>(s1.tj), wv::bcast<13>(s1.tj), wv::bcast<14>(s1.tj), wv::bcast<15>(s1.tj)};
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) fr[a] = !(fabsf(us[a] - s1.lo[a]) <= 1e-8f || fabsf(us[a] - s1.hi[a]) <= 1e-8f);
+                    ldl4<true>(f, S, fr, 0.f);
+                } else {
+                    float sing = 0.f;
+                    ldl4<false, true>(f, S, fr, 0.f, &sing);
+                    if (sing != 0.f) status |= MPC_ST_QUU_SINGULAR;
+                }
+                const bool j12 = L.j == 12;
+                float K[4];
+                {
+                    float rhs[4], y[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) rhs[a] = sel(j12, qu[a], Q[12 + a]);
+                    if (MASKED) {
+                        ldl4_solve(f, fr[0] ? rhs[0] : 0.f, fr[1] ? rhs[1] : 0.f, fr[2] ? rhs[2] : 0.f, fr[3] ? rhs[3] : 0.f, y);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) K[a] = fr[a] ? -y[a] : 0.f;
+                    } else {
+                        ldl4_solve(f, rhs[0], rhs[1], rhs[2], rhs[3], y);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) K[a] = -y[a];
+                    }
+                }
+                // V = Qxx + Qxu K, v = qx + Qxu k  (:155-158: the K'(Qux + Quu K) terms vanish -- free rows of the bracket
+                // are zero, pinned rows of K are)
+                float Vn[12];
+#pragma unroll
+                for (int r = 0; r < 12; ++r) Vn[r] = Q[r];
+                wv::sched_fence();
+                feed.template part<3>();
+                wv::sched_fence();
+#pragma unroll
+                for (int a = 0; a < 4; ++a) outer_acc(Vn, Q[12 + a], K[a]);
+                wv::sched_fence();
+                float vn = q;
+                wv::fmac_bcast<12>(vn, K[0], Q[12]); wv::fmac_bcast<12>(vn, K[1], Q[13]);
+                wv::fmac_bcast<12>(vn, K[2], Q[14]); wv::fmac_bcast<12>(vn, K[3], Q[15]);
+                {
+                    float w = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) w = fmaf(wv::bcast<12>(K[a]), 0.5f * qu[a], w);
+                    w0 += (double)w;
+                }
+                // g_t = F_x' g_{t+1} - Qxu k_t (the header): Qxu k_t is what v just took on
+                float gn = q - vn;
+                if (!last) wv::dot_bcast12(gn, gv, s1.Fc);
+                gain_put(G, t, f32x4{K[0], K[1], K[2], K[3]});
+#pragma unroll
+                for (int r = 0; r < 12; ++r) Vc[r] = Vn[r];
+                vv = vn;
+                lam = ln;
+                gv = gn;
+                // V_t (upper triangle: register r of lane j is V[r][j], kept for j >= r), v_t, lambda_t, g_t -> workspace
+#ifdef MPC_KF_SKIP           // diagnostic builds (tools/ab_kkt_phases.sh): 1 no workspace stores, 2 no gradient stores, 4 pass 1 only
+                if (xs_lane && !(MPC_KF_SKIP & 1)) {
+#else
+                if (xs_lane) {
+#endif
+#pragma unroll
+                    for (int r = 0; r < 12; ++r)
+                        if (L.j >= r) wv::store_f32_out(vp + (tri_off(r) - r), Vn[r]);
+                    wv::store_f32_out(vp + 78, vn);
+                    wv::store_f32_out(lp, ln);
+                    wv::store_f32_out(lp + 12, gn);
+                }
+                vp -= vstep;
+                lp -= lstep;
+            }
+        }
+    }
+    wv::dma_wait<0>();
+    // the nested step's line search (:176-179, 247): cost(alpha) - cost(0) = (2 alpha - alpha^2) w0 along the sweep's
+    // direction; the first trial that does not make it worse, else the last one
+    float alpha = 1.f;
+    {
+        const float w0f = (float)w0;
+        for (int trial = 1; trial < k.max_ls; ++trial) {
+            const bool worse = (2.f * alpha - alpha * alpha) * w0f > 0.f;
+            alpha = worse ? alpha * k.decay : alpha;
+        }
+    }
+    // dx_init = -dlambda_0 = -(V_0 0 + v_0 + (1 - alpha) g_0)   (:404)
+    if (L.live && xs_lane) k.dx_init[pb * 12 + L.j] = -fmaf(1.f - alpha, gv, vv);
+    wv::fence_own_stores();            // (V, v, lambda, g) come back through the DMA
+#ifdef MPC_KF_SKIP
+    if (MPC_KF_SKIP & 4) return;
+#endif
+
+    // ---- pass 2: rollout of the nested solve + every gradient of the timestep -------------------------------------
+    // stage (5.5 KiB): F (row order) | record: granules 4-6 x*, 7 u*, 8-10 lambda_{t+1}, 11-13 g_{t+1} | (V | v)_{t+1} x 4
+    const char *f2_ptr[3], *r2_ptr, *v2_ptr[2];
+    long r2_step;
+    bool r2_active, v2_active;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int Gq = 64 * q + lane;
+        const int slot = Gq / 48, g2 = Gq - 48 * slot;
+        const int pbk = 4 * wave + slot < p.B ? 4 * wave + slot : p.B - 1;
+        f2_ptr[q] = T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) + 16 * src_granule_rows(g2) : (const char *)p.C;
+    }
+    {
+        r2_active = gi >= 4 && gi < 14;
+        const char *q = (const char *)p.cur_x;
+        long st = 0;
+        if (gi >= 4 && gi < 7) { q = (const char *)(p.cur_x + pb * 12 + 4 * (gi - 4)); st = 4 * B * 12; }
+        else if (gi == 7) { q = (const char *)(p.cur_u + pb * 4); st = 4 * B * 4; }
+        else if (gi >= 8 && gi < 14) { q = (const char *)(k.vws + (long)T * B * KF_VBLK + pb * 24 + 4 * (gi - 8)); st = 4 * B * 24; }
+        r2_ptr = q;
+        r2_step = st;
+        // (V | v): 24 granules per problem, 96 per wave: instruction 0 lanes 0..63, instruction 1 lanes 0..31
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            const int Gq = 64 * q2 + lane;
+            const int slot = Gq / 24, g2 = Gq - 24 * slot;
+            const int pbk = slot < 4 ? (4 * wave + slot < p.B ? 4 * wave + slot : p.B - 1) : (int)pb;
+            v2_ptr[q2] = (const char *)(k.vws + (long)pbk * KF_VBLK) + 16 * (slot < 4 ? g2 : 0);
+        }
+        v2_active = lane < 32;
+    }
+    const long v2_step = 4 * B * KF_VBLK, f_step = T > 1 ? 4 * p.F_st : 0;
+    auto issue2 = [&](int t, int slot) {
+        // stage t holds F_t, tau*_t and lambda / g / V / v of t+1 (t = T-1: copies of T-1 that nothing looks at)
+        t = t < T ? t : T - 1;
+        const unsigned sb = (unsigned)slot * KF_P2_STAGE;
+        const long tf = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
+        const long t1 = t < T - 1 ? t + 1 : t;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wv::dma16_once(f2_ptr[q] + tf * f_step, sb + 1024 * q);
+        wv::dma16_if(r2_active, r2_ptr + (gi >= 8 ? t1 : (long)t) * r2_step, sb + 3072);
+        wv::dma16_once(v2_ptr[0] + t1 * v2_step, sb + 4096);
+        wv::dma16_if(v2_active, v2_ptr[1] + t1 * v2_step, sb + 4096 + 1024);
+    };
+    // index of V[i][j] in the packed block, for this lane's column j
+    int vidx[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) vidx[i] = 4 * (L.p * KF_VBLK + (i <= jx ? tri_off(i) + jx - i : tri_off(jx) + i - jx));
+    auto read2 = [&](KfStage2 &s, int slot) {
+        const int sb = slot * KF_P2_STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = wv::lds_f32x4((unsigned)(sb - SF + L.aFq[q]));
+            s.Fr[4 * q] = v[0]; s.Fr[4 * q + 1] = v[1]; s.Fr[4 * q + 2] = v[2]; s.Fr[4 * q + 3] = v[3];
+        }
+        s.tj = wv::lds_f32((unsigned)(sb + 3072 - SR + L.aRec + 64));                    // tau*_t[j]
+        s.l1 = wv::lds_f32((unsigned)(sb + 3072 + L.p * 256 + 128 + 4 * jx));            // lambda_{t+1}[j]
+        s.g1 = wv::lds_f32((unsigned)(sb + 3072 + L.p * 256 + 176 + 4 * jx));            // g_{t+1}[j]
+#pragma unroll
+        for (int r = 0; r < 12; ++r) s.Vn[r] = wv::lds_f32((unsigned)(sb + 4096 + vidx[r]));
+        s.v1 = wv::lds_f32((unsigned)(sb + 4096 + 4 * (L.p * KF_VBLK + 78 + jx)));
+    };
+    float xs = 0.f;                                            // dx_t[j]: dx_0 = 0
+    // Rows r, r+1 of a gradient block leave as ONE 8-byte store per lane: the even lane of a pair writes (row r, columns
+    // j, j+1), the odd one (row r+1, columns j-1, j) -- a problem's 16 lanes then cover the two rows, 128 contiguous bytes,
+    // where a dword per lane and row wrote 64-byte halves of a cache line with twice the instructions (28 per timestep).
+    const bool odd = (L.j & 1) != 0;
+    float *dC_p = k.dC + pb * 256 + (L.j & ~1) + (odd ? 16 : 0), *dF_p = k.dF + pb * 192 + (L.j & ~1) + (odd ? 16 : 0);
+    float *dc_p = k.dc + pb * 16 + L.j;
+    float *df_p = k.df ? k.df + pb * 12 + L.j : nullptr;
+    float *so_p = (k.dx_out && k.du_out) ? (L.isu ? k.du_out + pb * 4 + L.a : k.dx_out + pb * 12 + L.j) : nullptr;
+    const long so_step = L.isu ? B * 4 : B * 12;
+#pragma unroll
+    for (int i = 0; i < KF_P2_AHEAD; ++i) issue2(i, i);
+    KfStage2 s2;
+    wv::dma_wait<(KF_P2_AHEAD - 1) * KF_P2_DMA>();
+    read2(s2, 0);
+    for (int t0 = 0; t0 < T; t0 += KF_P2_SLOTS) {
+#pragma unroll
+        for (int i = 0; i < KF_P2_SLOTS; ++i) {
+            const int t = t0 + i;
+            if (t < T) {
+                const bool have = t < T - 1;
+                issue2(t + KF_P2_AHEAD, (i + KF_P2_AHEAD) % KF_P2_SLOTS);
+                const f32x4 rec = gain_get(G, t);
+                // du = K dx + alpha k  (:192; pinned controls have zero rows of K and k: they stay at 0)
+                const float dxj = L.isu ? 0.f : xs;
+                const float mult = L.j == 12 ? alpha : dxj;
+                const float du = wv::quad_sums(rec[0] * mult, rec[1] * mult, rec[2] * mult, rec[3] * mult, L.j);
+                const float dj = L.isu ? du : xs;                           // dtau_t[j]
+                float xn = 0.f, dl1 = 0.f;
+                float colF[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (have) {
+                    wv::dot_bcast16(xn, dj, s2.Fr);                        // dx_{t+1} = F dtau   (f = None, :333)
+                    dl1 = fmaf(1.f - alpha, s2.g1, s2.v1);
+                    wv::dot_bcast12(dl1, xn, s2.Vn);                       // dlambda_{t+1} = V dx + v + (1 - alpha) g
+                    // dF_t = -(dlambda_{t+1} tau' + lambda_{t+1} dtau'), df_t = -dlambda_{t+1}   (:387-400)
+                    outer_acc(colF, -dl1, s2.tj);
+                    outer_acc(colF, -s2.l1, dj);
+                }
+                // dC_t = -0.5 (dtau tau' + tau dtau'), dc_t = -dtau   (:346-353)
+                float colC[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                outer_acc(colC, s2.tj, -0.5f * dj);
+                outer_acc(colC, dj, -0.5f * s2.tj);
+                xs = xn;
+                // the next stage has had this timestep to land: read it, THEN send this timestep's gradients off
+                wv::dma_wait<(KF_P2_AHEAD - 1) * KF_P2_DMA>();
+                read2(s2, (i + 1) % KF_P2_SLOTS);
+                // (the exchange with the neighbouring lane happens for every lane: rows of a ragged last wave only skip the stores)
+                float pF0[6], pF1[6], pC0[8], pC1[8];
+#pragma unroll
+                for (int r = 0; r < 12; r += 2) {
+                    const float n0 = wv::swap1(colF[r]), n1 = wv::swap1(colF[r + 1]);
+                    pF0[r / 2] = odd ? n1 : colF[r];
+                    pF1[r / 2] = odd ? colF[r + 1] : n0;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float n0 = wv::swap1(colC[r]), n1 = wv::swap1(colC[r + 1]);
+                    pC0[r / 2] = odd ? n1 : colC[r];
+                    pC1[r / 2] = odd ? colC[r + 1] : n0;
+                }
+#ifdef MPC_KF_SKIP
+                if (L.live && (!(MPC_KF_SKIP & 2) || t == T - 1)) {
+#else
+                if (L.live) {
+#endif
+                    if (so_p) wv::store_f32_out(so_p, dj);
+                    if (have) {
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) wv::store_f32x2_out(dF_p + 32 * r, pF0[r], pF1[r]);
+                        if (df_p && xs_lane) wv::store_f32_out(df_p, -dl1);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) wv::store_f32x2_out(dC_p + 32 * r, pC0[r], pC1[r]);
+                    wv::store_f32_out(dc_p, -dj);
+                }
+                if (so_p) so_p += so_step;
+                dC_p += B * 256;
+                dF_p += B * 192;
+                dc_p += B * 16;
+                if (df_p) df_p += B * 12;
+            }
+        }
+    }
+    wv::dma_wait<0>();
+    if (L.j == 0 && L.live && p.status) p.status[pb] = status;
+}
+
 }  // namespace dpp16
 }  // namespace mpclqr

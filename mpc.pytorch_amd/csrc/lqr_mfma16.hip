@@ -75,8 +75,10 @@ namespace mpclqr {
 namespace {
 
 // MODE: 0 unconstrained, 1 unconstrained + u_zero_I, 2 box-constrained (pnqp in the sweep)
+// (the box-constrained instantiation needs ~140 registers: at four waves per SIMD -- 128 -- it spilled 16-21 of them to
+//  scratch memory; three waves per SIMD keep it in the register file, tests/test_isa_lint.py)
 template <bool FULL, int MODE>
-__global__ void __launch_bounds__(64, 4) lqr_step_mfma16_kernel(StepParams<float> p)
+__global__ void __launch_bounds__(64, MODE == 2 ? 3 : 4) lqr_step_mfma16_kernel(StepParams<float> p)
 {
     mfma16::step_problem<FULL, MODE>(p);
 }

@@ -140,7 +140,8 @@ class Outputs(ctypes.Structure):
 EXPORTS = ("mpc_lqr_abi_version", "mpc_lqr_build_info", "mpc_lqr_last_error", "mpc_lqr_workspace_bytes",
            "mpc_lqr_step", "mpc_lqr_impl_supported", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_lqr_kkt_prepare",
            "mpc_pnqp", "mpc_pnqp_lu", "mpc_traj_cost", "mpc_env_traj_cost", "mpc_env_linearize", "mpc_select_best",
-           "mpc_mlp_workspace_bytes", "mpc_mlp_rollout", "mpc_mlp_linearize")
+           "mpc_mlp_workspace_bytes", "mpc_mlp_rollout", "mpc_mlp_linearize",
+           "mpc_lqr_kkt_fused_supported", "mpc_lqr_kkt_fused_workspace_bytes", "mpc_lqr_kkt_fused")
 
 _lib = None
 
@@ -177,6 +178,10 @@ def load():
     L.mpc_lqr_rollout.argtypes = [PP, OP, UP, _vp, _vp]
     L.mpc_lqr_kkt_grads.argtypes = [PP] + [_vp] * 10
     L.mpc_lqr_kkt_prepare.argtypes = [ctypes.c_int] * 5 + [_vp, _vp, _vp, OP, _vp, _vp, _vp]
+    L.mpc_lqr_kkt_fused_supported.argtypes = [PP, OP]
+    L.mpc_lqr_kkt_fused_workspace_bytes.restype = _i64
+    L.mpc_lqr_kkt_fused_workspace_bytes.argtypes = [PP]
+    L.mpc_lqr_kkt_fused.argtypes = [PP, OP] + [_vp] * 11 + [_i64, _vp]
     L.mpc_pnqp.argtypes = [ctypes.c_int] * 3 + [_vp] * 5 + [ctypes.c_int] + [_vp] * 6
     L.mpc_pnqp_lu.argtypes = [ctypes.c_int] * 3 + [_vp] * 5 + [ctypes.c_int] + [_vp] * 8
     L.mpc_traj_cost.argtypes = [PP, _vp, _vp, _vp]
@@ -490,6 +495,25 @@ class HipBackend:
         x_star = x_star.detach().contiguous()
         u_star = u_star.detach().contiguous()
         o, keep_o = opts.to_struct(T, B, nc, C)
+        has_f = f is not None and f.numel() > 0
+        if impl == IMPL_AUTO:
+            # the whole backward in one launch where a kernel for it exists (12/4, fp32, T <= 64, C vouched symmetric)
+            pf, keep_f = self._problem(x_star[0], C, c, F, f, x_star, u_star)
+            if L.mpc_lqr_kkt_fused_supported(ctypes.byref(pf), ctypes.byref(o)):
+                g = dict(dC=torch.empty(T, B, n, n, **kw), dc=torch.empty(T, B, n, **kw), dF=torch.empty(F.shape, **kw),
+                         df=torch.empty(T - 1, B, ns, **kw) if has_f and T > 1 else (torch.empty(0, B, ns, **kw) if has_f else None),
+                         dx_init=torch.empty(B, ns, **kw), dx=torch.empty(T, B, ns, **kw), du=torch.empty(T, B, nc, **kw))
+                nbytes = int(L.mpc_lqr_kkt_fused_workspace_bytes(ctypes.byref(pf)))
+                ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+                rc = L.mpc_lqr_kkt_fused(ctypes.byref(pf), ctypes.byref(o), dl_dx.data_ptr(), dl_du.data_ptr(), g["dC"].data_ptr(),
+                                         g["dc"].data_ptr(), g["dF"].data_ptr(), _ptr(g["df"]) if (has_f and T > 1) else None,
+                                         g["dx_init"].data_ptr(), g["dx"].data_ptr(), g["du"].data_ptr(), None, ws.data_ptr(),
+                                         nbytes, st)
+                if rc == 0:
+                    g["_keep"] = (keep_f, keep_o, ws, dl_dx, dl_du, x_star, u_star)
+                    return g
+                if rc != -1:          # MPC_E_DIMS = misaligned views: the three calls below take anything
+                    _check(rc, "mpc_lqr_kkt_fused")
         negr = torch.empty(T, B, n, **kw)
         mask = None
         if o.bound_mode != BOUND_NONE:
@@ -503,7 +527,6 @@ class HipBackend:
         inner = StepOptions(u_zero_I=mask, nominal_on_dynamics=True, c_symmetric=opts.c_symmetric)
         sol = self.lqr_step(z0, C, negr, F, None, zx, zu, inner, impl=impl)
         p, keep = self._problem(z0, C, c, F, f, x_star, u_star)
-        has_f = f is not None and f.numel() > 0
         dC = torch.empty(T, B, n, n, **kw)
         dc = torch.empty(T, B, n, **kw)
         dF = torch.empty(F.shape, **kw)          # every kernel writes all of it (t < T-1 is all there is)

@@ -264,6 +264,15 @@ static inline float row_max(float x)
     }
     return x;
 }
+static inline float swap1(float x)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = x;
+    emu::yield_lane();
+    return w.fa[gen][l ^ 1];
+}
+static inline void store_f32x2_out(float *g, float a, float b) { g[0] = a; g[1] = b; }
 static inline void absmax3(float &acc, float a, float b) { acc = fmaxf(acc, fmaxf(fabsf(a), fabsf(b))); }
 // register-resident gains of lqr_dpp16.hip (accumulation registers a[4t..4t+3] there): one array per lane here
 static f32x4 g_rg[64][64];
@@ -487,6 +496,35 @@ extern "C" int emu_kkt_dpp16(const mpc_lqr_problem *p, const float *dx, const fl
     g_p = &sp;
     g_k = &k;
     for (int w = 0; 4 * w < sp.B; ++w) emu::run_wave(w, body_kkt16);
+    return 0;
+}
+
+static const mpclqr::dpp16::KktFusedArgs *g_kf;
+template <bool MASKED> static void body_kkt_fused() { mpclqr::dpp16::kkt_fused_wave<MASKED>(*g_p, *g_kf); }
+
+// the whole KKT backward in one (emulated) launch: lqr_dpp16_body.h, kkt_fused_wave
+extern "C" int emu_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const float *dl_dx, const float *dl_du,
+                             float *dC, float *dc, float *dF, float *df, float *dx_init, float *dx_out, float *du_out,
+                             int *status)
+{
+    mpc_lqr_outputs out;
+    memset(&out, 0, sizeof(out));
+    out.status = status;
+    mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, &out);
+    if (!(sp.ns == 12 && sp.nc == 4 && sp.T <= mpclqr::dpp16::RG_STEPS)) return MPC_E_DIMS;
+    const size_t need = (size_t)sp.T * sp.B * (mpclqr::dpp16::KF_VBLK + 24) + 4;
+    float *ws = (float *)aligned_alloc(16, (need * sizeof(float) + 15) / 16 * 16);
+    for (size_t i = 0; i < need; ++i) ws[i] = NAN;
+    mpclqr::dpp16::KktFusedArgs k;
+    k.dl_dx = dl_dx; k.dl_du = dl_du; k.dC = dC; k.dc = dc; k.dF = dF; k.df = df; k.dx_init = dx_init;
+    k.dx_out = dx_out; k.du_out = du_out; k.vws = ws;
+    k.decay = o ? (float)o->linesearch_decay : 0.2f;
+    k.max_ls = o ? o->max_linesearch_iter : 10;
+    g_p = &sp;
+    g_kf = &k;
+    const bool masked = sp.bound_mode != MPC_BOUND_NONE;
+    for (int w = 0; 4 * w < sp.B; ++w) emu::run_wave(w, masked ? body_kkt_fused<true> : body_kkt_fused<false>);
+    free(ws);
     return 0;
 }
 

@@ -176,6 +176,52 @@ def kkt_grads(C, c, F, f, x_star, u_star, dx, du, dl_dx, dma_late=False, ring2=F
     return out
 
 
+def kkt_fused(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_upper=None, dma_late=False, ring2=True,
+              linesearch_decay=0.2, max_linesearch_iter=10):
+    """ALL of LQRStepFn.backward (mpc/lqr_step.py:312-407) through the emulated fused kernel (kkt_fused_wave,
+    lqr_dpp16_body.h): n_state = 12, n_ctrl = 4, float32, T <= 64.  Returns dC, dc, dF, df, dx_init and the KKT
+    solve's own (dx, du)."""
+    f32 = np.float32
+    cast = lambda a: np.ascontiguousarray(a, f32)
+    C, c, F, x_star, u_star, dl_dx, dl_du = map(cast, (C, c, F, x_star, u_star, dl_dx, dl_du))
+    T, B, n, _ = C.shape
+    ns, nc = 12, 4
+    p = N.Problem()
+    p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, N.MPC_F32
+    x0 = np.zeros((B, ns), f32)
+    p.x_init = _ptr(x0)
+    p.C, p.C_st, p.C_sb = _ptr(C), B * n * n, n * n
+    p.c, p.c_st, p.c_sb = _ptr(c), B * n, n
+    if T > 1:
+        p.F, p.F_st, p.F_sb = _ptr(F), B * ns * n, ns * n
+    p.cur_x, p.cur_u = _ptr(x_star), _ptr(u_star)
+    o = N.Options()
+    o.max_linesearch_iter, o.linesearch_decay, o.delta_u, o.pnqp_iter = int(max_linesearch_iter), float(linesearch_decay), float("nan"), 20
+    keep = []
+    if u_lower is None:
+        o.bound_mode = N.BOUND_NONE
+    elif isinstance(u_lower, (float, int)):
+        o.bound_mode, o.lo_s, o.hi_s = N.BOUND_SCALAR, float(u_lower), float(u_upper)
+    else:
+        lo = np.ascontiguousarray(np.broadcast_to(u_lower, (T, B, nc)), f32)
+        hi = np.ascontiguousarray(np.broadcast_to(u_upper, (T, B, nc)), f32)
+        keep += [lo, hi]
+        o.bound_mode, o.lo, o.hi = N.BOUND_TENSOR, _ptr(lo), _ptr(hi)
+    has_f = f is not None and np.asarray(f).size > 0
+    out = dict(dC=np.full((T, B, n, n), np.nan, f32), dc=np.full((T, B, n), np.nan, f32),
+               dF=np.full((max(T - 1, 0), B, ns, n), np.nan, f32), df=np.full((max(T - 1, 0), B, ns), np.nan, f32) if has_f else None,
+               dx_init=np.full((B, ns), np.nan, f32), dx=np.full((T, B, ns), np.nan, f32), du=np.full((T, B, nc), np.nan, f32),
+               status=np.zeros(B, np.int32))
+    L = lib_ring2() if ring2 else lib()
+    L.emu_set_dma_late(int(bool(dma_late)))
+    vp = ctypes.c_void_p
+    L.emu_kkt_fused.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options)] + [vp] * 10
+    rc = L.emu_kkt_fused(ctypes.byref(p), ctypes.byref(o), _ptr(dl_dx), _ptr(dl_du), _ptr(out["dC"]), _ptr(out["dc"]),
+                         _ptr(out["dF"]), _ptr(out["df"]), _ptr(out["dx_init"]), _ptr(out["dx"]), _ptr(out["du"]), _ptr(out["status"]))
+    assert rc == 0, rc
+    return out
+
+
 def env_linearize(kind, params, dt, u_max, x, u, dtype=np.float64):
     """mpc.pytorch_amd/csrc/env_dynamics.h compiled for the host: next state, F, f at N points."""
     sfx = "f64" if dtype == np.float64 else "f32"

@@ -256,6 +256,60 @@ def test_emulated_kkt_dpp16_matches_oracle(emu, bounded, with_f, B, dma_late, ri
         np.testing.assert_allclose(r[k], o[k], rtol=1e-4, atol=1e-4 * max(1.0, np.abs(o[k]).max()), err_msg=k)
 
 
+@pytest.mark.parametrize("ring2", [False, True], ids=["ring4", "ring2"])
+@pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
+@pytest.mark.parametrize("case", ["unbounded", "bounded", "bounded_nof", "tensor_bounds", "T1", "T2", "T3", "T7_B9", "T64", "nonconvex"])
+def test_emulated_fused_kkt_backward_matches_oracle(emu, case, dma_late, ring2):
+    """kkt_fused_wave: ALL of LQRStepFn.backward (mpc/lqr_step.py:312-407) in one launch -- the nested LQR solve's sweep
+    with lambda riding along, then its rollout with dlambda = V dx + v and every gradient of the timestep -- against
+    the oracle's three-stage backward (active set from u* and the bounds, nested LQRStep, costate recursions), short
+    horizons around the ring depths, a ragged batch, the longest horizon the register-resident gains take, and a
+    non-convex cost whose nested step backtracks (alpha < 1: the correction vector g).  ring4 = the compilation the
+    library builds the kernel in (four sweep stages, six rollout stages in flight); ring2 = the same source on the small
+    staging array (two / three stages), other wait counts."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(sum(map(ord, case)))
+    T = {"T1": 1, "T2": 2, "T3": 3, "T7_B9": 7, "T64": 64}.get(case, 6)
+    B = 9 if case == "T7_B9" else (3 if case == "T64" else 5)
+    bounded = case in ("bounded", "bounded_nof", "tensor_bounds", "T7_B9", "T2")
+    pr = _ns_problem(rng, max(T, 2), B, with_f=case != "bounded_nof")
+    if case == "nonconvex":
+        # Quu indefinite on two problems: the sweep's stationary point is no minimum there, the nested step's cost goes UP
+        # at every step size and the line search ends on its last trial (mpc/lqr_step.py:176-179, 252)
+        pr["C"][:, (1, 3), 12:, 12:] -= 250.0 * np.eye(4)
+    if T == 1:
+        pr = {k: (v[:1] if k in ("C", "c") else (v[:0] if k in ("F", "f") and v is not None else v)) for k, v in pr.items()}
+    cur_u = np.clip(0.5 * rng.standard_normal((T, B, 4)), -0.4, 0.4)
+    cur_x, _ = O.traj_cost(pr["x_init"], cur_u, pr["F"], pr["f"])
+    lo, hi = (-0.4, 0.4) if bounded else (None, None)
+    if case == "tensor_bounds":
+        lo, hi = -0.3 - 0.2 * rng.random((T, B, 4)), 0.3 + 0.2 * rng.random((T, B, 4))
+        lo, hi = lo.astype(np.float32).astype(np.float64), hi.astype(np.float32).astype(np.float64)   # (a control ON a bound stays on it in float32)
+    # the solution the backward differentiates at: a few LQR steps from the nominal (the bounded ones end on the bounds)
+    x, u = cur_x, cur_u
+    for _ in range(4):
+        sol = O.lqr_step(lockstep=False, cur_x=x, cur_u=u, u_lower=lo, u_upper=hi, **pr)
+        x, u = sol["new_x"], sol["new_u"]
+    x, u = x.astype(np.float32).astype(np.float64), u.astype(np.float32).astype(np.float64)     # what the kernel will see
+    dl_dx, dl_du = rng.standard_normal((T, B, 12)), rng.standard_normal((T, B, 4))
+    o = O.kkt_backward(pr["C"], pr["c"], pr["F"], pr["f"], x, u, dl_dx, dl_du, lo, hi, lockstep=False)
+    if bounded:
+        act = np.abs(np.abs(u) - 0.4) <= 1e-8 if case != "tensor_bounds" else (np.abs(u - lo) <= 1e-8) | (np.abs(u - hi) <= 1e-8)
+        assert 0.02 < act.mean() < 0.95, act.mean()
+    if case == "nonconvex":
+        # the nested solve (:328-340) must really backtrack for this case to mean anything
+        nested = O.lqr_step(np.zeros((B, 12)), pr["C"], -np.concatenate((dl_dx, dl_du), 2), pr["F"], None, np.zeros((T, B, 12)),
+                            np.zeros((T, B, 4)), lockstep=False)
+        assert (nested["alphas"] < 1).any() and (nested["alphas"] == 1).any(), nested["alphas"]
+    r = emu.kkt_fused(pr["C"], pr["c"], pr["F"], pr["f"], x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, ring2=ring2)
+    wide = 10.0 if case == "nonconvex" else 1.0           # (an indefinite Quu: float32 keeps fewer digits)
+    for k in ("dx", "du", "dC", "dc", "dF", "dx_init") + (("df",) if pr["f"] is not None and T > 1 else ()):
+        if o[k] is None or o[k].size == 0:
+            continue
+        assert np.isfinite(r[k]).all(), k
+        np.testing.assert_allclose(r[k], o[k], rtol=1e-4 * wide, atol=1e-4 * wide * max(1.0, np.abs(o[k]).max()), err_msg=k)
+
+
 @pytest.mark.parametrize("bounded", [False, True])
 def test_emulated_dpp16_nominal_off_the_dynamics(emu, bounded):
     """current_x that is NOT the rollout of current_u (LQRStep allows it): the cost identity the

@@ -156,13 +156,17 @@ def test_headline_bounded_every_problem_vs_oracle(be, case):
 # ------------------------------------------------------------------------------------------------
 # (b) KKT backward at the headline size
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fused", [False, True], ids=["three-launch", "fused"])
 @pytest.mark.parametrize("bounded", [False, True])
 @pytest.mark.parametrize("B", [4096, 4093])
-def test_kkt_backward_full_size_vs_oracle(be, bounded, B):
+def test_kkt_backward_full_size_vs_oracle(be, bounded, B, fused):
     """LQRStepFn.backward (mpc/lqr_step.py:312-407) at ns=12 nc=4 T=50, B = 4096 (1024 full waves: multi-round
     scheduling) and 4093 (a partial last wave), fp32, all five gradients against the float64 oracle fed the very
     same (x*, u*, dl_dx, dl_du).  dF is NOT zero-filled by the host (mpc/_native.py): the kernel must write all
-    of it -- the buffer is poisoned with NaN first through the caching allocator."""
+    of it -- the buffer is poisoned with NaN first through the caching allocator.
+    fused: with C vouched symmetric (MPC_OPT_C_SYMMETRIC, what mpc.MPC hands its backward) the whole backward is ONE launch
+    (mpc_lqr_kkt_fused: sweep + lambda, then rollout + dlambda = V dx + v + every gradient); without the promise it is
+    mpc_lqr_kkt_prepare + mpc_lqr_step + mpc_lqr_kkt_grads.  Same oracle, same tolerance."""
     import bench
     from mpc._native import StepOptions
     from oracle import lqr_oracle as O
@@ -170,7 +174,7 @@ def test_kkt_backward_full_size_vs_oracle(be, bounded, B):
     B = full_batch(B)
     p = bench.make_problem(12, 4, T, B, torch.float32, DEV, seed=2, u_scale=0.3 if bounded else 0.0,
                            clamp=1.0 if bounded else None)
-    opts = StepOptions(u_lower=-1.0, u_upper=1.0) if bounded else StepOptions()
+    opts = StepOptions(u_lower=-1.0, u_upper=1.0, c_symmetric=fused) if bounded else StepOptions(c_symmetric=fused)
     r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts)
     g = torch.Generator(device=DEV).manual_seed(5)
     gx = torch.randn(tuple(r["new_x"].shape), generator=g, device=DEV)
@@ -196,7 +200,14 @@ def test_kkt_backward_full_size_vs_oracle(be, bounded, B):
         rel = (np.abs(a - o[k]) / scale).max(axis=ax)
         d[k] = float(rel.max())
         assert rel.max() < 2e-4, "%s: problem %d off by %.2e of its scale" % (k, int(rel.argmax()), rel.max())
-    diag("kkt_B%d_%s" % (B, "bounded" if bounded else "unbounded"), **d)
+    if not DRY:
+        from mpc import _native
+        # (the route is the library's choice: make sure the test is testing what its name says)
+        pf, _k = be._problem(p["x_init"], p["C"], p["c"], p["F"], p["f"], r["new_x"], r["new_u"])
+        of, _k2 = opts.to_struct(T, B, 4, p["C"])
+        import ctypes
+        assert bool(_native.load().mpc_lqr_kkt_fused_supported(ctypes.byref(pf), ctypes.byref(of))) == fused
+    diag("kkt_B%d_%s_%s" % (B, "bounded" if bounded else "unbounded", "fused" if fused else "3launch"), **d)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -373,17 +373,20 @@ def test_kkt_backward_wave_kernels(be, ns, nc, T, B, with_f, bounded):
         p["cur_x"] = util.get_traj(T, p["cur_u"], p["x_init"], LinDx(p["F"], None))
     r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], f, p["cur_x"], p["cur_u"], opts)
     gx, gu = torch.randn_like(r["new_x"]), torch.randn_like(r["new_u"])
-    g = be.kkt_backward(p["C"], p["c"], p["F"], f, r["new_x"], r["new_u"], gx, gu, opts)
-    torch.cuda.synchronize()
     h = lambda t: None if t is None else host(t).astype(np.float64)
     o = O.kkt_backward(h(p["C"]), h(p["c"]), h(p["F"]), h(f), h(r["new_x"]), h(r["new_u"]), h(gx), h(gu),
                        -0.5 if bounded else None, 0.5 if bounded else None, lockstep=False)
-    for k in ("dx_init", "dC", "dc", "dF", "df"):
-        if o[k] is None or o[k].size == 0:
-            assert g[k] is None or g[k].numel() == 0
-            continue
-        scale = max(1.0, np.abs(o[k]).max())
-        np.testing.assert_allclose(host(g[k]) / scale, o[k] / scale, rtol=0, atol=2e-4, err_msg=k)
+    # C vouched symmetric (MPC_OPT_C_SYMMETRIC): the 12/4 shape then takes the one-launch backward (mpc_lqr_kkt_fused)
+    for promise in (False, True):
+        opts.c_symmetric = promise
+        g = be.kkt_backward(p["C"], p["c"], p["F"], f, r["new_x"], r["new_u"], gx, gu, opts)
+        torch.cuda.synchronize()
+        for k in ("dx_init", "dC", "dc", "dF", "df"):
+            if o[k] is None or o[k].size == 0:
+                assert g[k] is None or g[k].numel() == 0
+                continue
+            scale = max(1.0, np.abs(o[k]).max())
+            np.testing.assert_allclose(host(g[k]) / scale, o[k] / scale, rtol=0, atol=2e-4, err_msg="%s promise=%s" % (k, promise))
 
 
 @pytest.mark.parametrize("name", ["jac_unconstrained", "jac_constrained"])

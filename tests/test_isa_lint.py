@@ -36,10 +36,49 @@ def _findings(name):
     return out
 
 
-@pytest.mark.parametrize("tu,kernels", [("lqr_dpp16", 4), ("lqr_dpp16_ring2", 5)])
+def _metadata(name):
+    """{kernel: {sgpr_spill_count, vgpr_spill_count, private_segment_fixed_size, vgpr_count}} from the code object notes"""
+    import re
+    import isa_lint
+    text = "\n".join(isa_lint.assembly(name))
+    out = {}
+    for b in text.split("- .agpr_count")[1:]:
+        nm = re.search(r"\.name:\s+(\S+)", b)
+        if nm:
+            out[nm.group(1)] = {k: int(re.search(r"\." + k + r":\s+(\d+)", b).group(1))
+                                for k in ("sgpr_spill_count", "vgpr_spill_count", "private_segment_fixed_size", "vgpr_count")}
+    return out
+
+
+# Scalar-register spills per kernel, as built for round 3 (+10 % head room): a spilled SGPR is a v_writelane / v_readlane
+# pair in the loops (DESIGN.md 8.7), cheap one by one, and the count crept from 162 to 486 over round 2 unnoticed.  A
+# change that pushes a kernel past its line here has to look at where the new spills execute (tools/isa_lint.py --loops).
+SGPR_SPILL_LIMITS = {
+    "lqr_dpp16": {"kernelILi0E": 200, "kernelILi1E": 440, "kernelILi2E": 550, "kernelILi3E": 160, "kkt_fused": 8},
+    "lqr_dpp16_ring2": {"kernelILi0E": 140, "kernelILi1E": 425, "kernelILi2E": 315, "kernelILi3E": 170, "lqr_kkt_dpp16": 0},
+    "lqr_mfma40": {"kernelILi0E": 75, "kernelILi1E": 105, "kernelILi2E": 150},
+    "lqr_mfma16": {"ILb1ELi0E": 35, "ILb1ELi1E": 45, "ILb1ELi2E": 80, "ILb0ELi0E": 215, "ILb0ELi1E": 205, "ILb0ELi2E": 305},
+}
+
+
+@pytest.mark.parametrize("tu", sorted(SGPR_SPILL_LIMITS))
+def test_no_vector_spills_no_scratch_and_bounded_scalar_spills(tu):
+    """Every fused kernel: nothing in scratch memory, no spilled vector register, scalar spills under their recorded line."""
+    md = _metadata(tu)
+    seen = set()
+    for k, v in md.items():
+        assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (k, v)
+        for pat, lim in SGPR_SPILL_LIMITS[tu].items():
+            if pat in k:
+                seen.add(pat)
+                assert v["sgpr_spill_count"] <= lim, (k, v["sgpr_spill_count"], lim)
+    assert seen == set(SGPR_SPILL_LIMITS[tu]), (seen, list(md))
+
+
+@pytest.mark.parametrize("tu,kernels", [("lqr_dpp16", 6), ("lqr_dpp16_ring2", 5)])
 def test_dpp16_kernels_keep_their_arrays_in_registers_and_their_dma_queue_full(tu, kernels):
-    """Both compilations of lqr_dpp16.hip (csrc/Makefile): the 4-slot ring (step kernel modes 0..3) and the 2-slot one
-    (the same four + the KKT kernel)."""
+    """Both compilations of lqr_dpp16.hip (csrc/Makefile): the 4-slot ring (step kernel modes 0..3 + the two fused KKT
+    backward kernels) and the 2-slot one (the same four + the three-launch KKT gradient kernel)."""
     f = _findings(tu)
     assert len(f) == kernels
     for k, v in f.items():
