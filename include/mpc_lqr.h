@@ -261,6 +261,11 @@ typedef struct mpc_mlp_dynamics {
     const void *b[MPC_MLP_MAX_LAYERS];
 } mpc_mlp_dynamics;
 
+/* Which of the two calls below take this network at these sizes (widths and the 160 KiB of LDS the staged kernels work
+ * in; pointers are not looked at): bit 0 = mpc_mlp_rollout, bit 1 = mpc_mlp_linearize.  0 = neither (the caller keeps
+ * calling the module itself). */
+int mpc_mlp_supported(const mpc_mlp_dynamics *net, int n_state, int n_ctrl);
+
 /* device scratch (16-byte aligned) the two calls below need for the re-packed weights */
 int64_t mpc_mlp_workspace_bytes(const mpc_mlp_dynamics *net);
 

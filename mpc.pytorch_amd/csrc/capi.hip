@@ -427,6 +427,8 @@ int64_t mpc_mlp_workspace_bytes(const mpc_mlp_dynamics *net)
     return fl * 4 + 256;
 }
 
+int mpc_mlp_supported(const mpc_mlp_dynamics *net, int n_state, int n_ctrl) { return nn_budget(net, n_state, n_ctrl); }
+
 int mpc_mlp_rollout(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_mlp_dynamics *net, const void *K,
                     const void *k, const void *old_costs, const mpc_lqr_outputs *out, void *workspace,
                     int64_t workspace_bytes, void *stream)

@@ -72,6 +72,7 @@ bool mfma40_supported(const StepParams<float> &p);
 int launch_step_mfma40(const StepParams<float> &p, hipStream_t st);
 
 // NNDynamics inside the kernels: rollout / line search and Jacobian on MFMA, 16 problems per wave (nn_dynamics.hip)
+int nn_budget(const mpc_mlp_dynamics *net, int ns, int nc);     // bit 0: the rollout kernels take this network, bit 1: the linearisation ones
 int launch_nn_rollout(const StepParams<float> &p, const mpc_mlp_dynamics *net, void *workspace, int64_t bytes, hipStream_t st);
 int launch_nn_linearize(const mpc_mlp_dynamics *net, long N, int ns, int nc, const float *x, const float *u, float *F,
                         float *f, void *workspace, int64_t bytes, hipStream_t st);

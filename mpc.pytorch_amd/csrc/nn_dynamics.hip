@@ -822,6 +822,31 @@ template <typename K> void allow_lds(K kernel, size_t lds)
 
 }  // namespace
 
+// Does the general (LDS-staged) kernel of either entry point fit a network of these layer widths?  The same two budget
+// tests the launchers below apply -- exported as mpc_mlp_supported so that a caller can ask BEFORE it routes a module here
+// (a 1024-unit layer is a legal NNDynamics, it just keeps the host-driven path).  bit 0: rollout, bit 1: linearisation.
+int nn_budget(const mpc_mlp_dynamics *net, int ns, int nc)
+{
+    if (!net || net->n_layers < 1 || net->n_layers > MPC_MLP_MAX_LAYERS || ns < 1 || ns > 16 || nc < 1) return 0;
+    if (net->widths[0] != ns + nc || net->widths[net->n_layers] != ns) return 0;
+    int wp[MPC_MLP_MAX_LAYERS + 1], total = 0, hid = 16;
+    for (int l = 0; l <= net->n_layers; ++l) {
+        if (net->widths[l] < 1 || net->widths[l] > 4096) return 0;
+        wp[l] = pad16(net->widths[l]);
+    }
+    for (int l = 0; l < net->n_layers; ++l) total += wp[l + 1] * (wp[l] + 4) + wp[l + 1];
+    for (int l = 1; l < net->n_layers; ++l) hid = wp[l] > hid ? wp[l] : hid;
+    const int TS = wp[0] + 4, ZS = hid + 4, NTJ = wp[0] >> 4, L = net->n_layers;
+    int GT = 1;
+    for (int l = 1; l < L; ++l) GT = (wp[l] >> 4) * NTJ > GT ? (wp[l] >> 4) * NTJ : GT;
+    const size_t wbytes = (size_t)total * 4;
+    const size_t roll = (size_t)(2 * 16 * TS + 2 * 16 * ZS) * 4;
+    const size_t lin = (size_t)(16 * TS + (L > 1 ? L - 1 : 1) * 16 * ZS + 2 * GT * 64 * 4) * 4;
+    auto fits = [&](size_t per_wave) { return (wbytes <= WEIGHTS_IN_LDS_MAX && wbytes + per_wave <= LDS_MAX) || per_wave <= LDS_MAX; };
+    const bool fast = L == 2 && wp[0] == 16 && wp[1] <= 128;          // the register-resident kernels: no staging at all
+    return ((fast || fits(roll)) ? 1 : 0) | ((fast || fits(lin)) ? 2 : 0);
+}
+
 int launch_nn_rollout(const StepParams<float> &p, const mpc_mlp_dynamics *net, void *workspace, int64_t bytes, hipStream_t st)
 {
     MlpDesc d;

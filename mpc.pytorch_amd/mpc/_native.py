@@ -107,11 +107,25 @@ class MlpSpec:
 
     @staticmethod
     def supported(weights, activation, like):
-        """fp32 on the device of `like`, at most four layers, n_state <= 16 (the kernels' limits)."""
-        return (like.is_cuda and like.dtype == torch.float32 and 1 <= len(weights) <= MLP_MAX_LAYERS
+        """fp32 on the device of `like`, at most four layers, n_state <= 16, and layer widths whose staging areas fit the
+        160 KiB of LDS the kernels work in -- the library's own test (mpc_mlp_supported: both the rollout and the
+        linearisation kernel must take the network, e.g. NNDynamics(4, 1, [1024]) does not and keeps the module path)."""
+        if not (like.is_cuda and like.dtype == torch.float32 and 1 <= len(weights) <= MLP_MAX_LAYERS
                 and activation in ACT_CODES and weights[-1].shape[0] <= 16
                 and all(W.shape[0] <= 4096 for W in weights)
-                and all(W.is_cuda and W.dtype == torch.float32 for W in weights))
+                and all(W.is_cuda and W.dtype == torch.float32 for W in weights)):
+            return False
+        return MlpSpec.widths_supported([weights[0].shape[1]] + [W.shape[0] for W in weights])
+
+    @staticmethod
+    def widths_supported(widths):
+        """mpc_mlp_supported for a network of these layer widths ([n_state + n_ctrl, hidden..., n_state])."""
+        e = MlpDynamics()
+        e.n_layers = len(widths) - 1
+        for l, w in enumerate(widths):
+            e.widths[l] = int(w)
+        ns = int(widths[-1])
+        return int(load().mpc_mlp_supported(ctypes.byref(e), ns, int(widths[0]) - ns)) == 3
 
     def to_struct(self, like):
         e = MlpDynamics()
@@ -141,7 +155,7 @@ EXPORTS = ("mpc_lqr_abi_version", "mpc_lqr_build_info", "mpc_lqr_last_error", "m
            "mpc_lqr_step", "mpc_lqr_impl_supported", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_lqr_kkt_prepare",
            "mpc_pnqp", "mpc_pnqp_lu", "mpc_traj_cost", "mpc_env_traj_cost", "mpc_env_linearize", "mpc_select_best",
            "mpc_mlp_workspace_bytes", "mpc_mlp_rollout", "mpc_mlp_linearize",
-           "mpc_lqr_kkt_fused_supported", "mpc_lqr_kkt_fused_workspace_bytes", "mpc_lqr_kkt_fused")
+           "mpc_mlp_supported", "mpc_lqr_kkt_fused_supported", "mpc_lqr_kkt_fused_workspace_bytes", "mpc_lqr_kkt_fused")
 
 _lib = None
 
@@ -191,6 +205,7 @@ def load():
     MP = ctypes.POINTER(MlpDynamics)
     L.mpc_mlp_workspace_bytes.restype = _i64
     L.mpc_mlp_workspace_bytes.argtypes = [MP]
+    L.mpc_mlp_supported.argtypes = [MP, ctypes.c_int, ctypes.c_int]
     L.mpc_mlp_rollout.argtypes = [PP, OP, MP, _vp, _vp, _vp, UP, _vp, _i64, _vp]
     L.mpc_mlp_linearize.argtypes = [MP, ctypes.c_int, ctypes.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
     if L.mpc_lqr_abi_version() != ABI_VERSION:

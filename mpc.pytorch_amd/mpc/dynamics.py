@@ -65,6 +65,7 @@ class NNDynamics(nn.Module):
         """(Re)build the views the reference exposes: per-layer activations `acts`, weights `Ws`."""
         hidden = len(self.fcs) - 1
         self.acts = [_ACTIVATIONS[self.activation]] * hidden + [lambda z: z]
+        self._stock_acts = list(self.acts)        # native_net: a caller that swaps an activation keeps the module path
         self.Ws = [layer.weight for layer in self.fcs]
         self.zs = []
 
@@ -93,9 +94,16 @@ class NNDynamics(nn.Module):
         when this network / tensor is outside their limits (fp32 on the device, <= 4 layers, n_state <= 16) -- the
         caller then calls the module timestep by timestep like the reference (mpc/lqr_step.py:223-225)."""
         from ._native import MlpSpec
+        # the kernels rebuild the computation from fcs / activation / passthrough: a subclass that overrides forward
+        # (input normalisation, extra terms), a changed self.acts or a registered forward hook would be bypassed
+        if type(self).forward is not NNDynamics.forward or self._forward_hooks or self._forward_pre_hooks:
+            return None
+        if len(self.acts) != len(self.fcs) or any(a is not b for a, b in zip(self.acts, self._stock_acts)):
+            return None
         weights = [layer.weight for layer in self.fcs]
         if not MlpSpec.supported(weights, self.activation, like):
             return None
+        self.zs = []          # (the kernels do not fill the activations grad_input re-uses: a stale set must not pass for a fresh one)
         return MlpSpec(weights, [layer.bias for layer in self.fcs], self.activation, self.passthrough)
 
     def _slope(self, z):
@@ -144,6 +152,8 @@ class CtrlPassthroughDynamics(nn.Module):
 
     def native_net(self, like):
         """Around an NNDynamics the kernels can run (fp32, augmented n_state <= 16): the augmented network, else None."""
+        if type(self).forward is not CtrlPassthroughDynamics.forward or self._forward_hooks or self._forward_pre_hooks:
+            return None
         inner = getattr(self.dynamics, "native_net", None)
         net = inner(like) if inner is not None and not isinstance(self.dynamics, CtrlPassthroughDynamics) else None
         if net is None or net.n_state + net.n_ctrl > 16:

@@ -190,46 +190,67 @@ def _module_rollout(n_state, n_ctrl, T, x_init, K, k, cur_x, cur_u, old_cost, tr
 
 class _AsyncHostScalar(torch.Tensor):
     """A 1-element CPU tensor whose value arrives by an asynchronous device->host copy; the first torch operation
-    that touches it (float(), .item(), printing, arithmetic, .numpy()) first waits for the stream the copy was
-    enqueued on.  What `LQRStep(...)` returns as `n_total_qp_iter`: the reference hands back a CPU float tensor
-    there (mpc/lqr_step.py:308) and pays a device synchronisation for it in every forward; here nothing waits
-    unless somebody looks."""
+    that touches it (float(), .item(), printing, arithmetic, .numpy(), torch.stack([...]), torch.add(x, other=...))
+    first waits for the EVENT recorded behind the copy -- not for the whole stream -- and moves the value out of its
+    pinned landing slot into storage of its own (the slots are a ring that later solves reuse).  What `LQRStep(...)`
+    returns as `n_total_qp_iter`: the reference hands back a CPU float tensor there (mpc/lqr_step.py:308) and pays a
+    device synchronisation for it in every forward; here nothing waits unless somebody looks."""
 
     @staticmethod
-    def __new__(cls, host, waiter):
+    def __new__(cls, host, event):
         t = torch.Tensor._make_subclass(cls, host)
-        t._waiter = waiter
+        t._event = event
         return t
+
+    def _settle(self):
+        ev = getattr(self, "_event", None)
+        if ev is not None:
+            self._event = None
+            ev.synchronize()
+            with torch._C.DisableTorchFunctionSubclass():
+                own = torch.Tensor.clone(self)
+                torch.Tensor.set_(self, own.untyped_storage(), 0, own.shape, own.stride())
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
-        for a in args:
-            w = getattr(a, "_waiter", None) if isinstance(a, cls) else None
-            if w is not None:
-                a._waiter = None
-                w()
+        from torch.utils._pytree import tree_flatten
+        for a in tree_flatten((args, kwargs or {}))[0]:          # nested lists / tuples / keyword arguments too
+            if isinstance(a, cls):
+                a._settle()
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **(kwargs or {}))
 
 
-_PINNED_RING = {}      # device index -> [pinned float32 tensor of _RING slots, next slot]
+_PINNED_RING = {}      # device index -> [pinned float32 tensor of _RING slots, next slot, the event guarding each slot]
 _RING = 256
 
 
 def _host_scalar_async(dev_scalar):
     """int32 / float device tensor [1] -> CPU float tensor [1], without synchronising (see _AsyncHostScalar).
-    The pinned landing slots are a ring per device: a value is valid until _RING later solves have been issued."""
+    The pinned landing slots are a ring per device; a value leaves its slot the first time it is looked at, and a slot
+    is only written again once the copy that last used it has completed (its event is waited for: 256 solves later,
+    i.e. never in practice)."""
     if not dev_scalar.is_cuda:
         return dev_scalar.to(torch.float32).reshape(1).cpu()
     key = dev_scalar.device.index
     ring = _PINNED_RING.get(key)
     if ring is None:
-        ring = _PINNED_RING[key] = [torch.zeros(_RING, dtype=torch.float32).pin_memory(), 0]
-    slot = ring[0][ring[1]:ring[1] + 1]
-    ring[1] = (ring[1] + 1) % _RING
+        ring = _PINNED_RING[key] = [torch.zeros(_RING, dtype=torch.float32).pin_memory(), 0, [None] * _RING]
+    i = ring[1]
+    ring[1] = (i + 1) % _RING
+    prev = ring[2][i]
+    if prev is not None:
+        prev[0].synchronize()
+        holder = prev[1]()
+        if holder is not None:
+            holder._settle()              # an unread value still living in the slot: move it out before the slot is reused
+    slot = ring[0][i:i + 1]
     slot.copy_(dev_scalar.to(torch.float32).reshape(1), non_blocking=True)
-    stream = torch.cuda.current_stream(dev_scalar.device)
-    return _AsyncHostScalar(slot, stream.synchronize)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev_scalar.device))
+    out = _AsyncHostScalar(slot, ev)
+    ring[2][i] = (ev, weakref.ref(out))
+    return out
 
 
 class _StepConfig:

@@ -65,3 +65,20 @@ class _LazyIterCount:
     def __mul__(self, o): return self._get() * o
     def __rmul__(self, o): return o * self._get()
     def __neg__(self): return -self._get()
+    def __pos__(self): return +self._get()
+    def __abs__(self): return abs(self._get())
+    def __truediv__(self, o): return self._get() / o
+    def __rtruediv__(self, o): return o / self._get()
+    def __floordiv__(self, o): return self._get() // o
+    def __rfloordiv__(self, o): return o // self._get()
+    def __mod__(self, o): return self._get() % o
+    def __rmod__(self, o): return o % self._get()
+    def __pow__(self, o): return self._get() ** o
+    def __rpow__(self, o): return o ** self._get()
+    def __divmod__(self, o): return divmod(self._get(), o)
+    def __round__(self, n=None): return round(self._get(), n) if n is not None else self._get()
+
+    def __getattr__(self, name):           # anything else an int has (bit_length, to_bytes, real, ...): the int's own
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._get(), name)

@@ -124,6 +124,10 @@ def mpc_forward_sharded(ctrl, x_init, cost, dx, group=None, lockstep=False, gath
     # A shard that raises UnconvergedError (exit_unconverged=True, mpc/mpc.py:321-324) must not leave the other
     # ranks blocked in the collective below: every rank learns whether ANY shard failed (one 1-word MAX
     # all-reduce, only when a collective follows) and then all raise, or none does.
+    # (only when the solve CAN raise it: exit_unconverged with detach_unconverged, mpc/mpc.py:321-324 -- otherwise the
+    # agreement would be a collective and a host synchronisation per forward for nothing.  Any other exception on one
+    # rank is a programming error on every rank alike; it is reported to the others the same way so that nobody hangs.)
+    can_raise = bool(ctrl.exit_unconverged and ctrl.detach_unconverged)
     err = None
     try:
         x, u, costs = local(_cut(x_init, lo, hi, 0), cost, dx)
@@ -131,10 +135,17 @@ def mpc_forward_sharded(ctrl, x_init, cost, dx, group=None, lockstep=False, gath
         if world == 1 or not (gather or lockstep):
             raise
         err = e
-    if world > 1 and (gather or lockstep):
+    except BaseException as e:
+        if world > 1 and (gather or lockstep) and can_raise:
+            bad = torch.tensor([2.0], device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+        raise
+    if world > 1 and (gather or lockstep) and can_raise:
         dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
         bad = torch.tensor([0.0 if err is None else 1.0], device=dev)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+        if float(bad.item()) > 1.5 and err is None:
+            raise RuntimeError("MPC (sharded): another rank failed inside its solve")
         if float(bad.item()) > 0:
             raise err if err is not None else UnconvergedError(
                 "MPC (sharded): another rank's block of problems did not converge (exit_unconverged=True)")

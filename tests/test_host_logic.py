@@ -692,3 +692,74 @@ def test_augmented_network_is_the_ctrl_passthrough_map(hidden):
         np.testing.assert_allclose(out.numpy(), want.numpy(), rtol=1e-12, atol=1e-12)
     # on CPU tensors (or fp64) the modules keep the host-driven path
     assert net.native_net(torch.zeros(1)) is None and CtrlPassthroughDynamics(net).native_net(torch.zeros(1)) is None
+
+
+# ---------------------------------------------------------------------------------------------
+# round-2 advisor findings
+# ---------------------------------------------------------------------------------------------
+def test_async_host_scalar_waits_wherever_it_is_buried_and_leaves_its_ring_slot():
+    """n_total_qp_iter arrives by an asynchronous copy into a pinned ring slot.  Every way of handing it to torch must wait
+    for the copy first -- also nested in a list (torch.stack / torch.cat) or passed by keyword -- and the value must move
+    out of the slot, which a later solve reuses."""
+    from mpc.lqr_step import _AsyncHostScalar
+
+    class LateCopy:                       # stands in for the CUDA event: the "copy" lands when somebody waits for it
+        def __init__(self, slot, value):
+            self.slot, self.value, self.waits = slot, value, 0
+
+        def synchronize(self):
+            self.waits += 1
+            self.slot.fill_(self.value)
+
+    def fresh(value):
+        slot = torch.zeros(1)
+        ev = LateCopy(slot, value)
+        return _AsyncHostScalar(slot, ev), slot, ev
+
+    n, slot, ev = fresh(7.0)
+    assert float(torch.stack([n])[0]) == 7.0 and ev.waits == 1
+    n, slot, ev = fresh(5.0)
+    assert float(torch.cat((n, torch.ones(1)))[0]) == 5.0
+    n, slot, ev = fresh(3.0)
+    assert float(torch.add(torch.ones(1), other=n)) == 4.0
+    n, slot, ev = fresh(9.0)
+    assert float(n) == 9.0 and ev.waits == 1
+    slot.fill_(-1.0)                      # the ring comes round: a later solve lands in the same slot
+    assert float(n) == 9.0 and n.item() == 9.0 and ev.waits == 1
+
+
+def test_lazy_iter_count_quacks_like_an_int():
+    from mpc.pnqp import _LazyIterCount
+    n = _LazyIterCount(torch.tensor([3, 7, 5]), torch.tensor([0, 0, 0]))
+    assert n / 2 == 3.5 and n // 2 == 3 and n % 4 == 3 and n ** 2 == 49 and abs(n) == 7 and divmod(n, 4) == (1, 3)
+    assert 14 / n == 2 and 15 // n == 2 and 2 ** n == 128 and n.bit_length() == 3 and list(range(n))[-1] == 6
+
+
+def test_network_kernels_are_offered_only_what_they_take(monkeypatch):
+    """NNDynamics.native_net: the library's own LDS-budget test decides (mpc_mlp_supported), and a module whose forward is
+    not the stock one -- a subclass overriding it, a registered hook, a swapped activation -- keeps the module path."""
+    from mpc import _native
+    from mpc.dynamics import NNDynamics, CtrlPassthroughDynamics
+    W = _native.MlpSpec.widths_supported
+    assert W([16, 100, 12]) and W([16, 300, 300, 12]) and W([5, 800, 4])
+    assert not W([5, 1024, 4]) and not W([20, 512, 12]) and not W([5, 2048, 4])       # the advisor's examples: too wide for the LDS
+    monkeypatch.setattr(_native.MlpSpec, "supported", staticmethod(lambda weights, activation, like: True))
+    like = torch.zeros(1)
+    assert NNDynamics(3, 1, [8]).native_net(like) is not None
+
+    class Normalised(NNDynamics):
+        def forward(self, x, u):
+            return super().forward(x / 2.0, u)
+    assert Normalised(3, 1, [8]).native_net(like) is None
+    hooked = NNDynamics(3, 1, [8])
+    hooked.register_forward_hook(lambda m, i, o: o)
+    assert hooked.native_net(like) is None
+    swapped = NNDynamics(3, 1, [8])
+    swapped.acts[0] = torch.tanh
+    assert swapped.native_net(like) is None
+    plain = NNDynamics(3, 1, [8])
+    plain(torch.zeros(2, 3), torch.zeros(2, 1))
+    assert len(plain.zs) == 1
+    plain.native_net(like)
+    assert plain.zs == []                 # the kernels do not refresh the activations grad_input re-uses
+    assert CtrlPassthroughDynamics(NNDynamics(3, 1, [8])).native_net(like) is not None
