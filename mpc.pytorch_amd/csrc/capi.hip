@@ -316,7 +316,7 @@ int mpc_lqr_kkt_grads(const mpc_lqr_problem *p, const void *dx, const void *du, 
             return launch_kkt_dpp16(sp, (const float *)dx, (const float *)du, (const float *)dl_dx, (float *)dC,
                                     (float *)dc, (float *)dF, (float *)df, (float *)dx_init, st);
         // other shapes up to n = 64: costate recursion per wavefront + fully parallel outer products
-        if (kkt_wave_supported(sp, (const float *)dC, (const float *)dF))
+        if (kkt_wave_supported(sp, (const float *)dx, (const float *)du, (const float *)dl_dx, (const float *)dC, (const float *)dF))
             return launch_kkt_wave(sp, (const float *)dx, (const float *)du, (const float *)dl_dx, (float *)dC,
                                    (float *)dc, (float *)dF, (float *)df, (float *)dx_init, st);
         return launch_kkt_grads<float>(sp, (const float *)dx, (const float *)du, (const float *)dl_dx,

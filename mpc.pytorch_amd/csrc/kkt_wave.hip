@@ -37,45 +37,71 @@ __device__ __forceinline__ void dma_block(const float *g, char *lds, int bytes, 
                                              (lds_void_t *)(lds + off), 16, 0, 0);
 }
 
+// s_waitcnt vmcnt(n) for a run-time n (the immediate has to be a constant): at most n of the newest vector-memory
+// operations may still be in flight
+__device__ __forceinline__ void wait_newer(int n)
+{
+#define MPC_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        MPC_W(0) MPC_W(1) MPC_W(2) MPC_W(3) MPC_W(4) MPC_W(5) MPC_W(6) MPC_W(7) MPC_W(8) MPC_W(9) MPC_W(10) MPC_W(11) MPC_W(12)
+        MPC_W(13) MPC_W(14) MPC_W(15) MPC_W(16) MPC_W(17) MPC_W(18) MPC_W(19) MPC_W(20) MPC_W(21) MPC_W(22) MPC_W(23) MPC_W(24)
+        MPC_W(25) MPC_W(26) MPC_W(27) MPC_W(28) MPC_W(29) MPC_W(30) MPC_W(31) MPC_W(32) MPC_W(33) MPC_W(34) MPC_W(35) MPC_W(36)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef MPC_W
+}
+
+// NSLOT ring slots of [C_t | F_t | record]; record = four rows of 64 floats: tau* | dtau | c_x | dl_dx.  Everything a
+// timestep needs arrives by LDS-DMA NSLOT - 1 steps ahead (round 3: one step ahead and `vmcnt(0)` per step left a
+// wavefront waiting out a full HBM round trip every timestep -- 3.8 us per step at config 5, 0.244 ms of its backward);
+// the wait counts the DMA instructions of the newer stages, every stage issues the same number of them.
+template <int NSLOT>
 __global__ void __launch_bounds__(64) kkt_costate_kernel(StepParams<float> p, const float *dx, const float *du,
                                                          const float *dl_dx, float *dF, float *df, float *dx_init)
 {
-    // two slots of [C_t | F_t]; the block of step t-1 streams in while step t is summed
     extern __shared__ __attribute__((aligned(16))) char kkt_lds[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T, B = p.B;
-    const int cbytes = n * n * 4, fbytes = ns * n * 4, slot_bytes = cbytes + fbytes;
+    const int cbytes = n * n * 4, fbytes = ns * n * 4, slot_bytes = cbytes + fbytes + 1024;
+    const int nd = (cbytes + 1023) / 1024 + (T > 1 ? (fbytes + 1023) / 1024 : 0) + 1;      // DMA instructions per stage
     const bool st = lane < ns;
     const int li = st ? lane : 0;
+    // the record's lane -> source map: row = lane / 16, granule g = lane % 16 of that row
+    const int row = lane >> 4, g = lane & 15;
+    const float *rsrc = nullptr;
+    long rstep = 0;
+    if (row == 0) {
+        if (4 * g < ns) { rsrc = p.cur_x + (long)b * ns + 4 * g; rstep = (long)B * ns; }
+        else if (4 * g < n) { rsrc = p.cur_u + (long)b * nc + (4 * g - ns); rstep = (long)B * nc; }
+    } else if (row == 1) {
+        if (4 * g < ns) { rsrc = dx + (long)b * ns + 4 * g; rstep = (long)B * ns; }
+        else if (4 * g < n) { rsrc = du + (long)b * nc + (4 * g - ns); rstep = (long)B * nc; }
+    } else if (row == 2) {
+        if (4 * g < ns) { rsrc = p.c + (long)b * p.c_sb + 4 * g; rstep = p.c_st; }
+    } else if (4 * g < ns) { rsrc = dl_dx + (long)b * ns + 4 * g; rstep = (long)B * ns; }
     auto issue = [&](int t, int slot) {
+        t = t >= 0 ? t : 0;                                   // past the end: stage 0 again, the count per stage stays fixed
         char *base = kkt_lds + slot * slot_bytes;
         dma_block(p.C + (long)t * p.C_st + (long)b * p.C_sb, base, cbytes, lane);
-        if (t < T - 1) dma_block(p.F + (long)t * p.F_st + (long)b * p.F_sb, base + cbytes, fbytes, lane);
-    };
-    auto vectors = [&](int t, float &tau, float &d, float &cc, float &gx) {
-        const long tb = (long)t * B + b;
-        tau = 0.f; d = 0.f;
-        if (lane < ns) { tau = p.cur_x[tb * ns + lane]; d = dx[tb * ns + lane]; }
-        else if (lane < n) { tau = p.cur_u[tb * nc + (lane - ns)]; d = du[tb * nc + (lane - ns)]; }
-        cc = st ? p.c[(long)t * p.c_st + (long)b * p.c_sb + lane] : 0.f;
-        gx = st ? dl_dx[tb * ns + lane] : 0.f;
+        if (T > 1) dma_block(p.F + (long)(t < T - 1 ? t : T - 2) * p.F_st + (long)b * p.F_sb, base + cbytes, fbytes, lane);
+        if (rsrc)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(rsrc + (long)t * rstep), (lds_void_t *)(base + cbytes + fbytes), 16, 0, 0);
     };
     float lam = 0.f, dlam = 0.f;
-    float tau, d, cc, gx;
-    issue(T - 1, 0);
-    vectors(T - 1, tau, d, cc, gx);
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i) issue(T - 1 - i, i);
     int slot = 0;
     for (int t = T - 1; t >= 0; --t) {
-        // everything in flight is the stage of step t (and parked stores): wait, then start step t-1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float tau_n = 0.f, d_n = 0.f, cc_n = 0.f, gx_n = 0.f;
-        if (t > 0) {
-            issue(t - 1, slot ^ 1);
-            vectors(t - 1, tau_n, d_n, cc_n, gx_n);
-        }
-        const long tb = (long)t * B + b;
+        wait_newer((NSLOT - 2) * nd);
         const float *Cl = (const float *)(kkt_lds + slot * slot_bytes);
         const float *Fl = (const float *)(kkt_lds + slot * slot_bytes + cbytes);
+        const float *Rl = (const float *)(kkt_lds + slot * slot_bytes + cbytes + fbytes);
+        const float tau = lane < n ? Rl[lane] : 0.f, d = lane < n ? Rl[64 + lane] : 0.f;
+        const float cc = st ? Rl[128 + lane] : 0.f, gx = st ? Rl[192 + lane] : 0.f;
+        // the slot the PREVIOUS timestep worked on is free (its reads fed that timestep's products): the stage NSLOT - 1
+        // steps on goes there
+        issue(t - (NSLOT - 1), (slot + NSLOT - 1) % NSLOT);
+        const long tb = (long)t * B + b;
         float r1 = cc, r2 = -gx;
         // (C tau)[i], (C dtau)[i] for the state rows, through column i of the symmetric C
         for (int j = 0; j < n; j += 4) {
@@ -95,17 +121,16 @@ __global__ void __launch_bounds__(64) kkt_costate_kernel(StepParams<float> p, co
                     r2 = fmaf(fm, lane_bcast(dlam, m + v), r2);
                 }
             }
-            if (st) {
-                float *park = dF + tb * (long)(ns * n);
-                park[lane] = lam;
-                park[ns + lane] = dlam;
-                if (df) df[tb * ns + lane] = -dlam;                               // :397-400
-            }
+        }
+        if (t < T - 1 && st) {
+            float *park = dF + tb * (long)(ns * n);
+            park[lane] = lam;
+            park[ns + lane] = dlam;
+            if (df) df[tb * ns + lane] = -dlam;                                   // :397-400
         }
         lam = r1;
         dlam = r2;
-        tau = tau_n; d = d_n; cc = cc_n; gx = gx_n;
-        slot ^= 1;
+        slot = (slot + 1) % NSLOT;
     }
     if (st) dx_init[(long)b * ns + lane] = -dlam;                                 // :404
 }
@@ -208,12 +233,15 @@ int launch_traj_wave(const StepParams<float> &p, float *x, hipStream_t st)
     return MPC_OK;
 }
 
-bool kkt_wave_supported(const StepParams<float> &p, const float *dC, const float *dF)
+bool kkt_wave_supported(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, const float *dC,
+                        const float *dF)
 {
     const int n = p.ns + p.nc;
     auto al = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+    // (the small vectors travel as 16-byte granules too: rows of x*, u*, dx, du, dl_dx and c start on 16-byte boundaries)
     return n <= 64 && n % 4 == 0 && p.ns % 4 == 0 && p.ns * n >= 2 * p.ns && p.B > 0 && al(p.C) && (p.T == 1 || al(p.F)) &&
            p.C_st % 4 == 0 && p.C_sb % 4 == 0 && p.F_st % 4 == 0 && p.F_sb % 4 == 0 &&
+           al(p.c) && p.c_st % 4 == 0 && p.c_sb % 4 == 0 && al(p.cur_x) && al(p.cur_u) && al(dx) && al(du) && al(dl_dx) &&
            ((uintptr_t)dC & 15) == 0 && (p.T == 1 || ((uintptr_t)dF & 15) == 0);
 }
 
@@ -221,10 +249,19 @@ int launch_kkt_wave(const StepParams<float> &p, const float *dx, const float *du
                     float *dc, float *dF, float *df, float *dx_init, hipStream_t st)
 {
     const int n = p.ns + p.nc;
-    const size_t lds = 2 * (size_t)(n * n + p.ns * n) * 4;
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_costate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kkt_costate_kernel, dim3(p.B), dim3(64), lds, st, p, dx, du, dl_dx, dF, df, dx_init);
+    // three slots (the DMA two timesteps ahead) while four wavefronts of them fit a CU's 160 KiB, else two
+    const size_t slot = (size_t)(n * n + p.ns * n) * 4 + 1024;
+    const bool deep = 3 * slot * 4 <= 160 * 1024;
+    const size_t lds = (deep ? 3 : 2) * slot;
+    if (deep) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_costate_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kkt_costate_kernel<3>, dim3(p.B), dim3(64), lds, st, p, dx, du, dl_dx, dF, df, dx_init);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_costate_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kkt_costate_kernel<2>, dim3(p.B), dim3(64), lds, st, p, dx, du, dl_dx, dF, df, dx_init);
+    }
     hipLaunchKernelGGL(kkt_outer_kernel, dim3((unsigned)((long)p.T * p.B)), dim3(64), 0, st, p, dx, du, dC, dc, dF);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -63,7 +63,8 @@ template <typename real> int launch_step_tiny(const StepParams<real> &p, hipStre
 bool traj_wave_supported(const StepParams<float> &p);
 int launch_traj_wave(const StepParams<float> &p, float *x, hipStream_t st);
 // costate + outer-product kernels of the KKT backward for n <= 64, f32 (kkt_wave.hip)
-bool kkt_wave_supported(const StepParams<float> &p, const float *dC, const float *dF);
+bool kkt_wave_supported(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, const float *dC,
+                        const float *dF);
 int launch_kkt_wave(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,
                     float *dc, float *dF, float *df, float *dx_init, hipStream_t st);
 

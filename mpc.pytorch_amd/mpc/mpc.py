@@ -288,7 +288,9 @@ class MPC(Module):
             any_improved = (bits & 1) != 0
             if i == 0 and not (bits & 2):
                 self._c_symmetric = True
-                if self.lqr_iter > 2:
+                # (a simulator solve runs on the lane-per-problem kernel, which keeps Q and V general and has no test to
+                #  skip: building two more plans would only cost host time in a loop that is launch-latency bound)
+                if self.lqr_iter > 2 and sim is None:
                     import copy
                     so = copy.copy(opts)
                     so.c_symmetric = True

@@ -96,7 +96,7 @@ def strict_step_check(name, r, o, B, rtol=1e-3, atol=1e-4, cost_rtol=5e-4, cost_
     # error means nothing)
     cost_err = np.abs(host(r["costs"]).astype(np.float64) - o["costs"]) / (1e-12 + np.abs(o["costs"]) + cost_atol / cost_rtol)
     st = host(r["status"])
-    diag(name, ties=int(ties.sum()), alpha_ties=int(alpha_ties.sum()), active_set_ties=int(set_ties.sum()),
+    diag(name, ties=int(ties.sum()), tie_idx=[int(i) for i in np.nonzero(ties)[0][:16]], alpha_ties=int(alpha_ties.sum()), active_set_ties=int(set_ties.sum()),
          worst_x_over_tol=worst["new_x"], worst_u_over_tol=worst["new_u"], over_tol=over,
          cost_rel_err_nontie=float(cost_err[same].max()), median_abs_cost=float(np.median(np.abs(o["costs"]))), cost_rel_err_tie=float(cost_err[ties].max()) if ties.any() else 0.0,
          unconverged_qp=int((st & 1).sum()), nonfinite=int((st & 2 != 0).sum()))
