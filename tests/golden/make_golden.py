@@ -122,6 +122,50 @@ def add_asymmetry(C, which, seed, scale=1.0):
     return out
 
 
+def tie_case(name, which=(150, 773, 1695)):
+    """The problems of the full-size box-constrained test (tests/test_gpu_fullsize.py, case "tight": bench.make_problem(12, 4,
+    50, 4096, seed 0, u_scale 0.2, clamp 0.3), bounds +-0.3) on which a float32 kernel and the float64 oracle end on
+    different active sets: a QP minimiser that sits on its bound to within rounding is "clamped" or "free" by the sign of a
+    1e-7 gradient (mpc/pnqp.py:32), which zeroes or keeps a row of K -- a discontinuity of the reference algorithm itself.
+    The fixture holds what the reference returns on exactly these problems in float32 AND in float64 (per problem), so that a
+    kernel can be held to "one of the branches the reference takes"."""
+    if ONLY is not None and name not in ONLY:
+        return
+    ns, nc, T, B = 12, 4, 50, 4096
+    g = torch.Generator().manual_seed(0)
+    n = ns + nc
+    kw = dict(generator=g, dtype=torch.float32)
+    chunks = []
+    for t0 in range(0, T, 10):                       # the very draws of bench.make_problem
+        A = torch.randn(min(10, T - t0), B, n, n, **kw)
+        chunks.append(A.transpose(2, 3).matmul(A))
+    C = torch.cat(chunks)
+    c = torch.randn(T, B, n, **kw)
+    R = torch.eye(ns) + 0.2 * torch.randn(T - 1, B, ns, ns, **kw) / ns ** 0.5
+    S = torch.randn(T - 1, B, ns, nc, **kw) / ns ** 0.5
+    F = torch.cat((R, S), 3)
+    f = 0.1 * torch.randn(T - 1, B, ns, **kw)
+    x_init = torch.randn(B, ns, **kw)
+    u = (0.2 * torch.randn(T, B, nc, **kw)).clamp(-0.3, 0.3)
+    idx = torch.tensor(list(which))
+    p = dict(C=C[:, idx].contiguous(), c=c[:, idx].contiguous(), F=F[:, idx].contiguous(), f=f[:, idx].contiguous(),
+             x_init=x_init[idx].contiguous(), u=u[:, idx].contiguous())
+    outs32, outs64 = [], []
+    to64 = lambda t: t.double() if torch.is_tensor(t) else t
+    for b in range(len(which)):
+        pb = {k: slice_b(v, b, 0 if k == "x_init" else 1) for k, v in p.items()}
+        outs32.append(run_step(pb, ns, nc, T, u_lower=-0.3, u_upper=0.3))
+        outs64.append(run_step({k: to64(v) for k, v in pb.items()}, ns, nc, T, u_lower=-0.3, u_upper=0.3))
+    cat = lambda outs, key, dim: npy(torch.cat([o[key] for o in outs], dim))
+    save(name, meta=np.array([ns, nc, T, len(which), -1, 10], dtype=np.int64), decay=np.array([0.2]), delta_u=np.array([np.nan]),
+         which=np.array(which), C=npy(p["C"]), c=npy(p["c"]), F=npy(p["F"]), f=npy(p["f"]), x_init=npy(p["x_init"]),
+         cur_u=npy(p["u"]), cur_x=cat(outs32, "cur_x", 1), u_lower=np.array([-0.3]), u_upper=np.array([0.3]),
+         new_x_pp=cat(outs32, "new_x", 1), new_u_pp=cat(outs32, "new_u", 1), costs_pp=cat(outs32, "costs", 0),
+         alphas_pp=cat(outs32, "mean_alphas", 0), n_qp_pp=cat(outs32, "n_qp", 0),
+         new_x_ref64=cat(outs64, "new_x", 1), new_u_ref64=cat(outs64, "new_u", 1), costs_ref64=cat(outs64, "costs", 0),
+         alphas_ref64=cat(outs64, "mean_alphas", 0))
+
+
 def step_case(name, ns, nc, T, B, dtype, seed, with_f=True, bounds=None, mask_seed=None,
               delta_u=None, decay=0.2, max_ls=10, u_scale=0.3, indef=0.0, asym=None, asym_scale=1.0, zero_ctrl=None):
     if ONLY is not None and name not in ONLY:
@@ -652,6 +696,7 @@ if __name__ == "__main__":
     step_case("step_singular_cfg5_f64", 32, 8, 6, 3, f64, 72, bounds=None, zero_ctrl=((0, 5),))     # (float32: the reference's own 8x8 pinverse is noise there)
     step_case("step_singular_small_f64", 4, 2, 8, 3, f64, 73, bounds=None, zero_ctrl=((1, 1),))
     step_case("step_singular_odd_f32", 7, 3, 9, 3, f32, 74, bounds=None, zero_ctrl=((2, 0),))
+    tie_case("ties_tight_f32")
     if ONLY is not None:
         _grad_case("grad_asym_ns_f32", 12, 4, 8, 4, f32, 36, None, asym=(1, 2))
         _grad_case("grad_asym_small_f64", 4, 2, 6, 3, f64, 37, 0.4, asym=(0, 2))

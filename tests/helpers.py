@@ -65,3 +65,21 @@ def keep_problems(d, keep):
                 v = v[:, keep]
         out[k] = v
     return out
+
+
+def check_tie_problems(r, z, rtol=1e-3, atol=1e-4):
+    """tests/golden/ties_tight_f32.npz: problems on which the reference's own float32 and float64 runs end on different
+    active sets (a QP minimiser on its bound to within rounding).  A kernel result must be ONE of the two branches the
+    reference takes, whole trajectory, per problem.  Returns which branch each problem took ("f32" / "f64" / "both")."""
+    took = []
+    for b in range(z["new_u_pp"].shape[1]):
+        ok = {}
+        for name, sfx in (("f32", "_pp"), ("f64", "_ref64")):
+            eu = np.abs(np.asarray(r["new_u"][:, b], np.float64) - z["new_u" + sfx][:, b])
+            ex = np.abs(np.asarray(r["new_x"][:, b], np.float64) - z["new_x" + sfx][:, b])
+            ok[name] = bool((eu <= atol + rtol * np.abs(z["new_u" + sfx][:, b])).all() and
+                            (ex <= atol + rtol * np.abs(z["new_x" + sfx][:, b])).all() and
+                            abs(float(r["costs"][b]) - float(z["costs" + sfx][b])) <= 5e-4 * abs(float(z["costs" + sfx][b])))
+        assert ok["f32"] or ok["f64"], "problem %d (%d of the full batch) follows neither branch of the reference" % (b, int(z["which"][b]))
+        took.append("both" if ok["f32"] and ok["f64"] else ("f32" if ok["f32"] else "f64"))
+    return took

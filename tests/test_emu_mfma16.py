@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, golden
-from helpers import asymmetric_problems, keep_problems, step_kwargs
+from helpers import asymmetric_problems, check_tie_problems, keep_problems, step_kwargs
 
 STEP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "step_*.npz")))
 STEP_CASES = [c for c in STEP_CASES if "cfg5" not in c]      # n = 40 is the generic kernel's
@@ -182,6 +182,19 @@ def test_symmetric_promise_changes_nothing_but_the_test(emu, kernel):
         np.testing.assert_array_equal(keep_problems(a, ~asym)[k], keep_problems(b, ~asym)[k], err_msg=k)
         # (the promise is the caller's: broken, the kernel computes what it computes for the symmetric reading of C)
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+@pytest.mark.parametrize("kernel", ["dpp16", "dpp16_ring2", "mfma16"])
+def test_tie_problems_follow_a_branch_the_reference_takes(emu, kernel):
+    """ties_tight_f32: three problems of the full-size box-constrained test where the float32 and the float64 run of the
+    REFERENCE ITSELF end on different active sets (a whole control flips from bound to bound, the float32 branch even at
+    the lower cost).  The full-size test can only count such problems; here each is held to one of the reference's own
+    two answers."""
+    z = golden("ties_tight_f32")
+    r = emu.lqr_step(kernel=kernel, dma_late=True, **step_kwargs(z))
+    assert (r["status"] & 3 == 0).all()
+    took = check_tie_problems(r, z)
+    assert len(took) == 3
 
 
 def _ns_problem(rng, T, B, indef=0.0, with_f=True):

@@ -131,6 +131,19 @@ def test_lqr_step_parity(be, name):
         assert int(r["qp_iters"].max()) == int(z["n_qp_pp"].max())
 
 
+def test_tie_problems_follow_a_branch_the_reference_takes(be):
+    """tests/golden/ties_tight_f32.npz (make_golden.py: tie_case): the three problems of the full-size "tight" test on which
+    kernels and float64 oracle part ways -- and on which the REFERENCE's own float32 and float64 runs part ways too, by a
+    whole bound-to-bound flip of a control.  Every kernel must land on one of the reference's two answers."""
+    from helpers import check_tie_problems
+    z = golden("ties_tight_f32")
+    for impl in [0] + impls_for(z):
+        r = hip_step(be, z, impl=impl)
+        assert (r["status"] & 3 == 0).all()
+        took = check_tie_problems(r, z)
+        print("impl", impl, "branches", took)
+
+
 @pytest.mark.parametrize("ns,nc,T", [(32, 8, 12), (20, 5, 6), (30, 3, 5), (17, 9, 7), (45, 10, 4), (24, 1, 5)])
 @pytest.mark.parametrize("bounded", [False, True])
 def test_generic_kernel_large_shapes_on_mfma(be, ns, nc, T, bounded):
