@@ -293,23 +293,6 @@ int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double b
                     void *best_x, void *best_u, void *best_costs, void *best_du_norm,
                     int32_t *any_improved, void *max_du_norm, const int32_t *status, void *stream);
 
-/* (8) MPC.forward's whole iLQR loop for a shipped simulator in ONE launch (mpc/mpc.py:245-306; n_ctrl = 1, n_state <= 6,
- *     f32 / f64): per iteration the simulator is linearised at the nominal, the LQR step is taken with the simulator as
- *     true_dynamics, every problem keeps its best iterate (:279-285: the first, or one whose cost is within best_cost_eps
- *     of the best so far), and the batch-wide stop test (:283-306: max ||du|| < eps, or no problem improved for more than
- *     not_improved_lim iterations, or lqr_iter reached) is exchanged between the workgroups inside the kernel.
- *     p: x_init, C, c (+ strides), cur_u = u_init [T,B,1]; F, f, cur_x are not read.  o: bounds, linesearch_decay,
- *     max_linesearch_iter, true_dynamics (required; its `linearize` field is ignored: always in the kernel).
- *     Outputs: best_x [T,B,ns], best_u [T,B,1], best_costs [B], best_du_norm [B] (||du|| of the step that produced the best
- *     iterate), n_iter[1] (iterations run; may be NULL).  workspace: mpc_ilqr_env_workspace_bytes(p, lqr_iter), 16-byte
- *     aligned; it is zeroed / filled by copies enqueued on the same stream.
- *     Returns MPC_E_DIMS when the batch needs more wavefronts than the device holds at once (the iterations synchronise
- *     through a grid barrier): the caller then iterates mpc_lqr_step + mpc_select_best itself. */
-int64_t mpc_ilqr_env_workspace_bytes(const mpc_lqr_problem *p, int lqr_iter);
-int mpc_ilqr_env_solve(const mpc_lqr_problem *p, const mpc_lqr_options *o, int lqr_iter, double eps, double best_cost_eps,
-                       int not_improved_lim, void *best_x, void *best_u, void *best_costs, void *best_du_norm,
-                       int32_t *n_iter, void *workspace, int64_t workspace_bytes, void *stream);
-
 #ifdef __cplusplus
 }
 #endif

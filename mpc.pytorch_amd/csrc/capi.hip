@@ -213,30 +213,6 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
     }
     return launch_step_generic<real>(sp, phase_mask, st);
 }
-template <typename real>
-static int ilqr_env_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, int lqr_iter, double eps, double best_cost_eps,
-                         int not_improved_lim, void *best_x, void *best_u, void *best_costs, void *best_du_norm, int32_t *n_iter,
-                         void *workspace, hipStream_t st)
-{
-    mpc_lqr_outputs out;
-    memset(&out, 0, sizeof(out));
-    StepParams<real> sp = make_params<real>(p, o, &out);
-    sp.env.linearize = 1;
-    const int64_t e = sizeof(real);
-    const int64_t nx = (int64_t)p->T * p->B * p->ns * e, nu = (int64_t)p->T * p->B * e;
-    const int64_t traj = (nx + nu + 15) & ~(int64_t)15;
-    char *w = (char *)workspace;
-    real *xa = (real *)w, *ua = (real *)(w + nx);
-    real *xb = (real *)(w + traj), *ub = (real *)(w + traj + nx);
-    sp.Kk = (real *)(w + 2 * traj);
-    int *sync = (int *)(w + 3 * traj);
-    if (hipMemsetAsync(sync, 0, 16 * (size_t)lqr_iter, st) != hipSuccess ||
-        hipMemcpyAsync(ua, p->cur_u, (size_t)nu, hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return fail(MPC_E_LAUNCH, "ilqr_env_solve: could not enqueue the workspace set-up");
-    return launch_ilqr_env_tiny<real>(sp, xa, ua, xb, ub, (real *)best_x, (real *)best_u, (real *)best_costs, (real *)best_du_norm,
-                                      lqr_iter, (real)eps, (real)best_cost_eps, not_improved_lim, sync, n_iter, st);
-}
-
 }  // namespace mpclqr
 
 using namespace mpclqr;
@@ -248,7 +224,7 @@ int mpc_lqr_abi_version(void) { return MPC_LQR_ABI_VERSION; }
 const char *mpc_lqr_build_info(void)
 {
     return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32>, lqr_step_dpp16<f32>, "
-           "lqr_step_tiny<f32,f64>, lqr_step_mfma40<f32>, nn_rollout<f32>, nn_linearize<f32>, env_linearize, kkt_grads, kkt_fused<f32>, ilqr_env<f32,f64>, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
+           "lqr_step_tiny<f32,f64>, lqr_step_mfma40<f32>, nn_rollout<f32>, nn_linearize<f32>, env_linearize, kkt_grads, kkt_fused<f32>, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
 }
 
 const char *mpc_lqr_last_error(void) { return g_last_error.c_str(); }
@@ -416,40 +392,6 @@ int mpc_env_traj_cost(const mpc_lqr_problem *p, const mpc_env_dynamics *env, voi
     StepParams<double> sp = make_params<double>(p, nullptr, nullptr);
     set_env(sp.env, env);
     return launch_traj_cost<double>(sp, (double *)x, (double *)cost, st);
-}
-
-int64_t mpc_ilqr_env_workspace_bytes(const mpc_lqr_problem *p, int lqr_iter)
-{
-    if (!p || lqr_iter < 1) return 0;
-    const int64_t e = p->dtype == MPC_F64 ? 8 : 4;
-    const int64_t traj = (int64_t)p->T * p->B * (p->ns + 1) * e;           // x and u of one nominal; the gains [T][ns+1][B]
-    return 3 * ((traj + 15) & ~(int64_t)15) + 16 * (int64_t)lqr_iter + 256;
-}
-
-int mpc_ilqr_env_solve(const mpc_lqr_problem *p, const mpc_lqr_options *o, int lqr_iter, double eps, double best_cost_eps,
-                       int not_improved_lim, void *best_x, void *best_u, void *best_costs, void *best_du_norm,
-                       int32_t *n_iter, void *workspace, int64_t workspace_bytes, void *stream)
-{
-    if (!p || !o || !o->true_dynamics) return fail(MPC_E_NULL, "ilqr_env_solve: problem / options / true_dynamics is NULL");
-    if (p->B < 0 || p->T < 2 || p->ns < 1 || p->nc < 1) return fail(MPC_E_DIMS, "need B>=0, T>=2, ns>=1, nc>=1");
-    if (p->dtype != MPC_F32 && p->dtype != MPC_F64) return fail(MPC_E_DTYPE, "dtype must be MPC_F32 or MPC_F64");
-    int rc = check_options(p, o);
-    if (rc) return rc;
-    if (!tiny_supported(p->ns, p->nc)) return fail(MPC_E_DIMS, "ilqr_env_solve: the lane-per-problem kernel needs n_ctrl = 1, n_state <= 6");
-    if (lqr_iter < 1 || lqr_iter > 4096) return fail(MPC_E_ARG, "ilqr_env_solve: lqr_iter out of range");
-    if (o->zero_mask) return fail(MPC_E_ARG, "ilqr_env_solve: u_zero_I is not supported here");
-    if (p->B == 0) return MPC_OK;
-    if (!p->x_init || !p->C || !p->c || !p->cur_u) return fail(MPC_E_NULL, "ilqr_env_solve: x_init / C / c / u_init is NULL");
-    if (!best_x || !best_u || !best_costs || !best_du_norm) return fail(MPC_E_NULL, "ilqr_env_solve: an output is NULL");
-    if (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < mpc_ilqr_env_workspace_bytes(p, lqr_iter))
-        return fail(MPC_E_ARG, "workspace too small or misaligned (see mpc_ilqr_env_workspace_bytes)");
-    // the iterations meet at a grid barrier: every wavefront has to be resident at once
-    if (ilqr_tiny_wavefronts(p->B, o->max_linesearch_iter) > device_facts().simds)
-        return fail(MPC_E_DIMS, "ilqr_env_solve: the batch needs more wavefronts than the device holds at once");
-    hipStream_t st = (hipStream_t)stream;
-    return p->dtype == MPC_F32
-               ? ilqr_env_impl<float>(p, o, lqr_iter, eps, best_cost_eps, not_improved_lim, best_x, best_u, best_costs, best_du_norm, n_iter, workspace, st)
-               : ilqr_env_impl<double>(p, o, lqr_iter, eps, best_cost_eps, not_improved_lim, best_x, best_u, best_costs, best_du_norm, n_iter, workspace, st);
 }
 
 int mpc_env_linearize(const mpc_env_dynamics *env, int dtype, int64_t N, const void *x, const void *u, void *F,

@@ -58,12 +58,6 @@ int launch_kkt_fused_dpp16(const StepParams<float> &p, const float *dl_dx, const
 // one lane per problem, n_ctrl = 1, n_state <= 6, f32 / f64 (lqr_tiny.hip)
 bool tiny_supported(int ns, int nc);
 template <typename real> int launch_step_tiny(const StepParams<real> &p, hipStream_t st);
-// the whole iLQR solve for a shipped simulator in one launch (grid barrier between iterations: every wavefront resident)
-long ilqr_tiny_wavefronts(int B, int max_ls);
-template <typename real>
-int launch_ilqr_env_tiny(const StepParams<real> &p, real *xa, real *ua, real *xb, real *ub, real *best_x, real *best_u,
-                         real *best_cost, real *best_du, int lqr_iter, real eps, real best_cost_eps, int not_improved_lim,
-                         int *sync, int *n_iter_out, hipStream_t st);
 
 // wave-per-problem trajectory kernel for 16 < n <= 64, f32 (kkt_wave.hip)
 bool traj_wave_supported(const StepParams<float> &p);

@@ -326,12 +326,8 @@ MPC_HD void rollout_pass(const StepParams<real> &p, int b, const real *Kw, real 
 // group evaluates G consecutive trials at once; trial 0 (alpha = 1, the usual winner) writes its trajectory
 // as it goes, any other winner is replayed once.  `active`: this lane belongs to a real problem (idle tail
 // lanes shadow the last one so that the group exchanges stay uniform).
-// what a step hands to a caller that keeps iterating in the same kernel (the whole-solve kernel below)
-template <typename real> struct StepResult { double cost; real full_du; };
-
 template <typename real, int NS, class Lanes>
-MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw, const Lanes &L, bool active = true,
-                             StepResult<real> *res = nullptr)
+MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw, const Lanes &L, bool active = true)
 {
     const int G = L.G(), g = L.g();
     const bool writer = active && g == 0;
@@ -373,7 +369,6 @@ MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw, const L
         rollout_pass<real, NS>(p, b, Kw, win_alpha, writer, c2, d2);
     }
     (void)cost0;
-    if (res) { res->cost = win_cost; res->full_du = full; }          // (uniform over the group: every lane gathered them)
     if (!writer) return;
     if (!(win_cost == win_cost) || absr<double>(win_cost) > 3e38) status |= MPC_ST_NONFINITE;
     if (p.costs) p.costs[b] = (real)win_cost;
@@ -383,77 +378,6 @@ MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw, const L
     if (p.alphas) p.alphas[b] = win_alpha;
     if (p.qp_iters) p.qp_iters[b] = qp_total;
     if (p.status) p.status[b] = status;
-}
-
-// ---------------------------------------------------------------------------
-// The whole iLQR solve of MPC.forward for a shipped simulator (mpc/mpc.py:245-306) in ONE launch (round 3): the loop
-// over lqr_iter runs in the kernel, every iteration = this file's step (linearisation of the simulator at the nominal,
-// sweep, line search through the simulator) + the best-iterate bookkeeping of :271-285 per problem + the two batch-wide
-// words of the stop test (:283-306: did any problem improve, max ||du||), which the launch exchanges through a grid
-// barrier (lqr_tiny.hip).  Replaces, per iteration, a step launch, a select launch and a device->host read.
-// ---------------------------------------------------------------------------
-template <typename real> struct IlqrArgs {
-    real *xa, *ua, *xb, *ub;        // the nominal ping-pongs between these: [T,B,NS], [T,B,1]; ua holds u_init on entry
-    real *best_x, *best_u, *best_cost, *best_du;     // outputs: the best iterate of every problem (:279-285)
-    int lqr_iter, not_improved_lim;
-    real eps, best_cost_eps;
-    int *sync;                      // [4 * lqr_iter] zeros: arrival count, improved flag, max ||du|| bits, spare -- per iteration
-    int *n_iter_out;                // iterations run (the same for every problem: the stop test is batch-wide)
-};
-
-// util.get_traj through the simulator (mpc/util.py:107-113): x_0 = x_init, x_{t+1} = env(x_t, u_t)
-template <typename real, int NS>
-MPC_HD void env_traj_problem(const StepParams<real> &p, int b, const real *u, real *x)
-{
-    const int T = p.T, B = p.B;
-    real xs[NS > 5 ? NS : 5];
-    for (int i = 0; i < NS; ++i) { xs[i] = p.x_init[(long)b * NS + i]; x[(long)b * NS + i] = xs[i]; }
-    for (int t = 0; t + 1 < T; ++t) {
-        real xn[NS > 5 ? NS : 5];
-        env_step<real>(p.env, xs, u[(long)t * B + b], xn, nullptr);
-        for (int i = 0; i < NS; ++i) { xs[i] = xn[i]; x[((long)(t + 1) * B + b) * NS + i] = xn[i]; }
-    }
-}
-
-// One iteration of one problem: the step from nominal (cx, cu) into (nx, nu), then :271-285 -- the iterate becomes the
-// best one if it is the first or its cost is within best_cost_eps of the best so far.  Returns the two things the
-// batch-wide stop test wants from this problem.
-template <typename real, int NS, class Lanes>
-MPC_HD void ilqr_iterate_problem(const StepParams<real> &p, const IlqrArgs<real> &a, int b, int it, real *Kw, const Lanes &L,
-                                 bool active, bool &improved, real &full_du)
-{
-    StepParams<real> q = p;
-    const bool even = (it & 1) == 0;
-    q.cur_x = even ? a.xa : a.xb; q.cur_u = even ? a.ua : a.ub;
-    q.new_x = even ? a.xb : a.xa; q.new_u = even ? a.ub : a.ua;
-    q.costs = nullptr; q.old_costs = nullptr; q.full_du_norm = nullptr; q.alpha_du_norm = nullptr; q.alphas = nullptr;
-    q.K = nullptr; q.k = nullptr;
-    StepResult<real> r;
-    lqr_step_problem<real, NS>(q, b, Kw, L, active, &r);
-    const real cost = (real)r.cost;
-    const bool take = it == 0 || cost <= a.best_cost[b] + a.best_cost_eps;          // :279 (first iterate always)
-    improved = take && it > 0;
-    full_du = r.full_du;
-    if (active && L.g() == 0 && take) {
-        const int T = p.T, B = p.B;
-        for (int t = 0; t < T; ++t) {
-            const long tb = (long)t * B + b;
-            for (int i = 0; i < NS; ++i) a.best_x[tb * NS + i] = q.new_x[tb * NS + i];
-            a.best_u[tb] = q.new_u[tb];
-        }
-        a.best_cost[b] = cost;
-        a.best_du[b] = r.full_du;
-    }
-}
-
-// :283-306 after an iteration, on the batch-wide words: keep going?
-MPC_HD bool ilqr_continue(int it, int lqr_iter, bool any_improved, double max_du, double eps, int not_improved_lim, int &n_not_improved)
-{
-    n_not_improved += 1;
-    if (any_improved) n_not_improved = 0;
-    // (a NaN maximum is not < eps: the loop runs on, as the reference's does)
-    if (max_du < eps || n_not_improved > not_improved_lim) return false;
-    return it + 1 < lqr_iter;
 }
 
 MPC_HD bool shape_supported(int ns, int nc) { return nc == 1 && ns >= 1 && ns <= 6; }

@@ -155,7 +155,7 @@ EXPORTS = ("mpc_lqr_abi_version", "mpc_lqr_build_info", "mpc_lqr_last_error", "m
            "mpc_lqr_step", "mpc_lqr_impl_supported", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_lqr_kkt_prepare",
            "mpc_pnqp", "mpc_pnqp_lu", "mpc_traj_cost", "mpc_env_traj_cost", "mpc_env_linearize", "mpc_select_best",
            "mpc_mlp_workspace_bytes", "mpc_mlp_rollout", "mpc_mlp_linearize",
-           "mpc_ilqr_env_workspace_bytes", "mpc_ilqr_env_solve", "mpc_mlp_supported", "mpc_lqr_kkt_fused_supported", "mpc_lqr_kkt_fused_workspace_bytes", "mpc_lqr_kkt_fused")
+           "mpc_mlp_supported", "mpc_lqr_kkt_fused_supported", "mpc_lqr_kkt_fused_workspace_bytes", "mpc_lqr_kkt_fused")
 
 _lib = None
 
@@ -192,9 +192,6 @@ def load():
     L.mpc_lqr_rollout.argtypes = [PP, OP, UP, _vp, _vp]
     L.mpc_lqr_kkt_grads.argtypes = [PP] + [_vp] * 10
     L.mpc_lqr_kkt_prepare.argtypes = [ctypes.c_int] * 5 + [_vp, _vp, _vp, OP, _vp, _vp, _vp]
-    L.mpc_ilqr_env_workspace_bytes.restype = _i64
-    L.mpc_ilqr_env_workspace_bytes.argtypes = [PP, ctypes.c_int]
-    L.mpc_ilqr_env_solve.argtypes = [PP, OP, ctypes.c_int, _f64, _f64, ctypes.c_int] + [_vp] * 6 + [_i64, _vp]
     L.mpc_lqr_kkt_fused_supported.argtypes = [PP, OP]
     L.mpc_lqr_kkt_fused_workspace_bytes.restype = _i64
     L.mpc_lqr_kkt_fused_workspace_bytes.argtypes = [PP]
@@ -630,35 +627,6 @@ class HipBackend:
         _check(L.mpc_env_traj_cost(ctypes.byref(p), ctypes.byref(e), _ptr(x), _ptr(cost), _stream(dev)),
                "mpc_env_traj_cost")
         return x, cost
-
-    def ilqr_env_solve(self, x_init, C, c, u_init, opts, lqr_iter, eps, best_cost_eps, not_improved_lim):
-        """MPC.forward's whole iLQR loop for a shipped simulator in one launch (mpc_ilqr_env_solve): returns
-        dict(x, u, costs, full_du_norm, n_iter) -- n_iter a device int32[1] -- or None when the batch is larger than the
-        device holds at once (the caller then iterates step + select_best itself)."""
-        dev = _require_device(x_init, C, c, u_init)
-        L = load()
-        T, B, nc = u_init.shape
-        ns = x_init.shape[1]
-        kw = dict(device=dev, dtype=u_init.dtype)
-        p = Problem()
-        p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, _dtype_code(u_init)
-        xi = x_init.detach().contiguous(); p.x_init = xi.data_ptr()
-        cu = u_init.detach().contiguous(); p.cur_u = cu.data_ptr()
-        Cc, p.C_st, p.C_sb = _block_strided(C.detach(), 2); p.C = Cc.data_ptr()
-        cc, p.c_st, p.c_sb = _block_strided(c.detach(), 1); p.c = cc.data_ptr()
-        o, keep_o = opts.to_struct(T, B, nc, C)
-        res = dict(x=torch.empty(T, B, ns, **kw), u=torch.empty(T, B, nc, **kw), costs=torch.empty(B, **kw),
-                   full_du_norm=torch.empty(B, **kw), n_iter=torch.zeros(1, device=dev, dtype=torch.int32))
-        nbytes = int(L.mpc_ilqr_env_workspace_bytes(ctypes.byref(p), int(lqr_iter)))
-        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        rc = L.mpc_ilqr_env_solve(ctypes.byref(p), ctypes.byref(o), int(lqr_iter), float(eps), float(best_cost_eps),
-                                  int(not_improved_lim), res["x"].data_ptr(), res["u"].data_ptr(), res["costs"].data_ptr(),
-                                  res["full_du_norm"].data_ptr(), res["n_iter"].data_ptr(), ws.data_ptr(), nbytes, _stream(dev))
-        if rc == -1:              # MPC_E_DIMS: too many wavefronts for the grid barrier (or an unsupported shape)
-            return None
-        _check(rc, "mpc_ilqr_env_solve")
-        res["_keep"] = (xi, cu, Cc, cc, keep_o, ws)
-        return res
 
     def env_linearize(self, env, x, u, out_F=None, out_f=None):
         """x [N,ns], u [N,1] -> F [N,ns,ns+1], f [N,ns] (closed-form Jacobian of the simulator)."""

@@ -247,16 +247,6 @@ class MPC(Module):
         if self.u_init is not None and ua.untyped_storage().data_ptr() == self.u_init.untyped_storage().data_ptr():
             ua = ua.clone()
         opts = self._step_options()
-        if (sim is not None and self.flag_reducer is None and self.verbose <= 0 and self.u_zero_I is None
-                and hasattr(be, "ilqr_env_solve")):
-            # the whole loop in ONE launch (mpc_ilqr_env_solve): linearisation, step, best-iterate bookkeeping and the
-            # batch-wide stop test all in the kernel -- no launch, select kernel or flag read-back per iteration
-            sim.linearize = True
-            opts.true_dynamics = sim
-            r = be.ilqr_env_solve(xi, cost.C, cost.c, ua, opts, self.lqr_iter, self.eps, self.best_cost_eps, self.not_improved_lim)
-            if r is not None:
-                self._c_symmetric = False
-                return dict(x=r["x"], u=r["u"], costs=r["costs"], full_du_norm=r["full_du_norm"])
         if sim is not None:
             xa, _ = be.env_traj_cost(xi, ua, sim)                         # util.get_traj, :251
             # linearize_dynamics (:490-549) happens inside the step kernel: no F, f round trip through memory

@@ -589,68 +589,6 @@ extern "C" int emu_lqr_step_tiny(const mpc_lqr_problem *p, const mpc_lqr_options
 }
 
 
-// the whole iLQR solve of lqr_tiny_body.h on the host: the same per-problem iteration and the same stop rule as the
-// kernel; what the kernel exchanges through its grid barrier is a loop over the problems here
-template <typename real, int NS>
-static int ilqr_host_ns(mpclqr::StepParams<real> &sp, mpclqr::tiny::IlqrArgs<real> &a, real *kw)
-{
-    for (int b = 0; b < sp.B; ++b) mpclqr::tiny::env_traj_problem<real, NS>(sp, b, a.ua, a.xa);
-    int n_not = 0, it = 0;
-    for (;;) {
-        bool any = false, nan = false;
-        double mx = 0;
-        for (int b = 0; b < sp.B; ++b) {
-            bool imp = false;
-            real du = 0;
-            mpclqr::tiny::ilqr_iterate_problem<real, NS>(sp, a, b, it, kw, mpclqr::tiny::OneLane(), true, imp, du);
-            any = any || imp;
-            if (!(du == du)) nan = true; else if ((double)du > mx) mx = (double)du;
-        }
-        if (!mpclqr::tiny::ilqr_continue(it, a.lqr_iter, any, nan ? (double)NAN : mx, (double)a.eps, a.not_improved_lim, n_not)) break;
-        ++it;
-    }
-    return it + 1;
-}
-template <typename real>
-static int ilqr_host(const mpc_lqr_problem *p, const mpc_lqr_options *o, int lqr_iter, double eps, double bce, int lim,
-                     real *bx, real *bu, real *bc, real *bd, int *n_iter)
-{
-    mpc_lqr_outputs out;
-    memset(&out, 0, sizeof(out));
-    mpclqr::StepParams<real> sp = mpclqr::make_params<real>(p, o, &out);
-    if (!mpclqr::tiny::shape_supported(sp.ns, sp.nc) || !sp.env.kind) return MPC_E_DIMS;
-    sp.env.linearize = 1;
-    const size_t nx = (size_t)sp.T * sp.B * sp.ns, nu = (size_t)sp.T * sp.B, nk = (size_t)sp.T * sp.B * (sp.ns + 1);
-    real *buf = (real *)malloc((2 * (nx + nu) + nk) * sizeof(real));
-    for (size_t i = 0; i < 2 * (nx + nu) + nk; ++i) buf[i] = (real)NAN;
-    mpclqr::tiny::IlqrArgs<real> a;
-    a.xa = buf; a.ua = buf + nx; a.xb = buf + nx + nu; a.ub = buf + 2 * nx + nu;
-    real *kw = buf + 2 * (nx + nu);
-    memcpy(a.ua, p->cur_u, nu * sizeof(real));
-    a.best_x = bx; a.best_u = bu; a.best_cost = bc; a.best_du = bd;
-    a.lqr_iter = lqr_iter; a.not_improved_lim = lim; a.eps = (real)eps; a.best_cost_eps = (real)bce;
-    a.sync = nullptr; a.n_iter_out = nullptr;
-    int n = 0;
-    switch (sp.ns) {
-    case 1: n = ilqr_host_ns<real, 1>(sp, a, kw); break;
-    case 2: n = ilqr_host_ns<real, 2>(sp, a, kw); break;
-    case 3: n = ilqr_host_ns<real, 3>(sp, a, kw); break;
-    case 4: n = ilqr_host_ns<real, 4>(sp, a, kw); break;
-    case 5: n = ilqr_host_ns<real, 5>(sp, a, kw); break;
-    case 6: n = ilqr_host_ns<real, 6>(sp, a, kw); break;
-    }
-    if (n_iter) *n_iter = n;
-    free(buf);
-    return 0;
-}
-extern "C" int emu_ilqr_env_tiny(const mpc_lqr_problem *p, const mpc_lqr_options *o, int lqr_iter, double eps, double bce, int lim,
-                                 void *bx, void *bu, void *bc, void *bd, int *n_iter)
-{
-    return p->dtype == MPC_F32 ? ilqr_host<float>(p, o, lqr_iter, eps, bce, lim, (float *)bx, (float *)bu, (float *)bc, (float *)bd, n_iter)
-                               : ilqr_host<double>(p, o, lqr_iter, eps, bce, lim, (double *)bx, (double *)bu, (double *)bc, (double *)bd, n_iter);
-}
-
-
 // ---- lqr_mfma40_body.h: the n_state = 32, n_ctrl = 8 sweep (one emulated wavefront per problem) ----
 static int g_m40_full = 0;
 template <int MODE> static void body_mfma40_mode()

@@ -222,42 +222,6 @@ def kkt_fused(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_upper=No
     return out
 
 
-def ilqr_env_solve(x_init, Q, pvec, u_init, env, u_lower, u_upper, linesearch_decay, max_linesearch_iter, lqr_iter, eps,
-                   best_cost_eps=1e-4, not_improved_lim=5, dtype=np.float64):
-    """MPC.forward's whole iLQR loop for a shipped simulator through the host build of lqr_tiny_body.h (the same
-    per-problem iteration and stop rule the one-launch kernel runs, mpc_ilqr_env_solve).  env = (kind, params, dt, u_max)."""
-    f = np.dtype(dtype).type
-    x_init = np.ascontiguousarray(x_init, f); Q = np.ascontiguousarray(Q, f); pvec = np.ascontiguousarray(pvec, f)
-    u_init = np.ascontiguousarray(u_init, f)
-    T, B, nc = u_init.shape
-    ns = x_init.shape[1]
-    n = ns + nc
-    p = N.Problem()
-    p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, (N.MPC_F32 if f == np.float32 else N.MPC_F64)
-    p.x_init = _ptr(x_init)
-    p.C, p.C_st, p.C_sb = _ptr(Q), B * n * n, n * n
-    p.c, p.c_st, p.c_sb = _ptr(pvec), B * n, n
-    p.cur_u = _ptr(u_init)
-    o = N.Options()
-    o.max_linesearch_iter, o.linesearch_decay, o.delta_u, o.pnqp_iter = int(max_linesearch_iter), float(linesearch_decay), float("nan"), 20
-    o.bound_mode, o.lo_s, o.hi_s = N.BOUND_SCALAR, float(u_lower), float(u_upper)
-    e = N.EnvDynamics()
-    prm = np.ascontiguousarray(env[1], f)
-    e.kind, e.params, e.dt, e.u_max, e.linearize = int(env[0]), _ptr(prm), float(env[2]), float(env[3]), 1
-    o.true_dynamics = ctypes.pointer(e)
-    res = dict(x=np.full((T, B, ns), np.nan, f), u=np.full((T, B, nc), np.nan, f), costs=np.full(B, np.nan, f),
-               full_du_norm=np.full(B, np.nan, f))
-    n_iter = ctypes.c_int(0)
-    fn = lib().emu_ilqr_env_tiny
-    fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int] + \
-                  [ctypes.c_void_p] * 4 + [ctypes.POINTER(ctypes.c_int)]
-    rc = fn(ctypes.byref(p), ctypes.byref(o), int(lqr_iter), float(eps), float(best_cost_eps), int(not_improved_lim),
-            _ptr(res["x"]), _ptr(res["u"]), _ptr(res["costs"]), _ptr(res["full_du_norm"]), ctypes.byref(n_iter))
-    assert rc == 0, rc
-    res["n_iter"] = n_iter.value
-    return res
-
-
 def env_linearize(kind, params, dt, u_max, x, u, dtype=np.float64):
     """mpc.pytorch_amd/csrc/env_dynamics.h compiled for the host: next state, F, f at N points."""
     sfx = "f64" if dtype == np.float64 else "f32"

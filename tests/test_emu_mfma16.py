@@ -685,28 +685,3 @@ def test_emulated_dpp16_long_horizons(emu, kernel, T):
             np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=2e-4, err_msg=mode)
             np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4, atol=1e-4)
             np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=2e-4)
-
-
-@pytest.mark.parametrize("kind", ["pendulum", "cartpole"])
-def test_whole_ilqr_solve_body_matches_the_reference_solve(emu, kind):
-    """mpc_ilqr_env_solve's body (lqr_tiny_body.h: ilqr_iterate_problem + ilqr_continue, compiled for the host): the
-    reference's own PendulumDx / CartpoleDx solves (goldens ilqr_*_f64: MPC.forward, AUTO_DIFF linearisation, module in the
-    line search, 8 iterations, B = 4) -- linearisation, step, best-iterate bookkeeping and the batch-wide stop test all
-    inside the one call."""
-    from oracle import env_oracle as E
-    z = golden("ilqr_%s_f64" % kind)
-    ns, nc, T, B, lqr_iter = (int(v) for v in z["meta"])
-    ek = E.PENDULUM if kind == "pendulum" else E.CARTPOLE
-    prm = np.array([10.0, 1.0, 1.0]) if kind == "pendulum" else np.array([9.8, 1.0, 0.1, 0.5])
-    r = emu.ilqr_env_solve(z["x_init"], z["Q"], z["p"], np.zeros((T, B, 1)), (ek, prm, 0.05, float(z["upper"][0])),
-                           float(z["lower"][0]), float(z["upper"][0]), float(z["decay"][0]), int(z["max_ls"][0]), lqr_iter,
-                           float(z["eps"][0]))
-    assert 1 <= r["n_iter"] <= lqr_iter
-    np.testing.assert_allclose(r["costs"], z["costs"], rtol=1e-5)
-    np.testing.assert_allclose(r["x"], z["x"], rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(r["u"], z["u"], rtol=1e-4, atol=1e-4)
-    # float32: the precision configs 2 / 3 of BASELINE.json run in
-    r32 = emu.ilqr_env_solve(z["x_init"], z["Q"], z["p"], np.zeros((T, B, 1)), (ek, prm, 0.05, float(z["upper"][0])),
-                             float(z["lower"][0]), float(z["upper"][0]), float(z["decay"][0]), int(z["max_ls"][0]), lqr_iter,
-                             float(z["eps"][0]), dtype=np.float32)
-    np.testing.assert_allclose(r32["costs"], z["costs"], rtol=2e-3, atol=1e-3)

@@ -640,62 +640,6 @@ def test_ilqr_on_shipped_simulators_on_gpu(be, kind):
     assert float((ua.abs() <= dx.upper + 1e-6).float().mean()) == 1.0
 
 
-@pytest.mark.parametrize("kind,B,T", [("pendulum", 1024, 20), ("cartpole", 4096, 25), ("pendulum", 37, 7)])
-def test_whole_ilqr_solve_in_one_launch_equals_the_iterated_solve(be, kind, B, T, monkeypatch):
-    """mpc_ilqr_env_solve (the loop over lqr_iter, the best-iterate bookkeeping and the batch-wide stop test inside ONE
-    kernel, workgroups meeting at a grid barrier after every iteration) against the same package iterating mpc_lqr_step +
-    mpc_select_best from the host: the same step arithmetic, so the same numbers -- at the batch sizes of BASELINE configs
-    2 / 3 and on a ragged small batch, float32, with an `eps` that stops the loop early on the small one."""
-    from mpc import mpc, _native
-    from mpc.mpc import QuadCost
-    from mpc.env_dx import cartpole, pendulum
-    g = torch.Generator().manual_seed(11)
-    if kind == "pendulum":
-        dx = pendulum.PendulumDx()
-        th = (torch.rand(B, generator=g) - 0.5) * np.pi
-        x0 = torch.stack((th.cos(), th.sin(), (torch.rand(B, generator=g) - 0.5) * 2), 1)
-    else:
-        dx = cartpole.CartpoleDx()
-        th = (torch.rand(B, generator=g) - 0.5) * 0.6
-        zz = 0.2 * torch.randn(B, 3, generator=g)
-        x0 = torch.stack((zz[:, 0], zz[:, 1], th.cos(), th.sin(), zz[:, 2]), 1)
-    q, p = dx.get_true_obj()
-    Q = torch.diag(q).repeat(T, B, 1, 1).to(DEV)
-    pp = p.repeat(T, B, 1).to(DEV)
-    mk = lambda: mpc.MPC(dx.n_state, 1, T, u_lower=dx.lower, u_upper=dx.upper, lqr_iter=6, verbose=-1, exit_unconverged=False,
-                         detach_unconverged=False, linesearch_decay=dx.linesearch_decay, max_linesearch_iter=dx.max_linesearch_iter,
-                         grad_method=mpc.GradMethods.AUTO_DIFF, eps=1e-2 if B < 100 else 1e-7, backprop=False)
-    calls = []
-    real = _native.HipBackend.ilqr_env_solve
-    monkeypatch.setattr(_native.HipBackend, "ilqr_env_solve", lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1])
-    xa, ua, ca = mk()(x0.to(DEV), QuadCost(Q, pp), dx)
-    assert calls, "the simulator solve must take the one-launch path"
-    monkeypatch.setattr(_native.HipBackend, "ilqr_env_solve", lambda self, *a, **k: None)       # "batch too large": iterate from the host
-    xb, ub, cb = mk()(x0.to(DEV), QuadCost(Q, pp), dx)
-    torch.cuda.synchronize()
-    assert torch.isfinite(xa).all() and torch.isfinite(ca).all()
-    np.testing.assert_allclose(host(ca), host(cb), rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(host(ua), host(ub), rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(host(xa), host(xb), rtol=1e-5, atol=1e-5)
-
-
-def test_whole_ilqr_solve_declines_what_a_grid_barrier_cannot_hold(be):
-    """More wavefronts than the device has SIMDs cannot all be resident, and the iterations meet at a barrier: the entry
-    point says MPC_E_DIMS (the Python front returns None and iterates from the host) instead of deadlocking."""
-    from mpc._native import StepOptions
-    from mpc.env_dx import pendulum
-    dx = pendulum.PendulumDx()
-    B, T = 16384, 5                       # x 8 lanes per problem (max_linesearch_iter 5) = 2048 wavefronts
-    x0 = torch.zeros(B, 3, device=DEV); x0[:, 0] = 1.0
-    Q = torch.diag(dx.get_true_obj()[0]).repeat(T, B, 1, 1).to(DEV)
-    pp = dx.get_true_obj()[1].repeat(T, B, 1).to(DEV)
-    sim = dx.native_env()
-    sim.linearize = True
-    opts = StepOptions(u_lower=dx.lower, u_upper=dx.upper, linesearch_decay=dx.linesearch_decay,
-                       max_linesearch_iter=dx.max_linesearch_iter, true_dynamics=sim)
-    assert be.ilqr_env_solve(x0, Q, pp, torch.zeros(T, B, 1, device=DEV), opts, 3, 1e-7, 1e-4, 5) is None
-
-
 def test_slew_rate_properties_on_gpu(be):
     """reference tests/test_mpc.py:802-861 on the device (float64)."""
     from test_host_logic import _slew_rate_properties
