@@ -338,6 +338,30 @@ def extra_rows(be, dev, steps):
     return rows
 
 
+def attach_traffic(rows):
+    """HBM bytes per launch from the tracked rocprofv3 counter summaries (profiles/r03_prof_*.json: separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes, (2 x FETCH + WRITE) x 1024 per MI355X_MICROARCH.md), per kernel; a row that is ONE kernel launch gets
+    `roofline.traffic` and `roofline.traffic_over_algorithmic`.  Counter runs are separate runs of the same commands
+    (tools/prof_any.sh), never mixed with the timed ones."""
+    def load(tag):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", "r03_prof_%s.json" % tag)))["pmc_avg_per_dispatch"]
+        except Exception:
+            return {}
+    kkt, cfg5, bnd = load("kkt"), load("cfg5"), load("bounded")
+    pick = {"lqr_step_bounded": bnd.get("lqr_step_dpp16_kernel<2>"),
+            "kkt_backward_unbounded": kkt.get("lqr_kkt_fused_dpp16_kernel<false>"),
+            "kkt_backward_bounded": kkt.get("lqr_kkt_fused_dpp16_kernel<true>"),
+            "cfg5_step_B1024_verified_nominal": cfg5.get("lqr_step_mfma40_kernel<0>"),
+            "cfg5_step_bounded_B1024": cfg5.get("lqr_step_mfma40_kernel<2>")}
+    for key, v in pick.items():
+        if v and key in rows and "roofline" in rows[key] and "hbm_bytes_per_dispatch" in v:
+            r = rows[key]["roofline"]
+            r["traffic"] = v["hbm_bytes_per_dispatch"]
+            r["traffic_over_algorithmic"] = v["hbm_bytes_per_dispatch"] / r["algorithmic_bytes_per_launch"]
+    return rows
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -484,8 +508,13 @@ def main():
         value = world * B * T_H / (elapsed / args.steps)
         abytes = algorithmic_bytes_per_problem(NS, NC, T_H) * B
         traffic = None
+        try:        # round 3: the per-kernel counter summary of tools/prof_any.sh
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_prof_%s.json" % ("bounded" if args.bounded else "headline"))))["pmc_avg_per_dispatch"]
+            traffic = pm["lqr_step_dpp16_kernel<%d>" % (2 if args.bounded else 0)]["hbm_bytes_per_dispatch"] if impl_used == 3 else None
+        except Exception:
+            traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if traffic is None and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("bounded" if args.bounded else "unbounded", {}).get(
                     "impl%d" % impl_used)
@@ -520,7 +549,7 @@ def main():
                 out["config"]["finite"] = ok = False
         if world == 1 and not args.no_extra:
             try:
-                out["extra"] = extra_rows(be, dev, args.steps)
+                out["extra"] = attach_traffic(extra_rows(be, dev, args.steps))
             except Exception as e:      # the contract line must survive a failing secondary row
                 out["extra"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:

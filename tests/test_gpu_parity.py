@@ -507,6 +507,90 @@ def test_select_best_kernel(be):
     assert torch.equal(best["x"], x) and int(any_imp.item()) == 0
 
 
+def test_select_best_reports_an_asymmetric_C(be):
+    """bit 1 of mpc_select_best's flag word: some status word of the step carries MPC_ST_C_ASYMMETRIC -- how mpc.MPC learns,
+    with the convergence flags it reads anyway, whether it may promise a symmetric C to the remaining steps."""
+    g = torch.Generator().manual_seed(1)
+    T, B, ns, nc = 4, 70, 3, 2
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float32).to(DEV)
+    best = dict(x=mk(T, B, ns), u=mk(T, B, nc), costs=mk(B), full_du_norm=mk(B).abs())
+    x, u, costs, du = mk(T, B, ns), mk(T, B, nc), mk(B), mk(B).abs()
+    st = torch.zeros(B, dtype=torch.int32, device=DEV)
+    any_imp, _ = be.select_best(True, 1e-4, x, u, costs, du, best, status=st)
+    assert int(any_imp.item()) & 2 == 0
+    st[66] = 8 | 1
+    any_imp, _ = be.select_best(True, 1e-4, x, u, costs, du, best, status=st)
+    assert int(any_imp.item()) & 2 == 2
+    any_imp, _ = be.select_best(False, 1e-4, x, u, costs - 100, du, best, status=st)
+    assert int(any_imp.item()) == 3
+
+
+@pytest.mark.parametrize("bounded", [False, True])
+def test_asymmetric_C_end_to_end_through_mpc_forward_and_backward(be, bounded):
+    """The drop-in promise for a cost matrix that is not symmetric: mpc.MPC on the fast 12/4 path --
+    which tests C on the device, re-solves the flagged problems on the generic kernel, and therefore never promises a
+    symmetric C to later steps or to the backward -- against the SAME package forced onto the generic kernels (float64,
+    reference-faithful by test_lqr_step_parity on the step_asym_* fixtures): solution and all five gradients."""
+    import bench
+    from mpc import mpc
+    from mpc.mpc import LinDx, QuadCost
+    T, B = 12, 9
+    p = bench.make_problem(12, 4, T, B, torch.float32, DEV, seed=77)
+    g = torch.Generator().manual_seed(3)
+    N = torch.randn(T, B, 16, 16, generator=g).to(DEV)
+    C = p["C"].clone()
+    C[:, (1, 4, 8)] += 0.3 * 2.0 * torch.triu(N[:, (1, 4, 8)], 1)            # three of nine problems
+    kw = dict(u_lower=-0.8, u_upper=0.8) if bounded else {}
+    outs = []
+    for dt in (torch.float32, torch.float64):
+        leaves = [t.to(dt).clone().requires_grad_(True) for t in (C, p["c"], p["F"], p["f"], p["x_init"])]
+        ctrl = mpc.MPC(12, 4, T, lqr_iter=25, verbose=-1, exit_unconverged=False, detach_unconverged=False,
+                       eps=1e-9 if dt == torch.float64 else 1e-5, **kw)
+        x, u, costs = ctrl(leaves[4], QuadCost(leaves[0], leaves[1]), LinDx(leaves[2], leaves[3]))
+        if dt == torch.float32:
+            assert not ctrl._c_symmetric            # the first step flagged C: no promise for the rest of the solve
+        gw = torch.Generator().manual_seed(9)
+        wx, wu = torch.randn(x.shape, generator=gw).to(DEV).to(dt), torch.randn(u.shape, generator=gw).to(DEV).to(dt)
+        grads = torch.autograd.grad((x * wx).sum() + (u * wu).sum(), leaves)
+        outs.append((x.detach(), u.detach(), [gr.detach() for gr in grads]))
+    (x32, u32, g32), (x64, u64, g64) = outs
+    np.testing.assert_allclose(host(u32), host(u64), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(host(x32), host(x64), rtol=2e-3, atol=2e-3)
+    for a, b_, name in zip(g32, g64, ("dC", "dc", "dF", "df", "dx_init")):
+        scale = max(1.0, float(b_.abs().max()))
+        np.testing.assert_allclose(host(a) / scale, host(b_) / scale, rtol=0, atol=5e-3, err_msg=name)
+    # and the symmetrised matrix is a DIFFERENT problem: the test would not notice a kernel that symmetrises silently otherwise
+    Cs = 0.5 * (C + C.transpose(2, 3))
+    xs, us, _ = mpc.MPC(12, 4, T, lqr_iter=25, verbose=-1, exit_unconverged=False, detach_unconverged=False, eps=1e-5, **kw)(
+        p["x_init"], QuadCost(Cs, p["c"]), LinDx(p["F"], p["f"]))
+    assert float((us - u32)[:, (1, 4, 8)].abs().max()) > 0.05
+    assert float((us - u32)[:, (0, 2, 3, 5, 6, 7)].abs().max()) < 1e-3
+
+
+def test_wide_network_keeps_the_module_path(be):
+    """NNDynamics(4, 1, [1024]) is outside the LDS budget of the network kernels; native_net() says so (the
+    library's own test, mpc_mlp_supported) and util.get_traj / MPC.forward call the module instead of raising."""
+    from mpc import mpc, util
+    from mpc.dynamics import NNDynamics
+    from mpc.mpc import QuadCost
+    torch.manual_seed(0)
+    dyn = NNDynamics(4, 1, [1024]).to(DEV)
+    assert dyn.native_net(torch.empty(1, device=DEV)) is None
+    assert NNDynamics(4, 1, [64]).to(DEV).native_net(torch.empty(1, device=DEV)) is not None
+    T, B = 6, 5
+    x0 = torch.randn(B, 4, device=DEV)
+    u = 0.1 * torch.randn(T, B, 1, device=DEV)
+    with torch.no_grad():
+        x = util.get_traj(T, u, x_init=x0, dynamics=dyn)
+    assert x.shape == (T, B, 4) and torch.isfinite(x).all()
+    A = torch.randn(T, B, 5, 5, device=DEV)
+    C = A.transpose(2, 3).matmul(A) + 0.1 * torch.eye(5, device=DEV)
+    with torch.no_grad():
+        xs, us, _ = mpc.MPC(4, 1, T, u_lower=-1.0, u_upper=1.0, lqr_iter=2, verbose=-1, exit_unconverged=False,
+                            grad_method=mpc.GradMethods.ANALYTIC, backprop=False)(x0, QuadCost(C, torch.zeros(T, B, 5, device=DEV)), dyn)
+    assert torch.isfinite(xs).all() and float(us.abs().max()) <= 1.0 + 1e-6
+
+
 MPC_CASES = ["mpc_notebook_tvlq", "mpc_linear_unbounded_big_bounds", "mpc_linear_unbounded_none",
              "mpc_linear_bounded", "mpc_linear_bounded_delta", "mpc_singleton_big_bounds", "mpc_singleton_none"]
 
