@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPC_LQR_ABI_VERSION 5
+#define MPC_LQR_ABI_VERSION 6
 
 enum { MPC_F32 = 0, MPC_F64 = 1 };
 enum { MPC_BOUND_NONE = 0, MPC_BOUND_SCALAR = 1, MPC_BOUND_TENSOR = 2 };
@@ -284,14 +284,19 @@ int mpc_mlp_linearize(const mpc_mlp_dynamics *net, int n_state, int n_ctrl, int6
                       void *F, void *f, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* (7) Device-side pieces of the iLQR driver loop (mpc/mpc.py:271-285, 299):
- *     per-problem best-iterate select without host round trips.
+ *     per-problem best-iterate select without host round trips, ONE launch.
  *     take[b] = first || cost[b] <= best_cost[b] + eps ; where taken copy x,u,cost,du-norm.
- *     any_improved[0]: bit 0 = any(take); bit 1 = some status[b] has MPC_ST_C_ASYMMETRIC (`status` [B] = the step's
- *     status words, may be NULL) ; max_du[0] = max_b full_du_norm. */
+ *     `flags`: 16 bytes of device memory, 8-byte aligned.  After the call, in stream order: int32 at byte 0: bit 0 =
+ *     any(take) on a call with first == 0; bit 1 = some status[b] has MPC_ST_C_ASYMMETRIC (`status` [B] = the step's
+ *     status words, may be NULL); the real at byte 8 = max_b du_norm[b] (NaN if any is).
+ *     `host_flags`: NULL, or 16 bytes of page-locked host memory the device can write (hipHostMalloc): the kernel
+ *     stores the same two results there as well (same offsets) -- the driver loop waits for an event recorded behind
+ *     this call and reads them, with no device-to-host copy in between.  (ABI 5 took `int32_t *any_improved, void
+ *     *max_du_norm` in these two positions and needed three launches.) */
 int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double best_cost_eps,
                     const void *x, const void *u, const void *costs, const void *du_norm,
                     void *best_x, void *best_u, void *best_costs, void *best_du_norm,
-                    int32_t *any_improved, void *max_du_norm, const int32_t *status, void *stream);
+                    void *flags, void *host_flags, const int32_t *status, void *stream);
 
 #ifdef __cplusplus
 }

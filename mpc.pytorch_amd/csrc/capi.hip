@@ -532,24 +532,25 @@ int mpc_traj_cost(const mpc_lqr_problem *p, void *x, void *cost, void *stream)
 
 int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double best_cost_eps, const void *x,
                     const void *u, const void *costs, const void *du_norm, void *best_x, void *best_u,
-                    void *best_costs, void *best_du_norm, int32_t *any_improved, void *max_du_norm, const int32_t *status,
+                    void *best_costs, void *best_du_norm, void *flags, void *host_flags, const int32_t *status,
                     void *stream)
 {
     if (dtype != MPC_F32 && dtype != MPC_F64) return fail(MPC_E_DTYPE, "bad dtype");
     if (B < 0 || T < 1 || ns < 1 || nc < 1) return fail(MPC_E_DIMS, "bad dims");
     if (B == 0) return MPC_OK;
-    if (!x || !u || !costs || !du_norm || !best_x || !best_u || !best_costs || !best_du_norm)
+    if (!x || !u || !costs || !du_norm || !best_x || !best_u || !best_costs || !best_du_norm || !flags)
         return fail(MPC_E_NULL, "select_best: NULL argument");
+    if ((uintptr_t)flags & 7 || (uintptr_t)host_flags & 7) return fail(MPC_E_ARG, "select_best: the flags blocks must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MPC_F32)
         return launch_select_best<float>(B, T, ns, nc, first, (float)best_cost_eps, (const float *)x,
                                          (const float *)u, (const float *)costs, (const float *)du_norm,
                                          (float *)best_x, (float *)best_u, (float *)best_costs,
-                                         (float *)best_du_norm, any_improved, (float *)max_du_norm, status, st);
+                                         (float *)best_du_norm, flags, host_flags, status, st);
     return launch_select_best<double>(B, T, ns, nc, first, best_cost_eps, (const double *)x, (const double *)u,
                                       (const double *)costs, (const double *)du_norm, (double *)best_x,
                                       (double *)best_u, (double *)best_costs, (double *)best_du_norm,
-                                      any_improved, (double *)max_du_norm, status, st);
+                                      flags, host_flags, status, st);
 }
 
 }  // extern "C"

@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(MAX_THREADS) traj_cost_kernel(StepParams<real>
 // reads row i of F_t (a group reads one contiguous block per step), tau is exchanged by row shuffles, the
 // next step's row is in flight while this one is summed.  The generic kernel above spends a whole
 // wavefront and two barriers per step on the same 192 multiply-adds.
-template <typename real>
+template <typename real, bool VEC>
 __global__ void __launch_bounds__(256) traj_rows16_kernel(StepParams<real> p, real *x)
 {
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, i = threadIdx.x & 15;
@@ -812,26 +812,59 @@ __global__ void __launch_bounds__(256) traj_rows16_kernel(StepParams<real> p, re
     const bool own = gid < B && i < ns;
     real xi = i < ns ? p.x_init[(long)b * ns + i] : (real)0;
     if (own) x[(long)b * ns + i] = xi;
-    real row[16], nxt[16];
+    if (T < 2) return;
+    // The recursion is a chain of one row-times-vector product per timestep: what it waits for is memory.  DEPTH rows of
+    // F (and the matching u / f entry) are kept in flight in registers.  Every load of the loop is unconditional (indices
+    // clamped, zeros selected afterwards) so that the compiler can COUNT them: with a branch per element it drained the
+    // whole queue (`s_waitcnt vmcnt(0)`) once per trip, and the 154 MB of F at the headline shape took 76-90 us.
+    constexpr int DEPTH = 4;
+    real row[DEPTH][16], aux[DEPTH];
     const int ir = i < ns ? i : 0;
-    auto load_row = [&](int t, real *dst) {
-        const real *Ft = p.F + (long)t * p.F_st + (long)b * p.F_sb + (long)ir * n;
+    const bool hasf = p.f != nullptr;
+    const bool isu = i >= ns && i < n;
+    // lane i < ns: f_t[i];  ns <= i < n: u_t[i - ns];  the rest (and f absent): any valid address, the value is dropped
+    const real *aux0 = isu ? p.cur_u + (long)b * nc + (i - ns) : (hasf && i < ns ? p.f + (long)b * p.f_sb + i : p.x_init);
+    const long aux_st = isu ? (long)B * nc : (hasf && i < ns ? p.f_st : 0);
+    const bool auxv = isu || (hasf && i < ns);
+    const real *F0 = p.F + (long)b * p.F_sb + (long)ir * n;
+    auto load_stage = [&](int t, int slot) {
+        t = t < T - 2 ? t : T - 2;
+        const real *Ft = F0 + (long)t * p.F_st;
+        if constexpr (VEC) {
+            const float4 *F4 = reinterpret_cast<const float4 *>(Ft);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) dst[j] = j < n ? Ft[j] : (real)0;
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = F4[q];
+                row[slot][4 * q] = v.x, row[slot][4 * q + 1] = v.y, row[slot][4 * q + 2] = v.z, row[slot][4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) row[slot][j] = Ft[j < n ? j : 0];
+        }
+        aux[slot] = aux0[(long)t * aux_st];
     };
-    if (T > 1) load_row(0, row);
-    for (int t = 0; t < T - 1; ++t) {
-        if (t + 1 < T - 1) load_row(t + 1, nxt);
-        const real ui = (i >= ns && i < n) ? p.cur_u[((long)t * B + b) * nc + (i - ns)] : (real)0;
-        const real tau = i < ns ? xi : ui;
-        real acc = (p.f && i < ns) ? p.f[(long)t * p.f_st + (long)b * p.f_sb + i] : (real)0;
+    auto advance = [&](int t, int slot) {
+        const real a = auxv ? aux[slot] : (real)0;
+        const real tau = i < ns ? xi : a;
+        real acc = i < ns ? a : (real)0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc += row[j] * __shfl(tau, j, 16);
+        for (int j = 0; j < 16; ++j) acc += (VEC || j < n ? row[slot][j] : (real)0) * __shfl(tau, j, 16);
         xi = acc;
         if (own) x[((long)(t + 1) * B + b) * ns + i] = xi;
+    };
 #pragma unroll
-        for (int j = 0; j < 16; ++j) row[j] = nxt[j];
+    for (int d = 0; d < DEPTH; ++d) load_stage(d, d);
+    int t0 = 0;
+    for (; t0 + DEPTH <= T - 1; t0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            advance(t0 + d, d);
+            load_stage(t0 + d + DEPTH, d);                  // the slot just used takes the stage DEPTH steps on
+        }
     }
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d)
+        if (t0 + d < T - 1) advance(t0 + d, d);
 }
 
 // ---------------------------------------------------------------------------
@@ -937,70 +970,90 @@ template <typename real> struct BitsOf;
 template <> struct BitsOf<float> { using type = unsigned int; };
 template <> struct BitsOf<double> { using type = unsigned long long; };
 
-// Pass 1: copy the trajectories of the problems that improved.  One thread per float, flat over [T,B,d]
-// (fully coalesced); every thread derives its problem's `take` from costs and the OLD best costs, which
-// pass 2 (stream-ordered after this one) then overwrites.
-template <typename real>
-__global__ void select_copy_kernel(long total, int B, int d, int first, real eps, const real *src, real *dst,
-                                   const real *costs, const real *bc, int *zero_flag, real *zero_max)
-{
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e == 0) {                         // pass 2 accumulates into these with atomics (no memset launches)
-        if (zero_flag) *zero_flag = 0;
-        if (zero_max) *zero_max = 0;
-    }
-    if (e >= total) return;
-    const int b = (int)((e / d) % B);
-    if (first || costs[b] <= bc[b] + eps) dst[e] = src[e];
-}
+// One launch (round 3; rounds 1-2: a copy kernel per array + an update kernel + the caller's device-to-host copy of the
+// two result words: 22 us per iLQR iteration at the headline shape).
+//   Workgroups 1..: each owns kSelPB consecutive problems -- their `take` bits come from costs and the OLD best costs,
+// which it then overwrites; their rows of x_t and u_t are one contiguous piece per timestep.
+//   Workgroup 0 computes the two batch-wide words on its own, reading all B problems' scalars: no atomics, no ticket, no
+// fence (on this chip an agent-scope fence writes an XCD's L2 back; 512 workgroups drawing tickets took 30 us).  It
+// races with the owners' updates of best_costs and that is harmless: an owner stores cost[b] there only where the
+// problem was taken, and cost[b] <= cost[b] + eps, so the old and the new word give the same `take` (eps >= 0).
+constexpr int kSelPB = 8;
 
-// Pass 2: best costs / du-norms and the two batch-wide reductions; one atomic per block.
-template <typename real>
-__global__ void select_update_kernel(int B, int first, real eps, const real *costs, const real *du_norm, real *bc,
-                                     real *bd, int *any_improved, real *max_du, const int *status)
+template <typename real> struct SelectArgs {
+    int B, T, ns, nc, first;
+    real eps;
+    const real *x, *u, *costs, *du;
+    real *bx, *bu, *bc, *bd;
+    const int *status;
+    unsigned char *flags, *host;      // int32 result bits at byte 0, the maximum at byte 8; host: the same, page-locked
+};
+
+template <typename real, typename vec>
+__global__ void __launch_bounds__(256) select_best_kernel(SelectArgs<real> a, int owners_only)
 {
-    __shared__ real s_max[4];
-    __shared__ int s_flag[4];
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    real d = 0;
-    int improved = 0, isnan_ = 0;
-    if (b < B) {
-        d = du_norm[b];
-        const real cnew = costs[b];
-        if (first || cnew <= bc[b] + eps) {
-            bc[b] = cnew;
-            bd[b] = d;
-            improved = 1;
-        }
-        if (d != d) { isnan_ = 1; d = 0; }
-        if (d < 0) d = 0;
-        // bit 2 of the block's flag word: some problem's C is not symmetric (MPC_ST_C_ASYMMETRIC of the step's status)
-        if (status && (status[b] & MPC_ST_C_ASYMMETRIC)) isnan_ |= 2;
-    }
-    // wave reduction, then across the (<= 4) waves of the block
-    for (int off = 32; off > 0; off >>= 1) {
-        const real o = __shfl_down(d, off);
-        d = o > d ? o : d;
-        improved |= __shfl_down(improved, off);
-        isnan_ |= __shfl_down(isnan_, off);
-    }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_max[w] = d; s_flag[w] = improved | (isnan_ << 1); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    constexpr int VW = sizeof(vec) / sizeof(real);
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && !owners_only) {
+        __shared__ real s_max[4];
+        __shared__ int s_fl[4];
+        const volatile real *bc = a.bc;
+        real d = 0;
         int fl = 0;
-        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { d = s_max[i] > d ? s_max[i] : d; fl |= s_flag[i]; }
-        if ((fl & 1) && !first && any_improved) atomicOr(any_improved, 1);
-        if ((fl & 4) && any_improved) atomicOr(any_improved, 2);
-        if (max_du) {
-            // non-negative floats order like their bit patterns; NaN sorts above everything
-            using bits = typename BitsOf<real>::type;
-            real v = (fl & 2) ? (real)NAN : d;
-            bits u;
-            __builtin_memcpy(&u, &v, sizeof(bits));
-            if (fl & 2) u = u & ~((bits)1 << (sizeof(bits) * 8 - 1));
-            atomicMax(reinterpret_cast<bits *>(max_du), u);
+        for (int b = tid; b < a.B; b += 256) {
+            real v = a.du[b];
+            if (a.first || a.costs[b] <= bc[b] + a.eps) fl |= 1;
+            if (v != v) { fl |= 2; v = 0; }
+            d = v > d ? v : d;
+            if (a.status && (a.status[b] & MPC_ST_C_ASYMMETRIC)) fl |= 4;
         }
+        for (int off = 32; off > 0; off >>= 1) {
+            const real o = __shfl_down(d, off);
+            d = o > d ? o : d;
+            fl |= __shfl_down(fl, off);
+        }
+        if ((tid & 63) == 0) s_max[tid >> 6] = d, s_fl[tid >> 6] = fl;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) d = s_max[w] > d ? s_max[w] : d, fl |= s_fl[w];
+            if (fl & 2) d = (real)NAN;                  // a NaN norm anywhere: the maximum is NaN, as torch.max reports it
+            const int word = (((fl & 1) && !a.first) ? 1 : 0) | ((fl & 4) ? 2 : 0);
+            *reinterpret_cast<int *>(a.flags) = word;
+            *reinterpret_cast<real *>(a.flags + 8) = d;
+            if (a.host) {
+                *reinterpret_cast<volatile int *>(a.host) = word;
+                *reinterpret_cast<volatile real *>(a.host + 8) = d;
+                __threadfence_system();
+            }
+        }
+        return;
+    }
+    __shared__ int s_take[kSelPB];
+    const int b0 = (blockIdx.x - (owners_only ? 0 : 1)) * kSelPB;
+    const int nb = a.B - b0 < kSelPB ? a.B - b0 : kSelPB;
+    if (tid < nb) {
+        const int b = b0 + tid;
+        const real cnew = a.costs[b];
+        const int take = a.first || cnew <= a.bc[b] + a.eps;
+        if (take) {
+            a.bc[b] = cnew;
+            a.bd[b] = a.du[b];
+        }
+        s_take[tid] = take;
+    }
+    __syncthreads();
+    const int wx = nb * a.ns / VW, wu = nb * a.nc / VW, W = wx + wu;
+    const vec *__restrict__ x = reinterpret_cast<const vec *>(a.x), *__restrict__ u = reinterpret_cast<const vec *>(a.u);
+    vec *__restrict__ bx = reinterpret_cast<vec *>(a.bx), *__restrict__ bu = reinterpret_cast<vec *>(a.bu);
+    const int total = a.T * W;
+    for (int it = tid; it < total; it += 256) {
+        const int t = it / W, r = it - t * W;
+        const bool isx = r < wx;
+        const int e = isx ? r : r - wx, d = isx ? a.ns : a.nc;
+        if (!s_take[e * VW / d]) continue;
+        const long at = ((long)t * a.B + b0) * d / VW + e;
+        if (isx) bx[at] = x[at];
+        else bu[at] = u[at];
     }
 }
 
@@ -1056,7 +1109,12 @@ template <typename real> int launch_traj_cost(const StepParams<real> &p, real *x
 {
     if (!cost && x && !p.env.kind && p.ns + p.nc <= 16) {
         const long groups = p.B;
-        hipLaunchKernelGGL(traj_rows16_kernel<real>, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, st, p, x);
+        const dim3 grid((unsigned)((groups * 16 + 255) / 256));
+        bool vec = false;
+        if constexpr (sizeof(real) == 4)
+            vec = p.ns + p.nc == 16 && ((uintptr_t)p.F & 15) == 0 && p.F_st % 4 == 0 && p.F_sb % 4 == 0;
+        if (vec) hipLaunchKernelGGL((traj_rows16_kernel<real, sizeof(real) == 4>), grid, dim3(256), 0, st, p, x);
+        else hipLaunchKernelGGL((traj_rows16_kernel<real, false>), grid, dim3(256), 0, st, p, x);
         return check_launch("traj_rows16_kernel");
     }
     const size_t lds = generic_lds_bytes(p.ns, p.nc, sizeof(real));
@@ -1100,15 +1158,23 @@ int launch_kkt_prepare(int B, int T, int ns, int nc, const real *dl_dx, const re
 template <typename real>
 int launch_select_best(int B, int T, int ns, int nc, int first, real eps, const real *x, const real *u,
                        const real *costs, const real *du_norm, real *bx, real *bu, real *bc, real *bd,
-                       int *any_improved, real *max_du, const int *status, hipStream_t st)
+                       void *flags, void *host_flags, const int *status, hipStream_t st)
 {
-    const long tx = (long)T * B * ns, tu = (long)T * B * nc;
-    hipLaunchKernelGGL(select_copy_kernel<real>, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, st, tx, B, ns, first,
-                       eps, x, bx, costs, bc, any_improved, max_du);
-    hipLaunchKernelGGL(select_copy_kernel<real>, dim3((unsigned)((tu + 255) / 256)), dim3(256), 0, st, tu, B, nc, first,
-                       eps, u, bu, costs, bc, (int *)nullptr, (real *)nullptr);
-    hipLaunchKernelGGL(select_update_kernel<real>, dim3((B + 255) / 256), dim3(256), 0, st, B, first, eps, costs, du_norm,
-                       bc, bd, any_improved, max_du, status);
+    SelectArgs<real> a{B, T, ns, nc, first, eps, x, u, costs, du_norm, bx, bu, bc, bd, status,
+                       (unsigned char *)flags, (unsigned char *)host_flags};
+    const unsigned owners = (unsigned)((B + kSelPB - 1) / kSelPB);
+    bool vec4 = false;
+    if constexpr (sizeof(real) == 4)
+        vec4 = ns % 4 == 0 && nc % 4 == 0 && (((uintptr_t)x | (uintptr_t)bx | (uintptr_t)u | (uintptr_t)bu) & 15) == 0;
+    auto go = [&](unsigned grid, int owners_only) {
+        if (vec4) hipLaunchKernelGGL((select_best_kernel<real, float4>), dim3(grid), dim3(256), 0, st, a, owners_only);
+        else hipLaunchKernelGGL((select_best_kernel<real, real>), dim3(grid), dim3(256), 0, st, a, owners_only);
+    };
+    if (eps >= 0) go(1 + owners, 0);
+    else {                       // (a negative tolerance voids the argument that lets workgroup 0 run beside the owners)
+        go(1, 0);
+        go(owners, 1);
+    }
     return check_launch("select_best_kernel");
 }
 
@@ -1159,8 +1225,8 @@ int launch_env_linearize(const EnvDesc<real> &env, long N, const real *x, const 
     template int launch_env_linearize<real>(const EnvDesc<real> &, long, const real *, const real *, real *,   \
                                             real *, hipStream_t);                                             \
     template int launch_select_best<real>(int, int, int, int, int, real, const real *, const real *,          \
-                                          const real *, const real *, real *, real *, real *, real *, int *,  \
-                                          real *, const int *, hipStream_t);
+                                          const real *, const real *, real *, real *, real *, real *, void *, \
+                                          void *, const int *, hipStream_t);
 INSTANTIATE(float)
 INSTANTIATE(double)
 

@@ -19,7 +19,7 @@ BOUND_NONE, BOUND_SCALAR, BOUND_TENSOR = 0, 1, 2
 ST_PNQP_UNCONVERGED, ST_NONFINITE, ST_NOMINAL_OFF_DYNAMICS, ST_C_ASYMMETRIC, ST_QUU_SINGULAR = 1, 2, 4, 8, 16
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA16, IMPL_DPP16, IMPL_TINY, IMPL_MFMA40 = 0, 1, 2, 3, 4, 5
 
-ABI_VERSION = 5      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
+ABI_VERSION = 6      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
 
 _vp, _i32, _i64, _f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 
@@ -429,12 +429,8 @@ class HipBackend:
         o, keep_o = opts.to_struct(T, B, nc, C)
         kw = dict(device=dev, dtype=C.dtype)
         res = dict(new_x=torch.empty(T, B, ns, **kw) if out_x is None else out_x,
-                   new_u=torch.empty(T, B, nc, **kw) if out_u is None else out_u,
-                   costs=torch.empty(B, **kw), old_costs=torch.empty(B, **kw),
-                   full_du_norm=torch.empty(B, **kw), alpha_du_norm=torch.empty(B, **kw),
-                   alphas=torch.empty(B, **kw),
-                   qp_iters=torch.zeros(B, device=dev, dtype=torch.int32),
-                   status=torch.zeros(B, device=dev, dtype=torch.int32))
+                   new_u=torch.empty(T, B, nc, **kw) if out_u is None else out_u)
+        res.update(self._per_problem_outputs(B, dev, C.dtype))
         assert res["new_x"].is_contiguous() and res["new_u"].is_contiguous()
         out = Outputs()
         for k in res:
@@ -442,9 +438,21 @@ class HipBackend:
         nbytes = int(L.mpc_lqr_workspace_bytes(ctypes.byref(p)))
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8) if workspace is None else workspace
         assert ws.numel() >= nbytes
+        return self._bind_plan(p, o, out, res, ws, nbytes, int(impl), dev, (keep, keep_o))
+
+    @staticmethod
+    def _per_problem_outputs(B, dev, dtype):
+        """The seven [B] outputs of a step as views of two allocations (one fill): a plan is built per MPC.forward call, and
+        nine allocator calls + two fill launches per plan were a third of the host time in front of the first step."""
+        fl = torch.empty(5, B, device=dev, dtype=dtype)
+        it = torch.zeros(2, B, device=dev, dtype=torch.int32)
+        return dict(costs=fl[0], old_costs=fl[1], full_du_norm=fl[2], alpha_du_norm=fl[3], alphas=fl[4],
+                    qp_iters=it[0], status=it[1])
+
+    @staticmethod
+    def _bind_plan(p, o, out, res, ws, nbytes, impl, dev, keep):
         pp, op, up, wp = ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), ws.data_ptr()
-        fn = L.mpc_lqr_step
-        impl = int(impl)
+        fn = load().mpc_lqr_step
 
         def run():
             rc = fn(pp, op, up, wp, nbytes, impl, torch.cuda.current_stream(dev).cuda_stream)
@@ -452,8 +460,38 @@ class HipBackend:
                 _check(rc, "mpc_lqr_step")
             return res
         run.outputs = res
-        run._keep = (p, o, out, keep, keep_o, ws)
+        run._keep = (p, o, out, keep, ws)
+        run._bind = (nbytes, impl, dev)
         return run
+
+    def plan_variant(self, plan, opts=None, cur_x=None, cur_u=None, out_x=None, out_u=None):
+        """A second plan over the SAME problem tensors as `plan`, differing in the nominal it reads (`cur_x`, `cur_u`), the
+        buffers it writes (`out_x`, `out_u`) and / or its options: the structs are copied and patched, nothing is walked or
+        checked again (MPC.forward's ping-pong partner and its MPC_OPT_C_SYMMETRIC twins).  Without new out_x / out_u it also
+        shares the per-problem outputs of `plan` -- the two must then never be in flight together with different readers
+        (MPC.forward runs them on one stream, each consumed by the select that follows it)."""
+        p0, o0, out0, keep0, ws = plan._keep
+        nbytes, impl, dev = plan._bind
+        p = Problem.from_buffer_copy(p0)
+        out = Outputs.from_buffer_copy(out0)
+        res = dict(plan.outputs)
+        keep = [keep0]
+        T, B, ns, nc = p.T, p.B, p.ns, p.nc
+        if cur_x is not None:
+            assert cur_x.is_contiguous() and cur_u.is_contiguous() and tuple(cur_x.shape) == (T, B, ns) and tuple(cur_u.shape) == (T, B, nc)
+            p.cur_x, p.cur_u = cur_x.data_ptr(), cur_u.data_ptr()
+            keep += [cur_x, cur_u]
+        if out_x is not None:
+            assert out_x.is_contiguous() and out_u.is_contiguous() and tuple(out_x.shape) == (T, B, ns) and tuple(out_u.shape) == (T, B, nc)
+            res["new_x"], res["new_u"] = out_x, out_u
+            res.update(self._per_problem_outputs(B, dev, out_x.dtype))
+            for k in res:
+                setattr(out, k, res[k].data_ptr())
+        o = o0
+        if opts is not None:
+            o, keep_o = opts.to_struct(T, B, nc, res["new_x"])
+            keep.append(keep_o)
+        return self._bind_plan(p, o, out, res, ws, nbytes, impl, dev, keep)
 
     def lqr_sweep(self, x_init, C, c, F, cur_x, cur_u, opts):
         """c_back + lqr_backward only -> dict(K, k, old_costs, qp_iters, status)."""
@@ -712,26 +750,35 @@ class HipBackend:
         return F, f
 
     # -- (7) driver reductions ------------------------------------------------------------------
-    def select_best(self, first, eps, x, u, costs, du_norm, best, flags=None, status=None):
-        """In-place update of best = dict(x,u,costs,full_du_norm); returns the 2-word device flag
-        buffers (any_improved int32[1], max_du real[1]) without synchronising.  flags: write into
-        these two pre-allocated buffers.  status: the step's status words -- bit 1 of any_improved then
-        reports whether any of them carries ST_C_ASYMMETRIC."""
+    writes_host_flags = True
+
+    def select_best(self, first, eps, x, u, costs, du_norm, best, flags=None, status=None, host=None):
+        """In-place update of best = dict(x,u,costs,full_du_norm); returns the two result words (any_improved int32[1],
+        max_du real[1]) as device views, without synchronising.  flags: a `select_flags()` block to reuse.  status: the step's status words -- bit 1 of any_improved then reports whether any of them carries
+        ST_C_ASYMMETRIC.  host: 16 bytes of pinned host memory (uint8 tensor) the kernel also stores the two words in."""
         dev = _require_device(x, u, costs, du_norm)
         L = load()
         T, B, ns = x.shape
         nc = u.shape[2]
         if flags is None:
-            any_improved = torch.empty(1, device=dev, dtype=torch.int32)
-            max_du = torch.empty(1, device=dev, dtype=x.dtype)
-        else:
-            any_improved, max_du = flags
+            flags = self.select_flags(dev, x.dtype)
+        any_improved, max_du = flags
+        # the two views are bytes [0,4) and [8,8+size) of one 16-byte block (select_flags)
+        assert max_du.data_ptr() == any_improved.data_ptr() + 8
+        if host is not None:
+            assert host.is_pinned() and host.numel() * host.element_size() >= 16
         _check(L.mpc_select_best(_dtype_code(x), B, T, ns, nc, int(bool(first)), float(eps),
                                  x.data_ptr(), u.data_ptr(), costs.data_ptr(), du_norm.data_ptr(),
                                  best["x"].data_ptr(), best["u"].data_ptr(), best["costs"].data_ptr(),
-                                 best["full_du_norm"].data_ptr(), any_improved.data_ptr(), max_du.data_ptr(),
+                                 best["full_du_norm"].data_ptr(), any_improved.data_ptr(), _ptr(host),
                                  _ptr(status), _stream(dev)), "mpc_select_best")
         return any_improved, max_du
+
+    @staticmethod
+    def select_flags(device, dtype):
+        """The 16-byte device block mpc_select_best reports in, as its two views (int32 word, real maximum)."""
+        blk = torch.empty(16, dtype=torch.uint8, device=device)
+        return blk[0:4].view(torch.int32), blk[8:8 + torch.empty(0, dtype=dtype).element_size()].view(dtype)
 
 
 _backend = None

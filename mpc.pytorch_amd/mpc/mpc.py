@@ -54,11 +54,18 @@ class _FlagReader:
     """The two words the driver needs from the device per iteration (any problem improved, max ||du||),
     copied into pinned host memory asynchronously; `wait()` blocks on an event, not on the stream."""
 
-    def __init__(self, device, dtype):
-        # one 16-byte block: int32 flag at byte 0, the maximum (float32 / float64) at byte 8 -> one copy
-        self._dev = torch.zeros(16, dtype=torch.uint8, device=device)
-        self.device_flags = (self._dev[0:4].view(torch.int32), self._dev[8:8 + torch.empty(0, dtype=dtype).element_size()].view(dtype))
+    def __init__(self, device, dtype, be=None):
+        # int32 flag at byte 0, the maximum (float32 / float64) at byte 8 of one block
         self.cuda = device.type == "cuda"
+        # mpc_select_best stores its two words in page-locked host memory itself: nothing to copy, `start` only marks the
+        # place in the stream (the test stand-ins compute on the host and have no such path)
+        self.direct = self.cuda and getattr(be, "writes_host_flags", False)
+        if self.direct:
+            self.device_flags = be.select_flags(device, dtype)
+        else:
+            self._dev = torch.empty(16, dtype=torch.uint8, device=device)
+            self.device_flags = (self._dev[0:4].view(torch.int32), self._dev[8:8 + torch.empty(0, dtype=dtype).element_size()].view(dtype))
+        self.host_kw = {}
         if self.cuda:
             # page-locking memory costs milliseconds: one block per device, kept for the life of the process
             key = (device.type, device.index)
@@ -67,10 +74,13 @@ class _FlagReader:
             self._host = _PINNED[key]
             self.host = (self._host[0:4].view(torch.int32), self._host[8:8 + self.device_flags[1].element_size()].view(dtype))
             self.event = torch.cuda.Event()
+            if self.direct:
+                self.host_kw = dict(host=self._host)
 
     def start(self):
         if self.cuda:
-            self._host.copy_(self._dev, non_blocking=True)
+            if not self.direct:
+                self._host.copy_(self._dev, non_blocking=True)
             self.event.record()
 
     def wait(self):
@@ -260,8 +270,12 @@ class MPC(Module):
             opts.nominal_on_dynamics = True
         xb, ub = torch.empty_like(xa), torch.empty_like(ua)
         pa = be.plan_step(xi, cost.C, cost.c, F, f, xa, ua, opts, out_x=xb, out_u=ub)
-        pb = be.plan_step(xi, cost.C, cost.c, F, f, xb, ub, opts, out_x=xa, out_u=ua,
-                          workspace=pa._keep[-1] if hasattr(pa, "_keep") else None)
+        r = pa()                  # the first step is on its way before anything else of the loop is set up (host time hidden)
+        variant = getattr(be, "plan_variant", None)      # (the test backends build every plan from scratch)
+        if variant is not None:
+            pb = variant(pa, cur_x=xb, cur_u=ub, out_x=xa, out_u=ua)
+        else:
+            pb = be.plan_step(xi, cost.C, cost.c, F, f, xb, ub, opts, out_x=xa, out_u=ua)
         plans = (pa, pb)
         # C does not change during the solve: once the first step has reported that it is symmetric (no
         # MPC_ST_C_ASYMMETRIC in its status, read back with the convergence flags), the remaining steps run with the
@@ -275,13 +289,12 @@ class MPC(Module):
         best = dict(x=torch.empty_like(xa), u=torch.empty_like(ua),
                     costs=torch.empty(n_batch, dtype=xa.dtype, device=xa.device),
                     full_du_norm=torch.empty(n_batch, dtype=xa.dtype, device=xa.device))
-        reader = _FlagReader(xa.device, xa.dtype)
+        reader = _FlagReader(xa.device, xa.dtype, be)
         n_not_improved, i = 0, 0
-        r = launch(0)
         while True:
             # best-iterate tracking, :271-285 -- on the device
             be.select_best(i == 0, self.best_cost_eps, r["new_x"], r["new_u"], r["costs"], r["full_du_norm"],
-                           best, flags=reader.device_flags, status=r["status"] if i == 0 else None)
+                           best, flags=reader.device_flags, status=r["status"] if i == 0 else None, **reader.host_kw)
             reader.start()
             nxt = launch(i + 1) if i + 1 < self.lqr_iter else None        # overlaps the read-back
             bits, max_du_norm = reader.wait()
@@ -294,9 +307,11 @@ class MPC(Module):
                     import copy
                     so = copy.copy(opts)
                     so.c_symmetric = True
-                    ws = pa._keep[-1] if hasattr(pa, "_keep") else None
-                    sym_plans = (be.plan_step(xi, cost.C, cost.c, F, f, xa, ua, so, out_x=xb, out_u=ub, workspace=ws),
-                                 be.plan_step(xi, cost.C, cost.c, F, f, xb, ub, so, out_x=xa, out_u=ua, workspace=ws))
+                    if variant is not None:          # the same structs with one more option bit: no walk, no allocation
+                        sym_plans = (variant(pa, opts=so), variant(pb, opts=so))
+                    else:
+                        sym_plans = (be.plan_step(xi, cost.C, cost.c, F, f, xa, ua, so, out_x=xb, out_u=ub),
+                                     be.plan_step(xi, cost.C, cost.c, F, f, xb, ub, so, out_x=xa, out_u=ua))
             if self.flag_reducer is not None:          # shards agree on the batch-wide stop test (mpc.shard)
                 any_improved, max_du_norm = self.flag_reducer(any_improved, max_du_norm)
             n_not_improved += 1

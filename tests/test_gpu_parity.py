@@ -507,6 +507,44 @@ def test_select_best_kernel(be):
     assert torch.equal(best["x"], x) and int(any_imp.item()) == 0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("dims", [(50, 4096, 12, 4), (7, 1003, 12, 4), (5, 37, 3, 2), (3, 9, 5, 1), (1, 1, 4, 4)])
+def test_select_best_one_launch_flags_block_and_host_mirror(be, dtype, dims):
+    """ABI 6: one launch, the two result words also stored in page-locked host memory by the kernel, NaN norms reported
+    as torch.max reports them; vector and scalar copy paths, partial last workgroup, one flags block over several calls."""
+    T, B, ns, nc = dims
+    g = torch.Generator().manual_seed(B)
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=dtype).to(DEV)
+    flags = be.select_flags(torch.device(DEV), dtype)
+    host = torch.zeros(16, dtype=torch.uint8).pin_memory()
+    hview = (host[0:4].view(torch.int32), host[8:8 + torch.empty(0, dtype=dtype).element_size()].view(dtype))
+    best = dict(x=mk(T, B, ns), u=mk(T, B, nc), costs=mk(B), full_du_norm=mk(B).abs())
+    for call in range(4):
+        first = call == 0
+        x, u, costs, du = mk(T, B, ns), mk(T, B, nc), mk(B), mk(B).abs()
+        if call == 2 and B > 1:
+            du[B // 2] = float("nan")
+        if call == 3:
+            costs = best["costs"] + 1.0               # nothing improves
+        st = torch.zeros(B, dtype=torch.int32, device=DEV)
+        if call == 1:
+            st[B - 1] = 8
+        ref = {k: v.clone() for k, v in best.items()}
+        take = torch.ones(B, dtype=torch.bool, device=DEV) if first else costs <= ref["costs"] + 1e-4
+        ai, md = be.select_best(first, 1e-4, x, u, costs, du, best, flags=flags, status=st, host=host)
+        torch.cuda.synchronize()
+        assert torch.equal(best["x"], torch.where(take.view(1, B, 1), x, ref["x"]))
+        assert torch.equal(best["u"], torch.where(take.view(1, B, 1), u, ref["u"]))
+        assert torch.equal(best["costs"], torch.where(take, costs, ref["costs"]))
+        assert torch.allclose(best["full_du_norm"], torch.where(take, du, ref["full_du_norm"]), rtol=0, atol=0, equal_nan=True)
+        want_bits = (0 if first else int(bool(take.any()))) | (2 if call == 1 else 0)
+        assert int(ai.item()) == want_bits == int(hview[0][0])
+        if call == 2 and B > 1:
+            assert md.isnan().all() and hview[1].isnan().all()
+        else:
+            assert float(md.item()) == float(du.max().item()) == float(hview[1][0])
+
+
 def test_select_best_reports_an_asymmetric_C(be):
     """bit 1 of mpc_select_best's flag word: some status word of the step carries MPC_ST_C_ASYMMETRIC -- how mpc.MPC learns,
     with the convergence flags it reads anyway, whether it may promise a symmetric C to the remaining steps."""
@@ -831,7 +869,7 @@ def test_step_and_select_are_graph_capturable(be, shape):
     plan = be.plan_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts)
     best = dict(x=torch.zeros(T, B, ns, device=DEV), u=torch.zeros(T, B, nc, device=DEV),
                 costs=torch.zeros(B, device=DEV), full_du_norm=torch.zeros(B, device=DEV))
-    flags = (torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, device=DEV))
+    flags = be.select_flags(torch.device(DEV), torch.float32)
     plan()                                                    # warm up outside the capture
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
