@@ -163,12 +163,15 @@ int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p);
  *     n_state <= 12, n_ctrl <= 4), 3 = 4-problems-per-wave DPP kernel (f32, n_state = 12,
  *     n_ctrl = 4, 16-byte aligned blocks), 4 = one lane per problem (n_ctrl = 1, n_state <= 6, f32/f64;
  *     the only fast kernel that takes a simulator as true_dynamics), 5 = register-resident MFMA step (f32,
- *     n_state = 32, n_ctrl = 8).  Auto picks 5, 4, 3, 2, else 1.  The fused kernels need
+ *     n_state = 32, n_ctrl = 8), 6 = one wavefront per problem (the shapes of 4, f32, the problem in LDS: everything
+ *     independent over t for all timesteps at once, all line-search trials at once; max_linesearch_iter <= 64; what auto
+ *     takes instead of 4 while B is too small to fill the chip with a lane per problem).
+ *     Auto picks 5, 6 / 4, 3, 2, else 1.  The fused kernels need
  *     `workspace` (mpc_lqr_workspace_bytes, 16-byte aligned); out->K / out->k are optional there. */
 int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
                  void *workspace, int64_t workspace_bytes, int impl, void *stream);
 
-/* Does kernel `impl` (1 generic, 2 fused MFMA, 3 DPP, 4 lane-per-problem, 5 MFMA sweep) accept this problem/options pair?  1 yes, 0 no. */
+/* Does kernel `impl` (1 generic, 2 fused MFMA, 3 DPP, 4 lane-per-problem, 5 MFMA sweep, 6 wavefront-per-problem) accept this problem/options pair?  1 yes, 0 no. */
 int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, int impl);
 
 /* (2) The sweep alone: c_back + lqr_backward (mpc/lqr_step.py:284-296, 52-160).

@@ -147,18 +147,38 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
             return launch_step_generic<real>(sp, 1, st);
         }
     }
-    if (sp.env.kind && sp.env.linearize && !(phase_mask == 3 && tiny_supported(p->ns, p->nc) && (impl == 0 || impl == 4)))
+    if (sp.env.kind && sp.env.linearize && !(phase_mask == 3 && tiny_supported(p->ns, p->nc) && (impl == 0 || impl == 4 || impl == 6)))
         return fail(MPC_E_ARG, "in-kernel linearisation needs the lane-per-problem kernel (n_ctrl = 1, n_state <= 6)");
     if (sp.env.kind && (impl == 2 || impl == 3))
         return fail(MPC_E_ARG, "a simulator as true_dynamics runs on the generic kernels only");
-    if (impl == 4 && (phase_mask != 3 || !tiny_supported(p->ns, p->nc)))
-        return fail(MPC_E_DIMS, "lane-per-problem kernel needs n_ctrl = 1, n_state <= 6");
-    if (phase_mask == 3 && (impl == 4 || (impl == 0 && tiny_supported(p->ns, p->nc)))) {
-        // one lane per problem; gains parked in the workspace as [T][ns+1][B]
-        if (!workspace || workspace_bytes < needK + needk)
+    if ((impl == 4 || impl == 6) && (phase_mask != 3 || !tiny_supported(p->ns, p->nc)))
+        return fail(MPC_E_DIMS, "lane-per-problem / wavefront-per-problem kernel needs n_ctrl = 1, n_state <= 6");
+    if (impl == 6) {
+        bool ok = false;
+        if constexpr (sizeof(real) == 4) ok = wave1_supported(sp);
+        if (!ok) return fail(MPC_E_DIMS, "the row-per-problem kernel is float32, max_linesearch_iter <= 16, four problems in 150 KiB of LDS");
+    }
+    if (phase_mask == 3 && (impl == 4 || impl == 6 || (impl == 0 && tiny_supported(p->ns, p->nc)))) {
+        // one lane per problem; gains parked in the workspace as [T][ns+1][B], behind them one trajectory column
+        // [T][ns+1] per line-search trial lane (<= 8 per problem): 9 (ns + 1) reals per problem-step <= 504 bytes
+        if (!workspace || workspace_bytes < (needK + needk) * 9)
             return fail(MPC_E_ARG, "workspace too small (see mpc_lqr_workspace_bytes)");
         sp.Kk = (real *)workspace;
-        // (this kernel keeps Q and V as general matrices, like the reference: nothing to test, nothing to re-solve)
+        // (these kernels keep Q and V as general matrices, like the reference: nothing to test, nothing to re-solve)
+        if constexpr (sizeof(real) == 4) {
+            // A lane per problem leaves the chip empty at the batch sizes iLQR is run at (B = 1024: 16 .. 128 wavefronts
+            // on 1024 SIMDs) and its time is one lane's instruction count times the horizon; a 16-lane row per problem
+            // does everything that is independent over t for 16 timesteps at once and every line-search trial at once.
+            // Worth its sixteen lanes while all its wavefronts are resident together, at most two to a SIMD (measured,
+            // profiles/r03_experiments.md section 6: pendulum up to B = 8192, cart-pole -- 39.6 KB of LDS per wavefront --
+            // up to 4096; twice that and the lane-per-problem kernel is level or ahead).
+            bool wide = impl == 6;
+            if (impl == 0 && wave1_supported(sp)) {
+                const long per_cu = (160L * 1024) / wave1_lds_bytes(sp);
+                wide = (p->B + 3) / 4 <= (device_facts().simds / 4) * (per_cu < 8 ? per_cu : 8);
+            }
+            if (wide) return launch_step_wave1(sp, st);
+        }
         return launch_step_tiny<real>(sp, st);
     }
     if (phase_mask == 3 && impl != 1 && !sp.env.kind) {
@@ -224,7 +244,7 @@ int mpc_lqr_abi_version(void) { return MPC_LQR_ABI_VERSION; }
 const char *mpc_lqr_build_info(void)
 {
     return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32>, lqr_step_dpp16<f32>, "
-           "lqr_step_tiny<f32,f64>, lqr_step_mfma40<f32>, nn_rollout<f32>, nn_linearize<f32>, env_linearize, kkt_grads, kkt_fused<f32>, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
+           "lqr_step_tiny<f32,f64>, lqr_step_wave1<f32>, lqr_step_mfma40<f32>, nn_rollout<f32>, nn_linearize<f32>, env_linearize, kkt_grads, kkt_fused<f32>, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
 }
 
 const char *mpc_lqr_last_error(void) { return g_last_error.c_str(); }
@@ -255,6 +275,7 @@ int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, i
     if (!p || check_problem(p, false, false) != MPC_OK || check_options(p, o) != MPC_OK) return 0;
     if (impl == 1) return generic_lds_bytes(p->ns, p->nc, p->dtype == MPC_F64 ? 8 : 4) <= 160 * 1024;
     if (impl == 4) return tiny_supported(p->ns, p->nc) ? 1 : 0;
+    if (impl == 6) return (p->dtype == MPC_F32 && tiny_supported(p->ns, p->nc) && wave1_supported(make_params<float>(p, o, nullptr))) ? 1 : 0;
     if (impl == 5) {
         if (p->dtype != MPC_F32) return 0;
         mpc_lqr_outputs out;

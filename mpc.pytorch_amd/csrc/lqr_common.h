@@ -58,6 +58,10 @@ int launch_kkt_fused_dpp16(const StepParams<float> &p, const float *dl_dx, const
 // one lane per problem, n_ctrl = 1, n_state <= 6, f32 / f64 (lqr_tiny.hip)
 bool tiny_supported(int ns, int nc);
 template <typename real> int launch_step_tiny(const StepParams<real> &p, hipStream_t st);
+// a 16-lane row per problem, the same shapes, f32, the problem in LDS (lqr_wave1.hip)
+bool wave1_supported(const StepParams<float> &p);
+long wave1_lds_bytes(const StepParams<float> &p);        // per wavefront (four problems)
+int launch_step_wave1(const StepParams<float> &p, hipStream_t st);
 
 // wave-per-problem trajectory kernel for 16 < n <= 64, f32 (kkt_wave.hip)
 bool traj_wave_supported(const StepParams<float> &p);

@@ -16,9 +16,12 @@ struct GroupLanes {
     {
         for (int i = 0; i < G_; ++i) all[i] = __shfl(mine, base_ + i);
     }
+    // The group's lanes sit in one wavefront, the workgroup IS that wavefront: what one lane stored is visible to the
+    // others once the stores have left the wavefront (workgroup scope: a wait, no cache maintenance).  An agent-scope
+    // fence here writes the XCD's L2 back -- once per wavefront, microseconds each.
     __device__ void gains_visible() const
     {
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
 };
@@ -31,7 +34,7 @@ __global__ void __launch_bounds__(64) lqr_step_tiny_kernel(StepParams<real> p, i
     const bool active = b < p.B;
     if (!active) b = p.B - 1;                // whole idle groups shadow the last problem, storing nothing
     GroupLanes L{G, gid % G, (int)(threadIdx.x & 63) & ~(G - 1)};
-    tiny::lqr_step_problem<real, NS>(p, b, p.Kk, L, active);
+    tiny::lqr_step_problem<real, NS>(p, b, p.Kk, p.Kk + (long)p.T * (NS + 1) * p.B, L, active);
 }
 
 // lanes per problem: one per line-search trial of a round, a power of two <= 8

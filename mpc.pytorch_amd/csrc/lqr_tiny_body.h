@@ -217,19 +217,21 @@ MPC_HD void sweep_problem(const StepParams<real> &p, int b, real *Kw, bool write
 
 }
 
-// One rollout with step size alpha (mpc/lqr_step.py:186-241): trajectory cost and ||u - u'||; the trajectory
-// itself is written only when `store`.
+// One rollout with step size alpha (mpc/lqr_step.py:186-241): trajectory cost and ||u - u'||.  The trajectory goes
+// to ox [T][OB][NS] / ou [T][OB] at column ob (the outputs themselves for trial 0, a scratch column per trial lane
+// otherwise); ox == nullptr: nowhere.
 template <typename real, int NS>
-MPC_HD void rollout_pass(const StepParams<real> &p, int b, const real *Kw, real alpha, bool store, double &cost,
-                         real &dun)
+MPC_HD void rollout_pass(const StepParams<real> &p, int b, const real *Kw, real alpha, real *ox, real *ou, long OB, long ob,
+                         double &cost, real &dun)
 {
     constexpr int N = NS + 1;
     const int T = p.T, B = p.B;
+    const bool store = ox != nullptr;
     real x[NS], dx[NS];
     for (int i = 0; i < NS; ++i) {
         x[i] = p.x_init[(long)b * NS + i];
         dx[i] = 0;
-        if (store) p.new_x[(long)b * NS + i] = x[i];
+        if (store) ox[ob * NS + i] = x[i];
     }
     real da = 0;
     double ca = 0;
@@ -286,7 +288,7 @@ MPC_HD void rollout_pass(const StepParams<real> &p, int b, const real *Kw, real 
             }
             un = clampr<real>(un, l, h);
         }
-        if (store) p.new_u[tb] = un;
+        if (store) ou[(long)t * OB + ob] = un;
         da += (u - un) * (u - un);
         real tau[N];
         for (int j = 0; j < NS; ++j) tau[j] = x[j];
@@ -309,11 +311,11 @@ MPC_HD void rollout_pass(const StepParams<real> &p, int b, const real *Kw, real 
                     xn[i] = ft ? s + ft[i] : s;
                 }
             }
-            const long tb1 = (long)(t + 1) * B + b;
+            const long o1 = ((long)(t + 1) * OB + ob) * NS;
             for (int i = 0; i < NS; ++i) {
                 x[i] = xn[i];
                 dx[i] = xn[i] - now.xn[i];
-                if (store) p.new_x[tb1 * NS + i] = xn[i];
+                if (store) ox[o1 + i] = xn[i];
             }
         }
     }
@@ -324,13 +326,18 @@ MPC_HD void rollout_pass(const StepParams<real> &p, int b, const real *Kw, real 
 // One problem on a group of lanes.  The reference's line search (:176-179, 247) tries alpha = decay^j for
 // j = 0, 1, ... and keeps the first trial whose cost is not worse than the nominal's, else the last one.  A
 // group evaluates G consecutive trials at once; trial 0 (alpha = 1, the usual winner) writes its trajectory
-// as it goes, any other winner is replayed once.  `active`: this lane belongs to a real problem (idle tail
-// lanes shadow the last one so that the group exchanges stay uniform).
+// to the outputs as it goes, every other trial into its lane's column of the scratch Tw (x [T][B*G][NS], then
+// u [T][B*G]), from where the group copies an accepted one -- rounds 1-2 replayed the accepted trial instead, a whole
+// extra rollout pass for every wavefront in which one problem took a shorter step (all of them, in practice:
+// 72 -> 52 us per pendulum step, 103 -> 84 per cart-pole step).  `active`: this lane belongs to a real problem
+// (idle tail lanes shadow the last one so that the group exchanges stay uniform).
 template <typename real, int NS, class Lanes>
-MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw, const Lanes &L, bool active = true)
+MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw, real *Tw, const Lanes &L, bool active = true)
 {
     const int G = L.G(), g = L.g();
     const bool writer = active && g == 0;
+    const long OB = (long)p.B * G, ob = (long)b * G + g;
+    real *const tx = Tw, *const tu = Tw + (long)p.T * OB * NS;
     double old_cost;
     int status, qp_total;
     sweep_problem<real, NS>(p, b, Kw, writer, old_cost, status, qp_total);
@@ -345,7 +352,12 @@ MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw, const L
         for (int i = 0; i < j; ++i) alpha *= p.ls_decay;          // the same products the sequential search forms
         double cost = 0;
         real dun = 0;
-        if (j < p.max_ls) rollout_pass<real, NS>(p, b, Kw, alpha, writer && j == 0, cost, dun);
+        if (j < p.max_ls) {              // (ONE call: the lanes of a group differ in where they store, not in what they run)
+            const bool first = j == 0;
+            real *ox = first ? p.new_x : tx;
+            if (!active) ox = nullptr;
+            rollout_pass<real, NS>(p, b, Kw, alpha, ox, first ? p.new_u : tu, first ? (long)p.B : OB, first ? (long)b : ob, cost, dun);
+        }
         double costs[8], duns[8];
         L.gather(cost, costs);
         L.gather((double)dun, duns);
@@ -363,10 +375,15 @@ MPC_HD void lqr_step_problem(const StepParams<real> &p, int b, real *Kw, const L
             for (int i = 0; i < win; ++i) win_alpha *= p.ls_decay;
         }
     }
-    if (win != 0) {                      // replay the accepted trial to write its trajectory
-        double c2;
-        real d2;
-        rollout_pass<real, NS>(p, b, Kw, win_alpha, writer, c2, d2);
+    if (win != 0) {                      // the accepted trial's trajectory: out of its lane's scratch column, a slice per lane
+        L.gains_visible();
+        const long wb = (long)b * G + win % G;
+        if (active)
+            for (int t = g; t < p.T; t += G) {
+                const long src = (long)t * OB + wb, dst = (long)t * p.B + b;
+                for (int i = 0; i < NS; ++i) p.new_x[dst * NS + i] = tx[src * NS + i];
+                p.new_u[dst] = tu[src];
+            }
     }
     (void)cost0;
     if (!writer) return;

@@ -38,7 +38,7 @@ struct Wave {
     int ia[2][NL];
     unsigned seq[NL];
     // LDS of the (single-wave) workgroup + the in-order queue of LDS-DMA instructions in flight
-    unsigned char lds[3 * 13056 + 512];     // the largest of the kernels' rings
+    alignas(16) unsigned char lds[160 * 1024];   // a CU's whole LDS (the staged kernels' rings use 40 KB of it, lqr_wave1 up to 150)
     struct Dma { unsigned char data[NL][16]; bool act[NL]; unsigned char seen[NL]; unsigned off; int size; };
     Dma q[64];
     int qn;
@@ -325,6 +325,29 @@ static inline double row_sum_f64(double x)
     }
     return x;
 }
+// lqr_wave1.hip's extra primitives: the LDS as an array of floats, doubles across lanes
+static inline float &sm(int i) { return reinterpret_cast<float *>(emu::W.lds)[i]; }
+static inline double shfl_xor_f64(double x, int m)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fd[gen][l] = x;
+    emu::yield_lane();
+    return w.fd[gen][l ^ m];
+}
+static inline double readlane_f64(double x, int src)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fd[gen][l] = x;
+    emu::yield_lane();
+    return w.fd[gen][src];
+}
+static inline double wave_sum_f64(double x)
+{
+    for (int off = 32; off > 0; off >>= 1) x += shfl_xor_f64(x, off);
+    return x;
+}
 static inline bool any(bool c)
 {
     emu::Wave &w = emu::W;
@@ -567,17 +590,17 @@ template <typename real> static int tiny_host(const mpc_lqr_problem *p, const mp
     mpclqr::StepParams<real> sp = mpclqr::make_params<real>(p, o, out);
     if (!mpclqr::tiny::shape_supported(sp.ns, sp.nc)) return MPC_E_DIMS;
     if (!sp.new_x || !sp.new_u) return MPC_E_NULL;
-    const size_t need = (size_t)sp.T * sp.B * (sp.ns + 1);
+    const size_t gains = (size_t)sp.T * sp.B * (sp.ns + 1), need = 2 * gains;     // + one trial column per problem (G = 1)
     real *kw = (real *)malloc(need * sizeof(real));
     for (size_t i = 0; i < need; ++i) kw[i] = (real)NAN;
     for (int b = 0; b < sp.B; ++b) {
         switch (sp.ns) {
-        case 1: mpclqr::tiny::lqr_step_problem<real, 1>(sp, b, kw, mpclqr::tiny::OneLane()); break;
-        case 2: mpclqr::tiny::lqr_step_problem<real, 2>(sp, b, kw, mpclqr::tiny::OneLane()); break;
-        case 3: mpclqr::tiny::lqr_step_problem<real, 3>(sp, b, kw, mpclqr::tiny::OneLane()); break;
-        case 4: mpclqr::tiny::lqr_step_problem<real, 4>(sp, b, kw, mpclqr::tiny::OneLane()); break;
-        case 5: mpclqr::tiny::lqr_step_problem<real, 5>(sp, b, kw, mpclqr::tiny::OneLane()); break;
-        case 6: mpclqr::tiny::lqr_step_problem<real, 6>(sp, b, kw, mpclqr::tiny::OneLane()); break;
+        case 1: mpclqr::tiny::lqr_step_problem<real, 1>(sp, b, kw, kw + gains, mpclqr::tiny::OneLane()); break;
+        case 2: mpclqr::tiny::lqr_step_problem<real, 2>(sp, b, kw, kw + gains, mpclqr::tiny::OneLane()); break;
+        case 3: mpclqr::tiny::lqr_step_problem<real, 3>(sp, b, kw, kw + gains, mpclqr::tiny::OneLane()); break;
+        case 4: mpclqr::tiny::lqr_step_problem<real, 4>(sp, b, kw, kw + gains, mpclqr::tiny::OneLane()); break;
+        case 5: mpclqr::tiny::lqr_step_problem<real, 5>(sp, b, kw, kw + gains, mpclqr::tiny::OneLane()); break;
+        case 6: mpclqr::tiny::lqr_step_problem<real, 6>(sp, b, kw, kw + gains, mpclqr::tiny::OneLane()); break;
         }
     }
     free(kw);
@@ -610,5 +633,31 @@ extern "C" int emu_lqr_sweep_mfma40(const mpc_lqr_problem *p, const mpc_lqr_opti
     if (!(sp.ns == 32 && sp.nc == 8) || !sp.K || !sp.k) return MPC_E_DIMS;
     g_p = &sp;
     for (int b = 0; b < sp.B; ++b) emu::run_wave(b, body_mfma40);
+    return 0;
+}
+
+// ---- lqr_wave1_body.h: one wavefront per problem, n_ctrl = 1, n_state <= 6, the problem in LDS ----
+#include "../../mpc.pytorch_amd/csrc/lqr_wave1_body.h"
+template <int NS> static void body_wave1_ns() { mpclqr::wave1::step_wave<NS>(*g_p); }
+static void body_wave1()
+{
+    switch (g_p->ns) {
+    case 1: body_wave1_ns<1>(); break;
+    case 2: body_wave1_ns<2>(); break;
+    case 3: body_wave1_ns<3>(); break;
+    case 4: body_wave1_ns<4>(); break;
+    case 5: body_wave1_ns<5>(); break;
+    case 6: body_wave1_ns<6>(); break;
+    }
+}
+extern "C" int emu_lqr_step_wave1(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out)
+{
+    if (p->dtype != MPC_F32) return MPC_E_DTYPE;
+    mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, out);
+    if (!mpclqr::wave1::shape_supported(sp)) return MPC_E_DIMS;
+    if (!sp.new_x || !sp.new_u) return MPC_E_NULL;
+    if ((size_t)mpclqr::wave1::layout(sp).total * 16 > sizeof(emu::W.lds)) return MPC_E_DIMS;
+    g_p = &sp;
+    for (int w = 0; w < (sp.B + 3) / 4; ++w) emu::run_wave(w, body_wave1);
     return 0;
 }

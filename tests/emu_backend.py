@@ -24,7 +24,7 @@ def build(ring2=False):
     src = os.path.join(_EMU, "emu_mfma16.cpp")
     csrc = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc")
     deps = [src] + [os.path.join(csrc, h) for h in ("lqr_mfma16_body.h", "lqr_dpp16_body.h", "lqr_small_math.h",
-                                                    "lqr_params.h", "env_dynamics.h", "lqr_tiny_body.h", "lqr_mfma40_body.h")]
+                                                    "lqr_params.h", "env_dynamics.h", "lqr_tiny_body.h", "lqr_wave1_body.h", "lqr_mfma40_body.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         cxx = "/opt/rocm/lib/llvm/bin/clang++"
         if not os.path.exists(cxx):
@@ -133,6 +133,10 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
         rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
     elif kernel == "tiny":
         fn = lib().emu_lqr_step_tiny
+        fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs)]
+        rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
+    elif kernel == "wave1":
+        fn = lib().emu_lqr_step_wave1
         fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs)]
         rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
     elif kernel == "dpp16":

@@ -467,6 +467,98 @@ def test_tiny_body_rolls_out_through_the_simulator(emu, name, kind):
 
 
 # ---------------------------------------------------------------------------------------------
+# One wavefront per problem (csrc/lqr_wave1_body.h): the same shapes, float32, the problem in LDS
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", NC1_CASES)
+def test_wave1_body_matches_oracle(emu, name):
+    """The one-control fixtures through the emulated wavefront-per-problem kernel (timestep-parallel set-up, DPP-row Riccati
+    recursion, all line-search trials at once) against the float64 oracle, at the float32 tolerance of the fused kernels."""
+    from oracle import lqr_oracle as O
+    z = golden(name)
+    kw = step_kwargs(z)
+    o = O.lqr_step(lockstep=False, return_gains=True, **{k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == "f" else v)
+                                                          for k, v in kw.items()})
+    r = emu.lqr_step(kernel="wave1", dtype=np.float32, **kw)
+    tol = dict(rtol=1e-3, atol=1e-4)
+    for key in ("new_x", "new_u", "costs", "old_costs", "full_du_norm", "alpha_du_norm", "K", "k"):
+        np.testing.assert_allclose(r[key], o[key], err_msg=key, **tol)
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+    assert (kw["u_lower"] is None) == (r["qp_iters"].max() == 0)
+
+
+@pytest.mark.parametrize("ns", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("case", ["scalar_bounds", "tensor_bounds", "delta_u", "no_f", "backtrack", "masked", "T1", "many_trials"])
+def test_wave1_body_options_against_the_lane_per_problem_body(emu, ns, case):
+    """Every option of the step on the wavefront-per-problem kernel against the lane-per-problem body in float32 (the same
+    arithmetic spread differently: agreement to float32 rounding of the sums, the same accepted step sizes) and the
+    float64 oracle; `many_trials`: a line search of 11 trials (eleven trial lanes, sixteen-lane cost slices)."""
+    from oracle import lqr_oracle as O
+    for attempt in range(40):
+        if _wave1_option_case(emu, O, ns, case, 1000 * ns + len(case) + 7919 * attempt):
+            return
+    assert False, "no seed made the line search backtrack"
+
+
+def _wave1_option_case(emu, O, ns, case, seed):
+    rng = np.random.default_rng(seed)
+    T, B, n = (1 if case == "T1" else 7), 6, ns + 1
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A) + 0.1 * np.eye(n)
+    if case in ("backtrack", "many_trials"):
+        C[:, :, :ns, :ns] -= (4.0 if case == "backtrack" else 6.0) * np.eye(ns)
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((max(T - 1, 0), B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((max(T - 1, 0), B, ns, 1)) / np.sqrt(ns)), 3)
+    f = None if case == "no_f" else 0.1 * rng.standard_normal((max(T - 1, 0), B, ns))
+    x_init = rng.standard_normal((B, ns))
+    cur_u = np.clip(0.3 * rng.standard_normal((T, B, 1)), -0.4, 0.4)
+    cur_x, _ = O.traj_cost(x_init, cur_u, F, f)
+    kw = dict(x_init=x_init, C=C, c=c, F=F, f=f, cur_x=cur_x, cur_u=cur_u, linesearch_decay=0.5,
+              max_linesearch_iter=11 if case == "many_trials" else 4)
+    if case == "tensor_bounds":
+        kw.update(u_lower=-0.5 - rng.random((T, B, 1)), u_upper=0.5 + rng.random((T, B, 1)))
+    elif case == "delta_u":
+        kw.update(u_lower=-0.5, u_upper=0.5, delta_u=0.05)
+    elif case == "masked":
+        kw.update(u_zero_I=rng.random((T, B, 1)) < 0.4)
+    elif case != "no_f":
+        kw.update(u_lower=-0.5, u_upper=0.5)
+    kw = {k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype.kind == "f" else v) for k, v in kw.items()}
+    o = O.lqr_step(lockstep=False, **{k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == "f" else v) for k, v in kw.items()})
+    t = emu.lqr_step(kernel="tiny", dtype=np.float32, **kw)
+    r = emu.lqr_step(kernel="wave1", dtype=np.float32, **kw)
+    same = np.isclose(r["alphas"], o["alphas"], rtol=1e-6) & np.isclose(t["alphas"], o["alphas"], rtol=1e-6)
+    assert same.mean() >= 0.8, (r["alphas"], t["alphas"], o["alphas"])          # (a tie of two trial costs may fall either way)
+    for key in ("new_x", "new_u", "costs", "old_costs", "full_du_norm", "alpha_du_norm"):
+        np.testing.assert_allclose(r[key][..., same, :] if r[key].ndim == 3 else r[key][same],
+                                   o[key][..., same, :] if o[key].ndim == 3 else o[key][same], rtol=2e-3, atol=5e-4, err_msg=key)
+        np.testing.assert_allclose(r[key][..., same, :] if r[key].ndim == 3 else r[key][same],
+                                   t[key][..., same, :] if t[key].ndim == 3 else t[key][same], rtol=1e-3, atol=2e-4, err_msg=key + " (tiny)")
+    if case == "many_trials":
+        return bool((o["alphas"] < 0.5 ** 7.5).any())          # some problem went into the second round of trial lanes
+    return case != "backtrack" or bool((o["alphas"] < 1).any())
+
+
+@pytest.mark.parametrize("name,kind", [("env_pendulum_f64", 1), ("env_pendulum_full_f64", 2), ("env_cartpole_f64", 3)])
+def test_wave1_body_rolls_out_and_linearises_through_the_simulator(emu, name, kind):
+    """LQRStep(true_dynamics=PendulumDx / CartpoleDx) of the reference (mpc/lqr_step.py:223-225): the wavefront-per-problem
+    kernel with the simulator in its rollouts, F, f given and then with the simulator's Jacobian taken inside the kernel."""
+    z = golden(name)
+    args = [v.astype(np.float32) for v in (z["x_init"], z["Q"], z["p"], z["step_F"], z["step_f"], z["step_cur_x"], z["step_cur_u"])]
+    common = dict(linesearch_decay=float(z["decay"][0]), max_linesearch_iter=int(z["max_ls"][0]), kernel="wave1", dtype=np.float32)
+    envt = (kind, z["params"], 0.05, 100.0 if kind == 3 else 2.0)
+    r = emu.lqr_step(*args, float(z["lower"][0]), float(z["upper"][0]), env=envt, **common)
+    tol = dict(rtol=2e-3, atol=5e-4)
+    np.testing.assert_allclose(r["new_x"], z["step_new_x"], **tol)
+    np.testing.assert_allclose(r["new_u"], z["step_new_u"], **tol)
+    np.testing.assert_allclose(r["costs"], z["step_costs"], rtol=1e-3)
+    args[3], args[4] = np.zeros_like(args[3]), None
+    r2 = emu.lqr_step(*args, float(z["lower"][0]), float(z["upper"][0]), env=envt + (True,), **common)
+    np.testing.assert_allclose(r2["new_x"], z["step_new_x"], **tol)
+    np.testing.assert_allclose(r2["new_u"], z["step_new_u"], **tol)
+
+
+# ---------------------------------------------------------------------------------------------
 # The register-resident MFMA sweep (csrc/lqr_mfma40_body.h): n_state = 32, n_ctrl = 8, unconstrained
 # ---------------------------------------------------------------------------------------------
 def _cfg5_problem(rng, T, B):

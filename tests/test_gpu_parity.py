@@ -64,7 +64,7 @@ def impls_for(z):
     ns, nc = int(z["meta"][0]), int(z["meta"][1])
     from mpc import _native
     out = [1]
-    for impl in (_native.IMPL_MFMA16, _native.IMPL_DPP16, _native.IMPL_TINY, _native.IMPL_MFMA40):
+    for impl in (_native.IMPL_MFMA16, _native.IMPL_DPP16, _native.IMPL_TINY, _native.IMPL_MFMA40, _native.IMPL_WAVE1):
         if _native.backend().impl_supported(ns, nc, torch.from_numpy(z["C"][:0]).dtype, impl):
             out.append(impl)
     return out
@@ -113,7 +113,7 @@ def test_lqr_step_parity(be, name):
     asym = asymmetric_problems(z)
     for impl in [0] + impls_for(z):
         r = hip_step(be, z, impl=impl)
-        if asym.any() and impl not in (0, _native.IMPL_GENERIC, _native.IMPL_TINY):
+        if asym.any() and impl not in (0, _native.IMPL_GENERIC, _native.IMPL_TINY, _native.IMPL_WAVE1):
             # a FORCED fused kernel reads C through its symmetry: it owes MPC_ST_C_ASYMMETRIC on exactly the problems whose
             # C is not symmetric (include/mpc_lqr.h) and the reference's numbers on the others
             assert ((r["status"] & 8) != 0).tolist() == asym.tolist(), (impl, r["status"])
@@ -243,6 +243,61 @@ def test_lane_per_problem_kernel_parallel_line_search(be, ns, max_ls):
         np.testing.assert_allclose(host(r[k]), o[k], rtol=1e-9, atol=1e-10, err_msg=k)
     if max_ls > 2:
         assert len(np.unique(o["alphas"])) >= 2          # different trials win across the batch
+
+
+@pytest.mark.parametrize("ns", [1, 3, 5, 6])
+@pytest.mark.parametrize("max_ls", [1, 2, 5, 11])
+@pytest.mark.parametrize("mode", ["box", "free", "masked"])
+def test_wavefront_per_problem_kernel(be, ns, max_ls, mode):
+    """impl 6 (lqr_wave1): the one-control shapes with a wavefront per problem -- timestep-parallel set-up in LDS, the Riccati
+    recursion on a DPP row, every line-search trial on a lane of its own -- float32, against the float64 oracle and the
+    lane-per-problem kernel on the same float32 inputs."""
+    from oracle import lqr_oracle as O
+    from mpc._native import StepOptions, IMPL_TINY, IMPL_WAVE1
+    rng = np.random.default_rng(31 * ns + max_ls + len(mode))
+    T, B, n = 9, 37, ns + 1
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A) + 0.1 * np.eye(n)
+    C[:, :, :ns, :ns] -= 3.0 * np.eye(ns)
+    C = C + 0.05 * rng.standard_normal(C.shape)                  # not symmetric: these kernels use C as given
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.3 * rng.standard_normal((T - 1, B, ns, ns)) / np.sqrt(ns), rng.standard_normal((T - 1, B, ns, 1))), 3)
+    f = 0.1 * rng.standard_normal((T - 1, B, ns))
+    x_init = rng.standard_normal((B, ns))
+    cur_u = np.clip(0.3 * rng.standard_normal((T, B, 1)), -0.4, 0.4)
+    h = [a.astype(np.float32) for a in (x_init, C, c, F, f)] 
+    cu = cur_u.astype(np.float32)
+    cur_x, _ = O.traj_cost(h[0].astype(np.float64), cu.astype(np.float64), h[3].astype(np.float64), h[4].astype(np.float64))
+    cx = cur_x.astype(np.float32)
+    kw = dict(linesearch_decay=0.5, max_linesearch_iter=max_ls)
+    mask = None
+    if mode == "box":
+        kw.update(u_lower=-0.5, u_upper=0.5)
+    elif mode == "masked":
+        mask = rng.random((T, B, 1)) < 0.3
+    d64 = lambda a: a.astype(np.float64)
+    o = O.lqr_step(d64(h[0]), d64(h[1]), d64(h[2]), d64(h[3]), d64(h[4]), d64(cx), d64(cu), kw.get("u_lower"), kw.get("u_upper"),
+                   u_zero_I=mask, linesearch_decay=0.5, max_linesearch_iter=max_ls, lockstep=False)
+    opts = StepOptions(u_zero_I=None if mask is None else torch.from_numpy(mask), **kw)
+    args = [torch.from_numpy(a).to(DEV) for a in (h[0], h[1], h[2], h[3], h[4], cx, cu)]
+    r = be.lqr_step(*args, opts, impl=IMPL_WAVE1, want_gains=True)
+    t = be.lqr_step(*args, opts, impl=IMPL_TINY, want_gains=True)
+    torch.cuda.synchronize()
+    same = np.isclose(host(r["alphas"]), o["alphas"], rtol=1e-6) & np.isclose(host(t["alphas"]), o["alphas"], rtol=1e-6)
+    assert same.mean() > 0.85                                    # (a float32 tie of two trial costs may fall either way)
+    for k in ("costs", "old_costs", "full_du_norm", "alpha_du_norm", "new_x", "new_u"):
+        a, b, w = host(r[k]), host(t[k]), o[k]
+        sel = (lambda v: v[:, same] if v.ndim == 3 else v[same])
+        np.testing.assert_allclose(sel(a), sel(w), rtol=2e-3, atol=5e-4, err_msg=k)
+        np.testing.assert_allclose(sel(a), sel(b), rtol=1e-3, atol=2e-4, err_msg=k + " (lane-per-problem)")
+    # (the xx block of C is indefinite: a problem whose Quu comes out near zero has gains in the thousands, and float32
+    #  rounding of Quu is all of their difference -- such problems are compared through their trajectories only)
+    tame = (np.abs(host(t["K"])).reshape(T, B, -1).max(axis=(0, 2)) < 50) & (np.abs(host(t["k"])).reshape(T, B, -1).max(axis=(0, 2)) < 50)
+    assert tame.mean() > 0.7
+    for k in ("K", "k"):
+        a, b = host(r[k])[:, tame], host(t[k])[:, tame]
+        assert np.abs(a - b).max() <= 5e-3 * max(1.0, np.abs(b).max()), (k, np.abs(a - b).max(), np.abs(b).max())
+    assert np.array_equal(host(r["qp_iters"]) > 0, host(t["qp_iters"]) > 0)
 
 
 @pytest.mark.parametrize("T,B", [(12, 7), (1, 2), (64, 3)])

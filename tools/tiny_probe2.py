@@ -22,12 +22,13 @@ for kind, B, T in (("pendulum", 1024, 20), ("cartpole", 4096, 25)):
         env = dx.native_env()
         env.linearize = True
         res = {}
-        for name, ls, sweep in (("sweep", 1, True), ("sweep+1pass", 1, False), ("real", dx.max_linesearch_iter, False)):
+        for name, ls, sweep in (("sweep+1pass", 1, False), ("real", dx.max_linesearch_iter, False)):
             o = StepOptions(u_lower=dx.lower, u_upper=dx.upper, linesearch_decay=dx.linesearch_decay, max_linesearch_iter=ls,
                             true_dynamics=env, sweep_only=sweep)
-            plan = be.plan_step(x0, Q, pp, None, None, x, u, o)
-            r = plan(); torch.cuda.synchronize()
-            res[name] = round(1e3 * timed(plan, n=20), 1)
+            for impl in (4, 6):
+                plan = be.plan_step(x0, Q, pp, None, None, x, u, o, impl=impl)
+                r = plan(); torch.cuda.synchronize()
+                res[name + "_impl%d" % impl] = round(1e3 * timed(plan, n=20), 1)
             if name == "real":
                 res["alpha_lt1"] = float((r["alphas"] < 1).float().mean())
         out["%s_it%d" % (kind, IT)] = res
