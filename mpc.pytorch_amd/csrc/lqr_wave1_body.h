@@ -151,11 +151,16 @@ template <int NS> MPC_DEV void step_wave(const StepParams<float> &p)
             g.hi = bounded ? wv::sm(L.hi + t) : 0.f;
             g.mask = masked_call ? wv::sm(L.mask + t) : 0.f;
         };
-        Stage ahead;
-        fetch(T - 1, ahead);
-        for (int t = T - 1; t >= 0; --t) {
-            const Stage now = ahead;
-            if (t > 0) fetch(t - 1, ahead);
+#ifdef MPC_W1_PROF                                             // (diagnostic build: clock stamps of one timestep of wavefront 0 into qp_iters[8..])
+#define W1_STAMP(k) do { if (t == T / 2) stamp[k] = wv::clock(); } while (0)
+#define W1_STAMP5 stamp[5] = wv::clock()
+        long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+#define W1_STAMP(k) do { } while (0)
+#define W1_STAMP5 (void)0
+#endif
+        auto riccati = [&](int t, const Stage &now) {
+            W1_STAMP(0);
             float qj = now.cb, Qc[N], Qjn = now.Crn;          // q[j]; column j of Q; Q[j][NS]
             for (int i = 0; i < N; ++i) Qc[i] = now.Cc[i];
             if (t < T - 1) {                                  // Q = C + F'VF, q = c_back + F'v (:65-70)
@@ -170,6 +175,7 @@ template <int NS> MPC_DEV void step_wave(const StepParams<float> &p)
                 }
                 static_for<0, NS>([&](auto m) { wv::fmac_bcast<m.value>(qj, vj, now.Fc[m.value]); });
             }
+            W1_STAMP(1);
             const float Quu = wv::bcast<NS>(Qc[NS]), qu = wv::bcast<NS>(qj);
             float Kj, k;
             if (!bounded) {
@@ -186,6 +192,8 @@ template <int NS> MPC_DEV void step_wave(const StepParams<float> &p)
                 float x = warm ? kprev : -(qu * env_inv(Quu));
                 float Hf;
                 bool is_free, conv;
+                // (per-lane loops as the compiler lays them out: a wavefront-uniform predicated loop with `any` votes, as the
+                //  12/4 kernel's pnqp4_rows has, measured 2 us SLOWER here -- the votes sit on the dependent chain)
                 const int it = tiny::pnqp1<float>(Quu, qu, lb, ub, x, Hf, is_free, p.pnqp_iter, conv);
                 qp_total += 1 + it;                           // :140
                 if (!conv) status |= MPC_ST_PNQP_UNCONVERGED;
@@ -194,6 +202,7 @@ template <int NS> MPC_DEV void step_wave(const StepParams<float> &p)
                 Kj = is_free ? -(Qc[NS] * env_inv(Hf)) : 0.f; // :142-146
             }
             kprev = k;
+            W1_STAMP(2);
             if (j < N) {
                 wv::sm(L.K + t * N + j) = j < NS ? Kj : k;
                 const long tb = (long)t * B + b;
@@ -204,6 +213,7 @@ template <int NS> MPC_DEV void step_wave(const StepParams<float> &p)
                 }
             }
             // :155-158 V = Qxx + Qxu K + K'Qux + K'Quu K, v likewise (unmasked Quu, qu)
+            W1_STAMP(3);
             const float Mj = Qc[NS] + Quu * Kj, mk = qu + Quu * k;
             static_for<0, NS>([&](auto i) {
                 float v = Qc[i.value];
@@ -212,7 +222,24 @@ template <int NS> MPC_DEV void step_wave(const StepParams<float> &p)
                 Vc[i.value] = v;
             });
             vj = qj + Qjn * k + Kj * mk;
+            W1_STAMP(4);
+            if (t == T / 2 - 1) W1_STAMP5;
+        };
+        // two stages that take turns (the body is compiled twice): the operands of step t - 1 are read from LDS while step t
+        // is computed, and nothing is copied from one stage to the other
+        Stage sa, sb;
+        fetch(T - 1, sa);
+        for (int t = T - 1; t >= 0; t -= 2) {
+            if (t > 0) fetch(t - 1, sb);
+            riccati(t, sa);
+            if (t == 0) break;
+            if (t > 1) fetch(t - 2, sa);
+            riccati(t - 1, sb);
         }
+#ifdef MPC_W1_PROF
+        if (wv::problem() == 0 && lane == 0 && p.qp_iters)
+            for (int k = 0; k < 5; ++k) p.qp_iters[8 + k] = (int)(stamp[k + 1] - stamp[k]);
+#endif
     }
     wv::lds_sync();
 
@@ -237,11 +264,7 @@ template <int NS> MPC_DEV void step_wave(const StepParams<float> &p)
             g.hi = bounded ? wv::sm(L.hi + t) : 0.f;
             for (int i = 0; i < NS; ++i) g.xn[i] = t < T - 1 ? wv::sm(L.tau + (t + 1) * N + i) : 0.f;
         };
-        Stage ahead;
-        fetch(0, ahead);
-        for (int t = 0; t < T; ++t) {
-            const Stage now = ahead;
-            if (t + 1 < T) fetch(t + 1, ahead);
+        auto advance = [&](int t, const Stage &now) {
             float r = 0;
             for (int i = 0; i < NS; ++i) r += now.K[i] * dx[i];
             const float u = now.u;
@@ -276,6 +299,15 @@ template <int NS> MPC_DEV void step_wave(const StepParams<float> &p)
                     dx[i] = xn[i] - now.xn[i];
                 }
             }
+        };
+        Stage sa, sb;                                  // (two stages taking turns, as in the recursion)
+        fetch(0, sa);
+        for (int t = 0; t < T; t += 2) {
+            if (t + 1 < T) fetch(t + 1, sb);
+            advance(t, sa);
+            if (t + 1 >= T) break;
+            if (t + 2 < T) fetch(t + 2, sa);
+            advance(t + 1, sb);
         }
         dun = sqrtf(da);
     }
@@ -321,6 +353,9 @@ template <int NS> MPC_DEV void step_wave(const StepParams<float> &p)
     if (p.full_du_norm) p.full_du_norm[b] = full;
     if (p.alpha_du_norm) p.alpha_du_norm[b] = win_dun;
     if (p.alphas) p.alphas[b] = win_alpha;
+#ifdef MPC_W1_PROF
+    if (b >= 8 && b < 16) return;
+#endif
     if (p.qp_iters) p.qp_iters[b] = qp_total;
     if (p.status) p.status[b] = status;
 }
