@@ -293,13 +293,14 @@ int mpc_mlp_linearize(const mpc_mlp_dynamics *net, int n_state, int n_ctrl, int6
  *     any(take) on a call with first == 0; bit 1 = some status[b] has MPC_ST_C_ASYMMETRIC (`status` [B] = the step's
  *     status words, may be NULL); the real at byte 8 = max_b du_norm[b] (NaN if any is).
  *     `host_flags`: NULL, or 16 bytes of page-locked host memory the device can write (hipHostMalloc): the kernel
- *     stores the same two results there as well (same offsets) -- the driver loop waits for an event recorded behind
- *     this call and reads them, with no device-to-host copy in between.  (ABI 5 took `int32_t *any_improved, void
+ *     stores the same two results there as well (same offsets) and then `host_tag` at byte 4: the driver loop polls that
+ *     word for the tag of its call -- no device-to-host copy, no event (whose system-scope release costs the next kernel
+ *     6 us) -- or waits for an event recorded behind the call.  (ABI 5 took `int32_t *any_improved, void
  *     *max_du_norm` in these two positions and needed three launches.) */
 int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double best_cost_eps,
                     const void *x, const void *u, const void *costs, const void *du_norm,
                     void *best_x, void *best_u, void *best_costs, void *best_du_norm,
-                    void *flags, void *host_flags, const int32_t *status, void *stream);
+                    void *flags, void *host_flags, int32_t host_tag, const int32_t *status, void *stream);
 
 #ifdef __cplusplus
 }

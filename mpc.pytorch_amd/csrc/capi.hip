@@ -553,8 +553,8 @@ int mpc_traj_cost(const mpc_lqr_problem *p, void *x, void *cost, void *stream)
 
 int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double best_cost_eps, const void *x,
                     const void *u, const void *costs, const void *du_norm, void *best_x, void *best_u,
-                    void *best_costs, void *best_du_norm, void *flags, void *host_flags, const int32_t *status,
-                    void *stream)
+                    void *best_costs, void *best_du_norm, void *flags, void *host_flags, int32_t host_tag,
+                    const int32_t *status, void *stream)
 {
     if (dtype != MPC_F32 && dtype != MPC_F64) return fail(MPC_E_DTYPE, "bad dtype");
     if (B < 0 || T < 1 || ns < 1 || nc < 1) return fail(MPC_E_DIMS, "bad dims");
@@ -567,11 +567,11 @@ int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double b
         return launch_select_best<float>(B, T, ns, nc, first, (float)best_cost_eps, (const float *)x,
                                          (const float *)u, (const float *)costs, (const float *)du_norm,
                                          (float *)best_x, (float *)best_u, (float *)best_costs,
-                                         (float *)best_du_norm, flags, host_flags, status, st);
+                                         (float *)best_du_norm, flags, host_flags, host_tag, status, st);
     return launch_select_best<double>(B, T, ns, nc, first, best_cost_eps, (const double *)x, (const double *)u,
                                       (const double *)costs, (const double *)du_norm, (double *)best_x,
                                       (double *)best_u, (double *)best_costs, (double *)best_du_norm,
-                                      flags, host_flags, status, st);
+                                      flags, host_flags, host_tag, status, st);
 }
 
 }  // extern "C"

@@ -32,7 +32,7 @@ template <typename real> int launch_kkt_prepare(int B, int T, int ns, int nc, co
 template <typename real> int launch_select_best(int B, int T, int ns, int nc, int first, real eps,
                                                 const real *x, const real *u, const real *costs,
                                                 const real *du_norm, real *bx, real *bu, real *bc,
-                                                real *bd, void *flags, void *host_flags, const int *status,
+                                                real *bd, void *flags, void *host_flags, int host_tag, const int *status,
                                                 hipStream_t st);
 template <typename real> int launch_env_linearize(const EnvDesc<real> &env, long N, const real *x, const real *u,
                                                   real *F, real *f, hipStream_t st);

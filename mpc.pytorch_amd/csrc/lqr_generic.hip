@@ -987,6 +987,7 @@ template <typename real> struct SelectArgs {
     real *bx, *bu, *bc, *bd;
     const int *status;
     unsigned char *flags, *host;      // int32 result bits at byte 0, the maximum at byte 8; host: the same, page-locked
+    int host_tag;                     // stored at byte 4 of `host` once the two results are visible there
 };
 
 template <typename real, typename vec>
@@ -1023,6 +1024,8 @@ __global__ void __launch_bounds__(256) select_best_kernel(SelectArgs<real> a, in
             if (a.host) {
                 *reinterpret_cast<volatile int *>(a.host) = word;
                 *reinterpret_cast<volatile real *>(a.host + 8) = d;
+                __threadfence_system();               // the results first, then the tag a polling host waits for
+                *reinterpret_cast<volatile int *>(a.host + 4) = a.host_tag;
                 __threadfence_system();
             }
         }
@@ -1105,8 +1108,38 @@ int launch_pnqp(int B, int n, const real *H, const real *q, const real *lo, cons
     return check_launch("pnqp_kernel");
 }
 
+// util.get_traj through a shipped simulator (mpc/util.py:102-126 with the module of mpc/env_dx): a lane per problem -- the
+// transition is ~100 instructions of one lane's arithmetic, and the generic kernel above spends a workgroup and two barriers
+// per timestep on it (19 / 33 us at the pendulum / cart-pole sizes against 7 / 11 here).
+template <typename real>
+__global__ void __launch_bounds__(64) env_traj_lane_kernel(StepParams<real> p, real *x)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= p.B) return;
+    const int ns = p.ns, T = p.T, B = p.B;
+    real xi[5], xn[5];
+    for (int i = 0; i < ns; ++i) {
+        xi[i] = p.x_init[(long)b * ns + i];
+        x[(long)b * ns + i] = xi[i];
+    }
+    real u = T > 1 ? p.cur_u[b] : (real)0;
+    for (int t = 0; t < T - 1; ++t) {
+        const real un = t + 1 < T - 1 ? p.cur_u[(long)(t + 1) * B + b] : (real)0;     // (next step's control in flight)
+        env_step<real>(p.env, xi, u, xn, nullptr);
+        for (int i = 0; i < ns; ++i) {
+            xi[i] = xn[i];
+            x[((long)(t + 1) * B + b) * ns + i] = xn[i];
+        }
+        u = un;
+    }
+}
+
 template <typename real> int launch_traj_cost(const StepParams<real> &p, real *x, real *cost, hipStream_t st)
 {
+    if (!cost && x && p.env.kind && p.nc == 1 && p.ns <= 5) {
+        hipLaunchKernelGGL(env_traj_lane_kernel<real>, dim3((unsigned)((p.B + 63) / 64)), dim3(64), 0, st, p, x);
+        return check_launch("env_traj_lane_kernel");
+    }
     if (!cost && x && !p.env.kind && p.ns + p.nc <= 16) {
         const long groups = p.B;
         const dim3 grid((unsigned)((groups * 16 + 255) / 256));
@@ -1158,10 +1191,10 @@ int launch_kkt_prepare(int B, int T, int ns, int nc, const real *dl_dx, const re
 template <typename real>
 int launch_select_best(int B, int T, int ns, int nc, int first, real eps, const real *x, const real *u,
                        const real *costs, const real *du_norm, real *bx, real *bu, real *bc, real *bd,
-                       void *flags, void *host_flags, const int *status, hipStream_t st)
+                       void *flags, void *host_flags, int host_tag, const int *status, hipStream_t st)
 {
     SelectArgs<real> a{B, T, ns, nc, first, eps, x, u, costs, du_norm, bx, bu, bc, bd, status,
-                       (unsigned char *)flags, (unsigned char *)host_flags};
+                       (unsigned char *)flags, (unsigned char *)host_flags, host_tag};
     const unsigned owners = (unsigned)((B + kSelPB - 1) / kSelPB);
     bool vec4 = false;
     if constexpr (sizeof(real) == 4)
@@ -1226,7 +1259,7 @@ int launch_env_linearize(const EnvDesc<real> &env, long N, const real *x, const 
                                             real *, hipStream_t);                                             \
     template int launch_select_best<real>(int, int, int, int, int, real, const real *, const real *,          \
                                           const real *, const real *, real *, real *, real *, real *, void *, \
-                                          void *, const int *, hipStream_t);
+                                          void *, int, const int *, hipStream_t);
 INSTANTIATE(float)
 INSTANTIATE(double)
 

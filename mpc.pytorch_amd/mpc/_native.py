@@ -62,11 +62,32 @@ class EnvSpec:
         self.n_ctrl = 1
 
     def to_struct(self, like):
-        prm = self.params.detach().to(device=like.device, dtype=like.dtype).contiguous()
+        prm = _device_copy_of(self.params, like.device, like.dtype)
         e = EnvDynamics()
         e.kind, e.params, e.dt, e.u_max = self.kind, prm.data_ptr(), self.dt, self.u_max
         e.linearize = int(self.linearize)
         return e, prm
+
+
+_PARAM_COPIES = {}
+
+
+def _device_copy_of(t, device, dtype):
+    """`t` on `device` as `dtype`, contiguous.  A simulator's parameter block usually lives on the host and MPC.forward asks for it
+    three times per solve: the copy is kept until the tensor is replaced or written to (its version counter moves -- an
+    optimiser step on learned parameters does that)."""
+    if t.device == device and t.dtype == dtype and t.is_contiguous():
+        return t.detach()
+    import weakref
+    key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, str(device), dtype)
+    hit = _PARAM_COPIES.get(key)
+    if hit is not None and hit[0]() is t and hit[1] == t._version:
+        return hit[2]
+    if len(_PARAM_COPIES) > 64:
+        _PARAM_COPIES.clear()
+    c = t.detach().to(device=device, dtype=dtype).contiguous()
+    _PARAM_COPIES[key] = (weakref.ref(t), t._version, c)
+    return c
 
 
 MLP_MAX_LAYERS = 4
@@ -201,7 +222,7 @@ def load():
     L.mpc_traj_cost.argtypes = [PP, _vp, _vp, _vp]
     L.mpc_env_traj_cost.argtypes = [PP, ctypes.POINTER(EnvDynamics), _vp, _vp, _vp]
     L.mpc_env_linearize.argtypes = [ctypes.POINTER(EnvDynamics), ctypes.c_int, _i64, _vp, _vp, _vp, _vp, _vp]
-    L.mpc_select_best.argtypes = [ctypes.c_int] * 6 + [_f64] + [_vp] * 12
+    L.mpc_select_best.argtypes = [ctypes.c_int] * 6 + [_f64] + [_vp] * 10 + [ctypes.c_int32, _vp, _vp]
     MP = ctypes.POINTER(MlpDynamics)
     L.mpc_mlp_workspace_bytes.restype = _i64
     L.mpc_mlp_workspace_bytes.argtypes = [MP]
@@ -752,10 +773,11 @@ class HipBackend:
     # -- (7) driver reductions ------------------------------------------------------------------
     writes_host_flags = True
 
-    def select_best(self, first, eps, x, u, costs, du_norm, best, flags=None, status=None, host=None):
+    def select_best(self, first, eps, x, u, costs, du_norm, best, flags=None, status=None, host=None, tag=0):
         """In-place update of best = dict(x,u,costs,full_du_norm); returns the two result words (any_improved int32[1],
         max_du real[1]) as device views, without synchronising.  flags: a `select_flags()` block to reuse.  status: the step's status words -- bit 1 of any_improved then reports whether any of them carries
-        ST_C_ASYMMETRIC.  host: 16 bytes of pinned host memory (uint8 tensor) the kernel also stores the two words in."""
+        ST_C_ASYMMETRIC.  host: 16 bytes of pinned host memory (uint8 tensor) the kernel also stores the two words in, followed
+        by the int32 `tag` at byte 4 (what a polling caller waits for)."""
         dev = _require_device(x, u, costs, du_norm)
         L = load()
         T, B, ns = x.shape
@@ -770,7 +792,7 @@ class HipBackend:
         _check(L.mpc_select_best(_dtype_code(x), B, T, ns, nc, int(bool(first)), float(eps),
                                  x.data_ptr(), u.data_ptr(), costs.data_ptr(), du_norm.data_ptr(),
                                  best["x"].data_ptr(), best["u"].data_ptr(), best["costs"].data_ptr(),
-                                 best["full_du_norm"].data_ptr(), any_improved.data_ptr(), _ptr(host),
+                                 best["full_du_norm"].data_ptr(), any_improved.data_ptr(), _ptr(host), int(tag),
                                  _ptr(status), _stream(dev)), "mpc_select_best")
         return any_improved, max_du
 

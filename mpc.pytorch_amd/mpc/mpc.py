@@ -51,40 +51,59 @@ _PINNED = {}
 
 
 class _FlagReader:
-    """The two words the driver needs from the device per iteration (any problem improved, max ||du||),
-    copied into pinned host memory asynchronously; `wait()` blocks on an event, not on the stream."""
+    """The two words the driver needs from the device per iteration (any problem improved, max ||du||).
+    With the HIP backend the select kernel stores them in page-locked host memory itself, followed by a tag; `wait()` polls
+    that tag -- no device-to-host copy and no event (an event's system-scope release held the next kernel back by 6 us per
+    iteration).  Other backends (the test stand-ins): an asynchronous copy and an event."""
+
+    _POLL_TIMEOUT_S = 20.0
 
     def __init__(self, device, dtype, be=None):
-        # int32 flag at byte 0, the maximum (float32 / float64) at byte 8 of one block
+        # int32 flag at byte 0, the tag at byte 4, the maximum (float32 / float64) at byte 8 of one block
         self.cuda = device.type == "cuda"
-        # mpc_select_best stores its two words in page-locked host memory itself: nothing to copy, `start` only marks the
-        # place in the stream (the test stand-ins compute on the host and have no such path)
         self.direct = self.cuda and getattr(be, "writes_host_flags", False)
         if self.direct:
             self.device_flags = be.select_flags(device, dtype)
         else:
             self._dev = torch.empty(16, dtype=torch.uint8, device=device)
             self.device_flags = (self._dev[0:4].view(torch.int32), self._dev[8:8 + torch.empty(0, dtype=dtype).element_size()].view(dtype))
-        self.host_kw = {}
         if self.cuda:
-            # page-locking memory costs milliseconds: one block per device, kept for the life of the process
-            key = (device.type, device.index)
+            # page-locking memory costs milliseconds: one block per device and stream, kept for the life of the process
+            key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
             if key not in _PINNED:
-                _PINNED[key] = torch.zeros(16, dtype=torch.uint8).pin_memory()
-            self._host = _PINNED[key]
+                blk = torch.zeros(16, dtype=torch.uint8).pin_memory()
+                _PINNED[key] = [blk, blk.numpy().view("int32"), 0]
+            self._slot = _PINNED[key]
+            self._host = self._slot[0]
             self.host = (self._host[0:4].view(torch.int32), self._host[8:8 + self.device_flags[1].element_size()].view(dtype))
-            self.event = torch.cuda.Event()
-            if self.direct:
-                self.host_kw = dict(host=self._host)
+            if not self.direct:
+                self.event = torch.cuda.Event()
+
+    def select_kw(self):
+        """keyword arguments of the select call this reader will wait for"""
+        if not self.direct:
+            return {}
+        self._slot[2] = (self._slot[2] % 0x7fffffff) + 1          # a tag no earlier call on this block has used (never 0)
+        return dict(host=self._host, tag=self._slot[2])
 
     def start(self):
-        if self.cuda:
-            if not self.direct:
-                self._host.copy_(self._dev, non_blocking=True)
+        if self.cuda and not self.direct:
+            self._host.copy_(self._dev, non_blocking=True)
             self.event.record()
 
     def wait(self):
         """-> (flag bits: 1 = some problem improved, 2 = some C is not symmetric; max ||du||)"""
+        if self.direct:
+            words, tag = self._slot[1], self._slot[2]
+            if words[1] != tag:
+                import time
+                t0 = time.monotonic()
+                while words[1] != tag:
+                    if time.monotonic() - t0 > self._POLL_TIMEOUT_S:
+                        torch.cuda.synchronize()              # surfaces a launch failure as the error it is
+                        if words[1] != tag:
+                            raise RuntimeError("mpc_select_best did not report (tag %d, host word %d)" % (tag, int(words[1])))
+            return int(self.host[0][0]), float(self.host[1][0])
         if self.cuda:
             self.event.synchronize()
             return int(self.host[0][0]), float(self.host[1][0])
@@ -294,7 +313,7 @@ class MPC(Module):
         while True:
             # best-iterate tracking, :271-285 -- on the device
             be.select_best(i == 0, self.best_cost_eps, r["new_x"], r["new_u"], r["costs"], r["full_du_norm"],
-                           best, flags=reader.device_flags, status=r["status"] if i == 0 else None, **reader.host_kw)
+                           best, flags=reader.device_flags, status=r["status"] if i == 0 else None, **reader.select_kw())
             reader.start()
             nxt = launch(i + 1) if i + 1 < self.lqr_iter else None        # overlaps the read-back
             bits, max_du_norm = reader.wait()

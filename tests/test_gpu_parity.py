@@ -586,7 +586,13 @@ def test_select_best_one_launch_flags_block_and_host_mirror(be, dtype, dims):
             st[B - 1] = 8
         ref = {k: v.clone() for k, v in best.items()}
         take = torch.ones(B, dtype=torch.bool, device=DEV) if first else costs <= ref["costs"] + 1e-4
-        ai, md = be.select_best(first, 1e-4, x, u, costs, du, best, flags=flags, status=st, host=host)
+        ai, md = be.select_best(first, 1e-4, x, u, costs, du, best, flags=flags, status=st, host=host, tag=1000 + call)
+        words = host.numpy().view("int32")
+        import time
+        t0 = time.monotonic()
+        while words[1] != 1000 + call:                          # the tag lands behind the results, with no event and no sync
+            assert time.monotonic() - t0 < 10.0
+        assert int(hview[0][0]) == (0 if first else int(bool(take.any()))) | (2 if call == 1 else 0)
         torch.cuda.synchronize()
         assert torch.equal(best["x"], torch.where(take.view(1, B, 1), x, ref["x"]))
         assert torch.equal(best["u"], torch.where(take.view(1, B, 1), u, ref["u"]))
