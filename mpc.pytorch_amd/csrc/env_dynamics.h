@@ -55,6 +55,23 @@ MPC_HD float env_cos(float x)
 }
 MPC_HD double env_sin(double x) { return sin(x); }
 MPC_HD double env_cos(double x) { return cos(x); }
+// both of one angle behind ONE range test (a lane-dependent branch costs a lone wavefront ~50 clocks)
+MPC_HD void env_sincos(float x, float &s, float &c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (fabsf(x) <= MPC_ENV_FAST_TRIG_MAX) {
+        s = __sinf(x);
+        c = __cosf(x);
+    } else {
+        s = sinf(x);
+        c = cosf(x);
+    }
+#else
+    s = sinf(x);
+    c = cosf(x);
+#endif
+}
+MPC_HD void env_sincos(double x, double &s, double &c) { s = sin(x), c = cos(x); }
 
 // 1 / x and 1 / sqrt(x).  float on the device: v_rcp_f32 / v_rsq_f32 and one Newton step (<= 1 ulp, 3 instructions); `a / b`
 // compiles to the IEEE sequence (v_div_scale x2, v_rcp, four FMAs, v_div_fmas, v_div_fixup: 10 instructions), of which
@@ -87,13 +104,11 @@ template <typename real>
 MPC_HD void rotate_direction(real c, real s, real delta, real &c2, real &s2)
 {
     const real r2 = c * c + s * s;
-    real cu = 1, su = 0;                              // atan2(0, 0) = 0
-    if (r2 > 0) {
-        const real rinv = env_rsqrt(r2);
-        cu = c * rinv;
-        su = s * rinv;
-    }
-    const real cd = env_cos(delta), sd = env_sin(delta);
+    const real rinv = env_rsqrt(r2);                  // (selects, not a branch: r2 = 0 leaves an unused inf / NaN behind)
+    const real cu = r2 > 0 ? c * rinv : (real)1;      // atan2(0, 0) = 0
+    const real su = r2 > 0 ? s * rinv : (real)0;
+    real cd, sd;
+    env_sincos(delta, sd, cd);
     c2 = cu * cd - su * sd;
     s2 = su * cd + cu * sd;
 }
@@ -164,8 +179,7 @@ MPC_HD void env_step(const EnvDesc<real> &e, const real *x, real u, real *out, r
         acc = kg * env_sin(th + b) + ku * uc - d * th;            // pendulum.py:73-75
         acc_th = kg * env_cos(th + b) - d;
         const real th2 = th + dt * (w + dt * acc);
-        c2 = env_cos(th2);
-        s2 = env_sin(th2);
+        env_sincos(th2, s2, c2);
     }
     const real w2 = w + dt * acc;
     out[0] = c2;

@@ -31,6 +31,7 @@ MPC_DEV double shfl_xor_f64(double x, int off) { return __shfl_xor(x, off); }
 MPC_DEV double readlane_f64(double x, int src) { return __shfl(x, src); }
 MPC_DEV float readlane(float x, int src) { return __shfl(x, src); }
 MPC_DEV unsigned long long ballot(bool c) { return __ballot(c); }
+MPC_DEV bool any(bool c) { return __ballot(c) != 0ull; }
 MPC_DEV int ctz64(unsigned long long m) { return __builtin_ctzll(m); }
 // the workgroup is this one wavefront and its LDS instructions execute in order: the phases only have to be kept apart
 MPC_DEV void lds_sync()

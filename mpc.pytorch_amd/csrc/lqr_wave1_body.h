@@ -21,6 +21,10 @@
 #include <type_traits>
 #include "lqr_tiny_body.h"
 
+#ifndef MPC_STAT
+#define MPC_STAT(i)          // (tests/emu counts events through this)
+#endif
+
 namespace mpclqr {
 namespace wave1 {
 
@@ -65,6 +69,50 @@ MPC_HD bool shape_supported(const StepParams<float> &p)
     if (!(p.nc == 1 && p.ns >= 1 && p.ns <= 6 && p.T >= 1 && p.max_ls >= 1 && p.max_ls <= 16)) return false;
     if ((long)p.T * 49 * 16 > 160 * 1024) return false;                   // (before the sum below could overflow)
     return (long)layout(p).total * 16 <= 150 * 1024;                      // four problems per wavefront
+}
+
+// tiny::pnqp1 (mpc/pnqp.py:5-82 with n = 1) without its loops, for the case that is nearly every case: H > 0.  Then the
+// iteration is over after at most two passes, and what it leaves behind can be written down directly --
+//   pass 0 at x0 = clamp(warm start): clamped with the gradient pointing outward, or a Newton step below 1e-4: done, x = x0;
+//   otherwise the Newton step, inside the box as it is or projected onto the bound it crosses (its Armijo ratio is
+//   1 - d / (2 dx) > 1/2: the first trial of :64-76 is always accepted), and pass 1 finds nothing left to do --
+// with the same operations in the same order as the loop (the free flag of pass 1 is evaluated as the loop does, rounding
+// of the residual gradient included).  A divergent branch costs a lone wavefront ~50 clocks (VALU -> SALU -> exec and
+// back) and the loop form had a dozen per timestep: 892 of the recursion's 2156 clocks per pendulum step.  Anything
+// else (H <= 0, a residual Newton step that is not below 1e-4) sends the wavefront through the loop itself.
+MPC_DEV int pnqp1_fast(float H, float q, float lb, float ub, float &x, float &Hfree, bool &is_free, int n_iter, bool &conv)
+{
+    const float x0 = tiny::clampr<float>(x, lb, ub);               // :23
+    const float g0 = H * x0 + q;                                   // :29
+    const bool fr0 = !((x0 == lb && g0 > 0) || (x0 == ub && g0 < 0));      // :32
+    const float Hf0 = (fr0 ? H : 0.f) + 1e-11f;                    // :44-48
+    const float dx0 = -((fr0 ? g0 : 0.f) * env_inv(Hf0));          // :50-51
+    const bool done0 = !(tiny::absr<float>(dx0) >= 1e-4f);         // :56-59
+    const float xs = x0 + dx0;
+    const bool inside = xs >= lb && xs <= ub;
+    // the projected step: xn = clamp(x0 + dx0), d = xn - x0, accepted at alpha = 1 iff its Armijo ratio exceeds 0.1 (:64-76)
+    const float xc = tiny::clampr<float>(xs, lb, ub), d = xc - x0;
+    const float arm = (-g0 * d - 0.5f * H * d * d) * env_inv(-g0 * d);
+    const float x1 = inside ? xs : xc;
+    const float g1 = H * x1 + q;
+    const bool fr1 = !((x1 == lb && g1 > 0) || (x1 == ub && g1 < 0));
+    const float Hf1 = (fr1 ? H : 0.f) + 1e-11f;
+    const float dx1 = -((fr1 ? g1 : 0.f) * env_inv(Hf1));
+    const bool done1 = !(tiny::absr<float>(dx1) >= 1e-4f);
+    const bool simple = n_iter >= 2 && H > 0 && (done0 || ((inside || arm > 0.1f) && done1));
+    int ret;
+    if (wv::any(!simple)) {                                        // (wavefront-uniform and rare: the loop, for everybody)
+        MPC_STAT(14);
+        ret = tiny::pnqp1<float>(H, q, lb, ub, x, Hfree, is_free, n_iter, conv);
+    } else {
+        MPC_STAT(15);
+        ret = done0 ? 0 : 1;
+        x = done0 ? x0 : x1;
+        is_free = done0 ? fr0 : fr1;
+        Hfree = done0 ? Hf0 : Hf1;
+        conv = true;
+    }
+    return ret;
 }
 
 template <int NS> MPC_DEV void step_wave(const StepParams<float> &p)
@@ -192,9 +240,7 @@ template <int NS> MPC_DEV void step_wave(const StepParams<float> &p)
                 float x = warm ? kprev : -(qu * env_inv(Quu));
                 float Hf;
                 bool is_free, conv;
-                // (per-lane loops as the compiler lays them out: a wavefront-uniform predicated loop with `any` votes, as the
-                //  12/4 kernel's pnqp4_rows has, measured 2 us SLOWER here -- the votes sit on the dependent chain)
-                const int it = tiny::pnqp1<float>(Quu, qu, lb, ub, x, Hf, is_free, p.pnqp_iter, conv);
+                const int it = pnqp1_fast(Quu, qu, lb, ub, x, Hf, is_free, p.pnqp_iter, conv);
                 qp_total += 1 + it;                           // :140
                 if (!conv) status |= MPC_ST_PNQP_UNCONVERGED;
                 warm = true;
@@ -203,12 +249,12 @@ template <int NS> MPC_DEV void step_wave(const StepParams<float> &p)
             }
             kprev = k;
             W1_STAMP(2);
-            if (j < N) {
-                wv::sm(L.K + t * N + j) = j < NS ? Kj : k;
+            wv::sm(L.K + t * N + jc) = j < NS ? Kj : k;       // (every lane stores: columns >= N repeat k in column N - 1's slot)
+            if ((p.K || p.k) && active) {                     // (a wavefront-uniform test first: mpc.MPC's loop asks for no gains)
                 const long tb = (long)t * B + b;
                 if (j < NS) {
-                    if (p.K && active) p.K[tb * NS + j] = Kj;
-                } else if (p.k && active) {
+                    if (p.K) p.K[tb * NS + j] = Kj;
+                } else if (j == NS && p.k) {
                     p.k[tb] = k;
                 }
             }

@@ -661,3 +661,34 @@ extern "C" int emu_lqr_step_wave1(const mpc_lqr_problem *p, const mpc_lqr_option
     for (int w = 0; w < (sp.B + 3) / 4; ++w) emu::run_wave(w, body_wave1);
     return 0;
 }
+
+// ---- the loop-free scalar QP of lqr_wave1_body.h against the loop it replaces, 64 cases per emulated wavefront ----
+static const float *g_qp_in;     // [n][5]: H, q, lb, ub, x0
+static float *g_qp_out;          // [n][5]: x, Hfree, is_free, ret, conv
+static int g_qp_n, g_qp_iter;
+static void body_pnqp1_fast()
+{
+    const int i = mpclqr::wv::problem() * 64 + mpclqr::wv::lane();
+    const int k = i < g_qp_n ? i : g_qp_n - 1;
+    const float *in = g_qp_in + 5 * k;
+    float x = in[4], Hf;
+    bool fr, conv;
+    const int ret = mpclqr::wave1::pnqp1_fast(in[0], in[1], in[2], in[3], x, Hf, fr, g_qp_iter, conv);
+    if (i < g_qp_n) {
+        float *o = g_qp_out + 5 * i;
+        o[0] = x, o[1] = Hf, o[2] = fr, o[3] = (float)ret, o[4] = conv;
+    }
+}
+extern "C" void emu_pnqp1_pair(int n, int n_iter, const float *in, float *fast, float *loop)
+{
+    g_qp_in = in, g_qp_out = fast, g_qp_n = n, g_qp_iter = n_iter;
+    for (int w = 0; w < (n + 63) / 64; ++w) emu::run_wave(w, body_pnqp1_fast);
+    for (int i = 0; i < n; ++i) {
+        const float *a = in + 5 * i;
+        float x = a[4], Hf;
+        bool fr, conv;
+        const int ret = mpclqr::tiny::pnqp1<float>(a[0], a[1], a[2], a[3], x, Hf, fr, n_iter, conv);
+        float *o = loop + 5 * i;
+        o[0] = x, o[1] = Hf, o[2] = fr, o[3] = (float)ret, o[4] = conv;
+    }
+}

@@ -558,6 +558,48 @@ def test_wave1_body_rolls_out_and_linearises_through_the_simulator(emu, name, ki
     np.testing.assert_allclose(r2["new_u"], z["step_new_u"], **tol)
 
 
+def test_wave1_loop_free_scalar_qp_is_the_loop(emu):
+    """`wave1::pnqp1_fast` (the scalar box QP written out for H > 0, with the loop as its fall-back behind a wavefront vote)
+    returns BIT FOR BIT what `tiny::pnqp1` returns -- x, the free flag, the regularised free Hessian, the iteration index,
+    the convergence flag -- on random problems and on the corners: warm starts on and beyond the bounds, Newton steps that
+    land exactly on a bound, steps below the 1e-4 threshold, H tiny / zero / negative, degenerate boxes, one iteration only."""
+    import ctypes
+    import emu_backend
+    lib = emu_backend.lib()
+    rng = np.random.default_rng(5)
+    n = 64 * 400
+    H = np.abs(rng.standard_normal(n)) * 10.0 ** rng.integers(-4, 3, n)
+    q = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 2, n)
+    lb = -np.abs(rng.standard_normal(n)) - 0.01
+    ub = np.abs(rng.standard_normal(n)) + 0.01
+    x0 = rng.standard_normal(n) * 1.5
+    kind = rng.integers(0, 12, n)
+    x0 = np.where(kind == 0, lb, np.where(kind == 1, ub, x0))              # warm start on a bound
+    q = np.where(kind == 2, -H * ub, np.where(kind == 3, -H * lb, q))        # unconstrained minimiser exactly on a bound
+    q = np.where(kind == 4, -H * (x0 + 5e-5), q)                             # Newton step just below the threshold
+    H = np.where(kind == 5, 0.0, np.where(kind == 6, -H, H))                 # H = 0, H < 0
+    H = np.where(kind == 7, 1e-9, H)
+    ub = np.where(kind == 8, lb, ub)                                         # a degenerate box
+    x0 = np.where(kind == 9, 0.5 * (lb + ub), x0)
+    inp = np.stack((H, q, lb, ub, x0), 1).astype(np.float32)
+    # the written-out path is taken only by a wavefront ALL of whose 64 problems qualify: the second half of the cases is
+    # sorted by kind so that whole wavefronts do (counted below), the first half mixes everything
+    order = np.concatenate((np.arange(n // 2), n // 2 + np.argsort(kind[n // 2:], kind="stable")))
+    inp = inp[order].copy()
+    stats = (ctypes.c_long * 16).in_dll(lib, "emu_stats")
+    for n_iter in (20, 1, 2):
+        stats[14] = stats[15] = 0
+        fast, loop = np.full((n, 5), np.nan, np.float32), np.full((n, 5), np.nan, np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        lib.emu_pnqp1_pair.argtypes = [ctypes.c_int, ctypes.c_int, fp, fp, fp]
+        lib.emu_pnqp1_pair.restype = None
+        lib.emu_pnqp1_pair(n, n_iter, inp.ctypes.data_as(fp), fast.ctypes.data_as(fp), loop.ctypes.data_as(fp))
+        assert np.array_equal(fast.view(np.uint32), loop.view(np.uint32)), np.flatnonzero((fast.view(np.uint32) != loop.view(np.uint32)).any(1))[:10]
+        if n_iter == 20:
+            assert (loop[:, 3] == 0).mean() > 0.1 and (loop[:, 3] == 1).mean() > 0.3 and (loop[:, 3] > 1).any()
+            assert stats[15] >= 4 * 100 and stats[14] >= 4 * 100, (stats[14], stats[15])      # (four counting lanes per wavefront) both routes well exercised
+
+
 # ---------------------------------------------------------------------------------------------
 # The register-resident MFMA sweep (csrc/lqr_mfma40_body.h): n_state = 32, n_ctrl = 8, unconstrained
 # ---------------------------------------------------------------------------------------------
