@@ -56,11 +56,12 @@ class _FlagReader:
     that tag -- no device-to-host copy and no event (an event's system-scope release held the next kernel back by 6 us per
     iteration).  Other backends (the test stand-ins): an asynchronous copy and an event."""
 
-    _POLL_TIMEOUT_S = 20.0
+    _POLL_S = 0.005
 
     def __init__(self, device, dtype, be=None):
         # int32 flag at byte 0, the tag at byte 4, the maximum (float32 / float64) at byte 8 of one block
         self.cuda = device.type == "cuda"
+        self._host_device = device
         self.direct = self.cuda and getattr(be, "writes_host_flags", False)
         if self.direct:
             self.device_flags = be.select_flags(device, dtype)
@@ -99,8 +100,11 @@ class _FlagReader:
                 import time
                 t0 = time.monotonic()
                 while words[1] != tag:
-                    if time.monotonic() - t0 > self._POLL_TIMEOUT_S:
-                        torch.cuda.synchronize()              # surfaces a launch failure as the error it is
+                    if time.monotonic() - t0 > self._POLL_S:
+                        # not there after a few milliseconds: a long queue in front of the select kernel, or host memory
+                        # the device's stores reach only when the kernel retires -- wait for the stream (which also
+                        # surfaces a launch failure as the error it is); the words are there afterwards or never
+                        torch.cuda.current_stream(self._host_device).synchronize()
                         if words[1] != tag:
                             raise RuntimeError("mpc_select_best did not report (tag %d, host word %d)" % (tag, int(words[1])))
             return int(self.host[0][0]), float(self.host[1][0])
