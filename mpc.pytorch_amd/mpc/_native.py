@@ -475,8 +475,9 @@ class HipBackend:
         pp, op, up, wp = ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), ws.data_ptr()
         fn = load().mpc_lqr_step
 
-        def run():
-            rc = fn(pp, op, up, wp, nbytes, impl, torch.cuda.current_stream(dev).cuda_stream)
+        def run(stream=None):
+            # stream: the raw handle of the stream to enqueue on (a loop that looked it up once); default: torch's current one
+            rc = fn(pp, op, up, wp, nbytes, impl, torch.cuda.current_stream(dev).cuda_stream if stream is None else stream)
             if rc != 0:
                 _check(rc, "mpc_lqr_step")
             return res
@@ -795,6 +796,40 @@ class HipBackend:
                                  best["full_du_norm"].data_ptr(), any_improved.data_ptr(), _ptr(host), int(tag),
                                  _ptr(status), _stream(dev)), "mpc_select_best")
         return any_improved, max_du
+
+    def plan_select(self, eps, sources, best, flags, host=None):
+        """mpc_select_best with everything but (which source, first, tag, status on / off) bound once: `sources` are the
+        output dicts of the step plans whose results are selected from (MPC.forward's ping-pong pair).  The call per
+        iteration is then one C call -- the general entry above spends ~14 us of host time per call on checks and pointer
+        look-ups, which an iLQR iteration of 37 us on the device does not hide.  -> sel(k, first, tag=0, with_status=False,
+        stream=None)."""
+        x0 = sources[0]["new_x"]
+        dev = _require_device(x0, best["x"])
+        T, B, ns = x0.shape
+        nc = sources[0]["new_u"].shape[2]
+        any_improved, max_du = flags
+        assert max_du.data_ptr() == any_improved.data_ptr() + 8
+        if host is not None:
+            assert host.is_pinned() and host.numel() * host.element_size() >= 16
+        fn = load().mpc_select_best
+        head = (_dtype_code(x0), B, T, ns, nc)
+        feps = float(eps)
+        tails = []
+        for r in sources:
+            assert r["new_x"].is_contiguous() and r["new_u"].is_contiguous() and r["new_x"].shape == x0.shape
+            tails.append(((r["new_x"].data_ptr(), r["new_u"].data_ptr(), r["costs"].data_ptr(), r["full_du_norm"].data_ptr(),
+                           best["x"].data_ptr(), best["u"].data_ptr(), best["costs"].data_ptr(), best["full_du_norm"].data_ptr(),
+                           any_improved.data_ptr(), _ptr(host)), r["status"].data_ptr()))
+        keep = (sources, best, flags, host)
+
+        def sel(k, first, tag=0, with_status=False, stream=None):
+            ptrs, st = tails[k]
+            rc = fn(*head, 1 if first else 0, feps, *ptrs, tag, st if with_status else None,
+                    torch.cuda.current_stream(dev).cuda_stream if stream is None else stream)
+            if rc != 0:
+                _check(rc, "mpc_select_best")
+        sel._keep = keep
+        return sel
 
     @staticmethod
     def select_flags(device, dtype):
