@@ -234,7 +234,9 @@ def extra_rows(be, dev, steps):
         of, _keep2 = opts.to_struct(T, B, nc, p["C"])
         fused = bool(_native.load().mpc_lqr_kkt_fused_supported(ctypes.byref(pf), ctypes.byref(of)))
         return dict(ms=ms, wall_ms=wall, finite=bool(torch.isfinite(g["dC"]).all().item()),
-                    launches=("mpc_lqr_kkt_fused: ONE launch (sweep + lambda, then rollout + dlambda = V dx + v + all gradients)" if fused
+                    launches=(("mpc_lqr_kkt_fused: ONE launch (sweep + lambda, then rollout + dlambda = V dx + v + all gradients)" if ns == 12 else
+                               "mpc_lqr_kkt_fused: the nested step with lambda along its sweep and dlambda = V dx + v along its rollout, "
+                               "then the outer-product kernel (two launches)") if fused
                               else "mpc_lqr_kkt_prepare + mpc_lqr_step (nested solve) + mpc_lqr_kkt_grads"),
                     roofline=hbm_roofline(kkt_algorithmic_bytes_per_problem(ns, nc, T) * B, ms))
 

@@ -353,7 +353,8 @@ int mpc_lqr_kkt_grads(const mpc_lqr_problem *p, const void *dx, const void *du, 
 int mpc_lqr_kkt_fused_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o)
 {
     if (!p || check_problem(p, false, false) != MPC_OK || check_options(p, o) != MPC_OK) return 0;
-    if (p->dtype != MPC_F32 || p->ns != 12 || p->nc != 4 || p->T > 64) return 0;
+    const bool s12 = p->ns == 12 && p->nc == 4 && p->T <= 64, s32 = p->ns == 32 && p->nc == 8;
+    if (p->dtype != MPC_F32 || !(s12 || s32)) return 0;
     if (!o || !(o->flags & MPC_OPT_C_SYMMETRIC)) return 0;
     if (o->zero_mask || o->true_dynamics || (o->delta_u == o->delta_u && o->delta_u >= 0)) return 0;
     return 1;
@@ -361,7 +362,8 @@ int mpc_lqr_kkt_fused_supported(const mpc_lqr_problem *p, const mpc_lqr_options 
 
 int64_t mpc_lqr_kkt_fused_workspace_bytes(const mpc_lqr_problem *p)
 {
-    return p ? kkt_fused_dpp16_workspace_bytes(p->T, p->B) : 0;
+    if (!p) return 0;
+    return p->ns == 32 ? kkt_fused_mfma40_workspace_bytes(p->T, p->B) : kkt_fused_dpp16_workspace_bytes(p->T, p->B);
 }
 
 int mpc_lqr_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const void *dl_dx, const void *dl_du,
@@ -372,19 +374,29 @@ int mpc_lqr_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const 
     if (rc) return rc;
     if ((rc = check_options(p, o))) return rc;
     if (!mpc_lqr_kkt_fused_supported(p, o))
-        return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: needs fp32, n_state = 12, n_ctrl = 4, T <= 64 and MPC_OPT_C_SYMMETRIC "
-                                "(otherwise: mpc_lqr_kkt_prepare + mpc_lqr_step + mpc_lqr_kkt_grads)");
+        return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: needs fp32, n_state = 12, n_ctrl = 4, T <= 64 or n_state = 32, n_ctrl = 8, and "
+                                "MPC_OPT_C_SYMMETRIC (otherwise: mpc_lqr_kkt_prepare + mpc_lqr_step + mpc_lqr_kkt_grads)");
     if (p->B == 0) return MPC_OK;
     if (!dl_dx || !dl_du || !dC || !dc || !dx_init) return fail(MPC_E_NULL, "kkt_fused: NULL argument");
     if (p->T > 1 && !dF) return fail(MPC_E_NULL, "kkt_fused: dF is NULL");
     if ((df != nullptr) != (p->f != nullptr && p->T > 1)) return fail(MPC_E_NULL, "kkt_fused: df goes with f");
     if ((dx_out == nullptr) != (du_out == nullptr)) return fail(MPC_E_NULL, "kkt_fused: pass both dx_out and du_out, or neither");
-    if (!workspace || workspace_bytes < kkt_fused_dpp16_workspace_bytes(p->T, p->B))
+    if (!workspace || workspace_bytes < mpc_lqr_kkt_fused_workspace_bytes(p))
         return fail(MPC_E_ARG, "workspace too small (see mpc_lqr_kkt_fused_workspace_bytes)");
     mpc_lqr_outputs out;
     memset(&out, 0, sizeof(out));
     out.status = status;
     StepParams<float> sp = make_params<float>(p, o, &out);
+    if (p->ns == 32) {
+        // config 5's shape: the nested step with the costates riding along, then the outer-product kernel (two launches)
+        if (!kkt_fused_mfma40_supported(sp, (const float *)dl_dx, (const float *)dl_du, (const float *)dC, (const float *)dF,
+                                        (const float *)workspace) ||
+            (dx_out && (((uintptr_t)dx_out | (uintptr_t)du_out) & 15)) || ((uintptr_t)dx_init & 15) || (df && ((uintptr_t)df & 15)))
+            return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: blocks must be 16-byte aligned");
+        return launch_kkt_fused_mfma40(sp, (const float *)dl_dx, (const float *)dl_du, (float *)dC, (float *)dc, (float *)dF,
+                                       (float *)df, (float *)dx_init, (float *)dx_out, (float *)du_out, (float *)workspace, 0.2f,
+                                       10, (hipStream_t)stream);
+    }
     if (!kkt_fused_dpp16_supported(sp, (const float *)dl_dx, (const float *)dl_du, (const float *)dC, (const float *)dF,
                                    (const float *)workspace))
         return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: blocks must be 16-byte aligned");

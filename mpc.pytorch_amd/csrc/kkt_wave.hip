@@ -271,4 +271,17 @@ int launch_kkt_wave(const StepParams<float> &p, const float *dx, const float *du
     return MPC_OK;
 }
 
+// the outer products alone: lambda_{t+1}, dlambda_{t+1} already sit in the dF_t blocks (the fused backward of the 32/8
+// shape, lqr_mfma40.hip, parks them there itself)
+int launch_kkt_outer(const StepParams<float> &p, const float *dx, const float *du, float *dC, float *dc, float *dF, hipStream_t st)
+{
+    hipLaunchKernelGGL(kkt_outer_kernel, dim3((unsigned)((long)p.T * p.B)), dim3(64), 0, st, p, dx, du, dC, dc, dF);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error((std::string("kkt_outer_kernel: ") + hipGetErrorString(e)).c_str());
+        return MPC_E_LAUNCH;
+    }
+    return MPC_OK;
+}
+
 }  // namespace mpclqr

@@ -72,9 +72,18 @@ bool kkt_wave_supported(const StepParams<float> &p, const float *dx, const float
 int launch_kkt_wave(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,
                     float *dc, float *dF, float *df, float *dx_init, hipStream_t st);
 
+int launch_kkt_outer(const StepParams<float> &p, const float *dx, const float *du, float *dC, float *dc, float *dF, hipStream_t st);
+
 // register-resident MFMA step for n_state = 32, n_ctrl = 8, f32 (lqr_mfma40.hip)
 bool mfma40_supported(const StepParams<float> &p);
 int launch_step_mfma40(const StepParams<float> &p, hipStream_t st);
+// the KKT backward of that shape: the nested step with both costates riding along + kkt_outer_kernel (lqr_mfma40.hip, -DMPC_MFMA40_KKT)
+bool kkt_fused_mfma40_supported(const StepParams<float> &p, const float *dl_dx, const float *dl_du, const float *dC,
+                                const float *dF, const float *ws);
+int64_t kkt_fused_mfma40_workspace_bytes(int T, int B);
+int launch_kkt_fused_mfma40(const StepParams<float> &p, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
+                            float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
+                            hipStream_t st);
 
 // NNDynamics inside the kernels: rollout / line search and Jacobian on MFMA, 16 problems per wave (nn_dynamics.hip)
 int nn_budget(const mpc_mlp_dynamics *net, int ns, int nc);     // bit 0: the rollout kernels take this network, bit 1: the linearisation ones

@@ -71,7 +71,13 @@ MPC_DEV unsigned load_uniform_u32(const unsigned *g)
 MPC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // an opaque register-to-register identity (see mfma40::pick)
 MPC_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
+// Compiled twice (Makefile): the step kernels on a 26 KiB staging array (six wavefronts per CU), and with -DMPC_MFMA40_KKT
+// the fused KKT backward alone, whose second pass stages V_{t+1} as well (three slots of 10.5 KiB: four wavefronts per CU)
+#ifdef MPC_MFMA40_KKT
+#define MPC_MFMA40_LDS (3 * 10752)
+#else
 #define MPC_MFMA40_LDS (2 * 13056 + 512)
+#endif
 __shared__ __attribute__((aligned(16))) char g_stage40[MPC_MFMA40_LDS];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -107,6 +113,63 @@ template <int N> MPC_DEV void dma_wait()
 
 #include "lqr_mfma40_body.h"
 
+#ifdef MPC_MFMA40_KKT
+namespace mpclqr {
+namespace {
+static_assert(mfma40::KLDS_TOTAL <= MPC_MFMA40_LDS && mfma40::LDS_TOTAL <= MPC_MFMA40_LDS, "the fused KKT kernel's rings do not fit");
+// MODE 0: no bounds; 1: controls on a bound pinned in the nested solve
+template <int MODE> __global__ void __launch_bounds__(64, 1) lqr_kkt_fused_mfma40_kernel(StepParams<float> p, float *K, float *k,
+                                                                                        mfma40::KktArgs40 kx)
+{
+    mfma40::kkt_fused_wave<MODE>(p, K, k, kx);
+}
+}  // namespace
+
+// floats: K [T,B,8,32] | k [T,B,8] | V [T,B,1024] | v,g [T,B,64] | (dx [T,B,32] | du [T,B,8] when the caller keeps none)
+int64_t kkt_fused_mfma40_workspace_bytes(int T, int B) { return (int64_t)T * B * (256 + 8 + 1024 + 64 + 40) * 4 + 64; }
+
+bool kkt_fused_mfma40_supported(const StepParams<float> &p, const float *dl_dx, const float *dl_du, const float *dC,
+                                const float *dF, const float *ws)
+{
+    auto al = [](const void *q, long st, long sb) { return ((uintptr_t)q % 16 == 0) && (st % 4 == 0) && (sb % 4 == 0); };
+    if (!(p.ns == 32 && p.nc == 8 && p.T >= 1)) return false;
+    if (!al(p.C, p.C_st, p.C_sb) || !al(p.c, p.c_st, p.c_sb)) return false;
+    if (p.T > 1 && !al(p.F, p.F_st, p.F_sb)) return false;
+    if (p.bound_mode == MPC_BOUND_TENSOR && ((((uintptr_t)p.lo | (uintptr_t)p.hi) & 3) != 0)) return false;
+    if (p.zero_mask || p.has_delta || p.env.kind) return false;
+    return al(p.cur_x, 0, 0) && al(p.cur_u, 0, 0) && al(dl_dx, 0, 0) && al(dl_du, 0, 0) && al(dC, 0, 0) && al(ws, 0, 0) &&
+           (p.T == 1 || al(dF, 0, 0));
+}
+
+// the nested step with lambda and dlambda riding along (one launch), then the outer products (kkt_wave.hip)
+int launch_kkt_fused_mfma40(const StepParams<float> &p_in, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
+                            float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
+                            hipStream_t st)
+{
+    StepParams<float> p = p_in;
+    const long TB = (long)p.T * p.B;
+    float *K = ws, *k = K + TB * 256, *V = k + TB * 8, *vg = V + TB * 1024, *dx = vg + TB * 64, *du = dx + TB * 32;
+    if (dx_out && du_out) { dx = dx_out; du = du_out; }
+    p.new_x = dx;
+    p.new_u = du;
+    p.ls_decay = decay;
+    p.max_ls = max_ls;
+    p.old_costs = nullptr;
+    p.qp_iters = nullptr;
+    p.c_symmetric = true;
+    mfma40::KktArgs40 kx;
+    kx.dl_dx = dl_dx; kx.dl_du = dl_du; kx.dF = dF; kx.df = df; kx.dx_init = dx_init; kx.Vws = V; kx.vgws = vg;
+    if (p.bound_mode != MPC_BOUND_NONE) hipLaunchKernelGGL((lqr_kkt_fused_mfma40_kernel<1>), dim3(p.B), dim3(64), 0, st, p, K, k, kx);
+    else hipLaunchKernelGGL((lqr_kkt_fused_mfma40_kernel<0>), dim3(p.B), dim3(64), 0, st, p, K, k, kx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error((std::string("lqr_kkt_fused_mfma40_kernel: ") + hipGetErrorString(e)).c_str());
+        return MPC_E_LAUNCH;
+    }
+    return launch_kkt_outer(p, dx, du, dC, dc, dF, st);
+}
+}  // namespace mpclqr
+#else
 namespace mpclqr {
 namespace {
 
@@ -154,3 +217,4 @@ int launch_step_mfma40(const StepParams<float> &p, hipStream_t st)
 }
 
 }  // namespace mpclqr
+#endif

@@ -61,7 +61,7 @@ MPC_DEV float uniform_f32(const float *g)
 using wv::f32x4;
 constexpr int NS = 32, NC = 8, N = 40;
 constexpr int NSTAGE = 2;      // slots of the LDS-DMA ring: one step in flight (27 KiB per wave -> 6 waves per CU)
-constexpr unsigned OFF_C = 0, OFF_F = 6400, OFF_R = 11520, STAGE_BYTES = 11904;
+constexpr unsigned OFF_C = 0, OFF_F = 6400, OFF_R = 11520, STAGE_BYTES = 12032;   // (the record: 320 B, 448 B in the fused backward)
 constexpr int DMA_PER_STAGE = 13;                           // 7 (C) + 5 (F) + 1 (c | x | u)
 // rollout stage: C | F | K_t (1 KiB) | record (c, x_{t+1}, u_t, f_t, k_t)
 constexpr unsigned ROFF_K = 11520, ROFF_R = 12544, RSTAGE_BYTES = 13056;
@@ -79,13 +79,28 @@ struct Lane {
     int lane, r, q, b;
 };
 
+// ---- LQRStepFn.backward (mpc/lqr_step.py:312-407) fused into the step of its nested problem (kkt_fused_wave below) ----
+// The sweep and the lean rollout compiled with KKT = true carry the two costate recursions along; what they need beyond
+// the step's own parameters:
+struct KktArgs40 {
+    const float *dl_dx, *dl_du;     // [T,B,32], [T,B,8]: the nested problem's linear term is c = -(dl_dx | dl_du)  (:315-320, :338)
+    float *dF, *df, *dx_init;       // dF [T-1,B,32,40]: lambda_{t+1}, dlambda_{t+1} parked in the first 64 words of block t
+                                    // (kkt_outer_kernel's convention, kkt_wave.hip); df [T-1,B,32] or NULL; dx_init [B,32]
+    float *Vws;                     // workspace [T,B,1024]: V_t as the sweep holds it (four D-layout tiles, 16 B per lane)
+    float *vgws;                    // workspace [T,B,64]: v_t | g_t
+};
+// pass 2's stage: F | K_t | record (v_{t+1}, g_{t+1}, k_t) | V_{t+1}; three slots, the DMA two timesteps ahead
+constexpr unsigned KOFF_F = 0, KOFF_K = 5120, KOFF_R = 6144, KOFF_V = 6656, KSTAGE_BYTES = 10752;
+constexpr int KSLOTS = 3, KDMA_PER_STAGE = 11;                 // 5 (F) + 1 (K) + 1 (record) + 4 (V)
+constexpr unsigned KLDS_TOTAL = KSLOTS * KSTAGE_BYTES;         // 31.5 KiB per wave: four waves per CU
+
 struct Stream {
     const char *c_ptr, *f_ptr, *r_ptr;      // this lane's 16-byte column of each block, timestep 0
     long c_step, f_step, r_step;            // bytes per timestep
     bool r_active;
 };
 
-MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L)
+MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L, const KktArgs40 *kk = nullptr)
 {
     const long b = L.b;
     d.c_ptr = (const char *)(p.C + b * p.C_sb) + 16 * L.lane;
@@ -105,6 +120,41 @@ MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L)
         d.r_ptr = (const char *)(p.cur_u + b * NC) + 16 * ((L.lane < 20 ? L.lane : 18) - 18);
         d.r_step = (long)p.B * NC * 4;
     }
+    if (kk) {
+        // the fused backward: lanes 0..7 dl_dx_t, 8..9 dl_du_t (negated where they are read), 10..19 tau*_t as above,
+        // 20..27 c_t[0..31] of the ORIGINAL problem (lambda's constant term)
+        d.r_active = L.lane < 28;
+        if (L.lane < 8) {
+            d.r_ptr = (const char *)(kk->dl_dx + b * NS) + 16 * L.lane;
+            d.r_step = (long)p.B * NS * 4;
+        } else if (L.lane < 10) {
+            d.r_ptr = (const char *)(kk->dl_du + b * NC) + 16 * (L.lane - 8);
+            d.r_step = (long)p.B * NC * 4;
+        } else if (L.lane >= 20) {
+            d.r_ptr = (const char *)(p.c + b * p.c_sb) + 16 * ((L.lane < 28 ? L.lane : 20) - 20);
+            d.r_step = p.c_st * 4;
+        }
+    }
+}
+
+// The fused backward pins the controls that sit on a bound (to 1e-8, mpc/lqr_step.py:322-326) -- the u_zero_I of its nested
+// solve -- straight from u* and the bounds: the same flag words zero_mask_word would read from a mask array.
+MPC_DEV unsigned kkt_pinned_word(const P &p, long tb, int w)
+{
+    unsigned z = 0u;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int a = 4 * w + v;
+        const float u = uniform_f32(p.cur_u + tb * NC + a);
+        float lo = p.lo_s, hi = p.hi_s;
+        if (p.bound_mode != MPC_BOUND_SCALAR) {
+            lo = uniform_f32(p.lo + tb * NC + a);
+            hi = uniform_f32(p.hi + tb * NC + a);
+        }
+        const bool pinned = fabsf(u - lo) <= 1e-8f || fabsf(u - hi) <= 1e-8f;
+        z |= pinned ? (1u << (8 * v)) : 0u;
+    }
+    return z;
 }
 
 MPC_DEV void stage_issue(const P &p, const Stream &d, const Lane &L, int t, int slot)
@@ -452,7 +502,15 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
 
 // The sweep of one problem: K [T,B,8,32] and k [T,B,8] in the reference layout, old_costs[b].
 // MODE 0: unconstrained; 1: u_zero_I mask; 2: box constraints (pnqp8 on wave-uniform values).
-template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out = nullptr)
+// KKT (the fused backward, kkt_fused_wave): the nested problem of LQRStepFn.backward -- zero nominal, c = -(dl_dx | dl_du),
+// pinned controls from u* and the bounds (MODE 1) -- with two more vector recursions riding along:
+//   lambda_t = C_x tau*_t + c_x + F_x' lambda_{t+1}   (:355-369; nothing the nested solve produces is in it)
+//   g_t = F_x' g_{t+1} - Qxu k_t                      (the correction of dlambda when the nested line search ends below 1)
+// V_t, v_t, g_t go to the workspace for pass 2 (dlambda_t = V_t dx_t + v_t + (1 - alpha) g_t), lambda_{t+1} into the
+// first 32 words of the dF_t block.  v_0, g_0 (row layout) come back through v0g0 for dx_init.
+template <int MODE, bool KKT = false>
+MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out = nullptr, const KktArgs40 *kx = nullptr,
+                          float *v0g0 = nullptr)
 {
     Lane L;
     L.lane = wv::lane();
@@ -462,16 +520,17 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
     if (L.b >= p.B) return 0.0;
     const int T = p.T;
     Stream d;
-    stream_init(d, p, L);
+    stream_init(d, p, L, KKT ? kx : nullptr);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 Vd[2][2];                    // V, D layout
     float vcol[2][4];                  // v, column layout: vcol[I][v] = v[16I + 4q + v]
+    float lcol[2][4], gcol[2][4];      // lambda_{t+1}, g_{t+1} in the same layout (KKT)
 #pragma unroll
     for (int I = 0; I < 2; ++I) {
 #pragma unroll
         for (int J = 0; J < 2; ++J) Vd[I][J] = zero4;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) vcol[I][v] = 0.f;
+        for (int v = 0; v < 4; ++v) vcol[I][v] = lcol[I][v] = gcol[I][v] = 0.f;
     }
     double old_cost = 0.0;
     double w0 = 0.0;                   // sum_t 0.5 qu'k: the value function's predicted change of the cost (unconstrained)
@@ -537,21 +596,29 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
             const float x = wv::lds_f32(base + OFF_R + 160 + 4u * (unsigned)(j < N ? j : 0));
             const float c = wv::lds_f32(base + OFF_R + 4u * (unsigned)(j < N ? j : 0));
             trow[J] = j < N ? x : 0.f;
-            crow[J] = j < N ? c : 0.f;
+            crow[J] = j < N ? (KKT ? -c : c) : 0.f;
         }
         // c_back = C tau + c (mpc/lqr_step.py:289-295) in row layout, and the nominal cost (:169)
         float qrow[3];
+        float lrow[2] = {0.f, 0.f}, grow[2] = {0.f, 0.f};
 #pragma unroll
         for (int J = 0; J < 3; ++J) {
+            if (KKT && J == 2) { qrow[J] = crow[J]; continue; }
             float s = 0.f;
 #pragma unroll
             for (int I = 0; I < 3; ++I)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) s = fmaf(Qd[I][J][v], tcol[I][v], s);
             const float ct = sum_q(s);                       // (C tau)[16J + r]
-            qrow[J] = ct + crow[J];
+            if (KKT) {
+                // the nested nominal is zero: c_back = c = -r; tau here is tau*, C tau* + c_x starts lambda_t
+                qrow[J] = crow[J];
+                lrow[J] = ct + wv::lds_f32(base + OFF_R + 320 + 4u * (unsigned)(16 * J + L.r));
+            } else {
+                qrow[J] = ct + crow[J];
+            }
         }
-        {
+        if (!KKT) {
             float s = 0.f;
 #pragma unroll
             for (int J = 0; J < 3; ++J) s = fmaf(trow[J], fmaf(0.5f, qrow[J] - crow[J], crow[J]), s);
@@ -612,6 +679,28 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
                     for (int v = 0; v < 4; ++v) s = fmaf(FB[4 * Ip + v][J], vcol[Ip][v], s);
                 qrow[J] += sum_q(s);
             }
+            if (KKT) {
+                // lambda_t += F_x' lambda_{t+1}, g_t = F_x' g_{t+1} (- Qxu k_t below); lambda_{t+1} into dF_t's block
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+                    float sl = 0.f, sg = 0.f;
+#pragma unroll
+                    for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            sl = fmaf(FB[4 * Ip + v][J], lcol[Ip][v], sl);
+                            sg = fmaf(FB[4 * Ip + v][J], gcol[Ip][v], sg);
+                        }
+                    lrow[J] += sum_q(sl);
+                    grow[J] = sum_q(sg);
+                }
+                if (L.r == 0) {
+#pragma unroll
+                    for (int I = 0; I < 2; ++I)
+                        wv::store_f32x4(kx->dF + tb * (long)(NS * N) + 16 * I + 4 * L.q,
+                                        f32x4{lcol[I][0], lcol[I][1], lcol[I][2], lcol[I][3]});
+                }
+            }
         }
 
         // ---- Quu, qu; K = -Quu^-1 Qux, k = -Quu^-1 qu   (:84-94; LDL' for the pinverse)
@@ -644,7 +733,8 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
             // (k comes out of the first of the two K solves below: lane rows 2, 3 carry qu as their right-hand side)
         } else if (MODE == 1) {                          // :99-127: pinned controls drop out of the solve
             float rq[8];
-            const unsigned zlo = zero_mask_word(p, tb, 0), zhi = zero_mask_word(p, tb, 1);
+            const unsigned zlo = KKT ? kkt_pinned_word(p, tb, 0) : zero_mask_word(p, tb, 0);
+            const unsigned zhi = KKT ? kkt_pinned_word(p, tb, 1) : zero_mask_word(p, tb, 1);
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
                 fr[a] = (((a < 4 ? zlo : zhi) >> (8 * (a & 3))) & 0xffu) == 0u;
@@ -654,6 +744,12 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
             ldl8_solve(fac, rq, kk);
 #pragma unroll
             for (int a = 0; a < 8; ++a) kk[a] = fr[a] ? -kk[a] : 0.f;
+            if (KKT) {                                   // the line search's predicted change, as in the unconstrained mode
+                float w = 0.f;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) w = fmaf(qu[a], kk[a], w);
+                w0 += 0.5 * (double)w;
+            }
         } else {                                         // :128-148: box QP, warm start k_{t+1}
             // the QP's data spread over lanes (pnqp8v): H's columns by two row swaps per accumulator register
             float col0[8];
@@ -816,12 +912,19 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
                 }
             }
             vrow[J] = qrow[J] + sum_q(s);
+            if (KKT) grow[J] += qrow[J] - vrow[J];          // - Qxu k_t: what v just took on
         }
         // row -> column layout through the scratch words
         wv::lds_sync();
         if (L.q == 0) {
             wv::lds_store_f32(OFF_SCR + 4u * (unsigned)L.r, vrow[0]);
             wv::lds_store_f32(OFF_SCR + 64 + 4u * (unsigned)L.r, vrow[1]);
+            if (KKT) {
+                wv::lds_store_f32(OFF_SCR + 128 + 4u * (unsigned)L.r, lrow[0]);
+                wv::lds_store_f32(OFF_SCR + 192 + 4u * (unsigned)L.r, lrow[1]);
+                wv::lds_store_f32(OFF_SCR + 256 + 4u * (unsigned)L.r, grow[0]);
+                wv::lds_store_f32(OFF_SCR + 320 + 4u * (unsigned)L.r, grow[1]);
+            }
         }
         wv::lds_sync();
 #pragma unroll
@@ -829,6 +932,29 @@ template <int MODE> MPC_DEV double sweep_wave(const P &p, float *Kout, float *ko
             const f32x4 w = wv::lds_f32x4(OFF_SCR + 64u * (unsigned)I + 16u * (unsigned)L.q);
 #pragma unroll
             for (int v = 0; v < 4; ++v) vcol[I][v] = w[v];
+            if (KKT) {
+                const f32x4 wl = wv::lds_f32x4(OFF_SCR + 128 + 64u * (unsigned)I + 16u * (unsigned)L.q);
+                const f32x4 wg = wv::lds_f32x4(OFF_SCR + 256 + 64u * (unsigned)I + 16u * (unsigned)L.q);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { lcol[I][v] = wl[v]; gcol[I][v] = wg[v]; }
+            }
+        }
+        if (KKT) {
+            // V_t (the four tiles as they sit in the registers: pass 2 reads them back as A operands), v_t | g_t
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J) wv::store_f32x4(kx->Vws + tb * 1024 + (2 * I + J) * 256 + 4 * L.lane, Vd[I][J]);
+            if (L.q == 0) {
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+                    kx->vgws[tb * 64 + 16 * J + L.r] = vrow[J];
+                    kx->vgws[tb * 64 + 32 + 16 * J + L.r] = grow[J];
+                }
+            }
+            if (t == 0 && v0g0) {
+                v0g0[0] = vrow[0]; v0g0[1] = vrow[1]; v0g0[2] = grow[0]; v0g0[3] = grow[1];
+            }
         }
         slot ^= 1;
     }
@@ -1331,6 +1457,214 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
         if (p.alphas) p.alphas[L.b] = win_alpha;
         if (p.status) p.status[L.b] |= status;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LQRStepFn.backward (mpc/lqr_step.py:312-407) for this shape: the step of its nested problem with the costates riding
+// along, then kkt_outer_kernel (kkt_wave.hip) for the outer products.  The reference walks the horizon four times
+// (nested sweep, nested rollout, lambda, dlambda); here lambda rides with the sweep (sweep_wave<MODE, true>) and
+//     dlambda_t = V_t dx_t + v_t + (1 - alpha) g_t
+// -- the costate of the nested LQR problem along its own optimal trajectory is the gradient of its cost-to-go; the
+// derivation is in lqr_dpp16_body.h (kkt_fused_wave), which does the same for the 12/4 shape -- with the rollout:
+// 16 more MFMAs per timestep (V_{t+1} out of the workspace is its own A operand, the new state tile the B operand)
+// instead of a third and fourth pass over C and F.  The nested line search (:176-179, decay 0.2, 10 trials) is decided
+// from the sweep's predicted change (2 alpha - alpha^2) w0 like the lean rollout's; column r still rolls alpha = decay^r,
+// the winner's column stores dx, du, dlambda.  MODE 0: no bounds; MODE 1: controls on a bound pinned (kkt_pinned_word).
+// ---------------------------------------------------------------------------------------------
+MPC_DEV void kstage_issue(const P &p, const RStream &d, const char *v_ptr, long v_step, int t, int slot)
+{
+    const unsigned base = (unsigned)slot * KSTAGE_BYTES;
+    const long tl = t;
+    const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);      // F has T-1 entries
+    const long tx = t + 1 < p.T ? t + 1 : t;                         // (V, v, g) of t+1
+#pragma unroll
+    for (int k = 0; k < 5; ++k) wv::dma16(d.f_ptr + tf * d.f_step + 1024 * k, base + KOFF_F + 1024 * k);
+    wv::dma16(d.k_ptr + tl * d.k_step, base + KOFF_K);
+    wv::dma16_if(d.r_active, d.r_ptr + (d.r_is_x ? tx : tl) * d.r_step, base + KOFF_R);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wv::dma16(v_ptr + tx * v_step + 1024 * k, base + KOFF_V + 1024 * k);
+}
+
+template <int MODE>
+MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float *kin, const KktArgs40 &kx, double w0,
+                       const float (&v0g0)[4])
+{
+    const int T = p.T;
+    // record: lanes 10..17 v_{t+1} | 20..27 g_{t+1} | 28..29 k_t
+    RStream d;
+    d.c_ptr = nullptr; d.c_step = 0;
+    d.f_ptr = T > 1 ? (const char *)(p.F + (long)L.b * p.F_sb) + 16 * L.lane : (const char *)(p.C + (long)L.b * p.C_sb) + 16 * L.lane;
+    d.f_step = T > 1 ? p.F_st * 4 : 0;
+    d.k_ptr = (const char *)(Kin + (long)L.b * (NC * NS)) + 16 * L.lane;
+    d.k_step = (long)p.B * NC * NS * 4;
+    d.r_is_f = false;
+    d.r_is_x = L.lane < 28;
+    d.r_active = (L.lane >= 10 && L.lane < 18) || (L.lane >= 20 && L.lane < 30);
+    if (L.lane >= 28) {
+        d.r_ptr = (const char *)(kin + (long)L.b * NC) + 16 * ((L.lane < 30 ? L.lane : 28) - 28);
+        d.r_step = (long)p.B * NC * 4;
+    } else {
+        const int g = L.lane >= 20 ? 8 + (L.lane - 20) : (L.lane >= 10 && L.lane < 18 ? L.lane - 10 : 0);
+        d.r_ptr = (const char *)(kx.vgws + (long)L.b * 64) + 16 * g;
+        d.r_step = (long)p.B * 64 * 4;
+    }
+    const char *v_ptr = (const char *)(kx.Vws + (long)L.b * 1024) + 16 * L.lane;
+    const long v_step = (long)p.B * 4096;
+
+    float alpha = 1.f;
+    for (int i = 0; i < L.r; ++i) alpha *= p.ls_decay;            // column r tries decay^r
+    // first trial that does not make the nested cost worse, else the last one (:176-179, 247)
+    int win = p.max_ls - 1;
+    {
+        float a = 1.f;
+        for (int j = 0; j < p.max_ls; ++j) {
+            if (!((2.0 * (double)a - (double)a * (double)a) * w0 > 0.0)) { win = j; break; }
+            a *= p.ls_decay;
+        }
+    }
+    const bool store = L.r == win;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // dx_init = -dlambda_0 = -(V_0 0 + v_0 + (1 - alpha) g_0)   (:404)
+    {
+        // v0g0 is in row layout (lane r of every lane group holds entry 16J + r); the winner's alpha is a wave-uniform number
+        float wa = 1.f;
+        for (int i = 0; i < win; ++i) wa *= p.ls_decay;
+        if (L.q == 0) {
+#pragma unroll
+            for (int J = 0; J < 2; ++J) kx.dx_init[(long)L.b * NS + 16 * J + L.r] = -fmaf(1.f - wa, v0g0[2 + J], v0g0[J]);
+        }
+    }
+    f32x4 Xd[2];                     // dx_t, D layout: column r = trial r (dx_0 = 0: the nested x_init, :327, 338)
+    Xd[0] = zero4;
+    Xd[1] = zero4;
+    if (store) {
+#pragma unroll
+        for (int I = 0; I < 2; ++I) wv::store_f32x4(p.new_x + (long)L.b * NS + 16 * I + 4 * L.q, zero4);
+    }
+    wv::dma_wait<0>();          // nothing of the sweep may still land in the ring
+#pragma unroll
+    for (int i = 0; i < KSLOTS - 1; ++i) kstage_issue(p, d, v_ptr, v_step, i < T ? i : T - 1, i);
+    for (int t = 0; t < T; ++t) {
+        wv::dma_wait<(KSLOTS - 2) * KDMA_PER_STAGE>();
+        const unsigned base = (unsigned)(t % KSLOTS) * KSTAGE_BYTES;
+        const long tb = (long)t * p.B + L.b;
+        const unsigned rec = base + KOFF_R;
+        // ---- du = K dx + alpha k   (:192 around the zero nominal)
+        f32x4 Ud = zero4;
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float x = wv::lds_f32(base + KOFF_K + 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 16 * (k >> 2) + 4 * L.q + (k & 3)));
+            a[k] = L.r < NC ? x : 0.f;
+        }
+        const unsigned qo = 16u * (unsigned)(L.q < 2 ? L.q : 0);
+        const f32x4 kb = wv::lds_f32x4(rec + 448 + qo);
+        // F's A operands and V_{t+1}'s, before the slot two steps on is overwritten ... (it is a different slot: t + 2)
+        float fa[2][12];
+#pragma unroll
+        for (int Im = 0; Im < 2; ++Im) {
+            const int row = 16 * Im + L.r;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                fa[Im][k] = wv::lds_f32(base + KOFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float x = wv::lds_f32(base + KOFF_F + 4u * (unsigned)(row * N + (L.q < 2 ? 32 + 4 * L.q + v : 0)));
+                fa[Im][8 + v] = L.q < 2 ? x : 0.f;
+            }
+        }
+        f32x4 Vt[2][2];
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J) Vt[I][J] = wv::lds_f32x4(base + KOFF_V + 1024u * (unsigned)(2 * I + J) + 16u * (unsigned)L.lane);
+        f32x4 DL[2];
+#pragma unroll
+        for (int Im = 0; Im < 2; ++Im) {
+            const f32x4 v1 = wv::lds_f32x4(rec + 160 + 4u * (unsigned)(16 * Im + 4 * L.q));
+            const f32x4 g1 = wv::lds_f32x4(rec + 320 + 4u * (unsigned)(16 * Im + 4 * L.q));
+#pragma unroll
+            for (int v = 0; v < 4; ++v) DL[Im][v] = fmaf(1.f - alpha, g1[v], v1[v]);
+        }
+        {
+            const int tn = t + KSLOTS - 1;
+            kstage_issue(p, d, v_ptr, v_step, tn < T ? tn : T - 1, tn % KSLOTS);
+        }
+        wv::sched_fence();
+        {
+            f32x4 U2 = zero4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                Ud = wv::mfma(a[k], Xd[0][k], Ud);
+                U2 = wv::mfma(a[4 + k], Xd[1][k], U2);
+            }
+            wv::sched_fence();
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Ud[v] += U2[v];
+        }
+        {
+            unsigned zw = 0u;                    // the pinned flags of controls 4q .. 4q+3
+            if (MODE == 1) {
+                const unsigned zlo = kkt_pinned_word(p, tb, 0), zhi = kkt_pinned_word(p, tb, 1);
+                zw = L.q == 0 ? zlo : zhi;
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float un = L.q < 2 ? fmaf(alpha, kb[v], Ud[v]) : 0.f;
+                if (MODE == 1 && ((zw >> (8 * v)) & 0xffu) != 0u) un = 0.f;                          // :197-198
+                Ud[v] = un;
+            }
+            if (store && L.q < 2) wv::store_f32x4(p.new_u + tb * NC + 4 * L.q, Ud);
+        }
+        // ---- dx_{t+1} = F dtau   (f = None, :333), dlambda_{t+1} = V_{t+1} dx_{t+1} + v_{t+1} + (1 - alpha) g_{t+1}
+        if (t < T - 1) {
+            const long tb1 = (long)(t + 1) * p.B + L.b;
+            f32x4 acc[2] = {zero4, zero4};
+            wv::sched_fence();
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][k], Xd[k >> 2][k & 3], acc[Im]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + v], Ud[v], acc[Im]);
+            // (A operand = V through its symmetry: register v of tile (I', Im), exactly as Y = V F in the sweep)
+#pragma unroll
+            for (int Ip = 0; Ip < 2; ++Ip)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int Im = 0; Im < 2; ++Im) DL[Im] = wv::mfma(Vt[Ip][Im][v], acc[Ip][v], DL[Im]);
+            wv::sched_fence();
+            if (store) {
+#pragma unroll
+                for (int Im = 0; Im < 2; ++Im) {
+                    wv::store_f32x4(p.new_x + tb1 * NS + 16 * Im + 4 * L.q, acc[Im]);
+                    wv::store_f32x4(kx.dF + tb * (long)(NS * N) + NS + 16 * Im + 4 * L.q, DL[Im]);
+                    if (kx.df) wv::store_f32x4(kx.df + tb * NS + 16 * Im + 4 * L.q, f32x4{-DL[Im][0], -DL[Im][1], -DL[Im][2], -DL[Im][3]});   // :397-400
+                }
+            }
+            Xd[0] = acc[0];
+            Xd[1] = acc[1];
+        }
+    }
+    wv::dma_wait<0>();
+}
+
+template <int MODE> MPC_DEV void kkt_fused_wave(const P &p, float *K, float *k, const KktArgs40 &kx)
+{
+    Lane L;
+    L.lane = wv::lane();
+    L.r = L.lane & 15;
+    L.q = L.lane >> 4;
+    L.b = wv::problem();
+    if (L.b >= p.B) return;
+    double w0 = 0.0;
+    float v0g0[4] = {0.f, 0.f, 0.f, 0.f};
+    (void)sweep_wave<MODE, true>(p, K, k, &w0, &kx, v0g0);
+    wv::fence_own_stores();            // K, k, V, v, g come back through the DMA
+    kkt_pass2<MODE>(p, L, K, k, kx, w0, v0g0);
 }
 
 template <int MODE> MPC_DEV void step_wave(const P &p, float *K, float *k)

@@ -636,6 +636,40 @@ extern "C" int emu_lqr_sweep_mfma40(const mpc_lqr_problem *p, const mpc_lqr_opti
     return 0;
 }
 
+// the fused KKT backward of that shape (kkt_fused_wave of lqr_mfma40_body.h): dx, du, dx_init, df and the costates
+// lambda_{t+1}, dlambda_{t+1} parked in the first 64 words of the dF_t blocks (the outer products are kkt_outer_kernel's)
+static const mpclqr::mfma40::KktArgs40 *g_k40;
+template <int MODE> static void body_kkt40() { mpclqr::mfma40::kkt_fused_wave<MODE>(*g_p, g_p->K, g_p->k, *g_k40); }
+extern "C" int emu_kkt_fused_mfma40(const mpc_lqr_problem *p, const mpc_lqr_options *o, const float *dl_dx, const float *dl_du,
+                                    float *dF, float *df, float *dx_init, float *dx_out, float *du_out, int *status)
+{
+    mpc_lqr_outputs out;
+    memset(&out, 0, sizeof(out));
+    out.status = status;
+    mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, &out);
+    if (!(sp.ns == 32 && sp.nc == 8)) return MPC_E_DIMS;
+    if (sizeof(emu::W.lds) < mpclqr::mfma40::KLDS_TOTAL) return MPC_E_DIMS;
+    const size_t TB = (size_t)sp.T * sp.B, need = TB * (256 + 8 + 1024 + 64) + 4;
+    float *ws = (float *)aligned_alloc(16, (need * sizeof(float) + 15) / 16 * 16);
+    for (size_t i = 0; i < need; ++i) ws[i] = NAN;
+    sp.K = ws;
+    sp.k = ws + TB * 256;
+    sp.new_x = dx_out;
+    sp.new_u = du_out;
+    sp.ls_decay = 0.2f;
+    sp.max_ls = 10;
+    sp.c_symmetric = 1;
+    mpclqr::mfma40::KktArgs40 k;
+    k.dl_dx = dl_dx; k.dl_du = dl_du; k.dF = dF; k.df = df; k.dx_init = dx_init;
+    k.Vws = ws + TB * 264; k.vgws = ws + TB * (264 + 1024);
+    g_p = &sp;
+    g_k40 = &k;
+    const bool masked = sp.bound_mode != MPC_BOUND_NONE;
+    for (int b = 0; b < sp.B; ++b) emu::run_wave(b, masked ? body_kkt40<1> : body_kkt40<0>);
+    free(ws);
+    return 0;
+}
+
 // ---- lqr_wave1_body.h: one wavefront per problem, n_ctrl = 1, n_state <= 6, the problem in LDS ----
 #include "../../mpc.pytorch_amd/csrc/lqr_wave1_body.h"
 template <int NS> static void body_wave1_ns() { mpclqr::wave1::step_wave<NS>(*g_p); }

@@ -226,6 +226,60 @@ def kkt_fused(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_upper=No
     return out
 
 
+def kkt_fused_mfma40(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_upper=None, dma_late=False):
+    """LQRStepFn.backward (mpc/lqr_step.py:312-407) at n_state = 32, n_ctrl = 8 through the emulated fused kernel
+    (kkt_fused_wave, lqr_mfma40_body.h): dx, du, dx_init, df and the two costates from the kernel; dC, dc, dF are then the
+    outer products kkt_outer_kernel (kkt_wave.hip) forms from exactly those vectors (:346-353, :387-396), here in numpy."""
+    f32 = np.float32
+    cast = lambda a: np.ascontiguousarray(a, f32)
+    C, c, x_star, u_star, dl_dx, dl_du = map(cast, (C, c, x_star, u_star, dl_dx, dl_du))
+    T, B, n, _ = C.shape
+    ns, nc = 32, 8
+    p = N.Problem()
+    p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, N.MPC_F32
+    x0 = np.zeros((B, ns), f32)
+    p.x_init = _ptr(x0)
+    p.C, p.C_st, p.C_sb = _ptr(C), B * n * n, n * n
+    p.c, p.c_st, p.c_sb = _ptr(c), B * n, n
+    if T > 1:
+        F = cast(F)
+        p.F, p.F_st, p.F_sb = _ptr(F), B * ns * n, ns * n
+    p.cur_x, p.cur_u = _ptr(x_star), _ptr(u_star)
+    o = N.Options()
+    o.max_linesearch_iter, o.linesearch_decay, o.delta_u, o.pnqp_iter = 10, 0.2, float("nan"), 20
+    keep = []
+    if u_lower is None:
+        o.bound_mode = N.BOUND_NONE
+    elif isinstance(u_lower, (float, int)):
+        o.bound_mode, o.lo_s, o.hi_s = N.BOUND_SCALAR, float(u_lower), float(u_upper)
+    else:
+        lo = np.ascontiguousarray(np.broadcast_to(u_lower, (T, B, nc)), f32)
+        hi = np.ascontiguousarray(np.broadcast_to(u_upper, (T, B, nc)), f32)
+        keep += [lo, hi]
+        o.bound_mode, o.lo, o.hi = N.BOUND_TENSOR, _ptr(lo), _ptr(hi)
+    has_f = f is not None and np.asarray(f).size > 0
+    out = dict(dF=np.full((max(T - 1, 0), B, ns, n), np.nan, f32), df=np.full((max(T - 1, 0), B, ns), np.nan, f32) if has_f else None,
+               dx_init=np.full((B, ns), np.nan, f32), dx=np.full((T, B, ns), np.nan, f32), du=np.full((T, B, nc), np.nan, f32),
+               status=np.zeros(B, np.int32))
+    L = lib()
+    L.emu_set_dma_late(int(bool(dma_late)))
+    vp = ctypes.c_void_p
+    L.emu_kkt_fused_mfma40.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options)] + [vp] * 8
+    rc = L.emu_kkt_fused_mfma40(ctypes.byref(p), ctypes.byref(o), _ptr(dl_dx), _ptr(dl_du), _ptr(out["dF"]), _ptr(out["df"]),
+                                _ptr(out["dx_init"]), _ptr(out["dx"]), _ptr(out["du"]), _ptr(out["status"]))
+    assert rc == 0, rc
+    tau = np.concatenate((x_star, u_star), 2)
+    dtau = np.concatenate((out["dx"], out["du"]), 2)
+    out["dC"] = -0.5 * (dtau[..., :, None] * tau[..., None, :] + tau[..., :, None] * dtau[..., None, :])
+    out["dc"] = -dtau
+    if T > 1:
+        park = out["dF"].reshape(T - 1, B, ns * n)
+        lam1, dlam1 = park[..., :ns].copy(), park[..., ns:2 * ns].copy()
+        out["lam1"], out["dlam1"] = lam1, dlam1
+        out["dF"] = -(dlam1[..., :, None] * tau[:-1, :, None, :] + lam1[..., :, None] * dtau[:-1, :, None, :])
+    return out
+
+
 def env_linearize(kind, params, dt, u_max, x, u, dtype=np.float64):
     """mpc.pytorch_amd/csrc/env_dynamics.h compiled for the host: next state, F, f at N points."""
     sfx = "f64" if dtype == np.float64 else "f32"

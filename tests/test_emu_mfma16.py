@@ -738,6 +738,56 @@ def test_emulated_mfma40_constrained_modes(emu, case, dma_late):
         assert int(r["qp_iters"].max()) <= o["n_qp_iter"] + 2
 
 
+@pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
+@pytest.mark.parametrize("case", ["unbounded", "bounded", "bounded_nof", "tensor_bounds", "T1", "T2", "T3", "T9", "nonconvex"])
+def test_emulated_fused_kkt_backward_mfma40_matches_oracle(emu, case, dma_late):
+    """kkt_fused_wave of lqr_mfma40_body.h (config 5's shape): LQRStepFn.backward (mpc/lqr_step.py:312-407) as the step
+    of its nested problem with lambda riding along the sweep and dlambda = V dx + v + (1 - alpha) g along the rollout --
+    dx, du, dx_init, df, both costates and (through them) dC, dc, dF against the oracle's three-stage backward: short
+    horizons around the ring depths, scalar and tensor bounds (pinned set from u*), a non-convex cost whose nested
+    step backtracks."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(sum(map(ord, case)) + 40)
+    T = {"T1": 1, "T2": 2, "T3": 3, "T9": 9}.get(case, 5)
+    B = 2 if case == "T9" else 3
+    bounded = case in ("bounded", "bounded_nof", "tensor_bounds", "T2", "T9")
+    pr = _cfg5_problem(rng, max(T, 2), B)
+    pr.pop("cur_x"); pr.pop("cur_u")
+    if case == "bounded_nof":
+        pr["f"] = None
+    if case == "nonconvex":
+        pr["C"][:, (0, 2), 32:, 32:] -= 400.0 * np.eye(8)
+    if T == 1:
+        pr = {k: (v[:1] if k in ("C", "c") else (v[:0] if k in ("F", "f") and v is not None else v)) for k, v in pr.items()}
+    cur_u = np.clip(0.5 * rng.standard_normal((T, B, 8)), -0.4, 0.4)
+    cur_x, _ = O.traj_cost(pr["x_init"], cur_u, pr["F"], pr["f"])
+    lo, hi = (-0.4, 0.4) if bounded else (None, None)
+    if case == "tensor_bounds":
+        lo, hi = -0.3 - 0.2 * rng.random((T, B, 8)), 0.3 + 0.2 * rng.random((T, B, 8))
+        lo, hi = lo.astype(np.float32).astype(np.float64), hi.astype(np.float32).astype(np.float64)
+    x, u = cur_x, cur_u
+    for _ in range(4):
+        sol = O.lqr_step(lockstep=False, cur_x=x, cur_u=u, u_lower=lo, u_upper=hi, **pr)
+        x, u = sol["new_x"], sol["new_u"]
+    x, u = x.astype(np.float32).astype(np.float64), u.astype(np.float32).astype(np.float64)
+    dl_dx, dl_du = rng.standard_normal((T, B, 32)), rng.standard_normal((T, B, 8))
+    o = O.kkt_backward(pr["C"], pr["c"], pr["F"], pr["f"], x, u, dl_dx, dl_du, lo, hi, lockstep=False)
+    if bounded:
+        act = np.abs(np.abs(u) - 0.4) <= 1e-8 if case != "tensor_bounds" else (np.abs(u - lo) <= 1e-8) | (np.abs(u - hi) <= 1e-8)
+        assert 0.02 < act.mean() < 0.95, act.mean()
+    if case == "nonconvex":
+        nested = O.lqr_step(np.zeros((B, 32)), pr["C"], -np.concatenate((dl_dx, dl_du), 2), pr["F"], None, np.zeros((T, B, 32)),
+                            np.zeros((T, B, 8)), lockstep=False)
+        assert (nested["alphas"] < 1).any() and (nested["alphas"] == 1).any(), nested["alphas"]
+    r = emu.kkt_fused_mfma40(pr["C"], pr["c"], pr["F"], pr["f"], x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late)
+    wide = 20.0 if case == "nonconvex" else 2.0
+    for k in ("dx", "du", "dC", "dc", "dF", "dx_init") + (("df",) if pr["f"] is not None and T > 1 else ()):
+        if o[k] is None or o[k].size == 0:
+            continue
+        assert np.isfinite(r[k]).all(), k
+        np.testing.assert_allclose(r[k], o[k], rtol=1e-4 * wide, atol=1e-4 * wide * max(1.0, np.abs(o[k]).max()), err_msg=k)
+
+
 # ---------------------------------------------------------------------------------------------
 # The same kernel on its 2-slot sweep ring (lqr_dpp16.hip is compiled twice; -DMPC_DPP16_NSTAGE=2 is what the
 # unconstrained step and large constrained batches run on): the staging look-ahead, its counted waits and the

@@ -317,6 +317,55 @@ def test_config5_full_waves_vs_oracle(be, mode):
         assert float(r["new_u"][mask].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "3launch"])
+@pytest.mark.parametrize("bounded", [False, True])
+def test_config5_kkt_backward_full_waves_vs_oracle(be, bounded, fused):
+    """LQRStepFn.backward (mpc/lqr_step.py:312-407) at ns=32 nc=8 T=64, B = 1030 (more waves than SIMDs, a ragged grid),
+    fp32, all five gradients against the float64 oracle fed the same (x*, u*, dl_dx, dl_du), output buffers poisoned.
+    fused: with C vouched symmetric the backward is mpc_lqr_kkt_fused -- the nested step with lambda riding along its sweep
+    and dlambda = V dx + v along its rollout (lqr_mfma40_body.h: kkt_fused_wave), then the outer-product kernel; without
+    the promise prepare + nested step + costate kernel + outer products."""
+    import bench
+    from mpc._native import StepOptions
+    from oracle import lqr_oracle as O
+    T, B = 64, full_batch(1030)
+    p = bench.make_problem(32, 8, T, B, torch.float32, DEV, seed=23, u_scale=0.3 if bounded else 0.0, clamp=0.5 if bounded else None)
+    kw = dict(u_lower=-0.5, u_upper=0.5) if bounded else {}
+    opts = StepOptions(c_symmetric=fused, **kw)
+    x, u = p["cur_x"], p["cur_u"]
+    for _ in range(3 if bounded else 1):          # (a few steps: the bounded solution then sits on its bounds for good)
+        r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], x, u, StepOptions(**kw))
+        x, u = r["new_x"], r["new_u"]
+    g = torch.Generator(device=DEV).manual_seed(5)
+    gx = torch.randn(tuple(x.shape), generator=g, device=DEV)
+    gu = torch.randn(tuple(u.shape), generator=g, device=DEV)
+    for shape in ((T, B, 40, 40), (T - 1, B, 32, 40), (T, B, 40), (T - 1, B, 32), (B, 32)):
+        torch.full(shape, float("nan"), device=DEV)
+    got = be.kkt_backward(p["C"], p["c"], p["F"], p["f"], x, u, gx, gu, opts)
+    sync()
+    o = O.kkt_backward(h64(p["C"]), h64(p["c"]), h64(p["F"]), h64(p["f"]), h64(x), h64(u), h64(gx), h64(gu),
+                       -0.5 if bounded else None, 0.5 if bounded else None, lockstep=False, nthreads=O.max_threads())
+    if bounded:
+        act = (np.abs(np.abs(h64(u)) - 0.5) <= 1e-8).mean()
+        assert 0.02 < act < 0.9, "the fixture should have active AND free controls (active share %.3f)" % act
+    d = {}
+    for k in ("dx_init", "dC", "dc", "dF", "df"):
+        a = host(got[k]).astype(np.float64)
+        assert np.isfinite(a).all(), k
+        ax = tuple(i for i in range(a.ndim) if i != (0 if k == "dx_init" else 1))
+        scale = np.maximum(1.0, np.abs(o[k]).max(axis=ax, keepdims=True))
+        rel = (np.abs(a - o[k]) / scale).max(axis=ax)
+        d[k] = float(rel.max())
+        assert rel.max() < 5e-4, "%s: problem %d off by %.2e of its scale" % (k, int(rel.argmax()), rel.max())
+    if not DRY:
+        from mpc import _native
+        import ctypes
+        pf, _k = be._problem(p["x_init"], p["C"], p["c"], p["F"], p["f"], x, u)
+        of, _k2 = opts.to_struct(T, B, 8, p["C"])
+        assert bool(_native.load().mpc_lqr_kkt_fused_supported(ctypes.byref(pf), ctypes.byref(of))) == fused
+    diag("cfg5_kkt_B%d_%s_%s" % (B, "bounded" if bounded else "unbounded", "fused" if fused else "3launch"), **d)
+
+
 # ------------------------------------------------------------------------------------------------
 # SURVEY.md 8(f-4): approximate_cost on the device
 # ------------------------------------------------------------------------------------------------
