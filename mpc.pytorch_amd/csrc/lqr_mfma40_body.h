@@ -502,6 +502,24 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
 
 // The sweep of one problem: K [T,B,8,32] and k [T,B,8] in the reference layout, old_costs[b].
 // MODE 0: unconstrained; 1: u_zero_I mask; 2: box constraints (pnqp8 on wave-uniform values).
+// V_t (the four tiles as they sit in the registers: pass 2 reads them back as A operands) and v_t | g_t (column layout:
+// lane group q holds entries 16I + 4q + v) to the fused backward's workspace
+MPC_DEV void kkt_store_vvg(const KktArgs40 &kx, long tb, const Lane &L, const wv::f32x4 (&Vd)[2][2], const float (&vcol)[2][4],
+                           const float (&gcol)[2][4])
+{
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) wv::store_f32x4(kx.Vws + tb * 1024 + (2 * I + J) * 256 + 4 * L.lane, Vd[I][J]);
+    if (L.r == 0) {
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            wv::store_f32x4(kx.vgws + tb * 64 + 16 * I + 4 * L.q, wv::f32x4{vcol[I][0], vcol[I][1], vcol[I][2], vcol[I][3]});
+            wv::store_f32x4(kx.vgws + tb * 64 + 32 + 16 * I + 4 * L.q, wv::f32x4{gcol[I][0], gcol[I][1], gcol[I][2], gcol[I][3]});
+        }
+    }
+}
+
 // KKT (the fused backward, kkt_fused_wave): the nested problem of LQRStepFn.backward -- zero nominal, c = -(dl_dx | dl_du),
 // pinned controls from u* and the bounds (MODE 1) -- with two more vector recursions riding along:
 //   lambda_t = C_x tau*_t + c_x + F_x' lambda_{t+1}   (:355-369; nothing the nested solve produces is in it)
@@ -547,6 +565,9 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         wv::dma_wait<DMA_PER_STAGE>();
         const unsigned base = (unsigned)slot * STAGE_BYTES;
         const long tb = (long)t * p.B + L.b;
+        // (V, v, g) of t+1 leave now, not when they were finished: vector stores share the counter the wait above counts
+        // the DMAs with, and a store issued at the end of a timestep would be waited out at the top of the next one
+        if (KKT && t < T - 1) kkt_store_vvg(*kx, tb + p.B, L, Vd, vcol, gcol);
 
         // ---- C in D layout (all nine tiles), tau in both layouts, c in row layout
         // Tile (I, J), registers v = 0..3 of lane (q, r) = C[16I + 4q + v][16J + r] -- read through C's symmetry as
@@ -939,22 +960,9 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                 for (int v = 0; v < 4; ++v) { lcol[I][v] = wl[v]; gcol[I][v] = wg[v]; }
             }
         }
-        if (KKT) {
-            // V_t (the four tiles as they sit in the registers: pass 2 reads them back as A operands), v_t | g_t
-#pragma unroll
-            for (int I = 0; I < 2; ++I)
-#pragma unroll
-                for (int J = 0; J < 2; ++J) wv::store_f32x4(kx->Vws + tb * 1024 + (2 * I + J) * 256 + 4 * L.lane, Vd[I][J]);
-            if (L.q == 0) {
-#pragma unroll
-                for (int J = 0; J < 2; ++J) {
-                    kx->vgws[tb * 64 + 16 * J + L.r] = vrow[J];
-                    kx->vgws[tb * 64 + 32 + 16 * J + L.r] = grow[J];
-                }
-            }
-            if (t == 0 && v0g0) {
-                v0g0[0] = vrow[0]; v0g0[1] = vrow[1]; v0g0[2] = grow[0]; v0g0[3] = grow[1];
-            }
+        if (KKT && t == 0) {
+            kkt_store_vvg(*kx, tb, L, Vd, vcol, gcol);
+            if (v0g0) { v0g0[0] = vrow[0]; v0g0[1] = vrow[1]; v0g0[2] = grow[0]; v0g0[3] = grow[1]; }
         }
         slot ^= 1;
     }
@@ -1537,6 +1545,7 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
     f32x4 Xd[2];                     // dx_t, D layout: column r = trial r (dx_0 = 0: the nested x_init, :327, 338)
     Xd[0] = zero4;
     Xd[1] = zero4;
+    f32x4 pU = zero4, pDL[2] = {zero4, zero4};     // du_{t-1}, dlambda_t: stored one timestep late (below)
     if (store) {
 #pragma unroll
         for (int I = 0; I < 2; ++I) wv::store_f32x4(p.new_x + (long)L.b * NS + 16 * I + 4 * L.q, zero4);
@@ -1590,6 +1599,19 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
             const int tn = t + KSLOTS - 1;
             kstage_issue(p, d, v_ptr, v_step, tn < T ? tn : T - 1, tn % KSLOTS);
         }
+        // what the PREVIOUS timestep produced leaves now: the wait at the top of the next trip counts vector stores with the
+        // DMAs, so stores issued here have a timestep of arithmetic to land in (issued at the end of their own timestep they
+        // were waited out at once)
+        if (store && t > 0) {
+            const long tbp = tb - p.B;
+            if (L.q < 2) wv::store_f32x4(p.new_u + tbp * NC + 4 * L.q, pU);
+#pragma unroll
+            for (int Im = 0; Im < 2; ++Im) {
+                wv::store_f32x4(p.new_x + tb * NS + 16 * Im + 4 * L.q, Xd[Im]);
+                wv::store_f32x4(kx.dF + tbp * (long)(NS * N) + NS + 16 * Im + 4 * L.q, pDL[Im]);
+                if (kx.df) wv::store_f32x4(kx.df + tbp * NS + 16 * Im + 4 * L.q, f32x4{-pDL[Im][0], -pDL[Im][1], -pDL[Im][2], -pDL[Im][3]});   // :397-400
+            }
+        }
         wv::sched_fence();
         {
             f32x4 U2 = zero4;
@@ -1614,11 +1636,10 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
                 if (MODE == 1 && ((zw >> (8 * v)) & 0xffu) != 0u) un = 0.f;                          // :197-198
                 Ud[v] = un;
             }
-            if (store && L.q < 2) wv::store_f32x4(p.new_u + tb * NC + 4 * L.q, Ud);
+            pU = Ud;
         }
         // ---- dx_{t+1} = F dtau   (f = None, :333), dlambda_{t+1} = V_{t+1} dx_{t+1} + v_{t+1} + (1 - alpha) g_{t+1}
         if (t < T - 1) {
-            const long tb1 = (long)(t + 1) * p.B + L.b;
             f32x4 acc[2] = {zero4, zero4};
             wv::sched_fence();
 #pragma unroll
@@ -1637,18 +1658,13 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
 #pragma unroll
                     for (int Im = 0; Im < 2; ++Im) DL[Im] = wv::mfma(Vt[Ip][Im][v], acc[Ip][v], DL[Im]);
             wv::sched_fence();
-            if (store) {
-#pragma unroll
-                for (int Im = 0; Im < 2; ++Im) {
-                    wv::store_f32x4(p.new_x + tb1 * NS + 16 * Im + 4 * L.q, acc[Im]);
-                    wv::store_f32x4(kx.dF + tb * (long)(NS * N) + NS + 16 * Im + 4 * L.q, DL[Im]);
-                    if (kx.df) wv::store_f32x4(kx.df + tb * NS + 16 * Im + 4 * L.q, f32x4{-DL[Im][0], -DL[Im][1], -DL[Im][2], -DL[Im][3]});   // :397-400
-                }
-            }
             Xd[0] = acc[0];
             Xd[1] = acc[1];
+            pDL[0] = DL[0];
+            pDL[1] = DL[1];
         }
     }
+    if (store && L.q < 2) wv::store_f32x4(p.new_u + ((long)(T - 1) * p.B + L.b) * NC + 4 * L.q, pU);
     wv::dma_wait<0>();
 }
 
@@ -1664,6 +1680,9 @@ template <int MODE> MPC_DEV void kkt_fused_wave(const P &p, float *K, float *k, 
     float v0g0[4] = {0.f, 0.f, 0.f, 0.f};
     (void)sweep_wave<MODE, true>(p, K, k, &w0, &kx, v0g0);
     wv::fence_own_stores();            // K, k, V, v, g come back through the DMA
+#ifdef MPC_KF40_P1_ONLY                 // (diagnostic build: where the time goes, tools/ab_kkt40_phases.sh)
+    if (w0 != 1.2345e300) return;
+#endif
     kkt_pass2<MODE>(p, L, K, k, kx, w0, v0g0);
 }
 
