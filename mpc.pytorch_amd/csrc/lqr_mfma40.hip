@@ -31,6 +31,14 @@ MPC_DEV void rows01(float x, float &r0, float &r1)
     r0 = __uint_as_float(b[0]);
     r1 = __uint_as_float(b[1]);
 }
+// lo = {a.row0, b.row0, a.row2, b.row2}, hi = {a.row1, b.row1, a.row3, b.row3} (rows of 16 lanes): v_permlane16_swap
+// exchanges the odd rows of its first operand with the even rows of its second
+MPC_DEV void swap16(float a, float b, float &lo, float &hi)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
 // DPP row broadcast: lane N of the caller's 16-lane row
 template <int N> MPC_DEV float bcast(float x)
 {

@@ -643,7 +643,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             float s = 0.f;
 #pragma unroll
             for (int J = 0; J < 3; ++J) s = fmaf(trow[J], fmaf(0.5f, qrow[J] - crow[J], crow[J]), s);
-            old_cost += (double)sum_r(s);
+            old_cost += (double)s;                           // this lane's entries; summed over the row after the loop
         }
 
         if (t < T - 1) {
@@ -827,20 +827,16 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         f32x4 Md[2];                    // M = Qux + Quu K in the same layout (constrained modes)
         Md[0] = zero4;
         Md[1] = zero4;
+        {
+            // ONE solve for all 32 columns of Qux (and qu): lane row 0 takes column r of tile 0, row 1 column r of tile 1 --
+            // a column's eight entries are registers v of rows 0 and 1 of its tile, and one row swap per register
+            // (wv::swap16: lo = {a.row0, b.row0, ..}, hi = {a.row1, b.row1, ..}) hands rows 0 / 1 entries 0..3 and 4..7 of
+            // THEIR column; row 2 solves for k (its rows of Qux are padding), row 3 rides along.  The same swap turns the
+            // solutions back into the two B-layout tiles.  (Round 2 solved tile by tile with every column in two lanes:
+            // two passes of 64 dependent multiply-adds instead of one.)
+            float rhs[8], sol[8];
 #pragma unroll
-        for (int J = 0; J < 2; ++J) {
-            float own[4], oth[4], rhs[8], sol[8];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                own[v] = Qd[2][J][v];
-                oth[v] = wv::shfl_xor(own[v], 16);
-            }
-            const bool odd = (L.q & 1) != 0;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                rhs[v] = odd ? oth[v] : own[v];
-                rhs[4 + v] = odd ? own[v] : oth[v];
-            }
+            for (int v = 0; v < 4; ++v) wv::swap16(Qd[2][0][v], Qd[2][1][v], rhs[v], rhs[4 + v]);
             float rhs_full[8];
 #pragma unroll
             for (int a = 0; a < 8; ++a) rhs_full[a] = rhs[a];
@@ -857,36 +853,45 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
 #pragma unroll
                 for (int a = 0; a < 8; ++a) sol[a] = fr[a] ? sol[a] : 0.f;
             } else {
-                // lane rows 2, 3 hold padding rows of Qux: in the first solve they take qu and return -k
 #pragma unroll
-                for (int a = 0; a < 8; ++a) sol[a] = (J == 0 && L.q >= 2) ? qu[a] : rhs[a];
+                for (int a = 0; a < 8; ++a) sol[a] = L.q == 2 ? qu[a] : rhs[a];
                 ldl8v_solve(facv, sol);
-                if (J == 0) {
-                    float w = 0.f;
+                float w = 0.f;
 #pragma unroll
-                    for (int a = 0; a < 8; ++a) {
-                        kk[a] = -wv::readlane(sol[a], 32);
-                        w = fmaf(qu[a], kk[a], w);
-                    }
-                    w0 += 0.5 * (double)w;
+                for (int a = 0; a < 8; ++a) {
+                    kk[a] = -wv::readlane(sol[a], 32);
+                    w = fmaf(qu[a], kk[a], w);
                 }
+                w0 += 0.5 * (double)w;
             }
+            float Kc[8];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) Kd[J][v] = L.q < 2 ? -pick(odd, sol[4 + v], sol[v]) : 0.f;
+            for (int a = 0; a < 8; ++a) Kc[a] = -sol[a];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float k0, k1;
+                wv::swap16(Kc[v], Kc[4 + v], k0, k1);
+                Kd[0][v] = L.q < 2 ? k0 : 0.f;
+                Kd[1][v] = L.q < 2 ? k1 : 0.f;
+            }
             if (MODE != 0) {
-                // M = Qux + Quu K for this lane's column (rows 4q+v), the B operand of K'M below
-                float Kc[8];
+                // M = Qux + Quu K for this lane's column, the B operand of K'M below
+                float m[8];
 #pragma unroll
-                for (int a = 0; a < 8; ++a) Kc[a] = -sol[a];
+                for (int a = 0; a < 8; ++a) m[a] = rhs_full[a] + sym8_row(S, a, Kc);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const float m0 = sym8_row(S, v, Kc), m1 = sym8_row(S, 4 + v, Kc);
-                    Md[J][v] = L.q < 2 ? pick(odd, rhs_full[4 + v] + m1, rhs_full[v] + m0) : 0.f;
+                    float m0, m1;
+                    wv::swap16(m[v], m[4 + v], m0, m1);
+                    Md[0][v] = L.q < 2 ? m0 : 0.f;
+                    Md[1][v] = L.q < 2 ? m1 : 0.f;
                 }
             }
             if (L.q < 2) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) Kout[(tb * NC + 4 * L.q + v) * NS + 16 * J + L.r] = Kd[J][v];
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) Kout[(tb * NC + 4 * L.q + v) * NS + 16 * J + L.r] = Kd[J][v];
             }
         }
         if (L.lane < 8) {
@@ -965,6 +970,13 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             if (v0g0) { v0g0[0] = vrow[0]; v0g0[1] = vrow[1]; v0g0[2] = grow[0]; v0g0[3] = grow[1]; }
         }
         slot ^= 1;
+    }
+    // the nominal cost: the sixteen lanes of a row hold disjoint entries' partial sums (one butterfly per sweep, not per timestep)
+#pragma unroll
+    for (int sh = 1; sh < (KKT ? 1 : 16); sh <<= 1) {
+        // (both partners add the same two rounded numbers: every lane ends with the same bits)
+        const float hi = (float)old_cost, lo = (float)(old_cost - (double)hi);
+        old_cost = ((double)hi + (double)lo) + ((double)wv::shfl_xor(hi, sh) + (double)wv::shfl_xor(lo, sh));
     }
     if (L.lane == 0 && p.old_costs) p.old_costs[L.b] = (float)old_cost;
     if (L.lane == 0 && p.qp_iters) p.qp_iters[L.b] = qp_total;

@@ -197,6 +197,18 @@ static inline void rows01(float x, float &r0, float &r1)
     r0 = w.fa[gen][l & 15];
     r1 = w.fa[gen][16 + (l & 15)];
 }
+// wv::swap16 of lqr_mfma40.hip: lo = {a.row0, b.row0, a.row2, b.row2}, hi = {a.row1, b.row1, a.row3, b.row3}
+static inline void swap16(float a, float b, float &lo, float &hi)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = a;
+    w.fb[gen][l] = b;
+    emu::yield_lane();
+    const bool odd = ((l >> 4) & 1) != 0;
+    lo = odd ? w.fb[gen][l - 16] : w.fa[gen][l];
+    hi = odd ? w.fb[gen][l] : w.fa[gen][l + 16];
+}
 template <int NN> static inline void dot_bcast(float &acc, float src, const float (&m)[NN])
 {
     emu::Wave &w = emu::W;
