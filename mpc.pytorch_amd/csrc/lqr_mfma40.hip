@@ -97,6 +97,16 @@ MPC_DEV void dma16_if(bool active, const void *g, unsigned off)
 {
     if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage40 + off), 16, 0, 0);
 }
+// the same with an immediate offset, which on gfx950 moves source AND destination: instructions of one block share pointer and M0
+template <int IMM> MPC_DEV void dma16_at(const void *g, unsigned off)
+{
+    static_assert(IMM >= 0 && IMM < 4096, "13-bit signed immediate");
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage40 + off), 16, IMM, 0);
+}
+template <int IMM> MPC_DEV void dma16_at_if(bool active, const void *g, unsigned off)
+{
+    if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage40 + off), 16, IMM, 0);
+}
 MPC_DEV float lds_f32(unsigned off) { return *(const float *)(g_stage40 + off); }
 MPC_DEV f32x4 lds_f32x4(unsigned off) { return *(const f32x4 *)(g_stage40 + off); }
 MPC_DEV void lds_store_f32(unsigned off, float v) { *(float *)(g_stage40 + off) = v; }

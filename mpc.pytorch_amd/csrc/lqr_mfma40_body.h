@@ -157,16 +157,25 @@ MPC_DEV unsigned kkt_pinned_word(const P &p, long tb, int w)
     return z;
 }
 
+// NB consecutive KiB of a block, source and destination alike: the immediate of an LDS-DMA moves both (gfx950; measured,
+// tools/ubench/dma_offset_probe.hip), so four instructions share one pointer and one M0
+template <int NB> MPC_DEV void dma_kib(const char *g, unsigned off)
+{
+    wv::dma16_at<0>(g, off);
+    if (NB > 1) wv::dma16_at<1024>(g, off);
+    if (NB > 2) wv::dma16_at<2048>(g, off);
+    if (NB > 3) wv::dma16_at<3072>(g, off);
+    if (NB > 4) dma_kib<(NB > 4 ? NB - 4 : 1)>(g + 4096, off + 4096);
+}
+
 MPC_DEV void stage_issue(const P &p, const Stream &d, const Lane &L, int t, int slot)
 {
     const unsigned base = (unsigned)slot * STAGE_BYTES;
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) wv::dma16(d.c_ptr + tl * d.c_step + 1024 * k, base + OFF_C + 1024 * k);
-    wv::dma16_if(L.lane < 16, d.c_ptr + tl * d.c_step + 6144, base + OFF_C + 6144);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) wv::dma16(d.f_ptr + (p.T > 1 ? tf * d.f_step : 0) + 1024 * k, base + OFF_F + 1024 * k);
+    dma_kib<6>(d.c_ptr + tl * d.c_step, base + OFF_C);
+    wv::dma16_at_if<2048>(L.lane < 16, d.c_ptr + tl * d.c_step + 4096, base + OFF_C + 4096);
+    dma_kib<5>(d.f_ptr + (p.T > 1 ? tf * d.f_step : 0), base + OFF_F);
     wv::dma16_if(d.r_active, d.r_ptr + tl * d.r_step, base + OFF_R);
 }
 
@@ -244,7 +253,9 @@ struct Ldl8V {
 template <int C, int M> struct Ldl8VElim {
     static MPC_DEVM void run(float (&col)[8], float nlc)
     {
-        wv::fmac_bcast<M>(col[M], col[C], nlc);             // A[a][m] -= L[a][c] A[m][c]
+        // (col[C] was last written by the previous pivot's first elimination, five or more instructions back: the DPP read needs
+        // no wait states of its own)
+        wv::fmac_bcast_settled<M>(col[M], col[C], nlc);     // A[a][m] -= L[a][c] A[m][c]
         Ldl8VElim<C, M + 1>::run(col, nlc);
     }
 };
@@ -1048,11 +1059,9 @@ MPC_DEV void rstage_issue(const P &p, const RStream &d, const Lane &L, int t, in
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);      // F, f have T-1 entries
     const long tx = t + 1 < p.T ? t + 1 : t;                         // x_{t+1}
-#pragma unroll
-    for (int k = 0; k < 6; ++k) wv::dma16(d.c_ptr + tl * d.c_step + 1024 * k, base + OFF_C + 1024 * k);
-    wv::dma16_if(L.lane < 16, d.c_ptr + tl * d.c_step + 6144, base + OFF_C + 6144);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) wv::dma16(d.f_ptr + tf * d.f_step + 1024 * k, base + OFF_F + 1024 * k);
+    dma_kib<6>(d.c_ptr + tl * d.c_step, base + OFF_C);
+    wv::dma16_at_if<2048>(L.lane < 16, d.c_ptr + tl * d.c_step + 4096, base + OFF_C + 4096);
+    dma_kib<5>(d.f_ptr + tf * d.f_step, base + OFF_F);
     wv::dma16(d.k_ptr + tl * d.k_step, base + ROFF_K);
     wv::dma16_if(d.r_active, d.r_ptr + (d.r_is_f ? tf : (d.r_is_x ? tx : tl)) * d.r_step, base + ROFF_R);
 }
@@ -1301,8 +1310,7 @@ MPC_DEV void lstage_issue(const P &p, const RStream &d, const Lane &L, int t, in
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);      // F, f have T-1 entries
     const long tx = t + 1 < p.T ? t + 1 : t;                         // x_{t+1}
-#pragma unroll
-    for (int k = 0; k < 5; ++k) wv::dma16(d.f_ptr + tf * d.f_step + 1024 * k, base + LOFF_F + 1024 * k);
+    dma_kib<5>(d.f_ptr + tf * d.f_step, base + LOFF_F);
     wv::dma16(d.k_ptr + tl * d.k_step, base + LOFF_K);
     // (lanes 0..9 would carry c_t, which this pass never looks at: they sit the instruction out)
     wv::dma16_if(d.r_active && L.lane >= 10, d.r_ptr + (d.r_is_f ? tf : (d.r_is_x ? tx : tl)) * d.r_step, base + LOFF_R);
@@ -1497,12 +1505,10 @@ MPC_DEV void kstage_issue(const P &p, const RStream &d, const char *v_ptr, long 
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);      // F has T-1 entries
     const long tx = t + 1 < p.T ? t + 1 : t;                         // (V, v, g) of t+1
-#pragma unroll
-    for (int k = 0; k < 5; ++k) wv::dma16(d.f_ptr + tf * d.f_step + 1024 * k, base + KOFF_F + 1024 * k);
+    dma_kib<5>(d.f_ptr + tf * d.f_step, base + KOFF_F);
     wv::dma16(d.k_ptr + tl * d.k_step, base + KOFF_K);
     wv::dma16_if(d.r_active, d.r_ptr + (d.r_is_x ? tx : tl) * d.r_step, base + KOFF_R);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) wv::dma16(v_ptr + tx * v_step + 1024 * k, base + KOFF_V + 1024 * k);
+    dma_kib<4>(v_ptr + tx * v_step, base + KOFF_V);
 }
 
 template <int MODE>

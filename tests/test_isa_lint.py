@@ -71,10 +71,11 @@ def test_no_vector_spills_no_scratch_and_bounded_scalar_spills(tu):
     scratch_ops = {k: v["scratch"] for k, v in _findings(tu).items()}
     for k, v in md.items():
         assert v["vgpr_spill_count"] == 0, (k, v)
-        # (the masked instantiation of the fused 32/8 backward spills 83 scalars into the lanes of TWO vector registers, and the
-        # compiler then leaves a 68-byte private segment in the descriptor that no instruction of the kernel addresses)
-        unused = tu == "lqr_mfma40_kkt" and "kernelILi1E" in k and v["private_segment_fixed_size"] <= 68
-        assert v["private_segment_fixed_size"] == 0 or unused, (k, v)
+        # No instruction of the kernel may address scratch memory.  (The descriptor's private segment itself is allowed to be
+        # non-zero only where that is provably dead weight: hipcc sometimes leaves the 68-byte frame of scalar spill slots it
+        # went on to place in vector-register lanes -- seen on one or the other instantiation of the fused 32/8 backward,
+        # flipping with unrelated edits; `-Rpass-analysis=kernel-resource-usage` reports it, the ISA has no scratch_ access.)
+        assert v["private_segment_fixed_size"] == 0 or (tu == "lqr_mfma40_kkt" and v["private_segment_fixed_size"] <= 68), (k, v)
         assert scratch_ops[[n for n in scratch_ops if n in k or k in n][0]] == 0, k
         for pat, lim in SGPR_SPILL_LIMITS[tu].items():
             if pat in k:
