@@ -199,9 +199,11 @@ int mpc_lqr_kkt_prepare(int dtype, int B, int T, int ns, int nc,
                         const void *dl_dx, const void *dl_du, const void *u_star,
                         const mpc_lqr_options *o, void *negr, uint8_t *mask, void *stream);
 
-/* (4c) ALL of LQRStepFn.backward (mpc/lqr_step.py:312-407) in ONE launch, where a kernel for it exists: fp32, n_state = 12,
- *     n_ctrl = 4, T <= 64, 16-byte aligned blocks, and the caller's promise MPC_OPT_C_SYMMETRIC in o->flags (without it the
- *     three calls above are the way: their step tests C and re-solves what is not symmetric).
+/* (4c) ALL of LQRStepFn.backward (mpc/lqr_step.py:312-407) in ONE call, where kernels for it exist: fp32, 16-byte aligned
+ *     blocks, the caller's promise MPC_OPT_C_SYMMETRIC in o->flags (without it the three calls above are the way: their step
+ *     tests C and re-solves what is not symmetric), and either n_state = 12, n_ctrl = 4, T <= 64 (one launch) or
+ *     n_state = 32, n_ctrl = 8, any T (two launches: the nested step with both costates riding along, then the outer
+ *     products; no prepare / costate passes over C and F).
  *     p = (C, c, F, f) of the forward with cur_x / cur_u = the solution (x*, u*); p->f only decides whether df is written.
  *     o = the forward's bounds: controls within 1e-8 of u_lower / u_upper are pinned in the KKT solve (:316-326); o may be
  *     NULL (no bounds).  dl_dx [T,B,ns], dl_du [T,B,nc].  Outputs as (4); dx_out / du_out (the KKT solve's own dx, du) and

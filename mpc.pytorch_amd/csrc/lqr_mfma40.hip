@@ -82,7 +82,8 @@ MPC_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
 // Compiled twice (Makefile): the step kernels on a 26 KiB staging array (six wavefronts per CU), and with -DMPC_MFMA40_KKT
 // the fused KKT backward alone, whose second pass stages V_{t+1} as well (three slots of 10.5 KiB: four wavefronts per CU)
 #ifdef MPC_MFMA40_KKT
-#define MPC_MFMA40_LDS (3 * 10752)
+#define MPC_MFMA40_SWEEP_NSTAGE 3
+#define MPC_MFMA40_LDS (3 * 12032 + 512)       // the sweep's three slots + the layout-turn words; pass 2's ring (31.5 KiB) lies inside
 #else
 #define MPC_MFMA40_LDS (2 * 13056 + 512)
 #endif
@@ -184,6 +185,9 @@ int launch_kkt_fused_mfma40(const StepParams<float> &p_in, const float *dl_dx, c
         set_last_error((std::string("lqr_kkt_fused_mfma40_kernel: ") + hipGetErrorString(e)).c_str());
         return MPC_E_LAUNCH;
     }
+#ifdef MPC_KF40_NO_OUTER          // (diagnostic build: the fused kernel without its memory-bound neighbour, tools/ab_cfg5b.py)
+    return MPC_OK;
+#endif
     return launch_kkt_outer(p, dx, du, dC, dc, dF, st);
 }
 }  // namespace mpclqr

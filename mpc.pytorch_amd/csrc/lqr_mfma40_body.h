@@ -60,13 +60,22 @@ MPC_DEV float uniform_f32(const float *g)
 
 using wv::f32x4;
 constexpr int NS = 32, NC = 8, N = 40;
-constexpr int NSTAGE = 2;      // slots of the LDS-DMA ring: one step in flight (27 KiB per wave -> 6 waves per CU)
+constexpr int NSTAGE = 2;      // slots of the pricing rollout's LDS-DMA ring: one step in flight (27 KiB per wave -> 6 waves per CU)
+// Slots of the SWEEP's ring.  Two (the DMA one timestep = 3.6 us ahead) is enough while the address translations of the
+// blocks are cached; behind a kernel that has walked other memory (its own outer-product kernel in the fused backward: 810 MB
+// of gradients) every stage starts with TLB misses and a sweep that is one step ahead waits them out, +2.3 us per timestep
+// (tools/k40_tlb_probe.py: a 16 us kernel touching one byte per page of 800 MB slows the next launch by 145 us).  The fused
+// backward is therefore compiled with three slots (two timesteps ahead).
+#ifndef MPC_MFMA40_SWEEP_NSTAGE
+#define MPC_MFMA40_SWEEP_NSTAGE 2
+#endif
+constexpr int SNSTAGE = MPC_MFMA40_SWEEP_NSTAGE;
 constexpr unsigned OFF_C = 0, OFF_F = 6400, OFF_R = 11520, STAGE_BYTES = 12032;   // (the record: 320 B, 448 B in the fused backward)
 constexpr int DMA_PER_STAGE = 13;                           // 7 (C) + 5 (F) + 1 (c | x | u)
 // rollout stage: C | F | K_t (1 KiB) | record (c, x_{t+1}, u_t, f_t, k_t)
 constexpr unsigned ROFF_K = 11520, ROFF_R = 12544, RSTAGE_BYTES = 13056;
 constexpr int RDMA_PER_STAGE = 14;                          // 7 (C) + 5 (F) + 1 (K) + 1 (record)
-constexpr unsigned OFF_SCR = NSTAGE * RSTAGE_BYTES;         // 512 B: row -> column layout turns
+constexpr unsigned OFF_SCR = SNSTAGE * STAGE_BYTES > NSTAGE * RSTAGE_BYTES ? SNSTAGE * STAGE_BYTES : NSTAGE * RSTAGE_BYTES;   // 512 B: row -> column layout turns
 constexpr unsigned LDS_TOTAL = OFF_SCR + 512;
 typedef StepParams<float> P;
 // the flags of controls 4w .. 4w+3 of u_zero_I [T,B,8] at (t, b) = tb
@@ -518,6 +527,9 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
 MPC_DEV void kkt_store_vvg(const KktArgs40 &kx, long tb, const Lane &L, const wv::f32x4 (&Vd)[2][2], const float (&vcol)[2][4],
                            const float (&gcol)[2][4])
 {
+#ifdef MPC_KF40_NOVS              // (diagnostic build: what the V stores cost)
+    if (tb < 0)
+#endif
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
@@ -568,12 +580,13 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
     bool warm = false;
     float kprev_v = 0.f;               // box QP: the previous timestep's solution, spread over lanes (warm start)
 
-    stage_issue(p, d, L, T - 1, 0);
+#pragma unroll
+    for (int i = 0; i < SNSTAGE - 1; ++i) stage_issue(p, d, L, T - 1 - i >= 0 ? T - 1 - i : 0, i);
     int slot = 0;
     for (int t = T - 1; t >= 0; --t) {
-        // keep the next timestep in flight (re-loading step 0 at the tail keeps the wait count fixed)
-        stage_issue(p, d, L, t - 1 >= 0 ? t - 1 : 0, slot ^ 1);
-        wv::dma_wait<DMA_PER_STAGE>();
+        // keep the next timestep(s) in flight (re-loading step 0 at the tail keeps the wait count fixed)
+        stage_issue(p, d, L, t - (SNSTAGE - 1) >= 0 ? t - (SNSTAGE - 1) : 0, (slot + SNSTAGE - 1) % SNSTAGE);
+        wv::dma_wait<(SNSTAGE - 1) * DMA_PER_STAGE>();
         const unsigned base = (unsigned)slot * STAGE_BYTES;
         const long tb = (long)t * p.B + L.b;
         // (V, v, g) of t+1 leave now, not when they were finished: vector stores share the counter the wait above counts
@@ -980,7 +993,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             kkt_store_vvg(*kx, tb, L, Vd, vcol, gcol);
             if (v0g0) { v0g0[0] = vrow[0]; v0g0[1] = vrow[1]; v0g0[2] = grow[0]; v0g0[3] = grow[1]; }
         }
-        slot ^= 1;
+        slot = (slot + 1) % SNSTAGE;
     }
     // the nominal cost: the sixteen lanes of a row hold disjoint entries' partial sums (one butterfly per sweep, not per timestep)
 #pragma unroll

@@ -19,7 +19,8 @@ _LIB = None
 
 
 def build(ring2=False):
-    """ring2: the 12/4 kernel with its 2-slot sweep ring (-DMPC_DPP16_NSTAGE=2, the second compilation of lqr_dpp16.hip)."""
+    """ring2: the 12/4 kernel with its 2-slot sweep ring (-DMPC_DPP16_NSTAGE=2, the second compilation of lqr_dpp16.hip) and
+    the 32/8 kernel with its 3-slot sweep ring (-DMPC_MFMA40_SWEEP_NSTAGE=3, the fused-backward compilation of lqr_mfma40.hip)."""
     so = os.path.join(_EMU, "libemu_mfma16_ring2.so" if ring2 else "libemu_mfma16.so")
     src = os.path.join(_EMU, "emu_mfma16.cpp")
     csrc = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc")
@@ -31,7 +32,7 @@ def build(ring2=False):
             cxx = shutil.which("clang++")
         assert cxx, "the emulator needs clang++ (ext_vector_type)"
         subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
-                              + (["-DMPC_DPP16_NSTAGE=2", "-DMPC_KKT16_NSTAGE=2"] if ring2 else []) + ["-o", so, src])
+                              + (["-DMPC_DPP16_NSTAGE=2", "-DMPC_KKT16_NSTAGE=2", "-DMPC_MFMA40_SWEEP_NSTAGE=3"] if ring2 else []) + ["-o", so, src])
     return so
 
 
@@ -226,7 +227,7 @@ def kkt_fused(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_upper=No
     return out
 
 
-def kkt_fused_mfma40(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_upper=None, dma_late=False):
+def kkt_fused_mfma40(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_upper=None, dma_late=False, sweep3=True):
     """LQRStepFn.backward (mpc/lqr_step.py:312-407) at n_state = 32, n_ctrl = 8 through the emulated fused kernel
     (kkt_fused_wave, lqr_mfma40_body.h): dx, du, dx_init, df and the two costates from the kernel; dC, dc, dF are then the
     outer products kkt_outer_kernel (kkt_wave.hip) forms from exactly those vectors (:346-353, :387-396), here in numpy."""
@@ -261,7 +262,7 @@ def kkt_fused_mfma40(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_u
     out = dict(dF=np.full((max(T - 1, 0), B, ns, n), np.nan, f32), df=np.full((max(T - 1, 0), B, ns), np.nan, f32) if has_f else None,
                dx_init=np.full((B, ns), np.nan, f32), dx=np.full((T, B, ns), np.nan, f32), du=np.full((T, B, nc), np.nan, f32),
                status=np.zeros(B, np.int32))
-    L = lib()
+    L = lib_ring2() if sweep3 else lib()          # (the library builds this kernel with the 3-slot sweep ring)
     L.emu_set_dma_late(int(bool(dma_late)))
     vp = ctypes.c_void_p
     L.emu_kkt_fused_mfma40.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options)] + [vp] * 8

@@ -738,9 +738,10 @@ def test_emulated_mfma40_constrained_modes(emu, case, dma_late):
         assert int(r["qp_iters"].max()) <= o["n_qp_iter"] + 2
 
 
+@pytest.mark.parametrize("sweep3", [True, False], ids=["sweep3", "sweep2"])
 @pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
 @pytest.mark.parametrize("case", ["unbounded", "bounded", "bounded_nof", "tensor_bounds", "T1", "T2", "T3", "T9", "nonconvex"])
-def test_emulated_fused_kkt_backward_mfma40_matches_oracle(emu, case, dma_late):
+def test_emulated_fused_kkt_backward_mfma40_matches_oracle(emu, case, dma_late, sweep3):
     """kkt_fused_wave of lqr_mfma40_body.h (config 5's shape): LQRStepFn.backward (mpc/lqr_step.py:312-407) as the step
     of its nested problem with lambda riding along the sweep and dlambda = V dx + v + (1 - alpha) g along the rollout --
     dx, du, dx_init, df, both costates and (through them) dC, dc, dF against the oracle's three-stage backward: short
@@ -779,7 +780,8 @@ def test_emulated_fused_kkt_backward_mfma40_matches_oracle(emu, case, dma_late):
         nested = O.lqr_step(np.zeros((B, 32)), pr["C"], -np.concatenate((dl_dx, dl_du), 2), pr["F"], None, np.zeros((T, B, 32)),
                             np.zeros((T, B, 8)), lockstep=False)
         assert (nested["alphas"] < 1).any() and (nested["alphas"] == 1).any(), nested["alphas"]
-    r = emu.kkt_fused_mfma40(pr["C"], pr["c"], pr["F"], pr["f"], x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late)
+    # sweep3: the compilation the library runs (three sweep slots, the DMA two timesteps ahead); sweep2: the step kernels' ring
+    r = emu.kkt_fused_mfma40(pr["C"], pr["c"], pr["F"], pr["f"], x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, sweep3=sweep3)
     wide = 20.0 if case == "nonconvex" else 2.0
     for k in ("dx", "du", "dC", "dc", "dF", "dx_init") + (("df",) if pr["f"] is not None and T > 1 else ()):
         if o[k] is None or o[k].size == 0:
