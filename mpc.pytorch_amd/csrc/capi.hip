@@ -23,6 +23,7 @@ static int fail(int code, const char *msg)
 struct DeviceFacts {
     int ring_force;      // 0 = pick by mode and batch, 2 / 4 = MPC_DPP16_RING
     int simds;
+    int ring40_force;    // MPC_MFMA40_RING (-1: not read yet)
     bool sticky;         // false with MPC_DPP16_RING_DYNAMIC set: the switch is re-read at every launch (the tests flip it)
 };
 static const DeviceFacts &device_facts()
@@ -30,6 +31,7 @@ static const DeviceFacts &device_facts()
     static DeviceFacts f = [] {
         DeviceFacts d;
         d.ring_force = 0;
+        d.ring40_force = -1;
         d.simds = 1024;
         hipDeviceProp_t prop;
         int dev = 0;
@@ -49,6 +51,23 @@ static int dpp16_ring_force()
     // MPC_DPP16_RING_DYNAMIC=1 (the test suite): the switch follows the environment from launch to launch
     const char *force = getenv("MPC_DPP16_RING");
     return (force && (force[0] == '2' || force[0] == '4')) ? force[0] - '0' : 0;
+}
+
+// The 32/8 kernel's sweep ring: three slots (the DMA two timesteps ahead: address-translation misses behind another kernel
+// stay hidden, lqr_mfma40_body.h) wherever four wavefronts per CU are all the batch asks for or the mode gains from them anyway
+// (unconstrained / masked: 2.33 against 2.40 ms at B = 8192); the box-constrained step of a larger batch wants six per CU on
+// the two-slot ring (4.65 against 5.06 ms).  MPC_MFMA40_RING=2|3 forces one (read like MPC_DPP16_RING).
+static int mfma40_ring(const StepParams<float> &sp)
+{
+    const DeviceFacts &f = device_facts();
+    if (!f.sticky || f.ring40_force < 0) {
+        const char *force = getenv("MPC_MFMA40_RING");
+        const int v = (force && (force[0] == '2' || force[0] == '3')) ? force[0] - '0' : 0;
+        if (!f.sticky) { if (v) return v; }
+        else const_cast<DeviceFacts &>(f).ring40_force = v;
+    }
+    if (f.sticky && f.ring40_force > 0) return f.ring40_force;
+    return (sp.bound_mode != MPC_BOUND_NONE && sp.B > f.simds) ? 2 : 3;
 }
 
 static int check_problem(const mpc_lqr_problem *p, bool need_cost, bool need_nominal, bool need_F = true)
@@ -225,7 +244,7 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
         if (impl == 5 && !(phase_mask == 3 && mfma40_supported(sp)))
             return fail(MPC_E_DIMS, "MFMA kernel needs fp32, n_state = 32, n_ctrl = 8, 16-byte aligned blocks, no simulator");
         if (phase_mask == 3 && (impl == 5 || impl == 0) && mfma40_supported(sp)) {
-            const int rc = launch_step_mfma40(sp, st);
+            const int rc = mfma40_ring(sp) == 2 ? launch_step_mfma40_ring2(sp, st) : launch_step_mfma40(sp, st);
             return rc ? rc : resolve_asymmetric(sp, impl, workspace, needK, st);
         }
     } else if (impl == 5) {

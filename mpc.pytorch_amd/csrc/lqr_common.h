@@ -76,7 +76,8 @@ int launch_kkt_outer(const StepParams<float> &p, const float *dx, const float *d
 
 // register-resident MFMA step for n_state = 32, n_ctrl = 8, f32 (lqr_mfma40.hip)
 bool mfma40_supported(const StepParams<float> &p);
-int launch_step_mfma40(const StepParams<float> &p, hipStream_t st);
+int launch_step_mfma40(const StepParams<float> &p, hipStream_t st);            // three-slot sweep ring (36 KiB per wave: four per CU)
+int launch_step_mfma40_ring2(const StepParams<float> &p, hipStream_t st);      // two slots (26 KiB: six per CU), see capi.hip
 // the KKT backward of that shape: the nested step with both costates riding along + kkt_outer_kernel (lqr_mfma40.hip, -DMPC_MFMA40_KKT)
 bool kkt_fused_mfma40_supported(const StepParams<float> &p, const float *dl_dx, const float *dl_du, const float *dC,
                                 const float *dF, const float *ws);

@@ -1,6 +1,6 @@
 // lqr_mfma40.hip -- gfx950 binding of the register-resident MFMA sweep for n_state = 32, n_ctrl = 8
-// (lqr_mfma40_body.h): one wavefront per problem and per workgroup, a 2-slot LDS-DMA ring (26 KiB),
-// up to 6 wavefronts per CU.
+// (lqr_mfma40_body.h): one wavefront per problem and per workgroup, a 3-slot LDS-DMA sweep ring (36 KiB: 4 wavefronts per
+// CU) or a 2-slot one (26 KiB: 6 per CU).
 #include <string>
 #include "lqr_common.h"
 
@@ -79,14 +79,14 @@ MPC_DEV unsigned load_uniform_u32(const unsigned *g)
 MPC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // an opaque register-to-register identity (see mfma40::pick)
 MPC_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
-// Compiled twice (Makefile): the step kernels on a 26 KiB staging array (six wavefronts per CU), and with -DMPC_MFMA40_KKT
-// the fused KKT backward alone, whose second pass stages V_{t+1} as well (three slots of 10.5 KiB: four wavefronts per CU)
-#ifdef MPC_MFMA40_KKT
-#define MPC_MFMA40_SWEEP_NSTAGE 3
-#define MPC_MFMA40_LDS (3 * 12032 + 512)       // the sweep's three slots + the layout-turn words; pass 2's ring (31.5 KiB) lies inside
-#else
-#define MPC_MFMA40_LDS (2 * 13056 + 512)
+// Compiled three times (Makefile): the step kernels on the three-slot sweep ring (launch_step_mfma40), the same with
+// -DMPC_MFMA40_SWEEP_NSTAGE=2 (launch_step_mfma40_ring2), and with -DMPC_MFMA40_KKT the fused KKT backward (three slots).
+#ifndef MPC_MFMA40_SWEEP_NSTAGE
+#define MPC_MFMA40_SWEEP_NSTAGE 3              // (lqr_mfma40_body.h: why the sweep looks two timesteps ahead)
 #endif
+// the sweep's slots (12032 B each) or the pricing rollout's two (13056 B), + the layout-turn words; the fused backward's
+// second ring (31.5 KiB) lies inside its three sweep slots
+#define MPC_MFMA40_LDS ((MPC_MFMA40_SWEEP_NSTAGE * 12032 > 2 * 13056 ? MPC_MFMA40_SWEEP_NSTAGE * 12032 : 2 * 13056) + 512)
 __shared__ __attribute__((aligned(16))) char g_stage40[MPC_MFMA40_LDS];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -131,6 +131,7 @@ template <int N> MPC_DEV void dma_wait()
 }  // namespace mpclqr
 
 #include "lqr_mfma40_body.h"
+static_assert(mpclqr::mfma40::LDS_TOTAL <= MPC_MFMA40_LDS, "the staging array is smaller than the body's rings");
 
 #ifdef MPC_MFMA40_KKT
 namespace mpclqr {
@@ -203,6 +204,7 @@ template <int MODE> __global__ void __launch_bounds__(64, 1) lqr_step_mfma40_ker
 
 }  // namespace
 
+#if MPC_MFMA40_SWEEP_NSTAGE == 3
 bool mfma40_supported(const StepParams<float> &p)
 {
     auto al = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
@@ -216,7 +218,12 @@ bool mfma40_supported(const StepParams<float> &p)
            (p.bound_mode != MPC_BOUND_TENSOR || ((((uintptr_t)p.lo | (uintptr_t)p.hi) & 3) == 0));
 }
 
-int launch_step_mfma40(const StepParams<float> &p, hipStream_t st)
+#define MPC_MFMA40_LAUNCH launch_step_mfma40
+#else
+bool mfma40_supported(const StepParams<float> &p);
+#define MPC_MFMA40_LAUNCH launch_step_mfma40_ring2
+#endif
+int MPC_MFMA40_LAUNCH(const StepParams<float> &p, hipStream_t st)
 {
     if (!mfma40_supported(p)) { set_last_error("mfma40: needs fp32, n_state = 32, n_ctrl = 8, 16-byte aligned blocks"); return MPC_E_DIMS; }
     if (!p.K || !p.k || (!p.sweep_only && (!p.new_x || !p.new_u))) { set_last_error("mfma40: K / k / new_x / new_u missing"); return MPC_E_NULL; }

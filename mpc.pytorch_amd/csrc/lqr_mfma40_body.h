@@ -64,10 +64,12 @@ constexpr int NSTAGE = 2;      // slots of the pricing rollout's LDS-DMA ring: o
 // Slots of the SWEEP's ring.  Two (the DMA one timestep = 3.6 us ahead) is enough while the address translations of the
 // blocks are cached; behind a kernel that has walked other memory (its own outer-product kernel in the fused backward: 810 MB
 // of gradients) every stage starts with TLB misses and a sweep that is one step ahead waits them out, +2.3 us per timestep
-// (tools/k40_tlb_probe.py: a 16 us kernel touching one byte per page of 800 MB slows the next launch by 145 us).  The fused
-// backward is therefore compiled with three slots (two timesteps ahead).
+// (tools/k40_tlb_probe.py: a 16 us kernel touching one byte per page of 800 MB slows the next launch by 145 us: the
+// step at B = 1024 465 us against 342 on three slots, box-constrained 1010 against 658; with warm translations the two rings
+// are level).  Three slots (two timesteps ahead, 36 KiB per wave) is therefore the default; the two-slot compilation
+// (26 KiB: six wavefronts per CU instead of four) serves the box-constrained step of batches beyond one wavefront per SIMD.
 #ifndef MPC_MFMA40_SWEEP_NSTAGE
-#define MPC_MFMA40_SWEEP_NSTAGE 2
+#define MPC_MFMA40_SWEEP_NSTAGE 3
 #endif
 constexpr int SNSTAGE = MPC_MFMA40_SWEEP_NSTAGE;
 constexpr unsigned OFF_C = 0, OFF_F = 6400, OFF_R = 11520, STAGE_BYTES = 12032;   // (the record: 320 B, 448 B in the fused backward)

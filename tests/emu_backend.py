@@ -20,7 +20,7 @@ _LIB = None
 
 def build(ring2=False):
     """ring2: the 12/4 kernel with its 2-slot sweep ring (-DMPC_DPP16_NSTAGE=2, the second compilation of lqr_dpp16.hip) and
-    the 32/8 kernel with its 3-slot sweep ring (-DMPC_MFMA40_SWEEP_NSTAGE=3, the fused-backward compilation of lqr_mfma40.hip)."""
+    the 32/8 kernel with its 2-slot sweep ring (-DMPC_MFMA40_SWEEP_NSTAGE=2, the second compilation of lqr_mfma40.hip's step kernels)."""
     so = os.path.join(_EMU, "libemu_mfma16_ring2.so" if ring2 else "libemu_mfma16.so")
     src = os.path.join(_EMU, "emu_mfma16.cpp")
     csrc = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc")
@@ -32,7 +32,7 @@ def build(ring2=False):
             cxx = shutil.which("clang++")
         assert cxx, "the emulator needs clang++ (ext_vector_type)"
         subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
-                              + (["-DMPC_DPP16_NSTAGE=2", "-DMPC_KKT16_NSTAGE=2", "-DMPC_MFMA40_SWEEP_NSTAGE=3"] if ring2 else []) + ["-o", so, src])
+                              + (["-DMPC_DPP16_NSTAGE=2", "-DMPC_KKT16_NSTAGE=2", "-DMPC_MFMA40_SWEEP_NSTAGE=2"] if ring2 else []) + ["-o", so, src])
     return so
 
 
@@ -127,9 +127,12 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
         e.linearize = int(len(env) > 4 and bool(env[4]))
         keep.append(e)
         o.true_dynamics = ctypes.pointer(e)
-    if kernel in ("mfma40_sweep", "mfma40"):
-        lib().emu_mfma40_full(int(kernel == "mfma40"))
-        fn = lib().emu_lqr_sweep_mfma40
+    if kernel in ("mfma40_sweep", "mfma40", "mfma40_ring2"):
+        # ("mfma40_ring2": the step kernels' second compilation, two sweep slots instead of three)
+        L40 = lib_ring2() if kernel == "mfma40_ring2" else lib()
+        L40.emu_set_dma_late(int(bool(dma_late)))
+        L40.emu_mfma40_full(int(kernel != "mfma40_sweep"))
+        fn = L40.emu_lqr_sweep_mfma40
         fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs)]
         rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
     elif kernel == "tiny":
@@ -262,7 +265,7 @@ def kkt_fused_mfma40(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_u
     out = dict(dF=np.full((max(T - 1, 0), B, ns, n), np.nan, f32), df=np.full((max(T - 1, 0), B, ns), np.nan, f32) if has_f else None,
                dx_init=np.full((B, ns), np.nan, f32), dx=np.full((T, B, ns), np.nan, f32), du=np.full((T, B, nc), np.nan, f32),
                status=np.zeros(B, np.int32))
-    L = lib_ring2() if sweep3 else lib()          # (the library builds this kernel with the 3-slot sweep ring)
+    L = lib() if sweep3 else lib_ring2()          # (the library builds this kernel with the 3-slot sweep ring)
     L.emu_set_dma_late(int(bool(dma_late)))
     vp = ctypes.c_void_p
     L.emu_kkt_fused_mfma40.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options)] + [vp] * 8

@@ -666,10 +666,11 @@ def test_emulated_mfma40_flags_asymmetric_C_and_drops_dead_controls(emu, name):
     np.testing.assert_allclose(r["new_u"], z["new_u_pp" if name.endswith("f64") else "new_u_ref64"], rtol=2e-3, atol=5e-4)
 
 
+@pytest.mark.parametrize("ring", ["mfma40", "mfma40_ring2"], ids=["ring3", "ring2"])
 @pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
 @pytest.mark.parametrize("vouch", [False, True], ids=["verified", "vouched"])
 @pytest.mark.parametrize("case", ["plain", "T1", "T2", "T5", "no_f", "backtrack", "backtrack_ls3"])
-def test_emulated_mfma40_full_step(emu, case, dma_late, vouch):
+def test_emulated_mfma40_full_step(emu, case, dma_late, vouch, ring):
     """Sweep + rollout of the config-5 kernel: the 16 columns of the rolled-out state are the line-search
     trials (alpha = decay^r); a non-convex stage cost makes trials other than the first win, which are then
     replayed.  Against the oracle."""
@@ -691,7 +692,8 @@ def test_emulated_mfma40_full_step(emu, case, dma_late, vouch):
             break
     else:
         assert False, "no seed made the line search backtrack"
-    r = emu.lqr_step(kernel="mfma40", dma_late=dma_late, nominal_on_dynamics=vouch, **kw, **opt)
+    # ring3 / ring2: the two compilations of the step kernels (three sweep slots, the DMA two timesteps ahead / two slots)
+    r = emu.lqr_step(kernel=ring, dma_late=dma_late, nominal_on_dynamics=vouch, **kw, **opt)
     np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
     # the non-convex problems are ill-conditioned on purpose (gains of order 10^2): float32 keeps ~3 digits there
     wide = 20.0 if case.startswith("backtrack") else 1.0
@@ -703,9 +705,10 @@ def test_emulated_mfma40_full_step(emu, case, dma_late, vouch):
     np.testing.assert_allclose(r["alpha_du_norm"], o["alpha_du_norm"], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("ring", ["mfma40", "mfma40_ring2"], ids=["ring3", "ring2"])
 @pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
 @pytest.mark.parametrize("case", ["bounded", "tensor_bounds", "delta_u", "masked"])
-def test_emulated_mfma40_constrained_modes(emu, case, dma_late):
+def test_emulated_mfma40_constrained_modes(emu, case, dma_late, ring):
     """Box constraints (pnqp in 8 unknowns on wave-uniform values, K'M terms of the value update on MFMA,
     clamped rollout) and the u_zero_I mask of the KKT backward's nested solve, against the oracle."""
     from oracle import lqr_oracle as O
@@ -724,7 +727,7 @@ def test_emulated_mfma40_constrained_modes(emu, case, dma_late):
     else:
         opt.update(u_lower=-0.5, u_upper=0.5)
     o = O.lqr_step(lockstep=False, return_gains=True, **kw, **opt)
-    r = emu.lqr_step(kernel="mfma40", dma_late=dma_late, **kw, **opt)
+    r = emu.lqr_step(kernel=ring, dma_late=dma_late, **kw, **opt)
     wide = 1.0      # (a non-convex box QP has no unique answer to compare: the unconstrained backtrack case above
     #                  covers the replay of the line search)
     np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)

@@ -275,13 +275,17 @@ def test_simulator_step_full_batch_vs_oracle(be, kind, B, T, inline_linearize):
 # ------------------------------------------------------------------------------------------------
 # (d) config 5 with > 1 wave per SIMD and a partial last wave
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ring", ["3", "2"], ids=["ring3", "ring2"])
 @pytest.mark.parametrize("mode", ["unbounded", "unbounded_vouched", "bounded", "masked"])
-def test_config5_full_waves_vs_oracle(be, mode):
+def test_config5_full_waves_vs_oracle(be, mode, ring, monkeypatch):
     """ns=32 nc=8 T=64 (BASELINE configs[4]) at B = 1030 -- one wavefront per problem: 1030 waves > 1024 SIMDs,
     so some SIMDs hold two waves and the grid has a ragged tail -- on the register-resident MFMA kernel
     (impl 5), against the float64 oracle: unconstrained, box-constrained (8-unknown pnqp), u_zero_I-masked;
     "vouched" = MPC_OPT_NOMINAL_ON_DYNAMICS, the unconstrained step's lean rollout (line search decided from the
-    sweep's predicted cost change, one pass without C)."""
+    sweep's predicted cost change, one pass without C).  ring: the step kernels are compiled on a three-slot sweep ring (the DMA
+    two timesteps ahead) and on a two-slot one; capi.hip picks by mode and batch, MPC_MFMA40_RING forces -- both are held to the
+    oracle here whatever it would pick."""
+    monkeypatch.setenv("MPC_MFMA40_RING", ring)
     import bench
     from mpc import util
     from mpc._native import StepOptions, IMPL_MFMA40

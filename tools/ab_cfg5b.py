@@ -19,6 +19,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     gx, gu = torch.randn_like(r["new_x"]), torch.randn_like(r["new_u"])
     nx, nu = r["new_x"].clone(), r["new_u"].clone()
     out = {}
+    # cold translations: a 16 us kernel that touches one byte in every 4 KiB page of 800 MB in front of every launch
+    big = torch.zeros(800 * 1024 * 1024, dtype=torch.uint8, device="cuda:0")
+    view = big[::4096]
+    _, t0, _ = bench.timed(lambda: view.sum(), 30, 8)
+    for name, fn in (("step_cold_tlb", lambda: (view.sum(), be.lqr_step(*a, o))[1]), ("step_bounded_cold_tlb", lambda: (view.sum(), be.lqr_step(*a, ob))[1])):
+        _, ms, _ = bench.timed(fn, 30, 8)
+        out[name] = [round((ms - t0) * 1e3, 1)]
     for rep in range(2):
         for name, fn in (("step", lambda: be.lqr_step(*a, o)), ("sweep", lambda: be.lqr_sweep(*a[:4], a[5], a[6], o)),
                          ("step_bounded", lambda: be.lqr_step(*a, ob)),
