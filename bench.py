@@ -283,6 +283,19 @@ def extra_rows(be, dev, steps):
             pb = dict(p)
             rowb, _ = step_row(pb, StepOptions(u_lower=-1.0, u_upper=1.0, c_symmetric=True), 32, 8, 64, B5)
             rows["cfg5_step_bounded_B1024"] = rowb
+            # The rows above are back-to-back launches: address translations of C and F stay cached.  An application runs other
+            # kernels between two steps; this row puts a 16 us kernel that reads one byte in every 4 KiB page of 800 MB in front
+            # of every launch and subtracts it (the 32/8 sweep is latency-bound: what it must not do is wait for TLB misses).
+            big = torch.zeros(800 * 1024 * 1024, dtype=torch.uint8, device=dev)
+            view = big[::4096]
+            _, t_touch, _ = timed(lambda: view.sum(), k, 10)
+            plan5 = be.plan_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"],
+                                 StepOptions(nominal_on_dynamics=True, c_symmetric=True))
+            _, t_cold, _ = timed(lambda: (view.sum(), plan5())[1], k, 10)
+            rows["cfg5_step_B1024_cold_translations"] = dict(
+                ms=t_cold - t_touch, toucher_ms=t_touch, roofline=hbm_roofline(algorithmic_bytes_per_problem(32, 8, 64) * B5, t_cold - t_touch),
+                workload="config 5 step as cfg5_step_B1024, every launch behind a kernel that walks 800 MB of other pages")
+            del big, view, plan5
         del p, r
     torch.cuda.empty_cache()
     # ---- configs 2 / 3: the shipped simulators, whole 10-iteration iLQR solves (L2-resident: latency-bound) ----

@@ -23,7 +23,7 @@ static int fail(int code, const char *msg)
 struct DeviceFacts {
     int ring_force;      // 0 = pick by mode and batch, 2 / 4 = MPC_DPP16_RING
     int simds;
-    int ring40_force;    // MPC_MFMA40_RING (-1: not read yet)
+    int ring40_force;    // 0 = pick by mode and batch, 2 / 3 = MPC_MFMA40_RING
     bool sticky;         // false with MPC_DPP16_RING_DYNAMIC set: the switch is re-read at every launch (the tests flip it)
 };
 static const DeviceFacts &device_facts()
@@ -31,7 +31,7 @@ static const DeviceFacts &device_facts()
     static DeviceFacts f = [] {
         DeviceFacts d;
         d.ring_force = 0;
-        d.ring40_force = -1;
+        d.ring40_force = 0;
         d.simds = 1024;
         hipDeviceProp_t prop;
         int dev = 0;
@@ -39,6 +39,8 @@ static const DeviceFacts &device_facts()
             d.simds = prop.multiProcessorCount * 4;
         const char *force = getenv("MPC_DPP16_RING");            // "2" / "4": A/B switch, read at load
         if (force && (force[0] == '2' || force[0] == '4')) d.ring_force = force[0] - '0';
+        const char *force40 = getenv("MPC_MFMA40_RING");         // "2" / "3": the 32/8 kernel's sweep ring, read at load
+        if (force40 && (force40[0] == '2' || force40[0] == '3')) d.ring40_force = force40[0] - '0';
         d.sticky = getenv("MPC_DPP16_RING_DYNAMIC") == nullptr;
         return d;
     }();
@@ -60,13 +62,12 @@ static int dpp16_ring_force()
 static int mfma40_ring(const StepParams<float> &sp)
 {
     const DeviceFacts &f = device_facts();
-    if (!f.sticky || f.ring40_force < 0) {
-        const char *force = getenv("MPC_MFMA40_RING");
-        const int v = (force && (force[0] == '2' || force[0] == '3')) ? force[0] - '0' : 0;
-        if (!f.sticky) { if (v) return v; }
-        else const_cast<DeviceFacts &>(f).ring40_force = v;
+    int force = f.ring40_force;
+    if (!f.sticky) {                       // MPC_DPP16_RING_DYNAMIC=1 (the test suite): the switch follows the environment
+        const char *e = getenv("MPC_MFMA40_RING");
+        force = (e && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 0;
     }
-    if (f.sticky && f.ring40_force > 0) return f.ring40_force;
+    if (force) return force;
     return (sp.bound_mode != MPC_BOUND_NONE && sp.B > f.simds) ? 2 : 3;
 }
 
