@@ -181,26 +181,50 @@ __global__ void __launch_bounds__(64) kkt_outer_kernel(StepParams<float> p, cons
     }
 }
 
-// util.get_traj (LinDx, mpc/util.py:114-126) for 16 < n <= 64: one wavefront per problem, F_t by LDS-DMA one
-// step ahead, lane i sums row i with tau[j] as readlane scalars.
+// util.get_traj (LinDx, mpc/util.py:114-126) for 16 < n <= 64: one wavefront per problem, lane i sums row i with tau[j] as
+// readlane scalars.  F_t and the step's small vector (lane < ns: f_t[lane], else u_t[lane - ns]: one 4-byte LDS-DMA per lane)
+// arrive NSLOT - 1 timesteps ahead with counted waits (round 3: one step ahead behind `vmcnt(0)`, and u_t / f_t by vector
+// loads whose results the compiler drained the DMA queue for, left the wavefront waiting out a memory round trip per timestep:
+// 118 us for the 335 MB of config 5's F).
+template <int NSLOT>
 __global__ void __launch_bounds__(64) traj_wave_kernel(StepParams<float> p, float *x)
 {
     extern __shared__ __attribute__((aligned(16))) char traj_lds[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T, B = p.B;
-    const int fbytes = ns * n * 4;
+    const int fbytes = ns * n * 4, slot_bytes = fbytes + 256;
+    const int nd = (fbytes + 1023) / 1024 + 1;                   // DMA instructions per stage
     const bool st = lane < ns;
     float xi = st ? p.x_init[(long)b * ns + lane] : 0.f;
     if (st) x[(long)b * ns + lane] = xi;
-    if (T > 1) dma_block(p.F + (long)b * p.F_sb, traj_lds, fbytes, lane);
+    if (T < 2) return;
+    // the record's source: f_t[lane] for the state lanes (x_init again when there is no f: never used), u_t[lane - ns] above
+    const float *rsrc;
+    long rstep;
+    if (st) {
+        rsrc = p.f ? p.f + (long)b * p.f_sb + lane : p.x_init + (long)b * ns + lane;
+        rstep = p.f ? p.f_st : 0;
+    } else {
+        rsrc = p.cur_u + (long)b * nc + (lane < n ? lane - ns : 0);
+        rstep = (long)B * nc;
+    }
+    auto issue = [&](int t, int slot) {
+        t = t < T - 1 ? t : T - 2;                               // past the end: the last stage again, the count per stage stays fixed
+        char *base = traj_lds + slot * slot_bytes;
+        dma_block(p.F + (long)t * p.F_st + (long)b * p.F_sb, base, fbytes, lane);
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(rsrc + (long)t * rstep), (lds_void_t *)(base + fbytes), 4, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i) issue(i, i);
     int slot = 0;
     for (int t = 0; t < T - 1; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (t + 1 < T - 1) dma_block(p.F + (long)(t + 1) * p.F_st + (long)b * p.F_sb, traj_lds + (slot ^ 1) * fbytes, fbytes, lane);
-        const float ui = (lane >= ns && lane < n) ? p.cur_u[((long)t * B + b) * nc + (lane - ns)] : 0.f;
-        const float tau = st ? xi : ui;
-        float acc = (p.f && st) ? p.f[(long)t * p.f_st + (long)b * p.f_sb + lane] : 0.f;
-        const float *Fl = (const float *)(traj_lds + slot * fbytes) + (st ? lane : 0) * n;
+        wait_newer((NSLOT - 2) * nd);
+        const float *Fl = (const float *)(traj_lds + slot * slot_bytes) + (st ? lane : 0) * n;
+        const float rec = ((const float *)(traj_lds + slot * slot_bytes + fbytes))[lane];
+        const float tau = st ? xi : (lane < n ? rec : 0.f);
+        float acc = (p.f && st) ? rec : 0.f;
+        // (the slot the previous timestep worked on is free: its reads fed that timestep's sums)
+        issue(t + NSLOT - 1, (slot + NSLOT - 1) % NSLOT);
         for (int j = 0; j < n; j += 4) {
             const f32x4 row = *(const f32x4 *)(Fl + j);
 #pragma unroll
@@ -208,7 +232,7 @@ __global__ void __launch_bounds__(64) traj_wave_kernel(StepParams<float> p, floa
         }
         xi = acc;
         if (st) x[((long)(t + 1) * B + b) * ns + lane] = xi;
-        slot ^= 1;
+        slot = (slot + 1) % NSLOT;
     }
 }
 
@@ -224,7 +248,21 @@ bool traj_wave_supported(const StepParams<float> &p)
 int launch_traj_wave(const StepParams<float> &p, float *x, hipStream_t st)
 {
     const int n = p.ns + p.nc;
-    hipLaunchKernelGGL(traj_wave_kernel, dim3(p.B), dim3(64), 2 * (size_t)p.ns * n * 4, st, p, x);
+    // four slots (the DMA three timesteps ahead) while the whole batch is resident with them (256 CUs x 160 KiB), else two: a
+    // batch that runs in rounds anyway hides the latency with more wavefronts per CU (config 5: 81 against 110 us at B = 1024,
+    // 557 against 519 at B = 8192)
+    const size_t slot = (size_t)p.ns * n * 4 + 256;
+    const bool deep = (size_t)((p.B + 255) / 256) * 4 * slot <= 160 * 1024;
+    const size_t lds = (deep ? 4 : 2) * slot;
+    if (deep) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&traj_wave_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(traj_wave_kernel<4>, dim3(p.B), dim3(64), lds, st, p, x);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&traj_wave_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(traj_wave_kernel<2>, dim3(p.B), dim3(64), lds, st, p, x);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_last_error((std::string("traj_wave_kernel: ") + hipGetErrorString(e)).c_str());
