@@ -307,7 +307,9 @@ def extra_rows(be, dev, steps):
                        max_linesearch_iter=dxm.max_linesearch_iter, grad_method=mpc.GradMethods.AUTO_DIFF,
                        eps=1e-12, backprop=False, not_improved_lim=10 ** 6)
         cost = QuadCost(Q, pp)
-        wall, ms, out = timed(lambda: ctrl(x0, cost, dxm), 5, 2)
+        # (20 solves behind 6 untimed ones: the first solves after the large blocks of the rows above went back to the driver
+        # can stall for milliseconds each -- tools/cfg3_repeat.py --pre --, and 5 timed solves made that a 0.7 / 1.8 ms lottery)
+        wall, ms, out = timed(lambda: ctrl(x0, cost, dxm), 20, 6)
         rows["cfg%d_ilqr_%s_10iter" % (2 if kind == "pendulum" else 3, kind)] = dict(
             ms=ms, wall_ms=wall, lqr_iter=10, B=B, T=T, ms_per_iteration=ms / 10,
             problem_steps_per_s=B * T * 10 / (ms * 1e-3), mean_cost=float(out[2].mean()),
