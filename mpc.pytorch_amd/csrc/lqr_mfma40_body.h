@@ -646,30 +646,31 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             crow[J] = j < N ? (KKT ? -c : c) : 0.f;
         }
         // c_back = C tau + c (mpc/lqr_step.py:289-295) in row layout, and the nominal cost (:169)
-        float qrow[3];
-        float lrow[2] = {0.f, 0.f}, grow[2] = {0.f, 0.f};
+        // Sums over the four lane groups are deferred: every vector below is kept as this lane group's PARTIAL sum (qpart,
+        // lpart, gpart: the products of its rows 16I + 4q + v) and reduced once, where its value is first needed -- q_u in
+        // front of the control block, q_x not before v = q_x + Qxu k (one reduction for c_back, F'v and Qxu k together;
+        // round 2 reduced each of them: eight two-swap butterflies per timestep, now three).
+        float qpart[3];
+        float lpart[2] = {0.f, 0.f}, gpart[2] = {0.f, 0.f};
 #pragma unroll
         for (int J = 0; J < 3; ++J) {
-            if (KKT && J == 2) { qrow[J] = crow[J]; continue; }
+            qpart[J] = 0.f;
+            if (KKT && J == 2) continue;
             float s = 0.f;
 #pragma unroll
             for (int I = 0; I < 3; ++I)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) s = fmaf(Qd[I][J][v], tcol[I][v], s);
-            const float ct = sum_q(s);                       // (C tau)[16J + r]
-            if (KKT) {
-                // the nested nominal is zero: c_back = c = -r; tau here is tau*, C tau* + c_x starts lambda_t
-                qrow[J] = crow[J];
-                lrow[J] = ct + wv::lds_f32(base + OFF_R + 320 + 4u * (unsigned)(16 * J + L.r));
-            } else {
-                qrow[J] = ct + crow[J];
-            }
+            // (the nested nominal of the fused backward is zero: c_back = c = -r; tau there is tau*, C tau* + c_x starts lambda_t)
+            if (KKT) lpart[J] = s;
+            else qpart[J] = s;                               // this lane group's share of (C tau)[16J + r]
         }
         if (!KKT) {
+            // nominal cost (:169): tau'(C tau / 2 + c) -- with the unreduced shares the sum runs over all 64 lanes after the loop
             float s = 0.f;
 #pragma unroll
-            for (int J = 0; J < 3; ++J) s = fmaf(trow[J], fmaf(0.5f, qrow[J] - crow[J], crow[J]), s);
-            old_cost += (double)s;                           // this lane's entries; summed over the row after the loop
+            for (int J = 0; J < 3; ++J) s = fmaf(trow[J], fmaf(0.5f, qpart[J], L.q == 0 ? crow[J] : 0.f), s);
+            old_cost += (double)s;
         }
 
         if (t < T - 1) {
@@ -719,18 +720,18 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             // ---- q = c_back + F'v
 #pragma unroll
             for (int J = 0; J < 3; ++J) {
-                float s = 0.f;
+                float s = qpart[J];
 #pragma unroll
                 for (int Ip = 0; Ip < 2; ++Ip)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) s = fmaf(FB[4 * Ip + v][J], vcol[Ip][v], s);
-                qrow[J] += sum_q(s);
+                qpart[J] = s;
             }
             if (KKT) {
                 // lambda_t += F_x' lambda_{t+1}, g_t = F_x' g_{t+1} (- Qxu k_t below); lambda_{t+1} into dF_t's block
 #pragma unroll
                 for (int J = 0; J < 2; ++J) {
-                    float sl = 0.f, sg = 0.f;
+                    float sl = lpart[J], sg = 0.f;
 #pragma unroll
                     for (int Ip = 0; Ip < 2; ++Ip)
 #pragma unroll
@@ -738,8 +739,8 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                             sl = fmaf(FB[4 * Ip + v][J], lcol[Ip][v], sl);
                             sg = fmaf(FB[4 * Ip + v][J], gcol[Ip][v], sg);
                         }
-                    lrow[J] += sum_q(sl);
-                    grow[J] = sum_q(sg);
+                    lpart[J] = sl;
+                    gpart[J] = sg;
                 }
                 if (L.r == 0) {
 #pragma unroll
@@ -759,9 +760,11 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         Ldl8V facv;
         float qu[8], kk[8];
         bool fr[8];
+        // q_u (row layout): the one vector needed before the gains; q_x stays in shares until v takes it
+        const float qrow2 = crow[2] + sum_q(qpart[2]);
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-            qu[a] = wv::readlane(qrow[2], a);
+            qu[a] = wv::readlane(qrow2, a);
             fr[a] = true;
         }
         if (MODE == 0) {
@@ -823,7 +826,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                 lbv = r8 ? fmaxf(lbv, -p.delta_u) : 0.f;
                 ubv = r8 ? fminf(ubv, p.delta_u) : 0.f;
             }
-            const float qv = r8 ? qrow[2] : 0.f;
+            const float qv = r8 ? qrow2 : 0.f;
             float xv = kprev_v;
             if (!warm) {                                 // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
                 float colc[8], y[8];
@@ -950,7 +953,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         float mk[8];
 #pragma unroll
         for (int a = 0; a < 8; ++a) mk[a] = MODE != 0 ? qu[a] + sym8_row(S, a, kk) : 0.f;
-        float vrow[2];
+        float vrow[2], lrow[2] = {0.f, 0.f}, grow[2] = {0.f, 0.f};
 #pragma unroll
         for (int J = 0; J < 2; ++J) {
             float s = 0.f;
@@ -963,8 +966,12 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                     s = fmaf(Kd[J][v], ma, s);
                 }
             }
-            vrow[J] = qrow[J] + sum_q(s);
-            if (KKT) grow[J] += qrow[J] - vrow[J];          // - Qxu k_t: what v just took on
+            // v = q_x + Qxu k (+ K'(qu + Quu k)): c_back's, F'v's and this step's shares reduced together
+            vrow[J] = crow[J] + sum_q(qpart[J] + s);
+            if (KKT) {
+                lrow[J] = sum_q(lpart[J]) + wv::lds_f32(base + OFF_R + 320 + 4u * (unsigned)(16 * J + L.r));
+                grow[J] = sum_q(gpart[J] - s);              // g_t = F_x' g_{t+1} - Qxu k_t: what v just took on
+            }
         }
         // row -> column layout through the scratch words
         wv::lds_sync();
@@ -997,9 +1004,9 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         }
         slot = (slot + 1) % SNSTAGE;
     }
-    // the nominal cost: the sixteen lanes of a row hold disjoint entries' partial sums (one butterfly per sweep, not per timestep)
+    // the nominal cost: every lane holds the partial sum of its entries and its lane group's rows (one butterfly per sweep)
 #pragma unroll
-    for (int sh = 1; sh < (KKT ? 1 : 16); sh <<= 1) {
+    for (int sh = 1; sh < (KKT ? 1 : 64); sh <<= 1) {
         // (both partners add the same two rounded numbers: every lane ends with the same bits)
         const float hi = (float)old_cost, lo = (float)(old_cost - (double)hi);
         old_cost = ((double)hi + (double)lo) + ((double)wv::shfl_xor(hi, sh) + (double)wv::shfl_xor(lo, sh));
