@@ -262,7 +262,7 @@ def extra_rows(be, dev, steps):
         ctrl = mpc.MPC(NS, NC, T_H, u_lower=-1.0 if bounded else None, u_upper=1.0 if bounded else None,
                        lqr_iter=5, verbose=-1, exit_unconverged=False, detach_unconverged=False, backprop=False)
         cost, dx = QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"])
-        wall, ms, _ = timed(lambda: ctrl(p["x_init"], cost, dx), 5, 2)
+        wall, ms, _ = timed(lambda: ctrl(p["x_init"], cost, dx), 12, 4)
         rows["mpc_forward_5iter_" + key] = dict(ms=ms, wall_ms=wall, lqr_iter=5,
                                                 note="whole MPC.forward: initial trajectory kernel + 5 x (step + select_best)")
         del p, r, ctrl, cost, dx

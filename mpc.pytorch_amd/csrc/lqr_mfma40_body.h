@@ -1608,7 +1608,8 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
         }
         const unsigned qo = 16u * (unsigned)(L.q < 2 ? L.q : 0);
         const f32x4 kb = wv::lds_f32x4(rec + 448 + qo);
-        // F's A operands and V_{t+1}'s, before the slot two steps on is overwritten ... (it is a different slot: t + 2)
+        // every operand of this timestep out of its stage first (F's rows as A operands, V_{t+1}'s tiles, v and g), then the
+        // matrix-core blocks undivided
         float fa[2][12];
 #pragma unroll
         for (int Im = 0; Im < 2; ++Im) {
