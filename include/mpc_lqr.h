@@ -44,8 +44,8 @@ enum {
 enum {
     MPC_ST_PNQP_UNCONVERGED = 1,   /* "pnqp warning: Did not converge" (mpc/pnqp.py:81) at some timestep   */
     MPC_ST_NONFINITE = 2,          /* the returned cost is NaN / inf                                        */
-    MPC_ST_NOMINAL_OFF_DYNAMICS = 4,/* informational (DPP kernel): current_x is not the rollout of current_u,
-                                      the trajectory cost was evaluated from a second pass over C            */
+    MPC_ST_NOMINAL_OFF_DYNAMICS = 4,/* informational (the 12/4 and 32/8 kernels): current_x is not the rollout of current_u
+                                      from x_init, the trajectory cost was evaluated from a second pass over C */
     MPC_ST_C_ASYMMETRIC = 8,       /* some C_t of this problem is not symmetric (max |C - C'| > 1e-5 max |C|).  The
                                       reference uses C as given (mpc/lqr_step.py:68 Q = C + F'VF, :294 C tau); the fused
                                       kernels (impl 2..5) read it through its symmetry.  impl = 0 re-solves exactly these
@@ -102,7 +102,9 @@ enum {
                                         The 4-problems-per-wave kernel prices its rollout by an identity of the sweep's
                                         value function that holds exactly then; without the flag it verifies the premise
                                         at every timestep (and prices from C itself where it fails, MPC_ST_NOMINAL_OFF_
-                                        DYNAMICS), with it the verification is skipped.  Other kernels ignore it. */,
+                                        DYNAMICS), with it the verification is skipped.  The 32/8 kernel decides its line
+                                        search from the sweep under the same premise, which its sweep verifies likewise
+                                        when the flag is absent.  Other kernels ignore it. */,
     MPC_OPT_C_SYMMETRIC = 4,         /* the caller GUARANTEES C_t = C_t' for every problem and timestep (bit-exact or to
                                         rounding): the fused kernels skip their symmetry test and mpc_lqr_step (impl 0) its
                                         second, gated launch of the generic kernels.  mpc.MPC makes the promise from its

@@ -109,11 +109,13 @@ struct Stream {
     const char *c_ptr, *f_ptr, *r_ptr;      // this lane's 16-byte column of each block, timestep 0
     long c_step, f_step, r_step;            // bytes per timestep
     bool r_active;
+    bool r_is_f;                            // this lane's record granule is f_t (T-1 entries: indexed like F)
 };
 
-MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L, const KktArgs40 *kk = nullptr)
+MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L, const KktArgs40 *kk = nullptr, bool with_f = false)
 {
     const long b = L.b;
+    d.r_is_f = false;
     d.c_ptr = (const char *)(p.C + b * p.C_sb) + 16 * L.lane;
     d.c_step = p.C_st * 4;
     // T = 1 has no dynamics (F may be NULL): its five DMA slots re-read C, so the wait counts stay the same
@@ -130,6 +132,13 @@ MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L, const KktArgs40 *
     } else {
         d.r_ptr = (const char *)(p.cur_u + b * NC) + 16 * ((L.lane < 20 ? L.lane : 18) - 18);
         d.r_step = (long)p.B * NC * 4;
+    }
+    if (with_f && L.lane >= 20 && L.lane < 28) {
+        // the unvouched step verifies the nominal while it sweeps (sweep_wave): lanes 20..27 carry f_t
+        d.r_active = true;
+        d.r_is_f = true;
+        d.r_ptr = (const char *)(p.f + b * p.f_sb) + 16 * (L.lane - 20);
+        d.r_step = p.f_st * 4;
     }
     if (kk) {
         // the fused backward: lanes 0..7 dl_dx_t, 8..9 dl_du_t (negated where they are read), 10..19 tau*_t as above,
@@ -187,7 +196,7 @@ MPC_DEV void stage_issue(const P &p, const Stream &d, const Lane &L, int t, int 
     dma_kib<6>(d.c_ptr + tl * d.c_step, base + OFF_C);
     wv::dma16_at_if<2048>(L.lane < 16, d.c_ptr + tl * d.c_step + 4096, base + OFF_C + 4096);
     dma_kib<5>(d.f_ptr + (p.T > 1 ? tf * d.f_step : 0), base + OFF_F);
-    wv::dma16_if(d.r_active, d.r_ptr + tl * d.r_step, base + OFF_R);
+    wv::dma16_if(d.r_active, d.r_ptr + (d.r_is_f ? tf : tl) * d.r_step, base + OFF_R);
 }
 
 // butterfly sums: across the four lane groups (lanes differing in bits 4,5), across the 16 lanes of a group
@@ -553,7 +562,7 @@ MPC_DEV void kkt_store_vvg(const KktArgs40 &kx, long tb, const Lane &L, const wv
 // first 32 words of the dF_t block.  v_0, g_0 (row layout) come back through v0g0 for dx_init.
 template <int MODE, bool KKT = false>
 MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out = nullptr, const KktArgs40 *kx = nullptr,
-                          float *v0g0 = nullptr)
+                          float *v0g0 = nullptr, bool *on_dynamics_out = nullptr)
 {
     Lane L;
     L.lane = wv::lane();
@@ -562,8 +571,20 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
     L.b = wv::problem();
     if (L.b >= p.B) return 0.0;
     const int T = p.T;
+    // An unconstrained step whose caller does not vouch for the nominal (a bare LQRStep call) checks it here: x_0 = x_init and
+    // x_{t+1} = F_t tau_t + f_t to 1e-5 (1 + |x|), the 4-problems-per-wave kernel's test.  F_t and tau_t are in registers for
+    // the sweep anyway: 24 multiply-adds and eight 16-lane sums per timestep.  A nominal that passes takes the lean rollout
+    // (the line search decided from the sweep, no pricing pass over C): the bare call costs 7 % more than the vouched one
+    // instead of 33 %; one that fails is priced from C like the reference and reports MPC_ST_NOMINAL_OFF_DYNAMICS.
+    const bool verify = MODE == 0 && !KKT && !p.on_dynamics && on_dynamics_out != nullptr;
+    float offdyn = 0.f;                // largest violation this lane has seen (> 0: off the dynamics)
+    float xnext[2][4];                 // the nominal state of the timestep worked on last (t + 1), column layout
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) xnext[I][v] = 0.f;
     Stream d;
-    stream_init(d, p, L, KKT ? kx : nullptr);
+    stream_init(d, p, L, KKT ? kx : nullptr, verify && p.f != nullptr && T > 1);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 Vd[2][2];                    // V, D layout
     float vcol[2][4];                  // v, column layout: vcol[I][v] = v[16I + 4q + v]
@@ -687,6 +708,24 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                         const float x = wv::lds_f32(base + OFF_F + 4u * (unsigned)(m * N + (in ? col : 0)));
                         FB[4 * Ip + v][J] = in ? x : 0.f;
                     }
+            if (verify) {
+                // F_t tau_t + f_t against x_{t+1}: rows 16I' + 4q + v of F times tau (row layout), summed over the 16 lanes
+#pragma unroll
+                for (int Ip = 0; Ip < 2; ++Ip) {
+                    f32x4 ft = zero4;
+                    if (p.f) ft = wv::lds_f32x4(base + OFF_R + 320 + 4u * (unsigned)(16 * Ip + 4 * L.q));
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int J = 0; J < 3; ++J) s = fmaf(FB[4 * Ip + v][J], trow[J], s);
+                        const float pred = wv::row_sum(s) + ft[v];
+                        float r = fabsf(pred - xnext[Ip][v]) - 1e-5f * (1.f + fabsf(xnext[Ip][v]));
+                        r = (r == r) ? r : 1.f;
+                        offdyn = r > offdyn ? r : offdyn;
+                    }
+                }
+            }
             // ---- Y = V F   (A operand = V by symmetry: register v of tile (I', Im))
             wv::sched_fence();
             // (three tiles at a time, their accumulation chains interleaved: an MFMA that waits for the previous one's
@@ -1002,7 +1041,33 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             kkt_store_vvg(*kx, tb, L, Vd, vcol, gcol);
             if (v0g0) { v0g0[0] = vrow[0]; v0g0[1] = vrow[1]; v0g0[2] = grow[0]; v0g0[3] = grow[1]; }
         }
+        if (verify) {
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) xnext[I][v] = tcol[I][v];
+        }
         slot = (slot + 1) % SNSTAGE;
+    }
+    if (on_dynamics_out) {
+        bool on = p.on_dynamics != 0;
+        if (verify) {
+            // the rollout starts from x_init: the nominal (xnext holds x_0 now) has to as well
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float x0 = p.x_init[(long)L.b * NS + 16 * I + 4 * L.q + v];
+                    float r = fabsf(x0 - xnext[I][v]) - 1e-5f * (1.f + fabsf(x0));
+                    r = (r == r) ? r : 1.f;
+                    offdyn = r > offdyn ? r : offdyn;
+                }
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) offdyn = fmaxf(offdyn, wv::shfl_xor(offdyn, sh));
+            on = !(offdyn > 0.f);
+            if (!on) status |= MPC_ST_NOMINAL_OFF_DYNAMICS;
+        }
+        *on_dynamics_out = on;
     }
     // the nominal cost: every lane holds the partial sum of its entries and its lane group's rows (one butterfly per sweep)
 #pragma unroll
@@ -1730,14 +1795,15 @@ template <int MODE> MPC_DEV void kkt_fused_wave(const P &p, float *K, float *k, 
 template <int MODE> MPC_DEV void step_wave(const P &p, float *K, float *k)
 {
     double w0 = 0.0;
-    const double old_cost = sweep_wave<MODE>(p, K, k, &w0);
+    bool on_dyn = false;
+    const double old_cost = sweep_wave<MODE>(p, K, k, &w0, nullptr, nullptr, &on_dyn);
     if (p.sweep_only) return;           // MPC_OPT_SWEEP_ONLY (the sweep has written K, k, old_costs, qp_iters, status)
     wv::fence_own_stores();
 #ifdef MPC_CFG5_SWEEP_ONLY
     if (old_cost == 1.2345e300) return;    // (diagnostic build: the sweep alone; keeps old_cost / w0 alive)
     if (old_cost != 1.2345e300) { if (wv::lane() == 0 && p.costs) p.costs[wv::problem()] = (float)(old_cost + w0); return; }
 #endif
-    if (MODE == 0 && p.on_dynamics) {
+    if (MODE == 0 && on_dyn) {          // vouched for by the caller, or verified by the sweep
         Lane L;
         L.lane = wv::lane();
         L.r = L.lane & 15;

@@ -705,6 +705,45 @@ def test_emulated_mfma40_full_step(emu, case, dma_late, vouch, ring):
     np.testing.assert_allclose(r["alpha_du_norm"], o["alpha_du_norm"], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("case", ["state", "x_init", "no_f", "nan"])
+def test_emulated_mfma40_verifies_the_nominal_it_is_not_vouched_for(emu, case):
+    """A bare LQRStep call at 32/8 (no MPC_OPT_NOMINAL_ON_DYNAMICS): the sweep checks x_0 = x_init and x_{t+1} = F tau + f while it
+    has F and tau in registers.  Problems whose nominal passes take the lean rollout (line search decided from the sweep);
+    the ones whose current_x is NOT the rollout of current_u -- LQRStep allows it -- are priced from C like the reference and
+    report status bit 4.  Both against the oracle, in one batch."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(17 + len(case))
+    T, B = 6, 4
+    kw = _cfg5_problem(rng, T, B)
+    if case == "no_f":
+        kw["f"] = None
+        kw["cur_x"], _ = O.traj_cost(kw["x_init"], kw["cur_u"], kw["F"], None)
+    off = [0, 2]
+    if case == "x_init":
+        kw["x_init"] = kw["x_init"].copy()
+        kw["x_init"][off] += 0.05 * rng.standard_normal((2, 32))          # the nominal no longer starts where the rollout does
+    elif case == "nan":
+        kw["cur_x"][3, off, 5] = np.nan
+    else:
+        kw["cur_x"][2:, off] += 0.05 * rng.standard_normal((T - 2, 2, 32))
+    r = emu.lqr_step(kernel="mfma40", dma_late=True, **kw)
+    assert ((r["status"] & 4) != 0).tolist() == [b in off for b in range(B)]
+    if case == "nan":
+        return                                              # (a NaN nominal is off the dynamics: flagged, nothing to compare)
+    o = O.lqr_step(lockstep=False, **kw)
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+    np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=2e-3, atol=2e-4 * (1 + np.abs(o["new_x"]).max()))
+    np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=2e-3, atol=2e-4 * (1 + np.abs(o["new_u"]).max()))
+    np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4, atol=1e-3)
+    np.testing.assert_allclose(r["old_costs"], o["old_costs"], rtol=1e-5)
+    # the vouched call on the problems that are on the dynamics gives the same numbers
+    on = [b for b in range(B) if b not in off]
+    sub = {k: (v[:, on] if v is not None and v.ndim > 2 else (v[on] if v is not None else None)) for k, v in kw.items()}
+    rv = emu.lqr_step(kernel="mfma40", dma_late=True, nominal_on_dynamics=True, **sub)
+    np.testing.assert_array_equal(rv["new_u"], r["new_u"][:, on])
+    np.testing.assert_array_equal(rv["costs"], r["costs"][on])
+
+
 @pytest.mark.parametrize("ring", ["mfma40", "mfma40_ring2"], ids=["ring3", "ring2"])
 @pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
 @pytest.mark.parametrize("case", ["bounded", "tensor_bounds", "delta_u", "masked"])

@@ -321,6 +321,29 @@ def test_config5_full_waves_vs_oracle(be, mode, ring, monkeypatch):
         assert float(r["new_u"][mask].abs().max()) == 0.0
 
 
+def test_config5_bare_call_verifies_its_nominal(be):
+    """mpc_lqr_step at 32/8 without MPC_OPT_NOMINAL_ON_DYNAMICS: the sweep verifies the nominal; problems that pass take the lean
+    rollout, every third problem here has a current_x that is NOT the rollout of current_u (LQRStep allows it) and must be
+    priced from C like the reference and flagged (status bit 4).  Both kinds in one launch, against the float64 oracle."""
+    import bench
+    from mpc._native import StepOptions, IMPL_MFMA40
+    from oracle import lqr_oracle as O
+    T, B = 64, full_batch(1030)
+    p = bench.make_problem(32, 8, T, B, torch.float32, DEV, seed=29)
+    off = torch.arange(B, device=DEV) % 3 == 1
+    g = torch.Generator(device=DEV).manual_seed(3)
+    p["cur_x"] = p["cur_x"].clone()
+    p["cur_x"][5:, off] += 0.02 * torch.randn(T - 5, int(off.sum()), 32, generator=g, device=DEV)
+    h = {k: h64(v) for k, v in p.items()}
+    o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], lockstep=False, nthreads=O.max_threads(),
+                   return_gains=True)
+    r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions(), impl=IMPL_MFMA40, want_gains=True)
+    sync()
+    if not DRY:
+        assert torch.equal((r["status"] & 4) != 0, off)
+    strict_step_check("cfg5_B1030_bare_call", r, o, B, rtol=2e-3, atol=5e-4, cost_rtol=5e-4)
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "3launch"])
 @pytest.mark.parametrize("bounded", [False, True])
 def test_config5_kkt_backward_full_waves_vs_oracle(be, bounded, fused):

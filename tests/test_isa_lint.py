@@ -56,8 +56,8 @@ def _metadata(name):
 SGPR_SPILL_LIMITS = {
     "lqr_dpp16": {"kernelILi0E": 200, "kernelILi1E": 440, "kernelILi2E": 550, "kernelILi3E": 160, "kkt_fused": 8},
     "lqr_dpp16_ring2": {"kernelILi0E": 140, "kernelILi1E": 425, "kernelILi2E": 315, "kernelILi3E": 170, "lqr_kkt_dpp16": 0},
-    "lqr_mfma40": {"kernelILi0E": 75, "kernelILi1E": 105, "kernelILi2E": 150},
-    "lqr_mfma40_ring2": {"kernelILi0E": 75, "kernelILi1E": 105, "kernelILi2E": 150},
+    "lqr_mfma40": {"kernelILi0E": 90, "kernelILi1E": 105, "kernelILi2E": 150},
+    "lqr_mfma40_ring2": {"kernelILi0E": 90, "kernelILi1E": 105, "kernelILi2E": 150},
     "lqr_mfma40_kkt": {"kernelILi0E": 55, "kernelILi1E": 115},
     "lqr_wave1": {"kernelILi1E": 20, "kernelILi2E": 12, "kernelILi3E": 28, "kernelILi4E": 20, "kernelILi5E": 20, "kernelILi6E": 20},
     "lqr_mfma16": {"ILb1ELi0E": 35, "ILb1ELi1E": 45, "ILb1ELi2E": 80, "ILb0ELi0E": 215, "ILb0ELi1E": 205, "ILb0ELi2E": 305},
