@@ -812,12 +812,14 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             for (int v = 0; v < 4; ++v) wv::rows01(Qd[2][2][v], col[v], col[4 + v]);
             ldl8v<true>(facv, col);
             if (facv.sing != 0.f) status |= MPC_ST_QUU_SINGULAR;
-        } else {
+        } else if (MODE == 1) {
+            // (the box-constrained mode keeps Quu spread over lanes and in its accumulator tile: pnqp8v, M = Qux + Quu K on MFMA)
 #pragma unroll
             for (int a = 0; a < 8; ++a)
 #pragma unroll
                 for (int c = a; c < 8; ++c) S[a][c] = wv::readlane(Qd[2][2][a & 3], 16 * (a >> 2) + c);
         }
+        float mkv = 0.f;                // box-constrained: m = qu + Quu k spread over lanes (lane a < 8 of every row: m[a])
         if (MODE == 0) {
             // (k comes out of the first of the two K solves below: lane rows 2, 3 carry qu as their right-hand side)
         } else if (MODE == 1) {                          // :99-127: pinned controls drop out of the solve
@@ -885,6 +887,9 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             if (!conv) status |= MPC_ST_PNQP_UNCONVERGED;
             warm = true;
             kprev_v = xv;
+            // m = qu + Quu k: the QP's gradient at its solution, eight DPP multiply-adds on the lane-spread data
+            mkv = qv;
+            Pnqp8vMv<0>::run(col0, xv, mkv);
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
                 kk[a] = wv::readlane(xv, a);
@@ -942,7 +947,17 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                 Kd[0][v] = L.q < 2 ? k0 : 0.f;
                 Kd[1][v] = L.q < 2 ? k1 : 0.f;
             }
-            if (MODE != 0) {
+            if (MODE == 2) {
+                // M = Qux + Quu K on the matrix core: the Quu tile of Q is, by symmetry, its own A operand (rows 8..15 and
+                // columns 8..15 of it are zero), K's tiles are B operands as they stand, the Qux tiles the accumulators --
+                // 8 MFMAs where every lane formed its column of M from 36 readlane copies of Quu (128 multiply-adds)
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+                    Md[J] = Qd[2][J];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) Md[J] = wv::mfma(Qd[2][2][v], Kd[J][v], Md[J]);
+                }
+            } else if (MODE == 1) {
                 // M = Qux + Quu K for this lane's column, the B operand of K'M below
                 float m[8];
 #pragma unroll
@@ -991,7 +1006,18 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         }
         float mk[8];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) mk[a] = MODE != 0 ? qu[a] + sym8_row(S, a, kk) : 0.f;
+        for (int a = 0; a < 8; ++a) mk[a] = MODE == 1 ? qu[a] + sym8_row(S, a, kk) : 0.f;
+        float mq[4] = {0.f, 0.f, 0.f, 0.f};         // m[4q + v] for this lane group (constrained modes)
+        if (MODE == 2) {
+            float lo4[4], hi4[4];
+            lo4[0] = wv::bcast<0>(mkv); lo4[1] = wv::bcast<1>(mkv); lo4[2] = wv::bcast<2>(mkv); lo4[3] = wv::bcast<3>(mkv);
+            hi4[0] = wv::bcast<4>(mkv); hi4[1] = wv::bcast<5>(mkv); hi4[2] = wv::bcast<6>(mkv); hi4[3] = wv::bcast<7>(mkv);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) mq[v] = pick(L.q == 0, lo4[v], pick(L.q == 1, hi4[v], 0.f));
+        } else if (MODE == 1) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) mq[v] = pick(L.q == 0, mk[v], pick(L.q == 1, mk[4 + v], 0.f));
+        }
         float vrow[2], lrow[2] = {0.f, 0.f}, grow[2] = {0.f, 0.f};
 #pragma unroll
         for (int J = 0; J < 2; ++J) {
@@ -1000,10 +1026,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             for (int v = 0; v < 4; ++v) {
                 const float ka = pick(L.q == 0, kk[v], pick(L.q == 1, kk[4 + v], 0.f));
                 s = fmaf(Qd[2][J][v], ka, s);
-                if (MODE != 0) {                         // + K'(qu + Quu k)
-                    const float ma = pick(L.q == 0, mk[v], pick(L.q == 1, mk[4 + v], 0.f));
-                    s = fmaf(Kd[J][v], ma, s);
-                }
+                if (MODE != 0) s = fmaf(Kd[J][v], mq[v], s);      // + K'(qu + Quu k)
             }
             // v = q_x + Qxu k (+ K'(qu + Quu k)): c_back's, F'v's and this step's shares reduced together
             vrow[J] = crow[J] + sum_q(qpart[J] + s);
