@@ -103,6 +103,8 @@ struct KktArgs40 {
 // pass 2's stage: F | K_t | record (v_{t+1}, g_{t+1}, k_t) | V_{t+1}; three slots, the DMA two timesteps ahead
 constexpr unsigned KOFF_F = 0, KOFF_K = 5120, KOFF_R = 6144, KOFF_V = 6656, KSTAGE_BYTES = 10752;
 constexpr int KSLOTS = 3, KDMA_PER_STAGE = 11;                 // 5 (F) + 1 (K) + 1 (record) + 4 (V)
+// the constrained modes' record for the rollout that prices without C (rollout_priced): floats per problem-step
+constexpr int PREC = 328;                                      // M [8][32] | Quu [8][8] | m [8]
 constexpr unsigned KLDS_TOTAL = KSLOTS * KSTAGE_BYTES;         // 31.5 KiB per wave: four waves per CU
 
 struct Stream {
@@ -1018,6 +1020,38 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
 #pragma unroll
             for (int v = 0; v < 4; ++v) mq[v] = pick(L.q == 0, mk[v], pick(L.q == 1, mk[4 + v], 0.f));
         }
+        if (MODE != 0 && !KKT && p.Kk) {
+            // what the priced rollout of the constrained modes needs (rollout_priced): M, Quu, m of this timestep, and the
+            // value function's constant w0 += k'(m + qu) / 2
+            float *rec = p.Kk + tb * (long)PREC;
+            if (L.q < 2) {
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) rec[(4 * L.q + v) * NS + 16 * J + L.r] = Md[J][v];
+                if (L.r < NC) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) rec[256 + (4 * L.q + v) * NC + L.r] = Qd[2][2][v];
+                }
+            }
+            float w;
+            if (MODE == 2) {
+                if (L.lane < NC) rec[320 + L.lane] = mkv;
+                const float kv = kprev_v;                                 // (k spread over lanes: the QP's solution)
+                w = wv::row_sum(kv * (mkv + (L.r < NC ? qrow2 : 0.f)));
+            } else {
+                if (L.lane < NC) {
+                    float mv = mk[0];
+#pragma unroll
+                    for (int a = 1; a < 8; ++a) mv = pick(L.lane == a, mk[a], mv);
+                    rec[320 + L.lane] = mv;
+                }
+                w = 0.f;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) w = fmaf(kk[a], mk[a] + qu[a], w);
+            }
+            w0 += 0.5 * (double)w;
+        }
         float vrow[2], lrow[2] = {0.f, 0.f}, grow[2] = {0.f, 0.f};
 #pragma unroll
         for (int J = 0; J < 2; ++J) {
@@ -1598,6 +1632,237 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// Constrained step (u_zero_I mask / box bounds) on a vouched-for nominal: the line search priced WITHOUT a second pass over C.
+// Around a nominal that obeys the dynamics the cost of ANY rollout is, exactly,
+//     J(tau') = J(nominal) + w0 + sum_t [ e'(m + M dx) + e'Quu e / 2 ],   e = du - K dx - k,
+//     m = qu + Quu k,  M = Qux + Quu K,  w0 = sum_t k'(m + qu) / 2
+// -- V, v of the sweep are the cost-to-go of the affine policy (K, k) whatever pinned or clamped it, and a deviation e from the
+// policy at timestep t changes the cost by the bracket (its effect on later states is in their dx) -- the identity the
+// 4-problems-per-wave kernel prices with (lqr_dpp16_body.h).  Clamps and masks make e != 0, so unlike the unconstrained case
+// the trials have to be rolled out to be priced: all sixteen columns in one pass, stage = F | K | record | M | Quu, m (7.8 KiB
+// against the 13 KiB of the pass that reads C), 12 more MFMAs per timestep than the lean pass (M dx: 8, Quu e: 4) against 36.
+// The sweep leaves (M, Quu, m) in the record p.Kk [T,B,328].  Trial 0 stores as it goes, another winner is replayed (lean).
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned POFF_F = 0, POFF_K = 5120, POFF_R = 6144, POFF_M = 6656, POFF_Q = 7680, PSTAGE_BYTES = 8000;
+constexpr int PSLOTS = LDS_TOTAL / PSTAGE_BYTES >= 4 ? 4 : 3, PDMA_PER_STAGE = 9;   // 5 (F) + K + record + M + (Quu | m)
+static_assert(PSLOTS * PSTAGE_BYTES <= LDS_TOTAL && PSLOTS >= 3, "priced rollout ring exceeds the wave's LDS");
+
+MPC_DEV void pstage_issue(const P &p, const RStream &d, const Lane &L, const char *m_ptr, int t, int slot)
+{
+    const unsigned base = (unsigned)slot * PSTAGE_BYTES;
+    const long tl = t;
+    const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);      // F, f have T-1 entries
+    const long tx = t + 1 < p.T ? t + 1 : t;                         // x_{t+1}
+    dma_kib<5>(d.f_ptr + tf * d.f_step, base + POFF_F);
+    wv::dma16(d.k_ptr + tl * d.k_step, base + POFF_K);
+    wv::dma16_if(d.r_active && L.lane >= 10, d.r_ptr + (d.r_is_f ? tf : (d.r_is_x ? tx : tl)) * d.r_step, base + POFF_R);
+    const char *rec = m_ptr + tl * ((long)p.B * PREC * 4);
+    wv::dma16(rec, base + POFF_M);
+    wv::dma16_if(L.lane < 18, rec + 1024, base + POFF_Q);
+}
+
+template <int MODE>
+MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const float *kin, double old_cost, double w0)
+{
+    const int T = p.T;
+    RStream d;
+    rstream_init(d, p, L, Kin, kin);
+    const char *m_ptr = (const char *)(p.Kk + (long)L.b * PREC) + 16 * L.lane;
+    float alpha = 1.f;
+    for (int i = 0; i < L.r; ++i) alpha *= p.ls_decay;            // column r tries decay^r
+    const bool store = L.r == 0;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 Xd[2], DXd[2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Xd[I][v] = p.x_init[(long)L.b * NS + 16 * I + 4 * L.q + v];
+        DXd[I] = zero4;
+        if (store) wv::store_f32x4(p.new_x + (long)L.b * NS + 16 * I + 4 * L.q, Xd[I]);
+    }
+    float dacc = 0.f;
+    double cacc = 0.0;
+    wv::dma_wait<0>();          // nothing of the sweep may still land in the ring
+#pragma unroll
+    for (int i = 0; i < PSLOTS - 1; ++i) pstage_issue(p, d, L, m_ptr, i < T ? i : T - 1, i);
+    for (int t = 0; t < T; ++t) {
+        wv::dma_wait<(PSLOTS - 2) * PDMA_PER_STAGE>();
+        const unsigned base = (unsigned)(t % PSLOTS) * PSTAGE_BYTES;
+        const long tb = (long)t * p.B + L.b;
+        const unsigned rec = base + POFF_R;
+        // ---- operands of the timestep out of its stage: rows of K and of M (A operands), Quu's columns, m, u, k
+        float a[8], am[8], aq[4];
+        const unsigned krow = 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 4 * L.q);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float x = wv::lds_f32(base + POFF_K + krow + 4u * (unsigned)(16 * (k >> 2) + (k & 3)));
+            const float y = wv::lds_f32(base + POFF_M + krow + 4u * (unsigned)(16 * (k >> 2) + (k & 3)));
+            a[k] = L.r < NC ? x : 0.f;
+            am[k] = L.r < NC ? y : 0.f;
+        }
+        const bool uq = L.q < 2;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float x = wv::lds_f32(base + POFF_Q + 4u * (unsigned)((L.r < NC ? L.r : 0) * NC + (uq ? 4 * L.q + v : 0)));
+            aq[v] = (L.r < NC && uq) ? x : 0.f;                   // A[i = r][k = q] = Quu[r][4q + v]
+        }
+        const unsigned qo = 16u * (unsigned)(uq ? L.q : 0);
+        const f32x4 ub = wv::lds_f32x4(rec + 288 + qo), kb = wv::lds_f32x4(rec + 448 + qo);
+        const f32x4 mm = wv::lds_f32x4(base + POFF_Q + 256 + qo);
+        {
+            const int tn = t + PSLOTS - 1;
+            pstage_issue(p, d, L, m_ptr, tn < T ? tn : T - 1, tn % PSLOTS);
+        }
+        // ---- K dx and M dx  (four accumulation chains side by side)
+        f32x4 Ud = zero4, G = zero4;
+        wv::sched_fence();
+        {
+            f32x4 U2 = zero4, G2 = zero4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                Ud = wv::mfma(a[k], DXd[0][k], Ud);
+                U2 = wv::mfma(a[4 + k], DXd[1][k], U2);
+                G = wv::mfma(am[k], DXd[0][k], G);
+                G2 = wv::mfma(am[4 + k], DXd[1][k], G2);
+            }
+            wv::sched_fence();
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { Ud[v] += U2[v]; G[v] += G2[v]; }
+        }
+        // ---- u' = clamp / mask (u + K dx + alpha k)   (:192-213),  e = du - K dx - k
+        f32x4 e = zero4;
+        {
+            float s = 0.f;
+            unsigned zw = 0u;
+            if (MODE == 1) {
+                const unsigned zlo = zero_mask_word(p, tb, 0), zhi = zero_mask_word(p, tb, 1);
+                zw = L.q == 0 ? zlo : zhi;
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float un = uq ? Ud[v] + ub[v] + alpha * kb[v] : 0.f;
+                if (MODE == 1 && uq && ((zw >> (8 * v)) & 0xffu) != 0u) un = 0.f;                    // :197-198
+                if (MODE == 2 && uq) {                                                               // :200-213
+                    float lo = p.lo_s, hi = p.hi_s;
+                    if (p.bound_mode != MPC_BOUND_SCALAR) {
+                        lo = pick(L.q == 0, uniform_f32(p.lo + tb * NC + v), uniform_f32(p.lo + tb * NC + 4 + v));
+                        hi = pick(L.q == 0, uniform_f32(p.hi + tb * NC + v), uniform_f32(p.hi + tb * NC + 4 + v));
+                    }
+                    if (p.has_delta) {
+                        const float l2 = ub[v] - p.delta_u, h2 = ub[v] + p.delta_u;
+                        lo = (l2 < lo) ? lo : l2;
+                        hi = (h2 > hi) ? hi : h2;
+                    }
+                    un = clampf(un, lo, hi);
+                }
+                const float du = uq ? un - ub[v] : 0.f;
+                e[v] = uq ? du - Ud[v] - kb[v] : 0.f;
+                Ud[v] = un;
+                s = fmaf(du, du, s);
+            }
+            dacc += s;
+            if (store && uq) wv::store_f32x4(p.new_u + tb * NC + 4 * L.q, Ud);
+        }
+        // ---- x+ = F tau' + f   (:216-222)  and  Quu e
+        f32x4 H = zero4;
+        if (t < T - 1) {
+            const long tb1 = (long)(t + 1) * p.B + L.b;
+            f32x4 acc[2];
+            float fa[2][12];
+#pragma unroll
+            for (int Im = 0; Im < 2; ++Im) {
+                acc[Im] = zero4;
+                if (p.f) acc[Im] = wv::lds_f32x4(rec + 320 + 4u * (unsigned)(16 * Im + 4 * L.q));
+                const int row = 16 * Im + L.r;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    fa[Im][k] = wv::lds_f32(base + POFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float x = wv::lds_f32(base + POFF_F + 4u * (unsigned)(row * N + (uq ? 32 + 4 * L.q + v : 0)));
+                    fa[Im][8 + v] = uq ? x : 0.f;
+                }
+            }
+            wv::sched_fence();
+#pragma unroll
+            for (int v = 0; v < 4; ++v) H = wv::mfma(aq[v], e[v], H);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][k], Xd[k >> 2][k & 3], acc[Im]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + v], Ud[v], acc[Im]);
+            wv::sched_fence();
+#pragma unroll
+            for (int Im = 0; Im < 2; ++Im) {
+                if (store) wv::store_f32x4(p.new_x + tb1 * NS + 16 * Im + 4 * L.q, acc[Im]);
+                const f32x4 xb = wv::lds_f32x4(rec + 160 + 4u * (unsigned)(16 * Im + 4 * L.q));
+                Xd[Im] = acc[Im];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) DXd[Im][v] = acc[Im][v] - xb[v];
+            }
+        } else {
+            wv::sched_fence();
+#pragma unroll
+            for (int v = 0; v < 4; ++v) H = wv::mfma(aq[v], e[v], H);
+            wv::sched_fence();
+        }
+        // (G was formed with the dx this timestep STARTED from: DXd above is already the next one's)
+        {
+            float term = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) term = fmaf(e[v], mm[v] + G[v] + 0.5f * H[v], term);
+            cacc += (double)(uq ? term : 0.f);
+        }
+    }
+    wv::dma_wait<0>();
+    // column totals: lane groups 0 and 1 hold the two halves of the controls
+    double c2 = cacc;
+    {
+        const float hi = (float)c2, lo = (float)(c2 - (double)hi);
+        const double o1 = (double)wv::shfl_xor(hi, 16) + (double)wv::shfl_xor(lo, 16);
+        c2 += o1;
+        const float hi2 = (float)c2, lo2 = (float)(c2 - (double)hi2);
+        c2 += (double)wv::shfl_xor(hi2, 32) + (double)wv::shfl_xor(lo2, 32);
+    }
+    const double cost = old_cost + w0 + c2;
+    const float du2 = sum_q(dacc);
+    // first trial that is not worse than the nominal, else the last one (:176-179, 247)
+    int win = p.max_ls - 1;
+    for (int j = p.max_ls - 1; j >= 0; --j) {
+        const double cj = (double)wv::readlane((float)cost, j) + (double)wv::readlane((float)(cost - (double)(float)cost), j);
+        if (!(cj > old_cost)) win = j;
+    }
+    const float full2 = wv::readlane(du2, 0);
+    float win_alpha = 1.f;
+    for (int i = 0; i < win; ++i) win_alpha *= p.ls_decay;
+    if (win != 0) rollout_lean<MODE, true>(p, L, Kin, kin, old_cost, 0.0, win_alpha);
+    float wc_hi = wv::readlane((float)cost, 0), wc_lo = wv::readlane((float)(cost - (double)(float)cost), 0);
+    float wd = full2;
+    for (int j = 1; j < 16; ++j) {                   // (uniform loop; readlane wants a constant lane only in the kernel build)
+        const float hj = wv::readlane((float)cost, j), lj = wv::readlane((float)(cost - (double)(float)cost), j);
+        const float dj = wv::readlane(du2, j);
+        if (j == win) {
+            wc_hi = hj;
+            wc_lo = lj;
+            wd = dj;
+        }
+    }
+    const double wc = (double)wc_hi + (double)wc_lo;
+    if (L.lane == 0) {
+        int status = 0;
+        if (!(wc == wc) || fabs(wc) > 3e38) status |= MPC_ST_NONFINITE;
+        if (p.costs) p.costs[L.b] = (float)wc;
+        if (p.full_du_norm) p.full_du_norm[L.b] = sqrtf(full2);
+        if (p.alpha_du_norm) p.alpha_du_norm[L.b] = sqrtf(wd);
+        if (p.alphas) p.alphas[L.b] = win_alpha;
+        if (p.status) p.status[L.b] |= status;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LQRStepFn.backward (mpc/lqr_step.py:312-407) for this shape: the step of its nested problem with the costates riding
 // along, then kkt_outer_kernel (kkt_wave.hip) for the outer products.  The reference walks the horizon four times
 // (nested sweep, nested rollout, lambda, dlambda); here lambda rides with the sweep (sweep_wave<MODE, true>) and
@@ -1834,6 +2099,15 @@ template <int MODE> MPC_DEV void step_wave(const P &p, float *K, float *k)
         L.b = wv::problem();
         if (L.b >= p.B) return;
         rollout_lean<0, false>(p, L, K, k, old_cost, w0);
+    } else if (MODE != 0 && on_dyn && p.Kk) {
+        // constrained, vouched for, and the caller left room for the (M, Quu, m) record: priced without a pass over C
+        Lane L;
+        L.lane = wv::lane();
+        L.r = L.lane & 15;
+        L.q = L.lane >> 4;
+        L.b = wv::problem();
+        if (L.b >= p.B) return;
+        rollout_priced<MODE>(p, L, K, k, old_cost, w0);
     } else {
         rollout_wave<MODE>(p, K, k, old_cost);
     }

@@ -637,14 +637,22 @@ static void body_mfma40()
     else if (g_p->zero_mask) body_mfma40_mode<1>();
     else body_mfma40_mode<0>();
 }
+static int g_m40_record = 1;
 extern "C" void emu_mfma40_full(int full) { g_m40_full = full; }
+extern "C" void emu_mfma40_record(int on) { g_m40_record = on; }
 extern "C" int emu_lqr_sweep_mfma40(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out)
 {
     if (p->dtype != MPC_F32) return MPC_E_DTYPE;
     mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, out);
     if (!(sp.ns == 32 && sp.nc == 8) || !sp.K || !sp.k) return MPC_E_DIMS;
+    // the (M, Quu, m) record of the constrained modes' priced rollout (capi.hip takes it out of the workspace)
+    const size_t need = (size_t)sp.T * sp.B * mpclqr::mfma40::PREC + 4;
+    float *rec = (float *)aligned_alloc(16, (need * sizeof(float) + 15) / 16 * 16);
+    for (size_t i = 0; i < need; ++i) rec[i] = NAN;
+    sp.Kk = g_m40_record ? rec : nullptr;
     g_p = &sp;
     for (int b = 0; b < sp.B; ++b) emu::run_wave(b, body_mfma40);
+    free(rec);
     return 0;
 }
 

@@ -705,6 +705,55 @@ def test_emulated_mfma40_full_step(emu, case, dma_late, vouch, ring):
     np.testing.assert_allclose(r["alpha_du_norm"], o["alpha_du_norm"], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("ring", ["mfma40", "mfma40_ring2"], ids=["ring3", "ring2"])
+@pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
+@pytest.mark.parametrize("case", ["bounded", "tensor_bounds", "delta_u", "masked", "bounded_T1", "bounded_T2", "bounded_backtrack", "bounded_nof"])
+def test_emulated_mfma40_constrained_modes_priced_without_C(emu, case, dma_late, ring):
+    """The constrained step on a vouched-for nominal (what mpc.MPC hands over): every line-search trial priced by the identity
+    J = J_nominal + w0 + sum e'(m + M dx) + e'Quu e / 2 from the record the sweep leaves (rollout_priced), no pass over C --
+    against the oracle, and against the same kernel's C-priced pass (the unvouched call)."""
+    from oracle import lqr_oracle as O
+    T = {"bounded_T1": 1, "bounded_T2": 2}.get(case, 6)
+    B = 3
+    for attempt in range(40):
+        rng = np.random.default_rng(31 + len(case) + 1000 * attempt)
+        kw = _cfg5_problem(rng, max(T, 2), B)
+        if T == 1:
+            kw = {k: (v[:1] if k in ("C", "c", "cur_u") else (v[:0] if k in ("F", "f") else v)) for k, v in kw.items()}
+        if case == "bounded_nof":
+            kw["f"] = None
+        if case == "bounded_backtrack":
+            kw["C"][:, :, :32, :32] -= 80.0 * np.eye(32)         # non-convex in x: the full step can make things worse
+        kw["cur_u"] = np.clip(kw["cur_u"], -0.4, 0.4)
+        kw["cur_x"], _ = O.traj_cost(kw["x_init"], kw["cur_u"], kw["F"], kw["f"])
+        opt = dict(linesearch_decay=0.5, max_linesearch_iter=6)
+        if case == "tensor_bounds":
+            opt.update(u_lower=-0.5 - rng.random((T, B, 8)), u_upper=0.5 + rng.random((T, B, 8)))
+        elif case == "delta_u":
+            opt.update(u_lower=-0.5, u_upper=0.5, delta_u=0.1)
+        elif case == "masked":
+            opt.update(u_zero_I=rng.random((T, B, 8)) < 0.35)
+        else:
+            opt.update(u_lower=-0.5, u_upper=0.5)
+        o = O.lqr_step(lockstep=False, **kw, **opt)
+        if case != "bounded_backtrack" or ((o["alphas"] < 1).any() and (o["alphas"] > 0.5 ** 5).all()):
+            break
+    else:
+        assert False, "no seed made the constrained line search backtrack"
+    r = emu.lqr_step(kernel=ring, dma_late=dma_late, nominal_on_dynamics=True, **kw, **opt)
+    rc = emu.lqr_step(kernel=ring, dma_late=dma_late, **kw, **opt)             # priced from C
+    if case == "bounded_backtrack":
+        assert (o["alphas"] < 1).any()
+    wide = 10.0 if case == "bounded_backtrack" else 1.0
+    for ref in (o, rc):
+        np.testing.assert_allclose(r["alphas"], ref["alphas"], rtol=1e-6)
+        np.testing.assert_allclose(r["new_x"], ref["new_x"], rtol=2e-3 * wide, atol=2e-4 * wide * (1 + np.abs(o["new_x"]).max()))
+        np.testing.assert_allclose(r["new_u"], ref["new_u"], rtol=2e-3 * wide, atol=2e-4 * wide)
+        np.testing.assert_allclose(r["costs"], ref["costs"], rtol=2e-4 * wide, atol=1e-3)
+        np.testing.assert_allclose(r["full_du_norm"], ref["full_du_norm"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(r["alpha_du_norm"], ref["alpha_du_norm"], rtol=1e-3, atol=1e-4)
+
+
 @pytest.mark.parametrize("case", ["state", "x_init", "no_f", "nan"])
 def test_emulated_mfma40_verifies_the_nominal_it_is_not_vouched_for(emu, case):
     """A bare LQRStep call at 32/8 (no MPC_OPT_NOMINAL_ON_DYNAMICS): the sweep checks x_0 = x_init and x_{t+1} = F tau + f while it

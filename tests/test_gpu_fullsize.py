@@ -276,13 +276,14 @@ def test_simulator_step_full_batch_vs_oracle(be, kind, B, T, inline_linearize):
 # (d) config 5 with > 1 wave per SIMD and a partial last wave
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ring", ["3", "2"], ids=["ring3", "ring2"])
-@pytest.mark.parametrize("mode", ["unbounded", "unbounded_vouched", "bounded", "masked"])
+@pytest.mark.parametrize("mode", ["unbounded", "unbounded_vouched", "bounded", "masked", "bounded_vouched", "masked_vouched"])
 def test_config5_full_waves_vs_oracle(be, mode, ring, monkeypatch):
     """ns=32 nc=8 T=64 (BASELINE configs[4]) at B = 1030 -- one wavefront per problem: 1030 waves > 1024 SIMDs,
     so some SIMDs hold two waves and the grid has a ragged tail -- on the register-resident MFMA kernel
     (impl 5), against the float64 oracle: unconstrained, box-constrained (8-unknown pnqp), u_zero_I-masked;
     "vouched" = MPC_OPT_NOMINAL_ON_DYNAMICS, the unconstrained step's lean rollout (line search decided from the
-    sweep's predicted cost change, one pass without C).  ring: the step kernels are compiled on a three-slot sweep ring (the DMA
+    sweep's predicted cost change, one pass without C); for the constrained modes "vouched" = every trial priced by the identity
+    of the sweep's value function from the (M, Quu, m) record, no pass over C (rollout_priced).  ring: the step kernels are compiled on a three-slot sweep ring (the DMA
     two timesteps ahead) and on a two-slot one; capi.hip picks by mode and batch, MPC_MFMA40_RING forces -- both are held to the
     oracle here whatever it would pick."""
     monkeypatch.setenv("MPC_MFMA40_RING", ring)
@@ -292,21 +293,23 @@ def test_config5_full_waves_vs_oracle(be, mode, ring, monkeypatch):
     from mpc.mpc import LinDx
     from oracle import lqr_oracle as O
     T, B = 64, full_batch(1030)
-    p = bench.make_problem(32, 8, T, B, torch.float32, DEV, seed=21, u_scale=0.0 if mode != "bounded" else 0.3)
+    p = bench.make_problem(32, 8, T, B, torch.float32, DEV, seed=21, u_scale=0.0 if not mode.startswith("bounded") else 0.3)
     kw, okw = {}, {}
     if mode == "unbounded_vouched":
         kw = dict(nominal_on_dynamics=True)
-    if mode == "bounded":
+    if mode.startswith("bounded"):
         ub = 0.5
         p["cur_u"] = p["cur_u"].clamp(-ub, ub)
         p["cur_x"] = util.get_traj(T, p["cur_u"], p["x_init"], LinDx(p["F"], p["f"]))
         kw = dict(u_lower=-ub, u_upper=ub)
         okw = dict(u_lower=-ub, u_upper=ub)
-    elif mode == "masked":
+    elif mode.startswith("masked"):
         g = torch.Generator().manual_seed(3)
         mask = (torch.rand(T, B, 8, generator=g) < 0.3).to(DEV)
         kw = dict(u_zero_I=mask)
         okw = dict(u_zero_I=host(mask))
+    if mode.endswith("_vouched") and mode != "unbounded_vouched":
+        kw["nominal_on_dynamics"] = True
     h = {k: h64(v) for k, v in p.items()}
     o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], lockstep=False,
                    nthreads=O.max_threads(), return_gains=True, **okw)
@@ -315,9 +318,9 @@ def test_config5_full_waves_vs_oracle(be, mode, ring, monkeypatch):
     sync()
     strict_step_check("cfg5_B1030_" + mode, r, o, B, rtol=2e-3, atol=5e-4, cost_rtol=5e-4)
     np.testing.assert_allclose(host(r["old_costs"]), o["old_costs"], rtol=1e-5)
-    if mode == "bounded":
+    if mode.startswith("bounded"):
         assert float(r["new_u"].abs().max()) <= 0.5 + 1e-6
-    if mode == "masked":
+    if mode.startswith("masked"):
         assert float(r["new_u"][mask].abs().max()) == 0.0
 
 
