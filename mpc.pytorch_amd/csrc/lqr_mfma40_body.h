@@ -491,6 +491,7 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
     int it_ret = n_iter - 1;
     converged = false;
     const float dgm = diagv + 1e-11f - 1.f;                        // :47 (identity off the free set)
+    bool full = false;                                             // the last trip took its whole Newton step
     for (int it = 0; it < n_iter; ++it) {
         float gv = qv;
         Pnqp8vMv<0>::run(col0, xv, gv);                            // :29
@@ -498,6 +499,15 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
         const float r_lo = (xv == lbv) ? gv : -1.f;
         const float r_hi = (xv == ubv) ? -gv : -1.f;
         const float mnv = (fmaxf(r_lo, r_hi) > 0.f) ? 0.f : 1.f;
+        // The confirming iteration costs a gradient, not a factorisation (as in pnqp4_rows, lqr_dpp16_body.h): after a FULL
+        // Newton step the gradient vanishes on the free set, so if the free set of the new point is the one just factorised
+        // the next step is zero to rounding -- this is the iteration the reference stops in (:56-59), and the factorisation
+        // it would recompute is the one at hand.
+        if (it > 0 && full && wv::uniform(wv::row_sum(fabsf(mnv - mv)) == 0.f)) {
+            converged = true;
+            it_ret = it;
+            break;
+        }
         float colm[8];
         Pnqp8vMat<0>::run(col0, mnv, fmaf(mnv, dgm, 1.f), r, colm);   // :44-48
         Ldl8V fn;
@@ -516,7 +526,8 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
             it_ret = it;
             break;
         }
-        if (!wv::uniform(outv == 0.f)) {                           // :61-76
+        full = wv::uniform(outv == 0.f);
+        if (!full) {                                               // :61-76
             float alpha = 1.f;
             for (int count = 0; count < 10; ++count) {
                 mxv = clampf(fmaf(alpha, dxv, xv), lbv, ubv);
