@@ -281,7 +281,8 @@ def extra_rows(be, dev, steps):
             rows["cfg5_step_B1024_verified_nominal"] = rowv
             rows["cfg5_kkt_backward_B1024"] = kkt_row(p, r, StepOptions(c_symmetric=True), 32, 8, 64, B5)
             pb = dict(p)
-            rowb, _ = step_row(pb, StepOptions(u_lower=-1.0, u_upper=1.0, c_symmetric=True), 32, 8, 64, B5)
+            rowb, _ = step_row(pb, StepOptions(u_lower=-1.0, u_upper=1.0, nominal_on_dynamics=True, c_symmetric=True), 32, 8, 64, B5)   # as mpc.MPC calls it
+            rowb["workload"] = "config 5 with box bounds +-1 (pnqp in 8 unknowns in the sweep; line search priced from the sweep's record, no pass over C)"
             rows["cfg5_step_bounded_B1024"] = rowb
             # The rows above are back-to-back launches: address translations of C and F stay cached.  An application runs other
             # kernels between two steps; this row puts a 16 us kernel that reads one byte in every 4 KiB page of 800 MB in front

@@ -22,8 +22,8 @@
 //   * vectors live in "row layout" (lane r holds entry 16J + r, the same in all four lane groups) or in
 //     "column layout" (lane group q holds entries 16I + 4q + v); matrix-vector products are per-lane partial
 //     sums over the tile registers plus a 2-step (across q) or 4-step (across r) butterfly.
-//   * the 8x8 Quu is factorised (LDL') spread over lanes in the unconstrained sweep (Ldl8V), and read out with 36
-//     readlanes and factorised on wave-uniform values where masks / the box QP need it uniform.
+//   * the 8x8 Quu is factorised (LDL') spread over lanes (Ldl8V) in every mode; masked / clamped controls are identity
+//     rows and columns of the factorised matrix, the box QP (pnqp8v) works on the same lane-spread data.
 // C is read as the symmetric matrix the reference documents it to be (mpc/mpc.py:61-68).
 #pragma once
 #include <math.h>
@@ -212,55 +212,7 @@ MPC_DEV float sum_r(float x)
     return x;
 }
 
-// LDL' of the wave-uniform SPD 8x8 matrix S (upper triangle S[a][b], a <= b): L unit lower, d = 1/D.
-struct Ldl8 {
-    float l[8][8];   // l[i][j], j < i
-    float inv[8];
-};
-MPC_DEV void ldl8(Ldl8 &f, const float S[8][8])
-{
-    float a[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) a[i][j] = S[j][i];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float dj = a[j][j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) dj = fmaf(-f.l[j][k], a[j][k], dj);      // a[j][k] holds L_jk * D_k
-        f.inv[j] = wv::rcp(dj);
-#pragma unroll
-        for (int i = j + 1; i < 8; ++i) {
-            float s = a[i][j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) s = fmaf(-f.l[i][k], a[j][k], s);
-            a[i][j] = s;                       // L_ij * D_j
-            f.l[i][j] = s * f.inv[j];
-        }
-    }
-}
-// y = S^-1 rhs
-MPC_DEV void ldl8_solve(const Ldl8 &f, const float rhs[8], float y[8])
-{
-    float z[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float s = rhs[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) s = fmaf(-f.l[i][k], z[k], s);
-        z[i] = s;
-    }
-#pragma unroll
-    for (int i = 7; i >= 0; --i) {
-        float s = z[i] * f.inv[i];
-#pragma unroll
-        for (int k = i + 1; k < 8; ++k) s = fmaf(-f.l[k][i], y[k], s);
-        y[i] = s;
-    }
-}
-
-// ---- the same factorisation with the matrix spread over lanes (unconstrained sweep) ------------------------------
+// ---- LDL' of the SPD 8x8 Quu with the matrix spread over lanes ----------------------------------------------------
 // All four 16-lane rows hold the same data; inside a row lane a < 8 holds matrix row a.  col[c] = column c of the
 // symmetric matrix (lane a: A[a][c]).  Right-looking LDL': per pivot one reciprocal, one scaling and one
 // v_fmac_f32_dpp per remaining column (60 instructions against ~170 on wave-uniform values, and no readlanes to make
@@ -345,31 +297,6 @@ MPC_DEV void ldl8v_solve(const Ldl8V &f, float (&y)[8])
     Ldl8VBwd<7>::run(f, y);
 }
 
-// Same factorisation of the free block: rows / columns outside `fr` become identity (their right-hand
-// sides are zero, so the solve returns zero there) -- mpc/pnqp.py:44-48 (H_ + 1e-11 I on the free set) and
-// mpc/lqr_step.py:99-127 (u_zero_I).
-MPC_DEV void ldl8_masked(Ldl8 &f, const float S[8][8], const bool fr[8], float reg)
-{
-    float M[8][8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int c = a; c < 8; ++c) {
-            // off the diagonal two dependent selects instead of one on the AND of the masks: the AND is a scalar
-            // instruction in the middle of a vector dependency chain (+16 clocks, see lqr_small_math.h)
-            float off = fr[c] ? S[a][c] : 0.f;
-            wv::pin(off);
-            M[a][c] = a == c ? (fr[a] ? S[a][a] + reg : 1.f) : (fr[a] ? off : 0.f);
-        }
-    ldl8(f, M);
-}
-MPC_DEV float sym8_row(const float S[8][8], int a, const float x[8])
-{
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) s = fmaf(a <= c ? S[a][c] : S[c][a], x[c], s);
-    return s;
-}
 MPC_DEV float clampf(float x, float lo, float hi)
 {
     if (x < lo) x = lo;      // util.eclamp (mpc/util.py:56-70): strict compares, bound written exactly
@@ -377,80 +304,13 @@ MPC_DEV float clampf(float x, float lo, float hi)
     return x;
 }
 
-// Projected-Newton box QP in 8 unknowns on wave-uniform values (mpc/pnqp.py:5-82, n_batch = 1), the
-// 8-dimensional sibling of lqr_small_math.h's pnqp4 (same Armijo restatements, see there).
-MPC_DEV int pnqp8(const float S[8][8], const float q[8], const float lb[8], const float ub[8], int n_iter, float x[8],
-                  bool fr[8], Ldl8 &f, bool &converged)
-{
-    int it_ret = n_iter - 1;
-    converged = false;
-    for (int it = 0; it < n_iter; ++it) {
-        float g[8], gm[8], dx[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            g[a] = sym8_row(S, a, x) + q[a];                                                         // :29
-            // :32 clamped = (x == lb & g > 0) | (x == ub & g < 0), on the vector ALU (as in pnqp4)
-            float r_lo = (x[a] == lb[a]) ? g[a] : -1.f;
-            float r_hi = (x[a] == ub[a]) ? -g[a] : -1.f;
-            wv::pin(r_lo);
-            wv::pin(r_hi);
-            float r = fmaxf(r_lo, r_hi);
-            wv::pin(r);
-            fr[a] = !(r > 0.f);
-            gm[a] = fr[a] ? g[a] : 0.f;
-        }
-        ldl8_masked(f, S, fr, 1e-11f);                                                                // :44-48
-        ldl8_solve(f, gm, dx);                                                                        // :50-54
-        float nrm2 = 0.f;
-        float in_f = 1.f;
-        float mx[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            dx[a] = fr[a] ? -dx[a] : 0.f;
-            nrm2 = fmaf(dx[a], dx[a], nrm2);
-            mx[a] = x[a] + dx[a];
-            in_f = (mx[a] >= lb[a]) ? in_f : 0.f;
-            wv::pin(in_f);
-            in_f = (mx[a] <= ub[a]) ? in_f : 0.f;
-            wv::pin(in_f);
-        }
-        const bool inside = in_f > 0.f;
-        if (wv::uniform(!(nrm2 >= 1e-8f))) {                                                          // :56-59
-            converged = true;
-            it_ret = it;
-            break;
-        }
-        if (!wv::uniform(inside)) {                                                                   // :61-76
-            float alpha = 1.f;
-            for (int count = 0; count < 10; ++count) {
-                float d[8];
-#pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    mx[a] = clampf(fmaf(alpha, dx[a], x[a]), lb[a], ub[a]);
-                    d[a] = mx[a] - x[a];
-                }
-                float den = 0.f, dhd = 0.f;
-#pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    den = fmaf(-g[a], d[a], den);
-                    dhd = fmaf(d[a], sym8_row(S, a, d), dhd);
-                }
-                const float arm = fmaf(-0.5f, dhd, den) * wv::rcp(den);
-                if (wv::uniform(arm <= 0.1f)) alpha *= 0.1f; else break;
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < 8; ++a) x[a] = mx[a];                                                      // :78
-    }
-    return it_ret;
-}
-
-// ---- the same box QP with its vectors spread over lanes (lane a < 8 of every 16-lane row: entry a; lanes 8..15 hold
+// ---- Projected-Newton box QP in 8 unknowns (mpc/pnqp.py:5-82, n_batch = 1; the Armijo restatements of lqr_small_math.h's
+// pnqp4) with its vectors spread over lanes (lane a < 8 of every 16-lane row: entry a; lanes 8..15 hold
 // zeros and stay free, which makes them inert in every product and row sum).  col0[c]: column c of H (lane a: H[a][c]).
 // A trip is ~210 instructions against ~500 on wave-uniform values: the gradient and H d are 8 DPP multiply-adds each, the
 // tests / clamps / steps one instruction per vector, the factorisation is ldl8v; only the triangular solve keeps its 64
 // multiply-adds (every lane solves the same right-hand side, read as DPP broadcasts).
-// Same iterates as pnqp8 / mpc/pnqp.py:5-82 (n_batch = 1).  On return xv is the solution, mv the free set (1 / 0) and f
+// Same iterates as mpc/pnqp.py:5-82 (n_batch = 1).  On return xv is the solution, mv the free set (1 / 0) and f
 // the factorisation of the iteration that recognised convergence (:56-59), as the reference returns them.
 template <int C> struct Pnqp8vMat {
     static MPC_DEVM void run(const float (&col0)[8], float mnv, float dgv, int r, float (&colm)[8])
@@ -545,7 +405,7 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
 }
 
 // The sweep of one problem: K [T,B,8,32] and k [T,B,8] in the reference layout, old_costs[b].
-// MODE 0: unconstrained; 1: u_zero_I mask; 2: box constraints (pnqp8 on wave-uniform values).
+// MODE 0: unconstrained; 1: u_zero_I mask; 2: box constraints (pnqp8v).
 // V_t (the four tiles as they sit in the registers: pass 2 reads them back as A operands) and v_t | g_t (column layout:
 // lane group q holds entries 16I + 4q + v) to the fused backward's workspace
 MPC_DEV void kkt_store_vvg(const KktArgs40 &kx, long tb, const Lane &L, const wv::f32x4 (&Vd)[2][2], const float (&vcol)[2][4],
@@ -804,11 +664,10 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         }
 
         // ---- Quu, qu; K = -Quu^-1 Qux, k = -Quu^-1 qu   (:84-94; LDL' for the pinverse)
-        // Constrained modes: Quu is read out with 36 readlanes and factorised on wave-uniform values (masks, the box QP).
-        // Unconstrained: Quu stays spread over lanes (Ldl8V): column c of it is register c & 3 of lane row c >> 2 of the
-        // accumulator tile, copied to all four lane rows with two row swaps per register.
-        float S[8][8];
-        Ldl8 fac;
+        // Quu stays spread over lanes in every mode (Ldl8V): column c of it is register c & 3 of lane row c >> 2 of the
+        // accumulator tile, copied to all four lane rows with two row swaps per register; pinned / clamped controls become
+        // identity rows and columns of the factorised matrix (Pnqp8vMat).  (Round 2 read Quu out with 36 readlanes and
+        // factorised on wave-uniform values in the constrained modes.)
         Ldl8V facv;
         float qu[8], kk[8];
         bool fr[8];
@@ -825,35 +684,30 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             for (int v = 0; v < 4; ++v) wv::rows01(Qd[2][2][v], col[v], col[4 + v]);
             ldl8v<true>(facv, col);
             if (facv.sing != 0.f) status |= MPC_ST_QUU_SINGULAR;
-        } else if (MODE == 1) {
-            // (the box-constrained mode keeps Quu spread over lanes and in its accumulator tile: pnqp8v, M = Qux + Quu K on MFMA)
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-#pragma unroll
-                for (int c = a; c < 8; ++c) S[a][c] = wv::readlane(Qd[2][2][a & 3], 16 * (a >> 2) + c);
         }
-        float mkv = 0.f;                // box-constrained: m = qu + Quu k spread over lanes (lane a < 8 of every row: m[a])
+        float mkv = 0.f;                // constrained modes: m = qu + Quu k spread over lanes (lane a < 8 of every row: m[a])
+        float col1[8];                  // u_zero_I mode: Quu's columns spread over lanes (m and the record need them again)
         if (MODE == 0) {
             // (k comes out of the first of the two K solves below: lane rows 2, 3 carry qu as their right-hand side)
         } else if (MODE == 1) {                          // :99-127: pinned controls drop out of the solve
-            float rq[8];
             const unsigned zlo = KKT ? kkt_pinned_word(p, tb, 0) : zero_mask_word(p, tb, 0);
             const unsigned zhi = KKT ? kkt_pinned_word(p, tb, 1) : zero_mask_word(p, tb, 1);
+            float frf[8];
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
                 fr[a] = (((a < 4 ? zlo : zhi) >> (8 * (a & 3))) & 0xffu) == 0u;
-                rq[a] = fr[a] ? qu[a] : 0.f;
+                frf[a] = fr[a] ? 1.f : 0.f;
             }
-            ldl8_masked(fac, S, fr, 0.f);
-            ldl8_solve(fac, rq, kk);
+            // the free block of Quu, identity elsewhere, factorised spread over lanes (k rides in the K solve below)
 #pragma unroll
-            for (int a = 0; a < 8; ++a) kk[a] = fr[a] ? -kk[a] : 0.f;
-            if (KKT) {                                   // the line search's predicted change, as in the unconstrained mode
-                float w = 0.f;
+            for (int v = 0; v < 4; ++v) wv::rows01(Qd[2][2][v], col1[v], col1[4 + v]);
+            float diagv = 0.f;
 #pragma unroll
-                for (int a = 0; a < 8; ++a) w = fmaf(qu[a], kk[a], w);
-                w0 += 0.5 * (double)w;
-            }
+            for (int a = 0; a < 8; ++a) diagv = pick(L.r == a, col1[a], diagv);
+            const float mnv = gather8(frf, L.r);
+            float colm[8];
+            Pnqp8vMat<0>::run(col1, mnv, fmaf(mnv, diagv - 1.f, 1.f), L.r, colm);
+            ldl8v(facv, colm);
         } else {                                         // :128-148: box QP, warm start k_{t+1}
             // the QP's data spread over lanes (pnqp8v): H's columns by two row swaps per accumulator register
             float col0[8];
@@ -923,21 +777,30 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             float rhs[8], sol[8];
 #pragma unroll
             for (int v = 0; v < 4; ++v) wv::swap16(Qd[2][0][v], Qd[2][1][v], rhs[v], rhs[4 + v]);
-            float rhs_full[8];
-#pragma unroll
-            for (int a = 0; a < 8; ++a) rhs_full[a] = rhs[a];
             if (MODE != 0) {
+                // (u_zero_I mode: lane row 2 carries qu, as in the unconstrained mode; the box QP has its k already)
 #pragma unroll
-                for (int a = 0; a < 8; ++a) rhs[a] = fr[a] ? rhs[a] : 0.f;                            // :142-143
-                if (MODE == 2) {
-#pragma unroll
-                    for (int a = 0; a < 8; ++a) sol[a] = rhs[a];
-                    ldl8v_solve(facv, sol);
-                } else {
-                    ldl8_solve(fac, rhs, sol);
+                for (int a = 0; a < 8; ++a) {
+                    const float x = (MODE == 1 && L.q == 2) ? qu[a] : rhs[a];
+                    sol[a] = fr[a] ? x : 0.f;                                                         // :142-143
                 }
+                ldl8v_solve(facv, sol);
 #pragma unroll
                 for (int a = 0; a < 8; ++a) sol[a] = fr[a] ? sol[a] : 0.f;
+                if (MODE == 1) {
+                    float w = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) {
+                        kk[a] = -wv::readlane(sol[a], 32);
+                        w = fmaf(qu[a], kk[a], w);
+                    }
+                    if (KKT) w0 += 0.5 * (double)w;      // the nested line search's predicted change (pinned controls: k = 0)
+                    // m = qu + Quu k on the lane-spread columns
+                    const float kv = gather8(kk, L.r);
+                    mkv = L.r < NC ? qrow2 : 0.f;
+                    Pnqp8vMv<0>::run(col1, kv, mkv);
+                    kprev_v = kv;                        // (k spread over lanes, for w0 of the priced rollout below)
+                }
             } else {
 #pragma unroll
                 for (int a = 0; a < 8; ++a) sol[a] = L.q == 2 ? qu[a] : rhs[a];
@@ -960,7 +823,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                 Kd[0][v] = L.q < 2 ? k0 : 0.f;
                 Kd[1][v] = L.q < 2 ? k1 : 0.f;
             }
-            if (MODE == 2) {
+            if (MODE != 0) {
                 // M = Qux + Quu K on the matrix core: the Quu tile of Q is, by symmetry, its own A operand (rows 8..15 and
                 // columns 8..15 of it are zero), K's tiles are B operands as they stand, the Qux tiles the accumulators --
                 // 8 MFMAs where every lane formed its column of M from 36 readlane copies of Quu (128 multiply-adds)
@@ -969,18 +832,6 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                     Md[J] = Qd[2][J];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) Md[J] = wv::mfma(Qd[2][2][v], Kd[J][v], Md[J]);
-                }
-            } else if (MODE == 1) {
-                // M = Qux + Quu K for this lane's column, the B operand of K'M below
-                float m[8];
-#pragma unroll
-                for (int a = 0; a < 8; ++a) m[a] = rhs_full[a] + sym8_row(S, a, Kc);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    float m0, m1;
-                    wv::swap16(m[v], m[4 + v], m0, m1);
-                    Md[0][v] = L.q < 2 ? m0 : 0.f;
-                    Md[1][v] = L.q < 2 ? m1 : 0.f;
                 }
             }
             if (L.q < 2) {
@@ -1017,19 +868,13 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
 #pragma unroll
                     for (int J = 0; J < 2; ++J) Vd[I][J] = wv::mfma(Kd[I][v], Md[J][v], Vd[I][J]);
         }
-        float mk[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) mk[a] = MODE == 1 ? qu[a] + sym8_row(S, a, kk) : 0.f;
         float mq[4] = {0.f, 0.f, 0.f, 0.f};         // m[4q + v] for this lane group (constrained modes)
-        if (MODE == 2) {
+        if (MODE != 0) {
             float lo4[4], hi4[4];
             lo4[0] = wv::bcast<0>(mkv); lo4[1] = wv::bcast<1>(mkv); lo4[2] = wv::bcast<2>(mkv); lo4[3] = wv::bcast<3>(mkv);
             hi4[0] = wv::bcast<4>(mkv); hi4[1] = wv::bcast<5>(mkv); hi4[2] = wv::bcast<6>(mkv); hi4[3] = wv::bcast<7>(mkv);
 #pragma unroll
             for (int v = 0; v < 4; ++v) mq[v] = pick(L.q == 0, lo4[v], pick(L.q == 1, hi4[v], 0.f));
-        } else if (MODE == 1) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) mq[v] = pick(L.q == 0, mk[v], pick(L.q == 1, mk[4 + v], 0.f));
         }
         if (MODE != 0 && !KKT && p.Kk) {
             // what the priced rollout of the constrained modes needs (rollout_priced): M, Quu, m of this timestep, and the
@@ -1045,23 +890,9 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                     for (int v = 0; v < 4; ++v) rec[256 + (4 * L.q + v) * NC + L.r] = Qd[2][2][v];
                 }
             }
-            float w;
-            if (MODE == 2) {
-                if (L.lane < NC) rec[320 + L.lane] = mkv;
-                const float kv = kprev_v;                                 // (k spread over lanes: the QP's solution)
-                w = wv::row_sum(kv * (mkv + (L.r < NC ? qrow2 : 0.f)));
-            } else {
-                if (L.lane < NC) {
-                    float mv = mk[0];
-#pragma unroll
-                    for (int a = 1; a < 8; ++a) mv = pick(L.lane == a, mk[a], mv);
-                    rec[320 + L.lane] = mv;
-                }
-                w = 0.f;
-#pragma unroll
-                for (int a = 0; a < 8; ++a) w = fmaf(kk[a], mk[a] + qu[a], w);
-            }
-            w0 += 0.5 * (double)w;
+            if (L.lane < NC) rec[320 + L.lane] = mkv;
+            const float kv = kprev_v;                                     // (k spread over lanes)
+            w0 += 0.5 * (double)wv::row_sum(kv * (mkv + (L.r < NC ? qrow2 : 0.f)));
         }
         float vrow[2], lrow[2] = {0.f, 0.f}, grow[2] = {0.f, 0.f};
 #pragma unroll
