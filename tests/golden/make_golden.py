@@ -700,6 +700,8 @@ if __name__ == "__main__":
     if ONLY is not None:
         _grad_case("grad_asym_ns_f32", 12, 4, 8, 4, f32, 36, None, asym=(1, 2))
         _grad_case("grad_asym_small_f64", 4, 2, 6, 3, f64, 37, 0.4, asym=(0, 2))
+        _grad_case("grad_cfg5_unconstrained_f32", 32, 8, 7, 3, f32, 38, None)
+        _grad_case("grad_cfg5_constrained_f32", 32, 8, 6, 3, f32, 39, 0.3)
         sys.exit(0)
     # ---- full solves --------------------------------------------------------
     if not only or "env" in only:
@@ -725,6 +727,9 @@ if __name__ == "__main__":
     grad_case("grad_ns_unconstrained_f64", 12, 4, 10, 2, f64, 35, None)
     grad_case("grad_asym_ns_f32", 12, 4, 8, 4, f32, 36, None, asym=(1, 2))
     grad_case("grad_asym_small_f64", 4, 2, 6, 3, f64, 37, 0.4, asym=(0, 2))
+    # config 5's shape (round 3: the backward fused into its nested step, lqr_mfma40_body.h)
+    grad_case("grad_cfg5_unconstrained_f32", 32, 8, 7, 3, f32, 38, None)
+    grad_case("grad_cfg5_constrained_f32", 32, 8, 6, 3, f32, 39, 0.3)
     jacobian_case("jac_unconstrained", 100.0)
     jacobian_case("jac_constrained", 0.5)
     # ---- pnqp / traj --------------------------------------------------------

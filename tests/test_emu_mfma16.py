@@ -829,6 +829,20 @@ def test_emulated_mfma40_constrained_modes(emu, case, dma_late, ring):
         assert int(r["qp_iters"].max()) <= o["n_qp_iter"] + 2
 
 
+@pytest.mark.parametrize("name", ["grad_cfg5_unconstrained_f32", "grad_cfg5_constrained_f32"])
+def test_emulated_fused_kkt_backward_mfma40_on_the_reference_fixtures(emu, name):
+    """The same kernel on what the REFERENCE itself returns at this shape: a float32 mpc.MPC solve to its fixed point and
+    LQRStepFn.backward through autograd (tests/golden/make_golden.py: grad_case), 71 % of the controls on a bound in the
+    constrained fixture."""
+    z = golden(name)
+    beta = float(z["beta"][0])
+    lo, hi = (None, None) if np.isnan(beta) else (-beta, beta)
+    r = emu.kkt_fused_mfma40(z["C"], z["c"], z["F"], z.get("f"), z["x"], z["u"], z["dl_dx"], z["dl_du"], lo, hi, dma_late=True)
+    for k in ("dx_init", "dC", "dc", "dF", "df"):
+        scale = max(1.0, np.abs(z[k]).max())
+        np.testing.assert_allclose(r[k] / scale, z[k] / scale, rtol=0, atol=5e-5, err_msg=k)
+
+
 @pytest.mark.parametrize("sweep3", [True, False], ids=["sweep3", "sweep2"])
 @pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
 @pytest.mark.parametrize("case", ["unbounded", "bounded", "bounded_nof", "tensor_bounds", "T1", "T2", "T3", "T9", "nonconvex"])

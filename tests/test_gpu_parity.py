@@ -411,9 +411,11 @@ def test_kkt_backward_parity(be, name):
     beta = float(z["beta"][0])
     lo, hi = (None, None) if np.isnan(beta) else (-beta, beta)
     f64 = z["C"].dtype == np.float64
-    for impl in (1, 0):          # the generic kernels, and whatever the library picks (asymmetric C: flagged and re-solved)
+    # the generic kernels, whatever the library picks (asymmetric C: flagged and re-solved), and -- where C is symmetric -- the
+    # route C's promise opens (12/4 and 32/8: mpc_lqr_kkt_fused)
+    for impl, promise in ((1, False), (0, False)) + (((0, True),) if "asym" not in name else ()):
         g = be.kkt_backward(dev(z["C"]), dev(z["c"]), dev(z["F"]), dev(z.get("f")), dev(z["x"]), dev(z["u"]),
-                            dev(z["dl_dx"]), dev(z["dl_du"]), StepOptions(u_lower=lo, u_upper=hi), impl=impl)
+                            dev(z["dl_dx"]), dev(z["dl_du"]), StepOptions(u_lower=lo, u_upper=hi, c_symmetric=promise), impl=impl)
         for k in ("dx_init", "dC", "dc", "dF", "df"):
             if k not in z:
                 assert g[k] is None
