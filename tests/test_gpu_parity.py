@@ -668,6 +668,42 @@ def test_asymmetric_C_end_to_end_through_mpc_forward_and_backward(be, bounded):
     assert float((us - u32)[:, (0, 2, 3, 5, 6, 7)].abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("bounded", [False, True])
+def test_config5_shape_end_to_end_through_mpc_forward_and_backward(be, bounded):
+    """mpc.MPC at n_state = 32, n_ctrl = 8 in float32 -- every step on the register-resident MFMA kernel with the promises
+    mpc.MPC makes (nominal on the dynamics; C symmetric from the second iteration on: the constrained line search priced from
+    the sweep's record), the backward through mpc_lqr_kkt_fused (the nested step with both costates riding along) -- against the
+    SAME package in float64, which runs the generic kernels (reference-faithful by the step_* / grad_* fixtures): solution and
+    all five gradients."""
+    import bench
+    from mpc import mpc
+    from mpc.mpc import LinDx, QuadCost
+    T, B = 10, 7
+    p = bench.make_problem(32, 8, T, B, torch.float32, DEV, seed=81, u_scale=0.3, clamp=0.5 if bounded else None)
+    kw = dict(u_lower=-0.5, u_upper=0.5) if bounded else {}
+    outs = []
+    for dt in (torch.float32, torch.float64):
+        leaves = [t.to(dt).clone().requires_grad_(True) for t in (p["C"], p["c"], p["F"], p["f"], p["x_init"])]
+        ctrl = mpc.MPC(32, 8, T, lqr_iter=25, verbose=-1, exit_unconverged=False, detach_unconverged=False,
+                       eps=1e-9 if dt == torch.float64 else 1e-5, **kw)
+        x, u, costs = ctrl(leaves[4], QuadCost(leaves[0], leaves[1]), LinDx(leaves[2], leaves[3]))
+        if dt == torch.float32:
+            assert ctrl._c_symmetric                # the first step found C symmetric: promised from then on, and to the backward
+        gw = torch.Generator().manual_seed(9)
+        wx, wu = torch.randn(x.shape, generator=gw).to(DEV).to(dt), torch.randn(u.shape, generator=gw).to(DEV).to(dt)
+        grads = torch.autograd.grad((x * wx).sum() + (u * wu).sum(), leaves)
+        outs.append((x.detach(), u.detach(), [gr.detach() for gr in grads]))
+    (x32, u32, g32), (x64, u64, g64) = outs
+    if bounded:
+        on = (host(u64).__abs__() >= 0.5 - 1e-9).mean()
+        assert 0.05 < on < 0.95, on
+    np.testing.assert_allclose(host(u32), host(u64), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(host(x32), host(x64), rtol=2e-3, atol=2e-3)
+    for a, b_, name in zip(g32, g64, ("dC", "dc", "dF", "df", "dx_init")):
+        scale = max(1.0, float(b_.abs().max()))
+        np.testing.assert_allclose(host(a) / scale, host(b_) / scale, rtol=0, atol=5e-3, err_msg=name)
+
+
 def test_wide_network_keeps_the_module_path(be):
     """NNDynamics(4, 1, [1024]) is outside the LDS budget of the network kernels; native_net() says so (the
     library's own test, mpc_mlp_supported) and util.get_traj / MPC.forward call the module instead of raising."""
