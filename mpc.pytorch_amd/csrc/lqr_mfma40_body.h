@@ -860,14 +860,10 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             for (int I = 0; I < 2; ++I)
 #pragma unroll
                 for (int J = 0; J < 2; ++J) Vd[I][J] = wv::mfma(Qd[2][I][v], Kd[J][v], Vd[I][J]);
-        if (MODE != 0) {                                 // + K'(Qux + Quu K): K' as A operand is K's own registers
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-#pragma unroll
-                for (int I = 0; I < 2; ++I)
-#pragma unroll
-                    for (int J = 0; J < 2; ++J) Vd[I][J] = wv::mfma(Kd[I][v], Md[J][v], Vd[I][J]);
-        }
+        // (+ K'(Qux + Quu K) of :155-158 is zero but for rounding in the constrained modes too: K's rows are exactly zero where a
+        // control is pinned or clamped, and on the free rows Qux + Quu K = 0 is what the direct solve for K just enforced --
+        // sixteen MFMAs that added 1e-7-relative noise.  The vector term K'(qu + Quu k) stays: the box QP stops at |dx| < 1e-4,
+        // its gradient on the free set is small, not rounding.)
         float mq[4] = {0.f, 0.f, 0.f, 0.f};         // m[4q + v] for this lane group (constrained modes)
         if (MODE != 0) {
             float lo4[4], hi4[4];
