@@ -366,11 +366,15 @@ def attach_traffic(rows):
             return json.load(open(os.path.join(ROOT, "profiles", "r03_prof_%s.json" % tag)))["pmc_avg_per_dispatch"]
         except Exception:
             return {}
-    kkt, cfg5, bnd = load("kkt"), load("cfg5"), load("bounded")
+    kkt, cfg5, bnd = load("kkt"), load("cfg5_final"), load("bounded")
+    # (config 5's backward is two launches: the fused kernel + the outer products; their counters add up)
+    k5, o5 = cfg5.get("lqr_kkt_fused_mfma40_kernel<0>"), cfg5.get("kkt_outer_kernel")
+    kkt5 = ({"hbm_bytes_per_dispatch": k5["hbm_bytes_per_dispatch"] + o5["hbm_bytes_per_dispatch"]}
+            if k5 and o5 and "hbm_bytes_per_dispatch" in k5 and "hbm_bytes_per_dispatch" in o5 else None)
     pick = {"lqr_step_bounded": bnd.get("lqr_step_dpp16_kernel<2>"),
             "kkt_backward_unbounded": kkt.get("lqr_kkt_fused_dpp16_kernel<false>"),
             "kkt_backward_bounded": kkt.get("lqr_kkt_fused_dpp16_kernel<true>"),
-            "cfg5_step_B1024_verified_nominal": cfg5.get("lqr_step_mfma40_kernel<0>"),
+            "cfg5_kkt_backward_B1024": kkt5,
             "cfg5_step_bounded_B1024": cfg5.get("lqr_step_mfma40_kernel<2>")}
     for key, v in pick.items():
         if v and key in rows and "roofline" in rows[key] and "hbm_bytes_per_dispatch" in v:
