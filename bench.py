@@ -297,6 +297,15 @@ def extra_rows(be, dev, steps):
                 ms=t_cold - t_touch, toucher_ms=t_touch, roofline=hbm_roofline(algorithmic_bytes_per_problem(32, 8, 64) * B5, t_cold - t_touch),
                 workload="config 5 step as cfg5_step_B1024, every launch behind a kernel that walks 800 MB of other pages")
             del big, view, plan5
+            # whole solves at this shape, like the headline's mpc_forward rows: trajectory kernel + 5 x (step + select_best)
+            for bounded5 in (False, True):
+                ctrl5 = mpc.MPC(32, 8, 64, u_lower=-1.0 if bounded5 else None, u_upper=1.0 if bounded5 else None, lqr_iter=5,
+                                verbose=-1, exit_unconverged=False, detach_unconverged=False, backprop=False)
+                cost5, dx5 = QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"])
+                wall5, ms5, _ = timed(lambda: ctrl5(p["x_init"], cost5, dx5), 12, 4)
+                rows["cfg5_mpc_forward_5iter_" + ("bounded" if bounded5 else "unbounded")] = dict(
+                    ms=ms5, wall_ms=wall5, lqr_iter=5, note="whole MPC.forward at config 5: initial trajectory kernel + 5 x (step + select_best)")
+                del ctrl5, cost5, dx5
         del p, r
     torch.cuda.empty_cache()
     # ---- configs 2 / 3: the shipped simulators, whole 10-iteration iLQR solves (L2-resident: latency-bound) ----
