@@ -10,7 +10,7 @@ import torch, bench
 from mpc import _native
 from mpc._native import StepOptions
 be = _native.HipBackend()
-NS, NC, T, B = 12, 4, 50, 4096
+NS, NC, T, B = 12, 4, 50, (int(sys.argv[1]) if len(sys.argv) > 1 else 4096)
 big = torch.zeros(800 * 1024 * 1024, dtype=torch.uint8, device="cuda:0")
 view = big[::4096]
 _, t0, _ = bench.timed(lambda: view.sum(), 50, 10)
