@@ -754,6 +754,34 @@ def test_emulated_mfma40_constrained_modes_priced_without_C(emu, case, dma_late,
         np.testing.assert_allclose(r["alpha_du_norm"], ref["alpha_du_norm"], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("max_ls", [1, 2, 16])
+@pytest.mark.parametrize("vouch", [False, True], ids=["verified", "vouched"])
+@pytest.mark.parametrize("bounded", [False, True], ids=["unbounded", "bounded"])
+def test_emulated_mfma40_line_search_lengths(emu, max_ls, vouch, bounded):
+    """max_linesearch_iter at its ends (1: the full step whatever it costs; 16: every column of the rolled-out state a trial) on a
+    non-convex problem whose full step is rejected, every rollout flavour (lean / priced from the record / priced from C)."""
+    from oracle import lqr_oracle as O
+    for attempt in range(40):
+        rng = np.random.default_rng(5 + 1000 * attempt)
+        kw = _cfg5_problem(rng, 5, 2)
+        kw["C"][:, :, :32, :32] -= 80.0 * np.eye(32)
+        if bounded:
+            kw["cur_u"] = np.clip(kw["cur_u"], -0.4, 0.4)
+            kw["cur_x"], _ = O.traj_cost(kw["x_init"], kw["cur_u"], kw["F"], kw["f"])
+        opt = dict(linesearch_decay=0.5, max_linesearch_iter=max_ls)
+        if bounded:
+            opt.update(u_lower=-0.5, u_upper=0.5)
+        o = O.lqr_step(lockstep=False, **kw, **opt)
+        if max_ls == 1 or (o["alphas"] < 1).any():
+            break
+    else:
+        assert False, "no seed made the line search backtrack"
+    r = emu.lqr_step(kernel="mfma40", dma_late=True, nominal_on_dynamics=vouch, **kw, **opt)
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+    np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=2e-2, atol=4e-3 * (1 + np.abs(o["new_u"]).max()))
+    np.testing.assert_allclose(r["costs"], o["costs"], rtol=4e-3, atol=1e-2)
+
+
 @pytest.mark.parametrize("case", ["state", "x_init", "no_f", "nan"])
 def test_emulated_mfma40_verifies_the_nominal_it_is_not_vouched_for(emu, case):
     """A bare LQRStep call at 32/8 (no MPC_OPT_NOMINAL_ON_DYNAMICS): the sweep checks x_0 = x_init and x_{t+1} = F tau + f while it
