@@ -528,7 +528,8 @@ def test_traj_cost_parity(be):
     np.testing.assert_allclose(host(cost), z["cost"], rtol=1e-12)
 
 
-@pytest.mark.parametrize("ns,nc,T,B", [(32, 8, 9, 5), (20, 4, 2, 3), (60, 4, 6, 2), (12, 4, 7, 9), (5, 2, 1, 3), (24, 8, 1, 2)])
+@pytest.mark.parametrize("ns,nc,T,B", [(32, 8, 9, 5), (20, 4, 2, 3), (60, 4, 6, 2), (12, 4, 7, 9), (5, 2, 1, 3), (24, 8, 1, 2),
+                                        (32, 8, 6, 2100)])          # (a batch that is not resident at once: the two-slot ring)
 @pytest.mark.parametrize("with_f", [True, False])
 def test_trajectory_kernels_float32(be, ns, nc, T, B, with_f):
     """util.get_traj (LinDx) in float32: the 16-lanes-per-problem kernel (n <= 16) and the wavefront-per-problem
