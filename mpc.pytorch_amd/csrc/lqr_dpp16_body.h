@@ -677,7 +677,7 @@ struct SwState {
 };
 
 template <int MODE>
-MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st, int t, Feed<MODE, false, false> &feed, Gains<rgm(MODE)> &G)
+MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st, int t, Feed<MODE, false, false> &feed, Gains<rgm(MODE)> &G PROF_ARG)
 {
     const bool last = (t == p.T - 1);
     feed.template part<0>();
@@ -712,6 +712,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         feed.template part<2>();
     }
 
+    PROF_MARK(10);              // slot 10: c_back + the products Y, Q, q
     // ---- the 4x4 control block: row-uniform copies out of lanes 12..15 --------------------------
     Sym4 S;
     S.s00 = wv::bcast<12>(Q[12]); S.s01 = wv::bcast<13>(Q[12]); S.s02 = wv::bcast<14>(Q[12]); S.s03 = wv::bcast<15>(Q[12]);
@@ -770,6 +771,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         for (int a = 0; a < 4; ++a) st.kprev[a] = kq[a];
     }
 
+    PROF_MARK(11);              // slot 11: the control block's factorisation / the box QP (slot 3 keeps the rest of the step)
     // K[:, j] = -H_free^-1 Qux[:, j]; lane 12 solves for k = -H_free^-1 qu instead
     const bool j12 = L.j == 12;
     float rhs[4], K[4];
@@ -809,10 +811,14 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     wv::sched_fence();              // the matrix-core block of the value update, undivided
 #pragma unroll
     for (int a = 0; a < 4; ++a) outer_acc(Vn, Q[12 + a], K[a]);      // += Qux[a][i] K[a][j]  (Qux = Qxu')
+#ifdef MPC_DPP16_KEEP_KM
+    // K'(Qux + Quu K) is zero but for rounding: a pinned row of K is exactly zero, a free row of the bracket is what the
+    // solve above enforced (lqr_mfma40_body.h dropped the term in round 3; diagnostic switch for the A/B)
     if (con(MODE)) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) outer_acc(Vn, K[a], M[a]);       // += K[a][i] M[a][j]
     }
+#endif
     wv::sched_fence();
     float vn = q;
     wv::fmac_bcast<12>(vn, K[0], Q[12]); wv::fmac_bcast<12>(vn, K[1], Q[13]);
@@ -1069,7 +1075,7 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
             const float d = sel(L.isu, s.tb - un1, 0.f);
             st.du21 = fmaf(d, d, st.du21);
         }
-        wv::store_out(st.out1, tp1);
+        *st.out1 = tp1;                      // (a plain store: read back by this wave within the launch, line_search)
         st.out1 += L.ostep1;
         if (!last) {
             float xn = s.fj;
@@ -1226,15 +1232,28 @@ MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, const Gain
         if (!wv::any(worse1)) {
             // trajectory of the second trial -> new_x / new_u, rows that took it (the stores of this wave's own pass
             // must have landed: they are read back through the vector path)
+            PROF_MARK_ALL(9);
             wv::fence_own_stores();
+            // COPY_N loads in flight, then their stores: one element per trip (load, wait, store) was a dependent
+            // HBM round trip per timestep -- T of them in every second wave, and the slowest wave is the kernel's time
+            enum { COPY_N = 16 };
             const float *src = L.scr0;
             float *dst = L.out0;
-            for (int t = 0; t < p.T; ++t) {
-                const float v = *src;
-                if (worse0) wv::store_out(dst, v);
-                src += L.ostep1;
-                dst += L.ostep;
+            const int T = p.T;
+            for (int t0 = 0; t0 < T; t0 += COPY_N) {
+                float v[COPY_N];
+#pragma unroll
+                for (int i = 0; i < COPY_N; ++i) {
+                    const int t = t0 + i < T ? t0 + i : T - 1;       // (tail: element T-1 again, the same value to the
+                    v[i] = src[(long)t * L.ostep1];                  //  same address: no branch per element)
+                }
+#pragma unroll
+                for (int i = 0; i < COPY_N; ++i) {
+                    const int t = t0 + i < T ? t0 + i : T - 1;
+                    if (worse0) wv::store_out(dst + (long)t * L.ostep, v[i]);
+                }
             }
+            PROF_MARK_ALL(12);          // slot 12: copy of the second trial's trajectory
             return;
         }
         const int nt = p.max_ls - 2;                                 // trials alpha = decay^2 .. decay^(max_ls-1)
@@ -1353,7 +1372,7 @@ MPC_DEV void step_wave(const P &p)
                     if (MODE == 1 && t >= AHEAD) zr = zm_fetch(p, L, t - AHEAD);
                     Feed<MODE, false, false> feed = {d, stage_mid<MODE, false, false>((i + AHEAD) % NSTAGE), t >= AHEAD, true};
                     PROF_MARK(2);
-                    sweep_step<MODE>(p, L, s, ss, t, feed, G);
+                    sweep_step<MODE>(p, L, s, ss, t, feed, G PROF_PASS);
                     if (MODE == 1) zq[(i + AHEAD) % NSTAGE] = zm_pick(L, zr);
                 }
             }

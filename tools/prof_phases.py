@@ -19,8 +19,9 @@ for B in (1024, 4096):
             r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts, impl=3, want_gains=True)
         torch.cuda.synchronize()
         prof = r["K"].reshape(-1)[: (B // 4) * 16].reshape(B // 4, 16).cpu().numpy().astype(np.float64)
-        names = ["sw_wait", "sw_lds", "sw_issue", "sw_math", "ro_wait", "ro_lds", "ro_issue", "ro_math", "setup+sweep_tail", "turn+rollout_tail"]
-        tot = prof[:, :10].sum(1)
+        names = ["sw_wait", "sw_lds", "sw_issue", "sw_rest(K,V,records)", "ro_wait", "ro_lds", "ro_issue", "ro_math", "setup+sweep_tail", "turn+rollout_tail",
+                 "sw_products", "sw_control_block(QP)", "copy_trial2"]
+        tot = prof[:, :13].sum(1)
         row = {n: round(float(prof[:, i].mean())) for i, n in enumerate(names)}
         row["total_mean"] = round(float(tot.mean())); row["total_max"] = round(float(tot.max())); row["total_min"] = round(float(tot.min()))
         out["B%d_%s" % (B, "bounded" if bounded else "unbounded")] = row
