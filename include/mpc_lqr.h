@@ -154,7 +154,7 @@ const char *mpc_lqr_last_error(void);
 
 /* Bytes of device scratch mpc_lqr_step / mpc_lqr_rollout need when out->K/k are
  * NULL (the generic path parks K,k there between sweep and rollout; the fused kernels always
- * park their gain record [T,B,64] there; the 32/8 kernel's constrained modes a record (M, Quu, m) [T,B,328] behind K | k,
+ * park their gain record [T,B,64] there; the 32/8 kernel's constrained modes a record (M, Quu, m) [T,B,328] + the second line-search trial's trajectory [T,B,40] behind K | k,
  * from which a vouched-for nominal's line search is priced without a second pass over C -- with a smaller or misaligned
  * workspace that step prices from C as the unvouched one does). */
 int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p);

@@ -116,7 +116,7 @@ static int64_t status_scratch_offset(const mpc_lqr_problem *p)
     const int64_t e = p->dtype == MPC_F64 ? 8 : 4;
     int64_t generic = ((int64_t)p->T * p->B * p->nc * p->ns + (int64_t)p->T * p->B * p->nc) * e;
     // the 32/8 kernel's constrained modes park (M, Quu, m) behind the gains for the rollout that prices without C
-    if (p->dtype == MPC_F32 && p->ns == 32 && p->nc == 8) generic += (int64_t)p->T * p->B * 328 * 4;
+    if (p->dtype == MPC_F32 && p->ns == 32 && p->nc == 8) generic += (int64_t)p->T * p->B * (328 + 40) * 4;   // + the second trial's trajectory
     const int64_t fused = (int64_t)p->T * p->B * (128 + 16) * 4;     // gain records of the fused kernels + the second
                                                                        // line-search trial's trajectory (box-constrained 12/4 kernel)
     return ((generic > fused ? generic : fused) + 15) & ~(int64_t)15;
@@ -250,7 +250,7 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
             // (M, Quu, m) record of the constrained modes: behind K | k where the workspace has the room (rollout_priced)
             sp.Kk = nullptr;
             if ((sp.bound_mode != MPC_BOUND_NONE || sp.zero_mask) && workspace && ((uintptr_t)workspace % 16 == 0) &&
-                workspace_bytes >= needK + needk + (int64_t)p->T * p->B * 328 * 4)
+                workspace_bytes >= needK + needk + (int64_t)p->T * p->B * (328 + 40) * 4)
                 sp.Kk = (real *)((char *)workspace + needK + needk);
             const int rc = mfma40_ring(sp) == 2 ? launch_step_mfma40_ring2(sp, st) : launch_step_mfma40(sp, st);
             return rc ? rc : resolve_asymmetric(sp, impl, workspace, needK, st);

@@ -105,6 +105,7 @@ constexpr unsigned KOFF_F = 0, KOFF_K = 5120, KOFF_R = 6144, KOFF_V = 6656, KSTA
 constexpr int KSLOTS = 3, KDMA_PER_STAGE = 11;                 // 5 (F) + 1 (K) + 1 (record) + 4 (V)
 // the constrained modes' record for the rollout that prices without C (rollout_priced): floats per problem-step
 constexpr int PREC = 328;                                      // M [8][32] | Quu [8][8] | m [8]
+constexpr int PSCR = 40;                                       // behind the records [T,B,PREC]: the second line-search trial's x' | u' [T,B,40]
 constexpr unsigned KLDS_TOTAL = KSLOTS * KSTAGE_BYTES;         // 31.5 KiB per wave: four waves per CU
 
 struct Stream {
@@ -1508,7 +1509,16 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
     const char *m_ptr = (const char *)(p.Kk + (long)L.b * PREC) + 16 * L.lane;
     float alpha = 1.f;
     for (int i = 0; i < L.r; ++i) alpha *= p.ls_decay;            // column r tries decay^r
-    const bool store = L.r == 0;
+    // Trial 0 (column 0) stores into new_x / new_u as it goes.  Trial 1 (alpha = decay) is the winner in most problems that
+    // reject trial 0 (box constraints: one problem in six), and with one wavefront per SIMD the slowest wavefront is the
+    // kernel's time: its column parks its trajectory behind the records, from where it is COPIED (ten 16-byte loads per lane
+    // in flight at once) instead of replayed by another pass over F and the gains; only a later winner is replayed.
+    const bool store = L.r < 2;
+    float *const scr = p.Kk + (long)T * p.B * PREC;
+    float *const xo = L.r == 0 ? p.new_x + (long)L.b * NS : scr + (long)L.b * PSCR;
+    float *const uo = L.r == 0 ? p.new_u + (long)L.b * NC : scr + (long)L.b * PSCR + NS;
+    const long xst = L.r == 0 ? (long)p.B * NS : (long)p.B * PSCR;
+    const long ust = L.r == 0 ? (long)p.B * NC : (long)p.B * PSCR;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 Xd[2], DXd[2];
 #pragma unroll
@@ -1516,7 +1526,7 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
 #pragma unroll
         for (int v = 0; v < 4; ++v) Xd[I][v] = p.x_init[(long)L.b * NS + 16 * I + 4 * L.q + v];
         DXd[I] = zero4;
-        if (store) wv::store_f32x4(p.new_x + (long)L.b * NS + 16 * I + 4 * L.q, Xd[I]);
+        if (store) wv::store_f32x4(xo + 16 * I + 4 * L.q, Xd[I]);
     }
     float dacc = 0.f;
     double cacc = 0.0;
@@ -1599,12 +1609,11 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
                 s = fmaf(du, du, s);
             }
             dacc += s;
-            if (store && uq) wv::store_f32x4(p.new_u + tb * NC + 4 * L.q, Ud);
+            if (store && uq) wv::store_f32x4(uo + (long)t * ust + 4 * L.q, Ud);
         }
         // ---- x+ = F tau' + f   (:216-222)  and  Quu e
         f32x4 H = zero4;
         if (t < T - 1) {
-            const long tb1 = (long)(t + 1) * p.B + L.b;
             f32x4 acc[2];
             float fa[2][12];
 #pragma unroll
@@ -1635,7 +1644,7 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
             wv::sched_fence();
 #pragma unroll
             for (int Im = 0; Im < 2; ++Im) {
-                if (store) wv::store_f32x4(p.new_x + tb1 * NS + 16 * Im + 4 * L.q, acc[Im]);
+                if (store) wv::store_f32x4(xo + (long)(t + 1) * xst + 16 * Im + 4 * L.q, acc[Im]);
                 const f32x4 xb = wv::lds_f32x4(rec + 160 + 4u * (unsigned)(16 * Im + 4 * L.q));
                 Xd[Im] = acc[Im];
 #pragma unroll
@@ -1676,7 +1685,31 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
     const float full2 = wv::readlane(du2, 0);
     float win_alpha = 1.f;
     for (int i = 0; i < win; ++i) win_alpha *= p.ls_decay;
-    if (win != 0) rollout_lean<MODE, true>(p, L, Kin, kin, old_cost, 0.0, win_alpha);
+    if (win == 1) {
+        // the parked trajectory -> new_x / new_u: PSCR / 4 = 10 16-byte chunks per timestep (8 of x', 2 of u'), chunk
+        // c = lane + 64 i; the tail repeats the last chunk (the same bytes to the same address)
+        wv::fence_own_stores();
+        enum { CH = 10 };
+        const int nchunk = T * (PSCR / 4);
+        for (int c0 = 0; c0 < nchunk; c0 += 64 * CH) {
+            f32x4 v[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int c = c0 + 64 * i + L.lane, cc = c < nchunk ? c : nchunk - 1;
+                const int t = cc / (PSCR / 4), k = cc - t * (PSCR / 4);
+                v[i] = *(const f32x4 *)(scr + ((long)t * p.B + L.b) * PSCR + 4 * k);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int c = c0 + 64 * i + L.lane, cc = c < nchunk ? c : nchunk - 1;
+                const int t = cc / (PSCR / 4), k = cc - t * (PSCR / 4);
+                const long tb = (long)t * p.B + L.b;
+                wv::store_f32x4(k < NS / 4 ? p.new_x + tb * NS + 4 * k : p.new_u + tb * NC + 4 * (k - NS / 4), v[i]);
+            }
+        }
+    } else if (win != 0) {
+        rollout_lean<MODE, true>(p, L, Kin, kin, old_cost, 0.0, win_alpha);
+    }
     float wc_hi = wv::readlane((float)cost, 0), wc_lo = wv::readlane((float)(cost - (double)(float)cost), 0);
     float wd = full2;
     for (int j = 1; j < 16; ++j) {                   // (uniform loop; readlane wants a constant lane only in the kernel build)

@@ -646,7 +646,7 @@ extern "C" int emu_lqr_sweep_mfma40(const mpc_lqr_problem *p, const mpc_lqr_opti
     mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, out);
     if (!(sp.ns == 32 && sp.nc == 8) || !sp.K || !sp.k) return MPC_E_DIMS;
     // the (M, Quu, m) record of the constrained modes' priced rollout (capi.hip takes it out of the workspace)
-    const size_t need = (size_t)sp.T * sp.B * mpclqr::mfma40::PREC + 4;
+    const size_t need = (size_t)sp.T * sp.B * (mpclqr::mfma40::PREC + mpclqr::mfma40::PSCR) + 4;
     float *rec = (float *)aligned_alloc(16, (need * sizeof(float) + 15) / 16 * 16);
     for (size_t i = 0; i < need; ++i) rec[i] = NAN;
     sp.Kk = g_m40_record ? rec : nullptr;

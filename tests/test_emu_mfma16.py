@@ -707,7 +707,8 @@ def test_emulated_mfma40_full_step(emu, case, dma_late, vouch, ring):
 
 @pytest.mark.parametrize("ring", ["mfma40", "mfma40_ring2"], ids=["ring3", "ring2"])
 @pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
-@pytest.mark.parametrize("case", ["bounded", "tensor_bounds", "delta_u", "masked", "bounded_T1", "bounded_T2", "bounded_backtrack", "bounded_nof"])
+@pytest.mark.parametrize("case", ["bounded", "tensor_bounds", "delta_u", "masked", "bounded_T1", "bounded_T2", "bounded_backtrack", "bounded_backtrack_once",
+                                  "bounded_nof"])
 def test_emulated_mfma40_constrained_modes_priced_without_C(emu, case, dma_late, ring):
     """The constrained step on a vouched-for nominal (what mpc.MPC hands over): every line-search trial priced by the identity
     J = J_nominal + w0 + sum e'(m + M dx) + e'Quu e / 2 from the record the sweep leaves (rollout_priced), no pass over C --
@@ -722,7 +723,7 @@ def test_emulated_mfma40_constrained_modes_priced_without_C(emu, case, dma_late,
             kw = {k: (v[:1] if k in ("C", "c", "cur_u") else (v[:0] if k in ("F", "f") else v)) for k, v in kw.items()}
         if case == "bounded_nof":
             kw["f"] = None
-        if case == "bounded_backtrack":
+        if case.startswith("bounded_backtrack"):
             kw["C"][:, :, :32, :32] -= 80.0 * np.eye(32)         # non-convex in x: the full step can make things worse
         kw["cur_u"] = np.clip(kw["cur_u"], -0.4, 0.4)
         kw["cur_x"], _ = O.traj_cost(kw["x_init"], kw["cur_u"], kw["F"], kw["f"])
@@ -736,15 +737,20 @@ def test_emulated_mfma40_constrained_modes_priced_without_C(emu, case, dma_late,
         else:
             opt.update(u_lower=-0.5, u_upper=0.5)
         o = O.lqr_step(lockstep=False, **kw, **opt)
-        if case != "bounded_backtrack" or ((o["alphas"] < 1).any() and (o["alphas"] > 0.5 ** 5).all()):
+        # (_once: some problem takes the SECOND trial, alpha = decay -- its trajectory is copied out of the scratch the trial
+        # parked it in (round 4); a later winner, as in the plain backtrack case, is replayed)
+        if case == "bounded_backtrack_once":
+            if (o["alphas"] == 0.5).any() and (o["alphas"] > 0.5 ** 5).all():
+                break
+        elif case != "bounded_backtrack" or ((o["alphas"] < 1).any() and (o["alphas"] > 0.5 ** 5).all()):
             break
     else:
         assert False, "no seed made the constrained line search backtrack"
     r = emu.lqr_step(kernel=ring, dma_late=dma_late, nominal_on_dynamics=True, **kw, **opt)
     rc = emu.lqr_step(kernel=ring, dma_late=dma_late, **kw, **opt)             # priced from C
-    if case == "bounded_backtrack":
+    if case.startswith("bounded_backtrack"):
         assert (o["alphas"] < 1).any()
-    wide = 10.0 if case == "bounded_backtrack" else 1.0
+    wide = 10.0 if case.startswith("bounded_backtrack") else 1.0
     for ref in (o, rc):
         np.testing.assert_allclose(r["alphas"], ref["alphas"], rtol=1e-6)
         np.testing.assert_allclose(r["new_x"], ref["new_x"], rtol=2e-3 * wide, atol=2e-4 * wide * (1 + np.abs(o["new_x"]).max()))

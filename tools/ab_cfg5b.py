@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         out[name] = [round((ms - t0) * 1e3, 1)]
     for rep in range(2):
         for name, fn in (("step", lambda: be.lqr_step(*a, o)), ("sweep", lambda: be.lqr_sweep(*a[:4], a[5], a[6], o)),
-                         ("step_bounded", lambda: be.lqr_step(*a, ob)),
+                         ("step_bounded", lambda: be.lqr_step(*a, ob)), ("sweep_bounded", lambda: be.lqr_sweep(*a[:4], a[5], a[6], ob)),
                          ("kkt_fused", lambda: be.kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, o)),
                          ("kkt_fused_bounded", lambda: be.kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, ob))):
             _, ms, _ = bench.timed(fn, 30, 8)
