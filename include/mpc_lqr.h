@@ -52,6 +52,11 @@ enum {
                                       problems on the generic kernels in the same call (results are the reference's,
                                       the bit stays set as information); a FORCED fused impl leaves its symmetric-C
                                       results in place and the bit tells the caller they are not the reference's.   */
+    MPC_ST_C_TESTED = 32,          /* (round 4) the kernel that solved this problem ran the symmetry test of C (the fused kernels, impl 2, 3, 5,
+                                      on a call without MPC_OPT_C_SYMMETRIC): MPC_ST_C_ASYMMETRIC clear then MEANS symmetric.  The
+                                      generic, lane-per-problem and row-per-problem kernels use C as given and never test it: without
+                                      this bit a clear MPC_ST_C_ASYMMETRIC says nothing, and a caller (mpc.MPC) must not derive the
+                                      promise MPC_OPT_C_SYMMETRIC from it.                                                       */
     MPC_ST_QUU_SINGULAR = 16       /* unconstrained solve with n_ctrl > 1 (the reference's pinverse, mpc/lqr_step.py:88-94):
                                       a pivot of Quu's factorisation was exactly zero and its control dropped out (gain 0).
                                       That is the pseudo-inverse when the null space is a coordinate axis -- a control that
@@ -167,8 +172,8 @@ int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p);
  *     n_state <= 12, n_ctrl <= 4), 3 = 4-problems-per-wave DPP kernel (f32, n_state = 12,
  *     n_ctrl = 4, 16-byte aligned blocks), 4 = one lane per problem (n_ctrl = 1, n_state <= 6, f32/f64;
  *     the only fast kernel that takes a simulator as true_dynamics), 5 = register-resident MFMA step (f32,
- *     n_state = 32, n_ctrl = 8), 6 = one wavefront per problem (the shapes of 4, f32, the problem in LDS: everything
- *     independent over t for all timesteps at once, all line-search trials at once; max_linesearch_iter <= 64; what auto
+ *     n_state = 32, n_ctrl = 8), 6 = a 16-lane row per problem (the shapes of 4, f32, the problem in LDS: everything
+ *     independent over t for all timesteps at once, all line-search trials at once; max_linesearch_iter <= 16; what auto
  *     takes instead of 4 while B is too small to fill the chip with a lane per problem).
  *     Auto picks 5, 6 / 4, 3, 2, else 1.  The fused kernels need
  *     `workspace` (mpc_lqr_workspace_bytes, 16-byte aligned); out->K / out->k are optional there. */
@@ -296,7 +301,7 @@ int mpc_mlp_linearize(const mpc_mlp_dynamics *net, int n_state, int n_ctrl, int6
  *     per-problem best-iterate select without host round trips, ONE launch.
  *     take[b] = first || cost[b] <= best_cost[b] + eps ; where taken copy x,u,cost,du-norm.
  *     `flags`: 16 bytes of device memory, 8-byte aligned.  After the call, in stream order: int32 at byte 0: bit 0 =
- *     any(take) on a call with first == 0; bit 1 = some status[b] has MPC_ST_C_ASYMMETRIC (`status` [B] = the step's
+ *     any(take) on a call with first == 0; bit 1 = C is NOT known to be symmetric: some status[b] has MPC_ST_C_ASYMMETRIC or lacks MPC_ST_C_TESTED (`status` [B] = the step's
  *     status words, may be NULL); the real at byte 8 = max_b du_norm[b] (NaN if any is).
  *     `host_flags`: NULL, or 16 bytes of page-locked host memory the device can write (hipHostMalloc): the kernel
  *     stores the same two results there as well (same offsets) and then `host_tag` at byte 4: the driver loop polls that

@@ -103,13 +103,17 @@ __global__ void __launch_bounds__(64) kkt_costate_kernel(StepParams<float> p, co
         issue(t - (NSLOT - 1), (slot + NSLOT - 1) % NSLOT);
         const long tb = (long)t * B + b;
         float r1 = cc, r2 = -gx;
-        // (C tau)[i], (C dtau)[i] for the state rows, through column i of the symmetric C
+        // (C tau)[i], (C dtau)[i] for the state rows: ROW i of C (mpc/lqr_step.py:355-383, bmv(Ct_xx, xt) + bmv(Ct_xu, ut)),
+        // 16 bytes a load.  (Rounds 2-3 read column i -- consecutive lanes, consecutive words -- which is the same numbers
+        // only for a symmetric C; the reference uses C as given and an asymmetric C is a supported input: ADVICE r03,
+        // fixtures grad_asym_cfg5_f32 / grad_asym_20_4_f32.  mpc_lqr_kkt_grads carries no options, so there is no promise to
+        // take the column read back under; the vouched route of this shape is the fused backward, lqr_mfma40_body.h.)
         for (int j = 0; j < n; j += 4) {
+            const f32x4 cr = *(const f32x4 *)(Cl + li * n + j);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float cj = Cl[(j + v) * n + li];
-                r1 = fmaf(cj, lane_bcast(tau, j + v), r1);
-                r2 = fmaf(cj, lane_bcast(d, j + v), r2);
+                r1 = fmaf(cr[v], lane_bcast(tau, j + v), r1);
+                r2 = fmaf(cr[v], lane_bcast(d, j + v), r2);
             }
         }
         if (t < T - 1) {

@@ -1383,7 +1383,7 @@ MPC_DEV void step_wave(const P &p)
     const double old_cost_d = wv::row_sum_f64(ss.oc);
     const float old_cost = (float)old_cost_d;
     // (a tolerance, not a bit test: C = A'A out of a float32 GEMM is symmetric to rounding only)
-    if (!p.c_symmetric && wv::row_max(ss.asym) > 1e-5f * wv::row_max(ss.cmax)) ss.status |= MPC_ST_C_ASYMMETRIC;
+    if (!p.c_symmetric) ss.status |= MPC_ST_C_TESTED | (wv::row_max(ss.asym) > 1e-5f * wv::row_max(ss.cmax) ? (int)MPC_ST_C_ASYMMETRIC : 0);
 
     if (p.sweep_only) {                  // MPC_OPT_SWEEP_ONLY: the caller rolls out itself (a module as true_dynamics)
         if (L.j == 0) {

@@ -643,15 +643,18 @@ __global__ void __launch_bounds__(MAX_THREADS, (sizeof(real) == 4 ? 6 : 2)) lqr_
     // p.gate (mpc_lqr_step, impl 0, after a fused kernel): a small grid walks the batch and solves only the problems the
     // fused kernel flagged as having a non-symmetric C -- usually none, and the launch is a few microseconds of reading flags
     if (p.gate) {
-        // all of this block's flags in ONE round of loads (a dependent load per problem made the empty launch 6.5 us)
-        const int mine = blockIdx.x + (int)threadIdx.x * (int)gridDim.x;
-        const int flag = (mine < p.B) ? (p.gate[mine] & MPC_ST_C_ASYMMETRIC) : 0;
+        // all of this block's flags in ONE round of loads (a dependent load per problem made the empty launch 6.5 us); the
+        // block owns b = blockIdx.x + k gridDim.x for EVERY k with b < B (the loop below), so beyond blockDim x gridDim
+        // problems (B > 65536 with the 64-thread block) the pre-check takes further rounds -- independent loads, one vote
+        int flag = 0;
+        for (long mine = (long)blockIdx.x + (long)threadIdx.x * (long)gridDim.x; mine < p.B; mine += (long)blockDim.x * (long)gridDim.x)
+            flag |= p.gate[mine] & MPC_ST_C_ASYMMETRIC;
         if (!__syncthreads_or(flag)) return;
     }
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
     if (p.gate && !(p.gate[b] & MPC_ST_C_ASYMMETRIC)) continue;
     __syncthreads();                      // the previous problem's last readers of the staging area
-    int status = p.gate ? (int)MPC_ST_C_ASYMMETRIC : 0, qp_total = 0;
+    int status = p.gate ? (int)(MPC_ST_C_ASYMMETRIC | MPC_ST_C_TESTED) : 0, qp_total = 0;      // (the fused kernel's verdict stays)
     real old_cost = 0;
     if (phase_mask & 1) {
         sweep_problem<real>(p, b, s, p.K, p.k, old_cost, qp_total, status);
@@ -1006,7 +1009,8 @@ __global__ void __launch_bounds__(256) select_best_kernel(SelectArgs<real> a, in
             if (a.first || a.costs[b] <= bc[b] + a.eps) fl |= 1;
             if (v != v) { fl |= 2; v = 0; }
             d = v > d ? v : d;
-            if (a.status && (a.status[b] & MPC_ST_C_ASYMMETRIC)) fl |= 4;
+            // C is known to be symmetric only where a kernel that TESTS it has run and found nothing (include/mpc_lqr.h)
+            if (a.status && (a.status[b] & (MPC_ST_C_ASYMMETRIC | MPC_ST_C_TESTED)) != MPC_ST_C_TESTED) fl |= 4;
         }
         for (int off = 32; off > 0; off >>= 1) {
             const real o = __shfl_down(d, off);

@@ -713,6 +713,7 @@ MPC_DEV void step_problem(const P &p)
         float m = ss.cmax;
 #pragma unroll
         for (int sh = 1; sh < 64; sh <<= 1) m = fmaxf(m, wv::shfl_xor(m, sh));
+        ss.status |= MPC_ST_C_TESTED;
         if (wv::ballot(ss.asym > 1e-5f * m) != 0ull) ss.status |= MPC_ST_C_ASYMMETRIC;
     }
 

@@ -981,6 +981,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             cmax = fmaxf(cmax, wv::shfl_xor(cmax, sh));
             asym = fmaxf(asym, wv::shfl_xor(asym, sh));
         }
+        status |= MPC_ST_C_TESTED;
         if (asym > 1e-5f * cmax) status |= MPC_ST_C_ASYMMETRIC;
     }
     if (L.lane == 0 && p.status) p.status[L.b] = status;

@@ -16,7 +16,7 @@ LIB_NAME = "libmpc_lqr_hip.so"
 
 MPC_F32, MPC_F64 = 0, 1
 BOUND_NONE, BOUND_SCALAR, BOUND_TENSOR = 0, 1, 2
-ST_PNQP_UNCONVERGED, ST_NONFINITE, ST_NOMINAL_OFF_DYNAMICS, ST_C_ASYMMETRIC, ST_QUU_SINGULAR = 1, 2, 4, 8, 16
+ST_PNQP_UNCONVERGED, ST_NONFINITE, ST_NOMINAL_OFF_DYNAMICS, ST_C_ASYMMETRIC, ST_QUU_SINGULAR, ST_C_TESTED = 1, 2, 4, 8, 16, 32
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA16, IMPL_DPP16, IMPL_TINY, IMPL_MFMA40, IMPL_WAVE1 = 0, 1, 2, 3, 4, 5, 6
 
 ABI_VERSION = 6      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
@@ -73,21 +73,31 @@ _PARAM_COPIES = {}
 
 
 def _device_copy_of(t, device, dtype):
-    """`t` on `device` as `dtype`, contiguous.  A simulator's parameter block usually lives on the host and MPC.forward asks for it
-    three times per solve: the copy is kept until the tensor is replaced or written to (its version counter moves -- an
-    optimiser step on learned parameters does that)."""
+    """`t` on `device` as `dtype`, contiguous.  A simulator's parameter block (five numbers) usually lives on the host and
+    MPC.forward asks for it three times per solve: the copy is kept while the tensor is the same object, its version counter
+    has not moved (an optimiser step moves it) AND its contents still equal the snapshot taken with the copy -- edits through
+    `params.data`, `.data.clamp_()` or a numpy alias do not move the counter.  The comparison is a few
+    microseconds for a block this small; tensors of more than 64 elements, or on another device than the host, are not
+    cached at all.  `invalidate_param_copies()` drops every cached copy."""
     if t.device == device and t.dtype == dtype and t.is_contiguous():
         return t.detach()
+    if t.numel() > 64 or t.device.type != "cpu":
+        return t.detach().to(device=device, dtype=dtype).contiguous()
     import weakref
     key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, str(device), dtype)
     hit = _PARAM_COPIES.get(key)
-    if hit is not None and hit[0]() is t and hit[1] == t._version:
+    if hit is not None and hit[0]() is t and hit[1] == t._version and torch.equal(hit[3], t.detach()):
         return hit[2]
     if len(_PARAM_COPIES) > 64:
         _PARAM_COPIES.clear()
     c = t.detach().to(device=device, dtype=dtype).contiguous()
-    _PARAM_COPIES[key] = (weakref.ref(t), t._version, c)
+    _PARAM_COPIES[key] = (weakref.ref(t), t._version, c, t.detach().clone())
     return c
+
+
+def invalidate_param_copies():
+    """Forget every cached device copy of a simulator parameter block (see _device_copy_of)."""
+    _PARAM_COPIES.clear()
 
 
 MLP_MAX_LAYERS = 4

@@ -69,8 +69,11 @@ class _FlagReader:
             self._dev = torch.empty(16, dtype=torch.uint8, device=device)
             self.device_flags = (self._dev[0:4].view(torch.int32), self._dev[8:8 + torch.empty(0, dtype=dtype).element_size()].view(dtype))
         if self.cuda:
-            # page-locking memory costs milliseconds: one block per device and stream, kept for the life of the process
-            key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+            # page-locking memory costs milliseconds: one block per device, stream AND host thread, kept for the life of the
+            # process (two solves on one stream from two threads would otherwise overwrite each other's tag and result words:
+            # ADVICE r03; within a thread solves are sequential, the tag counter tells their select calls apart)
+            import threading
+            key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
             if key not in _PINNED:
                 blk = torch.zeros(16, dtype=torch.uint8).pin_memory()
                 _PINNED[key] = [blk, blk.numpy().view("int32"), 0]

@@ -702,6 +702,8 @@ if __name__ == "__main__":
         _grad_case("grad_asym_small_f64", 4, 2, 6, 3, f64, 37, 0.4, asym=(0, 2))
         _grad_case("grad_cfg5_unconstrained_f32", 32, 8, 7, 3, f32, 38, None)
         _grad_case("grad_cfg5_constrained_f32", 32, 8, 6, 3, f32, 39, 0.3)
+        _grad_case("grad_asym_cfg5_f32", 32, 8, 6, 3, f32, 40, None, asym=(1,))
+        _grad_case("grad_asym_20_4_f32", 20, 4, 7, 3, f32, 41, 0.5, asym=(0, 2))
         sys.exit(0)
     # ---- full solves --------------------------------------------------------
     if not only or "env" in only:
@@ -730,6 +732,10 @@ if __name__ == "__main__":
     # config 5's shape (round 3: the backward fused into its nested step, lqr_mfma40_body.h)
     grad_case("grad_cfg5_unconstrained_f32", 32, 8, 7, 3, f32, 38, None)
     grad_case("grad_cfg5_constrained_f32", 32, 8, 6, 3, f32, 39, 0.3)
+    # round 4: a C that is not symmetric through the backward of the shapes kkt_wave.hip takes (its costate
+    # recursion read C by columns)
+    grad_case("grad_asym_cfg5_f32", 32, 8, 6, 3, f32, 40, None, asym=(1,))
+    grad_case("grad_asym_20_4_f32", 20, 4, 7, 3, f32, 41, 0.5, asym=(0, 2))
     jacobian_case("jac_unconstrained", 100.0)
     jacobian_case("jac_constrained", 0.5)
     # ---- pnqp / traj --------------------------------------------------------

@@ -66,7 +66,10 @@ class OracleBackend:
         res = {k: self._t(o[k], C) for k in ("new_x", "new_u", "costs", "old_costs", "full_du_norm",
                                              "alpha_du_norm", "alphas", "K", "k")}
         res["qp_iters"] = torch.full((B,), int(o["n_qp_iter"]), dtype=torch.int32)
-        res["status"] = torch.zeros(B, dtype=torch.int32)
+        # the stand-in plays a kernel that TESTS C's symmetry unless told otherwise (MPC_ST_C_TESTED = 32, include/mpc_lqr.h);
+        # `tests_c = False` plays the generic / lane-per-problem kernels, which never look
+        tested = getattr(self, "tests_c", True) and not getattr(opts, "c_symmetric", False)
+        res["status"] = torch.full((B,), 32 if tested else 0, dtype=torch.int32)
         return res
 
     def plan_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, impl=0, out_x=None, out_u=None, workspace=None):
@@ -135,7 +138,8 @@ class OracleBackend:
         best["u"][:, take] = u[:, take]
         best["costs"][take] = costs[take]
         best["full_du_norm"][take] = du_norm[take]
-        asym = status is not None and bool((status & 8).any())        # MPC_ST_C_ASYMMETRIC
+        # bit 1: C is NOT known to be symmetric -- MPC_ST_C_ASYMMETRIC (8) somewhere, or a status without MPC_ST_C_TESTED (32)
+        asym = status is not None and bool((((status & 8) != 0) | ((status & 32) == 0)).any())
         any_improved = torch.tensor([int((not first) and bool(take.any())) | (2 if asym else 0)], dtype=torch.int32)
         if flags is not None:
             flags[0].copy_(any_improved); flags[1].copy_(du_norm.max().reshape(1))

@@ -423,6 +423,23 @@ def test_mpc_promises_a_symmetric_C_only_after_the_first_step_has_checked_it(ora
     ctrl(x0, QuadCost(C, c), LinDx(F, None))
     steps = [s for s in oracle_backend.calls if s.startswith("step:")]
     assert len(steps) > 2 and set(steps) == {"step:c_unknown"} and not ctrl._c_symmetric
+    # (round 4) ... and a first step solved by a kernel that never TESTS C -- the generic, lane-per-problem and
+    # row-per-problem kernels: a 12/4 solve with max_linesearch_iter > 16, every float64 solve -- reports no
+    # MPC_ST_C_ASYMMETRIC either, which is not a verdict: without MPC_ST_C_TESTED in the status words there is no promise,
+    # and the backward keeps the route that uses C as given
+    oracle_backend.calls.clear()
+    oracle_backend.lqr_step = step
+    oracle_backend.tests_c = False
+    try:
+        Cg2 = C.clone().requires_grad_(True)
+        x2, u2, _ = ctrl(x0, QuadCost(Cg2, c), LinDx(F, None))
+        steps = [s for s in oracle_backend.calls if s.startswith("step:")]
+        assert len(steps) > 2 and set(steps) == {"step:c_unknown"} and not ctrl._c_symmetric
+        seen.clear()
+        u2.sum().backward()
+        assert not seen["opts"].c_symmetric
+    finally:
+        oracle_backend.tests_c = True
 
 
 def test_mpc_forward_never_writes_the_callers_u_init(oracle_backend):
@@ -763,3 +780,28 @@ def test_network_kernels_are_offered_only_what_they_take(monkeypatch):
     plain.native_net(like)
     assert plain.zs == []                 # the kernels do not refresh the activations grad_input re-uses
     assert CtrlPassthroughDynamics(NNDynamics(3, 1, [8])).native_net(like) is not None
+
+
+def test_cached_parameter_copy_follows_edits_the_version_counter_does_not_see():
+    """_native._device_copy_of keeps the device copy of a simulator's parameter block between the three requests of a solve.
+    In-place edits through `.data` (or a numpy alias) leave `_version` where it was: the cache must notice them
+    by content, an untouched block must keep hitting it, and the invalidate hook must empty it."""
+    from mpc import _native
+    t = torch.tensor([10.0, 1.0, 1.0], dtype=torch.float32)
+    dev, dt = torch.device("cpu"), torch.float64           # (another dtype: the same path a host -> device copy takes)
+    a = _native._device_copy_of(t, dev, dt)
+    assert _native._device_copy_of(t, dev, dt) is a                                  # unchanged: the cached copy
+    v = t._version
+    t.data.mul_(2.0)
+    assert t._version == v                                                            # the hole: no version bump ...
+    b = _native._device_copy_of(t, dev, dt)
+    assert b is not a and torch.equal(b, t.to(dt))                                    # ... and still the new numbers
+    t.numpy()[1] = 7.0                                                                # a numpy alias
+    assert float(_native._device_copy_of(t, dev, dt)[1]) == 7.0
+    t.mul_(0.5)                                                                       # an ordinary in-place op
+    c = _native._device_copy_of(t, dev, dt)
+    assert torch.equal(c, t.to(dt)) and _native._device_copy_of(t, dev, dt) is c
+    _native.invalidate_param_copies()
+    assert _native._device_copy_of(t, dev, dt) is not c
+    big = torch.zeros(65)
+    assert _native._device_copy_of(big, dev, dt) is not _native._device_copy_of(big, dev, dt)      # never cached
