@@ -397,8 +397,10 @@ class HipBackend:
 
     # -- (1) LQRStepFn.forward ------------------------------------------------------------------
     def lqr_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, want_gains=False, impl=IMPL_AUTO,
-                 rollout_problem=None):
+                 rollout_problem=None, out_x=None, out_u=None):
         """c_back + Riccati sweep + line-searched rollout.  Returns a dict of device tensors.
+        out_x / out_u: contiguous [T,B,ns] / [T,B,nc] tensors the kernel writes the new trajectory into (mpc.shard: views
+        of the all-gather's receive buffer).
 
         rollout_problem: optional (C, c, F, f) the rollout/true cost should use when they differ
         from the sweep's (mpc/lqr_step.py:218-232 reads true_dynamics / true_cost)."""
@@ -411,7 +413,11 @@ class HipBackend:
         p, keep = self._problem(x_init, C, c, F, f, cur_x, cur_u)
         o, keep_o = opts.to_struct(T, B, nc, C)
         kw = dict(device=dev, dtype=C.dtype)
-        res = dict(new_x=torch.empty(T, B, ns, **kw), new_u=torch.empty(T, B, nc, **kw),
+        if out_x is not None:
+            assert out_x.is_contiguous() and out_u.is_contiguous() and tuple(out_x.shape) == (T, B, ns) and tuple(out_u.shape) == (T, B, nc)
+            assert out_x.dtype == C.dtype and out_x.device == C.device and out_u.dtype == C.dtype and out_u.device == C.device
+        res = dict(new_x=torch.empty(T, B, ns, **kw) if out_x is None else out_x,
+                   new_u=torch.empty(T, B, nc, **kw) if out_u is None else out_u,
                    costs=torch.empty(B, **kw), old_costs=torch.empty(B, **kw),
                    full_du_norm=torch.empty(B, **kw), alpha_du_norm=torch.empty(B, **kw),
                    alphas=torch.empty(B, **kw),

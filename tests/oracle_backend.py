@@ -34,7 +34,7 @@ class OracleBackend:
     def _t(self, a, like):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dtype=like.dtype)
 
-    def lqr_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, want_gains=False, impl=0, rollout_problem=None):
+    def lqr_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, want_gains=False, impl=0, rollout_problem=None, out_x=None, out_u=None):
         assert rollout_problem is None, "oracle backend: split true-cost rollout not modelled"
         self.calls.append("lqr_step")
         T = C.shape[0]
@@ -70,6 +70,9 @@ class OracleBackend:
         # `tests_c = False` plays the generic / lane-per-problem kernels, which never look
         tested = getattr(self, "tests_c", True) and not getattr(opts, "c_symmetric", False)
         res["status"] = torch.full((B,), 32 if tested else 0, dtype=torch.int32)
+        if out_x is not None:          # (the device backend's kernel writes into the caller's buffers: mpc.shard's gather slots)
+            out_x.copy_(res["new_x"]); out_u.copy_(res["new_u"])
+            res["new_x"], res["new_u"] = out_x, out_u
         return res
 
     def plan_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, impl=0, out_x=None, out_u=None, workspace=None):

@@ -43,16 +43,36 @@ def _worker(rank, world, port, B, out_dir):
     opts = StepOptions(u_lower=lo, u_upper=hi)
     r = shard.lqr_step_sharded(x_init, C, c, F, f, cur_x, cur_u, opts)
     ref = _native.backend().lqr_step(x_init, C, c, F, f, cur_x, cur_u, opts)      # the whole batch, locally
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), block=np.array(r["block"]),
+    # the pre-sharded entry: this rank hands over ONLY its block (clones: nothing of the whole batch is reachable from them)
+    a, b = shard.shard_bounds(B, rank, world)
+    cut = lambda t, dim: t.narrow(dim, a, b - a).clone()
+    rp = shard.lqr_step_sharded(cut(x_init, 0), cut(C, 1), cut(c, 1), cut(F, 1), cut(f, 1), cut(cur_x, 1), cut(cur_u, 1),
+                                StepOptions(u_lower=cut(lo, 1), u_upper=cut(hi, 1)), presharded=True, n_batch=B)
+    # the kernel's outputs ARE the rank's slot of the collective's buffer (no packing pass), and every rank's block is
+    # readable from the slots without the assembling pass
+    vx, vu, vs = rp["slots"].views(rank)
+    own = (b == a) or (rp["local"]["new_x"].data_ptr() == vx.data_ptr() and rp["local"]["new_u"].data_ptr() == vu.data_ptr())
+    blocks_ok = all(torch.equal(rp["slots"].views(q)[0], rp["new_x"][:, shard.shard_bounds(B, q, world)[0]:shard.shard_bounds(B, q, world)[1]])
+                    for q in range(world))
+    bad = 0
+    try:        # a block that is not the one shard_bounds gives this rank is refused (every rank takes this branch: no collective inside)
+        shard.lqr_step_sharded(x_init, C, c, F, f, cur_x, cur_u, opts, presharded=True, n_batch=4 * B + 2 * world)
+    except ValueError:
+        bad = 1
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), block=np.array(r["block"]), own=int(own), blocks_ok=int(blocks_ok), refused=bad,
              **{k: r[k].numpy() for k in ("new_x", "new_u", "costs", "full_du_norm", "alphas")},
+             **{"pre_" + k: rp[k].numpy() for k in ("new_x", "new_u", "costs", "full_du_norm", "alphas")},
              **{"ref_" + k: ref[k].numpy() for k in ("new_x", "new_u", "costs", "full_du_norm", "alphas")})
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B", [8, 5])
+@pytest.mark.parametrize("B", [8, 5, 1])
 def test_two_ranks_shard_the_batch_and_gather_once(tmp_path, B):
-    """B = 5 leaves the ranks with blocks of 3 and 2 problems: the gather pads on the wire only."""
+    """B = 5 leaves the ranks with blocks of 3 and 2 problems: the slots of the gather are sized for the larger one.  B = 1 is
+    fewer problems than ranks: rank 1 solves nothing and still takes part in the collective.  Both entries -- full-batch
+    tensors cut by the rank, and (round 4) the rank's own block handed over pre-sharded -- against the whole batch solved
+    locally."""
     world = 2
     port = 29500 + (os.getpid() % 2000) + B
     mp.spawn(_worker, args=(world, port, B, str(tmp_path)), nprocs=world, join=True)
@@ -62,6 +82,8 @@ def test_two_ranks_shard_the_batch_and_gather_once(tmp_path, B):
     for g in got:
         for k in ("new_x", "new_u", "costs", "full_du_norm", "alphas"):
             np.testing.assert_allclose(g[k], g["ref_" + k], rtol=1e-12, atol=1e-12, err_msg=k)
+            np.testing.assert_allclose(g["pre_" + k], g["ref_" + k], rtol=1e-12, atol=1e-12, err_msg="pre-sharded " + k)
+        assert int(g["own"]) == 1 and int(g["blocks_ok"]) == 1 and int(g["refused"]) == 1
 
 
 def test_shard_bounds_cover_the_batch():
@@ -108,9 +130,16 @@ def _mpc_worker(rank, world, port, lockstep, out_dir):
     ctrl = mpc.MPC(ns, nc, T, u_lower=lo, u_upper=hi, lqr_iter=30, verbose=-1, exit_unconverged=False, eps=1e-6)
     x, u, costs = shard.mpc_forward_sharded(ctrl, x_init, QuadCost(C, c), LinDx(F), lockstep=lockstep)
     n_shard = len(iters)
+    # the pre-sharded entry (round 4): the rank hands over its own block of everything, the controller's tensor bounds included
+    a, b = shard.shard_bounds(B, rank, world)
+    cut = lambda t, dim: t.narrow(dim, a, b - a).clone()
+    ctrl_p = mpc.MPC(ns, nc, T, u_lower=cut(lo, 1), u_upper=cut(hi, 1), lqr_iter=30, verbose=-1, exit_unconverged=False, eps=1e-6)
+    xp, up, cp = shard.mpc_forward_sharded(ctrl_p, cut(x_init, 0), QuadCost(cut(C, 1), cut(c, 1)), LinDx(cut(F, 1)), lockstep=lockstep,
+                                           presharded=True, n_batch=B)
     del iters[:]
     xr, ur, cr = ctrl(x_init, QuadCost(C, c), LinDx(F))              # the whole batch on one rank
     np.savez(os.path.join(out_dir, "mpc_rank%d.npz" % rank), x=x.numpy(), u=u.numpy(), costs=costs.numpy(),
+             xp=xp.numpy(), up=up.numpy(), cp=cp.numpy(),
              xr=xr.detach().numpy(), ur=ur.detach().numpy(), cr=cr.detach().numpy(), n_shard=n_shard, n_full=len(iters))
     dist.barrier()
     dist.destroy_process_group()
@@ -129,6 +158,8 @@ def test_sharded_mpc_forward(tmp_path, lockstep):
         np.testing.assert_allclose(g["u"], g["ur"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(g["x"], g["xr"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(g["costs"], g["cr"], rtol=1e-6)
+        np.testing.assert_array_equal(g["xp"], g["x"]); np.testing.assert_array_equal(g["up"], g["u"])       # pre-sharded: the same solve
+        np.testing.assert_array_equal(g["cp"], g["costs"])
     np.testing.assert_array_equal(got[0]["u"], got[1]["u"])            # every rank holds the gathered result
     if lockstep:
         assert int(got[0]["n_shard"]) == int(got[1]["n_shard"]) == int(got[0]["n_full"])
