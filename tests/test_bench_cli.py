@@ -67,3 +67,84 @@ def test_parity_object_accepts_the_oracles_own_numbers_and_rejects_a_wrong_traje
     r["new_u"][3, 5, 1] += 0.01
     bad = bench.parity_check(p, r, False)
     assert not bad["ok"] and bad["max_err_over_tol_u"] > 1.0
+
+
+def _small_headline_problem(B, T=12, bounded=False, seed=3):
+    import numpy as np
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(seed)
+    ns, nc = 12, 4
+    n = ns + nc
+    A = rng.standard_normal((T, B, n, n)).astype(np.float32)
+    C = np.einsum("tbji,tbjk->tbik", A, A)
+    c = rng.standard_normal((T, B, n)).astype(np.float32)
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((T - 1, B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((T - 1, B, ns, nc)) / np.sqrt(ns)), 3).astype(np.float32)
+    f = (0.1 * rng.standard_normal((T - 1, B, ns))).astype(np.float32)
+    x0 = rng.standard_normal((B, ns)).astype(np.float32)
+    u = np.clip(0.3 * rng.standard_normal((T, B, nc)), -1, 1).astype(np.float32) if bounded else np.zeros((T, B, nc), np.float32)
+    x, _ = O.traj_cost(x0.astype(np.float64), u.astype(np.float64), F.astype(np.float64), f.astype(np.float64))
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in dict(x_init=x0, C=C, c=c, F=F, f=f, cur_x=x.astype(np.float32), cur_u=u).items()}
+
+
+def test_extra_rows_certify_themselves_box_constrained_step_and_backward():
+    """Round 4: every `extra` row that times a step or a backward carries a `parity` object.  The two
+    checkers, fed the oracle's own float32-rounded numbers (ok) and a spoiled copy (not ok): the box-constrained step with
+    its tie accounting, and the five gradients of the backward."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import lqr_oracle as O
+    p = _small_headline_problem(40, bounded=True)
+    h = [p[k].numpy().astype(np.float64) for k in ("x_init", "C", "c", "F", "f", "cur_x", "cur_u")]
+    o = O.lqr_step(*h, -1.0, 1.0, lockstep=False)
+    r = {k: torch.from_numpy(o[k].astype(np.float32)) for k in ("new_x", "new_u", "costs", "alphas")}
+    good = bench.parity_check(p, r, True, n=bench.PARITY_ROW)
+    assert good["ok"] and good["problems"] == 32 and good["active_set_ties"] == 0 and good["line_search_ties"] == 0
+    # ONE problem off (a flip of an active set looks like this) is counted, three are a failure
+    r["new_u"][2, 4, 0] += 0.05
+    one = bench.parity_check(p, r, True, n=bench.PARITY_ROW)
+    assert one["ok"] and one["active_set_ties"] == 1
+    for b in (7, 9):
+        r["new_u"][2, b, 0] += 0.05
+    assert not bench.parity_check(p, r, True, n=bench.PARITY_ROW)["ok"]
+    # ... and a problem that is off AND worse than the nominal is no tie at all
+    r = {k: torch.from_numpy(o[k].astype(np.float32)) for k in ("new_x", "new_u", "costs", "alphas")}
+    r["new_u"][2, 4, 0] += 0.05
+    r["costs"][4] = float(o["old_costs"][4]) + 10.0
+    assert not bench.parity_check(p, r, True, n=bench.PARITY_ROW)["ok"]
+    # the backward
+    nx, nu = torch.from_numpy(o["new_x"].astype(np.float32)), torch.from_numpy(o["new_u"].astype(np.float32))
+    g = torch.Generator().manual_seed(1)
+    gx, gu = torch.randn(nx.shape, generator=g), torch.randn(nu.shape, generator=g)
+    ob = O.kkt_backward(h[1], h[2], h[3], h[4], nx.numpy().astype(np.float64), nu.numpy().astype(np.float64), gx.numpy().astype(np.float64),
+                        gu.numpy().astype(np.float64), -1.0, 1.0, lockstep=False)
+    grads = {k: torch.from_numpy(ob[k].astype(np.float32)) for k in ("dx_init", "dC", "dc", "dF", "df")}
+    ok = bench.kkt_parity_check(p, nx, nu, gx, gu, grads, True)
+    assert ok["ok"] and ok["problems"] == bench.PARITY_KKT and set(ok["worst_rel"]) == {"dx_init", "dC", "dc", "dF", "df"}
+    grads["dF"][3, 2, 1, 1] += 1.0
+    assert not bench.kkt_parity_check(p, nx, nu, gx, gu, grads, True)["ok"]
+
+
+def test_cpu_baseline_times_the_unmodified_reference_where_it_is_on_the_box():
+    """north_star: "the reference timed on the host cores of the same box (core count stated) in the same run".  bench.py tries:
+    with $MPC_REFERENCE_DIR or /root/reference on the box, the unmodified LQRStep forward runs in a child interpreter on a chunk
+    of the timed batch and its float32 results are held against the timed results (here: the oracle's numbers stand in for
+    the kernel's).  The GPU box has no reference: the function then returns (None, None) and the port stands alone."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import lqr_oracle as O
+    if bench.reference_dir() is None:
+        assert bench.reference_cpu_baseline({}, False) == (None, None)
+        pytest.skip("no reference on this box")
+    p = _small_headline_problem(24, T=10)
+    row, o = bench.reference_cpu_baseline(p, False, reps=1)
+    assert o is not None, row
+    assert row["kind"] == "reference" and row["cores"] >= 1 and row["value"] > 0 and "UNMODIFIED" in row["sample"]
+    oo = O.lqr_step(*(p[k].numpy().astype(np.float64) for k in ("x_init", "C", "c", "F", "f", "cur_x", "cur_u")), None, None, lockstep=False)
+    r = dict(new_x=torch.from_numpy(oo["new_x"]), new_u=torch.from_numpy(oo["new_u"]))
+    par = bench.reference_parity(o, r, 24, False)
+    assert par["ok"] and par["asserted"] and par["share_within_tol"] == 1.0
+    r["new_u"][1, 2, 3] += 0.02
+    assert not bench.reference_parity(o, r, 24, False)["ok"]

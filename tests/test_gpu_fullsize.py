@@ -4,12 +4,12 @@ backward at B = 4096 x T = 50, one fp32 LQR step with the shipped simulators as 
 configs 2 / 3, and config 5 with more than one wave per SIMD and a partial last wave.
 
 Tolerance (BASELINE.md): float32, rtol 1e-3 / atol 1e-4 on x, u against the float64 oracle on identical inputs;
-config 5 (n = 40, T = 64) rtol 2e-3 / atol 5e-4 as in test_config5_mfma_sweep.  Two kinds of problems are compared
+config 5 (n = 40, T = 64) the same since round 4 (rounds 1-3: rtol 2e-3 / atol 5e-4).  Two kinds of problems are compared
 on their own terms because the REFERENCE ALGORITHM is discontinuous there (tools/stress_parity.py):
   * a line search whose trial cost ties with the nominal cost to rounding takes the other alpha;
   * a box QP whose minimiser sits on a bound to within rounding is "clamped" or "free" by the sign of a ~1e-7
     gradient, which zeroes or keeps a row of K.
-Both are detected from the outputs (alpha, zero rows of K), COUNTED, bounded (<= max(2, B / 500)), and still held
+Both are detected from the outputs (alpha, zero rows of K), COUNTED, bounded (<= max(2, B / 1000): observed <= 3 of 4096), and still held
 to the cost of the float64 solution; every other problem is held entry by entry.
 Each test appends its measured margins to gpurun_out/fullsize_diag.json (diagnostics only)."""
 import json
@@ -101,7 +101,8 @@ def strict_step_check(name, r, o, B, rtol=1e-3, atol=1e-4, cost_rtol=5e-4, cost_
          cost_rel_err_nontie=float(cost_err[same].max()), median_abs_cost=float(np.median(np.abs(o["costs"]))), cost_rel_err_tie=float(cost_err[ties].max()) if ties.any() else 0.0,
          unconverged_qp=int((st & 1).sum()), nonfinite=int((st & 2 != 0).sum()))
     assert (st & 2 == 0).all(), "%s: non-finite costs" % name
-    assert ties.sum() <= max(2, B // 500), "%s: %d tie problems of %d" % (name, ties.sum(), B)
+    # (observed over rounds 1-4: at most 3 of 4096, profiles/r0*_fullsize_parity_margins.json; allowed: one more)
+    assert ties.sum() <= max(2, B // 1000), "%s: %d tie problems of %d" % (name, ties.sum(), B)
     assert over == 0, "%s: %d entries beyond rtol %g / atol %g (worst x %.2f, u %.2f of the limit)" % (
         name, over, rtol, atol, worst["new_x"], worst["new_u"])
     assert cost_err[same].max() < cost_rtol, "%s: cost of a non-tie problem off by %.2e" % (name, cost_err[same].max())
@@ -316,7 +317,7 @@ def test_config5_full_waves_vs_oracle(be, mode, ring, monkeypatch):
     r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions(**kw), impl=IMPL_MFMA40,
                     want_gains=True)
     sync()
-    strict_step_check("cfg5_B1030_" + mode, r, o, B, rtol=2e-3, atol=5e-4, cost_rtol=5e-4)
+    strict_step_check("cfg5_B1030_" + mode, r, o, B, cost_rtol=5e-4)        # rtol 1e-3 / atol 1e-4: the stated tolerance (round 4)
     np.testing.assert_allclose(host(r["old_costs"]), o["old_costs"], rtol=1e-5)
     if mode.startswith("bounded"):
         assert float(r["new_u"].abs().max()) <= 0.5 + 1e-6
@@ -344,7 +345,7 @@ def test_config5_bare_call_verifies_its_nominal(be):
     sync()
     if not DRY:
         assert torch.equal((r["status"] & 4) != 0, off)
-    strict_step_check("cfg5_B1030_bare_call", r, o, B, rtol=2e-3, atol=5e-4, cost_rtol=5e-4)
+    strict_step_check("cfg5_B1030_bare_call", r, o, B, cost_rtol=5e-4)
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "3launch"])

@@ -1,5 +1,7 @@
-# rocprofv3 kernel trace + HBM-traffic counters (separate --pmc passes: FETCH_SIZE, WRITE_SIZE) of any command, summarised
-# per kernel into one JSON:   bash tools/prof_any.sh TAG 'python tools/ab_kkt.py 1'      (on the GPU box)
+# rocprofv3 kernel trace + counters (SEPARATE --pmc passes, never combined with a trace domain) of any command, summarised per
+# kernel into one JSON that records the command it profiled:
+#     bash tools/prof_any.sh TAG 'python tools/prof_one.py bounded'             (on the GPU box; -> gpurun_out/TAG/summary.json)
+#     PMC_SQ=1 bash tools/prof_any.sh TAG '...'     also the SQ passes: instruction mix, wave / wait / busy cycles
 TAG=$1; shift
 CMD="$@"
 cd /tmp && export TMPDIR=/tmp
@@ -8,10 +10,18 @@ O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $CMD > $O/kt.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- $CMD > $O/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o p -- $CMD > $O/pmc_write.log 2>&1
-python - "$O" <<'PY'
-import glob, json, sqlite3, sys
+if [ -n "$PMC_SQ" ]; then
+  timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS -d $O/pmc_sq1 -o p -- $CMD > $O/pmc_sq1.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d $O/pmc_sq2 -o p -- $CMD > $O/pmc_sq2.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY -d $O/pmc_sq3 -o p -- $CMD > $O/pmc_sq3.log 2>&1
+fi
+PROF_CMD="$CMD" python - "$O" <<'PY'
+import glob, json, os, re, sqlite3, sys
 src = sys.argv[1]
-out = {"command": open(src + "/kt.log").read()[-0:0]}
+out = {"command": os.environ.get("PROF_CMD", ""),
+       "method": "rocprofv3 --kernel-trace --stats (durations), then one separate rocprofv3 --pmc pass per counter group of the SAME command; "
+                 "counters are averages per dispatch over every dispatch of the kernel in that pass",
+       "command_stdout_tail": open(src + "/kt.log").read().strip().splitlines()[-1:]}
 con = sqlite3.connect(glob.glob(src + "/kt/**/*.db", recursive=True)[0])
 out["kernel_trace_stats"] = [dict(zip(("name", "calls", "total_us", "avg_us", "pct"), r)) for r in con.execute("select * from top_kernels limit 12")]
 for r in out["kernel_trace_stats"]:
@@ -21,19 +31,24 @@ for db in sorted(glob.glob(src + "/pmc*/**/*.db", recursive=True)):
     con = sqlite3.connect(db)
     for k, c, n, v in con.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"):
         if "mpclqr" in k:
-            import re
             short = re.sub(r"\(anonymous namespace\)::|mpclqr::|void ", "", k)
             short = re.sub(r"\(.*$", "", short)
             pm.setdefault(short, {})[c] = v
+            pm[short].setdefault("dispatches_counted", n)
 # MI355X_MICROARCH.md, HBM traffic: FETCH_SIZE counts 32-byte units for these 16-byte-per-lane loads on gfx950 and reads
 # half (x2); WRITE_SIZE in KiB-like units of 1024 B as reported.  Bytes per dispatch:
 for k, v in pm.items():
     f, w = v.get("FETCH_SIZE"), v.get("WRITE_SIZE")
     if f is not None and w is not None:
         v["hbm_bytes_per_dispatch"] = (2.0 * f + w) * 1024.0
+    # SQ counters are summed over the chip's shader engines / XCDs as rocprofv3 reports them; per-wave figures:
+    if v.get("SQ_WAVES"):
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if c in v:
+                v[c + "_per_wave"] = v[c] / v["SQ_WAVES"]
 out["pmc_avg_per_dispatch"] = pm
 json.dump(out, open(src + "/summary.json", "w"), indent=1)
-print(json.dumps(out["kernel_trace_stats"][:6], indent=0)[:1500])
+print(json.dumps(out["kernel_trace_stats"][:4], indent=0)[:900])
 print(json.dumps(pm, indent=0)[:2500])
 PY
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +200k -delete

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""ONE kind of call, launched `reps` times behind `warm` launches of the same kind -- the command tools/prof_any.sh profiles,
+so that a per-kernel average in profiles/r04_prof_*.json is the average of exactly that call kind (the
+round-3 summaries mixed sweep-only, vouched and bare calls of one kernel in one average).
+
+    python tools/prof_one.py KIND [reps [warm]]
+    KIND: headline | headline_bare | bounded | kkt | kkt_bounded | cfg5 | cfg5_bare | cfg5_bounded | cfg5_kkt | cfg5_kkt_bounded |
+          cfg5_B8192 | cfg5_bounded_B8192
+The problems are bench.py's (same seeds, same options as the rows of its `extra` object)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mpc.pytorch_amd")); sys.path.insert(0, ROOT)
+import torch
+import bench
+from mpc import _native
+from mpc._native import StepOptions
+
+kind = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+be = _native.HipBackend()
+dev = "cuda:0"
+cfg5 = kind.startswith("cfg5")
+bounded = "bounded" in kind
+bare = kind.endswith("_bare")
+ns, nc, T = (32, 8, 64) if cfg5 else (12, 4, 50)
+B = 8192 if kind.endswith("B8192") else (1024 if cfg5 else 4096)
+if cfg5:
+    p = bench.make_problem(ns, nc, T, B, torch.float32, dev, seed=9, on_device=True)
+else:
+    p = bench.make_problem(ns, nc, T, B, torch.float32, dev, seed=5, u_scale=0.3 if bounded else 0.0, clamp=1.0 if bounded else None)
+kw = dict(u_lower=-1.0, u_upper=1.0) if bounded else {}
+opts = StepOptions(**kw) if bare else StepOptions(nominal_on_dynamics=True, c_symmetric=True, **kw)
+a = (p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"])
+if "kkt" in kind:
+    r = be.lqr_step(*a, opts)
+    nx, nu = r["new_x"].clone(), r["new_u"].clone()
+    g = torch.Generator(device=dev).manual_seed(1)
+    gx, gu = torch.randn(nx.shape, generator=g, device=dev), torch.randn(nu.shape, generator=g, device=dev)
+    ko = StepOptions(c_symmetric=True, **kw)
+    fn = lambda: be.kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, ko)
+else:
+    fn = be.plan_step(*a, opts)
+for _ in range(warm):
+    fn()
+torch.cuda.synchronize()
+_, ms, _ = bench.timed(fn, reps, 0)
+print("prof_one %s: B=%d ns=%d nc=%d T=%d reps=%d warm=%d  %.4f ms per call by HIP events" % (kind, B, ns, nc, T, reps, warm, ms))
