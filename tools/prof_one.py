@@ -43,6 +43,16 @@ if "kkt" in kind:
     fn = lambda: be.kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, ko)
 else:
     fn = be.plan_step(*a, opts)
+if os.environ.get("PROF_ONE_TRACE"):
+    # the launch-by-launch picture: ms per launch over consecutive groups of 20 launches from a GPU that has just idled through
+    # the problem's set-up (boost clocks -> the power controller's dip -> the sustained state)
+    torch.cuda.synchronize()
+    groups = []
+    for g_ in range(int(os.environ["PROF_ONE_TRACE"])):
+        _, ms, _ = bench.timed(fn, 20, 0)
+        groups.append(round(ms * 1e3, 1))
+    print("prof_one %s: us per launch, consecutive groups of 20 launches: %s" % (kind, groups))
+    sys.exit(0)
 for _ in range(warm):
     fn()
 torch.cuda.synchronize()

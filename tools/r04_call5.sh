@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r04_call5
+( time python bench.py --steps 20 --warmup 5 > gpurun_out/r04_call5/bench.json 2> gpurun_out/r04_call5/bench.err ) 2>&1 | tail -3; echo "bench rc=$?"
+python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r04_call5/bench.json").read().strip().splitlines()[-1])
+print("value %.4g ms_per_step %.5f frac %.4f frac_all %.4f parity %s" % (d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["frac_all_launches"], d["parity"]["ok"]))
+for k, v in d.get("extra", {}).items():
+    if isinstance(v, dict):
+        print("  %-42s ms %-9s all %-9s frac %-7s parity %s" % (k, "%.4f" % v["ms"] if "ms" in v else "-", "%.4f" % v["ms_all_launches"] if "ms_all_launches" in v else "-", "%.3f" % v["roofline"]["frac"] if "roofline" in v else "-", v["parity"].get("ok") if "parity" in v else "-"))
+PY
+tail -3 gpurun_out/r04_call5/bench.err
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "north_star or select_best" 2>&1 | tail -3
