@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64) kkt_outer_kernel(StepParams<float> p, cons
         sv[3][lane] = dFt[ns + lane];
     }
     __syncthreads();
-    if (lane < n) dc[tb * n + lane] = -d;                                         // :352-353
+    if (lane < n) __builtin_nontemporal_store(-d, dc + tb * n + lane);                                         // :352-353
     // dC_t = -0.5 (dtau tau' + tau dtau')   (:346-351), four consecutive columns per lane
     float *dCt = dC + tb * (long)(n * n);
     for (int e = 4 * lane; e < n * n; e += 256) {
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(64) kkt_outer_kernel(StepParams<float> p, cons
         f32x4 o;
 #pragma unroll
         for (int v = 0; v < 4; ++v) o[v] = -0.5f * fmaf(di, tj[v], ti * dj[v]);
-        *(f32x4 *)(dCt + e) = o;
+        __builtin_nontemporal_store(o, (f32x4 *)(dCt + e));          // (write-once gradients: see store_f32x2_out, lqr_dpp16.hip)
     }
     // dF_t = -(dlam_{t+1} tau' + lam_{t+1} dtau')   (:387-396)
     if (have) {
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(64) kkt_outer_kernel(StepParams<float> p, cons
             f32x4 o;
 #pragma unroll
             for (int v = 0; v < 4; ++v) o[v] = -fmaf(dli, tj[v], li * dj[v]);
-            *(f32x4 *)(dFt + e) = o;
+            __builtin_nontemporal_store(o, (f32x4 *)(dFt + e));
         }
     }
 }

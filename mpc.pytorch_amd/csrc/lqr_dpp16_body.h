@@ -1557,8 +1557,8 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
                     if (L.live) {
                         float *dst = k.dF + tb * 192 + L.j;
 #pragma unroll
-                        for (int r = 0; r < 12; ++r) wv::store_f32_out(dst + 16 * r, col[r]);
-                        if (k.df && L.j < 12) k.df[tb * 12 + L.j] = -dlam;
+                        for (int r = 0; r < 12; ++r) wv::store_f32_grad(dst + 16 * r, col[r]);
+                        if (k.df && L.j < 12) wv::store_f32_grad(k.df + tb * 12 + L.j, -dlam);
                     }
                 }
                 // dC_t, dc_t: -0.5 (dtau tau' + tau dtau') is symmetric, row j = column j
@@ -1569,8 +1569,8 @@ MPC_DEV void kkt_wave(const P &p, const KktArgs &k)
                     if (L.live) {
                         float *dst = k.dC + tb * 256 + L.j;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) wv::store_f32_out(dst + 16 * r, col[r]);
-                        k.dc[tb * 16 + L.j] = -dj;
+                        for (int r = 0; r < 16; ++r) wv::store_f32_grad(dst + 16 * r, col[r]);
+                        wv::store_f32_grad(k.dc + tb * 16 + L.j, -dj);
                     }
                 }
                 // costate recursions (rows 0..11 of C; F_x = first 12 columns of F)
@@ -2017,15 +2017,15 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
 #else
                 if (L.live) {
 #endif
-                    if (so_p) wv::store_f32_out(so_p, dj);
+                    if (so_p) wv::store_f32_grad(so_p, dj);
                     if (have) {
 #pragma unroll
                         for (int r = 0; r < 6; ++r) wv::store_f32x2_out(dF_p + 32 * r, pF0[r], pF1[r]);
-                        if (df_p && xs_lane) wv::store_f32_out(df_p, -dl1);
+                        if (df_p && xs_lane) wv::store_f32_grad(df_p, -dl1);
                     }
 #pragma unroll
                     for (int r = 0; r < 8; ++r) wv::store_f32x2_out(dC_p + 32 * r, pC0[r], pC1[r]);
-                    wv::store_f32_out(dc_p, -dj);
+                    wv::store_f32_grad(dc_p, -dj);
                 }
                 if (so_p) so_p += so_step;
                 dC_p += B * 256;
