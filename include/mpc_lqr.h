@@ -174,8 +174,11 @@ int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p);
  *     the only fast kernel that takes a simulator as true_dynamics), 5 = register-resident MFMA step (f32,
  *     n_state = 32, n_ctrl = 8), 6 = a 16-lane row per problem (the shapes of 4, f32, the problem in LDS: everything
  *     independent over t for all timesteps at once, all line-search trials at once; max_linesearch_iter <= 16; what auto
- *     takes instead of 4 while B is too small to fill the chip with a lane per problem).
- *     Auto picks 5, 6 / 4, 3, 2, else 1.  The fused kernels need
+ *     takes instead of 4 while B is too small to fill the chip with a lane per problem), 7 = the kernel of 5 for ANY
+ *     n_state <= 32, n_ctrl <= 8 (f32; round 4): tau is padded to [x(32); u(8)] by the staging gathers, every mode of 5
+ *     (bounds, u_zero_I, delta_u, bare or vouched nominal); needs the workspace of mpc_lqr_workspace_bytes.
+ *     Auto picks 5, 6 / 4, 3, 2, 7, else 1 (float64, n_state > 32 or n_ctrl > 8, max_linesearch_iter > 16, a simulator
+ *     beyond n_ctrl = 1).  The fused kernels need
  *     `workspace` (mpc_lqr_workspace_bytes, 16-byte aligned); out->K / out->k are optional there. */
 int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
                  void *workspace, int64_t workspace_bytes, int impl, void *stream);

@@ -110,6 +110,9 @@ static int check_options(const mpc_lqr_problem *p, const mpc_lqr_options *o)
     return MPC_OK;
 }
 
+// floats of the padded 32/8 instantiation's workspace: K [T,B,8,32] | k [T,B,8] | (M, Quu, m) [T,B,328] | second trial [T,B,40]
+static int64_t pad_workspace_bytes(int T, int B) { return (int64_t)T * B * (256 + 8 + 328 + 40) * 4; }
+
 // where a caller's missing status array lives inside the workspace: behind the larger of the two uses of it
 static int64_t status_scratch_offset(const mpc_lqr_problem *p)
 {
@@ -117,6 +120,11 @@ static int64_t status_scratch_offset(const mpc_lqr_problem *p)
     int64_t generic = ((int64_t)p->T * p->B * p->nc * p->ns + (int64_t)p->T * p->B * p->nc) * e;
     // the 32/8 kernel's constrained modes park (M, Quu, m) behind the gains for the rollout that prices without C
     if (p->dtype == MPC_F32 && p->ns == 32 && p->nc == 8) generic += (int64_t)p->T * p->B * (328 + 40) * 4;   // + the second trial's trajectory
+    // its padded instantiation (any n_state <= 32, n_ctrl <= 8): the kernel's own padded gains [T,B,8,32] | [T,B,8] + the same records
+    else if (p->dtype == MPC_F32 && p->ns <= 32 && p->nc <= 8) {
+        const int64_t pad = pad_workspace_bytes(p->T, p->B);
+        generic = generic > pad ? generic : pad;
+    }
     const int64_t fused = (int64_t)p->T * p->B * (128 + 16) * 4;     // gain records of the fused kernels + the second
                                                                        // line-search trial's trajectory (box-constrained 12/4 kernel)
     return ((generic > fused ? generic : fused) + 15) & ~(int64_t)15;
@@ -138,6 +146,14 @@ static int resolve_asymmetric(StepParams<real> sp, int impl, void *workspace, in
     }
     return launch_step_generic<real>(sp, sp.sweep_only ? 1 : 3, st);
 }
+
+// may this call take the padded 32/8 instantiation?  (shape and options: mfma40_pad_supported; its workspace: the padded gains
+// and the constrained modes' records, 16-byte aligned)
+static bool pad_route(const StepParams<float> &sp, const void *workspace, int64_t workspace_bytes)
+{
+    return mfma40_pad_supported(sp) && workspace && ((uintptr_t)workspace % 16 == 0) && workspace_bytes >= pad_workspace_bytes(sp.T, sp.B);
+}
+static bool pad_route(const StepParams<double> &, const void *, int64_t) { return false; }
 
 template <typename real>
 static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
@@ -164,6 +180,7 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
         bool fused = false;
         if constexpr (sizeof(real) == 4) fused = (impl == 0 || impl == 3) ? dpp16_supported(sp) : false;
         if constexpr (sizeof(real) == 4) fused = fused || ((impl == 0 || impl == 5) && mfma40_supported(sp));
+        if constexpr (sizeof(real) == 4) fused = fused || ((impl == 0 || impl == 7) && pad_route(sp, workspace, workspace_bytes));
         if (!fused) {
             if (impl != 0 && impl != 1) return fail(MPC_E_ARG, "MPC_OPT_SWEEP_ONLY: this kernel cannot stop after its sweep");
             return launch_step_generic<real>(sp, 1, st);
@@ -235,6 +252,26 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
             return fail(MPC_E_DTYPE, "the fused kernels are fp32 only");
         }
     }
+    if constexpr (sizeof(real) == 4) {
+        // Every float32 shape up to 32/8 that has no kernel of its own (13/4, 20/5, 24/8, 32/4, 8/6 ...): the 32/8 kernel's
+        // PADDED instantiation (lqr_mfma40_body.h, PADK) -- the reference's sweep is shape-agnostic (mpc/lqr_step.py:61-158), and
+        // between the hand-tuned shapes the generic kernel ran at 4 % of the roofline (missing 1)
+        if (impl == 7 && !(phase_mask == 3 && pad_route(sp, workspace, workspace_bytes)))
+            return fail(MPC_E_DIMS, "padded MFMA kernel needs fp32, n_state <= 32, n_ctrl <= 8, max_linesearch_iter <= 16, no simulator, and the "
+                                    "workspace of mpc_lqr_workspace_bytes (16-byte aligned)");
+        if (phase_mask == 3 && (impl == 7 || (impl == 0 && !mfma40_supported(sp))) && pad_route(sp, workspace, workspace_bytes)) {
+            if ((sp.K == nullptr) != (sp.k == nullptr)) return fail(MPC_E_NULL, "pass both K and k, or neither");
+            StepParams<float> q = sp;
+            const int64_t TB = (int64_t)p->T * p->B;
+            q.K_user = sp.K;
+            q.k_user = sp.k;
+            q.K = (float *)workspace;
+            q.k = q.K + TB * 256;
+            q.Kk = q.k + TB * 8;
+            const int rc = mfma40_pad16_supported(q) ? launch_step_mfma40_pad16(q, st) : launch_step_mfma40_pad4(q, st);
+            return rc ? rc : resolve_asymmetric(sp, impl, workspace, needK, st);
+        }
+    }
     if (!sp.K || !sp.k) {
         if (phase_mask != 3) return fail(MPC_E_NULL, "K / k is NULL");
         if (!workspace || workspace_bytes < needK + needk)
@@ -271,7 +308,7 @@ int mpc_lqr_abi_version(void) { return MPC_LQR_ABI_VERSION; }
 const char *mpc_lqr_build_info(void)
 {
     return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32>, lqr_step_dpp16<f32>, "
-           "lqr_step_tiny<f32,f64>, lqr_step_wave1<f32>, lqr_step_mfma40<f32>, nn_rollout<f32>, nn_linearize<f32>, env_linearize, kkt_grads, kkt_fused<f32>, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
+           "lqr_step_tiny<f32,f64>, lqr_step_wave1<f32>, lqr_step_mfma40<f32>, lqr_step_mfma40_padded<f32>, nn_rollout<f32>, nn_linearize<f32>, env_linearize, kkt_grads, kkt_fused<f32>, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
 }
 
 const char *mpc_lqr_last_error(void) { return g_last_error.c_str(); }
@@ -309,6 +346,12 @@ int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, i
         memset(&out, 0, sizeof(out));
         StepParams<float> sp = make_params<float>(p, o, &out);
         return (sp.ns == 32 && sp.nc == 8 && !sp.env.kind) ? 1 : 0;
+    }
+    if (impl == 7) {
+        if (p->dtype != MPC_F32) return 0;
+        mpc_lqr_outputs out;
+        memset(&out, 0, sizeof(out));
+        return mfma40_pad_supported(make_params<float>(p, o, &out)) ? 1 : 0;
     }
     if (impl == 2 || impl == 3) {
         if (p->dtype != MPC_F32) return 0;

@@ -78,6 +78,12 @@ int launch_kkt_outer(const StepParams<float> &p, const float *dx, const float *d
 bool mfma40_supported(const StepParams<float> &p);
 int launch_step_mfma40(const StepParams<float> &p, hipStream_t st);            // three-slot sweep ring (36 KiB per wave: four per CU)
 int launch_step_mfma40_ring2(const StepParams<float> &p, hipStream_t st);      // two slots (26 KiB: six per CU), see capi.hip
+// the same kernel for ANY n_state <= 32, n_ctrl <= 8 (round 4): tau padded to [x(32); u(8)] by the staging gathers
+// (lqr_mfma40_body.h, PADK); p.K / p.k = the kernel's own padded gains [T,B,8,32] / [T,B,8], p.K_user / p.k_user the caller's
+bool mfma40_pad_supported(const StepParams<float> &p);
+bool mfma40_pad16_supported(const StepParams<float> &p);                        // ... with 16-byte gathers (n_state, n_ctrl multiples of 4)
+int launch_step_mfma40_pad4(const StepParams<float> &p, hipStream_t st);
+int launch_step_mfma40_pad16(const StepParams<float> &p, hipStream_t st);
 // the KKT backward of that shape: the nested step with both costates riding along + kkt_outer_kernel (lqr_mfma40.hip, -DMPC_MFMA40_KKT)
 bool kkt_fused_mfma40_supported(const StepParams<float> &p, const float *dl_dx, const float *dl_du, const float *dC,
                                 const float *dF, const float *ws);

@@ -108,6 +108,30 @@ template <int IMM> MPC_DEV void dma16_at_if(bool active, const void *g, unsigned
 {
     if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage40 + off), 16, IMM, 0);
 }
+// ---- the padded instantiation's staging (lqr_mfma40_body.h, PADK) -------------------------------------------------------------
+// G bytes per lane from `base + voff` (base wave-uniform: a raw buffer of `nbytes`, voff per lane) to LDS offset `off` + G * lane.
+// A lane whose voff lies beyond the buffer writes ZERO (the hardware's range check; measured, tools/ubench/buffer_lds_probe.hip):
+// that is the zero padding of the kernel's 40 x 40 / 32 x 40 blocks, at no instruction.
+template <int G> MPC_DEV void dma_buf(bool active, const void *base, unsigned nbytes, unsigned voff, unsigned off)
+{
+    static_assert(G == 4 || G == 16, "dword or dwordx4");
+    if (active) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)nbytes, 0x00020000);
+        if constexpr (G == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(g_stage40 + off), 4, (int)voff, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(g_stage40 + off), 16, (int)voff, 0, 0, 0);
+    }
+}
+// a dword to `base + voff` through a raw buffer of `nbytes`: a lane whose voff lies beyond the buffer stores nothing
+MPC_DEV void st_buf(float *base, unsigned nbytes, unsigned voff, float v)
+{
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)nbytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)voff, 0, 0);
+}
+MPC_DEV void dma4_if(bool active, const void *g, unsigned off)
+{
+    if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage40 + off), 4, 0, 0);
+}
+MPC_DEV void lds_store_f32x4(unsigned off, f32x4 v) { *(f32x4 *)(g_stage40 + off) = v; }
 MPC_DEV float lds_f32(unsigned off) { return *(const float *)(g_stage40 + off); }
 MPC_DEV f32x4 lds_f32x4(unsigned off) { return *(const f32x4 *)(g_stage40 + off); }
 MPC_DEV void lds_store_f32(unsigned off, float v) { *(float *)(g_stage40 + off) = v; }
@@ -204,6 +228,49 @@ template <int MODE> __global__ void __launch_bounds__(64, 1) lqr_step_mfma40_ker
 
 }  // namespace
 
+#ifdef MPC_MFMA40_PAD
+// ---- the padded instantiation (two more compilations of this file: -DMPC_MFMA40_PAD=4 / =16, both on the two-slot sweep ring) ----
+#if MPC_MFMA40_PAD == 4
+// any n_state <= 32, n_ctrl <= 8 in float32: every staging access is a dword, nothing but 4-byte alignment is asked for
+bool mfma40_pad_supported(const StepParams<float> &p)
+{
+    return p.ns >= 1 && p.ns <= 32 && p.nc >= 1 && p.nc <= 8 && p.T >= 1 && p.max_ls >= 1 && p.max_ls <= 16 && !p.env.kind &&
+           !(p.bound_mode != MPC_BOUND_NONE && p.zero_mask) &&
+           (p.bound_mode != MPC_BOUND_TENSOR || ((((uintptr_t)p.lo | (uintptr_t)p.hi) & 3) == 0));
+}
+// ... with 16-byte gathers: rows of C and F and the x | u boundary on 16 bytes
+bool mfma40_pad16_supported(const StepParams<float> &p)
+{
+    auto al = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+    return p.ns % 4 == 0 && p.nc % 4 == 0 && al(p.C) && (p.T == 1 || al(p.F)) && p.C_st % 4 == 0 && p.C_sb % 4 == 0 &&
+           p.F_st % 4 == 0 && p.F_sb % 4 == 0;
+}
+#define MPC_MFMA40_LAUNCH launch_step_mfma40_pad4
+#else
+bool mfma40_pad_supported(const StepParams<float> &p);
+#define MPC_MFMA40_LAUNCH launch_step_mfma40_pad16
+#endif
+// p.K / p.k: the kernel's own padded gains [T,B,8,32] / [T,B,8] (16-byte aligned, workspace); p.K_user / p.k_user the caller's
+int MPC_MFMA40_LAUNCH(const StepParams<float> &p, hipStream_t st)
+{
+    if (!mfma40_pad_supported(p)) { set_last_error("mfma40 (padded): needs fp32, n_state <= 32, n_ctrl <= 8, max_linesearch_iter <= 16, no simulator"); return MPC_E_DIMS; }
+    if (!p.K || !p.k || (!p.sweep_only && (!p.new_x || !p.new_u))) { set_last_error("mfma40 (padded): K / k / new_x / new_u missing"); return MPC_E_NULL; }
+    if (((uintptr_t)p.K & 15) || ((uintptr_t)p.k & 15)) { set_last_error("mfma40 (padded): the gain workspace must be 16-byte aligned"); return MPC_E_ARG; }
+    if (p.bound_mode != MPC_BOUND_NONE)
+        hipLaunchKernelGGL(lqr_step_mfma40_kernel<2>, dim3(p.B), dim3(64), 0, st, p);
+    else if (p.zero_mask)
+        hipLaunchKernelGGL(lqr_step_mfma40_kernel<1>, dim3(p.B), dim3(64), 0, st, p);
+    else
+        hipLaunchKernelGGL(lqr_step_mfma40_kernel<0>, dim3(p.B), dim3(64), 0, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error((std::string("lqr_step_mfma40_kernel (padded): ") + hipGetErrorString(e)).c_str());
+        return MPC_E_LAUNCH;
+    }
+    return MPC_OK;
+}
+}  // namespace mpclqr
+#else
 #if MPC_MFMA40_SWEEP_NSTAGE == 3
 bool mfma40_supported(const StepParams<float> &p)
 {
@@ -246,4 +313,5 @@ int MPC_MFMA40_LAUNCH(const StepParams<float> &p, hipStream_t st)
 }
 
 }  // namespace mpclqr
+#endif
 #endif

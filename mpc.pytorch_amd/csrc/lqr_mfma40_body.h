@@ -73,17 +73,55 @@ constexpr int NSTAGE = 2;      // slots of the pricing rollout's LDS-DMA ring: o
 #endif
 constexpr int SNSTAGE = MPC_MFMA40_SWEEP_NSTAGE;
 constexpr unsigned OFF_C = 0, OFF_F = 6400, OFF_R = 11520, STAGE_BYTES = 12032;   // (the record: 320 B, 448 B in the fused backward)
-constexpr int DMA_PER_STAGE = 13;                           // 7 (C) + 5 (F) + 1 (c | x | u)
+// ---- The PADDED instantiation (round 4; -DMPC_MFMA40_PAD=4|16, lqr_mfma40.hip): any n_state <= 32, n_ctrl <= 8 -----------------
+// The reference's sweep is shape-agnostic (mpc/lqr_step.py:61-158); rounds 1-3 had fast kernels for exactly 12/4 and 32/8 and a
+// generic kernel at 4 % of the roofline for everything between.  Here the 32/8 kernel runs ANY smaller shape: tau is padded to
+// [x(32); u(8)] -- state i at slot i, control a at slot 32 + a, zeros elsewhere, an identity on the padded diagonal of Quu --
+// and the padding is done BY THE STAGING DMA: every stage is gathered with `buffer_load ... lds`, whose per-lane source offset
+// is free and whose out-of-range lanes write ZERO into LDS (measured, tools/ubench/buffer_lds_probe.hip).  LDS therefore
+// holds the dense 40 x 40 / 32 x 40 blocks the kernel was written for and nothing downstream of the staging changes; only
+// what touches the caller's arrays directly (x_init, bounds, masks, the trajectory and gain outputs) indexes by the true shape.
+// PADG = bytes a lane moves per gather instruction: 16 when n_state and n_ctrl are multiples of 4 (rows and the x | u boundary
+// are then 16-byte aligned: the same instruction count as the exact kernel), 4 for every other shape.
+#ifdef MPC_MFMA40_PAD
+constexpr bool PADK = true;
+constexpr int PADG = MPC_MFMA40_PAD;
+#else
+constexpr bool PADK = false;
+constexpr int PADG = 16;
+#endif
+static_assert(PADG == 4 || PADG == 16, "gather granule");
+constexpr int CH_C = PADK ? (N * N * 4 + 64 * PADG - 1) / (64 * PADG) : 7;      // gather instructions of a C block (25 | 7)
+constexpr int CH_F = PADK ? (NS * N * 4 + 64 * PADG - 1) / (64 * PADG) : 5;     // ... of an F block (20 | 5)
+constexpr int CH_R = PADK ? 2 : 1;                                               // ... of a record (dwords: 2 x 64 words)
+constexpr int DMA_PER_STAGE = CH_C + CH_F + CH_R;           // 13 = 7 (C) + 5 (F) + 1 (c | x | u) in the exact kernel
 // rollout stage: C | F | K_t (1 KiB) | record (c, x_{t+1}, u_t, f_t, k_t)
 constexpr unsigned ROFF_K = 11520, ROFF_R = 12544, RSTAGE_BYTES = 13056;
-constexpr int RDMA_PER_STAGE = 14;                          // 7 (C) + 5 (F) + 1 (K) + 1 (record)
+constexpr int RDMA_PER_STAGE = CH_C + CH_F + 1 + CH_R;      // 14 = 7 (C) + 5 (F) + 1 (K) + 1 (record)
+static_assert((SNSTAGE - 1) * DMA_PER_STAGE < 64 && RDMA_PER_STAGE < 64, "vmcnt is 6 bits: the dword gather needs the two-slot sweep ring");
 constexpr unsigned OFF_SCR = SNSTAGE * STAGE_BYTES > NSTAGE * RSTAGE_BYTES ? SNSTAGE * STAGE_BYTES : NSTAGE * RSTAGE_BYTES;   // 512 B: row -> column layout turns
 constexpr unsigned LDS_TOTAL = OFF_SCR + 512;
 typedef StepParams<float> P;
 // the flags of controls 4w .. 4w+3 of u_zero_I [T,B,8] at (t, b) = tb
 MPC_DEV unsigned zero_mask_word(const P &p, long tb, int w)
 {
+#ifdef MPC_MFMA40_PAD
+    // u_zero_I [T,B,nc] bytes at any nc: the byte of control a out of the aligned dword that holds it (scalar loads want
+    // 4-byte alignment); padded controls are free (their row of Quu is the identity, they stay at zero)
+    unsigned z = 0u;
+    const int nc = p.nc;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int a = 4 * w + v;
+        const unsigned long A = (unsigned long)(p.zero_mask + tb * nc + (a < nc ? a : 0));
+        const unsigned word = wv::load_uniform_u32((const unsigned *)(A & ~3ul));
+        const unsigned byte = (word >> (8u * (unsigned)(A & 3ul))) & 0xffu;
+        z |= (a < nc && byte != 0u) ? (1u << (8 * v)) : 0u;
+    }
+    return z;
+#else
     return wv::load_uniform_u32((const unsigned *)(p.zero_mask + tb * 8) + w);
+#endif
 }
 
 struct Lane {
@@ -108,17 +146,171 @@ constexpr int PREC = 328;                                      // M [8][32] | Qu
 constexpr int PSCR = 40;                                       // behind the records [T,B,PREC]: the second line-search trial's x' | u' [T,B,40]
 constexpr unsigned KLDS_TOTAL = KSLOTS * KSTAGE_BYTES;         // 31.5 KiB per wave: four waves per CU
 
+// ---- staging of the padded instantiation ---------------------------------------------------------------------------------
+constexpr unsigned OOB_OFF = 0x7fffff00u;          // a source offset beyond every block: the gather writes zero there
+// slot of the padded tau = [x(32); u(8)] -> index in the caller's tau = [x(ns); u(nc)], or -1 (padding)
+MPC_DEV int pad_tau(int pi, int ns, int nc) { return pi < NS ? (pi < ns ? pi : -1) : (pi - NS < nc ? ns + (pi - NS) : -1); }
+struct Gather {
+    unsigned coff[CH_C], foff[CH_F];        // source byte offset of this lane's granule of chunk k inside C_t / F_t (OOB_OFF: padding)
+    unsigned cbytes, fbytes;                // bytes of the caller's C_t [n,n] and F_t [ns,n] blocks
+};
+MPC_DEV void gather_init(Gather &g, const P &p, int lane)
+{
+    const int ns = p.ns, nc = p.nc, n = ns + nc;
+    g.cbytes = (unsigned)(n * n * 4);
+    g.fbytes = (unsigned)(ns * n * 4);
+    constexpr int WPL = PADG / 4;           // words per lane and instruction
+#pragma unroll
+    for (int k = 0; k < CH_C; ++k) {
+        const int w = (64 * k + lane) * WPL, pi = w / N, pj = w - pi * N;
+        const int ai = pi < N ? pad_tau(pi, ns, nc) : -1, aj = pad_tau(pj, ns, nc);
+        // (16-byte granules: ns, nc multiples of 4 -- a granule is four valid consecutive columns or four padded ones)
+        g.coff[k] = (ai >= 0 && aj >= 0) ? (unsigned)(4 * (ai * n + aj)) : OOB_OFF;
+    }
+#pragma unroll
+    for (int k = 0; k < CH_F; ++k) {
+        const int w = (64 * k + lane) * WPL, pi = w / N, pj = w - pi * N;
+        const int aj = pad_tau(pj, ns, nc);
+        g.foff[k] = (pi < ns && aj >= 0) ? (unsigned)(4 * (pi * n + aj)) : OOB_OFF;
+    }
+}
+// the C_t / F_t block at `blk` (wave-uniform) into the dense 40 x 40 / 32 x 40 layout at LDS offset `off`
+MPC_DEV void gather_C(const Gather &g, const float *blk, unsigned off, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < CH_C; ++k)
+        wv::dma_buf<PADG>((64 * k + lane) * (PADG / 4) < N * N, blk, g.cbytes, g.coff[k], off + (unsigned)(64 * PADG * k));
+}
+MPC_DEV void gather_F(const Gather &g, const float *blk, unsigned nbytes, unsigned off)
+{
+#pragma unroll
+    for (int k = 0; k < CH_F; ++k) wv::dma_buf<PADG>(true, blk, nbytes, g.foff[k], off + (unsigned)(64 * PADG * k));
+}
+// The record (the small vectors of a timestep: c | x | u | f | k at words 0, 40, 72, 80, 112 of its 128) gathered dword by
+// dword: lane l fetches words l and 64 + l, each from its own array (or sits the instruction out: padding stays the zero
+// pad_clear left there).  kind: which timestep index the word follows (0: t, 1: min(t, T-2) -- f has T-1 entries, 2: t + 1).
+struct RecMap {
+    const char *ptr[2];
+    long step[2];
+    int kind[2];
+    bool act[2];
+};
+// x_next: the x segment holds x_{t+1} (rollouts) instead of x_t (sweep); with_c / with_f / kin: which segments this pass reads
+MPC_DEV void rec_init(RecMap &m, const P &p, int lane, long b, bool with_c, bool x_next, bool with_f, const float *kin)
+{
+    const int ns = p.ns, nc = p.nc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int w = 64 * j + lane;
+        m.ptr[j] = (const char *)p.cur_x;
+        m.step[j] = 0;
+        m.kind[j] = 0;
+        m.act[j] = false;
+        if (w < 40) {
+            const int a = pad_tau(w, ns, nc);
+            if (with_c && a >= 0) { m.act[j] = true; m.ptr[j] = (const char *)(p.c + b * p.c_sb + a); m.step[j] = p.c_st * 4; }
+        } else if (w < 72) {
+            const int i = w - 40;
+            if (i < ns) { m.act[j] = true; m.ptr[j] = (const char *)(p.cur_x + b * ns + i); m.step[j] = (long)p.B * ns * 4; m.kind[j] = x_next ? 2 : 0; }
+        } else if (w < 80) {
+            const int a = w - 72;
+            if (a < nc) { m.act[j] = true; m.ptr[j] = (const char *)(p.cur_u + b * nc + a); m.step[j] = (long)p.B * nc * 4; }
+        } else if (w < 112) {
+            const int i = w - 80;
+            if (with_f && p.f != nullptr && p.T > 1 && i < ns) {
+                m.act[j] = true; m.ptr[j] = (const char *)(p.f + b * p.f_sb + i); m.step[j] = p.f_st * 4; m.kind[j] = 1;
+            }
+        } else if (w < 120) {
+            if (kin) { m.act[j] = true; m.ptr[j] = (const char *)(kin + b * NC + (w - 112)); m.step[j] = (long)p.B * NC * 4; }
+        }
+    }
+}
+MPC_DEV void rec_issue(const RecMap &m, long tl, long tf, long tx, unsigned off, bool skip_c = false, int lane = 0)
+{
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long ti = m.kind[j] == 1 ? tf : (m.kind[j] == 2 ? tx : tl);
+        wv::dma4_if(m.act[j] && !(skip_c && j == 0 && lane < 40), m.ptr[j] + ti * m.step[j], off + 256u * (unsigned)j);
+    }
+}
+// every pass of the padded instantiation starts on cleared staging memory: the record words of padded entries are never
+// written by the gather above (their lanes sit the instruction out), and the passes lay their slots out differently
+MPC_DEV void pad_clear(int lane)
+{
+    if (!PADK) return;
+    wv::lds_sync();
+    for (unsigned off = 16u * (unsigned)lane; off + 16 <= LDS_TOTAL; off += 1024) wv::lds_store_f32x4(off, f32x4{0.f, 0.f, 0.f, 0.f});
+    wv::lds_sync();
+}
+// ---- the caller's arrays by their true shape (padded instantiation) or by the kernel's (exact one) ----------------------------
+MPC_DEV float ld_xinit(const P &p, long b, int i)
+{
+    if (PADK) return i < p.ns ? p.x_init[b * p.ns + i] : 0.f;
+    return p.x_init[b * NS + i];
+}
+// four consecutive state / control entries i0 .. i0+3 of timestep-problem tb
+// (padded instantiation: through a raw buffer over the ROW new_x[tb] / new_u[tb], whose range check drops the entries beyond the
+// true shape -- `if (i < ns) store` put every store in a block of its own and hipcc an `s_waitcnt vmcnt(0)`, a drain of the
+// staging gathers, in front of each)
+MPC_DEV void st_x4(const P &p, long tb, int i0, f32x4 v)
+{
+    if (PADK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wv::st_buf(p.new_x + tb * p.ns, (unsigned)(4 * p.ns), (unsigned)(4 * (i0 + e)), v[e]);
+    } else {
+        wv::store_f32x4(p.new_x + tb * NS + i0, v);
+    }
+}
+MPC_DEV void st_u4(const P &p, long tb, int a0, f32x4 v)
+{
+    if (PADK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wv::st_buf(p.new_u + tb * p.nc, (unsigned)(4 * p.nc), (unsigned)(4 * (a0 + e)), v[e]);
+    } else {
+        wv::store_f32x4(p.new_u + tb * NC + a0, v);
+    }
+}
+// bounds of control a at (t, b) = tb; a padded control is unbounded in every mode (it sits at zero: its row of Quu is the identity)
+MPC_DEV float bound_lo(const P &p, long tb, int a)
+{
+    if (PADK) {
+        const int nc = p.nc;
+        const float x = p.bound_mode != MPC_BOUND_SCALAR ? uniform_f32(p.lo + tb * nc + (a < nc ? a : nc - 1)) : p.lo_s;
+        return a < nc ? x : -3e38f;
+    }
+    return p.bound_mode != MPC_BOUND_SCALAR ? uniform_f32(p.lo + tb * NC + a) : p.lo_s;
+}
+MPC_DEV float bound_hi(const P &p, long tb, int a)
+{
+    if (PADK) {
+        const int nc = p.nc;
+        const float x = p.bound_mode != MPC_BOUND_SCALAR ? uniform_f32(p.hi + tb * nc + (a < nc ? a : nc - 1)) : p.hi_s;
+        return a < nc ? x : 3e38f;
+    }
+    return p.bound_mode != MPC_BOUND_SCALAR ? uniform_f32(p.hi + tb * NC + a) : p.hi_s;
+}
+
 struct Stream {
     const char *c_ptr, *f_ptr, *r_ptr;      // this lane's 16-byte column of each block, timestep 0
     long c_step, f_step, r_step;            // bytes per timestep
     bool r_active;
     bool r_is_f;                            // this lane's record granule is f_t (T-1 entries: indexed like F)
+    // the padded instantiation stages by gather instead (PADK): wave-uniform block pointers + the per-lane maps
+    const float *Cb, *Fb;                   // C_0 / F_0 of this problem
+    Gather g;
+    RecMap rm;
 };
 
 MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L, const KktArgs40 *kk = nullptr, bool with_f = false)
 {
     const long b = L.b;
     d.r_is_f = false;
+    if (PADK) {
+        d.Cb = p.C + b * p.C_sb;
+        d.Fb = p.T > 1 ? p.F + b * p.F_sb : d.Cb;
+        gather_init(d.g, p, L.lane);
+        rec_init(d.rm, p, L.lane, b, true, false, with_f, nullptr);
+    }
     d.c_ptr = (const char *)(p.C + b * p.C_sb) + 16 * L.lane;
     d.c_step = p.C_st * 4;
     // T = 1 has no dynamics (F may be NULL): its five DMA slots re-read C, so the wait counts stay the same
@@ -196,6 +388,13 @@ MPC_DEV void stage_issue(const P &p, const Stream &d, const Lane &L, int t, int 
     const unsigned base = (unsigned)slot * STAGE_BYTES;
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);
+    if (PADK) {
+        // (T = 1 has no dynamics: its F instructions gather an empty block -- zeros --, the wait counts stay the same)
+        gather_C(d.g, d.Cb + tl * p.C_st, base + OFF_C, L.lane);
+        gather_F(d.g, p.T > 1 ? d.Fb + tf * p.F_st : d.Cb, p.T > 1 ? d.g.fbytes : 0u, base + OFF_F);
+        rec_issue(d.rm, tl, tf, tl, base + OFF_R);
+        return;
+    }
     dma_kib<6>(d.c_ptr + tl * d.c_step, base + OFF_C);
     wv::dma16_at_if<2048>(L.lane < 16, d.c_ptr + tl * d.c_step + 4096, base + OFF_C + 4096);
     dma_kib<5>(d.f_ptr + (p.T > 1 ? tf * d.f_step : 0), base + OFF_F);
@@ -477,6 +676,14 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
     bool warm = false;
     float kprev_v = 0.f;               // box QP: the previous timestep's solution, spread over lanes (warm start)
 
+    pad_clear(L.lane);
+    // the identity on the padded diagonal of Quu (padded instantiation): register v of lane (q, r) of tile (2, 2) is
+    // Quu[4q + v][r] -- a control beyond n_ctrl gets H = 1, q = 0, no bounds: it stays at zero and its gains are zero
+    float padd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (PADK) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) padd[v] = (L.q < 2 && 4 * L.q + v == L.r && L.r >= p.nc) ? 1.f : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < SNSTAGE - 1; ++i) stage_issue(p, d, L, T - 1 - i >= 0 ? T - 1 - i : 0, i);
     int slot = 0;
@@ -664,6 +871,10 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             }
         }
 
+        if (PADK) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Qd[2][2][v] += padd[v];
+        }
         // ---- Quu, qu; K = -Quu^-1 Qux, k = -Quu^-1 qu   (:84-94; LDL' for the pinverse)
         // Quu stays spread over lanes in every mode (Ldl8V): column c of it is register c & 3 of lane row c >> 2 of the
         // accumulator tile, copied to all four lane rows with two row swaps per register; pinned / clamped controls become
@@ -720,12 +931,12 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             const bool r8 = L.r < 8;
             const float uav = wv::lds_f32(base + OFF_R + 288 + 4u * (unsigned)(r8 ? L.r : 0));
             float lov = p.lo_s, hiv = p.hi_s;
-            if (p.bound_mode != MPC_BOUND_SCALAR) {
+            if (PADK || p.bound_mode != MPC_BOUND_SCALAR) {
                 float lo8[8], hi8[8];
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {
-                    lo8[a] = uniform_f32(p.lo + tb * NC + a);
-                    hi8[a] = uniform_f32(p.hi + tb * NC + a);
+                    lo8[a] = bound_lo(p, tb, a);
+                    hi8[a] = bound_hi(p, tb, a);
                 }
                 lov = gather8(lo8, L.r);
                 hiv = gather8(hi8, L.r);
@@ -840,6 +1051,20 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                 for (int J = 0; J < 2; ++J)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) Kout[(tb * NC + 4 * L.q + v) * NS + 16 * J + L.r] = Kd[J][v];
+#ifdef MPC_MFMA40_PAD
+                // (Kout / kout above are the kernel's own padded gains in the workspace; the caller's K [T,B,nc,ns], if asked for:)
+                if (p.K_user) {
+                    // (rows of K_t [nc,ns] through a raw buffer over the block: entries beyond the true shape fall outside it)
+#pragma unroll
+                    for (int J = 0; J < 2; ++J)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const bool in = 4 * L.q + v < p.nc && 16 * J + L.r < p.ns;
+                            wv::st_buf(p.K_user + tb * (long)(p.nc * p.ns), (unsigned)(4 * p.nc * p.ns),
+                                       in ? (unsigned)(4 * ((4 * L.q + v) * p.ns + 16 * J + L.r)) : OOB_OFF, Kd[J][v]);
+                        }
+                }
+#endif
             }
         }
         if (L.lane < 8) {
@@ -847,6 +1072,9 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
 #pragma unroll
             for (int a = 1; a < 8; ++a) kv = pick(L.lane == a, kk[a], kv);
             kout[tb * NC + L.lane] = kv;
+#ifdef MPC_MFMA40_PAD
+            if (p.k_user) wv::st_buf(p.k_user + tb * p.nc, (unsigned)(4 * p.nc), (unsigned)(4 * L.lane), kv);
+#endif
         }
 
         // ---- V = Qxx + Qxu K, v = qx + Qxu k   (:155-158 with K'(Qux + Quu K) = 0, K'(qu + Quu k) = 0)
@@ -953,7 +1181,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             for (int I = 0; I < 2; ++I)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const float x0 = p.x_init[(long)L.b * NS + 16 * I + 4 * L.q + v];
+                    const float x0 = ld_xinit(p, L.b, 16 * I + 4 * L.q + v);
                     float r = fabsf(x0 - xnext[I][v]) - 1e-5f * (1.f + fabsf(x0));
                     r = (r == r) ? r : 1.f;
                     offdyn = r > offdyn ? r : offdyn;
@@ -1001,11 +1229,21 @@ struct RStream {
     const char *c_ptr, *f_ptr, *k_ptr, *r_ptr;
     long c_step, f_step, k_step, r_step;
     bool r_active, r_is_f, r_is_x;
+    // padded instantiation: gathers instead (see Stream)
+    const float *Cb, *Fb;
+    Gather g;
+    RecMap rm;
 };
 
 MPC_DEV void rstream_init(RStream &d, const P &p, const Lane &L, const float *Kin, const float *kin)
 {
     const long b = L.b;
+    if (PADK) {
+        d.Cb = p.C + b * p.C_sb;
+        d.Fb = p.T > 1 ? p.F + b * p.F_sb : d.Cb;
+        gather_init(d.g, p, L.lane);
+        rec_init(d.rm, p, L.lane, b, true, true, true, kin);
+    }
     d.c_ptr = (const char *)(p.C + b * p.C_sb) + 16 * L.lane;
     d.c_step = p.C_st * 4;
     d.f_ptr = p.T > 1 ? (const char *)(p.F + b * p.F_sb) + 16 * L.lane : d.c_ptr;
@@ -1043,6 +1281,13 @@ MPC_DEV void rstage_issue(const P &p, const RStream &d, const Lane &L, int t, in
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);      // F, f have T-1 entries
     const long tx = t + 1 < p.T ? t + 1 : t;                         // x_{t+1}
+    if (PADK) {
+        gather_C(d.g, d.Cb + tl * p.C_st, base + OFF_C, L.lane);
+        gather_F(d.g, p.T > 1 ? d.Fb + tf * p.F_st : d.Cb, p.T > 1 ? d.g.fbytes : 0u, base + OFF_F);
+        wv::dma16(d.k_ptr + tl * d.k_step, base + ROFF_K);
+        rec_issue(d.rm, tl, tf, tx, base + ROFF_R);
+        return;
+    }
     dma_kib<6>(d.c_ptr + tl * d.c_step, base + OFF_C);
     wv::dma16_at_if<2048>(L.lane < 16, d.c_ptr + tl * d.c_step + 4096, base + OFF_C + 4096);
     dma_kib<5>(d.f_ptr + tf * d.f_step, base + OFF_F);
@@ -1061,13 +1306,14 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
 #pragma unroll
     for (int I = 0; I < 2; ++I) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) Xd[I][v] = p.x_init[(long)L.b * NS + 16 * I + 4 * L.q + v];
+        for (int v = 0; v < 4; ++v) Xd[I][v] = ld_xinit(p, L.b, 16 * I + 4 * L.q + v);
         DXd[I] = zero4;
-        if (store && L.r == 0) wv::store_f32x4(p.new_x + (long)L.b * NS + 16 * I + 4 * L.q, Xd[I]);
+        if (store && L.r == 0) st_x4(p, L.b, 16 * I + 4 * L.q, Xd[I]);
     }
     double cacc = 0.0;
     float dacc = 0.f;
     wv::dma_wait<0>();          // nothing of the sweep / the previous pass may still land in the ring
+    pad_clear(L.lane);
     rstage_issue(p, d, L, 0, 0);
     int slot = 0;
     for (int t = 0; t < T; ++t) {
@@ -1107,9 +1353,9 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
                 if (MODE == 1 && L.q < 2 && ((zw >> (8 * v)) & 0xffu) != 0u) un = 0.f;               // :197-198
                 if (MODE == 2 && L.q < 2) {                                                          // :200-213
                     float lo = p.lo_s, hi = p.hi_s;
-                    if (p.bound_mode != MPC_BOUND_SCALAR) {
-                        lo = pick(L.q == 0, uniform_f32(p.lo + tb * NC + v), uniform_f32(p.lo + tb * NC + 4 + v));
-                        hi = pick(L.q == 0, uniform_f32(p.hi + tb * NC + v), uniform_f32(p.hi + tb * NC + 4 + v));
+                    if (PADK || p.bound_mode != MPC_BOUND_SCALAR) {
+                        lo = pick(L.q == 0, bound_lo(p, tb, v), bound_lo(p, tb, 4 + v));
+                        hi = pick(L.q == 0, bound_hi(p, tb, v), bound_hi(p, tb, 4 + v));
                     }
                     if (p.has_delta) {
                         const float l2 = ub[v] - p.delta_u, h2 = ub[v] + p.delta_u;
@@ -1123,7 +1369,7 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
                 s = fmaf(dd, dd, s);
             }
             dacc += s;
-            if (store && L.r == 0 && L.q < 2) wv::store_f32x4(p.new_u + tb * NC + 4 * L.q, Ud);
+            if (store && L.r == 0 && L.q < 2) st_u4(p, tb, 4 * L.q, Ud);
         }
         // ---- stage cost 0.5 tau'C tau + c'tau   (:230-232); C tau' on MFMA (C read through its symmetry)
         {
@@ -1189,7 +1435,7 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
                     for (int v = 0; v < 4; ++v) acc = wv::mfma(a[8 + v], Ud[v], acc);
                     wv::sched_fence();
                 }
-                if (store && L.r == 0) wv::store_f32x4(p.new_x + tb1 * NS + 16 * Im + 4 * L.q, acc);
+                if (store && L.r == 0) st_x4(p, tb1, 16 * Im + 4 * L.q, acc);
                 DXd[Im] = acc;      // parked here until both tiles are done (the second product still reads Xd)
             }
 #pragma unroll
@@ -1285,7 +1531,8 @@ template <int MODE> MPC_DEV void rollout_wave(const P &p, const float *Kin, cons
 // full_du_norm, :243-245); the winner's column stores.
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned LOFF_F = 0, LOFF_K = 5120, LOFF_R = 6144, LSTAGE_BYTES = 6656;
-constexpr int LSLOTS = 4, LDMA_PER_STAGE = 7;                  // 5 (F) + 1 (K) + 1 (record)
+constexpr int LSLOTS = 4, LDMA_PER_STAGE = CH_F + 1 + CH_R;    // 7 = 5 (F) + 1 (K) + 1 (record) in the exact kernel
+static_assert((LSLOTS - 2) * LDMA_PER_STAGE < 64, "vmcnt is 6 bits");
 static_assert(LSLOTS * LSTAGE_BYTES <= LDS_TOTAL, "lean rollout ring exceeds the wave's LDS");
 
 MPC_DEV void lstage_issue(const P &p, const RStream &d, const Lane &L, int t, int slot)
@@ -1294,6 +1541,12 @@ MPC_DEV void lstage_issue(const P &p, const RStream &d, const Lane &L, int t, in
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);      // F, f have T-1 entries
     const long tx = t + 1 < p.T ? t + 1 : t;                         // x_{t+1}
+    if (PADK) {
+        gather_F(d.g, p.T > 1 ? d.Fb + tf * p.F_st : d.Cb, p.T > 1 ? d.g.fbytes : 0u, base + LOFF_F);
+        wv::dma16(d.k_ptr + tl * d.k_step, base + LOFF_K);
+        rec_issue(d.rm, tl, tf, tx, base + LOFF_R, true, L.lane);        // (no c in this pass)
+        return;
+    }
     dma_kib<5>(d.f_ptr + tf * d.f_step, base + LOFF_F);
     wv::dma16(d.k_ptr + tl * d.k_step, base + LOFF_K);
     // (lanes 0..9 would carry c_t, which this pass never looks at: they sit the instruction out)
@@ -1334,12 +1587,13 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
 #pragma unroll
     for (int I = 0; I < 2; ++I) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) Xd[I][v] = p.x_init[(long)L.b * NS + 16 * I + 4 * L.q + v];
+        for (int v = 0; v < 4; ++v) Xd[I][v] = ld_xinit(p, L.b, 16 * I + 4 * L.q + v);
         DXd[I] = zero4;
-        if (store) wv::store_f32x4(p.new_x + (long)L.b * NS + 16 * I + 4 * L.q, Xd[I]);
+        if (store) st_x4(p, L.b, 16 * I + 4 * L.q, Xd[I]);
     }
     float dacc = 0.f;
     wv::dma_wait<0>();          // nothing of the sweep may still land in the ring
+    pad_clear(L.lane);
 #pragma unroll
     for (int i = 0; i < LSLOTS - 1; ++i) lstage_issue(p, d, L, i < T ? i : T - 1, i);
     for (int t = 0; t < T; ++t) {
@@ -1388,9 +1642,9 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
                 if (MODE == 1 && L.q < 2 && ((zw >> (8 * v)) & 0xffu) != 0u) un = 0.f;               // :197-198
                 if (MODE == 2 && L.q < 2) {                                                          // :200-213
                     float lo = p.lo_s, hi = p.hi_s;
-                    if (p.bound_mode != MPC_BOUND_SCALAR) {
-                        lo = pick(L.q == 0, uniform_f32(p.lo + tb * NC + v), uniform_f32(p.lo + tb * NC + 4 + v));
-                        hi = pick(L.q == 0, uniform_f32(p.hi + tb * NC + v), uniform_f32(p.hi + tb * NC + 4 + v));
+                    if (PADK || p.bound_mode != MPC_BOUND_SCALAR) {
+                        lo = pick(L.q == 0, bound_lo(p, tb, v), bound_lo(p, tb, 4 + v));
+                        hi = pick(L.q == 0, bound_hi(p, tb, v), bound_hi(p, tb, 4 + v));
                     }
                     if (p.has_delta) {
                         const float l2 = ub[v] - p.delta_u, h2 = ub[v] + p.delta_u;
@@ -1404,7 +1658,7 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
                 s = fmaf(dd, dd, s);
             }
             dacc += s;
-            if (store && L.q < 2) wv::store_f32x4(p.new_u + tb * NC + 4 * L.q, Ud);
+            if (store && L.q < 2) st_u4(p, tb, 4 * L.q, Ud);
         }
         // ---- x+ = F tau' + f   (:216-222)
         if (t < T - 1) {
@@ -1438,7 +1692,7 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
             wv::sched_fence();
 #pragma unroll
             for (int Im = 0; Im < 2; ++Im) {
-                if (store) wv::store_f32x4(p.new_x + tb1 * NS + 16 * Im + 4 * L.q, acc[Im]);
+                if (store) st_x4(p, tb1, 16 * Im + 4 * L.q, acc[Im]);
                 DXd[Im] = acc[Im];
             }
 #pragma unroll
@@ -1484,7 +1738,8 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
 // The sweep leaves (M, Quu, m) in the record p.Kk [T,B,328].  Trial 0 stores as it goes, another winner is replayed (lean).
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned POFF_F = 0, POFF_K = 5120, POFF_R = 6144, POFF_M = 6656, POFF_Q = 7680, PSTAGE_BYTES = 8000;
-constexpr int PSLOTS = LDS_TOTAL / PSTAGE_BYTES >= 4 ? 4 : 3, PDMA_PER_STAGE = 9;   // 5 (F) + K + record + M + (Quu | m)
+constexpr int PSLOTS = LDS_TOTAL / PSTAGE_BYTES >= 4 ? 4 : 3, PDMA_PER_STAGE = CH_F + 1 + CH_R + 2;   // 9 = 5 (F) + K + record + M + (Quu | m)
+static_assert((PSLOTS - 2) * PDMA_PER_STAGE < 64, "vmcnt is 6 bits");
 static_assert(PSLOTS * PSTAGE_BYTES <= LDS_TOTAL && PSLOTS >= 3, "priced rollout ring exceeds the wave's LDS");
 
 MPC_DEV void pstage_issue(const P &p, const RStream &d, const Lane &L, const char *m_ptr, int t, int slot)
@@ -1493,9 +1748,15 @@ MPC_DEV void pstage_issue(const P &p, const RStream &d, const Lane &L, const cha
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);      // F, f have T-1 entries
     const long tx = t + 1 < p.T ? t + 1 : t;                         // x_{t+1}
+    if (PADK) {
+        gather_F(d.g, p.T > 1 ? d.Fb + tf * p.F_st : d.Cb, p.T > 1 ? d.g.fbytes : 0u, base + POFF_F);
+        wv::dma16(d.k_ptr + tl * d.k_step, base + POFF_K);
+        rec_issue(d.rm, tl, tf, tx, base + POFF_R, true, L.lane);
+    } else {
     dma_kib<5>(d.f_ptr + tf * d.f_step, base + POFF_F);
     wv::dma16(d.k_ptr + tl * d.k_step, base + POFF_K);
     wv::dma16_if(d.r_active && L.lane >= 10, d.r_ptr + (d.r_is_f ? tf : (d.r_is_x ? tx : tl)) * d.r_step, base + POFF_R);
+    }
     const char *rec = m_ptr + tl * ((long)p.B * PREC * 4);
     wv::dma16(rec, base + POFF_M);
     wv::dma16_if(L.lane < 18, rec + 1024, base + POFF_Q);
@@ -1525,13 +1786,15 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
 #pragma unroll
     for (int I = 0; I < 2; ++I) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) Xd[I][v] = p.x_init[(long)L.b * NS + 16 * I + 4 * L.q + v];
+        for (int v = 0; v < 4; ++v) Xd[I][v] = ld_xinit(p, L.b, 16 * I + 4 * L.q + v);
         DXd[I] = zero4;
-        if (store) wv::store_f32x4(xo + 16 * I + 4 * L.q, Xd[I]);
+        if (PADK && L.r == 0) st_x4(p, L.b, 16 * I + 4 * L.q, Xd[I]);       // (the caller's arrays by their true shape; the scratch is padded)
+        else if (store) wv::store_f32x4(xo + 16 * I + 4 * L.q, Xd[I]);
     }
     float dacc = 0.f;
     double cacc = 0.0;
     wv::dma_wait<0>();          // nothing of the sweep may still land in the ring
+    pad_clear(L.lane);
 #pragma unroll
     for (int i = 0; i < PSLOTS - 1; ++i) pstage_issue(p, d, L, m_ptr, i < T ? i : T - 1, i);
     for (int t = 0; t < T; ++t) {
@@ -1593,9 +1856,9 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
                 if (MODE == 1 && uq && ((zw >> (8 * v)) & 0xffu) != 0u) un = 0.f;                    // :197-198
                 if (MODE == 2 && uq) {                                                               // :200-213
                     float lo = p.lo_s, hi = p.hi_s;
-                    if (p.bound_mode != MPC_BOUND_SCALAR) {
-                        lo = pick(L.q == 0, uniform_f32(p.lo + tb * NC + v), uniform_f32(p.lo + tb * NC + 4 + v));
-                        hi = pick(L.q == 0, uniform_f32(p.hi + tb * NC + v), uniform_f32(p.hi + tb * NC + 4 + v));
+                    if (PADK || p.bound_mode != MPC_BOUND_SCALAR) {
+                        lo = pick(L.q == 0, bound_lo(p, tb, v), bound_lo(p, tb, 4 + v));
+                        hi = pick(L.q == 0, bound_hi(p, tb, v), bound_hi(p, tb, 4 + v));
                     }
                     if (p.has_delta) {
                         const float l2 = ub[v] - p.delta_u, h2 = ub[v] + p.delta_u;
@@ -1610,7 +1873,8 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
                 s = fmaf(du, du, s);
             }
             dacc += s;
-            if (store && uq) wv::store_f32x4(uo + (long)t * ust + 4 * L.q, Ud);
+            if (PADK && L.r == 0) { if (uq) st_u4(p, tb, 4 * L.q, Ud); }
+            else if (store && uq) wv::store_f32x4(uo + (long)t * ust + 4 * L.q, Ud);
         }
         // ---- x+ = F tau' + f   (:216-222)  and  Quu e
         f32x4 H = zero4;
@@ -1645,7 +1909,8 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
             wv::sched_fence();
 #pragma unroll
             for (int Im = 0; Im < 2; ++Im) {
-                if (store) wv::store_f32x4(xo + (long)(t + 1) * xst + 16 * Im + 4 * L.q, acc[Im]);
+                if (PADK && L.r == 0) st_x4(p, (long)(t + 1) * p.B + L.b, 16 * Im + 4 * L.q, acc[Im]);
+                else if (store) wv::store_f32x4(xo + (long)(t + 1) * xst + 16 * Im + 4 * L.q, acc[Im]);
                 const f32x4 xb = wv::lds_f32x4(rec + 160 + 4u * (unsigned)(16 * Im + 4 * L.q));
                 Xd[Im] = acc[Im];
 #pragma unroll
@@ -1686,7 +1951,30 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
     const float full2 = wv::readlane(du2, 0);
     float win_alpha = 1.f;
     for (int i = 0; i < win; ++i) win_alpha *= p.ls_decay;
-    if (win == 1) {
+    if (PADK && win == 1) {
+        // padded instantiation: the parked trajectory is [T,B,40] in the kernel's padded slots, the caller's arrays have the
+        // true shape -- word by word, sixteen loads in flight
+        wv::fence_own_stores();
+        enum { CW = 16 };
+        const int nword = T * PSCR;
+        for (int c0 = 0; c0 < nword; c0 += 64 * CW) {
+            float v[CW];
+#pragma unroll
+            for (int i = 0; i < CW; ++i) {
+                const int w = c0 + 64 * i + L.lane, ww = w < nword ? w : nword - 1;
+                const int t = ww / PSCR;
+                v[i] = scr[((long)t * p.B + L.b) * PSCR + (ww - t * PSCR)];
+            }
+#pragma unroll
+            for (int i = 0; i < CW; ++i) {
+                const int w = c0 + 64 * i + L.lane;
+                const int ww = w < nword ? w : nword - 1, t = ww / PSCR, e = ww - t * PSCR;
+                const long tb = (long)t * p.B + L.b;
+                wv::st_buf(p.new_x + tb * p.ns, (unsigned)(4 * p.ns), (w < nword && e < NS) ? (unsigned)(4 * e) : OOB_OFF, v[i]);
+                wv::st_buf(p.new_u + tb * p.nc, (unsigned)(4 * p.nc), (w < nword && e >= NS) ? (unsigned)(4 * (e - NS)) : OOB_OFF, v[i]);
+            }
+        }
+    } else if (win == 1) {
         // the parked trajectory -> new_x / new_u: PSCR / 4 = 10 16-byte chunks per timestep (8 of x', 2 of u'), chunk
         // c = lane + 64 i; the tail repeats the last chunk (the same bytes to the same address)
         wv::fence_own_stores();

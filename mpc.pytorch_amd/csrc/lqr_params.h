@@ -25,6 +25,8 @@ struct StepParams {
     int sweep_only;              // MPC_OPT_SWEEP_ONLY: gains, nominal cost and QP counts, no rollout
     int c_symmetric;             // MPC_OPT_C_SYMMETRIC: the caller vouches for C = C' (no symmetry test in the fused kernels)
     const int *gate;             // generic kernel only: solve problem b iff gate[b] & MPC_ST_C_ASYMMETRIC (NULL = every problem)
+    real *K_user, *k_user;       // padded 32/8 instantiation only: the caller's K [T,B,nc,ns] / k [T,B,nc] (K, k are then the
+                                 // kernel's own padded gains [T,B,8,32] / [T,B,8] in the workspace); NULL = not asked for
     // outputs
     real *new_x, *new_u, *costs, *old_costs, *full_du_norm, *alpha_du_norm, *alphas;
     int *qp_iters, *status;
@@ -65,6 +67,7 @@ inline StepParams<real> make_params(const mpc_lqr_problem *p, const mpc_lqr_opti
     s.sweep_only = (o && (o->flags & MPC_OPT_SWEEP_ONLY)) ? 1 : 0;
     s.c_symmetric = (o && (o->flags & MPC_OPT_C_SYMMETRIC)) ? 1 : 0;
     s.gate = nullptr;
+    s.K_user = nullptr; s.k_user = nullptr;
     s.new_x = out ? (real *)out->new_x : nullptr; s.new_u = out ? (real *)out->new_u : nullptr;
     s.costs = out ? (real *)out->costs : nullptr; s.old_costs = out ? (real *)out->old_costs : nullptr;
     s.full_du_norm = out ? (real *)out->full_du_norm : nullptr;

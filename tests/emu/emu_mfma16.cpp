@@ -40,7 +40,7 @@ struct Wave {
     // LDS of the (single-wave) workgroup + the in-order queue of LDS-DMA instructions in flight
     alignas(16) unsigned char lds[160 * 1024];   // a CU's whole LDS (the staged kernels' rings use 40 KB of it, lqr_wave1 up to 150)
     struct Dma { unsigned char data[NL][16]; bool act[NL]; unsigned char seen[NL]; unsigned off; int size; };
-    Dma q[64];
+    Dma q[192];      // (the hardware counter holds 63: issuing beyond that stalls until the oldest lands; landing LATER, as here, is the stricter test)
     int qn;
     int region_start;     // queue entries from here on belong to the current lockstep region
 };
@@ -397,7 +397,7 @@ static inline void dma_n(const void *g, unsigned off, int size, bool active = tr
     for (int i = w.region_start; i < w.qn; ++i)
         if (w.q[i].off == off && w.q[i].size == size && w.q[i].seen[l] == 0) { d = &w.q[i]; break; }
     if (!d) {
-        if (w.qn >= 64) { fprintf(stderr, "emu: DMA queue overflow\n"); abort(); }
+        if (w.qn >= 192) { fprintf(stderr, "emu: DMA queue overflow\n"); abort(); }
         d = &w.q[w.qn++];
         memset(d->act, 0, sizeof(d->act));
         memset(d->seen, 0, sizeof(d->seen));
@@ -425,6 +425,20 @@ static inline void dma16_once(const void *g, unsigned off) { dma_n(g, off, 16); 
 static inline void store_out(float *g, float v) { *g = v; }
 static inline void dma16_if(bool active, const void *g, unsigned off) { dma_n(g, off, 16, active); }
 static inline void dma4(const void *g, unsigned off) { dma_n(g, off, 4); }
+static inline void dma4_if(bool active, const void *g, unsigned off) { dma_n(g, off, 4, active); }
+// buffer_store_dword through a raw buffer of `nbytes`: out-of-range lanes store nothing
+static inline void st_buf(float *base, unsigned nbytes, unsigned voff, float v)
+{
+    if ((unsigned long)voff + 4ul <= (unsigned long)nbytes) memcpy((char *)base + voff, &v, 4);
+}
+// buffer_load ... lds (the padded 32/8 instantiation's gathers): G bytes per lane from base + voff; a lane whose access lies
+// beyond the buffer's `nbytes` writes ZERO into LDS (the hardware's range check, tools/ubench/buffer_lds_probe.hip)
+template <int G> static inline void dma_buf(bool active, const void *base, unsigned nbytes, unsigned voff, unsigned off)
+{
+    static const char zero[16] = {0};
+    const bool in = (unsigned long)voff + (unsigned long)G <= (unsigned long)nbytes;
+    dma_n(in ? (const char *)base + voff : zero, off, G, active);
+}
 template <int N> static inline void dma_wait()
 {
     // lockstep point: every lane has issued its part of the preceding DMA instructions
@@ -645,7 +659,20 @@ extern "C" int emu_lqr_sweep_mfma40(const mpc_lqr_problem *p, const mpc_lqr_opti
 {
     if (p->dtype != MPC_F32) return MPC_E_DTYPE;
     mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, out);
+#ifdef MPC_MFMA40_PAD
+    // the padded instantiation (any n_state <= 32, n_ctrl <= 8): K / k are the kernel's own padded gains, the caller's go by K_user
+    if (sp.ns < 1 || sp.ns > 32 || sp.nc < 1 || sp.nc > 8) return MPC_E_DIMS;
+    if (MPC_MFMA40_PAD == 16 && (sp.ns % 4 || sp.nc % 4)) return MPC_E_DIMS;
+    const size_t ngain = (size_t)sp.T * sp.B * (256 + 8);
+    float *gains = (float *)aligned_alloc(16, (ngain * sizeof(float) + 15) / 16 * 16);
+    for (size_t i = 0; i < ngain; ++i) gains[i] = NAN;
+    sp.K_user = sp.K;
+    sp.k_user = sp.k;
+    sp.K = gains;
+    sp.k = gains + (size_t)sp.T * sp.B * 256;
+#else
     if (!(sp.ns == 32 && sp.nc == 8) || !sp.K || !sp.k) return MPC_E_DIMS;
+#endif
     // the (M, Quu, m) record of the constrained modes' priced rollout (capi.hip takes it out of the workspace)
     const size_t need = (size_t)sp.T * sp.B * (mpclqr::mfma40::PREC + mpclqr::mfma40::PSCR) + 4;
     float *rec = (float *)aligned_alloc(16, (need * sizeof(float) + 15) / 16 * 16);
@@ -654,6 +681,9 @@ extern "C" int emu_lqr_sweep_mfma40(const mpc_lqr_problem *p, const mpc_lqr_opti
     g_p = &sp;
     for (int b = 0; b < sp.B; ++b) emu::run_wave(b, body_mfma40);
     free(rec);
+#ifdef MPC_MFMA40_PAD
+    free(gains);
+#endif
     return 0;
 }
 

@@ -18,10 +18,11 @@ _EMU = os.path.join(_HERE, "emu")
 _LIB = None
 
 
-def build(ring2=False):
+def build(ring2=False, pad=0):
     """ring2: the 12/4 kernel with its 2-slot sweep ring (-DMPC_DPP16_NSTAGE=2, the second compilation of lqr_dpp16.hip) and
-    the 32/8 kernel with its 2-slot sweep ring (-DMPC_MFMA40_SWEEP_NSTAGE=2, the second compilation of lqr_mfma40.hip's step kernels)."""
-    so = os.path.join(_EMU, "libemu_mfma16_ring2.so" if ring2 else "libemu_mfma16.so")
+    the 32/8 kernel with its 2-slot sweep ring (-DMPC_MFMA40_SWEEP_NSTAGE=2, the second compilation of lqr_mfma40.hip's step kernels).
+    pad = 4 | 16: the 32/8 kernel's PADDED instantiation (-DMPC_MFMA40_PAD=4|16 on the two-slot ring, csrc/Makefile)."""
+    so = os.path.join(_EMU, "libemu_mfma16_pad%d.so" % pad if pad else ("libemu_mfma16_ring2.so" if ring2 else "libemu_mfma16.so"))
     src = os.path.join(_EMU, "emu_mfma16.cpp")
     csrc = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc")
     deps = [src] + [os.path.join(csrc, h) for h in ("lqr_mfma16_body.h", "lqr_dpp16_body.h", "lqr_small_math.h",
@@ -32,11 +33,20 @@ def build(ring2=False):
             cxx = shutil.which("clang++")
         assert cxx, "the emulator needs clang++ (ext_vector_type)"
         subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
-                              + (["-DMPC_DPP16_NSTAGE=2", "-DMPC_KKT16_NSTAGE=2", "-DMPC_MFMA40_SWEEP_NSTAGE=2"] if ring2 else []) + ["-o", so, src])
+                              + (["-DMPC_DPP16_NSTAGE=2", "-DMPC_KKT16_NSTAGE=2", "-DMPC_MFMA40_SWEEP_NSTAGE=2"] if (ring2 or pad) else [])
+                              + (["-DMPC_MFMA40_PAD=%d" % pad] if pad else []) + ["-o", so, src])
     return so
 
 
 _LIB2 = None
+_LIBPAD = {}
+
+
+def lib_pad(g):
+    if g not in _LIBPAD:
+        _LIBPAD[g] = ctypes.CDLL(build(pad=g))
+    return _LIBPAD[g]
+
 
 
 def lib_ring2():
@@ -127,11 +137,12 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
         e.linearize = int(len(env) > 4 and bool(env[4]))
         keep.append(e)
         o.true_dynamics = ctypes.pointer(e)
-    if kernel in ("mfma40_sweep", "mfma40", "mfma40_ring2"):
-        # ("mfma40_ring2": the step kernels' second compilation, two sweep slots instead of three)
-        L40 = lib_ring2() if kernel == "mfma40_ring2" else lib()
+    if kernel in ("mfma40_sweep", "mfma40", "mfma40_ring2", "mfma40_pad4", "mfma40_pad16", "mfma40_pad4_sweep", "mfma40_pad16_sweep"):
+        # ("mfma40_ring2": the step kernels' second compilation, two sweep slots instead of three; "mfma40_pad4 / _pad16": the
+        # padded instantiation for any n_state <= 32, n_ctrl <= 8, dword / 16-byte gathers)
+        L40 = lib_pad(4) if "pad4" in kernel else (lib_pad(16) if "pad16" in kernel else (lib_ring2() if kernel == "mfma40_ring2" else lib()))
         L40.emu_set_dma_late(int(bool(dma_late)))
-        L40.emu_mfma40_full(int(kernel != "mfma40_sweep"))
+        L40.emu_mfma40_full(int(not kernel.endswith("_sweep")))
         fn = L40.emu_lqr_sweep_mfma40
         fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs)]
         rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))

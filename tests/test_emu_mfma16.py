@@ -1010,3 +1010,124 @@ def test_emulated_dpp16_long_horizons(emu, kernel, T):
             np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=2e-4, err_msg=mode)
             np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4, atol=1e-4)
             np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# The PADDED instantiation of the 32/8 kernel (round 4; csrc/lqr_mfma40_body.h PADK, -DMPC_MFMA40_PAD=4|16): any n_state <= 32,
+# n_ctrl <= 8 -- the reference's sweep is shape-agnostic (mpc/lqr_step.py:61-158).  tau is padded to [x(32); u(8)] by the staging
+# gathers (buffer_load ... lds: out-of-range lanes write zero), everything downstream is the exact kernel's code.
+# ---------------------------------------------------------------------------------------------
+def _pad_problem(rng, ns, nc, T, B, u_scale=0.3, clamp=None):
+    from oracle import lqr_oracle as O
+    n = ns + nc
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A) + 0.1 * np.eye(n)
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((max(T - 1, 0), B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((max(T - 1, 0), B, ns, nc)) / np.sqrt(ns)), 3)
+    f = 0.1 * rng.standard_normal((max(T - 1, 0), B, ns))
+    x_init = rng.standard_normal((B, ns))
+    cur_u = u_scale * rng.standard_normal((T, B, nc))
+    if clamp is not None:
+        cur_u = np.clip(cur_u, -clamp, clamp)
+    cur_x, _ = O.traj_cost(x_init, cur_u, F, f)
+    return dict(x_init=x_init, C=C, c=c, F=F, f=f, cur_x=cur_x, cur_u=cur_u)
+
+
+# (13,4), (20,5), (24,8), (32,4): the shapes VERDICT r03 names; 8/6 more controls than the 12/4 kernels take; 1/1, 32/8 the ends
+PAD_SHAPES = [("mfma40_pad4", 13, 4), ("mfma40_pad4", 20, 5), ("mfma40_pad4", 8, 6), ("mfma40_pad4", 1, 1), ("mfma40_pad4", 32, 8),
+              ("mfma40_pad4", 31, 7), ("mfma40_pad16", 24, 8), ("mfma40_pad16", 32, 4), ("mfma40_pad16", 16, 4), ("mfma40_pad16", 4, 8)]
+
+
+@pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
+@pytest.mark.parametrize("kernel,ns,nc", PAD_SHAPES)
+def test_emulated_padded_mfma40_unconstrained(emu, kernel, ns, nc, dma_late):
+    """Gains, trajectory, costs of the padded kernel at shapes between the hand-tuned ones, vouched (lean rollout) and bare
+    (nominal verified in the sweep, C tested), under both LDS-DMA timing extremes, against the oracle."""
+    from oracle import lqr_oracle as O
+    kw = _pad_problem(np.random.default_rng(100 * ns + nc), ns, nc, 6, 2, u_scale=0.0)
+    o = O.lqr_step(lockstep=False, return_gains=True, **kw)
+    for vouch in (False, True):
+        r = emu.lqr_step(kernel=kernel, dma_late=dma_late, nominal_on_dynamics=vouch, c_symmetric=vouch, **kw)
+        np.testing.assert_allclose(r["K"], o["K"], rtol=1e-3, atol=2e-5)
+        np.testing.assert_allclose(r["k"], o["k"], rtol=1e-3, atol=2e-5)
+        np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(r["costs"], o["costs"], rtol=1e-4)
+        np.testing.assert_allclose(r["old_costs"], o["old_costs"], rtol=1e-5)
+        np.testing.assert_allclose(r["full_du_norm"], o["full_du_norm"], rtol=1e-3, atol=1e-4)
+        assert (r["status"] & ~32 == 0).all() and ((r["status"] & 32 != 0).all() == (not vouch))
+
+
+@pytest.mark.parametrize("case", ["bounded", "tensor_bounds", "delta_u", "masked", "T1", "T2", "no_f", "positive_bounds"])
+@pytest.mark.parametrize("kernel,ns,nc", [("mfma40_pad4", 13, 4), ("mfma40_pad4", 20, 5), ("mfma40_pad16", 24, 8), ("mfma40_pad16", 32, 4)])
+def test_emulated_padded_mfma40_constrained_modes(emu, kernel, ns, nc, case):
+    """Box bounds (scalar / tensor / with delta_u), u_zero_I, the short horizons and a problem without f on the padded kernel:
+    vouched (the line search priced from the sweep's record) and bare (priced from C), against the oracle.  positive_bounds: a
+    scalar box that does not contain zero -- the padded controls are unbounded whatever the box (they must stay at zero)."""
+    from oracle import lqr_oracle as O
+    T = {"T1": 1, "T2": 2}.get(case, 5)
+    B = 2
+    rng = np.random.default_rng(7 * ns + nc + len(case))
+    kw = _pad_problem(rng, ns, nc, max(T, 2), B, u_scale=0.3, clamp=0.4)
+    if T == 1:
+        kw = {k: (v[:1] if k in ("C", "c", "cur_u") else (v[:0] if k in ("F", "f") else v)) for k, v in kw.items()}
+        kw["cur_x"] = kw["x_init"][None].copy()
+    if case == "no_f":
+        kw["f"] = None
+        kw["cur_x"], _ = O.traj_cost(kw["x_init"], kw["cur_u"], kw["F"], None)
+    opt = dict(linesearch_decay=0.5, max_linesearch_iter=6)
+    if case == "tensor_bounds":
+        opt.update(u_lower=-0.5 - rng.random((T, B, nc)), u_upper=0.5 + rng.random((T, B, nc)))
+    elif case == "delta_u":
+        opt.update(u_lower=-0.5, u_upper=0.5, delta_u=0.1)
+    elif case == "masked":
+        opt.update(u_zero_I=rng.random((T, B, nc)) < 0.35)
+    elif case == "positive_bounds":
+        kw["cur_u"] = np.clip(np.abs(kw["cur_u"]) + 0.1, 0.1, 0.6)
+        kw["cur_x"], _ = O.traj_cost(kw["x_init"], kw["cur_u"], kw["F"], kw["f"])
+        opt.update(u_lower=0.1, u_upper=0.6)
+    else:
+        opt.update(u_lower=-0.5, u_upper=0.5)
+    o = O.lqr_step(lockstep=False, **kw, **opt)
+    for vouch in (True, False):
+        r = emu.lqr_step(kernel=kernel, dma_late=True, nominal_on_dynamics=vouch, **kw, **opt)
+        np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+        np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=2e-3, atol=2e-4 * (1 + np.abs(o["new_x"]).max()))
+        np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4, atol=1e-3)
+        np.testing.assert_allclose(r["full_du_norm"], o["full_du_norm"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("bounded", [False, True], ids=["unbounded", "bounded"])
+@pytest.mark.parametrize("kernel,ns,nc", [("mfma40_pad4", 13, 4), ("mfma40_pad16", 24, 8)])
+def test_emulated_padded_mfma40_line_search_and_off_dynamics_nominal(emu, kernel, ns, nc, bounded):
+    """A non-convex stage cost makes trials other than the first win (copy of the parked second trial / replay of a later one in
+    the box-constrained step, the analytic line search + one pass in the unconstrained one); and a nominal whose current_x is
+    NOT the rollout of current_u is noticed by the sweep (unconstrained: MPC_ST_NOMINAL_OFF_DYNAMICS) and priced from C."""
+    from oracle import lqr_oracle as O
+    for attempt in range(40):
+        rng = np.random.default_rng(11 + ns + 1000 * attempt)
+        kw = _pad_problem(rng, ns, nc, 6, 3, u_scale=0.3, clamp=0.4 if bounded else None)
+        kw["C"][:, :, :ns, :ns] -= (80.0 if bounded else 45.0) * np.eye(ns)
+        opt = dict(linesearch_decay=0.5, max_linesearch_iter=8)
+        if bounded:
+            opt.update(u_lower=-0.5, u_upper=0.5)
+        o = O.lqr_step(lockstep=False, **kw, **opt)
+        if (o["alphas"] < 1).any() and (not bounded or (o["alphas"] > 0.5 ** 7).all()):
+            break
+    else:
+        assert False, "no seed made the line search backtrack"
+    for vouch in (True, False):
+        r = emu.lqr_step(kernel=kernel, dma_late=True, nominal_on_dynamics=vouch, **kw, **opt)
+        np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+        np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=2e-2, atol=4e-3 * (1 + np.abs(o["new_u"]).max()))
+        np.testing.assert_allclose(r["costs"], o["costs"], rtol=4e-3, atol=1e-2)
+    if not bounded:
+        kw2 = _pad_problem(np.random.default_rng(5 + ns), ns, nc, 6, 3, u_scale=0.3)
+        kw2["cur_x"][3, 1, min(2, ns - 1)] += 0.05                  # problem 1 leaves the dynamics at t = 3
+        o2 = O.lqr_step(lockstep=False, **kw2)
+        r2 = emu.lqr_step(kernel=kernel, dma_late=True, **kw2)
+        assert ((r2["status"] & 4) != 0).tolist() == [False, True, False]
+        np.testing.assert_allclose(r2["new_u"], o2["new_u"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(r2["costs"], o2["costs"], rtol=1e-4)
