@@ -1141,7 +1141,7 @@ def test_padded_mfma40_shapes_between_the_tuned_ones(be, ns, nc, case):
     (mpc/lqr_step.py:61-158).  Every mode, bare and vouched, with and without the caller's K / k, against the float64 oracle at
     the stated tolerance and against the generic kernel."""
     from oracle import lqr_oracle as O
-    from mpc._native import StepOptions, IMPL_MFMA40_PAD
+    from mpc._native import StepOptions, IMPL_MFMA40_PAD, IMPL_MFMA16
     from mpc import util
     from mpc.mpc import LinDx
     import bench
@@ -1173,7 +1173,8 @@ def test_padded_mfma40_shapes_between_the_tuned_ones(be, ns, nc, case):
         r7 = be.lqr_step(*args, opts, impl=IMPL_MFMA40_PAD, want_gains=not vouch)
         r0 = be.lqr_step(*args, opts, impl=0)
         torch.cuda.synchronize()
-        assert torch.equal(r0["new_u"], r7["new_u"]) and torch.equal(r0["new_x"], r7["new_x"])          # auto = the padded kernel
+        if not be.impl_supported(ns, nc, torch.float32, IMPL_MFMA16):        # (5/3 is the wavefront-per-problem MFMA kernel's)
+            assert torch.equal(r0["new_u"], r7["new_u"]) and torch.equal(r0["new_x"], r7["new_x"])      # auto = the padded kernel
         same = np.isclose(host(r7["alphas"]), o["alphas"], rtol=1e-5)
         assert (~same).sum() <= 1
         for k in ("new_x", "new_u"):

@@ -59,6 +59,10 @@ SGPR_SPILL_LIMITS = {
     "lqr_mfma40": {"kernelILi0E": 90, "kernelILi1E": 105, "kernelILi2E": 150},
     "lqr_mfma40_ring2": {"kernelILi0E": 90, "kernelILi1E": 105, "kernelILi2E": 150},
     "lqr_mfma40_kkt": {"kernelILi0E": 55, "kernelILi1E": 115},
+    # the padded instantiation (round 4): every gather instruction wants a 128-bit descriptor and an M0 -- 47 of them a stage in the
+    # dword build; the ceilings are what that costs in scalar registers (none of it in vector spills or scratch)
+    "lqr_mfma40_pad4": {"kernelILi0E": 380, "kernelILi1E": 700, "kernelILi2E": 930},
+    "lqr_mfma40_pad16": {"kernelILi0E": 380, "kernelILi1E": 700, "kernelILi2E": 930},
     "lqr_wave1": {"kernelILi1E": 20, "kernelILi2E": 12, "kernelILi3E": 28, "kernelILi4E": 20, "kernelILi5E": 20, "kernelILi6E": 20},
     "lqr_mfma16": {"ILb1ELi0E": 35, "ILb1ELi1E": 45, "ILb1ELi2E": 80, "ILb0ELi0E": 215, "ILb0ELi1E": 205, "ILb0ELi2E": 305},
 }
