@@ -472,6 +472,18 @@ def extra_rows(be, dev, steps):
                     ms=ms5, wall_ms=wall5, lqr_iter=5, note="whole MPC.forward at config 5: initial trajectory kernel + 5 x (step + select_best)")
                 del ctrl5, cost5, dx5
         del p, r
+    # ---- shapes BETWEEN the hand-tuned ones (round 4): the 32/8 kernel's padded instantiation (impl 7 under impl 0), beside the
+    # generic kernel every such shape ran on in rounds 1-3 -- the reference's sweep is shape-agnostic (mpc/lqr_step.py:61-158)
+    for ns_p, nc_p in ((13, 4), (20, 5), (24, 8)):
+        p = make_problem(ns_p, nc_p, T_H, 1024, torch.float32, dev, seed=40 + ns_p)
+        row, _ = step_row(p, StepOptions(nominal_on_dynamics=True, c_symmetric=True), ns_p, nc_p, T_H, 1024)
+        rowg, _ = step_row(p, StepOptions(nominal_on_dynamics=True, c_symmetric=True), ns_p, nc_p, T_H, 1024, impl=1)
+        row["workload"] = ("n_state=%d n_ctrl=%d T=%d B=1024, unconstrained: the padded 32/8 kernel (%s gathers); generic_kernel_ms = the same call "
+                           "forced onto the generic kernel (rounds 1-3)" % (ns_p, nc_p, T_H, "16-byte" if ns_p % 4 == 0 and nc_p % 4 == 0 else "dword"))
+        row["generic_kernel_ms"] = rowg["ms"]
+        row["speedup_over_generic"] = rowg["ms"] / row["ms"]
+        rows["pad_step_%d_%d_B1024" % (ns_p, nc_p)] = row
+        del p
     torch.cuda.empty_cache()
     # ---- configs 2 / 3: the shipped simulators, whole 10-iteration iLQR solves (L2-resident: latency-bound) ----
     from tools.bench_ilqr_env import problem as env_problem
@@ -535,21 +547,25 @@ def attach_traffic(rows):
     WRITE_SIZE passes, (2 x FETCH + WRITE) x 1024 per MI355X_MICROARCH.md), per kernel; a row that is ONE kernel launch gets
     `roofline.traffic` and `roofline.traffic_over_algorithmic`.  Counter runs are separate runs of the same commands
     (tools/prof_any.sh), never mixed with the timed ones."""
-    def load(tag):
-        try:
-            return json.load(open(os.path.join(ROOT, "profiles", "r03_prof_%s.json" % tag)))["pmc_avg_per_dispatch"]
-        except Exception:
-            return {}
-    kkt, cfg5, bnd = load("kkt"), load("cfg5_final"), load("bounded")
+    def load(*tags):
+        # (the newest round's summary of that call kind: tools/prof_one.py profiles ONE kind of call per file since round 4)
+        for tag in tags:
+            try:
+                return json.load(open(os.path.join(ROOT, "profiles", tag + ".json")))["pmc_avg_per_dispatch"]
+            except Exception:
+                continue
+        return {}
+    kkt, kktb = load("r04_prof_kkt", "r03_prof_kkt"), load("r04_prof_kkt_bounded", "r03_prof_kkt")
+    cfg5, cfg5b, bnd = load("r04_prof_cfg5_kkt", "r03_prof_cfg5_final"), load("r04_prof_cfg5_bounded", "r03_prof_cfg5_final"), load("r04_prof_bounded", "r03_prof_bounded")
     # (config 5's backward is two launches: the fused kernel + the outer products; their counters add up)
     k5, o5 = cfg5.get("lqr_kkt_fused_mfma40_kernel<0>"), cfg5.get("kkt_outer_kernel")
     kkt5 = ({"hbm_bytes_per_dispatch": k5["hbm_bytes_per_dispatch"] + o5["hbm_bytes_per_dispatch"]}
             if k5 and o5 and "hbm_bytes_per_dispatch" in k5 and "hbm_bytes_per_dispatch" in o5 else None)
     pick = {"lqr_step_bounded": bnd.get("lqr_step_dpp16_kernel<2>"),
             "kkt_backward_unbounded": kkt.get("lqr_kkt_fused_dpp16_kernel<false>"),
-            "kkt_backward_bounded": kkt.get("lqr_kkt_fused_dpp16_kernel<true>"),
+            "kkt_backward_bounded": kktb.get("lqr_kkt_fused_dpp16_kernel<true>"),
             "cfg5_kkt_backward_B1024": kkt5,
-            "cfg5_step_bounded_B1024": cfg5.get("lqr_step_mfma40_kernel<2>")}
+            "cfg5_step_bounded_B1024": cfg5b.get("lqr_step_mfma40_kernel<2>")}
     for key, v in pick.items():
         if v and key in rows and "roofline" in rows[key] and "hbm_bytes_per_dispatch" in v:
             r = rows[key]["roofline"]
@@ -799,11 +815,13 @@ def main():
         value = world * B * T_H / (elapsed / args.steps)
         abytes = algorithmic_bytes_per_problem(NS, NC, T_H) * B
         traffic = None
-        try:        # round 3: the per-kernel counter summary of tools/prof_any.sh
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_prof_%s.json" % ("bounded" if args.bounded else "headline"))))["pmc_avg_per_dispatch"]
-            traffic = pm["lqr_step_dpp16_kernel<%d>" % (2 if args.bounded else 0)]["hbm_bytes_per_dispatch"] if impl_used == 3 else None
-        except Exception:
-            traffic = None
+        for rnd in ("r04", "r03"):        # the per-kernel counter summary of tools/prof_any.sh, newest round first
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "%s_prof_%s.json" % (rnd, "bounded" if args.bounded else "headline"))))["pmc_avg_per_dispatch"]
+                traffic = pm["lqr_step_dpp16_kernel<%d>" % (2 if args.bounded else 0)]["hbm_bytes_per_dispatch"] if impl_used == 3 else None
+                break
+            except Exception:
+                traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if traffic is None and os.path.exists(tpath):
             try:
