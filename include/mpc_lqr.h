@@ -218,7 +218,8 @@ int mpc_lqr_kkt_prepare(int dtype, int B, int T, int ns, int nc,
  *     products; no prepare / costate passes over C and F).
  *     p = (C, c, F, f) of the forward with cur_x / cur_u = the solution (x*, u*); p->f only decides whether df is written.
  *     o = the forward's bounds: controls within 1e-8 of u_lower / u_upper are pinned in the KKT solve (:316-326); o may be
- *     NULL (no bounds).  dl_dx [T,B,ns], dl_du [T,B,nc].  Outputs as (4); dx_out / du_out (the KKT solve's own dx, du) and
+ *     NULL (no bounds).  zero_mask and delta_u of o are ignored, as the reference's backward ignores them (:322-340: the
+ *     nested solve is built from the bounds alone).  dl_dx [T,B,ns], dl_du [T,B,nc].  Outputs as (4); dx_out / du_out (the KKT solve's own dx, du) and
  *     status [B] may be NULL.  workspace: mpc_lqr_kkt_fused_workspace_bytes(p), 16-byte aligned.
  *     mpc_lqr_kkt_fused_supported: 1 if this (problem, options) pair has the kernel -- sizes, dtype and flags only; pointer
  *     alignment is checked at launch (MPC_E_DIMS). */

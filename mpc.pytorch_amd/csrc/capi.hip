@@ -426,7 +426,10 @@ int mpc_lqr_kkt_fused_supported(const mpc_lqr_problem *p, const mpc_lqr_options 
     const bool s12 = p->ns == 12 && p->nc == 4 && p->T <= 64, s32 = p->ns == 32 && p->nc == 8;
     if (p->dtype != MPC_F32 || !(s12 || s32)) return 0;
     if (!o || !(o->flags & MPC_OPT_C_SYMMETRIC)) return 0;
-    if (o->zero_mask || o->true_dynamics || (o->delta_u == o->delta_u && o->delta_u >= 0)) return 0;
+    // (u_zero_I and delta_u of the FORWARD are not inputs of the backward: the reference's nested solve is built from the bounds
+    // alone, `u_zero_I = I` from u* and the bounds, `delta_u = None`, mpc/lqr_step.py:322-340 -- the launchers drop them; rounds
+    // 1-3 refused such options here and the caller fell to three launches for nothing)
+    if (o->true_dynamics) return 0;
     return 1;
 }
 

@@ -509,17 +509,21 @@ bool kkt_fused_dpp16_supported(const StepParams<float> &p, const float *dl_dx, c
     if (!al(p.C, p.C_st, p.C_sb) || !al(p.c, p.c_st, p.c_sb)) return false;
     if (p.T > 1 && !al(p.F, p.F_st, p.F_sb)) return false;
     if (p.bound_mode == MPC_BOUND_TENSOR && (!al(p.lo, 0, 0) || !al(p.hi, 0, 0))) return false;
-    if (p.zero_mask || p.has_delta) return false;
+    // (p.zero_mask / p.has_delta: the forward's u_zero_I and delta_u, which the backward does not use -- mpc/lqr_step.py:322-340;
+    // launch_kkt_fused_dpp16 clears them)
     return al(p.cur_x, 0, 0) && al(p.cur_u, 0, 0) && al(dl_dx, 0, 0) && al(dl_du, 0, 0) && al(dC, 0, 0) && al(ws, 0, 0) &&
            (p.T == 1 || al(dF, 0, 0));
 }
 
 int64_t kkt_fused_dpp16_workspace_bytes(int T, int B) { return (int64_t)T * B * (dpp16::KF_VBLK + 24) * 4 + 64; }
 
-int launch_kkt_fused_dpp16(const StepParams<float> &p, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
+int launch_kkt_fused_dpp16(const StepParams<float> &p_in, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
                            float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
                            hipStream_t st)
 {
+    StepParams<float> p = p_in;
+    p.zero_mask = nullptr;          // the forward's u_zero_I / delta_u are no inputs of the backward (mpc/lqr_step.py:322-340)
+    p.has_delta = 0;
     dpp16::KktFusedArgs k;
     k.dl_dx = dl_dx; k.dl_du = dl_du; k.dC = dC; k.dc = dc; k.dF = dF; k.df = df; k.dx_init = dx_init;
     k.dx_out = dx_out; k.du_out = du_out; k.vws = ws; k.decay = decay; k.max_ls = max_ls;

@@ -180,7 +180,7 @@ bool kkt_fused_mfma40_supported(const StepParams<float> &p, const float *dl_dx, 
     if (!al(p.C, p.C_st, p.C_sb) || !al(p.c, p.c_st, p.c_sb)) return false;
     if (p.T > 1 && !al(p.F, p.F_st, p.F_sb)) return false;
     if (p.bound_mode == MPC_BOUND_TENSOR && ((((uintptr_t)p.lo | (uintptr_t)p.hi) & 3) != 0)) return false;
-    if (p.zero_mask || p.has_delta || p.env.kind) return false;
+    if (p.env.kind) return false;           // (zero_mask / has_delta: the forward's, dropped by the launcher -- mpc/lqr_step.py:322-340)
     return al(p.cur_x, 0, 0) && al(p.cur_u, 0, 0) && al(dl_dx, 0, 0) && al(dl_du, 0, 0) && al(dC, 0, 0) && al(ws, 0, 0) &&
            (p.T == 1 || al(dF, 0, 0));
 }
@@ -201,6 +201,8 @@ int launch_kkt_fused_mfma40(const StepParams<float> &p_in, const float *dl_dx, c
     p.old_costs = nullptr;
     p.qp_iters = nullptr;
     p.c_symmetric = true;
+    p.zero_mask = nullptr;
+    p.has_delta = 0;
     mfma40::KktArgs40 kx;
     kx.dl_dx = dl_dx; kx.dl_du = dl_du; kx.dF = dF; kx.df = df; kx.dx_init = dx_init; kx.Vws = V; kx.vgws = vg;
     if (p.bound_mode != MPC_BOUND_NONE) hipLaunchKernelGGL((lqr_kkt_fused_mfma40_kernel<1>), dim3(p.B), dim3(64), 0, st, p, K, k, kx);

@@ -1229,3 +1229,30 @@ def test_padded_mfma40_full_waves_vs_oracle_and_the_exact_kernel_time(be, ns, nc
     except OSError:
         pass
     assert times["unbounded"] <= 1.5 * t32, (times, t32)
+
+
+@pytest.mark.parametrize("ns,nc,T,B", [(12, 4, 20, 9), (32, 8, 6, 3)])
+def test_fused_backward_ignores_the_forwards_u_zero_I_and_delta_u_like_the_reference(be, ns, nc, T, B):
+    """Round 4: options carrying the forward's u_zero_I or delta_u used to be refused by
+    mpc_lqr_kkt_fused_supported, so such a caller silently paid three launches.  The reference's backward uses neither
+    (mpc/lqr_step.py:322-340: the nested solve's mask is built from u* and the bounds, delta_u = None): the fused entry takes
+    the options and the gradients are those of the bounds-only call, bit for bit."""
+    import ctypes
+    import bench
+    from mpc import _native
+    from mpc._native import StepOptions
+    p = bench.make_problem(ns, nc, T, B, torch.float32, DEV, seed=3, u_scale=0.3, clamp=0.5)
+    r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions(u_lower=-0.5, u_upper=0.5))
+    g = torch.Generator(device=DEV).manual_seed(4)
+    gx, gu = torch.randn(tuple(r["new_x"].shape), generator=g, device=DEV), torch.randn(tuple(r["new_u"].shape), generator=g, device=DEV)
+    mask = torch.rand(T, B, nc, device=DEV) < 0.4
+    plain = StepOptions(u_lower=-0.5, u_upper=0.5, c_symmetric=True)
+    loaded = StepOptions(u_lower=-0.5, u_upper=0.5, c_symmetric=True, u_zero_I=mask, delta_u=0.05)
+    pf, _k = be._problem(p["x_init"], p["C"], p["c"], p["F"], p["f"], r["new_x"], r["new_u"])
+    of, _k2 = loaded.to_struct(T, B, nc, p["C"])
+    assert _native.load().mpc_lqr_kkt_fused_supported(ctypes.byref(pf), ctypes.byref(of)) == 1
+    a = be.kkt_backward(p["C"], p["c"], p["F"], p["f"], r["new_x"], r["new_u"], gx, gu, plain)
+    b = be.kkt_backward(p["C"], p["c"], p["F"], p["f"], r["new_x"], r["new_u"], gx, gu, loaded)
+    torch.cuda.synchronize()
+    for k in ("dx_init", "dC", "dc", "dF", "df"):
+        assert torch.equal(a[k], b[k]), k
