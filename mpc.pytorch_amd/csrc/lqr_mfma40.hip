@@ -108,6 +108,15 @@ template <int IMM> MPC_DEV void dma16_at_if(bool active, const void *g, unsigned
 {
     if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage40 + off), 16, IMM, 0);
 }
+// ... of a block read exactly once per launch: the non-temporal policy (aux bit 1; -DMPC_MFMA40_C_AUX=0 for the A/B)
+#ifndef MPC_MFMA40_C_AUX
+#define MPC_MFMA40_C_AUX 2
+#endif
+template <int IMM> MPC_DEV void dma16_once_at(const void *g, unsigned off)
+{
+    static_assert(IMM >= 0 && IMM < 4096, "13-bit signed immediate");
+    __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage40 + off), 16, IMM, MPC_MFMA40_C_AUX);
+}
 // ---- the padded instantiation's staging (lqr_mfma40_body.h, PADK) -------------------------------------------------------------
 // G bytes per lane from `base + voff` (base wave-uniform: a raw buffer of `nbytes`, voff per lane) to LDS offset `off` + G * lane.
 // A lane whose voff lies beyond the buffer writes ZERO (the hardware's range check; measured, tools/ubench/buffer_lds_probe.hip):

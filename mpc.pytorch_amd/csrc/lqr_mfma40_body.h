@@ -382,6 +382,16 @@ template <int NB> MPC_DEV void dma_kib(const char *g, unsigned off)
     if (NB > 3) wv::dma16_at<3072>(g, off);
     if (NB > 4) dma_kib<(NB > 4 ? NB - 4 : 1)>(g + 4096, off + 4096);
 }
+// the same for a block this launch reads exactly ONCE (C in the sweep): streamed past the caches' replacement (round 4: the
+// 420 MB of C otherwise push out the F blocks and gains the rollout is about to read again -- the 12/4 kernel's DMA_C)
+template <int NB> MPC_DEV void dma_kib_once(const char *g, unsigned off)
+{
+    wv::dma16_once_at<0>(g, off);
+    if (NB > 1) wv::dma16_once_at<1024>(g, off);
+    if (NB > 2) wv::dma16_once_at<2048>(g, off);
+    if (NB > 3) wv::dma16_once_at<3072>(g, off);
+    if (NB > 4) dma_kib_once<(NB > 4 ? NB - 4 : 1)>(g + 4096, off + 4096);
+}
 
 MPC_DEV void stage_issue(const P &p, const Stream &d, const Lane &L, int t, int slot)
 {
@@ -395,7 +405,7 @@ MPC_DEV void stage_issue(const P &p, const Stream &d, const Lane &L, int t, int 
         rec_issue(d.rm, tl, tf, tl, base + OFF_R);
         return;
     }
-    dma_kib<6>(d.c_ptr + tl * d.c_step, base + OFF_C);
+    dma_kib_once<6>(d.c_ptr + tl * d.c_step, base + OFF_C);
     wv::dma16_at_if<2048>(L.lane < 16, d.c_ptr + tl * d.c_step + 4096, base + OFF_C + 4096);
     dma_kib<5>(d.f_ptr + (p.T > 1 ? tf * d.f_step : 0), base + OFF_F);
     wv::dma16_if(d.r_active, d.r_ptr + (d.r_is_f ? tf : tl) * d.r_step, base + OFF_R);

@@ -417,6 +417,7 @@ template <int IMM, int KIND = DMA_PLAIN> static inline void dma16_at(const void 
 {
     dma_n((const char *)g + IMM, (unsigned)((int)mid + IMM), 16);
 }
+template <int IMM> static inline void dma16_once_at(const void *g, unsigned mid) { dma_n((const char *)g + IMM, (unsigned)((int)mid + IMM), 16); }
 template <int IMM> static inline void dma16_at_if(bool active, const void *g, unsigned mid)
 {
     dma_n((const char *)g + IMM, (unsigned)((int)mid + IMM), 16, active);
