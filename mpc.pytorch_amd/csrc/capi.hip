@@ -180,7 +180,11 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
         bool fused = false;
         if constexpr (sizeof(real) == 4) fused = (impl == 0 || impl == 3) ? dpp16_supported(sp) : false;
         if constexpr (sizeof(real) == 4) fused = fused || ((impl == 0 || impl == 5) && mfma40_supported(sp));
-        if constexpr (sizeof(real) == 4) fused = fused || ((impl == 0 || impl == 7) && pad_route(sp, workspace, workspace_bytes));
+        // (the padded 32/8 instantiation can stop after its sweep too -- for the shapes that reach it: under impl 0 the 12/4-class
+        // shapes belong to kernels in front of it that cannot, and keep the generic sweep they had)
+        if constexpr (sizeof(real) == 4)
+            fused = fused || (pad_route(sp, workspace, workspace_bytes) &&
+                              (impl == 7 || (impl == 0 && !mfma16_supported(sp) && !tiny_supported(p->ns, p->nc))));
         if (!fused) {
             if (impl != 0 && impl != 1) return fail(MPC_E_ARG, "MPC_OPT_SWEEP_ONLY: this kernel cannot stop after its sweep");
             return launch_step_generic<real>(sp, 1, st);
