@@ -43,7 +43,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert set(_native.EXPORTS) == declared
-    assert L.mpc_lqr_abi_version() == _native.ABI_VERSION == 6
+    assert L.mpc_lqr_abi_version() == _native.ABI_VERSION == 7
     assert b"gfx950" in L.mpc_lqr_build_info()
 
 

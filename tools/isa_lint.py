@@ -58,7 +58,7 @@ def in_timestep_loop(lines, loops, i):
     body) and has no other staging loop nested inside it (the loop over line-search passes does)."""
     key = id(lines)
     if key not in _DMA_LOOPS:
-        _DMA_LOOPS[key] = [(a, b) for a, b in loops if any("_load_lds_" in x for x in lines[a:b])]
+        _DMA_LOOPS[key] = [(a, b) for a, b in loops if any("_load_lds_" in x or (x.lstrip().startswith("buffer_load") and x.rstrip().endswith(" lds")) for x in lines[a:b])]
     dma = _DMA_LOOPS[key]
     around = sorted((b - a, a, b) for a, b in dma if a <= i <= b)
     if not around:
