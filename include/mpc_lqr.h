@@ -213,7 +213,7 @@ int mpc_lqr_kkt_prepare(int dtype, int B, int T, int ns, int nc,
 
 /* (4c) ALL of LQRStepFn.backward (mpc/lqr_step.py:312-407) in ONE call, where kernels for it exist: fp32, 16-byte aligned
  *     blocks, the caller's promise MPC_OPT_C_SYMMETRIC in o->flags (without it the three calls above are the way: their step
- *     tests C and re-solves what is not symmetric), and either n_state = 12, n_ctrl = 4, T <= 64 (one launch) or
+ *     tests C and re-solves what is not symmetric), and either n_state = 12, n_ctrl = 4 (one launch; beyond 64 timesteps the gains go through the workspace) or
  *     n_state = 32, n_ctrl = 8, any T (two launches: the nested step with both costates riding along, then the outer
  *     products; no prepare / costate passes over C and F).
  *     p = (C, c, F, f) of the forward with cur_x / cur_u = the solution (x*, u*); p->f only decides whether df is written.

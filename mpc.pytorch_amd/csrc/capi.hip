@@ -427,7 +427,7 @@ int mpc_lqr_kkt_grads(const mpc_lqr_problem *p, const void *dx, const void *du, 
 int mpc_lqr_kkt_fused_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o)
 {
     if (!p || check_problem(p, false, false) != MPC_OK || check_options(p, o) != MPC_OK) return 0;
-    const bool s12 = p->ns == 12 && p->nc == 4 && p->T <= 64, s32 = p->ns == 32 && p->nc == 8;
+    const bool s12 = p->ns == 12 && p->nc == 4, s32 = p->ns == 32 && p->nc == 8;      // (12/4: any horizon since round 4)
     if (p->dtype != MPC_F32 || !(s12 || s32)) return 0;
     if (!o || !(o->flags & MPC_OPT_C_SYMMETRIC)) return 0;
     // (u_zero_I and delta_u of the FORWARD are not inputs of the backward: the reference's nested solve is built from the bounds
@@ -451,7 +451,7 @@ int mpc_lqr_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const 
     if (rc) return rc;
     if ((rc = check_options(p, o))) return rc;
     if (!mpc_lqr_kkt_fused_supported(p, o))
-        return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: needs fp32, n_state = 12, n_ctrl = 4, T <= 64 or n_state = 32, n_ctrl = 8, and "
+        return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: needs fp32, n_state = 12, n_ctrl = 4 or n_state = 32, n_ctrl = 8, and "
                                 "MPC_OPT_C_SYMMETRIC (otherwise: mpc_lqr_kkt_prepare + mpc_lqr_step + mpc_lqr_kkt_grads)");
     if (p->B == 0) return MPC_OK;
     if (!dl_dx || !dl_du || !dC || !dc || !dx_init) return fail(MPC_E_NULL, "kkt_fused: NULL argument");

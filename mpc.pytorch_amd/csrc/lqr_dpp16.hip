@@ -453,10 +453,18 @@ __global__ void __launch_bounds__(64, 1) lqr_step_dpp16_kernel(StepParams<float>
 #if MPC_DPP16_NSTAGE == 4
 // the whole of LQRStepFn.backward in one launch (lqr_dpp16_body.h: kkt_fused_wave); MASKED = controls on a bound are pinned
 static_assert(dpp16::KF_P2_SLOTS * dpp16::KF_P2_STAGE <= MPC_DPP16_LDS, "the fused KKT kernel's second ring does not fit");
+static_assert((int)dpp16::KfP2<true>::SLOTS * (int)dpp16::KfP2<true>::STAGE <= MPC_DPP16_LDS && (int)dpp16::KfP2<true>::SLOTS >= 5,
+              "the long-horizon fused KKT kernel's second ring does not fit");
 template <bool MASKED>
 __global__ void __launch_bounds__(64, 1) lqr_kkt_fused_dpp16_kernel(StepParams<float> p, dpp16::KktFusedArgs k)
 {
     dpp16::kkt_fused_wave<MASKED>(p, k);
+}
+// T > 64 (round 4): the gains through the workspace instead of the accumulation registers (lqr_dpp16_body.h, KfP2<true>)
+template <bool MASKED>
+__global__ void __launch_bounds__(64, 1) lqr_kkt_fused_long_dpp16_kernel(StepParams<float> p, dpp16::KktFusedArgs k)
+{
+    dpp16::kkt_fused_wave<MASKED, true>(p, k);
 }
 
 #endif
@@ -505,7 +513,7 @@ bool kkt_fused_dpp16_supported(const StepParams<float> &p, const float *dl_dx, c
                                const float *dF, const float *ws)
 {
     auto al = [](const void *q, long st, long sb) { return ((uintptr_t)q % 16 == 0) && (st % 4 == 0) && (sb % 4 == 0); };
-    if (!(p.ns == 12 && p.nc == 4 && p.T >= 1 && p.T <= dpp16::RG_STEPS)) return false;
+    if (!(p.ns == 12 && p.nc == 4 && p.T >= 1)) return false;          // (any horizon since round 4: T > 64 on the LONG instantiation)
     if (!al(p.C, p.C_st, p.C_sb) || !al(p.c, p.c_st, p.c_sb)) return false;
     if (p.T > 1 && !al(p.F, p.F_st, p.F_sb)) return false;
     if (p.bound_mode == MPC_BOUND_TENSOR && (!al(p.lo, 0, 0) || !al(p.hi, 0, 0))) return false;
@@ -515,7 +523,11 @@ bool kkt_fused_dpp16_supported(const StepParams<float> &p, const float *dl_dx, c
            (p.T == 1 || al(dF, 0, 0));
 }
 
-int64_t kkt_fused_dpp16_workspace_bytes(int T, int B) { return (int64_t)T * B * (dpp16::KF_VBLK + 24) * 4 + 64; }
+// floats per problem-step: (V | v) 96, (lambda | g) 24, and beyond 64 timesteps the gain record 64
+int64_t kkt_fused_dpp16_workspace_bytes(int T, int B)
+{
+    return (int64_t)T * B * (dpp16::KF_VBLK + 24 + (T > dpp16::RG_STEPS ? 64 : 0)) * 4 + 64;
+}
 
 int launch_kkt_fused_dpp16(const StepParams<float> &p_in, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
                            float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
@@ -528,7 +540,10 @@ int launch_kkt_fused_dpp16(const StepParams<float> &p_in, const float *dl_dx, co
     k.dl_dx = dl_dx; k.dl_du = dl_du; k.dC = dC; k.dc = dc; k.dF = dF; k.df = df; k.dx_init = dx_init;
     k.dx_out = dx_out; k.du_out = du_out; k.vws = ws; k.decay = decay; k.max_ls = max_ls;
     const dim3 grid((p.B + 3) / 4), block(64);
-    if (p.bound_mode != MPC_BOUND_NONE) hipLaunchKernelGGL((lqr_kkt_fused_dpp16_kernel<true>), grid, block, 0, st, p, k);
+    if (p.T > dpp16::RG_STEPS) {
+        if (p.bound_mode != MPC_BOUND_NONE) hipLaunchKernelGGL((lqr_kkt_fused_long_dpp16_kernel<true>), grid, block, 0, st, p, k);
+        else hipLaunchKernelGGL((lqr_kkt_fused_long_dpp16_kernel<false>), grid, block, 0, st, p, k);
+    } else if (p.bound_mode != MPC_BOUND_NONE) hipLaunchKernelGGL((lqr_kkt_fused_dpp16_kernel<true>), grid, block, 0, st, p, k);
     else hipLaunchKernelGGL((lqr_kkt_fused_dpp16_kernel<false>), grid, block, 0, st, p, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -1635,8 +1635,15 @@ struct KktFusedArgs {
 // timestep's stores right behind that read: vector stores sit in the same vmcnt queue as the stage DMAs, a counted wait
 // can only count the loads (reads and writes complete out of order with respect to each other), so a wait pays for
 // every store still in flight -- behind the read they have a timestep of arithmetic to land in.
-enum { KF_VBLK = 96,
-       KF_P2_STAGE = 5632, KF_P2_SLOTS = LDS_TOTAL / KF_P2_STAGE >= 6 ? 6 : 3, KF_P2_AHEAD = KF_P2_SLOTS - 1, KF_P2_DMA = 6 };
+enum { KF_VBLK = 96 };
+// LONG (round 4): T > RG_STEPS -- the gains of the whole horizon do not fit the 256 accumulation registers; pass 1 stores the
+// record [T,B,64] behind (lambda | g) in the workspace like mode 3 of the step kernel, pass 2's stage carries it as a seventh
+// DMA instruction (+ 1 KiB: five slots in the same staging memory instead of six).  T <= 64 is the kernel of round 3, untouched.
+template <bool LONG> struct KfP2 {
+    enum { STAGE = LONG ? 6656 : 5632, SLOTS = (int)LDS_TOTAL / STAGE >= 6 ? 6 : ((int)LDS_TOTAL / STAGE >= 5 ? 5 : 3), AHEAD = SLOTS - 1,
+           DMA = LONG ? 7 : 6, GOFF = 5632 };
+};
+enum { KF_P2_STAGE = KfP2<false>::STAGE, KF_P2_SLOTS = KfP2<false>::SLOTS };
 // row offset of row i in the packed upper triangle of a symmetric 12 x 12: entries (i, j >= i) at tri_off(i) + j - i
 MPC_DEV int tri_off(int i) { return 12 * i - (i * (i - 1)) / 2; }
 
@@ -1650,9 +1657,11 @@ struct KfStage2 {            // pass 2
     float tj, l1, g1, v1;
 };
 
-template <bool MASKED>
+template <bool MASKED, bool LONG = false>
 MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
 {
+    enum { KF_P2_STAGE = KfP2<LONG>::STAGE, KF_P2_SLOTS = KfP2<LONG>::SLOTS, KF_P2_AHEAD = KfP2<LONG>::AHEAD, KF_P2_DMA = KfP2<LONG>::DMA };
+    static_assert((KF_P2_AHEAD - 1) * KF_P2_DMA < 64, "vmcnt is 6 bits");
     const int lane = wv::lane();
     const int wave = wv::problem();
     if (4 * wave >= p.B) return;
@@ -1709,7 +1718,10 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
     for (int i = 0; i < 12; ++i) Vc[i] = 0.f;
     double w0 = 0.0;
     int status = 0;
-    Gains<true> G;
+    Gains<!LONG> G;
+    // LONG: this lane's 16 bytes of the gain record [T,B,16,4] behind (V | v) [T,B,96] and (lambda | g) [T,B,24] in the workspace
+    float *const gws = k.vws + (long)T * B * (KF_VBLK + 24);
+    float *gp = gws + ((long)(T - 1) * B + pb) * 64 + 4 * L.j;
     // this lane's element (., j) of the packed (V | v) block and of (lambda | g), at t = T-1, stepping back a timestep a trip
     float *vp = k.vws + ((long)(T - 1) * B + pb) * KF_VBLK + L.j;
     float *lp = k.vws + (long)T * B * KF_VBLK + ((long)(T - 1) * B + pb) * 24 + L.j;
@@ -1848,7 +1860,12 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
                 // g_t = F_x' g_{t+1} - Qxu k_t (the header): Qxu k_t is what v just took on
                 float gn = q - vn;
                 if (!last) wv::dot_bcast12(gn, gv, s1.Fc);
-                gain_put(G, t, f32x4{K[0], K[1], K[2], K[3]});
+                if (LONG) {
+                    wv::store_f32x4(gp, f32x4{K[0], K[1], K[2], K[3]});
+                    gp -= B * 64;
+                } else {
+                    gain_put(G, t, f32x4{K[0], K[1], K[2], K[3]});
+                }
 #pragma unroll
                 for (int r = 0; r < 12; ++r) Vc[r] = Vn[r];
                 vv = vn;
@@ -1933,6 +1950,7 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
         wv::dma16_if(r2_active, r2_ptr + (gi >= 8 ? t1 : (long)t) * r2_step, sb + 3072);
         wv::dma16_once(v2_ptr[0] + t1 * v2_step, sb + 4096);
         wv::dma16_if(v2_active, v2_ptr[1] + t1 * v2_step, sb + 4096 + 1024);
+        if (LONG) wv::dma16_once((const char *)(gws + ((long)t * B + pb) * 64 + 4 * L.j), sb + (unsigned)KfP2<LONG>::GOFF);
     };
     // index of V[i][j] in the packed block, for this lane's column j
     int vidx[12];
@@ -1974,7 +1992,7 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
             if (t < T) {
                 const bool have = t < T - 1;
                 issue2(t + KF_P2_AHEAD, (i + KF_P2_AHEAD) % KF_P2_SLOTS);
-                const f32x4 rec = gain_get(G, t);
+                const f32x4 rec = LONG ? wv::lds_f32x4((unsigned)(i * KF_P2_STAGE + (int)KfP2<LONG>::GOFF + 16 * lane)) : gain_get(G, t);
                 // du = K dx + alpha k  (:192; pinned controls have zero rows of K and k: they stay at 0)
                 const float dxj = L.isu ? 0.f : xs;
                 const float mult = L.j == 12 ? alpha : dxj;

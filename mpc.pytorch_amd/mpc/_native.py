@@ -588,7 +588,7 @@ class HipBackend:
         o, keep_o = opts.to_struct(T, B, nc, C)
         has_f = f is not None and f.numel() > 0
         if impl == IMPL_AUTO:
-            # the whole backward in one launch where a kernel for it exists (12/4, fp32, T <= 64, C vouched symmetric)
+            # the whole backward in one launch where a kernel for it exists (12/4 or 32/8, fp32, C vouched symmetric)
             pf, keep_f = self._problem(x_star[0], C, c, F, f, x_star, u_star)
             if L.mpc_lqr_kkt_fused_supported(ctypes.byref(pf), ctypes.byref(o)):
                 g = dict(dC=torch.empty(T, B, n, n, **kw), dc=torch.empty(T, B, n, **kw), dF=torch.empty(F.shape, **kw),

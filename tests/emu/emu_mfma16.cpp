@@ -551,7 +551,11 @@ extern "C" int emu_kkt_dpp16(const mpc_lqr_problem *p, const float *dx, const fl
 }
 
 static const mpclqr::dpp16::KktFusedArgs *g_kf;
-template <bool MASKED> static void body_kkt_fused() { mpclqr::dpp16::kkt_fused_wave<MASKED>(*g_p, *g_kf); }
+template <bool MASKED> static void body_kkt_fused()
+{
+    if (g_p->T > mpclqr::dpp16::RG_STEPS) mpclqr::dpp16::kkt_fused_wave<MASKED, true>(*g_p, *g_kf);      // the long-horizon instantiation
+    else mpclqr::dpp16::kkt_fused_wave<MASKED>(*g_p, *g_kf);
+}
 
 // the whole KKT backward in one (emulated) launch: lqr_dpp16_body.h, kkt_fused_wave
 extern "C" int emu_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const float *dl_dx, const float *dl_du,
@@ -562,8 +566,8 @@ extern "C" int emu_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o,
     memset(&out, 0, sizeof(out));
     out.status = status;
     mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, &out);
-    if (!(sp.ns == 12 && sp.nc == 4 && sp.T <= mpclqr::dpp16::RG_STEPS)) return MPC_E_DIMS;
-    const size_t need = (size_t)sp.T * sp.B * (mpclqr::dpp16::KF_VBLK + 24) + 4;
+    if (!(sp.ns == 12 && sp.nc == 4)) return MPC_E_DIMS;
+    const size_t need = (size_t)sp.T * sp.B * (mpclqr::dpp16::KF_VBLK + 24 + (sp.T > mpclqr::dpp16::RG_STEPS ? 64 : 0)) + 4;
     float *ws = (float *)aligned_alloc(16, (need * sizeof(float) + 15) / 16 * 16);
     for (size_t i = 0; i < need; ++i) ws[i] = NAN;
     mpclqr::dpp16::KktFusedArgs k;

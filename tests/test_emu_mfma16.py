@@ -271,7 +271,7 @@ def test_emulated_kkt_dpp16_matches_oracle(emu, bounded, with_f, B, dma_late, ri
 
 @pytest.mark.parametrize("ring2", [False, True], ids=["ring4", "ring2"])
 @pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
-@pytest.mark.parametrize("case", ["unbounded", "bounded", "bounded_nof", "tensor_bounds", "T1", "T2", "T3", "T7_B9", "T64", "nonconvex"])
+@pytest.mark.parametrize("case", ["unbounded", "bounded", "bounded_nof", "tensor_bounds", "T1", "T2", "T3", "T7_B9", "T64", "nonconvex", "T65", "T70_bounded"])
 def test_emulated_fused_kkt_backward_matches_oracle(emu, case, dma_late, ring2):
     """kkt_fused_wave: ALL of LQRStepFn.backward (mpc/lqr_step.py:312-407) in one launch -- the nested LQR solve's sweep
     with lambda riding along, then its rollout with dlambda = V dx + v and every gradient of the timestep -- against
@@ -282,9 +282,11 @@ def test_emulated_fused_kkt_backward_matches_oracle(emu, case, dma_late, ring2):
     staging array (two / three stages), other wait counts."""
     from oracle import lqr_oracle as O
     rng = np.random.default_rng(sum(map(ord, case)))
-    T = {"T1": 1, "T2": 2, "T3": 3, "T7_B9": 7, "T64": 64}.get(case, 6)
-    B = 9 if case == "T7_B9" else (3 if case == "T64" else 5)
-    bounded = case in ("bounded", "bounded_nof", "tensor_bounds", "T7_B9", "T2")
+    # (T65, T70_bounded: round 4 -- beyond the 64 timesteps whose gains fit the accumulation registers the kernel's LONG
+    # instantiation takes the gains through the workspace and a seventh DMA instruction per pass-2 stage)
+    T = {"T1": 1, "T2": 2, "T3": 3, "T7_B9": 7, "T64": 64, "T65": 65, "T70_bounded": 70}.get(case, 6)
+    B = 9 if case == "T7_B9" else (3 if case == "T64" else (5 if T < 64 else 6))
+    bounded = case in ("bounded", "bounded_nof", "tensor_bounds", "T7_B9", "T2", "T70_bounded")
     pr = _ns_problem(rng, max(T, 2), B, with_f=case != "bounded_nof")
     if case == "nonconvex":
         # Quu indefinite on two problems: the sweep's stationary point is no minimum there, the nested step's cost goes UP

@@ -425,7 +425,7 @@ def test_kkt_backward_parity(be, name):
                                        err_msg="%s impl %d" % (k, impl))
 
 
-@pytest.mark.parametrize("ns,nc,T,B", [(32, 8, 9, 5), (20, 4, 6, 3), (8, 4, 5, 2), (32, 8, 1, 2), (60, 4, 3, 2), (12, 4, 7, 9)])
+@pytest.mark.parametrize("ns,nc,T,B", [(32, 8, 9, 5), (20, 4, 6, 3), (8, 4, 5, 2), (32, 8, 1, 2), (60, 4, 3, 2), (12, 4, 7, 9), (12, 4, 65, 9), (12, 4, 100, 70), (13, 4, 6, 3)])
 @pytest.mark.parametrize("with_f,bounded", [(True, False), (False, True)])
 def test_kkt_backward_wave_kernels(be, ns, nc, T, B, with_f, bounded):
     """float32 shapes up to n = 64 (config 5 among them): the costate recursion per wavefront + the fully
