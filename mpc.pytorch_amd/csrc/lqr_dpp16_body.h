@@ -342,7 +342,7 @@ struct Lane {
     long ostep;           // ... and its stride per timestep
     float *scr0;          // this lane's element of the second trial's trajectory [T,B,16] (workspace) at t = 0
     long ostep1;          // = 16 B
-    int aMrow;            // SC + p*256 + 4 a                   (second record; + RollRing::MADJ)
+    int aMcol;            // SC + p*256 + 16 j                  (second record, this lane's own 16 bytes = column j of (M | m); + RollRing::MADJ)
 };
 
 // cperm: the C blocks of this launch are staged with their rows permuted per problem slot (src_granule_C): only the
@@ -377,7 +377,7 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B, bool cperm = true)
     L.aRecA = SR + L.p * 256 + 4 * L.a;
     L.aRecF = SR + L.p * 256 + R_f + 4 * jx;
     L.aKrow = SG + L.p * 256 + 4 * L.a;
-    L.aMrow = SC + L.p * 256 + 4 * L.a;
+    L.aMcol = SC + L.p * 256 + 16 * L.j;
     // Quu in the gain record: lanes 13..15 carry columns 1..3 of Quu as they stand in their Q registers
     // (element r of lane 12 + c = Quu[r][c]); Quu[0][0], which only lane 12 (the k lane) holds, replaces the
     // redundant Quu[2][1] in lane 13.  Quu[a][b] is read as (column max(a,b), row min(a,b)).
@@ -715,12 +715,27 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     PROF_MARK(10);              // slot 10: c_back + the products Y, Q, q
     // ---- the 4x4 control block: row-uniform copies out of lanes 12..15 --------------------------
     Sym4 S;
+    float qu[4];
+#ifdef MPC_DPP16_DPP_BCAST          // (rounds 1-3: fourteen DPP row broadcasts, each a v_mov_b32_dpp behind its wait states)
     S.s00 = wv::bcast<12>(Q[12]); S.s01 = wv::bcast<13>(Q[12]); S.s02 = wv::bcast<14>(Q[12]); S.s03 = wv::bcast<15>(Q[12]);
     S.s11 = wv::bcast<13>(Q[13]); S.s12 = wv::bcast<14>(Q[13]); S.s13 = wv::bcast<15>(Q[13]);
     S.s22 = wv::bcast<14>(Q[14]); S.s23 = wv::bcast<15>(Q[14]);
     S.s33 = wv::bcast<15>(Q[15]);
-    float qu[4];
     qu[0] = wv::bcast<12>(q); qu[1] = wv::bcast<13>(q); qu[2] = wv::bcast<14>(q); qu[3] = wv::bcast<15>(q);
+#else
+    // Round 4: the 4x4x1 outer product with a unit B operand IS a broadcast -- d[v] (every lane of the row) = a (lane 12 + v) * 1:
+    // four lanes' values in one instruction (exact: one multiplication by 1, + 0).  Five instructions for Quu and qu.
+    {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 r0 = wv::mfma4<3>(Q[12], 1.f, z4), r1 = wv::mfma4<3>(Q[13], 1.f, z4);
+        const f32x4 r2 = wv::mfma4<3>(Q[14], 1.f, z4), r3 = wv::mfma4<3>(Q[15], 1.f, z4), rq = wv::mfma4<3>(q, 1.f, z4);
+        S.s00 = r0[0]; S.s01 = r0[1]; S.s02 = r0[2]; S.s03 = r0[3];
+        S.s11 = r1[1]; S.s12 = r1[2]; S.s13 = r1[3];
+        S.s22 = r2[2]; S.s23 = r2[3];
+        S.s33 = r3[3];
+        qu[0] = rq[0]; qu[1] = rq[1]; qu[2] = rq[2]; qu[3] = rq[3];
+    }
+#endif
 
     bool fr[4] = {true, true, true, true};
     const bool valid[4] = {true, true, true, true};
@@ -738,7 +753,14 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     } else {
         // :128-141 box constraints in delta space
         float lb[4], ub[4], ubar[4];
+#ifdef MPC_DPP16_DPP_BCAST
         ubar[0] = wv::bcast<12>(s.tb); ubar[1] = wv::bcast<13>(s.tb); ubar[2] = wv::bcast<14>(s.tb); ubar[3] = wv::bcast<15>(s.tb);
+#else
+        {
+            const f32x4 ru = wv::mfma4<3>(s.tb, 1.f, f32x4{0.f, 0.f, 0.f, 0.f});
+            ubar[0] = ru[0]; ubar[1] = ru[1]; ubar[2] = ru[2]; ubar[3] = ru[3];
+        }
+#endif
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             float l = s.lo[a] - ubar[a], h = s.hi[a] - ubar[a];
@@ -801,10 +823,19 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     float M[4] = {0.f, 0.f, 0.f, 0.f};
     if (con(MODE)) {
         // with a full free set Qux + Quu K vanishes; with masked / clamped controls it does not
+#ifdef MPC_DPP16_DPP_BCAST
         M[0] = fmaf(S.s03, K[3], fmaf(S.s02, K[2], fmaf(S.s01, K[1], fmaf(S.s00, K[0], rhs[0]))));
         M[1] = fmaf(S.s13, K[3], fmaf(S.s12, K[2], fmaf(S.s11, K[1], fmaf(S.s01, K[0], rhs[1]))));
         M[2] = fmaf(S.s23, K[3], fmaf(S.s22, K[2], fmaf(S.s12, K[1], fmaf(S.s02, K[0], rhs[2]))));
         M[3] = fmaf(S.s33, K[3], fmaf(S.s23, K[2], fmaf(S.s13, K[1], fmaf(S.s03, K[0], rhs[3]))));
+#else
+        // M = Qux + Quu K as four rank-1 updates on the matrix core: column b of Quu sits in lanes 12..15 of register Q[12 + b]
+        // (Quu symmetric), row b of K one entry per lane -- the same multiply-adds in the same order, four instructions for sixteen
+        f32x4 Mv = {rhs[0], rhs[1], rhs[2], rhs[3]};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Mv = wv::mfma4<3>(Q[12 + b], K[b], Mv);
+        M[0] = Mv[0]; M[1] = Mv[1]; M[2] = Mv[2]; M[3] = Mv[3];
+#endif
     }
     wv::sched_fence();
     feed.template part<3>();
@@ -881,9 +912,10 @@ struct RoStage {
     float Cr[16];     // row j of C                         (direct pricing only)
     float Fr[16];     // row j of F (state lanes)
     float Kr[12];     // row a of K (control lanes)
-    float Mr[12];     // row a of M = Qux + Quu K           (identity pricing, constrained modes)
+    float Mc[4];      // column j of M = Qux + Quu K (j < 12), m = qu + Quu k (j = 12): this lane's own granule of the sweep's
+                      // second record (identity pricing, constrained modes)
     float Sr[4];      // row a of Quu                       (identity pricing)
-    float cj, tb, fj, kk, mk, lo, hi;
+    float cj, tb, fj, kk, lo, hi;
     f32x4 rec;        // register-resident gains (mode 0): the record in the sweep's own layout, see Gains
     bool zm;
 };
@@ -914,7 +946,6 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
     const unsigned mrec = base + RollRing<MODE, DIRECT>::MADJ;
     const unsigned gain = base + RollRing<MODE, DIRECT>::GADJ;
     s.cj = 0.f;
-    s.mk = 0.f;
     if (DIRECT) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -926,9 +957,10 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
 #pragma unroll
         for (int b = 0; b < 4; ++b) s.Sr[b] = rgm(MODE) ? 0.f : wv::lds_f32(gain + L.aS[b]);
         if (con(MODE)) {
-#pragma unroll
-            for (int jj = 0; jj < 12; ++jj) s.Mr[jj] = wv::lds_f32(mrec + L.aMrow + 16 * jj);
-            s.mk = wv::lds_f32(mrec + L.aMrow + 192);
+            // (round 4: e'(m + M dx) = sum_j [dx_j; 1] (M | m)'e -- each lane needs ITS column, one 16-byte read, and four
+            // broadcast multiply-adds of e; rounds 1-3 read row a of M on the control lanes: 13 reads, 12 multiply-adds)
+            const f32x4 mc = wv::lds_f32x4(mrec + L.aMcol);
+            s.Mc[0] = mc[0]; s.Mc[1] = mc[1]; s.Mc[2] = mc[2]; s.Mc[3] = mc[3];
         }
     }
     // (t = T-1: a copy of F[T-2], unused)
@@ -1017,12 +1049,13 @@ MPC_DEV float stage_price(const Lane &L, const RoStage &s, float tp, float e, fl
     }
     float se = 0.f;
     wv::dot_bcast_u4(se, e, s.Sr);                 // sum_b bcast_{12+b}(e) Sr[b]
-    float lin = 0.5f * se;
-    if (con(MODE)) {
-        lin += s.mk;
-        wv::dot_bcast12(lin, dx, s.Mr);
-    }
-    return L.isu ? e * lin : 0.f;
+    const float quad = L.isu ? e * (0.5f * se) : 0.f;          // e'Quu e / 2, on the control lanes
+    if (!con(MODE)) return quad;
+    // e'(m + M dx): lane j < 12 adds dx_j (M'e)_j, lane 12 (whose column is m) adds m'e
+    float w = 0.f;
+    wv::dot_bcast_u4(w, e, s.Mc);
+    const float mult = L.j < 12 ? dx : 1.f;
+    return L.j <= 12 ? fmaf(mult, w, quad) : quad;          // (lanes 13..15 hold no column of the record)
 }
 
 template <int MODE, bool DIRECT, bool CHECK, bool PAIR = false>
