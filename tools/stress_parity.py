@@ -18,7 +18,9 @@ from oracle import lqr_oracle as O
 be = _native.HipBackend()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 NS, NC, TT = (int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (12, 4, 50)
-IMPLS = [i for i in (1, 2, 3, 4, 5, 6) if be.impl_supported(NS, NC, torch.float32, i)]
+IMPLS = [i for i in (1, 2, 3, 4, 5, 6, 7) if be.impl_supported(NS, NC, torch.float32, i)]
+if len(sys.argv) > 3:                      # e.g. "3,7": only these kernels (the generic one is slow at large batches)
+    IMPLS = [i for i in IMPLS if str(i) in sys.argv[3].split(",")]
 bad = 0
 for case in ("unbounded", "bounded", "tensor_bounds", "delta_u", "tight"):
     for seed in range(4):
