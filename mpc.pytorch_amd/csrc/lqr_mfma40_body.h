@@ -507,6 +507,69 @@ MPC_DEV void ldl8v_solve(const Ldl8V &f, float (&y)[8])
     Ldl8VBwd<7>::run(f, y);
 }
 
+// ---- Gauss-Jordan on the same lane-spread matrix: the factorisation of the box QP's trips (round 4) ----------------
+// A trip of the QP solves ONE system whose right-hand side is spread over lanes like the matrix (lane a: entry a).  With
+// LDL' that costs the factorisation, eight broadcasts to give every lane the whole right-hand side, 64 multiply-adds of
+// triangular solves on it and eight selects to spread the answer again.  Eliminating ABOVE the pivot as well (the same
+// instruction: lane a < c simply keeps a live multiplier) lets the right-hand side ride along as a ninth column -- one
+// DPP multiply-add per pivot -- and leaves the solution where it is wanted: 44 instructions in place of ~90.  The
+// multipliers are a factorisation too: the K solve behind the QP applies them to its per-lane right-hand sides at the
+// price of the triangular solves (56 + 8 against 64 + 8).  SPD matrix, same pivots as the LDL' -- no pivoting needed.
+struct Gj8V {
+    float nl[8];     // lane a: -(A[a][c] / d_c) as it stood at pivot c (the multiplier of row a), 0 in lane c itself
+    float inv[8];    // 1 / d_c in every lane
+};
+template <int C> struct Gj8VPivot {
+    static MPC_DEVM void run(Gj8V &f, float (&col)[8], float &rhs, float &invd, int r)
+    {
+        const float inv = wv::rcp(wv::bcast<C>(col[C]));
+        f.inv[C] = inv;
+        const float t = -(col[C] * inv);
+        f.nl[C] = r == C ? 0.f : t;
+        invd = r == C ? inv : invd;
+        // (the unpivoted block stays symmetric: A[c][m] is lane m of column c, as in ldl8v)
+        Ldl8VElim<C, C + 1>::run(col, f.nl[C]);
+        wv::fmac_bcast<C>(rhs, rhs, f.nl[C]);               // rhs[a] -= l[a] rhs[c]  (rhs was written by the previous pivot)
+        Gj8VPivot<C + 1>::run(f, col, rhs, invd, r);
+    }
+};
+template <> struct Gj8VPivot<8> { static MPC_DEVM void run(Gj8V &, float (&)[8], float &, float &, int) {} };
+// col: the matrix (destroyed); rhs: lane a holds entry a, on return entry a of the solution
+MPC_DEV void gj8v(Gj8V &f, float (&col)[8], float &rhs, int r)
+{
+    float invd = 0.f;
+    Gj8VPivot<0>::run(f, col, rhs, invd, r);
+    rhs *= invd;
+}
+template <int C, int A> struct Gj8VApplyRow {
+    static MPC_DEVM void run(const Gj8V &f, float (&z)[8])
+    {
+        if (A != C) wv::fmac_bcast_settled<A>(z[A], f.nl[C], z[C]);
+        Gj8VApplyRow<C, A + 1>::run(f, z);
+    }
+};
+template <int C> struct Gj8VApplyRow<C, 8> { static MPC_DEVM void run(const Gj8V &, float (&)[8]) {} };
+template <int C> struct Gj8VApply {
+    static MPC_DEVM void run(const Gj8V &f, float (&z)[8])
+    {
+        Gj8VApplyRow<C, 0>::run(f, z);
+        Gj8VApply<C + 1>::run(f, z);
+    }
+};
+template <> struct Gj8VApply<8> { static MPC_DEVM void run(const Gj8V &, float (&)[8]) {} };
+// z = A^-1 z for per-lane right-hand sides (every lane its own), from the multipliers of gj8v
+MPC_DEV void gj8v_solve(const Gj8V &f, float (&z)[8])
+{
+    Gj8VApply<0>::run(f, z);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) z[a] *= f.inv[a];
+}
+#ifdef MPC_MFMA40_QP_LDL          // (the round-3 form of the QP's linear algebra, kept for A/B timing)
+using QpFac = Ldl8V;
+#else
+using QpFac = Gj8V;
+#endif
+
 MPC_DEV float clampf(float x, float lo, float hi)
 {
     if (x < lo) x = lo;      // util.eclamp (mpc/util.py:56-70): strict compares, bound written exactly
@@ -556,7 +619,7 @@ MPC_DEV float gather8(const float (&y)[8], int r)
     return v;
 }
 MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, float ubv, int n_iter, int r, float &xv,
-                   float &mv, Ldl8V &f, bool &converged)
+                   float &mv, QpFac &f, bool &converged)
 {
     int it_ret = n_iter - 1;
     converged = false;
@@ -580,12 +643,20 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
         }
         float colm[8];
         Pnqp8vMat<0>::run(col0, mnv, fmaf(mnv, dgm, 1.f), r, colm);   // :44-48
+#ifdef MPC_MFMA40_QP_LDL
         Ldl8V fn;
         ldl8v(fn, colm);
         float y[8];
         Pnqp8vSpread<0>::run(mnv * gv, y);
         ldl8v_solve(fn, y);                                        // :50-54
         const float dxv = -(mnv * gather8(y, r));
+#else
+        // (rows off the free set are identity rows with a zero right-hand side: their entry of the solution is 0 as it comes)
+        Gj8V fn;
+        float sol = mnv * gv;
+        gj8v(fn, colm, sol, r);                                    // :50-54
+        const float dxv = -sol;
+#endif
         const float nrm2 = wv::row_sum(dxv * dxv);
         float mxv = xv + dxv;
         const float outv = wv::row_sum(((mxv < lbv) | (mxv > ubv)) ? 1.f : 0.f);
@@ -891,6 +962,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         // identity rows and columns of the factorised matrix (Pnqp8vMat).  (Round 2 read Quu out with 36 readlanes and
         // factorised on wave-uniform values in the constrained modes.)
         Ldl8V facv;
+        QpFac qpf;                      // box QP: the factorisation of its last trip
         float qu[8], kk[8];
         bool fr[8];
         // q_u (row layout): the one vector needed before the gains; q_x stays in shares until v takes it
@@ -971,7 +1043,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             xv = clampf(xv, lbv, ubv);                   // :23
             bool conv;
             float mv = 1.f;
-            const int it = pnqp8v(col0, diagv, qv, lbv, ubv, p.pnqp_iter, L.r, xv, mv, facv, conv);
+            const int it = pnqp8v(col0, diagv, qv, lbv, ubv, p.pnqp_iter, L.r, xv, mv, qpf, conv);
             qp_total += 1 + it;                          // :140
             if (!conv) status |= MPC_ST_PNQP_UNCONVERGED;
             warm = true;
@@ -1006,7 +1078,11 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                     const float x = (MODE == 1 && L.q == 2) ? qu[a] : rhs[a];
                     sol[a] = fr[a] ? x : 0.f;                                                         // :142-143
                 }
-                ldl8v_solve(facv, sol);
+#ifdef MPC_MFMA40_QP_LDL
+                ldl8v_solve(MODE == 2 ? qpf : facv, sol);
+#else
+                if (MODE == 2) gj8v_solve(qpf, sol); else ldl8v_solve(facv, sol);
+#endif
 #pragma unroll
                 for (int a = 0; a < 8; ++a) sol[a] = fr[a] ? sol[a] : 0.f;
                 if (MODE == 1) {
