@@ -11,10 +11,12 @@ namespace wv {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 MPC_DEV int lane() { return (int)threadIdx.x; }
 MPC_DEV int problem() { return (int)blockIdx.x; }
+MPC_DEV unsigned long long clock() { return (unsigned long long)clock64(); }
 MPC_DEV f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 MPC_DEV float readlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 MPC_DEV float shfl_xor(float x, int m) { return __shfl_xor(x, m, 64); }
 MPC_DEV bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+MPC_DEV bool any(bool c) { return __ballot(c) != 0ull; }
 // sum over the four 16-lane rows, result in every lane: two row swaps (gfx950 v_permlane{16,32}_swap), no LDS
 MPC_DEV float sum_rows(float x)
 {
@@ -77,6 +79,17 @@ MPC_DEV unsigned load_uniform_u32(const unsigned *g)
 }
 // nothing is scheduled across this point
 MPC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// ask the scheduler for N groups of (one MFMA, up to V vector instructions) in that order: arithmetic that does not
+// depend on the MFMAs around it issues while the matrix pipe works on them (32 clocks each) instead of behind them
+template <int N, int V, int LEAD = 0> MPC_DEV void sched_shadow()
+{
+    if (LEAD) __builtin_amdgcn_sched_group_barrier(0x008, LEAD, 0);      // (MFMAs the arithmetic waits for go first)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+    }
+}
 // an opaque register-to-register identity (see mfma40::pick)
 MPC_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
 // Compiled three times (Makefile): the step kernels on the three-slot sweep ring (launch_step_mfma40), the same with
@@ -190,6 +203,7 @@ bool kkt_fused_mfma40_supported(const StepParams<float> &p, const float *dl_dx, 
     if (p.T > 1 && !al(p.F, p.F_st, p.F_sb)) return false;
     if (p.bound_mode == MPC_BOUND_TENSOR && ((((uintptr_t)p.lo | (uintptr_t)p.hi) & 3) != 0)) return false;
     if (p.env.kind) return false;           // (zero_mask / has_delta: the forward's, dropped by the launcher -- mpc/lqr_step.py:322-340)
+    if (p.c_st >= (1L << 30) || (long)p.B * 64 >= (1L << 30)) return false;       // (32-bit record steps, lqr_mfma40_body.h: Stream)
     return al(p.cur_x, 0, 0) && al(p.cur_u, 0, 0) && al(dl_dx, 0, 0) && al(dl_du, 0, 0) && al(dC, 0, 0) && al(ws, 0, 0) &&
            (p.T == 1 || al(dF, 0, 0));
 }
@@ -286,7 +300,10 @@ int MPC_MFMA40_LAUNCH(const StepParams<float> &p, hipStream_t st)
 bool mfma40_supported(const StepParams<float> &p)
 {
     auto al = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+    // (the record's per-lane pointers step by 32-bit byte counts, lqr_mfma40_body.h: Stream)
+    auto fits = [](long elems) { return elems >= 0 && elems < (1L << 30); };
     return p.ns == 32 && p.nc == 8 && p.T >= 1 && p.max_ls >= 1 && p.max_ls <= 16 && !p.env.kind &&
+           fits(p.c_st) && fits(p.f ? p.f_st : 0) && fits((long)p.B * 64) &&
            !(p.bound_mode != MPC_BOUND_NONE && p.zero_mask) &&
            al(p.C) && al(p.c) && (p.T == 1 || al(p.F)) && al(p.cur_x) && al(p.cur_u) && p.C_st % 4 == 0 && p.C_sb % 4 == 0 &&
            p.c_st % 4 == 0 && p.c_sb % 4 == 0 && p.F_st % 4 == 0 && p.F_sb % 4 == 0 &&

@@ -290,9 +290,17 @@ MPC_DEV float bound_hi(const P &p, long tb, int a)
     return p.bound_mode != MPC_BOUND_SCALAR ? uniform_f32(p.hi + tb * NC + a) : p.hi_s;
 }
 
+// (round 4) c_ptr, f_ptr (and k_ptr, the workspace pointers of the rollouts) are WAVE-UNIFORM block addresses: `ptr + t * step`
+// is scalar arithmetic, and this lane's 16-byte column `lo` joins in one 64-bit vector add per block.  Rounds 1-3 kept per-lane
+// pointers: a 64-bit vector multiply-add (quarter rate) per block and timestep, ~47 clocks per DMA instruction issued against
+// the 12/4 kernel's 21.  The record's lanes point into different arrays: their pointer stays per lane, the step is 32 bits
+// (bytes per timestep < 4 GiB: checked by mfma40_supported) so that the product is ONE v_mad_u64_u32.
+MPC_DEV unsigned long rec_off(long t, unsigned step) { return (unsigned long)(unsigned)t * (unsigned long)step; }
 struct Stream {
-    const char *c_ptr, *f_ptr, *r_ptr;      // this lane's 16-byte column of each block, timestep 0
-    long c_step, f_step, r_step;            // bytes per timestep
+    const char *c_ptr, *f_ptr;              // the problem's C_0 / F_0 (wave-uniform)
+    const char *r_ptr;                      // this lane's 16-byte granule of the record, timestep 0
+    long c_step, f_step;                    // bytes per timestep
+    unsigned r_step, lo;                    // lo = 16 * lane
     bool r_active;
     bool r_is_f;                            // this lane's record granule is f_t (T-1 entries: indexed like F)
     // the padded instantiation stages by gather instead (PADK): wave-uniform block pointers + the per-lane maps
@@ -311,29 +319,30 @@ MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L, const KktArgs40 *
         gather_init(d.g, p, L.lane);
         rec_init(d.rm, p, L.lane, b, true, false, with_f, nullptr);
     }
-    d.c_ptr = (const char *)(p.C + b * p.C_sb) + 16 * L.lane;
+    d.lo = 16u * (unsigned)L.lane;
+    d.c_ptr = (const char *)(p.C + b * p.C_sb);
     d.c_step = p.C_st * 4;
     // T = 1 has no dynamics (F may be NULL): its five DMA slots re-read C, so the wait counts stay the same
-    d.f_ptr = p.T > 1 ? (const char *)(p.F + b * p.F_sb) + 16 * L.lane : d.c_ptr;
+    d.f_ptr = p.T > 1 ? (const char *)(p.F + b * p.F_sb) : d.c_ptr;
     d.f_step = p.T > 1 ? p.F_st * 4 : 0;
     // record: lanes 0..9 -> c_t (160 B), 10..17 -> x_t (128 B), 18..19 -> u_t (32 B)
     d.r_active = L.lane < 20;
     if (L.lane < 10) {
         d.r_ptr = (const char *)(p.c + b * p.c_sb) + 16 * L.lane;
-        d.r_step = p.c_st * 4;
+        d.r_step = (unsigned)(p.c_st * 4);
     } else if (L.lane < 18) {
         d.r_ptr = (const char *)(p.cur_x + b * NS) + 16 * (L.lane - 10);
-        d.r_step = (long)p.B * NS * 4;
+        d.r_step = (unsigned)((long)p.B * NS * 4);
     } else {
         d.r_ptr = (const char *)(p.cur_u + b * NC) + 16 * ((L.lane < 20 ? L.lane : 18) - 18);
-        d.r_step = (long)p.B * NC * 4;
+        d.r_step = (unsigned)((long)p.B * NC * 4);
     }
     if (with_f && L.lane >= 20 && L.lane < 28) {
         // the unvouched step verifies the nominal while it sweeps (sweep_wave): lanes 20..27 carry f_t
         d.r_active = true;
         d.r_is_f = true;
         d.r_ptr = (const char *)(p.f + b * p.f_sb) + 16 * (L.lane - 20);
-        d.r_step = p.f_st * 4;
+        d.r_step = (unsigned)(p.f_st * 4);
     }
     if (kk) {
         // the fused backward: lanes 0..7 dl_dx_t, 8..9 dl_du_t (negated where they are read), 10..19 tau*_t as above,
@@ -341,13 +350,13 @@ MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L, const KktArgs40 *
         d.r_active = L.lane < 28;
         if (L.lane < 8) {
             d.r_ptr = (const char *)(kk->dl_dx + b * NS) + 16 * L.lane;
-            d.r_step = (long)p.B * NS * 4;
+            d.r_step = (unsigned)((long)p.B * NS * 4);
         } else if (L.lane < 10) {
             d.r_ptr = (const char *)(kk->dl_du + b * NC) + 16 * (L.lane - 8);
-            d.r_step = (long)p.B * NC * 4;
+            d.r_step = (unsigned)((long)p.B * NC * 4);
         } else if (L.lane >= 20) {
             d.r_ptr = (const char *)(p.c + b * p.c_sb) + 16 * ((L.lane < 28 ? L.lane : 20) - 20);
-            d.r_step = p.c_st * 4;
+            d.r_step = (unsigned)(p.c_st * 4);
         }
     }
 }
@@ -405,10 +414,10 @@ MPC_DEV void stage_issue(const P &p, const Stream &d, const Lane &L, int t, int 
         rec_issue(d.rm, tl, tf, tl, base + OFF_R);
         return;
     }
-    dma_kib_once<6>(d.c_ptr + tl * d.c_step, base + OFF_C);
-    wv::dma16_at_if<2048>(L.lane < 16, d.c_ptr + tl * d.c_step + 4096, base + OFF_C + 4096);
-    dma_kib<5>(d.f_ptr + (p.T > 1 ? tf * d.f_step : 0), base + OFF_F);
-    wv::dma16_if(d.r_active, d.r_ptr + (d.r_is_f ? tf : tl) * d.r_step, base + OFF_R);
+    dma_kib_once<6>(d.c_ptr + tl * d.c_step + d.lo, base + OFF_C);
+    wv::dma16_at_if<2048>(L.lane < 16, d.c_ptr + tl * d.c_step + 4096 + d.lo, base + OFF_C + 4096);
+    dma_kib<5>(d.f_ptr + (p.T > 1 ? tf * d.f_step : 0) + d.lo, base + OFF_F);
+    wv::dma16_if(d.r_active, d.r_ptr + rec_off(d.r_is_f ? tf : tl, d.r_step), base + OFF_R);
 }
 
 // butterfly sums: across the four lane groups (lanes differing in bits 4,5), across the 16 lanes of a group
@@ -714,9 +723,21 @@ MPC_DEV void kkt_store_vvg(const KktArgs40 &kx, long tb, const Lane &L, const wv
 //   g_t = F_x' g_{t+1} - Qxu k_t                      (the correction of dlambda when the nested line search ends below 1)
 // V_t, v_t, g_t go to the workspace for pass 2 (dlambda_t = V_t dx_t + v_t + (1 - alpha) g_t), lambda_{t+1} into the
 // first 32 words of the dF_t block.  v_0, g_0 (row layout) come back through v0g0 for dx_init.
+// Diagnostic builds only (-DMPC_MFMA40_PROF, tools/prof_phases40.py): shader-clock totals of the sweep's phases per wave,
+// written over K behind the rollout.  Every probe drains the LDS queue: the phases are serialised, upper bounds each.
+//   0 DMA wait | 1 C, tau, c from LDS + c_back + nominal cost | 2 F from LDS + Y, Q, q (MFMA) | 3 Quu out of the tile, bounds,
+//   factorisation / box QP | 4 K solve, M, gain stores | 5 value update + records | 6 sweep tail | 7 rollout | 8 DMA issue
+#ifdef MPC_MFMA40_PROF
+struct Prof40 { unsigned long long acc[16], last; };
+#define PROF40_MARK(slot) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = wv::clock(); \
+                               prof->acc[slot] += n_ - prof->last; prof->last = n_; } while (0)
+#else
+struct Prof40;
+#define PROF40_MARK(slot)
+#endif
 template <int MODE, bool KKT = false>
 MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out = nullptr, const KktArgs40 *kx = nullptr,
-                          float *v0g0 = nullptr, bool *on_dynamics_out = nullptr)
+                          float *v0g0 = nullptr, bool *on_dynamics_out = nullptr, Prof40 *prof = nullptr)
 {
     Lane L;
     L.lane = wv::lane();
@@ -771,7 +792,9 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
     for (int t = T - 1; t >= 0; --t) {
         // keep the next timestep(s) in flight (re-loading step 0 at the tail keeps the wait count fixed)
         stage_issue(p, d, L, t - (SNSTAGE - 1) >= 0 ? t - (SNSTAGE - 1) : 0, (slot + SNSTAGE - 1) % SNSTAGE);
+        PROF40_MARK(8);
         wv::dma_wait<(SNSTAGE - 1) * DMA_PER_STAGE>();
+        PROF40_MARK(0);
         const unsigned base = (unsigned)slot * STAGE_BYTES;
         const long tb = (long)t * p.B + L.b;
         // (V, v, g) of t+1 leave now, not when they were finished: vector stores share the counter the wait above counts
@@ -855,6 +878,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             for (int J = 0; J < 3; ++J) s = fmaf(trow[J], fmaf(0.5f, qpart[J], L.q == 0 ? crow[J] : 0.f), s);
             old_cost += (double)s;
         }
+        PROF40_MARK(1);
 
         if (t < T - 1) {
             // ---- F as FB[(I',v)][J] = F[16I' + 4q + v][16J + r]
@@ -952,6 +976,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             }
         }
 
+        PROF40_MARK(2);
         if (PADK) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) Qd[2][2][v] += padd[v];
@@ -1057,6 +1082,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                 fr[a] = wv::readlane(mv, a) != 0.f;
             }
         }
+        PROF40_MARK(3);
         f32x4 Kd[2];                    // K, B layout of the value update: register v of lane (q,r) = K[4q+v][16J+r]
         f32x4 Md[2];                    // M = Qux + Quu K in the same layout (constrained modes)
         Md[0] = zero4;
@@ -1163,6 +1189,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
 #endif
         }
 
+        PROF40_MARK(4);
         // ---- V = Qxx + Qxu K, v = qx + Qxu k   (:155-158 with K'(Qux + Quu K) = 0, K'(qu + Quu k) = 0)
         // (the four tiles' chains interleaved, see Y above)
 #pragma unroll
@@ -1258,6 +1285,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                 for (int v = 0; v < 4; ++v) xnext[I][v] = tcol[I][v];
         }
         slot = (slot + 1) % SNSTAGE;
+        PROF40_MARK(5);
     }
     if (on_dynamics_out) {
         bool on = p.on_dynamics != 0;
@@ -1300,6 +1328,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
     }
     if (L.lane == 0 && p.status) p.status[L.b] = status;
     if (w0_out) *w0_out = w0;
+    PROF40_MARK(6);
     return old_cost;
 }
 
@@ -1312,8 +1341,10 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
 // trajectory as it goes; any other winner is replayed once with its alpha in every column.
 // ---------------------------------------------------------------------------------------------
 struct RStream {
-    const char *c_ptr, *f_ptr, *k_ptr, *r_ptr;
-    long c_step, f_step, k_step, r_step;
+    const char *c_ptr, *f_ptr, *k_ptr;      // wave-uniform block addresses (see Stream)
+    const char *r_ptr;
+    long c_step, f_step, k_step;
+    unsigned r_step, lo;
     bool r_active, r_is_f, r_is_x;
     // padded instantiation: gathers instead (see Stream)
     const float *Cb, *Fb;
@@ -1330,11 +1361,12 @@ MPC_DEV void rstream_init(RStream &d, const P &p, const Lane &L, const float *Ki
         gather_init(d.g, p, L.lane);
         rec_init(d.rm, p, L.lane, b, true, true, true, kin);
     }
-    d.c_ptr = (const char *)(p.C + b * p.C_sb) + 16 * L.lane;
+    d.lo = 16u * (unsigned)L.lane;
+    d.c_ptr = (const char *)(p.C + b * p.C_sb);
     d.c_step = p.C_st * 4;
-    d.f_ptr = p.T > 1 ? (const char *)(p.F + b * p.F_sb) + 16 * L.lane : d.c_ptr;
+    d.f_ptr = p.T > 1 ? (const char *)(p.F + b * p.F_sb) : d.c_ptr;
     d.f_step = p.T > 1 ? p.F_st * 4 : 0;
-    d.k_ptr = (const char *)(Kin + b * (NC * NS)) + 16 * L.lane;
+    d.k_ptr = (const char *)(Kin + b * (NC * NS));
     d.k_step = (long)p.B * NC * NS * 4;
     // record: lanes 0..9 c_t | 10..17 x_{t+1} | 18..19 u_t | 20..27 f_t | 28..29 k_t
     d.r_active = L.lane < 30;
@@ -1342,22 +1374,22 @@ MPC_DEV void rstream_init(RStream &d, const P &p, const Lane &L, const float *Ki
     d.r_is_x = false;
     if (L.lane < 10) {
         d.r_ptr = (const char *)(p.c + b * p.c_sb) + 16 * L.lane;
-        d.r_step = p.c_st * 4;
+        d.r_step = (unsigned)(p.c_st * 4);
     } else if (L.lane < 18) {
         d.r_ptr = (const char *)(p.cur_x + b * NS) + 16 * (L.lane - 10);
-        d.r_step = (long)p.B * NS * 4;
+        d.r_step = (unsigned)((long)p.B * NS * 4);
         d.r_is_x = true;
     } else if (L.lane < 20) {
         d.r_ptr = (const char *)(p.cur_u + b * NC) + 16 * (L.lane - 18);
-        d.r_step = (long)p.B * NC * 4;
+        d.r_step = (unsigned)((long)p.B * NC * 4);
     } else if (L.lane < 28) {
         d.r_is_f = true;
         d.r_active = p.f != nullptr && p.T > 1;
-        d.r_ptr = p.f ? (const char *)(p.f + b * p.f_sb) + 16 * (L.lane - 20) : d.c_ptr;
-        d.r_step = p.f_st * 4;
+        d.r_ptr = p.f ? (const char *)(p.f + b * p.f_sb) + 16 * (L.lane - 20) : d.c_ptr + d.lo;
+        d.r_step = (unsigned)(p.f_st * 4);
     } else {
         d.r_ptr = (const char *)(kin + b * NC) + 16 * ((L.lane < 30 ? L.lane : 28) - 28);
-        d.r_step = (long)p.B * NC * 4;
+        d.r_step = (unsigned)((long)p.B * NC * 4);
     }
 }
 
@@ -1370,15 +1402,15 @@ MPC_DEV void rstage_issue(const P &p, const RStream &d, const Lane &L, int t, in
     if (PADK) {
         gather_C(d.g, d.Cb + tl * p.C_st, base + OFF_C, L.lane);
         gather_F(d.g, p.T > 1 ? d.Fb + tf * p.F_st : d.Cb, p.T > 1 ? d.g.fbytes : 0u, base + OFF_F);
-        wv::dma16(d.k_ptr + tl * d.k_step, base + ROFF_K);
+        wv::dma16(d.k_ptr + tl * d.k_step + d.lo, base + ROFF_K);
         rec_issue(d.rm, tl, tf, tx, base + ROFF_R);
         return;
     }
-    dma_kib<6>(d.c_ptr + tl * d.c_step, base + OFF_C);
-    wv::dma16_at_if<2048>(L.lane < 16, d.c_ptr + tl * d.c_step + 4096, base + OFF_C + 4096);
-    dma_kib<5>(d.f_ptr + tf * d.f_step, base + OFF_F);
-    wv::dma16(d.k_ptr + tl * d.k_step, base + ROFF_K);
-    wv::dma16_if(d.r_active, d.r_ptr + (d.r_is_f ? tf : (d.r_is_x ? tx : tl)) * d.r_step, base + ROFF_R);
+    dma_kib<6>(d.c_ptr + tl * d.c_step + d.lo, base + OFF_C);
+    wv::dma16_at_if<2048>(L.lane < 16, d.c_ptr + tl * d.c_step + 4096 + d.lo, base + OFF_C + 4096);
+    dma_kib<5>(d.f_ptr + tf * d.f_step + d.lo, base + OFF_F);
+    wv::dma16(d.k_ptr + tl * d.k_step + d.lo, base + ROFF_K);
+    wv::dma16_if(d.r_active, d.r_ptr + rec_off(d.r_is_f ? tf : (d.r_is_x ? tx : tl), d.r_step), base + ROFF_R);
 }
 
 // One pass over the horizon.  alpha: this lane's (= its column's) step size.  Returns the column's cost and
@@ -1629,14 +1661,14 @@ MPC_DEV void lstage_issue(const P &p, const RStream &d, const Lane &L, int t, in
     const long tx = t + 1 < p.T ? t + 1 : t;                         // x_{t+1}
     if (PADK) {
         gather_F(d.g, p.T > 1 ? d.Fb + tf * p.F_st : d.Cb, p.T > 1 ? d.g.fbytes : 0u, base + LOFF_F);
-        wv::dma16(d.k_ptr + tl * d.k_step, base + LOFF_K);
+        wv::dma16(d.k_ptr + tl * d.k_step + d.lo, base + LOFF_K);
         rec_issue(d.rm, tl, tf, tx, base + LOFF_R, true, L.lane);        // (no c in this pass)
         return;
     }
-    dma_kib<5>(d.f_ptr + tf * d.f_step, base + LOFF_F);
-    wv::dma16(d.k_ptr + tl * d.k_step, base + LOFF_K);
+    dma_kib<5>(d.f_ptr + tf * d.f_step + d.lo, base + LOFF_F);
+    wv::dma16(d.k_ptr + tl * d.k_step + d.lo, base + LOFF_K);
     // (lanes 0..9 would carry c_t, which this pass never looks at: they sit the instruction out)
-    wv::dma16_if(d.r_active && L.lane >= 10, d.r_ptr + (d.r_is_f ? tf : (d.r_is_x ? tx : tl)) * d.r_step, base + LOFF_R);
+    wv::dma16_if(d.r_active && L.lane >= 10, d.r_ptr + rec_off(d.r_is_f ? tf : (d.r_is_x ? tx : tl), d.r_step), base + LOFF_R);
 }
 
 // REPLAY (any MODE): the line search has been decided by a pricing pass (rollout_wave) and its winner was not the
@@ -1698,6 +1730,29 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
         }
         const unsigned qo = 16u * (unsigned)(L.q < 2 ? L.q : 0);
         const f32x4 ub = wv::lds_f32x4(rec + 288 + qo), kb = wv::lds_f32x4(rec + 448 + qo);
+#ifdef MPC_MFMA40_RO_EARLYX
+        // (diagnostic build, round 4: the state part of x+ = F tau' + f does not wait for u' -- its operands read here, its
+        // sixteen MFMAs directly behind those of K dx, the arithmetic of u' in their shadow.  Measured level: 286.3 against
+        // 284.4 us at config 5, 447.7 against 449.2 box-constrained -- the pass is not waiting where this helps.)
+        f32x4 acc[2];
+        float fa[2][12];
+        if (t < T - 1) {
+#pragma unroll
+            for (int Im = 0; Im < 2; ++Im) {
+                acc[Im] = zero4;
+                if (p.f) acc[Im] = wv::lds_f32x4(rec + 320 + 4u * (unsigned)(16 * Im + 4 * L.q));
+                const int row = 16 * Im + L.r;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    fa[Im][k] = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float x = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + (L.q < 2 ? 32 + 4 * L.q + v : 0)));
+                    fa[Im][8 + v] = L.q < 2 ? x : 0.f;
+                }
+            }
+        }
+#endif
         {
             const int tn = t + LSLOTS - 1;
             lstage_issue(p, d, L, tn < T ? tn : T - 1, tn % LSLOTS);
@@ -1711,7 +1766,16 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
                 Ud = wv::mfma(a[k], DXd[0][k], Ud);
                 U2 = wv::mfma(a[4 + k], DXd[1][k], U2);
             }
+#ifndef MPC_MFMA40_RO_EARLYX
             wv::sched_fence();
+#else
+            if (t < T - 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][k], Xd[k >> 2][k & 3], acc[Im]);
+            }
+#endif
 #pragma unroll
             for (int v = 0; v < 4; ++v) Ud[v] += U2[v];
         }
@@ -1744,11 +1808,21 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
                 s = fmaf(dd, dd, s);
             }
             dacc += s;
+#ifdef MPC_MFMA40_RO_EARLYX
+            wv::sched_shadow<16, 3, 8>();         // K dx, then one MFMA of F_x x + three instructions of the above, sixteen times
+#endif
             if (store && L.q < 2) st_u4(p, tb, 4 * L.q, Ud);
         }
         // ---- x+ = F tau' + f   (:216-222)
         if (t < T - 1) {
             const long tb1 = (long)(t + 1) * p.B + L.b;
+#ifdef MPC_MFMA40_RO_EARLYX
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + v], Ud[v], acc[Im]);
+            wv::sched_fence();
+#else
             // both output tiles at once: operands of the two first, then their accumulation chains interleaved
             f32x4 acc[2];
             float fa[2][12];
@@ -1776,6 +1850,7 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
 #pragma unroll
                 for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + v], Ud[v], acc[Im]);
             wv::sched_fence();
+#endif
 #pragma unroll
             for (int Im = 0; Im < 2; ++Im) {
                 if (store) st_x4(p, tb1, 16 * Im + 4 * L.q, acc[Im]);
@@ -1836,25 +1911,26 @@ MPC_DEV void pstage_issue(const P &p, const RStream &d, const Lane &L, const cha
     const long tx = t + 1 < p.T ? t + 1 : t;                         // x_{t+1}
     if (PADK) {
         gather_F(d.g, p.T > 1 ? d.Fb + tf * p.F_st : d.Cb, p.T > 1 ? d.g.fbytes : 0u, base + POFF_F);
-        wv::dma16(d.k_ptr + tl * d.k_step, base + POFF_K);
+        wv::dma16(d.k_ptr + tl * d.k_step + d.lo, base + POFF_K);
         rec_issue(d.rm, tl, tf, tx, base + POFF_R, true, L.lane);
     } else {
-    dma_kib<5>(d.f_ptr + tf * d.f_step, base + POFF_F);
-    wv::dma16(d.k_ptr + tl * d.k_step, base + POFF_K);
-    wv::dma16_if(d.r_active && L.lane >= 10, d.r_ptr + (d.r_is_f ? tf : (d.r_is_x ? tx : tl)) * d.r_step, base + POFF_R);
+    dma_kib<5>(d.f_ptr + tf * d.f_step + d.lo, base + POFF_F);
+    wv::dma16(d.k_ptr + tl * d.k_step + d.lo, base + POFF_K);
+    wv::dma16_if(d.r_active && L.lane >= 10, d.r_ptr + rec_off(d.r_is_f ? tf : (d.r_is_x ? tx : tl), d.r_step), base + POFF_R);
     }
-    const char *rec = m_ptr + tl * ((long)p.B * PREC * 4);
+    const char *rec = m_ptr + tl * ((long)p.B * PREC * 4) + d.lo;
     wv::dma16(rec, base + POFF_M);
     wv::dma16_if(L.lane < 18, rec + 1024, base + POFF_Q);
 }
 
 template <int MODE>
-MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const float *kin, double old_cost, double w0)
+MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const float *kin, double old_cost, double w0,
+                            Prof40 *prof = nullptr)
 {
     const int T = p.T;
     RStream d;
     rstream_init(d, p, L, Kin, kin);
-    const char *m_ptr = (const char *)(p.Kk + (long)L.b * PREC) + 16 * L.lane;
+    const char *m_ptr = (const char *)(p.Kk + (long)L.b * PREC);        // (wave-uniform, see Stream)
     float alpha = 1.f;
     for (int i = 0; i < L.r; ++i) alpha *= p.ls_decay;            // column r tries decay^r
     // Trial 0 (column 0) stores into new_x / new_u as it goes.  Trial 1 (alpha = decay) is the winner in most problems that
@@ -1883,12 +1959,15 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
     pad_clear(L.lane);
 #pragma unroll
     for (int i = 0; i < PSLOTS - 1; ++i) pstage_issue(p, d, L, m_ptr, i < T ? i : T - 1, i);
+    PROF40_MARK(7);
     for (int t = 0; t < T; ++t) {
         wv::dma_wait<(PSLOTS - 2) * PDMA_PER_STAGE>();
+        PROF40_MARK(9);             // 9 rollout: DMA wait | 10 operand reads + DMA issue | 11 K dx, M dx | 12 u', e, store | 13 F reads, x+ | 14 tail
         const unsigned base = (unsigned)(t % PSLOTS) * PSTAGE_BYTES;
         const long tb = (long)t * p.B + L.b;
         const unsigned rec = base + POFF_R;
         // ---- operands of the timestep out of its stage: rows of K and of M (A operands), Quu's columns, m, u, k
+        // (the price e'(m + M dx + Quu e / 2) cannot be skipped where e = 0: e = (alpha - 1) k in every column but the first)
         float a[8], am[8], aq[4];
         const unsigned krow = 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 4 * L.q);
 #pragma unroll
@@ -1911,6 +1990,7 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
             const int tn = t + PSLOTS - 1;
             pstage_issue(p, d, L, m_ptr, tn < T ? tn : T - 1, tn % PSLOTS);
         }
+        PROF40_MARK(10);
         // ---- K dx and M dx  (four accumulation chains side by side)
         f32x4 Ud = zero4, G = zero4;
         wv::sched_fence();
@@ -1927,6 +2007,10 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
 #pragma unroll
             for (int v = 0; v < 4; ++v) { Ud[v] += U2[v]; G[v] += G2[v]; }
         }
+#ifdef MPC_MFMA40_PROF
+        asm volatile("" :: "v"(Ud[0]), "v"(G[0]));
+        PROF40_MARK(11);
+#endif
         // ---- u' = clamp / mask (u + K dx + alpha k)   (:192-213),  e = du - K dx - k
         f32x4 e = zero4;
         {
@@ -1962,6 +2046,7 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
             if (PADK && L.r == 0) { if (uq) st_u4(p, tb, 4 * L.q, Ud); }
             else if (store && uq) wv::store_f32x4(uo + (long)t * ust + 4 * L.q, Ud);
         }
+        PROF40_MARK(12);
         // ---- x+ = F tau' + f   (:216-222)  and  Quu e
         f32x4 H = zero4;
         if (t < T - 1) {
@@ -2008,6 +2093,10 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
             for (int v = 0; v < 4; ++v) H = wv::mfma(aq[v], e[v], H);
             wv::sched_fence();
         }
+#ifdef MPC_MFMA40_PROF
+        asm volatile("" :: "v"(DXd[0][0]), "v"(DXd[1][0]), "v"(H[0]));
+        PROF40_MARK(13);
+#endif
         // (G was formed with the dx this timestep STARTED from: DXd above is already the next one's)
         {
             float term = 0.f;
@@ -2015,6 +2104,7 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
             for (int v = 0; v < 4; ++v) term = fmaf(e[v], mm[v] + G[v] + 0.5f * H[v], term);
             cacc += (double)(uq ? term : 0.f);
         }
+        PROF40_MARK(14);
     }
     wv::dma_wait<0>();
     // column totals: lane groups 0 and 1 hold the two halves of the controls
@@ -2126,10 +2216,10 @@ MPC_DEV void kstage_issue(const P &p, const RStream &d, const char *v_ptr, long 
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);      // F has T-1 entries
     const long tx = t + 1 < p.T ? t + 1 : t;                         // (V, v, g) of t+1
-    dma_kib<5>(d.f_ptr + tf * d.f_step, base + KOFF_F);
-    wv::dma16(d.k_ptr + tl * d.k_step, base + KOFF_K);
-    wv::dma16_if(d.r_active, d.r_ptr + (d.r_is_x ? tx : tl) * d.r_step, base + KOFF_R);
-    dma_kib<4>(v_ptr + tx * v_step, base + KOFF_V);
+    dma_kib<5>(d.f_ptr + tf * d.f_step + d.lo, base + KOFF_F);
+    wv::dma16(d.k_ptr + tl * d.k_step + d.lo, base + KOFF_K);
+    wv::dma16_if(d.r_active, d.r_ptr + rec_off(d.r_is_x ? tx : tl, d.r_step), base + KOFF_R);
+    dma_kib<4>(v_ptr + tx * v_step + d.lo, base + KOFF_V);
 }
 
 template <int MODE>
@@ -2140,22 +2230,23 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
     // record: lanes 10..17 v_{t+1} | 20..27 g_{t+1} | 28..29 k_t
     RStream d;
     d.c_ptr = nullptr; d.c_step = 0;
-    d.f_ptr = T > 1 ? (const char *)(p.F + (long)L.b * p.F_sb) + 16 * L.lane : (const char *)(p.C + (long)L.b * p.C_sb) + 16 * L.lane;
+    d.lo = 16u * (unsigned)L.lane;
+    d.f_ptr = T > 1 ? (const char *)(p.F + (long)L.b * p.F_sb) : (const char *)(p.C + (long)L.b * p.C_sb);
     d.f_step = T > 1 ? p.F_st * 4 : 0;
-    d.k_ptr = (const char *)(Kin + (long)L.b * (NC * NS)) + 16 * L.lane;
+    d.k_ptr = (const char *)(Kin + (long)L.b * (NC * NS));
     d.k_step = (long)p.B * NC * NS * 4;
     d.r_is_f = false;
     d.r_is_x = L.lane < 28;
     d.r_active = (L.lane >= 10 && L.lane < 18) || (L.lane >= 20 && L.lane < 30);
     if (L.lane >= 28) {
         d.r_ptr = (const char *)(kin + (long)L.b * NC) + 16 * ((L.lane < 30 ? L.lane : 28) - 28);
-        d.r_step = (long)p.B * NC * 4;
+        d.r_step = (unsigned)((long)p.B * NC * 4);
     } else {
         const int g = L.lane >= 20 ? 8 + (L.lane - 20) : (L.lane >= 10 && L.lane < 18 ? L.lane - 10 : 0);
         d.r_ptr = (const char *)(kx.vgws + (long)L.b * 64) + 16 * g;
-        d.r_step = (long)p.B * 64 * 4;
+        d.r_step = (unsigned)((long)p.B * 64 * 4);
     }
-    const char *v_ptr = (const char *)(kx.Vws + (long)L.b * 1024) + 16 * L.lane;
+    const char *v_ptr = (const char *)(kx.Vws + (long)L.b * 1024);
     const long v_step = (long)p.B * 4096;
 
     float alpha = 1.f;
@@ -2330,7 +2421,24 @@ template <int MODE> MPC_DEV void step_wave(const P &p, float *K, float *k)
 {
     double w0 = 0.0;
     bool on_dyn = false;
+#ifdef MPC_MFMA40_PROF
+    Prof40 prof_;
+    for (int i_ = 0; i_ < 16; ++i_) prof_.acc[i_] = 0;
+    prof_.last = wv::clock();
+    const double old_cost = sweep_wave<MODE>(p, K, k, &w0, nullptr, nullptr, &on_dyn, &prof_);
+    struct ProfOut {
+        const P &p; float *K; Prof40 &pr;
+        MPC_DEVM ~ProfOut()
+        {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            pr.acc[7] += wv::clock() - pr.last;
+            if (wv::lane() == 0 && wv::problem() < p.B)
+                for (int i_ = 0; i_ < 16; ++i_) K[(long)wv::problem() * 16 + i_] = (float)pr.acc[i_];
+        }
+    } prof_out_{p, K, prof_};
+#else
     const double old_cost = sweep_wave<MODE>(p, K, k, &w0, nullptr, nullptr, &on_dyn);
+#endif
     if (p.sweep_only) return;           // MPC_OPT_SWEEP_ONLY (the sweep has written K, k, old_costs, qp_iters, status)
     wv::fence_own_stores();
 #ifdef MPC_CFG5_SWEEP_ONLY
@@ -2353,7 +2461,11 @@ template <int MODE> MPC_DEV void step_wave(const P &p, float *K, float *k)
         L.q = L.lane >> 4;
         L.b = wv::problem();
         if (L.b >= p.B) return;
+#ifdef MPC_MFMA40_PROF
+        rollout_priced<MODE>(p, L, K, k, old_cost, w0, &prof_);
+#else
         rollout_priced<MODE>(p, L, K, k, old_cost, w0);
+#endif
     } else {
         rollout_wave<MODE>(p, K, k, old_cost);
     }

@@ -165,6 +165,7 @@ static inline unsigned long long ballot(bool c)
 static inline float rcp(float x) { return 1.0f / x; }
 static inline void pin(float &) {}
 static inline void sched_fence() {}
+template <int N, int V, int LEAD = 0> static inline void sched_shadow() {}
 // v_mfma_f32_4x4x1_16b_f32 cbsz:2 abid:ABID (lqr_dpp16_body.h): rows 4*ABID..+3 of a per-row outer product
 template <int ABID> static inline f32x4 mfma4(float a, float b, f32x4 c)
 {
