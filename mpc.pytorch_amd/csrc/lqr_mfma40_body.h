@@ -586,6 +586,35 @@ MPC_DEV float clampf(float x, float lo, float hi)
     return x;
 }
 
+// The box of a rollout's four controls 4q .. 4q+3 at timestep tb (mpc/lqr_step.py:200-213): the bounds (scalars, or rows of
+// the bound tensors) narrowed by the trust region u +- delta_u, and the clamp -- straight-line code (round 4).  Rounds 1-3
+// wrote this per control inside `if (MODE == 2 && q < 2) { if (tensor bounds) ..; if (has_delta) ..; clamp }`: an exec-mask
+// branch and two uniform ones per control, four times a timestep -- the priced rollout spent 1,300 clocks a timestep there
+// (profiles/r04_prof_phases40.log).  max / min pick the same numbers as the reference's compare-and-select chain.
+struct Box4 { float lo[4], hi[4]; };
+MPC_DEV void box4(Box4 &bx, const P &p, long tb, const Lane &L, const wv::f32x4 &ub)
+{
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        bx.lo[v] = p.lo_s;
+        bx.hi[v] = p.hi_s;
+    }
+    if (PADK || p.bound_mode != MPC_BOUND_SCALAR) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            bx.lo[v] = pick(L.q == 0, bound_lo(p, tb, v), bound_lo(p, tb, 4 + v));
+            bx.hi[v] = pick(L.q == 0, bound_hi(p, tb, v), bound_hi(p, tb, 4 + v));
+        }
+    }
+    const float dlt = p.has_delta ? p.delta_u : 3.0e38f;           // (no trust region: u -+ 3e38 never narrows a bound)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        bx.lo[v] = fmaxf(bx.lo[v], ub[v] - dlt);                    // :202-207
+        bx.hi[v] = fminf(bx.hi[v], ub[v] + dlt);
+    }
+}
+MPC_DEV float box_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }       // util.eclamp, lo first
+
 // ---- Projected-Newton box QP in 8 unknowns (mpc/pnqp.py:5-82, n_batch = 1; the Armijo restatements of lqr_small_math.h's
 // pnqp4) with its vectors spread over lanes (lane a < 8 of every 16-lane row: entry a; lanes 8..15 hold
 // zeros and stay free, which makes them inert in every product and row sum).  col0[c]: column c of H (lane a: H[a][c]).
@@ -1465,23 +1494,13 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
                 const unsigned zlo = zero_mask_word(p, tb, 0), zhi = zero_mask_word(p, tb, 1);
                 zw = L.q == 0 ? zlo : zhi;
             }
+            Box4 bx;
+            if (MODE == 2) box4(bx, p, tb, L, ub);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 float un = L.q < 2 ? Ud[v] + ub[v] + alpha * kb[v] : 0.f;
                 if (MODE == 1 && L.q < 2 && ((zw >> (8 * v)) & 0xffu) != 0u) un = 0.f;               // :197-198
-                if (MODE == 2 && L.q < 2) {                                                          // :200-213
-                    float lo = p.lo_s, hi = p.hi_s;
-                    if (PADK || p.bound_mode != MPC_BOUND_SCALAR) {
-                        lo = pick(L.q == 0, bound_lo(p, tb, v), bound_lo(p, tb, 4 + v));
-                        hi = pick(L.q == 0, bound_hi(p, tb, v), bound_hi(p, tb, 4 + v));
-                    }
-                    if (p.has_delta) {
-                        const float l2 = ub[v] - p.delta_u, h2 = ub[v] + p.delta_u;
-                        lo = (l2 < lo) ? lo : l2;
-                        hi = (h2 > hi) ? hi : h2;
-                    }
-                    un = clampf(un, lo, hi);
-                }
+                if (MODE == 2) un = L.q < 2 ? box_clamp(un, bx.lo[v], bx.hi[v]) : 0.f;               // :200-213
                 const float dd = L.q < 2 ? ub[v] - un : 0.f;
                 Ud[v] = un;
                 s = fmaf(dd, dd, s);
@@ -1786,23 +1805,13 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
                 const unsigned zlo = zero_mask_word(p, tb, 0), zhi = zero_mask_word(p, tb, 1);
                 zw = L.q == 0 ? zlo : zhi;
             }
+            Box4 bx;
+            if (MODE == 2) box4(bx, p, tb, L, ub);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 float un = L.q < 2 ? Ud[v] + ub[v] + alpha * kb[v] : 0.f;
                 if (MODE == 1 && L.q < 2 && ((zw >> (8 * v)) & 0xffu) != 0u) un = 0.f;               // :197-198
-                if (MODE == 2 && L.q < 2) {                                                          // :200-213
-                    float lo = p.lo_s, hi = p.hi_s;
-                    if (PADK || p.bound_mode != MPC_BOUND_SCALAR) {
-                        lo = pick(L.q == 0, bound_lo(p, tb, v), bound_lo(p, tb, 4 + v));
-                        hi = pick(L.q == 0, bound_hi(p, tb, v), bound_hi(p, tb, 4 + v));
-                    }
-                    if (p.has_delta) {
-                        const float l2 = ub[v] - p.delta_u, h2 = ub[v] + p.delta_u;
-                        lo = (l2 < lo) ? lo : l2;
-                        hi = (h2 > hi) ? hi : h2;
-                    }
-                    un = clampf(un, lo, hi);
-                }
+                if (MODE == 2) un = L.q < 2 ? box_clamp(un, bx.lo[v], bx.hi[v]) : 0.f;               // :200-213
                 const float dd = L.q < 2 ? ub[v] - un : 0.f;
                 Ud[v] = un;
                 s = fmaf(dd, dd, s);
@@ -2020,23 +2029,13 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
                 const unsigned zlo = zero_mask_word(p, tb, 0), zhi = zero_mask_word(p, tb, 1);
                 zw = L.q == 0 ? zlo : zhi;
             }
+            Box4 bx;
+            if (MODE == 2) box4(bx, p, tb, L, ub);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 float un = uq ? Ud[v] + ub[v] + alpha * kb[v] : 0.f;
                 if (MODE == 1 && uq && ((zw >> (8 * v)) & 0xffu) != 0u) un = 0.f;                    // :197-198
-                if (MODE == 2 && uq) {                                                               // :200-213
-                    float lo = p.lo_s, hi = p.hi_s;
-                    if (PADK || p.bound_mode != MPC_BOUND_SCALAR) {
-                        lo = pick(L.q == 0, bound_lo(p, tb, v), bound_lo(p, tb, 4 + v));
-                        hi = pick(L.q == 0, bound_hi(p, tb, v), bound_hi(p, tb, 4 + v));
-                    }
-                    if (p.has_delta) {
-                        const float l2 = ub[v] - p.delta_u, h2 = ub[v] + p.delta_u;
-                        lo = (l2 < lo) ? lo : l2;
-                        hi = (h2 > hi) ? hi : h2;
-                    }
-                    un = clampf(un, lo, hi);
-                }
+                if (MODE == 2) un = uq ? box_clamp(un, bx.lo[v], bx.hi[v]) : 0.f;                   // :200-213
                 const float du = uq ? un - ub[v] : 0.f;
                 e[v] = uq ? du - Ud[v] - kb[v] : 0.f;
                 Ud[v] = un;
