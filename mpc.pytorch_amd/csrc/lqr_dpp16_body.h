@@ -761,15 +761,11 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
             ubar[0] = ru[0]; ubar[1] = ru[1]; ubar[2] = ru[2]; ubar[3] = ru[3];
         }
 #endif
+        const float dlt = p.has_delta ? p.delta_u : 3.0e38f;       // :132-134 (no trust region: never the tighter bound)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            float l = s.lo[a] - ubar[a], h = s.hi[a] - ubar[a];
-            if (p.has_delta) {                                      // :132-134
-                if (l < -p.delta_u) l = -p.delta_u;
-                if (h > p.delta_u) h = p.delta_u;
-            }
-            lb[a] = l;
-            ub[a] = h;
+            lb[a] = fmaxf(s.lo[a] - ubar[a], -dlt);
+            ub[a] = fminf(s.hi[a] - ubar[a], dlt);
         }
         if (!st.warm) {
             // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
@@ -1025,12 +1021,10 @@ MPC_DEV float control_law(const P &p, const Lane &L, const RoStage &s, float xs,
     const float pre = un;
     if (con(MODE) && s.zm) un = 0.f;
     if (MODE == 2) {
-        float l = s.lo, h = s.hi;
-        if (p.has_delta) {
-            const float l2 = s.tb - p.delta_u, h2 = s.tb + p.delta_u;
-            l = (l2 < l) ? l : l2;
-            h = (h2 > h) ? h : h2;
-        }
+        // (straight-line: without a trust region u -+ 3e38 never narrows a bound; max / min pick what the reference's
+        // compare-and-select chain picks, :202-207)
+        const float dlt = p.has_delta ? p.delta_u : 3.0e38f;
+        const float l = fmaxf(s.lo, s.tb - dlt), h = fminf(s.hi, s.tb + dlt);
         un = eclampf(un, l, h);
     }
     e = L.isu ? (un - pre) + (alpha - 1.f) * s.kk : 0.f;
