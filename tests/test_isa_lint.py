@@ -57,7 +57,8 @@ SGPR_SPILL_LIMITS = {
     "lqr_dpp16": {"kernelILi0E": 200, "kernelILi1E": 440, "kernelILi2E": 550, "kernelILi3E": 160, "kkt_fused": 8},
     "lqr_dpp16_ring2": {"kernelILi0E": 140, "kernelILi1E": 425, "kernelILi2E": 315, "kernelILi3E": 170, "lqr_kkt_dpp16": 0},
     "lqr_mfma40": {"kernelILi0E": 90, "kernelILi1E": 105, "kernelILi2E": 150},
-    "lqr_mfma40_ring2": {"kernelILi0E": 90, "kernelILi1E": 105, "kernelILi2E": 150},
+    # (round 4: block addresses as scalar arithmetic -- two more base pointers live in the two-slot build of mode 0)
+    "lqr_mfma40_ring2": {"kernelILi0E": 100, "kernelILi1E": 105, "kernelILi2E": 150},
     "lqr_mfma40_kkt": {"kernelILi0E": 55, "kernelILi1E": 115},
     # the padded instantiation (round 4): every gather instruction wants a 128-bit descriptor and an M0 -- 47 of them a stage in the
     # dword build; the ceilings are what that costs in scalar registers (none of it in vector spills or scratch)
