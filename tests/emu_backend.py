@@ -27,14 +27,24 @@ def build(ring2=False, pad=0):
     csrc = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc")
     deps = [src] + [os.path.join(csrc, h) for h in ("lqr_mfma16_body.h", "lqr_dpp16_body.h", "lqr_small_math.h",
                                                     "lqr_params.h", "env_dynamics.h", "lqr_tiny_body.h", "lqr_wave1_body.h", "lqr_mfma40_body.h")]
-    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        cxx = "/opt/rocm/lib/llvm/bin/clang++"
-        if not os.path.exists(cxx):
-            cxx = shutil.which("clang++")
-        assert cxx, "the emulator needs clang++ (ext_vector_type)"
-        subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
-                              + (["-DMPC_DPP16_NSTAGE=2", "-DMPC_KKT16_NSTAGE=2", "-DMPC_MFMA40_SWEEP_NSTAGE=2"] if (ring2 or pad) else [])
-                              + (["-DMPC_MFMA40_PAD=%d" % pad] if pad else []) + ["-o", so, src])
+    def stale():
+        return not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps)
+    if stale():
+        # several test processes (pytest -n) may find the library stale at once: one builds under the lock, into a
+        # temporary name moved into place, so that nobody ever loads a half-written file
+        import fcntl
+        with open(so + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if stale():
+                cxx = "/opt/rocm/lib/llvm/bin/clang++"
+                if not os.path.exists(cxx):
+                    cxx = shutil.which("clang++")
+                assert cxx, "the emulator needs clang++ (ext_vector_type)"
+                tmp = so + ".tmp%d" % os.getpid()
+                subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+                                      + (["-DMPC_DPP16_NSTAGE=2", "-DMPC_KKT16_NSTAGE=2", "-DMPC_MFMA40_SWEEP_NSTAGE=2"] if (ring2 or pad) else [])
+                                      + (["-DMPC_MFMA40_PAD=%d" % pad] if pad else []) + ["-o", tmp, src])
+                os.replace(tmp, so)
     return so
 
 
