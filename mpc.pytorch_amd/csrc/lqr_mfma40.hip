@@ -41,6 +41,13 @@ MPC_DEV void swap16(float a, float b, float &lo, float &hi)
     lo = __uint_as_float(r[0]);
     hi = __uint_as_float(r[1]);
 }
+// lo = {a.lanes 0..31, b.lanes 0..31}: v_permlane32_swap exchanges the upper half of its first operand with the lower half of
+// its second (the other result, the two upper halves, is not wanted where this is used)
+MPC_DEV float lower_halves(float a, float b)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]);
+}
 // DPP row broadcast: lane N of the caller's 16-lane row
 template <int N> MPC_DEV float bcast(float x)
 {

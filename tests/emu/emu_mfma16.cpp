@@ -210,6 +210,16 @@ static inline void swap16(float a, float b, float &lo, float &hi)
     lo = odd ? w.fb[gen][l - 16] : w.fa[gen][l];
     hi = odd ? w.fb[gen][l] : w.fa[gen][l + 16];
 }
+// wv::lower_halves of lqr_mfma40.hip: {a.lanes 0..31, b.lanes 0..31}
+static inline float lower_halves(float a, float b)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.fa[gen][l] = a;
+    w.fb[gen][l] = b;
+    emu::yield_lane();
+    return l < 32 ? w.fa[gen][l] : w.fb[gen][l - 32];
+}
 template <int NN> static inline void dot_bcast(float &acc, float src, const float (&m)[NN])
 {
     emu::Wave &w = emu::W;
