@@ -613,6 +613,11 @@ MPC_DEV void box4(Box4 &bx, const P &p, long tb, const Lane &L, const wv::f32x4 
         bx.hi[v] = fminf(bx.hi[v], ub[v] + dlt);
     }
 }
+// A contraction over the eight controls on the 16x16x4 MFMA: lane group q supplies k = q of each instruction, so two
+// instructions cover the controls when group q carries control uctl(q) + 2h in instruction h = 0, 1 (0 4 1 5 | 2 6 3 7) -- the
+// order wv::lower_halves gives to D-layout registers 2h, 2h + 1 (controls 4q + v of groups q = 0, 1).  Four instructions with
+// half their k on padding in rounds 1-3.
+MPC_DEV int uctl(int q) { return 4 * (q & 1) + (q >> 1); }
 MPC_DEV float box_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }       // util.eclamp, lo first
 
 // ---- Projected-Newton box QP in 8 unknowns (mpc/pnqp.py:5-82, n_batch = 1; the Armijo restatements of lqr_small_math.h's
@@ -1802,10 +1807,8 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
                 for (int k = 0; k < 8; ++k)
                     fa[Im][k] = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float x = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + (L.q < 2 ? 32 + 4 * L.q + v : 0)));
-                    fa[Im][8 + v] = L.q < 2 ? x : 0.f;
-                }
+                for (int h = 0; h < 2; ++h)        // the control columns as two full-k operands (uctl)
+                    fa[Im][8 + h] = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + 32 + uctl(L.q) + 2 * h));
             }
         }
 #endif
@@ -1864,9 +1867,11 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
             const long tb1 = (long)(t + 1) * p.B + L.b;
 #ifdef MPC_MFMA40_RO_EARLYX
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+            for (int h = 0; h < 2; ++h) {
+                const float up = wv::lower_halves(Ud[2 * h], Ud[2 * h + 1]);
 #pragma unroll
-                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + v], Ud[v], acc[Im]);
+                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + h], up, acc[Im]);
+            }
             wv::sched_fence();
 #else
             // both output tiles at once: operands of the two first, then their accumulation chains interleaved
@@ -1881,10 +1886,8 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
                 for (int k = 0; k < 8; ++k)
                     fa[Im][k] = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float x = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + (L.q < 2 ? 32 + 4 * L.q + v : 0)));
-                    fa[Im][8 + v] = L.q < 2 ? x : 0.f;
-                }
+                for (int h = 0; h < 2; ++h)        // the control columns as two full-k operands (uctl)
+                    fa[Im][8 + h] = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + 32 + uctl(L.q) + 2 * h));
             }
             wv::sched_fence();
 #pragma unroll
@@ -1892,9 +1895,11 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
 #pragma unroll
                 for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][k], Xd[k >> 2][k & 3], acc[Im]);
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+            for (int h = 0; h < 2; ++h) {
+                const float up = wv::lower_halves(Ud[2 * h], Ud[2 * h + 1]);
 #pragma unroll
-                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + v], Ud[v], acc[Im]);
+                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + h], up, acc[Im]);
+            }
             wv::sched_fence();
 #endif
 #pragma unroll
@@ -2014,7 +2019,7 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
         const unsigned rec = base + POFF_R;
         // ---- operands of the timestep out of its stage: rows of K and of M (A operands), Quu's columns, m, u, k
         // (the price e'(m + M dx + Quu e / 2) cannot be skipped where e = 0: e = (alpha - 1) k in every column but the first)
-        float a[8], am[8], aq[4];
+        float a[8], am[8], aq[2];
         const unsigned krow = 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 4 * L.q);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -2025,9 +2030,9 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
         }
         const bool uq = L.q < 2;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float x = wv::lds_f32(base + POFF_Q + 4u * (unsigned)((L.r < NC ? L.r : 0) * NC + (uq ? 4 * L.q + v : 0)));
-            aq[v] = (L.r < NC && uq) ? x : 0.f;                   // A[i = r][k = q] = Quu[r][4q + v]
+        for (int h = 0; h < 2; ++h) {
+            const float x = wv::lds_f32(base + POFF_Q + 4u * (unsigned)((L.r < NC ? L.r : 0) * NC + uctl(L.q) + 2 * h));
+            aq[h] = L.r < NC ? x : 0.f;                           // A[i = r][k = q] = Quu[r][uctl(q) + 2h]
         }
         const unsigned qo = 16u * (unsigned)(uq ? L.q : 0);
         const f32x4 ub = wv::lds_f32x4(rec + 288 + qo), kb = wv::lds_f32x4(rec + 448 + qo);
@@ -2097,22 +2102,22 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
                 for (int k = 0; k < 8; ++k)
                     fa[Im][k] = wv::lds_f32(base + POFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float x = wv::lds_f32(base + POFF_F + 4u * (unsigned)(row * N + (uq ? 32 + 4 * L.q + v : 0)));
-                    fa[Im][8 + v] = uq ? x : 0.f;
-                }
+                for (int h = 0; h < 2; ++h)        // the control columns as two full-k operands (uctl)
+                    fa[Im][8 + h] = wv::lds_f32(base + POFF_F + 4u * (unsigned)(row * N + 32 + uctl(L.q) + 2 * h));
             }
             wv::sched_fence();
 #pragma unroll
-            for (int v = 0; v < 4; ++v) H = wv::mfma(aq[v], e[v], H);
+            for (int h = 0; h < 2; ++h) H = wv::mfma(aq[h], wv::lower_halves(e[2 * h], e[2 * h + 1]), H);
 #pragma unroll
             for (int k = 0; k < 8; ++k)
 #pragma unroll
                 for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][k], Xd[k >> 2][k & 3], acc[Im]);
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+            for (int h = 0; h < 2; ++h) {
+                const float up = wv::lower_halves(Ud[2 * h], Ud[2 * h + 1]);
 #pragma unroll
-                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + v], Ud[v], acc[Im]);
+                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + h], up, acc[Im]);
+            }
             wv::sched_fence();
 #pragma unroll
             for (int Im = 0; Im < 2; ++Im) {
@@ -2126,7 +2131,7 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
         } else {
             wv::sched_fence();
 #pragma unroll
-            for (int v = 0; v < 4; ++v) H = wv::mfma(aq[v], e[v], H);
+            for (int h = 0; h < 2; ++h) H = wv::mfma(aq[h], wv::lower_halves(e[2 * h], e[2 * h + 1]), H);
             wv::sched_fence();
         }
 #ifdef MPC_MFMA40_PROF
@@ -2344,10 +2349,8 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
             for (int k = 0; k < 8; ++k)
                 fa[Im][k] = wv::lds_f32(base + KOFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float x = wv::lds_f32(base + KOFF_F + 4u * (unsigned)(row * N + (L.q < 2 ? 32 + 4 * L.q + v : 0)));
-                fa[Im][8 + v] = L.q < 2 ? x : 0.f;
-            }
+            for (int h = 0; h < 2; ++h)        // the control columns as two full-k operands (uctl)
+                fa[Im][8 + h] = wv::lds_f32(base + KOFF_F + 4u * (unsigned)(row * N + 32 + uctl(L.q) + 2 * h));
         }
         f32x4 Vt[2][2];
 #pragma unroll
@@ -2414,9 +2417,11 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
 #pragma unroll
                 for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][k], Xd[k >> 2][k & 3], acc[Im]);
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+            for (int h = 0; h < 2; ++h) {
+                const float up = wv::lower_halves(Ud[2 * h], Ud[2 * h + 1]);
 #pragma unroll
-                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + v], Ud[v], acc[Im]);
+                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + h], up, acc[Im]);
+            }
             // (A operand = V through its symmetry: register v of tile (I', Im), exactly as Y = V F in the sweep)
 #pragma unroll
             for (int Ip = 0; Ip < 2; ++Ip)
