@@ -640,7 +640,10 @@ template <> struct Pnqp8vMat<8> { static MPC_DEVM void run(const float (&)[8], f
 template <int C> struct Pnqp8vMv {          // acc += H v  (v spread over lanes)
     static MPC_DEVM void run(const float (&col0)[8], float v, float &acc)
     {
-        wv::fmac_bcast<C>(acc, v, col0[C]);
+        // (v may have been written by the instruction in front of the first product: that one waits out the DPP read-after-write
+        // states; the seven that follow it on the accumulator's chain find v settled)
+        if (C == 0) wv::fmac_bcast<C>(acc, v, col0[C]);
+        else wv::fmac_bcast_settled<C>(acc, v, col0[C]);
         Pnqp8vMv<C + 1>::run(col0, v, acc);
     }
 };
