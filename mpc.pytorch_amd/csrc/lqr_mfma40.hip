@@ -73,6 +73,7 @@ MPC_DEV float row_sum(float x)
     x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true));   // row_mirror
     return x;
 }
+MPC_DEV float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32 as it comes: 1 ulp
 MPC_DEV float rcp(float x)
 {
     float r = __builtin_amdgcn_rcpf(x);

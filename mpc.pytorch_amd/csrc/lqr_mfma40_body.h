@@ -531,14 +531,16 @@ struct Gj8V {
 template <int C> struct Gj8VPivot {
     static MPC_DEVM void run(Gj8V &f, float (&col)[8], float &rhs, float &invd, int r)
     {
-        const float inv = wv::rcp(wv::bcast<C>(col[C]));
+        // (v_rcp_f32 unrefined, as in the 12/4 kernel's QP: the eight pivots are one dependent chain, and the Newton step of
+        // wv::rcp was two more links of it per pivot -- 1 ulp against 1/2 in a solve that stops at |dx| < 1e-4)
+        const float inv = wv::rcp_fast(wv::bcast<C>(col[C]));
         f.inv[C] = inv;
         const float t = -(col[C] * inv);
         f.nl[C] = r == C ? 0.f : t;
         invd = r == C ? inv : invd;
         // (the unpivoted block stays symmetric: A[c][m] is lane m of column c, as in ldl8v)
         Ldl8VElim<C, C + 1>::run(col, f.nl[C]);
-        wv::fmac_bcast<C>(rhs, rhs, f.nl[C]);               // rhs[a] -= l[a] rhs[c]  (rhs was written by the previous pivot)
+        rhs = fmaf(wv::bcast<C>(rhs), f.nl[C], rhs);        // rhs[a] -= l[a] rhs[c]  (rhs was written by the previous pivot)
         Gj8VPivot<C + 1>::run(f, col, rhs, invd, r);
     }
 };

@@ -163,6 +163,7 @@ static inline unsigned long long ballot(bool c)
     return m;
 }
 static inline float rcp(float x) { return 1.0f / x; }
+static inline float rcp_fast(float x) { return 1.0f / x; }
 static inline void pin(float &) {}
 static inline void sched_fence() {}
 template <int N, int V, int LEAD = 0> static inline void sched_shadow() {}
