@@ -73,6 +73,17 @@ MPC_DEV float row_sum(float x)
     x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true));   // row_mirror
     return x;
 }
+// the sum over lanes 0..7 of a row, in lanes 0..7 of it (lanes 8..15: their own): the first three of row_sum's four steps --
+// for the box QP's vectors, which live in lanes 0..7 and whose sums are read in lane 0 (wv::first_lane)
+MPC_DEV float row_sum8(float x)
+{
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    return x;
+}
+// lane 0's truth value, as a wave-uniform one (uniform() says "every lane holds this"; this says "lane 0 decides")
+MPC_DEV bool first_lane(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 MPC_DEV float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32 as it comes: 1 ulp
 MPC_DEV float rcp(float x)
 {

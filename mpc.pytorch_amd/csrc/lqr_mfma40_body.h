@@ -457,7 +457,7 @@ template <int C, bool PINV> struct Ldl8VPivot {
     static MPC_DEVM void run(Ldl8V &f, float (&col)[8])
     {
         const float d = wv::bcast<C>(col[C]);
-        float inv = wv::rcp(d);
+        float inv = wv::rcp(d);           // (unrefined v_rcp_f32 here: 280.1 against 280.8 us at config 5 -- not taken)
         if (PINV) {                                         // a zero pivot drops out (the struct's comment)
             const bool ok = d != 0.f;
             f.sing = ok ? f.sing : 1.f;
@@ -684,7 +684,7 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
         // Newton step the gradient vanishes on the free set, so if the free set of the new point is the one just factorised
         // the next step is zero to rounding -- this is the iteration the reference stops in (:56-59), and the factorisation
         // it would recompute is the one at hand.
-        if (it > 0 && full && wv::uniform(wv::row_sum(fabsf(mnv - mv)) == 0.f)) {
+        if (it > 0 && full && wv::first_lane(wv::row_sum8(fabsf(mnv - mv)) == 0.f)) {
             converged = true;
             it_ret = it;
             break;
@@ -705,17 +705,17 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
         gj8v(fn, colm, sol, r);                                    // :50-54
         const float dxv = -sol;
 #endif
-        const float nrm2 = wv::row_sum(dxv * dxv);
+        const float nrm2 = wv::row_sum8(dxv * dxv);       // (the vectors live in lanes 0..7; lane 0 reads the sums)
         float mxv = xv + dxv;
-        const float outv = wv::row_sum(((mxv < lbv) | (mxv > ubv)) ? 1.f : 0.f);
+        const float outv = wv::row_sum8(((mxv < lbv) | (mxv > ubv)) ? 1.f : 0.f);
         f = fn;
         mv = mnv;
-        if (wv::uniform(!(nrm2 >= 1e-8f))) {                       // :56-59
+        if (wv::first_lane(!(nrm2 >= 1e-8f))) {                    // :56-59
             converged = true;
             it_ret = it;
             break;
         }
-        full = wv::uniform(outv == 0.f);
+        full = wv::first_lane(outv == 0.f);
         if (!full) {                                               // :61-76
             float alpha = 1.f;
             for (int count = 0; count < 10; ++count) {
@@ -723,9 +723,9 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
                 const float dv = mxv - xv;
                 float hdv = 0.f;
                 Pnqp8vMv<0>::run(col0, dv, hdv);
-                const float den = wv::row_sum(-gv * dv), dhd = wv::row_sum(dv * hdv);
-                const float arm = fmaf(-0.5f, dhd, den) * wv::rcp(den);
-                if (wv::uniform(arm <= 0.1f)) alpha *= 0.1f; else break;
+                const float den = wv::row_sum8(-gv * dv), dhd = wv::row_sum8(dv * hdv);
+                const float arm = fmaf(-0.5f, dhd, den) * wv::rcp_fast(den);
+                if (wv::first_lane(arm <= 0.1f)) alpha *= 0.1f; else break;
             }
         }
         xv = mxv;                                                  // :78

@@ -164,6 +164,7 @@ static inline unsigned long long ballot(bool c)
 }
 static inline float rcp(float x) { return 1.0f / x; }
 static inline float rcp_fast(float x) { return 1.0f / x; }
+static inline bool first_lane(bool c) { return readlane_i((int)c, 0) != 0; }
 static inline void pin(float &) {}
 static inline void sched_fence() {}
 template <int N, int V, int LEAD = 0> static inline void sched_shadow() {}
@@ -267,6 +268,20 @@ static inline float row_sum(float x)
         else if (step == 1) src = j ^ 2;
         else if (step == 2) src = (j & 8) | (7 - (j & 7));
         else src = 15 - j;
+        x += w.fa[gen][r + src];
+    }
+    return x;
+}
+// wv::row_sum8 of lqr_mfma40.hip: the first three steps of row_sum
+static inline float row_sum8(float x)
+{
+    emu::Wave &w = emu::W;
+    for (int step = 0; step < 3; ++step) {
+        const int l = w.cur, gen = w.seq[l]++ & 1;
+        w.fa[gen][l] = x;
+        emu::yield_lane();
+        const int r = l & ~15, j = l & 15;
+        const int src = step == 0 ? (j ^ 1) : (step == 1 ? (j ^ 2) : ((j & 8) | (7 - (j & 7))));
         x += w.fa[gen][r + src];
     }
     return x;
