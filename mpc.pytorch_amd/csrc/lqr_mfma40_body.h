@@ -684,7 +684,7 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
         // Newton step the gradient vanishes on the free set, so if the free set of the new point is the one just factorised
         // the next step is zero to rounding -- this is the iteration the reference stops in (:56-59), and the factorisation
         // it would recompute is the one at hand.
-        if (it > 0 && full && wv::first_lane(wv::row_sum8(fabsf(mnv - mv)) == 0.f)) {
+        if (it > 0 && full && !wv::any(mnv != mv)) {             // (a ballot: every row of the wave holds the same QP)
             converged = true;
             it_ret = it;
             break;
@@ -707,7 +707,7 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
 #endif
         const float nrm2 = wv::row_sum8(dxv * dxv);       // (the vectors live in lanes 0..7; lane 0 reads the sums)
         float mxv = xv + dxv;
-        const float outv = wv::row_sum8(((mxv < lbv) | (mxv > ubv)) ? 1.f : 0.f);
+        const bool outside = wv::any((mxv < lbv) | (mxv > ubv));
         f = fn;
         mv = mnv;
         if (wv::first_lane(!(nrm2 >= 1e-8f))) {                    // :56-59
@@ -715,7 +715,7 @@ MPC_DEV int pnqp8v(const float (&col0)[8], float diagv, float qv, float lbv, flo
             it_ret = it;
             break;
         }
-        full = wv::first_lane(outv == 0.f);
+        full = !outside;
         if (!full) {                                               // :61-76
             float alpha = 1.f;
             for (int count = 0; count < 10; ++count) {
