@@ -650,6 +650,14 @@ template <int C> struct Pnqp8vMv {          // acc += H v  (v spread over lanes)
     }
 };
 template <> struct Pnqp8vMv<8> { static MPC_DEVM void run(const float (&)[8], float, float &) {} };
+// out[a] = in[a] * (entry a of the 0 / 1 vector m): rows off the free set drop out of a per-lane right-hand side / solution
+template <int A> MPC_DEVM void free_rows(float m, const float (&in)[8], float (&out)[8])
+{
+    if constexpr (A < 8) {
+        out[A] = in[A] * wv::bcast<A>(m);
+        free_rows<A + 1>(m, in, out);
+    }
+}
 template <int A> struct Pnqp8vSpread {      // y[a] = entry a of the row's vector v, in every lane
     static MPC_DEVM void run(float v, float (&y)[8])
     {
@@ -1027,6 +1035,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         // factorised on wave-uniform values in the constrained modes.)
         Ldl8V facv;
         QpFac qpf;                      // box QP: the factorisation of its last trip
+        float kqp_v = 0.f, frq_v = 1.f; // box QP: its solution k and its free set (1 / 0), lane a of every row: entry a
         float qu[8], kk[8];
         bool fr[8];
         // q_u (row layout): the one vector needed before the gains; q_x stays in shares until v takes it
@@ -1035,6 +1044,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         for (int a = 0; a < 8; ++a) {
             qu[a] = wv::readlane(qrow2, a);
             fr[a] = true;
+            kk[a] = 0.f;
         }
         if (MODE == 0) {
             float col[8];
@@ -1115,11 +1125,10 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             // m = qu + Quu k: the QP's gradient at its solution, eight DPP multiply-adds on the lane-spread data
             mkv = qv;
             Pnqp8vMv<0>::run(col0, xv, mkv);
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                kk[a] = wv::readlane(xv, a);
-                fr[a] = wv::readlane(mv, a) != 0.f;
-            }
+            // (k and the free set stay where the QP left them, spread over lanes: what follows reads entry a as a DPP broadcast
+            // of lane a.  Rounds 2-3 made them wave-uniform first: sixteen v_readlane and their wait states per timestep.)
+            kqp_v = xv;
+            frq_v = mv;
         }
         PROF40_MARK(3);
         f32x4 Kd[2];                    // K, B layout of the value update: register v of lane (q,r) = K[4q+v][16J+r]
@@ -1144,13 +1153,18 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                     const float x = (MODE == 1 && L.q == 2) ? qu[a] : rhs[a];
                     sol[a] = fr[a] ? x : 0.f;                                                         // :142-143
                 }
+                if (MODE == 2) free_rows<0>(frq_v, rhs, sol);
 #ifdef MPC_MFMA40_QP_LDL
                 ldl8v_solve(MODE == 2 ? qpf : facv, sol);
 #else
                 if (MODE == 2) gj8v_solve(qpf, sol); else ldl8v_solve(facv, sol);
 #endif
+                if (MODE == 2) {
+                    free_rows<0>(frq_v, sol, sol);
+                } else {
 #pragma unroll
-                for (int a = 0; a < 8; ++a) sol[a] = fr[a] ? sol[a] : 0.f;
+                    for (int a = 0; a < 8; ++a) sol[a] = fr[a] ? sol[a] : 0.f;
+                }
                 if (MODE == 1) {
                     float w = 0.f;
 #pragma unroll
@@ -1243,6 +1257,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             float kv = kk[0];
 #pragma unroll
             for (int a = 1; a < 8; ++a) kv = pick(L.lane == a, kk[a], kv);
+            if (MODE == 2) kv = kqp_v;
             kout[tb * NC + L.lane] = kv;
 #ifdef MPC_MFMA40_PAD
             if (p.k_user) wv::st_buf(p.k_user + tb * p.nc, (unsigned)(4 * p.nc), (unsigned)(4 * L.lane), kv);
@@ -1309,12 +1324,15 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             w0 += 0.5 * (double)wv::row_sum(kv * (mkv + (L.r < NC ? qrow2 : 0.f)));
         }
         float vrow[2], lrow[2] = {0.f, 0.f}, grow[2] = {0.f, 0.f};
+        float kq4[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (MODE == 2) Pnqp8vSpread<0>::run(kqp_v, kq4);
 #pragma unroll
         for (int J = 0; J < 2; ++J) {
             float s = 0.f;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float ka = pick(L.q == 0, kk[v], pick(L.q == 1, kk[4 + v], 0.f));
+                const float ka = MODE == 2 ? pick(L.q == 0, kq4[v], pick(L.q == 1, kq4[4 + v], 0.f))
+                                           : pick(L.q == 0, kk[v], pick(L.q == 1, kk[4 + v], 0.f));
                 s = fmaf(Qd[2][J][v], ka, s);
                 if (MODE != 0) s = fmaf(Kd[J][v], mq[v], s);      // + K'(qu + Quu k)
             }
