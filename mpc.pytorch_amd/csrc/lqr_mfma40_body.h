@@ -1132,7 +1132,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         }
         PROF40_MARK(3);
         f32x4 Kd[2];                    // K, B layout of the value update: register v of lane (q,r) = K[4q+v][16J+r]
-        float Kp[2][2];                 // ... its registers 2h, 2h + 1 packed into one full-k operand (see below)
+        float Kp[2][2];                 // ... its registers 2h, 2h + 1 packed into one full-k MFMA operand (see below)
         f32x4 Md[2];                    // M = Qux + Quu K in the same layout (constrained modes)
         Md[0] = zero4;
         Md[1] = zero4;
@@ -1204,34 +1204,64 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
 #ifndef MPC_MFMA40_KPAD
             // (round 4) A contraction over the eight controls is register v of the operand tiles for v = 0..3, and in each only
             // lane groups q = 0, 1 (controls v and 4 + v) are not padding: half of every MFMA's k.  Moving the lower halves of
-            // registers v, v + 1 side by side (one v_permlane32_swap each) makes it TWO full MFMAs per output tile instead of four
-            // -- K's tiles here, the Quu / Qux tiles where they are used (M below, V further down).
+            // registers v, v + 1 side by side (one v_permlane32_swap each) makes it TWO full MFMAs per output tile instead of four:
+            // M = Qux + Quu K (constrained modes) and V = Qxx + Qxu K, all their operands packed first, then the MFMAs in one
+            // run (vector instructions between MFMAs cost more than they hide: profiles/r04_ab_mfma_shadow.log).
 #pragma unroll
             for (int J = 0; J < 2; ++J)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) Kp[J][h] = wv::lower_halves(Kd[J][2 * h], Kd[J][2 * h + 1]);
-#endif
+            float Qp[2] = {0.f, 0.f}, Ap[2][2];
             if (MODE != 0) {
-                // M = Qux + Quu K on the matrix core: the Quu tile of Q is, by symmetry, its own A operand (rows 8..15 and
-                // columns 8..15 of it are zero), K's tiles are B operands as they stand, the Qux tiles the accumulators --
-                // 8 MFMAs where every lane formed its column of M from 36 readlane copies of Quu (128 multiply-adds)
-#ifndef MPC_MFMA40_KPAD
-                float Qp[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) Qp[h] = wv::lower_halves(Qd[2][2][2 * h], Qd[2][2][2 * h + 1]);
-#endif
+            }
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) Ap[I][h] = wv::lower_halves(Qd[2][I][2 * h], Qd[2][I][2 * h + 1]);
+            wv::sched_fence();
+            if (MODE != 0) {
+                // M = Qux + Quu K: the Quu tile of Q is, by symmetry, its own A operand, the Qux tiles the accumulators
+#pragma unroll
+                for (int J = 0; J < 2; ++J) Md[J] = Qd[2][J];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int J = 0; J < 2; ++J) Md[J] = wv::mfma(Qp[h], Kp[J][h], Md[J]);
+            }
+            // ---- V = Qxx + Qxu K   (:155-158 with K'(Qux + Quu K) = 0; v follows below)
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J) Vd[I][J] = Qd[I][J];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int I = 0; I < 2; ++I)
+#pragma unroll
+                    for (int J = 0; J < 2; ++J) Vd[I][J] = wv::mfma(Ap[I][h], Kp[J][h], Vd[I][J]);
+            wv::sched_fence();
+#else
+            if (MODE != 0) {
 #pragma unroll
                 for (int J = 0; J < 2; ++J) {
                     Md[J] = Qd[2][J];
-#ifndef MPC_MFMA40_KPAD
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) Md[J] = wv::mfma(Qp[h], Kp[J][h], Md[J]);
-#else
 #pragma unroll
                     for (int v = 0; v < 4; ++v) Md[J] = wv::mfma(Qd[2][2][v], Kd[J][v], Md[J]);
-#endif
                 }
             }
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J) Vd[I][J] = Qd[I][J];
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int I = 0; I < 2; ++I)
+#pragma unroll
+                    for (int J = 0; J < 2; ++J) Vd[I][J] = wv::mfma(Qd[2][I][v], Kd[J][v], Vd[I][J]);
+#endif
             if (L.q < 2) {
 #pragma unroll
                 for (int J = 0; J < 2; ++J)
@@ -1265,34 +1295,6 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         }
 
         PROF40_MARK(4);
-        // ---- V = Qxx + Qxu K, v = qx + Qxu k   (:155-158 with K'(Qux + Quu K) = 0, K'(qu + Quu k) = 0)
-        // (the four tiles' chains interleaved, see Y above)
-#pragma unroll
-        for (int I = 0; I < 2; ++I)
-#pragma unroll
-            for (int J = 0; J < 2; ++J) Vd[I][J] = Qd[I][J];
-#ifndef MPC_MFMA40_KPAD
-        {
-            float Ap[2][2];
-#pragma unroll
-            for (int I = 0; I < 2; ++I)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) Ap[I][h] = wv::lower_halves(Qd[2][I][2 * h], Qd[2][I][2 * h + 1]);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int I = 0; I < 2; ++I)
-#pragma unroll
-                    for (int J = 0; J < 2; ++J) Vd[I][J] = wv::mfma(Ap[I][h], Kp[J][h], Vd[I][J]);
-        }
-#else
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-#pragma unroll
-            for (int I = 0; I < 2; ++I)
-#pragma unroll
-                for (int J = 0; J < 2; ++J) Vd[I][J] = wv::mfma(Qd[2][I][v], Kd[J][v], Vd[I][J]);
-#endif
         // (+ K'(Qux + Quu K) of :155-158 is zero but for rounding in the constrained modes too: K's rows are exactly zero where a
         // control is pinned or clamped, and on the free rows Qux + Quu K = 0 is what the direct solve for K just enforced --
         // sixteen MFMAs that added 1e-7-relative noise.  The vector term K'(qu + Quu k) stays: the box QP stops at |dx| < 1e-4,
