@@ -327,6 +327,26 @@ def timed(fn, steps=20, warmup=5):
     return elapsed * 1e3 / steps, kern_ms, r
 
 
+def timed_each(fn, steps=20, warmup=5):
+    """Every call bracketed by its own pair of events: -> (median ms, mean ms, max ms, last result).  For the rows whose call is a
+    whole solve with host round trips in it: one stalled solve (milliseconds, seen after large blocks went back to the driver)
+    moves a 20-solve mean by its full weight, the median says what a solve takes and the mean / max say that it happened."""
+    r = None
+    for _ in range(warmup):
+        r = fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2], sum(ts) / len(ts), ts[-1], r
+
+
 ROW_SETTLE = 150          # launches in front of a secondary row's timed region (see timed_sustained)
 
 
@@ -391,7 +411,12 @@ def extra_rows(be, dev, steps):
     def kkt_row(p, r, opts, ns, nc, T, B):
         gx, gu = torch.randn_like(r["new_x"]), torch.randn_like(r["new_u"])
         nx, nu = r["new_x"].clone(), r["new_u"].clone()
-        wall, ms, ms_all, g = timed_sustained(lambda: be.kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, opts), k, 100)
+        # (pre-bound like the step rows' plan_step: outputs and workspace allocated once -- with an allocation per call the row
+        # measured the host's allocator where the kernel is shorter than the call's host time)
+        kfn = be.plan_kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, opts)
+        if kfn is None:
+            kfn = lambda: be.kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, opts)
+        wall, ms, ms_all, g = timed_sustained(kfn, k, 100)
         import ctypes
         pf, _keep = be._problem(p["x_init"], p["C"], p["c"], p["F"], p["f"], nx, nu)
         of, _keep2 = opts.to_struct(T, B, nc, p["C"])
@@ -495,10 +520,13 @@ def extra_rows(be, dev, steps):
                        eps=1e-12, backprop=False, not_improved_lim=10 ** 6)
         cost = QuadCost(Q, pp)
         # (20 solves behind 6 untimed ones: the first solves after the large blocks of the rows above went back to the driver
-        # can stall for milliseconds each -- tools/cfg3_repeat.py --pre --, and 5 timed solves made that a 0.7 / 1.8 ms lottery)
-        wall, ms, out = timed(lambda: ctrl(x0, cost, dxm), 20, 6)
+        # can stall for milliseconds each -- tools/cfg3_repeat.py --pre --, and 5 timed solves made that a 0.7 / 1.8 ms lottery;
+        # round 4 saw the pendulum row at 0.46 ms in two runs and 2.1 / 2.7 ms in two others with the mean of 20
+        # -- the row is the MEDIAN of 20 solves timed one by one; mean and maximum beside it.)
+        ms, ms_mean, ms_max, out = timed_each(lambda: ctrl(x0, cost, dxm), 20, 6)
         rows["cfg%d_ilqr_%s_10iter" % (2 if kind == "pendulum" else 3, kind)] = dict(
-            ms=ms, wall_ms=wall, lqr_iter=10, B=B, T=T, ms_per_iteration=ms / 10,
+            ms=ms, ms_mean=ms_mean, ms_max=ms_max, statistic="median of 20 solves, each between its own events", lqr_iter=10, B=B, T=T,
+            ms_per_iteration=ms / 10,
             problem_steps_per_s=B * T * 10 / (ms * 1e-3), mean_cost=float(out[2].mean()),
             note="MPC.forward on mpc.env_dx.%s: the step kernel linearises the simulator and rolls it out itself"
                  % ("PendulumDx" if kind == "pendulum" else "CartpoleDx"))

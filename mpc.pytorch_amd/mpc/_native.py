@@ -589,22 +589,11 @@ class HipBackend:
         has_f = f is not None and f.numel() > 0
         if impl == IMPL_AUTO:
             # the whole backward in one launch where a kernel for it exists (12/4 or 32/8, fp32, C vouched symmetric)
-            pf, keep_f = self._problem(x_star[0], C, c, F, f, x_star, u_star)
-            if L.mpc_lqr_kkt_fused_supported(ctypes.byref(pf), ctypes.byref(o)):
-                g = dict(dC=torch.empty(T, B, n, n, **kw), dc=torch.empty(T, B, n, **kw), dF=torch.empty(F.shape, **kw),
-                         df=torch.empty(T - 1, B, ns, **kw) if has_f and T > 1 else (torch.empty(0, B, ns, **kw) if has_f else None),
-                         dx_init=torch.empty(B, ns, **kw), dx=torch.empty(T, B, ns, **kw), du=torch.empty(T, B, nc, **kw))
-                nbytes = int(L.mpc_lqr_kkt_fused_workspace_bytes(ctypes.byref(pf)))
-                ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-                rc = L.mpc_lqr_kkt_fused(ctypes.byref(pf), ctypes.byref(o), dl_dx.data_ptr(), dl_du.data_ptr(), g["dC"].data_ptr(),
-                                         g["dc"].data_ptr(), g["dF"].data_ptr(), _ptr(g["df"]) if (has_f and T > 1) else None,
-                                         g["dx_init"].data_ptr(), g["dx"].data_ptr(), g["du"].data_ptr(), None, ws.data_ptr(),
-                                         nbytes, st)
-                if rc == 0:
-                    g["_keep"] = (keep_f, keep_o, ws, dl_dx, dl_du, x_star, u_star)
+            plan = self.plan_kkt_backward(C, c, F, f, x_star, u_star, dl_dx, dl_du, opts, _prepared=True)
+            if plan is not None:
+                g = plan()
+                if g is not None:
                     return g
-                if rc != -1:          # MPC_E_DIMS = misaligned views: the three calls below take anything
-                    _check(rc, "mpc_lqr_kkt_fused")
         negr = torch.empty(T, B, n, **kw)
         mask = None
         if o.bound_mode != BOUND_NONE:
@@ -628,6 +617,49 @@ class HipBackend:
                                    dF.data_ptr(), _ptr(df), dx_init.data_ptr(), st), "mpc_lqr_kkt_grads")
         return dict(dx_init=dx_init, dC=dC, dc=dc, dF=dF, df=df, dx=sol["new_x"], du=sol["new_u"],
                     _keep=(keep, keep_o, negr, mask, sol))
+
+    def plan_kkt_backward(self, C, c, F, f, x_star, u_star, dl_dx, dl_du, opts, _prepared=False):
+        """Pre-bind the fused KKT backward (mpc_lqr_kkt_fused): argument structs, the gradient buffers and the workspace are
+        built once, `plan()` is then a single C call that overwrites the same outputs (clone what must survive) -- what a loop
+        over many backward calls of one shape wants (bench.py; an allocation-per-call caller spends as long in the allocator
+        as the GPU in the kernel).  Reads dl_dx / dl_du in place at every call.  None where no fused kernel covers the
+        problem; plan() returns None if the library refuses the views (misaligned): use kkt_backward then."""
+        dev = _require_device(C, c, F, x_star, u_star, dl_dx, dl_du)
+        L = load()
+        T, B, n = C.shape[0], C.shape[1], C.shape[2]
+        ns = x_star.shape[2]
+        nc = n - ns
+        kw = dict(device=dev, dtype=C.dtype)
+        if not _prepared:
+            dl_dx = dl_dx.detach().to(**kw).contiguous()
+            dl_du = dl_du.detach().to(**kw).contiguous()
+            x_star = x_star.detach().contiguous()
+            u_star = u_star.detach().contiguous()
+        o, keep_o = opts.to_struct(T, B, nc, C)
+        has_f = f is not None and f.numel() > 0
+        pf, keep_f = self._problem(x_star[0], C, c, F, f, x_star, u_star)
+        if not L.mpc_lqr_kkt_fused_supported(ctypes.byref(pf), ctypes.byref(o)):
+            return None
+        g = dict(dC=torch.empty(T, B, n, n, **kw), dc=torch.empty(T, B, n, **kw), dF=torch.empty(F.shape, **kw),
+                 df=torch.empty(T - 1, B, ns, **kw) if has_f and T > 1 else (torch.empty(0, B, ns, **kw) if has_f else None),
+                 dx_init=torch.empty(B, ns, **kw), dx=torch.empty(T, B, ns, **kw), du=torch.empty(T, B, nc, **kw))
+        nbytes = int(L.mpc_lqr_kkt_fused_workspace_bytes(ctypes.byref(pf)))
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        g["_keep"] = (keep_f, keep_o, ws, dl_dx, dl_du, x_star, u_star, pf, o)
+        fn = L.mpc_lqr_kkt_fused
+        args = (ctypes.byref(pf), ctypes.byref(o), dl_dx.data_ptr(), dl_du.data_ptr(), g["dC"].data_ptr(), g["dc"].data_ptr(),
+                g["dF"].data_ptr(), _ptr(g["df"]) if (has_f and T > 1) else None, g["dx_init"].data_ptr(), g["dx"].data_ptr(),
+                g["du"].data_ptr(), None, ws.data_ptr(), nbytes)
+
+        def run(stream=None):
+            rc = fn(*args, torch.cuda.current_stream(dev).cuda_stream if stream is None else stream)
+            if rc == -1:              # MPC_E_DIMS = misaligned views: kkt_backward's three calls take anything
+                return None
+            if rc != 0:
+                _check(rc, "mpc_lqr_kkt_fused")
+            return g
+        run.outputs = g
+        return run
 
     # -- (5) pnqp -------------------------------------------------------------------------------
     def pnqp(self, H, q, lower, upper, x_init=None, n_iter=20, want_Hfree=True, want_lu=False):

@@ -1095,6 +1095,37 @@ def test_kkt_backward_is_repeatable(be):
         assert all(float(t.abs().max()) == 0.0 for t in z)
 
 
+@pytest.mark.parametrize("ns,nc,T,B,bounded", [(12, 4, 9, 37, True), (12, 4, 70, 9, False), (32, 8, 6, 5, True)])
+def test_planned_kkt_backward_is_the_plain_one_and_reads_its_gradients_in_place(be, ns, nc, T, B, bounded):
+    """plan_kkt_backward binds the fused backward once (buffers, workspace, structs): each call of the plan is the one C
+    call, returns what kkt_backward returns on the same inputs, and follows dl_dx / dl_du when they are overwritten in place."""
+    from mpc._native import StepOptions
+    import bench
+    p = bench.make_problem(ns, nc, T, B, torch.float32, DEV, seed=11, u_scale=0.3 if bounded else 0.0, clamp=0.5 if bounded else None)
+    opts = StepOptions(u_lower=-0.5, u_upper=0.5, c_symmetric=True) if bounded else StepOptions(c_symmetric=True)
+    r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts)
+    nx, nu = r["new_x"].clone(), r["new_u"].clone()
+    gx, gu = torch.randn_like(nx), torch.randn_like(nu)
+    plan = be.plan_kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, opts)
+    assert plan is not None
+    for rep in range(2):
+        ref = be.kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, opts)
+        got = plan()
+        assert got is plan.outputs
+        torch.cuda.synchronize()
+        for k in ("dx_init", "dC", "dc", "dF", "df", "dx", "du"):
+            assert (ref[k] is None) == (got[k] is None), k
+            if ref[k] is not None:
+                assert torch.equal(ref[k], got[k]), (rep, k)
+        gx.normal_()
+        gu.normal_()
+    # a shape no fused kernel covers: no plan (kkt_backward's three-call route is the caller's)
+    q = bench.make_problem(5, 2, 4, 6, torch.float64, DEV, seed=4)
+    rq = be.lqr_step(q["x_init"], q["C"], q["c"], q["F"], q["f"], q["cur_x"], q["cur_u"], StepOptions())
+    assert be.plan_kkt_backward(q["C"], q["c"], q["F"], q["f"], rq["new_x"], rq["new_u"], torch.randn_like(rq["new_x"]),
+                                torch.randn_like(rq["new_u"]), StepOptions()) is None
+
+
 def test_sharded_solve_on_one_rank_is_the_plain_solve(be):
     """shard.mpc_forward_sharded without a process group (world size 1) is MPC.forward."""
     from mpc import mpc, shard

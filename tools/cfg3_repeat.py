@@ -19,7 +19,7 @@ if "--pre" in sys.argv:
     del ps, big, view
     if "--keep" not in sys.argv:
         torch.cuda.empty_cache()
-kind, B, T = "cartpole", 4096, 25
+kind, B, T = ("pendulum", 1024, 20) if "--pendulum" in sys.argv else ("cartpole", 4096, 25)
 dxm, _plain, x0, Q, pp = env_problem(kind, B, T)
 ctrl = mpc.MPC(dxm.n_state, 1, T, u_lower=dxm.lower, u_upper=dxm.upper, lqr_iter=10, verbose=-1,
                exit_unconverged=False, detach_unconverged=False, linesearch_decay=dxm.linesearch_decay,

@@ -40,7 +40,7 @@ if "kkt" in kind:
     g = torch.Generator(device=dev).manual_seed(1)
     gx, gu = torch.randn(nx.shape, generator=g, device=dev), torch.randn(nu.shape, generator=g, device=dev)
     ko = StepOptions(c_symmetric=True, **kw)
-    fn = lambda: be.kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, ko)
+    fn = be.plan_kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, ko)
 else:
     fn = be.plan_step(*a, opts)
 if os.environ.get("PROF_ONE_TRACE"):
