@@ -53,6 +53,13 @@ template <int N> MPC_DEV void fmac_bcast(float &acc, float src, float mul)
         "v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3" DPPM
         : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
 }
+// the same where src was written at least three instructions earlier (or has just been read through DPP by the instruction in
+// front): no read-after-write wait states -- each s_nop is an issue slot on a chain that has nothing to fill it with (round 4)
+template <int N> MPC_DEV void fmac_bcast_settled(float &acc, float src, float mul)
+{
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3" DPPM
+        : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
+}
 // acc += sum_i bcast_i(src) * mul[i]   (two accumulation chains)
 MPC_DEV void dot_bcast16(float &acc, float src, const float (&m)[16])
 {

@@ -152,8 +152,10 @@ MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const
     // The gradient H x + q (:29) is carried along: every step d is followed by g += H d, and H d is also what the
     // Armijo test of a projected step needs (:61-76) -- one product serves both.
     // (same order of additions as sym4_mv: the products are bit-identical to the row-uniform form)
-#define MPC_HV(out, v) do { out = wv::bcast<0>(v) * Hc[0]; wv::fmac_bcast<4>(out, v, Hc[1]); \
-                            wv::fmac_bcast<8>(out, v, Hc[2]); wv::fmac_bcast<12>(out, v, Hc[3]); } while (0)
+    // (the first product reads v through the compiler's DPP form, which waits out v's producer; the three behind it on the
+    // accumulator's chain find v settled)
+#define MPC_HV(out, v) do { out = wv::bcast<0>(v) * Hc[0]; wv::fmac_bcast_settled<4>(out, v, Hc[1]); \
+                            wv::fmac_bcast_settled<8>(out, v, Hc[2]); wv::fmac_bcast_settled<12>(out, v, Hc[3]); } while (0)
     float gv;
     MPC_HV(gv, xv);
     gv += MPC_QV(q[0], q[1], q[2], q[3]);
@@ -848,11 +850,12 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #endif
     wv::sched_fence();
     float vn = q;
-    wv::fmac_bcast<12>(vn, K[0], Q[12]); wv::fmac_bcast<12>(vn, K[1], Q[13]);
-    wv::fmac_bcast<12>(vn, K[2], Q[14]); wv::fmac_bcast<12>(vn, K[3], Q[15]);
+    // (K and M were finished in front of the matrix-core block above: settled sources, no wait states)
+    wv::fmac_bcast_settled<12>(vn, K[0], Q[12]); wv::fmac_bcast_settled<12>(vn, K[1], Q[13]);
+    wv::fmac_bcast_settled<12>(vn, K[2], Q[14]); wv::fmac_bcast_settled<12>(vn, K[3], Q[15]);
     if (con(MODE)) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) wv::fmac_bcast<12>(vn, M[a], K[a]);      // += K[a][j] m[a]
+        for (int a = 0; a < 4; ++a) wv::fmac_bcast_settled<12>(vn, M[a], K[a]);      // += K[a][j] m[a]
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) st.Vc[i] = Vn[i];
@@ -1876,8 +1879,8 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
                 for (int a = 0; a < 4; ++a) outer_acc(Vn, Q[12 + a], K[a]);
                 wv::sched_fence();
                 float vn = q;
-                wv::fmac_bcast<12>(vn, K[0], Q[12]); wv::fmac_bcast<12>(vn, K[1], Q[13]);
-                wv::fmac_bcast<12>(vn, K[2], Q[14]); wv::fmac_bcast<12>(vn, K[3], Q[15]);
+                wv::fmac_bcast_settled<12>(vn, K[0], Q[12]); wv::fmac_bcast_settled<12>(vn, K[1], Q[13]);
+                wv::fmac_bcast_settled<12>(vn, K[2], Q[14]); wv::fmac_bcast_settled<12>(vn, K[3], Q[15]);
                 {
                     float w = 0.f;
 #pragma unroll
