@@ -131,8 +131,36 @@ using mfma16::sel;
 //   * free-set flags are numbers (0 / 1) and the masked matrix is built by multiplication, not by selects on
 //     combined lane masks (see ldl4).
 // ---------------------------------------------------------------------------
+// ---- Gauss-Jordan in the quad layout: the factorisation of the QP's trips (round 4; the 32/8 kernel's Gj8V on four unknowns).
+// A trip solves ONE system whose right-hand side lives like the QP's vectors (quad a of the row: entry a).  On row-uniform
+// scalars that was ten products for the masked matrix, the LDL' (19), four broadcasts of the right-hand side, sixteen multiply-adds
+// of triangular solves and three selects to spread the answer.  With column c of the matrix as ONE register (quad a: A[a][c])
+// and elimination above the pivot as well, the right-hand side rides along as a fifth column and the answer is where it is
+// wanted.  The multipliers are a factorisation too: the K solve behind the QP applies them to its per-lane right-hand sides.
+struct Gj4 {
+    float nl[4];     // quad a: -(A[a][c] / d_c) as it stood at pivot c (the multiplier of row a), 0 in quad c itself
+    float inv[4];    // 1 / d_c (row-uniform)
+};
+// z = A^-1 z for per-lane right-hand sides z[0..3] (every lane its own), from the multipliers
+MPC_DEV void gj4_solve(const Gj4 &g, float (&z)[4])
+{
+#define MPC_GJ4_APPLY(c, a) wv::fmac_bcast_settled<4 * (a)>(z[a], g.nl[c], z[c])
+    MPC_GJ4_APPLY(0, 1); MPC_GJ4_APPLY(0, 2); MPC_GJ4_APPLY(0, 3);
+    MPC_GJ4_APPLY(1, 0); MPC_GJ4_APPLY(1, 2); MPC_GJ4_APPLY(1, 3);
+    MPC_GJ4_APPLY(2, 0); MPC_GJ4_APPLY(2, 1); MPC_GJ4_APPLY(2, 3);
+    MPC_GJ4_APPLY(3, 0); MPC_GJ4_APPLY(3, 1); MPC_GJ4_APPLY(3, 2);
+#undef MPC_GJ4_APPLY
+#pragma unroll
+    for (int a = 0; a < 4; ++a) z[a] *= g.inv[a];
+}
+#ifdef MPC_DPP16_QP_LDL           // (the round-3 form of the QP's linear algebra, kept for A/B timing)
+using QpFac4 = Ldl4;
+#else
+using QpFac4 = Gj4;
+#endif
+
 MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const float ub[4], int n_iter, int j,
-                       float x[4], bool fr_out[4], Ldl4 &f, bool &converged)
+                       float x[4], bool fr_out[4], QpFac4 &f, bool &converged)
 {
     // Everything that is one number per unknown (x, g, the bounds, the free-set flags, the step) lives as ONE register
     // with unknown a in the lanes of quad a (lanes 4a..4a+3 of the row): a clamp, a compare, a gradient update is one
@@ -146,6 +174,10 @@ MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const
     const float Hc[4] = {MPC_QV(s.s00, s.s01, s.s02, s.s03), MPC_QV(s.s01, s.s11, s.s12, s.s13),
                          MPC_QV(s.s02, s.s12, s.s22, s.s23), MPC_QV(s.s03, s.s13, s.s23, s.s33)};
     const float lbv = MPC_QV(lb[0], lb[1], lb[2], lb[3]), ubv = MPC_QV(ub[0], ub[1], ub[2], ub[3]);
+#ifndef MPC_DPP16_QP_LDL
+    const float dgv = MPC_QV(dg[0], dg[1], dg[2], dg[3]);
+    const bool qd[4] = {q0, q1 && !q0, q2 && !q1, !q2};            // "this lane belongs to quad c"
+#endif
     float xv = MPC_QV(x[0], x[1], x[2], x[3]);
     float mv = -1.f;                                                // free set of the last factorisation (none yet)
     float done = 0.f, conv = 0.f, full = 0.f, it_ret = (float)(n_iter - 1);
@@ -177,6 +209,7 @@ MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const
         if (done == 0.f) MPC_STAT(1);
         MPC_STAT(6);
         // :44-54  H_ = H on the free block (+1e-11 I, identity elsewhere), dx = -H_^-1 g_
+#ifdef MPC_DPP16_QP_LDL
         const float mn[4] = {wv::bcast<0>(mnv), wv::bcast<4>(mnv), wv::bcast<8>(mnv), wv::bcast<12>(mnv)};
         Ldl4 fn;
         {
@@ -202,6 +235,28 @@ MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const
         float y[4];
         ldl4_solve(fn, wv::bcast<0>(rv), wv::bcast<4>(rv), wv::bcast<8>(rv), wv::bcast<12>(rv), y);
         const float dxv = -(mnv * MPC_QV(y[0], y[1], y[2], y[3]));
+#else
+        Gj4 fn;
+        float col[4];
+#define MPC_GJ4_COL(c) do { col[c] = (mnv * wv::bcast<4 * (c)>(mnv)) * Hc[c]; col[c] = qd[c] ? dgq : col[c]; } while (0)
+        const float dgq = fmaf(mnv, dgv, 1.f);
+        MPC_GJ4_COL(0); MPC_GJ4_COL(1); MPC_GJ4_COL(2); MPC_GJ4_COL(3);
+#undef MPC_GJ4_COL
+        // (rows off the free set are identity rows with a zero right-hand side: their entry of the solution is 0 as it comes)
+        float sol = mnv * gv, invd = 0.f;
+#define MPC_GJ4_PIVOT(c) do { const float inv = wv::rcp(wv::bcast<4 * (c)>(col[c])); fn.inv[c] = inv; \
+                              const float t = -(col[c] * inv); fn.nl[c] = qd[c] ? 0.f : t; invd = qd[c] ? inv : invd; } while (0)
+#define MPC_GJ4_ELIM(c, m) wv::fmac_bcast_settled<4 * (m)>(col[m], col[c], fn.nl[c])   /* the unpivoted block stays symmetric */
+#define MPC_GJ4_RHS(c) sol = fmaf(wv::bcast<4 * (c)>(sol), fn.nl[c], sol)
+        MPC_GJ4_PIVOT(0); MPC_GJ4_ELIM(0, 1); MPC_GJ4_ELIM(0, 2); MPC_GJ4_ELIM(0, 3); MPC_GJ4_RHS(0);
+        MPC_GJ4_PIVOT(1); MPC_GJ4_ELIM(1, 2); MPC_GJ4_ELIM(1, 3); MPC_GJ4_RHS(1);
+        MPC_GJ4_PIVOT(2); MPC_GJ4_ELIM(2, 3); MPC_GJ4_RHS(2);
+        MPC_GJ4_PIVOT(3); MPC_GJ4_RHS(3);
+#undef MPC_GJ4_PIVOT
+#undef MPC_GJ4_ELIM
+#undef MPC_GJ4_RHS
+        const float dxv = -(sol * invd);
+#endif
         const float nrm2 = wv::ring_sum(dxv * dxv);
         // what this trip factorised is what the solve returns for every row (frozen rows recompute their own)
         f = fn;
@@ -742,6 +797,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     bool fr[4] = {true, true, true, true};
     const bool valid[4] = {true, true, true, true};
     Ldl4 f;
+    QpFac4 qf;                      // box QP: the factorisation of its last trip
     float kq[4] = {0.f, 0.f, 0.f, 0.f};
     if (!con(MODE)) {
         float sing = 0.f;
@@ -783,7 +839,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #pragma unroll
         for (int a = 0; a < 4; ++a) kq[a] = eclampf(kq[a], lb[a], ub[a]);
         bool conv = false;
-        const int it = pnqp4_rows(S, qu, lb, ub, p.pnqp_iter, L.j, kq, fr, f, conv);
+        const int it = pnqp4_rows(S, qu, lb, ub, p.pnqp_iter, L.j, kq, fr, qf, conv);
         st.qp_total += 1 + it;                                      // :140
         if (!conv) st.status |= MPC_ST_PNQP_UNCONVERGED;
         st.warm = 1;
@@ -804,7 +860,17 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #pragma unroll
             for (int a = 0; a < 4; ++a) K[a] = -y[a];
         } else {
-            ldl4_solve(f, fr[0] ? rhs[0] : 0.f, fr[1] ? rhs[1] : 0.f, fr[2] ? rhs[2] : 0.f, fr[3] ? rhs[3] : 0.f, y);
+#ifdef MPC_DPP16_QP_LDL
+            ldl4_solve(MODE == 2 ? qf : f, fr[0] ? rhs[0] : 0.f, fr[1] ? rhs[1] : 0.f, fr[2] ? rhs[2] : 0.f, fr[3] ? rhs[3] : 0.f, y);
+#else
+            if (MODE == 2) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) y[a] = fr[a] ? rhs[a] : 0.f;
+                gj4_solve(qf, y);
+            } else {
+                ldl4_solve(f, fr[0] ? rhs[0] : 0.f, fr[1] ? rhs[1] : 0.f, fr[2] ? rhs[2] : 0.f, fr[3] ? rhs[3] : 0.f, y);
+            }
+#endif
 #pragma unroll
             for (int a = 0; a < 4; ++a) K[a] = fr[a] ? -y[a] : 0.f;
             if (MODE == 2) {
