@@ -140,7 +140,11 @@ struct KktArgs40 {
 };
 // pass 2's stage: F | K_t | record (v_{t+1}, g_{t+1}, k_t) | V_{t+1}; three slots, the DMA two timesteps ahead
 constexpr unsigned KOFF_F = 0, KOFF_K = 5120, KOFF_R = 6144, KOFF_V = 6656, KSTAGE_BYTES = 10752;
+#ifdef MPC_KF40_VFULL
 constexpr int KSLOTS = 3, KDMA_PER_STAGE = 11;                 // 5 (F) + 1 (K) + 1 (record) + 4 (V)
+#else
+constexpr int KSLOTS = 3, KDMA_PER_STAGE = 10;                 // 5 (F) + 1 (K) + 1 (record) + 3 (V: tiles (0,0), (1,0), (1,1))
+#endif
 // the constrained modes' record for the rollout that prices without C (rollout_priced): floats per problem-step
 constexpr int PREC = 328;                                      // M [8][32] | Quu [8][8] | m [8]
 constexpr int PSCR = 40;                                       // behind the records [T,B,PREC]: the second line-search trial's x' | u' [T,B,40]
@@ -751,10 +755,18 @@ MPC_DEV void kkt_store_vvg(const KktArgs40 &kx, long tb, const Lane &L, const wv
 #ifdef MPC_KF40_NOVS              // (diagnostic build: what the V stores cost)
     if (tb < 0)
 #endif
+    // (round 4) V is symmetric: tile (0, 1) is the transpose of tile (1, 0) and stays home -- pass 2 reads it out of the staged
+    // (1, 0) tile with the indices swapped (`-DMPC_KF40_VFULL`: all four tiles, as in round 3).  3 KiB per problem-step each way
+    // instead of 4 in a kernel that moves 1.9 GB at 5 TB/s.
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
-        for (int J = 0; J < 2; ++J) wv::store_f32x4(kx.Vws + tb * 1024 + (2 * I + J) * 256 + 4 * L.lane, Vd[I][J]);
+        for (int J = 0; J < 2; ++J) {
+#ifndef MPC_KF40_VFULL
+            if (I == 0 && J == 1) continue;
+#endif
+            wv::store_f32x4(kx.Vws + tb * 1024 + (2 * I + J) * 256 + 4 * L.lane, Vd[I][J]);
+        }
     if (L.r == 0) {
 #pragma unroll
         for (int I = 0; I < 2; ++I) {
@@ -2285,7 +2297,17 @@ MPC_DEV void kstage_issue(const P &p, const RStream &d, const char *v_ptr, long 
     dma_kib<5>(d.f_ptr + tf * d.f_step + d.lo, base + KOFF_F);
     wv::dma16(d.k_ptr + tl * d.k_step + d.lo, base + KOFF_K);
     wv::dma16_if(d.r_active, d.r_ptr + rec_off(d.r_is_x ? tx : tl, d.r_step), base + KOFF_R);
+#ifdef MPC_KF40_VFULL
     dma_kib<4>(v_ptr + tx * v_step + d.lo, base + KOFF_V);
+#else
+    {
+        // tiles (0,0), (1,0), (1,1): KiB 0, 2, 3 of the record (the slot keeps its 4 KiB; KiB 1 is never written nor read)
+        const char *vp = v_ptr + tx * v_step + d.lo;
+        wv::dma16_at<0>(vp, base + KOFF_V);
+        wv::dma16_at<2048>(vp, base + KOFF_V);
+        wv::dma16_at<3072>(vp, base + KOFF_V);
+    }
+#endif
 }
 
 template <int MODE>
@@ -2381,7 +2403,18 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
 #pragma unroll
         for (int I = 0; I < 2; ++I)
 #pragma unroll
-            for (int J = 0; J < 2; ++J) Vt[I][J] = wv::lds_f32x4(base + KOFF_V + 1024u * (unsigned)(2 * I + J) + 16u * (unsigned)L.lane);
+            for (int J = 0; J < 2; ++J) {
+#ifndef MPC_KF40_VFULL
+                if (I == 0 && J == 1) continue;
+#endif
+                Vt[I][J] = wv::lds_f32x4(base + KOFF_V + 1024u * (unsigned)(2 * I + J) + 16u * (unsigned)L.lane);
+            }
+#ifndef MPC_KF40_VFULL
+        // tile (0,1), register v of lane (q,r) = V[4q+v][16+r] = V[16+r][4q+v] = register r & 3 of lane (r >> 2, 4q + v) of tile (1,0)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            Vt[0][1][v] = wv::lds_f32(base + KOFF_V + 2048u + 16u * (unsigned)(16 * (L.r >> 2) + 4 * L.q + v) + 4u * (unsigned)(L.r & 3));
+#endif
         f32x4 DL[2];
 #pragma unroll
         for (int Im = 0; Im < 2; ++Im) {
