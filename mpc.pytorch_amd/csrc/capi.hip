@@ -58,7 +58,7 @@ static int dpp16_ring_force()
 // The 32/8 kernel's sweep ring: three slots (the DMA two timesteps ahead: address-translation misses behind another kernel
 // stay hidden, lqr_mfma40_body.h) wherever four wavefronts per CU are all the batch asks for or the mode gains from them anyway
 // (unconstrained / masked: 2.33 against 2.40 ms at B = 8192); the box-constrained step of a larger batch wants six per CU on
-// the two-slot ring (4.65 against 5.06 ms).  MPC_MFMA40_RING=2|3 forces one (read like MPC_DPP16_RING).
+// the two-slot ring (round 3: 4.65 against 5.06 ms; round 4, after the QP's rewrite: 3.05 against 3.11).  MPC_MFMA40_RING=2|3 forces one (read like MPC_DPP16_RING).
 static int mfma40_ring(const StepParams<float> &sp)
 {
     const DeviceFacts &f = device_facts();
