@@ -909,6 +909,13 @@ def main():
                 out["config"]["finite"] = ok = False
         if saved_stdout is not None:
             sys.stdout.flush()
+            # (the banner sits in the C library's stdout buffer, not yet on the descriptor: flushed now it goes where
+            # descriptor 1 still points -- stderr --; flushed at exit it would follow the JSON line onto stdout)
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
             os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         if "parity" in out and not out["parity"]["ok"]:
