@@ -98,17 +98,6 @@ MPC_DEV unsigned load_uniform_u32(const unsigned *g)
 }
 // nothing is scheduled across this point
 MPC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
-// ask the scheduler for N groups of (one MFMA, up to V vector instructions) in that order: arithmetic that does not
-// depend on the MFMAs around it issues while the matrix pipe works on them (32 clocks each) instead of behind them
-template <int N, int V, int LEAD = 0> MPC_DEV void sched_shadow()
-{
-    if (LEAD) __builtin_amdgcn_sched_group_barrier(0x008, LEAD, 0);      // (MFMAs the arithmetic waits for go first)
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
-    }
-}
 // an opaque register-to-register identity (see mfma40::pick)
 MPC_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
 // Compiled three times (Makefile): the step kernels on the three-slot sweep ring (launch_step_mfma40), the same with

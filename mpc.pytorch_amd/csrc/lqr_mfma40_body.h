@@ -1828,27 +1828,6 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
         }
         const unsigned qo = 16u * (unsigned)(L.q < 2 ? L.q : 0);
         const f32x4 ub = wv::lds_f32x4(rec + 288 + qo), kb = wv::lds_f32x4(rec + 448 + qo);
-#ifdef MPC_MFMA40_RO_EARLYX
-        // (diagnostic build, round 4: the state part of x+ = F tau' + f does not wait for u' -- its operands read here, its
-        // sixteen MFMAs directly behind those of K dx, the arithmetic of u' in their shadow.  Measured level: 286.3 against
-        // 284.4 us at config 5, 447.7 against 449.2 box-constrained -- the pass is not waiting where this helps.)
-        f32x4 acc[2];
-        float fa[2][12];
-        if (t < T - 1) {
-#pragma unroll
-            for (int Im = 0; Im < 2; ++Im) {
-                acc[Im] = zero4;
-                if (p.f) acc[Im] = wv::lds_f32x4(rec + 320 + 4u * (unsigned)(16 * Im + 4 * L.q));
-                const int row = 16 * Im + L.r;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    fa[Im][k] = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
-#pragma unroll
-                for (int h = 0; h < 2; ++h)        // the control columns as two full-k operands (uctl)
-                    fa[Im][8 + h] = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + 32 + uctl(L.q) + 2 * h));
-            }
-        }
-#endif
         {
             const int tn = t + LSLOTS - 1;
             lstage_issue(p, d, L, tn < T ? tn : T - 1, tn % LSLOTS);
@@ -1862,16 +1841,7 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
                 Ud = wv::mfma(a[k], DXd[0][k], Ud);
                 U2 = wv::mfma(a[4 + k], DXd[1][k], U2);
             }
-#ifndef MPC_MFMA40_RO_EARLYX
             wv::sched_fence();
-#else
-            if (t < T - 1) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-#pragma unroll
-                    for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][k], Xd[k >> 2][k & 3], acc[Im]);
-            }
-#endif
 #pragma unroll
             for (int v = 0; v < 4; ++v) Ud[v] += U2[v];
         }
@@ -1894,23 +1864,11 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
                 s = fmaf(dd, dd, s);
             }
             dacc += s;
-#ifdef MPC_MFMA40_RO_EARLYX
-            wv::sched_shadow<16, 3, 8>();         // K dx, then one MFMA of F_x x + three instructions of the above, sixteen times
-#endif
             if (store && L.q < 2) st_u4(p, tb, 4 * L.q, Ud);
         }
         // ---- x+ = F tau' + f   (:216-222)
         if (t < T - 1) {
             const long tb1 = (long)(t + 1) * p.B + L.b;
-#ifdef MPC_MFMA40_RO_EARLYX
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float up = wv::lower_halves(Ud[2 * h], Ud[2 * h + 1]);
-#pragma unroll
-                for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + h], up, acc[Im]);
-            }
-            wv::sched_fence();
-#else
             // both output tiles at once: operands of the two first, then their accumulation chains interleaved
             f32x4 acc[2];
             float fa[2][12];
@@ -1938,7 +1896,6 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
                 for (int Im = 0; Im < 2; ++Im) acc[Im] = wv::mfma(fa[Im][8 + h], up, acc[Im]);
             }
             wv::sched_fence();
-#endif
 #pragma unroll
             for (int Im = 0; Im < 2; ++Im) {
                 if (store) st_x4(p, tb1, 16 * Im + 4 * L.q, acc[Im]);

@@ -167,7 +167,6 @@ static inline float rcp_fast(float x) { return 1.0f / x; }
 static inline bool first_lane(bool c) { return readlane_i((int)c, 0) != 0; }
 static inline void pin(float &) {}
 static inline void sched_fence() {}
-template <int N, int V, int LEAD = 0> static inline void sched_shadow() {}
 // v_mfma_f32_4x4x1_16b_f32 cbsz:2 abid:ABID (lqr_dpp16_body.h): rows 4*ABID..+3 of a per-row outer product
 template <int ABID> static inline f32x4 mfma4(float a, float b, f32x4 c)
 {
