@@ -68,7 +68,14 @@ static int mfma40_ring(const StepParams<float> &sp)
         force = (e && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 0;
     }
     if (force) return force;
-    return (sp.bound_mode != MPC_BOUND_NONE && sp.B > f.simds) ? 2 : 3;
+    // Box-constrained: the three-slot ring while one wave per SIMD holds the batch, six waves per CU on the two-slot ring beyond.
+    // Unconstrained / masked (round 4, final kernels, config 5 by HIP events): the two-slot ring keeps 1,536 waves resident, so a
+    // batch between 1,025 and 1,536 runs in ONE round on it (B = 1,536: 0.44 against 0.54 ms); beyond, the three-slot ring's
+    // shorter rounds win (2,048: 0.57 against 0.72 ms; 4,096: 1.11 against 1.21; 8,192: 2.22 against 2.30).  Up to 1,024 the two-slot
+    // ring is 1.4-3 % faster in the sustained state (277 against 281 us) but 30 % SLOWER behind a kernel that emptied the address
+    // translations (bench.py's cold_translations row: 0.436 against 0.33 ms) -- what the third slot is there for: it stays.
+    if (sp.bound_mode != MPC_BOUND_NONE) return sp.B > f.simds ? 2 : 3;
+    return (sp.B > f.simds && sp.B <= f.simds + f.simds / 2) ? 2 : 3;
 }
 
 static int check_problem(const mpc_lqr_problem *p, bool need_cost, bool need_nominal, bool need_F = true)

@@ -27,6 +27,7 @@ bounded = "bounded" in kind
 bare = kind.endswith("_bare")
 ns, nc, T = (32, 8, 64) if cfg5 else (12, 4, 50)
 B = 8192 if kind.endswith("B8192") else (1024 if cfg5 else 4096)
+B = int(os.environ.get("PROF_ONE_B", B))          # (another batch for the same kind of call)
 if cfg5:
     p = bench.make_problem(ns, nc, T, B, torch.float32, dev, seed=9, on_device=True)
 else:
