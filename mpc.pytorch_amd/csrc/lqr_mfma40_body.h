@@ -1555,9 +1555,10 @@ MPC_DEV void rollout_pass(const P &p, const RStream &d, const Lane &L, float alp
         {
             float a[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float x = wv::lds_f32(base + ROFF_K + 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 16 * (k >> 2) + 4 * L.q + (k & 3)));
-                a[k] = L.r < NC ? x : 0.f;
+            for (int J = 0; J < 2; ++J) {        // four consecutive words of K's row r per lane and state tile: one 16-byte LDS read
+                const f32x4 x = wv::lds_f32x4(base + ROFF_K + 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 16 * J + 4 * L.q));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[4 * J + i] = L.r < NC ? x[i] : 0.f;
             }
             wv::sched_fence();
 #pragma unroll
@@ -1822,9 +1823,10 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
         f32x4 Ud = zero4;
         float a[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float x = wv::lds_f32(base + LOFF_K + 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 16 * (k >> 2) + 4 * L.q + (k & 3)));
-            a[k] = L.r < NC ? x : 0.f;
+        for (int J = 0; J < 2; ++J) {        // four consecutive words of K's row r per lane and state tile: one 16-byte LDS read
+            const f32x4 x = wv::lds_f32x4(base + LOFF_K + 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 16 * J + 4 * L.q));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[4 * J + i] = L.r < NC ? x[i] : 0.f;
         }
         const unsigned qo = 16u * (unsigned)(L.q < 2 ? L.q : 0);
         const f32x4 ub = wv::lds_f32x4(rec + 288 + qo), kb = wv::lds_f32x4(rec + 448 + qo);
@@ -1878,8 +1880,11 @@ MPC_DEV void rollout_lean(const P &p, const Lane &L, const float *Kin, const flo
                 if (p.f) acc[Im] = wv::lds_f32x4(rec + 320 + 4u * (unsigned)(16 * Im + 4 * L.q));
                 const int row = 16 * Im + L.r;
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    fa[Im][k] = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
+                for (int J = 0; J < 2; ++J) {    // (rows of F are 160 B: every such quadruple is 16-byte aligned)
+                    const f32x4 x = wv::lds_f32x4(base + LOFF_F + 4u * (unsigned)(row * N + 16 * J + 4 * L.q));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[Im][4 * J + i] = x[i];
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h)        // the control columns as two full-k operands (uctl)
                     fa[Im][8 + h] = wv::lds_f32(base + LOFF_F + 4u * (unsigned)(row * N + 32 + uctl(L.q) + 2 * h));
@@ -2016,11 +2021,14 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
         float a[8], am[8], aq[2];
         const unsigned krow = 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 4 * L.q);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float x = wv::lds_f32(base + POFF_K + krow + 4u * (unsigned)(16 * (k >> 2) + (k & 3)));
-            const float y = wv::lds_f32(base + POFF_M + krow + 4u * (unsigned)(16 * (k >> 2) + (k & 3)));
-            a[k] = L.r < NC ? x : 0.f;
-            am[k] = L.r < NC ? y : 0.f;
+        for (int J = 0; J < 2; ++J) {        // (16-byte LDS reads: four consecutive words of row r of K, of M, per state tile)
+            const f32x4 x = wv::lds_f32x4(base + POFF_K + krow + 64u * (unsigned)J);
+            const f32x4 y = wv::lds_f32x4(base + POFF_M + krow + 64u * (unsigned)J);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[4 * J + i] = L.r < NC ? x[i] : 0.f;
+                am[4 * J + i] = L.r < NC ? y[i] : 0.f;
+            }
         }
         const bool uq = L.q < 2;
 #pragma unroll
@@ -2093,8 +2101,11 @@ MPC_DEV void rollout_priced(const P &p, const Lane &L, const float *Kin, const f
                 if (p.f) acc[Im] = wv::lds_f32x4(rec + 320 + 4u * (unsigned)(16 * Im + 4 * L.q));
                 const int row = 16 * Im + L.r;
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    fa[Im][k] = wv::lds_f32(base + POFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
+                for (int J = 0; J < 2; ++J) {    // (rows of F are 160 B: every such quadruple is 16-byte aligned)
+                    const f32x4 x = wv::lds_f32x4(base + POFF_F + 4u * (unsigned)(row * N + 16 * J + 4 * L.q));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[Im][4 * J + i] = x[i];
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h)        // the control columns as two full-k operands (uctl)
                     fa[Im][8 + h] = wv::lds_f32(base + POFF_F + 4u * (unsigned)(row * N + 32 + uctl(L.q) + 2 * h));
@@ -2337,9 +2348,10 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
         f32x4 Ud = zero4;
         float a[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float x = wv::lds_f32(base + KOFF_K + 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 16 * (k >> 2) + 4 * L.q + (k & 3)));
-            a[k] = L.r < NC ? x : 0.f;
+        for (int J = 0; J < 2; ++J) {        // four consecutive words of K's row r per lane and state tile: one 16-byte LDS read
+            const f32x4 x = wv::lds_f32x4(base + KOFF_K + 4u * (unsigned)((L.r < NC ? L.r : 0) * NS + 16 * J + 4 * L.q));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[4 * J + i] = L.r < NC ? x[i] : 0.f;
         }
         const unsigned qo = 16u * (unsigned)(L.q < 2 ? L.q : 0);
         const f32x4 kb = wv::lds_f32x4(rec + 448 + qo);
@@ -2350,8 +2362,11 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
         for (int Im = 0; Im < 2; ++Im) {
             const int row = 16 * Im + L.r;
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                fa[Im][k] = wv::lds_f32(base + KOFF_F + 4u * (unsigned)(row * N + 16 * (k >> 2) + 4 * L.q + (k & 3)));
+            for (int J = 0; J < 2; ++J) {    // (rows of F are 160 B: every such quadruple is 16-byte aligned)
+                const f32x4 x = wv::lds_f32x4(base + KOFF_F + 4u * (unsigned)(row * N + 16 * J + 4 * L.q));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[Im][4 * J + i] = x[i];
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h)        // the control columns as two full-k operands (uctl)
                 fa[Im][8 + h] = wv::lds_f32(base + KOFF_F + 4u * (unsigned)(row * N + 32 + uctl(L.q) + 2 * h));
