@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPC_LQR_ABI_VERSION 7
+#define MPC_LQR_ABI_VERSION 8
 
 enum { MPC_F32 = 0, MPC_F64 = 1 };
 enum { MPC_BOUND_NONE = 0, MPC_BOUND_SCALAR = 1, MPC_BOUND_TENSOR = 2 };
@@ -134,6 +134,19 @@ typedef struct mpc_lqr_options {
     int32_t flags;                    /* MPC_OPT_* bits (0 = none) */
     const mpc_env_dynamics *true_dynamics; /* NULL = LinDx(F,f) (mpc/lqr_step.py:216-222); else the rollout
                                               calls the simulator (:223-225) -- generic kernels only */
+    /* (ABI 8) A HINT for the box-constrained sweep: where the QP of timestep t, problem b starts, in the delta space of
+     * THIS call's nominal (the x_init argument of pnqp, mpc/pnqp.py:14-21; the kernel clamps it into the QP's box).  The
+     * reference starts every QP from the solution of timestep t+1 (mpc/lqr_step.py:137,141), which on a fresh nominal has
+     * the wrong free set in nine timesteps of ten: projected step, full Newton step, confirmation = ~3 trips.  The QP is
+     * strictly convex and the solve ends on a full Newton step on a confirmed free set, so the RESULT does not depend on the
+     * start (to the solve's own 1e-4 step tolerance, as in the reference); only the trip count does.  What a caller has:
+     * the k of an earlier step of the same nominal (out->k, or the gain record a fused kernel parks in `workspace`, see
+     * mpc_lqr_workspace_bytes -- the pointer may alias the workspace handed to the same call), or zeros from the second
+     * iteration of an iLQR solve on (the previous policy at the new nominal IS the new nominal: delta u = 0).
+     * [T,B,nc] reals of the problem's dtype through explicit ELEMENT strides of the T and B axes (0 = broadcast), the nc
+     * block contiguous and 16-byte aligned, strides multiples of 4 elements; NULL = the reference's start.  Honoured by the
+     * 12/4 and 32/8 fused kernels (impl 3, 5); every other kernel ignores it (same results). */
+    const void *qp_start; int64_t qp_start_st, qp_start_sb;
 } mpc_lqr_options;
 
 /* Outputs of LQRStepFn.forward (mpc/lqr_step.py:308-309) and LqrForOut (:17-20).
@@ -182,6 +195,13 @@ int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p);
  *     `workspace` (mpc_lqr_workspace_bytes, 16-byte aligned); out->K / out->k are optional there. */
 int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
                  void *workspace, int64_t workspace_bytes, int impl, void *stream);
+
+/* (ABI 8) Where mpc_lqr_step (this p, o, impl; out->K / out->k NULL; a workspace of mpc_lqr_workspace_bytes) leaves the
+ * solutions k_t of its sweep's box QPs inside `workspace`: byte offset of k[0][0][0] and the ELEMENT strides of its T and B
+ * axes -- the array a later call at the same nominal may pass as o->qp_start (workspace + offset; that later call may be
+ * handed the same workspace).  1 = filled; 0 = that step keeps no such array there (no bounds, float64, a kernel that
+ * ignores the hint: with out->k given, that is the array). */
+int mpc_lqr_qp_record(const mpc_lqr_problem *p, const mpc_lqr_options *o, int impl, int64_t *offset_bytes, int64_t *st, int64_t *sb);
 
 /* Does kernel `impl` (1 generic, 2 fused MFMA, 3 DPP, 4 lane-per-problem, 5 MFMA sweep, 6 wavefront-per-problem) accept this problem/options pair?  1 yes, 0 no. */
 int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, int impl);

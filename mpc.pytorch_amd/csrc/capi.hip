@@ -169,6 +169,10 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
 {
     StepParams<real> sp = make_params<real>(p, o, out);
     sp.old_costs_in = (const real *)old_costs_in;
+    // mpc_lqr_options.qp_start is a hint: an array the staging DMAs cannot fetch (16-byte granules) is ignored, not an error
+    if (sp.qp_start && (sp.bound_mode == MPC_BOUND_NONE || (uintptr_t)sp.qp_start % 16 || sp.qp_start_st % 4 || sp.qp_start_sb % 4 ||
+                        sp.qp_start_st < 0 || sp.qp_start_sb < 0 || sizeof(real) != 4))
+        sp.qp_start = nullptr;
     // the symmetry verdict travels in the status words: a caller that passes none gets them parked behind the workspace
     if (!sp.status && phase_mask == 3 && workspace) {
         const int64_t off = status_scratch_offset(p);
@@ -372,6 +376,33 @@ int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, i
         if (impl == 2) return mfma16_supported(sp) ? 1 : 0;
         // sizes only: the alignment of the actual tensors is checked at launch
         return (sp.ns == 12 && sp.nc == 4) ? 1 : 0;
+    }
+    return 0;
+}
+
+int mpc_lqr_qp_record(const mpc_lqr_problem *p, const mpc_lqr_options *o, int impl, int64_t *offset_bytes, int64_t *st, int64_t *sb)
+{
+    // mirrors the routing of step_impl for a box-constrained float32 step whose out->K / out->k are NULL
+    if (!p || !o || !offset_bytes || !st || !sb) return 0;
+    if (check_problem(p, false, false) != MPC_OK || check_options(p, o) != MPC_OK) return 0;
+    if (p->dtype != MPC_F32 || o->bound_mode == MPC_BOUND_NONE || o->true_dynamics || p->B == 0) return 0;
+    mpc_lqr_outputs out;
+    memset(&out, 0, sizeof(out));
+    const StepParams<float> sp = make_params<float>(p, o, &out);
+    const int64_t TB = (int64_t)p->T * p->B;
+    if ((impl == 0 || impl == 3) && p->ns == 12 && p->nc == 4) {
+        // the 12/4 kernel's gain record Kk[t][b][lane 0..15][4]: lane 12 holds k
+        *offset_bytes = 48 * 4; *st = (int64_t)p->B * 64; *sb = 64;
+        return 1;
+    }
+    if (impl == 0 && (tiny_supported(p->ns, p->nc) || mfma16_supported(sp))) return 0;
+    if ((impl == 0 || impl == 5) && p->ns == 32 && p->nc == 8) {
+        *offset_bytes = TB * 256 * 4; *st = (int64_t)p->B * 8; *sb = 8;       // K [T,B,8,32] | k [T,B,8]
+        return 1;
+    }
+    if ((impl == 0 || impl == 7) && mfma40_pad_supported(sp)) {
+        *offset_bytes = TB * 256 * 4; *st = (int64_t)p->B * 8; *sb = 8;       // the padded gains: K [T,B,8,32] | k [T,B,8] (entries >= n_ctrl zero)
+        return 1;
     }
     return 0;
 }

@@ -319,7 +319,7 @@ enum {
     // NSTAGE: slots of the sweep's staging ring (the DMA runs NSTAGE - 1 timesteps ahead).  4 in the product; the diagnostic
     // build -DMPC_DPP16_NSTAGE=2 halves the wave's LDS so that a CU holds eight waves (two per SIMD) instead of four.
     SC = 0, SF = 4096, SR = 7168, SG = 8192, STAGE_BYTES = 9216, NSTAGE = MPC_DPP16_NSTAGE, AHEAD = NSTAGE - 1,
-    R_c = 0, R_tau = 64, R_f = 128, R_lo = 192, R_hi = 208,
+    R_c = 0, R_tau = 64, R_f = 128, R_qs = 176, R_lo = 192, R_hi = 208,
     LDS_TOTAL = NSTAGE * STAGE_BYTES,
     DMA_SWEEP = 8       // 4 C + 3 F + 1 record
 };
@@ -449,7 +449,7 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B, bool cperm = true)
 // HBM -> LDS staging: lane l of DMA instruction k moves 16 B.
 //   C  : instruction k = problem slot k, granule l            (4 instructions)
 //   F  : granule G = 64 k + l of the 4 x 48 granules           (3 instructions)
-//   rec: problem slot l>>4, granule l&15: 0-3 c | 4-6 x | 7 u | 8-10 f | 12 lo | 13 hi
+//   rec: problem slot l>>4, granule l&15: 0-3 c | 4-6 x | 7 u | 8-10 f | 11 the QP's start (sweep, mode 2, when given) | 12 lo | 13 hi
 //   gains (rollout): problem slot l>>4, granule l&15 of the wave's own record Kk[t][b][16][4]
 // Every lane keeps RUNNING source pointers that step along the horizon (one 64-bit add per pointer and timestep;
 // t * stride + base per DMA cost three times that).  Every lane takes part in every instruction: a granule nobody
@@ -513,6 +513,10 @@ MPC_DEV void dma_seek(Dma &d, const P &p, const Lane &L, int wave)
             q = (const char *)(p.cur_u + pb * 4); st = 4 * B * 4;
         } else if (gi < 11) {
             if (want_f) { q = (const char *)(p.f + pb * p.f_sb + 4 * (gi - 8)); st = 4 * p.f_st; is_f = true; }
+        } else if (gi == 11) {
+            // (mpc_lqr_options.qp_start: strides may be 0 -- one block for the whole batch / horizon -- and the array may be
+            // the record this very sweep rewrites: stage t is fetched AHEAD timesteps before timestep t stores its own)
+            if (MPC_QP_START && MODE == 2 && !ROLL && p.qp_start) { q = (const char *)(p.qp_start + pb * p.qp_start_sb); st = 4 * p.qp_start_st; }
         } else if (gi == 12 || gi == 13) {
             if (want_b) { q = (const char *)((gi == 12 ? p.lo : p.hi) + pb * 4); st = 4 * B * 4; }
         }
@@ -671,6 +675,7 @@ struct SwStage {
     float Fc[12];
     float cj, tb;
     float lo[4], hi[4];     // bounds of the row's four controls (row-uniform)
+    float qs[4];            // the caller's start of this timestep's QP (row-uniform; read only when p.qp_start)
     unsigned zm;
 };
 
@@ -711,6 +716,11 @@ MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, uns
         } else {
 #pragma unroll
             for (int a = 0; a < 4; ++a) { s.lo[a] = p.lo_s; s.hi[a] = p.hi_s; }
+        }
+        if (MPC_QP_START && p.qp_start) {
+            const f32x4 z = wv::lds_f32x4(base + SR + L.p * 256 + R_qs);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s.qs[a] = z[a];
         }
     }
     s.zm = MODE == 1 ? zm : 0u;
@@ -825,7 +835,12 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
             lb[a] = fmaxf(s.lo[a] - ubar[a], -dlt);
             ub[a] = fminf(s.hi[a] - ubar[a], dlt);
         }
-        if (!st.warm) {
+        if (MPC_QP_START && p.qp_start) {
+            // the caller's start (mpc_lqr_options.qp_start): a hint -- the solve below ends on a confirmed free set whatever it is.
+            // (a NaN start would survive the clamp and poison the QP: such an entry falls back to the middle of the box's reach)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) kq[a] = (s.qs[a] == s.qs[a]) ? s.qs[a] : 0.f;
+        } else if (!st.warm) {
             // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
             ldl4<false>(f, S, valid, 0.f);
             float y[4];
@@ -1957,7 +1972,8 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
                 float gn = q - vn;
                 if (!last) wv::dot_bcast12(gn, gv, s1.Fc);
                 if (LONG) {
-                    wv::store_f32x4(gp, f32x4{K[0], K[1], K[2], K[3]});
+                    // (rows of a partial last wave repeat problem B-1: only the live row stores its record, like V, v, lambda below)
+                    if (L.live) wv::store_f32x4(gp, f32x4{K[0], K[1], K[2], K[3]});
                     gp -= B * 64;
                 } else {
                     gain_put(G, t, f32x4{K[0], K[1], K[2], K[3]});

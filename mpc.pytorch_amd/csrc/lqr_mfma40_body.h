@@ -1116,7 +1116,20 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             }
             const float qv = r8 ? qrow2 : 0.f;
             float xv = kprev_v;
-            if (!warm) {                                 // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
+            if (MPC_QP_START && p.qp_start) {
+                // the caller's start (mpc_lqr_options.qp_start; a hint: the solve ends on a confirmed free set whatever it is): eight
+                // wave-uniform words through the scalar path, like the tensor bounds.  (The array may be this kernel's own k of an
+                // earlier launch: timestep t's words are read here, before the store of this timestep's k further down.)
+                const float *qs = p.qp_start + (long)t * p.qp_start_st + (long)L.b * p.qp_start_sb;
+                float s8[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    if (PADK) s8[a] = a < p.nc ? uniform_f32(qs + (a < p.nc ? a : 0)) : 0.f;
+                    else s8[a] = uniform_f32(qs + a);
+                }
+                xv = r8 ? gather8(s8, L.r) : 0.f;
+                xv = (xv == xv) ? xv : 0.f;              // (a NaN would survive the clamp)
+            } else if (!warm) {                          // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
                 float colc[8], y[8];
 #pragma unroll
                 for (int a = 0; a < 8; ++a) colc[a] = col0[a];

@@ -5,6 +5,11 @@
 #include "../../include/mpc_lqr.h"
 #include "env_dynamics.h"
 
+// diagnostic builds (-DMPC_QP_START=0): the kernels without the mpc_lqr_options.qp_start branch, for A/B timing of the cold path
+#ifndef MPC_QP_START
+#define MPC_QP_START 1
+#endif
+
 namespace mpclqr {
 
 template <typename real>
@@ -24,6 +29,8 @@ struct StepParams {
     int on_dynamics;             // MPC_OPT_NOMINAL_ON_DYNAMICS: the nominal is known to obey the dynamics
     int sweep_only;              // MPC_OPT_SWEEP_ONLY: gains, nominal cost and QP counts, no rollout
     int c_symmetric;             // MPC_OPT_C_SYMMETRIC: the caller vouches for C = C' (no symmetry test in the fused kernels)
+    const real *qp_start;        // MODE 2 of the 12/4 and 32/8 kernels: where the box QP of (t, b) starts, [T,B,nc] through the two
+    long qp_start_st, qp_start_sb;   // element strides (mpc_lqr_options.qp_start); NULL = the reference's start (k of timestep t+1)
     const int *gate;             // generic kernel only: solve problem b iff gate[b] & MPC_ST_C_ASYMMETRIC (NULL = every problem)
     real *K_user, *k_user;       // padded 32/8 instantiation only: the caller's K [T,B,nc,ns] / k [T,B,nc] (K, k are then the
                                  // kernel's own padded gains [T,B,8,32] / [T,B,8] in the workspace); NULL = not asked for
@@ -66,6 +73,8 @@ inline StepParams<real> make_params(const mpc_lqr_problem *p, const mpc_lqr_opti
     s.on_dynamics = (o && (o->flags & MPC_OPT_NOMINAL_ON_DYNAMICS)) ? 1 : 0;
     s.sweep_only = (o && (o->flags & MPC_OPT_SWEEP_ONLY)) ? 1 : 0;
     s.c_symmetric = (o && (o->flags & MPC_OPT_C_SYMMETRIC)) ? 1 : 0;
+    s.qp_start = o ? (const real *)o->qp_start : nullptr;
+    s.qp_start_st = o ? o->qp_start_st : 0; s.qp_start_sb = o ? o->qp_start_sb : 0;
     s.gate = nullptr;
     s.K_user = nullptr; s.k_user = nullptr;
     s.new_x = out ? (real *)out->new_x : nullptr; s.new_u = out ? (real *)out->new_u : nullptr;

@@ -19,7 +19,7 @@ BOUND_NONE, BOUND_SCALAR, BOUND_TENSOR = 0, 1, 2
 ST_PNQP_UNCONVERGED, ST_NONFINITE, ST_NOMINAL_OFF_DYNAMICS, ST_C_ASYMMETRIC, ST_QUU_SINGULAR, ST_C_TESTED = 1, 2, 4, 8, 16, 32
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA16, IMPL_DPP16, IMPL_TINY, IMPL_MFMA40, IMPL_WAVE1, IMPL_MFMA40_PAD = 0, 1, 2, 3, 4, 5, 6, 7
 
-ABI_VERSION = 7      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
+ABI_VERSION = 8      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
 
 _vp, _i32, _i64, _f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 
@@ -42,7 +42,8 @@ class Options(ctypes.Structure):
     _fields_ = [("bound_mode", _i32), ("max_linesearch_iter", _i32), ("lo_s", _f64), ("hi_s", _f64),
                 ("lo", _vp), ("hi", _vp), ("zero_mask", _vp), ("delta_u", _f64),
                 ("linesearch_decay", _f64), ("pnqp_iter", _i32), ("flags", _i32),
-                ("true_dynamics", ctypes.POINTER(EnvDynamics))]
+                ("true_dynamics", ctypes.POINTER(EnvDynamics)),
+                ("qp_start", _vp), ("qp_start_st", _i64), ("qp_start_sb", _i64)]
 
 
 ENV_PENDULUM, ENV_PENDULUM_FULL, ENV_CARTPOLE = 1, 2, 3
@@ -183,7 +184,7 @@ class Outputs(ctypes.Structure):
 
 
 EXPORTS = ("mpc_lqr_abi_version", "mpc_lqr_build_info", "mpc_lqr_last_error", "mpc_lqr_workspace_bytes",
-           "mpc_lqr_step", "mpc_lqr_impl_supported", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_lqr_kkt_prepare",
+           "mpc_lqr_step", "mpc_lqr_impl_supported", "mpc_lqr_qp_record", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_lqr_kkt_prepare",
            "mpc_pnqp", "mpc_pnqp_lu", "mpc_traj_cost", "mpc_env_traj_cost", "mpc_env_linearize", "mpc_select_best",
            "mpc_mlp_workspace_bytes", "mpc_mlp_rollout", "mpc_mlp_linearize",
            "mpc_mlp_supported", "mpc_lqr_kkt_fused_supported", "mpc_lqr_kkt_fused_workspace_bytes", "mpc_lqr_kkt_fused")
@@ -219,6 +220,7 @@ def load():
     PP, OP, UP = ctypes.POINTER(Problem), ctypes.POINTER(Options), ctypes.POINTER(Outputs)
     L.mpc_lqr_step.argtypes = [PP, OP, UP, _vp, _i64, ctypes.c_int, _vp]
     L.mpc_lqr_impl_supported.argtypes = [PP, OP, ctypes.c_int]
+    L.mpc_lqr_qp_record.argtypes = [PP, OP, ctypes.c_int] + [ctypes.POINTER(_i64)] * 3
     L.mpc_lqr_sweep.argtypes = [PP, OP, UP, _vp]
     L.mpc_lqr_rollout.argtypes = [PP, OP, UP, _vp, _vp]
     L.mpc_lqr_kkt_grads.argtypes = [PP] + [_vp] * 10
@@ -303,8 +305,11 @@ class StepOptions:
 
     def __init__(self, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None, linesearch_decay=0.2,
                  max_linesearch_iter=10, pnqp_iter=20, true_dynamics=None, nominal_on_dynamics=False, sweep_only=False,
-                 c_symmetric=False):
+                 c_symmetric=False, qp_start=None):
         assert (u_lower is None) == (u_upper is None)
+        # mpc_lqr_options.qp_start: a [T,B,nc] tensor (any T / B strides, stride-0 views included; last axis contiguous) the box
+        # QPs of the sweep start from, in the delta space of this call's nominal -- a hint: results do not depend on it
+        self.qp_start = qp_start
         # the caller guarantees C_t = C_t' (MPC_OPT_C_SYMMETRIC): mpc.MPC does from its second iteration on, once the first
         # step of the solve has reported no MPC_ST_C_ASYMMETRIC; a bare LQRStep never does
         self.c_symmetric = bool(c_symmetric)
@@ -349,6 +354,14 @@ class StepOptions:
             e, prm = self.true_dynamics.to_struct(like)
             keep += [e, prm]
             o.true_dynamics = ctypes.pointer(e)
+        if self.qp_start is not None and lo is not None:
+            q = self.qp_start
+            if tuple(q.shape) != (T, B, nc) or q.dtype != like.dtype or q.device != like.device:
+                raise ValueError("qp_start must be a [T,B,n_ctrl] tensor of the problem's dtype and device")
+            if nc > 1 and q.stride(2) != 1:
+                q = q.contiguous()
+            keep.append(q)
+            o.qp_start, o.qp_start_st, o.qp_start_sb = q.data_ptr(), q.stride(0), q.stride(1)
         return o, keep
 
 
@@ -501,6 +514,20 @@ class HipBackend:
         run._keep = (p, o, out, keep, ws)
         run._bind = (nbytes, impl, dev)
         return run
+
+    @staticmethod
+    def qp_record(plan):
+        """The solutions k_t [T,B,n_ctrl] of the box QPs of `plan`'s sweep, as a strided VIEW of the plan's workspace
+        (mpc_lqr_qp_record): what a later step at the same nominal passes as StepOptions(qp_start=...) -- that step may be
+        a variant of `plan` on the very same workspace (it reads timestep t's block before it stores its own).  None when the
+        step keeps no such record (no bounds, float64, a kernel without the hint)."""
+        p, o, _out, _keep, ws = plan._keep
+        _nbytes, impl, _dev = plan._bind
+        off, st, sb = _i64(0), _i64(0), _i64(0)
+        if not load().mpc_lqr_qp_record(ctypes.byref(p), ctypes.byref(o), int(impl), ctypes.byref(off), ctypes.byref(st), ctypes.byref(sb)):
+            return None
+        flat = ws[off.value:].view(torch.float32)
+        return flat.as_strided((p.T, p.B, p.nc), (st.value, sb.value, 1))
 
     def plan_variant(self, plan, opts=None, cur_x=None, cur_u=None, out_x=None, out_u=None):
         """A second plan over the SAME problem tensors as `plan`, differing in the nominal it reads (`cur_x`, `cur_u`), the

@@ -7,6 +7,7 @@ reference does with a Python loop over the batch (best-iterate copy, `max(full_d
 mpc/mpc.py:279-285, 299) is the `mpc_select_best` kernel, so one iLQR iteration costs two launches
 and ONE small device->host read.
 """
+import collections
 from collections import namedtuple
 from enum import Enum
 
@@ -47,7 +48,8 @@ def _any_requires_grad(obj):
     return False
 
 
-_PINNED = {}
+_PINNED = collections.OrderedDict()     # (device, stream, host thread) -> [pinned block, its int32 view, tag counter]; LRU, see _FlagReader
+_PINNED_MAX = 64                         # a thread-per-request server would otherwise page-lock a block per thread for ever
 
 
 class _FlagReader:
@@ -74,10 +76,15 @@ class _FlagReader:
             # ADVICE r03; within a thread solves are sequential, the tag counter tells their select calls apart)
             import threading
             key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
-            if key not in _PINNED:
+            slot = _PINNED.get(key)
+            if slot is None:
                 blk = torch.zeros(16, dtype=torch.uint8).pin_memory()
-                _PINNED[key] = [blk, blk.numpy().view("int32"), 0]
-            self._slot = _PINNED[key]
+                slot = _PINNED[key] = [blk, blk.numpy().view("int32"), 0]
+                while len(_PINNED) > _PINNED_MAX:          # least recently used out; a reader still holding its slot keeps it alive
+                    _PINNED.popitem(last=False)
+            else:
+                _PINNED.move_to_end(key)
+            self._slot = slot
             self._host = self._slot[0]
             self.host = (self._host[0:4].view(torch.int32), self._host[8:8 + self.device_flags[1].element_size()].view(dtype))
             if not self.direct:

@@ -181,9 +181,11 @@ def mpc_forward_sharded(ctrl, x_init, cost, dx, group=None, lockstep=False, gath
         if n_batch is None:
             raise ValueError("mpc_forward_sharded(presharded=True) needs n_batch, the size of the whole batch")
         B = int(n_batch)
+        if B < world:
+            # EVERY rank can see this and raises: were it only the ranks whose block is empty, the others would go on into the
+            # lock-step all-reduce and the all-gather and wait there for ever
+            raise ValueError("mpc_forward_sharded: n_batch %d < world %d leaves rank(s) without a problem to solve" % (B, world))
         lo, hi = _block_of(x_init.shape[0], B, rank, world, "mpc_forward_sharded")
-        if hi == lo:
-            raise ValueError("mpc_forward_sharded: rank %d has no problem to solve (n_batch %d < world %d)" % (rank, B, world))
     else:
         B = x_init.shape[0]
         lo, hi = shard_bounds(B, rank, world)

@@ -84,7 +84,7 @@ def _ptr(a):
 
 def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zero_I=None, delta_u=None,
              linesearch_decay=0.2, max_linesearch_iter=10, pnqp_iter=20, force_general=False, dma_late=False,
-             kernel="mfma16", dtype=np.float32, env=None, nominal_on_dynamics=False, c_symmetric=False):
+             kernel="mfma16", dtype=np.float32, env=None, nominal_on_dynamics=False, c_symmetric=False, qp_start=None):
     """Same signature as oracle.lqr_oracle.lqr_step.  Returns the kernel's outputs.  The fused
     kernels are float32; kernel="tiny" (lane-per-problem body, n_ctrl = 1) also runs in float64 and
     takes env = (kind, params, dt, u_max): a shipped simulator as the rollout's true dynamics."""
@@ -128,6 +128,16 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
         zm = np.ascontiguousarray((np.asarray(u_zero_I) != 0).astype(np.uint8))
         keep.append(zm)
         o.zero_mask = _ptr(zm)
+    if qp_start is not None:
+        # mpc_lqr_options.qp_start: any array that broadcasts to [T,B,nc]; element strides of the T and B axes (0 where broadcast)
+        qs = np.asarray(qp_start, f32)
+        full = np.broadcast_to(qs, (T, B, nc))
+        if full.strides[2] not in (4, 0) or any(st % 16 for st in full.strides[:2]):
+            full = np.ascontiguousarray(full)
+        if full.strides[2] == 0:
+            full = np.ascontiguousarray(full)
+        keep.append(full); keep.append(qs)
+        o.qp_start, o.qp_start_st, o.qp_start_sb = full.ctypes.data, full.strides[0] // 4, full.strides[1] // 4
     res = dict(new_x=np.full((T, B, ns), np.nan, f32), new_u=np.full((T, B, nc), np.nan, f32),
                costs=np.empty(B, f32), old_costs=np.empty(B, f32), full_du_norm=np.empty(B, f32),
                alpha_du_norm=np.empty(B, f32), alphas=np.empty(B, f32),

@@ -101,18 +101,47 @@ def test_extra_rows_certify_themselves_box_constrained_step_and_backward():
     r = {k: torch.from_numpy(o[k].astype(np.float32)) for k in ("new_x", "new_u", "costs", "alphas")}
     good = bench.parity_check(p, r, True, n=bench.PARITY_ROW)
     assert good["ok"] and good["problems"] == 32 and good["active_set_ties"] == 0 and good["line_search_ties"] == 0
-    # ONE problem off (a flip of an active set looks like this) is counted, three are a failure
+
+    class SecondSolve:
+        """stands in for the HIP library's second solve of the problems in question (gains written out)"""
+        def __init__(self, flip):
+            self.flip, self.calls = flip, 0
+
+        def lqr_step(self, x_init, C, c, F, f, cur_x, cur_u, opts, want_gains=False, **kw):
+            assert want_gains and opts.u_lower == -1.0 and opts.u_upper == 1.0
+            self.calls += 1
+            oo = O.lqr_step(*(t.numpy().astype(np.float64) for t in (x_init, C, c, F, f, cur_x, cur_u)), -1.0, 1.0, lockstep=False, return_gains=True)
+            K = oo["K"].astype(np.float32)
+            if self.flip:          # the kernel's float32 run clamped a control the float64 run left free (or the other way round)
+                free = np.argwhere(~(K == 0).all(axis=-1))[0]
+                K[free[0], :, free[2]] = 0.0
+            return {"K": torch.from_numpy(K)}
+    # (round 5, ADVICE r04) ONE problem off: excused as an active-set tie only when CONFIRMED -- a second solve of that problem
+    # with the gains written out must clamp a different set of controls than the float64 run somewhere on the horizon
     r["new_u"][2, 4, 0] += 0.05
-    one = bench.parity_check(p, r, True, n=bench.PARITY_ROW)
-    assert one["ok"] and one["active_set_ties"] == 1
+    assert not bench.parity_check(p, r, True, n=bench.PARITY_ROW)["ok"]                        # nobody to confirm it: a failure
+    same_sets = SecondSolve(flip=False)
+    one = bench.parity_check(p, r, True, n=bench.PARITY_ROW, be=same_sets)
+    assert not one["ok"] and one["out_of_tolerance_unexplained"] == 1 and one["active_set_ties"] == 0 and same_sets.calls == 1
+    other_sets = SecondSolve(flip=True)
+    one = bench.parity_check(p, r, True, n=bench.PARITY_ROW, be=other_sets)
+    assert one["ok"] and one["active_set_ties"] == 1 and one["out_of_tolerance_unexplained"] == 0
+    # ... three confirmed ties are still a failure
     for b in (7, 9):
         r["new_u"][2, b, 0] += 0.05
-    assert not bench.parity_check(p, r, True, n=bench.PARITY_ROW)["ok"]
-    # ... and a problem that is off AND worse than the nominal is no tie at all
+    three = bench.parity_check(p, r, True, n=bench.PARITY_ROW, be=SecondSolve(flip=True))
+    assert not three["ok"] and three["active_set_ties"] == 3
+    # ... and a confirmed tie that is off AND worse than the nominal is no tie at all
     r = {k: torch.from_numpy(o[k].astype(np.float32)) for k in ("new_x", "new_u", "costs", "alphas")}
     r["new_u"][2, 4, 0] += 0.05
     r["costs"][4] = float(o["old_costs"][4]) + 10.0
-    assert not bench.parity_check(p, r, True, n=bench.PARITY_ROW)["ok"]
+    assert not bench.parity_check(p, r, True, n=bench.PARITY_ROW, be=SecondSolve(flip=True))["ok"]
+    # slices of one batch: the worst of them decides
+    r = {k: torch.from_numpy(o[k].astype(np.float32)) for k in ("new_x", "new_u", "costs", "alphas")}
+    sl = bench.parity_slices(p, r, True, [(0, 8), (16, 8), (32, 8)])
+    assert sl["ok"] and sl["problems"] == 24 and [d["first_problem"] for d in sl["slices"]] == [0, 16, 32]
+    r["new_u"][1, 35, 2] += 0.05
+    assert not bench.parity_slices(p, r, True, [(0, 8), (16, 8), (32, 8)])["ok"]
     # the backward
     nx, nu = torch.from_numpy(o["new_x"].astype(np.float32)), torch.from_numpy(o["new_u"].astype(np.float32))
     g = torch.Generator().manual_seed(1)

@@ -1133,3 +1133,56 @@ def test_emulated_padded_mfma40_line_search_and_off_dynamics_nominal(emu, kernel
         assert ((r2["status"] & 4) != 0).tolist() == [False, True, False]
         np.testing.assert_allclose(r2["new_u"], o2["new_u"], rtol=1e-3, atol=1e-4)
         np.testing.assert_allclose(r2["costs"], o2["costs"], rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# mpc_lqr_options.qp_start (ABI 8): the caller's start of every box QP of the sweep -- a hint
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", ["dpp16", "dpp16_ring2", "mfma40", "mfma40_ring2", "mfma40_pad4", "mfma40_pad16"])
+def test_qp_start_is_a_hint_results_do_not_depend_on_it(emu, kernel):
+    """The box QPs of the sweep started (a) from the k an earlier step at the same nominal found, (b) from zeros broadcast
+    with stride 0, (c) from garbage (far outside the box, NaN, inf): the step's results are the cold step's and the
+    oracle's (mpc/pnqp.py:5-82 is strictly convex -- its answer is the minimiser whatever x_init is, :14-21), and (a) pays
+    ONE factorisation per QP where the reference's start (k of timestep t+1, mpc/lqr_step.py:137,141) pays two or three."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(77)
+    if kernel.startswith("dpp16"):
+        T, B, ns, nc = 9, 6, 12, 4
+        pr = _ns_problem(rng, T, B)
+    else:
+        ns, nc = {"mfma40_pad4": (13, 4), "mfma40_pad16": (24, 8)}.get(kernel, (32, 8))
+        T, B = 5, 3
+        kw5 = _cfg5_problem(rng, T, B) if (ns, nc) == (32, 8) else _pad_problem(rng, ns, nc, T, B)
+        pr = {k: kw5[k] for k in ("C", "c", "F", "f", "x_init")}
+    cur_u = np.clip(0.5 * rng.standard_normal((T, B, nc)), -0.4, 0.4)
+    cur_x, _ = O.traj_cost(pr["x_init"], cur_u, pr["F"], pr["f"])
+    kw = dict(cur_x=cur_x, cur_u=cur_u, u_lower=-0.4, u_upper=0.4, **pr)
+    o = O.lqr_step(lockstep=False, **kw)
+    import ctypes
+    lib = emu.lib_pad(4) if "pad4" in kernel else (emu.lib_pad(16) if "pad16" in kernel else (emu.lib_ring2() if "ring2" in kernel else emu.lib()))
+    stats = (ctypes.c_long * 16).in_dll(lib, "emu_stats")
+
+    def run(**more):
+        for i in range(16):
+            stats[i] = 0
+        r = emu.lqr_step(kernel=kernel, dma_late=True, nominal_on_dynamics=True, c_symmetric=True, **kw, **more)
+        return r, list(stats)
+    cold, s_cold = run()
+    assert (cold["qp_iters"] > 0).all()
+    warm, s_warm = run(qp_start=cold["k"])
+    zeros, _ = run(qp_start=np.zeros(nc))                            # stride 0 over T and B
+    junk = rng.standard_normal((T, B, nc)) * 50.0
+    junk[0, 0, 0], junk[1, 1, 1], junk[2, 2, 2] = np.nan, np.inf, -np.inf
+    wild, _ = run(qp_start=junk)
+    for r in (cold, warm, zeros, wild):
+        assert (r["status"] & 3 == 0).all()
+        np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+        np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=1e-3, atol=2e-4 * (1 + np.abs(o["new_x"]).max()))
+        np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-4, atol=1e-3)
+    # started at its own solution every QP stops in its first trip: 1 + 0 iterations per timestep (mpc/lqr_step.py:140)
+    assert (warm["qp_iters"] == T).all(), warm["qp_iters"]
+    assert warm["qp_iters"].sum() < cold["qp_iters"].sum()
+    if kernel.startswith("dpp16"):
+        # (emu_stats 1 / 6: factorisations of live rows / wave-level trips that factorise)
+        assert s_warm[1] == 4 * ((B + 3) // 4) * T and s_warm[1] < s_cold[1] and s_warm[6] < s_cold[6]

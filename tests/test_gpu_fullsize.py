@@ -496,3 +496,57 @@ def test_headline_kernel_long_horizons_vs_oracle(be, ring, T, mode, monkeypatch)
                              StepOptions(nominal_on_dynamics=vouch), impl=IMPL_DPP16)
             sync()
             assert torch.equal(r2["new_u"], r["new_u"]) and torch.equal(r2["new_x"], r["new_x"])
+
+
+# ------------------------------------------------------------------------------------------------
+# (h) mpc_lqr_options.qp_start (ABI 8): the box QPs of a step started from an earlier step's solutions
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ns,nc,T,B,ring", [(12, 4, 50, 4099, "4"), (12, 4, 50, 4099, "2"), (12, 4, 70, 516, ""), (32, 8, 64, 1030, "3"),
+                                            (32, 8, 64, 1030, "2"), (13, 4, 20, 260, ""), (24, 8, 20, 260, "")])
+def test_qp_start_from_the_workspace_record_vs_oracle(be, ns, nc, T, B, ring, monkeypatch):
+    """A box-constrained step, then the SAME step again with its QPs started from the k the first one left in the workspace
+    (mpc_lqr_qp_record: a strided view, aliased by the second call's own record), then from garbage: all three are the float64
+    oracle's step entry by entry (the start is the x_init of mpc/pnqp.py:14-21 -- a strictly convex QP's answer does not depend
+    on it), and the restarted one reports 1 + 0 iterations per QP (mpc/lqr_step.py:140) where the first paid two or three."""
+    if DRY:
+        pytest.skip("needs the kernels' workspace record")
+    if ring:
+        monkeypatch.setenv("MPC_DPP16_RING" if ns == 12 else "MPC_MFMA40_RING", ring)
+    import bench
+    from mpc._native import StepOptions
+    from oracle import lqr_oracle as O
+    B = full_batch(B)
+    p = bench.make_problem(ns, nc, T, B, torch.float32, DEV, seed=31 + ns, u_scale=0.3, clamp=1.0)
+    h = {k: h64(v) for k, v in p.items()}
+    o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], -1.0, 1.0, lockstep=False,
+                   nthreads=O.max_threads(), return_gains=True)
+    base = dict(u_lower=-1.0, u_upper=1.0, nominal_on_dynamics=True, c_symmetric=True)
+    cold = be.plan_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions(**base))
+    rec = be.qp_record(cold)
+    assert rec is not None and tuple(rec.shape) == (T, B, nc)
+    r0 = {k: v.clone() for k, v in cold().items()}
+    sync()
+    ties = strict_step_check("qp_start_cold_%d_%d_%s" % (ns, nc, ring), r0, o, B, have_gains=False)
+    np.testing.assert_allclose(host(rec)[:, ~ties], o["k"][:, ~ties], rtol=2e-3, atol=2e-4)      # the record IS the sweep's k
+    warm = be.plan_variant(cold, opts=StepOptions(qp_start=rec, **base))
+    r1 = {k: v.clone() for k, v in warm().items()}
+    sync()
+    strict_step_check("qp_start_warm_%d_%d_%s" % (ns, nc, ring), r1, o, B, have_gains=False)
+    it0, it1 = host(r0["qp_iters"]), host(r1["qp_iters"])
+    assert (it1 == T).all(), (it1.min(), it1.max())
+    assert it0.mean() > 1.5 * T
+    # the restarted step is the first one again (same free sets, same final Newton systems)
+    np.testing.assert_allclose(host(r1["new_u"]), host(r0["new_u"]), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(host(r1["costs"]), host(r0["costs"]), rtol=1e-5)
+    # ... and a second restart from the record the first restart rewrote in place
+    r2 = {k: v.clone() for k, v in warm().items()}
+    sync()
+    assert (host(r2["qp_iters"]) == T).all()
+    np.testing.assert_allclose(host(r2["new_u"]), host(r0["new_u"]), rtol=1e-4, atol=2e-5)
+    g = torch.Generator().manual_seed(5)
+    junk = (40.0 * torch.randn(T, B, nc, generator=g)).to(DEV)
+    junk[0, 0, 0], junk[1, B - 1, 1], junk[T - 1, B // 2, nc - 1] = float("nan"), float("inf"), -float("inf")
+    wild = be.plan_variant(cold, opts=StepOptions(qp_start=junk, **base))
+    r3 = {k: v.clone() for k, v in wild().items()}
+    sync()
+    strict_step_check("qp_start_wild_%d_%d_%s" % (ns, nc, ring), r3, o, B, have_gains=False)

@@ -43,14 +43,14 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert set(_native.EXPORTS) == declared
-    assert L.mpc_lqr_abi_version() == _native.ABI_VERSION == 7
+    assert L.mpc_lqr_abi_version() == _native.ABI_VERSION == 8
     assert b"gfx950" in L.mpc_lqr_build_info()
 
 
 def test_struct_layout_matches_header():
     # sizeof checks guard the ctypes mirror against drift from include/mpc_lqr.h
     assert ctypes.sizeof(_native.Problem) == 6 * 4 + 8 + 4 * (8 + 16) + 16
-    assert ctypes.sizeof(_native.Options) == 8 + 16 + 24 + 16 + 8 + 8
+    assert ctypes.sizeof(_native.Options) == 8 + 16 + 24 + 16 + 8 + 8 + 24      # (+ qp_start and its two strides: ABI 8)
     assert ctypes.sizeof(_native.EnvDynamics) == 8 + 8 + 16
     assert ctypes.sizeof(_native.Outputs) == 11 * 8
     assert ctypes.sizeof(_native.MlpDynamics) == 4 * 4 + 5 * 4 + 4 + 4 * 8 + 4 * 8       # 9 ints + padding to 8
@@ -575,9 +575,9 @@ def test_pnqp_mirror(oracle_backend, capsys):
     np.testing.assert_allclose(x.numpy(), z["x_pp"], atol=1e-10)
     assert isinstance(fac, tuple) and len(fac) == 2 and n_it == int(z["iters_pp"].max())
     assert np.array_equal(If.numpy(), z["If_pp"])
-    # the iteration count is read from the device only when it is looked at; it then behaves like the int it is
-    assert n_it + 1 == int(z["iters_pp"].max()) + 1 and "%d" % n_it == str(int(n_it)) == "{}".format(n_it)
-    assert len(range(n_it)) == int(n_it)
+    # the iteration count: a 1-element CPU tensor (as n_total_qp_iter of LQRStep), read from the device only when looked at
+    assert n_it + 1 == int(z["iters_pp"].max()) + 1 and "%d" % n_it == str(int(n_it)) and n_it.shape == (1,)
+    assert len(range(int(n_it))) == int(n_it)
     # (LU, pivots) solve H_ like the reference's H_lu_ does (mpc/pnqp.py:53-54)
     rhs = torch.ones(fac[0].shape[0], fac[0].shape[1], 1, dtype=fac[0].dtype)
     sol = torch.linalg.lu_solve(fac[0], fac[1], rhs)
@@ -745,11 +745,24 @@ def test_async_host_scalar_waits_wherever_it_is_buried_and_leaves_its_ring_slot(
     assert float(n) == 9.0 and n.item() == 9.0 and ev.waits == 1
 
 
-def test_lazy_iter_count_quacks_like_an_int():
-    from mpc.pnqp import _LazyIterCount
-    n = _LazyIterCount(torch.tensor([3, 7, 5]), torch.tensor([0, 0, 0]))
-    assert n / 2 == 3.5 and n // 2 == 3 and n % 4 == 3 and n ** 2 == 49 and abs(n) == 7 and divmod(n, 4) == (1, 3)
-    assert 14 / n == 2 and 15 // n == 2 and 2 ** n == 128 and n.bit_length() == 3 and list(range(n))[-1] == 6
+def test_pnqp_iteration_count_is_a_host_scalar_that_warns_when_read(capsys):
+    """mpc.pnqp's 4th return value (the reference's `i`, mpc/pnqp.py:59, 82): a 1-element CPU tensor like n_total_qp_iter;
+    the "Did not converge" warning (:81) rides on the same host read -- at once for CPU tensors, at the first look otherwise."""
+    from mpc.pnqp import _iteration_count
+    from mpc.lqr_step import _AsyncHostScalar
+    n = _iteration_count(torch.tensor([3, 7, 5]), torch.tensor([0, 0, 0]))
+    assert int(n) == 7 and n / 2 == 3.5 and float(n + 1) == 8.0 and list(range(int(n)))[-1] == 6
+    assert "Did not converge" not in capsys.readouterr().out
+    _iteration_count(torch.tensor([19]), torch.tensor([1]))
+    assert "pnqp warning: Did not converge" in capsys.readouterr().out
+
+    class Ev:
+        def synchronize(self):
+            pass
+    late = _AsyncHostScalar(torch.full((1,), 4.0), Ev())
+    seen = []
+    late._on_settle = lambda: seen.append(1)
+    assert seen == [] and float(late) == 4.0 and seen == [1] and float(late * 2) == 8.0 and seen == [1]
 
 
 def test_network_kernels_are_offered_only_what_they_take(monkeypatch):

@@ -5,7 +5,8 @@ round-3 summaries mixed sweep-only, vouched and bare calls of one kernel in one 
 
     python tools/prof_one.py KIND [reps [warm]]
     KIND: headline | headline_bare | bounded | kkt | kkt_bounded | cfg5 | cfg5_bare | cfg5_bounded | cfg5_kkt | cfg5_kkt_bounded |
-          cfg5_B8192 | cfg5_bounded_B8192
+          cfg5_B8192 | cfg5_bounded_B8192 | bounded_warm | cfg5_bounded_warm   (_warm: the box QPs started from the k an earlier
+          step at the same nominal left in the workspace, mpc_lqr_options.qp_start)
 The problems are bench.py's (same seeds, same options as the rows of its `extra` object)."""
 import os
 import sys
@@ -25,8 +26,9 @@ dev = "cuda:0"
 cfg5 = kind.startswith("cfg5")
 bounded = "bounded" in kind
 bare = kind.endswith("_bare")
+kind_b = kind[:-5] if kind.endswith("_warm") else kind
 ns, nc, T = (32, 8, 64) if cfg5 else (12, 4, 50)
-B = 8192 if kind.endswith("B8192") else (1024 if cfg5 else 4096)
+B = 8192 if kind_b.endswith("B8192") else (1024 if cfg5 else 4096)
 B = int(os.environ.get("PROF_ONE_B", B))          # (another batch for the same kind of call)
 if cfg5:
     p = bench.make_problem(ns, nc, T, B, torch.float32, dev, seed=9, on_device=True)
@@ -44,6 +46,13 @@ if "kkt" in kind:
     fn = be.plan_kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, ko)
 else:
     fn = be.plan_step(*a, opts)
+    if kind.endswith("_warm"):
+        fn()                                        # the cold step leaves its k in the workspace
+        import copy
+        ow = copy.copy(opts)
+        ow.qp_start = be.qp_record(fn)
+        assert ow.qp_start is not None
+        fn = be.plan_variant(fn, opts=ow)
 if os.environ.get("PROF_ONE_TRACE"):
     # the launch-by-launch picture: ms per launch over consecutive groups of 20 launches from a GPU that has just idled through
     # the problem's set-up (boost clocks -> the power controller's dip -> the sustained state)
