@@ -749,7 +749,9 @@ def extra_rows(be, dev, steps):
                                                 note="whole MPC.forward on the network: per iteration get_traj + linearisation + sweep + "
                                                      "line-searched rollout kernels; the module called timestep by timestep (this package's "
                                                      "fallback, the reference's only path) takes ~450 ms (tools/nn_bench.py)"),
-                                           lambda: solve_parity(mk_nn, p["x_init"], (p["C"], p["c"]), dyn, out_nn))
+                                           # (x, u at 2e-2 like the simulator rows: float32 and float64 runs of a 5-iteration solve end 1e-2 apart in u with
+                                           # costs equal to 3e-7 -- a flat optimum; the costs are the tight figure)
+                                           lambda: solve_parity(mk_nn, p["x_init"], (p["C"], p["c"]), dyn, out_nn, rtol=2e-2, atol=2e-2))
     return rows
 
 

