@@ -171,7 +171,7 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
     sp.old_costs_in = (const real *)old_costs_in;
     // mpc_lqr_options.qp_start is a hint: an array the staging DMAs cannot fetch (16-byte granules) is ignored, not an error
     if (sp.qp_start && (sp.bound_mode == MPC_BOUND_NONE || (uintptr_t)sp.qp_start % 16 || sp.qp_start_st % 4 || sp.qp_start_sb % 4 ||
-                        sp.qp_start_st < 0 || sp.qp_start_sb < 0 || sizeof(real) != 4))
+                        sp.qp_start_st < 0 || sp.qp_start_sb < 0 || sp.qp_start_st * 4 >= (1ll << 32) || sizeof(real) != 4))
         sp.qp_start = nullptr;
     // the symmetry verdict travels in the status words: a caller that passes none gets them parked behind the workspace
     if (!sp.status && phase_mask == 3 && workspace) {

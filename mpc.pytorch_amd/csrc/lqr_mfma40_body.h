@@ -348,6 +348,13 @@ MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L, const KktArgs40 *
         d.r_ptr = (const char *)(p.f + b * p.f_sb) + 16 * (L.lane - 20);
         d.r_step = (unsigned)(p.f_st * 4);
     }
+    if (MPC_QP_START && !kk && p.qp_start && p.bound_mode != MPC_BOUND_NONE && (L.lane == 28 || L.lane == 29)) {
+        // mpc_lqr_options.qp_start: the caller's start of timestep t's box QP rides in the record, lanes 28..29 -> bytes 448..479
+        // (the array may be the k this very sweep rewrites: stage t is fetched at least one timestep before timestep t stores its own)
+        d.r_active = true;
+        d.r_ptr = (const char *)(p.qp_start + b * p.qp_start_sb) + 16 * (L.lane - 28);
+        d.r_step = (unsigned)(p.qp_start_st * 4);
+    }
     if (kk) {
         // the fused backward: lanes 0..7 dl_dx_t, 8..9 dl_du_t (negated where they are read), 10..19 tau*_t as above,
         // 20..27 c_t[0..31] of the ORIGINAL problem (lambda's constant term)
@@ -1117,17 +1124,21 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             const float qv = r8 ? qrow2 : 0.f;
             float xv = kprev_v;
             if (MPC_QP_START && p.qp_start) {
-                // the caller's start (mpc_lqr_options.qp_start; a hint: the solve ends on a confirmed free set whatever it is): eight
-                // wave-uniform words through the scalar path, like the tensor bounds.  (The array may be this kernel's own k of an
-                // earlier launch: timestep t's words are read here, before the store of this timestep's k further down.)
-                const float *qs = p.qp_start + (long)t * p.qp_start_st + (long)L.b * p.qp_start_sb;
-                float s8[8];
+                // the caller's start (mpc_lqr_options.qp_start; a hint: the solve ends on a confirmed free set whatever it is).
+                // (The array may be this kernel's own k of an earlier launch: timestep t's block was fetched before this timestep's
+                // store further down.)
+                if (PADK) {
+                    // eight wave-uniform words through the scalar path, like the tensor bounds
+                    const float *qs = p.qp_start + (long)t * p.qp_start_st + (long)L.b * p.qp_start_sb;
+                    float s8[8];
 #pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    if (PADK) s8[a] = a < p.nc ? uniform_f32(qs + (a < p.nc ? a : 0)) : 0.f;
-                    else s8[a] = uniform_f32(qs + a);
+                    for (int a = 0; a < 8; ++a) s8[a] = a < p.nc ? uniform_f32(qs + (a < p.nc ? a : 0)) : 0.f;
+                    xv = r8 ? gather8(s8, L.r) : 0.f;
+                } else {
+                    // it rode in with the record (stream_init: lanes 28..29), entry r in lane (q, r) like the nominal control
+                    xv = wv::lds_f32(base + OFF_R + 448 + 4u * (unsigned)(r8 ? L.r : 0));
+                    xv = r8 ? xv : 0.f;
                 }
-                xv = r8 ? gather8(s8, L.r) : 0.f;
                 xv = (xv == xv) ? xv : 0.f;              // (a NaN would survive the clamp)
             } else if (!warm) {                          // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
                 float colc[8], y[8];

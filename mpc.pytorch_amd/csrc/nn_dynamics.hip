@@ -158,6 +158,18 @@ template <bool WL> __device__ __forceinline__ const float *stage_weights(const M
     return wl;
 }
 
+// One row's share of J_t(tau') - J_t(tau_nominal) for the stage cost 0.5 tau'C tau + c'tau (mpc/lqr_step.py:230-232), any C:
+//     0.5 tau''C tau' - 0.5 tb'C tb = 0.5 [ d'(C tau') + tb'(C d) ],   d = tau' - tb,
+// from the row products s = (C tau')_i, s2 = (C d)_i, this row's tau'_i, d_i and c_i.  Round 5: the line search's test
+// "did the cost get worse" (:176-179) was the comparison of two float32 sums of ~1e4 whose difference, from the third iLQR
+// iteration on, is below their rounding (1e-2): a coin per trial and problem, and the unluckiest of the 16 problems of the
+// unluckiest wavefront ran all ten trials -- 1.3 ms a rollout instead of 0.13 (profiles/r05_trace_nn_before.txt).  Every
+// term here is proportional to d; the cost handed back is J(nominal) + this sum.
+__device__ __forceinline__ float line_search_delta(float tau_i, float d_i, float s, float s2, float c_i)
+{
+    return fmaf(d_i, fmaf(0.5f, s, c_i), 0.5f * (tau_i - d_i) * s2);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // lqr_forward through the network (mpc/lqr_step.py:164-261), sixteen problems per wavefront.
 // lane (q, r): problem r of the group, quarter q of every per-problem loop (controls i = q, q+4, ..; cost rows likewise);
@@ -232,6 +244,7 @@ __global__ void __launch_bounds__(256) nn_rollout_kernel(StepParams<float> p, Ml
                 }
                 tauS[r * TS + ns + i] = un;
                 const float d = u - un;
+                dxS[r * TS + ns + i] = -d;          // (the control part of tau' - tau_nominal, for the cost difference below; K reads states only)
                 da = fmaf(d, d, da);
             }
             wave_sync();
@@ -239,9 +252,18 @@ __global__ void __launch_bounds__(256) nn_rollout_kernel(StepParams<float> p, Ml
                 const float *Ct = p.C + (long)t * p.C_st + b * p.C_sb;
                 const float *ct = p.c + (long)t * p.c_st + b * p.c_sb;
                 for (int i = q; i < n; i += 4) {
-                    float s = 0.f;
-                    for (int j = 0; j < n; ++j) s = fmaf(Ct[i * n + j], tauS[r * TS + j], s);
-                    ca = fmaf(tauS[r * TS + i], fmaf(0.5f, s, ct[i]), ca);
+                    float s = 0.f, s2 = 0.f;
+                    for (int j = 0; j < n; ++j) {
+                        const float cij = Ct[i * n + j];
+                        s = fmaf(cij, tauS[r * TS + j], s);
+                        if (has_gain) s2 = fmaf(cij, dxS[r * TS + j], s2);
+                    }
+                    if (has_gain) {
+                        // the line search compares J(tau') with J(nominal) (:176-179): summed as their DIFFERENCE, see line_search_delta
+                        ca += line_search_delta(tauS[r * TS + i], dxS[r * TS + i], s, s2, ct[i]);
+                    } else {
+                        ca = fmaf(tauS[r * TS + i], fmaf(0.5f, s, ct[i]), ca);
+                    }
                 }
             }
             if (t < T - 1) {                                                                // :223-225
@@ -266,10 +288,10 @@ __global__ void __launch_bounds__(256) nn_rollout_kernel(StepParams<float> p, Ml
         const float dn = sqrtf(da);
         if (pass == 0) full = dn;                                                           // :243-245
         if (active) {
-            cost = ca;
+            cost = has_gain ? old_cost + ca : ca;       // (with gains `ca` is J(tau') - J(nominal))
             dun = dn;
             // :176-179, 247: keep shrinking while this problem's cost got worse
-            if (has_gain && ca > old_cost && pass + 1 < max_ls) alpha *= p.ls_decay; else active = false;
+            if (has_gain && ca > 0.f && pass + 1 < max_ls) alpha *= p.ls_decay; else active = false;
         }
         if (!__any(active)) break;
     }
@@ -516,6 +538,7 @@ __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p
     const long b_raw = (long)blockIdx.x * 16 + r;
     const bool valid = b_raw < p.B;
     const long b = valid ? b_raw : p.B - 1;
+    const long b_raw_clamped = b;
     const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T;
     const long B = p.B;
     constexpr bool has_gain = GAIN, has_cost = COST, vecC = true, vecK = true;
@@ -541,7 +564,95 @@ __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p
     bool active = valid;
     const int max_ls = has_gain ? p.max_ls : 1;
     const bool own_u = q < nc;                  // this lane computes control i = q (n_ctrl <= 4)
-    for (int pass = 0; pass < max_ls; ++pass) {
+    // The line search as a JOB SCHEDULE over the wave's sixteen problem slots (round 5).  The reference runs pass after pass over the
+    // whole batch while any problem got worse (mpc/lqr_step.py:176-179); a wavefront did the same for its 16 problems -- and from the
+    // third iLQR iteration on a few problems of most wavefronts need the 4th, 7th or 10th step size (tools/r05_nn_iter_probe.py), so
+    // the rollout of 0.14 ms ran 1.3 - 1.7 ms with one or two slots of sixteen at work (profiles/r05_trace_nn_before.txt).  The trials
+    // of a problem do not depend on each other: after a pass, the slots nobody needs any more roll out FURTHER trials of the problems
+    // that are still searching -- a problem's next S step sizes side by side, S = 16 / (problems searching) --, the first of them with
+    // the stores on (as the sequential search would have it); a problem whose accepted trial is not the one in memory replays it
+    // once.  Same step sizes (the same chain of float32 multiplications from 1), same acceptance rule -- the first trial that did not
+    // get worse, else the last (:247-252) -- same results; three passes where the sequential search took up to max_ls.
+    __shared__ int tabR[16], tabS[16];
+    long bb = b;                                // the problem this lane's slot rolls out in the CURRENT pass
+    float al = 1.f;                             // ... with this step size
+    bool store = active;                        // ... writing new_x / new_u
+    bool done_all = false;
+    // the search state of this slot's OWN problem (what its q = 0 lane says counts; the other three carry copies)
+    int next_t = 0, acc_t = -1, stored_t = -1;  // first trial not rolled out yet; the accepted one; the one whose trajectory is in memory
+    bool done = !valid;
+    // this pass's job of the slot, and where the own problem's jobs sit: slots [base, base + share), trials first_t ..
+    int job_t = 0, base = r, share = valid ? 1 : 0, first_t = 0;
+    bool job_valid = valid, replaying = false;
+    auto chain = [&](int j) { float a = 1.f; for (int i = 0; i < j; ++i) a *= p.ls_decay; return a; };      // :247 alpha *= decay, j times
+    auto schedule = [&]() {
+        if (!done && acc_t < 0 && next_t >= max_ls) acc_t = max_ls - 1;                     // no trial improved: the last one stands (:250-252)
+        const bool need_replay = !done && acc_t >= 0 && stored_t != acc_t;
+        const bool searching = !done && acc_t < 0;
+        const unsigned mR = (unsigned)__ballot(need_replay && q == 0), mS = (unsigned)__ballot(searching && q == 0);
+        if ((mR | mS) == 0u) { done_all = true; return; }
+        const int nR = __popc(mR), nS = __popc(mS), free_slots = 16 - nR;
+        const int S = nS ? (free_slots >= nS ? free_slots / nS : 1) : 0;
+        const unsigned below = (1u << r) - 1u;
+        const int rankR = __popc(mR & below), rankS = __popc(mS & below);
+        if (q == 0 && need_replay) tabR[rankR] = r;
+        if (q == 0 && searching) tabS[rankS] = r;
+        wave_sync();
+        // the own problem's jobs of this pass
+        replaying = need_replay;
+        share = need_replay ? 1 : ((searching && rankS * S < free_slots) ? S : 0);
+        base = need_replay ? rankR : nR + rankS * S;
+        first_t = need_replay ? acc_t : next_t;
+        // this slot's job
+        const int k = r;
+        int home = 0, off = 0;
+        bool st = false;
+        job_valid = false;
+        if (k < nR) {
+            home = tabR[k]; st = true; job_valid = true;
+        } else if (S > 0 && (k - nR) / S < nS) {
+            home = tabS[(k - nR) / S]; off = (k - nR) % S; st = off == 0; job_valid = true;
+        }
+        const int h_acc = __shfl(acc_t, home), h_next = __shfl(next_t, home);               // (lane `home`: q = 0 of that slot)
+        job_t = (k < nR ? h_acc : h_next) + off;
+        job_valid = job_valid && job_t < max_ls;
+        bb = (long)__shfl((int)b_raw_clamped, home);
+        al = chain(job_t);
+        store = job_valid && st;
+        wave_sync();
+    };
+    auto update_after_pass = [&](int pass, float ca, float dn) {
+        if (!(GAIN && COST)) {                  // util.get_traj / get_cost: one pass, every slot its own problem
+            cost = ca; dun = dn; full = dn; alpha = 1.f;
+            done_all = true;
+            return;
+        }
+        const unsigned ok = (unsigned)__ballot(q == 0 && job_valid && !(ca > 0.f));         // bit k: the trial in slot k did not get worse
+        // the results of the own problem's first job (the one that stored) come from slot `base`
+        const float ca0 = __shfl(ca, base), dn0 = __shfl(dn, base);
+        if (!done && share > 0) {
+            if (pass == 0) full = dn0;                                                      // :243-245 (trial 0 is alpha = 1)
+            if (replaying) {
+                cost = old_cost + ca0; dun = dn0; alpha = chain(acc_t);
+                stored_t = acc_t; done = true;
+            } else {
+                const unsigned mine = (ok >> base) & ((1u << share) - 1u);
+                const int n_run = min(share, max_ls - first_t);
+                if (mine != 0u) acc_t = first_t + __ffs((int)mine) - 1;
+                stored_t = first_t;
+                next_t = first_t + n_run;
+                // (what the sequential search would report had it stopped here: the trial in memory)
+                cost = old_cost + ca0; dun = dn0; alpha = chain(first_t);
+                if (acc_t < 0 && next_t >= max_ls) acc_t = max_ls - 1;
+                if (acc_t == stored_t) done = true;
+            }
+        }
+        schedule();
+    };
+    for (int pass = 0; ; ++pass) {
+        const long b = bb;                      // (shadows the slot's own problem inside the pass)
+        const float alpha = al;
+        const bool active = store;
         f32x4 xr;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -611,22 +722,34 @@ __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p
                 }
                 tauS[r * 20 + ns + q] = un;
                 const float d = uq - un;
+                if (has_gain) dxS[r * 20 + ns + q] = -d;      // (the control part of tau' - tau_nominal; K's padded columns are zero)
                 da = fmaf(d, d, da);
             }
             wave_sync();
             const f32x4 tq = *reinterpret_cast<const f32x4 *>(tauS + r * 20 + 4 * q);
             if (has_cost) {                                                                 // :230-232
-                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 tg = *reinterpret_cast<const f32x4 *>(tauS + r * 20 + 4 * g);
+                    const f32x4 dg = has_gain ? *reinterpret_cast<const f32x4 *>(dxS + r * 20 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int v = 0; v < 4; ++v)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) s[v] = fmaf(o.Cr[v][g][e], tg[e], s[v]);
+                        for (int e = 0; e < 4; ++e) {
+                            s[v] = fmaf(o.Cr[v][g][e], tg[e], s[v]);
+                            if (has_gain) s2[v] = fmaf(o.Cr[v][g][e], dg[e], s2[v]);
+                        }
                 }
+                if (has_gain) {
+                    // J(tau') - J(nominal), summed as a difference (line_search_delta)
+                    const f32x4 dq = *reinterpret_cast<const f32x4 *>(dxS + r * 20 + 4 * q);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) ca = fmaf(tq[v], fmaf(0.5f, s[v], o.cq[v]), ca);
+                    for (int v = 0; v < 4; ++v) ca += line_search_delta(tq[v], dq[v], s[v], s2[v], o.cq[v]);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) ca = fmaf(tq[v], fmaf(0.5f, s[v], o.cq[v]), ca);
+                }
             }
             if (t + 1 < T) request(t + 1, o);
             if (t + 1 < T) {
@@ -652,13 +775,8 @@ __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p
         da += __shfl_xor(da, 16);
         da += __shfl_xor(da, 32);
         const float dn = sqrtf(da);
-        if (pass == 0) full = dn;                                                           // :243-245
-        if (active) {
-            cost = ca;
-            dun = dn;
-            if (has_gain && ca > old_cost && pass + 1 < max_ls) alpha *= p.ls_decay; else active = false;   // :176-179, 247
-        }
-        if (!__any(active)) break;
+        update_after_pass(pass, ca, dn);
+        if (done_all) break;
     }
     if (q == 0 && valid) {
         if (p.costs) p.costs[b] = cost;

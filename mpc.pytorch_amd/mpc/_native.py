@@ -846,6 +846,88 @@ class HipBackend:
                                    ws.data_ptr(), nbytes, _stream(dev)), "mpc_mlp_linearize")
         return F, f
 
+    def plan_network_iteration(self, x_init, C, c, net, opts, nominals, scratch=None):
+        """One iLQR iteration on an NNDynamics network (mpc/mpc.py:245-306 with dx a module: util.get_traj is the previous
+        rollout's own new_x, then MPC.linearize_dynamics(ANALYTIC) :495-512, lqr_backward :52-160, lqr_forward through the
+        network :164-261) bound ONCE per solve: three C calls on the stream per iteration -- mpc_mlp_linearize, mpc_lqr_step
+        (MPC_OPT_SWEEP_ONLY, the fused kernel of the shape), mpc_mlp_rollout -- no allocation, no struct rebuilt, no torch op.
+        nominals = ((xa, ua), (xb, ub)): iteration k reads nominals[k % 2] and writes nominals[1 - k % 2] (contiguous buffers).
+        -> (run(k, stream=None) -> outputs dict of that parity, (outputs_0, outputs_1), vouch_c()): vouch_c() re-binds the two
+        sweeps with MPC_OPT_C_SYMMETRIC once the first sweep has reported C symmetric."""
+        dev = _require_device(x_init, C, c, nominals[0][0], nominals[0][1])
+        L = load()
+        T, B, n = C.shape[0], C.shape[1], C.shape[2]
+        ns = x_init.shape[1]
+        nc = n - ns
+        kw = dict(device=dev, dtype=C.dtype)
+        N = (T - 1) * B
+        F, f = torch.empty(T - 1, B, ns, n, **kw), torch.empty(T - 1, B, ns, **kw)
+        K, k = torch.empty(T, B, nc, ns, **kw), torch.empty(T, B, nc, **kw)
+        e, mws, mbytes, keep_e = net.to_struct(C)
+        import copy
+        so = copy.copy(opts)
+        so.sweep_only, so.true_dynamics = True, None
+        ro = copy.copy(opts)
+        ro.sweep_only, ro.true_dynamics = False, None
+        ro_struct, keep_ro = ro.to_struct(T, B, nc, C)
+        fl, it = torch.empty(2, 5, B, **kw), torch.zeros(2, 2, B, device=dev, dtype=torch.int32)
+        sweeps, rolls, outs, keeps = [], [], [], [F, f, K, k, keep_e, keep_ro, fl, it]
+        for j in (0, 1):
+            cx, cu = nominals[j]
+            ox, ou = nominals[1 - j]
+            for t_ in (cx, cu, ox, ou):
+                assert t_.is_contiguous() and t_.dtype == C.dtype and t_.device == C.device
+            assert tuple(cx.shape) == (T, B, ns) and tuple(cu.shape) == (T, B, nc)
+            res = dict(new_x=ox, new_u=ou, costs=fl[j, 0], old_costs=fl[j, 1], full_du_norm=fl[j, 2], alpha_du_norm=fl[j, 3],
+                       alphas=fl[j, 4], qp_iters=it[j, 0], status=it[j, 1])
+            # the sweep: (x_init, C, c, F, f) at this nominal -> K, k, old_costs, qp_iters, status
+            sp, keep_p = self._problem(x_init, C, c, F, f, cx, cu)
+            sweeps.append([sp, None, None, keep_p])
+            # the rollout through the network: new_x, new_u, costs, full_du_norm, alphas
+            rp, keep_r = self._problem(x_init, C, c, None, None, cx, cu)
+            rout = Outputs()
+            for name in ("new_x", "new_u", "costs", "full_du_norm", "alpha_du_norm", "alphas"):
+                setattr(rout, name, res[name].data_ptr())
+            # (the rollout's status words would overwrite the sweep's: it reports none the driver reads -- left unbound)
+            rolls.append((rp, rout, keep_r, cx.data_ptr(), cu.data_ptr()))
+            outs.append(res)
+        nbytes = int(L.mpc_lqr_workspace_bytes(ctypes.byref(sweeps[0][0])))
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+
+        def bind_sweeps(o_):
+            st_, keep_s = o_.to_struct(T, B, nc, C)
+            st_.flags |= OPT_SWEEP_ONLY
+            for j in (0, 1):
+                sout = Outputs()
+                sout.K, sout.k = K.data_ptr(), k.data_ptr()
+                sout.old_costs, sout.qp_iters, sout.status = outs[j]["old_costs"].data_ptr(), outs[j]["qp_iters"].data_ptr(), outs[j]["status"].data_ptr()
+                sweeps[j][1], sweeps[j][2] = st_, sout
+            keeps.append(keep_s)
+        bind_sweeps(so)
+        step_fn, lin_fn, roll_fn = L.mpc_lqr_step, L.mpc_mlp_linearize, L.mpc_mlp_rollout
+        ep, rop, wsp, mwsp = ctypes.byref(e), ctypes.byref(ro_struct), ws.data_ptr(), mws.data_ptr()
+        Fp, fp, Kp, kp = F.data_ptr(), f.data_ptr(), K.data_ptr(), k.data_ptr()
+
+        def run(j, stream=None):
+            st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+            sp, so_, sout, _ = sweeps[j]
+            rp, rout, _, cxp, cup = rolls[j]
+            rc = lin_fn(ep, ns, nc, N, cxp, cup, Fp, fp, mwsp, mbytes, st)
+            if rc == 0:
+                rc = step_fn(ctypes.byref(sp), ctypes.byref(so_), ctypes.byref(sout), wsp, nbytes, IMPL_AUTO, st)
+            if rc == 0:
+                rc = roll_fn(ctypes.byref(rp), rop, ep, Kp, kp, outs[j]["old_costs"].data_ptr(), ctypes.byref(rout), mwsp, mbytes, st)
+            if rc != 0:
+                _check(rc, "network iteration (mpc_mlp_linearize / mpc_lqr_step / mpc_mlp_rollout)")
+            return outs[j]
+
+        def vouch_c():
+            so2 = copy.copy(so)
+            so2.c_symmetric = True
+            bind_sweeps(so2)
+        run._keep = (keeps, sweeps, rolls, ws, mws, x_init, C, c, nominals)
+        return run, tuple(outs), vouch_c
+
     # -- (7) driver reductions ------------------------------------------------------------------
     writes_host_flags = True
 

@@ -240,8 +240,20 @@ class MPC(Module):
                 and self.grad_method in (GradMethods.ANALYTIC, GradMethods.AUTO_DIFF) and T > 1):
             sim = dx.native_env()
         be = _native.backend()
+        # NNDynamics the kernels take (fp32 on the device, <= 4 layers, n_state <= 16), ANALYTIC linearisation: the whole
+        # iteration is three pre-bound C calls (round 5; the general loop below pays allocations, struct rebuilds, an autograd
+        # node and a device synchronisation per iteration: 1.1 ms an iteration for 0.52 ms of kernels at the headline shape)
+        net = None
+        if (sim is None and not fast and isinstance(cost, QuadCost) and self.slew_rate_penalty is None and T > 1
+                and self.grad_method == GradMethods.ANALYTIC and hasattr(dx, "native_net")
+                and hasattr(be, "plan_network_iteration")):
+            net = dx.native_net(x_init)
+            if net is not None and net.activation == "elu":      # (no grad_input in the reference: the module refuses, mpc/dynamics.py:113-114)
+                net = None
         if fast or sim is not None:
             best = self._iterate_planned(be, x_init, u, cost, dx, sim, n_batch)
+        elif net is not None:
+            best = self._iterate_network(be, x_init, u, cost, dx, net, n_batch)
         else:
             best = self._iterate_general(be, x_init, u, cost, dx)
 
@@ -323,14 +335,34 @@ class MPC(Module):
             plan = (sym_plans if sym_plans is not None else plans)[i % 2]
             return plan() if stream is None else plan(stream)
 
+        def on_symmetric():
+            # (a simulator solve runs on the lane-per-problem kernel, which keeps Q and V general and has no test to
+            #  skip: building two more plans would only cost host time in a loop that is launch-latency bound)
+            nonlocal sym_plans
+            if self.lqr_iter > 2 and sim is None:
+                import copy
+                so = copy.copy(opts)
+                so.c_symmetric = True
+                if variant is not None:          # the same structs with one more option bit: no walk, no allocation
+                    sym_plans = (variant(pa, opts=so), variant(pb, opts=so))
+                else:
+                    sym_plans = (be.plan_step(xi, cost.C, cost.c, F, f, xa, ua, so, out_x=xb, out_u=ub),
+                                 be.plan_step(xi, cost.C, cost.c, F, f, xb, ub, so, out_x=xa, out_u=ua))
+        return self._drive(be, launch, (pa.outputs, pb.outputs) if variant is not None else None, r, xa, ua, n_batch, stream, on_symmetric)
+
+    def _drive(self, be, launch, outputs, r, xa, ua, n_batch, stream, on_symmetric):
+        """The loop of mpc/mpc.py:245-306 around pre-bound iterations: launch(i) enqueues iteration i and returns its output
+        dict (`outputs`: the two dicts the iterations alternate between, for the pre-bound select call; None = the test
+        backends' general entry), `r` = the outputs of iteration 0, already on its way.  Best-iterate tracking on the device
+        (:271-285); the convergence flags of iteration i are read back while iteration i+1 already runs."""
         best = dict(x=torch.empty_like(xa), u=torch.empty_like(ua),
                     costs=torch.empty(n_batch, dtype=xa.dtype, device=xa.device),
                     full_du_norm=torch.empty(n_batch, dtype=xa.dtype, device=xa.device))
         reader = _FlagReader(xa.device, xa.dtype, be)
         # (the HIP backend binds the select call's arguments once per solve; the test stand-ins take the general entry)
         sel = None
-        if reader.direct and hasattr(be, "plan_select"):
-            sel = be.plan_select(self.best_cost_eps, (pa.outputs, pb.outputs), best, reader.device_flags, host=reader._host)
+        if reader.direct and hasattr(be, "plan_select") and outputs is not None:
+            sel = be.plan_select(self.best_cost_eps, outputs, best, reader.device_flags, host=reader._host)
         n_not_improved, i = 0, 0
         while True:
             # best-iterate tracking, :271-285 -- on the device
@@ -345,17 +377,7 @@ class MPC(Module):
             any_improved = (bits & 1) != 0
             if i == 0 and not (bits & 2):
                 self._c_symmetric = True
-                # (a simulator solve runs on the lane-per-problem kernel, which keeps Q and V general and has no test to
-                #  skip: building two more plans would only cost host time in a loop that is launch-latency bound)
-                if self.lqr_iter > 2 and sim is None:
-                    import copy
-                    so = copy.copy(opts)
-                    so.c_symmetric = True
-                    if variant is not None:          # the same structs with one more option bit: no walk, no allocation
-                        sym_plans = (variant(pa, opts=so), variant(pb, opts=so))
-                    else:
-                        sym_plans = (be.plan_step(xi, cost.C, cost.c, F, f, xa, ua, so, out_x=xb, out_u=ub),
-                                     be.plan_step(xi, cost.C, cost.c, F, f, xb, ub, so, out_x=xa, out_u=ua))
+                on_symmetric()
             if self.flag_reducer is not None:          # shards agree on the batch-wide stop test (mpc.shard)
                 any_improved, max_du_norm = self.flag_reducer(any_improved, max_du_norm)
             n_not_improved += 1
@@ -373,6 +395,29 @@ class MPC(Module):
                 break
             r, i = nxt, i + 1
         return best
+
+    def _iterate_network(self, be, x_init, u, cost, dx, net, n_batch):
+        """The loop when dx is an NNDynamics the kernels take (`net` = its MlpSpec) and the cost a QuadCost: per iteration
+        MPC.linearize_dynamics (mpc/mpc.py:495-512), lqr_backward and lqr_forward through the network (mpc/lqr_step.py:52-261,
+        module branch :223-225) as three pre-bound C calls (HipBackend.plan_network_iteration); the states of a rollout ARE
+        util.get_traj of its controls through the network (:251 recomputes them), so only the first nominal needs get_traj.
+        Inner iterations are never differentiated (the reference detaches them too)."""
+        T = self.T
+        xi = util.detach_maybe(x_init).contiguous()
+        ua = util.detach_maybe(u).contiguous()
+        if self.u_init is not None and ua.untyped_storage().data_ptr() == self.u_init.untyped_storage().data_ptr():
+            ua = ua.clone()               # the iterations WRITE into the nominal buffers: never the caller's u_init
+        xa = util.get_traj(T, ua, x_init=xi, dynamics=dx).contiguous()
+        xb, ub = torch.empty_like(xa), torch.empty_like(ua)
+        run, outs, vouch_c = be.plan_network_iteration(xi, cost.C, cost.c, net, self._step_options(), ((xa, ua), (xb, ub)))
+        stream = torch.cuda.current_stream(xa.device).cuda_stream if xa.is_cuda else None
+        r = run(0, stream)
+        self._c_symmetric = False
+
+        def on_symmetric():
+            if self.lqr_iter > 2:
+                vouch_c()
+        return self._drive(be, lambda i: run(i % 2, stream), outs, r, xa, ua, n_batch, stream, on_symmetric)
 
     def _iterate_general(self, be, x_init, u, cost, dx):
         """The same loop with module-valued cost / dynamics or a slew penalty: linearisation and cost

@@ -148,3 +148,44 @@ class OracleBackend:
             flags[0].copy_(any_improved); flags[1].copy_(du_norm.max().reshape(1))
             return flags
         return any_improved, du_norm.max().reshape(1)
+
+    # -- NNDynamics through the oracle (oracle/env_oracle.py, MLP): what MPC._iterate_network drives on the device ----------
+    @staticmethod
+    def _mlp(net):
+        return E.Mlp([_np(W).astype(np.float64) for W in net.weights], [_np(b).astype(np.float64) for b in net.biases],
+                     net.activation, net.passthrough)
+
+    def mlp_traj_cost(self, x_init, u, net, C=None, c=None):
+        self.calls.append("mlp_traj_cost")
+        x = E.traj(E.MLP, _np(x_init).astype(np.float64), _np(u).astype(np.float64), self._mlp(net))
+        cost = None if C is None else self._t(E.quad_cost(_np(C).astype(np.float64), _np(c).astype(np.float64), x, _np(u).astype(np.float64)), u)
+        return self._t(x, u), cost
+
+    def plan_network_iteration(self, x_init, C, c, net, opts, nominals, scratch=None):
+        """The stand-in of HipBackend.plan_network_iteration: linearise (MPC.linearize_dynamics, ANALYTIC), sweep, rollout
+        through the network with the line search -- each piece the oracle's."""
+        T, B = C.shape[0], C.shape[1]
+        ns = x_init.shape[1]
+        nc = C.shape[2] - ns
+        mlp = self._mlp(net)
+        outs = tuple(dict(new_x=nominals[1 - j][0], new_u=nominals[1 - j][1]) for j in (0, 1))
+        vouched = []
+
+        def run(j, stream=None):
+            self.calls.append("network_iteration" + (":c_symmetric" if vouched else ""))
+            cx, cu = (_np(t).astype(np.float64) for t in nominals[j])
+            Fl, fl = E.linearize(E.MLP, cx[:-1].reshape(-1, ns), cu[:-1].reshape(-1, nc), mlp)
+            o = O.lqr_step(_np(x_init), _np(C), _np(c), Fl.reshape(T - 1, B, ns, ns + nc), fl.reshape(T - 1, B, ns), cx, cu,
+                           _bound(opts.u_lower), _bound(opts.u_upper), _np(opts.u_zero_I), opts.delta_u, opts.linesearch_decay,
+                           opts.max_linesearch_iter, lockstep=self.lockstep, return_gains=True)
+            nx, nu, cs, full, al, _tr, old = E.rollout_batched(E.MLP, mlp, _np(x_init).astype(np.float64), _np(C).astype(np.float64),
+                                                               _np(c).astype(np.float64), o["K"], o["k"], cx, cu, _bound(opts.u_lower),
+                                                               _bound(opts.u_upper), opts.linesearch_decay, opts.max_linesearch_iter,
+                                                               delta_u=opts.delta_u, u_zero_I=_np(opts.u_zero_I))
+            r = outs[j]
+            r["new_x"].copy_(self._t(nx, C)); r["new_u"].copy_(self._t(nu, C))
+            r.update(costs=self._t(cs, C), old_costs=self._t(old, C), full_du_norm=self._t(full, C), alpha_du_norm=self._t(full, C),
+                     alphas=self._t(al, C), qp_iters=torch.full((B,), int(o["n_qp_iter"]), dtype=torch.int32),
+                     status=torch.full((B,), 0 if vouched else 32, dtype=torch.int32))
+            return r
+        return run, outs, lambda: vouched.append(True)

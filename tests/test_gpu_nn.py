@@ -177,21 +177,21 @@ def test_mpc_forward_with_nndynamics_matches_the_reference_solve(be, name, monke
     from mpc import _native
     z = golden(name)
     dyn = _module_of(z, DEV)
-    calls = {"rollout": 0, "linearize": 0}
-    orig_r, orig_l = _native.HipBackend.mlp_rollout, _native.HipBackend.mlp_linearize
+    calls = {"iterations": 0}
+    orig = _native.HipBackend.plan_network_iteration
 
-    def count_r(self, *a, **k):
-        calls["rollout"] += 1
-        return orig_r(self, *a, **k)
+    def counted(self, *a, **k):
+        run, outs, vouch = orig(self, *a, **k)
 
-    def count_l(self, *a, **k):
-        calls["linearize"] += 1
-        return orig_l(self, *a, **k)
-    monkeypatch.setattr(_native.HipBackend, "mlp_rollout", count_r)
-    monkeypatch.setattr(_native.HipBackend, "mlp_linearize", count_l)
+        def run2(j, stream=None):
+            calls["iterations"] += 1
+            return run(j, stream)
+        return run2, outs, vouch
+    # (round 5: the iterations are pre-bound -- linearise, sweep, rollout as three C calls each, MPC._iterate_network)
+    monkeypatch.setattr(_native.HipBackend, "plan_network_iteration", counted)
     x, u, costs = _mpc_solve(z, dyn, DEV)
     torch.cuda.synchronize()
-    assert calls["rollout"] >= 1 and calls["linearize"] >= 1          # the kernels ran, not the module loop
+    assert calls["iterations"] >= 2                                    # the kernels ran, not the module loop
     np.testing.assert_allclose(host(costs), z["solve_costs"], rtol=2e-3)
     np.testing.assert_allclose(host(u), z["solve_u"], rtol=5e-3, atol=5e-3)
     np.testing.assert_allclose(host(x), z["solve_x"], rtol=5e-3, atol=5e-3)
@@ -371,3 +371,54 @@ def test_network_rollout_with_tensor_bounds_delta_u_and_pinned_controls(be, ns, 
                           have_gains=False)
         if masked:
             assert (host(r["new_u"])[mask] == 0).all()
+
+
+@pytest.mark.parametrize("ns,nc,hidden,B,T,max_ls,decay,mult", [(12, 4, [100], 1000, 20, 10, 0.5, 3.0), (12, 4, [100], 333, 12, 16, 0.7, 8.0),
+                                                               (8, 4, [32, 16], 200, 10, 3, 0.2, 60.0), (5, 2, [24], 260, 15, 10, 0.5, 8.0)])
+def test_network_line_search_runs_every_depth_like_the_reference(be, ns, nc, hidden, B, T, max_ls, decay, mult):
+    """The line search of lqr_forward (mpc/lqr_step.py:176-179, 247-252) through the network on costs that are NOT convex in the
+    state, so that the problems of one wavefront stop at every depth between the full step and the last trial: per problem the
+    first step size that did not get worse, else the last one.  Round 5: the trials are decided on J(tau') - J(nominal) summed as
+    a difference, and a wavefront with ONE problem left rolls that problem's remaining trials out side by side (then replays the
+    accepted one) -- the step sizes, trajectories and costs are the sequential passes' (oracle/env_oracle.py, every problem)."""
+    from mpc._native import StepOptions
+    from oracle import env_oracle as E
+    from oracle import lqr_oracle as O
+    net = random_net(ns, nc, hidden, "sigmoid", True, seed=7 * ns + nc, scale=0.8)
+    sp = spec_of(net)
+    rng = np.random.RandomState(B + max_ls)
+    n = ns + nc
+    x0 = rng.randn(B, ns)
+    u0 = np.clip(0.3 * rng.randn(T, B, nc), -0.5, 0.5)
+    A = rng.randn(T, B, n, n)
+    C = np.einsum("tbki,tbkj->tbij", A, A) + 0.1 * np.eye(n)
+    C[:, :, :ns, :ns] -= (rng.rand(1, B, 1, 1) * mult * n) * np.eye(ns)          # per problem: from convex to strongly non-convex in x
+    c = rng.randn(T, B, n)
+    xs = E.traj(E.MLP, x0, u0, net)
+    Fl, fl = E.linearize(E.MLP, xs[:-1].reshape(-1, ns), u0[:-1].reshape(-1, nc), net)
+    Csw = C.copy()
+    Csw[:, :, :ns, :ns] += mult * n * np.eye(ns)                                 # (the sweep needs a convex model: gains from a regularised cost)
+    o = O.lqr_step(x0, Csw, c, Fl.reshape(T - 1, B, ns, n), fl.reshape(T - 1, B, ns), xs, u0, -0.5, 0.5, linesearch_decay=decay,
+                   max_linesearch_iter=max_ls, lockstep=False, nthreads=O.max_threads(), return_gains=True)
+    nx, nu, costs, full, alphas, trials, old = E.rollout_batched(E.MLP, net, x0, C, c, o["K"], o["k"], xs, u0, -0.5, 0.5, decay, max_ls)
+    depth = np.rint(np.log(alphas) / np.log(decay)).astype(int)
+    assert len(set(depth.tolist())) >= min(max_ls, 4) - 1 and (depth == max_ls - 1).any() and (depth == 0).any(), np.bincount(depth)
+    r = be.mlp_rollout(f32(x0), f32(C), f32(c), f32(o["K"]), f32(o["k"]), f32(xs), f32(u0), f32(old),
+                       StepOptions(u_lower=-0.5, u_upper=0.5, linesearch_decay=decay, max_linesearch_iter=max_ls), sp)
+    torch.cuda.synchronize()
+    ga = host(r["alphas"]).astype(np.float64)
+    gdepth = np.rint(np.log(ga) / np.log(decay)).astype(int)
+    # a trial whose cost ties with the nominal's to float32 rounding may fall either way (tests/test_gpu_fullsize.py): counted
+    tie = gdepth != depth
+    margin = np.abs(trials - old[None]) / np.maximum(1.0, np.abs(old))[None]
+    for b_ in np.nonzero(tie)[0]:
+        lo_, hi_ = sorted((gdepth[b_], depth[b_]))
+        assert margin[lo_, b_] < 1e-4, ("problem %d: step size %g for %g without a tie" % (b_, ga[b_], alphas[b_]), margin[:, b_])
+    assert tie.sum() <= max(2, B // 100), tie.sum()
+    same = ~tie
+    np.testing.assert_allclose(ga[same], alphas[same], rtol=1e-5)
+    scale = 1.0 + np.abs(nx).max()
+    np.testing.assert_allclose(host(r["new_u"])[:, same], nu[:, same], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(host(r["new_x"])[:, same], nx[:, same], rtol=1e-3, atol=2e-4 * scale)
+    np.testing.assert_allclose(host(r["costs"])[same], costs[same], rtol=1e-3, atol=1e-3 * np.abs(old).max() * 1e-3)
+    np.testing.assert_allclose(host(r["full_du_norm"]), full, rtol=2e-3, atol=2e-4)

@@ -818,3 +818,40 @@ def test_cached_parameter_copy_follows_edits_the_version_counter_does_not_see():
     assert _native._device_copy_of(t, dev, dt) is not c
     big = torch.zeros(65)
     assert _native._device_copy_of(big, dev, dt) is not _native._device_copy_of(big, dev, dt)      # never cached
+
+
+def test_network_iterations_are_the_general_loop(oracle_backend, monkeypatch):
+    """MPC._iterate_network (round 5: an NNDynamics the kernels take + QuadCost + ANALYTIC: linearise, sweep and the rollout
+    through the network as pre-bound calls, the nominal states taken from the previous rollout) against MPC._iterate_general
+    (the module called timestep by timestep, linearised through grad_input: the reference's only path, mpc/mpc.py:245-306,
+    495-512, mpc/lqr_step.py:223-225) on the oracle stand-in: the same iterates, the same best trajectory."""
+    from mpc import mpc as M, _native
+    from mpc.dynamics import NNDynamics
+    torch.manual_seed(3)
+    ns, nc, T, B = 4, 2, 6, 5
+    dyn = NNDynamics(ns, nc, [12], activation="sigmoid").double()
+    A = torch.randn(T, B, ns + nc, ns + nc, dtype=torch.float64)
+    C = A.transpose(2, 3).matmul(A) + 0.1 * torch.eye(ns + nc, dtype=torch.float64)
+    c = torch.randn(T, B, ns + nc, dtype=torch.float64)
+    x0 = torch.randn(B, ns, dtype=torch.float64)
+    u0 = 0.2 * torch.randn(T, B, nc, dtype=torch.float64)
+
+    def solve():
+        ctrl = M.MPC(ns, nc, T, u_lower=-0.5, u_upper=0.5, lqr_iter=4, verbose=-1, exit_unconverged=False, detach_unconverged=False,
+                     grad_method=M.GradMethods.ANALYTIC, backprop=False, u_init=u0.clone())
+        with torch.no_grad():
+            return ctrl(x0, M.QuadCost(C, c), dyn)
+    oracle_backend.calls.clear()
+    xg, ug, cg = solve()                                       # native_net is None on a CPU box: the general loop
+    assert "network_iteration" not in oracle_backend.calls and "lqr_sweep" in oracle_backend.calls
+    monkeypatch.setattr(_native.MlpSpec, "supported", staticmethod(lambda weights, activation, like: True))
+    oracle_backend.calls.clear()
+    xn, un, cn = solve()
+    calls = oracle_backend.calls
+    assert calls.count("mlp_traj_cost") == 1 and "lqr_sweep" not in calls               # one get_traj, then the rollouts' own states
+    assert [k for k in calls if k.startswith("network_iteration")] == ["network_iteration", "network_iteration",
+                                                                       "network_iteration:c_symmetric", "network_iteration:c_symmetric"]
+    np.testing.assert_allclose(un.numpy(), ug.numpy(), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(xn.numpy(), xg.numpy(), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(cn.numpy(), cg.numpy(), rtol=1e-9)
+    assert u0.abs().max() <= 0.2 * 6 and not torch.equal(un, u0)                          # the caller's u_init is never written into

@@ -9,7 +9,10 @@ if "--read" in sys.argv:
     f = glob.glob(os.path.join(sys.argv[-1], "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     # the last call: walk back from the end to the last trajectory kernel
-    starts = [i for i, r in enumerate(rows) if "traj_" in r["Kernel_Name"]]
+    starts = [i for i, r in enumerate(rows) if "traj_" in r["Kernel_Name"] or "nn_rollout" in r["Kernel_Name"] and "traj" in r["Kernel_Name"].lower()]
+    if not starts:          # (the network solves: the trajectory kernel is the first launch of a solve -- find the last select, walk back one solve)
+        sel = [i for i, r in enumerate(rows) if "select_best" in r["Kernel_Name"]]
+        starts = [sel[-6] + 1 if len(sel) > 5 else 0]
     rows = rows[starts[-1]:]
     t0 = int(rows[0]["Start_Timestamp"]); prev_end = t0
     for r in rows:
@@ -36,10 +39,24 @@ if env:                                            # BASELINE configs 2 / 3: the
         ctrl(x0, QuadCost(Q, pp), dxm)
     torch.cuda.synchronize()
     sys.exit(0)
-p = bench.make_problem(12, 4, 50, 4096, torch.float32, "cuda:0", seed=5, on_device=True)
+# (round 5: bench.py's own problems -- seed 5, the box-constrained one with its nominal u ~ 0.3 N clamped -- and 30 solves, so
+# that the LAST one, which --read prints, runs in the sustained state like the bench rows)
+if "nn" in sys.argv:                               # bench.py's nn_mpc_forward_5iter: NNDynamics(12, 4, [100]) as the dynamics
+    from mpc.dynamics import NNDynamics
+    torch.manual_seed(0)
+    dyn = NNDynamics(12, 4, [100], activation="sigmoid").to("cuda:0")
+    p = bench.make_problem(12, 4, 50, 4096, torch.float32, "cuda:0", seed=5, u_scale=0.3, clamp=1.0)
+    ctrl = mpc.MPC(12, 4, 50, u_lower=-1.0, u_upper=1.0, lqr_iter=5, verbose=-1, exit_unconverged=False, detach_unconverged=False,
+                   grad_method=mpc.GradMethods.ANALYTIC, backprop=False, u_init=p["cur_u"].clone())
+    with torch.no_grad():
+        for _ in range(12):
+            ctrl(p["x_init"], QuadCost(p["C"], p["c"]), dyn)
+    torch.cuda.synchronize()
+    sys.exit(0)
+p = bench.make_problem(12, 4, 50, 4096, torch.float32, "cuda:0", seed=5, u_scale=0.3 if bounded else 0.0, clamp=1.0 if bounded else None)
 ctrl = mpc.MPC(12, 4, 50, u_lower=-1.0 if bounded else None, u_upper=1.0 if bounded else None, lqr_iter=5, verbose=-1,
                exit_unconverged=False, detach_unconverged=False, backprop=False)
 cost, dx = QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"])
-for _ in range(4):
+for _ in range(30):
     ctrl(p["x_init"], cost, dx)
 torch.cuda.synchronize()
