@@ -426,6 +426,9 @@ MPC_DEV unsigned load_uniform_u32(const unsigned *g)
     return *(const_u32_t *)(unsigned long)g;
 }
 MPC_DEV float lds_f32(unsigned off) { return *(const float *)(g_stage16 + off); }
+// a word of flag bits travelling in a float slot of a record (moves and selects keep the bits)
+MPC_DEV float bits_f32(unsigned u) { return __uint_as_float(u); }
+MPC_DEV unsigned f32_bits(float f) { return __float_as_uint(f); }
 MPC_DEV f32x4 lds_f32x4(unsigned off) { return *(const f32x4 *)(g_stage16 + off); }
 MPC_DEV void store_f32x4(float *g, f32x4 v) { *(f32x4 *)g = v; }
 template <int N> MPC_DEV void dma_wait()

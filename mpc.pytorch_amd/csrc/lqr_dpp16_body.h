@@ -399,7 +399,9 @@ struct Lane {
     long ostep;           // ... and its stride per timestep
     float *scr0;          // this lane's element of the second trial's trajectory [T,B,16] (workspace) at t = 0
     long ostep1;          // = 16 B
-    int aMcol;            // SC + p*256 + 16 j                  (second record, this lane's own 16 bytes = column j of (M | m); + RollRing::MADJ)
+    int aMcol;            // SC + p*256 + 16 j                  (the m block of the stage, this lane's own granule: m for j = 12; + RollRing::MADJ)
+    int aGcol;            // SG + p*256 + 16 j                  (gain record, this lane's own granule: column j of K / M)
+    int aFm;              // SG + p*256 + 16*13 + 12            (the free-set flags of the row's problem, see sweep_step)
 };
 
 // cperm: the C blocks of this launch are staged with their rows permuted per problem slot (src_granule_C): only the
@@ -435,6 +437,8 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B, bool cperm = true)
     L.aRecF = SR + L.p * 256 + R_f + 4 * jx;
     L.aKrow = SG + L.p * 256 + 4 * L.a;
     L.aMcol = SC + L.p * 256 + 16 * L.j;
+    L.aGcol = SG + L.p * 256 + 16 * L.j;
+    L.aFm = SG + L.p * 256 + 16 * 13 + 12;
     // Quu in the gain record: lanes 13..15 carry columns 1..3 of Quu as they stand in their Q registers
     // (element r of lane 12 + c = Quu[r][c]); Quu[0][0], which only lane 12 (the k lane) holds, replaces the
     // redundant Quu[2][1] in lane 13.  Quu[a][b] is read as (column max(a,b), row min(a,b)).
@@ -466,6 +470,7 @@ struct Dma {
     const char *g_ptr;        // per lane                             imm -1024 (packed rollout)
     const char *g2_ptr;       // per lane: the (m, M) record          imm -2048 (packed rollout)
     long c_step, f_step, g_step;      // bytes per timestep (wave-uniform)
+    long g2_step;                     // ... of the m record (16 bytes per problem and timestep)
     long r_step;                      // bytes per timestep of this lane's record source
     long r_step_nof;                  // the same, but 0 on lanes that stream f (a move that leaves F / f in place)
 };
@@ -482,6 +487,7 @@ MPC_DEV void dma_seek(Dma &d, const P &p, const Lane &L, int wave)
     d.c_step = 4 * p.C_st;
     d.f_step = T > 1 ? 4 * p.F_st : 0;
     d.g_step = 4 * B * 64;
+    d.g2_step = 4 * B * 4;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int pbk = 4 * wave + k < p.B ? 4 * wave + k : p.B - 1;
@@ -524,7 +530,10 @@ MPC_DEV void dma_seek(Dma &d, const P &p, const Lane &L, int wave)
         d.r_step = st;
         d.r_step_nof = is_f ? 0 : st;
         d.g_ptr = (const char *)(p.Kk + pb * 64 + 4 * gi) + 1024 + t0 * d.g_step;
-        d.g2_ptr = (const char *)(p.Kk + (long)T * B * 64 + pb * 64 + 4 * gi) + 2048 + t0 * d.g_step;
+        // (round 5) the second record is m = qu + Quu k alone, 16 bytes per problem and timestep: every lane of a row fetches its
+        // problem's block (one request), so lane 12 finds m at its own granule of the stage's record block (M rides in the gain
+        // record, see sweep_step)
+        d.g2_ptr = (const char *)(p.Kk + (long)T * B * 64 + pb * 4) + 2048 + t0 * d.g2_step;
     }
 }
 
@@ -569,7 +578,7 @@ MPC_DEV void stage_move(Dma &d, bool move_f)
     d.r_ptr += ROLL ? rs : -rs;
     if (ROLL && !rgm(MODE)) {
         d.g_ptr += d.g_step;
-        if (con(MODE) && !DIRECT) d.g2_ptr += d.g_step;
+        if (con(MODE) && !DIRECT) d.g2_ptr += d.g2_step;
     }
 }
 
@@ -739,8 +748,8 @@ struct SwState {
     int status;
     float asym, cmax;  // max |C[j][i] - C[i][j]| and max |C[j][i]| over this lane's rows so far (the symmetry test)
     float *rec;        // this lane's 16 bytes of the gain record of the current timestep (steps back by rec_step)
-    float *rec2;       // ... of the (m, M) record
-    long rec_step;
+    float *rec2;       // the 16 bytes of m = qu + Quu k of this row's problem at the current timestep (constrained modes)
+    long rec_step, rec2_step;
 };
 
 template <int MODE>
@@ -960,7 +969,20 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     // (Rows of a partial last wave repeat problem B-1: the same values to the same addresses.)
     {
         const bool quu = L.j >= 13;
+        // (round 5, constrained modes) row a of the record is K[a] for a FREE control and M[a] = (Qux + Quu K)[a] for a pinned one:
+        // a pinned control's row of K is exactly zero, a free control's row of M is what the solve enforced -- zero but for
+        // rounding, and taken as zero from here on -- so one 4 x 12 block and four flag bits carry both.  The rollouts took M from a
+        // second 256-byte record: 512 of the 3,936 bytes a problem-step moved (written here, read back there).  m = qu + Quu k
+        // (lane 12 of M) keeps a record of its own, 16 bytes; lane 12 of THIS record stays k (mpc_lqr_qp_record).
         f32x4 rec = {sel(quu, Q[12], K[0]), sel(quu, Q[13], K[1]), sel(quu, Q[14], K[2]), sel(quu, Q[15], K[3])};
+        if (con(MODE)) {
+            const bool below12 = L.j < 12;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) rec[a] = (below12 && !fr[a]) ? M[a] : rec[a];
+            // the free-set flags in a slot of the Quu block nobody reads (element 3 of lane 13 = Quu[3][1], which is read as Quu[1][3])
+            const unsigned fm = (fr[0] ? 1u : 0u) | (fr[1] ? 2u : 0u) | (fr[2] ? 4u : 0u) | (fr[3] ? 8u : 0u);
+            rec[3] = sel(L.j == 13, wv::bits_f32(fm), rec[3]);
+        }
         rec[2] = sel(L.j == 13, S.s00, rec[2]);
         if (rgm(MODE)) {
             gain_put(G, t, rec);                         // stays in the register file until the rollouts
@@ -969,8 +991,8 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
             st.rec -= st.rec_step;
         }
         if (con(MODE)) {
-            wv::store_f32x4(st.rec2, f32x4{M[0], M[1], M[2], M[3]});       // lanes 13..15: never read
-            st.rec2 -= st.rec_step;
+            if (j12) wv::store_f32x4(st.rec2, f32x4{M[0], M[1], M[2], M[3]});       // m = qu + Quu k
+            st.rec2 -= st.rec2_step;
         }
 #ifndef MPC_DPP16_PROF
         if (p.K != nullptr) {
@@ -1039,8 +1061,12 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
         if (con(MODE)) {
             // (round 4: e'(m + M dx) = sum_j [dx_j; 1] (M | m)'e -- each lane needs ITS column, one 16-byte read, and four
             // broadcast multiply-adds of e; rounds 1-3 read row a of M on the control lanes: 13 reads, 12 multiply-adds)
-            const f32x4 mc = wv::lds_f32x4(mrec + L.aMcol);
-            s.Mc[0] = mc[0]; s.Mc[1] = mc[1]; s.Mc[2] = mc[2]; s.Mc[3] = mc[3];
+            // (round 5: column j of M is this lane's own granule of the GAIN record, the rows of the pinned controls; m has the
+            // 16-byte record of its own, lane 12's granule of the stage's m block)
+            const f32x4 mc = wv::lds_f32x4(L.j == 12 ? mrec + L.aMcol : gain + L.aGcol);
+            const unsigned fm = wv::f32_bits(wv::lds_f32(gain + L.aFm));
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s.Mc[a] = (L.j == 12 || !((fm >> a) & 1u)) ? mc[a] : 0.f;
         }
     }
     // (t = T-1: a copy of F[T-2], unused)
@@ -1053,6 +1079,13 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
     if (!rgm(MODE)) {
 #pragma unroll
         for (int jj = 0; jj < 12; ++jj) s.Kr[jj] = wv::lds_f32(gain + L.aKrow + 16 * jj);
+        if (con(MODE)) {
+            // a pinned control's row of the record is its row of M (sweep_step): its row of K is zero
+            const unsigned fm = wv::f32_bits(wv::lds_f32(gain + L.aFm));
+            const bool free_a = ((fm >> L.a) & 1u) != 0u;
+#pragma unroll
+            for (int jj = 0; jj < 12; ++jj) s.Kr[jj] = free_a ? s.Kr[jj] : 0.f;
+        }
         s.kk = wv::lds_f32(gain + L.aKrow + 192);
     } else {
         s.kk = 0.f;
@@ -1453,7 +1486,8 @@ MPC_DEV void step_wave(const P &p)
     ss.kprev[0] = ss.kprev[1] = ss.kprev[2] = ss.kprev[3] = 0.f;
     ss.rec_step = (long)p.B * 64;
     ss.rec = p.Kk + ((long)(T - 1) * p.B + L.pb) * 64 + 4 * L.j;
-    ss.rec2 = ss.rec + (long)T * p.B * 64;
+    ss.rec2_step = (long)p.B * 4;
+    ss.rec2 = p.Kk + (long)T * p.B * 64 + ((long)(T - 1) * p.B + L.pb) * 4;
     {
         unsigned zq[NSTAGE] = {};
         dma_seek<MODE, false, false>(d, p, L, wave);

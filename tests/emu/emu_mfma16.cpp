@@ -473,6 +473,8 @@ template <int N> static inline void dma_wait()
     if (emu::W.cur == 0) emu::dma_land(emu::g_dma_late ? N : 0);
 }
 static inline unsigned load_uniform_u32(const unsigned *g) { return *g; }
+static inline float bits_f32(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned f32_bits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float lds_f32(unsigned off)
 {
     float v;
