@@ -152,7 +152,7 @@ def reference_parity(o, r, n, bounded):
     """the HIP result of the timed launch against the unmodified reference's own
     float32 run on the same problems, in the same run.  Unbounded: rtol 1e-3 / atol 1e-4, asserted.  Box-constrained: the
     reference's pnqp is batch-global (it iterates until ALL problems of the chunk have converged) and its
-    float32 Armijo test is cancellation noise near convergence, so its own float32 run deviates from its
+    float32 Armijo test is cancellation noise near convergence (CHANGELOG.md 4.5), so its own float32 run deviates from its
     float64 one by more than the tolerance on some problems: reported (share of problems within tolerance), not asserted --
     the asserted check of those rows is `parity`, against the float64 oracle."""
     import numpy as np

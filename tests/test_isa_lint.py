@@ -1,6 +1,6 @@
 """Static checks on the gfx950 assembly of the two fused kernels (no GPU: hipcc cross-compiles).
 
-Two compiler behaviours cost the kernels 10-15 % before they were designed out:
+Two compiler behaviours cost the kernels 10-15 % before they were designed out (CHANGELOG.md 4.1, 4.4a):
 a select between two elements of a small local array turns the array into scratch memory, and a vector
 load whose result crosses the timestep loop (a mask, a bound row) makes the compiler put
 `s_waitcnt vmcnt(0)` -- a drain of the staging DMAs -- in front of every use.  tools/isa_lint.py finds both."""
@@ -51,7 +51,7 @@ def _metadata(name):
 
 
 # Scalar-register spills per kernel, as built for round 3 (+10 % head room): a spilled SGPR is a v_writelane / v_readlane
-# pair in the loops, cheap one by one, and the count crept from 162 to 486 over round 2 unnoticed.  A
+# pair in the loops (CHANGELOG.md 8.7), cheap one by one, and the count crept from 162 to 486 over round 2 unnoticed.  A
 # change that pushes a kernel past its line here has to look at where the new spills execute (tools/isa_lint.py --loops).
 SGPR_SPILL_LIMITS = {
     "lqr_dpp16": {"kernelILi0E": 200, "kernelILi1E": 440, "kernelILi2E": 550, "kernelILi3E": 160, "kkt_fused": 8},

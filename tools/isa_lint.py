@@ -9,7 +9,7 @@
                                       #   * VGPR / AGPR / spill counts
   python tools/isa_lint.py --loops lqr_dpp16 'Li0EEE'   # instruction mix of every loop of the kernels matching the regex
 
-Both findings cost config 5 10 % and the masked headline step 12 % before they were removed."""
+Both findings cost config 5 10 % and the masked headline step 12 % before they were removed (CHANGELOG.md 4.4a, 4.5)."""
 import collections, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mpc.pytorch_amd", "csrc")
