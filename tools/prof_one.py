@@ -4,7 +4,7 @@ so that a per-kernel average in profiles/r04_prof_*.json is the average of exact
 round-3 summaries mixed sweep-only, vouched and bare calls of one kernel in one average).
 
     python tools/prof_one.py KIND [reps [warm]]
-    KIND: headline | headline_bare | bounded | kkt | kkt_bounded | cfg5 | cfg5_bare | cfg5_bounded | cfg5_kkt | cfg5_kkt_bounded |
+    KIND: headline | headline_alt (two problem sets, alternating: bench.py's timed region) | headline_bare | bounded | kkt | kkt_bounded | cfg5 | cfg5_bare | cfg5_bounded | cfg5_kkt | cfg5_kkt_bounded |
           cfg5_B8192 | cfg5_bounded_B8192 | bounded_warm | cfg5_bounded_warm   (_warm: the box QPs started from the k an earlier
           step at the same nominal left in the workspace, mpc_lqr_options.qp_start)
 The problems are bench.py's (same seeds, same options as the rows of its `extra` object)."""
@@ -44,6 +44,15 @@ if "kkt" in kind:
     gx, gu = torch.randn(nx.shape, generator=g, device=dev), torch.randn(nu.shape, generator=g, device=dev)
     ko = StepOptions(c_symmetric=True, **kw)
     fn = be.plan_kkt_backward(p["C"], p["c"], p["F"], p["f"], nx, nu, gx, gu, ko)
+elif kind == "headline_alt":
+    # bench.py's timed region: the launches alternate between TWO problem sets (no launch finds its own inputs in the Infinity Cache)
+    p2 = bench.make_problem(ns, nc, T, B, torch.float32, dev, seed=5 + 7919)
+    plans = [be.plan_step(*a, opts), be.plan_step(p2["x_init"], p2["C"], p2["c"], p2["F"], p2["f"], p2["cur_x"], p2["cur_u"], opts)]
+    turn = [0]
+
+    def fn():
+        turn[0] ^= 1
+        return plans[turn[0]]()
 else:
     fn = be.plan_step(*a, opts)
     if kind.endswith("_warm"):

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-bash tools/r05_profiles.sh headline bounded bounded_warm cfg5 cfg5_bounded cfg5_bounded_warm kkt cfg5_kkt
-for k in headline bounded bounded_warm cfg5 cfg5_bounded cfg5_bounded_warm kkt cfg5_kkt; do
+bash tools/r05_profiles.sh ${KINDS:-headline headline_alt bounded bounded_warm cfg5 cfg5_bounded cfg5_bounded_warm kkt cfg5_kkt}
+for k in ${KINDS:-headline headline_alt bounded bounded_warm cfg5 cfg5_bounded cfg5_bounded_warm kkt cfg5_kkt}; do
   python - $k <<'PY'
 import json, sys
 k = sys.argv[1]
