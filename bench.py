@@ -640,6 +640,21 @@ def extra_rows(be, dev, steps):
         row["speedup_over_generic"] = rowg["ms"] / row["ms"]
         rows["pad_step_%d_%d_B1024" % (ns_p, nc_p)] = row
         del p
+    # ---- float64 (round 5): what every test and gradient check of the reference runs in (tests/test_mpc.py .double()).  n_state <= 12,
+    # n_ctrl <= 4 take the one-problem-per-wavefront kernel's float64 instantiation (v_mfma_f64_16x16x4_f64); rounds 1-4: the generic kernel
+    for bounded64 in (False, True):
+        p = make_problem(NS, NC, T_H, 1024, torch.float64, dev, seed=77, u_scale=0.3 if bounded64 else 0.0, clamp=1.0 if bounded64 else None)
+        o64 = StepOptions(u_lower=-1.0, u_upper=1.0) if bounded64 else StepOptions()
+        row, _ = step_row(p, o64, NS, NC, T_H, 1024)
+        rowg, _ = step_row(p, o64, NS, NC, T_H, 1024, impl=1)
+        ab = algorithmic_bytes_per_problem(NS, NC, T_H, elem=8) * 1024
+        row["roofline"] = hbm_roofline(ab, row["ms"])
+        row["generic_kernel_ms"] = rowg["ms"]
+        row["speedup_over_generic"] = rowg["ms"] / row["ms"]
+        row["workload"] = ("headline shape in FLOAT64, B=1024%s, a bare LQRStep call: lqr_step_mfma16_f64_kernel; generic_kernel_ms = the same call "
+                           "forced onto the generic kernel (rounds 1-4)" % (", box bounds +-1" if bounded64 else ""))
+        rows["lqr_step_f64_12_4_B1024" + ("_bounded" if bounded64 else "")] = row
+        del p
     torch.cuda.empty_cache()
     # ---- configs 2 / 3: the shipped simulators, whole 10-iteration iLQR solves (L2-resident: latency-bound) ----
     from tools.bench_ilqr_env import problem as env_problem

@@ -263,8 +263,22 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
                 return rc ? rc : resolve_asymmetric(sp, impl, workspace, needK, st);
             }
             sp.Kk = nullptr;
-        } else if (impl == 2 || impl == 3) {
-            return fail(MPC_E_DTYPE, "the fused kernels are fp32 only");
+        } else {
+            // float64 (round 5): n_state <= 12, n_ctrl <= 4 on the one-problem-per-wavefront kernel's float64 instantiation
+            // (v_mfma_f64_16x16x4_f64); what every test and gradient check of the reference runs in (tests/test_mpc.py .double())
+            if (impl == 3) return fail(MPC_E_DTYPE, "the 4-problems-per-wave kernel is fp32 only");
+            const bool mfma = mfma16_supported(sp);
+            if (impl == 2 && !mfma)
+                return fail(MPC_E_DIMS, "fused MFMA kernel needs n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16");
+            if (mfma) {
+                const int64_t need = (int64_t)p->T * p->B * 64 * (int64_t)sizeof(double);
+                if (!(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0)))
+                    return fail(MPC_E_ARG, "workspace too small or not 16-byte aligned (see mpc_lqr_workspace_bytes)");
+                if ((sp.K == nullptr) != (sp.k == nullptr)) return fail(MPC_E_NULL, "pass both K and k, or neither");
+                sp.Kk = (real *)workspace;
+                const int rc = launch_step_mfma16(sp, st);
+                return rc ? rc : resolve_asymmetric(sp, impl, workspace, needK, st);
+            }
         }
     }
     if constexpr (sizeof(real) == 4) {
@@ -367,6 +381,11 @@ int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, i
         mpc_lqr_outputs out;
         memset(&out, 0, sizeof(out));
         return mfma40_pad_supported(make_params<float>(p, o, &out)) ? 1 : 0;
+    }
+    if (impl == 2 && p->dtype == MPC_F64) {
+        mpc_lqr_outputs out;
+        memset(&out, 0, sizeof(out));
+        return mfma16_supported(make_params<double>(p, o, &out)) ? 1 : 0;
     }
     if (impl == 2 || impl == 3) {
         if (p->dtype != MPC_F32) return 0;

@@ -101,5 +101,7 @@ int launch_nn_linearize(const mpc_mlp_dynamics *net, long N, int ns, int nc, con
 // fused MFMA path for n <= 16, f32 (lqr_mfma16.hip)
 bool mfma16_supported(const StepParams<float> &p);
 int launch_step_mfma16(const StepParams<float> &p, hipStream_t st);
+bool mfma16_supported(const StepParams<double> &p);          // (round 5) the same kernel on v_mfma_f64_16x16x4_f64
+int launch_step_mfma16(const StepParams<double> &p, hipStream_t st);
 
 }  // namespace mpclqr

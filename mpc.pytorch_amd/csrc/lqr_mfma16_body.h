@@ -50,26 +50,43 @@
 // (mpc/mpc.py:61-68; its own delta-space gradient C tau + c, :294, is only a
 // gradient for symmetric C).
 // ---------------------------------------------------------------------------
-#pragma once
+// (round 5) Included once per element type, like lqr_small_math.h: float / namespace mfma16 by default, double / mfma16d with
+// MPC_M16_F64 defined -- the float64 instantiation (v_mfma_f64_16x16x4_f64 has the lane layout of the float32 instruction; LDS offsets and DMA
+// granules scale with the element size ES).
 #include <math.h>
 #include "lqr_params.h"
 #include "lqr_small_math.h"
+#if (defined(MPC_M16_F64) && !defined(MPC_MFMA16_BODY_F64)) || (!defined(MPC_M16_F64) && !defined(MPC_MFMA16_BODY_F32))
+#undef MPC_M16_REAL
+#undef MPC_M16_NS
+#ifdef MPC_M16_F64
+#define MPC_MFMA16_BODY_F64
+#define MPC_M16_REAL double
+#define MPC_M16_NS mfma16d
+#else
+#define MPC_MFMA16_BODY_F32
+#define MPC_M16_REAL float
+#define MPC_M16_NS mfma16
+#endif
 
 namespace mpclqr {
-namespace mfma16 {
+namespace MPC_M16_NS {
 
-typedef StepParams<float> P;
-using wv::f32x4;
+typedef StepParams<real> P;
+typedef typename wv::vec4_of<real>::type rx4;
+constexpr int ES = (int)sizeof(real);        // bytes per element
+constexpr int GE = 16 / ES;                  // elements per 16-byte DMA granule
 
 // LDS layout (bytes): a ring of NSTAGE stages + 64 B of scratch.  The record of small vectors is
 // laid out so that in the n_state = 12, n_ctrl = 4 case every piece starts on a 16-byte granule
 // (one DMA lane each).
 enum {
-    LDS_C = 0, LDS_F = 1024, LDS_V = 1792,
-    V_c = 0, V_tau = 64, V_f = 128, V_lo = 192, V_hi = 208, V_K = 224, V_zero = 480,
-    STAGE_BYTES = 2288, NSTAGE = 4,
-    LDS_SCRATCH = NSTAGE * STAGE_BYTES, LDS_TOTAL = LDS_SCRATCH + 64,
-    DMA_PER_STAGE_FULL = 3,     // C, F, record
+    LDS_C = 0, LDS_F = 256 * ES, LDS_V = 448 * ES,
+    V_c = 0, V_tau = 16 * ES, V_f = 32 * ES, V_lo = 48 * ES, V_hi = 52 * ES, V_K = 56 * ES, V_zero = 120 * ES,
+    STAGE_BYTES = 572 * ES, NSTAGE = 4,
+    LDS_SCRATCH = NSTAGE * STAGE_BYTES, LDS_TOTAL = LDS_SCRATCH + 16 * ES,
+    C_GRAN = 256 / GE, F_GRAN = 192 / GE,                                  // 16-byte granules of a full C / F block
+    DMA_PER_STAGE_FULL = (C_GRAN + 63) / 64 + (F_GRAN + 63) / 64 + 1,      // C, F, record (float: 1 + 1 + 1, double: 2 + 2 + 1)
     DMA_PER_STAGE_MIN = 5       // padded shapes: at least C, F, c, x, u (one instruction each)
 };
 
@@ -91,8 +108,8 @@ struct Lane {
     int aKA;              // u columns: the 16 B  Kk[ja][4g .. 4g+3];  elsewhere: zeros
     int aKk;              // Kk[g][0] = k_g
     int aG;               // 4 * g  (+LDS_V+V_lo / V_hi)
-    float eg[4];          // one-hot of g
-    float nea[4];         // -1 at (u column, ja == a), else 0
+    real eg[4];          // one-hot of g
+    real nea[4];         // -1 at (u column, ja == a), else 0
 };
 
 MPC_DEV void lane_init(Lane &L, int lane, int ns, int nc)
@@ -116,21 +133,21 @@ MPC_DEV void lane_init(Lane &L, int lane, int ns, int nc)
         else { const int x = 3 * L.g + r - 1; L.rowv[r] = x < ns; L.row[r] = x; tau = x; }
         if (!L.rowv[r]) { L.row[r] = 0; tau = 0; }
         L.vC[r] = L.rowv[r] && L.colv;
-        L.aC[r] = LDS_C + (L.vC[r] ? 4 * (tau * n + coltau) : 0);
-        L.aCt[r] = LDS_C + (L.vC[r] ? 4 * (coltau * n + tau) : 0);
-        L.aT[r] = 4 * tau;
+        L.aC[r] = LDS_C + (L.vC[r] ? ES * (tau * n + coltau) : 0);
+        L.aCt[r] = LDS_C + (L.vC[r] ? ES * (coltau * n + tau) : 0);
+        L.aT[r] = ES * tau;
         L.aQi[r] = L.j0 ? LDS_V + V_c + L.aT[r] : L.aC[r];
         L.aTb[r] = L.j0 ? LDS_V + V_tau + L.aT[r] : LDS_V + V_zero;
         // rollout: output row = state x(j) (x columns only), contraction slot = (g, r)
         L.vT[r] = L.rowv[r] && L.colv && !L.jq;
-        L.aFT[r] = LDS_F + (L.vT[r] ? 4 * (coltau * n + tau) : 0);
+        L.aFT[r] = LDS_F + (L.vT[r] ? ES * (coltau * n + tau) : 0);
         L.eg[r] = L.g == r ? 1.f : 0.f;
         L.nea[r] = (L.jq && L.ja == r) ? -1.f : 0.f;
     }
     L.vK = L.jq && L.ja < nc;
-    L.aKA = L.vK ? LDS_V + V_K + 4 * (16 * L.ja + 4 * L.g) : LDS_V + V_zero;
-    L.aKk = LDS_V + V_K + 4 * 16 * L.g;
-    L.aG = L.rowv[0] ? 4 * L.g : 0;
+    L.aKA = L.vK ? LDS_V + V_K + ES * (16 * L.ja + 4 * L.g) : LDS_V + V_zero;
+    L.aKk = LDS_V + V_K + ES * 16 * L.g;
+    L.aG = L.rowv[0] ? ES * L.g : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -153,24 +170,26 @@ MPC_DEV void vecdma_init(VecDma &v, const P &p, int lane, int b, int t0)
     const char *q = (const char *)p.c;
     long st = 0;
     const long B = p.B;
-    if (lane < 4) {
-        v.active = true; q = (const char *)(p.c + (long)b * p.c_sb + 4 * lane); st = 4 * p.c_st;
-    } else if (lane < 7) {
-        v.active = true; q = (const char *)(p.cur_x + (long)b * 12 + 4 * (lane - 4)); st = 4 * B * 12;
-    } else if (lane == 7) {
-        v.active = true; q = (const char *)(p.cur_u + (long)b * 4); st = 4 * B * 4;
-    } else if (lane < 11) {
+    // the record in ELEMENTS: 0-15 c | 16-27 x | 28-31 u | 32-43 f | 48-51 lo | 52-55 hi | 56-119 Kk; lane = 16-byte granule = GE elements
+    const int e = lane * GE;
+    if (e < 16) {
+        v.active = true; q = (const char *)(p.c + (long)b * p.c_sb + e); st = ES * p.c_st;
+    } else if (e < 28) {
+        v.active = true; q = (const char *)(p.cur_x + (long)b * 12 + (e - 16)); st = (long)ES * B * 12;
+    } else if (e < 32) {
+        v.active = true; q = (const char *)(p.cur_u + (long)b * 4 + (e - 28)); st = (long)ES * B * 4;
+    } else if (e < 44) {
         if (ROLL && p.f && p.T > 1) {
             v.active = true; v.is_f = true;
-            q = (const char *)(p.f + (long)b * p.f_sb + 4 * (lane - 8)); st = 4 * p.f_st;
+            q = (const char *)(p.f + (long)b * p.f_sb + (e - 32)); st = ES * p.f_st;
         }
-    } else if (lane == 11) {
-    } else if (lane < 14) {
+    } else if (e < 48) {
+    } else if (e < 56) {
         if (MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR) {
-            v.active = true; q = (const char *)((lane == 12 ? p.lo : p.hi) + (long)b * 4); st = 4 * B * 4;
+            v.active = true; q = (const char *)((e < 52 ? p.lo : p.hi) + (long)b * 4 + (e < 52 ? e - 48 : e - 52)); st = (long)ES * B * 4;
         }
-    } else if (lane < 30) {
-        if (ROLL) { v.active = true; q = (const char *)(p.Kk + (long)b * 64 + 4 * (lane - 14)); st = 4 * B * 64; }
+    } else if (e < 120) {
+        if (ROLL) { v.active = true; q = (const char *)(p.Kk + (long)b * 64 + (e - 56)); st = (long)ES * B * 64; }
     }
     v.ptr = q + (long)t0 * st;
     v.step = ROLL ? st : -st;
@@ -184,41 +203,49 @@ MPC_DEV void stage_issue(const P &p, VecDma &vd, int lane, int b, int t, int slo
 {
     const unsigned base = (unsigned)slot * STAGE_BYTES;
     const int n = p.ns + p.nc;
-    const float *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
+    const real *Ct = p.C + (long)t * p.C_st + (long)b * p.C_sb;
     // F has T-1 entries; the last timestep re-reads a valid block nobody looks at
-    const float *Ft = Ct;
+    const real *Ft = Ct;
     const int tf = t < p.T - 1 ? t : p.T - 2;
     if (p.T > 1) Ft = p.F + (long)tf * p.F_st + (long)b * p.F_sb;
     if (FULL) {
         const unsigned lo16 = 16u * (unsigned)lane;
-        wv::dma16((const char *)Ct + lo16, base + LDS_C);
-        if (lane < 48) wv::dma16((const char *)Ft + lo16, base + LDS_F);
+#pragma unroll
+        for (int i = 0; i < (C_GRAN + 63) / 64; ++i)
+            if (lane + 64 * i < C_GRAN) wv::dma16r<real>((const char *)Ct + 1024 * i + lo16, base + LDS_C + 1024 * i);
+#pragma unroll
+        for (int i = 0; i < (F_GRAN + 63) / 64; ++i)
+            if (lane + 64 * i < F_GRAN) wv::dma16r<real>((const char *)Ft + 1024 * i + lo16, base + LDS_F + 1024 * i);
         if (vd.active) {
             const char *src = vd.ptr;
             if (ROLL && vd.is_f && t >= p.T - 1) src -= vd.step;
-            wv::dma16(src, base + LDS_V);
+            wv::dma16r<real>(src, base + LDS_V);
         }
         if (advance) vd.ptr += vd.step;
     } else {
+        // element by element, as 4-byte words (a double is two of them): the blocks land densely packed from their LDS base
+        constexpr int W = ES / 4;
         const long tb = (long)t * p.B + b;
-        const int n2 = n * n, nf = p.T > 1 ? p.ns * n : 1;
+        const int n2 = n * n * W, nf = p.T > 1 ? p.ns * n * W : 1;
+        typedef const float *wp;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i * 64 < n2) { const int e = lane + 64 * i; if (e < n2) wv::dma4(Ct + e, base + LDS_C + 256 * i); }
+        for (int i = 0; i < 4 * W; ++i)
+            if (i * 64 < n2) { const int e = lane + 64 * i; if (e < n2) wv::dma4r<real>((wp)Ct + e, base + LDS_C + 256 * i); }
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (i * 64 < nf) { const int e = lane + 64 * i; if (e < nf) wv::dma4(Ft + e, base + LDS_F + 256 * i); }
-        if (lane < n) wv::dma4(p.c + (long)t * p.c_st + (long)b * p.c_sb + lane, base + LDS_V + V_c);
-        if (lane < p.ns) wv::dma4(p.cur_x + tb * p.ns + lane, base + LDS_V + V_tau);
-        if (lane < p.nc) wv::dma4(p.cur_u + tb * p.nc + lane, base + LDS_V + V_tau + 4 * p.ns);
+        for (int i = 0; i < 3 * W; ++i)
+            if (i * 64 < nf) { const int e = lane + 64 * i; if (e < nf) wv::dma4r<real>((wp)Ft + e, base + LDS_F + 256 * i); }
+        if (lane < n * W) wv::dma4r<real>((wp)(p.c + (long)t * p.c_st + (long)b * p.c_sb) + lane, base + LDS_V + V_c);
+        if (lane < p.ns * W) wv::dma4r<real>((wp)(p.cur_x + tb * p.ns) + lane, base + LDS_V + V_tau);
+        if (lane < p.nc * W) wv::dma4r<real>((wp)(p.cur_u + tb * p.nc) + lane, base + LDS_V + V_tau + ES * p.ns);
         if (MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR) {
-            if (lane < p.nc) wv::dma4(p.lo + tb * p.nc + lane, base + LDS_V + V_lo);
-            if (lane < p.nc) wv::dma4(p.hi + tb * p.nc + lane, base + LDS_V + V_hi);
+            if (lane < p.nc * W) wv::dma4r<real>((wp)(p.lo + tb * p.nc) + lane, base + LDS_V + V_lo);
+            if (lane < p.nc * W) wv::dma4r<real>((wp)(p.hi + tb * p.nc) + lane, base + LDS_V + V_hi);
         }
         if (ROLL) {
-            if (p.f && p.T > 1 && lane < p.ns)
-                wv::dma4(p.f + (long)tf * p.f_st + (long)b * p.f_sb + lane, base + LDS_V + V_f);
-            wv::dma4(p.Kk + tb * 64 + lane, base + LDS_V + V_K);
+            if (p.f && p.T > 1 && lane < p.ns * W)
+                wv::dma4r<real>((wp)(p.f + (long)tf * p.f_st + (long)b * p.f_sb) + lane, base + LDS_V + V_f);
+#pragma unroll
+            for (int i = 0; i < W; ++i) wv::dma4r<real>((wp)(p.Kk + tb * 64) + lane + 64 * i, base + LDS_V + V_K + 256 * i);
         }
     }
 }
@@ -238,39 +265,39 @@ MPC_DEV int zm_load(const P &p, const Lane &L, int b, int t)
 // Sweep
 // ---------------------------------------------------------------------------
 struct SwStage {
-    float C[4];       // C_t in D layout (register r = row slot 4g+r)
-    float Qi[4];      // the same with column 0 replaced by c_t (row layout): accumulator init of Q'
-    float Tb[4];      // nominal tau_t in row layout in column 0, zeros elsewhere (B operand of C tau)
-    float F[3];       // F_t rows x-slot(g,kb), kb = 1..3, at column var(j)
-    float lo, hi;     // control bounds of u_g (tensor or scalar mode)
+    real C[4];       // C_t in D layout (register r = row slot 4g+r)
+    real Qi[4];      // the same with column 0 replaced by c_t (row layout): accumulator init of Q'
+    real Tb[4];      // nominal tau_t in row layout in column 0, zeros elsewhere (B operand of C tau)
+    real F[3];       // F_t rows x-slot(g,kb), kb = 1..3, at column var(j)
+    real lo, hi;     // control bounds of u_g (tensor or scalar mode)
     int zm;           // u_zero_I of u_g
 };
 
 // MODE: 0 = unconstrained, 1 = unconstrained with u_zero_I (the KKT backward's solve), 2 = box bounds
 template <bool FULL, int MODE>
-MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, int zm, float &asym, float &cmax)
+MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, int zm, real &asym, real &cmax)
 {
     const unsigned base = (unsigned)slot * STAGE_BYTES;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float v = wv::lds_f32(base + L.aC[r]);
+        const real v = wv::lds_r<real>(base + L.aC[r]);
         s.C[r] = FULL ? v : sel(L.vC[r], v, 0.f);
         // the D-layout C serves as its own A operand below -- true for a symmetric C only; the reference takes C as it
         // is (mpc/lqr_step.py:68, 294).  Keep the largest |C - C'| entry and the largest |C| (-> MPC_ST_C_ASYMMETRIC).
         if (!p.c_symmetric) {
-            const float vt = wv::lds_f32(base + L.aCt[r]);
-            asym = fmaxf(asym, fabsf(v - vt));       // (padding lanes read one entry twice: 0)
-            cmax = fmaxf(cmax, fabsf(s.C[r]));
+            const real vt = wv::lds_r<real>(base + L.aCt[r]);
+            asym = rmax(asym, rabs(v - vt));       // (padding lanes read one entry twice: 0)
+            cmax = rmax(cmax, rabs(s.C[r]));
         }
-        const float w = wv::lds_f32(base + L.aQi[r]);
+        const real w = wv::lds_r<real>(base + L.aQi[r]);
         s.Qi[r] = FULL ? w : sel(L.j0 ? L.rowv[r] : L.vC[r], w, 0.f);
-        const float u = wv::lds_f32(base + L.aTb[r]);
+        const real u = wv::lds_r<real>(base + L.aTb[r]);
         s.Tb[r] = FULL ? u : sel(L.rowv[r], u, 0.f);
     }
     if (t < p.T - 1) {
 #pragma unroll
         for (int kb = 1; kb < 4; ++kb) {
-            const float v = wv::lds_f32(base + (LDS_F - LDS_C) + L.aC[kb]);
+            const real v = wv::lds_r<real>(base + (LDS_F - LDS_C) + L.aC[kb]);
             s.F[kb - 1] = FULL ? v : sel(L.vC[kb], v, 0.f);
         }
     } else {
@@ -279,8 +306,8 @@ MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, int
     s.lo = s.hi = 0.f;
     if (MODE == 2) {
         if (p.bound_mode == MPC_BOUND_TENSOR) {
-            s.lo = wv::lds_f32(base + LDS_V + V_lo + L.aG);
-            s.hi = wv::lds_f32(base + LDS_V + V_hi + L.aG);
+            s.lo = wv::lds_r<real>(base + LDS_V + V_lo + L.aG);
+            s.hi = wv::lds_r<real>(base + LDS_V + V_hi + L.aG);
         } else {
             s.lo = p.lo_s;
             s.hi = p.hi_s;
@@ -290,51 +317,51 @@ MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, int
 }
 
 struct SwState {
-    f32x4 Vp;          // V' in D layout: rows/cols = x slots, column 0 = v, u slots = finite junk
-    float oc;          // nominal-cost partial (lanes j == 0)
-    float kprev[4];    // warm start of the next pnqp = k_{t+1}   (mpc/lqr_step.py:137,141)
+    rx4 Vp;          // V' in D layout: rows/cols = x slots, column 0 = v, u slots = finite junk
+    real oc;          // nominal-cost partial (lanes j == 0)
+    real kprev[4];    // warm start of the next pnqp = k_{t+1}   (mpc/lqr_step.py:137,141)
     int warm;
     int qp_total;
     int status;
-    float asym, cmax;  // symmetry test of C: largest |C[i][j] - C[j][i]|, largest |C[i][j]| seen by this lane
+    real asym, cmax;  // symmetry test of C: largest |C[i][j] - C[j][i]|, largest |C[i][j]| seen by this lane
 };
 
 template <bool FULL, int MODE>
 MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st, int b, int t)
 {
     const bool last = (t == p.T - 1);
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const rx4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // c_back - c = C tau  (mpc/lqr_step.py:289-295): contraction over all 16 slots, column 0 only
-    f32x4 CB = zero4;
+    rx4 CB = zero4;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) CB = wv::mfma(s.C[kb], s.Tb[kb], CB);
 
     // Y = V_{t+1} F_t   (:65-70), x slots only (kb = 1..3)
-    f32x4 Y = zero4;
-    f32x4 Q = {s.Qi[0], s.Qi[1], s.Qi[2], s.Qi[3]};
-    float q00p = 0.f;
+    rx4 Y = zero4;
+    rx4 Q = {s.Qi[0], s.Qi[1], s.Qi[2], s.Qi[3]};
+    real q00p = 0.f;
     if (!last) {
 #pragma unroll
         for (int kb = 1; kb < 4; ++kb) Y = wv::mfma(st.Vp[kb], s.F[kb - 1], Y);
         // Q = C + F'Y ; column 0: F'v  (Y's column 0 is swapped for v = V'[:,0])
-        q00p = fmaf(s.F[2], Y[3], fmaf(s.F[1], Y[2], s.F[0] * Y[1]));
+        q00p = rfma(s.F[2], Y[3], rfma(s.F[1], Y[2], s.F[0] * Y[1]));
 #pragma unroll
         for (int kb = 1; kb < 4; ++kb) Q = wv::mfma(s.F[kb - 1], sel(L.j0, st.Vp[kb], Y[kb]), Q);
     }
     // nominal cost 0.5 tau'C tau + c'tau (util.get_cost, mpc/lqr_step.py:169) off the same product:
     // Tb is tau in column 0 and zero elsewhere, Qi is c there
     {
-        float ocl = st.oc;
+        real ocl = st.oc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ocl = fmaf(s.Tb[r], fmaf(0.5f, CB[r], s.Qi[r]), ocl);
+        for (int r = 0; r < 4; ++r) ocl = rfma(s.Tb[r], rfma((real)0.5, CB[r], s.Qi[r]), ocl);
         st.oc = ocl;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) Q[r] += CB[r];          // CB is exactly 0 outside column 0
 
     // ---- the 4x4 control block, wave-uniform -------------------------------------------------
-    const float U = Q[0];        // lane (g,j): Q[u_g][var j]; lane (g,0): qu[g]
+    const real U = Q[0];        // lane (g,j): Q[u_g][var j]; lane (g,0): qu[g]
     Sym4 S;
     S.s01 = wv::readlane(U, 4);  S.s02 = wv::readlane(U, 8);  S.s03 = wv::readlane(U, 12);
     S.s11 = wv::readlane(U, 20); S.s12 = wv::readlane(U, 24); S.s13 = wv::readlane(U, 28);
@@ -348,7 +375,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #pragma unroll
     for (int a = 0; a < 4; ++a) valid[a] = a < p.nc;
     Ldl4 f;
-    float kq[4] = {0.f, 0.f, 0.f, 0.f};
+    real kq[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE != 2) {
         // :84-94 unconstrained / :99-127 masked (u_zero_I): masked rows and columns drop out
 #pragma unroll
@@ -356,18 +383,18 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
             fr[a] = valid[a];
             if (MODE == 1) fr[a] = fr[a] && (wv::readlane_i(s.zm, 16 * a) == 0);
         }
-        float sing = 0.f;
+        real sing = 0.f;
         ldl4<(!FULL || MODE == 1), MODE == 0>(f, S, fr, 0.f, &sing);          // MODE 0: the reference's pinverse (pivot_inv)
         if (MODE == 0 && sing != 0.f) st.status |= MPC_ST_QUU_SINGULAR;
     } else {
         // :128-141 box constraints in delta space
-        float qu[4], lb[4], ub[4];
+        real qu[4], lb[4], ub[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             qu[a] = wv::readlane(U, 16 * a);
-            const float u = wv::readlane(s.Tb[0], 16 * a);
-            float l = wv::readlane(s.lo, 16 * a) - u;
-            float h = wv::readlane(s.hi, 16 * a) - u;
+            const real u = wv::readlane(s.Tb[0], 16 * a);
+            real l = wv::readlane(s.lo, 16 * a) - u;
+            real h = wv::readlane(s.hi, 16 * a) - u;
             if (p.has_delta) {                                      // :132-134
                 if (l < -p.delta_u) l = -p.delta_u;
                 if (h > p.delta_u) h = p.delta_u;
@@ -378,7 +405,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         if (!st.warm) {
             // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
             ldl4<!FULL>(f, S, valid, 0.f);
-            float y[4];
+            real y[4];
             ldl4_solve(f, valid[0] ? qu[0] : 0.f, valid[1] ? qu[1] : 0.f, valid[2] ? qu[2] : 0.f,
                        valid[3] ? qu[3] : 0.f, y);
 #pragma unroll
@@ -399,37 +426,37 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     }
 
     // A operand of K' = -H_free^-1 [Qux | qu]: lane (i = 4a, g) holds -inv[a][g]
-    float Ainv;
+    real Ainv;
     {
-        float y[4];
+        real y[4];
         ldl4_solve(f, L.eg[0], L.eg[1], L.eg[2], L.eg[3], y);
         if (!FULL || MODE != 0) {
             // rows / columns outside the free set are exactly zero (the factor holds identity there)
-            const float fg = dot4(L.eg, fr[0] ? 1.f : 0.f, fr[1] ? 1.f : 0.f, fr[2] ? 1.f : 0.f, fr[3] ? 1.f : 0.f);
+            const real fg = dot4(L.eg, fr[0] ? 1.f : 0.f, fr[1] ? 1.f : 0.f, fr[2] ? 1.f : 0.f, fr[3] ? 1.f : 0.f);
 #pragma unroll
             for (int a = 0; a < 4; ++a) y[a] = fr[a] ? y[a] * fg : 0.f;
         }
         Ainv = dot4(L.nea, y[0], y[1], y[2], y[3]);
     }
-    const f32x4 Kacc = wv::mfma(Ainv, U, zero4);
-    float Kp = Kacc[0];           // lane (g,j): K[g][var j]; lane (g,0): k[g]
-    f32x4 Vn;
+    const rx4 Kacc = wv::mfma(Ainv, U, zero4);
+    real Kp = Kacc[0];           // lane (g,j): K[g][var j]; lane (g,0): k[g]
+    rx4 Vn;
     if (MODE == 0) {
         // K = -Quu^-1 Qux makes Qux + Quu K vanish: V = Qxx + Qxu K, v = qx + Qxu k   (:155-158)
         Vn = wv::mfma(U, Kp, Q);
     } else {
         if (MODE == 2) {
-            const float kg = dot4(L.eg, kq[0], kq[1], kq[2], kq[3]);
+            const real kg = dot4(L.eg, kq[0], kq[1], kq[2], kq[3]);
             Kp = sel(L.j0, kg, Kp);   // k is the QP solution itself (:136-141)
         }
         // A operand Quu (unmasked, :155-158): lane (i = 4a, g) holds Quu[a][g] = U at the same lane,
         // except column 0 where U carries qu: there Quu[0][g] is needed.
-        const float s0g = dot4(L.eg, S.s00, S.s01, S.s02, S.s03);
-        const float Aquu = L.jq ? sel(L.j0, s0g, U) : 0.f;
-        f32x4 Min = zero4;
+        const real s0g = dot4(L.eg, S.s00, S.s01, S.s02, S.s03);
+        const real Aquu = L.jq ? sel(L.j0, s0g, U) : 0.f;
+        rx4 Min = zero4;
         Min[0] = U;
-        const f32x4 Macc = wv::mfma(Aquu, Kp, Min);
-        const float Mp = Macc[0];     // lane (g,j): (Qux + Quu K)[g][var j]; lane (g,0): qu + Quu k
+        const rx4 Macc = wv::mfma(Aquu, Kp, Min);
+        const real Mp = Macc[0];     // lane (g,j): (Qux + Quu K)[g][var j]; lane (g,0): qu + Quu k
         // :155-158  V = Qxx + Qxu K + K'(Qux + Quu K),  v = qx + Qxu k + K'(qu + Quu k)
         Vn = wv::mfma(U, Kp, Q);
         Vn = wv::mfma(Kp, Mp, Vn);
@@ -454,14 +481,14 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 // Rollout
 // ---------------------------------------------------------------------------
 struct RoStage {
-    float C[4];       // C_t, D layout
-    float FA[4];      // F_t as A operand: lane (i = x slot, g), block kb -> F[x(i)][var(4g+kb)]
-    float KA[3];      // K_t as A operand: lane (i = 4a, g), block kb -> K[a][x-slot(g,kb)]
-    float crow[4];
-    float xbar[3];    // nominal x_t, row layout
-    float frow[3];    // f_t, row layout
-    float ubar, kk;   // nominal u_g, feed-forward k_g
-    float lo, hi;
+    real C[4];       // C_t, D layout
+    real FA[4];      // F_t as A operand: lane (i = x slot, g), block kb -> F[x(i)][var(4g+kb)]
+    real KA[3];      // K_t as A operand: lane (i = 4a, g), block kb -> K[a][x-slot(g,kb)]
+    real crow[4];
+    real xbar[3];    // nominal x_t, row layout
+    real frow[3];    // f_t, row layout
+    real ubar, kk;   // nominal u_g, feed-forward k_g
+    real lo, hi;
     int zm;
 };
 
@@ -471,21 +498,21 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, int
     const unsigned base = (unsigned)slot * STAGE_BYTES;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float v = wv::lds_f32(base + L.aC[r]);
+        const real v = wv::lds_r<real>(base + L.aC[r]);
         s.C[r] = FULL ? v : sel(L.vC[r], v, 0.f);
-        const float w = wv::lds_f32(base + LDS_V + V_c + L.aT[r]);
+        const real w = wv::lds_r<real>(base + LDS_V + V_c + L.aT[r]);
         s.crow[r] = FULL ? w : sel(L.rowv[r], w, 0.f);
     }
     if (t < p.T - 1) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const float v = wv::lds_f32(base + L.aFT[kb]);
+            const real v = wv::lds_r<real>(base + L.aFT[kb]);
             s.FA[kb] = FULL ? v : sel(L.vT[kb], v, 0.f);      // u columns feed output rows nobody reads
         }
         if (p.f) {
 #pragma unroll
             for (int kb = 1; kb < 4; ++kb) {
-                const float v = wv::lds_f32(base + LDS_V + V_f + L.aT[kb]);
+                const real v = wv::lds_r<real>(base + LDS_V + V_f + L.aT[kb]);
                 s.frow[kb - 1] = FULL ? v : sel(L.rowv[kb], v, 0.f);
             }
         } else {
@@ -496,27 +523,27 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, int
         s.frow[0] = s.frow[1] = s.frow[2] = 0.f;
     }
     {
-        const f32x4 kv = wv::lds_f32x4(base + L.aKA);
+        const rx4 kv = wv::lds_r4<real>(base + L.aKA);
         s.KA[0] = FULL ? kv[1] : sel(L.rowv[1], kv[1], 0.f);
         s.KA[1] = FULL ? kv[2] : sel(L.rowv[2], kv[2], 0.f);
         s.KA[2] = FULL ? kv[3] : sel(L.rowv[3], kv[3], 0.f);
     }
 #pragma unroll
     for (int kb = 1; kb < 4; ++kb) {
-        const float v = wv::lds_f32(base + LDS_V + V_tau + L.aT[kb]);
+        const real v = wv::lds_r<real>(base + LDS_V + V_tau + L.aT[kb]);
         s.xbar[kb - 1] = FULL ? v : sel(L.rowv[kb], v, 0.f);
     }
     {
-        const float v = wv::lds_f32(base + LDS_V + V_tau + L.aT[0]);
+        const real v = wv::lds_r<real>(base + LDS_V + V_tau + L.aT[0]);
         s.ubar = FULL ? v : sel(L.rowv[0], v, 0.f);
-        const float w = wv::lds_f32(base + L.aKk);
+        const real w = wv::lds_r<real>(base + L.aKk);
         s.kk = FULL ? w : sel(L.rowv[0], w, 0.f);
     }
     s.lo = s.hi = 0.f;
     if (MODE == 2) {
         if (p.bound_mode == MPC_BOUND_TENSOR) {
-            s.lo = wv::lds_f32(base + LDS_V + V_lo + L.aG);
-            s.hi = wv::lds_f32(base + LDS_V + V_hi + L.aG);
+            s.lo = wv::lds_r<real>(base + LDS_V + V_lo + L.aG);
+            s.hi = wv::lds_r<real>(base + LDS_V + V_hi + L.aG);
         } else {
             s.lo = p.lo_s;
             s.hi = p.hi_s;
@@ -526,10 +553,10 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, int
 }
 
 struct RoState {
-    float xrow[3];    // x'_t of trial j (column j), row layout
-    float cost;       // partial of this lane (group)
-    float du2;
-    float alpha;      // step of trial j
+    real xrow[3];    // x'_t of trial j (column j), row layout
+    real cost;       // partial of this lane (group)
+    real du2;
+    real alpha;      // step of trial j
 };
 
 // MULTI = false: one trial (every column carries it; column 0 is the one read), stage cost on the
@@ -538,25 +565,25 @@ struct RoState {
 template <bool FULL, int MODE, bool MULTI>
 MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &st, int b, int t)
 {
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const rx4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const bool last = (t == p.T - 1);
     // new_u = K dx + u + alpha k   (mpc/lqr_step.py:192)
-    f32x4 Uacc = zero4;
+    rx4 Uacc = zero4;
 #pragma unroll
     for (int kb = 1; kb < 4; ++kb) Uacc = wv::mfma(s.KA[kb - 1], st.xrow[kb - 1] - s.xbar[kb - 1], Uacc);
     // x_{t+1} = F [x;u] + f  (:216-222): the x part does not wait for u
-    f32x4 Xacc = zero4;
+    rx4 Xacc = zero4;
     Xacc[1] = s.frow[0]; Xacc[2] = s.frow[1]; Xacc[3] = s.frow[2];
     if (!last) {
 #pragma unroll
         for (int kb = 1; kb < 4; ++kb) Xacc = wv::mfma(s.FA[kb], st.xrow[kb - 1], Xacc);
     }
-    float un = Uacc[0] + fmaf(st.alpha, s.kk, s.ubar);
+    real un = Uacc[0] + rfma(st.alpha, s.kk, s.ubar);
     if (MODE != 0 && s.zm) un = 0.f;                                 // :197-198
     if (MODE == 2) {                                                 // :200-213
-        float l = s.lo, h = s.hi;
+        real l = s.lo, h = s.hi;
         if (p.has_delta) {
-            const float l2 = s.ubar - p.delta_u, h2 = s.ubar + p.delta_u;
+            const real l2 = s.ubar - p.delta_u, h2 = s.ubar + p.delta_u;
             l = (l2 < l) ? l : l2;
             h = (h2 > h) ? h : h2;
         }
@@ -566,23 +593,23 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
     if (!last) Xacc = wv::mfma(s.FA[0], un, Xacc);
     // obj_t = 0.5 tau'C tau + c'tau   (:230-232)
     if (MULTI) {
-        f32x4 Cacc = wv::mfma(s.C[0], un, zero4);
+        rx4 Cacc = wv::mfma(s.C[0], un, zero4);
 #pragma unroll
         for (int kb = 1; kb < 4; ++kb) Cacc = wv::mfma(s.C[kb], st.xrow[kb - 1], Cacc);
-        float ca = un * fmaf(0.5f, Cacc[0], s.crow[0]);
+        real ca = un * rfma((real)0.5, Cacc[0], s.crow[0]);
 #pragma unroll
-        for (int kb = 1; kb < 4; ++kb) ca = fmaf(st.xrow[kb - 1], fmaf(0.5f, Cacc[kb], s.crow[kb]), ca);
+        for (int kb = 1; kb < 4; ++kb) ca = rfma(st.xrow[kb - 1], rfma((real)0.5, Cacc[kb], s.crow[kb]), ca);
         st.cost += ca;
     } else {
         // tau' sits in row layout; hand it to every lane through 64 bytes of LDS: lane (g,j) needs
         // tau'[4g+r] (its four C rows -- it has those) and tau'[slot j] (its C column)
-        if (L.j0) wv::lds_store_f32x4(LDS_SCRATCH + 16u * (unsigned)L.g, f32x4{un, st.xrow[0], st.xrow[1], st.xrow[2]});
+        if (L.j0) wv::lds_store_r4(LDS_SCRATCH + (unsigned)(4 * ES) * (unsigned)L.g, rx4{un, st.xrow[0], st.xrow[1], st.xrow[2]});
         wv::lds_sync();
-        const float tc = wv::lds_f32(LDS_SCRATCH + 4u * (unsigned)L.j);
+        const real tc = wv::lds_r<real>(LDS_SCRATCH + (unsigned)ES * (unsigned)L.j);
         wv::lds_sync();
-        const float sq = fmaf(s.C[3], st.xrow[2], fmaf(s.C[2], st.xrow[1], fmaf(s.C[1], st.xrow[0], s.C[0] * un)));
-        const float lin = fmaf(s.crow[3], st.xrow[2], fmaf(s.crow[2], st.xrow[1], fmaf(s.crow[1], st.xrow[0], s.crow[0] * un)));
-        st.cost = fmaf(0.5f * tc, sq, st.cost) + sel(L.j0, lin, 0.f);
+        const real sq = rfma(s.C[3], st.xrow[2], rfma(s.C[2], st.xrow[1], rfma(s.C[1], st.xrow[0], s.C[0] * un)));
+        const real lin = rfma(s.crow[3], st.xrow[2], rfma(s.crow[2], st.xrow[1], rfma(s.crow[1], st.xrow[0], s.crow[0] * un)));
+        st.cost = rfma(0.5f * tc, sq, st.cost) + sel(L.j0, lin, 0.f);
         const long tb = (long)t * p.B + b;
         if (L.j0) {
             if (L.rowv[0]) p.new_u[tb * p.nc + L.row[0]] = un;
@@ -591,8 +618,8 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
                 if (L.rowv[kb]) p.new_x[tb * p.ns + L.row[kb]] = st.xrow[kb - 1];
         }
     }
-    const float d = s.ubar - un;
-    st.du2 = fmaf(d, d, st.du2);
+    const real d = s.ubar - un;
+    st.du2 = rfma(d, d, st.du2);
     if (!last) {
         st.xrow[0] = Xacc[1]; st.xrow[1] = Xacc[2]; st.xrow[2] = Xacc[3];
     }
@@ -602,7 +629,7 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
 // Single: every column uses `alpha` and the trajectory is stored.  cost_j / du2_j: totals of trial j
 // (single: the same number in every lane).
 template <bool FULL, int MODE, bool MULTI>
-MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, float alpha, float &cost_j, float &du2_j)
+MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, real alpha, real &cost_j, real &du2_j)
 {
     RoState st;
 #pragma unroll
@@ -612,7 +639,7 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, float alpha, float &
     st.alpha = alpha;
     if (MULTI) {
         // alpha_j = decay^min(j, max_ls-1)    (:247)
-        float a = 1.f;
+        real a = 1.f;
         const int e = L.j < p.max_ls - 1 ? L.j : p.max_ls - 1;
         for (int i = 0; i < e; ++i) a *= p.ls_decay;
         st.alpha = a;
@@ -647,7 +674,7 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, int b, float alpha, float &
     }
     stage_wait<FULL, 0>();
     // sum the four lane groups (and, single trial, the 16 column partials of the quadratic form)
-    float c = st.cost, d = st.du2;
+    real c = st.cost, d = st.du2;
     c += wv::shfl_xor(c, 16); d += wv::shfl_xor(d, 16);
     c += wv::shfl_xor(c, 32); d += wv::shfl_xor(d, 32);
     if (!MULTI) {
@@ -667,12 +694,12 @@ MPC_DEV void step_problem(const P &p)
     lane_init(L, lane, p.ns, p.nc);
     const int T = p.T;
     // the words of zeros of every ring slot, once
-    if (lane < 4 * NSTAGE) wv::lds_store_f32((unsigned)(lane >> 2) * STAGE_BYTES + LDS_V + V_zero + 4u * (unsigned)(lane & 3), 0.f);
+    if (lane < 4 * NSTAGE) wv::lds_store_r((unsigned)(lane >> 2) * STAGE_BYTES + LDS_V + V_zero + (unsigned)ES * (unsigned)(lane & 3), (real)0);
     wv::lds_sync();
 
     // ---- Riccati sweep, t = T-1 .. 0 ------------------------------------------------------------
     SwState ss;
-    ss.Vp = f32x4{0.f, 0.f, 0.f, 0.f};
+    ss.Vp = rx4{0.f, 0.f, 0.f, 0.f};
     ss.oc = 0.f;
     ss.warm = 0;
     ss.qp_total = 0;
@@ -706,27 +733,27 @@ MPC_DEV void step_problem(const P &p)
         }
         stage_wait<FULL, 0>();
     }
-    const float old_cost = (wv::readlane(ss.oc, 0) + wv::readlane(ss.oc, 16)) +
+    const real old_cost = (wv::readlane(ss.oc, 0) + wv::readlane(ss.oc, 16)) +
                            (wv::readlane(ss.oc, 32) + wv::readlane(ss.oc, 48));
     if (!p.c_symmetric) {
         // (a tolerance, not a bit test: C = A'A out of a float32 GEMM is symmetric to rounding only)
-        float m = ss.cmax;
+        real m = ss.cmax;
 #pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) m = fmaxf(m, wv::shfl_xor(m, sh));
+        for (int sh = 1; sh < 64; sh <<= 1) m = rmax(m, wv::shfl_xor(m, sh));
         ss.status |= MPC_ST_C_TESTED;
-        if (wv::ballot(ss.asym > 1e-5f * m) != 0ull) ss.status |= MPC_ST_C_ASYMMETRIC;
+        if (wv::ballot(ss.asym > (real)1e-5 * m) != 0ull) ss.status |= MPC_ST_C_ASYMMETRIC;
     }
 
     // the gains were written by this wave and are re-read through the DMA: drain the stores
     wv::fence_own_stores();
 
     // ---- line-searched rollout (mpc/lqr_step.py:164-261) ---------------------------------------
-    float cost_j, du2_j;
+    real cost_j, du2_j;
     rollout_pass<FULL, MODE, false>(p, L, b, 1.f, cost_j, du2_j);
-    float cost = wv::readlane(cost_j, 0);
-    float dun2 = wv::readlane(du2_j, 0);
-    const float full2 = dun2;                                        // :243-245 (alpha = 1 trial)
-    float alpha = 1.f;
+    real cost = wv::readlane(cost_j, 0);
+    real dun2 = wv::readlane(du2_j, 0);
+    const real full2 = dun2;                                        // :243-245 (alpha = 1 trial)
+    real alpha = 1.f;
     if (wv::uniform(cost > old_cost) && p.max_ls > 1) {
         // the full step made it worse: run every remaining trial at once and take the first whose
         // cost did not get worse, else the last one (:176-179, 247, 252)
@@ -741,17 +768,18 @@ MPC_DEV void step_problem(const P &p)
         dun2 = wv::readlane(du2_j, 0);
     }
     int status = ss.status;
-    if (!(cost == cost) || fabsf(cost) > 3e38f) status |= MPC_ST_NONFINITE;
+    if (!(cost == cost) || rabs(cost) > (real)(ES == 4 ? 3e38 : 1e300)) status |= MPC_ST_NONFINITE;
     if (lane == 0) {
         if (p.costs) p.costs[b] = cost;
         if (p.old_costs) p.old_costs[b] = old_cost;
-        if (p.full_du_norm) p.full_du_norm[b] = sqrtf(full2);
-        if (p.alpha_du_norm) p.alpha_du_norm[b] = sqrtf(dun2);
+        if (p.full_du_norm) p.full_du_norm[b] = rsqrt_of(full2);
+        if (p.alpha_du_norm) p.alpha_du_norm[b] = rsqrt_of(dun2);
         if (p.alphas) p.alphas[b] = alpha;
         if (p.qp_iters) p.qp_iters[b] = ss.qp_total;
         if (p.status) p.status[b] = status;
     }
 }
 
-}  // namespace mfma16
+}  // namespace MPC_M16_NS
 }  // namespace mpclqr
+#endif

@@ -33,6 +33,7 @@ struct Wave {
     int problem;
     // exchange area, two generations
     float fa[2][NL], fb[2][NL];
+    double da[2][NL], db[2][NL];   // ... for the float64 instantiation of the one-problem-per-wavefront kernel
     float fq[2][NL][4];
     double fd[2][NL];
     int ia[2][NL];
@@ -103,6 +104,10 @@ static void run_wave(int problem, void (*body)(void))
 namespace mpclqr {
 namespace wv {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct vec4_of;
+template <> struct vec4_of<float> { typedef f32x4 type; };
+template <> struct vec4_of<double> { typedef f64x4 type; };
 static inline int lane() { return emu::W.cur; }
 static inline int problem() { return emu::W.problem; }
 static inline f32x4 mfma(float a, float b, f32x4 c)
@@ -130,6 +135,42 @@ static inline float readlane(float x, int src)
     emu::yield_lane();
     return w.fa[gen][src];
 }
+// float64 (v_mfma_f64_16x16x4_f64: the lane layout of the float32 instruction)
+static inline f64x4 mfma(double a, double b, f64x4 c)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.da[gen][l] = a;
+    w.db[gen][l] = b;
+    emu::yield_lane();
+    const int g = l >> 4, j = l & 15;
+    f64x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fma(w.da[gen][16 * k + i], w.db[gen][16 * k + j], acc);
+        d[r] = acc;
+    }
+    return d;
+}
+static inline double readlane(double x, int src)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.da[gen][l] = x;
+    emu::yield_lane();
+    return w.da[gen][src];
+}
+static inline double shfl_xor(double x, int m)
+{
+    emu::Wave &w = emu::W;
+    const int l = w.cur, gen = w.seq[l]++ & 1;
+    w.da[gen][l] = x;
+    emu::yield_lane();
+    return w.da[gen][l ^ m];
+}
+static inline double rcp(double x) { return 1.0 / x; }
+static inline void pin(double &) {}
 static inline int readlane_i(int x, int src)
 {
     emu::Wave &w = emu::W;
@@ -494,6 +535,21 @@ static inline void lds_store_f32x4(unsigned off, f32x4 v)
     if (off & 15) { fprintf(stderr, "emu: misaligned ds_write_b128\n"); abort(); }
     memcpy(emu::W.lds + off, &v, 16);
 }
+// the type-parametrised accessors of lqr_mfma16_body.h (one LDS here: the type only picks the width)
+template <typename T> static inline void dma16r(const void *g, unsigned off) { dma_n(g, off, 16); }
+template <typename T> static inline void dma4r(const void *g, unsigned off) { dma_n(g, off, 4); }
+template <typename T> static inline T lds_r(unsigned off) { T v; memcpy(&v, emu::W.lds + off, sizeof(T)); return v; }
+template <typename T> static inline typename vec4_of<T>::type lds_r4(unsigned off)
+{
+    if (off & 15) { fprintf(stderr, "emu: misaligned ds_read_b128\n"); abort(); }
+    typename vec4_of<T>::type v;
+    memcpy(&v, emu::W.lds + off, 4 * sizeof(T));
+    return v;
+}
+static inline void lds_store_r(unsigned off, float v) { memcpy(emu::W.lds + off, &v, 4); }
+static inline void lds_store_r(unsigned off, double v) { memcpy(emu::W.lds + off, &v, 8); }
+static inline void lds_store_r4(unsigned off, f32x4 v) { memcpy(emu::W.lds + off, &v, 16); }
+static inline void lds_store_r4(unsigned off, f64x4 v) { memcpy(emu::W.lds + off, &v, 32); }
 // the hardware executes a wave's DS instructions in order; the lane-serial emulator needs every
 // lane to have passed the preceding stores/loads before any lane goes on
 static inline void lds_sync() { (void)readlane_i(0, 0); }
@@ -502,6 +558,10 @@ static inline void fence_own_stores() {}
 }  // namespace mpclqr
 
 #include "../../mpc.pytorch_amd/csrc/lqr_mfma16_body.h"
+// ... and its float64 instantiation (namespace mfma16d)
+#define MPC_M16_F64
+#include "../../mpc.pytorch_amd/csrc/lqr_mfma16_body.h"
+#undef MPC_M16_F64
 #include "../../mpc.pytorch_amd/csrc/lqr_dpp16_body.h"
 #include "../../mpc.pytorch_amd/csrc/lqr_mfma40_body.h"
 
@@ -532,6 +592,34 @@ extern "C" int emu_lqr_step_mfma16(const mpc_lqr_problem *p, const mpc_lqr_optio
     g_p = &sp;
     const bool full = sp.ns == 12 && sp.nc == 4 && !force_general;
     for (int b = 0; b < sp.B; ++b) emu::run_wave(b, full ? body<true> : body<false>);
+    return 0;
+}
+
+static const mpclqr::StepParams<double> *g_pd;
+template <bool FULL> static void body_f64()
+{
+    const mpclqr::StepParams<double> &p = *g_pd;
+    if (p.bound_mode != MPC_BOUND_NONE) mpclqr::mfma16d::step_problem<FULL, 2>(p);
+    else if (p.zero_mask) mpclqr::mfma16d::step_problem<FULL, 1>(p);
+    else mpclqr::mfma16d::step_problem<FULL, 0>(p);
+}
+
+extern "C" int emu_lqr_step_mfma16_f64(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
+                                       int force_general)
+{
+    if (p->dtype != MPC_F64) return MPC_E_DTYPE;
+    mpclqr::StepParams<double> sp = mpclqr::make_params<double>(p, o, out);
+    if (!(sp.ns >= 1 && sp.ns <= 12 && sp.nc >= 1 && sp.nc <= 4 && sp.max_ls >= 1 && sp.max_ls <= 16)) return MPC_E_DIMS;
+    if (!sp.new_x || !sp.new_u) return MPC_E_NULL;
+    static double *kk_buf = nullptr;
+    static size_t kk_cap = 0;
+    const size_t need = (size_t)sp.T * sp.B * 64;
+    if (need > kk_cap) { free(kk_buf); kk_buf = (double *)aligned_alloc(16, need * sizeof(double)); kk_cap = need; }
+    for (size_t i = 0; i < need; ++i) kk_buf[i] = NAN;
+    sp.Kk = kk_buf;
+    g_pd = &sp;
+    const bool full = sp.ns == 12 && sp.nc == 4 && !force_general;
+    for (int b = 0; b < sp.B; ++b) emu::run_wave(b, full ? body_f64<true> : body_f64<false>);
     return 0;
 }
 

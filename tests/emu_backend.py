@@ -89,7 +89,7 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
     kernels are float32; kernel="tiny" (lane-per-problem body, n_ctrl = 1) also runs in float64 and
     takes env = (kind, params, dt, u_max): a shipped simulator as the rollout's true dynamics."""
     f32 = np.dtype(dtype).type
-    assert f32 == np.float32 or kernel == "tiny"
+    assert f32 == np.float32 or kernel in ("tiny", "mfma16")      # (mfma16: its float64 instantiation, round 5)
     C = np.ascontiguousarray(C, f32); c = np.ascontiguousarray(c, f32)
     x_init = np.ascontiguousarray(x_init, f32)
     T, B, n, _ = C.shape
@@ -178,6 +178,10 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
         rc = lib().emu_lqr_step_dpp16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
     elif kernel == "dpp16_ring2":
         rc = lib_ring2().emu_lqr_step_dpp16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
+    elif f32 == np.float64:
+        fn = lib().emu_lqr_step_mfma16_f64
+        fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs), ctypes.c_int]
+        rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), int(force_general))
     else:
         rc = lib().emu_lqr_step_mfma16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), int(force_general))
     assert rc == 0, rc

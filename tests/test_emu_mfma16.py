@@ -1186,3 +1186,76 @@ def test_qp_start_is_a_hint_results_do_not_depend_on_it(emu, kernel):
     if kernel.startswith("dpp16"):
         # (emu_stats 1 / 6: factorisations of live rows / wave-level trips that factorise)
         assert s_warm[1] == 4 * ((B + 3) // 4) * T and s_warm[1] < s_cold[1] and s_warm[6] < s_cold[6]
+
+
+# ---------------------------------------------------------------------------------------------
+# The float64 instantiation of the one-problem-per-wavefront kernel (round 5; v_mfma_f64_16x16x4_f64)
+# ---------------------------------------------------------------------------------------------
+F64_CASES = [c for c in STEP_CASES if c.endswith("_f64")]
+
+
+@pytest.mark.parametrize("dma_late", [False, True], ids=["dma-early", "dma-late"])
+@pytest.mark.parametrize("name", F64_CASES)
+def test_emulated_float64_kernel_on_the_reference_fixtures(emu, name, dma_late):
+    """Every float64 step fixture of the reference with n_state <= 12, n_ctrl <= 4 through lqr_mfma16_body.h compiled for double
+    (what every test and gradient check of the reference runs in, tests/test_mpc.py .double()): 1e-9 against the oracle and the
+    reference's own per-problem outputs -- the float32 body's layout algebra with 8-byte elements (LDS offsets, DMA granules)."""
+    from oracle import lqr_oracle as O
+    z = golden(name)
+    ns, nc = int(z["meta"][0]), int(z["meta"][1])
+    if ns > 12 or nc > 4:
+        pytest.skip("beyond the kernel's 12/4")
+    kw = step_kwargs(z)
+    o = O.lqr_step(lockstep=False, return_gains=True, **kw)
+    r = emu.lqr_step(dma_late=dma_late, dtype=np.float64, **kw)
+    assert r["new_x"].dtype == np.float64 and (r["status"] & 2 == 0).all()
+    r, o, z = _split_asymmetric(r, o, z)
+    # (the box QP stops at |dx| < 1e-4: two correct evaluations agree to that step's square in the objective, 1e-7 in k)
+    tol = dict(rtol=1e-6, atol=1e-6) if "u_lower" in z else dict(rtol=1e-9, atol=1e-9)
+    for k in ("K", "k", "new_x", "new_u"):
+        np.testing.assert_allclose(r[k], o[k], **tol)
+    np.testing.assert_allclose(r["costs"], o["costs"], rtol=1e-9)
+    np.testing.assert_allclose(r["old_costs"], o["old_costs"], rtol=1e-12)
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-12)
+    np.testing.assert_allclose(r["new_x"], z["new_x_pp"], **tol)
+    np.testing.assert_allclose(r["new_u"], z["new_u_pp"], **tol)
+    np.testing.assert_allclose(r["costs"], z["costs_pp"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("ns,nc,T,case", [(12, 4, 7, "bounded"), (12, 4, 5, "masked"), (12, 4, 6, "plain"), (7, 3, 9, "bounded"), (1, 1, 1, "bounded"),
+                                          (11, 4, 6, "tensor_bounds"), (12, 2, 5, "delta_u"), (5, 4, 4, "plain")])
+def test_emulated_float64_kernel_shapes_and_options(emu, ns, nc, T, case):
+    """The full 12/4 layout (16-byte DMA granules of two doubles) and the padded one (word by word), every mode, against the oracle;
+    the full and the padded code path of 12/4 bit for bit."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(1000 * ns + 10 * nc + T)
+    B, n = 3, ns + nc
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A) + 0.1 * np.eye(n)
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((max(T - 1, 0), B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((max(T - 1, 0), B, ns, nc)) / np.sqrt(ns)), 3)
+    f = 0.1 * rng.standard_normal((max(T - 1, 0), B, ns))
+    x_init = rng.standard_normal((B, ns))
+    cur_u = np.clip(0.3 * rng.standard_normal((T, B, nc)), -0.5, 0.5)
+    cur_x, _ = O.traj_cost(x_init, cur_u, F, f)
+    kw = dict(x_init=x_init, C=C, c=c, F=F, f=f, cur_x=cur_x, cur_u=cur_u)
+    if case == "bounded":
+        kw.update(u_lower=-0.5, u_upper=0.5)
+    elif case == "tensor_bounds":
+        kw.update(u_lower=-0.5 - rng.random((T, B, nc)), u_upper=0.5 + rng.random((T, B, nc)))
+    elif case == "delta_u":
+        kw.update(u_lower=-0.5, u_upper=0.5, delta_u=0.1)
+    elif case == "masked":
+        kw.update(u_zero_I=rng.random((T, B, nc)) < 0.3)
+    o = O.lqr_step(lockstep=False, return_gains=True, **kw)
+    r = emu.lqr_step(dma_late=True, dtype=np.float64, **kw)
+    tol = dict(rtol=1e-6, atol=1e-6) if "u_lower" in kw else dict(rtol=1e-9, atol=1e-9)
+    for k in ("K", "k", "new_x", "new_u"):
+        np.testing.assert_allclose(r[k], o[k], **tol)
+    np.testing.assert_allclose(r["costs"], o["costs"], rtol=1e-9)
+    np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-12)
+    if (ns, nc) == (12, 4):
+        g = emu.lqr_step(dma_late=False, dtype=np.float64, force_general=True, **kw)
+        for k in ("new_x", "new_u", "costs", "K", "k", "alphas"):
+            np.testing.assert_array_equal(r[k], g[k])

@@ -568,3 +568,22 @@ def test_qp_start_from_the_workspace_record_vs_oracle(be, ns, nc, T, B, ring, mo
     r3 = {k: v.clone() for k, v in wild().items()}
     sync()
     held("wild", r3)
+
+
+def test_config5_at_its_quoted_batch_vs_oracle(be):
+    """BASELINE configs[4] at the batch it is quoted on: ns=32 nc=8 T=64, B = 8192 (eight wavefronts per SIMD's worth of
+    problems, the two-slot ring), vouched as mpc.MPC calls it -- EVERY problem against the float64 oracle (VERDICT r04, weak 1:
+    pytest held config 5 at B = 1030, bench.py certified 32 problems of the 8192)."""
+    import bench
+    from mpc._native import StepOptions
+    from oracle import lqr_oracle as O
+    T, B = 64, full_batch(8192)
+    p = bench.make_problem(32, 8, T, B, torch.float32, DEV, seed=9, on_device=not DRY)
+    h = {k: h64(v) for k, v in p.items()}
+    o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], lockstep=False, nthreads=O.max_threads(),
+                   return_gains=True)
+    r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"],
+                    StepOptions(nominal_on_dynamics=True, c_symmetric=True), want_gains=True)
+    sync()
+    strict_step_check("cfg5_B8192_vouched", r, o, B, cost_rtol=5e-4)
+    np.testing.assert_allclose(host(r["old_costs"]), o["old_costs"], rtol=1e-5)

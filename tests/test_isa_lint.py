@@ -65,7 +65,12 @@ SGPR_SPILL_LIMITS = {
     "lqr_mfma40_pad4": {"kernelILi0E": 380, "kernelILi1E": 700, "kernelILi2E": 930},
     "lqr_mfma40_pad16": {"kernelILi0E": 380, "kernelILi1E": 700, "kernelILi2E": 930},
     "lqr_wave1": {"kernelILi1E": 20, "kernelILi2E": 12, "kernelILi3E": 28, "kernelILi4E": 20, "kernelILi5E": 20, "kernelILi6E": 20},
-    "lqr_mfma16": {"ILb1ELi0E": 35, "ILb1ELi1E": 45, "ILb1ELi2E": 80, "ILb0ELi0E": 215, "ILb0ELi1E": 205, "ILb0ELi2E": 305},
+    # (round 5: the body is compiled for float and for double -- the record's granule map in elements costs the full float32
+    # box-constrained instantiation three more scalars; the float64 instantiations carry 64-bit everything)
+    "lqr_mfma16": {"mfma16_kernelILb1ELi0E": 35, "mfma16_kernelILb1ELi1E": 45, "mfma16_kernelILb1ELi2E": 92,
+                   "mfma16_kernelILb0ELi0E": 215, "mfma16_kernelILb0ELi1E": 205, "mfma16_kernelILb0ELi2E": 305,
+                   "f64_kernelILb1ELi0E": 60, "f64_kernelILb1ELi1E": 80, "f64_kernelILb1ELi2E": 130,
+                   "f64_kernelILb0ELi0E": 360, "f64_kernelILb0ELi1E": 365, "f64_kernelILb0ELi2E": 375},
 }
 
 
@@ -81,7 +86,8 @@ def test_no_vector_spills_no_scratch_and_bounded_scalar_spills(tu):
         # non-zero only where that is provably dead weight: hipcc sometimes leaves the 68-byte frame of scalar spill slots it
         # went on to place in vector-register lanes -- seen on one or the other instantiation of the fused 32/8 backward,
         # flipping with unrelated edits; `-Rpass-analysis=kernel-resource-usage` reports it, the ISA has no scratch_ access.)
-        assert v["private_segment_fixed_size"] == 0 or (tu == "lqr_mfma40_kkt" and v["private_segment_fixed_size"] <= 68), (k, v)
+        assert v["private_segment_fixed_size"] == 0 or (tu == "lqr_mfma40_kkt" and v["private_segment_fixed_size"] <= 68) or \
+            ("mfma16_f64" in k and v["private_segment_fixed_size"] <= 68), (k, v)
         assert scratch_ops[[n for n in scratch_ops if n in k or k in n][0]] == 0, k
         for pat, lim in SGPR_SPILL_LIMITS[tu].items():
             if pat in k:
