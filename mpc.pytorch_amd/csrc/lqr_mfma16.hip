@@ -20,7 +20,8 @@ template <> struct vec4_of<double> { typedef f64x4 type; };
 MPC_DEV int lane() { return (int)threadIdx.x; }
 MPC_DEV int problem() { return (int)blockIdx.x; }
 MPC_DEV f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-// (round 5) v_mfma_f64_16x16x4_f64: the same lane layout -- lane 16 g + j holds A[i=j][k=g], B[k=g][j], D[4g+r][j] in element r
+// (round 5) v_mfma_f64_16x16x4_f64: lane 16 g + j holds A[i=j][k=g], B[k=g][j] like the float32 instruction, but D[4r+g][j] in element r
+// (float32: D[4g+r][j]; measured, tools/ubench/mfma_f64_probe.hip) -- lqr_mfma16_body.h's SLOT_T
 MPC_DEV f64x4 mfma(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 MPC_DEV float readlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 MPC_DEV double readlane(double x, int l)

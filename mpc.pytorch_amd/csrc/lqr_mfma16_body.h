@@ -76,6 +76,13 @@ typedef StepParams<real> P;
 typedef typename wv::vec4_of<real>::type rx4;
 constexpr int ES = (int)sizeof(real);        // bytes per element
 constexpr int GE = 16 / ES;                  // elements per 16-byte DMA granule
+// Slot numbering.  Element r of lane group g of an accumulator is row 4 g + r of the tile in v_mfma_f32_16x16x4_f32 and row
+// 4 r + g in v_mfma_f64_16x16x4_f64 (measured: tools/ubench/mfma_f64_probe.hip); the A / B operand layouts are the same in both.
+// Everything below speaks of the slot (g, r); only where a slot becomes a COLUMN or LANE index does its number matter.
+constexpr bool SLOT_T = ES == 8;
+MPC_DEV constexpr int slot_of(int g, int r) { return SLOT_T ? 4 * r + g : 4 * g + r; }
+MPC_DEV int slot_group(int j) { return SLOT_T ? (j & 3) : (j >> 2); }
+MPC_DEV int slot_reg(int j) { return SLOT_T ? (j >> 2) : (j & 3); }
 
 // LDS layout (bytes): a ring of NSTAGE stages + 64 B of scratch.  The record of small vectors is
 // laid out so that in the n_state = 12, n_ctrl = 4 case every piece starts on a 16-byte granule
@@ -106,6 +113,7 @@ struct Lane {
     int aTb[4];           // column 0: tau[row r]; elsewhere: a word of zeros
     int aFT[4];           // LDS_F + F[x(col)][rowtau r]                  (F as the rollout's A operand)
     int aKA;              // u columns: the 16 B  Kk[ja][4g .. 4g+3];  elsewhere: zeros
+    int aKAe[3];          // ... entry by entry, Kk[ja][slot (g, kb)], where the slots of a lane group are not adjacent (SLOT_T)
     int aKk;              // Kk[g][0] = k_g
     int aG;               // 4 * g  (+LDS_V+V_lo / V_hi)
     real eg[4];          // one-hot of g
@@ -119,11 +127,11 @@ MPC_DEV void lane_init(Lane &L, int lane, int ns, int nc)
     L.g = lane >> 4;
     L.j = lane & 15;
     L.j0 = L.j == 0;
-    L.jq = (L.j & 3) == 0;
-    L.ja = L.j >> 2;
+    L.jq = slot_reg(L.j) == 0;
+    L.ja = slot_group(L.j);
     int coltau;
     if (L.jq) { L.colv = L.ja < nc; coltau = ns + L.ja; }
-    else { const int x = 3 * L.ja + (L.j & 3) - 1; L.colv = x < ns; coltau = x; }
+    else { const int x = 3 * L.ja + slot_reg(L.j) - 1; L.colv = x < ns; coltau = x; }
     if (!L.colv) coltau = 0;
     L.col = coltau;
 #pragma unroll
@@ -146,6 +154,8 @@ MPC_DEV void lane_init(Lane &L, int lane, int ns, int nc)
     }
     L.vK = L.jq && L.ja < nc;
     L.aKA = L.vK ? LDS_V + V_K + ES * (16 * L.ja + 4 * L.g) : LDS_V + V_zero;
+#pragma unroll
+    for (int kb = 1; kb < 4; ++kb) L.aKAe[kb - 1] = L.vK ? LDS_V + V_K + ES * (16 * L.ja + slot_of(L.g, kb)) : LDS_V + V_zero;
     L.aKk = LDS_V + V_K + ES * 16 * L.g;
     L.aG = L.rowv[0] ? ES * L.g : 0;
 }
@@ -363,10 +373,13 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
     // ---- the 4x4 control block, wave-uniform -------------------------------------------------
     const real U = Q[0];        // lane (g,j): Q[u_g][var j]; lane (g,0): qu[g]
     Sym4 S;
-    S.s01 = wv::readlane(U, 4);  S.s02 = wv::readlane(U, 8);  S.s03 = wv::readlane(U, 12);
-    S.s11 = wv::readlane(U, 20); S.s12 = wv::readlane(U, 24); S.s13 = wv::readlane(U, 28);
-    S.s22 = wv::readlane(U, 40); S.s23 = wv::readlane(U, 44);
-    S.s33 = wv::readlane(U, 60);
+    // Quu[a][b] sits in lane group a at the column slot of u_b
+#define MPC_QUU(a, b) wv::readlane(U, 16 * (a) + slot_of(b, 0))
+    S.s01 = MPC_QUU(0, 1); S.s02 = MPC_QUU(0, 2); S.s03 = MPC_QUU(0, 3);
+    S.s11 = MPC_QUU(1, 1); S.s12 = MPC_QUU(1, 2); S.s13 = MPC_QUU(1, 3);
+    S.s22 = MPC_QUU(2, 2); S.s23 = MPC_QUU(2, 3);
+    S.s33 = MPC_QUU(3, 3);
+#undef MPC_QUU
     S.s00 = wv::readlane(s.C[0], 0);
     if (!last)
         S.s00 += (wv::readlane(q00p, 0) + wv::readlane(q00p, 16)) + (wv::readlane(q00p, 32) + wv::readlane(q00p, 48));
@@ -522,7 +535,13 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, int
         s.FA[0] = s.FA[1] = s.FA[2] = s.FA[3] = 0.f;
         s.frow[0] = s.frow[1] = s.frow[2] = 0.f;
     }
-    {
+    if (SLOT_T) {
+#pragma unroll
+        for (int kb = 1; kb < 4; ++kb) {
+            const real v = wv::lds_r<real>(base + L.aKAe[kb - 1]);
+            s.KA[kb - 1] = FULL ? v : sel(L.rowv[kb], v, 0.f);
+        }
+    } else {
         const rx4 kv = wv::lds_r4<real>(base + L.aKA);
         s.KA[0] = FULL ? kv[1] : sel(L.rowv[1], kv[1], 0.f);
         s.KA[1] = FULL ? kv[2] : sel(L.rowv[2], kv[2], 0.f);
@@ -603,7 +622,15 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
     } else {
         // tau' sits in row layout; hand it to every lane through 64 bytes of LDS: lane (g,j) needs
         // tau'[4g+r] (its four C rows -- it has those) and tau'[slot j] (its C column)
-        if (L.j0) wv::lds_store_r4(LDS_SCRATCH + (unsigned)(4 * ES) * (unsigned)L.g, rx4{un, st.xrow[0], st.xrow[1], st.xrow[2]});
+        if (L.j0) {
+            if (SLOT_T) {
+                wv::lds_store_r(LDS_SCRATCH + (unsigned)ES * (unsigned)slot_of(L.g, 0), un);
+#pragma unroll
+                for (int kb = 1; kb < 4; ++kb) wv::lds_store_r(LDS_SCRATCH + (unsigned)ES * (unsigned)slot_of(L.g, kb), st.xrow[kb - 1]);
+            } else {
+                wv::lds_store_r4(LDS_SCRATCH + (unsigned)(4 * ES) * (unsigned)L.g, rx4{un, st.xrow[0], st.xrow[1], st.xrow[2]});
+            }
+        }
         wv::lds_sync();
         const real tc = wv::lds_r<real>(LDS_SCRATCH + (unsigned)ES * (unsigned)L.j);
         wv::lds_sync();

@@ -135,7 +135,7 @@ static inline float readlane(float x, int src)
     emu::yield_lane();
     return w.fa[gen][src];
 }
-// float64 (v_mfma_f64_16x16x4_f64: the lane layout of the float32 instruction)
+// float64 (v_mfma_f64_16x16x4_f64: the operand layouts of the float32 instruction, element r of lane group g of D is row 4 r + g)
 static inline f64x4 mfma(double a, double b, f64x4 c)
 {
     emu::Wave &w = emu::W;
@@ -146,7 +146,7 @@ static inline f64x4 mfma(double a, double b, f64x4 c)
     const int g = l >> 4, j = l & 15;
     f64x4 d = c;
     for (int r = 0; r < 4; ++r) {
-        const int i = 4 * g + r;
+        const int i = 4 * r + g;          // (NOT the float32 instruction's 4 g + r: measured, tools/ubench/mfma_f64_probe.hip)
         double acc = c[r];
         for (int k = 0; k < 4; ++k) acc = fma(w.da[gen][16 * k + i], w.db[gen][16 * k + j], acc);
         d[r] = acc;
