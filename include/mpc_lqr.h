@@ -181,8 +181,8 @@ int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p);
  *     delta-space linear term (:284-296) + Riccati sweep `lqr_backward`
  *     (:52-160, incl. pnqp mpc/pnqp.py:5-82 and the masked solve :99-127)
  *     + line-searched rollout `lqr_forward` (:164-261) for LinDx/QuadCost.
- *     `impl`: 0 = auto, 1 = generic kernels (any shape, f32/f64), 2 = fused MFMA kernel (f32,
- *     n_state <= 12, n_ctrl <= 4), 3 = 4-problems-per-wave DPP kernel (f32, n_state = 12,
+ *     `impl`: 0 = auto, 1 = generic kernels (any shape, f32/f64), 2 = fused MFMA kernel (f32 and, since ABI 8, f64 on
+ *     v_mfma_f64_16x16x4_f64; n_state <= 12, n_ctrl <= 4), 3 = 4-problems-per-wave DPP kernel (f32, n_state = 12,
  *     n_ctrl = 4, 16-byte aligned blocks), 4 = one lane per problem (n_ctrl = 1, n_state <= 6, f32/f64;
  *     the only fast kernel that takes a simulator as true_dynamics), 5 = register-resident MFMA step (f32,
  *     n_state = 32, n_ctrl = 8), 6 = a 16-lane row per problem (the shapes of 4, f32, the problem in LDS: everything
@@ -190,7 +190,7 @@ int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p);
  *     takes instead of 4 while B is too small to fill the chip with a lane per problem), 7 = the kernel of 5 for ANY
  *     n_state <= 32, n_ctrl <= 8 (f32; round 4): tau is padded to [x(32); u(8)] by the staging gathers, every mode of 5
  *     (bounds, u_zero_I, delta_u, bare or vouched nominal); needs the workspace of mpc_lqr_workspace_bytes.
- *     Auto picks 5, 6 / 4, 3, 2, 7, else 1 (float64, n_state > 32 or n_ctrl > 8, max_linesearch_iter > 16, a simulator
+ *     Auto picks 5, 6 / 4, 3, 2, 7, else 1 (float64 beyond 12/4, n_state > 32 or n_ctrl > 8, max_linesearch_iter > 16, a simulator
  *     beyond n_ctrl = 1).  The fused kernels need
  *     `workspace` (mpc_lqr_workspace_bytes, 16-byte aligned); out->K / out->k are optional there. */
 int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
