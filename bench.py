@@ -644,6 +644,7 @@ def extra_rows(be, dev, steps):
     # n_ctrl <= 4 take the one-problem-per-wavefront kernel's float64 instantiation (v_mfma_f64_16x16x4_f64); rounds 1-4: the generic kernel
     for bounded64 in (False, True):
         p = make_problem(NS, NC, T_H, 1024, torch.float64, dev, seed=77, u_scale=0.3 if bounded64 else 0.0, clamp=1.0 if bounded64 else None)
+        p["C"] = 0.5 * (p["C"] + p["C"].transpose(2, 3))      # (make_problem multiplies in float32: symmetric to 1e-7 only)
         o64 = StepOptions(u_lower=-1.0, u_upper=1.0) if bounded64 else StepOptions()
         row, _ = step_row(p, o64, NS, NC, T_H, 1024)
         rowg, _ = step_row(p, o64, NS, NC, T_H, 1024, impl=1)

@@ -768,7 +768,10 @@ MPC_DEV void step_problem(const P &p)
 #pragma unroll
         for (int sh = 1; sh < 64; sh <<= 1) m = rmax(m, wv::shfl_xor(m, sh));
         ss.status |= MPC_ST_C_TESTED;
-        if (wv::ballot(ss.asym > (real)1e-5 * m) != 0ull) ss.status |= MPC_ST_C_ASYMMETRIC;
+        // (float64: a C that is symmetric to float32 rounding only -- A'A out of a float32 product, cast up -- moves the results by
+        // 1e-7 against the reference, which uses C as given: far above what float64 callers compare to; it is flagged, and
+        // impl = 0 re-solves it the reference's way)
+        if (wv::ballot(ss.asym > (real)(ES == 4 ? 1e-5 : 1e-12) * m) != 0ull) ss.status |= MPC_ST_C_ASYMMETRIC;
     }
 
     // the gains were written by this wave and are re-read through the DMA: drain the stores

@@ -1259,3 +1259,31 @@ def test_emulated_float64_kernel_shapes_and_options(emu, ns, nc, T, case):
         g = emu.lqr_step(dma_late=False, dtype=np.float64, force_general=True, **kw)
         for k in ("new_x", "new_u", "costs", "K", "k", "alphas"):
             np.testing.assert_array_equal(r[k], g[k])
+
+
+def test_emulated_float64_kernel_flags_a_C_symmetric_to_float32_rounding_only(emu):
+    """C = A'A out of a float32 product cast to float64 is symmetric to ~1e-7: the reference uses C as given (mpc/lqr_step.py:68,
+    294), the fused kernel reads it through its symmetry -- a difference of 1e-7 in the results, invisible in float32, far above
+    what a float64 caller compares to.  The float64 instantiation raises MPC_ST_C_ASYMMETRIC from 1e-12 max |C| on (impl = 0 then
+    re-solves on the generic kernel); the float32 one keeps its 1e-5."""
+    from oracle import lqr_oracle as O
+    rng = np.random.default_rng(12)
+    ns, nc, T, B = 7, 3, 6, 4
+    n = ns + nc
+    A = rng.standard_normal((T, B, n, n)).astype(np.float32)
+    C = np.einsum("tbji,tbjk->tbik", A, A).astype(np.float64)
+    C[:, 1::2] += 1e-8 * np.triu(rng.standard_normal((n, n)), 1)              # every second problem: asymmetric at float32 rounding
+    C[:, 0::2] = 0.5 * (C[:, 0::2] + C[:, 0::2].transpose(0, 1, 3, 2))
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((T - 1, B, ns, ns)) / np.sqrt(ns), rng.standard_normal((T - 1, B, ns, nc)) / np.sqrt(ns)), 3)
+    f = 0.1 * rng.standard_normal((T - 1, B, ns))
+    x_init = rng.standard_normal((B, ns))
+    cur_u = np.zeros((T, B, nc))
+    cur_x, _ = O.traj_cost(x_init, cur_u, F, f)
+    kw = dict(x_init=x_init, C=C, c=c, F=F, f=f, cur_x=cur_x, cur_u=cur_u)
+    r = emu.lqr_step(dtype=np.float64, **kw)
+    assert ((r["status"] & 8) != 0).tolist() == [False, True, False, True], r["status"]
+    o = O.lqr_step(lockstep=False, **kw)
+    np.testing.assert_allclose(r["new_u"][:, 0::2], o["new_u"][:, 0::2], rtol=1e-10, atol=1e-11)
+    r32 = emu.lqr_step(dtype=np.float32, **kw)
+    assert ((r32["status"] & 8) == 0).all()
