@@ -1044,6 +1044,11 @@ def main():
         dist.all_gather_into_tensor(sums, mine)
         got = torch.stack([torch.stack([v.double().sum() for v in slots.views(q)]) for q in range(world)])
         arrived = bool(torch.allclose(got, sums, rtol=1e-12, atol=0.0)) and bool(torch.isfinite(got).all())
+        # ... and the in-place collective (send buffer = this rank's slot INSIDE the receive buffer) against a plain out-of-place
+        # all_gather of a copy of that slot (the in-place RCCL path is exercised on a GPU box only)
+        plain = [torch.empty_like(slots.buf[rank]) for _ in range(world)]
+        dist.all_gather(plain, slots.buf[rank].clone())
+        arrived = arrived and all(bool(torch.equal(plain[q], slots.buf[q])) for q in range(world))
         # + 16 problems of every rank's block through the oracle
         try:
             par_rank = parity_check(p, r, args.bounded, n=16, be=be)
@@ -1103,7 +1108,8 @@ def main():
                        "launcher": ("torch.distributed.run (self-spawned by bench.py)" if os.environ.get("MPC_BENCH_SPAWNED")
                                     else "torch.distributed.run") if launched else "single process",
                        "collective": None if dist is None else ("one in-place all_gather_into_tensor (RCCL) inside the timed region: every rank's kernel writes "
-                                                                "new_x, new_u into its slot of the receive buffer (mpc.shard.GatherSlots), scalars in 3 B words"),
+                                                                "new_x, new_u into its slot of the receive buffer (mpc.shard.GatherSlots), scalars in 3 B words; "
+                                                                "checked bit for bit against an out-of-place all_gather after the timed region"),
                        "ranks_seen": ranks_seen},
             "roofline": hbm_roofline(abytes, kern_ms, traffic=traffic, traffic_source=traffic_source, kernel_ms_all_launches=kern_ms_all,
                                      frac_all_launches=abytes / (kern_ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
