@@ -1073,9 +1073,13 @@ def main():
         value = world * B * T_H / (elapsed / args.steps)
         abytes = algorithmic_bytes_per_problem(NS, NC, T_H) * B
         traffic, traffic_source = None, None
-        for rnd in ("r05", "r04", "r03"):        # the per-kernel counter summary of tools/prof_any.sh, newest round first
+        # (the per-kernel counter summary of tools/prof_any.sh, newest round first; "headline_alt" = two alternating problem sets,
+        # like this run's timed region)
+        for rnd, kindname in (("r05", "bounded" if args.bounded else ("headline" if args.one_set else "headline_alt")),
+                              ("r05", "bounded" if args.bounded else "headline"), ("r04", "bounded" if args.bounded else "headline"),
+                              ("r03", "bounded" if args.bounded else "headline")):
             try:
-                tfile = "profiles/%s_prof_%s.json" % (rnd, "bounded" if args.bounded else "headline")
+                tfile = "profiles/%s_prof_%s.json" % (rnd, kindname)
                 pm = json.load(open(os.path.join(ROOT, tfile)))["pmc_avg_per_dispatch"]
                 traffic = pm["lqr_step_dpp16_kernel<%d>" % (2 if args.bounded else 0)]["hbm_bytes_per_dispatch"] if impl_used == 3 else None
                 # NOT a counter of this run: rocprofv3 --pmc passes of the same call kind (tools/prof_one.py), separate runs
