@@ -587,3 +587,45 @@ def test_config5_at_its_quoted_batch_vs_oracle(be):
     sync()
     strict_step_check("cfg5_B8192_vouched", r, o, B, cost_rtol=5e-4)
     np.testing.assert_allclose(host(r["old_costs"]), o["old_costs"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("ns,nc,T,B,mode", [(12, 4, 50, 4096, "unbounded"), (12, 4, 50, 2051, "bounded"), (12, 4, 20, 1030, "masked"),
+                                            (7, 3, 30, 1500, "bounded"), (12, 2, 25, 1000, "delta_u"), (3, 2, 10, 777, "tensor_bounds")])
+def test_float64_kernel_full_batches_vs_oracle(be, ns, nc, T, B, mode):
+    """The float64 instantiation of the one-problem-per-wavefront kernel (v_mfma_f64_16x16x4_f64; what impl 0 gives float64
+    problems with n_state <= 12, n_ctrl <= 4 since round 5) at BASELINE-sized batches, every problem, 1e-9 against the float64
+    oracle -- the reference's own tests and gradient checks run in float64 (tests/test_mpc.py .double())."""
+    import bench
+    from mpc._native import StepOptions, IMPL_MFMA16
+    from oracle import lqr_oracle as O
+    B = full_batch(B)
+    p = bench.make_problem(ns, nc, T, B, torch.float64, DEV, seed=50 + ns + nc, u_scale=0.0 if mode == "unbounded" else 0.3,
+                           clamp=None if mode == "unbounded" else 1.0)
+    p["C"] = 0.5 * (p["C"] + p["C"].transpose(2, 3))             # (make_problem multiplies in float32: symmetric to 1e-7 only)
+    kw, okw = {}, {}
+    if mode == "bounded":
+        kw = okw = dict(u_lower=-1.0, u_upper=1.0)
+    elif mode == "delta_u":
+        kw = okw = dict(u_lower=-1.0, u_upper=1.0, delta_u=0.25)
+    elif mode == "tensor_bounds":
+        g = torch.Generator().manual_seed(2)
+        lo, hi = (-1.0 - torch.rand(T, B, nc, generator=g, dtype=torch.float64)).to(DEV), (1.0 + torch.rand(T, B, nc, generator=g, dtype=torch.float64)).to(DEV)
+        kw, okw = dict(u_lower=lo, u_upper=hi), dict(u_lower=host(lo), u_upper=host(hi))
+    elif mode == "masked":
+        g = torch.Generator().manual_seed(3)
+        mask = (torch.rand(T, B, nc, generator=g) < 0.3).to(DEV)
+        kw, okw = dict(u_zero_I=mask), dict(u_zero_I=host(mask))
+    h = {k: h64(v) for k, v in p.items()}
+    o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], lockstep=False, nthreads=O.max_threads(),
+                   return_gains=True, **okw)
+    for impl in ((0,) if DRY else (0, IMPL_MFMA16)):
+        r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], StepOptions(**kw), impl=impl, want_gains=True)
+        sync()
+        assert r["new_x"].dtype == torch.float64
+        # (the box QP stops at |dx| < 1e-4: two correct evaluations of it agree to that step squared; ties as everywhere)
+        tol = dict(rtol=1e-6, atol=1e-7) if mode in ("bounded", "delta_u", "tensor_bounds") else dict(rtol=1e-9, atol=1e-9)
+        strict_step_check("f64_%d_%d_%s_impl%d" % (ns, nc, mode, impl), r, o, B, cost_rtol=1e-8, **tol)
+        np.testing.assert_allclose(host(r["old_costs"]), o["old_costs"], rtol=1e-12)
+        if not DRY:
+            st = host(r["status"])
+            assert (st & 8 == 0).all() and (st & 32 != 0).all()          # C tested, symmetric: nothing re-solved
