@@ -1235,12 +1235,19 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
 enum { MAX_TRIALS = 15 };
 struct Trials {
     float xs[MAX_TRIALS], cost[MAX_TRIALS], alpha[MAX_TRIALS];
+    // (round 5, the box-constrained step) the LAST trial of the pass parks its trajectory in the workspace, for the rows still
+    // searching: a problem that gets worse for every step size -- what the late iterations of a solve see, two to five problems of
+    // 4096 -- ends on exactly that trial, and its wavefront then copies the trajectory out instead of replaying a pass
+    float du2_last;
+    float *park;
+    bool park_row;
 };
 
 template <int MODE, bool DIRECT>
 MPC_DEV void trials_step(const P &p, const Lane &L, const RoStage &s, Trials &tr, int nt, int t)
 {
     const bool last = (t == p.T - 1);
+    constexpr bool PARK = MODE == 2 && !DIRECT;
 #pragma unroll
     for (int k = 0; k < MAX_TRIALS; ++k) {
         if (k < nt) {
@@ -1248,6 +1255,12 @@ MPC_DEV void trials_step(const P &p, const Lane &L, const RoStage &s, Trials &tr
             const float un = control_law<MODE>(p, L, s, tr.xs[k], tr.alpha[k], e, dx);
             const float tp = L.isu ? un : tr.xs[k];
             tr.cost[k] += stage_price<MODE, DIRECT>(L, s, tp, e, dx);
+            if (PARK && k == nt - 1) {
+                const float d = sel(L.isu, s.tb - un, 0.f);
+                tr.du2_last = fmaf(d, d, tr.du2_last);
+                if (tr.park_row) *tr.park = tp;          // (a plain store: read back by this wave within the launch)
+                tr.park += L.ostep1;
+            }
             if (!last) {
                 float xn = s.fj;
                 wv::dot_bcast16(xn, tp, s.Fr);
@@ -1271,6 +1284,8 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gai
     if (MULTI) {
 #pragma unroll
         for (int k = 0; k < MAX_TRIALS; ++k) { tr.xs[k] = x0; tr.cost[k] = 0.f; }
+        tr.du2_last = 0.f;
+        tr.park = L.scr0;
     } else {
         st.xs = x0;
         st.cost = 0.f;
@@ -1337,6 +1352,7 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gai
 #pragma unroll
         for (int k = 0; k < MAX_TRIALS; ++k)
             if (k < nt) tr.cost[k] = base + wv::row_sum(tr.cost[k]);
+        tr.du2_last = wv::row_sum(tr.du2_last);
     } else {
         st.cost = base + wv::row_sum(st.cost);
         st.du2 = wv::row_sum(st.du2);
@@ -1358,6 +1374,7 @@ MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, const Gain
     Trials tr;
     rs.alpha = 1.f;
     bool worse0 = false;
+    bool copy_parked = false;
     if (MODE == 2 && !DIRECT && p.max_ls >= 2) {
         // Box constraints: one problem in six steps back to alpha = decay, i.e. every second wave -- and the slowest wave
         // is the kernel's time.  The first pass therefore rolls out alpha = 1 AND alpha = decay side by side (one read of
@@ -1373,51 +1390,64 @@ MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, const Gain
             rs.cost = rs.cost1;
             rs.du2 = rs.du21;
         }
-        if (!wv::any(worse1)) {
-            // trajectory of the second trial -> new_x / new_u, rows that took it (the stores of this wave's own pass
-            // must have landed: they are read back through the vector path)
-            PROF_MARK_ALL(9);
-            wv::fence_own_stores();
-            // COPY_N loads in flight, then their stores: one element per trip (load, wait, store) was a dependent
-            // HBM round trip per timestep -- T of them in every second wave, and the slowest wave is the kernel's time
-            enum { COPY_N = 16 };
-            const float *src = L.scr0;
-            float *dst = L.out0;
-            const int T = p.T;
-            for (int t0 = 0; t0 < T; t0 += COPY_N) {
-                float v[COPY_N];
+        if (wv::any(worse1)) {
+            const int nt = p.max_ls - 2;                                 // trials alpha = decay^2 .. decay^(max_ls-1)
+            float a = p.ls_decay;
 #pragma unroll
-                for (int i = 0; i < COPY_N; ++i) {
-                    const int t = t0 + i < T ? t0 + i : T - 1;       // (tail: element T-1 again, the same value to the
-                    v[i] = src[(long)t * L.ostep1];                  //  same address: no branch per element)
-                }
+            for (int k = 0; k < MAX_TRIALS; ++k) { a *= p.ls_decay; tr.alpha[k] = a; }
+            tr.park_row = worse1;                                        // (a row that took alpha = decay keeps ITS parked trajectory)
+            rollout_pass<MODE, true, DIRECT, CHECK>(p, L, d, wave, G, rs, tr, nt, base PROF_PASS);
+            bool ended_on_last = false;
+            if (worse1) {
+                float acc = tr.alpha[0], cacc = tr.cost[0];
+                bool found = false;
+                int kacc = 0;
 #pragma unroll
-                for (int i = 0; i < COPY_N; ++i) {
-                    const int t = t0 + i < T ? t0 + i : T - 1;
-                    if (worse0) wv::store_out(dst + (long)t * L.ostep, v[i]);
+                for (int k = 0; k < MAX_TRIALS; ++k) {
+                    if (k < nt && !found) {
+                        acc = tr.alpha[k];
+                        cacc = tr.cost[k];
+                        kacc = k;
+                        if (!(tr.cost[k] > old_cost)) found = true;
+                    }
                 }
+                rs.alpha = acc;
+                ended_on_last = kacc == nt - 1;
+                if (ended_on_last) { rs.cost = cacc; rs.du2 = tr.du2_last; }
             }
-            PROF_MARK_ALL(12);          // slot 12: copy of the second trial's trajectory
-            return;
-        }
-        const int nt = p.max_ls - 2;                                 // trials alpha = decay^2 .. decay^(max_ls-1)
-        float a = p.ls_decay;
-#pragma unroll
-        for (int k = 0; k < MAX_TRIALS; ++k) { a *= p.ls_decay; tr.alpha[k] = a; }
-        rollout_pass<MODE, true, DIRECT, CHECK>(p, L, d, wave, G, rs, tr, nt, base PROF_PASS);
-        if (worse1) {
-            float acc = tr.alpha[0];
-            bool found = false;
-#pragma unroll
-            for (int k = 0; k < MAX_TRIALS; ++k) {
-                if (k < nt && !found) {
-                    acc = tr.alpha[k];
-                    if (!(tr.cost[k] > old_cost)) found = true;
-                }
+            if (wv::any(worse1 && !ended_on_last)) {
+                rollout_pass<MODE, false, DIRECT, CHECK>(p, L, d, wave, G, rs, tr, 0, base PROF_PASS);   // replay: every row stores its accepted trial
+                return;
             }
-            rs.alpha = acc;
         }
-        rollout_pass<MODE, false, DIRECT, CHECK>(p, L, d, wave, G, rs, tr, 0, base PROF_PASS);       // replay: every row stores its accepted trial
+        // every row's accepted trajectory is on hand: trial 0 in new_x / new_u, trial 1 or the last one parked in the workspace
+        copy_parked = true;
+    }
+    if (copy_parked) {
+        // parked trajectory -> new_x / new_u, rows that did not take the full step (the stores of this wave's own passes must
+        // have landed: they are read back through the vector path)
+        PROF_MARK_ALL(9);
+        wv::fence_own_stores();
+        // COPY_N loads in flight, then their stores: one element per trip (load, wait, store) was a dependent
+        // HBM round trip per timestep -- T of them in every second wave, and the slowest wave is the kernel's time
+        enum { COPY_N = 16 };
+        const float *src = L.scr0;
+        float *dst = L.out0;
+        const int T = p.T;
+        for (int t0 = 0; t0 < T; t0 += COPY_N) {
+            float v[COPY_N];
+#pragma unroll
+            for (int i = 0; i < COPY_N; ++i) {
+                const int t = t0 + i < T ? t0 + i : T - 1;
+                v[i] = src[(long)t * L.ostep1];
+            }
+#pragma unroll
+            for (int i = 0; i < COPY_N; ++i) {
+                const int t = t0 + i < T ? t0 + i : T - 1;
+                if (worse0) wv::store_out(dst + (long)t * L.ostep, v[i]);
+            }
+        }
+        PROF_MARK_ALL(12);          // slot 12: copy of the parked trajectory
         return;
     }
 #pragma unroll 1

@@ -1287,3 +1287,36 @@ def test_emulated_float64_kernel_flags_a_C_symmetric_to_float32_rounding_only(em
     np.testing.assert_allclose(r["new_u"][:, 0::2], o["new_u"][:, 0::2], rtol=1e-10, atol=1e-11)
     r32 = emu.lqr_step(dtype=np.float32, **kw)
     assert ((r32["status"] & 8) == 0).all()
+
+
+@pytest.mark.parametrize("kernel", ["dpp16", "dpp16_ring2"])
+@pytest.mark.parametrize("max_ls,decay", [(10, 0.2), (4, 0.5), (3, 0.5)])
+def test_emulated_dpp16_rows_that_never_improve_end_on_the_parked_last_trial(emu, kernel, max_ls, decay):
+    """The box-constrained line search of the 12/4 kernel with rows of one wavefront ending everywhere: the full step, alpha =
+    decay (copied out of the workspace), a middle trial (replayed) and -- round 5 -- the LAST trial of the multi-trial pass, whose
+    trajectory that pass parks for the rows still searching so that a wavefront whose rows all end on trial 0, 1 or the last
+    copies instead of replaying (what the late iterations of a solve see: problems that get worse for every step size, the
+    reference returns their last trial, mpc/lqr_step.py:176-179, 250-252).  Against the oracle: step sizes, trajectories, costs,
+    both du norms."""
+    from oracle import lqr_oracle as O
+    seen = set()
+    for seed in range(12):
+        rng = np.random.default_rng(900 + seed)
+        T, B = 7, 8
+        pr = _ns_problem(rng, T, B)
+        # per problem: convex, mildly or strongly non-convex in the state (the full step then makes things worse)
+        pr["C"][:, :, :12, :12] -= (rng.choice([0.0, 30.0, 60.0], size=(1, B, 1, 1))) * np.eye(12)
+        cur_u = np.clip(0.5 * rng.standard_normal((T, B, 4)), -0.4, 0.4)
+        cur_x, _ = O.traj_cost(pr["x_init"], cur_u, pr["F"], pr["f"])
+        kw = dict(cur_x=cur_x, cur_u=cur_u, u_lower=-0.4, u_upper=0.4, linesearch_decay=decay, max_linesearch_iter=max_ls, **pr)
+        o = O.lqr_step(lockstep=False, **kw)
+        depth = np.rint(np.log(o["alphas"]) / np.log(decay)).astype(int)
+        seen |= set(depth.tolist())
+        r = emu.lqr_step(kernel=kernel, dma_late=bool(seed & 1), nominal_on_dynamics=True, **kw)
+        np.testing.assert_allclose(r["alphas"], o["alphas"], rtol=1e-6)
+        np.testing.assert_allclose(r["new_x"], o["new_x"], rtol=2e-3, atol=2e-3 * (1 + np.abs(o["new_x"]).max() * 0.05))
+        np.testing.assert_allclose(r["new_u"], o["new_u"], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(r["costs"], o["costs"], rtol=2e-3, atol=1e-2)
+        np.testing.assert_allclose(r["full_du_norm"], o["full_du_norm"], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(r["alpha_du_norm"], o["alpha_du_norm"], rtol=2e-3, atol=2e-3)
+    assert {0, 1, max_ls - 1} <= seen, seen
