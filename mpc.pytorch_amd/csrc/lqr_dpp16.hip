@@ -25,6 +25,9 @@ MPC_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
 MPC_DEV bool uniform(bool c) { return c; }
 MPC_DEV int uniform(int v) { return v; }
 MPC_DEV bool any(bool c) { return __ballot(c) != 0ull; }
+MPC_DEV unsigned long long ballot(bool c) { return __ballot(c); }
+// the value of lane l (wave-uniform l)
+MPC_DEV float readlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), __builtin_amdgcn_readfirstlane(l))); }
 
 // ---- batched 4x4 outer products on the matrix core -------------------------------------------------
 // v_mfma_f32_4x4x1_16b_f32 with cbsz=2: sixteen independent 4x4 rank-1 updates, four per 16-lane row; the A

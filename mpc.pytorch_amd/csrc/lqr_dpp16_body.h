@@ -1241,6 +1241,7 @@ struct Trials {
     float du2_last;
     float *park;
     bool park_row;
+    int park_k;             // which of this row's trials is "the last one" (-1: none of them)
 };
 
 template <int MODE, bool DIRECT>
@@ -1255,7 +1256,7 @@ MPC_DEV void trials_step(const P &p, const Lane &L, const RoStage &s, Trials &tr
             const float un = control_law<MODE>(p, L, s, tr.xs[k], tr.alpha[k], e, dx);
             const float tp = L.isu ? un : tr.xs[k];
             tr.cost[k] += stage_price<MODE, DIRECT>(L, s, tp, e, dx);
-            if (PARK && k == nt - 1) {
+            if (PARK && k == tr.park_k) {
                 const float d = sel(L.isu, s.tb - un, 0.f);
                 tr.du2_last = fmaf(d, d, tr.du2_last);
                 if (tr.park_row) *tr.park = tp;          // (a plain store: read back by this wave within the launch)
@@ -1363,6 +1364,25 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gai
     }
 }
 
+// The lane offsets of row L as if it held problem slot `ps` of the wave (identity-priced rollouts only: F rows, record, gains):
+// what lets the four rows of a wavefront roll out trials of ONE problem side by side (line_search).
+MPC_DEV Lane lane_as_slot(const Lane &L, int ps, const P &p, int wave)
+{
+    Lane X = L;
+    const int dp = ps - L.p;
+    const int pb = 4 * wave + ps < p.B ? 4 * wave + ps : p.B - 1;
+    X.p = ps;
+    X.pb = pb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) X.aFq[q] += dp * 768;
+    X.aRec += dp * 256; X.aRecA += dp * 256; X.aRecF += dp * 256;
+    X.aKrow += dp * 256; X.aMcol += dp * 256; X.aGcol += dp * 256; X.aFm += dp * 256;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) X.aS[b] += dp * 256;
+    X.scr0 = p.Kk + (long)p.T * p.B * 128 + (long)pb * 16 + L.j;
+    return X;
+}
+
 // The line search of mpc/lqr_step.py:164-261, every row (problem) on its own.
 // :176-179, 247, 252: the step shrinks while the cost got worse; the first trial that did not get worse is
 // taken, else the last one.  Backtracking is usually one step deep (box-constrained problems) or runs to
@@ -1392,28 +1412,69 @@ MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, const Gain
         }
         if (wv::any(worse1)) {
             const int nt = p.max_ls - 2;                                 // trials alpha = decay^2 .. decay^(max_ls-1)
-            float a = p.ls_decay;
-#pragma unroll
-            for (int k = 0; k < MAX_TRIALS; ++k) { a *= p.ls_decay; tr.alpha[k] = a; }
-            tr.park_row = worse1;                                        // (a row that took alpha = decay keeps ITS parked trajectory)
-            rollout_pass<MODE, true, DIRECT, CHECK>(p, L, d, wave, G, rs, tr, nt, base PROF_PASS);
             bool ended_on_last = false;
-            if (worse1) {
-                float acc = tr.alpha[0], cacc = tr.cost[0];
-                bool found = false;
-                int kacc = 0;
+            const unsigned long long wm = wv::ballot(worse1 && L.j == 0);    // bit 16 r: row r is still searching
+            const int n_w = (int)__builtin_popcountll(wm);
+            // (round 5) ONE row left -- in the late iterations of a solve, one row of one wavefront in a thousand: a problem that gets
+            // worse for every step size --: the FOUR rows roll out the trials of that one problem side by side, nt / 4 each (the stage
+            // holds all four problems' blocks: a row reads another slot's by its offsets), instead of every row all nt trials of its
+            // own problem: a quarter of the pass's arithmetic.  Same step sizes, same rule.  ONE call
+            // site serves both forms (every row its own problem = slot L.p, all nt trials): the pass is inlined where it is called.
+            const bool shared = n_w == 1 && nt >= 4;
+            const int ps1 = (int)(__builtin_ctzll(wm | (1ull << 63)) >> 4);                   // the one row still searching
+            const int nt_row = shared ? (nt + 3) / 4 : nt;
+            const int r_last = shared ? (nt - 1) / nt_row : 0;
+            if (shared) MPC_STAT(7); else MPC_STAT(8);
+            {
+                const int ps = ps1;
+                const Lane X = lane_as_slot(L, shared ? ps : L.p, p, wave);
+                const int idx0 = shared ? L.p * nt_row : 0;
+                float a = p.ls_decay;
+                for (int i = 0; i <= (idx0 < nt - 1 ? idx0 : nt - 1); ++i) a *= p.ls_decay;            // decay^(2 + min(idx0, nt - 1))
 #pragma unroll
                 for (int k = 0; k < MAX_TRIALS; ++k) {
-                    if (k < nt && !found) {
-                        acc = tr.alpha[k];
-                        cacc = tr.cost[k];
-                        kacc = k;
-                        if (!(tr.cost[k] > old_cost)) found = true;
+                    tr.alpha[k] = a;
+                    if (idx0 + k + 1 <= nt - 1) a *= p.ls_decay;                                      // (trials past the last repeat it)
+                }
+                tr.park_k = shared ? (L.p == r_last ? (nt - 1) - r_last * nt_row : -1) : nt - 1;
+                tr.park_row = shared || worse1;                                // (a row that took alpha = decay keeps ITS parked trajectory)
+                const float base_s = shared ? wv::readlane(base, 16 * ps) : base, old_s = shared ? wv::readlane(old_cost, 16 * ps) : old_cost;
+                rollout_pass<MODE, true, DIRECT, CHECK>(p, X, d, wave, G, rs, tr, nt_row, base_s PROF_PASS);
+                // the first trial that did not get worse, else the last
+                float acc = 0.f, cacc = 0.f, du2_l = tr.du2_last;
+                int kacc = 0;
+                bool found = false;
+                if (shared) {
+                    // trial idx = r nt_row + k sits in row r, slot k
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int k = 0; k < MAX_TRIALS; ++k) {
+                            if (k < nt_row && r * nt_row + k < nt && !found) {
+                                acc = wv::readlane(tr.alpha[k], 16 * r);
+                                cacc = wv::readlane(tr.cost[k], 16 * r);
+                                kacc = r * nt_row + k;
+                                if (!(cacc > old_s)) found = true;
+                            }
+                        }
+                    }
+                    du2_l = wv::readlane(tr.du2_last, 16 * r_last);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < MAX_TRIALS; ++k) {
+                        if (k < nt && !found) {
+                            acc = tr.alpha[k];
+                            cacc = tr.cost[k];
+                            kacc = k;
+                            if (!(tr.cost[k] > old_cost)) found = true;
+                        }
                     }
                 }
-                rs.alpha = acc;
-                ended_on_last = kacc == nt - 1;
-                if (ended_on_last) { rs.cost = cacc; rs.du2 = tr.du2_last; }
+                if (shared ? L.p == ps : worse1) {
+                    rs.alpha = acc;
+                    ended_on_last = kacc == nt - 1;
+                    if (ended_on_last) { rs.cost = cacc; rs.du2 = du2_l; }
+                }
             }
             if (wv::any(worse1 && !ended_on_last)) {
                 rollout_pass<MODE, false, DIRECT, CHECK>(p, L, d, wave, G, rs, tr, 0, base PROF_PASS);   // replay: every row stores its accepted trial

@@ -1299,6 +1299,9 @@ def test_emulated_dpp16_rows_that_never_improve_end_on_the_parked_last_trial(emu
     reference returns their last trial, mpc/lqr_step.py:176-179, 250-252).  Against the oracle: step sizes, trajectories, costs,
     both du norms."""
     from oracle import lqr_oracle as O
+    import ctypes
+    stats = (ctypes.c_long * 16).in_dll(emu.lib_ring2() if "ring2" in kernel else emu.lib(), "emu_stats")
+    stats[7] = stats[8] = 0
     seen = set()
     for seed in range(12):
         rng = np.random.default_rng(900 + seed)
@@ -1320,3 +1323,8 @@ def test_emulated_dpp16_rows_that_never_improve_end_on_the_parked_last_trial(emu
         np.testing.assert_allclose(r["full_du_norm"], o["full_du_norm"], rtol=2e-3, atol=2e-3)
         np.testing.assert_allclose(r["alpha_du_norm"], o["alpha_du_norm"], rtol=2e-3, atol=2e-3)
     assert {0, 1, max_ls - 1} <= seen, seen
+    # (emu_stats 7 / 8: wavefronts whose remaining trials ran row-parallel for one problem at a time / every row its own)
+    if max_ls >= 6:
+        assert stats[7] > 0 and stats[8] > 0, (stats[7], stats[8])
+    else:
+        assert stats[7] == 0 and stats[8] > 0, (stats[7], stats[8])
