@@ -1287,3 +1287,28 @@ def test_fused_backward_ignores_the_forwards_u_zero_I_and_delta_u_like_the_refer
     torch.cuda.synchronize()
     for k in ("dx_init", "dC", "dc", "dF", "df"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_the_checker_on_this_box_is_the_pinned_one():
+    """Every full-size parity test in the -m gpu run leans on the C oracle as built ON THIS BOX (oracle/liblqr_oracle.so travels
+    prebuilt, but the box's libm / OpenMP runtime are its own).  Hold it to the reference's fixtures here too -- the same checks
+    as tests/test_oracle_golden.py, which the CPU run collects: step (whole batch and per problem), KKT backward, pnqp, trajectory
+    and cost."""
+    import test_oracle_golden as G
+    G.test_fixture_inventory()
+    for name in G.STEP_CASES:
+        for mode in ("batch", "pp"):
+            G.test_lqr_step_matches_reference(name, mode)
+        try:
+            G.test_full_du_norm_and_reference_scramble(name)
+        except pytest.skip.Exception:
+            pass                                             # (cases whose per-problem fixture came from duplicated pairs)
+    for name in G.GRAD_CASES:
+        for lock in (True, False):
+            G.test_kkt_backward_matches_reference(name, lock)
+    for name in G.PNQP_CASES:
+        for mode in ("batch", "pp"):
+            G.test_pnqp_matches_reference(name, mode)
+    G.test_traj_and_cost_match_reference()
+    G.test_oracle_edge_cases()

@@ -35,6 +35,8 @@ if cfg5:
 else:
     p = bench.make_problem(ns, nc, T, B, torch.float32, dev, seed=5, u_scale=0.3 if bounded else 0.0, clamp=1.0 if bounded else None)
 kw = dict(u_lower=-1.0, u_upper=1.0) if bounded else {}
+if os.environ.get("PROF_ONE_MAXLS"):            # (what the line search beyond the first trial costs: 1 = full step only)
+    kw["max_linesearch_iter"] = int(os.environ["PROF_ONE_MAXLS"])
 opts = StepOptions(**kw) if bare else StepOptions(nominal_on_dynamics=True, c_symmetric=True, **kw)
 a = (p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"])
 if "kkt" in kind:
