@@ -1312,3 +1312,68 @@ def test_the_checker_on_this_box_is_the_pinned_one():
             G.test_pnqp_matches_reference(name, mode)
     G.test_traj_and_cost_match_reference()
     G.test_oracle_edge_cases()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_ls,decay", [(10, 0.2), (7, 0.5), (4, 0.5)])
+@pytest.mark.parametrize("stuck_per_wave", [1, 2])
+def test_box_constrained_12_4_line_search_tails_vs_oracle(be, max_ls, decay, stuck_per_wave):
+    """The tail of the 12/4 kernel's box-constrained line search on the GPU (lqr_dpp16_body.h, line_search): problems whose state cost
+    is non-convex get worse for several step sizes, some for all of them (the reference then returns the last trial,
+    mpc/lqr_step.py:176-179, 250-252).  ONE such problem in a wavefront: the four rows roll out its remaining trials side by side;
+    two: every row its own.  Either way the parked last trial is copied out or the accepted one replayed.  Step sizes, trajectories,
+    costs and both norms against the oracle, 64 wavefronts, float32."""
+    from oracle import lqr_oracle as O
+    from mpc import _native
+    from mpc._native import StepOptions
+    rng = np.random.default_rng(4242 + max_ls + stuck_per_wave)
+    T, B, ns, nc, n = 8, 256, 12, 4, 16      # (a short horizon: over a long one the negative curvature piles up in V and Quu stops being positive definite)
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A)
+    # per wavefront (four consecutive problems): `stuck_per_wave` problems mildly / strongly non-convex in the state
+    indef = np.zeros(B)
+    for w in range(B // 4):
+        rows = rng.choice(4, size=stuck_per_wave, replace=False)
+        indef[4 * w + rows] = rng.choice([30.0, 60.0], size=stuck_per_wave)
+    C[:, :, :ns, :ns] -= indef[None, :, None, None] * np.eye(ns)
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((T - 1, B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((T - 1, B, ns, nc)) / np.sqrt(ns)), 3)
+    f = 0.1 * rng.standard_normal((T - 1, B, ns))
+    x_init = rng.standard_normal((B, ns))
+    cur_u = np.clip(0.5 * rng.standard_normal((T, B, nc)), -0.4, 0.4)
+    f32 = lambda a: a.astype(np.float32)
+    C, c, F, f, x_init, cur_u = map(f32, (C, c, F, f, x_init, cur_u))
+    cur_x = f32(O.traj_cost(x_init.astype(np.float64), cur_u.astype(np.float64), F.astype(np.float64), f.astype(np.float64))[0])
+    kw = dict(u_lower=-0.4, u_upper=0.4, linesearch_decay=decay, max_linesearch_iter=max_ls)
+    o = O.lqr_step(x_init=x_init.astype(np.float64), C=C.astype(np.float64), c=c.astype(np.float64), F=F.astype(np.float64),
+                   f=f.astype(np.float64), cur_x=cur_x.astype(np.float64), cur_u=cur_u.astype(np.float64), lockstep=False, **kw)
+    depth = np.rint(np.log(o["alphas"]) / np.log(decay)).astype(int)
+    assert (depth == max_ls - 1).sum() >= 3 and (depth == 0).sum() >= 4 and ((depth > 1) & (depth < max_ls - 1)).sum() >= 1, np.bincount(depth)
+    for nominal_on_dynamics in (False, True):
+        r = be.lqr_step(dev(x_init), dev(C), dev(c), dev(F), dev(f), dev(cur_x), dev(cur_u),
+                        StepOptions(nominal_on_dynamics=nominal_on_dynamics, **kw), impl=_native.IMPL_DPP16)
+        torch.cuda.synchronize()
+        r = {k: host(v) for k, v in r.items() if torch.is_tensor(v)}
+        # a cost within rounding of the old one may fall on either side of the acceptance test: such problems are named, not compared
+        margin = np.abs(o["costs"] - o["old_costs"]) <= 2e-5 * (1 + np.abs(o["old_costs"]))
+        # ... and so is a problem whose box QP did not converge AND whose step size came out different: the non-convex problems'
+        # Quu is not positive definite at every timestep (MPC_ST_PNQP_UNCONVERGED on all of them, as the reference warns), and where
+        # float32 and float64 trips part ways the costs do too.  A handful; everything else -- most of the stuck problems among
+        # them -- is held to the oracle.
+        qp_open = (r["status"] & 1) != 0
+        flip = ~np.isclose(r["alphas"], o["alphas"], rtol=1e-6)
+        assert (flip & ~margin & ~qp_open).sum() == 0 and flip.sum() <= 4, (np.nonzero(flip)[0], r["alphas"][flip], o["alphas"][flip])
+        # (the same for a QP that ended in a different corner of the box at an equal step size: the emulator -- the kernel's own float32
+        # arithmetic on the CPU -- lands where the GPU does, tests/test_emu_mfma16.py holds that path entry by entry)
+        corner = qp_open & ((np.abs(r["new_u"] - o["new_u"]).max(axis=(0, 2)) > 2e-3) |
+                            ~np.isclose(r["full_du_norm"], o["full_du_norm"], rtol=2e-3, atol=2e-3))     # (the full step's corner: a small step hides it in new_u)
+        assert corner.sum() <= (4 if stuck_per_wave == 1 else 8), np.nonzero(corner)[0]      # (of 64 / 128 non-convex problems)
+        keep = ~flip & ~corner
+        assert (keep & (depth == max_ls - 1)).sum() >= 3 and (keep & (depth > 1)).sum() >= 8
+        scale = 1 + np.abs(o["new_x"]).max(axis=(0, 2))
+        np.testing.assert_allclose(r["new_x"][:, keep], o["new_x"][:, keep], rtol=2e-3, atol=2e-3 * scale[keep].max())
+        np.testing.assert_allclose(r["new_u"][:, keep], o["new_u"][:, keep], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(r["costs"][keep], o["costs"][keep], rtol=2e-3, atol=1e-2)
+        np.testing.assert_allclose(r["full_du_norm"][keep], o["full_du_norm"][keep], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(r["alpha_du_norm"][keep], o["alpha_du_norm"][keep], rtol=2e-3, atol=2e-3)
