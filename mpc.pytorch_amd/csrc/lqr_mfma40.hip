@@ -181,6 +181,11 @@ template <int N> MPC_DEV void dma_wait()
     static_assert(N >= 0 && N < 64, "vmcnt is 6 bits on gfx9");
     asm volatile("s_waitcnt vmcnt(%0) ; counted" ::"n"(N) : "memory");
 }
+// acc = max(acc, |a|, |b|): one v_max3_f32 with source modifiers (fmaxf() costs a canonicalising v_max per operand)
+MPC_DEV void absmax3(float &acc, float a, float b)
+{
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(acc) : "v"(a), "v"(b));
+}
 }  // namespace wv
 }  // namespace mpclqr
 

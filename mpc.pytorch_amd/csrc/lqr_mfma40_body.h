@@ -878,7 +878,8 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             for (int J = 0; J < 3; ++J) {
                 // only tile row / column 2 has padding (rows, columns 40..47)
                 const bool in = (I < 2 || L.q < 2) && (J < 2 || L.r < 8);
-                const f32x4 x = wv::lds_f32x4(base + OFF_C + 4u * (unsigned)(in ? (16 * J + L.r) * N + 16 * I + 4 * L.q : 0));
+                // (a padding lane reads on -- into the next row, or F's block of the stage -- and is zeroed below: one lane address + compile-time offsets)
+                const f32x4 x = wv::lds_f32x4(base + OFF_C + 4u * (unsigned)(L.r * N + 4 * L.q) + 4u * (unsigned)(16 * J * N + 16 * I));
 #pragma unroll
                 for (int v = 0; v < 4; ++v) Qd[I][J][v] = in ? x[v] : 0.f;
             }
@@ -887,17 +888,26 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         // of the upper-triangle tiles (every unordered pair once) and keep the largest difference, with the largest
         // entry as the scale: MPC_ST_C_ASYMMETRIC at the end of the sweep.  Skipped when the caller vouches for C.
         if (!p.c_symmetric) {
+            // (round 5: ONE lane address and compile-time offsets -- a lane of the padding, rows / columns 40..47 of the third tile row /
+            // column, reads on into F's block of the stage and is masked in the compare, not in the address: 24 address selects and
+            // adds a timestep less; the maxima as v_max3 with |.| modifiers, two entries an instruction)
+            const unsigned a0 = base + OFF_C + 4u * (unsigned)(4 * L.q * N + L.r);
 #pragma unroll
             for (int I = 0; I < 3; ++I)
 #pragma unroll
                 for (int J = I; J < 3; ++J) {
                     const bool in = (I < 2 || L.q < 2) && (J < 2 || L.r < 8);
+                    float dq[4];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const float tr = wv::lds_f32(base + OFF_C + 4u * (unsigned)(in ? (16 * I + 4 * L.q + v) * N + 16 * J + L.r : 0));
-                        asym = fmaxf(asym, fabsf(in ? Qd[I][J][v] - tr : 0.f));
-                        cmax = fmaxf(cmax, fabsf(Qd[I][J][v]));
+                        const float tr = wv::lds_f32(a0 + 4u * (unsigned)((16 * I + v) * N + 16 * J));
+                        const float dd = Qd[I][J][v] - tr;
+                        dq[v] = (J < 2) ? dd : (in ? dd : 0.f);          // (I = 2 means J = 2: only the third tile column has padding here)
                     }
+                    wv::absmax3(asym, dq[0], dq[1]);
+                    wv::absmax3(asym, dq[2], dq[3]);
+                    wv::absmax3(cmax, Qd[I][J][0], Qd[I][J][1]);
+                    wv::absmax3(cmax, Qd[I][J][2], Qd[I][J][3]);
                 }
         }
         float tcol[3][4], trow[3], crow[3];
@@ -906,14 +916,14 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int i = 16 * I + 4 * L.q + v;
-                const float x = wv::lds_f32(base + OFF_R + 160 + 4u * (unsigned)(i < N ? i : 0));
+                const float x = wv::lds_f32(base + OFF_R + 160 + 4u * (unsigned)i);        // (i up to 47: still inside the record, zeroed below)
                 tcol[I][v] = i < N ? x : 0.f;
             }
 #pragma unroll
         for (int J = 0; J < 3; ++J) {
             const int j = 16 * J + L.r;
-            const float x = wv::lds_f32(base + OFF_R + 160 + 4u * (unsigned)(j < N ? j : 0));
-            const float c = wv::lds_f32(base + OFF_R + 4u * (unsigned)(j < N ? j : 0));
+            const float x = wv::lds_f32(base + OFF_R + 160 + 4u * (unsigned)j);
+            const float c = wv::lds_f32(base + OFF_R + 4u * (unsigned)j);
             trow[J] = j < N ? x : 0.f;
             crow[J] = j < N ? (KKT ? -c : c) : 0.f;
         }
@@ -957,7 +967,7 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                     for (int J = 0; J < 3; ++J) {
                         const int m = 16 * Ip + 4 * L.q + v, col = 16 * J + L.r;
                         const bool in = J < 2 || L.r < 8;
-                        const float x = wv::lds_f32(base + OFF_F + 4u * (unsigned)(m * N + (in ? col : 0)));
+                        const float x = wv::lds_f32(base + OFF_F + 4u * (unsigned)(m * N + col));       // (col up to 47: the next row, zeroed below)
                         FB[4 * Ip + v][J] = in ? x : 0.f;
                     }
             if (verify) {
@@ -979,6 +989,8 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                 }
             }
             // ---- Y = V F   (A operand = V by symmetry: register v of tile (I', Im))
+            // (round 5, tried: c_back and q = c_back + F'v issued INSIDE this region, interleaved with the MFMAs by scheduling groups --
+            // one MFMA, one or two vector instructions --: 281 -> 283-292 us.  The blocks stay undivided.)
             wv::sched_fence();
             // (three tiles at a time, their accumulation chains interleaved: an MFMA that waits for the previous one's
             // accumulator issues every 40 clocks, an independent one every 32)

@@ -1,5 +1,5 @@
 """One MPC.forward at the headline shape under `rocprofv3 --kernel-trace --output-format csv`: which kernels, in what order,
-with what gaps.   rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tr -o tr -- python tools/trace_mpc_forward.py [bounded | pendulum | cartpole]
+with what gaps.   rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tr -o tr -- python tools/trace_mpc_forward.py [bounded | cfg5 | pendulum | cartpole | nn]
 then   python tools/trace_mpc_forward.py --read gpurun_out/tr"""
 import sys, os, glob, csv, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -53,8 +53,9 @@ if "nn" in sys.argv:                               # bench.py's nn_mpc_forward_5
             ctrl(p["x_init"], QuadCost(p["C"], p["c"]), dyn)
     torch.cuda.synchronize()
     sys.exit(0)
-p = bench.make_problem(12, 4, 50, 4096, torch.float32, "cuda:0", seed=5, u_scale=0.3 if bounded else 0.0, clamp=1.0 if bounded else None)
-ctrl = mpc.MPC(12, 4, 50, u_lower=-1.0 if bounded else None, u_upper=1.0 if bounded else None, lqr_iter=5, verbose=-1,
+ns_, nc_, T_, B_ = (32, 8, 64, 1024) if "cfg5" in sys.argv else (12, 4, 50, 4096)          # (cfg5: BASELINE config 5 per GPU)
+p = bench.make_problem(ns_, nc_, T_, B_, torch.float32, "cuda:0", seed=9 if "cfg5" in sys.argv else 5, u_scale=0.3 if bounded else 0.0, clamp=1.0 if bounded else None)
+ctrl = mpc.MPC(ns_, nc_, T_, u_lower=-1.0 if bounded else None, u_upper=1.0 if bounded else None, lqr_iter=5, verbose=-1,
                exit_unconverged=False, detach_unconverged=False, backprop=False)
 cost, dx = QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"])
 for _ in range(30):
