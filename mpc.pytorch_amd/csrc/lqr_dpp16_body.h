@@ -1643,9 +1643,15 @@ MPC_DEV void step_wave(const P &p)
         line_search<MODE, false, true>(p, L, d, wave, G, rs, old_cost, (float)(old_cost_d + ss.w0), full2 PROF_PASS);
         // a nominal that does not obey the dynamics voids the identity the pass was priced with: price the
         // rollout the reference's way, from a second stream of C
-        const bool broken = wv::row_sum(rs.viol > 0.f ? 1.f : 0.f) > 0.f;
+        const bool off = wv::row_sum(rs.viol > 0.f ? 1.f : 0.f) > 0.f;
+        // (round 5) ... and so is a problem one of whose box QPs did not converge -- in practice a Quu that is not positive definite:
+        // V then grows to 1e5 times the cost, J_nominal + w0 is what is left of two float32 sums that size, and the identity's price
+        // was seen 3 % off the cost of the very trajectory it belongs to (a positive definite problem: 1e-7).  The call that makes
+        // no promises checks this premise like the other one; the vouched call trusts its caller with both (the same test on that
+        // path -- a second site for the inlined pass -- cost the convex step 4 %: profiles/r05_ab_direct_pricing.log).
+        const bool broken = off || (MODE == 2 && (ss.status & MPC_ST_PNQP_UNCONVERGED) != 0);
         if (wv::any(broken)) line_search<MODE, true, false>(p, L, d, wave, G, rs, old_cost, 0.f, full2 PROF_PASS);
-        if (broken) ss.status |= MPC_ST_NOMINAL_OFF_DYNAMICS;
+        if (off) ss.status |= MPC_ST_NOMINAL_OFF_DYNAMICS;
     }
 #ifdef MPC_DPP16_PROF
     PROF_MARK_ALL(9);           // slot 9: between the loops + rollout tail; slots 4-7: the same four phases of the rollout
