@@ -1649,6 +1649,10 @@ MPC_DEV void step_wave(const P &p)
         // was seen 3 % off the cost of the very trajectory it belongs to (a positive definite problem: 1e-7).  The call that makes
         // no promises checks this premise like the other one; the vouched call trusts its caller with both (the same test on that
         // path -- a second site for the inlined pass -- cost the convex step 4 %: profiles/r05_ab_direct_pricing.log).
+        // (NOT checked: a price that is the small difference of large numbers.  The identity's cost carries an absolute error of about
+        // 3e-8 (|J_nominal| + |w0|) -- 1 % of the cost was seen on a nominal 1.5e5 times dearer than the step it leads to,
+        // tools/emu_fuzz.py; the decisions stand on margins that size.  A test for it here fires on one problem in a few thousand
+        // of the benchmark's batch, and one wavefront that re-prices is the launch: 92 -> 123 us.  DESIGN 6.)
         const bool broken = off || (MODE == 2 && (ss.status & MPC_ST_PNQP_UNCONVERGED) != 0);
         if (wv::any(broken)) line_search<MODE, true, false>(p, L, d, wave, G, rs, old_cost, 0.f, full2 PROF_PASS);
         if (off) ss.status |= MPC_ST_NOMINAL_OFF_DYNAMICS;

@@ -1,0 +1,25 @@
+"""A slice of tools/emu_fuzz.py in the CPU suite: the fused kernels' bodies on the wavefront emulator against the float64 oracle over
+random option sets (ragged batches, horizons, bounds of every kind, delta_u, u_zero_I, promises, qp_start, line-search depth).
+The tool runs thousands of cases in minutes; here a fixed seed's first cases, so that a change to a body that breaks an option
+combination no parametrised test names shows up without the GPU."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("kernels,cases,long_t", [("dpp16,dpp16_ring2,mfma16", 150, False), ("mfma40,mfma40_ring2", 24, False),
+                                                   ("dpp16,dpp16_ring2", 24, True)])
+def test_emulated_bodies_on_random_option_sets(kernels, cases, long_t):
+    if not (os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or __import__("shutil").which("clang++")):
+        pytest.skip("the emulator needs clang++")
+    env = dict(os.environ)
+    if long_t:
+        env["FUZZ_LONG_T"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_fuzz.py"), str(cases), "11", kernels],
+                       capture_output=True, text=True, env=env, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "violations 0" in p.stdout
