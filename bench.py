@@ -1020,6 +1020,15 @@ def main():
                             "late-t blocks in the Infinity Cache for the next launch's sweep"}
         r = plans[(turn[0] - 1) % len(plans)]()      # (the certified results again: plan outputs are overwritten by every call)
         torch.cuda.synchronize()
+    # (round 5) ... and the timed region's own launches once more, behind it: `value` is the K steps of the contract whatever happened in
+    # them; a box that stalled for milliseconds inside (seen once in ten runs: 0.79 ms per step where every other measure of the
+    # run said 0.09) shows as `repeat_kernel_ms` far below `kernel_ms`
+    repeat_ms = None
+    if dist is None:
+        _w, repeat_ms, _r = timed(step, args.steps, 0)
+        r = plans[(turn[0] - 1) % len(plans)]() if len(plans) > 1 else step()
+        p = psets[(turn[0] - 1) % len(plans)]
+        torch.cuda.synchronize()
     kern_ms_all = (sum(a.elapsed_time(b_) for a, b_ in pre_ev) + kern_ms * args.steps) / max(1, n_all)
     ranks_seen = 1
     if dist is not None:
@@ -1117,7 +1126,7 @@ def main():
                        "ranks_seen": ranks_seen},
             "roofline": hbm_roofline(abytes, kern_ms, traffic=traffic, traffic_source=traffic_source, kernel_ms_all_launches=kern_ms_all,
                                      frac_all_launches=abytes / (kern_ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     launches_all=n_all, problem_sets=len(plans), same_set=same_set),
+                                     launches_all=n_all, problem_sets=len(plans), same_set=same_set, repeat_kernel_ms=repeat_ms),
         }
         if dist is not None:
             out["parity"] = dict(par_rank, scope="rank 0's first 16 problems; every rank checks its own 16 and the run's `finite` is the MIN over ranks")
