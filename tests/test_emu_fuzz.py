@@ -23,3 +23,15 @@ def test_emulated_bodies_on_random_option_sets(kernels, cases, long_t):
                        capture_output=True, text=True, env=env, timeout=1500)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "violations 0" in p.stdout
+
+
+@pytest.mark.parametrize("which,cases", [("dpp16", 60), ("mfma40", 16)])
+def test_emulated_kkt_backward_on_random_option_sets(which, cases):
+    """tools/emu_fuzz_kkt.py: the fused KKT backward bodies against LQRStepFn.backward of the oracle -- horizons across the 64-step
+    limit of the register-resident gains, ragged batches, bounds of every kind, f on / off, both ring builds."""
+    if not (os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or __import__("shutil").which("clang++")):
+        pytest.skip("the emulator needs clang++")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_fuzz_kkt.py"), str(cases), "11", which],
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "violations 0" in p.stdout

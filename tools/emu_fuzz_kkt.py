@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""No GPU: the fused KKT backward kernels' bodies (12/4: kkt_fused_wave of lqr_dpp16_body.h, plain / masked / long-horizon; 32/8:
+kkt_fused_wave of lqr_mfma40_body.h) on the CPU wavefront emulator against LQRStepFn.backward of the float64 oracle over random
+horizons (across the 64-step limit of the register-resident gains), ragged batches, bounds (none / scalar / tensor), f on / off,
+ring variants.  The solution differentiated at is a few oracle LQR steps from a random nominal.  Exits non-zero on a violation.
+    python tools/emu_fuzz_kkt.py [cases [seed [dpp16|mfma40]]]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "mpc.pytorch_amd"))
+from oracle import lqr_oracle as O
+import emu_backend as emu
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+which = sys.argv[3] if len(sys.argv) > 3 else "dpp16"
+bad = 0
+t0 = time.time()
+for case in range(cases):
+    rng = np.random.default_rng(seed0 * 7919 + case)
+    ns, nc = (32, 8) if which == "mfma40" else (12, 4)
+    n = ns + nc
+    T = int(rng.choice([1, 2, 3, 5, 8, 20, 40, 66]) if which == "mfma40" else rng.choice([1, 2, 3, 4, 6, 7, 9, 17, 33, 63, 64, 65, 70]))
+    B = int(rng.choice([1, 2, 3])) if which == "mfma40" else int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9]))
+    Tm = max(T, 2)
+    A = rng.standard_normal((Tm, B, n, n)); C = np.einsum("tbji,tbjk->tbik", A, A)
+    c = rng.standard_normal((Tm, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((Tm - 1, B, ns, ns)) / np.sqrt(ns), rng.standard_normal((Tm - 1, B, ns, nc)) / np.sqrt(ns)), 3)
+    f = 0.1 * rng.standard_normal((Tm - 1, B, ns)) if rng.random() < 0.7 else None
+    x_init = rng.standard_normal((B, ns))
+    if T == 1:
+        C, c, F, f = C[:1], c[:1], F[:0], (f[:0] if f is not None else None)
+    bnd = float(rng.choice([0.25, 0.5, 1.0]))          # (float32-exact: a control ON a bound stays on it when the solution is rounded to float32)
+    mode = str(rng.choice(["none", "scalar", "tensor"]))
+    lo = hi = None
+    if mode == "scalar":
+        lo, hi = -bnd, bnd
+    elif mode == "tensor":
+        lo, hi = -bnd - 0.2 * rng.random((T, B, nc)), bnd + 0.2 * rng.random((T, B, nc))
+        lo, hi = lo.astype(np.float32).astype(np.float64), hi.astype(np.float32).astype(np.float64)
+    cur_u = np.clip(0.5 * rng.standard_normal((T, B, nc)), -bnd, bnd)
+    cur_x, _ = O.traj_cost(x_init, cur_u, F, f)
+    x, u = cur_x, cur_u
+    for _ in range(4):
+        sol = O.lqr_step(x_init, C, c, F, f, x, u, lockstep=False, u_lower=lo, u_upper=hi)
+        x, u = sol["new_x"], sol["new_u"]
+    x, u = x.astype(np.float32).astype(np.float64), u.astype(np.float32).astype(np.float64)
+    dl_dx, dl_du = rng.standard_normal((T, B, ns)), rng.standard_normal((T, B, nc))
+    o = O.kkt_backward(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, lockstep=False)
+    dma_late = bool(rng.integers(0, 2))
+    if which == "mfma40":
+        r = emu.kkt_fused_mfma40(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, sweep3=True)
+        label = "mfma40"
+    else:
+        ring2 = bool(rng.integers(0, 2))
+        r = emu.kkt_fused(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, ring2=ring2)
+        label = "dpp16 ring2=%s" % ring2
+    worst = {}
+    for k in ("dx", "du", "dC", "dc", "dF", "dx_init") + (("df",) if f is not None and T > 1 else ()):
+        if o.get(k) is None or o[k].size == 0 or r.get(k) is None:
+            continue
+        err = np.abs(r[k] - o[k]).max() / max(1.0, np.abs(o[k]).max()) if np.isfinite(r[k]).all() else np.inf
+        worst[k] = float("%.3g" % err)
+    if max(worst.values()) > 3e-4:
+        bad += 1
+        print("VIOLATION case %d seed0 %d %s T %d B %d bounds %s f %s dma_late %s: %s" % (case, seed0, label, T, B, mode, f is not None, dma_late, worst))
+print("cases %d violations %d  (%.0f s)" % (cases, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
