@@ -22,8 +22,14 @@ for case in range(cases):
     rng = np.random.default_rng(seed0 * 100003 + case)
     kernel = kernels[case % len(kernels)]
     ns, nc = (32, 8) if kernel.startswith("mfma40") else (12, 4)
-    if kernel == "mfma16" and rng.random() < 0.5:
+    f64 = kernel == "mfma16_f64"                       # the float64 instantiation of the one-problem-per-wave body
+    if kernel in ("mfma16", "mfma16_f64") and rng.random() < 0.5:
         ns, nc = int(rng.integers(1, 13)), int(rng.integers(1, 5))
+    if kernel == "mfma40_pad":                        # the padded instantiation of the 32/8 body: dword or 16-byte gathers
+        if rng.random() < 0.5:
+            ns, nc, kernel = int(rng.integers(1, 33)), int(rng.integers(1, 9)), "mfma40_pad4"
+        else:
+            ns, nc, kernel = 4 * int(rng.integers(1, 9)), 4 * int(rng.integers(1, 3)), "mfma40_pad16"
     n = ns + nc
     long_T = os.environ.get("FUZZ_LONG_T")            # horizons across the register-resident gains' limit (64) and several ring turns
     T = int(rng.choice([1, 2, 3, 5, 8, 13] + ([40, 66] if long_T else []))) if ns > 12 else int(rng.choice([1, 2, 3, 4, 5, 7, 9, 12, 17] + ([33, 63, 64, 65, 70] if long_T else [])))
@@ -54,10 +60,10 @@ for case in range(cases):
     if mode in ("scalar", "tensor") and rng.random() < 0.25:
         kw.update(delta_u=float(rng.choice([0.05, 0.2, 1.0])))
     o = O.lqr_step(lockstep=False, **kw)
-    ekw = dict(kernel=kernel, dma_late=bool(rng.integers(0, 2)), nominal_on_dynamics=bool(rng.integers(0, 2)), c_symmetric=bool(rng.integers(0, 2)))
-    if kernel == "mfma16" and (ns, nc) == (12, 4):
+    ekw = dict(kernel="mfma16" if f64 else kernel, **({"dtype": np.float64} if f64 else {}), dma_late=bool(rng.integers(0, 2)), nominal_on_dynamics=bool(rng.integers(0, 2)), c_symmetric=bool(rng.integers(0, 2)))
+    if kernel == "mfma16" and (ns, nc) == (12, 4) and not f64:
         ekw["force_general"] = bool(rng.integers(0, 2))
-    if mode in ("scalar", "tensor") and kernel != "mfma16" and rng.random() < 0.3:
+    if mode in ("scalar", "tensor") and kernel in ("dpp16", "dpp16_ring2", "mfma40", "mfma40_ring2") and rng.random() < 0.3:
         ekw["qp_start"] = rng.standard_normal((T, B, nc)) if rng.random() < 0.5 else np.zeros((1, 1, nc))
     if only and ":" in only:
         ekw["kernel"] = only.split(":")[1]
@@ -78,11 +84,13 @@ for case in range(cases):
                 du=(np.abs(r["full_du_norm"] - o["full_du_norm"]) / (1 + o["full_du_norm"]))[k].max(initial=0))
     if only:
         print("case %d kernel %s vouched %s T %d B %d mode %s: errs %s, |x| max %.3g, cost %s old %s" % (case, ekw["kernel"], ekw["nominal_on_dynamics"], T, B, mode, {k2: float("%.3g" % v) for k2, v in errs.items()}, np.abs(o["new_x"]).max(), np.round(o["costs"], 1), np.round(o["old_costs"], 1)))
-    # (the 12/4 kernel prices by the identity J_nominal + w0 + ...: its reported cost carries ~1e-7 |J_nominal| / |J|)
-    ctol = 2e-4 + (3e-7 * float((np.abs(o["old_costs"]) / (1 + np.abs(o["costs"]))).max()) if ekw["kernel"].startswith("dpp16") else 0.0)
+    # (the 12/4 and 32/8 kernels price by the identity J_nominal + w0 + ...: the reported cost carries ~1e-7 |J_nominal| / |J|)
+    ctol = 2e-4 + (3e-7 * float((np.abs(o["old_costs"]) / (1 + np.abs(o["costs"]))).max()) if ekw["kernel"].startswith(("dpp16", "mfma40")) else 0.0)
     # (new_u = u + k + K dx in float32: the error grows with how far the step moves the states, 1e-6 of it)
     move = float(np.abs(np.asarray(kw["cur_x"]) - o["new_x"]).max())
     xtol = 1e-3 + 3e-6 * move
+    if f64:
+        xtol, ctol = 1e-8 + 1e-12 * move, 1e-9
     viol = (flip & ~tie).any() or errs["x"] * scale > xtol * scale or errs["u"] > xtol or errs["cost"] > ctol or errs["du"] > 1e-3 or not np.isfinite(r["new_x"]).all()
     if viol:
         bad += 1
