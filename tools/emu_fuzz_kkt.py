@@ -3,13 +3,33 @@
 kkt_fused_wave of lqr_mfma40_body.h) on the CPU wavefront emulator against LQRStepFn.backward of the float64 oracle over random
 horizons (across the 64-step limit of the register-resident gains), ragged batches, bounds (none / scalar / tensor), f on / off,
 ring variants.  The solution differentiated at is a few oracle LQR steps from a random nominal.  Exits non-zero on a violation.
-    python tools/emu_fuzz_kkt.py [cases [seed [dpp16|mfma40]]]"""
+    python tools/emu_fuzz_kkt.py [cases [seed [dpp16|mfma40]]]
+FUZZ_GPU=1: the same cases through mpc_lqr_kkt_fused / the three-launch route on the MI355X (c_symmetric on or off, float32)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "mpc.pytorch_amd"))
 from oracle import lqr_oracle as O
-import emu_backend as emu
+GPU = bool(os.environ.get("FUZZ_GPU"))
+if GPU:
+    import torch
+    from mpc import _native
+    from mpc._native import StepOptions
+    _be = _native.HipBackend()
+    _dev = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(torch.float32).to("cuda:0")
+
+    def _gpu_kkt(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, c_symmetric):
+        T, B, n = C.shape[0], C.shape[1], C.shape[2]
+        ns = x.shape[2]
+        Fd = _dev(F) if T > 1 else torch.zeros((0, B, ns, n), dtype=torch.float32, device="cuda:0")
+        if isinstance(lo, np.ndarray):
+            lo, hi = _dev(lo), _dev(hi)
+        g = _be.kkt_backward(_dev(C), _dev(c), Fd, _dev(f) if (f is not None and T > 1) else None, _dev(x), _dev(u), _dev(dl_dx), _dev(dl_du),
+                             StepOptions(u_lower=lo, u_upper=hi, c_symmetric=c_symmetric))
+        torch.cuda.synchronize()
+        return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else None) for k, v in g.items() if k != "_keep"}
+else:
+    import emu_backend as emu
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -21,7 +41,7 @@ for case in range(cases):
     ns, nc = (32, 8) if which == "mfma40" else (12, 4)
     n = ns + nc
     T = int(rng.choice([1, 2, 3, 5, 8, 20, 40, 66]) if which == "mfma40" else rng.choice([1, 2, 3, 4, 6, 7, 9, 17, 33, 63, 64, 65, 70]))
-    B = int(rng.choice([1, 2, 3])) if which == "mfma40" else int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9]))
+    B = int(rng.choice([1, 2, 3] + ([17, 40] if GPU else []))) if which == "mfma40" else int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9] + ([33, 130] if GPU else [])))
     Tm = max(T, 2)
     A = rng.standard_normal((Tm, B, n, n)); C = np.einsum("tbji,tbjk->tbik", A, A)
     c = rng.standard_normal((Tm, B, n))
@@ -48,7 +68,11 @@ for case in range(cases):
     dl_dx, dl_du = rng.standard_normal((T, B, ns)), rng.standard_normal((T, B, nc))
     o = O.kkt_backward(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, lockstep=False)
     dma_late = bool(rng.integers(0, 2))
-    if which == "mfma40":
+    if GPU:
+        csym = bool(rng.integers(0, 2))
+        r = _gpu_kkt(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, csym)
+        label = "%s GPU c_symmetric=%s" % (which, csym)
+    elif which == "mfma40":
         r = emu.kkt_fused_mfma40(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, sweep3=True)
         label = "mfma40"
     else:
