@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Child of tools/ref_diff_mpc.py: runs the UNMODIFIED reference (locuslab/mpc.pytorch under $MPC_REFERENCE_DIR or /root/reference)
+on pickled cases and pickles what it returned.  Imports nothing of this repository (both packages are called `mpc`)."""
+import os, pickle, sys, warnings
+ref = os.environ.get("MPC_REFERENCE_DIR", "/root/reference")
+sys.path.insert(0, ref)
+import torch
+from mpc import mpc
+from mpc.mpc import QuadCost, LinDx
+warnings.filterwarnings("ignore")
+cases = pickle.load(open(sys.argv[1], "rb"))
+out = []
+for cs in cases:
+    t = lambda a: None if a is None else torch.from_numpy(a).clone()
+    C, c, F, f, x0 = t(cs["C"]), t(cs["c"]), t(cs["F"]), t(cs["f"]), t(cs["x_init"])
+    if cs["grads"]:
+        C.requires_grad_(True); c.requires_grad_(True); x0.requires_grad_(True)
+    kw = dict(cs["kw"])
+    for k in ("u_lower", "u_upper", "u_init", "u_zero_I"):
+        if isinstance(kw.get(k), __import__("numpy").ndarray):
+            kw[k] = t(kw[k])
+    try:
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            ctrl = mpc.MPC(cs["ns"], cs["nc"], cs["T"], verbose=-1, **kw)
+            x, u, costs = ctrl(x0, QuadCost(C, c), LinDx(F, f))
+        r = dict(x=x.detach().numpy(), u=u.detach().numpy(), costs=costs.detach().numpy())
+        if cs["grads"]:
+            w = torch.from_numpy(cs["w"])
+            (u * w).sum().backward()
+            r.update(gC=C.grad.numpy(), gc=c.grad.numpy(), gx0=x0.grad.numpy())
+    except Exception as e:                       # (the reference asserts / raises on some configurations: the mirror must raise too)
+        r = dict(error=type(e).__name__ + ": " + str(e)[:200])
+    out.append(r)
+pickle.dump(out, open(sys.argv[2], "wb"))
