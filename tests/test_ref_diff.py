@@ -16,3 +16,12 @@ def test_mpc_host_logic_against_the_unmodified_reference_on_random_configuration
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_diff_mpc.py"), "120", "17"], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "violations 0" in p.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "mpc")), reason="the reference is not on this box")
+def test_the_oracle_against_the_unmodified_reference_on_random_problems():
+    """tools/ref_diff_oracle.py: the pin of tests/test_oracle_golden.py (72 fixtures) on random problems -- LQRStep forward with
+    lockstep semantics and LQRStepFn.backward through the reference's own autograd, float64, 1e-7."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_diff_oracle.py"), "150", "17"], capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "violations 0" in p.stdout
