@@ -25,3 +25,11 @@ def test_the_oracle_against_the_unmodified_reference_on_random_problems():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_diff_oracle.py"), "150", "17"], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "violations 0" in p.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "mpc")), reason="the reference is not on this box")
+def test_the_oracle_other_entry_points_against_the_unmodified_reference():
+    """tools/ref_diff_misc.py: pnqp (solution, free set, iteration count), get_traj / get_cost, NNDynamics forward and grad_input."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_diff_misc.py"), "240", "17"], capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "violations 0" in p.stdout
