@@ -21,6 +21,21 @@ for cs in cases:
             x = util.get_traj(cs["T"], t(cs["u"]), x_init=t(cs["x_init"]), dynamics=dx)
             cost = util.get_cost(cs["T"], t(cs["u"]), QuadCost(t(cs["C"]), t(cs["c"])), dx, x_init=t(cs["x_init"]))
             r = dict(x=x.numpy(), cost=cost.numpy())
+        elif cs["kind"] == "env":
+            import importlib
+            mod = importlib.import_module("mpc.env_dx." + cs["env"])
+            if cs["env"] == "pendulum":
+                dx = mod.PendulumDx(params=t(cs["params"]), simple=cs["simple"])
+            else:
+                dx = mod.CartpoleDx(params=t(cs["params"]))
+            x, u = t(cs["x"]).requires_grad_(True), t(cs["u"]).requires_grad_(True)
+            y = dx(x, u)
+            # the Jacobian MPC.linearize_dynamics(AUTO_DIFF) forms (mpc/mpc.py:528-549): one backward per output
+            J = []
+            for k in range(y.shape[1]):
+                gx, gu = torch.autograd.grad(y[:, k].sum(), (x, u), retain_graph=True)
+                J.append(torch.cat((gx, gu), 1))
+            r = dict(y=y.detach().numpy(), J=torch.stack(J, 1).numpy())
         else:
             net = NNDynamics(cs["ns"], cs["nc"], hidden_sizes=list(cs["hidden"]), activation=cs["act"], passthrough=cs["passthrough"]).double()
             with torch.no_grad():
