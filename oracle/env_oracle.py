@@ -89,12 +89,14 @@ def u_max_of(kind):
     return 100.0 if kind == CARTPOLE else 2.0
 
 
-def pendulum_step(x, u, params, simple=True, dt=DT, max_torque=2.0):
-    """x [N,3] = (cos th, sin th, dth), u [N,1]."""
+def pendulum_step(x, u, params, simple=True, dt=DT, max_torque=2.0, th=None):
+    """x [N,3] = (cos th, sin th, dth), u [N,1].  th: the angle as an argument of its own (linearize differentiates through it by the
+    chain rule, not across atan2's branch cut); None: atan2 of the state, as the module has it."""
     x = np.asarray(x, dtype=np.float64)
     tq = np.clip(np.asarray(u, dtype=np.float64)[:, 0], -max_torque, max_torque)      # :66
     c, s, w = x[:, 0], x[:, 1], x[:, 2]
-    th = np.arctan2(s, c)                                                             # :68
+    if th is None:
+        th = np.arctan2(s, c)                                                         # :68
     if simple:
         g, m, l = params[:3]
         w2 = w + dt * (-3. * g / (2. * l) * (-s) + 3. * tq / (m * l ** 2))            # :70-71
@@ -105,14 +107,15 @@ def pendulum_step(x, u, params, simple=True, dt=DT, max_torque=2.0):
     return np.stack((np.cos(th2), np.sin(th2), w2), 1)                                # :77
 
 
-def cartpole_step(st, u, params, dt=DT, force_mag=100.0):
-    """st [N,5] = (x, dx, cos th, sin th, dth), u [N,1]."""
+def cartpole_step(st, u, params, dt=DT, force_mag=100.0, th=None):
+    """st [N,5] = (x, dx, cos th, sin th, dth), u [N,1].  th: see pendulum_step."""
     st = np.asarray(st, dtype=np.float64)
     g, mc, mp, l = params
     mt, pml = mp + mc, mp * l                                                         # :70-71
     f = np.clip(np.asarray(u, dtype=np.float64)[:, 0], -force_mag, force_mag)         # :73
     x, v, c, s, w = (st[:, i] for i in range(5))
-    th = np.arctan2(s, c)                                                             # :76
+    if th is None:
+        th = np.arctan2(s, c)                                                         # :76
     cart_in = (f + pml * w ** 2 * s) / mt                                             # :78
     th_acc = (g * s - c * cart_in) / (l * (4. / 3. - mp * c ** 2 / mt))               # :79-81
     xacc = cart_in - pml * th_acc * c / mt                                            # :82
@@ -120,13 +123,13 @@ def cartpole_step(st, u, params, dt=DT, force_mag=100.0):
     return np.stack((x + dt * v, v + dt * xacc, np.cos(th2), np.sin(th2), w + dt * th_acc), 1)   # :84-91
 
 
-def step(kind, x, u, params, clamp=True):
+def step(kind, x, u, params, clamp=True, th=None):
     if kind == MLP:
         return mlp_step(x, u, params)
     lim = u_max_of(kind) if clamp else np.inf
     if kind == CARTPOLE:
-        return cartpole_step(x, u, params, force_mag=lim)
-    return pendulum_step(x, u, params, simple=(kind == PENDULUM), max_torque=lim)
+        return cartpole_step(x, u, params, force_mag=lim, th=th)
+    return pendulum_step(x, u, params, simple=(kind == PENDULUM), max_torque=lim, th=th)
 
 
 def linearize(kind, x, u, params, h=2e-4):
@@ -147,14 +150,30 @@ def linearize(kind, x, u, params, h=2e-4):
     lim = u_max_of(kind)
     tau_c = np.concatenate((x, np.clip(u, -lim, lim)), 1)
 
+    # The angle th = atan2(sin, cos) is differentiated by the chain rule (d th = (c ds - s dc) / (c^2 + s^2), autograd's rule), the
+    # differences are taken with th as an argument of its own: a difference ACROSS atan2's branch cut (a state within h of
+    # th = +-pi) is 2 pi / h times the damping coefficient of the full pendulum model, not a derivative
+    # (tools/ref_diff_misc.py found one such point in 30,000).
+    ic, isn = (0, 1) if kind != CARTPOLE else (2, 3)
+    th0 = np.arctan2(x[:, isn], x[:, ic])
+
     def central(j, hh):
         e = np.zeros(ns + 1)
         e[j] = hh
-        hi = step(kind, (tau_c + e)[:, :ns], (tau_c + e)[:, ns:], params, clamp=False)
-        lo = step(kind, (tau_c - e)[:, :ns], (tau_c - e)[:, ns:], params, clamp=False)
+        hi = step(kind, (tau_c + e)[:, :ns], (tau_c + e)[:, ns:], params, clamp=False, th=th0)
+        lo = step(kind, (tau_c - e)[:, :ns], (tau_c - e)[:, ns:], params, clamp=False, th=th0)
+        return (hi - lo) / (2 * hh)
+
+    def central_th(hh):
+        hi = step(kind, tau_c[:, :ns], tau_c[:, ns:], params, clamp=False, th=th0 + hh)
+        lo = step(kind, tau_c[:, :ns], tau_c[:, ns:], params, clamp=False, th=th0 - hh)
         return (hi - lo) / (2 * hh)
     for j in range(ns + 1):
         F[:, :, j] = (4.0 * central(j, h / 2) - central(j, h)) / 3.0     # Richardson: O(h^4)
+    dth = (4.0 * central_th(h / 2) - central_th(h)) / 3.0
+    r2 = x[:, ic] ** 2 + x[:, isn] ** 2
+    F[:, :, ic] += dth * (-x[:, isn] / r2)[:, None]
+    F[:, :, isn] += dth * (x[:, ic] / r2)[:, None]
     F[:, :, ns] *= ((u[:, 0] >= -lim) & (u[:, 0] <= lim))[:, None]
     f = step(kind, x, u, params) - np.einsum("nij,nj->ni", F, tau)
     return F, f
