@@ -20,10 +20,15 @@ for cs in cases:
         if isinstance(kw.get(k), __import__("numpy").ndarray):
             kw[k] = t(kw[k])
     try:
-        import io, contextlib
+        import io, contextlib, importlib
+        dyn = None
+        if cs.get("env"):                                    # iLQR on a shipped simulator: the module is the dynamics
+            mod = importlib.import_module("mpc.env_dx." + cs["env"])
+            dyn = mod.PendulumDx(params=t(cs["params"]), simple=cs["simple"]) if cs["env"] == "pendulum" else mod.CartpoleDx(params=t(cs["params"]))
+            kw["grad_method"] = getattr(mpc.GradMethods, kw["grad_method"])
         with contextlib.redirect_stdout(io.StringIO()):
             ctrl = mpc.MPC(cs["ns"], cs["nc"], cs["T"], verbose=-1, **kw)
-            x, u, costs = ctrl(x0, QuadCost(C, c), LinDx(F, f))
+            x, u, costs = ctrl(x0, QuadCost(C, c), dyn if dyn is not None else LinDx(F, f))
         r = dict(x=x.detach().numpy(), u=u.detach().numpy(), costs=costs.detach().numpy())
         if cs["grads"]:
             w = torch.from_numpy(cs["w"])
