@@ -26,6 +26,14 @@ for cs in cases:
             mod = importlib.import_module("mpc.env_dx." + cs["env"])
             dyn = mod.PendulumDx(params=t(cs["params"]), simple=cs["simple"]) if cs["env"] == "pendulum" else mod.CartpoleDx(params=t(cs["params"]))
             kw["grad_method"] = getattr(mpc.GradMethods, kw["grad_method"])
+        if cs.get("net"):                                    # iLQR on NNDynamics: ANALYTIC linearisation through grad_input
+            from mpc.dynamics import NNDynamics
+            nt = cs["net"]
+            dyn = NNDynamics(cs["ns"], cs["nc"], hidden_sizes=list(nt["hidden"]), activation=nt["act"], passthrough=nt["passthrough"]).double()
+            with torch.no_grad():
+                for fc, W, b in zip(dyn.fcs, nt["Ws"], nt["bs"]):
+                    fc.weight.copy_(t(W)); fc.bias.copy_(t(b))
+            kw["grad_method"] = getattr(mpc.GradMethods, kw["grad_method"])
         with contextlib.redirect_stdout(io.StringIO()):
             ctrl = mpc.MPC(cs["ns"], cs["nc"], cs["T"], verbose=-1, **kw)
             x, u, costs = ctrl(x0, QuadCost(C, c), dyn if dyn is not None else LinDx(F, f))

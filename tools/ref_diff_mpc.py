@@ -82,6 +82,18 @@ for i in range(n_cases):
         cases.append(dict(ns=ns, nc=nc, T=T, B=B, C=Cq, c=cq, F=None, f=None, x_init=x_init, kw=kw, grads=False, w=None,
                           env=env, params=params, simple=simple))
         continue
+    if rng.random() < 0.12:
+        # iLQR on NNDynamics (mpc/dynamics.py): the network linearised by its own grad_input (ANALYTIC) every iteration
+        hidden = [int(rng.integers(2, 24)) for _ in range(int(rng.integers(1, 3)))]
+        sizes = [n] + hidden + [ns]
+        net = dict(hidden=hidden, act=str(rng.choice(["sigmoid", "relu"])), passthrough=bool(rng.integers(0, 2)),
+                   Ws=[rng.standard_normal((sizes[k + 1], sizes[k])) / np.sqrt(sizes[k]) for k in range(len(sizes) - 1)],
+                   bs=[0.1 * rng.standard_normal(sizes[k + 1]) for k in range(len(sizes) - 1)])
+        kwn = dict(lqr_iter=int(rng.choice([1, 2, 4])), exit_unconverged=False, detach_unconverged=False, backprop=False, eps=1e-13,
+                   u_lower=-1.0, u_upper=1.0, linesearch_decay=float(rng.choice([0.2, 0.5])), max_linesearch_iter=int(rng.choice([3, 10])),
+                   grad_method="ANALYTIC", not_improved_lim=5, best_cost_eps=1e-4)
+        cases.append(dict(ns=ns, nc=nc, T=T, B=B, C=C, c=c, F=None, f=None, x_init=rng.standard_normal((B, ns)), kw=kwn, grads=False, w=None, net=net))
+        continue
     cases.append(dict(ns=ns, nc=nc, T=T, B=B, C=C, c=c, F=F, f=f, x_init=rng.standard_normal((B, ns)), kw=kw, grads=grads,
                       w=rng.standard_normal((T, B, nc))))
 tmp = tempfile.mkdtemp()
@@ -104,6 +116,14 @@ try:
             if cs.get("env"):
                 from mpc.env_dx import cartpole, pendulum
                 dyn = pendulum.PendulumDx(params=t(cs["params"]), simple=cs["simple"]) if cs["env"] == "pendulum" else cartpole.CartpoleDx(params=t(cs["params"]))
+                kw["grad_method"] = getattr(mpc.GradMethods, kw["grad_method"])
+            if cs.get("net"):
+                from mpc.dynamics import NNDynamics
+                nt = cs["net"]
+                dyn = NNDynamics(cs["ns"], cs["nc"], hidden_sizes=list(nt["hidden"]), activation=nt["act"], passthrough=nt["passthrough"]).double()
+                with torch.no_grad():
+                    for fc, W, b in zip(dyn.fcs, nt["Ws"], nt["bs"]):
+                        fc.weight.copy_(t(W)); fc.bias.copy_(t(b))
                 kw["grad_method"] = getattr(mpc.GradMethods, kw["grad_method"])
             ctrl = mpc.MPC(cs["ns"], cs["nc"], cs["T"], verbose=-1, **kw)
             x, u, costs = ctrl(x0, QuadCost(C, c), dyn if dyn is not None else LinDx(F, f))
@@ -132,12 +152,12 @@ try:
         worst = {}
         for k in r:
             worst[k] = float("%.3g" % (np.abs(m[k] - r[k]).max() / max(1.0, np.abs(r[k]).max())))
-        if cs.get("env"):
+        if cs.get("env") or cs.get("net"):
             if max(worst.values()) > (2e-4 if cs["kw"]["grad_method"] == "FINITE_DIFF" else 1e-6):
                 bad += 1
-                print("VIOLATION (iLQR) case %d %s simple %s T %d B %d kw %s: %s" % (i, cs["env"], cs["simple"], cs["T"], cs["B"], {k: v for k, v in cs["kw"].items()}, worst))
+                print("VIOLATION (iLQR) case %d %s simple %s T %d B %d kw %s: %s" % (i, cs.get("env", "network"), cs.get("simple"), cs["T"], cs["B"], {k: v for k, v in cs["kw"].items()}, worst))
             continue
-        if max(worst.values()) > 1e-6 and worst["costs"] < 1e-8 and max(worst["x"], worst["u"]) < 2e-4 and max(worst.values()) <= 10 * max(worst["x"], worst["u"]):
+        if max(worst.values()) > 1e-6 and worst["costs"] < 1e-7 and max(worst["x"], worst["u"]) < 2e-4 and max(worst.values()) <= 10 * max(worst["x"], worst["u"]):
             edge = globals().get("edge", 0) + 1; globals()["edge"] = edge       # (the same: a last iterate inside the QP's own tolerance)
             continue
         if max(worst.values()) > 1e-6:
