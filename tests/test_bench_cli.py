@@ -177,3 +177,64 @@ def test_cpu_baseline_times_the_unmodified_reference_where_it_is_on_the_box():
     assert par["ok"] and par["asserted"] and par["share_within_tol"] == 1.0
     r["new_u"][1, 2, 3] += 0.02
     assert not bench.reference_parity(o, r, 24, False)["ok"]
+
+
+def test_contract_line_fits_the_driver_whatever_the_run_recorded():
+    """the one stdout line had grown to 31.8 KB and the driver recorded `parsed: null`.  The line is now built by
+    bench.contract_line: <= 4 KB, `roofline` and `cpu_baseline` inside, the secondary rows as a digest -- held here on the
+    largest full record there is (round 5's), on the same record with every string and row count inflated, and on an N > 1
+    record."""
+    import copy
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line_final.json")))
+    assert len(json.dumps(full)) > 20000
+    s = bench.contract_line(full)
+    assert "\n" not in s and len(s) < 4096
+    d = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in d, k
+    assert d["value"] == pytest.approx(full["value"], rel=1e-4) and d["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-4)
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-4)
+    assert d["roofline"]["achieved"] / d["roofline"]["peak"] == pytest.approx(d["roofline"]["frac"], rel=1e-3)
+    assert d["roofline"]["traffic"] and d["roofline"]["same_set"]["frac"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and "reference_probe" not in d["cpu_baseline"]
+    assert d["parity"]["ok"] is True and "workload" in d["config"] and "model" not in d["config"]
+    assert set(d["extra_digest"]) == set(full["extra"]) and d["extra_digest"]["lqr_step_bounded"][2] is True
+    # a run that recorded far more: the line sheds its optional parts instead of growing
+    big = copy.deepcopy(full)
+    for i in range(400):
+        big["extra"]["another_row_with_a_long_name_%03d" % i] = copy.deepcopy(full["extra"]["lqr_step_bounded"])
+    big["config"]["workload"] = big["config"]["workload"]
+    big["cpu_baseline"]["sample"] = "x" * 5000
+    s2 = bench.contract_line(big)
+    d2 = json.loads(s2)
+    assert len(s2) <= 4096 and "roofline" in d2 and "cpu_baseline" in d2 and d2["value"] == d["value"]
+    # N > 1: the rows of the distributed line are digested too
+    multi = copy.deepcopy(full)
+    multi["n_gpus"] = 8
+    multi.pop("cpu_baseline")
+    multi["extra"] = {"strong_scaling": {"ms_per_step": 0.05, "value": 4.0e9, "roofline": {"frac": 0.2}, "parity_all_ranks_ok": True,
+                                         "collective": "y" * 300},
+                      "cfg5": {"ms_per_step": 0.4, "value": 1.3e9, "roofline": {"frac": 0.3}, "parity_all_ranks_ok": True}}
+    d3 = json.loads(bench.contract_line(multi))
+    assert d3["extra_digest"]["strong_scaling"] == [0.05, 0.2, True, 4.0e9] and "cpu_baseline" not in d3
+
+
+@pytest.mark.gpu
+def test_bench_stdout_is_one_short_json_line():
+    """The driver's own call, shortened (no secondary rows): stdout is exactly one line, < 4 KB, json.loads gives `roofline`
+    and `cpu_baseline`; the full record is on stderr and in bench_full.json."""
+    import json
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        r = _run(["--gpus", "1", "--steps", "5", "--warmup", "2", "--no-extra"], {"MPC_BENCH_RECORD_DIR": td})
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = r.stdout.strip().splitlines()
+        assert len(lines) == 1 and len(lines[0]) < 4096
+        d = json.loads(lines[0])
+        assert d["roofline"]["frac"] > 0.2 and d["cpu_baseline"]["value"] > 0 and d["parity"]["ok"]
+        assert d["steps"] == 5 and d["warmup"] == 2 and d["n_gpus"] == 1
+        full = json.load(open(os.path.join(td, "bench_full.json")))
+        assert full["value"] == pytest.approx(d["value"], rel=1e-4) and "bench.py full record: " in r.stderr
