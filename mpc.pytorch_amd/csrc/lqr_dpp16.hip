@@ -28,6 +28,13 @@ MPC_DEV bool any(bool c) { return __ballot(c) != 0ull; }
 MPC_DEV unsigned long long ballot(bool c) { return __ballot(c); }
 // the value of lane l (wave-uniform l)
 MPC_DEV float readlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), __builtin_amdgcn_readfirstlane(l))); }
+MPC_DEV double readlane_f64(double x, int l)
+{
+    const unsigned long long b = __double_as_longlong(x);
+    const int ll = __builtin_amdgcn_readfirstlane(l);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, ll), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), ll);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 
 // ---- batched 4x4 outer products on the matrix core -------------------------------------------------
 // v_mfma_f32_4x4x1_16b_f32 with cbsz=2: sixteen independent 4x4 rank-1 updates, four per 16-lane row; the A

@@ -63,6 +63,10 @@
 #ifndef MPC_DPP16_NSTAGE
 #define MPC_DPP16_NSTAGE 4
 #endif
+// 1: start the box QP of timestep t from the solution of timestep t+1 like the reference (rounds 1-5; kept for the A/B)
+#ifndef MPC_DPP16_QP_WARM
+#define MPC_DPP16_QP_WARM 0
+#endif
 
 namespace mpclqr {
 namespace dpp16 {
@@ -849,13 +853,22 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
             // (a NaN start would survive the clamp and poison the QP: such an entry falls back to the middle of the box's reach)
 #pragma unroll
             for (int a = 0; a < 4; ++a) kq[a] = (s.qs[a] == s.qs[a]) ? s.qs[a] : 0.f;
-        } else if (!st.warm) {
-            // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
+        } else if (!MPC_DPP16_QP_WARM || !st.warm) {
+            // cold start x = -H^-1 q (mpc/pnqp.py:14-19) -- at EVERY timestep whose Quu is positive definite (round 6).  The reference
+            // hands timestep t the solution of timestep t+1 (mpc/lqr_step.py:137,141); a strictly convex QP has ONE minimiser, so
+            // the start decides the trip count and nothing else (qp_start), and the clamped unconstrained minimiser is the
+            // better guess of the active set by a whole trip: 2.91 -> 1.99 trips per QP in the first iteration of the benchmark's
+            // box-constrained solve, 2.62 -> 1.74, 2.32 -> 1.40, 2.03 -> 1.22 in the next three (tools/qp_start_study.py, float64
+            // numpy on the harvested QPs) -- one factorisation and a confirming gradient instead of two and one, for the ~40
+            // instructions of an LDL' and its solve.  A Quu that is NOT positive definite (a pivot <= 0 or not finite: an indefinite
+            // C) keeps the reference's start: where such a QP ends does depend on where it starts.
             ldl4<false>(f, S, valid, 0.f);
             float y[4];
             ldl4_solve(f, qu[0], qu[1], qu[2], qu[3], y);
+            const bool spd = fminf(fminf(f.i0, f.i1), fminf(f.i2, f.i3)) > 0.f && fmaxf(fmaxf(f.i0, f.i1), fmaxf(f.i2, f.i3)) < 3.0e38f;
+            const bool cold = !st.warm || spd;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) kq[a] = -y[a];
+            for (int a = 0; a < 4; ++a) kq[a] = cold ? -y[a] : st.kprev[a];
         } else {
 #pragma unroll
             for (int a = 0; a < 4; ++a) kq[a] = st.kprev[a];
@@ -1275,7 +1288,7 @@ MPC_DEV void trials_step(const P &p, const Lane &L, const RoStage &s, Trials &tr
 // (trajectory stored).  Costs come back as full trajectory costs (base = J_nominal + w_0 when priced by
 // the identity, 0 when priced directly).
 template <int MODE, bool MULTI, bool DIRECT, bool CHECK, bool PAIR = false>
-MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gains<rgm(MODE)> &G, RoState &st, Trials &tr, int nt, float base PROF_ARG)
+MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gains<rgm(MODE)> &G, RoState &st, Trials &tr, int nt, double base PROF_ARG)
 {
     const int T = p.T;
     float x0 = L.isu ? 0.f : p.x_init[(long)L.pb * 12 + L.j];
@@ -1349,16 +1362,22 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gai
         }
     }
     wv::dma_wait<0>();
+    // (round 6) ONE rounding: J_nominal + w_0 + (stage terms) is added up in double and rounded once.  Rounded twice --
+    // float(J_nominal + w_0) first, the stage terms onto that -- a trial whose true change is a small DEcrease could come out one
+    // ulp ABOVE float(J_nominal) when the first rounding went up, and it did so for every step size alike (the stage terms tend to
+    // -w_0 as alpha -> 0): in the late iterations of a box-constrained solve two to five problems of 4096 "got worse for every step
+    // size", searched to the end, and their one wavefront was the launch (206-216 us against 148).  Rounding is monotone: with one
+    // rounding a trial that does not raise the cost never compares above the nominal's (mpc/lqr_step.py:176-179).
     if (MULTI) {
 #pragma unroll
         for (int k = 0; k < MAX_TRIALS; ++k)
-            if (k < nt) tr.cost[k] = base + wv::row_sum(tr.cost[k]);
+            if (k < nt) tr.cost[k] = (float)(base + (double)wv::row_sum(tr.cost[k]));
         tr.du2_last = wv::row_sum(tr.du2_last);
     } else {
-        st.cost = base + wv::row_sum(st.cost);
+        st.cost = (float)(base + (double)wv::row_sum(st.cost));
         st.du2 = wv::row_sum(st.du2);
         if (PAIR) {
-            st.cost1 = base + wv::row_sum(st.cost1);
+            st.cost1 = (float)(base + (double)wv::row_sum(st.cost1));
             st.du21 = wv::row_sum(st.du21);
         }
     }
@@ -1389,7 +1408,7 @@ MPC_DEV Lane lane_as_slot(const Lane &L, int ps, const P &p, int wave)
 // the end (a nominal that is already optimal): alpha = 1, then alpha = decay on its own, then ALL
 // remaining trials in one pass and a replay of the accepted ones.
 template <int MODE, bool DIRECT, bool CHECK>
-MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, const Gains<rgm(MODE)> &G, RoState &rs, float old_cost, float base, float &full2 PROF_ARG)
+MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, const Gains<rgm(MODE)> &G, RoState &rs, float old_cost, double base, float &full2 PROF_ARG)
 {
     Trials tr;
     rs.alpha = 1.f;
@@ -1438,7 +1457,8 @@ MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, const Gain
                 }
                 tr.park_k = shared ? (L.p == r_last ? (nt - 1) - r_last * nt_row : -1) : nt - 1;
                 tr.park_row = shared || worse1;                                // (a row that took alpha = decay keeps ITS parked trajectory)
-                const float base_s = shared ? wv::readlane(base, 16 * ps) : base, old_s = shared ? wv::readlane(old_cost, 16 * ps) : old_cost;
+                const double base_s = shared ? wv::readlane_f64(base, 16 * ps) : base;
+                const float old_s = shared ? wv::readlane(old_cost, 16 * ps) : old_cost;
                 rollout_pass<MODE, true, DIRECT, CHECK>(p, X, d, wave, G, rs, tr, nt_row, base_s PROF_PASS);
                 // the first trial that did not get worse, else the last
                 float acc = 0.f, cacc = 0.f, du2_l = tr.du2_last;
@@ -1638,9 +1658,9 @@ MPC_DEV void step_wave(const P &p)
     float full2 = 0.f;
     if (p.on_dynamics) {
         // the caller vouches for the nominal (MPC_OPT_NOMINAL_ON_DYNAMICS): no verification in the loop
-        line_search<MODE, false, false>(p, L, d, wave, G, rs, old_cost, (float)(old_cost_d + ss.w0), full2 PROF_PASS);
+        line_search<MODE, false, false>(p, L, d, wave, G, rs, old_cost, old_cost_d + ss.w0, full2 PROF_PASS);
     } else {
-        line_search<MODE, false, true>(p, L, d, wave, G, rs, old_cost, (float)(old_cost_d + ss.w0), full2 PROF_PASS);
+        line_search<MODE, false, true>(p, L, d, wave, G, rs, old_cost, old_cost_d + ss.w0, full2 PROF_PASS);
         // a nominal that does not obey the dynamics voids the identity the pass was priced with: price the
         // rollout the reference's way, from a second stream of C
         const bool off = wv::row_sum(rs.viol > 0.f ? 1.f : 0.f) > 0.f;
@@ -1654,7 +1674,7 @@ MPC_DEV void step_wave(const P &p)
         // tools/emu_fuzz.py; the decisions stand on margins that size.  A test for it here fires on one problem in a few thousand
         // of the benchmark's batch, and one wavefront that re-prices is the launch: 92 -> 123 us.  DESIGN 6.)
         const bool broken = off || (MODE == 2 && (ss.status & MPC_ST_PNQP_UNCONVERGED) != 0);
-        if (wv::any(broken)) line_search<MODE, true, false>(p, L, d, wave, G, rs, old_cost, 0.f, full2 PROF_PASS);
+        if (wv::any(broken)) line_search<MODE, true, false>(p, L, d, wave, G, rs, old_cost, 0.0, full2 PROF_PASS);
         if (off) ss.status |= MPC_ST_NOMINAL_OFF_DYNAMICS;
     }
 #ifdef MPC_DPP16_PROF

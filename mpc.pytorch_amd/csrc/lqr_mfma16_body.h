@@ -69,6 +69,11 @@
 #define MPC_M16_NS mfma16
 #endif
 
+// 1: start the box QP of timestep t from the solution of timestep t+1 like the reference (rounds 1-5; kept for the A/B)
+#ifndef MPC_MFMA16_QP_WARM
+#define MPC_MFMA16_QP_WARM 0
+#endif
+
 namespace mpclqr {
 namespace MPC_M16_NS {
 
@@ -415,14 +420,23 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
             lb[a] = valid[a] ? l : 0.f;
             ub[a] = valid[a] ? h : 0.f;
         }
-        if (!st.warm) {
-            // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
+        // (float64 keeps the reference's start, k of timestep t+1: pnqp returns the iterate whose Newton step is shorter than 1e-4
+        // WITHOUT taking that step (mpc/pnqp.py:56-59), so where the reference ends -- to within 1e-4 -- does depend on where it
+        // started, and the float64 instantiation is held to the reference at 1e-9; in float32 that 1e-4 is inside the tolerance
+        // and inside what the reference's own float32 and float64 runs differ by)
+        constexpr bool REF_START = MPC_MFMA16_QP_WARM || sizeof(real) == 8;
+        if (!REF_START || !st.warm) {
+            // cold start x = -H^-1 q (mpc/pnqp.py:14-19) at EVERY timestep whose Quu is positive definite (round 6, see
+            // lqr_dpp16_body.h: a better guess of the active set than the reference's start k_{t+1} by a whole trip per QP; a convex
+            // QP has one minimiser whatever the start).  Not positive definite: the reference's start.
             ldl4<!FULL>(f, S, valid, 0.f);
             real y[4];
             ldl4_solve(f, valid[0] ? qu[0] : 0.f, valid[1] ? qu[1] : 0.f, valid[2] ? qu[2] : 0.f,
                        valid[3] ? qu[3] : 0.f, y);
+            const real imin = rmin(rmin(f.i0, f.i1), rmin(f.i2, f.i3)), imax = rmax(rmax(f.i0, f.i1), rmax(f.i2, f.i3));
+            const bool cold = !st.warm || (imin > (real)0 && imax < (real)3.0e38);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) kq[a] = valid[a] ? -y[a] : 0.f;
+            for (int a = 0; a < 4; ++a) kq[a] = cold ? -y[a] : st.kprev[a];      // (an invalid row is an identity row with a zero right-hand side: y = 0)
         } else {
 #pragma unroll
             for (int a = 0; a < 4; ++a) kq[a] = st.kprev[a];

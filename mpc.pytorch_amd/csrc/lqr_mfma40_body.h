@@ -33,6 +33,14 @@
 #define MPC_DEVM MPC_DEV
 #endif
 
+// 1: start the box QP of timestep t from the solution of timestep t+1 like the reference (the product).
+// 0: pnqp's cold start at every timestep whose Quu is positive definite, as the 12/4 kernel does since round 6 -- measured level
+// here: 3.27 -> 2.41 trips per QP, but the 8 x 8 LDL' and its solve cost what the saved trip costs (box-constrained step at
+// B = 1024: 396 us against 394, gpurun_out r06b) -- so this kernel keeps the reference's start and the reference's path.
+#ifndef MPC_MFMA40_QP_WARM
+#define MPC_MFMA40_QP_WARM 1
+#endif
+
 namespace mpclqr {
 namespace mfma40 {
 
@@ -1152,7 +1160,9 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                     xv = r8 ? xv : 0.f;
                 }
                 xv = (xv == xv) ? xv : 0.f;              // (a NaN would survive the clamp)
-            } else if (!warm) {                          // cold start x = -H^-1 q (mpc/pnqp.py:14-19)
+            } else if (!MPC_MFMA40_QP_WARM || !warm) {
+                // cold start x = -H^-1 q (mpc/pnqp.py:14-19): the first QP of the sweep -- or, with MPC_MFMA40_QP_WARM = 0, every QP
+                // whose Quu is positive definite (see the switch's comment: measured level at this shape, not the product)
                 float colc[8], y[8];
 #pragma unroll
                 for (int a = 0; a < 8; ++a) colc[a] = col0[a];
@@ -1160,7 +1170,12 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                 ldl8v(f0, colc);
                 Pnqp8vSpread<0>::run(qv, y);
                 ldl8v_solve(f0, y);
-                xv = -gather8(y, L.r);
+                // (a Quu that is not positive definite -- a pivot <= 0 or not finite -- keeps the reference's start: where a
+                // non-convex QP ends depends on where it starts)
+                const float imin = fminf(fminf(fminf(f0.inv[0], f0.inv[1]), fminf(f0.inv[2], f0.inv[3])), fminf(fminf(f0.inv[4], f0.inv[5]), fminf(f0.inv[6], f0.inv[7])));
+                const float imax = fmaxf(fmaxf(fmaxf(f0.inv[0], f0.inv[1]), fmaxf(f0.inv[2], f0.inv[3])), fmaxf(fmaxf(f0.inv[4], f0.inv[5]), fmaxf(f0.inv[6], f0.inv[7])));
+                const bool cold = !warm || (imin > 0.f && imax < 3.0e38f);
+                xv = cold ? -gather8(y, L.r) : kprev_v;
             }
             xv = clampf(xv, lbv, ubv);                   // :23
             bool conv;

@@ -27,6 +27,8 @@ MPC_DEV float rfma(float a, float b, float c) { return fmaf(a, b, c); }
 MPC_DEV double rfma(double a, double b, double c) { return fma(a, b, c); }
 MPC_DEV float rmax(float a, float b) { return fmaxf(a, b); }
 MPC_DEV double rmax(double a, double b) { return fmax(a, b); }
+MPC_DEV float rmin(float a, float b) { return fminf(a, b); }
+MPC_DEV double rmin(double a, double b) { return fmin(a, b); }
 MPC_DEV float rabs(float a) { return fabsf(a); }
 MPC_DEV double rabs(double a) { return fabs(a); }
 MPC_DEV float rsqrt_of(float a) { return sqrtf(a); }

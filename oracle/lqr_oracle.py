@@ -23,7 +23,7 @@ class _Cfg(ctypes.Structure):
                 ("bound_mode", ctypes.c_int), ("lo_s", ctypes.c_double), ("hi_s", ctypes.c_double),
                 ("delta_u", ctypes.c_double), ("ls_decay", ctypes.c_double),
                 ("max_ls_iter", ctypes.c_int), ("pnqp_iter", ctypes.c_int),
-                ("lockstep", ctypes.c_int), ("nthreads", ctypes.c_int)]
+                ("lockstep", ctypes.c_int), ("nthreads", ctypes.c_int), ("qp_cold", ctypes.c_int)]
 
 
 def build(force=False):
@@ -70,11 +70,13 @@ def _bounds(u_lower, u_upper, T, B, nc, dtype):
 
 def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zero_I=None,
              delta_u=None, linesearch_decay=0.2, max_linesearch_iter=10, lockstep=False,
-             nthreads=1, pnqp_iter=20, return_gains=False):
+             nthreads=1, pnqp_iter=20, return_gains=False, qp_cold=False):
     """LQRStepFn.forward (mpc/lqr_step.py:277-309) on numpy arrays.
 
     lockstep=True  -> the reference called with the whole batch;
     lockstep=False -> the reference called once per problem (n_batch = 1).
+    qp_cold=True   -> every box QP whose Quu is positive definite takes pnqp's own cold start (mpc/pnqp.py:14-19) instead of
+                      k of timestep t+1 (mpc/lqr_step.py:137,141): lqr_oracle.h, the start of the fused float32 kernels.
     Returns dict(new_x, new_u, costs, old_costs, full_du_norm, alpha_du_norm, alphas, n_qp_iter[, K, k]).
     """
     C = np.asarray(C)
@@ -90,7 +92,7 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
     zm = None if u_zero_I is None else np.ascontiguousarray(np.asarray(u_zero_I).astype(np.uint8))
     cfg = _Cfg(B, T, ns, nc, mode, lo_s, hi_s, float("nan") if delta_u is None else float(delta_u),
                float(linesearch_decay), int(max_linesearch_iter), int(pnqp_iter), int(bool(lockstep)),
-               int(nthreads))
+               int(nthreads), int(bool(qp_cold)))
     out = dict(new_x=np.empty((T, B, ns), dtype), new_u=np.empty((T, B, nc), dtype),
                costs=np.empty(B, dtype), old_costs=np.empty(B, dtype), full_du_norm=np.empty(B, dtype),
                alpha_du_norm=np.empty(B, dtype), alphas=np.empty(B, dtype))

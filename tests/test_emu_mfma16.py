@@ -75,8 +75,11 @@ def test_emulated_kernel_matches_oracle_and_reference(emu, name, dma_late):
     np.testing.assert_allclose(r["new_u"], z["new_u" + sfx], rtol=1e-3, atol=atol)
     np.testing.assert_allclose(r["costs"], z["costs" + sfx], rtol=1e-4)
     if "u_lower" in z and not had_asym:        # (the oracle's count is one number for the whole batch)
-        # trip counts are not a parity quantity (float32 vs float64 stop at |dx| < 1e-4 differently): same ballpark
-        assert abs(int(r["qp_iters"].max()) - int(o["n_qp_iter"])) <= 0.1 * int(o["n_qp_iter"]) + 2
+        # trip counts are not a parity quantity (float32 vs float64 stop at |dx| < 1e-4 differently; round 6: the fused kernels start
+        # a convex QP from the clamped unconstrained minimiser, a whole trip per QP closer than the reference's k_{t+1}): at least one
+        # trip per timestep, never beyond the reference's ballpark
+        T_ = z["C"].shape[0]
+        assert T_ <= int(r["qp_iters"].max()) <= 1.1 * int(o["n_qp_iter"]) + 2
 
 
 @pytest.mark.parametrize("name", ["step_backtrack_a_f64", "step_backtrack_b_f64"])

@@ -128,7 +128,9 @@ def test_lqr_step_parity(be, name):
     if "singular" in name and z["C"].dtype == np.float32:
         assert (r["status"] & 16 != 0).sum() >= 1          # MPC_ST_QUU_SINGULAR: the problems with a dead control
     if z["C"].dtype == np.float64 and "u_lower" in z:
-        assert int(r["qp_iters"].max()) == int(z["n_qp_pp"].max())
+        # (round 6: the fused kernels start a convex QP from the clamped unconstrained minimiser instead of k_{t+1}: fewer trips
+        # than the reference, never more; the generic and lane-per-problem kernels keep the reference's start and its count)
+        assert z["C"].shape[0] <= int(r["qp_iters"].max()) <= int(z["n_qp_pp"].max())
 
 
 def test_tie_problems_follow_a_branch_the_reference_takes(be):
