@@ -463,10 +463,7 @@ namespace mpclqr {
 namespace {
 
 // MODE: 0 unconstrained with the gains in registers (T <= 64), 1 unconstrained + u_zero_I, 2 box-constrained (pnqp in the
-// sweep), 3 unconstrained with the gains through memory (any T), 4 box-constrained with the gains in registers (T <= 64)
-#ifndef MPC_DPP16_BOX_RG
-#define MPC_DPP16_BOX_RG 1          // 0: every box-constrained step on mode 2 (rounds 1-5; the A/B)
-#endif
+// sweep), 3 unconstrained with the gains through memory (any T)
 template <int MODE>
 __global__ void __launch_bounds__(64, 1) lqr_step_dpp16_kernel(StepParams<float> p)
 {
@@ -614,12 +611,7 @@ int MPC_DPP16_LAUNCH(const StepParams<float> &p, hipStream_t st)
     if (!p.sweep_only && (!p.new_x || !p.new_u)) { set_last_error("dpp16: new_x / new_u is NULL"); return MPC_E_NULL; }
     static_assert(MPC_DPP16_LDS == dpp16::LDS_TOTAL, "LDS layout out of sync");
     const dim3 grid((p.B + 3) / 4), block(64);
-    // (mode 4, round 6: the box-constrained step with its gain record in the register file, horizons up to RG_STEPS; a sweep-only
-    // call hands the record to its caller through memory: mode 2)
-    if (p.bound_mode != MPC_BOUND_NONE) {
-        if (p.T <= dpp16::RG_STEPS && !p.sweep_only && MPC_DPP16_BOX_RG) hipLaunchKernelGGL((lqr_step_dpp16_kernel<4>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((lqr_step_dpp16_kernel<2>), grid, block, 0, st, p);
-    }
+    if (p.bound_mode != MPC_BOUND_NONE) hipLaunchKernelGGL((lqr_step_dpp16_kernel<2>), grid, block, 0, st, p);
     else if (p.zero_mask) hipLaunchKernelGGL((lqr_step_dpp16_kernel<1>), grid, block, 0, st, p);
     else if (p.T <= dpp16::RG_STEPS) hipLaunchKernelGGL((lqr_step_dpp16_kernel<0>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((lqr_step_dpp16_kernel<3>), grid, block, 0, st, p);

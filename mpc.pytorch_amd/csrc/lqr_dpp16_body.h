@@ -97,13 +97,8 @@ using wv::f32x4;
 //      sweep and the rollouts (no record written, none read back: 512 of the 3,376 bytes a problem-step moves)
 //   1  unconstrained + u_zero_I          2  box-constrained (pnqp in the sweep)
 //   3  unconstrained, any T: gains through the record in memory like modes 1 and 2
-//   4  box-constrained, T <= RG_STEPS (round 6): mode 2 with the gain record -- K on the rows of the free controls, M on the rows of
-//      the pinned ones, k, Quu, the free-set flags: the same four registers a lane as mode 0's -- kept in the register file between
-//      the sweep and the rollouts; only m = qu + Quu k (16 bytes a problem-step) and k (for mpc_lqr_qp_record) go through memory:
-//      512 of the 3,456 bytes a problem-step moved, and the rollout's thirteen LDS reads of its row of K
-constexpr bool con(int MODE) { return MODE == 1 || MODE == 2 || MODE == 4; }       // constrained: (m, M) terms, masks, clamps
-constexpr bool rgm(int MODE) { return MODE < 1 || MODE == 4; }                     // register-resident gains
-constexpr bool box(int MODE) { return MODE == 2 || MODE == 4; }                    // box constraints: pnqp in the sweep, clamps in the rollout
+constexpr bool con(int MODE) { return MODE == 1 || MODE == 2; }       // constrained: (m, M) terms, masks, clamps
+constexpr bool rgm(int MODE) { return MODE < 1; }                     // register-resident gains
 
 // The gain record of timestep t as the sweep holds it: lane j < 12 K[0..3][j], lane 12 k[0..3], lanes 13..15 columns
 // 1..3 of Quu (Quu[0][0] in element 2 of lane 13).  Registers cannot be indexed by a runtime t, so put / get are
@@ -343,19 +338,16 @@ template <int MODE, bool DIRECT> struct RollDma { enum { N = 3 + 1 + (rgm(MODE) 
 // sweep's 9 KiB layout with the gains behind the record.
 template <int MODE, bool DIRECT> struct RollRing {
     enum {
-        // (register-resident gains: the stage is F | record = 4 KiB, nine stages in flight; with constraints the m block in front
-        // of it, 5 KiB: seven)
-        PACKED = con(MODE) ? (rgm(MODE) ? 5120 : 6144) : (rgm(MODE) ? 4096 : 5120),
-        BYTES = DIRECT ? (int)STAGE_BYTES : (int)PACKED,
+        // (register-resident gains: the stage is F | record = 4 KiB, nine stages in flight)
+        BYTES = DIRECT ? (int)STAGE_BYTES : (con(MODE) ? 6144 : (rgm(MODE) ? 4096 : 5120)),
 #ifdef MPC_DPP16_RSLOTS
         SLOTS = DIRECT ? (int)NSTAGE : (MPC_DPP16_RSLOTS),
 #else
-        SLOTS = DIRECT ? (int)NSTAGE : (int)LDS_TOTAL / (int)PACKED,
+        SLOTS = DIRECT ? (int)NSTAGE : (int)LDS_TOTAL / (con(MODE) ? 6144 : (rgm(MODE) ? 4096 : 5120)),
 #endif
-        FOFF = DIRECT ? (int)SF : (int)PACKED - 4096,                // F block inside a slot
-        M_IMM = (con(MODE) && rgm(MODE)) ? -1024 : -2048,            // the m block relative to the F block (packed stage)
+        FOFF = DIRECT ? (int)SF : (con(MODE) ? 2048 : (rgm(MODE) ? 0 : 1024)),        // F block inside a slot
         GADJ = DIRECT ? 0 : (int)SF - 1024 - (int)SG,                // gains / (m, M) relative to the lane offsets,
-        MADJ = DIRECT ? 0 : (int)SF + (int)M_IMM - (int)SC           // which are written for the sweep's layout
+        MADJ = DIRECT ? 0 : (int)SF - 2048 - (int)SC                 // which are written for the sweep's layout
     };
 };
 // anchor of ring slot `slot`, and the base the lane offsets (SC / SF / SR / SG relative) apply to
@@ -519,7 +511,7 @@ MPC_DEV void dma_seek(Dma &d, const P &p, const Lane &L, int wave)
         const long pb = L.pb;
         const bool want_c = !ROLL || DIRECT;            // the identity-priced rollout never looks at c
         const bool want_f = ROLL && p.f && T > 1;       // the sweep never looks at f
-        const bool want_b = box(MODE) && p.bound_mode == MPC_BOUND_TENSOR;
+        const bool want_b = MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR;
         const char *q = (const char *)(p.cur_x + pb * 12 + 4 * (gi % 3));       // the alias: a granule of the nominal state
         long st = 4 * B * 12;
         bool is_f = false;
@@ -534,7 +526,7 @@ MPC_DEV void dma_seek(Dma &d, const P &p, const Lane &L, int wave)
         } else if (gi == 11) {
             // (mpc_lqr_options.qp_start: strides may be 0 -- one block for the whole batch / horizon -- and the array may be
             // the record this very sweep rewrites: stage t is fetched AHEAD timesteps before timestep t stores its own)
-            if (MPC_QP_START && box(MODE) && !ROLL && p.qp_start) { q = (const char *)(p.qp_start + pb * p.qp_start_sb); st = 4 * p.qp_start_st; }
+            if (MPC_QP_START && MODE == 2 && !ROLL && p.qp_start) { q = (const char *)(p.qp_start + pb * p.qp_start_sb); st = 4 * p.qp_start_st; }
         } else if (gi == 12 || gi == 13) {
             if (want_b) { q = (const char *)((gi == 12 ? p.lo : p.hi) + pb * 4); st = 4 * B * 4; }
         }
@@ -545,7 +537,7 @@ MPC_DEV void dma_seek(Dma &d, const P &p, const Lane &L, int wave)
         // (round 5) the second record is m = qu + Quu k alone, 16 bytes per problem and timestep: every lane of a row fetches its
         // problem's block (one request), so lane 12 finds m at its own granule of the stage's record block (M rides in the gain
         // record, see sweep_step)
-        d.g2_ptr = (const char *)(p.Kk + (long)T * B * 64 + pb * 4) - (int)RollRing<MODE, false>::M_IMM + t0 * d.g2_step;
+        d.g2_ptr = (const char *)(p.Kk + (long)T * B * 64 + pb * 4) + 2048 + t0 * d.g2_step;
     }
 }
 
@@ -569,9 +561,9 @@ MPC_DEV void stage_issue(const Dma &d, unsigned mid)
             wv::dma16_at<0>(d.g_ptr - 1024, mid + (SG - SF));
         } else {
             wv::dma16_at<-1024>(d.g_ptr, mid);
+            if (con(MODE)) wv::dma16_at<-2048>(d.g2_ptr, mid);
         }
     }
-    if (ROLL && !DIRECT && con(MODE)) wv::dma16_at<RollRing<MODE, false>::M_IMM>(d.g2_ptr, mid);
 }
 
 // Step the pointers to the next stage of the pass (t-1 in the sweep, t+1 in a rollout).  move_f (wave-uniform):
@@ -588,8 +580,10 @@ MPC_DEV void stage_move(Dma &d, bool move_f)
 #pragma unroll
     for (int k = 0; k < 3; ++k) d.f_ptr[k] += ROLL ? fs : -fs;
     d.r_ptr += ROLL ? rs : -rs;
-    if (ROLL && !rgm(MODE)) d.g_ptr += d.g_step;
-    if (ROLL && con(MODE) && !DIRECT) d.g2_ptr += d.g2_step;
+    if (ROLL && !rgm(MODE)) {
+        d.g_ptr += d.g_step;
+        if (con(MODE) && !DIRECT) d.g2_ptr += d.g2_step;
+    }
 }
 
 // counted wait in the tail of a pass: exactly `rem` (<= K) stages of ND instructions each are newer than the one needed
@@ -622,7 +616,7 @@ template <int MODE, bool ROLL, bool DIRECT> struct Feed {
                 wv::dma16_at<3072>(d.r_ptr, mid);
             } else if (K == 2) {
                 if (!rgm(MODE)) wv::dma16_at<-1024>(d.g_ptr, mid);
-                if (con(MODE)) wv::dma16_at<RollRing<MODE, false>::M_IMM>(d.g2_ptr, mid);
+                if (con(MODE)) wv::dma16_at<-2048>(d.g2_ptr, mid);
             } else {
                 stage_move<MODE, ROLL, DIRECT>(d, move_f);
             }
@@ -726,7 +720,7 @@ MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, uns
     s.tb = wv::lds_f32(base + L.aRec + R_tau);
 #pragma unroll
     for (int a = 0; a < 4; ++a) { s.lo[a] = 0.f; s.hi[a] = 0.f; }
-    if (box(MODE)) {
+    if (MODE == 2) {
         if (p.bound_mode == MPC_BOUND_TENSOR) {
             const f32x4 l = wv::lds_f32x4(base + SR + L.p * 256 + R_lo);
             const f32x4 h = wv::lds_f32x4(base + SR + L.p * 256 + R_hi);
@@ -904,9 +898,9 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
             for (int a = 0; a < 4; ++a) K[a] = -y[a];
         } else {
 #ifdef MPC_DPP16_QP_LDL
-            ldl4_solve(box(MODE) ? qf : f, fr[0] ? rhs[0] : 0.f, fr[1] ? rhs[1] : 0.f, fr[2] ? rhs[2] : 0.f, fr[3] ? rhs[3] : 0.f, y);
+            ldl4_solve(MODE == 2 ? qf : f, fr[0] ? rhs[0] : 0.f, fr[1] ? rhs[1] : 0.f, fr[2] ? rhs[2] : 0.f, fr[3] ? rhs[3] : 0.f, y);
 #else
-            if (box(MODE)) {
+            if (MODE == 2) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) y[a] = fr[a] ? rhs[a] : 0.f;
                 gj4_solve(qf, y);
@@ -916,7 +910,7 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
 #endif
 #pragma unroll
             for (int a = 0; a < 4; ++a) K[a] = fr[a] ? -y[a] : 0.f;
-            if (box(MODE)) {
+            if (MODE == 2) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) K[a] = sel(j12, kq[a], K[a]);     // k is the QP solution (:136-141)
             }
@@ -1005,11 +999,6 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         rec[2] = sel(L.j == 13, S.s00, rec[2]);
         if (rgm(MODE)) {
             gain_put(G, t, rec);                         // stays in the register file until the rollouts
-            if (con(MODE)) {
-                // (mode 4) ... and lane 12's granule, k, to the record in memory all the same: mpc_lqr_qp_record
-                if (j12) wv::store_f32x4(st.rec, rec);
-                st.rec -= st.rec_step;
-            }
         } else {
             wv::store_f32x4(st.rec, rec);
             st.rec -= st.rec_step;
@@ -1065,23 +1054,6 @@ MPC_DEV void rg_price_terms(RoStage &s, const Lane &L)
     s.Sr[3] = a == 0 ? q03 : (a == 1 ? q13 : (a == 2 ? q23 : q33));
 }
 
-// Mode 4: the register record holds K on the rows of the free controls and M = Qux + Quu K on the rows of the pinned ones (sweep_step),
-// the free-set flags in element 3 of lane 13.  For the control law a pinned control's row of K is zero; for the identity's price lane
-// j < 12 wants column j of M -- zero on the rows of the free controls -- and lane 12 keeps m, which ro_read took from the stage.
-template <bool DIRECT>
-MPC_DEV void rg_con_terms(RoStage &s, const Lane &L)
-{
-    const unsigned fm = wv::f32_bits(wv::bcast<13>(s.rec[3]));
-    const bool below12 = L.j < 12, j12 = L.j == 12;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const bool free_a = ((fm >> a) & 1u) != 0u;
-        const float r = s.rec[a];
-        if (!DIRECT) s.Mc[a] = j12 ? s.Mc[a] : (free_a ? 0.f : r);
-        s.rec[a] = (below12 && !free_a) ? 0.f : r;
-    }
-}
-
 template <int MODE, bool DIRECT>
 MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, unsigned zm)
 {
@@ -1099,7 +1071,7 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
     } else {
 #pragma unroll
         for (int b = 0; b < 4; ++b) s.Sr[b] = rgm(MODE) ? 0.f : wv::lds_f32(gain + L.aS[b]);
-        if (con(MODE) && !rgm(MODE)) {
+        if (con(MODE)) {
             // (round 4: e'(m + M dx) = sum_j [dx_j; 1] (M | m)'e -- each lane needs ITS column, one 16-byte read, and four
             // broadcast multiply-adds of e; rounds 1-3 read row a of M on the control lanes: 13 reads, 12 multiply-adds)
             // (round 5: column j of M is this lane's own granule of the GAIN record, the rows of the pinned controls; m has the
@@ -1108,12 +1080,6 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
             const unsigned fm = wv::f32_bits(wv::lds_f32(gain + L.aFm));
 #pragma unroll
             for (int a = 0; a < 4; ++a) s.Mc[a] = (L.j == 12 || !((fm >> a) & 1u)) ? mc[a] : 0.f;
-        }
-        if (con(MODE) && rgm(MODE)) {
-            // (mode 4) m of this row's problem; rg_con_terms keeps it on lane 12 and takes the columns of M from the register record
-            const f32x4 mc = wv::lds_f32x4(mrec + L.aMcol);        // (every lane of the row fetched the row's 16 bytes into its own granule)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) s.Mc[a] = mc[a];
         }
     }
     // (t = T-1: a copy of F[T-2], unused)
@@ -1139,7 +1105,7 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
     }
     s.tb = wv::lds_f32(base + L.aRec + R_tau);
     s.lo = s.hi = 0.f;
-    if (box(MODE)) {
+    if (MODE == 2) {
         if (p.bound_mode == MPC_BOUND_TENSOR) {
             s.lo = wv::lds_f32(base + L.aRecA + R_lo);
             s.hi = wv::lds_f32(base + L.aRecA + R_hi);
@@ -1184,7 +1150,7 @@ MPC_DEV float control_law(const P &p, const Lane &L, const RoStage &s, float xs,
     }
     const float pre = un;
     if (con(MODE) && s.zm) un = 0.f;
-    if (box(MODE)) {
+    if (MODE == 2) {
         // (straight-line: without a trust region u -+ 3e38 never narrows a bound; max / min pick what the reference's
         // compare-and-select chain picks, :202-207)
         const float dlt = p.has_delta ? p.delta_u : 3.0e38f;
@@ -1295,7 +1261,7 @@ template <int MODE, bool DIRECT>
 MPC_DEV void trials_step(const P &p, const Lane &L, const RoStage &s, Trials &tr, int nt, int t)
 {
     const bool last = (t == p.T - 1);
-    constexpr bool PARK = box(MODE) && !DIRECT;
+    constexpr bool PARK = MODE == 2 && !DIRECT;
 #pragma unroll
     for (int k = 0; k < MAX_TRIALS; ++k) {
         if (k < nt) {
@@ -1347,7 +1313,7 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gai
             st.out1 = L.scr0;
         }
     }
-    st.price_on = MULTI || con(MODE) || wv::any(st.alpha != 1.f);        // (constraints: a clamped control is off the policy at any alpha)
+    st.price_on = MULTI || wv::any(st.alpha != 1.f);
     const bool use_zm = con(MODE) && p.zero_mask != nullptr;
     enum { NS = RollRing<MODE, DIRECT>::SLOTS, LA = NS - 1, ND = RollDma<MODE, DIRECT>::N };
     static_assert((LA - 1) * ND + 2 * LA < 64, "vmcnt is 6 bits");
@@ -1377,7 +1343,6 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gai
                 ro_read<MODE, DIRECT>(s, p, L, t, i, zq[i]);
                 if (rgm(MODE)) {
                     s.rec = gain_get(G, t);
-                    if (con(MODE)) rg_con_terms<DIRECT>(s, L);
                     if (!DIRECT && st.price_on) rg_price_terms(s, L);
                 }
                 PROF_MARK(5);
@@ -1449,7 +1414,7 @@ MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, const Gain
     rs.alpha = 1.f;
     bool worse0 = false;
     bool copy_parked = false;
-    if (box(MODE) && !DIRECT && p.max_ls >= 2) {
+    if (MODE == 2 && !DIRECT && p.max_ls >= 2) {
         // Box constraints: one problem in six steps back to alpha = decay, i.e. every second wave -- and the slowest wave
         // is the kernel's time.  The first pass therefore rolls out alpha = 1 AND alpha = decay side by side (one read of
         // the stage, two states; the second trajectory goes to the workspace); a row that takes the second trial copies
@@ -1474,7 +1439,7 @@ MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, const Gain
             // holds all four problems' blocks: a row reads another slot's by its offsets), instead of every row all nt trials of its
             // own problem: a quarter of the pass's arithmetic.  Same step sizes, same rule.  ONE call
             // site serves both forms (every row its own problem = slot L.p, all nt trials): the pass is inlined where it is called.
-            const bool shared = !rgm(MODE) && n_w == 1 && nt >= 4;        // (mode 4: a row's gains live in its own lanes)
+            const bool shared = n_w == 1 && nt >= 4;
             const int ps1 = (int)(__builtin_ctzll(wm | (1ull << 63)) >> 4);                   // the one row still searching
             const int nt_row = shared ? (nt + 3) / 4 : nt;
             const int r_last = shared ? (nt - 1) / nt_row : 0;
@@ -1708,7 +1673,7 @@ MPC_DEV void step_wave(const P &p)
         // 3e-8 (|J_nominal| + |w0|) -- 1 % of the cost was seen on a nominal 1.5e5 times dearer than the step it leads to,
         // tools/emu_fuzz.py; the decisions stand on margins that size.  A test for it here fires on one problem in a few thousand
         // of the benchmark's batch, and one wavefront that re-prices is the launch: 92 -> 123 us.  DESIGN 6.)
-        const bool broken = off || (box(MODE) && (ss.status & MPC_ST_PNQP_UNCONVERGED) != 0);
+        const bool broken = off || (MODE == 2 && (ss.status & MPC_ST_PNQP_UNCONVERGED) != 0);
         if (wv::any(broken)) line_search<MODE, true, false>(p, L, d, wave, G, rs, old_cost, 0.0, full2 PROF_PASS);
         if (off) ss.status |= MPC_ST_NOMINAL_OFF_DYNAMICS;
     }

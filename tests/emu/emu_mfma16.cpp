@@ -624,18 +624,10 @@ extern "C" int emu_lqr_step_mfma16_f64(const mpc_lqr_problem *p, const mpc_lqr_o
 }
 
 // ---- the 4-problems-per-wave DPP kernel (lqr_dpp16_body.h) -------------------------------------
-static int g_dpp16_box_rg = 1;
-extern "C" void emu_dpp16_box_rg(int on) { g_dpp16_box_rg = on; }
 static void body_dpp16()
 {
     const mpclqr::StepParams<float> &p = *g_p;
-    // (the library's routing, lqr_dpp16.hip: the box-constrained step keeps its gain record in the register file up to RG_STEPS
-    // timesteps -- mode 4 --, beyond that and for sweep-only calls the record goes through memory -- mode 2; emu_dpp16_box_rg(0)
-    // puts every horizon on mode 2, so that the tests reach both)
-    if (p.bound_mode != MPC_BOUND_NONE) {
-        if (p.T <= mpclqr::dpp16::RG_STEPS && !p.sweep_only && g_dpp16_box_rg) mpclqr::dpp16::step_wave<4>(p);
-        else mpclqr::dpp16::step_wave<2>(p);
-    }
+    if (p.bound_mode != MPC_BOUND_NONE) mpclqr::dpp16::step_wave<2>(p);
     else if (p.zero_mask) mpclqr::dpp16::step_wave<1>(p);
     else if (p.T <= mpclqr::dpp16::RG_STEPS) mpclqr::dpp16::step_wave<0>(p);
     else mpclqr::dpp16::step_wave<3>(p);

@@ -147,7 +147,7 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
     for key, arr in res.items():
         setattr(out, key, _ptr(arr))
     lib().emu_set_dma_late(int(bool(dma_late)))
-    if kernel in ("dpp16_ring2", "dpp16_ring2_mem"):
+    if kernel == "dpp16_ring2":
         lib_ring2().emu_set_dma_late(int(bool(dma_late)))
     if env is not None:
         e = N.EnvDynamics()
@@ -174,16 +174,10 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
         fn = lib().emu_lqr_step_wave1
         fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs)]
         rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
-    elif kernel in ("dpp16", "dpp16_mem"):
-        # ("dpp16_mem": the box-constrained step with its gain record through memory at every horizon -- mode 2, what the library
-        # runs beyond 64 timesteps and for sweep-only calls; "dpp16" routes like the library: mode 4 up to 64 timesteps)
-        lib().emu_dpp16_box_rg(int(kernel == "dpp16"))
+    elif kernel == "dpp16":
         rc = lib().emu_lqr_step_dpp16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
-        lib().emu_dpp16_box_rg(1)
-    elif kernel in ("dpp16_ring2", "dpp16_ring2_mem"):
-        lib_ring2().emu_dpp16_box_rg(int(kernel == "dpp16_ring2"))
+    elif kernel == "dpp16_ring2":
         rc = lib_ring2().emu_lqr_step_dpp16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
-        lib_ring2().emu_dpp16_box_rg(1)
     elif f32 == np.float64:
         fn = lib().emu_lqr_step_mfma16_f64
         fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs), ctypes.c_int]

@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("kernels,cases,long_t", [("dpp16,dpp16_ring2,dpp16_mem,dpp16_ring2_mem,mfma16", 200, False), ("mfma40,mfma40_ring2", 24, False),
+@pytest.mark.parametrize("kernels,cases,long_t", [("dpp16,dpp16_ring2,mfma16", 150, False), ("mfma40,mfma40_ring2", 24, False),
                                                    ("dpp16,dpp16_ring2", 24, True),
                                                    ("mfma16_f64", 60, False), ("mfma40_pad", 20, False)])
 def test_emulated_bodies_on_random_option_sets(kernels, cases, long_t):

@@ -60,10 +60,8 @@ SGPR_SPILL_LIMITS = {
     # pass, not per timestep: tools/isa_lint.py --loops shows the timestep loops unchanged, and the first-iteration step measures
     # 152.4 us against 152.8 before, profiles/r05_ab_row_parallel_trials.log.  Letting two rows take turns through a loop around the
     # pass put the count at 1499 / 1084 for nothing measurable; that form was dropped.)
-    # (round 6: mode 4 = the box-constrained step with its gain record in the accumulation registers -- the register switches of
-    # mode 0 inlined into every pass of mode 2's line search)
-    "lqr_dpp16": {"kernelILi0E": 200, "kernelILi1E": 440, "kernelILi2E": 690, "kernelILi3E": 160, "kernelILi4E": 860, "kkt_fused": 8},
-    "lqr_dpp16_ring2": {"kernelILi0E": 140, "kernelILi1E": 425, "kernelILi2E": 430, "kernelILi3E": 170, "kernelILi4E": 400, "lqr_kkt_dpp16": 0},
+    "lqr_dpp16": {"kernelILi0E": 200, "kernelILi1E": 440, "kernelILi2E": 690, "kernelILi3E": 160, "kkt_fused": 8},
+    "lqr_dpp16_ring2": {"kernelILi0E": 140, "kernelILi1E": 425, "kernelILi2E": 430, "kernelILi3E": 170, "lqr_kkt_dpp16": 0},
     "lqr_mfma40": {"kernelILi0E": 90, "kernelILi1E": 105, "kernelILi2E": 150},
     # (round 4: block addresses as scalar arithmetic -- two more base pointers live in the two-slot build of mode 0)
     "lqr_mfma40_ring2": {"kernelILi0E": 100, "kernelILi1E": 105, "kernelILi2E": 150},
@@ -104,10 +102,10 @@ def test_no_vector_spills_no_scratch_and_bounded_scalar_spills(tu):
     assert seen == set(SGPR_SPILL_LIMITS[tu]), (seen, list(md))
 
 
-@pytest.mark.parametrize("tu,kernels", [("lqr_dpp16", 9), ("lqr_dpp16_ring2", 6)])
+@pytest.mark.parametrize("tu,kernels", [("lqr_dpp16", 8), ("lqr_dpp16_ring2", 5)])
 def test_dpp16_kernels_keep_their_arrays_in_registers_and_their_dma_queue_full(tu, kernels):
-    """Both compilations of lqr_dpp16.hip (csrc/Makefile): the 4-slot ring (step kernel modes 0..4 + the fused KKT
-    backward kernels: register-resident gains up to T = 64 and the long-horizon one, each plain and masked) and the 2-slot one (the same five + the three-launch KKT gradient kernel)."""
+    """Both compilations of lqr_dpp16.hip (csrc/Makefile): the 4-slot ring (step kernel modes 0..3 + the fused KKT
+    backward kernels: register-resident gains up to T = 64 and the long-horizon one, each plain and masked) and the 2-slot one (the same four + the three-launch KKT gradient kernel)."""
     f = _findings(tu)
     assert len(f) == kernels
     for k, v in f.items():
@@ -126,18 +124,17 @@ def test_mfma40_kernels_keep_their_arrays_in_registers_and_their_dma_queue_full(
         assert v == {"scratch": 0, "drains": 0}, (k, v)
 
 
-@pytest.mark.parametrize("mode", ["Li0E", "Li4E"])
 @pytest.mark.parametrize("tu", ["lqr_dpp16", "lqr_dpp16_ring2"])
-def test_register_resident_gains_own_the_accumulation_registers(tu, mode):
-    """Mode 0 of the headline kernel (and, round 6, mode 4: the box-constrained step) parks the gains of the whole horizon in
-    a[0..255] through inline assembly (wv::rg_put / rg_get, lqr_dpp16.hip).  That is only sound while the compiler itself never
-    allocates an AccVGPR in that kernel: every a-register access must be one of the hand-written v_accvgpr_write /
-    v_accvgpr_read, and no MFMA may accumulate there."""
+def test_register_resident_gains_own_the_accumulation_registers(tu):
+    """Mode 0 of the headline kernel parks the gains of the whole horizon in a[0..255] through inline assembly
+    (wv::rg_put / rg_get, lqr_dpp16.hip).  That is only sound while the compiler itself never allocates an AccVGPR in
+    that kernel: every a-register access must be one of the hand-written v_accvgpr_write / v_accvgpr_read, and no MFMA
+    may accumulate there."""
     import re
     import isa_lint
     lines = isa_lint.assembly(tu)          # (the unconstrained step runs on the 2-slot compilation)
     kernels, _ = isa_lint.structure(lines)
-    start = [i for i, n in kernels if "kernelI" + mode in n][0]
+    start = [i for i, n in kernels if "kernelILi0E" in n][0]
     end = min([i for i, n in kernels if i > start] + [len(lines)])
     body = [l for l in lines[start:end] if not l.strip().startswith(";")]
     acc = [l for l in body if re.search(r"\ba\[?\d", l)]

@@ -26,7 +26,7 @@ if GPU:
                      qp_start=None, x_init=None, C=None, c=None, F=None, f=None, cur_x=None, cur_u=None, u_lower=None, u_upper=None,
                      u_zero_I=None, delta_u=None, linesearch_decay=0.2, max_linesearch_iter=10, auto=False):
             dt = torch.float64 if dtype == np.float64 else torch.float32
-            impl = 0 if auto else {"dpp16": 3, "dpp16_ring2": 3, "dpp16_mem": 3, "dpp16_ring2_mem": 3, "mfma16": 2, "mfma40": 5, "mfma40_ring2": 5, "mfma40_pad4": 7, "mfma40_pad16": 7}[kernel]
+            impl = 0 if auto else {"dpp16": 3, "dpp16_ring2": 3, "mfma16": 2, "mfma40": 5, "mfma40_ring2": 5, "mfma40_pad4": 7, "mfma40_pad16": 7}[kernel]
             T, B = C.shape[0], C.shape[1]
             ns = x_init.shape[1]
             n = C.shape[2]
@@ -47,7 +47,7 @@ else:
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-kernels = sys.argv[3].split(",") if len(sys.argv) > 3 else ["dpp16", "dpp16_ring2", "dpp16_mem", "mfma16"]
+kernels = sys.argv[3].split(",") if len(sys.argv) > 3 else ["dpp16", "dpp16_ring2", "mfma16"]
 bad = 0
 t0 = time.time()
 only = os.environ.get("FUZZ_ONLY")                  # FUZZ_ONLY=<case>[:kernel]: that case alone (with another kernel on the same problem)
@@ -98,7 +98,7 @@ for case in range(cases):
     ekw = dict(kernel="mfma16" if f64 else kernel, **({"dtype": np.float64} if f64 else {}), dma_late=bool(rng.integers(0, 2)), nominal_on_dynamics=bool(rng.integers(0, 2)), c_symmetric=bool(rng.integers(0, 2)))
     if kernel == "mfma16" and (ns, nc) == (12, 4) and not f64:
         ekw["force_general"] = bool(rng.integers(0, 2))
-    if mode in ("scalar", "tensor") and kernel in ("dpp16", "dpp16_ring2", "dpp16_mem", "dpp16_ring2_mem", "mfma40", "mfma40_ring2") and rng.random() < 0.3:
+    if mode in ("scalar", "tensor") and kernel in ("dpp16", "dpp16_ring2", "mfma40", "mfma40_ring2") and rng.random() < 0.3:
         ekw["qp_start"] = rng.standard_normal((T, B, nc)) if rng.random() < 0.5 else np.zeros((1, 1, nc))
     if os.environ.get("FUZZ_NO_QS"):
         ekw.pop("qp_start", None)
