@@ -246,8 +246,13 @@ def parity_check(p, r, bounded, n=PARITY_SLICE, lo=None, hi=None, be=None, start
 
     def cut(t, ax):
         return None if t is None else t.narrow(ax, start, n).detach().cpu().numpy().astype(np.float64)
+    # (round 6) the fused float32 kernels of n_state <= 12, n_ctrl <= 4 start every convex box QP from pnqp's own cold start
+    # (mpc/pnqp.py:14-19) where the reference passes k of timestep t+1: the oracle makes the same substitution (lqr_oracle.h,
+    # qp_cold) -- pnqp's result moves with its start by up to its stopping tolerance of 1e-4, which IS this check's atol
+    ns_, nc_ = int(p["x_init"].shape[1]), int(p["C"].shape[-1]) - int(p["x_init"].shape[1])
+    qp_cold = bool(lo is not None and p["C"].dtype == torch.float32 and ns_ <= 12 and nc_ <= 4 and not (nc_ == 1 and ns_ <= 6))
     o = O.lqr_step(cut(p["x_init"], 0), cut(p["C"], 1), cut(p["c"], 1), cut(p["F"], 1), cut(p["f"], 1),
-                   cut(p["cur_x"], 1), cut(p["cur_u"], 1), lo, hi, lockstep=False, nthreads=O.max_threads(), return_gains=True)
+                   cut(p["cur_x"], 1), cut(p["cur_u"], 1), lo, hi, lockstep=False, nthreads=O.max_threads(), return_gains=True, qp_cold=qp_cold)
     gx, gu, gc, ga = cut(r["new_x"], 1), cut(r["new_u"], 1), cut(r["costs"], 0), cut(r["alphas"], 0)
     rtol, atol = 1e-3, 1e-4
     px = (np.abs(gx - o["new_x"]) / (atol + rtol * np.abs(o["new_x"]))).max(axis=(0, 2))         # per problem, in units of the tolerance
@@ -279,7 +284,8 @@ def parity_check(p, r, bounded, n=PARITY_SLICE, lo=None, hi=None, be=None, start
     tie_ok = bool(np.all((gc[ties] <= old[ties] + 1e-4 * (1 + np.abs(old[ties]))) | (o["costs"][ties] > old[ties] - 1e-4 * (1 + np.abs(old[ties])))))
     ok = bool(np.isfinite(gx).all() and np.isfinite(gu).all() and mx <= 1.0 and mu <= 1.0 and mc <= 5e-4
               and not unexplained.any() and int(ties.sum()) <= max(2, n // 32) and tie_ok)
-    return {"ok": ok, "problems": n, "first_problem": int(start), "checker": "oracle/lqr_oracle.c (float64, per-problem mode)", "tol": "rtol 1e-3 atol 1e-4 (x, u), 5e-4 relative (costs)",
+    return {"ok": ok, "problems": n, "first_problem": int(start), "checker": "oracle/lqr_oracle.c (float64, per-problem mode%s)" % (", box QPs from pnqp's own cold start like the kernel" if qp_cold else ""),
+            "tol": "rtol 1e-3 atol 1e-4 (x, u), 5e-4 relative (costs)",
             "max_err_over_tol_x": mx, "max_err_over_tol_u": mu, "cost_rel": mc, "line_search_ties": int(alpha_tie.sum()),
             "active_set_ties": int(set_tie.sum()), "active_set_ties_confirmed_by": "zero rows of K (a second HIP solve of those problems with the gains written out) against the float64 run's",
             "out_of_tolerance_unexplained": int(unexplained.sum()),
