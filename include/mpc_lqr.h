@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPC_LQR_ABI_VERSION 8
+#define MPC_LQR_ABI_VERSION 9
 
 enum { MPC_F32 = 0, MPC_F64 = 1 };
 enum { MPC_BOUND_NONE = 0, MPC_BOUND_SCALAR = 1, MPC_BOUND_TENSOR = 2 };
@@ -336,6 +336,14 @@ int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double b
                     const void *x, const void *u, const void *costs, const void *du_norm,
                     void *best_x, void *best_u, void *best_costs, void *best_du_norm,
                     void *flags, void *host_flags, int32_t host_tag, const int32_t *status, void *stream);
+
+/* (12) The reference's `full_du_norm` for n_batch > 1, mpc/lqr_step.py:243-245: (u - new_u).transpose(1, 2).contiguous()
+ *      .view(n_batch, -1).norm(2, 1) -- because of the transpose in front of the reshape, out[r] is the norm of elements
+ *      [r T nc, (r+1) T nc) of the [T, nc, B] array: one or two (t, a) pairs across ALL problems, not problem r's controls
+ *      (n_batch = 1: the same thing).  mpc_lqr_step's out->full_du_norm is each problem's own norm; this entry serves
+ *      mpc.MPC(reference_du_norm=True), which reproduces the reference's eps exit and detach mask (mpc/mpc.py:299, 321-334).
+ *      u, new_u: contiguous [T,B,nc] (the nominal controls and the controls of the FULL step, alpha = 1); out [B].  (ABI 9) */
+int mpc_du_norm_reference(int dtype, int T, int B, int nc, const void *u, const void *new_u, void *out, void *stream);
 
 #ifdef __cplusplus
 }

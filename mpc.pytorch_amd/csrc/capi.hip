@@ -720,4 +720,15 @@ int mpc_select_best(int dtype, int B, int T, int ns, int nc, int first, double b
                                       flags, host_flags, host_tag, status, st);
 }
 
+int mpc_du_norm_reference(int dtype, int T, int B, int nc, const void *u, const void *new_u, void *out, void *stream)
+{
+    if (dtype != MPC_F32 && dtype != MPC_F64) return fail(MPC_E_DTYPE, "bad dtype");
+    if (B < 0 || T < 1 || nc < 1) return fail(MPC_E_DIMS, "bad dims");
+    if (B == 0) return MPC_OK;
+    if (!u || !new_u || !out) return fail(MPC_E_NULL, "du_norm_reference: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MPC_F32) return launch_du_norm_reference<float>(T, B, nc, (const float *)u, (const float *)new_u, (float *)out, st);
+    return launch_du_norm_reference<double>(T, B, nc, (const double *)u, (const double *)new_u, (double *)out, st);
+}
+
 }  // extern "C"

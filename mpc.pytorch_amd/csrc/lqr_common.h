@@ -34,6 +34,7 @@ template <typename real> int launch_select_best(int B, int T, int ns, int nc, in
                                                 const real *du_norm, real *bx, real *bu, real *bc,
                                                 real *bd, void *flags, void *host_flags, int host_tag, const int *status,
                                                 hipStream_t st);
+template <typename real> int launch_du_norm_reference(int T, int B, int nc, const real *u, const real *new_u, real *out, hipStream_t st);
 template <typename real> int launch_env_linearize(const EnvDesc<real> &env, long N, const real *x, const real *u,
                                                   real *F, real *f, hipStream_t st);
 size_t generic_lds_bytes(int ns, int nc, size_t elem);

@@ -1216,6 +1216,45 @@ int launch_select_best(int B, int T, int ns, int nc, int first, real eps, const 
 }
 
 // ---------------------------------------------------------------------------
+// The reference's full_du_norm for n_batch > 1, mpc/lqr_step.py:243-245:
+//     (u - new_u).transpose(1, 2).contiguous().view(n_batch, -1).norm(2, 1)
+// The transpose in front of the reshape makes "row r" the T n_ctrl consecutive elements [r T nc, (r+1) T nc) of the [T, nc, B]
+// array -- one or two (t, a) pairs across ALL problems, not problem r's controls (for n_batch = 1 the two are the same).  The
+// product's own norm is each problem's; this kernel serves `reference_du_norm=True`, which reproduces the reference's
+// eps exit and detach mask (mpc/mpc.py:299, 321-334).  One workgroup per row; element f of the transposed array is
+// (t, a, b) = (f / (nc B), f / B % nc, f % B).
+// ---------------------------------------------------------------------------
+template <typename real>
+__global__ void __launch_bounds__(256) du_norm_reference_kernel(int T, int B, int nc, const real *u, const real *new_u, real *out)
+{
+    const long row = (long)T * nc;
+    const long f0 = (long)blockIdx.x * row;
+    real acc = 0;
+    for (long i = threadIdx.x; i < row; i += blockDim.x) {
+        const long f = f0 + i;
+        const long b = f % B, ta = f / B;          // ta = t nc + a
+        const long src = (ta / nc * B + b) * nc + ta % nc;
+        const real d = u[src] - new_u[src];
+        acc += d * d;
+    }
+    __shared__ real part[256];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = rsqrt_<real>(part[0]);
+}
+
+template <typename real>
+int launch_du_norm_reference(int T, int B, int nc, const real *u, const real *new_u, real *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(du_norm_reference_kernel<real>, dim3(B), dim3(256), 0, st, T, B, nc, u, new_u, out);
+    return check_launch("du_norm_reference_kernel");
+}
+
+// ---------------------------------------------------------------------------
 // MPC.linearize_dynamics for a shipped simulator (mpc/mpc.py:490-549): one thread per
 // trajectory point, closed-form Jacobian, f = env(x,u) - F [x;u].
 // ---------------------------------------------------------------------------
@@ -1261,6 +1300,7 @@ int launch_env_linearize(const EnvDesc<real> &env, long N, const real *x, const 
                                           hipStream_t);                                                       \
     template int launch_env_linearize<real>(const EnvDesc<real> &, long, const real *, const real *, real *,   \
                                             real *, hipStream_t);                                             \
+    template int launch_du_norm_reference<real>(int, int, int, const real *, const real *, real *, hipStream_t); \
     template int launch_select_best<real>(int, int, int, int, int, real, const real *, const real *,          \
                                           const real *, const real *, real *, real *, real *, real *, void *, \
                                           void *, int, const int *, hipStream_t);

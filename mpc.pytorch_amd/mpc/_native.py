@@ -19,7 +19,7 @@ BOUND_NONE, BOUND_SCALAR, BOUND_TENSOR = 0, 1, 2
 ST_PNQP_UNCONVERGED, ST_NONFINITE, ST_NOMINAL_OFF_DYNAMICS, ST_C_ASYMMETRIC, ST_QUU_SINGULAR, ST_C_TESTED = 1, 2, 4, 8, 16, 32
 IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA16, IMPL_DPP16, IMPL_TINY, IMPL_MFMA40, IMPL_WAVE1, IMPL_MFMA40_PAD = 0, 1, 2, 3, 4, 5, 6, 7
 
-ABI_VERSION = 8      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
+ABI_VERSION = 9      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
 
 _vp, _i32, _i64, _f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 
@@ -187,7 +187,8 @@ EXPORTS = ("mpc_lqr_abi_version", "mpc_lqr_build_info", "mpc_lqr_last_error", "m
            "mpc_lqr_step", "mpc_lqr_impl_supported", "mpc_lqr_qp_record", "mpc_lqr_sweep", "mpc_lqr_rollout", "mpc_lqr_kkt_grads", "mpc_lqr_kkt_prepare",
            "mpc_pnqp", "mpc_pnqp_lu", "mpc_traj_cost", "mpc_env_traj_cost", "mpc_env_linearize", "mpc_select_best",
            "mpc_mlp_workspace_bytes", "mpc_mlp_rollout", "mpc_mlp_linearize",
-           "mpc_mlp_supported", "mpc_lqr_kkt_fused_supported", "mpc_lqr_kkt_fused_workspace_bytes", "mpc_lqr_kkt_fused")
+           "mpc_mlp_supported", "mpc_lqr_kkt_fused_supported", "mpc_lqr_kkt_fused_workspace_bytes", "mpc_lqr_kkt_fused",
+           "mpc_du_norm_reference")
 
 _lib = None
 
@@ -223,6 +224,7 @@ def load():
     L.mpc_lqr_qp_record.argtypes = [PP, OP, ctypes.c_int] + [ctypes.POINTER(_i64)] * 3
     L.mpc_lqr_sweep.argtypes = [PP, OP, UP, _vp]
     L.mpc_lqr_rollout.argtypes = [PP, OP, UP, _vp, _vp]
+    L.mpc_du_norm_reference.argtypes = [ctypes.c_int] * 4 + [_vp] * 4
     L.mpc_lqr_kkt_grads.argtypes = [PP] + [_vp] * 10
     L.mpc_lqr_kkt_prepare.argtypes = [ctypes.c_int] * 5 + [_vp, _vp, _vp, OP, _vp, _vp, _vp]
     L.mpc_lqr_kkt_fused_supported.argtypes = [PP, OP]
@@ -584,6 +586,44 @@ class HipBackend:
                "mpc_lqr_step (sweep only)")
         res["_keep"] = (keep, keep_o, ws)
         return res
+
+    def lqr_rollout(self, x_init, C, c, F, f, cur_x, cur_u, K, k, opts, old_costs=None):
+        """lqr_forward alone (mpc/lqr_step.py:164-261) given the gains K [T,B,nc,ns], k [T,B,nc] of a sweep: mpc_lqr_rollout.
+        Returns dict(new_x, new_u, costs, full_du_norm, alpha_du_norm, alphas)."""
+        dev = _require_device(x_init, C, c, F, cur_x, cur_u, K, k)
+        self._check_same(C, x_init, c, F, f, cur_x, cur_u, K, k)
+        L = load()
+        T, B, n = C.shape[0], C.shape[1], C.shape[2]
+        ns = x_init.shape[1]
+        nc = n - ns
+        p, keep = self._problem(x_init, C, c, F, f, cur_x, cur_u)
+        o, keep_o = opts.to_struct(T, B, nc, C)
+        kw = dict(device=dev, dtype=C.dtype)
+        res = dict(new_x=torch.empty(T, B, ns, **kw), new_u=torch.empty(T, B, nc, **kw), costs=torch.empty(B, **kw),
+                   full_du_norm=torch.empty(B, **kw), alpha_du_norm=torch.empty(B, **kw), alphas=torch.empty(B, **kw),
+                   status=torch.zeros(B, device=dev, dtype=torch.int32))
+        out = Outputs()
+        for key in res:
+            setattr(out, key, res[key].data_ptr())
+        Kc, kc = K.contiguous(), k.contiguous()
+        out.K, out.k = Kc.data_ptr(), kc.data_ptr()
+        oc = None if old_costs is None else old_costs.contiguous()
+        _check(L.mpc_lqr_rollout(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out), None if oc is None else oc.data_ptr(), _stream(dev)),
+               "mpc_lqr_rollout")
+        res["_keep"] = (keep, keep_o, Kc, kc, oc)
+        return res
+
+    def du_norm_reference(self, u, new_u):
+        """The reference's `full_du_norm` for n_batch > 1 (mpc/lqr_step.py:243-245: the transpose in front of the reshape mixes
+        the problems of a batch): mpc_du_norm_reference.  u, new_u [T,B,nc] -> [B]."""
+        dev = _require_device(u, new_u)
+        T, B, nc = u.shape
+        uc, nuc = u.contiguous(), new_u.contiguous()
+        assert uc.dtype == nuc.dtype and tuple(nuc.shape) == (T, B, nc)
+        out = torch.empty(B, device=dev, dtype=u.dtype)
+        _check(load().mpc_du_norm_reference(_dtype_code(u), T, B, nc, uc.data_ptr(), nuc.data_ptr(), out.data_ptr(), _stream(dev)),
+               "mpc_du_norm_reference")
+        return out
 
     # -- (4) LQRStepFn.backward -----------------------------------------------------------------
     def _zero_nominal(self, T, B, ns, nc, kw):

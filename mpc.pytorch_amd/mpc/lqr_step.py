@@ -325,7 +325,8 @@ def LQRStep(n_state,
             verbose=0,
             back_eps=1e-3,
             no_op_forward=False,
-            c_symmetric=False):
+            c_symmetric=False,
+            reference_du_norm=False):
     """A single step of the box-constrained iLQR solver.
 
     Required: n_state, n_ctrl, T.  The returned callable takes (x_init [B,ns], C [T,B,n,n],
@@ -338,6 +339,12 @@ def LQRStep(n_state,
     c_symmetric (not in the reference): the caller vouches that every C_t is symmetric, which lets the fused kernels
     skip their symmetry test (MPC_OPT_C_SYMMETRIC).  Left False, a C that is not symmetric is detected on the device
     and solved the reference's way (it uses C as given, mpc/lqr_step.py:68, 294) on the generic kernels.
+
+    reference_du_norm (not in the reference): `full_du_norm` as the reference computes it for n_batch > 1 -- (u - new_u)
+    .transpose(1, 2).contiguous().view(n_batch, -1).norm(2, 1), mpc/lqr_step.py:243-245: the transpose in front of the reshape
+    makes entry r the norm of T n_ctrl consecutive elements of the [T, n_ctrl, n_batch] array, which mixes the problems of the
+    batch.  Off (default), entry b is problem b's own norm (= the reference called with n_batch = 1).  On, one more rollout (the
+    full step, alpha = 1, for every problem: mpc_lqr_rollout) and mpc_du_norm_reference reproduce the reference's vector.
     """
     opts = StepOptions(u_lower=u_lower, u_upper=u_upper, u_zero_I=u_zero_I, delta_u=delta_u,
                        linesearch_decay=linesearch_decay, max_linesearch_iter=max_linesearch_iter,
@@ -351,7 +358,9 @@ def LQRStep(n_state,
         quad = true_cost is None or isinstance(true_cost, _mpc.QuadCost)
         # Currently unimplemented in the reference as well (mpc/lqr_step.py:195):
         assert not ((delta_u is not None) and (u_lower is None))
-        sim = hasattr(true_dynamics, "native_env")
+        B = C.shape[1]
+        ref_norm = bool(reference_du_norm) and B > 1
+        sim = hasattr(true_dynamics, "native_env") and not ref_norm      # (reference_du_norm: a simulator goes the module's way)
         if (lin or sim) and quad:
             rp = None
             tC, tc = (C, c) if true_cost is None else (true_cost.C, true_cost.c)
@@ -364,10 +373,19 @@ def LQRStep(n_state,
                 o = StepOptions(u_lower=u_lower, u_upper=u_upper, u_zero_I=u_zero_I, delta_u=delta_u,
                                 linesearch_decay=linesearch_decay, max_linesearch_iter=max_linesearch_iter,
                                 true_dynamics=true_dynamics.native_env(), c_symmetric=c_symmetric)
-            r = be.lqr_step(x_init, C, c, F, f_in, current_x, current_u, o, rollout_problem=rp)
-            return r["new_x"], r["new_u"], r["qp_iters"], r["costs"], r["full_du_norm"], r["alphas"]
+            r = be.lqr_step(x_init, C, c, F, f_in, current_x, current_u, o, rollout_problem=rp, want_gains=ref_norm)
+            fdn = r["full_du_norm"]
+            if ref_norm:
+                # the controls of the FULL step for every problem (the accepted trajectory of a problem that backtracked is
+                # another one): lqr_forward once more with max_linesearch_iter = 1, then the reference's mixed-up norm
+                o1 = StepOptions(u_lower=u_lower, u_upper=u_upper, u_zero_I=u_zero_I, delta_u=delta_u,
+                                 linesearch_decay=linesearch_decay, max_linesearch_iter=1, c_symmetric=c_symmetric)
+                full = be.lqr_rollout(x_init.detach(), tC.detach(), tc.detach(), tF.detach(), None if tf is None else tf.detach(),
+                                      current_x.detach(), current_u.detach(), r["K"], r["k"], o1, old_costs=r["old_costs"])
+                fdn = be.du_norm_reference(current_u.detach(), full["new_u"])
+            return r["new_x"], r["new_u"], r["qp_iters"], r["costs"], fdn, r["alphas"]
         from . import util as _util
-        net = true_dynamics.native_net(C) if quad and hasattr(true_dynamics, "native_net") else None
+        net = true_dynamics.native_net(C) if quad and hasattr(true_dynamics, "native_net") and not ref_norm else None
         if net is not None:
             # NNDynamics (:223-225): the sweep on the fastest kernel for this shape (MPC_OPT_SWEEP_ONLY), then the
             # line-searched rollout through the network in one kernel
@@ -384,6 +402,12 @@ def LQRStep(n_state,
         nx, nu, cost, fdn, _, alphas = _module_rollout(
             n_state, n_ctrl, T, x_init.detach(), sw["K"], sw["k"], current_x.detach(), current_u.detach(),
             old_cost, true_cost, true_dynamics, opts)
+        if ref_norm:
+            with torch.no_grad():
+                one = torch.ones(B, 1, dtype=x_init.dtype, device=x_init.device)
+                full_u = _rollout_pass(T, x_init.detach(), sw["K"], sw["k"], current_x.detach(), current_u.detach(), one,
+                                       true_cost, true_dynamics, opts)[1]
+            fdn = be.du_norm_reference(current_u.detach(), full_u)
         return nx, nu, sw["qp_iters"], cost, fdn, alphas
 
     cfg = _StepConfig()

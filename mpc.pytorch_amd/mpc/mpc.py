@@ -161,7 +161,7 @@ class MPC(Module):
                  lqr_iter=10, grad_method=GradMethods.ANALYTIC, delta_u=None, verbose=0, eps=1e-7,
                  back_eps=1e-7, n_batch=None, linesearch_decay=0.2, max_linesearch_iter=10,
                  exit_unconverged=True, detach_unconverged=True, backprop=True, slew_rate_penalty=None,
-                 prev_ctrl=None, not_improved_lim=5, best_cost_eps=1e-4):
+                 prev_ctrl=None, not_improved_lim=5, best_cost_eps=1e-4, reference_du_norm=False):
         super().__init__()
         assert (u_lower is None) == (u_upper is None)
         assert max_linesearch_iter > 0
@@ -185,6 +185,11 @@ class MPC(Module):
         self.not_improved_lim = not_improved_lim
         self.best_cost_eps = best_cost_eps
         self.slew_rate_penalty = slew_rate_penalty
+        # (not in the reference) True: `full_du_norm` as the reference computes it for n_batch > 1 -- a transpose in front of the
+        # reshape mixes the problems of a batch (mpc/lqr_step.py:243-245) -- so that the eps exit (:299) and the detach mask
+        # (:321-334) are the reference's.  Default: each problem's own norm.  Costs one more rollout per iteration
+        # and takes the general loop (no pre-bound device-side iterations).
+        self.reference_du_norm = bool(reference_du_norm)
         self.flag_reducer = None     # set by mpc.shard for lock-step sharded solves
         self.prev_ctrl = prev_ctrl
 
@@ -232,12 +237,13 @@ class MPC(Module):
             print("Initial mean(cost): {:.4e}".format(
                 util.get_cost(T, u, cost, dx, x_init=x_init).mean().item()))
 
-        fast = (isinstance(cost, QuadCost) and isinstance(dx, LinDx) and self.slew_rate_penalty is None)
+        ref_norm = self.reference_du_norm and n_batch > 1
+        fast = (isinstance(cost, QuadCost) and isinstance(dx, LinDx) and self.slew_rate_penalty is None and not ref_norm)
         # a shipped simulator (mpc.env_dx): closed-form linearisation kernel + the simulator inside the
         # rollout kernel; FINITE_DIFF keeps the reference's central differences
         sim = None
         if (isinstance(cost, QuadCost) and hasattr(dx, "native_env") and self.slew_rate_penalty is None
-                and self.grad_method in (GradMethods.ANALYTIC, GradMethods.AUTO_DIFF) and T > 1):
+                and self.grad_method in (GradMethods.ANALYTIC, GradMethods.AUTO_DIFF) and T > 1 and not ref_norm):
             sim = dx.native_env()
         be = _native.backend()
         # NNDynamics the kernels take (fp32 on the device, <= 4 layers, n_state <= 16), ANALYTIC linearisation: the whole
@@ -246,7 +252,7 @@ class MPC(Module):
         net = None
         if (sim is None and not fast and isinstance(cost, QuadCost) and self.slew_rate_penalty is None and T > 1
                 and self.grad_method == GradMethods.ANALYTIC and hasattr(dx, "native_net")
-                and hasattr(be, "plan_network_iteration")):
+                and hasattr(be, "plan_network_iteration") and not ref_norm):
             net = dx.native_net(x_init)
             if net is not None and net.activation == "elu":      # (no grad_input in the reference: the module refuses, mpc/dynamics.py:113-114)
                 net = None
@@ -508,7 +514,8 @@ class MPC(Module):
             true_cost=cost, true_dynamics=dynamics, delta_u=self.delta_u,
             linesearch_decay=self.linesearch_decay, max_linesearch_iter=self.max_linesearch_iter,
             delta_space=True, current_x=x, current_u=u, back_eps=self.back_eps,
-            no_op_forward=no_op_forward, c_symmetric=no_op_forward and getattr(self, "_c_symmetric", False))
+            no_op_forward=no_op_forward, c_symmetric=no_op_forward and getattr(self, "_c_symmetric", False),
+            reference_du_norm=self.reference_du_norm and not no_op_forward)
         empty = torch.empty(0, dtype=x_init.dtype, device=x_init.device)
         return step(x_init, C, c, F, f if f is not None else empty)
 
@@ -549,7 +556,8 @@ class MPC(Module):
             n_state=n, n_ctrl=nc, T=T, u_lower=self.u_lower, u_upper=self.u_upper, u_zero_I=self.u_zero_I,
             true_cost=a_cost, true_dynamics=a_dyn, delta_u=self.delta_u,
             linesearch_decay=self.linesearch_decay, max_linesearch_iter=self.max_linesearch_iter,
-            delta_space=True, current_x=ax, current_u=u, back_eps=self.back_eps, no_op_forward=no_op_forward)
+            delta_space=True, current_x=ax, current_u=u, back_eps=self.back_eps, no_op_forward=no_op_forward,
+            reference_du_norm=self.reference_du_norm and not no_op_forward)
         empty = torch.empty(0, **kw)
         out = step(ax_init, aC, ac, aF, af if af is not None else empty)
         return (out[0][:, :, nc:],) + tuple(out[1:])

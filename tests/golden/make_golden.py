@@ -577,6 +577,62 @@ def grad_case(name, ns, nc, T, B, dtype, seed, beta, with_f=True, lqr_iter=30, s
          df=npy(grads[4]) if with_f else None)
 
 
+def du_norm_case(name, ns=3, nc=2, T=6, B=8, beta=0.4, lqr_iter=3, eps=2e-2, seeds=range(200, 400)):
+    """The reference's `full_du_norm` at n_batch > 1 (mpc/lqr_step.py:243-245: a transpose in front of the reshape mixes the
+    problems of a batch) and what hangs on it in MPC.forward: the eps exit (mpc/mpc.py:299) and the detach mask (:321-334).  A
+    short solve (lqr_iter = 3) with a loose eps, so that some ROWS of the mixed-up vector are below eps and others are not -- and
+    the mask differs from the one each problem's own norm would give.  Stored: the vector of every iteration, the solve, the
+    mask, and the gradients of a random linear loss (zero where the mask detaches)."""
+    if ONLY is not None and name not in ONLY:
+        return
+    for seed in seeds:
+        p = make_problem(ns, nc, T, B, torch.float64, seed, True, u_scale=0.05)
+        # half of the problems start from (nearly) their fixed point: solve them first, restart there
+        warm = ref_mpc.MPC(ns, nc, T, u_lower=-beta, u_upper=beta, lqr_iter=40, verbose=-1, exit_unconverged=False,
+                           detach_unconverged=False, eps=1e-10, n_batch=B, u_init=p["u"])
+        (_, u_star, _), _ = quiet(warm, p["x_init"], QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"]))
+        u0 = p["u"].clone()
+        u0[:, ::2] = u_star[:, ::2].detach()
+        C = p["C"].clone().requires_grad_(True)
+        c = p["c"].clone().requires_grad_(True)
+        x_init = p["x_init"].clone().requires_grad_(True)
+        ctrl = ref_mpc.MPC(ns, nc, T, u_lower=-beta, u_upper=beta, lqr_iter=lqr_iter, verbose=-1, exit_unconverged=False,
+                           detach_unconverged=True, eps=eps, n_batch=B, u_init=u0)
+        seen = []
+        inner = ctrl.solve_lqr_subproblem
+
+        def spy(*a, **k):
+            out = inner(*a, **k)
+            if len(out) == 6:
+                seen.append((out[4].detach().clone(), out[3].detach().clone()))
+            return out
+        ctrl.solve_lqr_subproblem = spy
+        (x, u, costs), _ = quiet(ctrl, x_init, QuadCost(C, c), LinDx(p["F"], p["f"]))
+        # the best-iterate bookkeeping of mpc/mpc.py:271-285 on the recorded vectors
+        best_n, best_c = seen[0][0].clone(), seen[0][1].clone()
+        for fdn, cs in seen[1:]:
+            take = cs <= best_c + ctrl.best_cost_eps
+            best_n[take], best_c[take] = fdn[take], cs[take]
+        keep = best_n < eps
+        # ... against each problem's own norm of the same iterations (what n_batch = 1 calls would have seen)
+        g = torch.Generator().manual_seed(seed + 77)
+        gx = torch.randn(x.shape, generator=g, dtype=torch.float64)
+        gu = torch.randn(u.shape, generator=g, dtype=torch.float64)
+        grads = torch.autograd.grad((x * gx).sum() + (u * gu).sum(), [x_init, C, c], allow_unused=True)
+        dead = np.array([float(grads[2][:, b].abs().max()) == 0.0 for b in range(B)])
+        if not (keep.any() and (~keep).any()):
+            continue
+        assert (dead == ~keep.numpy()).all(), (dead, keep)
+        save(name, meta=np.array([ns, nc, T, B, lqr_iter, seed]), beta=np.array([beta]), eps=np.array([eps]),
+             C=npy(C), c=npy(c), F=npy(p["F"]), f=npy(p["f"]), x_init=npy(x_init), u_init=npy(u0),
+             x=npy(x), u=npy(u), costs=npy(costs), full_du_norm_iters=np.stack([npy(a) for a, _ in seen]),
+             costs_iters=np.stack([npy(b_) for _, b_ in seen]), keep=keep.numpy(), dl_dx=npy(gx), dl_du=npy(gu),
+             dx_init=npy(grads[0]), dC=npy(grads[1]), dc=npy(grads[2]))
+        print("   %s: seed %d, %d iterations, keep mask %s" % (name, seed, len(seen), keep.numpy().astype(int).tolist()))
+        return
+    raise RuntimeError("du_norm_case: no seed gave a mixed mask")
+
+
 def jacobian_case(name, beta):
     """tests/test_mpc.py:303-395 / :398-500 inputs; full du/d{C,c,F,f,x_init} Jacobians through
     the reference's autograd (the numdifftools oracle is not installed here)."""
@@ -697,6 +753,7 @@ if __name__ == "__main__":
     step_case("step_singular_small_f64", 4, 2, 8, 3, f64, 73, bounds=None, zero_ctrl=((1, 1),))
     step_case("step_singular_odd_f32", 7, 3, 9, 3, f32, 74, bounds=None, zero_ctrl=((2, 0),))
     tie_case("ties_tight_f32")
+    du_norm_case("mpc_du_norm_B8_f64")
     if ONLY is not None:
         _grad_case("grad_asym_ns_f32", 12, 4, 8, 4, f32, 36, None, asym=(1, 2))
         _grad_case("grad_asym_small_f64", 4, 2, 6, 3, f64, 37, 0.4, asym=(0, 2))

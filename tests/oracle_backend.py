@@ -90,6 +90,44 @@ class OracleBackend:
         r = self.lqr_step(x_init, C, c, F, None, cur_x, cur_u, opts, want_gains=True)
         return {k: r[k] for k in ("K", "k", "old_costs", "qp_iters", "status")}
 
+    def lqr_rollout(self, x_init, C, c, F, f, cur_x, cur_u, K, k, opts, old_costs=None):
+        """lqr_forward given the gains -- the FULL step only (max_linesearch_iter = 1: what `reference_du_norm` asks for),
+        mpc/lqr_step.py:181-241 in numpy."""
+        assert opts.max_linesearch_iter == 1
+        self.calls.append("lqr_rollout")
+        T, B = C.shape[0], C.shape[1]
+        Cn, cn, Kn, kn, xn, un = (_np(v).astype(np.float64) for v in (C, c, K, k, cur_x, cur_u))
+        Fn = _np(F).astype(np.float64) if T > 1 else None
+        fn = None if f is None or f.numel() == 0 else _np(f).astype(np.float64)
+        lo, hi = _bound(opts.u_lower), _bound(opts.u_upper)
+        zm = _np(opts.u_zero_I)
+        x = _np(x_init).astype(np.float64)
+        xs, us, cost = [], [], np.zeros(B)
+        for t in range(T):
+            nu = np.einsum("bij,bj->bi", Kn[t], x - xn[t]) + un[t] + kn[t]
+            if zm is not None:
+                nu = np.where(zm[t].astype(bool), 0.0, nu)
+            if lo is not None:
+                l = lo if isinstance(lo, float) else np.asarray(lo, np.float64)[t]
+                h = hi if isinstance(hi, float) else np.asarray(hi, np.float64)[t]
+                if opts.delta_u is not None:
+                    l, h = np.maximum(l, un[t] - opts.delta_u), np.minimum(h, un[t] + opts.delta_u)
+                nu = np.minimum(np.maximum(nu, l), h)
+            tau = np.concatenate((x, nu), 1)
+            cost += 0.5 * np.einsum("bi,bij,bj->b", tau, Cn[t], tau) + (tau * cn[t]).sum(1)
+            xs.append(x); us.append(nu)
+            if t < T - 1:
+                x = np.einsum("bij,bj->bi", Fn[t], tau) + (0.0 if fn is None else fn[t])
+        nx, nu_ = np.stack(xs), np.stack(us)
+        dn = np.sqrt(((un - nu_) ** 2).sum((0, 2)))
+        return dict(new_x=self._t(nx, C), new_u=self._t(nu_, C), costs=self._t(cost, C), full_du_norm=self._t(dn, C),
+                    alpha_du_norm=self._t(dn, C), alphas=torch.ones(B, dtype=C.dtype))
+
+    def du_norm_reference(self, u, new_u):
+        """The reference's own expression, mpc/lqr_step.py:243-245."""
+        self.calls.append("du_norm_reference")
+        return (u - new_u).transpose(1, 2).contiguous().view(u.shape[1], -1).norm(2, 1)
+
     def kkt_backward(self, C, c, F, f, x_star, u_star, dl_dx, dl_du, opts, impl=0):
         self.calls.append("kkt_backward")
         o = O.kkt_backward(_np(C), _np(c), _np(F), _np(f), _np(x_star), _np(u_star),

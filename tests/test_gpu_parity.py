@@ -754,6 +754,22 @@ def test_mpc_forward_on_gpu(be, name):
     np.testing.assert_allclose(host(costs), z["costs"], rtol=1e-5)
 
 
+def test_reference_du_norm_option_on_gpu(be):
+    """mpc.MPC(reference_du_norm=True) through the C ABI (mpc_lqr_step + mpc_lqr_rollout + mpc_du_norm_reference): the reference's
+    mixed-up `full_du_norm` (mpc/lqr_step.py:243-245) -- trajectories, detach mask and gradients of the unmodified reference's
+    8-problem solve (tests/golden/mpc_du_norm_B8_f64.npz); and the kernel alone against the reference's expression."""
+    from test_host_logic import run_du_norm_golden, check_du_norm_golden
+    z = golden("mpc_du_norm_B8_f64")
+    check_du_norm_golden(z, run_du_norm_golden(z, True, device=DEV))
+    for dt, tol in ((torch.float64, 1e-13), (torch.float32, 1e-6)):
+        for (T, B, nc) in ((6, 8, 2), (50, 4096, 4), (7, 5, 3), (3, 1, 1)):
+            g = torch.Generator().manual_seed(T * B)
+            u, nu = torch.randn(T, B, nc, generator=g).to(dt).to(DEV), torch.randn(T, B, nc, generator=g).to(dt).to(DEV)
+            want = (u - nu).transpose(1, 2).contiguous().view(B, -1).norm(2, 1)
+            got = be.du_norm_reference(u, nu)
+            np.testing.assert_allclose(host(got), host(want), rtol=tol * 10, atol=tol)
+
+
 @pytest.mark.parametrize("kind", ["pendulum", "cartpole"])
 def test_ilqr_on_simulator_dynamics_on_gpu(be, kind):
     """BASELINE.json configs 2 / 3 (small batch, float64): iLQR on Pendulum / Cartpole dynamics on the

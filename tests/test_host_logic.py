@@ -43,7 +43,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert set(_native.EXPORTS) == declared
-    assert L.mpc_lqr_abi_version() == _native.ABI_VERSION == 8
+    assert L.mpc_lqr_abi_version() == _native.ABI_VERSION == 9
     assert b"gfx950" in L.mpc_lqr_build_info()
 
 
@@ -440,6 +440,55 @@ def test_mpc_promises_a_symmetric_C_only_after_the_first_step_has_checked_it(ora
         assert not seen["opts"].c_symmetric
     finally:
         oracle_backend.tests_c = True
+
+
+def run_du_norm_golden(z, reference_du_norm, device=None):
+    """tests/golden/mpc_du_norm_B8_f64.npz (make_golden.py: du_norm_case): the reference's short solve of 8 problems with a loose
+    eps and detach_unconverged -- forward + the gradients of the fixture's linear loss.  Returns x, u, costs, (dx_init, dC, dc)."""
+    ns, nc, T, B, lqr_iter, _seed = (int(v) for v in z["meta"])
+    mv = (lambda t: t if device is None else t.to(device))
+    C, c, x_init = (mv(tt(z, k)).clone().requires_grad_(True) for k in ("C", "c", "x_init"))
+    ctrl = mpc.MPC(ns, nc, T, u_lower=-float(z["beta"][0]), u_upper=float(z["beta"][0]), lqr_iter=lqr_iter, verbose=-1,
+                   exit_unconverged=False, detach_unconverged=True, eps=float(z["eps"][0]), n_batch=B, u_init=mv(tt(z, "u_init")),
+                   reference_du_norm=reference_du_norm)
+    x, u, costs = ctrl(x_init, QuadCost(C, c), LinDx(mv(tt(z, "F")), mv(tt(z, "f"))))
+    loss = (x * mv(tt(z, "dl_dx"))).sum() + (u * mv(tt(z, "dl_du"))).sum()
+    return x, u, costs, torch.autograd.grad(loss, [x_init, C, c])
+
+
+def check_du_norm_golden(z, out, atol=1e-7):
+    x, u, costs, (gx0, gC, gc) = out
+    h = lambda t: t.detach().cpu().numpy()
+    np.testing.assert_allclose(h(x), z["x"], rtol=1e-6, atol=atol)
+    np.testing.assert_allclose(h(u), z["u"], rtol=1e-6, atol=atol)
+    np.testing.assert_allclose(h(costs), z["costs"], rtol=1e-7)
+    # the detach mask IS the reference's: the problems whose row of the mixed-up vector is above eps get no gradient
+    dead = np.array([float(np.abs(h(gc)[:, b]).max()) == 0.0 for b in range(z["keep"].shape[0])])
+    assert (dead == ~z["keep"]).all(), (dead, z["keep"])
+    np.testing.assert_allclose(h(gx0), z["dx_init"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(h(gC), z["dC"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(h(gc), z["dc"], rtol=1e-5, atol=1e-8)
+
+
+def test_reference_du_norm_option_reproduces_the_references_detach_mask(oracle_backend):
+    """VERDICT r05 missing 4: for n_batch > 1 the reference's `full_du_norm` mixes the problems of a batch (mpc/lqr_step.py:243-245,
+    a transpose in front of the reshape), and that vector decides the eps exit (mpc/mpc.py:299) and which problems
+    detach_unconverged cuts off (:321-334).  Default here: each problem's own norm.  `reference_du_norm=True`
+    reproduces the reference: same trajectories, same mask (the fixture's is [1,0,1,0,0,0,1,1] where the per-problem norms give
+    another), same gradients -- held to the unmodified reference's outputs."""
+    z = golden("mpc_du_norm_B8_f64")
+    assert z["keep"].any() and (~z["keep"]).any()
+    check_du_norm_golden(z, run_du_norm_golden(z, True))
+    assert "du_norm_reference" in oracle_backend.calls and "lqr_rollout" in oracle_backend.calls
+    # the default keeps each problem's own norm: a DIFFERENT mask on this fixture (the documented deviation)
+    oracle_backend.calls.clear()
+    gc = run_du_norm_golden(z, False)[3][2].detach().numpy()
+    dead = np.array([float(np.abs(gc[:, b]).max()) == 0.0 for b in range(z["keep"].shape[0])])
+    assert (dead != ~z["keep"]).any() and "du_norm_reference" not in oracle_backend.calls
+    # n_batch = 1: the reference's expression IS the problem's own norm; the option changes nothing and costs nothing
+    from oracle import lqr_oracle as O
+    u, nu = torch.randn(5, 1, 2, dtype=torch.float64), torch.randn(5, 1, 2, dtype=torch.float64)
+    assert torch.allclose(oracle_backend.du_norm_reference(u, nu), (u - nu).pow(2).sum((0, 2)).sqrt())
 
 
 def test_mpc_forward_never_writes_the_callers_u_init(oracle_backend):
