@@ -144,8 +144,11 @@ typedef struct mpc_lqr_options {
      * mpc_lqr_workspace_bytes -- the pointer may alias the workspace handed to the same call), or zeros from the second
      * iteration of an iLQR solve on (the previous policy at the new nominal IS the new nominal: delta u = 0).
      * [T,B,nc] reals of the problem's dtype through explicit ELEMENT strides of the T and B axes (0 = broadcast), the nc
-     * block contiguous and 16-byte aligned, strides multiples of 4 elements; NULL = the reference's start.  Honoured by the
-     * 12/4 and 32/8 fused kernels (impl 3, 5); every other kernel ignores it (same results). */
+     * block contiguous and 16-byte aligned, strides multiples of 4 elements; NULL = the kernel's own start: k of timestep t+1 like
+     * the reference (mpc/lqr_step.py:137,141) -- except the fused float32 kernels of n_state <= 12, n_ctrl <= 4 (impl 2, 3), which
+     * since round 6 take pnqp's cold start, clamp(-Quu^-1 qu) (mpc/pnqp.py:14-19), at every timestep whose Quu is positive
+     * definite: the better guess of the active set by a whole trip per QP.  Honoured by the
+     * 12/4 and 32/8 fused kernels and the padded instantiation of the latter (impl 3, 5, 7); every other kernel ignores it (same results). */
     const void *qp_start; int64_t qp_start_st, qp_start_sb;
 } mpc_lqr_options;
 
@@ -310,6 +313,11 @@ int64_t mpc_mlp_workspace_bytes(const mpc_mlp_dynamics *net);
 /*      lqr_forward with the network as true_dynamics (mpc/lqr_step.py:164-261, the module branch :223-225) and a
  *      QuadCost: gains K [T,B,nc,ns], k [T,B,nc] of a sweep (mpc_lqr_step's out->K/k), old_costs [B] = cost of the
  *      nominal (its out->old_costs); fills out->new_x/new_u/costs/full_du_norm/alpha_du_norm/alphas.
+ *      CONTRACT (round 5): old_costs must be the cost of the nominal (p->cur_x, p->cur_u) under the SAME (p->C, p->c).
+ *      A trial is accepted on J(trial) - J(nominal) <= 0 with both costs summed by the kernel as ONE difference from p->C, p->c
+ *      (two float32 sums of ~1e5 lose the quantity of interest); old_costs only offsets the reported out->costs.  A caller
+ *      that passes a threshold, or a cost under another model, gets the decisions of the true nominal cost all the same --
+ *      not the reference's `current_cost > old_cost` against that number (mpc/lqr_step.py:176-179).
  *      K == NULL: util.get_traj (+ get_cost when p->C is given) of the controls p->cur_u through the network
  *      (mpc/util.py:102-153): out->new_x, out->costs. */
 int mpc_mlp_rollout(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_mlp_dynamics *net, const void *K,

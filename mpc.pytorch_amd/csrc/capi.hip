@@ -270,10 +270,13 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
             const bool mfma = mfma16_supported(sp);
             if (impl == 2 && !mfma)
                 return fail(MPC_E_DIMS, "fused MFMA kernel needs n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16");
-            if (mfma) {
-                const int64_t need = (int64_t)p->T * p->B * 64 * (int64_t)sizeof(double);
-                if (!(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0)))
-                    return fail(MPC_E_ARG, "workspace too small or not 16-byte aligned (see mpc_lqr_workspace_bytes)");
+            const int64_t need = (int64_t)p->T * p->B * 64 * (int64_t)sizeof(double);
+            const bool have_ws = workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0);
+            // (a caller written against ABI 7 -- out->K / out->k given, no or a small workspace -- keeps the generic
+            // kernel under impl 0; only a FORCED impl 2 insists on the fused kernel's workspace)
+            if (impl == 2 && !have_ws)
+                return fail(MPC_E_ARG, "workspace too small or not 16-byte aligned (see mpc_lqr_workspace_bytes)");
+            if (mfma && have_ws) {
                 if ((sp.K == nullptr) != (sp.k == nullptr)) return fail(MPC_E_NULL, "pass both K and k, or neither");
                 sp.Kk = (real *)workspace;
                 const int rc = launch_step_mfma16(sp, st);
@@ -409,11 +412,14 @@ int mpc_lqr_qp_record(const mpc_lqr_problem *p, const mpc_lqr_options *o, int im
     memset(&out, 0, sizeof(out));
     const StepParams<float> sp = make_params<float>(p, o, &out);
     const int64_t TB = (int64_t)p->T * p->B;
-    if ((impl == 0 || impl == 3) && p->ns == 12 && p->nc == 4) {
-        // the 12/4 kernel's gain record Kk[t][b][lane 0..15][4]: lane 12 holds k
+    if ((impl == 0 || impl == 3) && p->ns == 12 && p->nc == 4 && dpp16_supported(sp)) {
+        // the 12/4 kernel's gain record Kk[t][b][lane 0..15][4]: lane 12 holds k.  (only where that kernel really takes
+        // the call -- blocks or strides that are not 16-byte aligned go to the one-problem-per-wavefront kernel under impl 0, whose
+        // record keeps k elsewhere: "0 = not filled" below; a forced impl 3 fails at launch with MPC_E_DIMS)
         *offset_bytes = 48 * 4; *st = (int64_t)p->B * 64; *sb = 64;
         return 1;
     }
+    if (impl == 3) return 0;
     if (impl == 0 && (tiny_supported(p->ns, p->nc) || mfma16_supported(sp))) return 0;
     if ((impl == 0 || impl == 5) && p->ns == 32 && p->nc == 8) {
         *offset_bytes = TB * 256 * 4; *st = (int64_t)p->B * 8; *sb = 8;       // K [T,B,8,32] | k [T,B,8]

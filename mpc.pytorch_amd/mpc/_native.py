@@ -821,7 +821,9 @@ class HipBackend:
     # -- (6d) NNDynamics in the kernels --------------------------------------------------------
     def mlp_rollout(self, x_init, C, c, K, k, cur_x, cur_u, old_costs, opts, net, out_x=None, out_u=None):
         """lqr_forward with the network as true_dynamics (mpc/lqr_step.py:164-261): gains K, k and the nominal's
-        cost come from a sweep (`lqr_step(..., want_gains=True)`)."""
+        cost come from a sweep (`lqr_step(..., want_gains=True)`).  `old_costs` MUST be the cost of (cur_x, cur_u) under the
+        same (C, c): the kernel decides a trial on J(trial) - J(nominal), both summed from C, c as one difference, and uses
+        old_costs only as the offset of the reported costs (include/mpc_lqr.h, mpc_mlp_rollout)."""
         dev = _require_device(x_init, C, c, K, k, cur_x, cur_u, old_costs)
         L = load()
         T, B, nc = cur_u.shape

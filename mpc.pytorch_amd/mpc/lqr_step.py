@@ -215,6 +215,13 @@ class _AsyncHostScalar(torch.Tensor):
                 self._on_settle = None
                 cb()
 
+    def __index__(self):
+        # (pnqp's 4th return value is the Python int `i` in the reference, mpc/pnqp.py:59, 82 -- range(i), seq[i] and
+        # friends go through __index__, which torch refuses for a float tensor)
+        self._settle()
+        with torch._C.DisableTorchFunctionSubclass():
+            return int(torch.Tensor.item(self))
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         from torch.utils._pytree import tree_flatten
@@ -235,7 +242,7 @@ def _host_scalar_async(dev_scalar):
     is only written again once the copy that last used it has completed (its event is waited for: 256 solves later,
     i.e. never in practice)."""
     if not dev_scalar.is_cuda:
-        return dev_scalar.to(torch.float32).reshape(1).cpu()
+        return _AsyncHostScalar(dev_scalar.to(torch.float32).reshape(1).cpu().clone(), None)     # (settled: nothing to wait for)
     key = dev_scalar.device.index
     ring = _PINNED_RING.get(key)
     if ring is None:

@@ -801,6 +801,8 @@ def test_pnqp_iteration_count_is_a_host_scalar_that_warns_when_read(capsys):
     from mpc.lqr_step import _AsyncHostScalar
     n = _iteration_count(torch.tensor([3, 7, 5]), torch.tensor([0, 0, 0]))
     assert int(n) == 7 and n / 2 == 3.5 and float(n + 1) == 8.0 and list(range(int(n)))[-1] == 6
+    # ... and it goes wherever the reference's Python int goes: range(), indexing, a comparison used as a bool
+    assert list(range(n))[-1] == 6 and "abcdefgh"[n] == "h" and (n == 7) and not (n == 6) and [0] * n == [0] * 7
     assert "Did not converge" not in capsys.readouterr().out
     _iteration_count(torch.tensor([19]), torch.tensor([1]))
     assert "pnqp warning: Did not converge" in capsys.readouterr().out
