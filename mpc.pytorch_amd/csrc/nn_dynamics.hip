@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(64) nn_rollout_fast_kernel(StepParams<float> p
     const bool own_u = q < nc;                  // this lane computes control i = q (n_ctrl <= 4)
     // The line search as a JOB SCHEDULE over the wave's sixteen problem slots (round 5).  The reference runs pass after pass over the
     // whole batch while any problem got worse (mpc/lqr_step.py:176-179); a wavefront did the same for its 16 problems -- and from the
-    // third iLQR iteration on a few problems of most wavefronts need the 4th, 7th or 10th step size (tools/r05_nn_iter_probe.py), so
+    // third iLQR iteration on a few problems of most wavefronts need the 4th, 7th or 10th step size (tools/archive/r05_nn_iter_probe.py), so
     // the rollout of 0.14 ms ran 1.3 - 1.7 ms with one or two slots of sixteen at work (profiles/r05_trace_nn_before.txt).  The trials
     // of a problem do not depend on each other: after a pass, the slots nobody needs any more roll out FURTHER trials of the problems
     // that are still searching -- a problem's next S step sizes side by side, S = 16 / (problems searching) --, the first of them with
