@@ -46,7 +46,7 @@ FP32_MFMA_PEAK_TF = 157.3  # same guide: v_mfma_f32_16x16x4_f32, dense
 SETTLE_LAUNCHES = 200     # the power controller settles over the first ~120 launches of a fresh process: ~17 at boost
                           # clocks (87 us), a dip to 100 us, back to 87-88 us (profiles/r02_kt_durations.json)
 KERNEL_NAMES = {1: "lqr_step_generic_kernel<float>", 2: "lqr_step_mfma16_kernel", 3: "lqr_step_dpp16_kernel",
-                4: "lqr_step_tiny_kernel", 5: "lqr_step_mfma40_kernel"}
+                4: "lqr_step_tiny_kernel", 5: "lqr_step_mfma40_kernel", 8: "lqr_step_dpp16_kernel (padded instantiation)"}
 
 
 def make_problem(ns, nc, T, B, dtype, device, seed=0, u_scale=0.0, clamp=None, with_f=True, on_device=False):
@@ -646,6 +646,21 @@ def extra_rows(be, dev, steps):
         row["generic_kernel_ms"] = rowg["ms"]
         row["speedup_over_generic"] = rowg["ms"] / row["ms"]
         rows["pad_step_%d_%d_B1024" % (ns_p, nc_p)] = row
+        del p
+    # ---- shapes UP TO 12/4 (round 6): the 12/4 kernel's padded instantiation (impl 8 under impl 0: dword gathers of the staging DMA pad
+    # tau to [x(12); u(4)]), beside the one-problem-per-wavefront kernel (impl 2) every such shape ran on in rounds 1-5
+    from mpc._native import IMPL_MFMA16
+    for ns_p, nc_p, bnd in ((8, 4, False), (10, 3, False), (12, 2, False), (10, 3, True)):
+        p = make_problem(ns_p, nc_p, T_H, B_PER_GPU, torch.float32, dev, seed=60 + ns_p, u_scale=0.3 if bnd else 0.0, clamp=1.0 if bnd else None)
+        o_p = (StepOptions(u_lower=-1.0, u_upper=1.0, nominal_on_dynamics=True, c_symmetric=True) if bnd
+               else StepOptions(nominal_on_dynamics=True, c_symmetric=True))
+        row, _ = step_row(p, o_p, ns_p, nc_p, T_H, B_PER_GPU)
+        rowm, _ = step_row(p, o_p, ns_p, nc_p, T_H, B_PER_GPU, impl=IMPL_MFMA16)
+        row["workload"] = ("n_state=%d n_ctrl=%d T=%d B=%d, %s: the padded 12/4 kernel (lqr_step_dpp16_kernel, -DMPC_DPP16_PAD); mfma16_kernel_ms = the "
+                           "same call forced onto the one-problem-per-wavefront kernel (rounds 1-5)" % (ns_p, nc_p, T_H, B_PER_GPU, "box bounds +-1" if bnd else "unconstrained"))
+        row["mfma16_kernel_ms"] = rowm["ms"]
+        row["speedup_over_mfma16"] = rowm["ms"] / row["ms"]
+        rows["pad12_step_%d_%d_B%d%s" % (ns_p, nc_p, B_PER_GPU, "_bounded" if bnd else "")] = row
         del p
     # ---- float64 (round 5): what every test and gradient check of the reference runs in (tests/test_mpc.py .double()).  n_state <= 12,
     # n_ctrl <= 4 take the one-problem-per-wavefront kernel's float64 instantiation (v_mfma_f64_16x16x4_f64); rounds 1-4: the generic kernel

@@ -192,8 +192,10 @@ int64_t mpc_lqr_workspace_bytes(const mpc_lqr_problem *p);
  *     independent over t for all timesteps at once, all line-search trials at once; max_linesearch_iter <= 16; what auto
  *     takes instead of 4 while B is too small to fill the chip with a lane per problem), 7 = the kernel of 5 for ANY
  *     n_state <= 32, n_ctrl <= 8 (f32; round 4): tau is padded to [x(32); u(8)] by the staging gathers, every mode of 5
- *     (bounds, u_zero_I, delta_u, bare or vouched nominal); needs the workspace of mpc_lqr_workspace_bytes.
- *     Auto picks 5, 6 / 4, 3, 2, 7, else 1 (float64 beyond 12/4, n_state > 32 or n_ctrl > 8, max_linesearch_iter > 16, a simulator
+ *     (bounds, u_zero_I, delta_u, bare or vouched nominal); needs the workspace of mpc_lqr_workspace_bytes, 8 = the kernel of 3 for
+ *     ANY n_state <= 12, n_ctrl <= 4 (f32; round 6): tau is padded to [x(12); u(4)] by dword gathers of the staging DMA, every mode
+ *     of 3, no alignment asked of any block (so also 12/4 itself where 3 refuses); float64 of these shapes stays on 2.
+ *     Auto picks 5, 6 / 4, 3, 8, 2 (float64), 7, else 1 (float64 beyond 12/4, n_state > 32 or n_ctrl > 8, max_linesearch_iter > 16, a simulator
  *     beyond n_ctrl = 1).  The fused kernels need
  *     `workspace` (mpc_lqr_workspace_bytes, 16-byte aligned); out->K / out->k are optional there. */
 int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_lqr_outputs *out,
@@ -206,7 +208,7 @@ int mpc_lqr_step(const mpc_lqr_problem *p, const mpc_lqr_options *o, const mpc_l
  * ignores the hint: with out->k given, that is the array). */
 int mpc_lqr_qp_record(const mpc_lqr_problem *p, const mpc_lqr_options *o, int impl, int64_t *offset_bytes, int64_t *st, int64_t *sb);
 
-/* Does kernel `impl` (1 generic, 2 fused MFMA, 3 DPP, 4 lane-per-problem, 5 MFMA sweep, 6 wavefront-per-problem) accept this problem/options pair?  1 yes, 0 no. */
+/* Does kernel `impl` (1 generic, 2 fused MFMA, 3 DPP, 4 lane-per-problem, 5 MFMA sweep, 6 wavefront-per-problem, 7 padded 32/8, 8 padded 12/4) accept this problem/options pair?  1 yes, 0 no. */
 int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, int impl);
 
 /* (2) The sweep alone: c_back + lqr_backward (mpc/lqr_step.py:284-296, 52-160).

@@ -190,6 +190,7 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
         // the kernels that can stop after their sweep: the 12/4 and 32/8 fused ones; every other shape takes the generic sweep
         bool fused = false;
         if constexpr (sizeof(real) == 4) fused = (impl == 0 || impl == 3) ? dpp16_supported(sp) : false;
+        if constexpr (sizeof(real) == 4) fused = fused || ((impl == 0 || impl == 8) && dpp16_pad_supported(sp));
         if constexpr (sizeof(real) == 4) fused = fused || ((impl == 0 || impl == 5) && mfma40_supported(sp));
         // (the padded 32/8 instantiation can stop after its sweep too -- for the shapes that reach it: under impl 0 the 12/4-class
         // shapes belong to kernels in front of it that cannot, and keep the generic sweep they had)
@@ -203,7 +204,7 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
     }
     if (sp.env.kind && sp.env.linearize && !(phase_mask == 3 && tiny_supported(p->ns, p->nc) && (impl == 0 || impl == 4 || impl == 6)))
         return fail(MPC_E_ARG, "in-kernel linearisation needs the lane-per-problem kernel (n_ctrl = 1, n_state <= 6)");
-    if (sp.env.kind && (impl == 2 || impl == 3))
+    if (sp.env.kind && (impl == 2 || impl == 3 || impl == 8))
         return fail(MPC_E_ARG, "a simulator as true_dynamics runs on the generic kernels only");
     if ((impl == 4 || impl == 6) && (phase_mask != 3 || !tiny_supported(p->ns, p->nc)))
         return fail(MPC_E_DIMS, "lane-per-problem / wavefront-per-problem kernel needs n_ctrl = 1, n_state <= 6");
@@ -242,12 +243,14 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
             const bool have_ws = workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0);
             if ((sp.K == nullptr) != (sp.k == nullptr)) return fail(MPC_E_NULL, "pass both K and k, or neither");
             sp.Kk = (float *)workspace;
-            const bool dpp = dpp16_supported(sp), mfma = mfma16_supported(sp);
+            const bool dpp = dpp16_supported(sp), mfma = mfma16_supported(sp), dpad = dpp16_pad_supported(sp);
             if (impl == 3 && !dpp)
                 return fail(MPC_E_DIMS, "DPP kernel needs fp32, n_state = 12, n_ctrl = 4 and 16-byte aligned blocks");
+            if (impl == 8 && !dpad)
+                return fail(MPC_E_DIMS, "padded DPP kernel needs fp32, n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16");
             if (impl == 2 && !mfma)
                 return fail(MPC_E_DIMS, "fused MFMA kernel needs fp32, n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16");
-            if ((impl == 3 || impl == 2 || dpp || mfma) && !have_ws)
+            if ((impl == 3 || impl == 2 || impl == 8 || dpp || mfma || dpad) && !have_ws)
                 return fail(MPC_E_ARG, "workspace too small or not 16-byte aligned (see mpc_lqr_workspace_bytes)");
             if (impl == 3 || (impl == 0 && dpp)) {
                 // ring depth (lqr_dpp16.hip): the unconstrained step always on the short ring; the constrained one there
@@ -258,6 +261,12 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
                 const int rc = ring2 ? launch_step_dpp16_ring2(sp, st) : launch_step_dpp16(sp, st);
                 return rc ? rc : resolve_asymmetric(sp, impl, workspace, needK, st);
             }
+            // (round 6) every other float32 shape up to 12/4 -- and 12/4 itself where a block is not 16-byte aligned --: the 12/4
+            // kernel's PADDED instantiation, ahead of the one-problem-per-wavefront kernel that served them in rounds 1-5
+            if (impl == 8 || (impl == 0 && dpad)) {
+                const int rc = launch_step_dpp16_pad(sp, st);
+                return rc ? rc : resolve_asymmetric(sp, impl, workspace, needK, st);
+            }
             if (impl == 2 || (impl == 0 && mfma)) {
                 const int rc = launch_step_mfma16(sp, st);
                 return rc ? rc : resolve_asymmetric(sp, impl, workspace, needK, st);
@@ -266,7 +275,7 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
         } else {
             // float64 (round 5): n_state <= 12, n_ctrl <= 4 on the one-problem-per-wavefront kernel's float64 instantiation
             // (v_mfma_f64_16x16x4_f64); what every test and gradient check of the reference runs in (tests/test_mpc.py .double())
-            if (impl == 3) return fail(MPC_E_DTYPE, "the 4-problems-per-wave kernel is fp32 only");
+            if (impl == 3 || impl == 8) return fail(MPC_E_DTYPE, "the 4-problems-per-wave kernel is fp32 only");
             const bool mfma = mfma16_supported(sp);
             if (impl == 2 && !mfma)
                 return fail(MPC_E_DIMS, "fused MFMA kernel needs n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16");
@@ -384,6 +393,12 @@ int mpc_lqr_impl_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o, i
         mpc_lqr_outputs out;
         memset(&out, 0, sizeof(out));
         return mfma40_pad_supported(make_params<float>(p, o, &out)) ? 1 : 0;
+    }
+    if (impl == 8) {
+        if (p->dtype != MPC_F32) return 0;
+        mpc_lqr_outputs out;
+        memset(&out, 0, sizeof(out));
+        return dpp16_pad_supported(make_params<float>(p, o, &out)) ? 1 : 0;
     }
     if (impl == 2 && p->dtype == MPC_F64) {
         mpc_lqr_outputs out;

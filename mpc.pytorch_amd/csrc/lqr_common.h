@@ -43,6 +43,8 @@ size_t generic_lds_bytes(int ns, int nc, size_t elem);
 bool dpp16_supported(const StepParams<float> &p);
 int launch_step_dpp16(const StepParams<float> &p, hipStream_t st);
 int launch_step_dpp16_ring2(const StepParams<float> &p, hipStream_t st);    // the same kernels on a 2-slot sweep ring (two waves per SIMD)
+bool dpp16_pad_supported(const StepParams<float> &p);                          // (round 6) the PADDED instantiation: any n_state <= 12, n_ctrl <= 4, no alignment asked
+int launch_step_dpp16_pad(const StepParams<float> &p, hipStream_t st);
 bool kkt_dpp16_supported(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx,
                          const float *dC, const float *dF);
 int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,

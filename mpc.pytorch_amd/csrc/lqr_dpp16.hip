@@ -413,6 +413,24 @@ MPC_DEV void dma16_if(bool active, const void *g, unsigned off)
 {
     if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 16, 0, 0);
 }
+// ---- the padded instantiation's staging (lqr_dpp16_body.h, PADK; the same two primitives as lqr_mfma40.hip) ----------------
+// 4 bytes per lane from `base + voff` (base wave-uniform: a raw buffer of `nbytes`, voff per lane) to LDS offset `off` + 4 * lane.
+// A lane whose voff lies beyond the buffer writes ZERO (the hardware's range check; measured, tools/ubench/buffer_lds_probe.hip).
+template <int G> MPC_DEV void dma_buf(bool active, const void *base, unsigned nbytes, unsigned voff, unsigned off)
+{
+    static_assert(G == 4, "dword gathers");
+    if (active) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)nbytes, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(g_stage16 + off), 4, (int)voff, 0, 0, 0);
+    }
+}
+MPC_DEV void dma4_if(bool active, const void *g, unsigned off)
+{
+    if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 4, 0, 0);
+}
+MPC_DEV void lds_store_f32x4(unsigned off, f32x4 v) { *(f32x4 *)(g_stage16 + off) = v; }
+// DS instructions of one wave execute in program order: a compiler barrier is all there is to ask for
+MPC_DEV void lds_sync() { asm volatile("" ::: "memory"); }
 // The immediate offset of an LDS-DMA moves the LDS destination together with the global source
 // (tools/ubench/dma_offset_probe.hip).  With the source pointer biased by -IMM once, at set-up, every DMA of a
 // stage names the same LDS anchor `mid` and differs only in IMM: one M0 write per stage instead of one per
@@ -598,7 +616,18 @@ bool dpp16_supported(const StepParams<float> &p)
 // flight per CU: 83.3 against 86.0 us at B = 4096, 65 against 74 at 1024); the instruction-bound constrained step wants the
 // deep ring while there is one wave per SIMD (B <= 4096: 184.8 against 191.0 us) and a second wave per SIMD beyond it
 // (B = 6144: 248 against 347 us; 8192: 304 against 371) -- profiles/r02_experiments.md 15.
-#if MPC_DPP16_NSTAGE == 4
+// ... and a third time with -DMPC_DPP16_PAD (on the 2-slot ring) as launch_step_dpp16_pad: the PADDED instantiation for any n_state <=
+// 12, n_ctrl <= 4 (lqr_dpp16_body.h, PADK): dword gathers with the zero padding done by the DMA, no alignment asked of anybody.
+#ifdef MPC_DPP16_PAD
+#define MPC_DPP16_LAUNCH launch_step_dpp16_pad
+bool dpp16_pad_supported(const StepParams<float> &p)
+{
+    // (dword gathers: float arrays are 4-byte aligned by construction; u_zero_I is read byte-wise.  12/4 itself is welcome too: blocks or
+    // strides that are not 16-byte aligned, which the exact kernel refuses)
+    return p.ns >= 1 && p.ns <= 12 && p.nc >= 1 && p.nc <= 4 && p.T >= 1 && p.max_ls >= 1 && p.max_ls <= 16 && !p.env.kind;
+}
+#define MPC_DPP16_TAKES(p) dpp16_pad_supported(p)
+#elif MPC_DPP16_NSTAGE == 4
 #define MPC_DPP16_LAUNCH launch_step_dpp16
 #else
 #define MPC_DPP16_LAUNCH launch_step_dpp16_ring2
@@ -606,7 +635,10 @@ bool dpp16_supported(const StepParams<float> &p);
 #endif
 int MPC_DPP16_LAUNCH(const StepParams<float> &p, hipStream_t st)
 {
-    if (!dpp16_supported(p)) { set_last_error("dpp16: needs n_state = 12, n_ctrl = 4, fp32, 16-byte aligned blocks"); return MPC_E_DIMS; }
+#ifndef MPC_DPP16_TAKES
+#define MPC_DPP16_TAKES(p) dpp16_supported(p)
+#endif
+    if (!MPC_DPP16_TAKES(p)) { set_last_error(dpp16::PADK ? "dpp16 (padded): needs fp32, n_state <= 12, n_ctrl <= 4, max_linesearch_iter <= 16" : "dpp16: needs n_state = 12, n_ctrl = 4, fp32, 16-byte aligned blocks"); return MPC_E_DIMS; }
     if (!p.Kk || (uintptr_t)p.Kk % 16 != 0) { set_last_error("dpp16: gain workspace missing or misaligned"); return MPC_E_NULL; }
     if (!p.sweep_only && (!p.new_x || !p.new_u)) { set_last_error("dpp16: new_x / new_u is NULL"); return MPC_E_NULL; }
     static_assert(MPC_DPP16_LDS == dpp16::LDS_TOTAL, "LDS layout out of sync");

@@ -68,8 +68,28 @@
 #define MPC_DPP16_QP_WARM 0
 #endif
 
+// ---- The PADDED instantiation (round 6; -DMPC_DPP16_PAD, the third compilation of lqr_dpp16.hip): any n_state <= 12, n_ctrl <= 4 --
+// Rounds 1-5 ran every shape of that range other than exactly 12/4 on the one-problem-per-wavefront kernel (lqr_mfma16_body.h) at
+// half this kernel's rate.  Here tau is padded to [x(12); u(4)] -- state i in lane i, control a in lane 12 + a, zeros elsewhere, an
+// identity on the padded diagonal of Quu -- and the padding is done BY THE STAGING DMA, as in the padded 32/8 kernel
+// (lqr_mfma40_body.h): C and F are gathered dword by dword with `buffer_load ... lds`, whose per-lane source offset is free and whose
+// out-of-range lanes write ZERO into LDS; the small vectors of the record by per-lane `global_load_lds_dword`.  LDS holds the dense
+// 16 x 16 / 12 x 16 blocks in the permuted layout the kernel was written for and nothing downstream of the staging changes; only
+// what touches the caller's arrays directly (x_init, tensor bounds, masks, qp_start, the trajectory and gain outputs) indexes by the
+// true shape.  A stage is 32 DMA instructions instead of 8 (vmcnt is six bits wide): the two-slot ring, one stage ahead -- what the
+// exact kernel's unconstrained step runs on anyway.  No 16-byte alignment is asked of anybody's blocks.
+#ifdef MPC_DPP16_PAD
+#define MPC_DPP16_PADK 1
+#else
+#define MPC_DPP16_PADK 0
+#endif
+
 namespace mpclqr {
 namespace dpp16 {
+constexpr bool PADK = MPC_DPP16_PADK != 0;
+constexpr unsigned OOB_OFF = 0x7fffff00u;          // a source offset beyond every block: the gather writes zero there
+// slot of the padded tau = [x(12); u(4)] -> index in the caller's tau = [x(ns); u(nc)], or -1 (padding)
+MPC_DEV int pad_tau(int pj, int ns, int nc) { return pj < 12 ? (pj < ns ? pj : -1) : (pj - 12 < nc ? ns + (pj - 12) : -1); }
 
 // Diagnostic builds only (-DMPC_DPP16_PROF, tools/prof_phases.py): shader-clock totals of the phases of the two
 // loops, per wave, written where K would go.  Every probe drains the LDS / scalar queue (s_memtime), so the phases
@@ -325,11 +345,11 @@ enum {
     SC = 0, SF = 4096, SR = 7168, SG = 8192, STAGE_BYTES = 9216, NSTAGE = MPC_DPP16_NSTAGE, AHEAD = NSTAGE - 1,
     R_c = 0, R_tau = 64, R_f = 128, R_qs = 176, R_lo = 192, R_hi = 208,
     LDS_TOTAL = NSTAGE * STAGE_BYTES,
-    DMA_SWEEP = 8       // 4 C + 3 F + 1 record
+    DMA_SWEEP = MPC_DPP16_PADK ? 32 : 8       // 4 C + 3 F + 1 record (padded instantiation, dwords: 16 + 12 + 4)
 };
 // DMA instructions of one rollout stage: F, record, gains (+ C when priced directly, + (m, M) otherwise
 // when constraints are present)
-template <int MODE, bool DIRECT> struct RollDma { enum { N = 3 + 1 + (rgm(MODE) ? 0 : 1) + (DIRECT ? 4 : (con(MODE) ? 1 : 0)) }; };
+template <int MODE, bool DIRECT> struct RollDma { enum { N = (MPC_DPP16_PADK ? 12 + 4 : 3 + 1) + (rgm(MODE) ? 0 : 1) + (DIRECT ? (MPC_DPP16_PADK ? 16 : 4) : (con(MODE) ? 1 : 0)) }; };
 // The identity-priced rollout does not stage C: its stage is [(m, M)] | gains | F | record = 5 (6) KiB, packed
 // back to back so the same LDS holds 7 (6) stages instead of 4 and the DMA runs 6 (5) timesteps ahead -- a
 // rollout step is ~0.45 us, four-deep staging would leave the loads less than an HBM round trip under load.
@@ -355,6 +375,16 @@ template <int MODE, bool ROLL, bool DIRECT> MPC_DEV unsigned stage_mid(int slot)
 {
     return ROLL ? (unsigned)(slot * (int)RollRing<MODE, DIRECT>::BYTES + (int)RollRing<MODE, DIRECT>::FOFF)
                 : (unsigned)(slot * (int)STAGE_BYTES + (int)SF);
+}
+
+// every pass of the padded instantiation starts on cleared staging memory: the record words of padded entries are never written by
+// the gathers (their lanes sit the instruction out), and the passes lay their slots out differently
+MPC_DEV void pad_clear(int lane)
+{
+    if (!PADK) return;
+    wv::lds_sync();
+    for (unsigned off = 16u * (unsigned)lane; off + 16 <= (unsigned)LDS_TOTAL; off += 1024) wv::lds_store_f32x4(off, f32x4{0.f, 0.f, 0.f, 0.f});
+    wv::lds_sync();
 }
 
 // ---- LDS bank conflicts ----------------------------------------------------------------------------------
@@ -386,6 +416,8 @@ struct Lane {
     int b0;               // first problem of the wave (uniform)
     bool live;            // pb is a real problem of this wave
     bool isu;             // j >= 12
+    bool ovalid;          // this lane's variable exists in the caller's tau (always, in the exact kernel)
+    float padd[4];        // padded instantiation: 1 in lane 12 + a of entry a for a control beyond n_ctrl -- the identity on the padded diagonal of Quu
     int a;                // control index of this lane (j - 12), 0 for state lanes
     // LDS byte offsets inside a stage
     // C and F sit in LDS in granule-permuted order (see lds_swizzle below): a lane's 16-byte DMA destination is
@@ -425,6 +457,8 @@ MPC_DEV void lane_init(Lane &L, int lane, int wave, int B, bool cperm = true)
     L.live = pb < B;
     L.pb = L.live ? pb : B - 1;
     L.isu = L.j >= 12;
+    L.ovalid = true;
+    L.padd[0] = L.padd[1] = L.padd[2] = L.padd[3] = 0.f;
     L.a = L.isu ? L.j - 12 : 0;
     const int jx = L.j < 12 ? L.j : 11;
 #pragma unroll
@@ -477,6 +511,16 @@ struct Dma {
     long g2_step;                     // ... of the m record (16 bytes per problem and timestep)
     long r_step;                      // bytes per timestep of this lane's record source
     long r_step_nof;                  // the same, but 0 on lanes that stream f (a move that leaves F / f in place)
+#ifdef MPC_DPP16_PAD
+    // the padded instantiation's gathers: wave-uniform block bases of the four problems at the stage the pointers stand on, the
+    // per-lane source offsets of the 16 + 12 dword instructions of a C / F stage, and this lane's word of each problem's record
+    const char *Cb[4], *Fb[4];
+    unsigned coff[16], foff[12];
+    unsigned cbytes, fbytes;
+    const char *rq[4];
+    long rq_step[4];
+    bool rq_act[4], rq_isf[4];
+#endif
 };
 
 // Position the pointers on the first stage of a pass: t = T-1 for the sweep, t = 0 for a rollout.
@@ -539,13 +583,116 @@ MPC_DEV void dma_seek(Dma &d, const P &p, const Lane &L, int wave)
         // record, see sweep_step)
         d.g2_ptr = (const char *)(p.Kk + (long)T * B * 64 + pb * 4) + 2048 + t0 * d.g2_step;
     }
+#ifdef MPC_DPP16_PAD
+    {
+        // ---- the padded instantiation's maps (see the head of the file).  LDS position -> source element, through the SAME granule
+        // permutations the exact kernel's 16-byte DMA applies (src_granule_C / _cols / _rows), one dword at a time.
+        const int ns = p.ns, nc = p.nc, n = ns + nc;
+        d.cbytes = (unsigned)(n * n * 4);
+        d.fbytes = T > 1 ? (unsigned)(ns * n * 4) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pbk = 4 * wave + k < p.B ? 4 * wave + k : p.B - 1;
+            d.Cb[k] = (const char *)(p.C + (long)pbk * p.C_sb) + t0 * d.c_step;
+            d.Fb[k] = T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) + tf0 * d.f_step : (const char *)p.C;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int slot = kk >> 2, dw = 64 * (kk & 3) + L.lane, g = dw >> 2, e = dw & 3;
+            const int gs = src_granule_C(g, p.c_symmetric ? 0 : slot), R = gs >> 2, col = 4 * (gs & 3) + e;
+            const int aR = pad_tau(R, ns, nc), ac = pad_tau(col, ns, nc);
+            d.coff[kk] = (aR >= 0 && ac >= 0) ? (unsigned)(4 * (aR * n + ac)) : OOB_OFF;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 12; ++kk) {
+            const int slot = kk / 3, G = 16 * kk + (L.lane >> 2), gi = G - 48 * slot, e = L.lane & 3;
+            const int perm = ROLL ? src_granule_rows(gi) : src_granule_cols(gi, slot);
+            const int m = perm >> 2, ac = pad_tau(4 * (perm & 3) + e, ns, nc);
+            d.foff[kk] = (m < ns && ac >= 0) ? (unsigned)(4 * (m * n + ac)) : OOB_OFF;
+        }
+        // the record of problem slot kk: lane l = word l of its 64: granule gi = l >> 2 (0-3 c | 4-6 x | 7 u | 8-10 f | 11 the QP's
+        // start | 12 lo | 13 hi), entry e = l & 3 of it.  A word with no source sits the instruction out: it keeps the zero that
+        // pad_clear left there.
+        const int gi = L.lane >> 2, e = L.lane & 3;
+        const bool want_c = !ROLL || DIRECT, want_f = ROLL && p.f && T > 1;
+        const bool want_b = MODE == 2 && p.bound_mode == MPC_BOUND_TENSOR;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const long pbk = 4 * wave + kk < p.B ? 4 * wave + kk : p.B - 1;
+            const char *q = (const char *)p.cur_x;
+            long st = 0;
+            bool act = false, isf = false;
+            if (gi < 4) {
+                const int a = pad_tau(4 * gi + e, ns, nc);
+                if (want_c && a >= 0) { q = (const char *)(p.c + pbk * p.c_sb + a); st = 4 * p.c_st; act = true; }
+            } else if (gi < 7) {
+                const int i = 4 * (gi - 4) + e;
+                if (i < ns) { q = (const char *)(p.cur_x + pbk * ns + i); st = 4 * B * ns; act = true; }
+            } else if (gi == 7) {
+                if (e < nc) { q = (const char *)(p.cur_u + pbk * nc + e); st = 4 * B * nc; act = true; }
+            } else if (gi < 11) {
+                const int i = 4 * (gi - 8) + e;
+                if (want_f && i < ns) { q = (const char *)(p.f + pbk * p.f_sb + i); st = 4 * p.f_st; act = true; isf = true; }
+            } else if (gi == 11) {
+                if (MPC_QP_START && MODE == 2 && !ROLL && p.qp_start && e < nc) { q = (const char *)(p.qp_start + pbk * p.qp_start_sb + e); st = 4 * p.qp_start_st; act = true; }
+            } else if (gi == 12 || gi == 13) {
+                if (want_b && e < nc) { q = (const char *)((gi == 12 ? p.lo : p.hi) + pbk * nc + e); st = 4 * B * nc; act = true; }
+            }
+            d.rq[kk] = q + (isf ? tf0 : t0) * st;
+            d.rq_step[kk] = st;
+            d.rq_act[kk] = act;
+            d.rq_isf[kk] = isf;
+        }
+    }
+#endif
 }
+
+#ifdef MPC_DPP16_PAD
+// the gathers of one stage, in the four parts the arithmetic of a timestep takes them in (Feed): `mid` = the stage's F block
+template <int MODE, bool ROLL, bool DIRECT, int K> MPC_DEV void pad_part(const Dma &d, unsigned mid)
+{
+    constexpr bool WITH_C = !ROLL || DIRECT;
+    // sweep / direct rollout: C 0-7 | C 8-15 | F 0-7 | F 8-11 + record;   packed rollout: F 0-5 | F 6-11 | record | -
+    if (WITH_C) {
+        if (K == 0 || K == 1) {
+#pragma unroll
+            for (int kk = 8 * K; kk < 8 * K + 8; ++kk) wv::dma_buf<4>(true, d.Cb[kk >> 2], d.cbytes, d.coff[kk], mid - 4096 + 256 * kk);
+        } else if (K == 2) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) wv::dma_buf<4>(true, d.Fb[kk / 3], d.fbytes, d.foff[kk], mid + 256 * kk);
+        } else {
+#pragma unroll
+            for (int kk = 8; kk < 12; ++kk) wv::dma_buf<4>(true, d.Fb[kk / 3], d.fbytes, d.foff[kk], mid + 256 * kk);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wv::dma4_if(d.rq_act[kk], d.rq[kk], mid + 3072 + 256 * kk);
+        }
+    } else {
+        if (K == 0 || K == 1) {
+#pragma unroll
+            for (int kk = 6 * K; kk < 6 * K + 6; ++kk) wv::dma_buf<4>(true, d.Fb[kk / 3], d.fbytes, d.foff[kk], mid + 256 * kk);
+        } else if (K == 2) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wv::dma4_if(d.rq_act[kk], d.rq[kk], mid + 3072 + 256 * kk);
+        }
+    }
+}
+#endif
 
 // DMA of the stage the pointers stand on into the ring slot anchored at `mid`: exactly DMA_SWEEP /
 // RollDma<MODE, DIRECT>::N instructions, all but the directly-priced rollout's gains on one M0.
 template <int MODE, bool ROLL, bool DIRECT>
 MPC_DEV void stage_issue(const Dma &d, unsigned mid)
 {
+#ifdef MPC_DPP16_PAD
+    pad_part<MODE, ROLL, DIRECT, 0>(d, mid); pad_part<MODE, ROLL, DIRECT, 1>(d, mid);
+    pad_part<MODE, ROLL, DIRECT, 2>(d, mid); pad_part<MODE, ROLL, DIRECT, 3>(d, mid);
+    if (ROLL && !rgm(MODE)) {
+        if (DIRECT) wv::dma16_at<0>(d.g_ptr - 1024, mid + (SG - SF));
+        else wv::dma16_at<-1024>(d.g_ptr, mid);
+    }
+    if (ROLL && !DIRECT && con(MODE)) wv::dma16_at<-2048>(d.g2_ptr, mid);
+    return;
+#endif
     if (!ROLL || DIRECT) {
         wv::dma16_at<-4096, wv::DMA_C>(d.c_ptr[0], mid);
         wv::dma16_at<-3072, wv::DMA_C>(d.c_ptr[1], mid);
@@ -571,6 +718,23 @@ MPC_DEV void stage_issue(const Dma &d, unsigned mid)
 template <int MODE, bool ROLL, bool DIRECT>
 MPC_DEV void stage_move(Dma &d, bool move_f)
 {
+#ifdef MPC_DPP16_PAD
+    {
+        const long fsp = move_f ? d.f_step : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ROLL || DIRECT) d.Cb[k] += ROLL ? d.c_step : -d.c_step;
+            d.Fb[k] += ROLL ? fsp : -fsp;
+            const long rs = (d.rq_isf[k] && !move_f) ? 0 : d.rq_step[k];
+            d.rq[k] += ROLL ? rs : -rs;
+        }
+        if (ROLL && !rgm(MODE)) {
+            d.g_ptr += d.g_step;
+            if (con(MODE) && !DIRECT) d.g2_ptr += d.g2_step;
+        }
+        return;
+    }
+#endif
     const long fs = move_f ? d.f_step : 0;
     const long rs = ROLL ? (move_f ? d.r_step : d.r_step_nof) : d.r_step;
     if (!ROLL || DIRECT) {
@@ -605,6 +769,21 @@ template <int MODE, bool ROLL, bool DIRECT> struct Feed {
     template <int K> MPC_DEVM void part()
     {
         if (!on) return;
+#ifdef MPC_DPP16_PAD
+        pad_part<MODE, ROLL, DIRECT, K>(d, mid);
+        if (ROLL && !DIRECT) {
+            if (K == 2) {
+                if (!rgm(MODE)) wv::dma16_at<-1024>(d.g_ptr, mid);
+                if (con(MODE)) wv::dma16_at<-2048>(d.g2_ptr, mid);
+            } else if (K == 3) {
+                stage_move<MODE, ROLL, DIRECT>(d, move_f);
+            }
+        } else if (K == 3) {
+            if (ROLL && !rgm(MODE)) wv::dma16_at<0>(d.g_ptr - 1024, mid + (SG - SF));
+            stage_move<MODE, ROLL, DIRECT>(d, move_f);
+        }
+        return;
+#endif
         enum { NC = (!ROLL || DIRECT) ? 4 : 0 };      // C instructions of a stage
         if (ROLL && !DIRECT) {
             // packed rollout stage: F0 F1 | F2 REC | G [G2] | moves
@@ -648,9 +827,28 @@ MPC_DEV ZmRaw zm_fetch(const P &p, const Lane &L, int t)
     // stage DMAs, and the compiler -- which cannot count those across the loop -- would drain the whole queue in
     // front of every use (measured: the masked kernel at 152 us against 104 us unmasked).
     // Split in two so that a timestep of arithmetic sits between the loads and the first look at their result.
-    const unsigned *row = (const unsigned *)p.zero_mask + (long)t * p.B + L.b0;
     const int last = p.B - 1 - L.b0;                         // a partial last wave repeats its last problem
     ZmRaw r;
+    if (PADK) {
+        // u_zero_I [T,B,nc] bytes at any nc: the byte of control a out of the aligned dword that holds it (scalar loads want 4-byte
+        // alignment); a padded control is free (its row of Quu is the identity, it stays at zero)
+        const int nc = p.nc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long b = L.b0 + (k < last ? k : last);
+            unsigned z = 0u;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const unsigned long A = (unsigned long)(p.zero_mask + ((long)t * p.B + b) * nc + (a < nc ? a : 0));
+                const unsigned word = wv::load_uniform_u32((const unsigned *)(A & ~3ul));
+                const unsigned byte = (word >> (8u * (unsigned)(A & 3ul))) & 0xffu;
+                z |= (a < nc && byte != 0u) ? (1u << (8 * a)) : 0u;
+            }
+            r.m[k] = z;
+        }
+        return r;
+    }
+    const unsigned *row = (const unsigned *)p.zero_mask + (long)t * p.B + L.b0;
     r.m[0] = wv::load_uniform_u32(row);
     r.m[1] = wv::load_uniform_u32(row + (1 < last ? 1 : last));
     r.m[2] = wv::load_uniform_u32(row + (2 < last ? 2 : last));
@@ -728,7 +926,11 @@ MPC_DEV void sw_read(SwStage &s, const P &p, const Lane &L, int t, int slot, uns
             for (int a = 0; a < 4; ++a) { s.lo[a] = l[a]; s.hi[a] = h[a]; }
         } else {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) { s.lo[a] = p.lo_s; s.hi[a] = p.hi_s; }
+            for (int a = 0; a < 4; ++a) {
+                const bool pad = PADK && a >= p.nc;          // (a padded control has no reach: it stays at zero)
+                s.lo[a] = pad ? 0.f : p.lo_s;
+                s.hi[a] = pad ? 0.f : p.hi_s;
+            }
         }
         if (MPC_QP_START && p.qp_start) {
             const f32x4 z = wv::lds_f32x4(base + SR + L.p * 256 + R_qs);
@@ -792,6 +994,11 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
         feed.template part<2>();
     }
 
+    if (PADK) {
+        // a control beyond n_ctrl: H = 1, q = 0, no reach -- it stays at zero and its gains are zero
+#pragma unroll
+        for (int a = 0; a < 4; ++a) Q[12 + a] += L.padd[a];
+    }
     PROF_MARK(10);              // slot 10: c_back + the products Y, Q, q
     // ---- the 4x4 control block: row-uniform copies out of lanes 12..15 --------------------------
     Sym4 S;
@@ -1012,7 +1219,12 @@ MPC_DEV void sweep_step(const P &p, const Lane &L, const SwStage &s, SwState &st
             const long tb = (long)t * p.B + L.pb;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                if (L.j < 12) p.K[(tb * 4 + a) * 12 + L.j] = K[a];
+                if (PADK) {
+                    if (a < p.nc) {
+                        if (L.j < p.ns) p.K[(tb * p.nc + a) * p.ns + L.j] = K[a];
+                        else if (j12) p.k[tb * p.nc + a] = K[a];
+                    }
+                } else if (L.j < 12) p.K[(tb * 4 + a) * 12 + L.j] = K[a];
                 else if (j12) p.k[tb * 4 + a] = K[a];
             }
         }
@@ -1110,8 +1322,9 @@ MPC_DEV void ro_read(RoStage &s, const P &p, const Lane &L, int t, int slot, uns
             s.lo = wv::lds_f32(base + L.aRecA + R_lo);
             s.hi = wv::lds_f32(base + L.aRecA + R_hi);
         } else {
-            s.lo = p.lo_s;
-            s.hi = p.hi_s;
+            const bool pad = PADK && !L.ovalid;
+            s.lo = pad ? 0.f : p.lo_s;
+            s.hi = pad ? 0.f : p.hi_s;
         }
     }
     s.zm = ((zm >> (8 * L.a)) & 0xffu) != 0u;
@@ -1197,7 +1410,7 @@ MPC_DEV void rollout_step(const P &p, const Lane &L, const RoStage &s, RoState &
         const float d = sel(L.isu, s.tb - un, 0.f);                  // (selects, not branches: lane-dependent
         st.du2 = fmaf(d, d, st.du2);                                 //  branches cost exec-mask bookkeeping)
     }
-    wv::store_out(st.out, tp);                                  // new_u (control lanes) / new_x: one store
+    if (!PADK || L.ovalid) wv::store_out(st.out, tp);           // new_u (control lanes) / new_x: one store
     st.out += L.ostep;
     feed.template part<2>();
     if (!DIRECT && CHECK) {
@@ -1291,7 +1504,7 @@ template <int MODE, bool MULTI, bool DIRECT, bool CHECK, bool PAIR = false>
 MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gains<rgm(MODE)> &G, RoState &st, Trials &tr, int nt, double base PROF_ARG)
 {
     const int T = p.T;
-    float x0 = L.isu ? 0.f : p.x_init[(long)L.pb * 12 + L.j];
+    float x0 = L.isu ? 0.f : (PADK ? (L.ovalid ? p.x_init[(long)L.pb * p.ns + L.j] : 0.f) : p.x_init[(long)L.pb * 12 + L.j]);
     // have the load land HERE: a vector load still pending when the loop is entered makes the compiler drain the
     // whole DMA queue (s_waitcnt vmcnt(0)) in front of its first use in every trip -- it cannot count across the loop
     wv::pin(x0);
@@ -1321,6 +1534,7 @@ MPC_DEV void rollout_pass(const P &p, const Lane &L, Dma &d, int wave, const Gai
 #pragma unroll
     for (int i = 0; i < NS; ++i) zq[i] = 0u;
     dma_seek<MODE, true, DIRECT>(d, p, L, wave);
+    pad_clear(L.lane);
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         if (i < T) {
@@ -1525,7 +1739,7 @@ MPC_DEV void line_search(const P &p, const Lane &L, Dma &d, int wave, const Gain
 #pragma unroll
             for (int i = 0; i < COPY_N; ++i) {
                 const int t = t0 + i < T ? t0 + i : T - 1;
-                if (worse0) wv::store_out(dst + (long)t * L.ostep, v[i]);
+                if (worse0 && (!PADK || L.ovalid)) wv::store_out(dst + (long)t * L.ostep, v[i]);
             }
         }
         PROF_MARK_ALL(12);          // slot 12: copy of the parked trajectory
@@ -1575,6 +1789,14 @@ MPC_DEV void step_wave(const P &p)
     lane_init(L, lane, wave, p.B, !p.c_symmetric);
     L.out0 = L.isu ? p.new_u + (long)L.pb * 4 + L.a : p.new_x + (long)L.pb * 12 + L.j;
     L.ostep = L.isu ? (long)p.B * 4 : (long)p.B * 12;
+    if (PADK) {
+        // the caller's arrays by their true shape; a lane of the padding stores nothing (its out0 is never dereferenced)
+        L.ovalid = L.isu ? L.a < p.nc : L.j < p.ns;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) L.padd[a] = (L.j == 12 + a && a >= p.nc) ? 1.f : 0.f;
+        L.out0 = L.isu ? p.new_u + (long)L.pb * p.nc + (L.ovalid ? L.a : 0) : p.new_x + (long)L.pb * p.ns + (L.ovalid ? L.j : 0);
+        L.ostep = L.isu ? (long)p.B * p.nc : (long)p.B * p.ns;
+    }
     L.scr0 = p.Kk + (long)p.T * p.B * 128 + (long)L.pb * 16 + L.j;      // behind the two records
     L.ostep1 = (long)p.B * 16;
     const int T = p.T;
@@ -1602,6 +1824,7 @@ MPC_DEV void step_wave(const P &p)
     {
         unsigned zq[NSTAGE] = {};
         dma_seek<MODE, false, false>(d, p, L, wave);
+        pad_clear(L.lane);
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i) {
             const int ti = T - 1 - i;

@@ -17,7 +17,7 @@ LIB_NAME = "libmpc_lqr_hip.so"
 MPC_F32, MPC_F64 = 0, 1
 BOUND_NONE, BOUND_SCALAR, BOUND_TENSOR = 0, 1, 2
 ST_PNQP_UNCONVERGED, ST_NONFINITE, ST_NOMINAL_OFF_DYNAMICS, ST_C_ASYMMETRIC, ST_QUU_SINGULAR, ST_C_TESTED = 1, 2, 4, 8, 16, 32
-IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA16, IMPL_DPP16, IMPL_TINY, IMPL_MFMA40, IMPL_WAVE1, IMPL_MFMA40_PAD = 0, 1, 2, 3, 4, 5, 6, 7
+IMPL_AUTO, IMPL_GENERIC, IMPL_MFMA16, IMPL_DPP16, IMPL_TINY, IMPL_MFMA40, IMPL_WAVE1, IMPL_MFMA40_PAD, IMPL_DPP16_PAD = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 ABI_VERSION = 9      # include/mpc_lqr.h: MPC_LQR_ABI_VERSION
 

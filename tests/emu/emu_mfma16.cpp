@@ -637,7 +637,11 @@ extern "C" int emu_lqr_step_dpp16(const mpc_lqr_problem *p, const mpc_lqr_option
 {
     if (p->dtype != MPC_F32) return MPC_E_DTYPE;
     mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, out);
+#ifdef MPC_DPP16_PAD          // the padded instantiation (csrc/Makefile: lqr_dpp16_pad.o): any n_state <= 12, n_ctrl <= 4
+    if (!(sp.ns >= 1 && sp.ns <= 12 && sp.nc >= 1 && sp.nc <= 4 && sp.max_ls >= 1 && sp.max_ls <= 16)) return MPC_E_DIMS;
+#else
     if (!(sp.ns == 12 && sp.nc == 4 && sp.max_ls >= 1 && sp.max_ls <= 16)) return MPC_E_DIMS;
+#endif
     if (!sp.new_x || !sp.new_u) return MPC_E_NULL;
     static float *kk_buf = nullptr;
     static size_t kk_cap = 0;

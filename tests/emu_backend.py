@@ -21,7 +21,8 @@ _LIB = None
 def build(ring2=False, pad=0):
     """ring2: the 12/4 kernel with its 2-slot sweep ring (-DMPC_DPP16_NSTAGE=2, the second compilation of lqr_dpp16.hip) and
     the 32/8 kernel with its 2-slot sweep ring (-DMPC_MFMA40_SWEEP_NSTAGE=2, the second compilation of lqr_mfma40.hip's step kernels).
-    pad = 4 | 16: the 32/8 kernel's PADDED instantiation (-DMPC_MFMA40_PAD=4|16 on the two-slot ring, csrc/Makefile)."""
+    pad = 4 | 16: the 32/8 kernel's PADDED instantiation (-DMPC_MFMA40_PAD=4|16 on the two-slot ring, csrc/Makefile) -- and, round 6, the
+    12/4 kernel's (-DMPC_DPP16_PAD: any n_state <= 12, n_ctrl <= 4; kernel name "dpp16_pad")."""
     so = os.path.join(_EMU, "libemu_mfma16_pad%d.so" % pad if pad else ("libemu_mfma16_ring2.so" if ring2 else "libemu_mfma16.so"))
     src = os.path.join(_EMU, "emu_mfma16.cpp")
     csrc = os.path.join(_HERE, "..", "mpc.pytorch_amd", "csrc")
@@ -43,7 +44,7 @@ def build(ring2=False, pad=0):
                 tmp = so + ".tmp%d" % os.getpid()
                 subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
                                       + (["-DMPC_DPP16_NSTAGE=2", "-DMPC_KKT16_NSTAGE=2", "-DMPC_MFMA40_SWEEP_NSTAGE=2"] if (ring2 or pad) else [])
-                                      + (["-DMPC_MFMA40_PAD=%d" % pad] if pad else []) + ["-o", tmp, src])
+                                      + (["-DMPC_MFMA40_PAD=%d" % pad, "-DMPC_DPP16_PAD"] if pad else []) + ["-o", tmp, src])
                 os.replace(tmp, so)
     return so
 
@@ -174,6 +175,11 @@ def lqr_step(x_init, C, c, F, f, cur_x, cur_u, u_lower=None, u_upper=None, u_zer
         fn = lib().emu_lqr_step_wave1
         fn.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs)]
         rc = fn(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
+    elif kernel == "dpp16_pad":
+        Lp = lib_pad(4)
+        Lp.emu_set_dma_late(int(bool(dma_late)))
+        Lp.emu_lqr_step_dpp16.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options), ctypes.POINTER(N.Outputs)]
+        rc = Lp.emu_lqr_step_dpp16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
     elif kernel == "dpp16":
         rc = lib().emu_lqr_step_dpp16(ctypes.byref(p), ctypes.byref(o), ctypes.byref(out))
     elif kernel == "dpp16_ring2":

@@ -644,3 +644,74 @@ def test_float64_kernel_full_batches_vs_oracle(be, ns, nc, T, B, mode):
         if not DRY:
             st = host(r["status"])
             assert (st & 8 == 0).all() and (st & 32 != 0).all()          # C tested, symmetric: nothing re-solved
+
+
+# ------------------------------------------------------------------------------------------------
+# (j) round 6: the PADDED instantiation of the 12/4 kernel (impl 8): every float32 shape up to 12/4
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ns,nc,T,B,mode", [(8, 4, 50, 4096, "unbounded"), (10, 3, 50, 4093, "bounded"), (12, 2, 50, 2051, "tensor_bounds"),
+                                            (7, 3, 30, 1500, "masked"), (12, 2, 25, 1000, "delta_u"), (3, 2, 10, 777, "bounded"),
+                                            (12, 4, 70, 1030, "bounded"), (5, 4, 66, 515, "unbounded"), (12, 4, 50, 4096, "unaligned")])
+def test_padded_dpp16_full_batches_vs_oracle(be, ns, nc, T, B, mode):
+    """shapes near 12/4 were a wall (the one-problem-per-wavefront kernel at half the 12/4 kernel's rate, 0.06-0.27
+    of their roofline).  Round 6: the 12/4 kernel's PADDED instantiation (csrc/lqr_dpp16_body.h, PADK; impl 8 = what impl 0 picks for
+    every float32 shape up to 12/4 that the exact kernel does not take) -- tau padded to [x(12); u(4)] by dword gathers of the
+    staging DMA.  Every mode at BASELINE-sized batches, horizons across the 64-step limit of the register-resident gains, ragged
+    last waves, every problem against the float64 oracle at the stated tolerance (box-constrained: the oracle with the kernel's QP
+    start, like the 12/4 kernel); `unaligned`: 12/4 blocks that are NOT 16-byte aligned, which the exact kernel refuses."""
+    import bench
+    from mpc._native import StepOptions, IMPL_DPP16_PAD, IMPL_DPP16
+    from oracle import lqr_oracle as O
+    B = full_batch(B)
+    bounded = mode in ("bounded", "tensor_bounds", "delta_u")
+    p = bench.make_problem(ns, nc, T, B, torch.float32, DEV, seed=70 + ns + nc, u_scale=0.3 if bounded else 0.0, clamp=1.0 if bounded else None)
+    if mode == "unaligned":
+        # the same numbers one float off a 16-byte boundary
+        for k in ("C", "c", "F", "f", "cur_x", "cur_u", "x_init"):
+            flat = torch.empty(p[k].numel() + 1, dtype=torch.float32, device=DEV)
+            flat[1:] = p[k].reshape(-1)
+            p[k] = flat[1:].view(p[k].shape)
+        assert p["C"].data_ptr() % 16 == 4
+    kw, okw = {}, {}
+    if mode == "bounded":
+        kw = okw = dict(u_lower=-1.0, u_upper=1.0)
+    elif mode == "delta_u":
+        kw = okw = dict(u_lower=-1.0, u_upper=1.0, delta_u=0.25)
+    elif mode == "tensor_bounds":
+        g = torch.Generator().manual_seed(2)
+        lo, hi = (-1.0 - torch.rand(T, B, nc, generator=g)).to(DEV), (1.0 + torch.rand(T, B, nc, generator=g)).to(DEV)
+        kw, okw = dict(u_lower=lo, u_upper=hi), dict(u_lower=h64(lo), u_upper=h64(hi))
+    elif mode == "masked":
+        g = torch.Generator().manual_seed(3)
+        mask = (torch.rand(T, B, nc, generator=g) < 0.3).to(DEV)
+        p["cur_u"] = 0.3 * torch.randn(T, B, nc, generator=g).to(DEV)
+        p["cur_u"][mask] = 0.0
+        from mpc import util
+        from mpc.mpc import LinDx
+        p["cur_x"] = util.get_traj(T, p["cur_u"], p["x_init"], LinDx(p["F"], p["f"]))
+        kw, okw = dict(u_zero_I=mask), dict(u_zero_I=host(mask))
+    h = {k: h64(v) for k, v in p.items()}
+    o = O.lqr_step(h["x_init"], h["C"], h["c"], h["F"], h["f"], h["cur_x"], h["cur_u"], lockstep=False, nthreads=O.max_threads(),
+                   return_gains=True, qp_cold=bounded, **okw)
+    args = (p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"])
+    if not DRY:
+        assert be.impl_supported(ns, nc, torch.float32, IMPL_DPP16_PAD)
+    for vouch in (False, True):
+        opts = StepOptions(nominal_on_dynamics=vouch, c_symmetric=vouch, **kw)
+        r = be.lqr_step(*args, opts, impl=1 if DRY else IMPL_DPP16_PAD, want_gains=True)
+        sync()
+        strict_step_check("pad12_%d_%d_%s_%s" % (ns, nc, mode, "vouched" if vouch else "bare"), r, o, B)
+        np.testing.assert_allclose(host(r["old_costs"]), o["old_costs"], rtol=2e-5)
+        np.testing.assert_allclose(host(r["full_du_norm"]), o["full_du_norm"], rtol=2e-3, atol=2e-4)
+        if DRY:
+            continue
+        st = host(r["status"])
+        assert (st & 2 == 0).all() and ((st & 32 != 0).all() if not vouch else (st & 32 == 0).all())
+        # impl 0 = this kernel for every such shape (12/4 itself only where the exact kernel refuses the blocks)
+        r0 = be.lqr_step(*args, opts, impl=0)
+        sync()
+        if (ns, nc) != (12, 4) or mode == "unaligned":
+            assert torch.equal(r0["new_u"], r["new_u"]) and torch.equal(r0["new_x"], r["new_x"]) and torch.equal(r0["costs"], r["costs"])
+        if mode == "unaligned":
+            with pytest.raises(RuntimeError):
+                be.lqr_step(*args, opts, impl=IMPL_DPP16)

@@ -64,7 +64,7 @@ def impls_for(z):
     ns, nc = int(z["meta"][0]), int(z["meta"][1])
     from mpc import _native
     out = [1]
-    for impl in (_native.IMPL_MFMA16, _native.IMPL_DPP16, _native.IMPL_TINY, _native.IMPL_MFMA40, _native.IMPL_WAVE1):
+    for impl in (_native.IMPL_MFMA16, _native.IMPL_DPP16, _native.IMPL_DPP16_PAD, _native.IMPL_TINY, _native.IMPL_MFMA40, _native.IMPL_WAVE1):
         if _native.backend().impl_supported(ns, nc, torch.from_numpy(z["C"][:0]).dtype, impl):
             out.append(impl)
     return out

@@ -62,6 +62,8 @@ SGPR_SPILL_LIMITS = {
     # pass put the count at 1499 / 1084 for nothing measurable; that form was dropped.)
     "lqr_dpp16": {"kernelILi0E": 200, "kernelILi1E": 440, "kernelILi2E": 690, "kernelILi3E": 160, "kkt_fused": 8},
     "lqr_dpp16_ring2": {"kernelILi0E": 140, "kernelILi1E": 425, "kernelILi2E": 430, "kernelILi3E": 170, "lqr_kkt_dpp16": 0},
+    # (round 6) the padded instantiation of the 12/4 kernel: 44 registers of gather maps a lane and eight wave-uniform block bases
+    "lqr_dpp16_pad": {"kernelILi0E": 345, "kernelILi1E": 650, "kernelILi2E": 870, "kernelILi3E": 510},
     "lqr_mfma40": {"kernelILi0E": 90, "kernelILi1E": 105, "kernelILi2E": 150},
     # (round 4: block addresses as scalar arithmetic -- two more base pointers live in the two-slot build of mode 0)
     "lqr_mfma40_ring2": {"kernelILi0E": 100, "kernelILi1E": 105, "kernelILi2E": 150},
@@ -102,7 +104,7 @@ def test_no_vector_spills_no_scratch_and_bounded_scalar_spills(tu):
     assert seen == set(SGPR_SPILL_LIMITS[tu]), (seen, list(md))
 
 
-@pytest.mark.parametrize("tu,kernels", [("lqr_dpp16", 8), ("lqr_dpp16_ring2", 5)])
+@pytest.mark.parametrize("tu,kernels", [("lqr_dpp16", 8), ("lqr_dpp16_ring2", 5), ("lqr_dpp16_pad", 4)])
 def test_dpp16_kernels_keep_their_arrays_in_registers_and_their_dma_queue_full(tu, kernels):
     """Both compilations of lqr_dpp16.hip (csrc/Makefile): the 4-slot ring (step kernel modes 0..3 + the fused KKT
     backward kernels: register-resident gains up to T = 64 and the long-horizon one, each plain and masked) and the 2-slot one (the same four + the three-launch KKT gradient kernel)."""
@@ -124,7 +126,7 @@ def test_mfma40_kernels_keep_their_arrays_in_registers_and_their_dma_queue_full(
         assert v == {"scratch": 0, "drains": 0}, (k, v)
 
 
-@pytest.mark.parametrize("tu", ["lqr_dpp16", "lqr_dpp16_ring2"])
+@pytest.mark.parametrize("tu", ["lqr_dpp16", "lqr_dpp16_ring2", "lqr_dpp16_pad"])
 def test_register_resident_gains_own_the_accumulation_registers(tu):
     """Mode 0 of the headline kernel parks the gains of the whole horizon in a[0..255] through inline assembly
     (wv::rg_put / rg_get, lqr_dpp16.hip).  That is only sound while the compiler itself never allocates an AccVGPR in

@@ -2,7 +2,7 @@
 """No GPU: the fused kernels' bodies on the CPU wavefront emulator (tests/emu) against the float64 oracle over RANDOM option sets --
 batch (ragged waves), horizon, bounds (none / scalar / tensor), delta_u, u_zero_I, f on / off, line-search depth and decay, promises,
 qp_start -- on convex problems, where parity is exact up to float32 rounding.  One line per violation; exits non-zero if any.
-    python tools/emu_fuzz.py [cases [seed [kernel,...]]]        kernels: dpp16 dpp16_ring2 mfma16 mfma16_f64 mfma40 mfma40_ring2 mfma40_pad
+    python tools/emu_fuzz.py [cases [seed [kernel,...]]]        kernels: dpp16 dpp16_ring2 dpp16_pad mfma16 mfma16_f64 mfma40 mfma40_ring2 mfma40_pad
 FUZZ_GPU=1: the SAME cases through the C ABI on the MI355X instead of the emulator (impl 3 / 2 / 5 / 7 for the kernel named, or
 impl 0 -- the library's own choice -- for every third case): what the emulator does not model (DMA timing, wait counts, the
 launchers' routing) under the same random options."""
@@ -26,7 +26,7 @@ if GPU:
                      qp_start=None, x_init=None, C=None, c=None, F=None, f=None, cur_x=None, cur_u=None, u_lower=None, u_upper=None,
                      u_zero_I=None, delta_u=None, linesearch_decay=0.2, max_linesearch_iter=10, auto=False):
             dt = torch.float64 if dtype == np.float64 else torch.float32
-            impl = 0 if auto else {"dpp16": 3, "dpp16_ring2": 3, "mfma16": 2, "mfma40": 5, "mfma40_ring2": 5, "mfma40_pad4": 7, "mfma40_pad16": 7}[kernel]
+            impl = 0 if auto else {"dpp16": 3, "dpp16_ring2": 3, "dpp16_pad": 8, "mfma16": 2, "mfma40": 5, "mfma40_ring2": 5, "mfma40_pad4": 7, "mfma40_pad16": 7}[kernel]
             T, B = C.shape[0], C.shape[1]
             ns = x_init.shape[1]
             n = C.shape[2]
@@ -58,7 +58,7 @@ for case in range(cases):
     kernel = kernels[case % len(kernels)]
     ns, nc = (32, 8) if kernel.startswith("mfma40") else (12, 4)
     f64 = kernel == "mfma16_f64"                       # the float64 instantiation of the one-problem-per-wave body
-    if kernel in ("mfma16", "mfma16_f64") and rng.random() < 0.5:
+    if (kernel in ("mfma16", "mfma16_f64") and rng.random() < 0.5) or (kernel == "dpp16_pad" and rng.random() < 0.8):
         ns, nc = int(rng.integers(1, 13)), int(rng.integers(1, 5))
     if kernel == "mfma40_pad":                        # the padded instantiation of the 32/8 body: dword or 16-byte gathers
         if rng.random() < 0.5:
@@ -98,7 +98,7 @@ for case in range(cases):
     ekw = dict(kernel="mfma16" if f64 else kernel, **({"dtype": np.float64} if f64 else {}), dma_late=bool(rng.integers(0, 2)), nominal_on_dynamics=bool(rng.integers(0, 2)), c_symmetric=bool(rng.integers(0, 2)))
     if kernel == "mfma16" and (ns, nc) == (12, 4) and not f64:
         ekw["force_general"] = bool(rng.integers(0, 2))
-    if mode in ("scalar", "tensor") and kernel in ("dpp16", "dpp16_ring2", "mfma40", "mfma40_ring2") and rng.random() < 0.3:
+    if mode in ("scalar", "tensor") and kernel in ("dpp16", "dpp16_ring2", "dpp16_pad", "mfma40", "mfma40_ring2") and rng.random() < 0.3:
         ekw["qp_start"] = rng.standard_normal((T, B, nc)) if rng.random() < 0.5 else np.zeros((1, 1, nc))
     if os.environ.get("FUZZ_NO_QS"):
         ekw.pop("qp_start", None)
