@@ -190,7 +190,10 @@ static int step_impl(const mpc_lqr_problem *p, const mpc_lqr_options *o, const m
         // the kernels that can stop after their sweep: the 12/4 and 32/8 fused ones; every other shape takes the generic sweep
         bool fused = false;
         if constexpr (sizeof(real) == 4) fused = (impl == 0 || impl == 3) ? dpp16_supported(sp) : false;
-        if constexpr (sizeof(real) == 4) fused = fused || ((impl == 0 || impl == 8) && dpp16_pad_supported(sp));
+        // (round 6: the padded 12/4 instantiation stops after its sweep like the exact kernel -- where the call reaches it: under impl 0
+        // the one-control shapes up to six states belong to the lane-per-problem kernels in front of it, which cannot)
+        if constexpr (sizeof(real) == 4)
+            fused = fused || ((impl == 8 || (impl == 0 && !tiny_supported(p->ns, p->nc))) && dpp16_pad_supported(sp));
         if constexpr (sizeof(real) == 4) fused = fused || ((impl == 0 || impl == 5) && mfma40_supported(sp));
         // (the padded 32/8 instantiation can stop after its sweep too -- for the shapes that reach it: under impl 0 the 12/4-class
         // shapes belong to kernels in front of it that cannot, and keep the generic sweep they had)
