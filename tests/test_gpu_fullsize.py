@@ -704,10 +704,10 @@ def test_padded_dpp16_full_batches_vs_oracle(be, ns, nc, T, B, mode):
         # the horizon, the emulator's IEEE arithmetic shows the same growth; costs: + the identity's 3e-7 |J_nominal| of absolute
         # error, DESIGN 6 -- a zero nominal on 66 steps of growing dynamics costs 5e3 times the optimum it leads to)
         tol = dict(rtol=2e-3, atol=5e-4) if T > 65 else {}
-        strict_step_check("pad12_%d_%d_%s_%s" % (ns, nc, mode, "vouched" if vouch else "bare"), r, o, B,
-                          cost_atol=3e-7 * float(np.abs(o["old_costs"]).max()), **tol)
+        ties = strict_step_check("pad12_%d_%d_%s_%s" % (ns, nc, mode, "vouched" if vouch else "bare"), r, o, B,
+                                 cost_atol=3e-7 * float(np.abs(o["old_costs"]).max()), **tol)
         np.testing.assert_allclose(host(r["old_costs"]), o["old_costs"], rtol=2e-5)
-        np.testing.assert_allclose(host(r["full_du_norm"]), o["full_du_norm"], rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(host(r["full_du_norm"])[~ties], o["full_du_norm"][~ties], rtol=2e-3, atol=2e-4)
         if DRY:
             continue
         st = host(r["status"])
