@@ -807,8 +807,10 @@ def attach_traffic(rows):
             except Exception:
                 continue
         return {}
-    kkt, kktb = load("r04_prof_kkt", "r03_prof_kkt"), load("r04_prof_kkt_bounded", "r03_prof_kkt")
-    cfg5, cfg5b, bnd = load("r04_prof_cfg5_kkt", "r03_prof_cfg5_final"), load("r04_prof_cfg5_bounded", "r03_prof_cfg5_final"), load("r04_prof_bounded", "r03_prof_bounded")
+    kkt, kktb = load("r06_prof_kkt", "r05_prof_kkt", "r04_prof_kkt", "r03_prof_kkt"), load("r04_prof_kkt_bounded", "r03_prof_kkt")
+    cfg5, cfg5b = load("r06_prof_cfg5_kkt", "r05_prof_cfg5_kkt", "r04_prof_cfg5_kkt"), load("r06_prof_cfg5_bounded", "r05_prof_cfg5_bounded", "r04_prof_cfg5_bounded")
+    bnd = load("r06_prof_bounded", "r05_prof_bounded", "r04_prof_bounded", "r03_prof_bounded")
+    c5, p12, p12b = load("r06_prof_cfg5", "r05_prof_cfg5"), load("r06_prof_pad12_10_3"), load("r06_prof_pad12_10_3_bounded")
     # (config 5's backward is two launches: the fused kernel + the outer products; their counters add up)
     k5, o5 = cfg5.get("lqr_kkt_fused_mfma40_kernel<0>"), cfg5.get("kkt_outer_kernel")
     kkt5 = ({"hbm_bytes_per_dispatch": k5["hbm_bytes_per_dispatch"] + o5["hbm_bytes_per_dispatch"]}
@@ -817,6 +819,9 @@ def attach_traffic(rows):
             "kkt_backward_unbounded": kkt.get("lqr_kkt_fused_dpp16_kernel<false>"),
             "kkt_backward_bounded": kktb.get("lqr_kkt_fused_dpp16_kernel<true>"),
             "cfg5_kkt_backward_B1024": kkt5,
+            "cfg5_step_B1024": c5.get("lqr_step_mfma40_kernel<0>"),
+            "pad12_step_10_3_B4096": p12.get("lqr_step_dpp16_kernel<0>"),
+            "pad12_step_10_3_B4096_bounded": p12b.get("lqr_step_dpp16_kernel<2>"),
             "cfg5_step_bounded_B1024": cfg5b.get("lqr_step_mfma40_kernel<2>")}
     for key, v in pick.items():
         if v and key in rows and "roofline" in rows[key] and "hbm_bytes_per_dispatch" in v:
@@ -1187,7 +1192,8 @@ def main():
         traffic, traffic_source = None, None
         # (the per-kernel counter summary of tools/prof_any.sh, newest round first; "headline_alt" = two alternating problem sets,
         # like this run's timed region)
-        for rnd, kindname in (("r05", "bounded" if args.bounded else ("headline" if args.one_set else "headline_alt")),
+        for rnd, kindname in (("r06", "bounded" if args.bounded else ("headline" if args.one_set else "headline_alt")),
+                              ("r05", "bounded" if args.bounded else ("headline" if args.one_set else "headline_alt")),
                               ("r05", "bounded" if args.bounded else "headline"), ("r04", "bounded" if args.bounded else "headline"),
                               ("r03", "bounded" if args.bounded else "headline")):
             try:

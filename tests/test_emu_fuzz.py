@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("kernels,cases,long_t", [("dpp16,dpp16_ring2,mfma16", 150, False), ("mfma40,mfma40_ring2", 24, False),
                                                    ("dpp16,dpp16_ring2", 24, True),
-                                                   ("mfma16_f64", 60, False), ("mfma40_pad", 20, False), ("dpp16_pad", 120, False), ("dpp16_pad", 24, True)])
+                                                   ("mfma16_f64", 60, False), ("mfma40_pad", 20, False), ("dpp16_pad", 80, False), ("dpp16_pad", 16, True)])
 def test_emulated_bodies_on_random_option_sets(kernels, cases, long_t):
     if not (os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or __import__("shutil").which("clang++")):
         pytest.skip("the emulator needs clang++")

@@ -6,7 +6,7 @@ round-3 summaries mixed sweep-only, vouched and bare calls of one kernel in one 
     python tools/prof_one.py KIND [reps [warm]]
     KIND: headline | headline_alt (two problem sets, alternating: bench.py's timed region) | headline_bare | bounded | kkt | kkt_bounded | cfg5 | cfg5_bare | cfg5_bounded | cfg5_kkt | cfg5_kkt_bounded |
           cfg5_B8192 | cfg5_bounded_B8192 | bounded_warm | cfg5_bounded_warm   (_warm: the box QPs started from the k an earlier
-          step at the same nominal left in the workspace, mpc_lqr_options.qp_start)
+          step at the same nominal left in the workspace, mpc_lqr_options.qp_start) | pad12_<ns>_<nc>[_bounded] (round 6: the padded 12/4 kernel)
 The problems are bench.py's (same seeds, same options as the rows of its `extra` object)."""
 import os
 import sys
@@ -28,6 +28,8 @@ bounded = "bounded" in kind
 bare = kind.endswith("_bare")
 kind_b = kind[:-5] if kind.endswith("_warm") else kind
 ns, nc, T = (32, 8, 64) if cfg5 else (12, 4, 50)
+if kind.startswith("pad12_"):          # (round 6) pad12_<ns>_<nc>[_bounded]: a shape up to 12/4 on the padded 12/4 kernel (impl 0 = impl 8)
+    ns, nc = int(kind.split("_")[1]), int(kind.split("_")[2])
 B = 8192 if kind_b.endswith("B8192") else (1024 if cfg5 else 4096)
 B = int(os.environ.get("PROF_ONE_B", B))          # (another batch for the same kind of call)
 if cfg5:
