@@ -356,12 +356,17 @@ def solve_parity(make_ctrl, x0, cost_slices, dyn, out, n=PARITY_SOLVE, rtol=5e-3
     from mpc.mpc import QuadCost
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_backend import OracleBackend
-    prev = _native.set_backend_for_testing(OracleBackend())
+    ns_, nc_ = int(x0.shape[1]), int(cost_slices[0].shape[-1]) - int(x0.shape[1])
+    cold = x0.dtype == torch.float32 and ns_ <= 12 and nc_ <= 4 and not (nc_ == 1 and ns_ <= 6)     # (the kernels' QP start, see parity_check)
+    prev = _native.set_backend_for_testing(OracleBackend(qp_cold=cold))
     try:
         ctrl = make_ctrl()
         C64, c64 = (t[:, :n].detach().double().cpu() for t in cost_slices)
         dyn64 = dyn
-        if isinstance(dyn, torch.nn.Module) and any(True for _ in dyn.parameters()):
+        from mpc.mpc import LinDx
+        if isinstance(dyn, LinDx):          # (linear dynamics: the first n problems' blocks, in float64 on the host)
+            dyn64 = LinDx(dyn.F[:, :n].detach().double().cpu(), None if dyn.f is None else dyn.f[:, :n].detach().double().cpu())
+        elif isinstance(dyn, torch.nn.Module) and any(True for _ in dyn.parameters()):
             import copy
             dyn64 = copy.deepcopy(dyn).double().cpu()
         with torch.no_grad():
@@ -582,13 +587,33 @@ def extra_rows(be, dev, steps):
             if roww is not None:
                 roww["workload"] = row["workload"] + "; the box QPs started from the solutions of an earlier step at this nominal"
                 rows["lqr_step_bounded_warm"] = roww
+            # (round 6) the same step as the FOURTH iteration of a solve sees it: three steps, each from the previous
+            # one's result, then this one timed at that nominal -- where rounds 4-5 had a few problems of 4096 search to the last trial
+            # (206-216 us: a double rounding of the priced cost) and the QPs are nearly confirmed by their start
+            xi, ui = p["cur_x"], p["cur_u"]
+            for _ in range(3):
+                ri = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], xi, ui, opts)
+                xi, ui = ri["new_x"].clone(), ri["new_u"].clone()
+            p4 = dict(p, cur_x=xi, cur_u=ui)
+            row4, r4 = step_row(p4, opts, NS, NC, T_H, B_PER_GPU)
+            row4["workload"] = "headline shape, box bounds +-1: the step of lqr_step_bounded as iteration 4 of the solve that starts there"
+            row4["alpha_below_decay"] = int((r4["alphas"] < 0.19).sum().item())       # problems that searched beyond alpha = decay
+            rows["lqr_step_bounded_in_solve_iter4"] = row4
+            del p4, xi, ui, r4
         rows["kkt_backward_" + key] = kkt_row(p, r, opts, NS, NC, T_H, B_PER_GPU)
         ctrl = mpc.MPC(NS, NC, T_H, u_lower=-1.0 if bounded else None, u_upper=1.0 if bounded else None,
                        lqr_iter=5, verbose=-1, exit_unconverged=False, detach_unconverged=False, backprop=False)
         cost, dx = QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"])
-        wall, ms, _ = timed(lambda: ctrl(p["x_init"], cost, dx), 12, 25)        # (25 solves = 125 steps in front: the sustained state)
-        rows["mpc_forward_5iter_" + key] = dict(ms=ms, wall_ms=wall, lqr_iter=5,
-                                                note="whole MPC.forward: initial trajectory kernel + 5 x (step + select_best)")
+        wall, ms, out5 = timed(lambda: ctrl(p["x_init"], cost, dx), 12, 25)        # (25 solves = 125 steps in front: the sustained state)
+
+        def mk5(bounded=bounded):
+            return mpc.MPC(NS, NC, T_H, u_lower=-1.0 if bounded else None, u_upper=1.0 if bounded else None,
+                           lqr_iter=5, verbose=-1, exit_unconverged=False, detach_unconverged=False, backprop=False)
+        # (round 6: the whole solve certified like the simulator rows -- its first 16 problems solved again by mpc.MPC on the oracle in
+        # float64: five box-constrained iterations end within 2e-3 in x, u of that run, costs within 1e-4)
+        rows["mpc_forward_5iter_" + key] = certify(dict(ms=ms, wall_ms=wall, lqr_iter=5,
+                                                        note="whole MPC.forward: initial trajectory kernel + 5 x (step + select_best)"),
+                                                   lambda: solve_parity(mk5, p["x_init"], (p["C"], p["c"]), dx, out5, rtol=2e-3, atol=2e-3))
         del p, r, ctrl, cost, dx
     # ---- config 5: n_state=32 n_ctrl=8 T=64, the MFMA tile path; B=1024 is one GPU's share of 8192 over 8 ------
     for B5 in (1024, 8192):

@@ -27,8 +27,9 @@ def _bound(v):
 class OracleBackend:
     name = "cpu-oracle (tests only)"
 
-    def __init__(self, lockstep=False):
+    def __init__(self, lockstep=False, qp_cold=False):
         self.lockstep = lockstep
+        self.qp_cold = qp_cold          # every convex box QP from pnqp's own cold start, like the fused float32 kernels up to 12/4 (lqr_oracle.h)
         self.calls = []
 
     def _t(self, a, like):
@@ -50,7 +51,7 @@ class OracleBackend:
         o = O.lqr_step(_np(x_init), _np(C), _np(c), Fn, _np(f), _np(cur_x), _np(cur_u),
                        _bound(opts.u_lower), _bound(opts.u_upper), _np(opts.u_zero_I), opts.delta_u,
                        opts.linesearch_decay, opts.max_linesearch_iter, lockstep=self.lockstep,
-                       return_gains=True)
+                       return_gains=True, qp_cold=self.qp_cold and not self.lockstep)
         B = C.shape[1]
         env = getattr(opts, "true_dynamics", None)
         if env is not None:      # the simulator is the true dynamics of the rollout (mpc/lqr_step.py:223-225)

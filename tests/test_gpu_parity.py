@@ -1395,3 +1395,27 @@ def test_box_constrained_12_4_line_search_tails_vs_oracle(be, max_ls, decay, stu
         np.testing.assert_allclose(r["costs"][keep], o["costs"][keep], rtol=2e-3, atol=1e-2)
         np.testing.assert_allclose(r["full_du_norm"][keep], o["full_du_norm"][keep], rtol=2e-3, atol=2e-3)
         np.testing.assert_allclose(r["alpha_du_norm"][keep], o["alpha_du_norm"][keep], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("ns,nc", [(12, 4), (10, 3), (8, 4)])
+def test_six_iteration_box_constrained_solve_vs_the_oracle_backed_solve(be, ns, nc):
+    """a whole box-constrained `MPC.forward` (6 iterations: the pre-bound ping-pong plans, the promise of a symmetric
+    C from the second iteration on, select_best, the late iterations whose line searches used to straggle) on the device in float32
+    against the SAME host logic on the CPU oracle in float64 (bench.solve_parity: the first 16 problems), at 12/4 (the exact kernel)
+    and at 10/3, 8/4 (round 6: the padded instantiation under impl 0)."""
+    import bench
+    from mpc import mpc
+    from mpc.mpc import LinDx, QuadCost
+    B, T = 256, 50
+    p = bench.make_problem(ns, nc, T, B, torch.float32, DEV, seed=11 + ns, u_scale=0.3, clamp=1.0)
+
+    def mk():
+        return mpc.MPC(ns, nc, T, u_lower=-1.0, u_upper=1.0, lqr_iter=6, verbose=-1, exit_unconverged=False, detach_unconverged=False,
+                       backprop=False)
+    dx = LinDx(p["F"], p["f"])
+    with torch.no_grad():
+        out = mk()(p["x_init"], QuadCost(p["C"], p["c"]), dx)
+    torch.cuda.synchronize()
+    assert float(out[1].abs().max()) <= 1.0 + 1e-6
+    par = bench.solve_parity(mk, p["x_init"], (p["C"], p["c"]), dx, out, rtol=2e-3, atol=2e-3)
+    assert par["ok"], par
