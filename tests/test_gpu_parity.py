@@ -1417,5 +1417,5 @@ def test_six_iteration_box_constrained_solve_vs_the_oracle_backed_solve(be, ns, 
         out = mk()(p["x_init"], QuadCost(p["C"], p["c"]), dx)
     torch.cuda.synchronize()
     assert float(out[1].abs().max()) <= 1.0 + 1e-6
-    par = bench.solve_parity(mk, p["x_init"], (p["C"], p["c"]), dx, out, rtol=2e-3, atol=2e-3)
+    par = bench.solve_parity(mk, p["x_init"], (p["C"], p["c"]), dx, out, rtol=5e-4, atol=5e-4)
     assert par["ok"], par
