@@ -49,11 +49,16 @@ for i in range(n_cases):
         kw["u_zero_I"] = (rng.random((T, B, nc)) < 0.3)
     # (slew_rate_penalty: the reference's own path for it runs on module dynamics only -- with LinDx it raises 'NoneType is not callable';
     #  the goldens mpc_slew_* made from tests/test_mpc.py:652-744 cover it)
+    ref_norm = False
     if B > 1:
         # The reference's full_du_norm mixes the problems of a batch (mpc/lqr_step.py:243-245: transpose(1,2).view(n_batch, -1));
         # this package's is per problem (= the reference at n_batch = 1).  Where that number decides -- the eps exit and
-        # which problems detach_unconverged cuts off -- a batch is not comparable: batches run with neither in play.
-        kw.update(eps=1e-13, detach_unconverged=False)
+        # which problems detach_unconverged cuts off -- a batch is comparable only with `reference_du_norm=True` (round 6), which every
+        # second batch runs with; the others run with neither the exit nor the mask in play.
+        if rng.random() < 0.5:
+            ref_norm = True
+        else:
+            kw.update(eps=1e-13, detach_unconverged=False)
     grads = bool(rng.random() < 0.6)
     if rng.random() < 0.25:
         # iLQR on a shipped simulator (mpc/env_dx): time-invariant goal cost, the module linearised every iteration and rolled out in
@@ -94,7 +99,7 @@ for i in range(n_cases):
                    grad_method="ANALYTIC", not_improved_lim=5, best_cost_eps=1e-4)
         cases.append(dict(ns=ns, nc=nc, T=T, B=B, C=C, c=c, F=None, f=None, x_init=rng.standard_normal((B, ns)), kw=kwn, grads=False, w=None, net=net))
         continue
-    cases.append(dict(ns=ns, nc=nc, T=T, B=B, C=C, c=c, F=F, f=f, x_init=rng.standard_normal((B, ns)), kw=kw, grads=grads,
+    cases.append(dict(ns=ns, nc=nc, T=T, B=B, C=C, c=c, F=F, f=f, x_init=rng.standard_normal((B, ns)), kw=kw, grads=grads, ref_norm=ref_norm,
                       w=rng.standard_normal((T, B, nc))))
 tmp = tempfile.mkdtemp()
 pickle.dump(cases, open(os.path.join(tmp, "cases.pkl"), "wb"))
@@ -125,7 +130,7 @@ try:
                     for fc, W, b in zip(dyn.fcs, nt["Ws"], nt["bs"]):
                         fc.weight.copy_(t(W)); fc.bias.copy_(t(b))
                 kw["grad_method"] = getattr(mpc.GradMethods, kw["grad_method"])
-            ctrl = mpc.MPC(cs["ns"], cs["nc"], cs["T"], verbose=-1, **kw)
+            ctrl = mpc.MPC(cs["ns"], cs["nc"], cs["T"], verbose=-1, reference_du_norm=bool(cs.get("ref_norm")), **kw)
             x, u, costs = ctrl(x0, QuadCost(C, c), dyn if dyn is not None else LinDx(F, f))
             m = dict(x=x.detach().numpy(), u=u.detach().numpy(), costs=costs.detach().numpy())
             if cs["grads"]:
