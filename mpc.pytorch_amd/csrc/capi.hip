@@ -351,7 +351,7 @@ int mpc_lqr_abi_version(void) { return MPC_LQR_ABI_VERSION; }
 
 const char *mpc_lqr_build_info(void)
 {
-    return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32,f64>, lqr_step_dpp16<f32>, "
+    return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32,f64>, lqr_step_dpp16<f32>, lqr_step_dpp16_padded<f32>, "
            "lqr_step_tiny<f32,f64>, lqr_step_wave1<f32>, lqr_step_mfma40<f32>, lqr_step_mfma40_padded<f32>, nn_rollout<f32>, nn_linearize<f32>, env_linearize, kkt_grads, kkt_fused<f32>, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
 }
 
