@@ -94,7 +94,17 @@ for case in range(cases):
         cur_u = np.where(kw["u_zero_I"], 0.0, cur_u); cur_x, _ = O.traj_cost(x_init, cur_u, F, f); kw.update(cur_u=cur_u, cur_x=cur_x)
     if mode in ("scalar", "tensor") and rng.random() < 0.25:
         kw.update(delta_u=float(rng.choice([0.05, 0.2, 1.0])))
-    o = O.lqr_step(lockstep=False, **kw)
+    # (round 6) the float32 kernels up to 12/4 start every convex box QP from pnqp's own cold start (mpc/pnqp.py:14-19) where the reference
+    # passes k of timestep t+1; the oracle makes the same substitution for them (lqr_oracle.h, qp_cold).  pnqp returns the iterate whose
+    # Newton step is shorter than 1e-4 without taking it, so the reference's result moves with its start by that much -- which a long
+    # horizon on growing dynamics amplifies (seen: 2.5e-4 in one k_t at t = 42 of 64, ns = 1, 0.1 in u thirty steps upstream, float64
+    # against float64): the cases where the reference's two starts end apart by more than the tolerance are COUNTED, not compared through.
+    cold_kernel = kernel in ("dpp16", "dpp16_ring2", "dpp16_pad", "mfma16")
+    o = O.lqr_step(lockstep=False, qp_cold=cold_kernel, **kw)
+    if cold_kernel and mode in ("scalar", "tensor"):
+        o_ref = O.lqr_step(lockstep=False, **kw)
+        if np.abs(o_ref["new_u"] - o["new_u"]).max() > 1e-3 + 3e-6 * float(np.abs(np.asarray(kw["cur_x"]) - o["new_x"]).max()):
+            globals()["start_sensitive"] = globals().get("start_sensitive", 0) + 1
     ekw = dict(kernel="mfma16" if f64 else kernel, **({"dtype": np.float64} if f64 else {}), dma_late=bool(rng.integers(0, 2)), nominal_on_dynamics=bool(rng.integers(0, 2)), c_symmetric=bool(rng.integers(0, 2)))
     if kernel == "mfma16" and (ns, nc) == (12, 4) and not f64:
         ekw["force_general"] = bool(rng.integers(0, 2))
@@ -160,5 +170,6 @@ for case in range(cases):
         print("VIOLATION case %d seed0 %d kernel %s ns %d nc %d T %d B %d mode %s opts %s ls (%g, %d): flips %s errs %s status %s" % (
             case, seed0, kernel, ns, nc, T, B, mode, {k2: (v if isinstance(v, (bool, int, float)) else "array") for k2, v in ekw.items()},
             kw["linesearch_decay"], kw["max_linesearch_iter"], np.nonzero(flip)[0].tolist(), {k2: float("%.3g" % v) for k2, v in errs.items()}, r["status"].tolist()))
-print("cases %d violations %d refused %d active-set ties named %d  (%.0f s)%s" % (cases, bad, globals().get("refused", 0), globals().get("as_ties", 0), time.time() - t0, "  [GPU]" if GPU else ""))
+print("cases %d violations %d refused %d active-set ties named %d  reference-start-sensitive cases %d  (%.0f s)%s" % (
+    cases, bad, globals().get("refused", 0), globals().get("as_ties", 0), globals().get("start_sensitive", 0), time.time() - t0, "  [GPU]" if GPU else ""))
 sys.exit(1 if bad else 0)
