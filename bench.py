@@ -661,9 +661,14 @@ def extra_rows(be, dev, steps):
                 ctrl5 = mpc.MPC(32, 8, 64, u_lower=-1.0 if bounded5 else None, u_upper=1.0 if bounded5 else None, lqr_iter=5,
                                 verbose=-1, exit_unconverged=False, detach_unconverged=False, backprop=False)
                 cost5, dx5 = QuadCost(p["C"], p["c"]), LinDx(p["F"], p["f"])
-                wall5, ms5, _ = timed(lambda: ctrl5(p["x_init"], cost5, dx5), 12, 12)
-                rows["cfg5_mpc_forward_5iter_" + ("bounded" if bounded5 else "unbounded")] = dict(
-                    ms=ms5, wall_ms=wall5, lqr_iter=5, note="whole MPC.forward at config 5: initial trajectory kernel + 5 x (step + select_best)")
+                wall5, ms5, out55 = timed(lambda: ctrl5(p["x_init"], cost5, dx5), 12, 12)
+
+                def mk55(bounded5=bounded5):
+                    return mpc.MPC(32, 8, 64, u_lower=-1.0 if bounded5 else None, u_upper=1.0 if bounded5 else None, lqr_iter=5,
+                                   verbose=-1, exit_unconverged=False, detach_unconverged=False, backprop=False)
+                rows["cfg5_mpc_forward_5iter_" + ("bounded" if bounded5 else "unbounded")] = certify(dict(
+                    ms=ms5, wall_ms=wall5, lqr_iter=5, note="whole MPC.forward at config 5: initial trajectory kernel + 5 x (step + select_best)"),
+                    lambda: solve_parity(mk55, p["x_init"], (p["C"], p["c"]), dx5, out55, n=8, rtol=1e-3, atol=1e-3))
                 del ctrl5, cost5, dx5
         del p, r
     # ---- shapes BETWEEN the hand-tuned ones (round 4): the 32/8 kernel's padded instantiation (impl 7 under impl 0), beside the
