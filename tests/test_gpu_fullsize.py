@@ -720,3 +720,33 @@ def test_padded_dpp16_full_batches_vs_oracle(be, ns, nc, T, B, mode):
         if mode == "unaligned":
             with pytest.raises(RuntimeError):
                 be.lqr_step(*args, opts, impl=IMPL_DPP16)
+
+
+@pytest.mark.parametrize("bounded", [False, True])
+@pytest.mark.parametrize("ns,nc,B", [(10, 3, 1030), (8, 4, 515), (12, 2, 777)])
+def test_kkt_backward_on_padded_dpp16_shapes_vs_oracle(be, ns, nc, B, bounded):
+    """LQRStepFn.backward (mpc/lqr_step.py:312-407) at the shapes of the padded 12/4 kernel (round 6): the three-launch route --
+    mpc_lqr_kkt_prepare, the nested step with the active controls pinned (u_zero_I mode of the padded kernel under impl 0), mpc_lqr_kkt_grads --
+    in float32 against the float64 oracle fed the very same (x*, u*, dl_dx, dl_du); ragged last waves."""
+    import bench
+    from mpc._native import StepOptions
+    from oracle import lqr_oracle as O
+    T = 30
+    B = full_batch(B)
+    p = bench.make_problem(ns, nc, T, B, torch.float32, DEV, seed=4 + ns, u_scale=0.3 if bounded else 0.0, clamp=1.0 if bounded else None)
+    opts = StepOptions(u_lower=-1.0, u_upper=1.0) if bounded else StepOptions()
+    r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    gx = torch.randn(tuple(r["new_x"].shape), generator=g, device=DEV)
+    gu = torch.randn(tuple(r["new_u"].shape), generator=g, device=DEV)
+    got = be.kkt_backward(p["C"], p["c"], p["F"], p["f"], r["new_x"], r["new_u"], gx, gu, opts)
+    sync()
+    o = O.kkt_backward(h64(p["C"]), h64(p["c"]), h64(p["F"]), h64(p["f"]), h64(r["new_x"]), h64(r["new_u"]), h64(gx), h64(gu),
+                       -1.0 if bounded else None, 1.0 if bounded else None, lockstep=False, nthreads=O.max_threads())
+    for k in ("dx_init", "dC", "dc", "dF", "df"):
+        a = host(got[k]).astype(np.float64)
+        assert np.isfinite(a).all(), k
+        ax = tuple(i for i in range(a.ndim) if i != (0 if k == "dx_init" else 1))
+        scale = np.maximum(1.0, np.abs(o[k]).max(axis=ax, keepdims=True))
+        rel = (np.abs(a - o[k]) / scale).max(axis=ax)
+        assert rel.max() < 2e-4, "%s: problem %d off by %.2e of its scale" % (k, int(rel.argmax()), rel.max())
