@@ -831,7 +831,9 @@ MPC_DEV ZmRaw zm_fetch(const P &p, const Lane &L, int t)
     ZmRaw r;
     if (PADK) {
         // u_zero_I [T,B,nc] bytes at any nc: the byte of control a out of the aligned dword that holds it (scalar loads want 4-byte
-        // alignment); a padded control is free (its row of Quu is the identity, it stays at zero)
+        // alignment); a padded control is free (its row of Quu is the identity, it stays at zero).  (The aligned dword of the array's
+        // last bytes can reach up to three bytes past its end -- inside the same 4-byte word, hence the same page: the one finding of the
+        // emulator under AddressSanitizer, as for the padded 32/8 kernel's zero_mask_word.)
         const int nc = p.nc;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
