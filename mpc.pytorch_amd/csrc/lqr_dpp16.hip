@@ -428,6 +428,20 @@ MPC_DEV void dma4_if(bool active, const void *g, unsigned off)
 {
     if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + off), 4, 0, 0);
 }
+// ... with the instruction's immediate offset IMM: it moves the LDS destination and the buffer offset together (like dma16_at: one M0 per
+// group of gathers instead of one per gather -- three instructions a gather became one).  `voff` = source offset - IMM + BIAS, `base_biased` =
+// the block's base - BIAS, `nbytes_biased` = its size + BIAS: the bias keeps voff non-negative, the hardware's range check of voff + IMM
+// against the record count still sends every offset beyond the block to zero.  `anchor`: the LDS address IMM counts from.
+template <int IMM, int BIAS> MPC_DEV void dma_buf_at(const void *base_biased, unsigned nbytes_biased, unsigned voff, unsigned anchor)
+{
+    static_assert(IMM >= 0 && IMM < 4096, "12-bit unsigned immediate");
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base_biased, (short)0, (int)nbytes_biased, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(g_stage16 + anchor), 4, (int)voff, 0, IMM, 0);
+}
+template <int IMM> MPC_DEV void dma4_at_if(bool active, const void *g, unsigned anchor)
+{
+    if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + anchor), 4, IMM, 0);
+}
 MPC_DEV void lds_store_f32x4(unsigned off, f32x4 v) { *(f32x4 *)(g_stage16 + off) = v; }
 // DS instructions of one wave execute in program order: a compiler barrier is all there is to ask for
 MPC_DEV void lds_sync() { asm volatile("" ::: "memory"); }

@@ -87,7 +87,8 @@
 namespace mpclqr {
 namespace dpp16 {
 constexpr bool PADK = MPC_DPP16_PADK != 0;
-constexpr unsigned OOB_OFF = 0x7fffff00u;          // a source offset beyond every block: the gather writes zero there
+constexpr unsigned OOB_OFF = 0x7fff0000u;          // a source offset beyond every block: the gather writes zero there
+enum { PAD_BIAS = 4096 };                          // see wv::dma_buf_at: source offsets are stored as offset - IMM + PAD_BIAS (never negative)
 // slot of the padded tau = [x(12); u(4)] -> index in the caller's tau = [x(ns); u(nc)], or -1 (padding)
 MPC_DEV int pad_tau(int pj, int ns, int nc) { return pj < 12 ? (pj < ns ? pj : -1) : (pj - 12 < nc ? ns + (pj - 12) : -1); }
 
@@ -588,27 +589,28 @@ MPC_DEV void dma_seek(Dma &d, const P &p, const Lane &L, int wave)
         // ---- the padded instantiation's maps (see the head of the file).  LDS position -> source element, through the SAME granule
         // permutations the exact kernel's 16-byte DMA applies (src_granule_C / _cols / _rows), one dword at a time.
         const int ns = p.ns, nc = p.nc, n = ns + nc;
-        d.cbytes = (unsigned)(n * n * 4);
-        d.fbytes = T > 1 ? (unsigned)(ns * n * 4) : 0u;
+        d.cbytes = (unsigned)(n * n * 4) + (unsigned)PAD_BIAS;
+        d.fbytes = (T > 1 ? (unsigned)(ns * n * 4) : 0u) + (unsigned)PAD_BIAS;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int pbk = 4 * wave + k < p.B ? 4 * wave + k : p.B - 1;
-            d.Cb[k] = (const char *)(p.C + (long)pbk * p.C_sb) + t0 * d.c_step;
-            d.Fb[k] = T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) + tf0 * d.f_step : (const char *)p.C;
+            d.Cb[k] = (const char *)(p.C + (long)pbk * p.C_sb) + t0 * d.c_step - (int)PAD_BIAS;
+            d.Fb[k] = (T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) + tf0 * d.f_step : (const char *)p.C) - (int)PAD_BIAS;
         }
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int slot = kk >> 2, dw = 64 * (kk & 3) + L.lane, g = dw >> 2, e = dw & 3;
             const int gs = src_granule_C(g, p.c_symmetric ? 0 : slot), R = gs >> 2, col = 4 * (gs & 3) + e;
             const int aR = pad_tau(R, ns, nc), ac = pad_tau(col, ns, nc);
-            d.coff[kk] = (aR >= 0 && ac >= 0) ? (unsigned)(4 * (aR * n + ac)) : OOB_OFF;
+            // (stored biased: - the instruction's immediate, 256 kk from the stage's C block, + PAD_BIAS)
+            d.coff[kk] = ((aR >= 0 && ac >= 0) ? (unsigned)(4 * (aR * n + ac)) : OOB_OFF) + (unsigned)PAD_BIAS - 256u * (unsigned)kk;
         }
 #pragma unroll
         for (int kk = 0; kk < 12; ++kk) {
             const int slot = kk / 3, G = 16 * kk + (L.lane >> 2), gi = G - 48 * slot, e = L.lane & 3;
             const int perm = ROLL ? src_granule_rows(gi) : src_granule_cols(gi, slot);
             const int m = perm >> 2, ac = pad_tau(4 * (perm & 3) + e, ns, nc);
-            d.foff[kk] = (m < ns && ac >= 0) ? (unsigned)(4 * (m * n + ac)) : OOB_OFF;
+            d.foff[kk] = ((m < ns && ac >= 0) ? (unsigned)(4 * (m * n + ac)) : OOB_OFF) + (unsigned)PAD_BIAS - 256u * (unsigned)kk;      // (immediate: 256 kk from the F block)
         }
         // the record of problem slot kk: lane l = word l of its 64: granule gi = l >> 2 (0-3 c | 4-6 x | 7 u | 8-10 f | 11 the QP's
         // start | 12 lo | 13 hi), entry e = l & 3 of it.  A word with no source sits the instruction out: it keeps the zero that
@@ -638,7 +640,7 @@ MPC_DEV void dma_seek(Dma &d, const P &p, const Lane &L, int wave)
             } else if (gi == 12 || gi == 13) {
                 if (want_b && e < nc) { q = (const char *)((gi == 12 ? p.lo : p.hi) + pbk * nc + e); st = 4 * B * nc; act = true; }
             }
-            d.rq[kk] = q + (isf ? tf0 : t0) * st;
+            d.rq[kk] = q + (isf ? tf0 : t0) * st - (3072 + 256 * kk);       // (biased by minus the immediate: the record sits 3072 behind the F block)
             d.rq_step[kk] = st;
             d.rq_act[kk] = act;
             d.rq_isf[kk] = isf;
@@ -653,28 +655,23 @@ template <int MODE, bool ROLL, bool DIRECT, int K> MPC_DEV void pad_part(const D
 {
     constexpr bool WITH_C = !ROLL || DIRECT;
     // sweep / direct rollout: C 0-7 | C 8-15 | F 0-7 | F 8-11 + record;   packed rollout: F 0-5 | F 6-11 | record | -
+    // (ONE LDS anchor per block -- the stage's C block, its F block -- and the gather's place as the instruction's immediate)
+#define MPC_PAD_C(kk) wv::dma_buf_at<256 * (kk), PAD_BIAS>(d.Cb[(kk) >> 2], d.cbytes, d.coff[kk], mid - 4096)
+#define MPC_PAD_F(kk) wv::dma_buf_at<256 * (kk), PAD_BIAS>(d.Fb[(kk) / 3], d.fbytes, d.foff[kk], mid)
+#define MPC_PAD_R(kk) wv::dma4_at_if<3072 + 256 * (kk)>(d.rq_act[kk], d.rq[kk], mid)
     if (WITH_C) {
-        if (K == 0 || K == 1) {
-#pragma unroll
-            for (int kk = 8 * K; kk < 8 * K + 8; ++kk) wv::dma_buf<4>(true, d.Cb[kk >> 2], d.cbytes, d.coff[kk], mid - 4096 + 256 * kk);
-        } else if (K == 2) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) wv::dma_buf<4>(true, d.Fb[kk / 3], d.fbytes, d.foff[kk], mid + 256 * kk);
-        } else {
-#pragma unroll
-            for (int kk = 8; kk < 12; ++kk) wv::dma_buf<4>(true, d.Fb[kk / 3], d.fbytes, d.foff[kk], mid + 256 * kk);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) wv::dma4_if(d.rq_act[kk], d.rq[kk], mid + 3072 + 256 * kk);
-        }
+        if (K == 0) { MPC_PAD_C(0); MPC_PAD_C(1); MPC_PAD_C(2); MPC_PAD_C(3); MPC_PAD_C(4); MPC_PAD_C(5); MPC_PAD_C(6); MPC_PAD_C(7); }
+        else if (K == 1) { MPC_PAD_C(8); MPC_PAD_C(9); MPC_PAD_C(10); MPC_PAD_C(11); MPC_PAD_C(12); MPC_PAD_C(13); MPC_PAD_C(14); MPC_PAD_C(15); }
+        else if (K == 2) { MPC_PAD_F(0); MPC_PAD_F(1); MPC_PAD_F(2); MPC_PAD_F(3); MPC_PAD_F(4); MPC_PAD_F(5); MPC_PAD_F(6); MPC_PAD_F(7); }
+        else { MPC_PAD_F(8); MPC_PAD_F(9); MPC_PAD_F(10); MPC_PAD_F(11); MPC_PAD_R(0); MPC_PAD_R(1); MPC_PAD_R(2); MPC_PAD_R(3); }
     } else {
-        if (K == 0 || K == 1) {
-#pragma unroll
-            for (int kk = 6 * K; kk < 6 * K + 6; ++kk) wv::dma_buf<4>(true, d.Fb[kk / 3], d.fbytes, d.foff[kk], mid + 256 * kk);
-        } else if (K == 2) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) wv::dma4_if(d.rq_act[kk], d.rq[kk], mid + 3072 + 256 * kk);
-        }
+        if (K == 0) { MPC_PAD_F(0); MPC_PAD_F(1); MPC_PAD_F(2); MPC_PAD_F(3); MPC_PAD_F(4); MPC_PAD_F(5); }
+        else if (K == 1) { MPC_PAD_F(6); MPC_PAD_F(7); MPC_PAD_F(8); MPC_PAD_F(9); MPC_PAD_F(10); MPC_PAD_F(11); }
+        else if (K == 2) { MPC_PAD_R(0); MPC_PAD_R(1); MPC_PAD_R(2); MPC_PAD_R(3); }
     }
+#undef MPC_PAD_C
+#undef MPC_PAD_F
+#undef MPC_PAD_R
 }
 #endif
 

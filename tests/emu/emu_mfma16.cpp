@@ -507,6 +507,21 @@ template <int G> static inline void dma_buf(bool active, const void *base, unsig
     const bool in = (unsigned long)voff + (unsigned long)G <= (unsigned long)nbytes;
     dma_n(in ? (const char *)base + voff : zero, off, G, active);
 }
+// ... with an immediate offset IMM (round 6, the padded 12/4 kernel): the instruction offset moves the LDS destination AND the buffer
+// offset together, like dma16_at -- `voff` is the lane's source offset biased by -IMM + BIAS and `base_biased` the block's base minus BIAS
+// (the bias keeps voff non-negative; the range check sees voff + IMM against nbytes + BIAS), `anchor` the LDS address IMM counts from
+template <int IMM, int BIAS> static inline void dma_buf_at(const void *base_biased, unsigned nbytes_biased, unsigned voff, unsigned anchor)
+{
+    static const char zero[16] = {0};
+    const unsigned long o = (unsigned long)voff + (unsigned long)IMM;        // what the hardware adds up and range-checks
+    const bool in = o + 4ul <= (unsigned long)nbytes_biased && o >= (unsigned long)BIAS;
+    dma_n(in ? (const char *)base_biased + o : zero, anchor + (unsigned)IMM, 4, true);
+}
+// global_load_lds_dword with an immediate offset (g = the lane's pointer biased by -IMM)
+template <int IMM> static inline void dma4_at_if(bool active, const void *g, unsigned anchor)
+{
+    dma_n((const char *)g + IMM, anchor + (unsigned)IMM, 4, active);
+}
 template <int N> static inline void dma_wait()
 {
     // lockstep point: every lane has issued its part of the preceding DMA instructions
