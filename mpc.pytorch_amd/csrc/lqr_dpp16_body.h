@@ -301,7 +301,7 @@ MPC_DEV int pnqp4_rows(const Sym4 &s, const float q[4], const float lb[4], const
         const bool inside = out == 0.f;
         full = inside ? 1.f : 0.f;
         const bool test = !inside & (done == 0.f);
-        if (wv::any(test)) {
+        if (wv::any(test)) {        // (round 6 A/B: computed in every trip instead -- one wave-uniform branch fewer --: 144.8 against 143.4 us)
             if (test) MPC_STAT(2);
             // f(x) - f(m) = -g'd - d'Hd/2 with d = m - x, against 0.1 g'(x - m)
             const float den = wv::ring_sum(-gv * dv), dhd = wv::ring_sum(dv * hdv);
