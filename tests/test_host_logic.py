@@ -74,6 +74,25 @@ def test_argument_validation_without_gpu():
     assert L.mpc_pnqp(3, 1, 4, None, None, None, None, None, 20, None, None, None, None, None, None) == -3
 
 
+def test_kernel_routing_queries_without_gpu():
+    """mpc_lqr_impl_supported answers from sizes and dtype alone (no GPU needed): round 6's padded 12/4 instantiation (impl 8) takes every
+    float32 shape up to 12/4 -- 12/4 itself included: blocks the exact kernel refuses for their alignment --, nothing beyond, no float64;
+    mpc_du_norm_reference validates its arguments."""
+    be = _native.HipBackend()
+    for ns, nc in ((12, 4), (10, 3), (8, 4), (1, 1), (12, 1), (3, 4)):
+        assert be.impl_supported(ns, nc, torch.float32, _native.IMPL_DPP16_PAD), (ns, nc)
+        assert not be.impl_supported(ns, nc, torch.float64, _native.IMPL_DPP16_PAD)
+    for ns, nc in ((13, 4), (12, 5), (32, 8)):
+        assert not be.impl_supported(ns, nc, torch.float32, _native.IMPL_DPP16_PAD)
+        assert be.impl_supported(ns, nc, torch.float32, _native.IMPL_MFMA40_PAD)
+    assert be.impl_supported(12, 4, torch.float32, _native.IMPL_DPP16) and not be.impl_supported(10, 3, torch.float32, _native.IMPL_DPP16)
+    L = _native.load()
+    assert L.mpc_du_norm_reference(0, 5, 0, 2, None, None, None, None) == 0           # empty batch: a no-op
+    assert L.mpc_du_norm_reference(0, 5, 3, 2, None, None, None, None) == -2          # NULL arrays
+    assert L.mpc_du_norm_reference(7, 5, 3, 2, None, None, None, None) == -3          # bad dtype
+    assert L.mpc_du_norm_reference(0, 0, 3, 2, None, None, None, None) == -1          # bad dims
+
+
 def test_network_and_sweep_only_entry_points_validate_arguments_without_gpu():
     """mpc_mlp_* (NNDynamics in the kernels) and MPC_OPT_SWEEP_ONLY reject bad arguments before any launch."""
     L = _native.load()
