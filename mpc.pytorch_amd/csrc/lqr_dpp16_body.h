@@ -535,6 +535,9 @@ MPC_DEV void dma_seek(Dma &d, const P &p, const Lane &L, int wave)
     const long tf0 = (ROLL || T < 2) ? 0 : T - 2;
     d.c_step = 4 * p.C_st;
     d.f_step = T > 1 ? 4 * p.F_st : 0;
+#ifdef MPC_DPP16_PROBE_ROLL_F          // (diagnostic build only: the rollouts read timestep 0's F at every timestep -- WRONG results, the time of a
+    if (ROLL) d.f_step = 0;            //  step whose rollout costs no HBM traffic for F: the bound of every scheme that keeps F on chip)
+#endif
     d.g_step = 4 * B * 64;
     d.g2_step = 4 * B * 4;
 #pragma unroll
