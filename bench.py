@@ -541,7 +541,7 @@ def extra_rows(be, dev, steps):
         fused = bool(_native.load().mpc_lqr_kkt_fused_supported(ctypes.byref(pf), ctypes.byref(of)))
         kb = kkt_algorithmic_bytes_per_problem(ns, nc, T) * B
         return certify(dict(ms=ms, wall_ms=wall, ms_all_launches=ms_all, settle_launches=100, finite=bool(torch.isfinite(g["dC"]).all().item()),
-                    launches=(("mpc_lqr_kkt_fused: ONE launch (sweep + lambda, then rollout + dlambda = V dx + v + all gradients)" if ns == 12 else
+                    launches=(("mpc_lqr_kkt_fused: ONE launch (sweep + lambda, then rollout + dlambda = V dx + v + all gradients)" if ns <= 12 else
                                "mpc_lqr_kkt_fused: the nested step with lambda along its sweep and dlambda = V dx + v along its rollout, "
                                "then the outer-product kernel (two launches)") if fused
                               else "mpc_lqr_kkt_prepare + mpc_lqr_step (nested solve) + mpc_lqr_kkt_grads"),
@@ -690,8 +690,13 @@ def extra_rows(be, dev, steps):
         p = make_problem(ns_p, nc_p, T_H, B_PER_GPU, torch.float32, dev, seed=60 + ns_p, u_scale=0.3 if bnd else 0.0, clamp=1.0 if bnd else None)
         o_p = (StepOptions(u_lower=-1.0, u_upper=1.0, nominal_on_dynamics=True, c_symmetric=True) if bnd
                else StepOptions(nominal_on_dynamics=True, c_symmetric=True))
-        row, _ = step_row(p, o_p, ns_p, nc_p, T_H, B_PER_GPU)
+        row, r_p = step_row(p, o_p, ns_p, nc_p, T_H, B_PER_GPU)
         rowm, _ = step_row(p, o_p, ns_p, nc_p, T_H, B_PER_GPU, impl=IMPL_MFMA16)
+        if (ns_p, nc_p) == (10, 3):
+            # the KKT backward of such a shape (round 6): the fused kernel's padded instantiation, lqr_dpp16_padkkt.o -- one launch where
+            # rounds 1-5 took three (mpc_lqr_kkt_prepare, the nested step, the generic mpc_lqr_kkt_grads: 0.60 / 0.76 ms)
+            rows["pad12_kkt_backward_%d_%d_B%d%s" % (ns_p, nc_p, B_PER_GPU, "_bounded" if bnd else "")] = kkt_row(p, r_p, o_p, ns_p, nc_p, T_H, B_PER_GPU)
+        del r_p
         row["workload"] = ("n_state=%d n_ctrl=%d T=%d B=%d, %s: the padded 12/4 kernel (lqr_step_dpp16_kernel, -DMPC_DPP16_PAD); mfma16_kernel_ms = the "
                            "same call forced onto the one-problem-per-wavefront kernel (rounds 1-5)" % (ns_p, nc_p, T_H, B_PER_GPU, "box bounds +-1" if bnd else "unconstrained"))
         row["mfma16_kernel_ms"] = rowm["ms"]

@@ -352,7 +352,7 @@ int mpc_lqr_abi_version(void) { return MPC_LQR_ABI_VERSION; }
 const char *mpc_lqr_build_info(void)
 {
     return "libmpc_lqr_hip gfx950 (CDNA4) | kernels: lqr_step_generic<f32,f64>, lqr_step_mfma16<f32,f64>, lqr_step_dpp16<f32>, lqr_step_dpp16_padded<f32>, "
-           "lqr_step_tiny<f32,f64>, lqr_step_wave1<f32>, lqr_step_mfma40<f32>, lqr_step_mfma40_padded<f32>, nn_rollout<f32>, nn_linearize<f32>, env_linearize, kkt_grads, kkt_fused<f32>, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
+           "lqr_step_tiny<f32,f64>, lqr_step_wave1<f32>, lqr_step_mfma40<f32>, lqr_step_mfma40_padded<f32>, nn_rollout<f32>, nn_linearize<f32>, env_linearize, kkt_grads, kkt_fused<f32>, kkt_fused_padded<f32>, pnqp, traj_cost, select_best | built " __DATE__ " " __TIME__;
 }
 
 const char *mpc_lqr_last_error(void) { return g_last_error.c_str(); }
@@ -508,7 +508,8 @@ int mpc_lqr_kkt_grads(const mpc_lqr_problem *p, const void *dx, const void *du, 
 int mpc_lqr_kkt_fused_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o)
 {
     if (!p || check_problem(p, false, false) != MPC_OK || check_options(p, o) != MPC_OK) return 0;
-    const bool s12 = p->ns == 12 && p->nc == 4, s32 = p->ns == 32 && p->nc == 8;      // (12/4: any horizon since round 4)
+    // (12/4: any horizon since round 4; every shape UP TO 12/4 since round 6: the padded instantiation, lqr_dpp16.hip -DMPC_DPP16_PAD_KKT)
+    const bool s12 = p->ns >= 1 && p->ns <= 12 && p->nc >= 1 && p->nc <= 4, s32 = p->ns == 32 && p->nc == 8;
     if (p->dtype != MPC_F32 || !(s12 || s32)) return 0;
     if (!o || !(o->flags & MPC_OPT_C_SYMMETRIC)) return 0;
     // (u_zero_I and delta_u of the FORWARD are not inputs of the backward: the reference's nested solve is built from the bounds
@@ -532,7 +533,7 @@ int mpc_lqr_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const 
     if (rc) return rc;
     if ((rc = check_options(p, o))) return rc;
     if (!mpc_lqr_kkt_fused_supported(p, o))
-        return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: needs fp32, n_state = 12, n_ctrl = 4 or n_state = 32, n_ctrl = 8, and "
+        return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: needs fp32, n_state <= 12, n_ctrl <= 4 or n_state = 32, n_ctrl = 8, and "
                                 "MPC_OPT_C_SYMMETRIC (otherwise: mpc_lqr_kkt_prepare + mpc_lqr_step + mpc_lqr_kkt_grads)");
     if (p->B == 0) return MPC_OK;
     if (!dl_dx || !dl_du || !dC || !dc || !dx_init) return fail(MPC_E_NULL, "kkt_fused: NULL argument");
@@ -556,8 +557,14 @@ int mpc_lqr_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const 
                                        10, (hipStream_t)stream);
     }
     if (!kkt_fused_dpp16_supported(sp, (const float *)dl_dx, (const float *)dl_du, (const float *)dC, (const float *)dF,
-                                   (const float *)workspace))
-        return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: blocks must be 16-byte aligned");
+                                   (const float *)workspace)) {
+        // every other shape up to 12/4, and 12/4 itself where a block is not 16-byte aligned: the padded instantiation (round 6)
+        if (!kkt_fused_dpp16_pad_supported(sp, (const float *)workspace))
+            return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: the workspace must be 16-byte aligned");
+        return launch_kkt_fused_dpp16_pad(sp, (const float *)dl_dx, (const float *)dl_du, (float *)dC, (float *)dc, (float *)dF,
+                                          (float *)df, (float *)dx_init, (float *)dx_out, (float *)du_out, (float *)workspace, 0.2f, 10,
+                                          (hipStream_t)stream);
+    }
     // the nested solve is a plain LQRStep(...) in the reference (:328-338): linesearch_decay 0.2, max_linesearch_iter 10
     return launch_kkt_fused_dpp16(sp, (const float *)dl_dx, (const float *)dl_du, (float *)dC, (float *)dc, (float *)dF,
                                   (float *)df, (float *)dx_init, (float *)dx_out, (float *)du_out, (float *)workspace, 0.2f, 10,

@@ -54,6 +54,11 @@ int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *d
 bool kkt_fused_dpp16_supported(const StepParams<float> &p, const float *dl_dx, const float *dl_du, const float *dC,
                                const float *dF, const float *ws);
 int64_t kkt_fused_dpp16_workspace_bytes(int T, int B);
+// ... and its PADDED instantiation: any n_state <= 12, n_ctrl <= 4, no alignment asked (lqr_dpp16.hip, -DMPC_DPP16_PAD_KKT; the same workspace)
+bool kkt_fused_dpp16_pad_supported(const StepParams<float> &p, const float *ws);
+int launch_kkt_fused_dpp16_pad(const StepParams<float> &p, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
+                               float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
+                               hipStream_t st);
 int launch_kkt_fused_dpp16(const StepParams<float> &p, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
                            float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
                            hipStream_t st);

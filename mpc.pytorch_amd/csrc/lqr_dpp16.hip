@@ -345,7 +345,13 @@ MPC_DEV double row_sum_f64(double x)
 #ifndef MPC_DPP16_NSTAGE
 #define MPC_DPP16_NSTAGE 4
 #endif
+// (MPC_KF_LDS_BYTES: the compilation that holds only the PADDED fused KKT kernel -- Makefile, lqr_dpp16_padkkt.o -- sweeps on two slots
+// like every padded sweep but gives its second pass the deep ring's 36 KiB)
+#ifdef MPC_KF_LDS_BYTES
+#define MPC_DPP16_LDS (MPC_KF_LDS_BYTES)
+#else
 #define MPC_DPP16_LDS (MPC_DPP16_NSTAGE * 9216)
+#endif
 // the KKT kernel shares this file's staging array: it lives in the compilation whose array fits its ring
 #ifndef MPC_KKT16_NSTAGE
 #define MPC_KKT16_NSTAGE 4
@@ -502,11 +508,13 @@ __global__ void __launch_bounds__(64, 1) lqr_step_dpp16_kernel(StepParams<float>
     dpp16::step_wave<MODE>(p);
 }
 
-#if MPC_DPP16_NSTAGE == 4
+#if MPC_DPP16_NSTAGE == 4 || defined(MPC_DPP16_PAD_KKT)
 // the whole of LQRStepFn.backward in one launch (lqr_dpp16_body.h: kkt_fused_wave); MASKED = controls on a bound are pinned
-static_assert(dpp16::KF_P2_SLOTS * dpp16::KF_P2_STAGE <= MPC_DPP16_LDS, "the fused KKT kernel's second ring does not fit");
+static_assert((int)dpp16::KfP2<false>::SLOTS * (int)dpp16::KfP2<false>::STAGE <= MPC_DPP16_LDS && (int)dpp16::KfP2<false>::SLOTS >= 5,
+              "the fused KKT kernel's second ring does not fit");
 static_assert((int)dpp16::KfP2<true>::SLOTS * (int)dpp16::KfP2<true>::STAGE <= MPC_DPP16_LDS && (int)dpp16::KfP2<true>::SLOTS >= 5,
               "the long-horizon fused KKT kernel's second ring does not fit");
+static_assert((int)dpp16::LDS_TOTAL <= MPC_DPP16_LDS, "the fused KKT kernel's sweep ring does not fit");
 template <bool MASKED>
 __global__ void __launch_bounds__(64, 1) lqr_kkt_fused_dpp16_kernel(StepParams<float> p, dpp16::KktFusedArgs k)
 {
@@ -559,7 +567,16 @@ int launch_kkt_dpp16(const StepParams<float> &p, const float *dx, const float *d
 
 #endif
 
-#if MPC_DPP16_NSTAGE == 4
+#ifdef MPC_DPP16_PAD_KKT
+// the PADDED instantiation of the fused KKT backward (round 6): any n_state <= 12, n_ctrl <= 4, no alignment asked of the caller's blocks
+// (dword gathers and dword stores); the workspace -- the library's own layout, padded to 12/4 -- on 16 bytes
+bool kkt_fused_dpp16_pad_supported(const StepParams<float> &p, const float *ws)
+{
+    return p.ns >= 1 && p.ns <= 12 && p.nc >= 1 && p.nc <= 4 && p.T >= 1 && (uintptr_t)ws % 16 == 0;
+}
+#define MPC_KF_LAUNCH launch_kkt_fused_dpp16_pad
+#elif MPC_DPP16_NSTAGE == 4
+#define MPC_KF_LAUNCH launch_kkt_fused_dpp16
 // (built in the compilation with the deep staging array: four sweep stages, six rollout stages, see kkt_fused_wave)
 bool kkt_fused_dpp16_supported(const StepParams<float> &p, const float *dl_dx, const float *dl_du, const float *dC,
                                const float *dF, const float *ws)
@@ -580,14 +597,17 @@ int64_t kkt_fused_dpp16_workspace_bytes(int T, int B)
 {
     return (int64_t)T * B * (dpp16::KF_VBLK + 24 + (T > dpp16::RG_STEPS ? 64 : 0)) * 4 + 64;
 }
+#endif
 
-int launch_kkt_fused_dpp16(const StepParams<float> &p_in, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
-                           float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
-                           hipStream_t st)
+#if MPC_DPP16_NSTAGE == 4 || defined(MPC_DPP16_PAD_KKT)
+int MPC_KF_LAUNCH(const StepParams<float> &p_in, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
+                  float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
+                  hipStream_t st)
 {
     StepParams<float> p = p_in;
     p.zero_mask = nullptr;          // the forward's u_zero_I / delta_u are no inputs of the backward (mpc/lqr_step.py:322-340)
     p.has_delta = 0;
+    if (dpp16::PADK) p.c_symmetric = 1;          // (the fused backward is only taken under that promise: the plain row layout of C)
     dpp16::KktFusedArgs k;
     k.dl_dx = dl_dx; k.dl_du = dl_du; k.dC = dC; k.dc = dc; k.dF = dF; k.df = df; k.dx_init = dx_init;
     k.dx_out = dx_out; k.du_out = du_out; k.vws = ws; k.decay = decay; k.max_ls = max_ls;
@@ -632,6 +652,7 @@ bool dpp16_supported(const StepParams<float> &p)
 // (B = 6144: 248 against 347 us; 8192: 304 against 371) -- profiles/r02_experiments.md 15.
 // ... and a third time with -DMPC_DPP16_PAD (on the 2-slot ring) as launch_step_dpp16_pad: the PADDED instantiation for any n_state <=
 // 12, n_ctrl <= 4 (lqr_dpp16_body.h, PADK): dword gathers with the zero padding done by the DMA, no alignment asked of anybody.
+#ifndef MPC_DPP16_PAD_KKT
 #ifdef MPC_DPP16_PAD
 #define MPC_DPP16_LAUNCH launch_step_dpp16_pad
 bool dpp16_pad_supported(const StepParams<float> &p)
@@ -668,5 +689,6 @@ int MPC_DPP16_LAUNCH(const StepParams<float> &p, hipStream_t st)
     }
     return MPC_OK;
 }
+#endif
 
 }  // namespace mpclqr

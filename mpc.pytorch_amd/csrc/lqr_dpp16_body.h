@@ -380,11 +380,11 @@ template <int MODE, bool ROLL, bool DIRECT> MPC_DEV unsigned stage_mid(int slot)
 
 // every pass of the padded instantiation starts on cleared staging memory: the record words of padded entries are never written by
 // the gathers (their lanes sit the instruction out), and the passes lay their slots out differently
-MPC_DEV void pad_clear(int lane)
+MPC_DEV void pad_clear(int lane, unsigned bytes = (unsigned)LDS_TOTAL)
 {
     if (!PADK) return;
     wv::lds_sync();
-    for (unsigned off = 16u * (unsigned)lane; off + 16 <= (unsigned)LDS_TOTAL; off += 1024) wv::lds_store_f32x4(off, f32x4{0.f, 0.f, 0.f, 0.f});
+    for (unsigned off = 16u * (unsigned)lane; off + 16 <= bytes; off += 1024) wv::lds_store_f32x4(off, f32x4{0.f, 0.f, 0.f, 0.f});
     wv::lds_sync();
 }
 
@@ -2130,9 +2130,17 @@ enum { KF_VBLK = 96 };
 // LONG (round 4): T > RG_STEPS -- the gains of the whole horizon do not fit the 256 accumulation registers; pass 1 stores the
 // record [T,B,64] behind (lambda | g) in the workspace like mode 3 of the step kernel, pass 2's stage carries it as a seventh
 // DMA instruction (+ 1 KiB: five slots in the same staging memory instead of six).  T <= 64 is the kernel of round 3, untouched.
+// The padded instantiation (round 6): F by 12 dword gathers, tau* by one dword instruction into a block of its own behind the stage
+// (TOFF: lane l = word l), lambda | g and (V | v) out of the workspace as before -- 16 (17) instructions a stage, and vmcnt's six
+// bits then cap the ring at five slots.  The kernel is built in a compilation of its own (csrc/Makefile, lqr_dpp16_padkkt.o) whose
+// staging array has the deep ring's 36 KiB (MPC_KF_LDS_BYTES) although its sweep runs on two slots like every padded sweep.
+#ifndef MPC_KF_LDS_BYTES
+#define MPC_KF_LDS_BYTES ((int)LDS_TOTAL)
+#endif
 template <bool LONG> struct KfP2 {
-    enum { STAGE = LONG ? 6656 : 5632, SLOTS = (int)LDS_TOTAL / STAGE >= 6 ? 6 : ((int)LDS_TOTAL / STAGE >= 5 ? 5 : 3), AHEAD = SLOTS - 1,
-           DMA = LONG ? 7 : 6, GOFF = 5632 };
+    enum { TOFF = LONG ? 6656 : 5632, STAGE = TOFF + (MPC_DPP16_PADK ? 256 : 0), DMA = MPC_DPP16_PADK ? (LONG ? 17 : 16) : (LONG ? 7 : 6),
+           FIT = (int)(MPC_KF_LDS_BYTES) / STAGE, CAP = 63 / DMA + 2,          // (AHEAD - 1) * DMA < 64
+           SLOTS0 = FIT >= 6 ? 6 : (FIT >= 5 ? 5 : 3), SLOTS = SLOTS0 < CAP ? SLOTS0 : CAP, AHEAD = SLOTS - 1, GOFF = 5632 };
 };
 enum { KF_P2_STAGE = KfP2<false>::STAGE, KF_P2_SLOTS = KfP2<false>::SLOTS };
 // row offset of row i in the packed upper triangle of a symmetric 12 x 12: entries (i, j >= i) at tri_off(i) + j - i
@@ -2164,12 +2172,57 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
     const long pb = L.pb;
     const bool xs_lane = L.j < 12;
     const int jx = xs_lane ? L.j : 11;
+    // the caller's arrays by their true shape (the padded instantiation; 12 / 4 / 16 in the exact kernel)
+    const int ns_o = PADK ? p.ns : 12, nc_o = PADK ? p.nc : 4, n_o = ns_o + nc_o;
+    if (PADK) {
+        L.ovalid = L.isu ? L.a < nc_o : L.j < ns_o;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) L.padd[a] = (L.j == 12 + a && a >= nc_o) ? 1.f : 0.f;
+    }
 
     // ---- pass 1: Riccati sweep of the nested problem + lambda + g ------------------------------------------------
     // The step kernel's own sweep staging (Dma / stage_issue / Feed: running pointers, one M0 per stage, the DMA handed
     // to the arithmetic in four parts, C with the read-once policy); only the record's sources differ:
     // granules 0-2 dl_dx, 3 dl_du, 4-6 x*, 7 u*, 8-10 c_x, 12 lo, 13 hi (tensor bounds), the rest aliased to x*
     Dma d;
+#ifdef MPC_DPP16_PAD
+    {
+        // the sweep's own gathers of C and F (dma_seek; the launcher sets c_symmetric: the plain row layout), and the record's words
+        // from THIS pass's sources: lane l = word l of a problem's 64: granule l >> 2, entry l & 3
+        dma_seek<0, false, false>(d, p, L, wave);
+        const long t0 = T - 1;
+        const int g4 = lane >> 2, e = lane & 3;
+        const bool tb = MASKED && p.bound_mode == MPC_BOUND_TENSOR;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const long pbk = 4 * wave + kk < p.B ? 4 * wave + kk : p.B - 1;
+            const char *q = (const char *)p.cur_x;
+            long st = 0;
+            bool act = false;
+            if (g4 < 3) {
+                const int i = 4 * g4 + e;
+                if (i < ns_o) { q = (const char *)(k.dl_dx + pbk * ns_o + i); st = 4 * B * ns_o; act = true; }
+            } else if (g4 == 3) {
+                if (e < nc_o) { q = (const char *)(k.dl_du + pbk * nc_o + e); st = 4 * B * nc_o; act = true; }
+            } else if (g4 < 7) {
+                const int i = 4 * (g4 - 4) + e;
+                if (i < ns_o) { q = (const char *)(p.cur_x + pbk * ns_o + i); st = 4 * B * ns_o; act = true; }
+            } else if (g4 == 7) {
+                if (e < nc_o) { q = (const char *)(p.cur_u + pbk * nc_o + e); st = 4 * B * nc_o; act = true; }
+            } else if (g4 < 11) {
+                const int i = 4 * (g4 - 8) + e;
+                if (i < ns_o) { q = (const char *)(p.c + pbk * p.c_sb + i); st = 4 * p.c_st; act = true; }
+            } else if (tb && (g4 == 12 || g4 == 13)) {
+                if (e < nc_o) { q = (const char *)((g4 == 12 ? p.lo : p.hi) + pbk * nc_o + e); st = 4 * B * nc_o; act = true; }
+            }
+            d.rq[kk] = q + t0 * st - (3072 + 256 * kk);
+            d.rq_step[kk] = st;
+            d.rq_act[kk] = act;
+            d.rq_isf[kk] = false;
+        }
+    }
+    pad_clear(lane, MPC_KF_LDS_BYTES);
+#else
     {
         const long t0 = T - 1, tf0 = T < 2 ? 0 : T - 2;
         d.c_step = 4 * p.C_st;
@@ -2203,6 +2256,7 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
         d.r_step_nof = st;
         d.g_ptr = d.g2_ptr = d.r_ptr;
     }
+#endif
 
     float Vc[12], vv = 0.f, lam = 0.f, gv = 0.f;
 #pragma unroll
@@ -2291,6 +2345,11 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
                 } else {
                     feed.template part<1>();
                     feed.template part<2>();
+                }
+                if (PADK) {
+                    // a control beyond n_ctrl: H = 1, q = 0, no reach -- its dtau stays at zero
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) Q[12 + a] += L.padd[a];
                 }
                 Sym4 S;
                 S.s00 = wv::bcast<12>(Q[12]); S.s01 = wv::bcast<13>(Q[12]); S.s02 = wv::bcast<14>(Q[12]); S.s03 = wv::bcast<15>(Q[12]);
@@ -2393,7 +2452,7 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
         }
     }
     // dx_init = -dlambda_0 = -(V_0 0 + v_0 + (1 - alpha) g_0)   (:404)
-    if (L.live && xs_lane) k.dx_init[pb * 12 + L.j] = -fmaf(1.f - alpha, gv, vv);
+    if (L.live && xs_lane && (!PADK || L.ovalid)) k.dx_init[pb * ns_o + L.j] = -fmaf(1.f - alpha, gv, vv);
     wv::fence_own_stores();            // (V, v, lambda, g) come back through the DMA
 #ifdef MPC_KF_SKIP
     if (MPC_KF_SKIP & 4) return;
@@ -2404,6 +2463,15 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
     const char *f2_ptr[3], *r2_ptr, *v2_ptr[2];
     long r2_step;
     bool r2_active, v2_active;
+#ifdef MPC_DPP16_PAD
+    // F in the rollout's row-read order by the rollout's own gathers (dma_seek: Fb / foff of a ROLL pass, standing on t = 0); tau*
+    // by one dword instruction: lane l = entry l & 15 of problem slot l >> 4
+    Dma d2;
+    dma_seek<0, true, false>(d2, p, L, wave);
+    const char *const t2_ptr = L.isu ? (const char *)(p.cur_u + pb * nc_o + (L.ovalid ? L.a : 0)) : (const char *)(p.cur_x + pb * ns_o + (L.ovalid ? L.j : 0));
+    const long t2_step = L.isu ? 4 * B * nc_o : 4 * B * ns_o;
+    pad_clear(lane, MPC_KF_LDS_BYTES);
+#endif
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int Gq = 64 * q + lane;
@@ -2412,7 +2480,7 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
         f2_ptr[q] = T > 1 ? (const char *)(p.F + (long)pbk * p.F_sb) + 16 * src_granule_rows(g2) : (const char *)p.C;
     }
     {
-        r2_active = gi >= 4 && gi < 14;
+        r2_active = gi >= (PADK ? 8 : 4) && gi < 14;
         const char *q = (const char *)p.cur_x;
         long st = 0;
         if (gi >= 4 && gi < 7) { q = (const char *)(p.cur_x + pb * 12 + 4 * (gi - 4)); st = 4 * B * 12; }
@@ -2437,8 +2505,19 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
         const unsigned sb = (unsigned)slot * KF_P2_STAGE;
         const long tf = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
         const long t1 = t < T - 1 ? t + 1 : t;
+#ifdef MPC_DPP16_PAD
+        {
+            const long fo = tf * f_step;
+#define MPC_PAD_F2(kk) wv::dma_buf_at<256 * (kk), PAD_BIAS>(d2.Fb[(kk) / 3] + fo, d2.fbytes, d2.foff[kk], sb)
+            MPC_PAD_F2(0); MPC_PAD_F2(1); MPC_PAD_F2(2); MPC_PAD_F2(3); MPC_PAD_F2(4); MPC_PAD_F2(5);
+            MPC_PAD_F2(6); MPC_PAD_F2(7); MPC_PAD_F2(8); MPC_PAD_F2(9); MPC_PAD_F2(10); MPC_PAD_F2(11);
+#undef MPC_PAD_F2
+            wv::dma4_if(L.ovalid, t2_ptr + (long)t * t2_step, sb + (unsigned)KfP2<LONG>::TOFF);
+        }
+#else
 #pragma unroll
         for (int q = 0; q < 3; ++q) wv::dma16_once(f2_ptr[q] + tf * f_step, sb + 1024 * q);
+#endif
         wv::dma16_if(r2_active, r2_ptr + (gi >= 8 ? t1 : (long)t) * r2_step, sb + 3072);
         wv::dma16_once(v2_ptr[0] + t1 * v2_step, sb + 4096);
         wv::dma16_if(v2_active, v2_ptr[1] + t1 * v2_step, sb + 4096 + 1024);
@@ -2455,7 +2534,8 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
             const f32x4 v = wv::lds_f32x4((unsigned)(sb - SF + L.aFq[q]));
             s.Fr[4 * q] = v[0]; s.Fr[4 * q + 1] = v[1]; s.Fr[4 * q + 2] = v[2]; s.Fr[4 * q + 3] = v[3];
         }
-        s.tj = wv::lds_f32((unsigned)(sb + 3072 - SR + L.aRec + 64));                    // tau*_t[j]
+        s.tj = PADK ? wv::lds_f32((unsigned)(sb + (int)KfP2<LONG>::TOFF + 4 * lane))             // tau*_t[j] (its own block, see KfP2)
+                    : wv::lds_f32((unsigned)(sb + 3072 - SR + L.aRec + 64));
         s.l1 = wv::lds_f32((unsigned)(sb + 3072 + L.p * 256 + 128 + 4 * jx));            // lambda_{t+1}[j]
         s.g1 = wv::lds_f32((unsigned)(sb + 3072 + L.p * 256 + 176 + 4 * jx));            // g_{t+1}[j]
 #pragma unroll
@@ -2471,7 +2551,18 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
     float *dc_p = k.dc + pb * 16 + L.j;
     float *df_p = k.df ? k.df + pb * 12 + L.j : nullptr;
     float *so_p = (k.dx_out && k.du_out) ? (L.isu ? k.du_out + pb * 4 + L.a : k.dx_out + pb * 12 + L.j) : nullptr;
-    const long so_step = L.isu ? B * 4 : B * 12;
+    long so_step = L.isu ? B * 4 : B * 12;
+    // the padded instantiation: the caller's blocks are [n, n] / [n_state, n] with n = n_state + n_ctrl -- this lane's COLUMN of them,
+    // a dword per row (a row of the padding is skipped: wave-uniform), rows of n floats instead of 16
+    const int aj = PADK ? (L.isu ? ns_o + L.a : L.j) : L.j;          // this lane's entry of the caller's tau (when ovalid)
+    if (PADK) {
+        dC_p = k.dC + pb * (n_o * n_o) + (L.ovalid ? aj : 0);
+        dF_p = k.dF + pb * (ns_o * n_o) + (L.ovalid ? aj : 0);
+        dc_p = k.dc + pb * n_o + (L.ovalid ? aj : 0);
+        df_p = k.df ? k.df + pb * ns_o + (L.ovalid ? L.j : 0) : nullptr;
+        so_p = (k.dx_out && k.du_out) ? (L.isu ? k.du_out + pb * nc_o + (L.ovalid ? L.a : 0) : k.dx_out + pb * ns_o + (L.ovalid ? L.j : 0)) : nullptr;
+        so_step = L.isu ? B * nc_o : B * ns_o;
+    }
 #pragma unroll
     for (int i = 0; i < KF_P2_AHEAD; ++i) issue2(i, i);
     KfStage2 s2;
@@ -2508,6 +2599,28 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
                 // the next stage has had this timestep to land: read it, THEN send this timestep's gradients off
                 wv::dma_wait<(KF_P2_AHEAD - 1) * KF_P2_DMA>();
                 read2(s2, (i + 1) % KF_P2_SLOTS);
+#ifdef MPC_DPP16_PAD
+                if (L.live && L.ovalid) {
+                    if (so_p) wv::store_f32_grad(so_p, dj);
+                    if (have) {
+#pragma unroll
+                        for (int r = 0; r < 12; ++r)
+                            if (r < ns_o) wv::store_f32_grad(dF_p + r * n_o, colF[r]);
+                        if (df_p && xs_lane) wv::store_f32_grad(df_p, -dl1);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ar = pad_tau(r, ns_o, nc_o);
+                        if (ar >= 0) wv::store_f32_grad(dC_p + ar * n_o, colC[r]);
+                    }
+                    wv::store_f32_grad(dc_p, -dj);
+                }
+                if (so_p) so_p += so_step;
+                dC_p += B * (n_o * n_o);
+                dF_p += B * (ns_o * n_o);
+                dc_p += B * n_o;
+                if (df_p) df_p += B * ns_o;
+#else
                 // (the exchange with the neighbouring lane happens for every lane: rows of a ragged last wave only skip the stores)
                 float pF0[6], pF1[6], pC0[8], pC1[8];
 #pragma unroll
@@ -2542,6 +2655,7 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
                 dF_p += B * 192;
                 dc_p += B * 16;
                 if (df_p) df_p += B * 12;
+#endif
             }
         }
     }

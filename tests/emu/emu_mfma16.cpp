@@ -701,7 +701,14 @@ extern "C" int emu_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o,
     memset(&out, 0, sizeof(out));
     out.status = status;
     mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, &out);
+#ifdef MPC_DPP16_PAD
+    if (!(sp.ns >= 1 && sp.ns <= 12 && sp.nc >= 1 && sp.nc <= 4)) return MPC_E_DIMS;      // the padded instantiation (launch_kkt_fused_dpp16_pad)
+    sp.c_symmetric = 1;
+    sp.zero_mask = nullptr;
+    sp.has_delta = 0;
+#else
     if (!(sp.ns == 12 && sp.nc == 4)) return MPC_E_DIMS;
+#endif
     const size_t need = (size_t)sp.T * sp.B * (mpclqr::dpp16::KF_VBLK + 24 + (sp.T > mpclqr::dpp16::RG_STEPS ? 64 : 0)) + 4;
     float *ws = (float *)aligned_alloc(16, (need * sizeof(float) + 15) / 16 * 16);
     for (size_t i = 0; i < need; ++i) ws[i] = NAN;

@@ -44,7 +44,7 @@ def build(ring2=False, pad=0):
                 tmp = so + ".tmp%d" % os.getpid()
                 subprocess.check_call([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
                                       + (["-DMPC_DPP16_NSTAGE=2", "-DMPC_KKT16_NSTAGE=2", "-DMPC_MFMA40_SWEEP_NSTAGE=2"] if (ring2 or pad) else [])
-                                      + (["-DMPC_MFMA40_PAD=%d" % pad, "-DMPC_DPP16_PAD"] if pad else []) + ["-o", tmp, src])
+                                      + (["-DMPC_MFMA40_PAD=%d" % pad, "-DMPC_DPP16_PAD", "-DMPC_KF_LDS_BYTES=36864"] if pad else []) + ["-o", tmp, src])
                 os.replace(tmp, so)
     return so
 
@@ -226,15 +226,16 @@ def kkt_grads(C, c, F, f, x_star, u_star, dx, du, dl_dx, dma_late=False, ring2=F
 
 
 def kkt_fused(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_upper=None, dma_late=False, ring2=True,
-              linesearch_decay=0.2, max_linesearch_iter=10):
+              linesearch_decay=0.2, max_linesearch_iter=10, kernel="dpp16"):
     """ALL of LQRStepFn.backward (mpc/lqr_step.py:312-407) through the emulated fused kernel (kkt_fused_wave,
-    lqr_dpp16_body.h): n_state = 12, n_ctrl = 4, float32, T <= 64.  Returns dC, dc, dF, df, dx_init and the KKT
-    solve's own (dx, du)."""
+    lqr_dpp16_body.h): n_state = 12, n_ctrl = 4, float32.  Returns dC, dc, dF, df, dx_init and the KKT
+    solve's own (dx, du).  kernel="dpp16_pad": the padded instantiation, any n_state <= 12, n_ctrl <= 4 (the library's
+    lqr_dpp16_padkkt.o: two sweep slots, the second pass on 36 KiB)."""
     f32 = np.float32
     cast = lambda a: np.ascontiguousarray(a, f32)
     C, c, F, x_star, u_star, dl_dx, dl_du = map(cast, (C, c, F, x_star, u_star, dl_dx, dl_du))
     T, B, n, _ = C.shape
-    ns, nc = 12, 4
+    ns, nc = (x_star.shape[2], n - x_star.shape[2]) if kernel == "dpp16_pad" else (12, 4)
     p = N.Problem()
     p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, N.MPC_F32
     x0 = np.zeros((B, ns), f32)
@@ -261,7 +262,7 @@ def kkt_fused(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_upper=No
                dF=np.full((max(T - 1, 0), B, ns, n), np.nan, f32), df=np.full((max(T - 1, 0), B, ns), np.nan, f32) if has_f else None,
                dx_init=np.full((B, ns), np.nan, f32), dx=np.full((T, B, ns), np.nan, f32), du=np.full((T, B, nc), np.nan, f32),
                status=np.zeros(B, np.int32))
-    L = lib_ring2() if ring2 else lib()
+    L = lib_pad(4) if kernel == "dpp16_pad" else (lib_ring2() if ring2 else lib())
     L.emu_set_dma_late(int(bool(dma_late)))
     vp = ctypes.c_void_p
     L.emu_kkt_fused.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options)] + [vp] * 10

@@ -339,6 +339,64 @@ def test_emulated_fused_kkt_backward_matches_oracle(emu, case, dma_late, ring2):
         np.testing.assert_allclose(r[k], o[k], rtol=1e-4 * wide, atol=1e-4 * wide * max(1.0, np.abs(o[k]).max()), err_msg=k)
 
 
+def _shape_problem(rng, T, B, ns, nc, with_f=True):
+    n = ns + nc
+    A = rng.standard_normal((T, B, n, n))
+    C = np.einsum("tbji,tbjk->tbik", A, A) + 0.5 * np.eye(n)
+    c = rng.standard_normal((T, B, n))
+    F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((T - 1, B, ns, ns)) / np.sqrt(ns),
+                        rng.standard_normal((T - 1, B, ns, nc)) / np.sqrt(ns)), 3)
+    f = 0.1 * rng.standard_normal((T - 1, B, ns)) if with_f else None
+    return dict(C=C, c=c, F=F, f=f, x_init=rng.standard_normal((B, ns)))
+
+
+@pytest.mark.parametrize("case", ["10_3", "10_3_bounded", "8_4_tensor", "12_2_nof", "1_1_bounded", "5_1", "3_4_T1", "11_3_T2", "7_2_B9_bounded", "12_4_T64",
+                                  "9_3_T66_bounded", "10_3_nonconvex", "4_2_T3"])
+def test_emulated_padded_fused_kkt_backward_matches_oracle(emu, case):
+    """The PADDED instantiation of kkt_fused_wave (round 6, -DMPC_DPP16_PAD; the library's lqr_dpp16_padkkt.o): ALL of
+    LQRStepFn.backward (mpc/lqr_step.py:312-407) in one launch for any n_state <= 12, n_ctrl <= 4 -- C and F by dword gathers
+    that pad tau to [x(12); u(4)], the record's words each from its own array, every gradient stored by the caller's true
+    shape -- against the oracle's three-stage backward: scalar and tensor bounds, no f, one control, one state, T = 1, 2, 3
+    (around the ring depths), a ragged batch, the longest horizon on register-resident gains and the LONG instantiation beyond
+    it, and a non-convex cost whose nested step backtracks.  Outputs are pre-filled with NaN: an entry the kernel skips fails."""
+    from oracle import lqr_oracle as O
+    parts = case.split("_")
+    ns, nc = int(parts[0]), int(parts[1])
+    rng = np.random.default_rng(sum(map(ord, case)))
+    T = next((int(q[1:]) for q in parts[2:] if q[0] == "T"), 6)
+    B = next((int(q[1:]) for q in parts[2:] if q[0] == "B"), 3 if T >= 64 else 5)
+    bounded = "bounded" in parts or "tensor" in parts
+    pr = _shape_problem(rng, max(T, 2), B, ns, nc, with_f="nof" not in parts)
+    if "nonconvex" in parts:
+        pr["C"][:, (1, 3), ns:, ns:] -= 250.0 * np.eye(nc)
+    if T == 1:
+        pr = {k: (v[:1] if k in ("C", "c") else (v[:0] if k in ("F", "f") and v is not None else v)) for k, v in pr.items()}
+    cur_u = np.clip(0.5 * rng.standard_normal((T, B, nc)), -0.4, 0.4)
+    cur_x, _ = O.traj_cost(pr["x_init"], cur_u, pr["F"], pr["f"])
+    lo, hi = (-0.4, 0.4) if bounded else (None, None)
+    if "tensor" in parts:
+        lo, hi = -0.3 - 0.2 * rng.random((T, B, nc)), 0.3 + 0.2 * rng.random((T, B, nc))
+        lo, hi = lo.astype(np.float32).astype(np.float64), hi.astype(np.float32).astype(np.float64)
+    x, u = cur_x, cur_u
+    for _ in range(4):
+        sol = O.lqr_step(lockstep=False, cur_x=x, cur_u=u, u_lower=lo, u_upper=hi, **pr)
+        x, u = sol["new_x"], sol["new_u"]
+    x, u = x.astype(np.float32).astype(np.float64), u.astype(np.float32).astype(np.float64)
+    dl_dx, dl_du = rng.standard_normal((T, B, ns)), rng.standard_normal((T, B, nc))
+    o = O.kkt_backward(pr["C"], pr["c"], pr["F"], pr["f"], x, u, dl_dx, dl_du, lo, hi, lockstep=False)
+    if bounded and T > 2:
+        act = np.abs(np.abs(u) - 0.4) <= 1e-8 if "tensor" not in parts else (np.abs(u - lo) <= 1e-8) | (np.abs(u - hi) <= 1e-8)
+        assert 0.01 < act.mean() < 0.97, act.mean()
+    for dma_late in (False, True):
+        r = emu.kkt_fused(pr["C"], pr["c"], pr["F"], pr["f"], x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, kernel="dpp16_pad")
+        wide = 10.0 if "nonconvex" in parts else 1.0
+        for k in ("dx", "du", "dC", "dc", "dF", "dx_init") + (("df",) if pr["f"] is not None and T > 1 else ()):
+            if o[k] is None or o[k].size == 0:
+                continue
+            assert np.isfinite(r[k]).all(), (k, dma_late)
+            np.testing.assert_allclose(r[k], o[k], rtol=1e-4 * wide, atol=1e-4 * wide * max(1.0, np.abs(o[k]).max()), err_msg="%s %s" % (k, dma_late))
+
+
 @pytest.mark.parametrize("bounded", [False, True])
 def test_emulated_dpp16_nominal_off_the_dynamics(emu, bounded):
     """current_x that is NOT the rollout of current_u (LQRStep allows it): the cost identity the

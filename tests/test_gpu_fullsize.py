@@ -750,3 +750,62 @@ def test_kkt_backward_on_padded_dpp16_shapes_vs_oracle(be, ns, nc, B, bounded):
         scale = np.maximum(1.0, np.abs(o[k]).max(axis=ax, keepdims=True))
         rel = (np.abs(a - o[k]) / scale).max(axis=ax)
         assert rel.max() < 2e-4, "%s: problem %d off by %.2e of its scale" % (k, int(rel.argmax()), rel.max())
+
+
+@pytest.mark.parametrize("mode", ["unbounded", "scalar", "tensor"])
+@pytest.mark.parametrize("ns,nc,B,T", [(10, 3, 1030, 30), (8, 4, 515, 30), (12, 2, 777, 30), (1, 1, 260, 12), (5, 4, 300, 70), (12, 4, 514, 30)])
+def test_fused_kkt_backward_on_padded_dpp16_shapes_vs_oracle(be, ns, nc, B, T, mode):
+    """The fused KKT backward's PADDED instantiation (round 6, lqr_dpp16_padkkt.o): LQRStepFn.backward (mpc/lqr_step.py:312-407) in ONE
+    launch at any n_state <= 12, n_ctrl <= 4 under MPC_OPT_C_SYMMETRIC -- what `mpc.MPC` promises from its second iteration on -- in
+    float32 against the float64 oracle fed the very same (x*, u*, dl_dx, dl_du): scalar and tensor bounds, ragged last waves, a horizon
+    beyond the register-resident gains (T = 70: the LONG instantiation), and 12/4 itself with blocks OFF the 16-byte grid (which the exact
+    kernel refuses).  The gradient buffers are pre-filled with NaN: an entry the kernel skips fails."""
+    import ctypes
+    import bench
+    from mpc import _native
+    from mpc._native import StepOptions
+    from oracle import lqr_oracle as O
+    B = full_batch(B)
+    bounded = mode != "unbounded"
+    p = bench.make_problem(ns, nc, T, B, torch.float32, DEV, seed=4 + ns, u_scale=0.3 if bounded else 0.0, clamp=1.0 if bounded else None)
+    if (ns, nc) == (12, 4):
+        for k in ("C", "F", "c"):          # the same numbers, one float off the 16-byte grid
+            buf = torch.empty(p[k].numel() + 1, device=DEV, dtype=torch.float32)
+            buf[1:].copy_(p[k].reshape(-1))
+            p[k] = buf[1:].view(p[k].shape)
+            assert p[k].data_ptr() % 16 == 4
+    lo = hi = None
+    if mode == "scalar":
+        opts = StepOptions(u_lower=-1.0, u_upper=1.0, c_symmetric=True)
+    elif mode == "tensor":
+        g0 = torch.Generator(device=DEV).manual_seed(9)
+        lo = -0.8 - 0.4 * torch.rand(T, B, nc, generator=g0, device=DEV)
+        hi = 0.8 + 0.4 * torch.rand(T, B, nc, generator=g0, device=DEV)
+        opts = StepOptions(u_lower=lo, u_upper=hi, c_symmetric=True)
+    else:
+        opts = StepOptions(c_symmetric=True)
+    r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    gx = torch.randn(tuple(r["new_x"].shape), generator=g, device=DEV)
+    gu = torch.randn(tuple(r["new_u"].shape), generator=g, device=DEV)
+    plan = be.plan_kkt_backward(p["C"], p["c"], p["F"], p["f"], r["new_x"], r["new_u"], gx, gu, opts)
+    assert plan is not None, "the fused backward must cover every shape up to 12/4"
+    for k in ("dx_init", "dC", "dc", "dF", "df", "dx", "du"):
+        plan.outputs[k].fill_(float("nan"))
+    got = plan()
+    assert got is not None
+    sync()
+    if bounded:
+        act = ((r["new_u"] - (lo if lo is not None else -1.0)).abs() <= 1e-8) | ((r["new_u"] - (hi if hi is not None else 1.0)).abs() <= 1e-8)
+        assert 0.005 < act.float().mean().item() < 0.95
+    o = O.kkt_backward(h64(p["C"]), h64(p["c"]), h64(p["F"]), h64(p["f"]), h64(r["new_x"]), h64(r["new_u"]), h64(gx), h64(gu),
+                       (h64(lo) if lo is not None else -1.0) if bounded else None, (h64(hi) if hi is not None else 1.0) if bounded else None,
+                       lockstep=False, nthreads=O.max_threads())
+    for k in ("dx_init", "dC", "dc", "dF", "df", "dx", "du"):
+        a = host(got[k]).astype(np.float64)
+        assert np.isfinite(a).all(), k
+        ax = tuple(i for i in range(a.ndim) if i != (0 if k == "dx_init" else 1))
+        scale = np.maximum(1.0, np.abs(o[k]).max(axis=ax, keepdims=True))
+        rel = (np.abs(a - o[k]) / scale).max(axis=ax)
+        assert rel.max() < 2e-4, "%s: problem %d off by %.2e of its scale" % (k, int(rel.argmax()), rel.max())
+

@@ -66,6 +66,9 @@ SGPR_SPILL_LIMITS = {
     # (... and, with the gathers on shared LDS anchors + immediates, eight buffer descriptors that stay live across a stage: the spill
     # count went up by ~80 and the kernels got 2-10 % faster, profiles/r06_pad12_bench.log)
     "lqr_dpp16_pad": {"kernelILi0E": 430, "kernelILi1E": 715, "kernelILi2E": 945, "kernelILi3E": 655},
+    # ... and of its fused KKT backward (the fourth compilation of lqr_dpp16.hip): the sweep's gather maps and block bases in pass 1, the
+    # rollout's twelve F gathers in pass 2
+    "lqr_dpp16_padkkt": {"kkt_fused": 130},
     "lqr_mfma40": {"kernelILi0E": 90, "kernelILi1E": 105, "kernelILi2E": 150},
     # (round 4: block addresses as scalar arithmetic -- two more base pointers live in the two-slot build of mode 0)
     "lqr_mfma40_ring2": {"kernelILi0E": 100, "kernelILi1E": 105, "kernelILi2E": 150},
@@ -106,7 +109,7 @@ def test_no_vector_spills_no_scratch_and_bounded_scalar_spills(tu):
     assert seen == set(SGPR_SPILL_LIMITS[tu]), (seen, list(md))
 
 
-@pytest.mark.parametrize("tu,kernels", [("lqr_dpp16", 8), ("lqr_dpp16_ring2", 5), ("lqr_dpp16_pad", 4)])
+@pytest.mark.parametrize("tu,kernels", [("lqr_dpp16", 8), ("lqr_dpp16_ring2", 5), ("lqr_dpp16_pad", 4), ("lqr_dpp16_padkkt", 4)])
 def test_dpp16_kernels_keep_their_arrays_in_registers_and_their_dma_queue_full(tu, kernels):
     """Both compilations of lqr_dpp16.hip (csrc/Makefile): the 4-slot ring (step kernel modes 0..3 + the fused KKT
     backward kernels: register-resident gains up to T = 64 and the long-horizon one, each plain and masked) and the 2-slot one (the same four + the three-launch KKT gradient kernel)."""
@@ -128,7 +131,7 @@ def test_mfma40_kernels_keep_their_arrays_in_registers_and_their_dma_queue_full(
         assert v == {"scratch": 0, "drains": 0}, (k, v)
 
 
-@pytest.mark.parametrize("tu", ["lqr_dpp16", "lqr_dpp16_ring2", "lqr_dpp16_pad"])
+@pytest.mark.parametrize("tu", ["lqr_dpp16", "lqr_dpp16_ring2", "lqr_dpp16_pad", "lqr_dpp16_padkkt"])
 def test_register_resident_gains_own_the_accumulation_registers(tu):
     """Mode 0 of the headline kernel parks the gains of the whole horizon in a[0..255] through inline assembly
     (wv::rg_put / rg_get, lqr_dpp16.hip).  That is only sound while the compiler itself never allocates an AccVGPR in
@@ -138,7 +141,8 @@ def test_register_resident_gains_own_the_accumulation_registers(tu):
     import isa_lint
     lines = isa_lint.assembly(tu)          # (the unconstrained step runs on the 2-slot compilation)
     kernels, _ = isa_lint.structure(lines)
-    start = [i for i, n in kernels if "kernelILi0E" in n][0]
+    # (the padded fused KKT backward's compilation holds no step kernel: its own register-resident kernel, the unmasked T <= 64 one)
+    start = [i for i, n in kernels if ("kkt_fused_dpp16_kernelILb0E" if tu == "lqr_dpp16_padkkt" else "kernelILi0E") in n][0]
     end = min([i for i, n in kernels if i > start] + [len(lines)])
     body = [l for l in lines[start:end] if not l.strip().startswith(";")]
     acc = [l for l in body if re.search(r"\ba\[?\d", l)]

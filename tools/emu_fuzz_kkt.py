@@ -3,7 +3,9 @@
 kkt_fused_wave of lqr_mfma40_body.h) on the CPU wavefront emulator against LQRStepFn.backward of the float64 oracle over random
 horizons (across the 64-step limit of the register-resident gains), ragged batches, bounds (none / scalar / tensor), f on / off,
 ring variants.  The solution differentiated at is a few oracle LQR steps from a random nominal.  Exits non-zero on a violation.
-    python tools/emu_fuzz_kkt.py [cases [seed [dpp16|mfma40]]]
+    python tools/emu_fuzz_kkt.py [cases [seed [dpp16|dpp16_pad|mfma40]]]
+dpp16_pad (round 6): random shapes n_state <= 12, n_ctrl <= 4 through the padded instantiation (kernel "dpp16_pad" of the emulator; on the
+GPU whatever impl 0 routes the shape to -- the padded fused kernel under c_symmetric, the three-launch route without).
 FUZZ_GPU=1: the same cases through mpc_lqr_kkt_fused / the three-launch route on the MI355X (c_symmetric on or off, float32)."""
 import os, sys, time
 import numpy as np
@@ -39,6 +41,8 @@ t0 = time.time()
 for case in range(cases):
     rng = np.random.default_rng(seed0 * 7919 + case)
     ns, nc = (32, 8) if which == "mfma40" else (12, 4)
+    if which == "dpp16_pad":
+        ns, nc = int(rng.integers(1, 13)), int(rng.integers(1, 5))
     n = ns + nc
     T = int(rng.choice([1, 2, 3, 5, 8, 20, 40, 66]) if which == "mfma40" else rng.choice([1, 2, 3, 4, 6, 7, 9, 17, 33, 63, 64, 65, 70]))
     B = int(rng.choice([1, 2, 3] + ([17, 40] if GPU else []))) if which == "mfma40" else int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9] + ([33, 130] if GPU else [])))
@@ -71,10 +75,13 @@ for case in range(cases):
     if GPU:
         csym = bool(rng.integers(0, 2))
         r = _gpu_kkt(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, csym)
-        label = "%s GPU c_symmetric=%s" % (which, csym)
+        label = "%s %d/%d GPU c_symmetric=%s" % (which, ns, nc, csym)
     elif which == "mfma40":
         r = emu.kkt_fused_mfma40(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, sweep3=True)
         label = "mfma40"
+    elif which == "dpp16_pad":
+        r = emu.kkt_fused(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, kernel="dpp16_pad")
+        label = "dpp16_pad %d/%d" % (ns, nc)
     else:
         ring2 = bool(rng.integers(0, 2))
         r = emu.kkt_fused(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, ring2=ring2)
