@@ -413,6 +413,16 @@ MPC_DEV void store_f32_grad(float *g, float v)
     __builtin_nontemporal_store(v, g);
 #endif
 }
+// 16 bytes of a gradient block at 4-byte alignment (the padded fused backward's runs: global memory takes unaligned vector accesses)
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+MPC_DEV void store_f32x4_grad(float *g, float __attribute__((ext_vector_type(4))) v)
+{
+#ifdef MPC_KF_CACHED_GRADS
+    *(f32x4_a4 *)g = v;
+#else
+    __builtin_nontemporal_store(v, (f32x4_a4 *)g);
+#endif
+}
 // the value of the neighbouring lane j ^ 1 (quad_perm [1,0,3,2])
 MPC_DEV float swap1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true)); }
 MPC_DEV void dma16_if(bool active, const void *g, unsigned off)
@@ -449,6 +459,7 @@ template <int IMM> MPC_DEV void dma4_at_if(bool active, const void *g, unsigned 
     if (active) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(g_stage16 + anchor), 4, IMM, 0);
 }
 MPC_DEV void lds_store_f32x4(unsigned off, f32x4 v) { *(f32x4 *)(g_stage16 + off) = v; }
+MPC_DEV void lds_store_f32(unsigned off, float v) { *(float *)(g_stage16 + off) = v; }
 // DS instructions of one wave execute in program order: a compiler barrier is all there is to ask for
 MPC_DEV void lds_sync() { asm volatile("" ::: "memory"); }
 // The immediate offset of an LDS-DMA moves the LDS destination together with the global source
@@ -510,10 +521,10 @@ __global__ void __launch_bounds__(64, 1) lqr_step_dpp16_kernel(StepParams<float>
 
 #if MPC_DPP16_NSTAGE == 4 || defined(MPC_DPP16_PAD_KKT)
 // the whole of LQRStepFn.backward in one launch (lqr_dpp16_body.h: kkt_fused_wave); MASKED = controls on a bound are pinned
-static_assert((int)dpp16::KfP2<false>::SLOTS * (int)dpp16::KfP2<false>::STAGE <= MPC_DPP16_LDS && (int)dpp16::KfP2<false>::SLOTS >= 5,
-              "the fused KKT kernel's second ring does not fit");
-static_assert((int)dpp16::KfP2<true>::SLOTS * (int)dpp16::KfP2<true>::STAGE <= MPC_DPP16_LDS && (int)dpp16::KfP2<true>::SLOTS >= 5,
-              "the long-horizon fused KKT kernel's second ring does not fit");
+static_assert((int)dpp16::KfP2<false>::SLOTS * (int)dpp16::KfP2<false>::STAGE + (int)dpp16::KfP2<false>::GST <= MPC_DPP16_LDS &&
+              (int)dpp16::KfP2<false>::SLOTS >= 5, "the fused KKT kernel's second ring does not fit");
+static_assert((int)dpp16::KfP2<true>::SLOTS * (int)dpp16::KfP2<true>::STAGE + (int)dpp16::KfP2<true>::GST <= MPC_DPP16_LDS &&
+              (int)dpp16::KfP2<true>::SLOTS >= (dpp16::PADK ? 4 : 5), "the long-horizon fused KKT kernel's second ring does not fit");
 static_assert((int)dpp16::LDS_TOTAL <= MPC_DPP16_LDS, "the fused KKT kernel's sweep ring does not fit");
 template <bool MASKED>
 __global__ void __launch_bounds__(64, 1) lqr_kkt_fused_dpp16_kernel(StepParams<float> p, dpp16::KktFusedArgs k)

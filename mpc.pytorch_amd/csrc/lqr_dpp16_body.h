@@ -2137,10 +2137,16 @@ enum { KF_VBLK = 96 };
 #ifndef MPC_KF_LDS_BYTES
 #define MPC_KF_LDS_BYTES ((int)LDS_TOTAL)
 #endif
+// GST: the padded instantiation's gradient blocks leave through LDS (behind the ring): a lane holds a COLUMN of dC_t / dF_t, the caller's
+// block has rows of n = n_state + n_ctrl floats at no particular alignment -- a dword per lane and row was 23-28 store instructions a
+// timestep on rows that straddle cache lines (10/3: 123 of the backward's 301 us; 12/2: 126 of 319).  The four problems' blocks of a
+// timestep are ONE contiguous run of 4 n^2 (4 n_state n) floats in the caller's array: the lanes park their columns in LDS (rows of
+// 20 dwords: conflict-free ds_write_b128), gather them back in the run's order and store 16 bytes a lane.
 template <bool LONG> struct KfP2 {
     enum { TOFF = LONG ? 6656 : 5632, STAGE = TOFF + (MPC_DPP16_PADK ? 256 : 0), DMA = MPC_DPP16_PADK ? (LONG ? 17 : 16) : (LONG ? 7 : 6),
-           FIT = (int)(MPC_KF_LDS_BYTES) / STAGE, CAP = 63 / DMA + 2,          // (AHEAD - 1) * DMA < 64
-           SLOTS0 = FIT >= 6 ? 6 : (FIT >= 5 ? 5 : 3), SLOTS = SLOTS0 < CAP ? SLOTS0 : CAP, AHEAD = SLOTS - 1, GOFF = 5632 };
+           GST = MPC_DPP16_PADK ? 5120 : 0,
+           FIT = ((int)(MPC_KF_LDS_BYTES) - GST) / STAGE, CAP = 63 / DMA + 2,          // (AHEAD - 1) * DMA < 64
+           SLOTS0 = FIT >= 6 ? 6 : FIT, SLOTS = SLOTS0 < CAP ? SLOTS0 : CAP, AHEAD = SLOTS - 1, GOFF = 5632 };
 };
 enum { KF_P2_STAGE = KfP2<false>::STAGE, KF_P2_SLOTS = KfP2<false>::SLOTS };
 // row offset of row i in the packed upper triangle of a symmetric 12 x 12: entries (i, j >= i) at tri_off(i) + j - i
@@ -2555,6 +2561,39 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
     // the padded instantiation: the caller's blocks are [n, n] / [n_state, n] with n = n_state + n_ctrl -- this lane's COLUMN of them,
     // a dword per row (a row of the padding is skipped: wave-uniform), rows of n floats instead of 16
     const int aj = PADK ? (L.isu ? ns_o + L.a : L.j) : L.j;          // this lane's entry of the caller's tau (when ovalid)
+#ifdef MPC_DPP16_PAD
+    // the staged form (KfP2::GST): this lane's 16 bytes of the wave's run of dC_t (dF_t) in store instruction i are the run's floats
+    // 4 (64 i + lane) .. + 3; each is element (row, column) of problem slot q of the run, parked at gst + 1280 q + 80 pad(column) + 4 pad(row)
+    // [dC_t is symmetric: the lane that holds column j holds row j], pad(a) = a for a state, 12 + (a - n_state) for a control
+    const bool full4 = 4 * wave + 3 < p.B;            // (a ragged last wave keeps the dword stores: its run is shorter)
+    constexpr unsigned gst = (unsigned)(KF_P2_SLOTS * KF_P2_STAGE);
+    const int n2C = n_o * n_o, n2F = ns_o * n_o;      // 16-byte stores of a full wave's run: 4 n^2 / 4
+    unsigned gaC[4][4], gaF[3][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int e = 4 * (64 * i + lane);
+        int q = e / n2C, rem = e - q * n2C, ar = rem / n_o, ac = rem - ar * n_o;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int pr = ar < ns_o ? ar : 12 + (ar - ns_o), pc = ac < ns_o ? ac : 12 + (ac - ns_o);
+            gaC[i][v] = gst + (unsigned)(1280 * (q & 3) + 80 * (pc & 15) + 4 * (pr & 15));
+            if (++ac == n_o) { ac = 0; if (++ar == n_o) { ar = 0; ++q; } }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int e = 4 * (64 * i + lane);
+        int q = e / n2F, rem = e - q * n2F, ar = rem / n_o, ac = rem - ar * n_o;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int pc = ac < ns_o ? ac : 12 + (ac - ns_o);
+            gaF[i][v] = gst + (unsigned)(1280 * (q & 3) + 80 * (pc & 15) + 4 * (ar & 15));
+            if (++ac == n_o) { ac = 0; if (++ar == ns_o) { ar = 0; ++q; } }
+        }
+    }
+    const unsigned gw = gst + (unsigned)(1280 * L.p + 80 * L.j);        // where this lane parks its column
+    float *dCs_p = k.dC + (long)(4 * wave) * n2C + 4 * lane, *dFs_p = k.dF + (long)(4 * wave) * n2F + 4 * lane;
+#endif
     if (PADK) {
         dC_p = k.dC + pb * (n_o * n_o) + (L.ovalid ? aj : 0);
         dF_p = k.dF + pb * (ns_o * n_o) + (L.ovalid ? aj : 0);
@@ -2600,21 +2639,55 @@ MPC_DEV void kkt_fused_wave(const P &p, const KktFusedArgs &k)
                 wv::dma_wait<(KF_P2_AHEAD - 1) * KF_P2_DMA>();
                 read2(s2, (i + 1) % KF_P2_SLOTS);
 #ifdef MPC_DPP16_PAD
-                if (L.live && L.ovalid) {
+#ifdef MPC_KF_SKIP
+                const bool skip_ = (MPC_KF_SKIP & 2) && t != T - 1;
+#else
+                const bool skip_ = false;
+#endif
+                if (full4 && !skip_) {
+                    // dC_t: park the columns, gather the run, 16 bytes a lane (DS instructions of a wave execute in order)
+                    wv::lds_sync();
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) wv::lds_store_f32x4(gw + 16u * q, f32x4{colC[4 * q], colC[4 * q + 1], colC[4 * q + 2], colC[4 * q + 3]});
+                    wv::lds_sync();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (64 * i < n2C && 64 * i + lane < n2C)
+                            wv::store_f32x4_grad(dCs_p + 256 * i, f32x4{wv::lds_f32(gaC[i][0]), wv::lds_f32(gaC[i][1]), wv::lds_f32(gaC[i][2]), wv::lds_f32(gaC[i][3])});
+                    }
+                    if (have) {
+                        wv::lds_sync();
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) wv::lds_store_f32x4(gw + 16u * q, f32x4{colF[4 * q], colF[4 * q + 1], colF[4 * q + 2], colF[4 * q + 3]});
+                        wv::lds_sync();
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            if (64 * i < n2F && 64 * i + lane < n2F)
+                                wv::store_f32x4_grad(dFs_p + 256 * i, f32x4{wv::lds_f32(gaF[i][0]), wv::lds_f32(gaF[i][1]), wv::lds_f32(gaF[i][2]), wv::lds_f32(gaF[i][3])});
+                        }
+                    }
+                }
+                if (L.live && L.ovalid && !skip_) {
                     if (so_p) wv::store_f32_grad(so_p, dj);
                     if (have) {
+                        if (!full4) {
 #pragma unroll
-                        for (int r = 0; r < 12; ++r)
-                            if (r < ns_o) wv::store_f32_grad(dF_p + r * n_o, colF[r]);
+                            for (int r = 0; r < 12; ++r)
+                                if (r < ns_o) wv::store_f32_grad(dF_p + r * n_o, colF[r]);
+                        }
                         if (df_p && xs_lane) wv::store_f32_grad(df_p, -dl1);
                     }
+                    if (!full4) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ar = pad_tau(r, ns_o, nc_o);
-                        if (ar >= 0) wv::store_f32_grad(dC_p + ar * n_o, colC[r]);
+                        for (int r = 0; r < 16; ++r) {
+                            const int ar = pad_tau(r, ns_o, nc_o);
+                            if (ar >= 0) wv::store_f32_grad(dC_p + ar * n_o, colC[r]);
+                        }
                     }
                     wv::store_f32_grad(dc_p, -dj);
                 }
+                dCs_p += B * n2C;
+                dFs_p += B * n2F;
                 if (so_p) so_p += so_step;
                 dC_p += B * (n_o * n_o);
                 dF_p += B * (ns_o * n_o);

@@ -68,7 +68,7 @@ SGPR_SPILL_LIMITS = {
     "lqr_dpp16_pad": {"kernelILi0E": 430, "kernelILi1E": 715, "kernelILi2E": 945, "kernelILi3E": 655},
     # ... and of its fused KKT backward (the fourth compilation of lqr_dpp16.hip): the sweep's gather maps and block bases in pass 1, the
     # rollout's twelve F gathers in pass 2
-    "lqr_dpp16_padkkt": {"kkt_fused": 130},
+    "lqr_dpp16_padkkt": {"kkt_fused": 150},          # (+20 with the gradient blocks leaving through LDS: the run pointers and lane masks of seven 16-byte stores)
     "lqr_mfma40": {"kernelILi0E": 90, "kernelILi1E": 105, "kernelILi2E": 150},
     # (round 4: block addresses as scalar arithmetic -- two more base pointers live in the two-slot build of mode 0)
     "lqr_mfma40_ring2": {"kernelILi0E": 100, "kernelILi1E": 105, "kernelILi2E": 150},
