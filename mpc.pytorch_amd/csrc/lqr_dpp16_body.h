@@ -346,11 +346,22 @@ enum {
     SC = 0, SF = 4096, SR = 7168, SG = 8192, STAGE_BYTES = 9216, NSTAGE = MPC_DPP16_NSTAGE, AHEAD = NSTAGE - 1,
     R_c = 0, R_tau = 64, R_f = 128, R_qs = 176, R_lo = 192, R_hi = 208,
     LDS_TOTAL = NSTAGE * STAGE_BYTES,
+#if defined(MPC_PAD_PROBE_DUP) && MPC_DPP16_PADK
+    DMA_SWEEP = 48
+#else
     DMA_SWEEP = MPC_DPP16_PADK ? 32 : 8       // 4 C + 3 F + 1 record (padded instantiation, dwords: 16 + 12 + 4)
+#endif
 };
 // DMA instructions of one rollout stage: F, record, gains (+ C when priced directly, + (m, M) otherwise
 // when constraints are present)
-template <int MODE, bool DIRECT> struct RollDma { enum { N = (MPC_DPP16_PADK ? 12 + 4 : 3 + 1) + (rgm(MODE) ? 0 : 1) + (DIRECT ? (MPC_DPP16_PADK ? 16 : 4) : (con(MODE) ? 1 : 0)) }; };
+#if defined(MPC_PAD_PROBE_DUP) && MPC_DPP16_PADK
+#define MPC_PAD_NF 12
+#define MPC_PAD_NC 32
+#else
+#define MPC_PAD_NF 12
+#define MPC_PAD_NC 16
+#endif
+template <int MODE, bool DIRECT> struct RollDma { enum { N = (MPC_DPP16_PADK ? MPC_PAD_NF + 4 : 3 + 1) + (rgm(MODE) ? 0 : 1) + (DIRECT ? (MPC_DPP16_PADK ? MPC_PAD_NC : 4) : (con(MODE) ? 1 : 0)) }; };
 // The identity-priced rollout does not stage C: its stage is [(m, M)] | gains | F | record = 5 (6) KiB, packed
 // back to back so the same LDS holds 7 (6) stages instead of 4 and the DMA runs 6 (5) timesteps ahead -- a
 // rollout step is ~0.45 us, four-deep staging would leave the loads less than an HBM round trip under load.
@@ -659,8 +670,14 @@ template <int MODE, bool ROLL, bool DIRECT, int K> MPC_DEV void pad_part(const D
     constexpr bool WITH_C = !ROLL || DIRECT;
     // sweep / direct rollout: C 0-7 | C 8-15 | F 0-7 | F 8-11 + record;   packed rollout: F 0-5 | F 6-11 | record | -
     // (ONE LDS anchor per block -- the stage's C block, its F block -- and the gather's place as the instruction's immediate)
+#if defined(MPC_PAD_PROBE_DUP) && MPC_DPP16_PADK          // (diagnostic build only: every gather of C issued twice -- the same results, the time of a stage of 48 instead of 32 instructions)
+#define MPC_PAD_C(kk) do { wv::dma_buf_at<256 * (kk), PAD_BIAS>(d.Cb[(kk) >> 2], d.cbytes, d.coff[kk], mid - 4096); \
+                           wv::dma_buf_at<256 * (kk), PAD_BIAS>(d.Cb[(kk) >> 2], d.cbytes, d.coff[kk], mid - 4096); } while (0)
+#define MPC_PAD_F(kk) wv::dma_buf_at<256 * (kk), PAD_BIAS>(d.Fb[(kk) / 3], d.fbytes, d.foff[kk], mid)
+#else
 #define MPC_PAD_C(kk) wv::dma_buf_at<256 * (kk), PAD_BIAS>(d.Cb[(kk) >> 2], d.cbytes, d.coff[kk], mid - 4096)
 #define MPC_PAD_F(kk) wv::dma_buf_at<256 * (kk), PAD_BIAS>(d.Fb[(kk) / 3], d.fbytes, d.foff[kk], mid)
+#endif
 #define MPC_PAD_R(kk) wv::dma4_at_if<3072 + 256 * (kk)>(d.rq_act[kk], d.rq[kk], mid)
     if (WITH_C) {
         if (K == 0) { MPC_PAD_C(0); MPC_PAD_C(1); MPC_PAD_C(2); MPC_PAD_C(3); MPC_PAD_C(4); MPC_PAD_C(5); MPC_PAD_C(6); MPC_PAD_C(7); }
