@@ -37,6 +37,14 @@ __device__ __forceinline__ void dma_block(const float *g, char *lds, int bytes, 
                                              (lds_void_t *)(lds + off), 16, 0, 0);
 }
 
+// ... 4 bytes per lane, for blocks and rows at any (4-byte) alignment and of any length: the general-shape instantiations (round 6)
+__device__ __forceinline__ void dma_block4(const float *g, char *lds, int bytes, int lane)
+{
+    for (int off = 0; off < bytes; off += 256)
+        if (off + 4 * lane < bytes)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)((const char *)g + off + 4 * lane), (lds_void_t *)(lds + off), 4, 0, 0);
+}
+
 // s_waitcnt vmcnt(n) for a run-time n (the immediate has to be a constant): at most n of the newest vector-memory
 // operations may still be in flight
 __device__ __forceinline__ void wait_newer(int n)
@@ -46,6 +54,9 @@ __device__ __forceinline__ void wait_newer(int n)
         MPC_W(0) MPC_W(1) MPC_W(2) MPC_W(3) MPC_W(4) MPC_W(5) MPC_W(6) MPC_W(7) MPC_W(8) MPC_W(9) MPC_W(10) MPC_W(11) MPC_W(12)
         MPC_W(13) MPC_W(14) MPC_W(15) MPC_W(16) MPC_W(17) MPC_W(18) MPC_W(19) MPC_W(20) MPC_W(21) MPC_W(22) MPC_W(23) MPC_W(24)
         MPC_W(25) MPC_W(26) MPC_W(27) MPC_W(28) MPC_W(29) MPC_W(30) MPC_W(31) MPC_W(32) MPC_W(33) MPC_W(34) MPC_W(35) MPC_W(36)
+        MPC_W(37) MPC_W(38) MPC_W(39) MPC_W(40) MPC_W(41) MPC_W(42) MPC_W(43) MPC_W(44) MPC_W(45) MPC_W(46) MPC_W(47) MPC_W(48)
+        MPC_W(49) MPC_W(50) MPC_W(51) MPC_W(52) MPC_W(53) MPC_W(54) MPC_W(55) MPC_W(56) MPC_W(57) MPC_W(58) MPC_W(59) MPC_W(60)
+        MPC_W(61) MPC_W(62) MPC_W(63)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 #undef MPC_W
@@ -55,7 +66,10 @@ __device__ __forceinline__ void wait_newer(int n)
 // timestep needs arrives by LDS-DMA NSLOT - 1 steps ahead (round 3: one step ahead and `vmcnt(0)` per step left a
 // wavefront waiting out a full HBM round trip every timestep -- 3.8 us per step at config 5, 0.244 ms of its backward);
 // the wait counts the DMA instructions of the newer stages, every stage issues the same number of them.
-template <int NSLOT>
+// AL: every block and row on the 16-byte grid (n, n_state multiples of 4, aligned bases and strides): 16 bytes a lane.  !AL (round 6): any
+// shape and alignment -- the same stages moved 4 bytes a lane (a record row = one instruction: lane l fetches word l), rows of C read
+// word by word.  Rounds 3-5 sent such shapes (13/4, 20/5 ...) to the generic kernel: 0.45 of their 1.0 ms backward.
+template <int NSLOT, bool AL>
 __global__ void __launch_bounds__(64) kkt_costate_kernel(StepParams<float> p, const float *dx, const float *du,
                                                          const float *dl_dx, float *dF, float *df, float *dx_init)
 {
@@ -63,7 +77,8 @@ __global__ void __launch_bounds__(64) kkt_costate_kernel(StepParams<float> p, co
     const int b = blockIdx.x, lane = threadIdx.x;
     const int ns = p.ns, nc = p.nc, n = ns + nc, T = p.T, B = p.B;
     const int cbytes = n * n * 4, fbytes = ns * n * 4, slot_bytes = cbytes + fbytes + 1024;
-    const int nd = (cbytes + 1023) / 1024 + (T > 1 ? (fbytes + 1023) / 1024 : 0) + 1;      // DMA instructions per stage
+    const int nd = AL ? (cbytes + 1023) / 1024 + (T > 1 ? (fbytes + 1023) / 1024 : 0) + 1      // DMA instructions per stage
+                      : (cbytes + 255) / 256 + (T > 1 ? (fbytes + 255) / 256 : 0) + 4;
     const bool st = lane < ns;
     const int li = st ? lane : 0;
     // the record's lane -> source map: row = lane / 16, granule g = lane % 16 of that row
@@ -79,13 +94,36 @@ __global__ void __launch_bounds__(64) kkt_costate_kernel(StepParams<float> p, co
     } else if (row == 2) {
         if (4 * g < ns) { rsrc = p.c + (long)b * p.c_sb + 4 * g; rstep = p.c_st; }
     } else if (4 * g < ns) { rsrc = dl_dx + (long)b * ns + 4 * g; rstep = (long)B * ns; }
+    // !AL: the record's four rows word by word -- lane l: tau*[l] | dtau[l] | c[l] (states) | dl_dx[l] (states)
+    const float *rs4[4] = {nullptr, nullptr, nullptr, nullptr};
+    long rst4[4] = {0, 0, 0, 0};
+    if (!AL) {
+        if (lane < ns) {
+            rs4[0] = p.cur_x + (long)b * ns + lane; rst4[0] = (long)B * ns;
+            rs4[1] = dx + (long)b * ns + lane; rst4[1] = (long)B * ns;
+            rs4[2] = p.c + (long)b * p.c_sb + lane; rst4[2] = p.c_st;
+            rs4[3] = dl_dx + (long)b * ns + lane; rst4[3] = (long)B * ns;
+        } else if (lane < n) {
+            rs4[0] = p.cur_u + (long)b * nc + (lane - ns); rst4[0] = (long)B * nc;
+            rs4[1] = du + (long)b * nc + (lane - ns); rst4[1] = (long)B * nc;
+        }
+    }
     auto issue = [&](int t, int slot) {
         t = t >= 0 ? t : 0;                                   // past the end: stage 0 again, the count per stage stays fixed
         char *base = kkt_lds + slot * slot_bytes;
-        dma_block(p.C + (long)t * p.C_st + (long)b * p.C_sb, base, cbytes, lane);
-        if (T > 1) dma_block(p.F + (long)(t < T - 1 ? t : T - 2) * p.F_st + (long)b * p.F_sb, base + cbytes, fbytes, lane);
-        if (rsrc)
-            __builtin_amdgcn_global_load_lds((glb_void_t *)(rsrc + (long)t * rstep), (lds_void_t *)(base + cbytes + fbytes), 16, 0, 0);
+        if (AL) {
+            dma_block(p.C + (long)t * p.C_st + (long)b * p.C_sb, base, cbytes, lane);
+            if (T > 1) dma_block(p.F + (long)(t < T - 1 ? t : T - 2) * p.F_st + (long)b * p.F_sb, base + cbytes, fbytes, lane);
+            if (rsrc)
+                __builtin_amdgcn_global_load_lds((glb_void_t *)(rsrc + (long)t * rstep), (lds_void_t *)(base + cbytes + fbytes), 16, 0, 0);
+        } else {
+            dma_block4(p.C + (long)t * p.C_st + (long)b * p.C_sb, base, cbytes, lane);
+            if (T > 1) dma_block4(p.F + (long)(t < T - 1 ? t : T - 2) * p.F_st + (long)b * p.F_sb, base + cbytes, fbytes, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)          // (every row has a lane that takes part: n_state >= 1)
+                if (rs4[q])
+                    __builtin_amdgcn_global_load_lds((glb_void_t *)(rs4[q] + (long)t * rst4[q]), (lds_void_t *)(base + cbytes + fbytes + 256 * q), 4, 0, 0);
+        }
     };
     float lam = 0.f, dlam = 0.f;
 #pragma unroll
@@ -108,21 +146,37 @@ __global__ void __launch_bounds__(64) kkt_costate_kernel(StepParams<float> p, co
         // only for a symmetric C; the reference uses C as given and an asymmetric C is a supported input: ADVICE r03,
         // fixtures grad_asym_cfg5_f32 / grad_asym_20_4_f32.  mpc_lqr_kkt_grads carries no options, so there is no promise to
         // take the column read back under; the vouched route of this shape is the fused backward, lqr_mfma40_body.h.)
-        for (int j = 0; j < n; j += 4) {
-            const f32x4 cr = *(const f32x4 *)(Cl + li * n + j);
+        if (AL) {
+            for (int j = 0; j < n; j += 4) {
+                const f32x4 cr = *(const f32x4 *)(Cl + li * n + j);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                r1 = fmaf(cr[v], lane_bcast(tau, j + v), r1);
-                r2 = fmaf(cr[v], lane_bcast(d, j + v), r2);
+                for (int v = 0; v < 4; ++v) {
+                    r1 = fmaf(cr[v], lane_bcast(tau, j + v), r1);
+                    r2 = fmaf(cr[v], lane_bcast(d, j + v), r2);
+                }
+            }
+        } else {
+            for (int j = 0; j < n; ++j) {
+                const float cr = Cl[li * n + j];
+                r1 = fmaf(cr, lane_bcast(tau, j), r1);
+                r2 = fmaf(cr, lane_bcast(d, j), r2);
             }
         }
         if (t < T - 1) {
-            for (int m = 0; m < ns; m += 4) {
+            if (AL) {
+                for (int m = 0; m < ns; m += 4) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float fm = Fl[(m + v) * n + li];
-                    r1 = fmaf(fm, lane_bcast(lam, m + v), r1);
-                    r2 = fmaf(fm, lane_bcast(dlam, m + v), r2);
+                    for (int v = 0; v < 4; ++v) {
+                        const float fm = Fl[(m + v) * n + li];
+                        r1 = fmaf(fm, lane_bcast(lam, m + v), r1);
+                        r2 = fmaf(fm, lane_bcast(dlam, m + v), r2);
+                    }
+                }
+            } else {
+                for (int m = 0; m < ns; ++m) {
+                    const float fm = Fl[m * n + li];
+                    r1 = fmaf(fm, lane_bcast(lam, m), r1);
+                    r2 = fmaf(fm, lane_bcast(dlam, m), r2);
                 }
             }
         }
@@ -139,6 +193,9 @@ __global__ void __launch_bounds__(64) kkt_costate_kernel(StepParams<float> p, co
     if (st) dx_init[(long)b * ns + lane] = -dlam;                                 // :404
 }
 
+// element e = i n + j of -0.5 (a b' + b a') resp. -(a2 b' + a1 b2') for a run of four consecutive e that may cross rows (n not a multiple of 4)
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <bool AL>
 __global__ void __launch_bounds__(64) kkt_outer_kernel(StepParams<float> p, const float *dx, const float *du, float *dC,
                                                        float *dc, float *dF)
 {
@@ -163,24 +220,56 @@ __global__ void __launch_bounds__(64) kkt_outer_kernel(StepParams<float> p, cons
     // dC_t = -0.5 (dtau tau' + tau dtau')   (:346-351), four consecutive columns per lane
     float *dCt = dC + tb * (long)(n * n);
     for (int e = 4 * lane; e < n * n; e += 256) {
-        const int i = e / n, j = e - i * n;
-        const float di = sv[1][i], ti = sv[0][i];
-        const f32x4 tj = *(const f32x4 *)&sv[0][j], dj = *(const f32x4 *)&sv[1][j];
-        f32x4 o;
+        int i = e / n, j = e - i * n;
+        if (AL) {
+            const float di = sv[1][i], ti = sv[0][i];
+            const f32x4 tj = *(const f32x4 *)&sv[0][j], dj = *(const f32x4 *)&sv[1][j];
+            f32x4 o;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) o[v] = -0.5f * fmaf(di, tj[v], ti * dj[v]);
-        __builtin_nontemporal_store(o, (f32x4 *)(dCt + e));          // (write-once gradients: see store_f32x2_out, lqr_dpp16.hip)
+            for (int v = 0; v < 4; ++v) o[v] = -0.5f * fmaf(di, tj[v], ti * dj[v]);
+            __builtin_nontemporal_store(o, (f32x4 *)(dCt + e));          // (write-once gradients: see store_f32x2_out, lqr_dpp16.hip)
+        } else {
+            // (round 6) any n: the four elements may cross a row; the block starts on a 4-byte boundary only -- 16 bytes a lane all the
+            // same (global memory takes unaligned vector stores), the block's last 1-3 elements one by one
+            f32x4 o;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int ii = i < n ? i : n - 1;
+                o[v] = -0.5f * fmaf(sv[1][ii], sv[0][j], sv[0][ii] * sv[1][j]);
+                if (++j == n) { j = 0; ++i; }
+            }
+            if (e + 4 <= n * n) __builtin_nontemporal_store(o, (f32x4_a4 *)(dCt + e));
+            else
+#pragma unroll
+                for (int v = 0; v < 3; ++v)
+                    if (e + v < n * n) __builtin_nontemporal_store(o[v], dCt + e + v);
+        }
     }
     // dF_t = -(dlam_{t+1} tau' + lam_{t+1} dtau')   (:387-396)
     if (have) {
         for (int e = 4 * lane; e < ns * n; e += 256) {
-            const int i = e / n, j = e - i * n;
-            const float li = sv[2][i], dli = sv[3][i];
-            const f32x4 tj = *(const f32x4 *)&sv[0][j], dj = *(const f32x4 *)&sv[1][j];
-            f32x4 o;
+            int i = e / n, j = e - i * n;
+            if (AL) {
+                const float li = sv[2][i], dli = sv[3][i];
+                const f32x4 tj = *(const f32x4 *)&sv[0][j], dj = *(const f32x4 *)&sv[1][j];
+                f32x4 o;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) o[v] = -fmaf(dli, tj[v], li * dj[v]);
-            __builtin_nontemporal_store(o, (f32x4 *)(dFt + e));
+                for (int v = 0; v < 4; ++v) o[v] = -fmaf(dli, tj[v], li * dj[v]);
+                __builtin_nontemporal_store(o, (f32x4 *)(dFt + e));
+            } else {
+                f32x4 o;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int ii = i < ns ? i : ns - 1;
+                    o[v] = -fmaf(sv[3][ii], sv[0][j], sv[2][ii] * sv[1][j]);
+                    if (++j == n) { j = 0; ++i; }
+                }
+                if (e + 4 <= ns * n) __builtin_nontemporal_store(o, (f32x4_a4 *)(dFt + e));
+                else
+#pragma unroll
+                    for (int v = 0; v < 3; ++v)
+                        if (e + v < ns * n) __builtin_nontemporal_store(o[v], dFt + e + v);
+            }
         }
     }
 }
@@ -275,8 +364,9 @@ int launch_traj_wave(const StepParams<float> &p, float *x, hipStream_t st)
     return MPC_OK;
 }
 
-bool kkt_wave_supported(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, const float *dC,
-                        const float *dF)
+// every block and row on the 16-byte grid: the AL instantiations
+static bool kkt_wave_aligned(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, const float *dC,
+                             const float *dF)
 {
     const int n = p.ns + p.nc;
     auto al = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
@@ -287,24 +377,42 @@ bool kkt_wave_supported(const StepParams<float> &p, const float *dx, const float
            ((uintptr_t)dC & 15) == 0 && (p.T == 1 || ((uintptr_t)dF & 15) == 0);
 }
 
+// (round 6) any float32 shape with n <= 64: what is not on the 16-byte grid takes the general instantiations (4 bytes a lane)
+bool kkt_wave_supported(const StepParams<float> &p, const float *, const float *, const float *, const float *, const float *)
+{
+    const int n = p.ns + p.nc;
+    return n <= 64 && n >= 2 && p.ns >= 1 && p.nc >= 1 && p.B > 0;          // (n >= 2: the costates park in the first 2 n_state words of dF_t)
+}
+
+template <int NSLOT, bool AL>
+static void launch_costate(const StepParams<float> &p, size_t lds, const float *dx, const float *du, const float *dl_dx, float *dF, float *df,
+                           float *dx_init, hipStream_t st)
+{
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_costate_kernel<NSLOT, AL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((kkt_costate_kernel<NSLOT, AL>), dim3(p.B), dim3(64), lds, st, p, dx, du, dl_dx, dF, df, dx_init);
+}
+
 int launch_kkt_wave(const StepParams<float> &p, const float *dx, const float *du, const float *dl_dx, float *dC,
                     float *dc, float *dF, float *df, float *dx_init, hipStream_t st)
 {
     const int n = p.ns + p.nc;
+    const bool al = kkt_wave_aligned(p, dx, du, dl_dx, dC, dF);
     // three slots (the DMA two timesteps ahead) while four wavefronts of them fit a CU's 160 KiB, else two
+    // (the general instantiation: a stage is up to 4x the instructions -- three slots only while two stages stay under vmcnt's 63)
     const size_t slot = (size_t)(n * n + p.ns * n) * 4 + 1024;
-    const bool deep = 3 * slot * 4 <= 160 * 1024;
+    const int nd4 = (n * n * 4 + 255) / 256 + (p.T > 1 ? (p.ns * n * 4 + 255) / 256 : 0) + 4;
+    const bool deep = 3 * slot * 4 <= 160 * 1024 && (al || nd4 <= 63);
     const size_t lds = (deep ? 3 : 2) * slot;
     if (deep) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_costate_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kkt_costate_kernel<3>, dim3(p.B), dim3(64), lds, st, p, dx, du, dl_dx, dF, df, dx_init);
+        if (al) launch_costate<3, true>(p, lds, dx, du, dl_dx, dF, df, dx_init, st);
+        else launch_costate<3, false>(p, lds, dx, du, dl_dx, dF, df, dx_init, st);
     } else {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_costate_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kkt_costate_kernel<2>, dim3(p.B), dim3(64), lds, st, p, dx, du, dl_dx, dF, df, dx_init);
+        if (al) launch_costate<2, true>(p, lds, dx, du, dl_dx, dF, df, dx_init, st);
+        else launch_costate<2, false>(p, lds, dx, du, dl_dx, dF, df, dx_init, st);
     }
-    hipLaunchKernelGGL(kkt_outer_kernel, dim3((unsigned)((long)p.T * p.B)), dim3(64), 0, st, p, dx, du, dC, dc, dF);
+    if (al) hipLaunchKernelGGL(kkt_outer_kernel<true>, dim3((unsigned)((long)p.T * p.B)), dim3(64), 0, st, p, dx, du, dC, dc, dF);
+    else hipLaunchKernelGGL(kkt_outer_kernel<false>, dim3((unsigned)((long)p.T * p.B)), dim3(64), 0, st, p, dx, du, dC, dc, dF);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_last_error((std::string("kkt_wave kernels: ") + hipGetErrorString(e)).c_str());
@@ -317,7 +425,7 @@ int launch_kkt_wave(const StepParams<float> &p, const float *dx, const float *du
 // shape, lqr_mfma40.hip, parks them there itself)
 int launch_kkt_outer(const StepParams<float> &p, const float *dx, const float *du, float *dC, float *dc, float *dF, hipStream_t st)
 {
-    hipLaunchKernelGGL(kkt_outer_kernel, dim3((unsigned)((long)p.T * p.B)), dim3(64), 0, st, p, dx, du, dC, dc, dF);
+    hipLaunchKernelGGL(kkt_outer_kernel<true>, dim3((unsigned)((long)p.T * p.B)), dim3(64), 0, st, p, dx, du, dC, dc, dF);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_last_error((std::string("kkt_outer_kernel: ") + hipGetErrorString(e)).c_str());
