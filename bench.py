@@ -675,8 +675,13 @@ def extra_rows(be, dev, steps):
     # generic kernel every such shape ran on in rounds 1-3 -- the reference's sweep is shape-agnostic (mpc/lqr_step.py:61-158)
     for ns_p, nc_p in ((13, 4), (20, 5), (24, 8)):
         p = make_problem(ns_p, nc_p, T_H, 1024, torch.float32, dev, seed=40 + ns_p)
-        row, _ = step_row(p, StepOptions(nominal_on_dynamics=True, c_symmetric=True), ns_p, nc_p, T_H, 1024)
+        row, r_p = step_row(p, StepOptions(nominal_on_dynamics=True, c_symmetric=True), ns_p, nc_p, T_H, 1024)
         rowg, _ = step_row(p, StepOptions(nominal_on_dynamics=True, c_symmetric=True), ns_p, nc_p, T_H, 1024, impl=1)
+        if (ns_p, nc_p) == (20, 5):
+            # its KKT backward (round 6): the 32/8 kernel's fused backward, padded instantiation (lqr_mfma40_padkkt.o) + the outer-product
+            # kernel's general form, where rounds 1-5 took three launches ending in the generic gradient kernel
+            rows["pad_kkt_backward_20_5_B1024"] = kkt_row(p, r_p, StepOptions(c_symmetric=True), ns_p, nc_p, T_H, 1024)
+        del r_p
         row["workload"] = ("n_state=%d n_ctrl=%d T=%d B=1024, unconstrained: the padded 32/8 kernel (%s gathers); generic_kernel_ms = the same call "
                            "forced onto the generic kernel (rounds 1-3)" % (ns_p, nc_p, T_H, "16-byte" if ns_p % 4 == 0 and nc_p % 4 == 0 else "dword"))
         row["generic_kernel_ms"] = rowg["ms"]

@@ -240,16 +240,17 @@ int mpc_lqr_kkt_prepare(int dtype, int B, int T, int ns, int nc,
  *     MPC_OPT_C_SYMMETRIC in o->flags (without it the three calls above are the way: their step tests C and re-solves what is
  *     not symmetric), and either n_state <= 12, n_ctrl <= 4 (one launch; beyond 64 timesteps the gains go through the workspace;
  *     exactly 12/4 on 16-byte aligned blocks takes the exact kernel, every other shape -- and 12/4 off that grid -- the padded
- *     instantiation, which asks no alignment of the caller's blocks: round 6) or n_state = 32, n_ctrl = 8 on 16-byte aligned
- *     blocks, any T (two launches: the nested step with both costates riding along, then the outer products; no prepare /
- *     costate passes over C and F).
+ *     instantiation, which asks no alignment of the caller's blocks: round 6) or any larger shape up to n_state = 32, n_ctrl = 8,
+ *     any T (two launches: the nested step with both costates riding along, then the outer products; no prepare / costate
+ *     passes over C and F; exactly 32/8 on 16-byte aligned blocks takes the exact kernel, every other shape and alignment its
+ *     padded instantiations: round 6).
  *     p = (C, c, F, f) of the forward with cur_x / cur_u = the solution (x*, u*); p->f only decides whether df is written.
  *     o = the forward's bounds: controls within 1e-8 of u_lower / u_upper are pinned in the KKT solve (:316-326); o may be
  *     NULL (no bounds).  zero_mask and delta_u of o are ignored, as the reference's backward ignores them (:322-340: the
  *     nested solve is built from the bounds alone).  dl_dx [T,B,ns], dl_du [T,B,nc].  Outputs as (4); dx_out / du_out (the KKT solve's own dx, du) and
  *     status [B] may be NULL.  workspace: mpc_lqr_kkt_fused_workspace_bytes(p), 16-byte aligned.
  *     mpc_lqr_kkt_fused_supported: 1 if this (problem, options) pair has the kernel -- sizes, dtype and flags only; pointer
- *     alignment (32/8; the workspace) is checked at launch (MPC_E_DIMS). */
+ *     alignment (the workspace: 16 bytes) is checked at launch (MPC_E_DIMS). */
 int mpc_lqr_kkt_fused_supported(const mpc_lqr_problem *p, const mpc_lqr_options *o);
 int64_t mpc_lqr_kkt_fused_workspace_bytes(const mpc_lqr_problem *p);
 int mpc_lqr_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const void *dl_dx, const void *dl_du,

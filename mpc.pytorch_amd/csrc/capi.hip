@@ -509,7 +509,8 @@ int mpc_lqr_kkt_fused_supported(const mpc_lqr_problem *p, const mpc_lqr_options 
 {
     if (!p || check_problem(p, false, false) != MPC_OK || check_options(p, o) != MPC_OK) return 0;
     // (12/4: any horizon since round 4; every shape UP TO 12/4 since round 6: the padded instantiation, lqr_dpp16.hip -DMPC_DPP16_PAD_KKT)
-    const bool s12 = p->ns >= 1 && p->ns <= 12 && p->nc >= 1 && p->nc <= 4, s32 = p->ns == 32 && p->nc == 8;
+    // ... and every shape up to 32/8: the padded instantiation of the 32/8 kernel's fused backward, lqr_mfma40.hip -DMPC_MFMA40_KKT -DMPC_MFMA40_PAD=4
+    const bool s12 = p->ns >= 1 && p->ns <= 12 && p->nc >= 1 && p->nc <= 4, s32 = p->ns >= 1 && p->ns <= 32 && p->nc >= 1 && p->nc <= 8;
     if (p->dtype != MPC_F32 || !(s12 || s32)) return 0;
     if (!o || !(o->flags & MPC_OPT_C_SYMMETRIC)) return 0;
     // (u_zero_I and delta_u of the FORWARD are not inputs of the backward: the reference's nested solve is built from the bounds
@@ -522,7 +523,7 @@ int mpc_lqr_kkt_fused_supported(const mpc_lqr_problem *p, const mpc_lqr_options 
 int64_t mpc_lqr_kkt_fused_workspace_bytes(const mpc_lqr_problem *p)
 {
     if (!p) return 0;
-    return p->ns == 32 ? kkt_fused_mfma40_workspace_bytes(p->T, p->B) : kkt_fused_dpp16_workspace_bytes(p->T, p->B);
+    return (p->ns > 12 || p->nc > 4) ? kkt_fused_mfma40_workspace_bytes(p->T, p->B) : kkt_fused_dpp16_workspace_bytes(p->T, p->B);
 }
 
 int mpc_lqr_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const void *dl_dx, const void *dl_du,
@@ -533,7 +534,7 @@ int mpc_lqr_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const 
     if (rc) return rc;
     if ((rc = check_options(p, o))) return rc;
     if (!mpc_lqr_kkt_fused_supported(p, o))
-        return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: needs fp32, n_state <= 12, n_ctrl <= 4 or n_state = 32, n_ctrl = 8, and "
+        return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: needs fp32, n_state <= 32, n_ctrl <= 8, and "
                                 "MPC_OPT_C_SYMMETRIC (otherwise: mpc_lqr_kkt_prepare + mpc_lqr_step + mpc_lqr_kkt_grads)");
     if (p->B == 0) return MPC_OK;
     if (!dl_dx || !dl_du || !dC || !dc || !dx_init) return fail(MPC_E_NULL, "kkt_fused: NULL argument");
@@ -546,12 +547,22 @@ int mpc_lqr_kkt_fused(const mpc_lqr_problem *p, const mpc_lqr_options *o, const 
     memset(&out, 0, sizeof(out));
     out.status = status;
     StepParams<float> sp = make_params<float>(p, o, &out);
-    if (p->ns == 32) {
+    if (p->ns > 12 || p->nc > 4) {
         // config 5's shape: the nested step with the costates riding along, then the outer-product kernel (two launches)
         if (!kkt_fused_mfma40_supported(sp, (const float *)dl_dx, (const float *)dl_du, (const float *)dC, (const float *)dF,
                                         (const float *)workspace) ||
-            (dx_out && (((uintptr_t)dx_out | (uintptr_t)du_out) & 15)) || ((uintptr_t)dx_init & 15) || (df && ((uintptr_t)df & 15)))
-            return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: blocks must be 16-byte aligned");
+            (dx_out && (((uintptr_t)dx_out | (uintptr_t)du_out) & 15)) || ((uintptr_t)dx_init & 15) || (df && ((uintptr_t)df & 15))) {
+            // every other shape up to 32/8, and 32/8 itself off the 16-byte grid: the padded instantiation (round 6)
+            if (!kkt_fused_mfma40_pad_supported(sp, (const float *)workspace))
+                return fail(MPC_E_DIMS, "mpc_lqr_kkt_fused: the workspace must be 16-byte aligned (tensor bounds 4-byte aligned)");
+            if (kkt_fused_mfma40_pad16_supported(sp, (const float *)workspace))
+                return launch_kkt_fused_mfma40_pad16(sp, (const float *)dl_dx, (const float *)dl_du, (float *)dC, (float *)dc, (float *)dF,
+                                                     (float *)df, (float *)dx_init, (float *)dx_out, (float *)du_out, (float *)workspace, 0.2f,
+                                                     10, (hipStream_t)stream);
+            return launch_kkt_fused_mfma40_pad(sp, (const float *)dl_dx, (const float *)dl_du, (float *)dC, (float *)dc, (float *)dF,
+                                               (float *)df, (float *)dx_init, (float *)dx_out, (float *)du_out, (float *)workspace, 0.2f,
+                                               10, (hipStream_t)stream);
+        }
         return launch_kkt_fused_mfma40(sp, (const float *)dl_dx, (const float *)dl_du, (float *)dC, (float *)dc, (float *)dF,
                                        (float *)df, (float *)dx_init, (float *)dx_out, (float *)du_out, (float *)workspace, 0.2f,
                                        10, (hipStream_t)stream);

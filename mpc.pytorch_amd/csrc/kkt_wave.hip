@@ -425,7 +425,11 @@ int launch_kkt_wave(const StepParams<float> &p, const float *dx, const float *du
 // shape, lqr_mfma40.hip, parks them there itself)
 int launch_kkt_outer(const StepParams<float> &p, const float *dx, const float *du, float *dC, float *dc, float *dF, hipStream_t st)
 {
-    hipLaunchKernelGGL(kkt_outer_kernel<true>, dim3((unsigned)((long)p.T * p.B)), dim3(64), 0, st, p, dx, du, dC, dc, dF);
+    // (the padded fused backward of the 32/8 kernel comes here with any shape: rows of four on the 16-byte grid, or the general form)
+    const int n = p.ns + p.nc;
+    const bool al = n % 4 == 0 && p.ns % 4 == 0 && ((((uintptr_t)dC | (uintptr_t)dF) & 15) == 0);
+    if (al) hipLaunchKernelGGL(kkt_outer_kernel<true>, dim3((unsigned)((long)p.T * p.B)), dim3(64), 0, st, p, dx, du, dC, dc, dF);
+    else hipLaunchKernelGGL(kkt_outer_kernel<false>, dim3((unsigned)((long)p.T * p.B)), dim3(64), 0, st, p, dx, du, dC, dc, dF);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_last_error((std::string("kkt_outer_kernel: ") + hipGetErrorString(e)).c_str());

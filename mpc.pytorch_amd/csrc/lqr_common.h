@@ -96,6 +96,15 @@ int launch_step_mfma40_pad16(const StepParams<float> &p, hipStream_t st);
 bool kkt_fused_mfma40_supported(const StepParams<float> &p, const float *dl_dx, const float *dl_du, const float *dC,
                                 const float *dF, const float *ws);
 int64_t kkt_fused_mfma40_workspace_bytes(int T, int B);
+// ... and its PADDED instantiation: any n_state <= 32, n_ctrl <= 8 (lqr_mfma40.hip, -DMPC_MFMA40_KKT -DMPC_MFMA40_PAD=4; the same workspace)
+bool kkt_fused_mfma40_pad_supported(const StepParams<float> &p, const float *ws);
+bool kkt_fused_mfma40_pad16_supported(const StepParams<float> &p, const float *ws);          // (n_state, n_ctrl multiples of 4, 16-byte aligned C / F)
+int launch_kkt_fused_mfma40_pad16(const StepParams<float> &p, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
+                                  float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
+                                  hipStream_t st);
+int launch_kkt_fused_mfma40_pad(const StepParams<float> &p, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
+                                float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
+                                hipStream_t st);
 int launch_kkt_fused_mfma40(const StepParams<float> &p, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
                             float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
                             hipStream_t st);

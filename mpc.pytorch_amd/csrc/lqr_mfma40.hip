@@ -107,7 +107,13 @@ MPC_DEV void pin(float &x) { asm volatile("" : "+v"(x)); }
 #endif
 // the sweep's slots (12032 B each) or the pricing rollout's two (13056 B), + the layout-turn words; the fused backward's
 // second ring (31.5 KiB) lies inside its three sweep slots
-#define MPC_MFMA40_LDS ((MPC_MFMA40_SWEEP_NSTAGE * 12032 > 2 * 13056 ? MPC_MFMA40_SWEEP_NSTAGE * 12032 : 2 * 13056) + 512)
+#define MPC_MFMA40_LDS_STEP ((MPC_MFMA40_SWEEP_NSTAGE * 12032 > 2 * 13056 ? MPC_MFMA40_SWEEP_NSTAGE * 12032 : 2 * 13056) + 512)
+// (the padded fused backward sweeps on two slots: its second ring alone sets the size then)
+#if defined(MPC_MFMA40_KKT) && MPC_MFMA40_LDS_STEP < 3 * 10752
+#define MPC_MFMA40_LDS (3 * 10752)
+#else
+#define MPC_MFMA40_LDS MPC_MFMA40_LDS_STEP
+#endif
 __shared__ __attribute__((aligned(16))) char g_stage40[MPC_MFMA40_LDS];
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -204,6 +210,28 @@ template <int MODE> __global__ void __launch_bounds__(64, 1) lqr_kkt_fused_mfma4
 }
 }  // namespace
 
+#ifdef MPC_MFMA40_PAD
+// the PADDED instantiation (round 6; -DMPC_MFMA40_KKT -DMPC_MFMA40_PAD=4 on the two-slot sweep ring, lqr_mfma40_padkkt.o): any n_state <= 32,
+// n_ctrl <= 8, dword gathers -- nothing but 4-byte alignment asked of the caller's blocks; the workspace (the library's padded layout) on 16
+#if MPC_MFMA40_PAD == 4
+bool kkt_fused_mfma40_pad_supported(const StepParams<float> &p, const float *ws)
+{
+    return p.ns >= 1 && p.ns <= 32 && p.nc >= 1 && p.nc <= 8 && p.T >= 1 && !p.env.kind && ((uintptr_t)ws & 15) == 0 &&
+           (p.bound_mode != MPC_BOUND_TENSOR || ((((uintptr_t)p.lo | (uintptr_t)p.hi) & 3) == 0));
+}
+// ... with 16-byte gathers (lqr_mfma40_pad16kkt.o): rows of C and F and the x | u boundary on 16 bytes -- a quarter of the staging instructions
+bool kkt_fused_mfma40_pad16_supported(const StepParams<float> &p, const float *ws)
+{
+    auto al = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+    return kkt_fused_mfma40_pad_supported(p, ws) && p.ns % 4 == 0 && p.nc % 4 == 0 && al(p.C) && (p.T == 1 || al(p.F)) && p.C_st % 4 == 0 &&
+           p.C_sb % 4 == 0 && p.F_st % 4 == 0 && p.F_sb % 4 == 0;
+}
+#define MPC_KF40_LAUNCH launch_kkt_fused_mfma40_pad
+#else
+#define MPC_KF40_LAUNCH launch_kkt_fused_mfma40_pad16
+#endif
+#else
+#define MPC_KF40_LAUNCH launch_kkt_fused_mfma40
 // floats: K [T,B,8,32] | k [T,B,8] | V [T,B,1024] | v,g [T,B,64] | (dx [T,B,32] | du [T,B,8] when the caller keeps none)
 int64_t kkt_fused_mfma40_workspace_bytes(int T, int B) { return (int64_t)T * B * (256 + 8 + 1024 + 64 + 40) * 4 + 64; }
 
@@ -221,8 +249,10 @@ bool kkt_fused_mfma40_supported(const StepParams<float> &p, const float *dl_dx, 
            (p.T == 1 || al(dF, 0, 0));
 }
 
+#endif
+
 // the nested step with lambda and dlambda riding along (one launch), then the outer products (kkt_wave.hip)
-int launch_kkt_fused_mfma40(const StepParams<float> &p_in, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
+int MPC_KF40_LAUNCH(const StepParams<float> &p_in, const float *dl_dx, const float *dl_du, float *dC, float *dc, float *dF,
                             float *df, float *dx_init, float *dx_out, float *du_out, float *ws, float decay, int max_ls,
                             hipStream_t st)
 {

@@ -151,7 +151,12 @@ constexpr unsigned KOFF_F = 0, KOFF_K = 5120, KOFF_R = 6144, KOFF_V = 6656, KSTA
 #ifdef MPC_KF40_VFULL
 constexpr int KSLOTS = 3, KDMA_PER_STAGE = 11;                 // 5 (F) + 1 (K) + 1 (record) + 4 (V)
 #else
-constexpr int KSLOTS = 3, KDMA_PER_STAGE = 10;                 // 5 (F) + 1 (K) + 1 (record) + 3 (V: tiles (0,0), (1,0), (1,1))
+constexpr int KSLOTS = 3, KDMA_PER_STAGE_EXACT = 10;           // 5 (F) + 1 (K) + 1 (record) + 3 (V: tiles (0,0), (1,0), (1,1))
+#endif
+#ifndef MPC_KF40_VFULL
+// pass 2 of the fused backward: F (gathered in the padded instantiation: CH_F instructions) + K + record + three V tiles
+constexpr int KDMA_PER_STAGE = PADK ? CH_F + 5 : KDMA_PER_STAGE_EXACT;
+static_assert((KSLOTS - 2) * KDMA_PER_STAGE < 64, "vmcnt is 6 bits");
 #endif
 // the constrained modes' record for the rollout that prices without C (rollout_priced): floats per problem-step
 constexpr int PREC = 328;                                      // M [8][32] | Quu [8][8] | m [8]
@@ -237,6 +242,31 @@ MPC_DEV void rec_init(RecMap &m, const P &p, int lane, long b, bool with_c, bool
         }
     }
 }
+// ... of the fused backward's sweep (stream_init with kk): words 0..39 r = (dl_dx | dl_du) in the padded tau's order, 40..79 tau*, 80..111
+// c_x of the original problem (lambda's constant term)
+MPC_DEV void rec_init_kkt(RecMap &m, const P &p, int lane, long b, const float *dl_dx, const float *dl_du)
+{
+    const int ns = p.ns, nc = p.nc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int w = 64 * j + lane;
+        m.ptr[j] = (const char *)p.cur_x;
+        m.step[j] = 0;
+        m.kind[j] = 0;
+        m.act[j] = false;
+        if (w < 32) {
+            if (w < ns) { m.act[j] = true; m.ptr[j] = (const char *)(dl_dx + b * ns + w); m.step[j] = (long)p.B * ns * 4; }
+        } else if (w < 40) {
+            if (w - 32 < nc) { m.act[j] = true; m.ptr[j] = (const char *)(dl_du + b * nc + (w - 32)); m.step[j] = (long)p.B * nc * 4; }
+        } else if (w < 72) {
+            if (w - 40 < ns) { m.act[j] = true; m.ptr[j] = (const char *)(p.cur_x + b * ns + (w - 40)); m.step[j] = (long)p.B * ns * 4; }
+        } else if (w < 80) {
+            if (w - 72 < nc) { m.act[j] = true; m.ptr[j] = (const char *)(p.cur_u + b * nc + (w - 72)); m.step[j] = (long)p.B * nc * 4; }
+        } else if (w < 112) {
+            if (w - 80 < ns) { m.act[j] = true; m.ptr[j] = (const char *)(p.c + b * p.c_sb + (w - 80)); m.step[j] = p.c_st * 4; }
+        }
+    }
+}
 MPC_DEV void rec_issue(const RecMap &m, long tl, long tf, long tx, unsigned off, bool skip_c = false, int lane = 0)
 {
 #pragma unroll
@@ -280,6 +310,17 @@ MPC_DEV void st_u4(const P &p, long tb, int a0, f32x4 v)
         for (int e = 0; e < 4; ++e) wv::st_buf(p.new_u + tb * p.nc, (unsigned)(4 * p.nc), (unsigned)(4 * (a0 + e)), v[e]);
     } else {
         wv::store_f32x4(p.new_u + tb * NC + a0, v);
+    }
+}
+// four consecutive entries i0 .. i0+3 of a caller's row of `len` floats (the fused backward's dF / df / dx_init rows): the entries beyond
+// the true length are dropped by the buffer's range check (padded instantiation), one 16-byte store otherwise
+MPC_DEV void st_row4(float *row, int len, int i0, f32x4 v)
+{
+    if (PADK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wv::st_buf(row, (unsigned)(4 * len), (unsigned)(4 * (i0 + e)), v[e]);
+    } else {
+        wv::store_f32x4(row + i0, v);
     }
 }
 // bounds of control a at (t, b) = tb; a padded control is unbounded in every mode (it sits at zero: its row of Quu is the identity)
@@ -329,7 +370,8 @@ MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L, const KktArgs40 *
         d.Cb = p.C + b * p.C_sb;
         d.Fb = p.T > 1 ? p.F + b * p.F_sb : d.Cb;
         gather_init(d.g, p, L.lane);
-        rec_init(d.rm, p, L.lane, b, true, false, with_f, nullptr);
+        if (kk) rec_init_kkt(d.rm, p, L.lane, b, kk->dl_dx, kk->dl_du);
+        else rec_init(d.rm, p, L.lane, b, true, false, with_f, nullptr);
     }
     d.lo = 16u * (unsigned)L.lane;
     d.c_ptr = (const char *)(p.C + b * p.C_sb);
@@ -385,16 +427,18 @@ MPC_DEV void stream_init(Stream &d, const P &p, const Lane &L, const KktArgs40 *
 MPC_DEV unsigned kkt_pinned_word(const P &p, long tb, int w)
 {
     unsigned z = 0u;
+    // (padded instantiation: u*, the bounds by the true n_ctrl; a control beyond it is free -- its row of Quu is the identity, it stays at zero)
+    const int nc = PADK ? p.nc : NC;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        const int a = 4 * w + v;
-        const float u = uniform_f32(p.cur_u + tb * NC + a);
+        const int a = 4 * w + v, as = a < nc ? a : nc - 1;
+        const float u = uniform_f32(p.cur_u + tb * nc + as);
         float lo = p.lo_s, hi = p.hi_s;
         if (p.bound_mode != MPC_BOUND_SCALAR) {
-            lo = uniform_f32(p.lo + tb * NC + a);
-            hi = uniform_f32(p.hi + tb * NC + a);
+            lo = uniform_f32(p.lo + tb * nc + as);
+            hi = uniform_f32(p.hi + tb * nc + as);
         }
-        const bool pinned = fabsf(u - lo) <= 1e-8f || fabsf(u - hi) <= 1e-8f;
+        const bool pinned = (fabsf(u - lo) <= 1e-8f || fabsf(u - hi) <= 1e-8f) && a < nc;
         z |= pinned ? (1u << (8 * v)) : 0u;
     }
     return z;
@@ -1056,8 +1100,8 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                 if (L.r == 0) {
 #pragma unroll
                     for (int I = 0; I < 2; ++I)
-                        wv::store_f32x4(kx->dF + tb * (long)(NS * N) + 16 * I + 4 * L.q,
-                                        f32x4{lcol[I][0], lcol[I][1], lcol[I][2], lcol[I][3]});
+                        st_row4(kx->dF + tb * (long)(PADK ? p.ns * (p.ns + p.nc) : NS * N), PADK ? p.ns : NS, 16 * I + 4 * L.q,
+                                f32x4{lcol[I][0], lcol[I][1], lcol[I][2], lcol[I][3]});
                 }
             }
         }
@@ -2313,7 +2357,9 @@ MPC_DEV void kstage_issue(const P &p, const RStream &d, const char *v_ptr, long 
     const long tl = t;
     const long tf = t < p.T - 1 ? t : (p.T > 1 ? p.T - 2 : 0);      // F has T-1 entries
     const long tx = t + 1 < p.T ? t + 1 : t;                         // (V, v, g) of t+1
-    dma_kib<5>(d.f_ptr + tf * d.f_step + d.lo, base + KOFF_F);
+    // (padded instantiation: the caller's F by the rollout's gather; K, the record and V are the workspace's own padded layout)
+    if (PADK) gather_F(d.g, p.T > 1 ? d.Fb + tf * p.F_st : d.Cb, p.T > 1 ? d.g.fbytes : 0u, base + KOFF_F);
+    else dma_kib<5>(d.f_ptr + tf * d.f_step + d.lo, base + KOFF_F);
     wv::dma16(d.k_ptr + tl * d.k_step + d.lo, base + KOFF_K);
     wv::dma16_if(d.r_active, d.r_ptr + rec_off(d.r_is_x ? tx : tl, d.r_step), base + KOFF_R);
 #ifdef MPC_KF40_VFULL
@@ -2338,6 +2384,13 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
     RStream d;
     d.c_ptr = nullptr; d.c_step = 0;
     d.lo = 16u * (unsigned)L.lane;
+    if (PADK) {
+        d.Cb = p.C + (long)L.b * p.C_sb;
+        d.Fb = T > 1 ? p.F + (long)L.b * p.F_sb : d.Cb;
+        gather_init(d.g, p, L.lane);
+    }
+    // the caller's rows by their true length (padded instantiation)
+    const int ns_o = PADK ? p.ns : NS, dfb = PADK ? p.ns * (p.ns + p.nc) : NS * N;
     d.f_ptr = T > 1 ? (const char *)(p.F + (long)L.b * p.F_sb) : (const char *)(p.C + (long)L.b * p.C_sb);
     d.f_step = T > 1 ? p.F_st * 4 : 0;
     d.k_ptr = (const char *)(Kin + (long)L.b * (NC * NS));
@@ -2376,7 +2429,8 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
         for (int i = 0; i < win; ++i) wa *= p.ls_decay;
         if (L.q == 0) {
 #pragma unroll
-            for (int J = 0; J < 2; ++J) kx.dx_init[(long)L.b * NS + 16 * J + L.r] = -fmaf(1.f - wa, v0g0[2 + J], v0g0[J]);
+            for (int J = 0; J < 2; ++J)
+                if (!PADK || 16 * J + L.r < ns_o) kx.dx_init[(long)L.b * ns_o + 16 * J + L.r] = -fmaf(1.f - wa, v0g0[2 + J], v0g0[J]);
         }
     }
     f32x4 Xd[2];                     // dx_t, D layout: column r = trial r (dx_0 = 0: the nested x_init, :327, 338)
@@ -2385,7 +2439,7 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
     f32x4 pU = zero4, pDL[2] = {zero4, zero4};     // du_{t-1}, dlambda_t: stored one timestep late (below)
     if (store) {
 #pragma unroll
-        for (int I = 0; I < 2; ++I) wv::store_f32x4(p.new_x + (long)L.b * NS + 16 * I + 4 * L.q, zero4);
+        for (int I = 0; I < 2; ++I) st_x4(p, L.b, 16 * I + 4 * L.q, zero4);
     }
     wv::dma_wait<0>();          // nothing of the sweep may still land in the ring
 #pragma unroll
@@ -2455,12 +2509,12 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
         // were waited out at once)
         if (store && t > 0) {
             const long tbp = tb - p.B;
-            if (L.q < 2) wv::store_f32x4(p.new_u + tbp * NC + 4 * L.q, pU);
+            if (L.q < 2) st_u4(p, tbp, 4 * L.q, pU);
 #pragma unroll
             for (int Im = 0; Im < 2; ++Im) {
-                wv::store_f32x4(p.new_x + tb * NS + 16 * Im + 4 * L.q, Xd[Im]);
-                wv::store_f32x4(kx.dF + tbp * (long)(NS * N) + NS + 16 * Im + 4 * L.q, pDL[Im]);
-                if (kx.df) wv::store_f32x4(kx.df + tbp * NS + 16 * Im + 4 * L.q, f32x4{-pDL[Im][0], -pDL[Im][1], -pDL[Im][2], -pDL[Im][3]});   // :397-400
+                st_x4(p, tb, 16 * Im + 4 * L.q, Xd[Im]);
+                st_row4(kx.dF + tbp * (long)dfb + ns_o, ns_o, 16 * Im + 4 * L.q, pDL[Im]);
+                if (kx.df) st_row4(kx.df + tbp * ns_o, ns_o, 16 * Im + 4 * L.q, f32x4{-pDL[Im][0], -pDL[Im][1], -pDL[Im][2], -pDL[Im][3]});   // :397-400
             }
         }
         wv::sched_fence();
@@ -2517,7 +2571,7 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
             pDL[1] = DL[1];
         }
     }
-    if (store && L.q < 2) wv::store_f32x4(p.new_u + ((long)(T - 1) * p.B + L.b) * NC + 4 * L.q, pU);
+    if (store && L.q < 2) st_u4(p, (long)(T - 1) * p.B + L.b, 4 * L.q, pU);
     wv::dma_wait<0>();
 }
 

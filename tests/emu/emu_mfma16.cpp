@@ -846,7 +846,13 @@ extern "C" int emu_kkt_fused_mfma40(const mpc_lqr_problem *p, const mpc_lqr_opti
     memset(&out, 0, sizeof(out));
     out.status = status;
     mpclqr::StepParams<float> sp = mpclqr::make_params<float>(p, o, &out);
+#ifdef MPC_MFMA40_PAD
+    if (!(sp.ns >= 1 && sp.ns <= 32 && sp.nc >= 1 && sp.nc <= 8)) return MPC_E_DIMS;      // the padded instantiation (launch_kkt_fused_mfma40_pad)
+    sp.zero_mask = nullptr;
+    sp.has_delta = 0;
+#else
     if (!(sp.ns == 32 && sp.nc == 8)) return MPC_E_DIMS;
+#endif
     if (sizeof(emu::W.lds) < mpclqr::mfma40::KLDS_TOTAL) return MPC_E_DIMS;
     const size_t TB = (size_t)sp.T * sp.B, need = TB * (256 + 8 + 1024 + 64) + 4;
     float *ws = (float *)aligned_alloc(16, (need * sizeof(float) + 15) / 16 * 16);

@@ -272,7 +272,7 @@ def kkt_fused(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_upper=No
     return out
 
 
-def kkt_fused_mfma40(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_upper=None, dma_late=False, sweep3=True):
+def kkt_fused_mfma40(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_upper=None, dma_late=False, sweep3=True, pad=0):
     """LQRStepFn.backward (mpc/lqr_step.py:312-407) at n_state = 32, n_ctrl = 8 through the emulated fused kernel
     (kkt_fused_wave, lqr_mfma40_body.h): dx, du, dx_init, df and the two costates from the kernel; dC, dc, dF are then the
     outer products kkt_outer_kernel (kkt_wave.hip) forms from exactly those vectors (:346-353, :387-396), here in numpy."""
@@ -280,7 +280,8 @@ def kkt_fused_mfma40(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_u
     cast = lambda a: np.ascontiguousarray(a, f32)
     C, c, x_star, u_star, dl_dx, dl_du = map(cast, (C, c, x_star, u_star, dl_dx, dl_du))
     T, B, n, _ = C.shape
-    ns, nc = 32, 8
+    # pad = 4: the padded instantiation (any n_state <= 32, n_ctrl <= 8; the library's lqr_mfma40_padkkt.o: dword gathers, two-slot sweep ring)
+    ns, nc = (x_star.shape[2], n - x_star.shape[2]) if pad else (32, 8)
     p = N.Problem()
     p.B, p.T, p.ns, p.nc, p.dtype = B, T, ns, nc, N.MPC_F32
     x0 = np.zeros((B, ns), f32)
@@ -307,7 +308,7 @@ def kkt_fused_mfma40(C, c, F, f, x_star, u_star, dl_dx, dl_du, u_lower=None, u_u
     out = dict(dF=np.full((max(T - 1, 0), B, ns, n), np.nan, f32), df=np.full((max(T - 1, 0), B, ns), np.nan, f32) if has_f else None,
                dx_init=np.full((B, ns), np.nan, f32), dx=np.full((T, B, ns), np.nan, f32), du=np.full((T, B, nc), np.nan, f32),
                status=np.zeros(B, np.int32))
-    L = lib() if sweep3 else lib_ring2()          # (the library builds this kernel with the 3-slot sweep ring)
+    L = lib_pad(pad) if pad else (lib() if sweep3 else lib_ring2())          # (the library builds this kernel with the 3-slot sweep ring)
     L.emu_set_dma_late(int(bool(dma_late)))
     vp = ctypes.c_void_p
     L.emu_kkt_fused_mfma40.argtypes = [ctypes.POINTER(N.Problem), ctypes.POINTER(N.Options)] + [vp] * 8

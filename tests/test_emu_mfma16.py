@@ -1461,3 +1461,52 @@ def test_emulated_dpp16_line_search_tails_in_a_ragged_wave(emu, B, T, tensor):
         np.testing.assert_allclose(rp["new_u"][:, same], o["new_u"][:, same], rtol=2e-3, atol=2e-3)
         np.testing.assert_allclose(rp["costs"][same], o["costs"][same], rtol=2e-3, atol=1e-2)
     assert hit >= 3 and stats[7] + stats[8] > 0, (hit, stats[7], stats[8])
+
+
+@pytest.mark.parametrize("case", ["13_4", "20_5_bounded", "24_8_tensor", "16_4_nof", "32_7_bounded", "13_1", "5_8_bounded", "17_3_T1", "20_5_T2_bounded",
+                                  "13_4_T3", "14_2_nonconvex", "32_8_T9_bounded", "2_5"])
+def test_emulated_padded_fused_kkt_backward_mfma40_matches_oracle(emu, case):
+    """The PADDED instantiation of the 32/8 kernel's fused KKT backward (round 6, -DMPC_MFMA40_KKT -DMPC_MFMA40_PAD=4; the library's
+    lqr_mfma40_padkkt.o): LQRStepFn.backward (mpc/lqr_step.py:312-407) for any n_state <= 32, n_ctrl <= 8 -- the nested step with lambda
+    along its sweep and dlambda = V dx + v + (1 - alpha) g along its rollout, C and F gathered dword by dword into the padded [x(32); u(8)]
+    layout, the record's words each from its own array, the pinned set from u* and the bounds by the true n_ctrl, and dx, du, dx_init, df
+    and the parked costates stored by the caller's true shape -- against the oracle's three-stage backward.  Outputs are pre-filled with
+    NaN: an entry the kernel skips fails."""
+    from oracle import lqr_oracle as O
+    parts = case.split("_")
+    ns, nc = int(parts[0]), int(parts[1])
+    rng = np.random.default_rng(sum(map(ord, case)) + 7)
+    T = next((int(q[1:]) for q in parts[2:] if q[0] == "T"), 5)
+    B = 3
+    bounded = "bounded" in parts or "tensor" in parts
+    pr = _shape_problem(rng, max(T, 2), B, ns, nc, with_f="nof" not in parts)
+    if "nonconvex" in parts:
+        pr["C"][:, (0, 2), ns:, ns:] -= 400.0 * np.eye(nc)
+    if T == 1:
+        pr = {k: (v[:1] if k in ("C", "c") else (v[:0] if k in ("F", "f") and v is not None else v)) for k, v in pr.items()}
+    cur_u = np.clip(0.5 * rng.standard_normal((T, B, nc)), -0.4, 0.4)
+    cur_x, _ = O.traj_cost(pr["x_init"], cur_u, pr["F"], pr["f"])
+    lo, hi = (-0.4, 0.4) if bounded else (None, None)
+    if "tensor" in parts:
+        lo, hi = -0.3 - 0.2 * rng.random((T, B, nc)), 0.3 + 0.2 * rng.random((T, B, nc))
+        lo, hi = lo.astype(np.float32).astype(np.float64), hi.astype(np.float32).astype(np.float64)
+    x, u = cur_x, cur_u
+    for _ in range(4):
+        sol = O.lqr_step(lockstep=False, cur_x=x, cur_u=u, u_lower=lo, u_upper=hi, **pr)
+        x, u = sol["new_x"], sol["new_u"]
+    x, u = x.astype(np.float32).astype(np.float64), u.astype(np.float32).astype(np.float64)
+    dl_dx, dl_du = rng.standard_normal((T, B, ns)), rng.standard_normal((T, B, nc))
+    o = O.kkt_backward(pr["C"], pr["c"], pr["F"], pr["f"], x, u, dl_dx, dl_du, lo, hi, lockstep=False)
+    if bounded and T > 2:
+        act = np.abs(np.abs(u) - 0.4) <= 1e-8 if "tensor" not in parts else (np.abs(u - lo) <= 1e-8) | (np.abs(u - hi) <= 1e-8)
+        assert 0.01 < act.mean() < 0.97, act.mean()
+    # (pad = 16: the 16-byte gathers of lqr_mfma40_pad16kkt.o, for shapes whose rows and x | u boundary sit on 16 bytes)
+    for dma_late, pad in ((False, 4), (True, 4)) + (((True, 16),) if ns % 4 == 0 and nc % 4 == 0 else ()):
+        r = emu.kkt_fused_mfma40(pr["C"], pr["c"], pr["F"], pr["f"], x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, pad=pad)
+        wide = 20.0 if "nonconvex" in parts else 2.0
+        for k in ("dx", "du", "dC", "dc", "dF", "dx_init") + (("df",) if pr["f"] is not None and T > 1 else ()):
+            if o[k] is None or o[k].size == 0:
+                continue
+            assert np.isfinite(r[k]).all(), (k, dma_late, pad)
+            np.testing.assert_allclose(r[k], o[k], rtol=1e-4 * wide, atol=1e-4 * wide * max(1.0, np.abs(o[k]).max()), err_msg="%s %s %s" % (k, dma_late, pad))
+

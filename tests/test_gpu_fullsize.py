@@ -809,3 +809,54 @@ def test_fused_kkt_backward_on_padded_dpp16_shapes_vs_oracle(be, ns, nc, B, T, m
         rel = (np.abs(a - o[k]) / scale).max(axis=ax)
         assert rel.max() < 2e-4, "%s: problem %d off by %.2e of its scale" % (k, int(rel.argmax()), rel.max())
 
+
+@pytest.mark.parametrize("mode", ["unbounded", "scalar", "tensor"])
+@pytest.mark.parametrize("ns,nc,B,T", [(13, 4, 130, 20), (20, 5, 97, 20), (24, 8, 64, 12), (32, 7, 33, 12), (5, 8, 70, 9), (32, 8, 40, 12)])
+def test_fused_kkt_backward_on_padded_mfma40_shapes_vs_oracle(be, ns, nc, B, T, mode):
+    """The 32/8 kernel's fused KKT backward, PADDED instantiation (round 6, lqr_mfma40_padkkt.o): LQRStepFn.backward (mpc/lqr_step.py:312-407)
+    as the nested step with the costates riding along + the outer-product kernel, at any shape up to 32/8 beyond 12/4 under
+    MPC_OPT_C_SYMMETRIC, in float32 against the float64 oracle fed the very same (x*, u*, dl_dx, dl_du): scalar and tensor bounds, and 32/8
+    itself with blocks OFF the 16-byte grid (which the exact kernel refuses).  The gradient buffers are pre-filled with NaN."""
+    import bench
+    from mpc._native import StepOptions
+    from oracle import lqr_oracle as O
+    bounded = mode != "unbounded"
+    p = bench.make_problem(ns, nc, T, B, torch.float32, DEV, seed=14 + ns, u_scale=0.3 if bounded else 0.0, clamp=1.0 if bounded else None)
+    if (ns, nc) == (32, 8):
+        for k in ("C", "F", "c"):
+            buf = torch.empty(p[k].numel() + 1, device=DEV, dtype=torch.float32)
+            buf[1:].copy_(p[k].reshape(-1))
+            p[k] = buf[1:].view(p[k].shape)
+            assert p[k].data_ptr() % 16 == 4
+    lo = hi = None
+    if mode == "scalar":
+        opts = StepOptions(u_lower=-1.0, u_upper=1.0, c_symmetric=True)
+    elif mode == "tensor":
+        g0 = torch.Generator(device=DEV).manual_seed(9)
+        lo = -0.8 - 0.4 * torch.rand(T, B, nc, generator=g0, device=DEV)
+        hi = 0.8 + 0.4 * torch.rand(T, B, nc, generator=g0, device=DEV)
+        opts = StepOptions(u_lower=lo, u_upper=hi, c_symmetric=True)
+    else:
+        opts = StepOptions(c_symmetric=True)
+    r = be.lqr_step(p["x_init"], p["C"], p["c"], p["F"], p["f"], p["cur_x"], p["cur_u"], opts)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    gx = torch.randn(tuple(r["new_x"].shape), generator=g, device=DEV)
+    gu = torch.randn(tuple(r["new_u"].shape), generator=g, device=DEV)
+    plan = be.plan_kkt_backward(p["C"], p["c"], p["F"], p["f"], r["new_x"], r["new_u"], gx, gu, opts)
+    assert plan is not None, "the fused backward must cover every shape up to 32/8"
+    for k in ("dx_init", "dC", "dc", "dF", "df", "dx", "du"):
+        plan.outputs[k].fill_(float("nan"))
+    got = plan()
+    assert got is not None
+    sync()
+    o = O.kkt_backward(h64(p["C"]), h64(p["c"]), h64(p["F"]), h64(p["f"]), h64(r["new_x"]), h64(r["new_u"]), h64(gx), h64(gu),
+                       (h64(lo) if lo is not None else -1.0) if bounded else None, (h64(hi) if hi is not None else 1.0) if bounded else None,
+                       lockstep=False, nthreads=O.max_threads())
+    for k in ("dx_init", "dC", "dc", "dF", "df", "dx", "du"):
+        a = host(got[k]).astype(np.float64)
+        assert np.isfinite(a).all(), k
+        ax = tuple(i for i in range(a.ndim) if i != (0 if k == "dx_init" else 1))
+        scale = np.maximum(1.0, np.abs(o[k]).max(axis=ax, keepdims=True))
+        rel = (np.abs(a - o[k]) / scale).max(axis=ax)
+        assert rel.max() < 3e-4, "%s: problem %d off by %.2e of its scale" % (k, int(rel.argmax()), rel.max())
+

@@ -3,7 +3,7 @@
 kkt_fused_wave of lqr_mfma40_body.h) on the CPU wavefront emulator against LQRStepFn.backward of the float64 oracle over random
 horizons (across the 64-step limit of the register-resident gains), ragged batches, bounds (none / scalar / tensor), f on / off,
 ring variants.  The solution differentiated at is a few oracle LQR steps from a random nominal.  Exits non-zero on a violation.
-    python tools/emu_fuzz_kkt.py [cases [seed [dpp16|dpp16_pad|mfma40]]]
+    python tools/emu_fuzz_kkt.py [cases [seed [dpp16|dpp16_pad|mfma40|mfma40_pad]]]
 dpp16_pad (round 6): random shapes n_state <= 12, n_ctrl <= 4 through the padded instantiation (kernel "dpp16_pad" of the emulator; on the
 GPU whatever impl 0 routes the shape to -- the padded fused kernel under c_symmetric, the three-launch route without).
 FUZZ_GPU=1: the same cases through mpc_lqr_kkt_fused / the three-launch route on the MI355X (c_symmetric on or off, float32)."""
@@ -45,14 +45,18 @@ for case in ([int(only)] if only else range(cases)):
     ns, nc = (32, 8) if which == "mfma40" else (12, 4)
     if which == "dpp16_pad":
         ns, nc = int(rng.integers(1, 13)), int(rng.integers(1, 5))
+    if which == "mfma40_pad":          # (round 6) the padded 32/8 fused backward: a shape beyond 12/4
+        ns, nc = int(rng.integers(1, 33)), int(rng.integers(1, 9))
+        if ns <= 12 and nc <= 4:
+            ns = int(rng.integers(13, 33))
     n = ns + nc
-    T = int(rng.choice([1, 2, 3, 5, 8, 20, 40, 66]) if which == "mfma40" else rng.choice([1, 2, 3, 4, 6, 7, 9, 17, 33, 63, 64, 65, 70]))
-    if which == "dpp16_pad" and ns <= 2 and T > 33:
+    T = int(rng.choice([1, 2, 3, 5, 8, 20, 40, 66]) if which.startswith("mfma40") else rng.choice([1, 2, 3, 4, 6, 7, 9, 17, 33, 63, 64, 65, 70]))
+    if which in ("dpp16_pad", "mfma40_pad") and ns <= 2 and T > 33:
         # one or two states over 60-70 timesteps of x+ = (1 +- 0.2) x: the cost-to-go spans ten orders of magnitude along the horizon and
         # float32 -- ANY float32 implementation: the generic kernel and the one-problem-per-wavefront kernel miss the float64 answer of
         # such a problem by 4e-4 ... 1.5e-3 like the padded kernel, tools/fuzz_case_probe.py 198 67 -- has no digits left for it
         T = 33
-    B = int(rng.choice([1, 2, 3] + ([17, 40] if GPU else []))) if which == "mfma40" else int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9] + ([33, 130] if GPU else [])))
+    B = int(rng.choice([1, 2, 3] + ([17, 40] if GPU else []))) if which.startswith("mfma40") else int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9] + ([33, 130] if GPU else [])))
     Tm = max(T, 2)
     A = rng.standard_normal((Tm, B, n, n)); C = np.einsum("tbji,tbjk->tbik", A, A)
     c = rng.standard_normal((Tm, B, n))
@@ -88,6 +92,9 @@ for case in ([int(only)] if only else range(cases)):
     elif which == "mfma40":
         r = emu.kkt_fused_mfma40(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, sweep3=True)
         label = "mfma40"
+    elif which == "mfma40_pad":
+        r = emu.kkt_fused_mfma40(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, pad=4)
+        label = "mfma40_pad %d/%d" % (ns, nc)
     elif which == "dpp16_pad":
         r = emu.kkt_fused(C, c, F, f, x, u, dl_dx, dl_du, lo, hi, dma_late=dma_late, kernel="dpp16_pad")
         label = "dpp16_pad %d/%d" % (ns, nc)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# TAG=r06_gpu_fuzz [KKT=1] [N1= N2= N3= K1= K2= K3=] bash tools/gpu_fuzz.sh   (on the GPU box): logs under gpurun_out/$TAG
+# TAG=r06_gpu_fuzz [KKT=1] [N1= N2= N3= K1= K2= K3= K4=] bash tools/gpu_fuzz.sh   (on the GPU box): logs under gpurun_out/$TAG
 # tools/emu_fuzz.py's random option sets through the C ABI on the GPU (FUZZ_GPU=1)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${TAG:-r06_gpu_fuzz}; mkdir -p $O
@@ -11,5 +11,6 @@ if [ -n "$KKT" ]; then
 FUZZ_GPU=1 timeout 600 python tools/emu_fuzz_kkt.py ${K1:-1500} 64 dpp16 > $O/kkt_12_4.log 2>&1; echo "kkt 12/4 rc=$?"; tail -1 $O/kkt_12_4.log
 FUZZ_GPU=1 timeout 600 python tools/emu_fuzz_kkt.py ${K3:-1500} 66 dpp16_pad > $O/kkt_pad12.log 2>&1; echo "kkt <=12/4 rc=$?"; tail -1 $O/kkt_pad12.log
 FUZZ_GPU=1 timeout 600 python tools/emu_fuzz_kkt.py ${K2:-500} 65 mfma40 > $O/kkt_32_8.log 2>&1; echo "kkt 32/8 rc=$?"; tail -1 $O/kkt_32_8.log
+FUZZ_GPU=1 timeout 600 python tools/emu_fuzz_kkt.py ${K4:-500} 67 mfma40_pad > $O/kkt_pad40.log 2>&1; echo "kkt <=32/8 rc=$?"; tail -1 $O/kkt_pad40.log
 grep -h "VIOLATION" $O/kkt_*.log | cut -c1-300 | head
 fi

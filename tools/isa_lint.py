@@ -21,12 +21,14 @@ FLAGS = {"lqr_dpp16": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DMPC_DPP16_NO_KKT"]
          "lqr_dpp16_padkkt": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DMPC_DPP16_NSTAGE=2", "-DMPC_DPP16_NO_KKT", "-DMPC_DPP16_PAD", "-DMPC_DPP16_PAD_KKT",
                               "-DMPC_KF_LDS_BYTES=36864"],
          "lqr_mfma40_kkt": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DMPC_MFMA40_KKT"],
+         "lqr_mfma40_padkkt": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DMPC_MFMA40_SWEEP_NSTAGE=2", "-DMPC_MFMA40_PAD=4", "-DMPC_MFMA40_KKT"],
+         "lqr_mfma40_pad16kkt": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DMPC_MFMA40_SWEEP_NSTAGE=2", "-DMPC_MFMA40_PAD=16", "-DMPC_MFMA40_KKT"],
          "lqr_mfma40_ring2": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DMPC_MFMA40_SWEEP_NSTAGE=2"],
          "lqr_mfma40_pad4": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DMPC_MFMA40_SWEEP_NSTAGE=2", "-DMPC_MFMA40_PAD=4"],
          "lqr_mfma40_pad16": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-DMPC_MFMA40_SWEEP_NSTAGE=2", "-DMPC_MFMA40_PAD=16"]}
-SOURCES = {"lqr_dpp16_ring2": "lqr_dpp16", "lqr_dpp16_pad": "lqr_dpp16", "lqr_dpp16_padkkt": "lqr_dpp16", "lqr_mfma40_kkt": "lqr_mfma40", "lqr_mfma40_ring2": "lqr_mfma40", "lqr_mfma40_pad4": "lqr_mfma40",
+SOURCES = {"lqr_dpp16_ring2": "lqr_dpp16", "lqr_dpp16_pad": "lqr_dpp16", "lqr_dpp16_padkkt": "lqr_dpp16", "lqr_mfma40_kkt": "lqr_mfma40", "lqr_mfma40_padkkt": "lqr_mfma40", "lqr_mfma40_pad16kkt": "lqr_mfma40", "lqr_mfma40_ring2": "lqr_mfma40", "lqr_mfma40_pad4": "lqr_mfma40",
            "lqr_mfma40_pad16": "lqr_mfma40"}
-FAST = ["lqr_dpp16", "lqr_dpp16_ring2", "lqr_dpp16_pad", "lqr_dpp16_padkkt", "lqr_mfma40", "lqr_mfma40_ring2", "lqr_mfma40_kkt", "lqr_mfma40_pad4", "lqr_mfma40_pad16", "lqr_mfma16", "lqr_tiny",
+FAST = ["lqr_dpp16", "lqr_dpp16_ring2", "lqr_dpp16_pad", "lqr_dpp16_padkkt", "lqr_mfma40", "lqr_mfma40_ring2", "lqr_mfma40_kkt", "lqr_mfma40_padkkt", "lqr_mfma40_pad16kkt", "lqr_mfma40_pad4", "lqr_mfma40_pad16", "lqr_mfma16", "lqr_tiny",
         "kkt_wave"]
 
 
