@@ -1361,8 +1361,8 @@ def test_emulated_float64_kernel_flags_a_C_symmetric_to_float32_rounding_only(em
     assert ((r32["status"] & 8) == 0).all()
 
 
-@pytest.mark.parametrize("kernel", ["dpp16", "dpp16_ring2"])
-@pytest.mark.parametrize("max_ls,decay", [(10, 0.2), (4, 0.5), (3, 0.5)])
+# (the two-slot ring build runs one of the three settings: the suite's time)
+@pytest.mark.parametrize("kernel,max_ls,decay", [("dpp16", 10, 0.2), ("dpp16", 4, 0.5), ("dpp16", 3, 0.5), ("dpp16_ring2", 4, 0.5)])
 def test_emulated_dpp16_rows_that_never_improve_end_on_the_parked_last_trial(emu, kernel, max_ls, decay):
     """The box-constrained line search of the 12/4 kernel with rows of one wavefront ending everywhere: the full step, alpha =
     decay (copied out of the workspace), a middle trial (replayed) and -- round 5 -- the LAST trial of the multi-trial pass, whose

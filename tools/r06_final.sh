@@ -10,3 +10,5 @@ MPC_BENCH_FORCE_DIST=1 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench
 TAG=r06_final/fuzz KKT=1 N1=${N1:-6000} N2=${N2:-2500} N3=${N3:-1500} K1=${K1:-3000} K2=${K2:-800} bash tools/gpu_fuzz.sh
 FUZZ_GPU=1 timeout 900 python tools/emu_fuzz.py ${N4:-5000} 81 dpp16_pad > $O/fuzz/pad12.log 2>&1; echo "pad12 rc=$?"; tail -1 $O/fuzz/pad12.log
 FUZZ_GPU=1 FUZZ_LONG_T=1 timeout 900 python tools/emu_fuzz.py ${N5:-1500} 82 dpp16_pad > $O/fuzz/pad12_long.log 2>&1; echo "pad12 long rc=$?"; tail -1 $O/fuzz/pad12_long.log
+python tools/pad12_kkt_bench.py > $O/pad12_kkt_bench.log 2>&1; tail -8 $O/pad12_kkt_bench.log
+python tools/pad40_kkt_bench.py > $O/pad40_kkt_bench.log 2>&1; tail -10 $O/pad40_kkt_bench.log
