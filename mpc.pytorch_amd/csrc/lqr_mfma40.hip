@@ -17,6 +17,7 @@ MPC_DEV float readlane(float x, int l) { return __int_as_float(__builtin_amdgcn_
 MPC_DEV float shfl_xor(float x, int m) { return __shfl_xor(x, m, 64); }
 MPC_DEV bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 MPC_DEV bool any(bool c) { return __ballot(c) != 0ull; }
+MPC_DEV unsigned long long ballot(bool c) { return __ballot(c); }
 // sum over the four 16-lane rows, result in every lane: two row swaps (gfx950 v_permlane{16,32}_swap), no LDS
 MPC_DEV float sum_rows(float x)
 {

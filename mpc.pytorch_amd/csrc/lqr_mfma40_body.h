@@ -155,7 +155,8 @@ constexpr int KSLOTS = 3, KDMA_PER_STAGE_EXACT = 10;           // 5 (F) + 1 (K) 
 #endif
 #ifndef MPC_KF40_VFULL
 // pass 2 of the fused backward: F (gathered in the padded instantiation: CH_F instructions) + K + record + three V tiles
-constexpr int KDMA_PER_STAGE = PADK ? CH_F + 5 : KDMA_PER_STAGE_EXACT;
+// (+ 3 in the padded instantiation: u*_t and its tensor bounds, words 0..23 of the record, for the pinned set -- kkt_pinned_lds)
+constexpr int KDMA_PER_STAGE = PADK ? CH_F + 5 + 3 : KDMA_PER_STAGE_EXACT;
 static_assert((KSLOTS - 2) * KDMA_PER_STAGE < 64, "vmcnt is 6 bits");
 #endif
 // the constrained modes' record for the rollout that prices without C (rollout_priced): floats per problem-step
@@ -264,8 +265,30 @@ MPC_DEV void rec_init_kkt(RecMap &m, const P &p, int lane, long b, const float *
             if (w - 72 < nc) { m.act[j] = true; m.ptr[j] = (const char *)(p.cur_u + b * nc + (w - 72)); m.step[j] = (long)p.B * nc * 4; }
         } else if (w < 112) {
             if (w - 80 < ns) { m.act[j] = true; m.ptr[j] = (const char *)(p.c + b * p.c_sb + (w - 80)); m.step[j] = p.c_st * 4; }
+        } else if (p.bound_mode == MPC_BOUND_TENSOR) {
+            // words 112..119 u_lower_t, 120..127 u_upper_t: the pinned set is decided from the record (kkt_pinned_lds)
+            const int a = (w - 112) & 7;
+            if (a < nc) { m.act[j] = true; m.ptr[j] = (const char *)((w < 120 ? p.lo : p.hi) + b * nc + a); m.step[j] = (long)p.B * nc * 4; }
         }
     }
+}
+// The padded fused backward decides its pinned set from LDS: lane a < 8 of the wave looks at u*[a] and its bounds where the stage
+// holds them (byte offsets of the three 8-word blocks), a ballot makes the two flag words kkt_pinned_word would have assembled from
+// 8-24 scalar loads at the true n_ctrl -- those, live across the inlined sweep, spilled 364 scalar registers and put the masked kernel
+// at 1.3x the unmasked one (the exact kernel: 1.1x).
+MPC_DEV void kkt_pinned_lds(const P &p, unsigned u_off, unsigned lo_off, unsigned hi_off, int lane, unsigned &zlo, unsigned &zhi)
+{
+    const int a = lane & 7;
+    const float u = wv::lds_f32(u_off + 4u * (unsigned)a);
+    float lo = p.lo_s, hi = p.hi_s;
+    if (p.bound_mode != MPC_BOUND_SCALAR) {
+        lo = wv::lds_f32(lo_off + 4u * (unsigned)a);
+        hi = wv::lds_f32(hi_off + 4u * (unsigned)a);
+    }
+    const bool pinned = (fabsf(u - lo) <= 1e-8f || fabsf(u - hi) <= 1e-8f) && a < p.nc && lane < 8;
+    const unsigned m = (unsigned)wv::ballot(pinned);
+    zlo = ((m & 1u) ? 1u : 0u) | ((m & 2u) ? 1u << 8 : 0u) | ((m & 4u) ? 1u << 16 : 0u) | ((m & 8u) ? 1u << 24 : 0u);
+    zhi = ((m & 16u) ? 1u : 0u) | ((m & 32u) ? 1u << 8 : 0u) | ((m & 64u) ? 1u << 16 : 0u) | ((m & 128u) ? 1u << 24 : 0u);
 }
 MPC_DEV void rec_issue(const RecMap &m, long tl, long tf, long tx, unsigned off, bool skip_c = false, int lane = 0)
 {
@@ -1141,8 +1164,13 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
         if (MODE == 0) {
             // (k comes out of the first of the two K solves below: lane rows 2, 3 carry qu as their right-hand side)
         } else if (MODE == 1) {                          // :99-127: pinned controls drop out of the solve
-            const unsigned zlo = KKT ? kkt_pinned_word(p, tb, 0) : zero_mask_word(p, tb, 0);
-            const unsigned zhi = KKT ? kkt_pinned_word(p, tb, 1) : zero_mask_word(p, tb, 1);
+            unsigned zlo, zhi;
+            if (PADK && KKT) {
+                kkt_pinned_lds(p, base + OFF_R + 4u * 72u, base + OFF_R + 4u * 112u, base + OFF_R + 4u * 120u, L.lane, zlo, zhi);
+            } else {
+                zlo = KKT ? kkt_pinned_word(p, tb, 0) : zero_mask_word(p, tb, 0);
+                zhi = KKT ? kkt_pinned_word(p, tb, 1) : zero_mask_word(p, tb, 1);
+            }
             float frf[8];
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
@@ -1549,6 +1577,7 @@ struct RStream {
     long c_step, f_step, k_step;
     unsigned r_step, lo;
     bool r_active, r_is_f, r_is_x;
+    long bidx;                              // the problem (padded fused backward: kstage_issue's u* and bounds)
     // padded instantiation: gathers instead (see Stream)
     const float *Cb, *Fb;
     Gather g;
@@ -2362,6 +2391,17 @@ MPC_DEV void kstage_issue(const P &p, const RStream &d, const char *v_ptr, long 
     else dma_kib<5>(d.f_ptr + tf * d.f_step + d.lo, base + KOFF_F);
     wv::dma16(d.k_ptr + tl * d.k_step + d.lo, base + KOFF_K);
     wv::dma16_if(d.r_active, d.r_ptr + rec_off(d.r_is_x ? tx : tl, d.r_step), base + KOFF_R);
+    if (PADK) {
+        // u*_t | u_lower_t | u_upper_t (tensor bounds; u* again otherwise: the instruction count of a stage is fixed), lane a < n_ctrl
+        const int nc = p.nc;
+        const unsigned lane = d.lo >> 4;
+        const bool act = (int)lane < nc;
+        const long o = ((long)tl * p.B + d.bidx) * nc + (act ? (int)lane : 0);
+        const bool tb_ = p.bound_mode == MPC_BOUND_TENSOR;
+        wv::dma4_if(act, p.cur_u + o, base + KOFF_R);
+        wv::dma4_if(act, (tb_ ? p.lo : p.cur_u) + o, base + KOFF_R + 32);
+        wv::dma4_if(act, (tb_ ? p.hi : p.cur_u) + o, base + KOFF_R + 64);
+    }
 #ifdef MPC_KF40_VFULL
     dma_kib<4>(v_ptr + tx * v_step + d.lo, base + KOFF_V);
 #else
@@ -2384,6 +2424,7 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
     RStream d;
     d.c_ptr = nullptr; d.c_step = 0;
     d.lo = 16u * (unsigned)L.lane;
+    d.bidx = L.b;
     if (PADK) {
         d.Cb = p.C + (long)L.b * p.C_sb;
         d.Fb = T > 1 ? p.F + (long)L.b * p.F_sb : d.Cb;
@@ -2532,7 +2573,13 @@ MPC_DEV void kkt_pass2(const P &p, const Lane &L, const float *Kin, const float 
         {
             unsigned zw = 0u;                    // the pinned flags of controls 4q .. 4q+3
             if (MODE == 1) {
-                const unsigned zlo = kkt_pinned_word(p, tb, 0), zhi = kkt_pinned_word(p, tb, 1);
+                unsigned zlo, zhi;
+                if (PADK) {
+                    kkt_pinned_lds(p, rec, rec + 32, rec + 64, L.lane, zlo, zhi);
+                } else {
+                    zlo = kkt_pinned_word(p, tb, 0);
+                    zhi = kkt_pinned_word(p, tb, 1);
+                }
                 zw = L.q == 0 ? zlo : zhi;
             }
 #pragma unroll

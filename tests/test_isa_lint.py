@@ -73,11 +73,11 @@ SGPR_SPILL_LIMITS = {
     # (round 4: block addresses as scalar arithmetic -- two more base pointers live in the two-slot build of mode 0)
     "lqr_mfma40_ring2": {"kernelILi0E": 100, "kernelILi1E": 105, "kernelILi2E": 150},
     "lqr_mfma40_kkt": {"kernelILi0E": 55, "kernelILi1E": 115},
-    # (round 6) the padded fused backward, dword / 16-byte gathers: the gathers' descriptors and M0 values as in the padded step kernels, and
-    # in the masked kernel the pinned set from u* and the bounds by the true n_ctrl (eight scalar loads a word).  The spills execute per
-    # timestep: the masked kernel is 1.3x its unmasked time (the exact kernel: 1.1x) -- what `mpc_lqr_kkt_fused` still beats is the three-launch route
-    "lqr_mfma40_padkkt": {"kernelILi0E": 150, "kernelILi1E": 400},
-    "lqr_mfma40_pad16kkt": {"kernelILi0E": 140, "kernelILi1E": 390},
+    # (round 6) the padded fused backward, dword / 16-byte gathers: the gathers' descriptors and M0 values as in the padded step kernels.
+    # (The masked kernel first assembled its pinned set from 8-24 scalar loads at the true n_ctrl, live across the inlined sweep: 364 spills
+    # and 1.3x the unmasked kernel's time; from the staged record by one ballot -- kkt_pinned_lds -- it is 160 and 1.07x.)
+    "lqr_mfma40_padkkt": {"kernelILi0E": 170, "kernelILi1E": 180},
+    "lqr_mfma40_pad16kkt": {"kernelILi0E": 160, "kernelILi1E": 165},
     # the padded instantiation (round 4): every gather instruction wants a 128-bit descriptor and an M0 -- 47 of them a stage in the
     # dword build; the ceilings are what that costs in scalar registers (none of it in vector spills or scratch)
     "lqr_mfma40_pad4": {"kernelILi0E": 380, "kernelILi1E": 700, "kernelILi2E": 930},
