@@ -28,3 +28,16 @@ def golden(name):
 @pytest.fixture
 def load_golden():
     return golden
+
+
+@pytest.fixture(scope="session")
+def emu_libs():
+    """tests/emu_backend.py's four emulator libraries, built in parallel before the first test that runs a kernel body on the CPU."""
+    import shutil
+    if not (os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or shutil.which("clang++")):
+        pytest.skip("the emulator needs clang++")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_backend
+    emu_backend.build_all()
+    return emu_backend
+

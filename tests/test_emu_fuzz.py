@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("kernels,cases,long_t", [("dpp16,dpp16_ring2,mfma16", 150, False), ("mfma40,mfma40_ring2", 24, False),
                                                    ("dpp16,dpp16_ring2", 24, True),
                                                    ("mfma16_f64", 60, False), ("mfma40_pad", 20, False), ("dpp16_pad", 80, False), ("dpp16_pad", 16, True)])
-def test_emulated_bodies_on_random_option_sets(kernels, cases, long_t):
+def test_emulated_bodies_on_random_option_sets(emu_libs, kernels, cases, long_t):
     if not (os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or __import__("shutil").which("clang++")):
         pytest.skip("the emulator needs clang++")
     env = dict(os.environ)
@@ -27,7 +27,7 @@ def test_emulated_bodies_on_random_option_sets(kernels, cases, long_t):
 
 
 @pytest.mark.parametrize("which,cases", [("dpp16", 40), ("dpp16_pad", 40), ("mfma40", 16), ("mfma40_pad", 12)])
-def test_emulated_kkt_backward_on_random_option_sets(which, cases):
+def test_emulated_kkt_backward_on_random_option_sets(emu_libs, which, cases):
     """tools/emu_fuzz_kkt.py: the fused KKT backward bodies against LQRStepFn.backward of the oracle -- horizons across the 64-step
     limit of the register-resident gains, ragged batches, bounds of every kind, f on / off, both ring builds; dpp16_pad: random shapes
     up to 12/4 through the padded instantiation (round 6)."""

@@ -38,7 +38,7 @@ def _split_asymmetric(r, o, z):
 
 
 @pytest.fixture(scope="module")
-def emu():
+def emu(emu_libs):
     import emu_backend
     emu_backend.lib()
     return emu_backend

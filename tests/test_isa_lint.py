@@ -17,6 +17,13 @@ pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") and sh
                                 reason="needs hipcc")
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _assemblies():
+    """Every compilation the checks below look at, assembled side by side (a cold cache took 3:45 one after the other)."""
+    import isa_lint
+    isa_lint.prefetch(sorted(set(isa_lint.FAST) | set(SGPR_SPILL_LIMITS) | {"nn_dynamics"}))
+
+
 def _findings(name):
     import isa_lint
     lines = isa_lint.assembly(name)

@@ -44,6 +44,15 @@ def assembly(name, out="/tmp/isa_lint"):
     return open(s).read().split("\n")
 
 
+def prefetch(names=None, workers=6):
+    """Build the assembly of several compilations at once (a cold cache costs 15-25 s a compilation one after the other; the CPU test
+    suite wants all of them)."""
+    from concurrent.futures import ThreadPoolExecutor
+    names = list(names or FAST)
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        list(ex.map(assembly, names))
+
+
 def structure(lines):
     kernels = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
     labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
@@ -61,7 +70,8 @@ _DMA_LOOPS = {}
 def in_timestep_loop(lines, loops, i):
     """Is line i inside a loop over timesteps?  = the smallest enclosing loop that stages data (has an LDS-DMA in its
     body) and has no other staging loop nested inside it (the loop over line-search passes does)."""
-    key = id(lines)
+    # (keyed by content, not by id(): a freed list's id is handed to the next one -- seen once the test suite assembled in parallel)
+    key = (len(lines), hash(lines[len(lines) // 2]), hash(tuple(lines[:40])), len(loops))
     if key not in _DMA_LOOPS:
         _DMA_LOOPS[key] = [(a, b) for a, b in loops if any("_load_lds_" in x or (x.lstrip().startswith("buffer_load") and x.rstrip().endswith(" lds")) for x in lines[a:b])]
     dma = _DMA_LOOPS[key]
