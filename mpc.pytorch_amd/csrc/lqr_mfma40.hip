@@ -149,6 +149,16 @@ template <int IMM> MPC_DEV void dma16_once_at(const void *g, unsigned off)
 // G bytes per lane from `base + voff` (base wave-uniform: a raw buffer of `nbytes`, voff per lane) to LDS offset `off` + G * lane.
 // A lane whose voff lies beyond the buffer writes ZERO (the hardware's range check; measured, tools/ubench/buffer_lds_probe.hip):
 // that is the zero padding of the kernel's 40 x 40 / 32 x 40 blocks, at no instruction.
+// a wave-uniform pointer / word the compiler has moved to vector registers, back in scalar ones (two / one v_readfirstlane): the dword build's
+// C block address is computed on the vector ALU next to the timestep counter, and a buffer descriptor made from it was then wrapped in a
+// readfirstlane LOOP -- per gather, 25 a timestep (round 6)
+MPC_DEV const void *uniform_ptr(const void *q)
+{
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const void *)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+MPC_DEV unsigned uniform_u32(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
 template <int G> MPC_DEV void dma_buf(bool active, const void *base, unsigned nbytes, unsigned voff, unsigned off)
 {
     static_assert(G == 4 || G == 16, "dword or dwordx4");

@@ -193,14 +193,23 @@ MPC_DEV void gather_init(Gather &g, const P &p, int lane)
     }
 }
 // the C_t / F_t block at `blk` (wave-uniform) into the dense 40 x 40 / 32 x 40 layout at LDS offset `off`
-MPC_DEV void gather_C(const Gather &g, const float *blk, unsigned off, int lane)
+MPC_DEV void gather_C(const Gather &g, const float *blk_, unsigned off, int lane)
 {
+    const float *blk = (const float *)wv::uniform_ptr(blk_);
+    const unsigned cbytes = wv::uniform_u32(g.cbytes);
 #pragma unroll
-    for (int k = 0; k < CH_C; ++k)
-        wv::dma_buf<PADG>((64 * k + lane) * (PADG / 4) < N * N, blk, g.cbytes, g.coff[k], off + (unsigned)(64 * PADG * k));
+    for (int k = 0; k < CH_C; ++k) {
+        // (a chunk that lies inside the block whole takes every lane: with the lane test in front of it -- always true, but not to the
+        // compiler -- hipcc kept the dword build's descriptor in vector registers and wrapped each of the 25 gathers in a readfirstlane
+        // loop: 300 instructions a timestep, round 6)
+        const bool whole = 64 * (k + 1) * (PADG / 4) <= N * N;
+        wv::dma_buf<PADG>(whole || (64 * k + lane) * (PADG / 4) < N * N, blk, cbytes, g.coff[k], off + (unsigned)(64 * PADG * k));
+    }
 }
-MPC_DEV void gather_F(const Gather &g, const float *blk, unsigned nbytes, unsigned off)
+MPC_DEV void gather_F(const Gather &g, const float *blk_, unsigned nbytes_, unsigned off)
 {
+    const float *blk = (const float *)wv::uniform_ptr(blk_);
+    const unsigned nbytes = wv::uniform_u32(nbytes_);
 #pragma unroll
     for (int k = 0; k < CH_F; ++k) wv::dma_buf<PADG>(true, blk, nbytes, g.foff[k], off + (unsigned)(64 * PADG * k));
 }

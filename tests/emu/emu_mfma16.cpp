@@ -438,6 +438,8 @@ static inline bool any(bool c)
 }
 static inline void store_f32x4(float *g, f32x4 v) { memcpy(g, &v, 16); }
 static inline void store_f32x4_grad(float *g, f32x4 v) { memcpy(g, &v, 16); }
+static inline const void *uniform_ptr(const void *q) { return q; }
+static inline unsigned uniform_u32(unsigned x) { return x; }
 static inline void store_f32_out(float *g, float v) { *g = v; }
 static inline void store_f32_grad(float *g, float v) { *g = v; }
 static inline bool uniform(bool c)
