@@ -169,10 +169,19 @@ template <int G> MPC_DEV void dma_buf(bool active, const void *base, unsigned nb
     }
 }
 // a dword to `base + voff` through a raw buffer of `nbytes`: a lane whose voff lies beyond the buffer stores nothing
+MPC_DEV const void *uniform_ptr(const void *q);
+MPC_DEV unsigned uniform_u32(unsigned x);
 MPC_DEV void st_buf(float *base, unsigned nbytes, unsigned voff, float v)
 {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)nbytes, 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)voff, 0, 0);
+}
+// ... where `base` is the same for every lane of the wave (a row of one problem and timestep): the address is wave-uniform, but the compiler
+// computes it next to the timestep counter on the vector ALU and then wraps the store in a readfirstlane loop -- see uniform_ptr.  (st_buf
+// itself stays general: the copy-out of a parked trajectory addresses a different row per lane.)
+MPC_DEV void st_buf_u(float *base, unsigned nbytes, unsigned voff, float v)
+{
+    st_buf((float *)uniform_ptr(base), uniform_u32(nbytes), voff, v);
 }
 MPC_DEV void dma4_if(bool active, const void *g, unsigned off)
 {

@@ -330,7 +330,7 @@ MPC_DEV void st_x4(const P &p, long tb, int i0, f32x4 v)
 {
     if (PADK) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wv::st_buf(p.new_x + tb * p.ns, (unsigned)(4 * p.ns), (unsigned)(4 * (i0 + e)), v[e]);
+        for (int e = 0; e < 4; ++e) wv::st_buf_u(p.new_x + tb * p.ns, (unsigned)(4 * p.ns), (unsigned)(4 * (i0 + e)), v[e]);
     } else {
         wv::store_f32x4(p.new_x + tb * NS + i0, v);
     }
@@ -339,7 +339,7 @@ MPC_DEV void st_u4(const P &p, long tb, int a0, f32x4 v)
 {
     if (PADK) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wv::st_buf(p.new_u + tb * p.nc, (unsigned)(4 * p.nc), (unsigned)(4 * (a0 + e)), v[e]);
+        for (int e = 0; e < 4; ++e) wv::st_buf_u(p.new_u + tb * p.nc, (unsigned)(4 * p.nc), (unsigned)(4 * (a0 + e)), v[e]);
     } else {
         wv::store_f32x4(p.new_u + tb * NC + a0, v);
     }
@@ -350,7 +350,7 @@ MPC_DEV void st_row4(float *row, int len, int i0, f32x4 v)
 {
     if (PADK) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wv::st_buf(row, (unsigned)(4 * len), (unsigned)(4 * (i0 + e)), v[e]);
+        for (int e = 0; e < 4; ++e) wv::st_buf_u(row, (unsigned)(4 * len), (unsigned)(4 * (i0 + e)), v[e]);
     } else {
         wv::store_f32x4(row + i0, v);
     }

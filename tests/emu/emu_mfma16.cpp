@@ -438,8 +438,15 @@ static inline bool any(bool c)
 }
 static inline void store_f32x4(float *g, f32x4 v) { memcpy(g, &v, 16); }
 static inline void store_f32x4_grad(float *g, f32x4 v) { memcpy(g, &v, 16); }
-static inline const void *uniform_ptr(const void *q) { return q; }
-static inline unsigned uniform_u32(unsigned x) { return x; }
+// v_readfirstlane: what the hardware would hand every lane is lane 0's value -- a call site whose value is NOT wave-uniform then goes wrong
+// here as it does on the GPU (round 6: st_buf with a per-lane row forced uniform was caught by the GPU fuzzer, not by the identity this was)
+static inline unsigned uniform_u32(unsigned x) { return (unsigned)readlane_i((int)x, 0); }
+static inline const void *uniform_ptr(const void *q)
+{
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = uniform_u32((unsigned)v), hi = uniform_u32((unsigned)(v >> 32));
+    return (const void *)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
 static inline void store_f32_out(float *g, float v) { *g = v; }
 static inline void store_f32_grad(float *g, float v) { *g = v; }
 static inline bool uniform(bool c)
@@ -502,6 +509,9 @@ static inline void st_buf(float *base, unsigned nbytes, unsigned voff, float v)
 {
     if ((unsigned long)voff + 4ul <= (unsigned long)nbytes) memcpy((char *)base + voff, &v, 4);
 }
+// (the hardware's v_readfirstlane under a partial exec mask reads the first ACTIVE lane; the emulator's cross-lane operations are wave-wide
+// rendezvous, and these stores sit behind `if (store)` and the like: the uniformity of their rows is the GPU fuzzer's to check)
+static inline void st_buf_u(float *base, unsigned nbytes, unsigned voff, float v) { st_buf(base, nbytes, voff, v); }
 // buffer_load ... lds (the padded 32/8 instantiation's gathers): G bytes per lane from base + voff; a lane whose access lies
 // beyond the buffer's `nbytes` writes ZERO into LDS (the hardware's range check, tools/ubench/buffer_lds_probe.hip)
 template <int G> static inline void dma_buf(bool active, const void *base, unsigned nbytes, unsigned voff, unsigned off)

@@ -185,3 +185,21 @@ def test_network_kernels_stay_in_registers():
     assert len(spills) >= len(names) and all(v == 0 for v in spills)
     # every layer product is on the matrix core
     assert sum(l.strip().startswith("v_mfma_f32_16x16x4") for l in lines) > 500
+
+
+def test_no_memory_instruction_sits_in_a_readfirstlane_loop():
+    """A buffer instruction wants its descriptor in scalar registers.  Where the compiler has computed a wave-uniform address on the
+    vector ALU (next to a loop counter it moved there) it does not complain: it wraps the instruction in a loop -- v_readfirstlane x 4,
+    two compares, s_and_saveexec, the instruction, s_cbranch_execnz -- twelve instructions and a branch per gather or store.  The
+    padded 32/8 kernels' dword build carried 25 of these a timestep from round 4 to round 6 (0.32 against 0.25 ms at 13/4); the cure
+    is wv::uniform_ptr on the address.  No compilation of a fused kernel may contain one around a LOAD or a staging gather.  (Stores are
+    not checked: the copy-out of a parked second trial in the padded 32/8 kernels addresses a different row per lane -- a descriptor per
+    lane is what that loop is for; forcing it uniform there broke 42 of 2,500 fuzz cases within the hour.)"""
+    import isa_lint
+    for tu in isa_lint.FAST:
+        lines = isa_lint.assembly(tu)
+        hits = [i for i, l in enumerate(lines[:-1]) if "s_and_saveexec_b64" in l and
+                any(op in lines[i + 1] for op in ("buffer_load", "_load_lds", "global_load")) and
+                sum("v_readfirstlane_b32" in x for x in lines[max(i - 10, 0):i]) >= 2]
+        assert not hits, (tu, len(hits), lines[hits[0] + 1].strip())
+
