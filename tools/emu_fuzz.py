@@ -156,6 +156,11 @@ for case in range(cases):
     # gradient: 50 |du error|); + the identity's 3e-7 |J_nominal| where a kernel prices that way (12/4, 32/8)
     ident = ekw["kernel"].startswith(("dpp16", "mfma40")) or bool(ekw.get("auto"))
     allowed = 2e-4 * (1 + np.abs(o["costs"])) + 50 * np.abs(r["new_u"] - o["new_u"]).max(axis=(0, 2)) + (3e-7 * np.abs(o["old_costs"]) if ident else 0.0)
+    # + what the problem's own (accepted) state error is worth: a quadratic cost moves by twice the relative error of its trajectory.  Seen
+    # once in 37,000 GPU cases: one state, |x| up to 35, states 4.5e-4 (relative) off -- inside the state tolerance -- and a cost of 4,118
+    # off by 9.4e-4 of itself, 4.5 allowances of the line above
+    xrel = (np.abs(r["new_x"] - o["new_x"]).max(axis=(0, 2)) / (1 + np.abs(o["new_x"]).max(axis=(0, 2))))
+    allowed = allowed + 3.0 * xrel * (1 + np.abs(o["costs"]))
     errs["cost"] = float((np.abs(r["costs"] - o["costs"]) / allowed)[k].max(initial=0))          # (in units of the allowance)
     ctol = 1.0
     # (new_u = u + k + K dx in float32: the error grows with how far the step moves the states, 1e-6 of it)

@@ -59,6 +59,11 @@ for case in ([int(only)] if only else range(cases)):
     B = int(rng.choice([1, 2, 3] + ([17, 40] if GPU else []))) if which.startswith("mfma40") else int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9] + ([33, 130] if GPU else [])))
     Tm = max(T, 2)
     A = rng.standard_normal((Tm, B, n, n)); C = np.einsum("tbji,tbjk->tbik", A, A)
+    if n <= 5:
+        # A'A of a square Gaussian matrix this small is singular to float32 every few hundred draws (ns = 1: the KKT system of a 1/3 problem
+        # over 130 problems missed float64 by 5.5e-4 where the threshold is 3e-4, once in 22,000 padded cases): a ridge keeps the fuzzer on
+        # shapes and options, not on conditioning
+        C = C + 0.3 * np.eye(n)
     c = rng.standard_normal((Tm, B, n))
     F = np.concatenate((np.eye(ns) + 0.2 * rng.standard_normal((Tm - 1, B, ns, ns)) / np.sqrt(ns), rng.standard_normal((Tm - 1, B, ns, nc)) / np.sqrt(ns)), 3)
     f = 0.1 * rng.standard_normal((Tm - 1, B, ns)) if rng.random() < 0.7 else None
