@@ -246,9 +246,17 @@ MPC_DEV void rec_init(RecMap &m, const P &p, int lane, long b, bool with_c, bool
             const int i = w - 80;
             if (with_f && p.f != nullptr && p.T > 1 && i < ns) {
                 m.act[j] = true; m.ptr[j] = (const char *)(p.f + b * p.f_sb + i); m.step[j] = p.f_st * 4; m.kind[j] = 1;
+            } else if (!with_f && !x_next && p.bound_mode == MPC_BOUND_TENSOR && i < 16 && (i & 7) < nc) {
+                // the box-constrained SWEEP (it never looks at f): words 80..87 u_lower_t, 88..95 u_upper_t ride in the record -- as sixteen
+                // scalar loads a timestep they sat in scalar registers across the QP's loop (round 6)
+                m.act[j] = true; m.ptr[j] = (const char *)((i < 8 ? p.lo : p.hi) + b * nc + (i & 7)); m.step[j] = (long)p.B * nc * 4;
             }
         } else if (w < 120) {
             if (kin) { m.act[j] = true; m.ptr[j] = (const char *)(kin + b * NC + (w - 112)); m.step[j] = (long)p.B * NC * 4; }
+            else if (MPC_QP_START && !x_next && p.qp_start && p.bound_mode != MPC_BOUND_NONE && w - 112 < nc) {
+                // mpc_lqr_options.qp_start in the sweep's record, where the exact kernel carries it (strides may be 0)
+                m.act[j] = true; m.ptr[j] = (const char *)(p.qp_start + b * p.qp_start_sb + (w - 112)); m.step[j] = p.qp_start_st * 4;
+            }
         }
     }
 }
@@ -696,7 +704,17 @@ MPC_DEV void box4(Box4 &bx, const P &p, long tb, const Lane &L, const wv::f32x4 
         bx.lo[v] = p.lo_s;
         bx.hi[v] = p.hi_s;
     }
-    if (PADK || p.bound_mode != MPC_BOUND_SCALAR) {
+    if (PADK && p.bound_mode == MPC_BOUND_SCALAR) {
+        // (round 6) padded instantiation, scalar bounds: a control beyond n_ctrl is unbounded -- decided per lane group on the vector ALU
+        // (as sixteen scalar selects the bounds lived in scalar registers across the rollout's timestep and spilled there)
+        const int nc = p.nc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const bool in = 4 * (L.q & 1) + v < nc;
+            bx.lo[v] = in ? p.lo_s : -3e38f;
+            bx.hi[v] = in ? p.hi_s : 3e38f;
+        }
+    } else if (PADK || p.bound_mode != MPC_BOUND_SCALAR) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             bx.lo[v] = pick(L.q == 0, bound_lo(p, tb, v), bound_lo(p, tb, 4 + v));
@@ -1207,7 +1225,16 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
             const bool r8 = L.r < 8;
             const float uav = wv::lds_f32(base + OFF_R + 288 + 4u * (unsigned)(r8 ? L.r : 0));
             float lov = p.lo_s, hiv = p.hi_s;
-            if (PADK || p.bound_mode != MPC_BOUND_SCALAR) {
+            if (PADK) {
+                // (round 6) this lane's own bounds: scalars, or the record's words 80.. / 88.. (rec_init); a control beyond n_ctrl is unbounded
+                const unsigned rr = 4u * (unsigned)(r8 ? L.r : 0);
+                if (p.bound_mode != MPC_BOUND_SCALAR) {
+                    lov = wv::lds_f32(base + OFF_R + 320 + rr);
+                    hiv = wv::lds_f32(base + OFF_R + 352 + rr);
+                }
+                lov = L.r < p.nc ? lov : -3e38f;
+                hiv = L.r < p.nc ? hiv : 3e38f;
+            } else if (p.bound_mode != MPC_BOUND_SCALAR) {
                 float lo8[8], hi8[8];
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {
@@ -1228,18 +1255,10 @@ MPC_DEV double sweep_wave(const P &p, float *Kout, float *kout, double *w0_out =
                 // the caller's start (mpc_lqr_options.qp_start; a hint: the solve ends on a confirmed free set whatever it is).
                 // (The array may be this kernel's own k of an earlier launch: timestep t's block was fetched before this timestep's
                 // store further down.)
-                if (PADK) {
-                    // eight wave-uniform words through the scalar path, like the tensor bounds
-                    const float *qs = p.qp_start + (long)t * p.qp_start_st + (long)L.b * p.qp_start_sb;
-                    float s8[8];
-#pragma unroll
-                    for (int a = 0; a < 8; ++a) s8[a] = a < p.nc ? uniform_f32(qs + (a < p.nc ? a : 0)) : 0.f;
-                    xv = r8 ? gather8(s8, L.r) : 0.f;
-                } else {
-                    // it rode in with the record (stream_init: lanes 28..29), entry r in lane (q, r) like the nominal control
-                    xv = wv::lds_f32(base + OFF_R + 448 + 4u * (unsigned)(r8 ? L.r : 0));
-                    xv = r8 ? xv : 0.f;
-                }
+                // it rode in with the record (stream_init: lanes 28..29; padded instantiation: rec_init's words 112..), entry r in lane (q, r)
+                // like the nominal control
+                xv = wv::lds_f32(base + OFF_R + 448 + 4u * (unsigned)(r8 ? L.r : 0));
+                xv = (r8 && (!PADK || L.r < p.nc)) ? xv : 0.f;
                 xv = (xv == xv) ? xv : 0.f;              // (a NaN would survive the clamp)
             } else if (!MPC_MFMA40_QP_WARM || !warm) {
                 // cold start x = -H^-1 q (mpc/pnqp.py:14-19): the first QP of the sweep -- or, with MPC_MFMA40_QP_WARM = 0, every QP
